@@ -1,0 +1,235 @@
+/*
+ * lipreading_hip.h — C ABI of the MI355X (gfx950) hot path of joseph-zhong/LipReading:
+ * landmark step -> recurrent sequence encoder -> CTC loss / greedy decode.
+ *
+ * The reference has no FFI of its own (it is pure Python over stock torch ops), so this
+ * ABI is the build's design; every entry point names the reference symbol (file:line under
+ * the reference root) whose arithmetic it replaces.  INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - every function only ENQUEUES work on `stream` (a hipStream_t passed as void*); it never
+ *     allocates, frees, synchronises or copies to the host, so a whole training step can be
+ *     captured in one hipGraph;
+ *   - scratch comes from the caller: ask `*_workspace_bytes`, pass the buffer back in;
+ *   - return value: LR_OK (0) or a negative lr_status; no C++ exception crosses the boundary;
+ *   - all floating point is IEEE fp32 (subnormals kept), all indices int32 unless noted.
+ */
+#ifndef LIPREADING_HIP_H
+#define LIPREADING_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lr_stream_t; /* hipStream_t */
+
+typedef enum lr_status {
+  LR_OK = 0,
+  LR_ERR_INVALID_ARG = -1, /* null pointer, negative size, unsupported shape            */
+  LR_ERR_WORKSPACE = -2,   /* caller workspace smaller than *_workspace_bytes()          */
+  LR_ERR_LAUNCH = -3,      /* hipLaunchKernel / hipGetLastError reported a failure       */
+  LR_ERR_UNSUPPORTED = -4, /* valid request outside what the kernels implement           */
+  LR_ERR_NO_DEVICE = -5    /* no gfx950 device visible                                   */
+} lr_status;
+
+typedef enum lr_rnn_mode {
+  LR_RNN_GRU = 0, /* torch.nn.GRU  gate order r,z,n   (3 gates) */
+  LR_RNN_LSTM = 1 /* torch.nn.LSTM gate order i,f,g,o (4 gates) */
+} lr_rnn_mode;
+
+typedef enum lr_ctc_reduction {
+  LR_CTC_SUM = 0, /* reference reduction='sum'  (src/train/ctc_loss.py:114) */
+  LR_CTC_MEAN = 1 /* reference reduction='mean' incl. its run-weighting quirk (:74,:103-105) */
+} lr_ctc_reduction;
+
+/* ---- library ------------------------------------------------------------------------- */
+
+/* ABI version: major*10000 + minor*100 + patch. */
+int lr_version(void);
+/* Static string for a status code (never NULL). */
+const char* lr_status_string(int status);
+/* Number of visible HIP devices (0 when none); does not create a context. */
+int lr_device_count(void);
+
+/* ---- A1: batch collation — src/data/data_loader.py:117-152 (_collate_fn, _pad) --------- */
+
+/* Zero-pad ragged rows to the batch maximum on the device.
+ *   packed   [sum(lens), feat]   rows of all samples back to back (sample b starts at
+ *                                row offsets[b])
+ *   offsets  [B] int64, lens [B] int32
+ *   out      [B, t_max, feat]    out[b,t,:] = t < lens[b] ? packed[offsets[b]+t,:] : 0
+ * Replaces the per-sample torch.Tensor(seq) copy loop of _pad (:139-141). */
+int lr_collate_pad_f32(const float* packed, const int64_t* offsets, const int32_t* lens,
+                       float* out, int B, int t_max, int feat, lr_stream_t stream);
+
+/* ---- A7: landmark step — src/utils/data/face.py:76-90,164-175 -------------------------- */
+
+/* _applyPadding (face.py:76-90) for n rectangles, integer arithmetic identical to the
+ * reference: left = max(0, left - int(padding*box_w)) ... ; rect layout (left,right,top,bottom).
+ *   rects_in/out [n,4] int32, dims [n,2] int32 = (img_h, img_w). */
+int lr_lmk_apply_padding(const int32_t* rects_in, const int32_t* dims, int32_t* rects_out,
+                         int n, float padding, lr_stream_t stream);
+
+/* getFace (face.py:164-175): out[i,p,0] = in[i,p,0]-left_i; out[i,p,1] = in[i,p,1]-top_i;
+ * z untouched.  lmk [n, npts, 3] f32, rects [n,4] int32 (left,right,top,bottom).  in==out ok. */
+int lr_lmk_translate(const float* lmk_in, const int32_t* rects, float* lmk_out, int n,
+                     int npts, lr_stream_t stream);
+
+/* ---- dense fp32 contraction (MFMA f32 16x16x4 / 32x32x2), used by A3 ------------------- */
+
+/* C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C + bias[N]   (row-major, fp32)
+ *   transA=0: A is [M,K] lda>=K ; transA=1: A is [K,M] lda>=M   (same for B with N)
+ *   bias may be NULL.  beta==0 never reads C.
+ *   row_shift/period: when period>0, row k of the K dimension of op(B) (transB=0 storage
+ *   [K,N]) is taken from row k+row_shift if 0 <= (k % period)+row_shift < period, else it
+ *   is zero — the "previous hidden state" view of a [B*T, H] matrix without a copy. */
+int lr_sgemm(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+             const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
+             int row_shift, int period, lr_stream_t stream);
+
+/* ---- A3: recurrent layer — src/models/lipreader/better_model.py:47-49,64-89 ------------ */
+
+/* One (bi)directional GRU/LSTM layer with torch packed-sequence semantics
+ * (pack_padded_sequence -> nn.GRU/LSTM -> pad_packed_sequence, better_model.py:68-78),
+ * WITHOUT the length sort: every sample stops at its own length, the reverse direction
+ * starts at each sample's last valid frame, positions past a length are zero in y and the
+ * final state is the state at each sample's last valid step.
+ *
+ *   x      [B,T,I]        layer input, batch-first, contiguous
+ *   lens   [B] int32      1 <= lens[b] <= T
+ *   w_ih   D pointers -> [G*H, I]   (torch weight_ih_l{k}[_reverse])
+ *   w_hh   D pointers -> [G*H, H]
+ *   b_ih, b_hh  D pointers -> [G*H]
+ *   y      [B,T,D*H]      outputs (direction d in columns [d*H,(d+1)*H))
+ *   h_n    [D,B,H]        final hidden state; c_n [D,B,H] (LSTM; may be NULL for GRU)
+ *   reserve               saved activations for the backward pass (lr_rnn_reserve_bytes)
+ * Pointer arrays (w_ih ...) are HOST arrays of D device pointers. */
+size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D);
+size_t lr_rnn_workspace_bytes(int mode, int B, int T, int I, int H, int D);
+
+int lr_rnn_layer_forward(int mode, const float* x, const int32_t* lens,
+                         const float* const* w_ih_host, const float* const* w_hh_host,
+                         const float* const* b_ih_host, const float* const* b_hh_host, float* y,
+                         float* h_n, float* c_n, void* reserve, size_t reserve_bytes, int B,
+                         int T, int I, int H, int D, lr_stream_t stream);
+
+/* Backward of the layer above.
+ *   dy [B,T,D*H]; dh_n, dc_n [D,B,H] (may be NULL = zero)
+ *   dx [B,T,I] (may be NULL when the input needs no gradient: layer 0)
+ *   dw_ih/dw_hh/db_ih/db_hh: HOST arrays of D device pointers, OVERWRITTEN with the grads.
+ *   workspace: lr_rnn_workspace_bytes. */
+int lr_rnn_layer_backward(int mode, const float* x, const int32_t* lens,
+                          const float* const* w_ih_host, const float* const* w_hh_host,
+                          const float* const* b_ih_host, const float* const* b_hh_host,
+                          const float* y, const float* dy, const float* dh_n, const float* dc_n,
+                          float* dx, float* const* dw_ih_host, float* const* dw_hh_host,
+                          float* const* db_ih_host, float* const* db_hh_host,
+                          const void* reserve, size_t reserve_bytes, void* workspace,
+                          size_t workspace_bytes, int B, int T, int I, int H, int D,
+                          lr_stream_t stream);
+
+/* ---- A3 tail: output_proj + masked_log_softmax — better_model.py:92-93 ------------------ */
+
+/* log_probs[r,:] = log_softmax(hidden[r,:] @ W^T + bias + log(mask + 1e-45))
+ *   hidden [R,K] (R = B*T rows, padded rows included exactly as the reference does),
+ *   W [C,K], bias [C], mask [C] (0/1 floats; masked classes end ~103.28 below, finite),
+ *   log_probs [R,C].  C <= 256. */
+int lr_proj_logsoftmax_forward(const float* hidden, const float* W, const float* bias,
+                               const float* mask, float* log_probs, int R, int K, int C,
+                               lr_stream_t stream);
+
+/* dlogits[r,c] = g[r,c] - exp(log_probs[r,c]) * sum_c g[r,c]; then
+ * dhidden = dlogits @ W, dW = dlogits^T @ hidden, dbias = colsum(dlogits).
+ *   dlogits [R,C] is caller scratch (also an output).  dhidden may be NULL. */
+int lr_proj_logsoftmax_backward(const float* g, const float* log_probs, const float* hidden,
+                                const float* W, float* dlogits, float* dhidden, float* dW,
+                                float* dbias, int R, int K, int C, lr_stream_t stream);
+
+/* ---- A4: CTC loss — src/train/ctc_loss.py:28-114 ---------------------------------------- */
+
+/* Per-sample CTC negative log-likelihood and its gradient, blank = 0, the same recursion as
+ * torch.nn.functional.ctc_loss which the reference calls at ctc_loss.py:85.
+ *   log_probs  element (b,t,c) at log_probs[b*stride_b + t*stride_t + c]; so both the
+ *              reference's (B,T,V') tensor and its transposed (T,B,V') view are accepted
+ *   labels     [B, label_stride] int32, ALREADY shifted by +1 (ctc_loss.py:80), PAD after
+ *              label_lens[b]
+ *   frame_lens [B] int32 (input lengths), label_lens [B] int32
+ *   nll        [B]  out: -log p(labels | log_probs); +inf when no valid alignment
+ *   grad       out, same addressing as log_probs, or NULL for loss only.  grad[b,t,c] =
+ *              grad_weight[b] * (exp(lp) - exp(log sum_{s:l'_s=c} alpha_t(s) beta_t(s) + nll - lp))
+ *              for t < frame_lens[b], 0 after — torch's ctc_loss backward formula.
+ *              grad_weight may be NULL (= 1).  Samples whose nll is inf or whose
+ *              grad_weight is 0 get an all-zero gradient.
+ *   workspace  lr_ctc_workspace_bytes(B, T, max_label_len) bytes.
+ * T is the padded time extent (number of t rows addressed), C = V'+... number of classes,
+ * max_label_len <= 256 bounds label_lens (ctc_loss.py:46). */
+size_t lr_ctc_workspace_bytes(int B, int T, int max_label_len);
+
+int lr_ctc_nll(const float* log_probs, int64_t stride_b, int64_t stride_t, const int32_t* labels,
+               int label_stride, const int32_t* frame_lens, const int32_t* label_lens, float* nll,
+               void* workspace, size_t workspace_bytes, int B, int T, int C, int max_label_len,
+               lr_stream_t stream);
+
+int lr_ctc_grad(const float* log_probs, int64_t stride_b, int64_t stride_t, const int32_t* labels,
+                int label_stride, const int32_t* frame_lens, const int32_t* label_lens,
+                const float* nll, const float* grad_weight, float* grad, void* workspace,
+                size_t workspace_bytes, int B, int T, int C, int max_label_len,
+                lr_stream_t stream);
+
+/* The reference's batch reduction (ctc_loss.py:46-114) evaluated on the device from the
+ * per-sample nll, so no host round trip is needed to apply it:
+ *   - samples with label_lens > 256 are dropped (:46);
+ *   - the (ascending) batch is cut into runs of equal frame_len (:64-65);
+ *   - a run containing an inf nll drops those samples (:87-101); a run with none left is
+ *     skipped WITHOUT advancing the run start (:92 `continue` before :107), so its samples
+ *     are re-examined as part of the next run;
+ *   - 'mean': each run's torch-'mean' (mean of nll/clamp(label_len,1)) is multiplied by
+ *     `minibatch_size`, which the reference reads BEFORE slicing (:74) — the whole batch for
+ *     the first run, the previous run's size afterwards — and `count` accumulates the same
+ *     number (:103-105); 'sum': plain sum.
+ *   out_loss[0]   the loss (total/count or total); 0 when status != 0
+ *   out_status[0] 0 = ok, 1 = reference would return None (everything dropped / total == 0)
+ *   grad_weight   [B] d out_loss / d nll[b]  (0 for dropped samples) -> lr_ctc_grad */
+int lr_ctc_reduce(const float* nll, const int32_t* frame_lens, const int32_t* label_lens,
+                  int reduction, float* out_loss, int32_t* out_status, float* grad_weight, int B,
+                  lr_stream_t stream);
+
+/* ---- A6: CTC greedy decode — src/models/lipreader/decoder.py:165-197 -------------------- */
+
+/* argmax over classes (first maximum, as torch.max), then per sample for t < sizes[b]:
+ * drop blanks, drop a frame whose argmax equals the previous FRAME's argmax (:168-173).
+ *   probs    element (b,t,c) at probs[b*stride_b + t*stride_t + c]
+ *   sizes    [B] int32 or NULL (= T)
+ *   class_map [C] int32 or NULL: the reference compares CHARACTERS (labels[i] == labels[j]),
+ *            so with duplicate label strings the caller passes the canonical index per class
+ *   out_ids  [B,T] int32 kept (mapped) class ids, out_offsets [B,T] int32 frame index of each kept id,
+ *   out_lens [B] int32 number kept.  Entries past out_lens[b] are -1. */
+int lr_ctc_greedy_decode(const float* probs, int64_t stride_b, int64_t stride_t,
+                         const int32_t* sizes, const int32_t* class_map, int32_t* out_ids,
+                         int32_t* out_offsets, int32_t* out_lens, int B, int T, int C, int blank,
+                         lr_stream_t stream);
+
+/* ---- A5 tail: optimiser side of the reference step — train_better_model.py:78-80 -------- */
+
+/* sum of squares of n floats accumulated into out[0] (caller zeroes it); used for
+ * clip_grad_norm_ (train_better_model.py:78) over a flat gradient buffer. */
+int lr_sumsq(const float* x, int64_t n, float* out, lr_stream_t stream);
+
+/* Fused clip + Adam step over a flat parameter buffer (torch.optim.Adam defaults as used at
+ * src/scripts/train.py:280: betas (0.9,0.999), eps 1e-8, no weight decay, no amsgrad).
+ *   scale = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) when max_norm > 0 (clip_grad_norm_),
+ *   else 1.  step_count_host is the 1-based step number used for bias correction.
+ *   grad_scale multiplies the gradient first (1/world_size after an all-reduce sum). */
+int lr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                 const float* sumsq, float max_norm, float grad_scale, float lr, float beta1,
+                 float beta2, float eps, int step_count_host, lr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIPREADING_HIP_H */

@@ -1,0 +1,95 @@
+"""ctypes binding of include/lipreading_hip.h.
+
+The product path has no CPU fallback: if the shared object is missing or a kernel reports an
+error, the call raises.  Nothing in this module imports from oracle/.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+from . import _build
+
+_lib = None
+
+P = c_void_p  # every device pointer crosses the boundary as void*
+
+# name -> (restype, argtypes); mirrors include/lipreading_hip.h declaration by declaration.
+SIGNATURES = {
+    "lr_version": (c_int, []),
+    "lr_status_string": (c_char_p, [c_int]),
+    "lr_device_count": (c_int, []),
+    "lr_collate_pad_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "lr_lmk_apply_padding": (c_int, [P, P, P, c_int, c_float, P]),
+    "lr_lmk_translate": (c_int, [P, P, P, c_int, c_int, P]),
+    "lr_sgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, P, c_int, P, c_int, c_float,
+                          P, c_int, P, c_int, c_int, P]),
+    "lr_rnn_reserve_bytes": (c_size_t, [c_int] * 6),
+    "lr_rnn_workspace_bytes": (c_size_t, [c_int] * 6),
+    "lr_rnn_layer_forward": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int,
+                                      c_int, c_int, c_int, P]),
+    "lr_rnn_layer_backward": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
+                                       c_size_t, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
+    "lr_proj_logsoftmax_forward": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
+    "lr_proj_logsoftmax_backward": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    "lr_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "lr_ctc_nll": (c_int, [P, c_int64, c_int64, P, c_int, P, P, P, P, c_size_t, c_int, c_int,
+                            c_int, c_int, P]),
+    "lr_ctc_grad": (c_int, [P, c_int64, c_int64, P, c_int, P, P, P, P, P, P, c_size_t, c_int,
+                             c_int, c_int, c_int, P]),
+    "lr_ctc_reduce": (c_int, [P, P, P, c_int, P, P, P, c_int, P]),
+    "lr_ctc_greedy_decode": (c_int, [P, c_int64, c_int64, P, P, P, P, P, c_int, c_int, c_int,
+                                      c_int, P]),
+    "lr_sumsq": (c_int, [P, c_int64, P, P]),
+    "lr_adam_step": (c_int, [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_float,
+                              c_float, c_int, P]),
+}
+
+
+class LipReadingHipError(RuntimeError):
+  pass
+
+
+def lib_path():
+  return _build.LIB_PATH
+
+
+def lib():
+  """Load (once) and return the C-ABI library.  Raises if it has not been built."""
+  global _lib
+  if _lib is None:
+    path = lib_path()
+    if not os.path.exists(path):
+      raise LipReadingHipError(
+          "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+          "(there is no CPU fallback for the MI355X hot path)" % path)
+    handle = ctypes.CDLL(path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+      fn = getattr(handle, name)  # AttributeError if the header and the .so disagree
+      fn.restype = restype
+      fn.argtypes = argtypes
+    _lib = handle
+  return _lib
+
+
+def check(status, what=""):
+  if status != 0:
+    msg = lib().lr_status_string(int(status)).decode()
+    raise LipReadingHipError("%s failed: %s (%d)" % (what or "lipreading_hip call", msg, status))
+
+
+def stream_handle():
+  """hipStream_t of torch's current stream as an integer (void*)."""
+  import torch
+  return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+  """Device pointer of a tensor (None -> NULL)."""
+  return None if t is None else t.data_ptr()
+
+
+def require_cuda(*tensors):
+  for t in tensors:
+    if t is not None and not t.is_cuda:
+      raise LipReadingHipError(
+          "lipreading_amd ops run on the MI355X only; got a %s tensor (no CPU fallback)" % t.device)

@@ -1,0 +1,52 @@
+// lr_common.h — shared helpers for the gfx950 kernels (internal; the public ABI is
+// include/lipreading_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/lipreading_hip.h"
+
+#define LR_WAVE 64
+
+#define LR_CHECK_ARG(cond)                 \
+  do {                                     \
+    if (!(cond)) return LR_ERR_INVALID_ARG; \
+  } while (0)
+
+// Launch check: hipGetLastError is cheap and does not synchronise.
+static inline int lr_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? LR_OK : LR_ERR_LAUNCH;
+}
+
+static inline size_t lr_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+#define LR_NEG_INF (-__builtin_inff())
+
+// log(exp(a)+exp(b)+exp(c)) with the -inf convention of torch's CTC kernels
+// (aten/native/LossCTC.cpp: lamax == -inf -> 0).
+__device__ __forceinline__ float lr_lse3(float a, float b, float c) {
+  float m = fmaxf(fmaxf(a, b), c);
+  if (m == LR_NEG_INF) m = 0.f;
+  return logf(expf(a - m) + expf(b - m) + expf(c - m)) + m;
+}
+__device__ __forceinline__ float lr_lse2(float a, float b) {
+  float m = fmaxf(a, b);
+  if (m == LR_NEG_INF) m = 0.f;
+  return logf(expf(a - m) + expf(b - m)) + m;
+}
+
+__device__ __forceinline__ float lr_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+// 64-lane butterfly reductions (wave = 64 on gfx950).
+__device__ __forceinline__ float lr_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float lr_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

@@ -1,0 +1,470 @@
+// lr_ctc.hip — CTC alpha/beta forward-backward, the reference's batch reduction, and greedy
+// decode for gfx950.
+//
+// Reference arithmetic replaced here:
+//   src/train/ctc_loss.py:85      F.ctc_loss(log_probs(T,N,C), concat targets, blank=0)
+//   src/train/ctc_loss.py:46-114  length filter, equal-length runs, inf fallback, weighting
+//   src/models/lipreader/decoder.py:165-197  GreedyDecoder.process_string / decode
+//
+// Layout: one workgroup per sample.  A sample's lattice is (T x C) fp32 log-probs (19.5 kB at
+// T=75, C=65); its 2L+1 CTC states live one per thread, the previous alpha/beta row is
+// exchanged through a double-buffered LDS row (one s_barrier per time step), and the
+// alpha (later alpha+beta) table goes to the caller's workspace, which stays L2 resident
+// between the two kernels.  The gradient rows are independent once alpha+beta is known, so
+// they are produced by all waves of the workgroup with lanes along the class axis (coalesced
+// stores of the (T x C) gradient).
+#include "lr_common.h"
+
+namespace {
+
+constexpr int kMaxLabelLen = 256;  // src/train/ctc_loss.py:46 (CuDNN-era limit the reference keeps)
+
+__host__ __device__ inline int ctc_state_stride(int max_label_len) {
+  return ((2 * max_label_len + 1) + 63) / 64 * 64;
+}
+
+// ---------------------------------------------------------------------------------------
+// alpha pass + nll
+// ---------------------------------------------------------------------------------------
+__global__ void ctc_alpha_kernel(const float* __restrict__ lp, int64_t stride_b, int64_t stride_t,
+                                 const int32_t* __restrict__ labels, int label_stride,
+                                 const int32_t* __restrict__ frame_lens,
+                                 const int32_t* __restrict__ label_lens, float* __restrict__ nll,
+                                 float* __restrict__ ws_alpha, int T, int C, int sst,
+                                 int max_label_len) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* row0 = reinterpret_cast<float*>(smem_raw);  // [2][sst]
+  const int b = blockIdx.x;
+  const int s = threadIdx.x;
+  const int L = label_lens[b];
+  int Tb = frame_lens[b];
+  if (Tb > T) Tb = T;
+  if (L > max_label_len || L < 0 || Tb <= 0) {
+    // dropped by lr_ctc_reduce when L > 256; otherwise a caller error: poison the loss.
+    if (s == 0) nll[b] = __builtin_inff();
+    return;
+  }
+  const int S = 2 * L + 1;
+  const bool live = s < S;
+  const int32_t* lab = labels + (int64_t)b * label_stride;
+  int cls = 0;
+  bool skip_ok = false;  // alpha_t(s) may come from alpha_{t-1}(s-2)
+  if (live && (s & 1)) {
+    cls = lab[s >> 1];
+    if (s >= 3) skip_ok = lab[(s >> 1) - 1] != cls;
+  }
+  // out-of-range class ids would read outside the lattice: clamp and let the caller's
+  // host-side checks reject them.
+  if (cls < 0 || cls >= C) cls = 0;
+  const float* lpb = lp + (int64_t)b * stride_b;
+  float* al = ws_alpha + ((int64_t)b * T) * sst;
+
+  float a = LR_NEG_INF;
+  if (live && s < 2) a = lpb[cls];
+  if (live) al[s] = a;
+  float lp_next = (live && Tb > 1) ? lpb[stride_t + cls] : 0.f;
+  for (int t = 1; t < Tb; ++t) {
+    float* row = row0 + (t & 1) * sst;
+    row[s] = a;
+    const float lp_t = lp_next;
+    if (live && t + 1 < Tb) lp_next = lpb[(int64_t)(t + 1) * stride_t + cls];
+    __syncthreads();
+    if (live) {
+      const float a1 = a;
+      const float a2 = s >= 1 ? row[s - 1] : LR_NEG_INF;
+      const float a3 = skip_ok ? row[s - 2] : LR_NEG_INF;
+      a = lr_lse3(a1, a2, a3) + lp_t;
+      al[(int64_t)t * sst + s] = a;
+    }
+  }
+  float* row = row0 + (Tb & 1) * sst;
+  row[s] = a;
+  __syncthreads();
+  if (s == 0) {
+    const float l1 = row[S - 1];
+    const float l2 = S > 1 ? row[S - 2] : LR_NEG_INF;
+    nll[b] = -lr_lse2(l1, l2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// beta pass + gradient
+// ---------------------------------------------------------------------------------------
+__global__ void ctc_beta_grad_kernel(const float* __restrict__ lp, int64_t stride_b,
+                                     int64_t stride_t, const int32_t* __restrict__ labels,
+                                     int label_stride, const int32_t* __restrict__ frame_lens,
+                                     const int32_t* __restrict__ label_lens,
+                                     const float* __restrict__ nll,
+                                     const float* __restrict__ grad_weight,
+                                     float* __restrict__ grad, float* __restrict__ ws_alpha, int T,
+                                     int C, int sst, int max_label_len) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* row0 = reinterpret_cast<float*>(smem_raw);              // [2][sst]
+  int* lab_s = reinterpret_cast<int*>(row0 + 2 * sst);           // [max_label_len]
+  int* nxt_s = lab_s + max_label_len;                            // [max_label_len]
+  int* first_s = nxt_s + max_label_len;                          // [C]
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int nthr = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nwave = nthr >> 6;
+  const int L = label_lens[b];
+  int Tb = frame_lens[b];
+  if (Tb > T) Tb = T;
+  const float w = grad_weight ? grad_weight[b] : 1.f;
+  const float nll_b = nll[b];
+  float* gb = grad + (int64_t)b * stride_b;
+
+  const bool dead = (L > max_label_len) || L < 0 || Tb <= 0 || w == 0.f || isinf(nll_b) ||
+                    isnan(nll_b);
+  if (dead) {  // uniform per workgroup
+    for (int t = wave; t < T; t += nwave)
+      for (int c = lane; c < C; c += 64) gb[(int64_t)t * stride_t + c] = 0.f;
+    return;
+  }
+
+  const int S = 2 * L + 1;
+  const int32_t* lab = labels + (int64_t)b * label_stride;
+  const float* lpb = lp + (int64_t)b * stride_b;
+  float* ab = ws_alpha + ((int64_t)b * T) * sst;
+
+  // ---- label tables: next occurrence chain per class, first occurrence per class --------
+  for (int i = tid; i < L; i += nthr) {
+    int c = lab[i];
+    if (c < 0 || c >= C) c = 0;
+    lab_s[i] = c;
+  }
+  for (int c = tid; c < C; c += nthr) first_s[c] = -1;
+  __syncthreads();
+  for (int i = tid; i < L; i += nthr) {
+    const int c = lab_s[i];
+    int n = -1;
+    for (int j = i + 1; j < L; ++j)
+      if (lab_s[j] == c) { n = j; break; }
+    nxt_s[i] = n;
+    bool first = true;
+    for (int j = 0; j < i; ++j)
+      if (lab_s[j] == c) { first = false; break; }
+    if (first) first_s[c] = i;
+  }
+  __syncthreads();
+
+  // ---- beta recursion, alpha+beta written back over alpha --------------------------------
+  {
+    const int s = tid;
+    const bool live = s < S;
+    int cls = 0;
+    bool skip_ok = false;  // beta_t(s) may come from beta_{t+1}(s+2)
+    if (live && (s & 1)) {
+      cls = lab_s[s >> 1];
+      if (s + 2 < S) skip_ok = lab_s[(s >> 1) + 1] != cls;
+    }
+    float bt = LR_NEG_INF;
+    if (live && s >= S - 2) bt = lpb[(int64_t)(Tb - 1) * stride_t + cls];
+    if (live) ab[(int64_t)(Tb - 1) * sst + s] += bt;
+    float lp_next = (live && Tb > 1) ? lpb[(int64_t)(Tb - 2) * stride_t + cls] : 0.f;
+    for (int t = Tb - 2; t >= 0; --t) {
+      float* row = row0 + (t & 1) * sst;
+      if (s < sst) row[s] = bt;
+      const float lp_t = lp_next;
+      if (live && t >= 1) lp_next = lpb[(int64_t)(t - 1) * stride_t + cls];
+      __syncthreads();
+      if (live) {
+        const float b1 = bt;
+        const float b2 = s + 1 < S ? row[s + 1] : LR_NEG_INF;
+        const float b3 = skip_ok ? row[s + 2] : LR_NEG_INF;
+        bt = lr_lse3(b1, b2, b3) + lp_t;
+        ab[(int64_t)t * sst + s] += bt;
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // ---- gradient rows: lanes along the class axis -----------------------------------------
+  for (int t = wave; t < T; t += nwave) {
+    float* grow = gb + (int64_t)t * stride_t;
+    if (t >= Tb) {
+      for (int c = lane; c < C; c += 64) grow[c] = 0.f;
+      continue;
+    }
+    const float* abr = ab + (int64_t)t * sst;
+    const float* lpr = lpb + (int64_t)t * stride_t;
+    // blank: log-sum-exp over the even states
+    float m = LR_NEG_INF;
+    for (int s = 2 * lane; s < S; s += 128) m = fmaxf(m, abr[s]);
+    m = lr_wave_max(m);
+    float blank_lcab = LR_NEG_INF;
+    if (m != LR_NEG_INF) {
+      float acc = 0.f;
+      for (int s = 2 * lane; s < S; s += 128) acc += expf(abr[s] - m);
+      acc = lr_wave_sum(acc);
+      blank_lcab = logf(acc) + m;
+    }
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      const int c = c0 + lane;
+      if (c < C) {
+        float v;
+        if (c == 0) {
+          v = blank_lcab;
+        } else {
+          v = LR_NEG_INF;
+          int i = first_s[c];
+          if (i >= 0) {
+            v = abr[2 * i + 1];
+            for (i = nxt_s[i]; i >= 0; i = nxt_s[i]) v = lr_lse2(v, abr[2 * i + 1]);
+          }
+        }
+        const float l = lpr[c];
+        // torch ctc_loss backward: (exp(lp) - exp(lcab + nll - lp)) * grad_out
+        grow[c] = w * (expf(l) - expf(v + nll_b - l));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// the reference's batch reduction, on the device
+// ---------------------------------------------------------------------------------------
+constexpr int kReduceMaxB = 2048;
+
+__global__ void ctc_reduce_kernel(const float* __restrict__ nll,
+                                  const int32_t* __restrict__ frame_lens,
+                                  const int32_t* __restrict__ label_lens, int reduction,
+                                  float* __restrict__ out_loss, int32_t* __restrict__ out_status,
+                                  float* __restrict__ grad_weight, int B) {
+  __shared__ float s_nll[kReduceMaxB];
+  __shared__ int s_fl[kReduceMaxB];
+  __shared__ int s_ll[kReduceMaxB];
+  __shared__ float s_w[kReduceMaxB];
+  // compact away the label_len > 256 samples (ctc_loss.py:46-56) while staging into LDS;
+  // done serially by thread 0 after a parallel copy so the order is preserved.
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    s_nll[i] = nll[i];
+    s_fl[i] = frame_lens[i];
+    s_ll[i] = label_lens[i];
+    s_w[i] = 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // kept list = indices with label_len <= 256; walk it through an index array stored in
+    // place of s_fl's upper half is not possible at B = max, so re-scan with a cursor.
+    int n = 0;
+    for (int i = 0; i < B; ++i) n += (s_ll[i] <= kMaxLabelLen);
+    float total = 0.f;
+    float count = 0.f;
+    bool any = false;
+    if (n > 0) {
+      // positions below are positions in the kept list; kept(i) maps through a cursor.
+      // Run boundaries (change points, ctc_loss.py:64-65) are detected on the kept list.
+      int cur_len = n;      // len(frame_lens) as the reference's loop sees it (:74)
+      int prev_i = -1;      // raw index of the first kept sample of the pending slice
+      // first kept raw index
+      int i = 0;
+      while (i < B && s_ll[i] > kMaxLabelLen) ++i;
+      prev_i = i;
+      int slice_cnt = 0;    // kept samples in [prev_i, cursor)
+      int cursor = i;
+      while (cursor < B) {
+        // advance cursor over one run of equal frame_len (kept samples only)
+        const int fl = s_fl[cursor];
+        int j = cursor;
+        int last_kept = cursor;
+        while (j < B) {
+          if (s_ll[j] <= kMaxLabelLen) {
+            if (s_fl[j] != fl) break;
+            ++slice_cnt;
+            last_kept = j;
+          }
+          ++j;
+        }
+        cursor = j;  // first kept sample of the next run, or B
+        // slice = kept samples in [prev_i, cursor)
+        int mb = cur_len;
+        cur_len = slice_cnt;
+        int m = 0;
+        bool has_inf = false;
+        for (int k = prev_i; k < cursor; ++k)
+          if (s_ll[k] <= kMaxLabelLen) {
+            if (isinf(s_nll[k])) has_inf = true; else ++m;
+          }
+        if (has_inf) {
+          if (m == 0) continue;  // ctc_loss.py:92 — prev_change_point NOT advanced
+          cur_len = m;
+          mb = m;
+        } else {
+          m = slice_cnt;
+        }
+        float run = 0.f;
+        if (reduction == LR_CTC_MEAN) {
+          for (int k = prev_i; k < cursor; ++k)
+            if (s_ll[k] <= kMaxLabelLen && !isinf(s_nll[k])) {
+              const float l = (float)(s_ll[k] < 1 ? 1 : s_ll[k]);
+              run += s_nll[k] / l;
+              s_w[k] = (float)mb / ((float)m * l);
+            }
+          run = run / (float)m * (float)mb;
+          count += (float)mb;
+        } else {
+          for (int k = prev_i; k < cursor; ++k)
+            if (s_ll[k] <= kMaxLabelLen && !isinf(s_nll[k])) {
+              run += s_nll[k];
+              s_w[k] = 1.f;
+            }
+        }
+        total += run;
+        any = true;
+        prev_i = cursor;
+        slice_cnt = 0;
+        (void)last_kept;
+      }
+    }
+    const bool none = !any || total == 0.f;  // ctc_loss.py:110-112
+    float inv = 1.f;
+    float loss = total;
+    if (!none && reduction == LR_CTC_MEAN) {
+      inv = 1.f / count;
+      loss = total / count;
+    }
+    out_loss[0] = none ? 0.f : loss;
+    out_status[0] = none ? 1 : 0;
+    s_nll[0] = none ? 0.f : inv;  // broadcast slot
+  }
+  __syncthreads();
+  const float inv = s_nll[0];
+  for (int i = threadIdx.x; i < B; i += blockDim.x) grad_weight[i] = s_w[i] * inv;
+}
+
+// ---------------------------------------------------------------------------------------
+// greedy decode
+// ---------------------------------------------------------------------------------------
+__global__ void ctc_greedy_kernel(const float* __restrict__ probs, int64_t stride_b,
+                                  int64_t stride_t, const int32_t* __restrict__ sizes,
+                                  const int32_t* __restrict__ class_map,
+                                  int32_t* __restrict__ out_ids, int32_t* __restrict__ out_off,
+                                  int32_t* __restrict__ out_lens, int T, int C, int blank) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int* amax = reinterpret_cast<int*>(smem_raw);  // [T]
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int nwave = blockDim.x >> 6;
+  int n = sizes ? sizes[b] : T;
+  if (n > T) n = T;
+  if (n < 0) n = 0;
+  const float* pb = probs + (int64_t)b * stride_b;
+  // argmax per frame: lanes along the class axis, first maximum wins (torch.max on CPU).
+  for (int t = wave; t < n; t += nwave) {
+    const float* pr = pb + (int64_t)t * stride_t;
+    float best = LR_NEG_INF;
+    int bi = C;  // sentinel larger than any index
+    for (int c = lane; c < C; c += 64) {
+      const float v = pr[c];
+      if (bi == C || v > best) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) amax[t] = class_map ? class_map[bi] : bi;
+  }
+  __syncthreads();
+  // collapse: ordered compaction by wave 0, 64 frames per pass.
+  if (wave == 0) {
+    int base = 0;
+    for (int t0 = 0; t0 < n; t0 += 64) {
+      const int t = t0 + lane;
+      bool keep = false;
+      int id = -1;
+      if (t < n) {
+        id = amax[t];
+        keep = (id != blank) && (t == 0 || id != amax[t - 1]);
+      }
+      const unsigned long long mask = __ballot(keep);
+      const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+      if (keep) {
+        out_ids[(int64_t)b * T + pos] = id;
+        out_off[(int64_t)b * T + pos] = t;
+      }
+      base += __popcll(mask);
+    }
+    for (int p = base + lane; p < T; p += 64) {
+      out_ids[(int64_t)b * T + p] = -1;
+      out_off[(int64_t)b * T + p] = -1;
+    }
+    if (lane == 0) out_lens[b] = base;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t lr_ctc_workspace_bytes(int B, int T, int max_label_len) {
+  if (B <= 0 || T <= 0 || max_label_len < 0) return 0;
+  if (max_label_len > kMaxLabelLen) max_label_len = kMaxLabelLen;
+  return (size_t)B * T * ctc_state_stride(max_label_len) * sizeof(float);
+}
+
+extern "C" int lr_ctc_nll(const float* log_probs, int64_t stride_b, int64_t stride_t,
+                          const int32_t* labels, int label_stride, const int32_t* frame_lens,
+                          const int32_t* label_lens, float* nll, void* workspace,
+                          size_t workspace_bytes, int B, int T, int C, int max_label_len,
+                          lr_stream_t stream) {
+  LR_CHECK_ARG(log_probs && labels && frame_lens && label_lens && nll && workspace);
+  LR_CHECK_ARG(B > 0 && T > 0 && C > 0 && max_label_len >= 0 && label_stride >= 0);
+  if (max_label_len > kMaxLabelLen) max_label_len = kMaxLabelLen;
+  if (workspace_bytes < lr_ctc_workspace_bytes(B, T, max_label_len)) return LR_ERR_WORKSPACE;
+  const int sst = ctc_state_stride(max_label_len);
+  const size_t lds = 2 * (size_t)sst * sizeof(float);
+  hipLaunchKernelGGL(ctc_alpha_kernel, dim3(B), dim3(sst), lds, (hipStream_t)stream, log_probs,
+                     stride_b, stride_t, labels, label_stride, frame_lens, label_lens, nll,
+                     (float*)workspace, T, C, sst, max_label_len);
+  return lr_launch_status();
+}
+
+extern "C" int lr_ctc_grad(const float* log_probs, int64_t stride_b, int64_t stride_t,
+                           const int32_t* labels, int label_stride, const int32_t* frame_lens,
+                           const int32_t* label_lens, const float* nll, const float* grad_weight,
+                           float* grad, void* workspace, size_t workspace_bytes, int B, int T,
+                           int C, int max_label_len, lr_stream_t stream) {
+  LR_CHECK_ARG(log_probs && labels && frame_lens && label_lens && nll && grad && workspace);
+  LR_CHECK_ARG(B > 0 && T > 0 && C > 0 && max_label_len >= 0 && label_stride >= 0);
+  if (max_label_len > kMaxLabelLen) max_label_len = kMaxLabelLen;
+  if (workspace_bytes < lr_ctc_workspace_bytes(B, T, max_label_len)) return LR_ERR_WORKSPACE;
+  const int sst = ctc_state_stride(max_label_len);
+  const int nthr = sst < 256 ? 256 : sst;
+  const size_t lds = 2 * (size_t)sst * sizeof(float) + 2 * (size_t)(max_label_len + 1) * sizeof(int) +
+                     (size_t)C * sizeof(int);
+  hipLaunchKernelGGL(ctc_beta_grad_kernel, dim3(B), dim3(nthr), lds, (hipStream_t)stream,
+                     log_probs, stride_b, stride_t, labels, label_stride, frame_lens, label_lens,
+                     nll, grad_weight, grad, (float*)workspace, T, C, sst, max_label_len);
+  return lr_launch_status();
+}
+
+extern "C" int lr_ctc_reduce(const float* nll, const int32_t* frame_lens,
+                             const int32_t* label_lens, int reduction, float* out_loss,
+                             int32_t* out_status, float* grad_weight, int B, lr_stream_t stream) {
+  LR_CHECK_ARG(nll && frame_lens && label_lens && out_loss && out_status && grad_weight);
+  LR_CHECK_ARG(B > 0 && (reduction == LR_CTC_SUM || reduction == LR_CTC_MEAN));
+  if (B > kReduceMaxB) return LR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(ctc_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nll,
+                     frame_lens, label_lens, reduction, out_loss, out_status, grad_weight, B);
+  return lr_launch_status();
+}
+
+extern "C" int lr_ctc_greedy_decode(const float* probs, int64_t stride_b, int64_t stride_t,
+                                    const int32_t* sizes, const int32_t* class_map,
+                                    int32_t* out_ids, int32_t* out_offsets, int32_t* out_lens,
+                                    int B, int T, int C, int blank, lr_stream_t stream) {
+  LR_CHECK_ARG(probs && out_ids && out_offsets && out_lens);
+  LR_CHECK_ARG(B > 0 && T > 0 && C > 0);
+  const size_t lds = (size_t)T * sizeof(int);
+  if (lds > 64 * 1024) return LR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(ctc_greedy_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, probs,
+                     stride_b, stride_t, sizes, class_map, out_ids, out_offsets, out_lens, T, C, blank);
+  return lr_launch_status();
+}

@@ -1,0 +1,198 @@
+// lr_misc.hip — library entry points plus the bandwidth-trivial kernels either side of the
+// encoder: batch collation (A1), the landmark step (A7), and the optimiser tail of the
+// reference step (A5).
+//
+// Reference arithmetic replaced here:
+//   src/data/data_loader.py:130-142   _pad (zero-pad ragged sequences to the batch max)
+//   src/utils/data/face.py:76-90      _applyPadding (integer rectangle padding)
+//   src/utils/data/face.py:164-175    getFace (translate x,y by the padded rect origin)
+//   src/train/train_better_model.py:78-80  clip_grad_norm_ + Adam.step
+#include "lr_common.h"
+
+extern "C" int lr_version(void) { return 100; /* 0.1.0 */ }
+
+extern "C" const char* lr_status_string(int status) {
+  switch (status) {
+    case LR_OK: return "ok";
+    case LR_ERR_INVALID_ARG: return "invalid argument";
+    case LR_ERR_WORKSPACE: return "workspace too small";
+    case LR_ERR_LAUNCH: return "kernel launch failed";
+    case LR_ERR_UNSUPPORTED: return "unsupported configuration";
+    case LR_ERR_NO_DEVICE: return "no gfx950 device";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int lr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+namespace {
+
+// One workgroup-row per (b,t): feat floats copied or zeroed; lanes along feat.
+__global__ void collate_pad_kernel(const float* __restrict__ packed,
+                                   const int64_t* __restrict__ offsets,
+                                   const int32_t* __restrict__ lens, float* __restrict__ out,
+                                   int B, int t_max, int feat) {
+  const int64_t total = (int64_t)B * t_max * feat;
+  const int64_t row_elems = (int64_t)t_max * feat;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / row_elems);
+    const int64_t r = i - (int64_t)b * row_elems;
+    const int t = (int)(r / feat);
+    const int f = (int)(r - (int64_t)t * feat);
+    float v = 0.f;
+    if (t < lens[b]) v = packed[(offsets[b] + t) * feat + f];
+    out[i] = v;
+  }
+}
+
+__global__ void lmk_apply_padding_kernel(const int32_t* __restrict__ rin,
+                                         const int32_t* __restrict__ dims,
+                                         int32_t* __restrict__ rout, int n, float padding) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int img_h = dims[2 * i], img_w = dims[2 * i + 1];
+  int left = rin[4 * i], right = rin[4 * i + 1], top = rin[4 * i + 2], bottom = rin[4 * i + 3];
+  const int box_h = bottom - top, box_w = right - left;
+  // Python: int(padding * box_w) — a double product truncated toward zero.
+  const int pw = (int)((double)padding * (double)box_w);
+  const int ph = (int)((double)padding * (double)box_h);
+  left = max(0, left - pw);
+  right = min(img_w, right + pw);
+  top = max(0, top - ph);
+  bottom = min(img_h, bottom + ph);
+  rout[4 * i] = left;
+  rout[4 * i + 1] = right;
+  rout[4 * i + 2] = top;
+  rout[4 * i + 3] = bottom;
+}
+
+__global__ void lmk_translate_kernel(const float* __restrict__ in, const int32_t* __restrict__ rects,
+                                     float* __restrict__ out, int64_t total, int per_frame) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t frame = i / per_frame;
+    const int comp = (int)((i - frame * per_frame) % 3);
+    float v = in[i];
+    if (comp == 0) v -= (float)rects[4 * frame];          // left
+    else if (comp == 1) v -= (float)rects[4 * frame + 2];  // top
+    out[i] = v;
+  }
+}
+
+__global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  float acc = 0.f;
+  const int64_t n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) acc += x[i] * x[i];
+  acc = lr_wave_sum(acc);
+  __shared__ float part[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += part[w];
+    atomicAdd(out, s);
+  }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v, int64_t n,
+                            const float* __restrict__ sumsq, float max_norm, float grad_scale,
+                            float lr, float beta1, float beta2, float eps, float bc1, float bc2) {
+  float scale = grad_scale;
+  if (max_norm > 0.f && sumsq) {
+    // clip_grad_norm_: total_norm of the (already grad_scale'd) gradient
+    const float norm = sqrtf(sumsq[0]) * grad_scale;
+    const float coef = max_norm / (norm + 1e-6f);
+    if (coef < 1.f) scale *= coef;
+  }
+  const float step = lr / bc1;
+  const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * scale;
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] -= step * (mi / denom);
+  }
+}
+
+inline int grid_for(int64_t n, int block) {
+  int64_t g = (n + block - 1) / block;
+  if (g > 2048) g = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int lr_collate_pad_f32(const float* packed, const int64_t* offsets,
+                                  const int32_t* lens, float* out, int B, int t_max, int feat,
+                                  lr_stream_t stream) {
+  LR_CHECK_ARG(packed && offsets && lens && out);
+  LR_CHECK_ARG(B > 0 && t_max > 0 && feat > 0);
+  const int64_t total = (int64_t)B * t_max * feat;
+  hipLaunchKernelGGL(collate_pad_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, packed, offsets, lens, out, B, t_max, feat);
+  return lr_launch_status();
+}
+
+extern "C" int lr_lmk_apply_padding(const int32_t* rects_in, const int32_t* dims,
+                                    int32_t* rects_out, int n, float padding,
+                                    lr_stream_t stream) {
+  LR_CHECK_ARG(rects_in && dims && rects_out && n > 0);
+  hipLaunchKernelGGL(lmk_apply_padding_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, rects_in, dims, rects_out, n, padding);
+  return lr_launch_status();
+}
+
+extern "C" int lr_lmk_translate(const float* lmk_in, const int32_t* rects, float* lmk_out, int n,
+                                int npts, lr_stream_t stream) {
+  LR_CHECK_ARG(lmk_in && rects && lmk_out && n > 0 && npts > 0);
+  const int64_t total = (int64_t)n * npts * 3;
+  hipLaunchKernelGGL(lmk_translate_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, lmk_in, rects, lmk_out, total, npts * 3);
+  return lr_launch_status();
+}
+
+extern "C" int lr_sumsq(const float* x, int64_t n, float* out, lr_stream_t stream) {
+  LR_CHECK_ARG(x && out && n >= 0);
+  if (n == 0) return LR_OK;
+  LR_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  int g = grid_for((n + 3) / 4, 256);
+  if (g > 256) g = 256;  // one atomic per workgroup
+  hipLaunchKernelGGL(sumsq_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  return lr_launch_status();
+}
+
+extern "C" int lr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                            int64_t n, const float* sumsq, float max_norm, float grad_scale,
+                            float lr, float beta1, float beta2, float eps, int step_count_host,
+                            lr_stream_t stream) {
+  LR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n >= 0 && step_count_host >= 1);
+  if (n == 0) return LR_OK;
+  const float bc1 = 1.f - powf(beta1, (float)step_count_host);
+  const float bc2 = 1.f - powf(beta2, (float)step_count_host);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     param, grad, exp_avg, exp_avg_sq, n, sumsq, max_norm, grad_scale, lr, beta1,
+                     beta2, eps, bc1, bc2);
+  return lr_launch_status();
+}

@@ -1,0 +1,255 @@
+"""CPU oracle for the video->characters hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product path (lipreading_amd/) never does and fails loudly without its HIP library.
+
+This is a restatement of the reference's algorithm with the same stock torch CPU ops the
+reference itself bottoms out in (nn.GRU/nn.LSTM on a PackedSequence, nn.Linear, log_softmax,
+F.ctc_loss), each function citing the reference file:line it follows (paths relative to the
+reference root).  It is pinned by tests/golden/*.npz, which were produced by importing the
+reference itself (tests/golden/make_golden.py):
+  - ctc_* fixtures: reference src/train/ctc_loss.py imported as-is            -> CLEAN pin
+  - greedy_* fixtures: reference decoder.py with an inert Levenshtein stub     -> CLEAN pin
+  - enc_* / step_* fixtures: reference VideoEncoder with a stand-in for the absent, unpinned
+    third-party `allennlp.nn.util` (masked_log_softmax / sort_batch_by_length) -> SHIMMED pin;
+    parity at that boundary is otherwise unpinned.
+  - lmk_*: face.py needs dlib to import, so those cases are hand-computed    -> parity unpinned
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# src/data/data_loader.py:29-35
+PAD, BOS, EOS, UNK = '<PAD>', '<BOS>', '<EOS>', '<UNK>'
+MARKERS = {PAD: 0, BOS: 1, EOS: 2, UNK: 3}
+DEFAULT_LABELS = list(" !\"#$%&'()*+,-./0123456789:;<>?@[]abcdefghijklmnopqrstuvwxyz")
+
+
+def default_char2idx():
+  """build_vocab fallback path — src/data/data_loader.py:100-115."""
+  c2i = dict(MARKERS)
+  for ch in DEFAULT_LABELS:
+    c2i[ch] = len(c2i)
+  return c2i
+
+
+# ------------------------------------------------------------------------------------------
+# A1: collation — src/data/data_loader.py:117-152
+# ------------------------------------------------------------------------------------------
+def collate(frames_list, captions_list):
+  """Zero-pad ragged (len_i,68,3) float and (cap_i,) int sequences to the batch maximum."""
+  def pad(seqs, dtype):
+    lens = torch.tensor([len(s) for s in seqs], dtype=torch.long)
+    tail = tuple(np.asarray(seqs[0]).shape[1:])
+    out = torch.zeros((len(seqs), int(lens.max())) + tail, dtype=dtype)
+    for i, s in enumerate(seqs):
+      out[i, :len(s)] = torch.as_tensor(np.asarray(s)).to(dtype)
+    return out, lens
+  f, fl = pad(frames_list, torch.float32)
+  c, cl = pad(captions_list, torch.long)
+  return f, fl, c, cl
+
+
+# ------------------------------------------------------------------------------------------
+# A7: landmark step — src/utils/data/face.py:76-90 and :164-175
+# ------------------------------------------------------------------------------------------
+def apply_padding(dims, rect, padding):
+  """face.py:76-90; rect = (left, right, top, bottom), dims = (img_h, img_w[, c])."""
+  img_h, img_w = dims[0], dims[1]
+  left, right, top, bottom = rect
+  box_h, box_w = bottom - top, right - left
+  return (max(0, left - int(padding * box_w)), min(img_w, right + int(padding * box_w)),
+          max(0, top - int(padding * box_h)), min(img_h, bottom + int(padding * box_h)))
+
+
+def get_face(lmks, rect):
+  """face.py:164-175: translate x by rect.left and y by rect.top."""
+  out = np.array(lmks, copy=True)
+  out[:, 0] -= rect[0]
+  out[:, 1] -= rect[2]
+  return out
+
+
+# ------------------------------------------------------------------------------------------
+# A3: encoder — src/models/lipreader/better_model.py:13-112
+# ------------------------------------------------------------------------------------------
+def masked_log_softmax(vector, mask, dim=-1):
+  """The allennlp.nn.util function the reference calls at better_model.py:93, as published
+  (allennlp 0.7-0.9): log_softmax(vector + log(mask + 1e-45)), mask broadcast from the left."""
+  mask = mask.float()
+  while mask.dim() < vector.dim():
+    mask = mask.unsqueeze(1)
+  return F.log_softmax(vector + (mask + 1e-45).log(), dim=dim)
+
+
+class OracleVideoEncoder(nn.Module):
+  """Same parameters and state_dict keys as the reference VideoEncoder (better_model.py:14-51)."""
+
+  def __init__(self, frame_dim, hidden_size, rnn_type='LSTM', num_layers=1, bidirectional=True,
+               rnn_dropout=0, enable_ctc=False, vocab_size=-1, char2idx=None):
+    super().__init__()
+    self.frame_dim, self.hidden_size = frame_dim, hidden_size
+    self.rnn_type, self.num_layers, self.bidirectional = rnn_type, num_layers, bidirectional
+    self.enable_ctc = enable_ctc
+    self.rnn = getattr(nn, rnn_type)(frame_dim, hidden_size, num_layers=num_layers,
+                                     bidirectional=bidirectional, batch_first=True,
+                                     dropout=rnn_dropout)
+    if enable_ctc:
+      self.adj_vocab_size = vocab_size + 1                       # :38
+      mask = torch.ones(self.adj_vocab_size)
+      mask[char2idx[PAD] + 1] = 0                                # :44
+      mask[char2idx[BOS] + 1] = 0                                # :45
+      self.output_mask = mask
+      dirs = 2 if bidirectional else 1
+      self.output_proj = nn.Linear(dirs * hidden_size, self.adj_vocab_size)  # :51
+
+  def forward(self, frames, frame_lens):
+    B = frames.shape[0]
+    x = frames.reshape(B, frames.shape[1], -1)                   # :61
+    # :64-70 — descending-length sort + pack; enforce_sorted=False performs the same sort
+    packed = nn.utils.rnn.pack_padded_sequence(x, frame_lens.cpu(), batch_first=True,
+                                               enforce_sorted=False)
+    packed_out, final = self.rnn(packed)                         # :74
+    hidden, _ = nn.utils.rnn.pad_packed_sequence(packed_out, batch_first=True)  # :78
+
+    def cat_dirs(s):                                             # :98-112
+      return torch.cat([s[0::2], s[1::2]], dim=2)
+    if self.bidirectional:
+      final = tuple(cat_dirs(s) for s in final) if isinstance(final, tuple) else cat_dirs(final)
+    if not self.enable_ctc:
+      return hidden, final
+    logits = self.output_proj(hidden)                            # :92
+    log_probs = masked_log_softmax(logits, self.output_mask.expand(B, self.adj_vocab_size))  # :93
+    return log_probs, hidden, final
+
+
+# ------------------------------------------------------------------------------------------
+# A4: CTC loss — src/train/ctc_loss.py:28-114
+# ------------------------------------------------------------------------------------------
+def ctc_nll_per_sample(log_probs, labels_plus1, frame_lens, label_lens):
+  """-log p(label | lattice) per sample with torch's CPU ctc_loss, blank = 0 (ctc_loss.py:85)."""
+  tgt = torch.cat([labels_plus1[i, :int(label_lens[i])] for i in range(len(label_lens))])
+  return F.ctc_loss(log_probs.transpose(0, 1), tgt.to(torch.int32),
+                    frame_lens.to(torch.int32), label_lens.to(torch.int32), blank=0,
+                    reduction='none')
+
+
+def ctc_loss(encoder_outputs, labels, frame_lens, label_lens, reduction):
+  """The reference's reduction over a batch, restated on per-sample losses.
+
+  Returns a differentiable 0-dim tensor or None, exactly where the reference returns None.
+  Follows ctc_loss.py: ascending-length assert :39; label_len>256 filter :46-56; equal-length
+  runs :64-65; labels+1 :80; inf fallback :87-101 (a fully-inf run is skipped BEFORE
+  prev_change_point advances, :92 vs :107); 'mean' weighting with minibatch_size read before
+  the slice :74,:103-105; None when the total is 0 :110-112.
+  """
+  frame_lens = frame_lens.to(torch.int64).cpu()
+  label_lens = label_lens.to(torch.int64).cpu()
+  assert bool((frame_lens[1:] - frame_lens[:-1] >= 0).all())
+  keep = [i for i in range(len(label_lens)) if int(label_lens[i]) <= 256]
+  if not keep:
+    return None
+  keep_t = torch.tensor(keep, dtype=torch.long)
+  lp = encoder_outputs.cpu().index_select(0, keep_t)
+  lab = labels.cpu().index_select(0, keep_t).to(torch.int64) + 1
+  fl, ll = frame_lens[keep_t], label_lens[keep_t]
+  # one detached call decides which samples are inf (the reference's fallback probes them one
+  # by one, :4-13); the differentiable call then sees only the finite ones, as at :95-101,
+  # so an inf sample never enters the graph.  Runs only change the weighting.
+  n = len(keep)
+  with torch.no_grad():
+    nll_probe = ctc_nll_per_sample(lp, lab, fl, ll)
+  finite = [k for k in range(n) if not math.isinf(float(nll_probe[k]))]
+  pos = {k: j for j, k in enumerate(finite)}
+  if finite:
+    ft = torch.tensor(finite, dtype=torch.long)
+    nll_f = ctc_nll_per_sample(lp.index_select(0, ft), lab[ft], fl[ft], ll[ft])
+  bounds = [k for k in range(1, n) if int(fl[k]) != int(fl[k - 1])] + [n]
+  total, count, prev, cur_len = None, 0, 0, n
+  for cp in bounds:
+    mb = cur_len
+    idx = list(range(prev, cp))
+    cur_len = len(idx)
+    if any(k not in pos for k in idx):
+      idx = [k for k in idx if k in pos]
+      if not idx:
+        continue
+      cur_len = mb = len(idx)
+    sel = nll_f[torch.tensor([pos[k] for k in idx])]
+    if reduction == 'mean':
+      run = (sel / ll[torch.tensor(idx)].clamp(min=1).to(sel.dtype)).mean() * mb
+      count += mb
+    else:
+      run = sel.sum()
+    total = run if total is None else total + run
+    prev = cp
+  if total is None or float(total.detach()) == 0.0:
+    return None
+  return total / count if reduction == 'mean' else total
+
+
+# ------------------------------------------------------------------------------------------
+# A6: greedy decode — src/models/lipreader/decoder.py:165-197
+# ------------------------------------------------------------------------------------------
+def ctc_labels(char2idx=None):
+  """The build-defined label list for the live model's V'=V+1 layout (the reference has no
+  live caller that defines one): index 0 = blank '_', index i+1 = idx2char[i]."""
+  c2i = char2idx or default_char2idx()
+  inv = {v: k for k, v in c2i.items()}
+  return ['_'] + [inv[i] for i in range(len(inv))]
+
+
+def greedy_decode(probs, sizes, labels, blank_index=0):
+  """argmax -> drop blanks -> drop frames equal to the previous frame's argmax."""
+  best = torch.max(probs, 2)[1]
+  strings, offsets = [], []
+  for b in range(best.shape[0]):
+    n = int(sizes[b]) if sizes is not None else best.shape[1]
+    out, off = '', []
+    for t in range(n):
+      ch = labels[int(best[b, t])]
+      if ch == labels[blank_index]:
+        continue
+      if t != 0 and ch == labels[int(best[b, t - 1])]:
+        continue
+      out += ch
+      off.append(t)
+    strings.append([out])
+    offsets.append([torch.tensor(off, dtype=torch.int)])
+  return strings, offsets
+
+
+def edit_distance(a, b):
+  """Levenshtein distance (what decoder.py:44-73 delegates to the Levenshtein package)."""
+  prev = list(range(len(b) + 1))
+  for i, ca in enumerate(a, 1):
+    cur = [i]
+    for j, cb in enumerate(b, 1):
+      cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+    prev = cur
+  return prev[-1]
+
+
+# ------------------------------------------------------------------------------------------
+# A5: the encoder+CTC part of one optimisation step — src/train/train_better_model.py:24-80
+# ------------------------------------------------------------------------------------------
+def encoder_ctc_step(encoder, opt, frames, frame_lens, chars, char_lens, grad_norm=None,
+                     reduction='mean'):
+  """labels = chars[:,1:] (:31-32) -> encoder (:46) -> ctc_loss 'mean' (:48) -> backward (:74)
+  -> clip (:78) -> opt.step (:80).  The attention decoder loop (:56-65) is the N1 'next' row
+  and not part of this oracle step.  Returns the loss (None if the batch is skipped)."""
+  labels = chars[:, 1:]
+  label_lens = char_lens - 1
+  log_probs, _, _ = encoder(frames, frame_lens)
+  loss = ctc_loss(log_probs, labels, frame_lens, label_lens, reduction)
+  if loss is None:
+    return None
+  opt.zero_grad()
+  loss.backward()
+  if grad_norm is not None:
+    torch.nn.utils.clip_grad_norm_(encoder.parameters(), grad_norm)
+  opt.step()
+  return loss.detach()

@@ -1,0 +1,311 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by IMPORTING THE REFERENCE (build container only).
+
+  python tests/golden/make_golden.py            # needs /root/reference; writes next to itself
+
+The reference cannot travel to the GPU box, so the vectors it produces are committed as data.
+Nothing here is reference source: the reference modules are imported from /root/reference and
+called; this file holds only input generation and the stand-ins listed below.
+
+Pins (see oracle/torch_oracle.py header):
+  ctc_cases.npz     reference src/train/ctc_loss.py imported as-is (torch only)        CLEAN
+  greedy_cases.npz  reference src/models/lipreader/decoder.py GreedyDecoder; the import needs
+                    a `Levenshtein` module, stubbed inert (only wer/cer use it)         CLEAN
+  enc_cases.npz     reference VideoEncoder (better_model.py).  Its import needs `spacy`
+                    (inert stub) and the unpinned third-party `allennlp.nn.util`; the three
+                    functions used are stood in below from allennlp's published definitions.
+                    sort_batch_by_length cannot change results (undone at better_model.py:84-89);
+                    masked_log_softmax's 1e-45 constant is the only observable part.  SHIMMED
+  step_cases.npz    reference VideoEncoder + reference ctc_loss composed as
+                    train_better_model.py:31-32,46-48,74-80 (CTC-only step)            SHIMMED
+  lmk_cases.npz     hand-computed from face.py:76-90,164-175 (face.py needs dlib to import)
+                    -> parity unpinned for the landmark row
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("LIPREADING_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+V = 64          # vocab incl. 4 markers (data_loader.py:33,35)
+VP = V + 1      # CTC classes (better_model.py:38)
+
+
+def install_stubs():
+  # -- inert: not on the arithmetic path
+  sys.modules.setdefault("spacy", types.ModuleType("spacy"))
+  lev = types.ModuleType("Levenshtein")
+  lev.distance = lambda a, b: (_ for _ in ()).throw(NotImplementedError("stub"))
+  sys.modules.setdefault("Levenshtein", lev)
+  # -- allennlp.nn.util stand-in (published definitions, allennlp 0.7-0.9)
+  def masked_log_softmax(vector, mask, dim=-1):
+    if mask is not None:
+      mask = mask.float()
+      while mask.dim() < vector.dim():
+        mask = mask.unsqueeze(1)
+      vector = vector + (mask + 1e-45).log()
+    return torch.nn.functional.log_softmax(vector, dim=dim)
+
+  def masked_softmax(vector, mask, dim=-1):
+    mask = mask.float()
+    while mask.dim() < vector.dim():
+      mask = mask.unsqueeze(1)
+    result = torch.nn.functional.softmax(vector * mask, dim=dim) * mask
+    return result / (result.sum(dim=dim, keepdim=True) + 1e-13)
+
+  def sort_batch_by_length(tensor, sequence_lengths):
+    sorted_lens, perm = sequence_lengths.sort(0, descending=True)
+    sorted_tensor = tensor.index_select(0, perm)
+    index_range = torch.arange(0, len(sequence_lengths), device=sequence_lengths.device)
+    _, reverse_mapping = perm.sort(0, descending=False)
+    restoration = index_range.index_select(0, reverse_mapping)
+    return sorted_tensor, sorted_lens, restoration, perm
+
+  a = types.ModuleType("allennlp")
+  a_nn = types.ModuleType("allennlp.nn")
+  a_util = types.ModuleType("allennlp.nn.util")
+  a_util.masked_log_softmax = masked_log_softmax
+  a_util.masked_softmax = masked_softmax
+  a_util.sort_batch_by_length = sort_batch_by_length
+  a.nn, a_nn.util = a_nn, a_util
+  sys.modules.update({"allennlp": a, "allennlp.nn": a_nn, "allennlp.nn.util": a_util})
+
+
+def rand_log_probs(g, B, T):
+  return torch.log_softmax(torch.randn(B, T, VP, generator=g), dim=-1)
+
+
+def make_labels(g, lens, width=None, lo=4, hi=V):
+  """ids uniform in [lo,hi) then EOS=2 as the last label (train_better_model.py:27,31)."""
+  width = width or max(max(lens), 1)
+  lab = torch.zeros(len(lens), width, dtype=torch.long)
+  for i, n in enumerate(lens):
+    if n > 0:
+      lab[i, :n - 1] = torch.randint(lo, hi, (n - 1,), generator=g)
+      lab[i, n - 1] = 2
+  return lab
+
+
+def gen_ctc(ref_ctc):
+  g = torch.Generator().manual_seed(123456)  # the reference's default seed (train.py:165)
+  cases = {}
+
+  def add(name, lp, labels, frame_lens, label_lens):
+    rec = {"lp": lp.numpy(), "labels": labels.numpy(), "frame_lens": np.asarray(frame_lens),
+           "label_lens": np.asarray(label_lens)}
+    for red in ("mean", "sum"):
+      x = lp.clone().requires_grad_(True)
+      loss = ref_ctc(x, labels, torch.tensor(frame_lens), torch.tensor(label_lens), red, "cpu")
+      if loss is None:
+        rec["none_" + red] = np.array(1)
+        rec["loss_" + red] = np.array(np.nan, dtype=np.float32)
+        rec["grad_" + red] = np.zeros_like(lp.numpy())
+      else:
+        loss.backward()
+        rec["none_" + red] = np.array(0)
+        rec["loss_" + red] = loss.detach().numpy().astype(np.float32)
+        rec["grad_" + red] = x.grad.numpy()
+    for k, v in rec.items():
+      cases["%s/%s" % (name, k)] = v
+
+  # equal lengths: one run, plain torch 'mean'
+  add("equal", rand_log_probs(g, 4, 20), make_labels(g, [6, 6, 6, 6]), [20] * 4, [6] * 4)
+  # run sizes (1,1,2): the SURVEY A4 quirk probe
+  add("runs112", rand_log_probs(g, 4, 24), make_labels(g, [5, 7, 6, 8]), [16, 20, 24, 24],
+      [5, 7, 6, 8])
+  # run sizes (2,3,3)
+  add("runs233", rand_log_probs(g, 8, 30), make_labels(g, [4, 9, 7, 7, 10, 3, 12, 6]),
+      [18, 18, 25, 25, 25, 30, 30, 30], [4, 9, 7, 7, 10, 3, 12, 6])
+  # repeated characters force the blank between equal neighbours
+  lab = make_labels(g, [7, 7, 7])
+  lab[0, :6] = torch.tensor([10, 10, 10, 11, 11, 10])
+  lab[1, :6] = torch.tensor([20, 20, 20, 20, 20, 20])
+  add("repeats", rand_log_probs(g, 3, 22), lab, [22] * 3, [7] * 3)
+  # a label longer than 256 is dropped (ctc_loss.py:46)
+  ll = [5, 300, 6]
+  add("toolong", rand_log_probs(g, 3, 14), make_labels(g, ll, width=300), [12, 14, 14], ll)
+  # every label too long -> None
+  add("alltoolong", rand_log_probs(g, 2, 8), make_labels(g, [257, 260], width=260), [8, 8],
+      [257, 260])
+  # an inf sample (label longer than its frames) inside a run with finite ones
+  ll = [4, 9, 4, 5]
+  add("infsample", rand_log_probs(g, 4, 10), make_labels(g, ll), [6, 6, 10, 10], ll)
+  # a run that is entirely inf is skipped without advancing prev_change_point (:92 vs :107)
+  ll = [3, 8, 8, 4, 5]
+  add("infrun", rand_log_probs(g, 5, 12), make_labels(g, ll), [5, 6, 6, 12, 12], ll)
+  # first run entirely inf, later runs fine
+  ll = [9, 3, 4]
+  add("inffirst", rand_log_probs(g, 3, 12), make_labels(g, ll), [4, 10, 12], ll)
+  # everything inf -> None
+  ll = [9, 9]
+  add("allinf", rand_log_probs(g, 2, 5), make_labels(g, ll), [5, 5], ll)
+  # the benchmark shape, reduced batch: T=75, L=30+EOS
+  add("bench", rand_log_probs(g, 4, 75), make_labels(g, [31] * 4), [75] * 4, [31] * 4)
+  # mixed lengths at the benchmark T, more than 64 states for one sample (L=40 -> 81 states)
+  ll = [12, 31, 40, 25, 31, 18]
+  add("mixed75", rand_log_probs(g, 6, 75), make_labels(g, ll), [45, 45, 60, 60, 75, 75], ll)
+  np.savez_compressed(os.path.join(OUT, "ctc_cases.npz"), **cases)
+  return cases
+
+
+def gen_greedy(ref_decoder_mod, char2idx):
+  g = torch.Generator().manual_seed(123456)
+  inv = {v: k for k, v in char2idx.items()}
+  labels = ['_'] + [inv[i] for i in range(len(inv))]
+  dec = ref_decoder_mod.GreedyDecoder(labels, blank_index=0)
+  cases = {}
+  B, T = 6, 40
+  lp = rand_log_probs(g, B, T)
+  # engineer repeats / blanks / spaces: a,_,a -> "aa"; a,a -> "a"; include the space class (5)
+  path = torch.randint(0, VP, (B, T), generator=g)
+  path[0, :8] = torch.tensor([40, 40, 0, 40, 0, 0, 5, 5])
+  path[1, :6] = torch.tensor([0, 0, 41, 41, 41, 0])
+  path[2, :] = 0
+  path[3, :] = 45
+  # classes 1..4 are the multi-character marker names; PAD/BOS are masked in the live model
+  path[path == 1] = 0
+  path[path == 2] = 0
+  path[path == 3] = 50
+  path[path == 4] = 51
+  lp.scatter_(2, path.unsqueeze(-1), 1.0)  # make `path` the argmax
+  sizes = torch.tensor([40, 33, 40, 17, 1, 25])
+  strings, offsets = dec.decode(lp, sizes)
+  cases["lp"] = lp.numpy()
+  cases["sizes"] = sizes.numpy()
+  cases["labels"] = np.array(labels, dtype=object)
+  cases["strings"] = np.array([s[0] for s in strings], dtype=object)
+  for b in range(B):
+    cases["offsets_%d" % b] = offsets[b][0].numpy()
+  # no sizes -> full length
+  strings2, _ = dec.decode(lp)
+  cases["strings_nosizes"] = np.array([s[0] for s in strings2], dtype=object)
+  np.savez_compressed(os.path.join(OUT, "greedy_cases.npz"), **cases)
+
+
+def enc_inputs(g, B, T, lens, scale):
+  frames = torch.randn(B, T, 68, 3, generator=g) * scale
+  for b, n in enumerate(lens):
+    frames[b, n:] = 0  # _collate_fn zero-pads (data_loader.py:137)
+  return frames
+
+
+def gen_enc(bm, char2idx):
+  g = torch.Generator().manual_seed(123456)
+  cases = {}
+  cfgs = [("gru_bi", "GRU", True, 1, 12), ("gru_uni", "GRU", False, 1, 8),
+          ("lstm_bi", "LSTM", True, 1, 12), ("lstm_uni", "LSTM", False, 1, 8),
+          ("gru_bi_l2", "GRU", True, 2, 8), ("lstm_bi_l2", "LSTM", True, 2, 8)]
+  for name, rnn_type, bi, layers, H in cfgs:
+    torch.manual_seed(123456)
+    enc = bm.VideoEncoder(204, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
+                          enable_ctc=True, vocab_size=V, char2idx=char2idx)
+    enc.eval()
+    for tag, lens in (("eq", [14, 14, 14, 14]), ("mix", [5, 9, 14, 14])):
+      frames = enc_inputs(g, 4, 14, lens, 1.0)
+      with torch.no_grad():
+        lp, hid, fin = enc(frames, torch.tensor(lens))
+      key = "%s/%s" % (name, tag)
+      cases[key + "/frames"] = frames.numpy()
+      cases[key + "/lens"] = np.asarray(lens)
+      cases[key + "/log_probs"] = lp.numpy()
+      cases[key + "/hidden"] = hid.numpy()
+      if isinstance(fin, tuple):
+        cases[key + "/h_n"], cases[key + "/c_n"] = fin[0].numpy(), fin[1].numpy()
+      else:
+        cases[key + "/h_n"] = fin.numpy()
+    for k, v in enc.state_dict().items():
+      cases["%s/sd/%s" % (name, k)] = v.numpy()
+    cases[name + "/cfg"] = np.array([H, layers, int(bi)])
+  np.savez_compressed(os.path.join(OUT, "enc_cases.npz"), **cases)
+
+
+def gen_step(bm, ref_ctc, char2idx):
+  """One CTC-only optimisation step: train_better_model.py:31-32,46-48,74,78,80 with
+  Adam(lr) as built at train.py:280."""
+  g = torch.Generator().manual_seed(123456)
+  cases = {}
+  for name, rnn_type, H in (("gru", "GRU", 12), ("lstm", "LSTM", 12)):
+    torch.manual_seed(123456)
+    enc = bm.VideoEncoder(204, H, rnn_type=rnn_type, num_layers=1, bidirectional=True,
+                          enable_ctc=True, vocab_size=V, char2idx=char2idx)
+    enc.train()
+    lens = [12, 12, 16, 20, 20, 20]
+    frames = enc_inputs(g, 6, 20, lens, 1.0)
+    cl = [6, 8, 7, 9, 5, 10]                       # char_lens incl. BOS and EOS
+    chars = torch.zeros(6, max(cl), dtype=torch.long)
+    for i, n in enumerate(cl):
+      chars[i, 0] = 1
+      chars[i, 1:n - 1] = torch.randint(4, V, (n - 2,), generator=g)
+      chars[i, n - 1] = 2
+    for k, v in enc.state_dict().items():
+      cases["%s/sd0/%s" % (name, k)] = v.clone().numpy()
+    opt = torch.optim.Adam(enc.parameters(), lr=1e-3)
+    labels, label_lens = chars[:, 1:], torch.tensor(cl) - 1
+    lp, _, _ = enc(frames, torch.tensor(lens))
+    loss = ref_ctc(lp, labels, torch.tensor(lens), label_lens, 'mean', 'cpu')
+    opt.zero_grad()
+    loss.backward()
+    for k, p in enc.named_parameters():
+      cases["%s/grad/%s" % (name, k)] = p.grad.clone().numpy()
+    total_norm = torch.nn.utils.clip_grad_norm_(enc.parameters(), 5.0)
+    opt.step()
+    for k, v in enc.state_dict().items():
+      cases["%s/sd1/%s" % (name, k)] = v.clone().numpy()
+    cases[name + "/frames"] = frames.numpy()
+    cases[name + "/lens"] = np.asarray(lens)
+    cases[name + "/chars"] = chars.numpy()
+    cases[name + "/char_lens"] = np.asarray(cl)
+    cases[name + "/loss"] = loss.detach().numpy()
+    cases[name + "/total_norm"] = np.asarray(float(total_norm), dtype=np.float32)
+    cases[name + "/cfg"] = np.array([H, 1, 1])
+  np.savez_compressed(os.path.join(OUT, "step_cases.npz"), **cases)
+
+
+def gen_lmk():
+  """Hand-computed from the formulas at face.py:76-90 and :164-175 (not produced by running
+  the reference: face.py imports dlib)."""
+  cases = {
+      # dims (h,w,c), rect (l,r,t,b), padding -> padded rect
+      "dims": np.array([[480, 640, 3], [100, 100, 3], [720, 1280, 3]]),
+      "rects": np.array([[200, 300, 100, 220], [5, 95, 10, 90], [1000, 1270, 600, 715]]),
+      "padding": np.array(0.3),
+      # int(0.3*100)=30,int(0.3*120)=36 ; int(0.3*90)=27,int(0.3*80)=24 ; int(0.3*270)=81,int(0.3*115)=34
+      "padded": np.array([[170, 330, 64, 256], [0, 100, 0, 100], [919, 1280, 566, 720]]),
+      "lmk": np.array([[[210.5, 130.25, -3.0], [250.0, 200.0, 12.5]],
+                       [[50.0, 50.0, 0.0], [7.25, 11.5, 1.0]],
+                       [[1100.0, 650.0, 30.0], [1279.0, 719.0, -60.0]]], dtype=np.float64),
+      "face": np.array([[[40.5, 66.25, -3.0], [80.0, 136.0, 12.5]],
+                        [[50.0, 50.0, 0.0], [7.25, 11.5, 1.0]],
+                        [[181.0, 84.0, 30.0], [360.0, 153.0, -60.0]]], dtype=np.float64),
+  }
+  np.savez_compressed(os.path.join(OUT, "lmk_cases.npz"), **cases)
+
+
+def main():
+  sys.path.insert(0, REF)
+  os.environ.setdefault("LIP_READING_WS_PATH", REF)
+  install_stubs()
+  torch.set_num_threads(1)
+  from src.train.ctc_loss import ctc_loss as ref_ctc          # clean import (torch only)
+  import src.models.lipreader.better_model as bm              # shimmed import
+  import src.models.lipreader.decoder as ref_decoder          # clean apart from Levenshtein
+  import src.data.data_loader as dl
+  char2idx = dict(dl._markers2Id)
+  for ch in dl._labels:                                       # build_vocab fallback (:100-115)
+    char2idx[ch] = len(char2idx)
+  assert len(char2idx) == V
+  gen_ctc(ref_ctc)
+  gen_greedy(ref_decoder, char2idx)
+  gen_enc(bm, char2idx)
+  gen_step(bm, ref_ctc, char2idx)
+  gen_lmk()
+  for f in sorted(os.listdir(OUT)):
+    if f.endswith(".npz"):
+      print("%-20s %8d bytes" % (f, os.path.getsize(os.path.join(OUT, f))))
+
+
+if __name__ == "__main__":
+  main()
