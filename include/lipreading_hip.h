@@ -87,10 +87,14 @@ int lr_lmk_translate(const float* lmk_in, const int32_t* rects, float* lmk_out, 
  *   bias may be NULL.  beta==0 never reads C.
  *   row_shift/period: when period>0, row k of the K dimension of op(B) (transB=0 storage
  *   [K,N]) is taken from row k+row_shift if 0 <= (k % period)+row_shift < period, else it
- *   is zero — the "previous hidden state" view of a [B*T, H] matrix without a copy. */
+ *   is zero — the "previous hidden state" view of a [B*T, H] matrix without a copy.
+ *   workspace: lr_sgemm_workspace_bytes(M,N,K) bytes enable a deterministic split along K
+ *   when M*N alone cannot fill the chip (weight gradients: K = B*T); NULL/0 = no split. */
+size_t lr_sgemm_workspace_bytes(int M, int N, int K);
 int lr_sgemm(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
              const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
-             int row_shift, int period, lr_stream_t stream);
+             int row_shift, int period, void* workspace, size_t workspace_bytes,
+             lr_stream_t stream);
 
 /* ---- A3: recurrent layer — src/models/lipreader/better_model.py:47-49,64-89 ------------ */
 
@@ -138,17 +142,19 @@ int lr_rnn_layer_backward(int mode, const float* x, const int32_t* lens,
 /* log_probs[r,:] = log_softmax(hidden[r,:] @ W^T + bias + log(mask + 1e-45))
  *   hidden [R,K] (R = B*T rows, padded rows included exactly as the reference does),
  *   W [C,K], bias [C], mask [C] (0/1 floats; masked classes end ~103.28 below, finite),
- *   log_probs [R,C].  C <= 256. */
+ *   log_probs [R,C].  C <= 256.  workspace: lr_proj_workspace_bytes(R,K,C). */
+size_t lr_proj_workspace_bytes(int R, int K, int C);
 int lr_proj_logsoftmax_forward(const float* hidden, const float* W, const float* bias,
-                               const float* mask, float* log_probs, int R, int K, int C,
-                               lr_stream_t stream);
+                               const float* mask, float* log_probs, void* workspace,
+                               size_t workspace_bytes, int R, int K, int C, lr_stream_t stream);
 
 /* dlogits[r,c] = g[r,c] - exp(log_probs[r,c]) * sum_c g[r,c]; then
  * dhidden = dlogits @ W, dW = dlogits^T @ hidden, dbias = colsum(dlogits).
  *   dlogits [R,C] is caller scratch (also an output).  dhidden may be NULL. */
 int lr_proj_logsoftmax_backward(const float* g, const float* log_probs, const float* hidden,
                                 const float* W, float* dlogits, float* dhidden, float* dW,
-                                float* dbias, int R, int K, int C, lr_stream_t stream);
+                                float* dbias, void* workspace, size_t workspace_bytes, int R, int K,
+                                int C, lr_stream_t stream);
 
 /* ---- A4: CTC loss — src/train/ctc_loss.py:28-114 ---------------------------------------- */
 

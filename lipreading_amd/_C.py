@@ -21,16 +21,19 @@ SIGNATURES = {
     "lr_collate_pad_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "lr_lmk_apply_padding": (c_int, [P, P, P, c_int, c_float, P]),
     "lr_lmk_translate": (c_int, [P, P, P, c_int, c_int, P]),
+    "lr_sgemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "lr_sgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, P, c_int, P, c_int, c_float,
-                          P, c_int, P, c_int, c_int, P]),
+                          P, c_int, P, c_int, c_int, P, c_size_t, P]),
     "lr_rnn_reserve_bytes": (c_size_t, [c_int] * 6),
     "lr_rnn_workspace_bytes": (c_size_t, [c_int] * 6),
     "lr_rnn_layer_forward": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int,
                                       c_int, c_int, c_int, P]),
     "lr_rnn_layer_backward": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                        c_size_t, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
-    "lr_proj_logsoftmax_forward": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
-    "lr_proj_logsoftmax_backward": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    "lr_proj_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "lr_proj_logsoftmax_forward": (c_int, [P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, P]),
+    "lr_proj_logsoftmax_backward": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int,
+                                             c_int, P]),
     "lr_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "lr_ctc_nll": (c_int, [P, c_int64, c_int64, P, c_int, P, P, P, P, c_size_t, c_int, c_int,
                             c_int, c_int, P]),

@@ -14,11 +14,20 @@
     if (!(cond)) return LR_ERR_INVALID_ARG; \
   } while (0)
 
-// Launch check: hipGetLastError is cheap and does not synchronise.
+// Launch check: hipGetLastError is cheap and does not synchronise.  The runtime keeps the last
+// error of ANY earlier call on this thread (torch leaves benign ones such as hipErrorNotReady
+// behind), so every entry point clears it before launching (lr_clear_error) and only then
+// reads it back.
+static inline void lr_clear_error() { (void)hipGetLastError(); }
 static inline int lr_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? LR_OK : LR_ERR_LAUNCH;
 }
+#define LR_LAUNCH(kernel, grid, block, lds, stream, ...)                          \
+  do {                                                                            \
+    lr_clear_error();                                                             \
+    hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)(stream), __VA_ARGS__); \
+  } while (0)
 
 static inline size_t lr_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

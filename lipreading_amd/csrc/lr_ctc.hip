@@ -420,7 +420,7 @@ extern "C" int lr_ctc_nll(const float* log_probs, int64_t stride_b, int64_t stri
   if (workspace_bytes < lr_ctc_workspace_bytes(B, T, max_label_len)) return LR_ERR_WORKSPACE;
   const int sst = ctc_state_stride(max_label_len);
   const size_t lds = 2 * (size_t)sst * sizeof(float);
-  hipLaunchKernelGGL(ctc_alpha_kernel, dim3(B), dim3(sst), lds, (hipStream_t)stream, log_probs,
+  LR_LAUNCH(ctc_alpha_kernel, dim3(B), dim3(sst), lds, stream, log_probs,
                      stride_b, stride_t, labels, label_stride, frame_lens, label_lens, nll,
                      (float*)workspace, T, C, sst, max_label_len);
   return lr_launch_status();
@@ -439,7 +439,7 @@ extern "C" int lr_ctc_grad(const float* log_probs, int64_t stride_b, int64_t str
   const int nthr = sst < 256 ? 256 : sst;
   const size_t lds = 2 * (size_t)sst * sizeof(float) + 2 * (size_t)(max_label_len + 1) * sizeof(int) +
                      (size_t)C * sizeof(int);
-  hipLaunchKernelGGL(ctc_beta_grad_kernel, dim3(B), dim3(nthr), lds, (hipStream_t)stream,
+  LR_LAUNCH(ctc_beta_grad_kernel, dim3(B), dim3(nthr), lds, stream,
                      log_probs, stride_b, stride_t, labels, label_stride, frame_lens, label_lens,
                      nll, grad_weight, grad, (float*)workspace, T, C, sst, max_label_len);
   return lr_launch_status();
@@ -451,7 +451,7 @@ extern "C" int lr_ctc_reduce(const float* nll, const int32_t* frame_lens,
   LR_CHECK_ARG(nll && frame_lens && label_lens && out_loss && out_status && grad_weight);
   LR_CHECK_ARG(B > 0 && (reduction == LR_CTC_SUM || reduction == LR_CTC_MEAN));
   if (B > kReduceMaxB) return LR_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(ctc_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nll,
+  LR_LAUNCH(ctc_reduce_kernel, dim3(1), dim3(256), 0, stream, nll,
                      frame_lens, label_lens, reduction, out_loss, out_status, grad_weight, B);
   return lr_launch_status();
 }
@@ -464,7 +464,7 @@ extern "C" int lr_ctc_greedy_decode(const float* probs, int64_t stride_b, int64_
   LR_CHECK_ARG(B > 0 && T > 0 && C > 0);
   const size_t lds = (size_t)T * sizeof(int);
   if (lds > 64 * 1024) return LR_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(ctc_greedy_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, probs,
+  LR_LAUNCH(ctc_greedy_kernel, dim3(B), dim3(256), lds, stream, probs,
                      stride_b, stride_t, sizes, class_map, out_ids, out_offsets, out_lens, T, C, blank);
   return lr_launch_status();
 }

@@ -1,0 +1,298 @@
+// lr_gemm.hip — fp32 dense contraction on the gfx950 matrix cores.
+//
+// C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C + bias[N], row-major fp32, computed with
+// v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate: bitwise a k-ordered fmaf chain, so the result
+// is in the same round-off class as the reference's CPU sgemm).  Used for the parts of the
+// encoder that are one-shot contractions (reference better_model.py:74 nn.GRU/LSTM input
+// projection and :92 output_proj, plus every weight gradient); the T-step recurrence itself is
+// in lr_rnn.hip.
+//
+// Tiling: 256 threads = 2x2 waves; workgroup tile BM x BN (128x128 or 64x64), wave tile
+// (BM/2)x(BN/2) made of 32x32 MFMA tiles, BK = 16 per LDS stage.  Operands are staged through
+// LDS in the orientation that keeps BOTH the global loads coalesced and the per-lane MFMA operand
+// reads bank-conflict free:
+//   K-contiguous operand  -> tile[row][BK+1]   (lane reads row*(BK+1)+k, 17 is odd: no conflict)
+//   M/N-contiguous operand -> tile[k][BM+4]    (lane reads k*(BM+4)+row, consecutive lanes)
+// Small M*N with long K (the weight gradients: K = B*T) is split along K into slabs in the
+// caller's workspace and reduced deterministically (fixed order) by a second kernel.
+#include "lr_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  int M, N, K;
+  int lda, ldb, ldc;
+  float alpha, beta;
+  int row_shift, period;  // B-row remap along K (transB == 0 only)
+  int k_chunk;            // K range per blockIdx.z (multiple of BK)
+  float* slabs;           // split-K partial sums [splits][M][N] or nullptr
+};
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
+  constexpr int WM = BM / 64;  // 32x32 tiles per wave along M
+  constexpr int WN = BN / 64;
+  constexpr int LDA_S = TA ? (BM + 4) : (BK + 1);
+  constexpr int LDB_S = TB ? (BK + 1) : (BN + 4);
+  constexpr int A_ELEMS = TA ? BK * LDA_S : BM * LDA_S;
+  constexpr int B_ELEMS = TB ? BN * LDB_S : BK * LDB_S;
+  __shared__ __attribute__((aligned(16))) float smem[A_ELEMS + B_ELEMS];
+  float* As = smem;
+  float* Bs = smem + A_ELEMS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * g.k_chunk;
+  const int kend = min(g.K, kbeg + g.k_chunk);
+
+  // per-thread staging registers: BM*BK/256 floats of A, BN*BK/256 floats of B
+  constexpr int A_PER = BM * BK / 256;
+  constexpr int B_PER = BN * BK / 256;
+  float ra[A_PER], rb[B_PER];
+
+  // ---- global -> registers ------------------------------------------------------------------
+  // K-contiguous operand (TA == false): element e -> row = e / BK, k = e % BK   (lanes along k)
+  // M-contiguous operand (TA == true):  element e -> k = e / BM,  row = e % BM  (lanes along m)
+  auto load_a = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int e = tid + i * 256;
+      int row, k;
+      if (TA) { k = e / BM; row = e % BM; } else { row = e / BK; k = e % BK; }
+      const int gm = m0 + row, gk = k0 + k;
+      float v = 0.f;
+      if (gm < g.M && gk < kend)
+        v = TA ? g.A[(int64_t)gk * g.lda + gm] : g.A[(int64_t)gm * g.lda + gk];
+      ra[i] = v;
+    }
+  };
+  auto load_b = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int e = tid + i * 256;
+      int col, k;
+      if (TB) { col = e / BK; k = e % BK; } else { k = e / BN; col = e % BN; }
+      const int gn = n0 + col, gk = k0 + k;
+      float v = 0.f;
+      if (gn < g.N && gk < kend) {
+        if (TB) {
+          v = g.B[(int64_t)gn * g.ldb + gk];
+        } else {
+          int64_t src = gk;
+          bool ok = true;
+          if (g.period > 0) {
+            const int t = gk % g.period + g.row_shift;
+            ok = t >= 0 && t < g.period;
+            src = (int64_t)gk + g.row_shift;
+          }
+          if (ok) v = g.B[src * g.ldb + gn];
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int e = tid + i * 256;
+      if (TA) As[(e / BM) * LDA_S + (e % BM)] = ra[i];
+      else As[(e / BK) * LDA_S + (e % BK)] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int e = tid + i * 256;
+      if (TB) Bs[(e / BK) * LDB_S + (e % BK)] = rb[i];
+      else Bs[(e / BN) * LDB_S + (e % BN)] = rb[i];
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lr = lane & 31;  // row (A) / col (B) inside a 32x32 tile
+  const int lk = lane >> 5;  // k slot 0/1
+
+  if (kbeg < kend) {
+    load_a(kbeg);
+    load_b(kbeg);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();  // previous tile fully consumed
+    store_tiles();
+    __syncthreads();
+    if (k0 + BK < kend) {  // prefetch the next stage while the MFMAs run
+      load_a(k0 + BK);
+      load_b(k0 + BK);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float af[WM], bf[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int row = wm * (BM / 2) + i * 32 + lr;
+        af[i] = TA ? As[(kk + lk) * LDA_S + row] : As[row * LDA_S + kk + lk];
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int col = wn * (BN / 2) + j * 32 + lr;
+        bf[j] = TB ? Bs[col * LDB_S + kk + lk] : Bs[(kk + lk) * LDB_S + col];
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -------------
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = n0 + wn * (BN / 2) + j * 32 + lr;
+      if (col >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= g.M) continue;
+        const float v = acc[i][j][r];
+        if (g.slabs) {
+          g.slabs[((int64_t)blockIdx.z * g.M + row) * g.N + col] = v;
+        } else {
+          float out = g.alpha * v;
+          if (g.bias) out += g.bias[col];
+          float* c = g.C + (int64_t)row * g.ldc + col;
+          if (g.beta != 0.f) out += g.beta * *c;
+          *c = out;
+        }
+      }
+    }
+}
+
+// Deterministic split-K combine: fixed summation order over the slabs, then alpha/beta/bias.
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, float* __restrict__ C,
+                                     int ldc, const float* __restrict__ bias, int M, int N,
+                                     float alpha, float beta) {
+  const int64_t total = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slabs[(int64_t)z * total + i];
+    const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
+    float out = alpha * s;
+    if (bias) out += bias[col];
+    float* c = C + (int64_t)row * ldc + col;
+    if (beta != 0.f) out += beta * *c;
+    *c = out;
+  }
+}
+
+template <int BM, int BN>
+void launch_tile(int transA, int transB, const GemmArgs& g, dim3 grid, hipStream_t stream) {
+  lr_clear_error();
+  if (!transA && !transB) hipLaunchKernelGGL((sgemm_kernel<BM, BN, false, false>), grid, dim3(256), 0, stream, g);
+  else if (!transA && transB) hipLaunchKernelGGL((sgemm_kernel<BM, BN, false, true>), grid, dim3(256), 0, stream, g);
+  else if (transA && !transB) hipLaunchKernelGGL((sgemm_kernel<BM, BN, true, false>), grid, dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((sgemm_kernel<BM, BN, true, true>), grid, dim3(256), 0, stream, g);
+}
+
+struct GemmPlan {
+  bool big;
+  int splits;
+  int k_chunk;
+};
+
+GemmPlan plan_gemm(int M, int N, int K, size_t ws_bytes) {
+  GemmPlan p;
+  const long tiles_big = (long)((M + 127) / 128) * ((N + 127) / 128);
+  p.big = tiles_big >= 192;  // enough 128x128 tiles to fill 256 CUs
+  const int bm = p.big ? 128 : 64;
+  const long tiles = (long)((M + bm - 1) / bm) * ((N + bm - 1) / bm);
+  p.splits = 1;
+  if (tiles < 256 && K >= 8 * BK) {
+    long want = (512 + tiles - 1) / tiles;            // aim at ~2 workgroups per CU
+    long max_by_k = K / (4 * BK);                     // keep >= 64 k per split
+    long max_by_ws = (long)(ws_bytes / ((size_t)M * N * sizeof(float)));
+    long s = want;
+    if (s > max_by_k) s = max_by_k;
+    if (s > max_by_ws) s = max_by_ws;
+    if (s > 64) s = 64;
+    if (s >= 2) p.splits = (int)s;
+  }
+  int chunk = (K + p.splits - 1) / p.splits;
+  chunk = (chunk + BK - 1) / BK * BK;
+  if (chunk < BK) chunk = BK;
+  p.k_chunk = chunk;
+  p.splits = (K + chunk - 1) / chunk;
+  if (p.splits < 1) p.splits = 1;
+  return p;
+}
+
+}  // namespace
+
+// Internal entry (lr_rnn.hip, lr_proj.hip): same contract as lr_sgemm.
+int lr_sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                  const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
+                  int row_shift, int period, void* workspace, size_t workspace_bytes,
+                  hipStream_t stream) {
+  LR_CHECK_ARG(A && B && C);
+  LR_CHECK_ARG(M > 0 && N > 0 && K >= 0 && lda > 0 && ldb > 0 && ldc >= N);
+  LR_CHECK_ARG(period >= 0 && (period == 0 || !transB));
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.bias = bias;
+  g.M = M; g.N = N; g.K = K;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.alpha = alpha; g.beta = beta;
+  g.row_shift = row_shift; g.period = period;
+  const GemmPlan p = plan_gemm(M, N, K, workspace ? workspace_bytes : 0);
+  g.k_chunk = p.k_chunk;
+  g.slabs = p.splits > 1 ? (float*)workspace : nullptr;
+  const int bm = p.big ? 128 : 64;
+  dim3 grid((N + bm - 1) / bm, (M + bm - 1) / bm, p.splits);
+  if (p.big) launch_tile<128, 128>(transA, transB, g, grid, stream);
+  else launch_tile<64, 64>(transA, transB, g, grid, stream);
+  int st = lr_launch_status();
+  if (st != LR_OK) return st;
+  if (p.splits > 1) {
+    const int64_t total = (int64_t)M * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    LR_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace,
+              p.splits, C, ldc, bias, M, N, alpha, beta);
+    st = lr_launch_status();
+  }
+  return st;
+}
+
+extern "C" size_t lr_sgemm_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  // room for the largest split count plan_gemm may choose
+  const GemmPlan p = plan_gemm(M, N, K, (size_t)64 * M * N * sizeof(float));
+  return p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
+}
+
+extern "C" int lr_sgemm(int transA, int transB, int M, int N, int K, float alpha, const float* A,
+                        int lda, const float* B, int ldb, float beta, float* C, int ldc,
+                        const float* bias, int row_shift, int period, void* workspace,
+                        size_t workspace_bytes, lr_stream_t stream) {
+  return lr_sgemm_impl(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias,
+                       row_shift, period, workspace, workspace_bytes, (hipStream_t)stream);
+}

@@ -150,8 +150,7 @@ extern "C" int lr_collate_pad_f32(const float* packed, const int64_t* offsets,
   LR_CHECK_ARG(packed && offsets && lens && out);
   LR_CHECK_ARG(B > 0 && t_max > 0 && feat > 0);
   const int64_t total = (int64_t)B * t_max * feat;
-  hipLaunchKernelGGL(collate_pad_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, packed, offsets, lens, out, B, t_max, feat);
+  LR_LAUNCH(collate_pad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, packed, offsets, lens, out, B, t_max, feat);
   return lr_launch_status();
 }
 
@@ -159,8 +158,7 @@ extern "C" int lr_lmk_apply_padding(const int32_t* rects_in, const int32_t* dims
                                     int32_t* rects_out, int n, float padding,
                                     lr_stream_t stream) {
   LR_CHECK_ARG(rects_in && dims && rects_out && n > 0);
-  hipLaunchKernelGGL(lmk_apply_padding_kernel, dim3((n + 255) / 256), dim3(256), 0,
-                     (hipStream_t)stream, rects_in, dims, rects_out, n, padding);
+  LR_LAUNCH(lmk_apply_padding_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, rects_in, dims, rects_out, n, padding);
   return lr_launch_status();
 }
 
@@ -168,8 +166,7 @@ extern "C" int lr_lmk_translate(const float* lmk_in, const int32_t* rects, float
                                 int npts, lr_stream_t stream) {
   LR_CHECK_ARG(lmk_in && rects && lmk_out && n > 0 && npts > 0);
   const int64_t total = (int64_t)n * npts * 3;
-  hipLaunchKernelGGL(lmk_translate_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, lmk_in, rects, lmk_out, total, npts * 3);
+  LR_LAUNCH(lmk_translate_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, lmk_in, rects, lmk_out, total, npts * 3);
   return lr_launch_status();
 }
 
@@ -179,7 +176,7 @@ extern "C" int lr_sumsq(const float* x, int64_t n, float* out, lr_stream_t strea
   LR_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   int g = grid_for((n + 3) / 4, 256);
   if (g > 256) g = 256;  // one atomic per workgroup
-  hipLaunchKernelGGL(sumsq_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  LR_LAUNCH(sumsq_kernel, dim3(g), dim3(256), 0, stream, x, n, out);
   return lr_launch_status();
 }
 
@@ -191,7 +188,7 @@ extern "C" int lr_adam_step(float* param, const float* grad, float* exp_avg, flo
   if (n == 0) return LR_OK;
   const float bc1 = 1.f - powf(beta1, (float)step_count_host);
   const float bc2 = 1.f - powf(beta2, (float)step_count_host);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+  LR_LAUNCH(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream,
                      param, grad, exp_avg, exp_avg_sq, n, sumsq, max_norm, grad_scale, lr, beta1,
                      beta2, eps, bc1, bc2);
   return lr_launch_status();

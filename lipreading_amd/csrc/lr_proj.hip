@@ -1,0 +1,158 @@
+// lr_proj.hip — output projection + masked log-softmax (and its backward) for gfx950.
+//
+// Reference arithmetic replaced here:
+//   src/models/lipreader/better_model.py:92  output_logits = self.output_proj(hidden_states)
+//   src/models/lipreader/better_model.py:93  masked_log_softmax(logits, output_mask)
+//     = log_softmax(logits + log(mask + 1e-45))   (allennlp.nn.util, unpinned third party)
+// 1e-45 rounds to the smallest fp32 subnormal (1.4e-45); its log is -103.2789, so masked classes
+// stay FINITE.  gfx950 keeps fp32 subnormals (hipcc default float_denorm_mode_32 = 3), which is
+// what makes this match the CPU value instead of producing -inf.
+//
+// The contraction (R x K)·(K x C), C = V+1 = 65, goes through the fp32-MFMA GEMM with the mask
+// term folded into the bias; the row-wise log-softmax is one wave per row (C <= 256).
+#include "lr_common.h"
+
+int lr_sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                  const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
+                  int row_shift, int period, void* workspace, size_t workspace_bytes,
+                  hipStream_t stream);
+extern "C" size_t lr_sgemm_workspace_bytes(int M, int N, int K);
+
+namespace {
+
+constexpr int kMaxClasses = 256;
+
+__global__ void mask_bias_kernel(const float* __restrict__ bias, const float* __restrict__ mask,
+                                 float* __restrict__ out, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  out[c] = bias[c] + logf(mask[c] + 1e-45f);
+}
+
+// in place: x[r,:] <- x[r,:] - logsumexp(x[r,:]); one wave per row, 4 rows per workgroup.
+__global__ void log_softmax_rows_kernel(float* __restrict__ x, int R, int C) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  float* row = x + (int64_t)r * C;
+  float v[kMaxClasses / 64];
+  float m = LR_NEG_INF;
+#pragma unroll
+  for (int i = 0; i < kMaxClasses / 64; ++i) {
+    const int c = lane + i * 64;
+    v[i] = c < C ? row[c] : LR_NEG_INF;
+    m = fmaxf(m, v[i]);
+  }
+  m = lr_wave_max(m);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxClasses / 64; ++i) s += (lane + i * 64 < C) ? expf(v[i] - m) : 0.f;
+  s = lr_wave_sum(s);
+  const float lse = m + logf(s);
+#pragma unroll
+  for (int i = 0; i < kMaxClasses / 64; ++i) {
+    const int c = lane + i * 64;
+    if (c < C) row[c] = v[i] - lse;
+  }
+}
+
+// dlogits[r,c] = g[r,c] - exp(lp[r,c]) * sum_c g[r,c]
+__global__ void log_softmax_bwd_rows_kernel(const float* __restrict__ g, const float* __restrict__ lp,
+                                            float* __restrict__ dlogits, int R, int C) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* gr = g + (int64_t)r * C;
+  const float* lr = lp + (int64_t)r * C;
+  float gv[kMaxClasses / 64];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMaxClasses / 64; ++i) {
+    const int c = lane + i * 64;
+    gv[i] = c < C ? gr[c] : 0.f;
+    s += gv[i];
+  }
+  s = lr_wave_sum(s);
+#pragma unroll
+  for (int i = 0; i < kMaxClasses / 64; ++i) {
+    const int c = lane + i * 64;
+    if (c < C) dlogits[(int64_t)r * C + c] = gv[i] - expf(lr[c]) * s;
+  }
+}
+
+// out[c] = sum_r x[r,c]; 4 row lanes x 64 columns per workgroup, fixed order.
+__global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C) {
+  __shared__ float part[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (col < C)
+    for (int r = rl; r < R; r += 4) s += x[(int64_t)r * C + col];
+  part[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && col < C)
+    out[col] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+
+}  // namespace
+
+extern "C" size_t lr_proj_workspace_bytes(int R, int K, int C) {
+  if (R <= 0 || K <= 0 || C <= 0) return 0;
+  size_t a = lr_sgemm_workspace_bytes(C, K, R);  // dW = dlogits^T @ hidden
+  size_t b = lr_sgemm_workspace_bytes(R, K, C);  // dhidden
+  size_t c = lr_sgemm_workspace_bytes(R, C, K);  // forward
+  size_t m = a > b ? a : b;
+  if (c > m) m = c;
+  return m + lr_align_up((size_t)C * sizeof(float), 256);
+}
+
+extern "C" int lr_proj_logsoftmax_forward(const float* hidden, const float* W, const float* bias,
+                                          const float* mask, float* log_probs, void* workspace,
+                                          size_t workspace_bytes, int R, int K, int C,
+                                          lr_stream_t stream_) {
+  LR_CHECK_ARG(hidden && W && bias && mask && log_probs && workspace);
+  LR_CHECK_ARG(R > 0 && K > 0 && C > 0);
+  if (C > kMaxClasses) return LR_ERR_UNSUPPORTED;
+  if (workspace_bytes < lr_proj_workspace_bytes(R, K, C)) return LR_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  float* mb = (float*)workspace;  // [C] bias + log(mask + 1e-45)
+  char* gws = (char*)workspace + lr_align_up((size_t)C * sizeof(float), 256);
+  const size_t gws_bytes = workspace_bytes - lr_align_up((size_t)C * sizeof(float), 256);
+  LR_LAUNCH(mask_bias_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, bias, mask, mb, C);
+  int st = lr_launch_status();
+  if (st != LR_OK) return st;
+  st = lr_sgemm_impl(0, 1, R, C, K, 1.f, hidden, K, W, K, 0.f, log_probs, C, mb, 0, 0, gws,
+                     gws_bytes, stream);
+  if (st != LR_OK) return st;
+  LR_LAUNCH(log_softmax_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, log_probs, R, C);
+  return lr_launch_status();
+}
+
+extern "C" int lr_proj_logsoftmax_backward(const float* g, const float* log_probs,
+                                           const float* hidden, const float* W, float* dlogits,
+                                           float* dhidden, float* dW, float* dbias, void* workspace,
+                                           size_t workspace_bytes, int R, int K, int C,
+                                           lr_stream_t stream_) {
+  LR_CHECK_ARG(g && log_probs && hidden && W && dlogits && dW && dbias && workspace);
+  LR_CHECK_ARG(R > 0 && K > 0 && C > 0);
+  if (C > kMaxClasses) return LR_ERR_UNSUPPORTED;
+  if (workspace_bytes < lr_proj_workspace_bytes(R, K, C)) return LR_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  char* gws = (char*)workspace + lr_align_up((size_t)C * sizeof(float), 256);
+  const size_t gws_bytes = workspace_bytes - lr_align_up((size_t)C * sizeof(float), 256);
+  LR_LAUNCH(log_softmax_bwd_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, g, log_probs,
+            dlogits, R, C);
+  int st = lr_launch_status();
+  if (st != LR_OK) return st;
+  if (dhidden) {
+    st = lr_sgemm_impl(0, 0, R, K, C, 1.f, dlogits, C, W, K, 0.f, dhidden, K, nullptr, 0, 0, gws,
+                       gws_bytes, stream);
+    if (st != LR_OK) return st;
+  }
+  st = lr_sgemm_impl(1, 0, C, K, R, 1.f, dlogits, C, hidden, K, 0.f, dW, K, nullptr, 0, 0, gws,
+                     gws_bytes, stream);
+  if (st != LR_OK) return st;
+  LR_LAUNCH(colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, (const float*)dlogits, dbias,
+            R, C);
+  return lr_launch_status();
+}

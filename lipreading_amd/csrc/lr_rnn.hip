@@ -1,0 +1,533 @@
+// lr_rnn.hip — (bi)directional GRU / LSTM layer with torch packed-sequence semantics on gfx950.
+//
+// Reference arithmetic replaced here (paths under the reference root):
+//   src/models/lipreader/better_model.py:47-49   self.rnn = nn.{LSTM,GRU}(..., batch_first=True)
+//   src/models/lipreader/better_model.py:64-78   sort -> pack_padded_sequence -> rnn -> pad_packed
+//   src/models/lipreader/better_model.py:84-89   undo the sort (not needed here: nothing is sorted)
+// Cell equations (torch.nn.GRU / LSTM, gate order r,z,n / i,f,g,o):
+//   GRU : r=s(Wir x+bir+Whr h+bhr)  z=s(...)  n=tanh(Win x+bin + r*(Whn h+bhn))  h'=(1-z)n+z h
+//   LSTM: i,f,o=s(...)  g=tanh(...)  c'=f c+i g  h'=o tanh(c')
+//
+// Structure (MI355X-first, not a translation of torch's cuDNN/MIOpen path):
+//   1. ONE fp32-MFMA GEMM per direction computes the input projection for all T frames
+//      (lr_gemm.hip), biases folded in, straight into the gate buffer.
+//   2. The T-step recurrence is a chain of small (B x H)·(H x G*H) products.  Each step is one
+//      launch covering BOTH directions; a workgroup owns a 16(batch) x 16(hidden unit) tile of all
+//      G gates, its 4 waves split the K=H reduction, operands go global/L2 -> VGPR as float4
+//      (W_hh rows and h rows are both K-contiguous, so no LDS staging is needed for the MFMA
+//      fragments), partial tiles are combined through LDS and the gate non-linearities are fused
+//      into the same kernel.  W_hh (0.75 MiB/dir at GRU-256, 9 MiB/dir at LSTM-768) stays resident
+//      in the per-XCD L2s across steps because a workgroup's tile -> XCD mapping is the same at
+//      every step.  A kernel boundary per step is the cheapest grid-wide hand-off on this chip
+//      (MI355X_MICROARCH.md price list: boundary ~1.5 us vs 4-5 us for an in-kernel grid barrier).
+//   3. The previous hidden state is read directly from y[b, t-1] (t+1 for the reverse direction):
+//      positions past a sample's length hold zeros, which is exactly the packed-sequence
+//      semantics (the reverse direction starts from zero state at each sample's own last frame).
+//   4. Backward: the same chain in reverse with dG·W_hh as the per-step product (W_hh transposed
+//      once per call so its rows are again K-contiguous), then one GEMM each for dW_ih, dW_hh
+//      (with the "previous hidden state" row-shift view of y), dx, and a column-sum for the biases.
+#include "lr_common.h"
+
+int lr_sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                  const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
+                  int row_shift, int period, void* workspace, size_t workspace_bytes,
+                  hipStream_t stream);
+extern "C" size_t lr_sgemm_workspace_bytes(int M, int N, int K);
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TILE = 16;      // batch rows and hidden units per workgroup (MFMA 16x16x4)
+constexpr int RED_LD = 17;    // padded row of the cross-wave reduction buffer
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+struct StepPtrs {
+  const float* w[2];   // per direction: W_hh [G*H][H]  (forward)  or W_hh^T [H][G*H] (backward)
+  const float* b[2];   // per direction: b_hh [G*H]
+};
+
+// ---------------------------------------------------------------------------------------------
+// forward step
+// ---------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void rnn_fwd_step_kernel(float* gates, float* extra, float* y,
+                                                           const int32_t* __restrict__ lens,
+                                                           StepPtrs p, int B, int T, int H, int D,
+                                                           int step) {
+  __shared__ float red[4 * G * TILE * RED_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = blockIdx.z;
+  const int t = d == 0 ? step : T - 1 - step;
+  const int tp = d == 0 ? t - 1 : t + 1;
+  const bool has_prev = tp >= 0 && tp < T;
+  const int j0 = blockIdx.x * TILE, b0 = blockIdx.y * TILE;
+  const int DH = D * H;
+
+  f32x4 acc[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (has_prev) {
+    const int rowi = lane & 15, kq = lane >> 4;
+    const int ab = b0 + rowi, wj = j0 + rowi;
+    const bool a_ok = ab < B, w_ok = wj < H;
+    const float* hrow = y + ((int64_t)ab * T + tp) * DH + d * H;
+    const float* W = p.w[d];
+    const int nchunk = (H + 15) >> 4;
+    for (int c = wave; c < nchunk; c += 4) {
+      const int k = c * 16 + kq * 4;
+      const bool k_ok = k < H;  // H % 4 == 0
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a_ok && k_ok) a = ld4(hrow + k);
+      float4 w[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        w[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (w_ok && k_ok) w[g] = ld4(W + ((int64_t)g * H + wj) * H + k);
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[g].x, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[g].y, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[g].z, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[g].w, acc[g], 0, 0, 0);
+      }
+    }
+    // C/D layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + r
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        red[((wave * G + g) * TILE + kq * 4 + r) * RED_LD + rowi] = acc[g][r];
+  }
+  __syncthreads();
+
+  const int bl = tid >> 4, jl = tid & 15;
+  const int b = b0 + bl, j = j0 + jl;
+  if (b >= B || j >= H) return;
+  float s[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    s[g] = 0.f;
+    if (has_prev) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s[g] += red[((w * G + g) * TILE + bl) * RED_LD + jl];
+    }
+  }
+  const bool valid = t < lens[b];
+  const int64_t bt = (int64_t)b * T + t;
+  float* yo = y + bt * DH + d * H + j;
+  float* eo = extra + (bt * D + d) * H + j;
+  if (!valid) {
+    *yo = 0.f;
+    *eo = 0.f;
+    return;
+  }
+  float* go = gates + (bt * D + d) * (int64_t)(G * H) + j;
+  const int64_t btp = (int64_t)b * T + tp;
+  if (G == 3) {
+    const float hn = s[2] + p.b[d][2 * H + j];
+    const float r = lr_sigmoid(go[0] + s[0]);
+    const float z = lr_sigmoid(go[H] + s[1]);
+    const float n = tanhf(go[2 * H] + r * hn);
+    const float hp = has_prev ? y[btp * DH + d * H + j] : 0.f;
+    const float h = (1.f - z) * n + z * hp;
+    go[0] = r;
+    go[H] = z;
+    go[2 * H] = n;
+    *eo = hn;
+    *yo = h;
+  } else {
+    const float ig = lr_sigmoid(go[0] + s[0]);
+    const float fg = lr_sigmoid(go[H] + s[1]);
+    const float gg = tanhf(go[2 * H] + s[2]);
+    const float og = lr_sigmoid(go[3 * H] + s[G - 1]);
+    const float cp = has_prev ? extra[(btp * D + d) * H + j] : 0.f;
+    const float c = fg * cp + ig * gg;
+    go[0] = ig;
+    go[H] = fg;
+    go[2 * H] = gg;
+    go[3 * H] = og;
+    *eo = c;
+    *yo = og * tanhf(c);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward step
+// ---------------------------------------------------------------------------------------------
+// dG has four slots per (b,t,d): GRU [dr_pre, dz_pre, dn_pre, dhn_lin], LSTM [di,df,dg,do]_pre.
+// The recurrent product uses slots (0,1,3) for the GRU (d/d(W_hh h + b_hh)) and (0,1,2,3) for
+// the LSTM; dW_ih / dx use slots (0,1,2) / (0,1,2,3).
+template <int G>
+__global__ __launch_bounds__(256) void rnn_bwd_step_kernel(
+    const float* __restrict__ gates, const float* __restrict__ extra, const float* __restrict__ y,
+    const float* __restrict__ dy, const float* __restrict__ dh_n, const float* __restrict__ dc_n,
+    float* dG, float* dcar, const int32_t* __restrict__ lens, StepPtrs p, int B, int T, int H, int D,
+    int step) {
+  __shared__ float red[4 * TILE * RED_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = blockIdx.z;
+  const int t = d == 0 ? T - 1 - step : step;   // reverse of the forward order
+  const int tn = d == 0 ? t + 1 : t - 1;        // step processed just before this one
+  const int tp = d == 0 ? t - 1 : t + 1;        // where h_prev / c_prev of step t live
+  const bool has_next = tn >= 0 && tn < T;
+  const bool has_prev = tp >= 0 && tp < T;
+  const int j0 = blockIdx.x * TILE, b0 = blockIdx.y * TILE;
+  const int DH = D * H, GH = G * H;
+
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (has_next) {
+    const int rowi = lane & 15, kq = lane >> 4;
+    const int ab = b0 + rowi, wj = j0 + rowi;
+    const bool a_ok = ab < B, w_ok = wj < H;
+    const float* arow = dG + (((int64_t)ab * T + tn) * D + d) * (int64_t)(4 * H);
+    const float* wrow = p.w[d] + (int64_t)wj * GH;  // W_hh^T row = all G*H recurrent inputs of unit wj
+    const int nchunk = (H + 15) >> 4;
+    const int total = G * nchunk;
+    for (int f = wave; f < total; f += 4) {
+      const int g = f / nchunk, c = f - g * nchunk;
+      const int slot = (G == 3 && g == 2) ? 3 : g;
+      const int k = c * 16 + kq * 4;
+      const bool k_ok = k < H;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), w = a;
+      if (a_ok && k_ok) a = ld4(arow + slot * H + k);
+      if (w_ok && k_ok) w = ld4(wrow + g * H + k);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * TILE + kq * 4 + r) * RED_LD + rowi] = acc[r];
+  }
+  __syncthreads();
+
+  const int bl = tid >> 4, jl = tid & 15;
+  const int b = b0 + bl, j = j0 + jl;
+  if (b >= B || j >= H) return;
+  const int64_t bt = (int64_t)b * T + t;
+  float* dgo = dG + (bt * D + d) * (int64_t)(4 * H) + j;
+  float* dco = dcar + (bt * D + d) * H + j;
+  const int len = lens[b];
+  if (t >= len) {  // padded position: contributes nothing, carries nothing
+    dgo[0] = 0.f;
+    dgo[H] = 0.f;
+    dgo[2 * H] = 0.f;
+    dgo[3 * H] = 0.f;
+    *dco = 0.f;
+    return;
+  }
+  float dh = dy[bt * DH + d * H + j];
+  if (has_next) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) dh += red[(w * TILE + bl) * RED_LD + jl];
+  }
+  const bool is_last = d == 0 ? (t == len - 1) : (t == 0);  // where the final state was read
+  if (is_last && dh_n) dh += dh_n[((int64_t)d * B + b) * H + j];
+  const float* gi = gates + (bt * D + d) * (int64_t)GH + j;
+  const int64_t btn = (int64_t)b * T + tn, btp = (int64_t)b * T + tp;
+  if (G == 3) {
+    if (has_next) dh += dcar[(btn * D + d) * H + j];  // dh_{t+1} * z_{t+1}
+    const float r = gi[0], z = gi[H], n = gi[2 * H];
+    const float hn = extra[(bt * D + d) * H + j];
+    const float hp = has_prev ? y[btp * DH + d * H + j] : 0.f;
+    const float dn = dh * (1.f - z);
+    const float dz = dh * (hp - n);
+    const float dn_pre = dn * (1.f - n * n);
+    const float dr = dn_pre * hn;
+    dgo[0] = dr * r * (1.f - r);
+    dgo[H] = dz * z * (1.f - z);
+    dgo[2 * H] = dn_pre;
+    dgo[3 * H] = dn_pre * r;
+    *dco = dh * z;
+  } else {
+    float dc = has_next ? dcar[(btn * D + d) * H + j] : 0.f;  // dc_{t+1} * f_{t+1}
+    if (is_last && dc_n) dc += dc_n[((int64_t)d * B + b) * H + j];
+    const float ig = gi[0], fg = gi[H], gg = gi[2 * H], og = gi[3 * H];
+    const float c = extra[(bt * D + d) * H + j];
+    const float cp = has_prev ? extra[(btp * D + d) * H + j] : 0.f;
+    const float tc = tanhf(c);
+    dc += dh * og * (1.f - tc * tc);
+    dgo[0] = dc * gg * ig * (1.f - ig);
+    dgo[H] = dc * cp * fg * (1.f - fg);
+    dgo[2 * H] = dc * ig * (1.f - gg * gg);
+    dgo[3 * H] = dh * tc * og * (1.f - og);
+    *dco = dc * fg;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------
+// bias folded into the input projection: b_ih + b_hh, except the GRU n-gate whose b_hn sits
+// inside r*(W_hn h + b_hn).
+__global__ void fold_bias_kernel(const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                 float* __restrict__ out, int G, int H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * H) return;
+  float v = b_ih[i];
+  if (G == 4 || i < 2 * H) v += b_hh[i];
+  out[i] = v;
+}
+
+// out[c][r] = in[r][c]  (rows x cols) -> (cols x rows)
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
+                                 int cols) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? in[(int64_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < rows && c < cols) out[(int64_t)c * rows + r] = tile[tx][i];
+  }
+}
+
+__global__ void final_state_kernel(const float* __restrict__ y, const float* __restrict__ extra,
+                                   const int32_t* __restrict__ lens, float* __restrict__ h_n,
+                                   float* __restrict__ c_n, int B, int T, int H, int D) {
+  const int64_t total = (int64_t)D * B * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % H);
+    const int b = (int)((i / H) % B);
+    const int d = (int)(i / ((int64_t)H * B));
+    int tl = d == 0 ? lens[b] - 1 : 0;
+    if (tl < 0) tl = 0;
+    if (tl >= T) tl = T - 1;
+    const int64_t bt = (int64_t)b * T + tl;
+    h_n[i] = y[bt * D * H + d * H + j];
+    if (c_n) c_n[i] = extra[(bt * D + d) * H + j];
+  }
+}
+
+// Column sums of dG [rows][D][4][H] scattered into the bias gradients.
+// blockDim = 256 = 4 row lanes x 64 columns; fixed summation order (deterministic).
+struct BiasPtrs {
+  float* db_ih[2];
+  float* db_hh[2];
+};
+__global__ void bias_grad_kernel(const float* __restrict__ dG, BiasPtrs p, int rows, int H, int D,
+                                 int G) {
+  __shared__ float part[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int ncol = D * 4 * H;
+  float s = 0.f;
+  if (col < ncol)
+    for (int r = rl; r < rows; r += 4) s += dG[(int64_t)r * ncol + col];
+  part[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && col < ncol) {
+    s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    const int d = col / (4 * H), slot = (col / H) & 3, j = col % H;
+    if (G == 4) {
+      p.db_ih[d][slot * H + j] = s;
+      p.db_hh[d][slot * H + j] = s;
+    } else {
+      if (slot < 3) p.db_ih[d][slot * H + j] = s;
+      if (slot != 2) p.db_hh[d][(slot == 3 ? 2 : slot) * H + j] = s;
+    }
+  }
+}
+
+struct Layout {
+  size_t gates, extra, bias, total;  // float offsets / total floats
+};
+Layout reserve_layout(int G, int B, int T, int H, int D) {
+  Layout l;
+  l.gates = 0;
+  l.extra = l.gates + (size_t)B * T * D * G * H;
+  l.bias = l.extra + (size_t)B * T * D * H;
+  l.total = l.bias + (size_t)D * G * H;
+  return l;
+}
+struct WsLayout {
+  size_t dG, dcar, wT, gemm, total;  // float offsets
+  size_t gemm_bytes;
+};
+WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
+  WsLayout l;
+  l.dG = 0;
+  l.dcar = l.dG + (size_t)B * T * D * 4 * H;
+  l.wT = l.dcar + (size_t)B * T * D * H;
+  l.gemm = l.wT + (size_t)D * H * G * H;
+  size_t gb = lr_sgemm_workspace_bytes(G * H, I, B * T);
+  size_t g2 = lr_sgemm_workspace_bytes(G * H, H, B * T);
+  if (g2 > gb) gb = g2;
+  g2 = lr_sgemm_workspace_bytes(2 * H, H, B * T);
+  if (g2 > gb) gb = g2;
+  g2 = lr_sgemm_workspace_bytes(H, H, B * T);
+  if (g2 > gb) gb = g2;
+  g2 = lr_sgemm_workspace_bytes(B * T, I, G * H);
+  if (g2 > gb) gb = g2;
+  l.gemm_bytes = gb;
+  l.total = l.gemm + (gb + 3) / 4;
+  return l;
+}
+
+bool dims_ok(int mode, int B, int T, int I, int H, int D) {
+  return (mode == LR_RNN_GRU || mode == LR_RNN_LSTM) && B > 0 && T > 0 && I > 0 && H > 0 &&
+         (D == 1 || D == 2);
+}
+
+}  // namespace
+
+extern "C" size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D) {
+  if (!dims_ok(mode, B, T, I, H, D)) return 0;
+  return reserve_layout(mode == LR_RNN_GRU ? 3 : 4, B, T, H, D).total * sizeof(float);
+}
+
+extern "C" size_t lr_rnn_workspace_bytes(int mode, int B, int T, int I, int H, int D) {
+  if (!dims_ok(mode, B, T, I, H, D)) return 0;
+  return ws_layout(mode == LR_RNN_GRU ? 3 : 4, B, T, I, H, D).total * sizeof(float);
+}
+
+extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* lens,
+                                    const float* const* w_ih, const float* const* w_hh,
+                                    const float* const* b_ih, const float* const* b_hh, float* y,
+                                    float* h_n, float* c_n, void* reserve, size_t reserve_bytes,
+                                    int B, int T, int I, int H, int D, lr_stream_t stream_) {
+  LR_CHECK_ARG(dims_ok(mode, B, T, I, H, D));
+  LR_CHECK_ARG(x && lens && w_ih && w_hh && b_ih && b_hh && y && h_n && reserve);
+  if (H % 4 != 0) return LR_ERR_UNSUPPORTED;  // float4 operand loads along K
+  const int G = mode == LR_RNN_GRU ? 3 : 4;
+  LR_CHECK_ARG(G == 3 || c_n);
+  for (int d = 0; d < D; ++d) LR_CHECK_ARG(w_ih[d] && w_hh[d] && b_ih[d] && b_hh[d]);
+  const Layout l = reserve_layout(G, B, T, H, D);
+  if (reserve_bytes < l.total * sizeof(float)) return LR_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  float* base = (float*)reserve;
+  float* gates = base + l.gates;
+  float* extra = base + l.extra;
+  float* bias = base + l.bias;
+  const int GH = G * H;
+
+  for (int d = 0; d < D; ++d) {
+    LR_LAUNCH(fold_bias_kernel, dim3((GH + 255) / 256), dim3(256), 0, stream, b_ih[d], b_hh[d],
+              bias + (size_t)d * GH, G, H);
+    int st = lr_launch_status();
+    if (st != LR_OK) return st;
+    // gates[b,t,d,:] = x[b,t,:] @ W_ih[d]^T + folded bias
+    st = lr_sgemm_impl(0, 1, B * T, GH, I, 1.f, x, I, w_ih[d], I, 0.f, gates + (size_t)d * GH,
+                       D * GH, bias + (size_t)d * GH, 0, 0, nullptr, 0, stream);
+    if (st != LR_OK) return st;
+  }
+  StepPtrs p;
+  for (int d = 0; d < 2; ++d) {
+    p.w[d] = w_hh[d < D ? d : 0];
+    p.b[d] = b_hh[d < D ? d : 0];
+  }
+  const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, D);
+  for (int s = 0; s < T; ++s) {
+    if (G == 3) LR_LAUNCH(rnn_fwd_step_kernel<3>, grid, dim3(256), 0, stream, gates, extra, y, lens, p, B, T, H, D, s);
+    else LR_LAUNCH(rnn_fwd_step_kernel<4>, grid, dim3(256), 0, stream, gates, extra, y, lens, p, B, T, H, D, s);
+  }
+  int st = lr_launch_status();
+  if (st != LR_OK) return st;
+  const int64_t total = (int64_t)D * B * H;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  LR_LAUNCH(final_state_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)y,
+            (const float*)extra, lens, h_n, G == 4 ? c_n : (float*)nullptr, B, T, H, D);
+  return lr_launch_status();
+}
+
+extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* lens,
+                                     const float* const* w_ih, const float* const* w_hh,
+                                     const float* const* b_ih, const float* const* b_hh,
+                                     const float* y, const float* dy, const float* dh_n,
+                                     const float* dc_n, float* dx, float* const* dw_ih,
+                                     float* const* dw_hh, float* const* db_ih, float* const* db_hh,
+                                     const void* reserve, size_t reserve_bytes, void* workspace,
+                                     size_t workspace_bytes, int B, int T, int I, int H, int D,
+                                     lr_stream_t stream_) {
+  LR_CHECK_ARG(dims_ok(mode, B, T, I, H, D));
+  LR_CHECK_ARG(x && lens && w_ih && w_hh && y && dy && reserve && workspace);
+  LR_CHECK_ARG(dw_ih && dw_hh && db_ih && db_hh);
+  if (H % 4 != 0) return LR_ERR_UNSUPPORTED;
+  const int G = mode == LR_RNN_GRU ? 3 : 4;
+  for (int d = 0; d < D; ++d)
+    LR_CHECK_ARG(w_ih[d] && w_hh[d] && dw_ih[d] && dw_hh[d] && db_ih[d] && db_hh[d]);
+  (void)b_ih;
+  (void)b_hh;
+  const Layout rl = reserve_layout(G, B, T, H, D);
+  if (reserve_bytes < rl.total * sizeof(float)) return LR_ERR_WORKSPACE;
+  const WsLayout wl = ws_layout(G, B, T, I, H, D);
+  if (workspace_bytes < wl.total * sizeof(float)) return LR_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const float* rbase = (const float*)reserve;
+  const float* gates = rbase + rl.gates;
+  const float* extra = rbase + rl.extra;
+  float* wbase = (float*)workspace;
+  float* dG = wbase + wl.dG;
+  float* dcar = wbase + wl.dcar;
+  float* wT = wbase + wl.wT;
+  void* gws = wbase + wl.gemm;
+  const int GH = G * H;
+
+  StepPtrs p;
+  for (int d = 0; d < D; ++d) {
+    float* out = wT + (size_t)d * H * GH;
+    LR_LAUNCH(transpose_kernel, dim3((H + 31) / 32, (GH + 31) / 32), dim3(256), 0, stream, w_hh[d],
+              out, GH, H);
+    p.w[d] = out;
+    p.b[d] = nullptr;
+  }
+  if (D == 1) { p.w[1] = p.w[0]; p.b[1] = nullptr; }
+  int st = lr_launch_status();
+  if (st != LR_OK) return st;
+
+  const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, D);
+  for (int s = 0; s < T; ++s) {
+    if (G == 3) LR_LAUNCH(rnn_bwd_step_kernel<3>, grid, dim3(256), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, lens, p, B, T, H, D, s);
+    else LR_LAUNCH(rnn_bwd_step_kernel<4>, grid, dim3(256), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, lens, p, B, T, H, D, s);
+  }
+  st = lr_launch_status();
+  if (st != LR_OK) return st;
+
+  const int R = B * T;
+  const int ldg = D * 4 * H;
+  for (int d = 0; d < D; ++d) {
+    const float* dGd = dG + (size_t)d * 4 * H;
+    // dW_ih[d] (G*H x I) = dGx^T (slots 0..G-1 are contiguous rows) @ x
+    st = lr_sgemm_impl(1, 0, GH, I, R, 1.f, dGd, ldg, x, I, 0.f, dw_ih[d], I, nullptr, 0, 0, gws,
+                       wl.gemm_bytes, stream);
+    if (st != LR_OK) return st;
+    // dW_hh[d] = dGh^T @ h_prev, h_prev[b,t] = y[b,t-1] (forward dir) / y[b,t+1] (reverse dir)
+    const float* yd = y + (size_t)d * H;
+    const int shift = d == 0 ? -1 : 1;
+    if (G == 3) {
+      st = lr_sgemm_impl(1, 0, 2 * H, H, R, 1.f, dGd, ldg, yd, D * H, 0.f, dw_hh[d], H, nullptr,
+                         shift, T, gws, wl.gemm_bytes, stream);
+      if (st != LR_OK) return st;
+      st = lr_sgemm_impl(1, 0, H, H, R, 1.f, dGd + 3 * H, ldg, yd, D * H, 0.f,
+                         dw_hh[d] + (size_t)2 * H * H, H, nullptr, shift, T, gws, wl.gemm_bytes,
+                         stream);
+    } else {
+      st = lr_sgemm_impl(1, 0, GH, H, R, 1.f, dGd, ldg, yd, D * H, 0.f, dw_hh[d], H, nullptr, shift,
+                         T, gws, wl.gemm_bytes, stream);
+    }
+    if (st != LR_OK) return st;
+    if (dx) {
+      st = lr_sgemm_impl(0, 0, R, I, GH, 1.f, dGd, ldg, w_ih[d], I, d == 0 ? 0.f : 1.f, dx, I,
+                         nullptr, 0, 0, gws, wl.gemm_bytes, stream);
+      if (st != LR_OK) return st;
+    }
+  }
+  BiasPtrs bp;
+  for (int d = 0; d < 2; ++d) {
+    bp.db_ih[d] = db_ih[d < D ? d : 0];
+    bp.db_hh[d] = db_hh[d < D ? d : 0];
+  }
+  LR_LAUNCH(bias_grad_kernel, dim3((D * 4 * H + 63) / 64), dim3(256), 0, stream, (const float*)dG,
+            bp, R, H, D, G);
+  return lr_launch_status();
+}

@@ -1,0 +1,247 @@
+"""VideoEncoder on the MI355X — drop-in for `src/models/lipreader/better_model.py:13 VideoEncoder`.
+
+Same constructor signature, attributes, forward contract and state_dict key names
+(`rnn.weight_ih_l{k}[_reverse]`, `rnn.weight_hh_l{k}[_reverse]`, `rnn.bias_ih_l{k}[_reverse]`,
+`rnn.bias_hh_l{k}[_reverse]`, `output_proj.{weight,bias}`), so the reference's `_init_models`
+(src/scripts/train.py:57-79), `restore()` (:82-132) and `save_best_model` keep working.  The
+arithmetic is the HIP path behind include/lipreading_hip.h: one fp32-MFMA input-projection GEMM,
+a chain of fused recurrent step kernels with packed-sequence masking (no length sort, no
+PackedSequence, no host sync), an MFMA output projection and a fused masked log-softmax.
+"""
+import ctypes
+import math
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _C
+from .data import BOS, PAD
+
+_ALLOWED_RNN_TYPES = {'LSTM', 'GRU', 'RNN'}          # better_model.py:9
+_ALLOWED_FRAME_PROCESSING = {'flatten'}              # better_model.py:10
+_MODES = {'GRU': 0, 'LSTM': 1}
+_GATES = {'GRU': 3, 'LSTM': 4}
+
+
+def _ptr_array(tensors):
+  return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class _RNNLayerFunction(torch.autograd.Function):
+  """One (bi)directional layer: lr_rnn_layer_forward / lr_rnn_layer_backward."""
+
+  @staticmethod
+  def forward(ctx, x, lens, mode, H, need_dx, *weights):
+    L = _C.lib()
+    B, T, I = x.shape
+    D = len(weights) // 4
+    dev = x.device
+    w_ih, w_hh = list(weights[0::4]), list(weights[1::4])
+    b_ih, b_hh = list(weights[2::4]), list(weights[3::4])
+    y = torch.empty((B, T, D * H), dtype=torch.float32, device=dev)
+    h_n = torch.empty((D, B, H), dtype=torch.float32, device=dev)
+    c_n = torch.empty((D, B, H), dtype=torch.float32, device=dev) if mode == 1 else None
+    rbytes = L.lr_rnn_reserve_bytes(mode, B, T, I, H, D)
+    reserve = torch.empty(rbytes, dtype=torch.uint8, device=dev)
+    _C.check(L.lr_rnn_layer_forward(mode, x.data_ptr(), lens.data_ptr(), _ptr_array(w_ih),
+                                    _ptr_array(w_hh), _ptr_array(b_ih), _ptr_array(b_hh),
+                                    y.data_ptr(), h_n.data_ptr(), _C.ptr(c_n), reserve.data_ptr(),
+                                    rbytes, B, T, I, H, D, _C.stream_handle()),
+             "lr_rnn_layer_forward")
+    ctx.save_for_backward(x, lens, y, reserve, *weights)
+    ctx.cfg = (mode, H, D, need_dx)
+    if c_n is None:
+      c_n = torch.zeros((0,), device=dev)
+      ctx.mark_non_differentiable(c_n)
+    return y, h_n, c_n
+
+  @staticmethod
+  def backward(ctx, dy, dh_n, dc_n):
+    x, lens, y, reserve = ctx.saved_tensors[:4]
+    weights = ctx.saved_tensors[4:]
+    mode, H, D, need_dx = ctx.cfg
+    L = _C.lib()
+    B, T, I = x.shape
+    dev = x.device
+    w_ih, w_hh = list(weights[0::4]), list(weights[1::4])
+    b_ih, b_hh = list(weights[2::4]), list(weights[3::4])
+    dy = dy.contiguous() if dy is not None else torch.zeros_like(y)
+    dh_n = dh_n.contiguous() if dh_n is not None else None
+    dc_n = dc_n.contiguous() if (mode == 1 and dc_n is not None) else None
+    grads = [torch.empty_like(w) for w in weights]
+    dx = torch.empty_like(x) if need_dx else None
+    wbytes = L.lr_rnn_workspace_bytes(mode, B, T, I, H, D)
+    ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+    _C.check(L.lr_rnn_layer_backward(
+        mode, x.data_ptr(), lens.data_ptr(), _ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(b_ih),
+        _ptr_array(b_hh), y.data_ptr(), dy.data_ptr(), _C.ptr(dh_n), _C.ptr(dc_n), _C.ptr(dx),
+        _ptr_array(grads[0::4]), _ptr_array(grads[1::4]), _ptr_array(grads[2::4]),
+        _ptr_array(grads[3::4]), reserve.data_ptr(), reserve.numel(), ws.data_ptr(), wbytes, B, T,
+        I, H, D, _C.stream_handle()), "lr_rnn_layer_backward")
+    return (dx, None, None, None, None) + tuple(grads)
+
+
+class _ProjLogSoftmaxFunction(torch.autograd.Function):
+  """output_proj + masked_log_softmax (better_model.py:92-93)."""
+
+  @staticmethod
+  def forward(ctx, hidden, weight, bias, mask):
+    L = _C.lib()
+    B, T, K = hidden.shape
+    C = weight.shape[0]
+    R = B * T
+    lp = torch.empty((B, T, C), dtype=torch.float32, device=hidden.device)
+    wbytes = L.lr_proj_workspace_bytes(R, K, C)
+    ws = torch.empty(wbytes, dtype=torch.uint8, device=hidden.device)
+    _C.check(L.lr_proj_logsoftmax_forward(hidden.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                          mask.data_ptr(), lp.data_ptr(), ws.data_ptr(), wbytes, R,
+                                          K, C, _C.stream_handle()), "lr_proj_logsoftmax_forward")
+    ctx.save_for_backward(hidden, weight, lp)
+    return lp
+
+  @staticmethod
+  def backward(ctx, g):
+    hidden, weight, lp = ctx.saved_tensors
+    L = _C.lib()
+    B, T, K = hidden.shape
+    C = weight.shape[0]
+    R = B * T
+    dev = hidden.device
+    g = g.contiguous()
+    dlogits = torch.empty((R, C), dtype=torch.float32, device=dev)
+    dhidden = torch.empty_like(hidden) if ctx.needs_input_grad[0] else None
+    dW = torch.empty_like(weight)
+    db = torch.empty((C,), dtype=torch.float32, device=dev)
+    wbytes = L.lr_proj_workspace_bytes(R, K, C)
+    ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+    _C.check(L.lr_proj_logsoftmax_backward(g.data_ptr(), lp.data_ptr(), hidden.data_ptr(),
+                                           weight.data_ptr(), dlogits.data_ptr(), _C.ptr(dhidden),
+                                           dW.data_ptr(), db.data_ptr(), ws.data_ptr(), wbytes, R, K,
+                                           C, _C.stream_handle()), "lr_proj_logsoftmax_backward")
+    return dhidden, dW, db, None
+
+
+class _RNNParams(nn.Module):
+  """Parameter container with torch.nn.RNNBase's names, shapes, registration order and
+  initialisation (uniform(-1/sqrt(H), 1/sqrt(H)) drawn in registration order), so that a seed
+  produces the same initial weights as the reference's `getattr(nn, rnn_type)(...)`
+  (better_model.py:47-49) and `state_dict()` keys are identical."""
+
+  def __init__(self, rnn_type, input_size, hidden_size, num_layers, bidirectional):
+    super().__init__()
+    G = _GATES[rnn_type]
+    D = 2 if bidirectional else 1
+    self.names = []
+    for layer in range(num_layers):
+      layer_in = input_size if layer == 0 else hidden_size * D
+      for d in range(D):
+        suffix = '_reverse' if d == 1 else ''
+        shapes = [('weight_ih', (G * hidden_size, layer_in)), ('weight_hh', (G * hidden_size, hidden_size)),
+                  ('bias_ih', (G * hidden_size,)), ('bias_hh', (G * hidden_size,))]
+        for base, shape in shapes:
+          name = '%s_l%d%s' % (base, layer, suffix)
+          self.register_parameter(name, nn.Parameter(torch.empty(shape)))
+          self.names.append(name)
+    stdv = 1.0 / math.sqrt(hidden_size) if hidden_size > 0 else 0
+    for p in self.parameters():
+      nn.init.uniform_(p, -stdv, stdv)
+
+  def layer_weights(self, layer, D):
+    return [getattr(self, self.names[(layer * D + d) * 4 + i]) for d in range(D) for i in range(4)]
+
+
+class VideoEncoder(nn.Module):
+  def __init__(self, frame_dim, hidden_size, frame_processing='flatten',
+               rnn_type='LSTM', num_layers=1, bidirectional=True, rnn_dropout=0,
+               enable_ctc=False, vocab_size=-1, char2idx=None, device="cpu"):
+    """When enable_ctc=True, vocab_size (including the special tokens) and char2idx must be
+    provided — better_model.py:14-25."""
+    super(VideoEncoder, self).__init__()
+    assert frame_processing in _ALLOWED_FRAME_PROCESSING
+    assert rnn_type in _ALLOWED_RNN_TYPES
+    if rnn_type == 'RNN':
+      # the reference allows nn.RNN (tanh) but ships no config that uses it
+      raise NotImplementedError("rnn_type='RNN' has no HIP kernel; use 'GRU' or 'LSTM'")
+    if enable_ctc:
+      assert vocab_size > 0 and char2idx is not None
+
+    self.frame_dim = frame_dim
+    self.hidden_size = hidden_size
+    self.frame_processing = frame_processing
+    self.rnn_type = rnn_type
+    self.num_layers = num_layers
+    self.bidirectional = bidirectional
+    self.rnn_dropout = rnn_dropout
+    self.enable_ctc = enable_ctc
+    self.best_error = 1
+    self.num_dirs = 2 if self.bidirectional else 1
+    if self.enable_ctc:
+      self.vocab_size = vocab_size
+      self.adj_vocab_size = self.vocab_size + 1      # idx 0 is reserved for the CTC blank
+      self.char2idx = char2idx
+      mask = torch.ones(self.adj_vocab_size, device=device)
+      mask[self.char2idx[PAD] + 1] = 0
+      mask[self.char2idx[BOS] + 1] = 0
+      # the reference keeps a plain attribute (not in state_dict); a non-persistent buffer has
+      # the same state_dict and additionally follows .to(device)
+      self.register_buffer("output_mask", mask, persistent=False)
+
+    self.rnn = _RNNParams(self.rnn_type, self.frame_dim, self.hidden_size, self.num_layers,
+                          self.bidirectional)
+    if self.enable_ctc:
+      self.output_proj = nn.Linear(self.num_dirs * self.hidden_size, self.adj_vocab_size)
+
+  def forward(self, frames, frame_lens, max_len=None):
+    """frames (B, seq_len, num_lmks, lmk_dim) f32, frame_lens (B,) -> as better_model.py:53-96:
+    (log_probs (B,Tmax,V+1), hidden (B,Tmax,D*H), final_state) if enable_ctc else
+    (hidden, final_state); final_state is (h, c) for the LSTM, each (layers, B, D*H).
+
+    `max_len` (optional, not in the reference) = max(frame_lens) when the caller already knows
+    it on the host; it avoids the one device->host read that the reference also performs
+    (better_model.py:69)."""
+    _C.require_cuda(frames)
+    if self.frame_processing == 'flatten':
+      frames = frames.reshape(frames.shape[0], frames.shape[1], -1)
+    B, T, I = frames.shape
+    assert I == self.frame_dim
+    if max_len is None:
+      max_len = int(frame_lens.max())          # host read iff frame_lens lives on the device
+    assert 1 <= max_len <= T
+    x = frames[:, :max_len].to(torch.float32).contiguous()
+    lens = frame_lens.to(device=x.device, dtype=torch.int32).contiguous()
+    mode, H, D = _MODES[self.rnn_type], self.hidden_size, self.num_dirs
+
+    h_fin, c_fin = [], []
+    for layer in range(self.num_layers):
+      weights = self.rnn.layer_weights(layer, D)
+      need_dx = layer > 0 or x.requires_grad
+      y, h_n, c_n = _RNNLayerFunction.apply(x, lens, mode, H, need_dx, *weights)
+      # (D,B,H) -> (B, D*H): forward direction first, as _cat_directions (better_model.py:98-112)
+      h_fin.append(h_n.permute(1, 0, 2).reshape(B, D * H))
+      if mode == 1:
+        c_fin.append(c_n.permute(1, 0, 2).reshape(B, D * H))
+      x = y
+      if self.rnn_dropout and self.training and layer + 1 < self.num_layers:
+        x = F.dropout(x, p=self.rnn_dropout, training=True)   # nn.GRU/LSTM inter-layer dropout
+    hidden_states = y
+    final_state = torch.stack(h_fin, 0)
+    if mode == 1:
+      final_state = (final_state, torch.stack(c_fin, 0))
+
+    if self.enable_ctc:
+      output_log_probs = _ProjLogSoftmaxFunction.apply(hidden_states, self.output_proj.weight,
+                                                       self.output_proj.bias, self.output_mask)
+      return output_log_probs, hidden_states, final_state
+    return hidden_states, final_state
+
+  def save_best_model(self, error, file_path):
+    """better_model.py:114-122."""
+    if error < self.best_error:
+      self.best_error = error
+      folder = os.path.dirname(file_path)
+      if folder and not os.path.exists(folder):
+        os.makedirs(folder)
+      torch.save(self.state_dict(), file_path)
+      print("\tSaving best error '{}' to '{}'".format(self.best_error, file_path))

@@ -1,0 +1,195 @@
+"""GPU parity: fp32-MFMA GEMM, recurrent layer (fwd+bwd), projection + masked log-softmax and
+the whole VideoEncoder through the C ABI, against the reference vectors and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_oracle as O
+from tests.test_oracle_golden import ENC_CASES, _flatten, build_oracle_encoder
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+  assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+  return torch.device("cuda:0")
+
+
+def hip_encoder_from(case, rnn_type, dev):
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.data import default_char2idx
+  H, layers, bi = [int(x) for x in case["cfg"]]
+  enc = VideoEncoder(204, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bool(bi),
+                     enable_ctc=True, vocab_size=64, char2idx=default_char2idx())
+  key = "sd" if "sd" in case else "sd0"
+  missing = enc.load_state_dict({k: torch.tensor(v) for k, v in _flatten(case[key]).items()})
+  assert not missing.missing_keys and not missing.unexpected_keys   # reference key names
+  return enc.to(dev)
+
+
+# ---- GEMM -----------------------------------------------------------------------------------
+def run_sgemm(ta, tb, M, N, K, dev, alpha=1.0, beta=0.0, bias=False, shift=0, period=0, seed=0):
+  from lipreading_amd import _C
+  L = _C.lib()
+  g = torch.Generator().manual_seed(seed)
+  A = torch.randn((K, M) if ta else (M, K), generator=g)
+  B = torch.randn((N, K) if tb else (K, N), generator=g)
+  C0 = torch.randn(M, N, generator=g)
+  bv = torch.randn(N, generator=g) if bias else None
+  opA = A.t() if ta else A
+  opB = B.t() if tb else B
+  if period:
+    rows = torch.arange(K)
+    ok = ((rows % period + shift) >= 0) & ((rows % period + shift) < period)
+    src = (rows + shift).clamp(0, K - 1)
+    opB = torch.where(ok[:, None], opB[src], torch.zeros_like(opB))
+  ref = alpha * (opA.double() @ opB.double()) + beta * C0.double()
+  if bias:
+    ref = ref + bv.double()
+  Ad, Bd, Cd = A.to(dev), B.to(dev), C0.clone().to(dev)
+  bd = bv.to(dev) if bias else None
+  wsb = L.lr_sgemm_workspace_bytes(M, N, K)
+  ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+  _C.check(L.lr_sgemm(int(ta), int(tb), M, N, K, alpha, Ad.data_ptr(), A.shape[1], Bd.data_ptr(),
+                      B.shape[1], beta, Cd.data_ptr(), N, _C.ptr(bd), shift, period,
+                      ws.data_ptr() if wsb else None, wsb, _C.stream_handle()), "lr_sgemm")
+  scale = max(1.0, float(ref.abs().max()))
+  err = float((Cd.cpu().double() - ref).abs().max()) / scale
+  assert err < 2e-6 * max(1, K) ** 0.5 + 1e-6, err
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(37, 65, 204), (2400, 768, 204), (130, 129, 31), (1, 1, 1)])
+def test_sgemm_layouts_and_ragged_edges(dev, ta, tb, M, N, K):
+  run_sgemm(ta, tb, M, N, K, dev, seed=M + N + K)
+
+
+def test_sgemm_epilogue_splitk_and_row_shift(dev):
+  run_sgemm(0, 1, 300, 200, 64, dev, alpha=0.5, beta=2.0, bias=True)
+  run_sgemm(1, 0, 768, 256, 2400, dev)                       # dW_hh shape: split along K
+  run_sgemm(1, 0, 65, 512, 2400, dev, alpha=2.0, beta=1.0)   # dW_proj shape, split + beta
+  run_sgemm(1, 0, 96, 32, 150, dev, shift=-1, period=75)     # h_prev view, forward direction
+  run_sgemm(1, 0, 96, 32, 150, dev, shift=1, period=75)      # h_prev view, reverse direction
+  run_sgemm(0, 0, 2400, 3072, 768, dev)                      # 128x128 tiles
+
+
+# ---- encoder forward against the reference vectors -------------------------------------------
+@pytest.mark.parametrize("name", ENC_CASES)
+@pytest.mark.parametrize("tag", ["eq", "mix"])
+def test_encoder_matches_reference_vectors(golden_enc, dev, name, tag):
+  case = golden_enc[name]
+  enc = hip_encoder_from(case, "GRU" if name.startswith("gru") else "LSTM", dev).eval()
+  io = case[tag]
+  with torch.no_grad():
+    lp, hid, fin = enc(torch.tensor(io["frames"], device=dev), torch.tensor(io["lens"]))
+  np.testing.assert_allclose(lp.cpu().numpy(), io["log_probs"], rtol=1e-4, atol=2e-5)
+  np.testing.assert_allclose(hid.cpu().numpy(), io["hidden"], rtol=1e-4, atol=2e-6)
+  if isinstance(fin, tuple):
+    np.testing.assert_allclose(fin[0].cpu().numpy(), io["h_n"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(fin[1].cpu().numpy(), io["c_n"], rtol=1e-4, atol=2e-6)
+  else:
+    np.testing.assert_allclose(fin.cpu().numpy(), io["h_n"], rtol=1e-4, atol=2e-6)
+  # masked classes: finite and ~103.28 below, not -inf (subnormal 1e-45 kept on gfx950)
+  masked = lp[..., 1:3].cpu().numpy()
+  assert np.isfinite(masked).all() and (masked < -90).all()
+  # padded positions: hidden is exactly zero
+  for b, n in enumerate(io["lens"]):
+    assert float(hid[b, int(n):].abs().sum()) == 0.0
+
+
+# ---- encoder forward + backward against the oracle at real sizes ------------------------------
+def make_pair(rnn_type, H, layers, bi, dev, seed=123456):
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.data import default_char2idx
+  torch.manual_seed(seed)
+  ref = O.OracleVideoEncoder(204, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
+                             enable_ctc=True, vocab_size=64, char2idx=O.default_char2idx())
+  enc = VideoEncoder(204, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
+                     enable_ctc=True, vocab_size=64, char2idx=default_char2idx())
+  enc.load_state_dict(ref.state_dict())
+  return ref, enc.to(dev)
+
+
+CFG = [("GRU", 256, 1, True, 32, 75), ("LSTM", 768, 1, True, 32, 75), ("GRU", 700, 1, True, 9, 40),
+       ("LSTM", 64, 2, True, 20, 33), ("GRU", 48, 2, False, 17, 21), ("LSTM", 36, 1, False, 5, 12)]
+
+
+@pytest.mark.parametrize("rnn_type,H,layers,bi,B,T", CFG)
+def test_encoder_forward_backward_matches_oracle(dev, rnn_type, H, layers, bi, B, T):
+  ref, enc = make_pair(rnn_type, H, layers, bi, dev)
+  g = torch.Generator().manual_seed(1)
+  lens = torch.sort(torch.randint(max(1, T // 2), T + 1, (B,), generator=g))[0]
+  lens[-1] = T
+  lens[0] = max(1, T // 3)
+  frames = torch.randn(B, T, 68, 3, generator=g)
+  for b in range(B):
+    frames[b, int(lens[b]):] = 0
+  w_lp = torch.randn(B, T, 65, generator=g) / 50
+  w_h = torch.randn(B, T, (2 if bi else 1) * H, generator=g) / 50
+
+  def loss_of(out):
+    lp, hid, fin = out
+    l = (lp * w_lp.to(lp.device)).sum() + (hid * w_h.to(hid.device)).sum()
+    fins = fin if isinstance(fin, tuple) else (fin,)
+    for f in fins:
+      l = l + (f * 0.01).sum()
+    return l
+
+  out_r = ref(frames, lens)
+  loss_of(out_r).backward()
+  out_g = enc(frames.to(dev), lens)
+  loss_of(out_g).backward()
+  tol = 3e-5 if H <= 256 else 1e-4
+  np.testing.assert_allclose(out_g[0].detach().cpu().numpy(), out_r[0].detach().numpy(), rtol=1e-4, atol=tol)
+  np.testing.assert_allclose(out_g[1].detach().cpu().numpy(), out_r[1].detach().numpy(), rtol=1e-4, atol=tol)
+  gr = dict(ref.named_parameters())
+  for k, p in enc.named_parameters():
+    a, b_ = p.grad.cpu().numpy(), gr[k].grad.numpy()
+    scale = max(1e-3, float(np.abs(b_).max()))
+    assert np.abs(a - b_).max() / scale < 2e-4, (k, np.abs(a - b_).max(), scale)
+
+
+def test_encoder_two_backward_passes_accumulate(dev):
+  """train_better_model.py:69,74: decoder_loss.backward(retain_graph=True) then
+  ctc_loss_.backward() traverse the same encoder graph; gradients accumulate."""
+  ref, enc = make_pair("GRU", 32, 1, True, dev)
+  g = torch.Generator().manual_seed(3)
+  frames = torch.randn(6, 10, 68, 3, generator=g)
+  lens = torch.tensor([4, 6, 10, 10, 10, 10])
+  outs = {}
+  for name, m, x in (("ref", ref, frames), ("hip", enc, frames.to(dev))):
+    lp, hid, fin = m(x, lens)
+    hid.sum().backward(retain_graph=True)
+    lp[..., 5].sum().backward()
+    outs[name] = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()}
+  for k in outs["ref"]:
+    np.testing.assert_allclose(outs["hip"][k], outs["ref"][k], rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("name", ["gru", "lstm"])
+def test_ctc_step_matches_reference_vectors(golden_step, dev, name):
+  """One CTC-only optimisation step (train_better_model.py:31-32,46-48,74,78,80)."""
+  from lipreading_amd.ctc import ctc_loss
+  case = golden_step[name]
+  enc = hip_encoder_from(case, name.upper(), dev).train()
+  opt = torch.optim.Adam(enc.parameters(), lr=1e-3)
+  chars = torch.tensor(case["chars"], device=dev)
+  lens = torch.tensor(case["lens"])
+  lp, _, _ = enc(torch.tensor(case["frames"], device=dev), lens)
+  loss = ctc_loss(lp, chars[:, 1:], lens.to(dev), torch.tensor(case["char_lens"], device=dev) - 1,
+                  'mean', dev)
+  assert abs(loss.item() - float(case["loss"])) < 1e-4
+  opt.zero_grad()
+  loss.backward()
+  grads = _flatten(case["grad"])
+  for k, p in enc.named_parameters():
+    ref = grads[k]
+    scale = max(1e-4, float(np.abs(ref).max()))
+    assert np.abs(p.grad.cpu().numpy() - ref).max() / scale < 2e-4, k
+  total = torch.nn.utils.clip_grad_norm_(enc.parameters(), 5.0)
+  assert abs(float(total) - float(case["total_norm"])) < 1e-3 * float(case["total_norm"])
+  opt.step()
+  sd1 = _flatten(case["sd1"])
+  for k, v in enc.state_dict().items():
+    np.testing.assert_allclose(v.cpu().numpy(), sd1[k], rtol=1e-3, atol=2e-5, err_msg=k)

@@ -1,0 +1,55 @@
+"""CPU: host-side mirror of the reference interface (no GPU, no kernels)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from lipreading_amd.data import default_char2idx
+from lipreading_amd.decoder import Decoder, ctc_labels
+from oracle import torch_oracle as O
+
+
+@pytest.mark.parametrize("rnn_type", ["GRU", "LSTM"])
+@pytest.mark.parametrize("layers,bi", [(1, True), (2, True), (2, False)])
+def test_encoder_state_dict_and_init_match_torch_rnn(rnn_type, layers, bi):
+  """Same key names, shapes and (given the seed) the same initial weights as the reference's
+  nn.GRU/nn.LSTM + nn.Linear (better_model.py:47-51)."""
+  from lipreading_amd.encoder import VideoEncoder
+  torch.manual_seed(123456)
+  ref = O.OracleVideoEncoder(204, 20, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
+                             enable_ctc=True, vocab_size=64, char2idx=O.default_char2idx())
+  torch.manual_seed(123456)
+  enc = VideoEncoder(204, 20, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
+                     enable_ctc=True, vocab_size=64, char2idx=default_char2idx())
+  a, b = ref.state_dict(), enc.state_dict()
+  assert list(a.keys()) == list(b.keys())
+  for k in a:
+    assert a[k].shape == b[k].shape, k
+    assert torch.equal(a[k], b[k]), k
+  assert enc.output_mask.tolist() == ref.output_mask.tolist()
+  assert enc.adj_vocab_size == 65 and enc.best_error == 1
+
+
+def test_encoder_rejects_cpu_tensors():
+  from lipreading_amd import _C
+  from lipreading_amd.encoder import VideoEncoder
+  enc = VideoEncoder(204, 8, rnn_type='GRU', enable_ctc=True, vocab_size=64,
+                     char2idx=default_char2idx())
+  with pytest.raises(_C.LipReadingHipError):
+    enc(torch.zeros(2, 3, 68, 3), torch.tensor([3, 3]))
+
+
+def test_vocab_and_labels():
+  c2i = default_char2idx()
+  assert c2i == O.default_char2idx() and len(c2i) == 64
+  labels = ctc_labels(c2i)
+  assert labels == O.ctc_labels() and len(labels) == 65 and labels[0] == '_' and labels[5] == ' '
+
+
+def test_wer_cer_edit_distance():
+  d = Decoder(ctc_labels(default_char2idx()))
+  assert d.cer("hello world", "helo wurld") == 2
+  assert d.wer("the cat sat", "the cat sat down") == 1
+  assert d.wer("a b c", "a x c") == 1
+  assert d.cer("", "abc") == 3
+  assert O.edit_distance("kitten", "sitting") == 3
