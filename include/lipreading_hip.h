@@ -137,6 +137,15 @@ int lr_rnn_layer_backward(int mode, const float* x, const int32_t* lens,
                           size_t workspace_bytes, int B, int T, int I, int H, int D,
                           lr_stream_t stream);
 
+/* Instrumentation for the roofline leg of bench.py (the only entry points that touch the host
+ * clock).  While enabled, every lr_rnn_layer_forward / _backward call brackets ONE of its step
+ * launches (the middle one) with a hipEvent pair recorded on the stream the kernel runs on.
+ * lr_profile_read(which: 0 = forward step kernel, 1 = backward step kernel) WAITS for the
+ * recorded events, returns the summed elapsed milliseconds and the number of samples in HOST
+ * memory, and clears the ring (2048 samples per kind; later samples are dropped). */
+int lr_profile_enable(int on);
+int lr_profile_read(int which, float* total_ms_host, int* samples_host);
+
 /* ---- A3 tail: output_proj + masked_log_softmax — better_model.py:92-93 ------------------ */
 
 /* log_probs[r,:] = log_softmax(hidden[r,:] @ W^T + bias + log(mask + 1e-45))
@@ -228,12 +237,18 @@ int lr_sumsq(const float* x, int64_t n, float* out, lr_stream_t stream);
 
 /* Fused clip + Adam step over a flat parameter buffer (torch.optim.Adam defaults as used at
  * src/scripts/train.py:280: betas (0.9,0.999), eps 1e-8, no weight decay, no amsgrad).
- *   scale = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) when max_norm > 0 (clip_grad_norm_),
- *   else 1.  step_count_host is the 1-based step number used for bias correction.
- *   grad_scale multiplies the gradient first (1/world_size after an all-reduce sum). */
+ *   grad_scale multiplies the gradient first (1/world_size after an all-reduce sum);
+ *   max_norm > 0 applies clip_grad_norm_ (train_better_model.py:78) with the total norm taken
+ *   from sumsq[0] (lr_sumsq over the same gradient buffer): coef = min(1, max_norm/(norm+1e-6)).
+ *   step_count  [1] int32 DEVICE counter, incremented here (bias correction uses the new value),
+ *               so a captured hipGraph replays correct corrections;
+ *   skip        [1] int32 DEVICE flag or NULL: non-zero = the reference skipped this batch
+ *               (`continue`, train_better_model.py:49-50): nothing is updated, step_count stays;
+ *   scratch     [4] floats of device scratch. */
 int lr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                  const float* sumsq, float max_norm, float grad_scale, float lr, float beta1,
-                 float beta2, float eps, int step_count_host, lr_stream_t stream);
+                 float beta2, float eps, int32_t* step_count, const int32_t* skip, float* scratch,
+                 lr_stream_t stream);
 
 #ifdef __cplusplus
 }

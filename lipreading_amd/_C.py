@@ -30,6 +30,8 @@ SIGNATURES = {
                                       c_int, c_int, c_int, P]),
     "lr_rnn_layer_backward": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                        c_size_t, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
+    "lr_profile_enable": (c_int, [c_int]),
+    "lr_profile_read": (c_int, [c_int, P, P]),
     "lr_proj_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "lr_proj_logsoftmax_forward": (c_int, [P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, P]),
     "lr_proj_logsoftmax_backward": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int,
@@ -44,7 +46,7 @@ SIGNATURES = {
                                       c_int, P]),
     "lr_sumsq": (c_int, [P, c_int64, P, P]),
     "lr_adam_step": (c_int, [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_float,
-                              c_float, c_int, P]),
+                              c_float, P, P, P, P]),
 }
 
 
@@ -65,6 +67,11 @@ def lib():
       raise LipReadingHipError(
           "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
           "(there is no CPU fallback for the MI355X hot path)" % path)
+    # torch bundles its own libamdhip64.so.7; load it FIRST so that this library binds to the
+    # same HIP runtime instance that owns torch's streams and allocations.  (Loaded the other
+    # way round, /opt/rocm's runtime and torch's coexist and every launch on a torch stream
+    # fails with an invalid-handle error.)
+    import torch  # noqa: F401
     handle = ctypes.CDLL(path)
     for name, (restype, argtypes) in SIGNATURES.items():
       fn = getattr(handle, name)  # AttributeError if the header and the .so disagree

@@ -110,19 +110,41 @@ __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __re
   }
 }
 
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                            float* __restrict__ m, float* __restrict__ v, int64_t n,
-                            const float* __restrict__ sumsq, float max_norm, float grad_scale,
-                            float lr, float beta1, float beta2, float eps, float bc1, float bc2) {
+// One thread: advance the device-side step counter (unless the batch is skipped), derive the
+// bias corrections and the clip coefficient.  Keeping the counter on the device makes the
+// whole optimiser step replayable from a hipGraph (host-computed corrections would be frozen).
+//   st[0] = active (0/1), st[1] = lr / (1 - beta1^t), st[2] = 1 / sqrt(1 - beta2^t),
+//   st[3] = gradient scale (grad_scale x clip coefficient)
+__global__ void adam_prepare_kernel(int32_t* __restrict__ step_count,
+                                    const int32_t* __restrict__ skip,
+                                    const float* __restrict__ sumsq, float max_norm,
+                                    float grad_scale, float lr, float beta1, float beta2,
+                                    float* __restrict__ st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const bool active = !(skip && skip[0] != 0);
+  int t = step_count[0];
+  if (active) step_count[0] = ++t;
+  if (t < 1) t = 1;
+  const float bc1 = 1.f - powf(beta1, (float)t);
+  const float bc2 = 1.f - powf(beta2, (float)t);
   float scale = grad_scale;
   if (max_norm > 0.f && sumsq) {
-    // clip_grad_norm_: total_norm of the (already grad_scale'd) gradient
-    const float norm = sqrtf(sumsq[0]) * grad_scale;
+    // clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
+    const float norm = sqrtf(sumsq[0]) * fabsf(grad_scale);
     const float coef = max_norm / (norm + 1e-6f);
     if (coef < 1.f) scale *= coef;
   }
-  const float step = lr / bc1;
-  const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  st[0] = active ? 1.f : 0.f;
+  st[1] = lr / bc1;
+  st[2] = 1.f / sqrtf(bc2);
+  st[3] = scale;
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v, int64_t n,
+                            const float* __restrict__ st, float beta1, float beta2, float eps) {
+  if (st[0] == 0.f) return;  // skipped batch: parameters and moments untouched
+  const float step = st[1], inv_sqrt_bc2 = st[2], scale = st[3];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * scale;
@@ -182,14 +204,14 @@ extern "C" int lr_sumsq(const float* x, int64_t n, float* out, lr_stream_t strea
 
 extern "C" int lr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                             int64_t n, const float* sumsq, float max_norm, float grad_scale,
-                            float lr, float beta1, float beta2, float eps, int step_count_host,
-                            lr_stream_t stream) {
-  LR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n >= 0 && step_count_host >= 1);
-  if (n == 0) return LR_OK;
-  const float bc1 = 1.f - powf(beta1, (float)step_count_host);
-  const float bc2 = 1.f - powf(beta2, (float)step_count_host);
-  LR_LAUNCH(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream,
-                     param, grad, exp_avg, exp_avg_sq, n, sumsq, max_norm, grad_scale, lr, beta1,
-                     beta2, eps, bc1, bc2);
+                            float lr, float beta1, float beta2, float eps, int32_t* step_count,
+                            const int32_t* skip, float* scratch, lr_stream_t stream) {
+  LR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_count && scratch && n >= 0);
+  LR_LAUNCH(adam_prepare_kernel, dim3(1), dim3(64), 0, stream, step_count, skip, sumsq, max_norm,
+            grad_scale, lr, beta1, beta2, scratch);
+  int st = lr_launch_status();
+  if (st != LR_OK || n == 0) return st;
+  LR_LAUNCH(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, param, grad, exp_avg,
+            exp_avg_sq, n, (const float*)scratch, beta1, beta2, eps);
   return lr_launch_status();
 }

@@ -373,12 +373,77 @@ WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
   return l;
 }
 
+// ---- optional instrumentation (bench.py roofline leg) -----------------------------------------
+// One step launch per layer call (the middle one) is bracketed by a hipEvent pair on the stream
+// the kernel runs on; lr_profile_read averages the pairs.  Two event records per ~75 launches,
+// so the timed region is not perturbed measurably.
+constexpr int kProfRing = 2048;
+struct ProfSlot {
+  hipEvent_t start[kProfRing], stop[kProfRing];
+  int count;
+  bool ready;
+};
+ProfSlot g_prof[2];
+bool g_prof_on = false;
+
+void prof_begin(int which, hipStream_t stream) {
+  ProfSlot& p = g_prof[which];
+  if (!g_prof_on || !p.ready || p.count >= kProfRing) return;
+  (void)hipEventRecord(p.start[p.count], stream);
+}
+void prof_end(int which, hipStream_t stream) {
+  ProfSlot& p = g_prof[which];
+  if (!g_prof_on || !p.ready || p.count >= kProfRing) return;
+  (void)hipEventRecord(p.stop[p.count], stream);
+  ++p.count;
+}
+
 bool dims_ok(int mode, int B, int T, int I, int H, int D) {
   return (mode == LR_RNN_GRU || mode == LR_RNN_LSTM) && B > 0 && T > 0 && I > 0 && H > 0 &&
          (D == 1 || D == 2);
 }
 
 }  // namespace
+
+extern "C" int lr_profile_enable(int on) {
+  if (on && !g_prof_on) {
+    for (int w = 0; w < 2; ++w) {
+      ProfSlot& p = g_prof[w];
+      if (!p.ready) {
+        for (int i = 0; i < kProfRing; ++i) {
+          if (hipEventCreate(&p.start[i]) != hipSuccess || hipEventCreate(&p.stop[i]) != hipSuccess) {
+            (void)hipGetLastError();
+            return LR_ERR_NO_DEVICE;
+          }
+        }
+        p.ready = true;
+      }
+      p.count = 0;
+    }
+  }
+  g_prof_on = on != 0;
+  return LR_OK;
+}
+
+extern "C" int lr_profile_read(int which, float* total_ms_host, int* samples_host) {
+  LR_CHECK_ARG((which == 0 || which == 1) && total_ms_host && samples_host);
+  ProfSlot& p = g_prof[which];
+  float total = 0.f;
+  int n = 0;
+  for (int i = 0; i < p.count; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.stop[i]) == hipSuccess &&
+        hipEventElapsedTime(&ms, p.start[i], p.stop[i]) == hipSuccess) {
+      total += ms;
+      ++n;
+    }
+  }
+  (void)hipGetLastError();
+  p.count = 0;
+  *total_ms_host = total;
+  *samples_host = n;
+  return LR_OK;
+}
 
 extern "C" size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D)) return 0;
@@ -427,8 +492,10 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
   }
   const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, D);
   for (int s = 0; s < T; ++s) {
+    if (s == T / 2) prof_begin(0, stream);
     if (G == 3) LR_LAUNCH(rnn_fwd_step_kernel<3>, grid, dim3(256), 0, stream, gates, extra, y, lens, p, B, T, H, D, s);
     else LR_LAUNCH(rnn_fwd_step_kernel<4>, grid, dim3(256), 0, stream, gates, extra, y, lens, p, B, T, H, D, s);
+    if (s == T / 2) prof_end(0, stream);
   }
   int st = lr_launch_status();
   if (st != LR_OK) return st;
@@ -487,8 +554,10 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
 
   const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, D);
   for (int s = 0; s < T; ++s) {
+    if (s == T / 2) prof_begin(1, stream);
     if (G == 3) LR_LAUNCH(rnn_bwd_step_kernel<3>, grid, dim3(256), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, lens, p, B, T, H, D, s);
     else LR_LAUNCH(rnn_bwd_step_kernel<4>, grid, dim3(256), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, lens, p, B, T, H, D, s);
+    if (s == T / 2) prof_end(1, stream);
   }
   st = lr_launch_status();
   if (st != LR_OK) return st;

@@ -1,0 +1,124 @@
+"""Single-node data parallelism for the encoder+CTC step: one process per GPU, gradients summed
+with RCCL all-reduce over xGMI (torch.distributed backend "nccl" IS RCCL on ROCm).
+
+The reference lipreader is single-process (src/scripts/train.py:200-203 carries a REVIEW note
+asking how to use several GPUs); its only distributed code is the unused vendored audio
+trainer.  The path shards by independent samples along the batch: every rank takes a contiguous
+slice of the length-sorted batch (so each shard keeps ascending frame_lens, ctc_loss.py:39) and
+the one exchange per step is the gradient sum.
+
+Design for xGMI (point-to-point links, a ring all-reduce is bound by ONE ~153 GB/s link and at
+these sizes by latency): the gradients already live in one flat buffer
+(optim.FlatParameters), so the exchange is a handful of large collectives over contiguous slices
+— one bucket per autograd stage (output_proj, then each recurrent layer from last to first) —
+each launched on a side HIP stream the moment its stage's gradients have been accumulated, so it
+overlaps the remaining backward kernels.  The optimiser waits on the side stream, not the host.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_batch(n_items, rank, world):
+  """Contiguous slice [lo, hi) of a length-sorted batch for `rank`: keeps ascending order and
+  keeps equal-length runs together as far as the split allows."""
+  base, rem = divmod(n_items, world)
+  lo = rank * base + min(rank, rem)
+  return lo, lo + base + (1 if rank < rem else 0)
+
+
+class GradSync(object):
+  """Bucketed gradient all-reduce over a FlatParameters buffer.
+
+  buckets: by default one per top-level child module of `module` (registration order), which for
+  VideoEncoder is [rnn (all layers), output_proj]; `per_param_groups` can refine that.  Works
+  with any torch.distributed backend (gloo on CPU for tests, nccl/RCCL on the GPUs)."""
+
+  def __init__(self, flat, groups=None, process_group=None, overlap=True):
+    self.flat = flat
+    self.pg = process_group
+    self.world = dist.get_world_size(process_group)
+    self.cuda = flat.grad.is_cuda
+    self.overlap = overlap and self.cuda
+    params = flat.params
+    if groups is None:
+      groups = [list(range(len(params)))]
+    self.groups = groups
+    self.bounds = []
+    for g in groups:
+      lo = flat.offsets[g[0]]
+      last = g[-1]
+      hi = flat.offsets[last + 1] if last + 1 < len(params) else flat.numel
+      self.bounds.append((lo, hi))
+    self._pending = [len(g) for g in groups]
+    self._owner = {}
+    for gi, g in enumerate(groups):
+      for pi in g:
+        self._owner[pi] = gi
+    self._works = []
+    self._launched = [False] * len(groups)
+    self.side = torch.cuda.Stream() if self.overlap else None
+    self._hooks = []
+    if self.overlap:
+      for pi, p in enumerate(params):
+        self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(pi)))
+
+  @staticmethod
+  def groups_for_encoder(encoder, flat):
+    """[each recurrent layer's parameters] + [output_proj]: the order backward finishes them is
+    the reverse of this list."""
+    index = {id(p): i for i, p in enumerate(flat.params)}
+    D = encoder.num_dirs
+    groups = []
+    for layer in range(encoder.num_layers):
+      groups.append([index[id(p)] for p in encoder.rnn.layer_weights(layer, D)])
+    if encoder.enable_ctc:
+      groups.append([index[id(encoder.output_proj.weight)], index[id(encoder.output_proj.bias)]])
+    return groups
+
+  def _make_hook(self, pi):
+    def hook(_param):
+      gi = self._owner[pi]
+      self._pending[gi] -= 1
+      if self._pending[gi] == 0:
+        self._launch(gi)
+    return hook
+
+  def _launch(self, gi):
+    if self._launched[gi]:
+      return
+    self._launched[gi] = True
+    lo, hi = self.bounds[gi]
+    buf = self.flat.grad[lo:hi]
+    if self.overlap:
+      self.side.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(self.side):
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+    else:
+      self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+  def __call__(self, status=None):
+    """Finish the exchange; returns the gradient scale (1/world).  Called between backward and
+    the optimiser (train.ctc_step's grad_sync).  `status` (int32[1]) becomes the MIN over ranks:
+    the step is skipped only if every rank's batch was skipped; a rank whose own batch was
+    skipped contributed zero gradients."""
+    for gi in range(len(self.groups)):
+      self._launch(gi)   # anything backward did not reach (or no-overlap mode)
+    if status is not None:
+      if self.overlap:
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+          dist.all_reduce(status, op=dist.ReduceOp.MIN, group=self.pg)
+      else:
+        self._works.append(dist.all_reduce(status, op=dist.ReduceOp.MIN, group=self.pg, async_op=True))
+    if self.overlap:
+      torch.cuda.current_stream().wait_stream(self.side)
+    for w in self._works:
+      w.wait()
+    self._works = []
+    self._pending = [len(g) for g in self.groups]
+    self._launched = [False] * len(self.groups)
+    return 1.0 / self.world
+
+  def broadcast_parameters(self, src=0):
+    """Start every rank from rank `src`'s weights."""
+    dist.broadcast(self.flat.data, src=src, group=self.pg)

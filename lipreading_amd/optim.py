@@ -1,0 +1,99 @@
+"""Flat parameter storage + fused clip/Adam for the reference's optimisation tail
+(`src/train/train_better_model.py:78-80`: clip_grad_norm_ per module, then Adam.step, with
+`torch.optim.Adam(params, lr)` rebuilt every epoch at `src/scripts/train.py:280`).
+
+All parameters of a module become views into ONE contiguous fp32 buffer (and their .grad views
+into one gradient buffer), so the tail of a step is: one sum-of-squares launch, one Adam launch,
+and — under data parallelism — a few large RCCL all-reduces over slices of the gradient buffer
+instead of one per tensor.
+"""
+import torch
+
+from . import _C
+
+_ALIGN = 64  # floats: every parameter starts 256-byte aligned (float4 operand loads need 16 B)
+
+
+class FlatParameters(object):
+  """Re-homes `module`'s parameters (already on the GPU) into one flat buffer."""
+
+  def __init__(self, module):
+    self.params = [p for p in module.parameters()]
+    assert self.params, "module has no parameters"
+    dev = self.params[0].device   # storage only: works on any device (gloo tests run on CPU)
+    self.offsets = []
+    off = 0
+    for p in self.params:
+      assert p.dtype == torch.float32 and p.device == dev
+      self.offsets.append(off)
+      off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+    self.numel = off
+    self.data = torch.zeros(off, dtype=torch.float32, device=dev)
+    self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+    for p, o in zip(self.params, self.offsets):
+      n = p.numel()
+      self.data[o:o + n].copy_(p.data.reshape(-1))
+      p.data = self.data[o:o + n].view(p.shape)
+    self.attach_grads()
+
+  def attach_grads(self):
+    """(Re)point every .grad at its slice of the flat gradient buffer; autograd then
+    accumulates in place (two backward passes per step in the reference, :69 and :74)."""
+    for p, o in zip(self.params, self.offsets):
+      n = p.numel()
+      view = self.grad[o:o + n].view(p.shape)
+      if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+        p.grad = view
+
+  def zero_grad(self):
+    self.grad.zero_()
+    self.attach_grads()
+
+
+class FusedAdam(object):
+  """Adam over a FlatParameters buffer: lr_sumsq (+ optional all-reduce hook) + lr_adam_step."""
+
+  def __init__(self, flat, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+    self.flat = flat
+    self.lr, self.betas, self.eps = float(lr), betas, float(eps)
+    dev = flat.data.device
+    self.exp_avg = torch.zeros_like(flat.data)
+    self.exp_avg_sq = torch.zeros_like(flat.data)
+    self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
+    self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+    self._scratch = torch.zeros(4, dtype=torch.float32, device=dev)
+
+  def zero_grad(self):
+    self.flat.zero_grad()
+
+  def reset(self, lr=None):
+    """What re-creating torch.optim.Adam each epoch does (train.py:280): moments and step
+    count start over."""
+    self.exp_avg.zero_()
+    self.exp_avg_sq.zero_()
+    self.step_count.zero_()
+    if lr is not None:
+      self.lr = float(lr)
+
+  def step(self, grad_norm=None, grad_scale=1.0, skip=None):
+    """grad_norm: max norm for clip_grad_norm_ (None = no clipping); grad_scale: multiplies the
+    gradient first (1/world after an all-reduce sum); skip: int32[1] device flag — non-zero
+    leaves parameters, moments and step count untouched (the reference's `continue`)."""
+    L = _C.lib()
+    f = self.flat
+    st = _C.stream_handle()
+    sumsq = None
+    if grad_norm is not None:
+      self._sumsq.zero_()
+      _C.check(L.lr_sumsq(f.grad.data_ptr(), f.numel, self._sumsq.data_ptr(), st), "lr_sumsq")
+      sumsq = self._sumsq
+    _C.check(L.lr_adam_step(f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),
+                            self.exp_avg_sq.data_ptr(), f.numel, _C.ptr(sumsq),
+                            float(grad_norm) if grad_norm is not None else 0.0, float(grad_scale),
+                            self.lr, self.betas[0], self.betas[1], self.eps,
+                            self.step_count.data_ptr(), _C.ptr(skip), self._scratch.data_ptr(), st),
+             "lr_adam_step")
+
+  def total_norm(self):
+    """sqrt of the last sum of squares (valid after a step with grad_norm)."""
+    return self._sumsq.sqrt()

@@ -80,7 +80,19 @@ def test_ctc_matches_oracle_seeded(dev, B, T, L):
     assert abs(loss.item() - ref.item()) <= tol, (loss.item(), ref.item())
     ref.backward()
     loss.backward()
-    np.testing.assert_allclose(xd.grad.cpu().numpy(), x.grad.numpy(), rtol=2e-4, atol=5e-6)
+    got, want = xd.grad.cpu().numpy(), x.grad.numpy()
+    if T <= 150:
+      np.testing.assert_allclose(got, want, rtol=2e-4, atol=5e-6)
+    else:
+      # nll ~ 1e3 here: exp(lcab + nll - lp) cancels two ~1e3 fp32 numbers, so BOTH fp32
+      # implementations carry ~1e-4 relative noise.  Judge each against an fp64 evaluation of
+      # the oracle and require the HIP path to be no worse than the fp32 CPU path (x2 slack).
+      x64 = lp.double().requires_grad_(True)
+      O.ctc_loss(x64, labels, fl, lens_l, red).backward()
+      truth = x64.grad.numpy()
+      err_hip = np.abs(got - truth).max()
+      err_cpu = np.abs(want - truth).max()
+      assert err_hip <= max(2 * err_cpu, 1e-5), (err_hip, err_cpu)
 
 
 def test_ctc_linearity_in_grad_output(dev):

@@ -1,0 +1,130 @@
+"""GPU parity: fused clip+Adam and the whole encoder+CTC optimisation step."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_oracle as O
+from tests.test_gpu_encoder import hip_encoder_from, make_pair
+from tests.test_oracle_golden import _flatten
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+  assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+  return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("max_norm", [None, 0.5, 1e6])
+def test_fused_adam_matches_torch_adam(dev, max_norm):
+  from lipreading_amd.optim import FlatParameters, FusedAdam
+  torch.manual_seed(0)
+  ref = torch.nn.Sequential(torch.nn.Linear(33, 17), torch.nn.Linear(17, 5))
+  mod = torch.nn.Sequential(torch.nn.Linear(33, 17), torch.nn.Linear(17, 5))
+  mod.load_state_dict(ref.state_dict())
+  mod = mod.to(dev)
+  flat = FlatParameters(mod)
+  opt = FusedAdam(flat, lr=1e-2)
+  ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+  g = torch.Generator().manual_seed(1)
+  for it in range(5):
+    x = torch.randn(8, 33, generator=g)
+    ropt.zero_grad()
+    ref(x).pow(2).sum().backward()
+    if max_norm is not None:
+      torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm)
+    ropt.step()
+    opt.zero_grad()
+    mod(x.to(dev)).pow(2).sum().backward()
+    opt.step(grad_norm=max_norm)
+  for a, b in zip(mod.parameters(), ref.parameters()):
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=2e-5, atol=2e-6)
+  assert int(opt.step_count.item()) == 5
+  # skip flag: nothing moves, the step counter stays (train_better_model.py:49-50 `continue`)
+  before = flat.data.clone()
+  skip = torch.ones(1, dtype=torch.int32, device=dev)
+  opt.step(grad_norm=max_norm, skip=skip)
+  assert torch.equal(before, flat.data) and int(opt.step_count.item()) == 5
+  # grad_scale = 1/world: same as averaging the gradient first
+  opt2 = FusedAdam(flat, lr=1e-2)
+  flat.grad.mul_(4.0)
+  snap = flat.data.clone()
+  opt2.step(grad_norm=None, grad_scale=0.25)
+  flat.grad.div_(4.0)
+  flat.data.copy_(snap)
+  opt3 = FusedAdam(flat, lr=1e-2)
+  snap2 = flat.data.clone()
+  opt3.step()
+  # both started from the same weights with the same effective gradient
+  assert torch.allclose(snap, snap2)
+
+
+@pytest.mark.parametrize("name", ["gru", "lstm"])
+def test_ctc_step_fused_matches_reference_vectors(golden_step, dev, name):
+  """train_better_model.py:31-32,46-48,74,78,80 through ctc_step (FlatParameters + FusedAdam),
+  against the step captured from the reference (clip 5.0, Adam 1e-3)."""
+  from lipreading_amd.optim import FlatParameters, FusedAdam
+  from lipreading_amd.train import ctc_step
+  case = golden_step[name]
+  enc = hip_encoder_from(case, name.upper(), dev).train()
+  opt = FusedAdam(FlatParameters(enc), lr=1e-3)
+  lens = torch.tensor(case["lens"], device=dev)
+  loss, status = ctc_step(enc, opt, torch.tensor(case["frames"], device=dev), lens,
+                          torch.tensor(case["chars"], device=dev),
+                          torch.tensor(case["char_lens"], device=dev), grad_norm=5.0)
+  assert int(status.item()) == 0
+  assert abs(loss.item() - float(case["loss"])) < 1e-4
+  assert abs(float(opt.total_norm()) - float(case["total_norm"])) < 1e-3 * float(case["total_norm"])
+  sd1 = _flatten(case["sd1"])
+  for k, v in enc.state_dict().items():
+    np.testing.assert_allclose(v.cpu().numpy(), sd1[k], rtol=1e-3, atol=2e-5, err_msg=k)
+
+
+def test_training_reduces_loss_and_matches_oracle_trajectory(dev):
+  """20 steps at the BASELINE shape family (reduced B): the HIP loss trajectory tracks the
+  oracle's (same seed, same data) and goes down."""
+  from lipreading_amd.optim import FlatParameters, FusedAdam
+  from lipreading_amd.train import ctc_step
+  import bench
+  ref, enc = make_pair("GRU", 64, 1, True, dev)
+  frames, fl, chars, cl = bench.synth_batch(8, 1)
+  ropt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+  opt = FusedAdam(FlatParameters(enc), lr=1e-3)
+  enc.train(); ref.train()
+  fd, fld, cd, cld = (x.to(dev) for x in (frames, fl, chars, cl))
+  hip, cpu = [], []
+  for _ in range(20):
+    cpu.append(float(O.encoder_ctc_step(ref, ropt, frames, fl, chars, cl, grad_norm=50)))
+    loss, _ = ctc_step(enc, opt, fd, fld, cd, cld, grad_norm=50, max_len=75)
+    hip.append(float(loss))
+  assert hip[-1] < hip[0]
+  np.testing.assert_allclose(hip, cpu, rtol=2e-3)
+  assert abs(hip[0] - cpu[0]) < 1e-4 * max(1.0, cpu[0])
+
+
+def test_train_and_eval_loops(dev):
+  from lipreading_amd.data import default_char2idx, make_collate_fn
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.optim import FlatParameters, FusedAdam
+  from lipreading_amd import train as T
+  c2i = default_char2idx()
+  rng = np.random.RandomState(0)
+  items = []
+  for n in sorted(rng.randint(20, 40, 12)):   # dataset is sorted by length (data_loader.py:93-98)
+    cap = np.r_[1, rng.randint(4, 64, 6), 2]
+    items.append((rng.randn(n, 68, 3).astype(np.float32), cap))
+  collate = make_collate_fn(dev)
+  loader = [collate(items[i:i + 4]) for i in range(0, 12, 4)]
+  torch.manual_seed(0)
+  enc = VideoEncoder(204, 32, rnn_type='GRU', bidirectional=True, enable_ctc=True, vocab_size=64,
+                     char2idx=c2i).to(dev)
+  opt = FusedAdam(FlatParameters(enc), lr=3e-3)
+  first = T.train(enc, None, loader, opt, dev, c2i, grad_norm=50)[1]
+  for _ in range(15):
+    last = T.train(enc, None, loader, opt, dev, c2i, grad_norm=50)[1]
+  assert last < first
+  _, _, _, ev = T.eval(enc, None, loader, dev, c2i)
+  assert np.isfinite(ev) and ev > 0
+  cer = T.greedy_cer(enc, loader, dev, c2i)
+  assert 0.0 <= cer <= 2.0
