@@ -180,10 +180,11 @@ int lr_proj_logsoftmax_backward(const float* g, const float* log_probs, const fl
  *              for t < frame_lens[b], 0 after — torch's ctc_loss backward formula.
  *              grad_weight may be NULL (= 1).  Samples whose nll is inf or whose
  *              grad_weight is 0 get an all-zero gradient.
- *   workspace  lr_ctc_workspace_bytes(B, T, max_label_len) bytes.
+ *   workspace  lr_ctc_workspace_bytes(B, T, C, max_label_len) bytes; lr_ctc_grad must get the
+ *              workspace lr_ctc_nll filled (alpha/beta tables and label chains), unmodified.
  * T is the padded time extent (number of t rows addressed), C = V'+... number of classes,
  * max_label_len <= 256 bounds label_lens (ctc_loss.py:46). */
-size_t lr_ctc_workspace_bytes(int B, int T, int max_label_len);
+size_t lr_ctc_workspace_bytes(int B, int T, int C, int max_label_len);
 
 int lr_ctc_nll(const float* log_probs, int64_t stride_b, int64_t stride_t, const int32_t* labels,
                int label_stride, const int32_t* frame_lens, const int32_t* label_lens, float* nll,

@@ -36,7 +36,7 @@ SIGNATURES = {
     "lr_proj_logsoftmax_forward": (c_int, [P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, P]),
     "lr_proj_logsoftmax_backward": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int,
                                              c_int, P]),
-    "lr_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "lr_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "lr_ctc_nll": (c_int, [P, c_int64, c_int64, P, c_int, P, P, P, P, c_size_t, c_int, c_int,
                             c_int, c_int, P]),
     "lr_ctc_grad": (c_int, [P, c_int64, c_int64, P, c_int, P, P, P, P, P, P, c_size_t, c_int,

@@ -59,3 +59,9 @@ __device__ __forceinline__ float lr_wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// ---- two-stage deterministic column sums (lr_misc.hip) -----------------------------------------
+// stage 1: partial[rs][col] = sum over the rs-th row slice of x[row][col]   (LR_COLSUM_SPLITS slices)
+// stage 2 (caller specific): out[col] = sum_rs partial[rs][col] in fixed order.
+constexpr int LR_COLSUM_SPLITS = 32;
+int lr_colsum_partial(const float* x, int ld, int rows, int ncol, float* partial, hipStream_t stream);

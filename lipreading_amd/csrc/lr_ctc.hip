@@ -6,13 +6,13 @@
 //   src/train/ctc_loss.py:46-114  length filter, equal-length runs, inf fallback, weighting
 //   src/models/lipreader/decoder.py:165-197  GreedyDecoder.process_string / decode
 //
-// Layout: one workgroup per sample.  A sample's lattice is (T x C) fp32 log-probs (19.5 kB at
-// T=75, C=65); its 2L+1 CTC states live one per thread, the previous alpha/beta row is
-// exchanged through a double-buffered LDS row (one s_barrier per time step), and the
-// alpha (later alpha+beta) table goes to the caller's workspace, which stays L2 resident
-// between the two kernels.  The gradient rows are independent once alpha+beta is known, so
-// they are produced by all waves of the workgroup with lanes along the class axis (coalesced
-// stores of the (T x C) gradient).
+// Layout: the recursions run one workgroup per sample.  A sample's lattice is (T x C) fp32
+// log-probs (19.5 kB at T=75, C=65), read ONCE from HBM with coalesced loads into LDS; its 2L+1
+// CTC states live one per thread, alpha and beta advance concurrently on the two halves of the
+// workgroup, the previous row is exchanged through a double-buffered LDS row (one s_barrier per
+// time step) and both tables go to the caller's workspace (L2 resident).  The gradient rows are
+// independent once alpha and beta are known, so they run one wave per (sample, frame) across the
+// whole chip with lanes along the class axis (coalesced stores of the (T x C) gradient).
 #include "lr_common.h"
 
 namespace {
@@ -23,204 +23,215 @@ __host__ __device__ inline int ctc_state_stride(int max_label_len) {
   return ((2 * max_label_len + 1) + 63) / 64 * 64;
 }
 
+// workspace: alpha [B][T][sst] | beta [B][T][sst] | nxt int[B][Lmax] | first int[B][C]
+struct CtcWs {
+  float* alpha;
+  float* beta;
+  int* nxt;
+  int* first;
+};
+__host__ __device__ inline size_t ctc_ws_floats(int B, int T, int C, int max_label_len) {
+  const size_t sst = ctc_state_stride(max_label_len);
+  return 2 * (size_t)B * T * sst + (size_t)B * max_label_len + (size_t)B * C;
+}
+inline CtcWs ctc_ws_carve(void* ws, int B, int T, int C, int max_label_len) {
+  const size_t sst = ctc_state_stride(max_label_len);
+  CtcWs w;
+  w.alpha = (float*)ws;
+  w.beta = w.alpha + (size_t)B * T * sst;
+  w.nxt = (int*)(w.beta + (size_t)B * T * sst);
+  w.first = w.nxt + (size_t)B * max_label_len;
+  return w;
+}
+
 // ---------------------------------------------------------------------------------------
-// alpha pass + nll
+// alpha and beta recursions, concurrently, + nll + label tables
 // ---------------------------------------------------------------------------------------
-__global__ void ctc_alpha_kernel(const float* __restrict__ lp, int64_t stride_b, int64_t stride_t,
-                                 const int32_t* __restrict__ labels, int label_stride,
-                                 const int32_t* __restrict__ frame_lens,
-                                 const int32_t* __restrict__ label_lens, float* __restrict__ nll,
-                                 float* __restrict__ ws_alpha, int T, int C, int sst,
-                                 int max_label_len) {
+// One workgroup per sample.  Threads [0,sst) own the alpha state s = tid, threads [sst,2*sst)
+// the beta state s = tid - sst (when 2*sst fits a workgroup; otherwise the two recursions run
+// one after the other on the same threads).  The sample's (T x C) lattice is staged into LDS
+// once with coalesced loads — the recursions then gather lp[t][l'_s] from LDS instead of paying
+// one global round trip per time step.
+template <bool LATTICE_IN_LDS>
+__global__ void ctc_alpha_beta_kernel(const float* __restrict__ lp, int64_t stride_b,
+                                      int64_t stride_t, const int32_t* __restrict__ labels,
+                                      int label_stride, const int32_t* __restrict__ frame_lens,
+                                      const int32_t* __restrict__ label_lens,
+                                      float* __restrict__ nll, CtcWs ws, int T, int C, int sst,
+                                      int max_label_len, int concurrent) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* row0 = reinterpret_cast<float*>(smem_raw);  // [2][sst]
+  float* rowa = reinterpret_cast<float*>(smem_raw);        // [2][sst] alpha exchange rows
+  float* rowb = rowa + 2 * sst;                            // [2][sst] beta exchange rows
+  int* lab_s = reinterpret_cast<int*>(rowb + 2 * sst);     // [max_label_len]
+  float* lat = reinterpret_cast<float*>(lab_s + max_label_len);  // [T][C] when LATTICE_IN_LDS
+
   const int b = blockIdx.x;
-  const int s = threadIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;
   const int L = label_lens[b];
   int Tb = frame_lens[b];
   if (Tb > T) Tb = T;
   if (L > max_label_len || L < 0 || Tb <= 0) {
     // dropped by lr_ctc_reduce when L > 256; otherwise a caller error: poison the loss.
-    if (s == 0) nll[b] = __builtin_inff();
+    if (tid == 0) nll[b] = __builtin_inff();
     return;
   }
   const int S = 2 * L + 1;
-  const bool live = s < S;
-  const int32_t* lab = labels + (int64_t)b * label_stride;
-  int cls = 0;
-  bool skip_ok = false;  // alpha_t(s) may come from alpha_{t-1}(s-2)
-  if (live && (s & 1)) {
-    cls = lab[s >> 1];
-    if (s >= 3) skip_ok = lab[(s >> 1) - 1] != cls;
-  }
-  // out-of-range class ids would read outside the lattice: clamp and let the caller's
-  // host-side checks reject them.
-  if (cls < 0 || cls >= C) cls = 0;
-  const float* lpb = lp + (int64_t)b * stride_b;
-  float* al = ws_alpha + ((int64_t)b * T) * sst;
-
-  float a = LR_NEG_INF;
-  if (live && s < 2) a = lpb[cls];
-  if (live) al[s] = a;
-  float lp_next = (live && Tb > 1) ? lpb[stride_t + cls] : 0.f;
-  for (int t = 1; t < Tb; ++t) {
-    float* row = row0 + (t & 1) * sst;
-    row[s] = a;
-    const float lp_t = lp_next;
-    if (live && t + 1 < Tb) lp_next = lpb[(int64_t)(t + 1) * stride_t + cls];
-    __syncthreads();
-    if (live) {
-      const float a1 = a;
-      const float a2 = s >= 1 ? row[s - 1] : LR_NEG_INF;
-      const float a3 = skip_ok ? row[s - 2] : LR_NEG_INF;
-      a = lr_lse3(a1, a2, a3) + lp_t;
-      al[(int64_t)t * sst + s] = a;
-    }
-  }
-  float* row = row0 + (Tb & 1) * sst;
-  row[s] = a;
-  __syncthreads();
-  if (s == 0) {
-    const float l1 = row[S - 1];
-    const float l2 = S > 1 ? row[S - 2] : LR_NEG_INF;
-    nll[b] = -lr_lse2(l1, l2);
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// beta pass + gradient
-// ---------------------------------------------------------------------------------------
-__global__ void ctc_beta_grad_kernel(const float* __restrict__ lp, int64_t stride_b,
-                                     int64_t stride_t, const int32_t* __restrict__ labels,
-                                     int label_stride, const int32_t* __restrict__ frame_lens,
-                                     const int32_t* __restrict__ label_lens,
-                                     const float* __restrict__ nll,
-                                     const float* __restrict__ grad_weight,
-                                     float* __restrict__ grad, float* __restrict__ ws_alpha, int T,
-                                     int C, int sst, int max_label_len) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* row0 = reinterpret_cast<float*>(smem_raw);              // [2][sst]
-  int* lab_s = reinterpret_cast<int*>(row0 + 2 * sst);           // [max_label_len]
-  int* nxt_s = lab_s + max_label_len;                            // [max_label_len]
-  int* first_s = nxt_s + max_label_len;                          // [C]
-
-  const int b = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int nthr = blockDim.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int nwave = nthr >> 6;
-  const int L = label_lens[b];
-  int Tb = frame_lens[b];
-  if (Tb > T) Tb = T;
-  const float w = grad_weight ? grad_weight[b] : 1.f;
-  const float nll_b = nll[b];
-  float* gb = grad + (int64_t)b * stride_b;
-
-  const bool dead = (L > max_label_len) || L < 0 || Tb <= 0 || w == 0.f || isinf(nll_b) ||
-                    isnan(nll_b);
-  if (dead) {  // uniform per workgroup
-    for (int t = wave; t < T; t += nwave)
-      for (int c = lane; c < C; c += 64) gb[(int64_t)t * stride_t + c] = 0.f;
-    return;
-  }
-
-  const int S = 2 * L + 1;
   const int32_t* lab = labels + (int64_t)b * label_stride;
   const float* lpb = lp + (int64_t)b * stride_b;
-  float* ab = ws_alpha + ((int64_t)b * T) * sst;
+  float* al = ws.alpha + ((int64_t)b * T) * sst;
+  float* be = ws.beta + ((int64_t)b * T) * sst;
 
-  // ---- label tables: next occurrence chain per class, first occurrence per class --------
+  // ---- stage labels (+ lattice) --------------------------------------------------------------
   for (int i = tid; i < L; i += nthr) {
     int c = lab[i];
-    if (c < 0 || c >= C) c = 0;
+    if (c < 0 || c >= C) c = 0;  // out-of-range ids are rejected by the host; stay in bounds
     lab_s[i] = c;
   }
-  for (int c = tid; c < C; c += nthr) first_s[c] = -1;
+  for (int c = tid; c < C; c += nthr) ws.first[(int64_t)b * C + c] = -1;
+  if (LATTICE_IN_LDS) {
+    const int n = Tb * C;
+    for (int i = tid; i < n; i += nthr) {
+      const int t = i / C, c = i - t * C;
+      lat[i] = lpb[(int64_t)t * stride_t + c];
+    }
+  }
   __syncthreads();
+  // next / first occurrence chains per class (for the gradient kernel)
   for (int i = tid; i < L; i += nthr) {
     const int c = lab_s[i];
     int n = -1;
     for (int j = i + 1; j < L; ++j)
       if (lab_s[j] == c) { n = j; break; }
-    nxt_s[i] = n;
+    ws.nxt[(int64_t)b * max_label_len + i] = n;
     bool first = true;
     for (int j = 0; j < i; ++j)
       if (lab_s[j] == c) { first = false; break; }
-    if (first) first_s[c] = i;
+    if (first) ws.first[(int64_t)b * C + c] = i;
   }
-  __syncthreads();
 
-  // ---- beta recursion, alpha+beta written back over alpha --------------------------------
-  {
-    const int s = tid;
-    const bool live = s < S;
-    int cls = 0;
-    bool skip_ok = false;  // beta_t(s) may come from beta_{t+1}(s+2)
-    if (live && (s & 1)) {
-      cls = lab_s[s >> 1];
-      if (s + 2 < S) skip_ok = lab_s[(s >> 1) + 1] != cls;
+  auto LP = [&](int t, int c) -> float {
+    return LATTICE_IN_LDS ? lat[t * C + c] : lpb[(int64_t)t * stride_t + c];
+  };
+
+  const bool is_beta_half = concurrent && tid >= sst;
+  const int s = is_beta_half ? tid - sst : tid;
+  const bool live = s < S && s < sst;
+  int cls = 0;
+  bool skip_a = false, skip_b = false;
+  if (live && (s & 1)) {
+    cls = lab_s[s >> 1];
+    if (s >= 3) skip_a = lab_s[(s >> 1) - 1] != cls;       // alpha_t(s) <- alpha_{t-1}(s-2)
+    if (s + 2 < S) skip_b = lab_s[(s >> 1) + 1] != cls;    // beta_t(s)  <- beta_{t+1}(s+2)
+  }
+
+  // one pass = the alpha recursion (threads < sst) and, when concurrent, the beta recursion on
+  // the other half at the same time; otherwise a second pass does beta.
+  for (int pass = 0; pass < (concurrent ? 1 : 2); ++pass) {
+    const bool do_beta = concurrent ? is_beta_half : (pass == 1);
+    float* row0 = do_beta ? rowb : rowa;
+    float v = LR_NEG_INF;
+    if (!do_beta) {
+      if (live && s < 2) v = LP(0, cls);
+      if (live) al[s] = v;
+    } else {
+      if (live && s >= S - 2) v = LP(Tb - 1, cls);
+      if (live) be[(int64_t)(Tb - 1) * sst + s] = v;
     }
-    float bt = LR_NEG_INF;
-    if (live && s >= S - 2) bt = lpb[(int64_t)(Tb - 1) * stride_t + cls];
-    if (live) ab[(int64_t)(Tb - 1) * sst + s] += bt;
-    float lp_next = (live && Tb > 1) ? lpb[(int64_t)(Tb - 2) * stride_t + cls] : 0.f;
-    for (int t = Tb - 2; t >= 0; --t) {
-      float* row = row0 + (t & 1) * sst;
-      if (s < sst) row[s] = bt;
-      const float lp_t = lp_next;
-      if (live && t >= 1) lp_next = lpb[(int64_t)(t - 1) * stride_t + cls];
+    for (int i = 1; i < Tb; ++i) {
+      const int t = do_beta ? Tb - 1 - i : i;
+      float* row = row0 + (i & 1) * sst;
+      if (s < sst) row[s] = v;
+      const float lp_t = live ? LP(t, cls) : 0.f;
       __syncthreads();
       if (live) {
-        const float b1 = bt;
-        const float b2 = s + 1 < S ? row[s + 1] : LR_NEG_INF;
-        const float b3 = skip_ok ? row[s + 2] : LR_NEG_INF;
-        bt = lr_lse3(b1, b2, b3) + lp_t;
-        ab[(int64_t)t * sst + s] += bt;
-      }
-    }
-  }
-  __threadfence_block();
-  __syncthreads();
-
-  // ---- gradient rows: lanes along the class axis -----------------------------------------
-  for (int t = wave; t < T; t += nwave) {
-    float* grow = gb + (int64_t)t * stride_t;
-    if (t >= Tb) {
-      for (int c = lane; c < C; c += 64) grow[c] = 0.f;
-      continue;
-    }
-    const float* abr = ab + (int64_t)t * sst;
-    const float* lpr = lpb + (int64_t)t * stride_t;
-    // blank: log-sum-exp over the even states
-    float m = LR_NEG_INF;
-    for (int s = 2 * lane; s < S; s += 128) m = fmaxf(m, abr[s]);
-    m = lr_wave_max(m);
-    float blank_lcab = LR_NEG_INF;
-    if (m != LR_NEG_INF) {
-      float acc = 0.f;
-      for (int s = 2 * lane; s < S; s += 128) acc += expf(abr[s] - m);
-      acc = lr_wave_sum(acc);
-      blank_lcab = logf(acc) + m;
-    }
-    for (int c0 = 0; c0 < C; c0 += 64) {
-      const int c = c0 + lane;
-      if (c < C) {
-        float v;
-        if (c == 0) {
-          v = blank_lcab;
+        if (!do_beta) {
+          const float a2 = s >= 1 ? row[s - 1] : LR_NEG_INF;
+          const float a3 = skip_a ? row[s - 2] : LR_NEG_INF;
+          v = lr_lse3(v, a2, a3) + lp_t;
+          al[(int64_t)t * sst + s] = v;
         } else {
-          v = LR_NEG_INF;
-          int i = first_s[c];
-          if (i >= 0) {
-            v = abr[2 * i + 1];
-            for (i = nxt_s[i]; i >= 0; i = nxt_s[i]) v = lr_lse2(v, abr[2 * i + 1]);
-          }
+          const float b2 = s + 1 < S ? row[s + 1] : LR_NEG_INF;
+          const float b3 = skip_b ? row[s + 2] : LR_NEG_INF;
+          v = lr_lse3(v, b2, b3) + lp_t;
+          be[(int64_t)t * sst + s] = v;
         }
-        const float l = lpr[c];
-        // torch ctc_loss backward: (exp(lp) - exp(lcab + nll - lp)) * grad_out
-        grow[c] = w * (expf(l) - expf(v + nll_b - l));
       }
+    }
+    if (!do_beta) {
+      float* row = row0 + (Tb & 1) * sst;
+      if (s < sst) row[s] = v;
+    }
+    __syncthreads();
+    if (!do_beta && tid == 0) {
+      const float* row = rowa + (Tb & 1) * sst;
+      const float l1 = row[S - 1];
+      const float l2 = S > 1 ? row[S - 2] : LR_NEG_INF;
+      nll[b] = -lr_lse2(l1, l2);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// gradient rows: one wave per (sample, frame), lanes along the class axis
+// ---------------------------------------------------------------------------------------
+__global__ void ctc_grad_rows_kernel(const float* __restrict__ lp, int64_t stride_b,
+                                     int64_t stride_t, const int32_t* __restrict__ frame_lens,
+                                     const int32_t* __restrict__ label_lens,
+                                     const float* __restrict__ nll,
+                                     const float* __restrict__ grad_weight,
+                                     float* __restrict__ grad, CtcWs ws, int T, int C, int sst,
+                                     int max_label_len) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const int L = label_lens[b];
+  int Tb = frame_lens[b];
+  if (Tb > T) Tb = T;
+  const float w = grad_weight ? grad_weight[b] : 1.f;
+  const float nll_b = nll[b];
+  float* grow = grad + (int64_t)b * stride_b + (int64_t)t * stride_t;
+  const bool dead = (L > max_label_len) || L < 0 || Tb <= 0 || w == 0.f || isinf(nll_b) ||
+                    isnan(nll_b);
+  if (dead || t >= Tb) {
+    for (int c = lane; c < C; c += 64) grow[c] = 0.f;
+    return;
+  }
+  const int S = 2 * L + 1;
+  const float* ar = ws.alpha + ((int64_t)b * T + t) * sst;
+  const float* br = ws.beta + ((int64_t)b * T + t) * sst;
+  const float* lpr = lp + (int64_t)b * stride_b + (int64_t)t * stride_t;
+  const int* nxt = ws.nxt + (int64_t)b * max_label_len;
+  const int* first = ws.first + (int64_t)b * C;
+  // blank: log-sum-exp over the even states
+  float m = LR_NEG_INF;
+  for (int s = 2 * lane; s < S; s += 128) m = fmaxf(m, ar[s] + br[s]);
+  m = lr_wave_max(m);
+  float blank_lcab = LR_NEG_INF;
+  if (m != LR_NEG_INF) {
+    float acc = 0.f;
+    for (int s = 2 * lane; s < S; s += 128) acc += expf(ar[s] + br[s] - m);
+    acc = lr_wave_sum(acc);
+    blank_lcab = logf(acc) + m;
+  }
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + lane;
+    if (c < C) {
+      float v;
+      if (c == 0) {
+        v = blank_lcab;
+      } else {
+        v = LR_NEG_INF;
+        int i = first[c];
+        if (i >= 0) {
+          v = ar[2 * i + 1] + br[2 * i + 1];
+          for (i = nxt[i]; i >= 0; i = nxt[i]) v = lr_lse2(v, ar[2 * i + 1] + br[2 * i + 1]);
+        }
+      }
+      const float l = lpr[c];
+      // torch ctc_loss backward: (exp(lp) - exp(lcab + nll - lp)) * grad_out
+      grow[c] = w * (expf(l) - expf(v + nll_b - l));
     }
   }
 }
@@ -403,10 +414,10 @@ __global__ void ctc_greedy_kernel(const float* __restrict__ probs, int64_t strid
 
 }  // namespace
 
-extern "C" size_t lr_ctc_workspace_bytes(int B, int T, int max_label_len) {
-  if (B <= 0 || T <= 0 || max_label_len < 0) return 0;
+extern "C" size_t lr_ctc_workspace_bytes(int B, int T, int C, int max_label_len) {
+  if (B <= 0 || T <= 0 || C <= 0 || max_label_len < 0) return 0;
   if (max_label_len > kMaxLabelLen) max_label_len = kMaxLabelLen;
-  return (size_t)B * T * ctc_state_stride(max_label_len) * sizeof(float);
+  return ctc_ws_floats(B, T, C, max_label_len) * sizeof(float);
 }
 
 extern "C" int lr_ctc_nll(const float* log_probs, int64_t stride_b, int64_t stride_t,
@@ -417,12 +428,22 @@ extern "C" int lr_ctc_nll(const float* log_probs, int64_t stride_b, int64_t stri
   LR_CHECK_ARG(log_probs && labels && frame_lens && label_lens && nll && workspace);
   LR_CHECK_ARG(B > 0 && T > 0 && C > 0 && max_label_len >= 0 && label_stride >= 0);
   if (max_label_len > kMaxLabelLen) max_label_len = kMaxLabelLen;
-  if (workspace_bytes < lr_ctc_workspace_bytes(B, T, max_label_len)) return LR_ERR_WORKSPACE;
+  if (workspace_bytes < lr_ctc_workspace_bytes(B, T, C, max_label_len)) return LR_ERR_WORKSPACE;
   const int sst = ctc_state_stride(max_label_len);
-  const size_t lds = 2 * (size_t)sst * sizeof(float);
-  LR_LAUNCH(ctc_alpha_kernel, dim3(B), dim3(sst), lds, stream, log_probs,
-                     stride_b, stride_t, labels, label_stride, frame_lens, label_lens, nll,
-                     (float*)workspace, T, C, sst, max_label_len);
+  const CtcWs ws = ctc_ws_carve(workspace, B, T, C, max_label_len);
+  const int concurrent = 2 * sst <= 1024 ? 1 : 0;
+  const int nthr = concurrent ? 2 * sst : sst;
+  const size_t base = 4 * (size_t)sst * sizeof(float) + (size_t)max_label_len * sizeof(int);
+  const size_t lat = (size_t)T * C * sizeof(float);
+  if (base + lat <= 60 * 1024) {
+    LR_LAUNCH(ctc_alpha_beta_kernel<true>, dim3(B), dim3(nthr), base + lat, stream, log_probs,
+              stride_b, stride_t, labels, label_stride, frame_lens, label_lens, nll, ws, T, C, sst,
+              max_label_len, concurrent);
+  } else {
+    LR_LAUNCH(ctc_alpha_beta_kernel<false>, dim3(B), dim3(nthr), base, stream, log_probs, stride_b,
+              stride_t, labels, label_stride, frame_lens, label_lens, nll, ws, T, C, sst,
+              max_label_len, concurrent);
+  }
   return lr_launch_status();
 }
 
@@ -434,14 +455,11 @@ extern "C" int lr_ctc_grad(const float* log_probs, int64_t stride_b, int64_t str
   LR_CHECK_ARG(log_probs && labels && frame_lens && label_lens && nll && grad && workspace);
   LR_CHECK_ARG(B > 0 && T > 0 && C > 0 && max_label_len >= 0 && label_stride >= 0);
   if (max_label_len > kMaxLabelLen) max_label_len = kMaxLabelLen;
-  if (workspace_bytes < lr_ctc_workspace_bytes(B, T, max_label_len)) return LR_ERR_WORKSPACE;
+  if (workspace_bytes < lr_ctc_workspace_bytes(B, T, C, max_label_len)) return LR_ERR_WORKSPACE;
   const int sst = ctc_state_stride(max_label_len);
-  const int nthr = sst < 256 ? 256 : sst;
-  const size_t lds = 2 * (size_t)sst * sizeof(float) + 2 * (size_t)(max_label_len + 1) * sizeof(int) +
-                     (size_t)C * sizeof(int);
-  LR_LAUNCH(ctc_beta_grad_kernel, dim3(B), dim3(nthr), lds, stream,
-                     log_probs, stride_b, stride_t, labels, label_stride, frame_lens, label_lens,
-                     nll, grad_weight, grad, (float*)workspace, T, C, sst, max_label_len);
+  const CtcWs ws = ctc_ws_carve(workspace, B, T, C, max_label_len);
+  LR_LAUNCH(ctc_grad_rows_kernel, dim3((T + 3) / 4, B), dim3(256), 0, stream, log_probs, stride_b,
+            stride_t, frame_lens, label_lens, nll, grad_weight, grad, ws, T, C, sst, max_label_len);
   return lr_launch_status();
 }
 

@@ -157,6 +157,24 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// 256 threads = 4 row lanes x 64 columns; blockIdx.y = row slice.
+__global__ void colsum_partial_kernel(const float* __restrict__ x, int ld, int rows, int ncol,
+                                      float* __restrict__ partial) {
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  const int per = (rows + LR_COLSUM_SPLITS - 1) / LR_COLSUM_SPLITS;
+  const int r0 = blockIdx.y * per;
+  const int r1 = min(rows, r0 + per);
+  float s = 0.f;
+  if (col < ncol)
+    for (int r = r0 + rl; r < r1; r += 4) s += x[(int64_t)r * ld + col];
+  part[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && col < ncol)
+    partial[(int64_t)blockIdx.y * ncol + col] = part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl];
+}
+
 inline int grid_for(int64_t n, int block) {
   int64_t g = (n + block - 1) / block;
   if (g > 2048) g = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
@@ -213,5 +231,11 @@ extern "C" int lr_adam_step(float* param, const float* grad, float* exp_avg, flo
   if (st != LR_OK || n == 0) return st;
   LR_LAUNCH(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, param, grad, exp_avg,
             exp_avg_sq, n, (const float*)scratch, beta1, beta2, eps);
+  return lr_launch_status();
+}
+
+int lr_colsum_partial(const float* x, int ld, int rows, int ncol, float* partial, hipStream_t stream) {
+  LR_LAUNCH(colsum_partial_kernel, dim3((ncol + 63) / 64, LR_COLSUM_SPLITS), dim3(256), 0, stream, x,
+            ld, rows, ncol, partial);
   return lr_launch_status();
 }

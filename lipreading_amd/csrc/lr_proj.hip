@@ -80,21 +80,21 @@ __global__ void log_softmax_bwd_rows_kernel(const float* __restrict__ g, const f
   }
 }
 
-// out[c] = sum_r x[r,c]; 4 row lanes x 64 columns per workgroup, fixed order.
-__global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int C) {
-  __shared__ float part[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
+// out[c] = fixed-order sum of the LR_COLSUM_SPLITS partial column sums (lr_colsum_partial).
+__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
   float s = 0.f;
-  if (col < C)
-    for (int r = rl; r < R; r += 4) s += x[(int64_t)r * C + col];
-  part[rl][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (rl == 0 && col < C)
-    out[col] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+  for (int r = 0; r < LR_COLSUM_SPLITS; ++r) s += partial[(int64_t)r * C + c];
+  out[c] = s;
 }
 
 }  // namespace
+
+// workspace head: [C] folded bias (forward) or [LR_COLSUM_SPLITS][C] partial sums (backward)
+static size_t proj_head_bytes(int C) {
+  return lr_align_up((size_t)LR_COLSUM_SPLITS * C * sizeof(float), 256);
+}
 
 extern "C" size_t lr_proj_workspace_bytes(int R, int K, int C) {
   if (R <= 0 || K <= 0 || C <= 0) return 0;
@@ -103,7 +103,7 @@ extern "C" size_t lr_proj_workspace_bytes(int R, int K, int C) {
   size_t c = lr_sgemm_workspace_bytes(R, C, K);  // forward
   size_t m = a > b ? a : b;
   if (c > m) m = c;
-  return m + lr_align_up((size_t)C * sizeof(float), 256);
+  return m + proj_head_bytes(C);
 }
 
 extern "C" int lr_proj_logsoftmax_forward(const float* hidden, const float* W, const float* bias,
@@ -116,8 +116,8 @@ extern "C" int lr_proj_logsoftmax_forward(const float* hidden, const float* W, c
   if (workspace_bytes < lr_proj_workspace_bytes(R, K, C)) return LR_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   float* mb = (float*)workspace;  // [C] bias + log(mask + 1e-45)
-  char* gws = (char*)workspace + lr_align_up((size_t)C * sizeof(float), 256);
-  const size_t gws_bytes = workspace_bytes - lr_align_up((size_t)C * sizeof(float), 256);
+  char* gws = (char*)workspace + proj_head_bytes(C);
+  const size_t gws_bytes = workspace_bytes - proj_head_bytes(C);
   LR_LAUNCH(mask_bias_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, bias, mask, mb, C);
   int st = lr_launch_status();
   if (st != LR_OK) return st;
@@ -138,8 +138,8 @@ extern "C" int lr_proj_logsoftmax_backward(const float* g, const float* log_prob
   if (C > kMaxClasses) return LR_ERR_UNSUPPORTED;
   if (workspace_bytes < lr_proj_workspace_bytes(R, K, C)) return LR_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
-  char* gws = (char*)workspace + lr_align_up((size_t)C * sizeof(float), 256);
-  const size_t gws_bytes = workspace_bytes - lr_align_up((size_t)C * sizeof(float), 256);
+  char* gws = (char*)workspace + proj_head_bytes(C);
+  const size_t gws_bytes = workspace_bytes - proj_head_bytes(C);
   LR_LAUNCH(log_softmax_bwd_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, g, log_probs,
             dlogits, R, C);
   int st = lr_launch_status();
@@ -152,7 +152,9 @@ extern "C" int lr_proj_logsoftmax_backward(const float* g, const float* log_prob
   st = lr_sgemm_impl(1, 0, C, K, R, 1.f, dlogits, C, hidden, K, 0.f, dW, K, nullptr, 0, 0, gws,
                      gws_bytes, stream);
   if (st != LR_OK) return st;
-  LR_LAUNCH(colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, (const float*)dlogits, dbias,
-            R, C);
+  st = lr_colsum_partial(dlogits, C, R, C, (float*)workspace, stream);
+  if (st != LR_OK) return st;
+  LR_LAUNCH(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream,
+            (const float*)workspace, dbias, C);
   return lr_launch_status();
 }

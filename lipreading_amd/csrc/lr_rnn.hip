@@ -49,14 +49,30 @@ struct StepPtrs {
 };
 
 // ---------------------------------------------------------------------------------------------
-// forward step
+// step kernels
 // ---------------------------------------------------------------------------------------------
+// A step is latency-bound, not FLOP-bound: after a kernel boundary every operand comes from the
+// Infinity Cache / remote L2 (~1 us per dependent round trip), so the kernels are written to
+// make exactly ONE round trip: every wave issues all of its float4 operand loads for the
+// product up front (NW waves x UF chunks x (1+G) loads in flight), the 256 epilogue threads
+// issue their gate / length / previous-state loads before the product starts, and only then do
+// the MFMAs, the LDS combine and the stores run.
+constexpr int NW = 8;        // waves per workgroup (512 threads): K is split NW ways
+constexpr int UF_FWD = 6;    // chunks (16 k each) a wave keeps in flight, forward
+constexpr int UF_BWD = 12;   // backward has one accumulator and 2 loads per chunk
+
+#define LR_MFMA4(accv, av, wv)                                                 \
+  accv = __builtin_amdgcn_mfma_f32_16x16x4f32((av).x, (wv).x, accv, 0, 0, 0); \
+  accv = __builtin_amdgcn_mfma_f32_16x16x4f32((av).y, (wv).y, accv, 0, 0, 0); \
+  accv = __builtin_amdgcn_mfma_f32_16x16x4f32((av).z, (wv).z, accv, 0, 0, 0); \
+  accv = __builtin_amdgcn_mfma_f32_16x16x4f32((av).w, (wv).w, accv, 0, 0, 0)
+
 template <int G>
-__global__ __launch_bounds__(256) void rnn_fwd_step_kernel(float* gates, float* extra, float* y,
-                                                           const int32_t* __restrict__ lens,
-                                                           StepPtrs p, int B, int T, int H, int D,
-                                                           int step) {
-  __shared__ float red[4 * G * TILE * RED_LD];
+__global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(float* gates, float* extra, float* y,
+                                                              const int32_t* __restrict__ lens,
+                                                              StepPtrs p, int B, int T, int H, int D,
+                                                              int step) {
+  __shared__ float red[NW * G * TILE * RED_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = blockIdx.z;
   const int t = d == 0 ? step : T - 1 - step;
@@ -64,35 +80,56 @@ __global__ __launch_bounds__(256) void rnn_fwd_step_kernel(float* gates, float* 
   const bool has_prev = tp >= 0 && tp < T;
   const int j0 = blockIdx.x * TILE, b0 = blockIdx.y * TILE;
   const int DH = D * H;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  f32x4 acc[G];
+  // ---- epilogue operands first (threads 0..255 own one (batch row, hidden unit) each) -------
+  const int bl = (tid >> 4) & 15, jl = tid & 15;
+  const int b = b0 + bl, j = j0 + jl;
+  const bool epi = tid < 256 && b < B && j < H;
+  const int64_t bt = (int64_t)b * T + t, btp = (int64_t)b * T + tp;
+  float gx[G];
+  float prev_own = 0.f, bhn = 0.f;
+  int len_b = 0;
+  float* go = gates + (bt * D + d) * (int64_t)(G * H) + j;
+  if (epi) {
+    len_b = lens[b];
 #pragma unroll
-  for (int g = 0; g < G; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < G; ++g) gx[g] = go[g * H];
+    if (G == 3) {
+      bhn = p.b[d][2 * H + j];
+      if (has_prev) prev_own = y[btp * DH + d * H + j];            // h_{t-1}
+    } else {
+      if (has_prev) prev_own = extra[(btp * D + d) * H + j];       // c_{t-1}
+    }
+  }
 
+  // ---- recurrent product: acc[g] (16 batch x 16 units) += h_prev (16 x K) . W_g^T (K x 16) ---
   if (has_prev) {
+    f32x4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int rowi = lane & 15, kq = lane >> 4;
     const int ab = b0 + rowi, wj = j0 + rowi;
     const bool a_ok = ab < B, w_ok = wj < H;
     const float* hrow = y + ((int64_t)ab * T + tp) * DH + d * H;
-    const float* W = p.w[d];
+    const float* W = p.w[d] + (int64_t)wj * H;
     const int nchunk = (H + 15) >> 4;
-    for (int c = wave; c < nchunk; c += 4) {
-      const int k = c * 16 + kq * 4;
-      const bool k_ok = k < H;  // H % 4 == 0
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a_ok && k_ok) a = ld4(hrow + k);
-      float4 w[G];
+    for (int c0 = wave; c0 < nchunk; c0 += NW * UF_FWD) {
+      float4 a[UF_FWD], w[UF_FWD][G];
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        w[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (w_ok && k_ok) w[g] = ld4(W + ((int64_t)g * H + wj) * H + k);
+      for (int u = 0; u < UF_FWD; ++u) {
+        const int k = (c0 + u * NW) * 16 + kq * 4;
+        const bool ok = k < H;   // also false for chunks past the end (H % 4 == 0)
+        a[u] = (a_ok && ok) ? ld4(hrow + k) : zero4;
+#pragma unroll
+        for (int g = 0; g < G; ++g) w[u][g] = (w_ok && ok) ? ld4(W + (int64_t)g * H * H + k) : zero4;
       }
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[g].x, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[g].y, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[g].z, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[g].w, acc[g], 0, 0, 0);
+      for (int u = 0; u < UF_FWD; ++u) {
+        if (c0 + u * NW < nchunk) {
+#pragma unroll
+          for (int g = 0; g < G; ++g) { LR_MFMA4(acc[g], a[u], w[u][g]); }
+        }
       }
     }
     // C/D layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + r
@@ -103,49 +140,40 @@ __global__ __launch_bounds__(256) void rnn_fwd_step_kernel(float* gates, float* 
         red[((wave * G + g) * TILE + kq * 4 + r) * RED_LD + rowi] = acc[g][r];
   }
   __syncthreads();
+  if (!epi) return;
 
-  const int bl = tid >> 4, jl = tid & 15;
-  const int b = b0 + bl, j = j0 + jl;
-  if (b >= B || j >= H) return;
   float s[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     s[g] = 0.f;
     if (has_prev) {
 #pragma unroll
-      for (int w = 0; w < 4; ++w) s[g] += red[((w * G + g) * TILE + bl) * RED_LD + jl];
+      for (int w = 0; w < NW; ++w) s[g] += red[((w * G + g) * TILE + bl) * RED_LD + jl];
     }
   }
-  const bool valid = t < lens[b];
-  const int64_t bt = (int64_t)b * T + t;
   float* yo = y + bt * DH + d * H + j;
   float* eo = extra + (bt * D + d) * H + j;
-  if (!valid) {
+  if (t >= len_b) {  // padded position: zero output, zero carried state
     *yo = 0.f;
     *eo = 0.f;
     return;
   }
-  float* go = gates + (bt * D + d) * (int64_t)(G * H) + j;
-  const int64_t btp = (int64_t)b * T + tp;
   if (G == 3) {
-    const float hn = s[2] + p.b[d][2 * H + j];
-    const float r = lr_sigmoid(go[0] + s[0]);
-    const float z = lr_sigmoid(go[H] + s[1]);
-    const float n = tanhf(go[2 * H] + r * hn);
-    const float hp = has_prev ? y[btp * DH + d * H + j] : 0.f;
-    const float h = (1.f - z) * n + z * hp;
+    const float hn = s[2] + bhn;
+    const float r = lr_sigmoid(gx[0] + s[0]);
+    const float z = lr_sigmoid(gx[1] + s[1]);
+    const float n = tanhf(gx[2] + r * hn);
     go[0] = r;
     go[H] = z;
     go[2 * H] = n;
     *eo = hn;
-    *yo = h;
+    *yo = (1.f - z) * n + z * prev_own;
   } else {
-    const float ig = lr_sigmoid(go[0] + s[0]);
-    const float fg = lr_sigmoid(go[H] + s[1]);
-    const float gg = tanhf(go[2 * H] + s[2]);
-    const float og = lr_sigmoid(go[3 * H] + s[G - 1]);
-    const float cp = has_prev ? extra[(btp * D + d) * H + j] : 0.f;
-    const float c = fg * cp + ig * gg;
+    const float ig = lr_sigmoid(gx[0] + s[0]);
+    const float fg = lr_sigmoid(gx[1] + s[1]);
+    const float gg = tanhf(gx[2] + s[2]);
+    const float og = lr_sigmoid(gx[G - 1] + s[G - 1]);
+    const float c = fg * prev_own + ig * gg;
     go[0] = ig;
     go[H] = fg;
     go[2 * H] = gg;
@@ -155,19 +183,16 @@ __global__ __launch_bounds__(256) void rnn_fwd_step_kernel(float* gates, float* 
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// backward step
-// ---------------------------------------------------------------------------------------------
 // dG has four slots per (b,t,d): GRU [dr_pre, dz_pre, dn_pre, dhn_lin], LSTM [di,df,dg,do]_pre.
 // The recurrent product uses slots (0,1,3) for the GRU (d/d(W_hh h + b_hh)) and (0,1,2,3) for
 // the LSTM; dW_ih / dx use slots (0,1,2) / (0,1,2,3).
 template <int G>
-__global__ __launch_bounds__(256) void rnn_bwd_step_kernel(
+__global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(
     const float* __restrict__ gates, const float* __restrict__ extra, const float* __restrict__ y,
     const float* __restrict__ dy, const float* __restrict__ dh_n, const float* __restrict__ dc_n,
     float* dG, float* dcar, const int32_t* __restrict__ lens, StepPtrs p, int B, int T, int H, int D,
     int step) {
-  __shared__ float red[4 * TILE * RED_LD];
+  __shared__ float red[NW * TILE * RED_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = blockIdx.z;
   const int t = d == 0 ? T - 1 - step : step;   // reverse of the forward order
@@ -177,42 +202,65 @@ __global__ __launch_bounds__(256) void rnn_bwd_step_kernel(
   const bool has_prev = tp >= 0 && tp < T;
   const int j0 = blockIdx.x * TILE, b0 = blockIdx.y * TILE;
   const int DH = D * H, GH = G * H;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // ---- epilogue operands first ----------------------------------------------------------------
+  const int bl = (tid >> 4) & 15, jl = tid & 15;
+  const int b = b0 + bl, j = j0 + jl;
+  const bool epi = tid < 256 && b < B && j < H;
+  const int64_t bt = (int64_t)b * T + t, btn = (int64_t)b * T + tn, btp = (int64_t)b * T + tp;
+  int len_b = 0;
+  float dh = 0.f, car = 0.f, inj_h = 0.f, inj_c = 0.f, gv[4] = {0.f, 0.f, 0.f, 0.f};
+  float ex = 0.f, prev = 0.f;
+  if (epi) {
+    len_b = lens[b];
+    dh = dy[bt * DH + d * H + j];
+    if (has_next) car = dcar[(btn * D + d) * H + j];
+    const float* gi = gates + (bt * D + d) * (int64_t)GH + j;
+#pragma unroll
+    for (int g = 0; g < G; ++g) gv[g] = gi[g * H];
+    ex = extra[(bt * D + d) * H + j];                       // GRU: W_hn h + b_hn ; LSTM: c_t
+    if (has_prev) prev = G == 3 ? y[btp * DH + d * H + j] : extra[(btp * D + d) * H + j];
+    if (dh_n) inj_h = dh_n[((int64_t)d * B + b) * H + j];
+    if (G == 4 && dc_n) inj_c = dc_n[((int64_t)d * B + b) * H + j];
+  }
+
+  // ---- recurrent product: dh[b][j] += sum_{g,k} dG_h[b][tn][g][k] * W_hh[g*H+k][j] -------------
   if (has_next) {
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int rowi = lane & 15, kq = lane >> 4;
     const int ab = b0 + rowi, wj = j0 + rowi;
     const bool a_ok = ab < B, w_ok = wj < H;
     const float* arow = dG + (((int64_t)ab * T + tn) * D + d) * (int64_t)(4 * H);
-    const float* wrow = p.w[d] + (int64_t)wj * GH;  // W_hh^T row = all G*H recurrent inputs of unit wj
+    const float* wrow = p.w[d] + (int64_t)wj * GH;  // W_hh^T row: the G*H recurrent inputs of unit wj
     const int nchunk = (H + 15) >> 4;
     const int total = G * nchunk;
-    for (int f = wave; f < total; f += 4) {
-      const int g = f / nchunk, c = f - g * nchunk;
-      const int slot = (G == 3 && g == 2) ? 3 : g;
-      const int k = c * 16 + kq * 4;
-      const bool k_ok = k < H;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), w = a;
-      if (a_ok && k_ok) a = ld4(arow + slot * H + k);
-      if (w_ok && k_ok) w = ld4(wrow + g * H + k);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
+    for (int f0 = wave; f0 < total; f0 += NW * UF_BWD) {
+      float4 a[UF_BWD], w[UF_BWD];
+#pragma unroll
+      for (int u = 0; u < UF_BWD; ++u) {
+        const int f = f0 + u * NW;
+        const int g = f / nchunk, c = f - g * nchunk;
+        const int slot = (G == 3 && g == 2) ? 3 : g;
+        const int k = c * 16 + kq * 4;
+        const bool ok = f < total && k < H;
+        a[u] = (a_ok && ok) ? ld4(arow + slot * H + k) : zero4;
+        w[u] = (w_ok && ok) ? ld4(wrow + g * H + k) : zero4;
+      }
+#pragma unroll
+      for (int u = 0; u < UF_BWD; ++u) {
+        if (f0 + u * NW < total) { LR_MFMA4(acc, a[u], w[u]); }
+      }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[(wave * TILE + kq * 4 + r) * RED_LD + rowi] = acc[r];
   }
   __syncthreads();
+  if (!epi) return;
 
-  const int bl = tid >> 4, jl = tid & 15;
-  const int b = b0 + bl, j = j0 + jl;
-  if (b >= B || j >= H) return;
-  const int64_t bt = (int64_t)b * T + t;
   float* dgo = dG + (bt * D + d) * (int64_t)(4 * H) + j;
   float* dco = dcar + (bt * D + d) * H + j;
-  const int len = lens[b];
-  if (t >= len) {  // padded position: contributes nothing, carries nothing
+  if (t >= len_b) {  // padded position: contributes nothing, carries nothing
     dgo[0] = 0.f;
     dgo[H] = 0.f;
     dgo[2 * H] = 0.f;
@@ -220,36 +268,26 @@ __global__ __launch_bounds__(256) void rnn_bwd_step_kernel(
     *dco = 0.f;
     return;
   }
-  float dh = dy[bt * DH + d * H + j];
   if (has_next) {
 #pragma unroll
-    for (int w = 0; w < 4; ++w) dh += red[(w * TILE + bl) * RED_LD + jl];
+    for (int w = 0; w < NW; ++w) dh += red[(w * TILE + bl) * RED_LD + jl];
   }
-  const bool is_last = d == 0 ? (t == len - 1) : (t == 0);  // where the final state was read
-  if (is_last && dh_n) dh += dh_n[((int64_t)d * B + b) * H + j];
-  const float* gi = gates + (bt * D + d) * (int64_t)GH + j;
-  const int64_t btn = (int64_t)b * T + tn, btp = (int64_t)b * T + tp;
+  const bool is_last = d == 0 ? (t == len_b - 1) : (t == 0);  // where the final state was read
+  if (is_last) dh += inj_h;
   if (G == 3) {
-    if (has_next) dh += dcar[(btn * D + d) * H + j];  // dh_{t+1} * z_{t+1}
-    const float r = gi[0], z = gi[H], n = gi[2 * H];
-    const float hn = extra[(bt * D + d) * H + j];
-    const float hp = has_prev ? y[btp * DH + d * H + j] : 0.f;
-    const float dn = dh * (1.f - z);
-    const float dz = dh * (hp - n);
-    const float dn_pre = dn * (1.f - n * n);
-    const float dr = dn_pre * hn;
-    dgo[0] = dr * r * (1.f - r);
-    dgo[H] = dz * z * (1.f - z);
+    dh += car;  // dh_{t+1} * z_{t+1}
+    const float r = gv[0], z = gv[1], n = gv[2], hn = ex, hp = prev;
+    const float dn_pre = dh * (1.f - z) * (1.f - n * n);
+    dgo[0] = dn_pre * hn * r * (1.f - r);
+    dgo[H] = dh * (hp - n) * z * (1.f - z);
     dgo[2 * H] = dn_pre;
     dgo[3 * H] = dn_pre * r;
     *dco = dh * z;
   } else {
-    float dc = has_next ? dcar[(btn * D + d) * H + j] : 0.f;  // dc_{t+1} * f_{t+1}
-    if (is_last && dc_n) dc += dc_n[((int64_t)d * B + b) * H + j];
-    const float ig = gi[0], fg = gi[H], gg = gi[2 * H], og = gi[3 * H];
-    const float c = extra[(bt * D + d) * H + j];
-    const float cp = has_prev ? extra[(btp * D + d) * H + j] : 0.f;
-    const float tc = tanhf(c);
+    float dc = car;  // dc_{t+1} * f_{t+1}
+    if (is_last) dc += inj_c;
+    const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3], cp = prev;
+    const float tc = tanhf(ex);
     dc += dh * og * (1.f - tc * tc);
     dgo[0] = dc * gg * ig * (1.f - ig);
     dgo[H] = dc * cp * fg * (1.f - fg);
@@ -308,33 +346,26 @@ __global__ void final_state_kernel(const float* __restrict__ y, const float* __r
   }
 }
 
-// Column sums of dG [rows][D][4][H] scattered into the bias gradients.
-// blockDim = 256 = 4 row lanes x 64 columns; fixed summation order (deterministic).
+// Bias gradients: fixed-order sum of the LR_COLSUM_SPLITS partial column sums of
+// dG [rows][D][4][H] (lr_colsum_partial), scattered into db_ih / db_hh.
 struct BiasPtrs {
   float* db_ih[2];
   float* db_hh[2];
 };
-__global__ void bias_grad_kernel(const float* __restrict__ dG, BiasPtrs p, int rows, int H, int D,
-                                 int G) {
-  __shared__ float part[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
+__global__ void bias_grad_final_kernel(const float* __restrict__ partial, BiasPtrs p, int H, int D,
+                                       int G) {
   const int ncol = D * 4 * H;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncol) return;
   float s = 0.f;
-  if (col < ncol)
-    for (int r = rl; r < rows; r += 4) s += dG[(int64_t)r * ncol + col];
-  part[rl][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (rl == 0 && col < ncol) {
-    s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-    const int d = col / (4 * H), slot = (col / H) & 3, j = col % H;
-    if (G == 4) {
-      p.db_ih[d][slot * H + j] = s;
-      p.db_hh[d][slot * H + j] = s;
-    } else {
-      if (slot < 3) p.db_ih[d][slot * H + j] = s;
-      if (slot != 2) p.db_hh[d][(slot == 3 ? 2 : slot) * H + j] = s;
-    }
+  for (int r = 0; r < LR_COLSUM_SPLITS; ++r) s += partial[(int64_t)r * ncol + col];
+  const int d = col / (4 * H), slot = (col / H) & 3, j = col % H;
+  if (G == 4) {
+    p.db_ih[d][slot * H + j] = s;
+    p.db_hh[d][slot * H + j] = s;
+  } else {
+    if (slot < 3) p.db_ih[d][slot * H + j] = s;
+    if (slot != 2) p.db_hh[d][(slot == 3 ? 2 : slot) * H + j] = s;
   }
 }
 
@@ -350,7 +381,7 @@ Layout reserve_layout(int G, int B, int T, int H, int D) {
   return l;
 }
 struct WsLayout {
-  size_t dG, dcar, wT, gemm, total;  // float offsets
+  size_t dG, dcar, wT, colsum, gemm, total;  // float offsets
   size_t gemm_bytes;
 };
 WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
@@ -358,7 +389,8 @@ WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
   l.dG = 0;
   l.dcar = l.dG + (size_t)B * T * D * 4 * H;
   l.wT = l.dcar + (size_t)B * T * D * H;
-  l.gemm = l.wT + (size_t)D * H * G * H;
+  l.colsum = l.wT + (size_t)D * H * G * H;
+  l.gemm = l.colsum + (size_t)LR_COLSUM_SPLITS * D * 4 * H;
   size_t gb = lr_sgemm_workspace_bytes(G * H, I, B * T);
   size_t g2 = lr_sgemm_workspace_bytes(G * H, H, B * T);
   if (g2 > gb) gb = g2;
@@ -493,8 +525,8 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
   const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, D);
   for (int s = 0; s < T; ++s) {
     if (s == T / 2) prof_begin(0, stream);
-    if (G == 3) LR_LAUNCH(rnn_fwd_step_kernel<3>, grid, dim3(256), 0, stream, gates, extra, y, lens, p, B, T, H, D, s);
-    else LR_LAUNCH(rnn_fwd_step_kernel<4>, grid, dim3(256), 0, stream, gates, extra, y, lens, p, B, T, H, D, s);
+    if (G == 3) LR_LAUNCH(rnn_fwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, lens, p, B, T, H, D, s);
+    else LR_LAUNCH(rnn_fwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, lens, p, B, T, H, D, s);
     if (s == T / 2) prof_end(0, stream);
   }
   int st = lr_launch_status();
@@ -555,8 +587,8 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
   const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, D);
   for (int s = 0; s < T; ++s) {
     if (s == T / 2) prof_begin(1, stream);
-    if (G == 3) LR_LAUNCH(rnn_bwd_step_kernel<3>, grid, dim3(256), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, lens, p, B, T, H, D, s);
-    else LR_LAUNCH(rnn_bwd_step_kernel<4>, grid, dim3(256), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, lens, p, B, T, H, D, s);
+    if (G == 3) LR_LAUNCH(rnn_bwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, lens, p, B, T, H, D, s);
+    else LR_LAUNCH(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, lens, p, B, T, H, D, s);
     if (s == T / 2) prof_end(1, stream);
   }
   st = lr_launch_status();
@@ -596,7 +628,10 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
     bp.db_ih[d] = db_ih[d < D ? d : 0];
     bp.db_hh[d] = db_hh[d < D ? d : 0];
   }
-  LR_LAUNCH(bias_grad_kernel, dim3((D * 4 * H + 63) / 64), dim3(256), 0, stream, (const float*)dG,
-            bp, R, H, D, G);
+  float* partial = wbase + wl.colsum;
+  st = lr_colsum_partial(dG, ldg, R, ldg, partial, stream);
+  if (st != LR_OK) return st;
+  LR_LAUNCH(bias_grad_final_kernel, dim3((ldg + 255) / 256), dim3(256), 0, stream,
+            (const float*)partial, bp, H, D, G);
   return lr_launch_status();
 }

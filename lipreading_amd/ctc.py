@@ -22,7 +22,7 @@ class _CTCLossFunction(torch.autograd.Function):
     L = _C.lib()
     B, T, C = log_probs.shape
     dev = log_probs.device
-    ws_bytes = L.lr_ctc_workspace_bytes(B, T, max_label_len)
+    ws_bytes = L.lr_ctc_workspace_bytes(B, T, C, max_label_len)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     nll = torch.empty(B, dtype=torch.float32, device=dev)
     out = torch.empty(1, dtype=torch.float32, device=dev)
@@ -38,7 +38,6 @@ class _CTCLossFunction(torch.autograd.Function):
              "lr_ctc_reduce")
     ctx.save_for_backward(log_probs, labels_p1, frame_lens, label_lens, nll, gw, ws)
     ctx.max_label_len = max_label_len
-    ctx.ws_is_alpha = True
     ctx.mark_non_differentiable(status, nll)
     return out.reshape(()), status, nll
 
@@ -49,13 +48,6 @@ class _CTCLossFunction(torch.autograd.Function):
     B, T, C = log_probs.shape
     st = _C.stream_handle()
     ml = ctx.max_label_len
-    if not ctx.ws_is_alpha:
-      # a second traversal (retain_graph): the beta pass overwrote alpha, so rebuild it
-      scratch = torch.empty_like(nll)
-      _C.check(L.lr_ctc_nll(log_probs.data_ptr(), log_probs.stride(0), log_probs.stride(1),
-                            labels_p1.data_ptr(), labels_p1.stride(0), frame_lens.data_ptr(),
-                            label_lens.data_ptr(), scratch.data_ptr(), ws.data_ptr(), ws.numel(),
-                            B, T, C, ml, st), "lr_ctc_nll")
     w = gw * grad_out.reshape(()).to(torch.float32)
     grad = torch.empty((B, T, C), dtype=torch.float32, device=log_probs.device)
     # grad is addressed with the same (stride_b, stride_t) as log_probs, so give the kernel a
@@ -65,7 +57,6 @@ class _CTCLossFunction(torch.autograd.Function):
                            labels_p1.stride(0), frame_lens.data_ptr(), label_lens.data_ptr(),
                            nll.data_ptr(), w.data_ptr(), grad.data_ptr(), ws.data_ptr(),
                            ws.numel(), B, T, C, ml, st), "lr_ctc_grad")
-    ctx.ws_is_alpha = False
     return grad, None, None, None, None, None
 
 

@@ -33,8 +33,9 @@ def test_version_and_status_strings():
   assert lib.lr_version() >= 100
   assert lib.lr_status_string(0) == b"ok"
   assert b"workspace" in lib.lr_status_string(-2)
-  assert lib.lr_ctc_workspace_bytes(32, 75, 31) == 32 * 75 * 64 * 4
-  assert lib.lr_ctc_workspace_bytes(1, 10, 300) == 1 * 10 * 576 * 4  # clamped to L<=256
+  assert lib.lr_ctc_workspace_bytes(32, 75, 65, 31) == (2 * 32 * 75 * 64 + 32 * 31 + 32 * 65) * 4
+  # label length clamped to <= 256 (ctc_loss.py:46): 513 states -> stride 576
+  assert lib.lr_ctc_workspace_bytes(1, 10, 65, 300) == (2 * 10 * 576 + 256 + 65) * 4
 
 
 def test_null_arguments_are_rejected_without_a_device():
