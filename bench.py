@@ -92,6 +92,8 @@ def main():
   ap.add_argument("--warmup", type=int, default=5)
   ap.add_argument("--model", choices=sorted(MODELS), default="gru256")
   ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
+  ap.add_argument("--no-graph", action="store_true",
+                  help="launch every kernel eagerly instead of replaying a captured hipGraph")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-budget", type=float, default=20.0)
   args = ap.parse_args()
@@ -125,17 +127,51 @@ def main():
                      enable_ctc=True, vocab_size=VOCAB, char2idx=default_char2idx()).to(dev).train()
   flat = FlatParameters(enc)
   opt = FusedAdam(flat, lr=1e-4)
+  use_graph = not args.no_graph
   sync = None
   if world > 1:
     from lipreading_amd.distributed import GradSync
-    sync = GradSync(flat, groups=GradSync.groups_for_encoder(enc, flat))
+    # eager: all-reduce each bucket from its autograd hook, overlapped with the rest of backward.
+    # graph: forward+backward replay as one hipGraph, the exchange follows it (hooks do not fire
+    # on replay, and no collective is ever captured).
+    sync = GradSync(flat, groups=GradSync.groups_for_encoder(enc, flat), overlap=not use_graph)
     sync.broadcast_parameters(0)
   # every rank gets its own shard of the global batch (weak scaling: B per GPU)
   frames, frame_lens, chars, char_lens = synth_batch(B, 123456 + rank, dev)
+  labels, label_lens = chars[:, 1:], char_lens - 1
+
+  def fwd_bwd():
+    # train_better_model.py:46-48,67,74 — everything up to and including backward
+    from lipreading_amd.ctc import ctc_loss_with_status
+    opt.zero_grad()
+    log_probs, _, _ = enc(frames, frame_lens, max_len=T_FRAMES)
+    loss, status, _ = ctc_loss_with_status(log_probs, labels, frame_lens, label_lens, 'mean')
+    loss.backward()
+    return loss.detach(), status
+
+  graph = None
+  if use_graph:
+    # one hipGraph for the ~400 launches of forward+backward: the T-step recurrent chains are
+    # launch-bound from Python (MI355X_MICROARCH.md: eager goes host-bound below ~3 us/kernel)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      for _ in range(2):
+        fwd_bwd()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+      g_loss, g_status = fwd_bwd()
 
   def step():
-    return ctc_step(enc, opt, frames, frame_lens, chars, char_lens, grad_norm=50, max_len=T_FRAMES,
-                    grad_sync=sync)
+    if graph is not None:
+      graph.replay()
+      loss, status = g_loss, g_status
+    else:
+      loss, status = fwd_bwd()
+    scale = sync(status) if sync is not None else 1.0          # RCCL all-reduce of the flat grads
+    opt.step(grad_norm=50, grad_scale=scale, skip=status)      # :78 clip + :80 Adam
+    return loss, status
 
   def fence():
     if world > 1:
@@ -146,12 +182,19 @@ def main():
   for _ in range(args.warmup):
     loss, status = step()
   fence()
-  _C.check(L.lr_profile_enable(1), "lr_profile_enable")
   t0 = time.perf_counter()
   for _ in range(args.steps):
     loss, status = step()
   fence()
   elapsed = time.perf_counter() - t0
+
+  # roofline leg (after the timed region, same process, same tensors): the same steps issued
+  # eagerly with one step-kernel launch per layer call stamped by a hipEvent pair on its stream
+  # (a hipGraph replay does not re-run the host code that records events).
+  _C.check(L.lr_profile_enable(1), "lr_profile_enable")
+  for _ in range(min(args.steps, 20)):
+    fwd_bwd()
+  torch.cuda.synchronize()
   L.lr_profile_enable(0)
 
   el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -197,7 +240,8 @@ def main():
                                "pixel regime (B,75,3,96,96)+conv3d has no reference and is not built"
                                % (B, layers, rnn_type, H, D * H),
                    "model": args.model, "per_gpu_batch": B, "global_batch": world * B,
-                   "seq_len": T_FRAMES, "parallelism": "dp%d" % world},
+                   "seq_len": T_FRAMES, "parallelism": "dp%d" % world,
+                   "launch": "hipGraph replay of forward+backward" if use_graph else "eager"},
         "final_loss": round(loss_v, 6), "skipped_last": status_v,
         "roofline": roofline,
     }

@@ -138,8 +138,9 @@ int lr_rnn_layer_backward(int mode, const float* x, const int32_t* lens,
                           lr_stream_t stream);
 
 /* Instrumentation for the roofline leg of bench.py (the only entry points that touch the host
- * clock).  While enabled, every lr_rnn_layer_forward / _backward call brackets ONE of its step
- * launches (the middle one) with a hipEvent pair recorded on the stream the kernel runs on.
+ * clock).  While enabled, every lr_rnn_layer_forward / _backward call issues ONE of its step
+ * launches (the middle one) with a hipEvent pair that stamps that dispatch's begin and end on
+ * the stream the kernel runs on.
  * lr_profile_read(which: 0 = forward step kernel, 1 = backward step kernel) WAITS for the
  * recorded events, returns the summed elapsed milliseconds and the number of samples in HOST
  * memory, and clears the ring (2048 samples per kind; later samples are dropped). */

@@ -33,6 +33,13 @@ static inline size_t lr_align_up(size_t x, size_t a) { return (x + a - 1) / a * 
 
 #define LR_NEG_INF (-__builtin_inff())
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it
+// waits for every outstanding GLOBAL store of the wave; inside a T-step recursion that streams
+// its rows out to HBM that wait (~1 us) would sit on the critical path of every step.
+__device__ __forceinline__ void lr_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // log(exp(a)+exp(b)+exp(c)) with the -inf convention of torch's CTC kernels
 // (aten/native/LossCTC.cpp: lamax == -inf -> 0).
 __device__ __forceinline__ float lr_lse3(float a, float b, float c) {

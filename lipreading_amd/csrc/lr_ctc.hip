@@ -142,7 +142,7 @@ __global__ void ctc_alpha_beta_kernel(const float* __restrict__ lp, int64_t stri
       float* row = row0 + (i & 1) * sst;
       if (s < sst) row[s] = v;
       const float lp_t = live ? LP(t, cls) : 0.f;
-      __syncthreads();
+      lr_lds_barrier();   // LDS only: the alpha/beta rows streaming out to HBM stay in flight
       if (live) {
         if (!do_beta) {
           const float a2 = s >= 1 ? row[s - 1] : LR_NEG_INF;

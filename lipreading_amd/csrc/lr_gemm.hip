@@ -34,6 +34,7 @@ struct GemmArgs {
   int row_shift, period;  // B-row remap along K (transB == 0 only)
   int k_chunk;            // K range per blockIdx.z (multiple of BK)
   float* slabs;           // split-K partial sums [splits][M][N] or nullptr
+  bool vecA, vecB;        // operand base + leading dimension allow 16-byte loads
 };
 
 template <int BM, int BN, bool TA, bool TB>
@@ -57,64 +58,86 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
   const int kbeg = blockIdx.z * g.k_chunk;
   const int kend = min(g.K, kbeg + g.k_chunk);
 
-  // per-thread staging registers: BM*BK/256 floats of A, BN*BK/256 floats of B
-  constexpr int A_PER = BM * BK / 256;
-  constexpr int B_PER = BN * BK / 256;
-  float ra[A_PER], rb[B_PER];
+  // per-thread staging registers: BM*BK/1024 float4 of A, BN*BK/1024 float4 of B
+  constexpr int A_V4 = BM * BK / 1024;
+  constexpr int B_V4 = BN * BK / 1024;
+  float4 ra[A_V4], rb[B_V4];
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // ---- global -> registers ------------------------------------------------------------------
-  // K-contiguous operand (TA == false): element e -> row = e / BK, k = e % BK   (lanes along k)
-  // M-contiguous operand (TA == true):  element e -> k = e / BM,  row = e % BM  (lanes along m)
+  // ---- global -> registers: every thread moves float4s along the operand's contiguous axis ----
+  // K-contiguous operand: float4 e -> row = e / (BK/4), k = 4*(e % (BK/4))   (4 lanes per row)
+  // M-contiguous operand: float4 e -> k = e / (BM/4),  row = 4*(e % (BM/4))  (lanes along m)
+  // `vec` = base pointer and leading dimension 16-byte aligned; otherwise (and at ragged
+  // edges) the four elements are fetched one by one with bounds checks.
+  auto fetch4 = [&](const float* base, int64_t ld, bool contig_is_minor, int major, int minor,
+                    int major_lim, int minor_lim, bool vec) -> float4 {
+    // element (major, minor + i) at base[major*ld + minor + i]
+    (void)contig_is_minor;
+    if (major >= major_lim) return zero4;
+    const float* ptr = base + (int64_t)major * ld + minor;
+    if (vec && minor + 3 < minor_lim) return *reinterpret_cast<const float4*>(ptr);
+    float4 v = zero4;
+    if (minor < minor_lim) v.x = ptr[0];
+    if (minor + 1 < minor_lim) v.y = ptr[1];
+    if (minor + 2 < minor_lim) v.z = ptr[2];
+    if (minor + 3 < minor_lim) v.w = ptr[3];
+    return v;
+  };
+  const bool vecA = g.vecA, vecB = g.vecB;
   auto load_a = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
+    for (int i = 0; i < A_V4; ++i) {
       const int e = tid + i * 256;
-      int row, k;
-      if (TA) { k = e / BM; row = e % BM; } else { row = e / BK; k = e % BK; }
-      const int gm = m0 + row, gk = k0 + k;
-      float v = 0.f;
-      if (gm < g.M && gk < kend)
-        v = TA ? g.A[(int64_t)gk * g.lda + gm] : g.A[(int64_t)gm * g.lda + gk];
-      ra[i] = v;
+      if (TA) {  // stored [K][M]: major = k, minor = m
+        const int k = e / (BM / 4), row = 4 * (e % (BM / 4));
+        ra[i] = fetch4(g.A, g.lda, true, k0 + k, m0 + row, kend, g.M, vecA);
+      } else {   // stored [M][K]: major = m, minor = k
+        const int row = e / (BK / 4), k = 4 * (e % (BK / 4));
+        ra[i] = fetch4(g.A, g.lda, true, m0 + row, k0 + k, g.M, kend, vecA);
+      }
     }
   };
   auto load_b = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i) {
+    for (int i = 0; i < B_V4; ++i) {
       const int e = tid + i * 256;
-      int col, k;
-      if (TB) { col = e / BK; k = e % BK; } else { k = e / BN; col = e % BN; }
-      const int gn = n0 + col, gk = k0 + k;
-      float v = 0.f;
-      if (gn < g.N && gk < kend) {
-        if (TB) {
-          v = g.B[(int64_t)gn * g.ldb + gk];
-        } else {
-          int64_t src = gk;
-          bool ok = true;
-          if (g.period > 0) {
-            const int t = gk % g.period + g.row_shift;
-            ok = t >= 0 && t < g.period;
-            src = (int64_t)gk + g.row_shift;
-          }
-          if (ok) v = g.B[src * g.ldb + gn];
+      if (TB) {  // stored [N][K]: major = n, minor = k
+        const int col = e / (BK / 4), k = 4 * (e % (BK / 4));
+        rb[i] = fetch4(g.B, g.ldb, true, n0 + col, k0 + k, g.N, kend, vecB);
+      } else {   // stored [K][N]: major = k (with the optional row remap), minor = n
+        const int k = e / (BN / 4), col = 4 * (e % (BN / 4));
+        const int gk = k0 + k;
+        int src = gk;
+        bool ok = gk < kend;
+        if (ok && g.period > 0) {
+          const int t = gk % g.period + g.row_shift;
+          ok = t >= 0 && t < g.period;
+          src = gk + g.row_shift;
         }
+        rb[i] = ok ? fetch4(g.B, g.ldb, true, src, n0 + col, 1 << 30, g.N, vecB) : zero4;
       }
-      rb[i] = v;
     }
   };
   auto store_tiles = [&]() {
 #pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
+    for (int i = 0; i < A_V4; ++i) {
       const int e = tid + i * 256;
-      if (TA) As[(e / BM) * LDA_S + (e % BM)] = ra[i];
-      else As[(e / BK) * LDA_S + (e % BK)] = ra[i];
+      if (TA) {
+        *reinterpret_cast<float4*>(&As[(e / (BM / 4)) * LDA_S + 4 * (e % (BM / 4))]) = ra[i];
+      } else {
+        float* dst = &As[(e / (BK / 4)) * LDA_S + 4 * (e % (BK / 4))];
+        dst[0] = ra[i].x; dst[1] = ra[i].y; dst[2] = ra[i].z; dst[3] = ra[i].w;
+      }
     }
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i) {
+    for (int i = 0; i < B_V4; ++i) {
       const int e = tid + i * 256;
-      if (TB) Bs[(e / BK) * LDB_S + (e % BK)] = rb[i];
-      else Bs[(e / BN) * LDB_S + (e % BN)] = rb[i];
+      if (TB) {
+        float* dst = &Bs[(e / (BK / 4)) * LDB_S + 4 * (e % (BK / 4))];
+        dst[0] = rb[i].x; dst[1] = rb[i].y; dst[2] = rb[i].z; dst[3] = rb[i].w;
+      } else {
+        *reinterpret_cast<float4*>(&Bs[(e / (BN / 4)) * LDB_S + 4 * (e % (BN / 4))]) = rb[i];
+      }
     }
   };
 
@@ -223,7 +246,8 @@ struct GemmPlan {
 GemmPlan plan_gemm(int M, int N, int K, size_t ws_bytes) {
   GemmPlan p;
   const long tiles_big = (long)((M + 127) / 128) * ((N + 127) / 128);
-  p.big = tiles_big >= 192;  // enough 128x128 tiles to fill 256 CUs
+  p.big = tiles_big >= 48;   // 128x128 tiles (4 MFMA tiles per wave) unless the output is tiny;
+                             // split-K below tops the grid up to the CU count
   const int bm = p.big ? 128 : 64;
   const long tiles = (long)((M + bm - 1) / bm) * ((N + bm - 1) / bm);
   p.splits = 1;
@@ -262,6 +286,8 @@ int lr_sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, cons
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.alpha = alpha; g.beta = beta;
   g.row_shift = row_shift; g.period = period;
+  g.vecA = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0;
+  g.vecB = (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0;
   const GemmPlan p = plan_gemm(M, N, K, workspace ? workspace_bytes : 0);
   g.k_chunk = p.k_chunk;
   g.slabs = p.splits > 1 ? (float*)workspace : nullptr;
