@@ -44,10 +44,19 @@ constexpr int RED_LD = 17;    // padded row of the cross-wave reduction buffer
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// Fragment-major ("packed") operands.  An MFMA 16x16x4 f32 operand fragment for 16 rows x 16 k
+// is 64 lanes x float4: lane l holds row (l & 15), k = 4*(l >> 4) + {0,1,2,3}.  Storing operands
+// in exactly that order makes every operand load of the recurrence ONE fully coalesced 1 KiB
+// read per wave instruction (instead of 16 row segments of 64 B whose row stride H*4 B lands on a
+// quarter of the memory channels):
+//   Wp  [unit tile][gate][chunk][64 lanes][4]     packed once per call from W_hh
+//   hp  [parity][dir][batch tile][chunk][64][4]   written by each step's epilogue for the next
+// Rows/k past B or H are zero (hp is memset per call, Wp is zero-filled by the pack kernel).
 struct StepPtrs {
-  const float* w[2];   // per direction: W_hh [G*H][H]  (forward)  or W_hh^T [H][G*H] (backward)
+  const float* w[2];   // per direction: packed W_hh (forward) / packed W_hh^T (backward)
   const float* b[2];   // per direction: b_hh [G*H]
 };
+constexpr int FRAG = 256;  // floats per 16x16 operand fragment
 
 // ---------------------------------------------------------------------------------------------
 // step kernels
@@ -70,6 +79,7 @@ constexpr int UF_BWD = 12;   // backward has one accumulator and 2 loads per chu
 
 template <int G>
 __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(float* gates, float* extra, float* y,
+                                                              float* hp,
                                                               const int32_t* __restrict__ lens,
                                                               StepPtrs p, int B, int T, int H, int D,
                                                               int step) {
@@ -110,20 +120,20 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(float* gates, flo
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int rowi = lane & 15, kq = lane >> 4;
-    const int ab = b0 + rowi, wj = j0 + rowi;
-    const bool a_ok = ab < B, w_ok = wj < H;
-    const float* hrow = y + ((int64_t)ab * T + tp) * DH + d * H;
-    const float* W = p.w[d] + (int64_t)wj * H;
     const int nchunk = (H + 15) >> 4;
+    const int nbt = gridDim.y;
+    // previous step's packed state: parity (step-1)&1
+    const float* hsrc = hp + ((((int64_t)((step + 1) & 1) * D + d) * nbt + blockIdx.y) * nchunk) * FRAG + lane * 4;
+    const float* wsrc = p.w[d] + ((int64_t)blockIdx.x * G * nchunk) * FRAG + lane * 4;
     for (int c0 = wave; c0 < nchunk; c0 += NW * UF_FWD) {
       float4 a[UF_FWD], w[UF_FWD][G];
 #pragma unroll
       for (int u = 0; u < UF_FWD; ++u) {
-        const int k = (c0 + u * NW) * 16 + kq * 4;
-        const bool ok = k < H;   // also false for chunks past the end (H % 4 == 0)
-        a[u] = (a_ok && ok) ? ld4(hrow + k) : zero4;
+        const int c = c0 + u * NW;
+        const bool ok = c < nchunk;
+        a[u] = ok ? ld4(hsrc + (int64_t)c * FRAG) : zero4;
 #pragma unroll
-        for (int g = 0; g < G; ++g) w[u][g] = (w_ok && ok) ? ld4(W + (int64_t)g * H * H + k) : zero4;
+        for (int g = 0; g < G; ++g) w[u][g] = ok ? ld4(wsrc + ((int64_t)g * nchunk + c) * FRAG) : zero4;
       }
 #pragma unroll
       for (int u = 0; u < UF_FWD; ++u) {
@@ -154,9 +164,14 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(float* gates, flo
   }
   float* yo = y + bt * DH + d * H + j;
   float* eo = extra + (bt * D + d) * H + j;
+  // this step's packed state for the next launch: fragment (batch tile, chunk = unit tile),
+  // lane = row + 16*(k/4), element k%4
+  float* ho = hp + ((((int64_t)(step & 1) * D + d) * gridDim.y + blockIdx.y) * ((H + 15) >> 4) + blockIdx.x) * FRAG +
+              (bl + 16 * (jl >> 2)) * 4 + (jl & 3);
   if (t >= len_b) {  // padded position: zero output, zero carried state
     *yo = 0.f;
     *eo = 0.f;
+    *ho = 0.f;
     return;
   }
   if (G == 3) {
@@ -164,11 +179,13 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(float* gates, flo
     const float r = lr_sigmoid(gx[0] + s[0]);
     const float z = lr_sigmoid(gx[1] + s[1]);
     const float n = tanhf(gx[2] + r * hn);
+    const float h = (1.f - z) * n + z * prev_own;
     go[0] = r;
     go[H] = z;
     go[2 * H] = n;
     *eo = hn;
-    *yo = (1.f - z) * n + z * prev_own;
+    *yo = h;
+    *ho = h;
   } else {
     const float ig = lr_sigmoid(gx[0] + s[0]);
     const float fg = lr_sigmoid(gx[1] + s[1]);
@@ -179,8 +196,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(float* gates, flo
     go[H] = fg;
     go[2 * H] = gg;
     go[3 * H] = og;
+    const float h = og * tanhf(c);
     *eo = c;
-    *yo = og * tanhf(c);
+    *yo = h;
+    *ho = h;
   }
 }
 
@@ -191,8 +210,8 @@ template <int G>
 __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(
     const float* __restrict__ gates, const float* __restrict__ extra, const float* __restrict__ y,
     const float* __restrict__ dy, const float* __restrict__ dh_n, const float* __restrict__ dc_n,
-    float* dG, float* dcar, const int32_t* __restrict__ lens, StepPtrs p, int B, int T, int H, int D,
-    int step) {
+    float* dG, float* dcar, float* dgp, const int32_t* __restrict__ lens, StepPtrs p, int B, int T,
+    int H, int D, int step) {
   __shared__ float red[NW * TILE * RED_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = blockIdx.z;
@@ -230,23 +249,18 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(
   if (has_next) {
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int rowi = lane & 15, kq = lane >> 4;
-    const int ab = b0 + rowi, wj = j0 + rowi;
-    const bool a_ok = ab < B, w_ok = wj < H;
-    const float* arow = dG + (((int64_t)ab * T + tn) * D + d) * (int64_t)(4 * H);
-    const float* wrow = p.w[d] + (int64_t)wj * GH;  // W_hh^T row: the G*H recurrent inputs of unit wj
     const int nchunk = (H + 15) >> 4;
-    const int total = G * nchunk;
+    const int total = G * nchunk;   // K = (gate, k) in fragments of 16
+    const float* asrc = dgp + ((((int64_t)((step + 1) & 1) * D + d) * gridDim.y + blockIdx.y) * total) * FRAG + lane * 4;
+    const float* wsrc = p.w[d] + ((int64_t)blockIdx.x * total) * FRAG + lane * 4;
     for (int f0 = wave; f0 < total; f0 += NW * UF_BWD) {
       float4 a[UF_BWD], w[UF_BWD];
 #pragma unroll
       for (int u = 0; u < UF_BWD; ++u) {
         const int f = f0 + u * NW;
-        const int g = f / nchunk, c = f - g * nchunk;
-        const int slot = (G == 3 && g == 2) ? 3 : g;
-        const int k = c * 16 + kq * 4;
-        const bool ok = f < total && k < H;
-        a[u] = (a_ok && ok) ? ld4(arow + slot * H + k) : zero4;
-        w[u] = (w_ok && ok) ? ld4(wrow + g * H + k) : zero4;
+        const bool ok = f < total;
+        a[u] = ok ? ld4(asrc + (int64_t)f * FRAG) : zero4;
+        w[u] = ok ? ld4(wsrc + (int64_t)f * FRAG) : zero4;
       }
 #pragma unroll
       for (int u = 0; u < UF_BWD; ++u) {
@@ -261,12 +275,19 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(
 
   float* dgo = dG + (bt * D + d) * (int64_t)(4 * H) + j;
   float* dco = dcar + (bt * D + d) * H + j;
+  // packed copy of d/d(W_hh h + b_hh) for the next launch's product: fragment f = g*nchunk + chunk
+  const int nchunk_e = (H + 15) >> 4;
+  float* po = dgp + ((((int64_t)(step & 1) * D + d) * gridDim.y + blockIdx.y) * (G * nchunk_e) + blockIdx.x) * FRAG +
+              (bl + 16 * (jl >> 2)) * 4 + (jl & 3);
+  const int64_t pstride = (int64_t)nchunk_e * FRAG;  // gate g -> + g * pstride
   if (t >= len_b) {  // padded position: contributes nothing, carries nothing
     dgo[0] = 0.f;
     dgo[H] = 0.f;
     dgo[2 * H] = 0.f;
     dgo[3 * H] = 0.f;
     *dco = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) po[g * pstride] = 0.f;
     return;
   }
   if (has_next) {
@@ -279,22 +300,35 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(
     dh += car;  // dh_{t+1} * z_{t+1}
     const float r = gv[0], z = gv[1], n = gv[2], hn = ex, hp = prev;
     const float dn_pre = dh * (1.f - z) * (1.f - n * n);
-    dgo[0] = dn_pre * hn * r * (1.f - r);
-    dgo[H] = dh * (hp - n) * z * (1.f - z);
+    const float dr_pre = dn_pre * hn * r * (1.f - r);
+    const float dz_pre = dh * (hp - n) * z * (1.f - z);
+    dgo[0] = dr_pre;
+    dgo[H] = dz_pre;
     dgo[2 * H] = dn_pre;
     dgo[3 * H] = dn_pre * r;
     *dco = dh * z;
+    po[0] = dr_pre;
+    po[pstride] = dz_pre;
+    po[2 * pstride] = dn_pre * r;   // recurrent path of the n gate: d/d(W_hn h + b_hn)
   } else {
     float dc = car;  // dc_{t+1} * f_{t+1}
     if (is_last) dc += inj_c;
     const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3], cp = prev;
     const float tc = tanhf(ex);
     dc += dh * og * (1.f - tc * tc);
-    dgo[0] = dc * gg * ig * (1.f - ig);
-    dgo[H] = dc * cp * fg * (1.f - fg);
-    dgo[2 * H] = dc * ig * (1.f - gg * gg);
-    dgo[3 * H] = dh * tc * og * (1.f - og);
+    const float di = dc * gg * ig * (1.f - ig);
+    const float df = dc * cp * fg * (1.f - fg);
+    const float dg_ = dc * ig * (1.f - gg * gg);
+    const float do_ = dh * tc * og * (1.f - og);
+    dgo[0] = di;
+    dgo[H] = df;
+    dgo[2 * H] = dg_;
+    dgo[3 * H] = do_;
     *dco = dc * fg;
+    po[0] = di;
+    po[pstride] = df;
+    po[2 * pstride] = dg_;
+    po[(G - 1) * pstride] = do_;
   }
 }
 
@@ -312,20 +346,28 @@ __global__ void fold_bias_kernel(const float* __restrict__ b_ih, const float* __
   out[i] = v;
 }
 
-// out[c][r] = in[r][c]  (rows x cols) -> (cols x rows)
-__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
-                                 int cols) {
-  __shared__ float tile[32][33];
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  for (int i = ty; i < 32; i += 8) {
-    const int r = r0 + i, c = c0 + tx;
-    tile[i][tx] = (r < rows && c < cols) ? in[(int64_t)r * cols + c] : 0.f;
-  }
-  __syncthreads();
-  for (int i = ty; i < 32; i += 8) {
-    const int c = c0 + i, r = r0 + tx;
-    if (r < rows && c < cols) out[(int64_t)c * rows + r] = tile[tx][i];
+// W_hh [G*H][H] -> fragment-major operand for the FORWARD product (rows = hidden units, K = h):
+//   out[((jt*G + g)*nchunk + c)*256 + l*4 + q] = W_hh[g*H + jt*16 + (l&15)][c*16 + 4*(l>>4) + q]
+// and for the BACKWARD product (rows = hidden units j, K = (gate, k) recurrent outputs):
+//   out[((jt*G + g)*nchunk + c)*256 + l*4 + q] = W_hh[g*H + c*16 + 4*(l>>4) + q][jt*16 + (l&15)]
+// zero where the unit or k index is >= H.
+__global__ void pack_w_kernel(const float* __restrict__ W, float* __restrict__ out, int G, int H,
+                              int transposed) {
+  const int nchunk = (H + 15) >> 4;
+  const int64_t total = (int64_t)nchunk * G * nchunk * FRAG;  // unit tiles == chunks
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i & 3), l = (int)((i >> 2) & 63);
+    int64_t r = i >> 8;
+    const int c = (int)(r % nchunk);
+    r /= nchunk;
+    const int g = (int)(r % G);
+    const int jt = (int)(r / G);
+    const int unit = jt * 16 + (l & 15), k = c * 16 + 4 * (l >> 4) + q;
+    float v = 0.f;
+    if (unit < H && k < H)
+      v = transposed ? W[((int64_t)g * H + k) * H + unit] : W[((int64_t)g * H + unit) * H + k];
+    out[i] = v;
   }
 }
 
@@ -371,26 +413,36 @@ __global__ void bias_grad_final_kernel(const float* __restrict__ partial, BiasPt
 }
 
 struct Layout {
-  size_t gates, extra, bias, total;  // float offsets / total floats
+  size_t gates, extra, bias, wp, hp, total;  // float offsets / total floats
+  size_t wp_per_dir, hp_floats;
 };
 Layout reserve_layout(int G, int B, int T, int H, int D) {
   Layout l;
+  const size_t nchunk = (H + 15) / 16, nbt = (B + 15) / 16;
   l.gates = 0;
   l.extra = l.gates + (size_t)B * T * D * G * H;
   l.bias = l.extra + (size_t)B * T * D * H;
-  l.total = l.bias + (size_t)D * G * H;
+  l.wp = (l.bias + (size_t)D * G * H + 63) / 64 * 64;       // 256-byte aligned
+  l.wp_per_dir = nchunk * G * nchunk * FRAG;
+  l.hp = l.wp + (size_t)D * l.wp_per_dir;
+  l.hp_floats = 2 * (size_t)D * nbt * nchunk * FRAG;
+  l.total = l.hp + l.hp_floats;
   return l;
 }
 struct WsLayout {
-  size_t dG, dcar, wT, colsum, gemm, total;  // float offsets
-  size_t gemm_bytes;
+  size_t dG, dcar, wT, dgp, colsum, gemm, total;  // float offsets
+  size_t gemm_bytes, wp_per_dir, dgp_floats;
 };
 WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
   WsLayout l;
+  const size_t nchunk = (H + 15) / 16, nbt = (B + 15) / 16;
   l.dG = 0;
   l.dcar = l.dG + (size_t)B * T * D * 4 * H;
-  l.wT = l.dcar + (size_t)B * T * D * H;
-  l.colsum = l.wT + (size_t)D * H * G * H;
+  l.wT = (l.dcar + (size_t)B * T * D * H + 63) / 64 * 64;   // packed W_hh^T, 256-byte aligned
+  l.wp_per_dir = nchunk * G * nchunk * FRAG;
+  l.dgp = l.wT + (size_t)D * l.wp_per_dir;                  // packed dG_h, two parities
+  l.dgp_floats = 2 * (size_t)D * nbt * G * nchunk * FRAG;
+  l.colsum = l.dgp + l.dgp_floats;
   l.gemm = l.colsum + (size_t)LR_COLSUM_SPLITS * D * 4 * H;
   size_t gb = lr_sgemm_workspace_bytes(G * H, I, B * T);
   size_t g2 = lr_sgemm_workspace_bytes(G * H, H, B * T);
@@ -517,22 +569,31 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
     if (st != LR_OK) return st;
   }
   StepPtrs p;
-  for (int d = 0; d < 2; ++d) {
-    p.w[d] = w_hh[d < D ? d : 0];
-    p.b[d] = b_hh[d < D ? d : 0];
+  float* wp = base + l.wp;
+  float* hp = base + l.hp;
+  for (int d = 0; d < D; ++d) {
+    float* out = wp + (size_t)d * l.wp_per_dir;
+    int blocks = (int)((l.wp_per_dir + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    LR_LAUNCH(pack_w_kernel, dim3(blocks), dim3(256), 0, stream, w_hh[d], out, G, H, 0);
+    p.w[d] = out;
+    p.b[d] = b_hh[d];
   }
+  if (D == 1) { p.w[1] = p.w[0]; p.b[1] = p.b[0]; }
+  lr_clear_error();
+  if (hipMemsetAsync(hp, 0, l.hp_floats * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
   const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, D);
   for (int s = 0; s < T; ++s) {
     hipEvent_t e0, e1;
     if (s == T / 2 && prof_next(0, &e0, &e1)) {
       // sampled launch: the events carry the dispatch's own begin/end timestamps
       lr_clear_error();
-      if (G == 3) hipExtLaunchKernelGGL(rnn_fwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, lens, p, B, T, H, D, s);
-      else hipExtLaunchKernelGGL(rnn_fwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, lens, p, B, T, H, D, s);
+      if (G == 3) hipExtLaunchKernelGGL(rnn_fwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, hp, lens, p, B, T, H, D, s);
+      else hipExtLaunchKernelGGL(rnn_fwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, hp, lens, p, B, T, H, D, s);
       continue;
     }
-    if (G == 3) LR_LAUNCH(rnn_fwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, lens, p, B, T, H, D, s);
-    else LR_LAUNCH(rnn_fwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, lens, p, B, T, H, D, s);
+    if (G == 3) LR_LAUNCH(rnn_fwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, D, s);
+    else LR_LAUNCH(rnn_fwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, D, s);
   }
   int st = lr_launch_status();
   if (st != LR_OK) return st;
@@ -578,28 +639,31 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
   const int GH = G * H;
 
   StepPtrs p;
+  float* dgp = wbase + wl.dgp;
   for (int d = 0; d < D; ++d) {
-    float* out = wT + (size_t)d * H * GH;
-    LR_LAUNCH(transpose_kernel, dim3((H + 31) / 32, (GH + 31) / 32), dim3(256), 0, stream, w_hh[d],
-              out, GH, H);
+    float* out = wT + (size_t)d * wl.wp_per_dir;
+    int blocks = (int)((wl.wp_per_dir + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    LR_LAUNCH(pack_w_kernel, dim3(blocks), dim3(256), 0, stream, w_hh[d], out, G, H, 1);
     p.w[d] = out;
     p.b[d] = nullptr;
   }
   if (D == 1) { p.w[1] = p.w[0]; p.b[1] = nullptr; }
   int st = lr_launch_status();
   if (st != LR_OK) return st;
+  if (hipMemsetAsync(dgp, 0, wl.dgp_floats * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
 
   const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, D);
   for (int s = 0; s < T; ++s) {
     hipEvent_t e0, e1;
     if (s == T / 2 && prof_next(1, &e0, &e1)) {
       lr_clear_error();
-      if (G == 3) hipExtLaunchKernelGGL(rnn_bwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n, dc_n, dG, dcar, lens, p, B, T, H, D, s);
-      else hipExtLaunchKernelGGL(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n, dc_n, dG, dcar, lens, p, B, T, H, D, s);
+      if (G == 3) hipExtLaunchKernelGGL(rnn_bwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
+      else hipExtLaunchKernelGGL(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
       continue;
     }
-    if (G == 3) LR_LAUNCH(rnn_bwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, lens, p, B, T, H, D, s);
-    else LR_LAUNCH(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, lens, p, B, T, H, D, s);
+    if (G == 3) LR_LAUNCH(rnn_bwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
+    else LR_LAUNCH(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
   }
   st = lr_launch_status();
   if (st != LR_OK) return st;
