@@ -217,11 +217,21 @@ def main():
     flops_per_launch = 2.0 * B * D * G * H * H    # (B x H)·(H x G*H) per direction
     dom = max((k for k in prof if prof[k]), key=lambda k: prof[k], default=None)
     roofline = None
+    traffic, traffic_src = None, None
+    try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+      with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        pmc = json.load(f)
+      if dom and B == 32:
+        traffic = pmc[args.model][dom]["traffic_bytes"]
+        traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction)"
+    except Exception:
+      pass
     if dom:
       us = prof[dom]
       ach = bytes_per_launch / (us * 1e-6) / 1e9
       roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                  "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                  "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                  "traffic_source": traffic_src,
                   "avg_launch_us": round(us, 3),
                   "algorithmic_bytes_per_launch": bytes_per_launch,
                   "launches_per_step": 2 * T_FRAMES * layers,
