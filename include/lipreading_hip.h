@@ -125,7 +125,9 @@ int lr_rnn_layer_forward(int mode, const float* x, const int32_t* lens,
 /* Backward of the layer above.
  *   dy [B,T,D*H]; dh_n, dc_n [D,B,H] (may be NULL = zero)
  *   dx [B,T,I] (may be NULL when the input needs no gradient: layer 0)
- *   dw_ih/dw_hh/db_ih/db_hh: HOST arrays of D device pointers, OVERWRITTEN with the grads.
+ *   dw_ih/dw_hh/db_ih/db_hh: HOST arrays of D device pointers; overwritten with the grads, or
+ *   (accumulate != 0) added to — the reference step runs two backward passes over the same
+ *   encoder graph and lets the gradients accumulate (train_better_model.py:69,74).
  *   workspace: lr_rnn_workspace_bytes. */
 int lr_rnn_layer_backward(int mode, const float* x, const int32_t* lens,
                           const float* const* w_ih_host, const float* const* w_hh_host,
@@ -134,7 +136,7 @@ int lr_rnn_layer_backward(int mode, const float* x, const int32_t* lens,
                           float* dx, float* const* dw_ih_host, float* const* dw_hh_host,
                           float* const* db_ih_host, float* const* db_hh_host,
                           const void* reserve, size_t reserve_bytes, void* workspace,
-                          size_t workspace_bytes, int B, int T, int I, int H, int D,
+                          size_t workspace_bytes, int accumulate, int B, int T, int I, int H, int D,
                           lr_stream_t stream);
 
 /* Instrumentation for the roofline leg of bench.py (the only entry points that touch the host
@@ -160,11 +162,12 @@ int lr_proj_logsoftmax_forward(const float* hidden, const float* W, const float*
 
 /* dlogits[r,c] = g[r,c] - exp(log_probs[r,c]) * sum_c g[r,c]; then
  * dhidden = dlogits @ W, dW = dlogits^T @ hidden, dbias = colsum(dlogits).
- *   dlogits [R,C] is caller scratch (also an output).  dhidden may be NULL. */
+ *   dlogits [R,C] is caller scratch (also an output).  dhidden may be NULL.
+ *   accumulate != 0: dW and dbias are added to instead of overwritten. */
 int lr_proj_logsoftmax_backward(const float* g, const float* log_probs, const float* hidden,
                                 const float* W, float* dlogits, float* dhidden, float* dW,
-                                float* dbias, void* workspace, size_t workspace_bytes, int R, int K,
-                                int C, lr_stream_t stream);
+                                float* dbias, void* workspace, size_t workspace_bytes, int accumulate,
+                                int R, int K, int C, lr_stream_t stream);
 
 /* ---- A4: CTC loss — src/train/ctc_loss.py:28-114 ---------------------------------------- */
 

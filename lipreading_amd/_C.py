@@ -29,12 +29,13 @@ SIGNATURES = {
     "lr_rnn_layer_forward": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int,
                                       c_int, c_int, c_int, P]),
     "lr_rnn_layer_backward": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
-                                       c_size_t, P, c_size_t, c_int, c_int, c_int, c_int, c_int, P]),
+                                       c_size_t, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       P]),
     "lr_profile_enable": (c_int, [c_int]),
     "lr_profile_read": (c_int, [c_int, P, P]),
     "lr_proj_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "lr_proj_logsoftmax_forward": (c_int, [P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, P]),
-    "lr_proj_logsoftmax_backward": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int,
+    "lr_proj_logsoftmax_backward": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int, c_int,
                                              c_int, P]),
     "lr_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "lr_ctc_nll": (c_int, [P, c_int64, c_int64, P, c_int, P, P, P, P, c_size_t, c_int, c_int,

@@ -81,12 +81,13 @@ __global__ void log_softmax_bwd_rows_kernel(const float* __restrict__ g, const f
 }
 
 // out[c] = fixed-order sum of the LR_COLSUM_SPLITS partial column sums (lr_colsum_partial).
-__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int C) {
+__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int C,
+                                    int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float s = 0.f;
   for (int r = 0; r < LR_COLSUM_SPLITS; ++r) s += partial[(int64_t)r * C + c];
-  out[c] = s;
+  out[c] = accumulate ? out[c] + s : s;
 }
 
 }  // namespace
@@ -131,8 +132,8 @@ extern "C" int lr_proj_logsoftmax_forward(const float* hidden, const float* W, c
 extern "C" int lr_proj_logsoftmax_backward(const float* g, const float* log_probs,
                                            const float* hidden, const float* W, float* dlogits,
                                            float* dhidden, float* dW, float* dbias, void* workspace,
-                                           size_t workspace_bytes, int R, int K, int C,
-                                           lr_stream_t stream_) {
+                                           size_t workspace_bytes, int accumulate, int R, int K,
+                                           int C, lr_stream_t stream_) {
   LR_CHECK_ARG(g && log_probs && hidden && W && dlogits && dW && dbias && workspace);
   LR_CHECK_ARG(R > 0 && K > 0 && C > 0);
   if (C > kMaxClasses) return LR_ERR_UNSUPPORTED;
@@ -149,12 +150,12 @@ extern "C" int lr_proj_logsoftmax_backward(const float* g, const float* log_prob
                        gws_bytes, stream);
     if (st != LR_OK) return st;
   }
-  st = lr_sgemm_impl(1, 0, C, K, R, 1.f, dlogits, C, hidden, K, 0.f, dW, K, nullptr, 0, 0, gws,
+  st = lr_sgemm_impl(1, 0, C, K, R, 1.f, dlogits, C, hidden, K, accumulate ? 1.f : 0.f, dW, K, nullptr, 0, 0, gws,
                      gws_bytes, stream);
   if (st != LR_OK) return st;
   st = lr_colsum_partial(dlogits, C, R, C, (float*)workspace, stream);
   if (st != LR_OK) return st;
   LR_LAUNCH(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream,
-            (const float*)workspace, dbias, C);
+            (const float*)workspace, dbias, C, accumulate);
   return lr_launch_status();
 }

@@ -69,7 +69,8 @@ constexpr int FRAG = 256;  // floats per 16x16 operand fragment
 // the MFMAs, the LDS combine and the stores run.
 constexpr int NW = 8;        // waves per workgroup (512 threads): K is split NW ways
 constexpr int UF_FWD = 6;    // chunks (16 k each) a wave keeps in flight, forward
-constexpr int UF_BWD = 12;   // backward has one accumulator and 2 loads per chunk
+constexpr int UF_BWD_GRU = 12;   // backward has one accumulator and 2 loads per fragment:
+constexpr int UF_BWD_LSTM = 24;  // K = G*H is 4x longer than forward's, keep a whole share in flight
 
 #define LR_MFMA4(accv, av, wv)                                                 \
   accv = __builtin_amdgcn_mfma_f32_16x16x4f32((av).x, (wv).x, accv, 0, 0, 0); \
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(
   }
 
   // ---- recurrent product: dh[b][j] += sum_{g,k} dG_h[b][tn][g][k] * W_hh[g*H+k][j] -------------
+  constexpr int UF_BWD = G == 4 ? UF_BWD_LSTM : UF_BWD_GRU;
   if (has_next) {
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int rowi = lane & 15, kq = lane >> 4;
@@ -396,20 +398,24 @@ struct BiasPtrs {
   float* db_hh[2];
 };
 __global__ void bias_grad_final_kernel(const float* __restrict__ partial, BiasPtrs p, int H, int D,
-                                       int G) {
+                                       int G, int accumulate) {
   const int ncol = D * 4 * H;
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= ncol) return;
   float s = 0.f;
   for (int r = 0; r < LR_COLSUM_SPLITS; ++r) s += partial[(int64_t)r * ncol + col];
   const int d = col / (4 * H), slot = (col / H) & 3, j = col % H;
+  float* ih = nullptr;
+  float* hh = nullptr;
   if (G == 4) {
-    p.db_ih[d][slot * H + j] = s;
-    p.db_hh[d][slot * H + j] = s;
+    ih = p.db_ih[d] + slot * H + j;
+    hh = p.db_hh[d] + slot * H + j;
   } else {
-    if (slot < 3) p.db_ih[d][slot * H + j] = s;
-    if (slot != 2) p.db_hh[d][(slot == 3 ? 2 : slot) * H + j] = s;
+    if (slot < 3) ih = p.db_ih[d] + slot * H + j;
+    if (slot != 2) hh = p.db_hh[d] + (slot == 3 ? 2 : slot) * H + j;
   }
+  if (ih) *ih = accumulate ? *ih + s : s;
+  if (hh) *hh = accumulate ? *hh + s : s;
 }
 
 struct Layout {
@@ -612,10 +618,11 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
                                      const float* dc_n, float* dx, float* const* dw_ih,
                                      float* const* dw_hh, float* const* db_ih, float* const* db_hh,
                                      const void* reserve, size_t reserve_bytes, void* workspace,
-                                     size_t workspace_bytes, int B, int T, int I, int H, int D,
-                                     lr_stream_t stream_) {
+                                     size_t workspace_bytes, int accumulate, int B, int T, int I,
+                                     int H, int D, lr_stream_t stream_) {
   LR_CHECK_ARG(dims_ok(mode, B, T, I, H, D));
   LR_CHECK_ARG(x && lens && w_ih && w_hh && y && dy && reserve && workspace);
+  const float wbeta = accumulate ? 1.f : 0.f;
   LR_CHECK_ARG(dw_ih && dw_hh && db_ih && db_hh);
   if (H % 4 != 0) return LR_ERR_UNSUPPORTED;
   const int G = mode == LR_RNN_GRU ? 3 : 4;
@@ -673,21 +680,21 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
   for (int d = 0; d < D; ++d) {
     const float* dGd = dG + (size_t)d * 4 * H;
     // dW_ih[d] (G*H x I) = dGx^T (slots 0..G-1 are contiguous rows) @ x
-    st = lr_sgemm_impl(1, 0, GH, I, R, 1.f, dGd, ldg, x, I, 0.f, dw_ih[d], I, nullptr, 0, 0, gws,
+    st = lr_sgemm_impl(1, 0, GH, I, R, 1.f, dGd, ldg, x, I, wbeta, dw_ih[d], I, nullptr, 0, 0, gws,
                        wl.gemm_bytes, stream);
     if (st != LR_OK) return st;
     // dW_hh[d] = dGh^T @ h_prev, h_prev[b,t] = y[b,t-1] (forward dir) / y[b,t+1] (reverse dir)
     const float* yd = y + (size_t)d * H;
     const int shift = d == 0 ? -1 : 1;
     if (G == 3) {
-      st = lr_sgemm_impl(1, 0, 2 * H, H, R, 1.f, dGd, ldg, yd, D * H, 0.f, dw_hh[d], H, nullptr,
+      st = lr_sgemm_impl(1, 0, 2 * H, H, R, 1.f, dGd, ldg, yd, D * H, wbeta, dw_hh[d], H, nullptr,
                          shift, T, gws, wl.gemm_bytes, stream);
       if (st != LR_OK) return st;
-      st = lr_sgemm_impl(1, 0, H, H, R, 1.f, dGd + 3 * H, ldg, yd, D * H, 0.f,
+      st = lr_sgemm_impl(1, 0, H, H, R, 1.f, dGd + 3 * H, ldg, yd, D * H, wbeta,
                          dw_hh[d] + (size_t)2 * H * H, H, nullptr, shift, T, gws, wl.gemm_bytes,
                          stream);
     } else {
-      st = lr_sgemm_impl(1, 0, GH, H, R, 1.f, dGd, ldg, yd, D * H, 0.f, dw_hh[d], H, nullptr, shift,
+      st = lr_sgemm_impl(1, 0, GH, H, R, 1.f, dGd, ldg, yd, D * H, wbeta, dw_hh[d], H, nullptr, shift,
                          T, gws, wl.gemm_bytes, stream);
     }
     if (st != LR_OK) return st;
@@ -706,6 +713,6 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
   st = lr_colsum_partial(dG, ldg, R, ldg, partial, stream);
   if (st != LR_OK) return st;
   LR_LAUNCH(bias_grad_final_kernel, dim3((ldg + 255) / 256), dim3(256), 0, stream,
-            (const float*)partial, bp, H, D, G);
+            (const float*)partial, bp, H, D, G, accumulate);
   return lr_launch_status();
 }

@@ -61,6 +61,18 @@ class GradSync(object):
     if self.overlap:
       for pi, p in enumerate(params):
         self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(pi)))
+      # gradients written in place by the HIP backward kernels bypass AccumulateGrad
+      from . import encoder as _encoder
+      index = {id(p): i for i, p in enumerate(params)}
+      per_param = [self._make_hook(i) for i in range(len(params))]
+
+      def direct_hook(ready):
+        for p in ready:
+          i = index.get(id(p))
+          if i is not None:
+            per_param[i](p)
+      self._direct_hook = direct_hook
+      _encoder.grad_ready_hooks.append(direct_hook)
 
   @staticmethod
   def groups_for_encoder(encoder, flat):

@@ -29,6 +29,29 @@ def _ptr_array(tensors):
   return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+# Callables invoked with the list of parameters whose .grad was just written IN PLACE by a
+# backward kernel (see _direct_grads).  distributed.GradSync registers here, because autograd's
+# own post-accumulate hooks do not fire for gradients that never pass through AccumulateGrad.
+grad_ready_hooks = []
+
+
+def _direct_grads(weights):
+  """Weight gradients can be accumulated straight into existing .grad buffers (the flat
+  gradient buffer of optim.FlatParameters) when every weight already has a dense fp32 .grad:
+  the GEMMs then run with beta = 1 and no AccumulateGrad add kernels are launched."""
+  for w in weights:
+    g = w.grad
+    if (g is None or not w.is_leaf or g.dtype != torch.float32 or not g.is_contiguous()
+        or g.shape != w.shape or g.device != w.device):
+      return False
+  return True
+
+
+def _notify(weights):
+  for hook in grad_ready_hooks:
+    hook(list(weights))
+
+
 class _RNNLayerFunction(torch.autograd.Function):
   """One (bi)directional layer: lr_rnn_layer_forward / lr_rnn_layer_backward."""
 
@@ -70,7 +93,8 @@ class _RNNLayerFunction(torch.autograd.Function):
     dy = dy.contiguous() if dy is not None else torch.zeros_like(y)
     dh_n = dh_n.contiguous() if dh_n is not None else None
     dc_n = dc_n.contiguous() if (mode == 1 and dc_n is not None) else None
-    grads = [torch.empty_like(w) for w in weights]
+    direct = _direct_grads(weights)
+    grads = [w.grad for w in weights] if direct else [torch.empty_like(w) for w in weights]
     dx = torch.empty_like(x) if need_dx else None
     wbytes = L.lr_rnn_workspace_bytes(mode, B, T, I, H, D)
     ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
@@ -78,8 +102,11 @@ class _RNNLayerFunction(torch.autograd.Function):
         mode, x.data_ptr(), lens.data_ptr(), _ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(b_ih),
         _ptr_array(b_hh), y.data_ptr(), dy.data_ptr(), _C.ptr(dh_n), _C.ptr(dc_n), _C.ptr(dx),
         _ptr_array(grads[0::4]), _ptr_array(grads[1::4]), _ptr_array(grads[2::4]),
-        _ptr_array(grads[3::4]), reserve.data_ptr(), reserve.numel(), ws.data_ptr(), wbytes, B, T,
-        I, H, D, _C.stream_handle()), "lr_rnn_layer_backward")
+        _ptr_array(grads[3::4]), reserve.data_ptr(), reserve.numel(), ws.data_ptr(), wbytes,
+        1 if direct else 0, B, T, I, H, D, _C.stream_handle()), "lr_rnn_layer_backward")
+    if direct:
+      _notify(weights)
+      return (dx, None, None, None, None) + (None,) * len(weights)
     return (dx, None, None, None, None) + tuple(grads)
 
 
@@ -98,12 +125,12 @@ class _ProjLogSoftmaxFunction(torch.autograd.Function):
     _C.check(L.lr_proj_logsoftmax_forward(hidden.data_ptr(), weight.data_ptr(), bias.data_ptr(),
                                           mask.data_ptr(), lp.data_ptr(), ws.data_ptr(), wbytes, R,
                                           K, C, _C.stream_handle()), "lr_proj_logsoftmax_forward")
-    ctx.save_for_backward(hidden, weight, lp)
+    ctx.save_for_backward(hidden, weight, lp, bias)
     return lp
 
   @staticmethod
   def backward(ctx, g):
-    hidden, weight, lp = ctx.saved_tensors
+    hidden, weight, lp, bias = ctx.saved_tensors
     L = _C.lib()
     B, T, K = hidden.shape
     C = weight.shape[0]
@@ -112,14 +139,19 @@ class _ProjLogSoftmaxFunction(torch.autograd.Function):
     g = g.contiguous()
     dlogits = torch.empty((R, C), dtype=torch.float32, device=dev)
     dhidden = torch.empty_like(hidden) if ctx.needs_input_grad[0] else None
-    dW = torch.empty_like(weight)
-    db = torch.empty((C,), dtype=torch.float32, device=dev)
+    direct = _direct_grads((weight, bias))
+    dW = weight.grad if direct else torch.empty_like(weight)
+    db = bias.grad if direct else torch.empty((C,), dtype=torch.float32, device=dev)
     wbytes = L.lr_proj_workspace_bytes(R, K, C)
     ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
     _C.check(L.lr_proj_logsoftmax_backward(g.data_ptr(), lp.data_ptr(), hidden.data_ptr(),
                                            weight.data_ptr(), dlogits.data_ptr(), _C.ptr(dhidden),
-                                           dW.data_ptr(), db.data_ptr(), ws.data_ptr(), wbytes, R, K,
-                                           C, _C.stream_handle()), "lr_proj_logsoftmax_backward")
+                                           dW.data_ptr(), db.data_ptr(), ws.data_ptr(), wbytes,
+                                           1 if direct else 0, R, K, C, _C.stream_handle()),
+             "lr_proj_logsoftmax_backward")
+    if direct:
+      _notify((weight, bias))
+      return dhidden, None, None, None
     return dhidden, dW, db, None
 
 

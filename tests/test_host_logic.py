@@ -53,3 +53,39 @@ def test_wer_cer_edit_distance():
   assert d.wer("a b c", "a x c") == 1
   assert d.cer("", "abc") == 3
   assert O.edit_distance("kitten", "sitting") == 3
+
+
+def test_checkpoint_round_trip_with_reference_format(tmp_path):
+  """N4: `best_encoder.pth` is a plain state_dict (better_model.py:114-122) that the reference
+  restores by name and shape (src/scripts/train.py:95-119).  A checkpoint written by the
+  reference-shaped oracle module loads into the HIP-backed module and vice versa."""
+  from lipreading_amd.encoder import VideoEncoder
+  torch.manual_seed(7)
+  ref = O.OracleVideoEncoder(204, 12, rnn_type="LSTM", num_layers=2, bidirectional=True,
+                             enable_ctc=True, vocab_size=64, char2idx=O.default_char2idx())
+  path = tmp_path / "weights" / "best_encoder.pth"
+  path.parent.mkdir()
+  torch.save(ref.state_dict(), str(path))
+  enc = VideoEncoder(204, 12, rnn_type="LSTM", num_layers=2, bidirectional=True, enable_ctc=True,
+                     vocab_size=64, char2idx=default_char2idx())
+  # the reference's restore(): copy every entry whose name and shape match
+  own = enc.state_dict()
+  loaded = torch.load(str(path))
+  matched = 0
+  for name, param in loaded.items():
+    assert name in own and own[name].shape == param.shape, name
+    own[name].copy_(param)
+    matched += 1
+  assert matched == len(own) == 18
+  for k, v in enc.state_dict().items():
+    assert torch.equal(v, ref.state_dict()[k])
+  # and back: save_best_model writes a file the reference-shaped module loads strictly
+  enc.best_error = 1
+  out = tmp_path / "weights2" / "best_encoder.pth"
+  enc.save_best_model(0.5, str(out))
+  assert enc.best_error == 0.5
+  enc.save_best_model(0.9, str(out))       # worse error: not overwritten, best_error kept
+  assert enc.best_error == 0.5
+  ref2 = O.OracleVideoEncoder(204, 12, rnn_type="LSTM", num_layers=2, bidirectional=True,
+                              enable_ctc=True, vocab_size=64, char2idx=O.default_char2idx())
+  ref2.load_state_dict(torch.load(str(out)), strict=True)
