@@ -128,3 +128,27 @@ def test_train_and_eval_loops(dev):
   assert np.isfinite(ev) and ev > 0
   cer = T.greedy_cer(enc, loader, dev, c2i)
   assert 0.0 <= cer <= 2.0
+
+
+def test_nano_dataset_end_to_end(dev, tmp_path):
+  """BASELINE configs[0] plumbing on the GPU path: synthetic dataview in the reference's on-disk
+  format -> FrameCaptionDataset -> device collation -> train()/eval()/greedy CER."""
+  from lipreading_amd import dataset as DS
+  from lipreading_amd import train as T
+  from lipreading_amd.data import make_collate_fn
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.optim import FlatParameters, FusedAdam
+  root = str(tmp_path)
+  DS.write_synthetic_dataview(root, "synthetic/nano", n_videos=3, captions_per_video=6, seed=1)
+  tr, va, te = DS.split_dataset(root, "synthetic/nano", 0.8, np.random.RandomState(123456))
+  ds = DS.FrameCaptionDataset(root, "synthetic/nano", "train", tr)
+  loader = DS.make_loader(ds, 4, make_collate_fn(dev))
+  assert len(loader) == (len(ds) + 3) // 4
+  torch.manual_seed(123456)
+  enc = VideoEncoder(204, 48, rnn_type='LSTM', bidirectional=True, enable_ctc=True,
+                     vocab_size=len(ds.char2idx), char2idx=ds.char2idx).to(dev)
+  opt = FusedAdam(FlatParameters(enc), lr=2e-3)
+  losses = [T.train(enc, None, loader, opt, dev, ds.char2idx, grad_norm=50)[1] for _ in range(12)]
+  assert all(np.isfinite(losses)) and losses[-1] < 0.8 * losses[0], losses
+  assert np.isfinite(T.eval(enc, None, loader, dev, ds.char2idx)[3])
+  assert 0.0 <= T.greedy_cer(enc, loader, dev, ds.char2idx) <= 2.0
