@@ -234,6 +234,48 @@ int lr_ctc_greedy_decode(const float* probs, int64_t stride_b, int64_t stride_t,
                          int32_t* out_offsets, int32_t* out_lens, int B, int T, int C, int blank,
                          lr_stream_t stream);
 
+/* ---- A8 (BUILD-DEFINED, no reference symbol): 3-D conv frontend on bf16 MFMA -------------- */
+/* The reference has no conv frontend (src/models/lipreader/model.py:122,153-156 are comments, the
+ * `ced` configs are empty); BASELINE.json's north_star asks for one ("im2col + MFMA GEMM for the 3D
+ * convs").  The specification is this build's; the oracle is torch conv3d on the CPU.
+ * Activations are channels-last bf16 [B][T][H][W][C]; accumulation is fp32.                      */
+
+/* clips [frames][3][H][W] (uint8, scaled by 1/255, or fp32 taken as is) -> [frames][H][W][4] bf16. */
+int lr_clip_to_ndhwc_bf16(const void* clips, int is_u8, void* out, int64_t frames, int H, int W,
+                          lr_stream_t stream);
+
+/* fp32 torch Conv3d weight [Cout][Cin_real][KT][KH][KW] -> bf16 operand of the implicit GEMM:
+ *   dgrad == 0: out[Cout][taps][Cin_pad]          (forward; channels >= Cin_real are zero)
+ *   dgrad == 1: out[Cin_real][taps][Cout], taps flipped (data gradient of a stride-1 "same" conv
+ *               becomes lr_conv3d_forward on dZ with this operand).                             */
+int lr_conv3d_pack_weights(const float* W, void* out, int Cout, int Cin_real, int Cin_pad, int KT,
+                           int KH, int KW, int dgrad, lr_stream_t stream);
+
+/* Y[b,t,ho,wo,n] = act( sum_{kt,kh,kw,c} X[b,t+kt-pt,ho*s+kh-ph,wo*s+kw-pw,c] * Wp[n][(kt,kh,kw)][c]
+ *                       + bias[n] ),  zero padding, temporal stride 1 and KT = 2*pt+1, spatial stride s.
+ *   X bf16 [B][T][Hin][Win][Cin] (Cin % 4 == 0), Wp from lr_conv3d_pack_weights, bias fp32 or NULL,
+ *   Y bf16 [B][T][Ho][Wo][Cout] (Cout in {32,64,96}); relu != 0 applies max(.,0).                */
+int lr_conv3d_forward(const void* X, const void* Wp, const float* bias, void* Y, int B, int T, int Hin,
+                      int Win, int Cin, int Cout, int KT, int KH, int KW, int stride, int pt, int ph,
+                      int pw, int relu, lr_stream_t stream);
+
+/* dW[Cout][Cin_real][KT][KH][KW] (fp32) (+)= sum_pixels dZ[pixel][n] * im2col(X)[pixel][(tap,c)];
+ * dbias[n] (+)= sum_pixels dZ[pixel][n] (NULL to skip).  dZ bf16 [B][T][Ho][Wo][Cout].          */
+size_t lr_conv3d_wgrad_workspace_bytes(int Cout, int Cin_pad, int KT, int KH, int KW);
+int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* dbias, void* workspace,
+                    size_t workspace_bytes, int accumulate, int B, int T, int Hin, int Win, int Cin_pad,
+                    int Cin_real, int Cout, int KT, int KH, int KW, int stride, int pt, int ph, int pw,
+                    lr_stream_t stream);
+
+/* MaxPool3d((1,2,2)) on channels-last bf16, and the backward of ReLU -> that pool: the gradient of
+ * a window goes to its FIRST maximum (row-major, torch's rule) if the activation there is > 0.   */
+int lr_maxpool_hw2_bf16(const void* in, void* out, int64_t frames, int H, int W, int C,
+                        lr_stream_t stream);
+int lr_unpool_relu_mask_bf16(const void* act, const void* dP, void* dZ, int64_t frames, int H, int W,
+                             int C, lr_stream_t stream);
+int lr_bf16_to_f32(const void* in, float* out, int64_t n, lr_stream_t stream);
+int lr_f32_to_bf16(const float* in, void* out, int64_t n, lr_stream_t stream);
+
 /* ---- A5 tail: optimiser side of the reference step — train_better_model.py:78-80 -------- */
 
 /* sum of squares of n floats accumulated into out[0] (caller zeroes it); used for

@@ -45,6 +45,15 @@ SIGNATURES = {
     "lr_ctc_reduce": (c_int, [P, P, P, c_int, P, P, P, c_int, P]),
     "lr_ctc_greedy_decode": (c_int, [P, c_int64, c_int64, P, P, P, P, P, c_int, c_int, c_int,
                                       c_int, P]),
+    "lr_clip_to_ndhwc_bf16": (c_int, [P, c_int, P, c_int64, c_int, c_int, P]),
+    "lr_conv3d_pack_weights": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "lr_conv3d_forward": (c_int, [P, P, P, P] + [c_int] * 14 + [P]),
+    "lr_conv3d_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),
+    "lr_conv3d_wgrad": (c_int, [P, P, P, P, P, c_size_t] + [c_int] * 15 + [P]),
+    "lr_maxpool_hw2_bf16": (c_int, [P, P, c_int64, c_int, c_int, c_int, P]),
+    "lr_unpool_relu_mask_bf16": (c_int, [P, P, P, c_int64, c_int, c_int, c_int, P]),
+    "lr_bf16_to_f32": (c_int, [P, P, c_int64, P]),
+    "lr_f32_to_bf16": (c_int, [P, P, c_int64, P]),
     "lr_sumsq": (c_int, [P, c_int64, P, P]),
     "lr_adam_step": (c_int, [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_float,
                               c_float, P, P, P, P]),

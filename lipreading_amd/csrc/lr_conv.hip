@@ -1,0 +1,541 @@
+// lr_conv.hip — 3-D convolution frontend (pixels -> per-frame features) on the gfx950 bf16
+// matrix cores.  BUILD-DEFINED: the reference has no conv frontend (its conv stack is commented
+// out, src/models/lipreader/model.py:122,153-156; the `ced` configs are empty files), so there is
+// no reference arithmetic to match — the specification is this repo's and the
+// oracle is torch.nn.functional.conv3d / max_pool3d on the CPU.  BASELINE.json's north_star asks for
+// "im2col + MFMA GEMM for the 3D convs": the im2col matrix is never materialised (6.6 GB for the
+// second layer at B=32); each workgroup gathers its (128 output pixels x 32 k) slice of it
+// straight into LDS — an implicit GEMM — and multiplies with v_mfma_f32_32x32x16_bf16.
+//
+// Layouts: activations are channels-last bf16, [B][T][H][W][C] (C = 4 for the padded RGB input,
+// else the channel count, a multiple of 32), so the K axis of the implicit GEMM, k = (tap, c)
+// with tap = (kt,kh,kw), reads C contiguous values per tap.  Weights are repacked per step from
+// the fp32 torch layout [Cout][Cin][kt][kh][kw] into bf16 [N][taps][Cpad] (forward) and into the
+// flipped/transposed form that turns the data gradient of a stride-1 convolution into the same
+// forward kernel.  Accumulation is fp32; bias + ReLU are fused into the forward epilogue.
+//
+// Weight gradient: dW[n][k] = sum_m dZ[m][n] * im2col[m][k] contracts over PIXELS, which are the
+// slow axis of both operands; tiles are staged pixel-major in LDS and the MFMA fragments are read
+// down the columns (ds_read_u16).  K is split over workgroups into fp32 slabs that a second kernel
+// reduces in fixed order (deterministic) into the torch-layout gradient.
+#include "lr_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short bf16_t;  // storage type
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 h = (__bf16)f;  // round to nearest even (v_cvt_pk_bf16_f32 on gfx950)
+  return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ float bf2f(bf16_t v) {
+  return __builtin_bit_cast(float, (unsigned)v << 16);
+}
+
+struct ConvGeom {
+  int B, T, Hin, Win, Cin;   // Cin = stored (padded) input channels
+  int Ho, Wo, Cout;
+  int KT, KH, KW;            // taps
+  int stride, pt, ph, pw;    // spatial stride, paddings (temporal stride is 1)
+  int Ktot;                  // KT*KH*KW*Cin
+  int64_t M;                 // B*T*Ho*Wo
+};
+
+constexpr int BM = 128;   // output pixels per workgroup
+constexpr int BK = 32;    // k per LDS stage
+constexpr int LDS_LD = BK + 8;  // bf16 elements per LDS row (80 B: 16-B aligned rows)
+
+// Gather one 8-byte unit (4 consecutive k) of im2col row `m` at k index `k` (k % 4 == 0).
+// The row's output coordinates are pre-decoded into (b*T + t, hi0, wi0).
+struct RowCoord {
+  int bt, t, hi0, wi0;
+  bool ok;
+};
+__device__ __forceinline__ RowCoord decode_row(const ConvGeom& g, int64_t m) {
+  RowCoord r;
+  r.ok = m < g.M;
+  const int64_t mm = r.ok ? m : 0;
+  const int wo = (int)(mm % g.Wo);
+  const int64_t q = mm / g.Wo;
+  const int ho = (int)(q % g.Ho);
+  r.bt = (int)(q / g.Ho);
+  r.t = r.bt % g.T;
+  r.hi0 = ho * g.stride - g.ph;
+  r.wi0 = wo * g.stride - g.pw;
+  return r;
+}
+__device__ __forceinline__ uint2 gather_unit(const ConvGeom& g, const bf16_t* __restrict__ X,
+                                             const RowCoord& r, int k) {
+  uint2 v = make_uint2(0u, 0u);
+  if (!r.ok || k >= g.Ktot) return v;
+  const int tap = k / g.Cin, c = k - tap * g.Cin;
+  const int kw = tap % g.KW;
+  const int kh = (tap / g.KW) % g.KH;
+  const int kt = tap / (g.KW * g.KH);
+  const int ti = r.t + kt - g.pt, hi = r.hi0 + kh, wi = r.wi0 + kw;
+  if (ti < 0 || ti >= g.T || hi < 0 || hi >= g.Hin || wi < 0 || wi >= g.Win) return v;
+  const int64_t off = ((((int64_t)(r.bt + kt - g.pt)) * g.Hin + hi) * g.Win + wi) * g.Cin + c;
+  return *reinterpret_cast<const uint2*>(X + off);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward / data-gradient implicit GEMM:  Y[m][n] = act( sum_k im2col(X)[m][k] * Wp[n][k] + b[n] )
+// ---------------------------------------------------------------------------------------------
+template <int NT>  // Cout / 32
+__global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvGeom g, const bf16_t* __restrict__ X,
+                                                           const bf16_t* __restrict__ Wp,
+                                                           const float* __restrict__ bias,
+                                                           bf16_t* __restrict__ Y, int relu) {
+  __shared__ __attribute__((aligned(16))) bf16_t As[BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t Bs[NT * 32 * LDS_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+
+  // A staging: 128 rows x 8 units of 8 B; thread -> rows tid/8 + 32*i, unit tid%8
+  const int a_unit = tid & 7;
+  RowCoord rc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rc[i] = decode_row(g, m0 + (tid >> 3) + 32 * i);
+  // B staging: NT*32 rows x 4 units of 16 B
+  constexpr int B_UNITS = NT * 32 * 4;
+  constexpr int B_PER = (B_UNITS + 255) / 256;
+
+  uint2 ra[4];
+  uint4 rb[B_PER];
+  auto load_stage = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = gather_unit(g, X, rc[i], k0 + a_unit * 4);
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int e = tid + i * 256;
+      rb[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (e < B_UNITS) {
+        const int n = e >> 2, k = k0 + (e & 3) * 8;
+        if (k < g.Ktot) rb[i] = *reinterpret_cast<const uint4*>(Wp + (int64_t)n * g.Ktot + k);
+      }
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<uint2*>(&As[((tid >> 3) + 32 * i) * LDS_LD + a_unit * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int e = tid + i * 256;
+      if (e < B_UNITS) *reinterpret_cast<uint4*>(&Bs[(e >> 2) * LDS_LD + (e & 3) * 8]) = rb[i];
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int lr = lane & 31, lk = lane >> 5;
+  load_stage(0);
+  for (int k0 = 0; k0 < g.Ktot; k0 += BK) {
+    __syncthreads();
+    store_stage();
+    __syncthreads();
+    if (k0 + BK < g.Ktot) load_stage(k0 + BK);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 16) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(&As[(wave * 32 + lr) * LDS_LD + kk + lk * 8]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(&Bs[(j * 32 + lr) * LDS_LD + kk + lk * 8]);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = j * 32 + lr;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (m >= g.M) continue;
+      float v = acc[j][r] + bv;
+      if (relu) v = fmaxf(v, 0.f);
+      Y[m * g.Cout + n] = f2bf(v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient:  slab[split][n][k] = sum_{m in split} dZ[m][n] * im2col(X)[m][k]
+// ---------------------------------------------------------------------------------------------
+// One workgroup = one 32-wide k chunk x one pixel range.  Each wave contracts its own 32 pixels
+// of every 128-pixel stage; the four partial tiles are summed through LDS at the end.
+template <int MT>  // Cout / 32
+__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(ConvGeom g, const bf16_t* __restrict__ X,
+                                                           const bf16_t* __restrict__ dZ,
+                                                           float* __restrict__ slabs,
+                                                           int64_t pix_per_split) {
+  constexpr int ZLD = MT * 32 + 2;   // dZ tile row (pixel-major), +2 to spread banks
+  constexpr int XLD = BK + 2;
+  __shared__ __attribute__((aligned(16))) bf16_t Zs[BM * ZLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Xs[BM * XLD];
+  __shared__ float red[4][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k0 = blockIdx.x * BK;
+  const int64_t mbeg = (int64_t)blockIdx.y * pix_per_split;
+  const int64_t mend = min(g.M, mbeg + pix_per_split);
+  const int lr = lane & 31, lk = lane >> 5;
+  const int a_unit = tid & 7;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  for (int64_t m0 = mbeg; m0 < mend; m0 += BM) {
+    __syncthreads();
+    // stage im2col rows (128 pixels x 32 k) and dZ rows (128 pixels x Cout), pixel-major
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      const int64_t m = m0 + row;
+      uint2 v = make_uint2(0u, 0u);
+      if (m < mend) {
+        const RowCoord rc = decode_row(g, m);
+        v = gather_unit(g, X, rc, k0 + a_unit * 4);
+      }
+      bf16_t* dst = &Xs[row * XLD + a_unit * 4];
+      dst[0] = (bf16_t)(v.x & 0xffffu);
+      dst[1] = (bf16_t)(v.x >> 16);
+      dst[2] = (bf16_t)(v.y & 0xffffu);
+      dst[3] = (bf16_t)(v.y >> 16);
+    }
+    constexpr int ZU = MT * 8;  // 8-byte units per dZ row
+    for (int e = tid; e < BM * ZU; e += 256) {
+      const int row = e / ZU, u = e - row * ZU;
+      const int64_t m = m0 + row;
+      uint2 v = make_uint2(0u, 0u);
+      if (m < mend) v = *reinterpret_cast<const uint2*>(dZ + m * g.Cout + u * 4);
+      bf16_t* dst = &Zs[row * ZLD + u * 4];
+      dst[0] = (bf16_t)(v.x & 0xffffu);
+      dst[1] = (bf16_t)(v.x >> 16);
+      dst[2] = (bf16_t)(v.y & 0xffffu);
+      dst[3] = (bf16_t)(v.y >> 16);
+    }
+    __syncthreads();
+    // wave w contracts pixels [32w, 32w+32): two MFMA k-steps of 16 pixels
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 16) {
+      const int p0 = wave * 32 + kk + lk * 8;
+      bf16x8 b;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        b[i] = __builtin_bit_cast(__bf16, Xs[(p0 + i) * XLD + lr]);       // B[k=pixel][col=k index]
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        bf16x8 a;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          a[i] = __builtin_bit_cast(__bf16, Zs[(p0 + i) * ZLD + j * 32 + lr]);  // A[row=n][k=pixel]
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  // combine the four waves' partial tiles (fixed order) and write the slab
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lk][lr] = acc[j][r];
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += 256) {
+      const int row = e >> 5, col = e & 31;
+      const float s = red[0][row][col] + red[1][row][col] + red[2][row][col] + red[3][row][col];
+      const int k = k0 + col;
+      if (k < g.Ktot)
+        slabs[((int64_t)blockIdx.y * g.Cout + j * 32 + row) * g.Ktot + k] = s;
+    }
+  }
+}
+
+// dW[n][c][kt][kh][kw] (fp32, torch layout) (+)= sum_splits slab[split][n][(tap, c)], c < Cin_real
+__global__ void conv3d_wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, float* __restrict__ dW,
+                                           int Cout, int Cin_real, int Cin_pad, int taps, int accumulate) {
+  const int64_t total = (int64_t)Cout * Cin_real * taps;
+  const int Ktot = taps * Cin_pad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps);
+    const int c = (int)((i / taps) % Cin_real);
+    const int n = (int)(i / ((int64_t)taps * Cin_real));
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slabs[((int64_t)z * Cout + n) * Ktot + tap * Cin_pad + c];
+    dW[i] = accumulate ? dW[i] + s : s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+// forward:  Wp[n][tap][c]  = W[n][c][tap]                      (c >= Cin_real -> 0)
+// dgrad:    Wd[c][tap'][n] = W[n][c][flip(tap')]               rows = Cin_real (multiple of 32)
+__global__ void conv3d_pack_weights_kernel(const float* __restrict__ W, bf16_t* __restrict__ out, int Cout,
+                                           int Cin_real, int Cin_pad, int KT, int KH, int KW,
+                                           int dgrad) {
+  const int taps = KT * KH * KW;
+  const int64_t total = dgrad ? (int64_t)Cin_real * taps * Cout : (int64_t)Cout * taps * Cin_pad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (!dgrad) {
+      const int c = (int)(i % Cin_pad);
+      const int tap = (int)((i / Cin_pad) % taps);
+      const int n = (int)(i / ((int64_t)Cin_pad * taps));
+      if (c < Cin_real) v = W[((int64_t)n * Cin_real + c) * taps + tap];
+    } else {
+      const int n = (int)(i % Cout);
+      const int tp = (int)((i / Cout) % taps);
+      const int c = (int)(i / ((int64_t)Cout * taps));
+      const int tap = taps - 1 - tp;  // flip kt, kh and kw together
+      v = W[((int64_t)n * Cin_real + c) * taps + tap];
+    }
+    out[i] = f2bf(v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// elementwise stages
+// ---------------------------------------------------------------------------------------------
+// clips [B*T][3][H][W] (u8 scaled by 1/255, or f32 as is) -> [B*T][H][W][4] bf16 (4th channel 0)
+__global__ void clip_to_ndhwc_kernel(const void* __restrict__ clips, int is_u8, bf16_t* __restrict__ out,
+                                     int64_t frames, int H, int W) {
+  const int64_t total = frames * H * W;
+  const int64_t hw = (int64_t)H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t f = i / hw, p = i - f * hw;
+    float c[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const int64_t src = (f * 3 + ch) * hw + p;
+      c[ch] = is_u8 ? (float)((const unsigned char*)clips)[src] * (1.f / 255.f) : ((const float*)clips)[src];
+    }
+    uint2 v;
+    v.x = (unsigned)f2bf(c[0]) | ((unsigned)f2bf(c[1]) << 16);
+    v.y = (unsigned)f2bf(c[2]);
+    *reinterpret_cast<uint2*>(out + i * 4) = v;
+  }
+}
+
+// MaxPool3d((1,2,2)) on channels-last bf16: [F][H][W][C] -> [F][H/2][W/2][C]
+__global__ void maxpool_hw2_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int64_t frames,
+                                   int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = frames * Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    int64_t q = i / C;
+    const int wo = (int)(q % Wo);
+    q /= Wo;
+    const int ho = (int)(q % Ho);
+    const int64_t f = q / Ho;
+    const bf16_t* p = in + (((f * H + 2 * ho) * W) + 2 * wo) * C + c;
+    const float a = bf2f(p[0]), b = bf2f(p[C]), d = bf2f(p[(int64_t)W * C]), e = bf2f(p[(int64_t)W * C + C]);
+    out[i] = f2bf(fmaxf(fmaxf(a, b), fmaxf(d, e)));
+  }
+}
+
+// Backward of ReLU -> MaxPool((1,2,2)):  dZ[pos] = dP[window] if pos is the FIRST maximum of its
+// window (row-major scan, torch's max_pool backward) and the activation there is > 0, else 0.
+__global__ void unpool_relu_mask_kernel(const bf16_t* __restrict__ act, const bf16_t* __restrict__ dP,
+                                        bf16_t* __restrict__ dZ, int64_t frames, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = frames * Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    int64_t q = i / C;
+    const int wo = (int)(q % Wo);
+    q /= Wo;
+    const int ho = (int)(q % Ho);
+    const int64_t f = q / Ho;
+    const int64_t base = (((f * H + 2 * ho) * W) + 2 * wo) * C + c;
+    const int64_t offs[4] = {0, C, (int64_t)W * C, (int64_t)W * C + C};
+    float best = -__builtin_inff();
+    int arg = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v = bf2f(act[base + offs[j]]);
+      if (v > best) { best = v; arg = j; }
+    }
+    const bf16_t g = best > 0.f ? dP[i] : (bf16_t)0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dZ[base + offs[j]] = j == arg ? g : (bf16_t)0;
+  }
+}
+
+__global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = bf2f(in[i]);
+}
+__global__ void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = f2bf(in[i]);
+}
+
+// column sums of a bf16 [M][C] matrix, two-stage (deterministic): stage 1
+__global__ void colsum_bf16_partial_kernel(const bf16_t* __restrict__ x, int64_t M, int C,
+                                           float* __restrict__ partial, int splits) {
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  const int64_t per = (M + splits - 1) / splits;
+  const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(M, r0 + per);
+  float s = 0.f;
+  if (col < C)
+    for (int64_t r = r0 + rl; r < r1; r += 4) s += bf2f(x[r * C + col]);
+  part[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && col < C)
+    partial[(int64_t)blockIdx.y * C + col] = part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl];
+}
+__global__ void colsum_final_acc_kernel(const float* __restrict__ partial, int splits, float* __restrict__ out,
+                                        int C, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * C + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+inline int grid1d(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+bool fill_geom(ConvGeom* g, int B, int T, int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW,
+               int stride, int pt, int ph, int pw) {
+  if (B <= 0 || T <= 0 || Hin <= 0 || Win <= 0 || Cin <= 0 || Cout <= 0 || stride <= 0) return false;
+  if (Cin % 4 != 0 || Cout % 32 != 0 || Cout > 96 || KT <= 0 || KH <= 0 || KW <= 0) return false;
+  g->B = B; g->T = T; g->Hin = Hin; g->Win = Win; g->Cin = Cin; g->Cout = Cout;
+  g->KT = KT; g->KH = KH; g->KW = KW; g->stride = stride; g->pt = pt; g->ph = ph; g->pw = pw;
+  g->Ho = (Hin + 2 * ph - KH) / stride + 1;
+  g->Wo = (Win + 2 * pw - KW) / stride + 1;
+  g->Ktot = KT * KH * KW * Cin;
+  g->M = (int64_t)B * T * g->Ho * g->Wo;
+  if (KT != 2 * pt + 1) return false;  // "same" in time, temporal stride 1
+  return g->Ho > 0 && g->Wo > 0;
+}
+
+constexpr int kWgradSplits = 64;
+constexpr int kColsumSplits = 64;
+
+}  // namespace
+
+extern "C" int lr_clip_to_ndhwc_bf16(const void* clips, int is_u8, void* out, int64_t frames, int H,
+                                     int W, lr_stream_t stream) {
+  LR_CHECK_ARG(clips && out && frames > 0 && H > 0 && W > 0);
+  LR_LAUNCH(clip_to_ndhwc_kernel, dim3(grid1d(frames * H * W)), dim3(256), 0, stream, clips, is_u8,
+            (bf16_t*)out, frames, H, W);
+  return lr_launch_status();
+}
+
+extern "C" int lr_conv3d_pack_weights(const float* W, void* out, int Cout, int Cin_real, int Cin_pad,
+                                      int KT, int KH, int KW, int dgrad, lr_stream_t stream) {
+  LR_CHECK_ARG(W && out && Cout > 0 && Cin_real > 0 && Cin_pad >= Cin_real);
+  const int64_t total = dgrad ? (int64_t)Cin_real * KT * KH * KW * Cout
+                              : (int64_t)Cout * KT * KH * KW * Cin_pad;
+  LR_LAUNCH(conv3d_pack_weights_kernel, dim3(grid1d(total)), dim3(256), 0, stream, W, (bf16_t*)out,
+            Cout, Cin_real, Cin_pad, KT, KH, KW, dgrad);
+  return lr_launch_status();
+}
+
+extern "C" int lr_conv3d_forward(const void* X, const void* Wp, const float* bias, void* Y, int B,
+                                 int T, int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW,
+                                 int stride, int pt, int ph, int pw, int relu, lr_stream_t stream) {
+  LR_CHECK_ARG(X && Wp && Y);
+  ConvGeom g;
+  if (!fill_geom(&g, B, T, Hin, Win, Cin, Cout, KT, KH, KW, stride, pt, ph, pw)) return LR_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)((g.M + BM - 1) / BM));
+  const bf16_t* x = (const bf16_t*)X;
+  const bf16_t* w = (const bf16_t*)Wp;
+  bf16_t* y = (bf16_t*)Y;
+  if (Cout == 32) LR_LAUNCH(conv3d_igemm_kernel<1>, grid, dim3(256), 0, stream, g, x, w, bias, y, relu);
+  else if (Cout == 64) LR_LAUNCH(conv3d_igemm_kernel<2>, grid, dim3(256), 0, stream, g, x, w, bias, y, relu);
+  else LR_LAUNCH(conv3d_igemm_kernel<3>, grid, dim3(256), 0, stream, g, x, w, bias, y, relu);
+  return lr_launch_status();
+}
+
+extern "C" size_t lr_conv3d_wgrad_workspace_bytes(int Cout, int Cin_pad, int KT, int KH, int KW) {
+  if (Cout <= 0 || Cin_pad <= 0) return 0;
+  return ((size_t)kWgradSplits * Cout * KT * KH * KW * Cin_pad + (size_t)kColsumSplits * Cout) * sizeof(float);
+}
+
+extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* dbias, void* workspace,
+                               size_t workspace_bytes, int accumulate, int B, int T, int Hin, int Win,
+                               int Cin_pad, int Cin_real, int Cout, int KT, int KH, int KW, int stride,
+                               int pt, int ph, int pw, lr_stream_t stream) {
+  LR_CHECK_ARG(X && dZ && dW && workspace && Cin_real > 0 && Cin_real <= Cin_pad);
+  ConvGeom g;
+  if (!fill_geom(&g, B, T, Hin, Win, Cin_pad, Cout, KT, KH, KW, stride, pt, ph, pw)) return LR_ERR_UNSUPPORTED;
+  if (workspace_bytes < lr_conv3d_wgrad_workspace_bytes(Cout, Cin_pad, KT, KH, KW)) return LR_ERR_WORKSPACE;
+  float* slabs = (float*)workspace;
+  float* cpart = slabs + (size_t)kWgradSplits * Cout * g.Ktot;
+  int64_t per = (g.M + kWgradSplits - 1) / kWgradSplits;
+  per = (per + BM - 1) / BM * BM;
+  const int splits = (int)((g.M + per - 1) / per);
+  const dim3 grid((g.Ktot + BK - 1) / BK, splits);
+  const bf16_t* x = (const bf16_t*)X;
+  const bf16_t* dz = (const bf16_t*)dZ;
+  if (Cout == 32) LR_LAUNCH(conv3d_wgrad_kernel<1>, grid, dim3(256), 0, stream, g, x, dz, slabs, per);
+  else if (Cout == 64) LR_LAUNCH(conv3d_wgrad_kernel<2>, grid, dim3(256), 0, stream, g, x, dz, slabs, per);
+  else LR_LAUNCH(conv3d_wgrad_kernel<3>, grid, dim3(256), 0, stream, g, x, dz, slabs, per);
+  int st = lr_launch_status();
+  if (st != LR_OK) return st;
+  const int taps = KT * KH * KW;
+  LR_LAUNCH(conv3d_wgrad_reduce_kernel, dim3(grid1d((int64_t)Cout * Cin_real * taps)), dim3(256), 0,
+            stream, (const float*)slabs, splits, dW, Cout, Cin_real, Cin_pad, taps, accumulate);
+  st = lr_launch_status();
+  if (st != LR_OK || !dbias) return st;
+  LR_LAUNCH(colsum_bf16_partial_kernel, dim3((Cout + 63) / 64, kColsumSplits), dim3(256), 0, stream, dz,
+            g.M, Cout, cpart, kColsumSplits);
+  LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(256), 0, stream, (const float*)cpart, kColsumSplits,
+            dbias, Cout, accumulate);
+  return lr_launch_status();
+}
+
+extern "C" int lr_maxpool_hw2_bf16(const void* in, void* out, int64_t frames, int H, int W, int C,
+                                   lr_stream_t stream) {
+  LR_CHECK_ARG(in && out && frames > 0 && H > 1 && W > 1 && C > 0 && H % 2 == 0 && W % 2 == 0);
+  LR_LAUNCH(maxpool_hw2_kernel, dim3(grid1d(frames * (H / 2) * (W / 2) * C)), dim3(256), 0, stream,
+            (const bf16_t*)in, (bf16_t*)out, frames, H, W, C);
+  return lr_launch_status();
+}
+
+extern "C" int lr_unpool_relu_mask_bf16(const void* act, const void* dP, void* dZ, int64_t frames, int H,
+                                        int W, int C, lr_stream_t stream) {
+  LR_CHECK_ARG(act && dP && dZ && frames > 0 && H > 1 && W > 1 && C > 0 && H % 2 == 0 && W % 2 == 0);
+  LR_LAUNCH(unpool_relu_mask_kernel, dim3(grid1d(frames * (H / 2) * (W / 2) * C)), dim3(256), 0, stream,
+            (const bf16_t*)act, (const bf16_t*)dP, (bf16_t*)dZ, frames, H, W, C);
+  return lr_launch_status();
+}
+
+extern "C" int lr_bf16_to_f32(const void* in, float* out, int64_t n, lr_stream_t stream) {
+  LR_CHECK_ARG(in && out && n > 0);
+  LR_LAUNCH(bf16_to_f32_kernel, dim3(grid1d(n)), dim3(256), 0, stream, (const bf16_t*)in, out, n);
+  return lr_launch_status();
+}
+
+extern "C" int lr_f32_to_bf16(const float* in, void* out, int64_t n, lr_stream_t stream) {
+  LR_CHECK_ARG(in && out && n > 0);
+  LR_LAUNCH(f32_to_bf16_kernel, dim3(grid1d(n)), dim3(256), 0, stream, in, (bf16_t*)out, n);
+  return lr_launch_status();
+}

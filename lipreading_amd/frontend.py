@@ -1,0 +1,160 @@
+"""3-D convolution frontend: pixel clips -> per-frame features for the sequence encoder.
+
+BUILD-DEFINED: the reference has no conv frontend — its conv stack is commented
+out (`src/models/lipreader/model.py:122,153-156`) and the `ced` experiment configs are empty
+files — but BASELINE.json's north_star and metric name one ("clips of shape (B,75,3,96,96)",
+"im2col+MFMA GEMM for the 3D convs").  The specification below is therefore this repo's own,
+LipNet-style (three spatio-temporal convolutions, each followed by ReLU and a (1,2,2) max-pool):
+
+    conv1  Conv3d(3, 32,  k=(3,5,5), stride=(1,2,2), padding=(1,2,2))   96x96 -> 48x48 -> pool 24x24
+    conv2  Conv3d(32, 64, k=(3,5,5), stride=1,       padding=(1,2,2))   24x24          -> pool 12x12
+    conv3  Conv3d(64, 96, k=(3,3,3), stride=1,       padding=(1,1,1))   12x12          -> pool  6x6
+    features[b, t] = pooled3[b, t].reshape(6*6*96)   (h, w, c order; 3456 per frame at 96x96)
+
+Parameters are held as nn.Conv3d modules (state_dict keys conv{1,2,3}.{weight,bias}, torch layout
+and initialisation) but never called: the arithmetic is the HIP path of lr_conv.hip — bf16
+channels-last activations, implicit-GEMM convolution on v_mfma_f32_32x32x16_bf16 with fp32
+accumulation, fused bias+ReLU.  There is NO reference parity for this stage; the oracle is torch
+conv3d/max_pool3d on the CPU (oracle/torch_oracle.py conv_frontend).
+"""
+import torch
+import torch.nn as nn
+
+from . import _C
+from .encoder import _direct_grads, _notify
+
+# (Cin, Cout, (KT,KH,KW), spatial stride, (pt,ph,pw))
+LAYERS = ((3, 32, (3, 5, 5), 2, (1, 2, 2)),
+          (32, 64, (3, 5, 5), 1, (1, 2, 2)),
+          (64, 96, (3, 3, 3), 1, (1, 1, 1)))
+
+
+def _pad4(c):
+  return (c + 3) // 4 * 4
+
+
+def feature_dim(H, W):
+  return 96 * (H // 16) * (W // 16)
+
+
+class _ConvFrontendFunction(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, clips, *params):
+    L = _C.lib()
+    st = _C.stream_handle()
+    B, T, C, H, W = clips.shape
+    assert C == 3 and H % 16 == 0 and W % 16 == 0
+    dev = clips.device
+    frames = B * T
+    bf = torch.bfloat16
+    x = torch.empty((frames, H, W, 4), dtype=bf, device=dev)
+    is_u8 = clips.dtype == torch.uint8
+    src = clips if is_u8 else clips.to(torch.float32)
+    src = src.contiguous()
+    _C.check(L.lr_clip_to_ndhwc_bf16(src.data_ptr(), 1 if is_u8 else 0, x.data_ptr(), frames, H, W, st),
+             "lr_clip_to_ndhwc_bf16")
+    saved = [x]
+    h, w = H, W
+    for li, (cin, cout, (kt, kh, kw), stride, (pt, ph, pw)) in enumerate(LAYERS):
+      weight, bias = params[2 * li], params[2 * li + 1]
+      cin_p = _pad4(cin)
+      wp = torch.empty((cout, kt * kh * kw, cin_p), dtype=bf, device=dev)
+      _C.check(L.lr_conv3d_pack_weights(weight.data_ptr(), wp.data_ptr(), cout, cin, cin_p, kt, kh, kw, 0,
+                                        st), "lr_conv3d_pack_weights")
+      ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
+      act = torch.empty((frames, ho, wo, cout), dtype=bf, device=dev)
+      _C.check(L.lr_conv3d_forward(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), act.data_ptr(), B, T, h,
+                                   w, cin_p, cout, kt, kh, kw, stride, pt, ph, pw, 1, st),
+               "lr_conv3d_forward")
+      pooled = torch.empty((frames, ho // 2, wo // 2, cout), dtype=bf, device=dev)
+      _C.check(L.lr_maxpool_hw2_bf16(act.data_ptr(), pooled.data_ptr(), frames, ho, wo, cout, st),
+               "lr_maxpool_hw2_bf16")
+      saved += [act, pooled]
+      x, h, w = pooled, ho // 2, wo // 2
+    feats = torch.empty((B, T, h * w * 96), dtype=torch.float32, device=dev)
+    _C.check(L.lr_bf16_to_f32(x.data_ptr(), feats.data_ptr(), feats.numel(), st), "lr_bf16_to_f32")
+    ctx.save_for_backward(*saved, *params)
+    ctx.dims = (B, T, H, W)
+    return feats
+
+  @staticmethod
+  def backward(ctx, dfeat):
+    L = _C.lib()
+    st = _C.stream_handle()
+    B, T, H, W = ctx.dims
+    frames = B * T
+    saved = ctx.saved_tensors
+    acts = saved[:7]            # x0, act1, pool1, act2, pool2, act3, pool3
+    params = saved[7:]
+    dev = dfeat.device
+    bf = torch.bfloat16
+    direct = _direct_grads(params)
+    grads = [p.grad for p in params] if direct else [torch.empty_like(p) for p in params]
+    dfeat = dfeat.contiguous().to(torch.float32)
+    dP = torch.empty(acts[6].shape, dtype=bf, device=dev)
+    _C.check(L.lr_f32_to_bf16(dfeat.data_ptr(), dP.data_ptr(), dfeat.numel(), st), "lr_f32_to_bf16")
+    # spatial size of each layer's input
+    sizes = [(H, W)]
+    for (_, _, (kt, kh, kw), stride, (pt, ph, pw)) in LAYERS:
+      h, w = sizes[-1]
+      sizes.append((((h + 2 * ph - kh) // stride + 1) // 2, ((w + 2 * pw - kw) // stride + 1) // 2))
+    for li in (2, 1, 0):
+      cin, cout, (kt, kh, kw), stride, (pt, ph, pw) = LAYERS[li]
+      cin_p = _pad4(cin)
+      x_in, act = acts[2 * li], acts[2 * li + 1]
+      h, w = sizes[li]
+      ho, wo = act.shape[1], act.shape[2]
+      dZ = torch.empty(act.shape, dtype=bf, device=dev)
+      _C.check(L.lr_unpool_relu_mask_bf16(act.data_ptr(), dP.data_ptr(), dZ.data_ptr(), frames, ho, wo,
+                                          cout, st), "lr_unpool_relu_mask_bf16")
+      wbytes = L.lr_conv3d_wgrad_workspace_bytes(cout, cin_p, kt, kh, kw)
+      ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+      _C.check(L.lr_conv3d_wgrad(x_in.data_ptr(), dZ.data_ptr(), grads[2 * li].data_ptr(),
+                                 grads[2 * li + 1].data_ptr(), ws.data_ptr(), wbytes, 1 if direct else 0,
+                                 B, T, h, w, cin_p, cin, cout, kt, kh, kw, stride, pt, ph, pw, st),
+               "lr_conv3d_wgrad")
+      if li > 0:
+        # data gradient of a stride-1 "same" convolution = the forward kernel on dZ with the
+        # flipped, channel-transposed weights
+        wd = torch.empty((cin, kt * kh * kw, cout), dtype=bf, device=dev)
+        _C.check(L.lr_conv3d_pack_weights(params[2 * li].data_ptr(), wd.data_ptr(), cout, cin, cin_p, kt,
+                                          kh, kw, 1, st), "lr_conv3d_pack_weights")
+        dP = torch.empty((frames, h, w, cin), dtype=bf, device=dev)
+        _C.check(L.lr_conv3d_forward(dZ.data_ptr(), wd.data_ptr(), None, dP.data_ptr(), B, T, ho, wo, cout,
+                                     cin, kt, kh, kw, 1, pt, ph, pw, 0, st), "lr_conv3d_forward(dgrad)")
+    if direct:
+      _notify(params)
+      return (None,) * (1 + len(params))
+    return (None,) + tuple(grads)
+
+
+class ConvFrontend3D(nn.Module):
+  """clips (B, T, 3, H, W) uint8 (scaled by 1/255 on the device) or float -> (B, T, feature_dim)."""
+
+  def __init__(self):
+    super().__init__()
+    for i, (cin, cout, k, stride, pad) in enumerate(LAYERS, 1):
+      setattr(self, "conv%d" % i, nn.Conv3d(cin, cout, k, stride=(1, stride, stride), padding=pad))
+
+  def parameters_in_order(self):
+    return [p for i in (1, 2, 3) for p in (getattr(self, "conv%d" % i).weight, getattr(self, "conv%d" % i).bias)]
+
+  def forward(self, clips):
+    _C.require_cuda(clips)
+    assert clips.dim() == 5 and clips.shape[2] == 3, "clips must be (B, T, 3, H, W)"
+    return _ConvFrontendFunction.apply(clips, *self.parameters_in_order())
+
+
+class PixelLipReader(nn.Module):
+  """frontend + VideoEncoder: the (B,75,3,96,96) regime of BASELINE.json (build-defined)."""
+
+  def __init__(self, encoder, frontend=None):
+    super().__init__()
+    self.frontend = frontend if frontend is not None else ConvFrontend3D()
+    self.encoder = encoder
+    self.enable_ctc = encoder.enable_ctc
+
+  def forward(self, clips, frame_lens, max_len=None):
+    feats = self.frontend(clips)
+    B, T, F = feats.shape
+    return self.encoder(feats.reshape(B, T, F, 1), frame_lens, max_len=max_len)

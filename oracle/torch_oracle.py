@@ -253,3 +253,34 @@ def encoder_ctc_step(encoder, opt, frames, frame_lens, chars, char_lens, grad_no
     torch.nn.utils.clip_grad_norm_(encoder.parameters(), grad_norm)
   opt.step()
   return loss.detach()
+
+
+# ------------------------------------------------------------------------------------------
+# A8: 3-D conv frontend — BUILD-DEFINED, no reference symbol.
+# The specification is lipreading_amd/frontend.py's; this is the same arithmetic on stock torch
+# CPU ops.  `emulate_bf16` rounds the input, the weights and each layer's post-ReLU activation
+# to bfloat16 (straight-through for gradients), which is what the HIP path stores, so that the
+# comparison isolates accumulation-order differences.
+# ------------------------------------------------------------------------------------------
+CONV_LAYERS = ((3, 32, (3, 5, 5), 2, (1, 2, 2)), (32, 64, (3, 5, 5), 1, (1, 2, 2)),
+               (64, 96, (3, 3, 3), 1, (1, 1, 1)))
+
+
+def _bf16_ste(x):
+  return x + (x.to(torch.bfloat16).to(torch.float32) - x).detach()
+
+
+def conv_frontend(clips, params, emulate_bf16=True):
+  """clips (B,T,3,H,W) uint8 or float; params = [w1,b1,w2,b2,w3,b3] in torch Conv3d layout.
+  Returns features (B, T, h*w*96) in (h, w, c) order."""
+  x = clips.float() / 255.0 if clips.dtype == torch.uint8 else clips.float()
+  x = x.permute(0, 2, 1, 3, 4)                        # (B, 3, T, H, W)
+  rnd = _bf16_ste if emulate_bf16 else (lambda v: v)
+  x = rnd(x)
+  for li, (_, _, _, stride, pad) in enumerate(CONV_LAYERS):
+    w, b = params[2 * li], params[2 * li + 1]
+    x = F.conv3d(x, rnd(w), b, stride=(1, stride, stride), padding=pad)
+    x = rnd(torch.relu(x))
+    x = F.max_pool3d(x, (1, 2, 2))
+  B, C, T, h, w_ = x.shape
+  return x.permute(0, 2, 3, 4, 1).reshape(B, T, h * w_ * C)

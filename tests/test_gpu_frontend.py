@@ -1,0 +1,113 @@
+"""GPU: the build-defined 3-D conv frontend (A8) against its torch-CPU oracle.  There is no
+reference arithmetic for this stage; tolerances are bf16-storage tolerances."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+  assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+  return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+  return float(np.abs(a - b).max() / max(1e-6, np.abs(b).max()))
+
+
+def test_single_conv_layer_and_dgrad_against_torch(dev):
+  """lr_conv3d_forward on each layer geometry, and its data-gradient use, against F.conv3d."""
+  from lipreading_amd import _C
+  L = _C.lib()
+  g = torch.Generator().manual_seed(0)
+  for cin, cout, (kt, kh, kw), stride, (pt, ph, pw), hw in ((3, 32, (3, 5, 5), 2, (1, 2, 2), 20),
+                                                             (32, 64, (3, 5, 5), 1, (1, 2, 2), 10),
+                                                             (64, 96, (3, 3, 3), 1, (1, 1, 1), 6)):
+    B, T = 2, 4
+    cin_p = (cin + 3) // 4 * 4
+    x = torch.randn(B, T, hw, hw, cin_p, generator=g)
+    x[..., cin:] = 0
+    w = torch.randn(cout, cin, kt, kh, kw, generator=g) / (cin * kt * kh * kw) ** 0.5
+    b = torch.randn(cout, generator=g)
+    xb, wb = x.bfloat16(), w.bfloat16()
+    ref = torch.nn.functional.conv3d(xb.float()[..., :cin].permute(0, 4, 1, 2, 3), wb.float(), b,
+                                     stride=(1, stride, stride), padding=(pt, ph, pw))
+    ho = ref.shape[-1]
+    xd, wd32, bd = xb.to(dev).contiguous(), w.to(dev), b.to(dev)
+    wp = torch.empty((cout, kt * kh * kw, cin_p), dtype=torch.bfloat16, device=dev)
+    y = torch.empty((B * T, ho, ho, cout), dtype=torch.bfloat16, device=dev)
+    st = _C.stream_handle()
+    _C.check(L.lr_conv3d_pack_weights(wd32.data_ptr(), wp.data_ptr(), cout, cin, cin_p, kt, kh, kw, 0, st))
+    _C.check(L.lr_conv3d_forward(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), y.data_ptr(), B, T, hw, hw,
+                                 cin_p, cout, kt, kh, kw, stride, pt, ph, pw, 0, st))
+    got = y.float().cpu().reshape(B, T, ho, ho, cout).permute(0, 4, 1, 2, 3)
+    assert rel_err(got.numpy(), ref.numpy()) < 1e-2, (cin, cout)
+    if stride == 1:   # data gradient through the same kernel
+      dz = torch.randn(B, T, ho, ho, cout, generator=g).bfloat16()
+      xr = xb.float()[..., :cin].permute(0, 4, 1, 2, 3).requires_grad_(True)
+      out = torch.nn.functional.conv3d(xr, wb.float(), None, stride=1, padding=(pt, ph, pw))
+      out.backward(dz.float().permute(0, 4, 1, 2, 3))
+      wdg = torch.empty((cin, kt * kh * kw, cout), dtype=torch.bfloat16, device=dev)
+      dx = torch.empty((B * T, hw, hw, cin), dtype=torch.bfloat16, device=dev)
+      dzd = dz.to(dev).contiguous()
+      _C.check(L.lr_conv3d_pack_weights(wd32.data_ptr(), wdg.data_ptr(), cout, cin, cin_p, kt, kh, kw, 1, st))
+      _C.check(L.lr_conv3d_forward(dzd.data_ptr(), wdg.data_ptr(), None, dx.data_ptr(), B, T, ho, ho, cout,
+                                   cin, kt, kh, kw, 1, pt, ph, pw, 0, st))
+      got = dx.float().cpu().reshape(B, T, hw, hw, cin).permute(0, 4, 1, 2, 3)
+      assert rel_err(got.numpy(), xr.grad.numpy()) < 1.5e-2, (cin, cout)
+
+
+@pytest.mark.parametrize("dtype", ["u8", "f32"])
+def test_frontend_forward_backward_matches_oracle(dev, dtype):
+  from lipreading_amd.frontend import ConvFrontend3D, feature_dim
+  torch.manual_seed(3)
+  fe = ConvFrontend3D()
+  params_cpu = [p.detach().clone().requires_grad_(True) for p in fe.parameters_in_order()]
+  fe = fe.to(dev)
+  g = torch.Generator().manual_seed(4)
+  B, T, H = 2, 6, 32
+  clips = torch.randint(0, 256, (B, T, 3, H, H), generator=g, dtype=torch.uint8)
+  if dtype == "f32":
+    clips = clips.float() / 255.0
+  wgt = torch.randn(B, T, feature_dim(H, H), generator=g)
+  ref = O.conv_frontend(clips, params_cpu)
+  (ref * wgt).sum().backward()
+  out = fe(clips.to(dev))
+  assert out.shape == (B, T, feature_dim(H, H)) and out.dtype == torch.float32
+  (out * wgt.to(dev)).sum().backward()
+  assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < 2e-2
+  for p, q in zip(fe.parameters_in_order(), params_cpu):
+    assert rel_err(p.grad.cpu().numpy(), q.grad.numpy()) < 4e-2, tuple(p.shape)
+
+
+def test_pixel_lipreader_trains_end_to_end(dev):
+  """pixels -> conv frontend -> BiGRU -> CTC -> backward -> fused Adam: loss goes down."""
+  from lipreading_amd.ctc import ctc_loss_with_status
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.frontend import ConvFrontend3D, PixelLipReader, feature_dim
+  from lipreading_amd.optim import FlatParameters, FusedAdam
+  torch.manual_seed(0)
+  H = 32
+  enc = VideoEncoder(feature_dim(H, H), 32, rnn_type='GRU', bidirectional=True, enable_ctc=True,
+                     vocab_size=64, char2idx=default_char2idx())
+  model = PixelLipReader(enc, ConvFrontend3D()).to(dev).train()
+  opt = FusedAdam(FlatParameters(model), lr=2e-3)
+  g = torch.Generator().manual_seed(1)
+  clips = torch.randint(0, 256, (4, 12, 3, H, H), generator=g, dtype=torch.uint8).to(dev)
+  lens = torch.full((4,), 12, device=dev)
+  labels = torch.randint(4, 64, (4, 5), generator=g).to(dev)
+  ll = torch.full((4,), 5, device=dev)
+  losses = []
+  for _ in range(25):
+    opt.zero_grad()
+    lp, _, _ = model(clips, lens, max_len=12)
+    loss, status, _ = ctc_loss_with_status(lp, labels, lens, ll, 'mean')
+    loss.backward()
+    opt.step(grad_norm=50, skip=status)
+    losses.append(float(loss))
+  assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], losses
