@@ -92,6 +92,10 @@ def main():
   ap.add_argument("--warmup", type=int, default=5)
   ap.add_argument("--model", choices=sorted(MODELS), default="gru256")
   ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
+  ap.add_argument("--regime", choices=["landmarks", "pixels"], default="landmarks",
+                  help="landmarks: reference-faithful (B,75,68,3) input; pixels: build-defined "
+                       "(B,75,3,96,96) uint8 clips through the 3-D conv frontend")
+  ap.add_argument("--layers", type=int, default=None, help="recurrent layers (default 1; 2 for pixels)")
   ap.add_argument("--no-graph", action="store_true",
                   help="launch every kernel eagerly instead of replaying a captured hipGraph")
   ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -120,12 +124,24 @@ def main():
     dist.init_process_group(backend="nccl", device_id=dev)
 
   rnn_type, H, layers, bi = MODELS[args.model]
+  pixels = args.regime == "pixels"
+  if args.layers is not None:
+    layers = args.layers
+  elif pixels:
+    layers = 2      # LipNet-style: STCNN x3 -> 2 x BiGRU-256 -> CTC
   D, G = (2 if bi else 1), (3 if rnn_type == "GRU" else 4)
   B = args.batch
   torch.manual_seed(123456)
-  enc = VideoEncoder(N_LMK * LMK_DIM, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
-                     enable_ctc=True, vocab_size=VOCAB, char2idx=default_char2idx()).to(dev).train()
-  flat = FlatParameters(enc)
+  frame_dim = N_LMK * LMK_DIM
+  if pixels:
+    from lipreading_amd.frontend import ConvFrontend3D, PixelLipReader, feature_dim
+    frame_dim = feature_dim(96, 96)
+  enc = VideoEncoder(frame_dim, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
+                     enable_ctc=True, vocab_size=VOCAB, char2idx=default_char2idx())
+  model = PixelLipReader(enc, ConvFrontend3D()) if pixels else enc
+  model = model.to(dev).train()
+  enc = model.encoder if pixels else model
+  flat = FlatParameters(model)
   opt = FusedAdam(flat, lr=1e-4)
   use_graph = not args.no_graph
   sync = None
@@ -134,17 +150,24 @@ def main():
     # eager: all-reduce each bucket from its autograd hook, overlapped with the rest of backward.
     # graph: forward+backward replay as one hipGraph, the exchange follows it (hooks do not fire
     # on replay, and no collective is ever captured).
-    sync = GradSync(flat, groups=GradSync.groups_for_encoder(enc, flat), overlap=not use_graph)
+    groups = GradSync.groups_for_encoder(enc, flat)
+    if pixels:   # conv parameters come first in the flat buffer: one more bucket
+      first = min(min(g) for g in groups)
+      groups = [list(range(first))] + groups
+    sync = GradSync(flat, groups=groups, overlap=not use_graph)
     sync.broadcast_parameters(0)
   # every rank gets its own shard of the global batch (weak scaling: B per GPU)
   frames, frame_lens, chars, char_lens = synth_batch(B, 123456 + rank, dev)
   labels, label_lens = chars[:, 1:], char_lens - 1
+  if pixels:   # uint8 clips (B,75,3,96,96), resident in HBM
+    gen = torch.Generator().manual_seed(123456 + rank)
+    frames = torch.randint(0, 256, (B, T_FRAMES, 3, 96, 96), generator=gen, dtype=torch.uint8).to(dev)
 
   def fwd_bwd():
     # train_better_model.py:46-48,67,74 — everything up to and including backward
     from lipreading_amd.ctc import ctc_loss_with_status
     opt.zero_grad()
-    log_probs, _, _ = enc(frames, frame_lens, max_len=T_FRAMES)
+    log_probs, _, _ = model(frames, frame_lens, max_len=T_FRAMES)
     loss, status, _ = ctc_loss_with_status(log_probs, labels, frame_lens, label_lens, 'mean')
     loss.backward()
     return loss.detach(), status
