@@ -19,6 +19,7 @@
 // down the columns (ds_read_u16).  K is split over workgroups into fp32 slabs that a second kernel
 // reduces in fixed order (deterministic) into the torch-layout gradient.
 #include "lr_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -83,72 +84,123 @@ __device__ __forceinline__ uint2 gather_unit(const ConvGeom& g, const bf16_t* __
 // ---------------------------------------------------------------------------------------------
 // forward / data-gradient implicit GEMM:  Y[m][n] = act( sum_k im2col(X)[m][k] * Wp[n][k] + b[n] )
 // ---------------------------------------------------------------------------------------------
-template <int NT>  // Cout / 32
+// Workgroup tile: 256 output pixels x Cout (all of N: Cout <= 96), K staged 64 at a time.
+// 4 waves, each 64 pixels (two 32-row MFMA tiles) so every weight fragment read from LDS feeds
+// two MFMAs; a 64-k stage is 8*NT MFMAs per wave between barriers.  The im2col slice is gathered
+// in 16-byte units (8 channels of one tap; 8-byte units for the 4-channel input layer), lanes
+// running along k so a row's slice is one contiguous 128-byte read when the stage stays inside
+// a tap.  Tap -> (dt,dh,dw) comes from a small LDS table instead of divisions.  LDS rows are
+// padded to 144 B, which makes the ds_read_b128 fragment reads conflict-free (36-dword stride
+// covers all 64 banks within each 16-lane group).
+constexpr int IG_BM = 256;
+constexpr int IG_BK = 64;
+constexpr int IG_LD = IG_BK + 8;   // bf16 per LDS row (144 B)
+
+template <int CIN, int NT>
 __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvGeom g, const bf16_t* __restrict__ X,
                                                            const bf16_t* __restrict__ Wp,
                                                            const float* __restrict__ bias,
                                                            bf16_t* __restrict__ Y, int relu) {
-  __shared__ __attribute__((aligned(16))) bf16_t As[BM * LDS_LD];
-  __shared__ __attribute__((aligned(16))) bf16_t Bs[NT * 32 * LDS_LD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
-
-  // A staging: 128 rows x 8 units of 8 B; thread -> rows tid/8 + 32*i, unit tid%8
-  const int a_unit = tid & 7;
-  RowCoord rc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) rc[i] = decode_row(g, m0 + (tid >> 3) + 32 * i);
-  // B staging: NT*32 rows x 4 units of 16 B
-  constexpr int B_UNITS = NT * 32 * 4;
+  constexpr int UE = CIN >= 8 ? 8 : 4;               // bf16 elements per gather unit (16 B / 8 B)
+  constexpr int UPR = IG_BK / UE;                    // units per row per stage (8 or 16)
+  constexpr int A_PER = IG_BM * UPR / 256;           // units per thread per stage (8 or 16)
+  constexpr int ROWS_PER_PASS = 256 / UPR;           // rows covered by one pass of the workgroup
+  constexpr int B_UNITS = NT * 32 * (IG_BK / 8);     // 16-byte units of the weight stage
   constexpr int B_PER = (B_UNITS + 255) / 256;
+  __shared__ __attribute__((aligned(16))) bf16_t As[IG_BM * IG_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t Bs[NT * 32 * IG_LD];
+  __shared__ int tap_dt[128], tap_dh[128], tap_dw[128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * IG_BM;
+  const int taps = g.KT * g.KH * g.KW;
+  for (int tp = tid; tp < taps; tp += 256) {
+    tap_dw[tp] = tp % g.KW;
+    tap_dh[tp] = (tp / g.KW) % g.KH;
+    tap_dt[tp] = tp / (g.KW * g.KH) - g.pt;
+  }
 
-  uint2 ra[4];
+  // this thread's rows: row = tid / UPR + ROWS_PER_PASS * i, unit column = tid % UPR
+  const int ucol = tid % UPR;
+  const int row0 = tid / UPR;
+  constexpr int NROW = A_PER;
+  int r_bt[NROW], r_t[NROW], r_hi[NROW], r_wi[NROW];
+#pragma unroll
+  for (int i = 0; i < NROW; ++i) {
+    const RowCoord rc = decode_row(g, m0 + row0 + ROWS_PER_PASS * i);
+    r_bt[i] = rc.ok ? rc.bt : -1;
+    r_t[i] = rc.t;
+    r_hi[i] = rc.hi0;
+    r_wi[i] = rc.wi0;
+  }
+  __syncthreads();
+
+  typedef typename std::conditional<UE == 8, uint4, uint2>::type unit_t;
+  unit_t ra[A_PER];
   uint4 rb[B_PER];
   auto load_stage = [&](int k0) {
+    const int k = k0 + ucol * UE;
+    const int tap = k / CIN, c = k - tap * CIN;
+    const bool kok = k < g.Ktot;
+    const int dt = kok ? tap_dt[tap] : 0, dh = kok ? tap_dh[tap] : 0, dw = kok ? tap_dw[tap] : 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = gather_unit(g, X, rc[i], k0 + a_unit * 4);
+    for (int i = 0; i < A_PER; ++i) {
+      unit_t v;
+      __builtin_memset(&v, 0, sizeof(v));
+      const int ti = r_t[i] + dt, hi = r_hi[i] + dh, wi = r_wi[i] + dw;
+      if (kok && r_bt[i] >= 0 && ti >= 0 && ti < g.T && hi >= 0 && hi < g.Hin && wi >= 0 && wi < g.Win)
+        v = *reinterpret_cast<const unit_t*>(X + ((((int64_t)(r_bt[i] + dt)) * g.Hin + hi) * g.Win + wi) * CIN + c);
+      ra[i] = v;
+    }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       const int e = tid + i * 256;
       rb[i] = make_uint4(0u, 0u, 0u, 0u);
       if (e < B_UNITS) {
-        const int n = e >> 2, k = k0 + (e & 3) * 8;
-        if (k < g.Ktot) rb[i] = *reinterpret_cast<const uint4*>(Wp + (int64_t)n * g.Ktot + k);
+        const int n = e / (IG_BK / 8), kk = k0 + (e % (IG_BK / 8)) * 8;
+        if (kk < g.Ktot) rb[i] = *reinterpret_cast<const uint4*>(Wp + (int64_t)n * g.Ktot + kk);
       }
     }
   };
   auto store_stage = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<uint2*>(&As[((tid >> 3) + 32 * i) * LDS_LD + a_unit * 4]) = ra[i];
+    for (int i = 0; i < A_PER; ++i)
+      *reinterpret_cast<unit_t*>(&As[(row0 + ROWS_PER_PASS * i) * IG_LD + ucol * UE]) = ra[i];
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       const int e = tid + i * 256;
-      if (e < B_UNITS) *reinterpret_cast<uint4*>(&Bs[(e >> 2) * LDS_LD + (e & 3) * 8]) = rb[i];
+      if (e < B_UNITS) *reinterpret_cast<uint4*>(&Bs[(e / (IG_BK / 8)) * IG_LD + (e % (IG_BK / 8)) * 8]) = rb[i];
     }
   };
 
-  f32x16 acc[NT];
+  f32x16 acc[2][NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int lr = lane & 31, lk = lane >> 5;
   load_stage(0);
-  for (int k0 = 0; k0 < g.Ktot; k0 += BK) {
+  for (int k0 = 0; k0 < g.Ktot; k0 += IG_BK) {
     __syncthreads();
     store_stage();
     __syncthreads();
-    if (k0 + BK < g.Ktot) load_stage(k0 + BK);
+    if (k0 + IG_BK < g.Ktot) load_stage(k0 + IG_BK);
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 16) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(&As[(wave * 32 + lr) * LDS_LD + kk + lk * 8]);
+    for (int kk = 0; kk < IG_BK; kk += 16) {
+      bf16x8 a[2], b[NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(&Bs[(j * 32 + lr) * LDS_LD + kk + lk * 8]);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
-      }
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const bf16x8*>(&As[(wave * 64 + i * 32 + lr) * IG_LD + kk + lk * 8]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        b[j] = *reinterpret_cast<const bf16x8*>(&Bs[(j * 32 + lr) * IG_LD + kk + lk * 8]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
   // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -157,13 +209,15 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvGeom g, const bf1
     const int n = j * 32 + lr;
     const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      if (m >= g.M) continue;
-      float v = acc[j][r] + bv;
-      if (relu) v = fmaxf(v, 0.f);
-      Y[m * g.Cout + n] = f2bf(v);
-    }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (m >= g.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (relu) v = fmaxf(v, 0.f);
+        Y[m * g.Cout + n] = f2bf(v);
+      }
   }
 }
 
@@ -389,21 +443,36 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restr
     out[i] = f2bf(in[i]);
 }
 
-// column sums of a bf16 [M][C] matrix, two-stage (deterministic): stage 1
+// column sums of a bf16 [M][C] matrix (C % 8 == 0), two-stage (deterministic).  Stage 1: every
+// thread owns 8 channels (one 16-byte load per row) and strides over the rows of its workgroup's
+// slice; the workgroup combines its row lanes through LDS and writes partial[blockIdx.x][C].
 __global__ void colsum_bf16_partial_kernel(const bf16_t* __restrict__ x, int64_t M, int C,
                                            float* __restrict__ partial, int splits) {
-  __shared__ float part[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cl;
+  __shared__ float red[256][9];
+  const int tpr = C >> 3;                    // threads per row
+  const int rl = threadIdx.x / tpr, cg = threadIdx.x - rl * tpr;
+  const int rows_per_iter = 256 / tpr;
   const int64_t per = (M + splits - 1) / splits;
-  const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(M, r0 + per);
-  float s = 0.f;
-  if (col < C)
-    for (int64_t r = r0 + rl; r < r1; r += 4) s += bf2f(x[r * C + col]);
-  part[rl][cl] = s;
+  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = min(M, r0 + per);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rl < rows_per_iter) {
+    for (int64_t r = r0 + rl; r < r1; r += rows_per_iter) {
+      const uint4 v = *reinterpret_cast<const uint4*>(x + r * C + cg * 8);
+      acc[0] += bf2f((bf16_t)(v.x & 0xffffu)); acc[1] += bf2f((bf16_t)(v.x >> 16));
+      acc[2] += bf2f((bf16_t)(v.y & 0xffffu)); acc[3] += bf2f((bf16_t)(v.y >> 16));
+      acc[4] += bf2f((bf16_t)(v.z & 0xffffu)); acc[5] += bf2f((bf16_t)(v.z >> 16));
+      acc[6] += bf2f((bf16_t)(v.w & 0xffffu)); acc[7] += bf2f((bf16_t)(v.w >> 16));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc[i];
   __syncthreads();
-  if (rl == 0 && col < C)
-    partial[(int64_t)blockIdx.y * C + col] = part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl];
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x, g = c >> 3, i = c & 7;
+    float s = 0.f;
+    for (int r = 0; r < rows_per_iter; ++r) s += red[r * tpr + g][i];
+    partial[(int64_t)blockIdx.x * C + c] = s;
+  }
 }
 __global__ void colsum_final_acc_kernel(const float* __restrict__ partial, int splits, float* __restrict__ out,
                                         int C, int accumulate) {
@@ -436,7 +505,7 @@ bool fill_geom(ConvGeom* g, int B, int T, int Hin, int Win, int Cin, int Cout, i
 }
 
 constexpr int kWgradSplits = 64;
-constexpr int kColsumSplits = 64;
+constexpr int kColsumSplits = 1024;
 
 }  // namespace
 
@@ -464,13 +533,24 @@ extern "C" int lr_conv3d_forward(const void* X, const void* Wp, const float* bia
   LR_CHECK_ARG(X && Wp && Y);
   ConvGeom g;
   if (!fill_geom(&g, B, T, Hin, Win, Cin, Cout, KT, KH, KW, stride, pt, ph, pw)) return LR_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)((g.M + BM - 1) / BM));
+  const dim3 grid((unsigned)((g.M + IG_BM - 1) / IG_BM));
   const bf16_t* x = (const bf16_t*)X;
   const bf16_t* w = (const bf16_t*)Wp;
   bf16_t* y = (bf16_t*)Y;
-  if (Cout == 32) LR_LAUNCH(conv3d_igemm_kernel<1>, grid, dim3(256), 0, stream, g, x, w, bias, y, relu);
-  else if (Cout == 64) LR_LAUNCH(conv3d_igemm_kernel<2>, grid, dim3(256), 0, stream, g, x, w, bias, y, relu);
-  else LR_LAUNCH(conv3d_igemm_kernel<3>, grid, dim3(256), 0, stream, g, x, w, bias, y, relu);
+#define LR_IGEMM(CI, NTT) LR_LAUNCH((conv3d_igemm_kernel<CI, NTT>), grid, dim3(256), 0, stream, g, x, w, bias, y, relu)
+  const int nt = Cout / 32;
+  if (Cin == 4 && nt == 1) LR_IGEMM(4, 1);
+  else if (Cin == 32 && nt == 2) LR_IGEMM(32, 2);
+  else if (Cin == 64 && nt == 3) LR_IGEMM(64, 3);
+  else if (Cin == 64 && nt == 1) LR_IGEMM(64, 1);     // data gradient of layer 2
+  else if (Cin == 96 && nt == 2) LR_IGEMM(96, 2);     // data gradient of layer 3
+  else if (Cin == 32 && nt == 1) LR_IGEMM(32, 1);
+  else if (Cin == 32 && nt == 3) LR_IGEMM(32, 3);
+  else if (Cin == 64 && nt == 2) LR_IGEMM(64, 2);
+  else if (Cin == 96 && nt == 1) LR_IGEMM(96, 1);
+  else if (Cin == 96 && nt == 3) LR_IGEMM(96, 3);
+  else return LR_ERR_UNSUPPORTED;
+#undef LR_IGEMM
   return lr_launch_status();
 }
 
@@ -505,8 +585,8 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
             stream, (const float*)slabs, splits, dW, Cout, Cin_real, Cin_pad, taps, accumulate);
   st = lr_launch_status();
   if (st != LR_OK || !dbias) return st;
-  LR_LAUNCH(colsum_bf16_partial_kernel, dim3((Cout + 63) / 64, kColsumSplits), dim3(256), 0, stream, dz,
-            g.M, Cout, cpart, kColsumSplits);
+  LR_LAUNCH(colsum_bf16_partial_kernel, dim3(kColsumSplits), dim3(256), 0, stream, dz, g.M, Cout, cpart,
+            kColsumSplits);
   LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(256), 0, stream, (const float*)cpart, kColsumSplits,
             dbias, Cout, accumulate);
   return lr_launch_status();
