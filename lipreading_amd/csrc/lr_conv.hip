@@ -224,95 +224,125 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvGeom g, const bf1
 // ---------------------------------------------------------------------------------------------
 // weight gradient:  slab[split][n][k] = sum_{m in split} dZ[m][n] * im2col(X)[m][k]
 // ---------------------------------------------------------------------------------------------
-// One workgroup = one 32-wide k chunk x one pixel range.  Each wave contracts its own 32 pixels
-// of every 128-pixel stage; the four partial tiles are summed through LDS at the end.
-template <int MT>  // Cout / 32
+// One workgroup = one (32*NTW)-wide k tile x one pixel range; all Cout rows.  Every stage brings
+// 128 pixels of dZ and of the im2col slice into LDS (pixel-major, as they lie in memory); wave w
+// contracts pixels [32w, 32w+32) of the stage into its own MT x NTW accumulator tiles (each dZ
+// fragment is reused NTW times, each im2col fragment MT times), and the four waves' partial
+// tiles are summed through LDS at the end in fixed order.  The contraction runs over PIXELS, the
+// slow axis of both operands, so fragments are read down LDS columns (ds_read_u16).
+constexpr int WG_PIX = 128;
+
+template <int CIN, int MT, int NTW>
 __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(ConvGeom g, const bf16_t* __restrict__ X,
                                                            const bf16_t* __restrict__ dZ,
                                                            float* __restrict__ slabs,
                                                            int64_t pix_per_split) {
-  constexpr int ZLD = MT * 32 + 2;   // dZ tile row (pixel-major), +2 to spread banks
-  constexpr int XLD = BK + 2;
-  __shared__ __attribute__((aligned(16))) bf16_t Zs[BM * ZLD];
-  __shared__ __attribute__((aligned(16))) bf16_t Xs[BM * XLD];
-  __shared__ float red[4][32][33];
+  constexpr int NC = NTW * 32;               // k columns per workgroup
+  constexpr int UE = CIN >= 8 ? 8 : 4;       // bf16 per gather unit
+  constexpr int UPR = NC / UE;               // units per pixel row
+  constexpr int XLD = NC + 8;                // bf16 per LDS row, rows 16-byte aligned
+  constexpr int ZLD = MT * 32 + 8;
+  constexpr int ZU = MT * 4;                 // 16-byte units per dZ row
+  __shared__ __attribute__((aligned(16))) bf16_t Xs[WG_PIX * XLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Zs[WG_PIX * ZLD];
+  __shared__ int rbt[WG_PIX], rt[WG_PIX], rhi[WG_PIX], rwi[WG_PIX];
+  __shared__ int tap_dt[128], tap_dh[128], tap_dw[128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int k0 = blockIdx.x * BK;
+  const int k0 = blockIdx.x * NC;
   const int64_t mbeg = (int64_t)blockIdx.y * pix_per_split;
   const int64_t mend = min(g.M, mbeg + pix_per_split);
   const int lr = lane & 31, lk = lane >> 5;
-  const int a_unit = tid & 7;
+  const int taps = g.KT * g.KH * g.KW;
+  for (int tp = tid; tp < taps; tp += 256) {
+    tap_dw[tp] = tp % g.KW;
+    tap_dh[tp] = (tp / g.KW) % g.KH;
+    tap_dt[tp] = tp / (g.KW * g.KH) - g.pt;
+  }
+  typedef typename std::conditional<UE == 8, uint4, uint2>::type unit_t;
 
-  f32x16 acc[MT];
+  f32x16 acc[MT][NTW];
 #pragma unroll
-  for (int j = 0; j < MT; ++j)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  for (int64_t m0 = mbeg; m0 < mend; m0 += BM) {
-    __syncthreads();
-    // stage im2col rows (128 pixels x 32 k) and dZ rows (128 pixels x Cout), pixel-major
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (tid >> 3) + 32 * i;
-      const int64_t m = m0 + row;
-      uint2 v = make_uint2(0u, 0u);
-      if (m < mend) {
-        const RowCoord rc = decode_row(g, m);
-        v = gather_unit(g, X, rc, k0 + a_unit * 4);
-      }
-      bf16_t* dst = &Xs[row * XLD + a_unit * 4];
-      dst[0] = (bf16_t)(v.x & 0xffffu);
-      dst[1] = (bf16_t)(v.x >> 16);
-      dst[2] = (bf16_t)(v.y & 0xffffu);
-      dst[3] = (bf16_t)(v.y >> 16);
+  for (int64_t m0 = mbeg; m0 < mend; m0 += WG_PIX) {
+    __syncthreads();   // previous stage consumed (and the tap table is visible)
+    if (tid < WG_PIX) {
+      const int64_t m = m0 + tid;
+      const RowCoord rc = decode_row(g, m < mend ? m : g.M);
+      rbt[tid] = rc.ok ? rc.bt : -1;
+      rt[tid] = rc.t;
+      rhi[tid] = rc.hi0;
+      rwi[tid] = rc.wi0;
     }
-    constexpr int ZU = MT * 8;  // 8-byte units per dZ row
-    for (int e = tid; e < BM * ZU; e += 256) {
+    // dZ rows: the 128 x Cout tile is one contiguous block of memory
+    for (int e = tid; e < WG_PIX * ZU; e += 256) {
       const int row = e / ZU, u = e - row * ZU;
-      const int64_t m = m0 + row;
-      uint2 v = make_uint2(0u, 0u);
-      if (m < mend) v = *reinterpret_cast<const uint2*>(dZ + m * g.Cout + u * 4);
-      bf16_t* dst = &Zs[row * ZLD + u * 4];
-      dst[0] = (bf16_t)(v.x & 0xffffu);
-      dst[1] = (bf16_t)(v.x >> 16);
-      dst[2] = (bf16_t)(v.y & 0xffffu);
-      dst[3] = (bf16_t)(v.y >> 16);
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (m0 + row < mend) v = *reinterpret_cast<const uint4*>(dZ + (m0 + row) * g.Cout + u * 8);
+      *reinterpret_cast<uint4*>(&Zs[row * ZLD + u * 8]) = v;
+    }
+    __syncthreads();   // row coordinates ready
+    for (int e = tid; e < WG_PIX * UPR; e += 256) {
+      const int row = e / UPR, u = e - row * UPR;
+      const int k = k0 + u * UE;
+      unit_t v;
+      __builtin_memset(&v, 0, sizeof(v));
+      if (k < g.Ktot && rbt[row] >= 0) {
+        const int tap = k / CIN, c = k - tap * CIN;
+        const int dt = tap_dt[tap];
+        const int ti = rt[row] + dt, hi = rhi[row] + tap_dh[tap], wi = rwi[row] + tap_dw[tap];
+        if (ti >= 0 && ti < g.T && hi >= 0 && hi < g.Hin && wi >= 0 && wi < g.Win)
+          v = *reinterpret_cast<const unit_t*>(X + ((((int64_t)(rbt[row] + dt)) * g.Hin + hi) * g.Win + wi) * CIN + c);
+      }
+      *reinterpret_cast<unit_t*>(&Xs[row * XLD + u * UE]) = v;
     }
     __syncthreads();
     // wave w contracts pixels [32w, 32w+32): two MFMA k-steps of 16 pixels
 #pragma unroll
     for (int kk = 0; kk < 32; kk += 16) {
       const int p0 = wave * 32 + kk + lk * 8;
-      bf16x8 b;
+      bf16x8 a[MT], b[NTW];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        b[i] = __builtin_bit_cast(__bf16, Xs[(p0 + i) * XLD + lr]);       // B[k=pixel][col=k index]
-#pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        bf16x8 a;
+      for (int j = 0; j < MT; ++j)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          a[i] = __builtin_bit_cast(__bf16, Zs[(p0 + i) * ZLD + j * 32 + lr]);  // A[row=n][k=pixel]
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
-      }
+          a[j][i] = __builtin_bit_cast(__bf16, Zs[(p0 + i) * ZLD + j * 32 + lr]);   // A[row=n][k=pixel]
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          b[j][i] = __builtin_bit_cast(__bf16, Xs[(p0 + i) * XLD + j * 32 + lr]);   // B[k=pixel][col]
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
   // combine the four waves' partial tiles (fixed order) and write the slab
+  float* red = reinterpret_cast<float*>(Xs);   // 4 x 32 x 33 floats = 16.9 kB <= sizeof(Xs)
+  static_assert(sizeof(bf16_t) * WG_PIX * XLD >= 4 * 32 * 33 * sizeof(float), "reduction scratch");
 #pragma unroll
-  for (int j = 0; j < MT; ++j) {
-    __syncthreads();
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lk][lr] = acc[j][r];
-    __syncthreads();
-    for (int e = tid; e < 32 * 32; e += 256) {
-      const int row = e >> 5, col = e & 31;
-      const float s = red[0][row][col] + red[1][row][col] + red[2][row][col] + red[3][row][col];
-      const int k = k0 + col;
-      if (k < g.Ktot)
-        slabs[((int64_t)blockIdx.y * g.Cout + j * 32 + row) * g.Ktot + k] = s;
+    for (int j = 0; j < NTW; ++j) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * 33 + lr] = acc[i][j][r];
+      __syncthreads();
+      for (int e = tid; e < 32 * 32; e += 256) {
+        const int row = e >> 5, col = e & 31;
+        const float sum = red[row * 33 + col] + red[(32 + row) * 33 + col] + red[(64 + row) * 33 + col] +
+                          red[(96 + row) * 33 + col];
+        const int k = k0 + j * 32 + col;
+        if (k < g.Ktot) slabs[((int64_t)blockIdx.y * g.Cout + i * 32 + row) * g.Ktot + k] = sum;
+      }
     }
-  }
 }
 
 // dW[n][c][kt][kh][kw] (fp32, torch layout) (+)= sum_splits slab[split][n][(tap, c)], c < Cin_real
@@ -504,8 +534,16 @@ bool fill_geom(ConvGeom* g, int B, int T, int Hin, int Win, int Cin, int Cout, i
   return g->Ho > 0 && g->Wo > 0;
 }
 
-constexpr int kWgradSplits = 64;
-constexpr int kColsumSplits = 1024;
+// pixel splits of the weight gradient: enough workgroups to fill the chip for each k-tile count
+static int wgrad_ntw(int Cout) { return Cout == 32 ? 5 : (Cout == 64 ? 4 : 2); }
+static int wgrad_splits(int Cout, int Ktot) {
+  const int coltiles = (Ktot + wgrad_ntw(Cout) * 32 - 1) / (wgrad_ntw(Cout) * 32);
+  int s = 1024 / coltiles;
+  if (s < 16) s = 16;
+  if (s > 512) s = 512;
+  return s;
+}
+constexpr int kColsumSplits = 256;
 
 }  // namespace
 
@@ -556,7 +594,8 @@ extern "C" int lr_conv3d_forward(const void* X, const void* Wp, const float* bia
 
 extern "C" size_t lr_conv3d_wgrad_workspace_bytes(int Cout, int Cin_pad, int KT, int KH, int KW) {
   if (Cout <= 0 || Cin_pad <= 0) return 0;
-  return ((size_t)kWgradSplits * Cout * KT * KH * KW * Cin_pad + (size_t)kColsumSplits * Cout) * sizeof(float);
+  const int Ktot = KT * KH * KW * Cin_pad;
+  return ((size_t)wgrad_splits(Cout, Ktot) * Cout * Ktot + (size_t)kColsumSplits * Cout) * sizeof(float);
 }
 
 extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* dbias, void* workspace,
@@ -567,17 +606,26 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
   ConvGeom g;
   if (!fill_geom(&g, B, T, Hin, Win, Cin_pad, Cout, KT, KH, KW, stride, pt, ph, pw)) return LR_ERR_UNSUPPORTED;
   if (workspace_bytes < lr_conv3d_wgrad_workspace_bytes(Cout, Cin_pad, KT, KH, KW)) return LR_ERR_WORKSPACE;
+  const int max_splits = wgrad_splits(Cout, g.Ktot);
   float* slabs = (float*)workspace;
-  float* cpart = slabs + (size_t)kWgradSplits * Cout * g.Ktot;
-  int64_t per = (g.M + kWgradSplits - 1) / kWgradSplits;
-  per = (per + BM - 1) / BM * BM;
+  float* cpart = slabs + (size_t)max_splits * Cout * g.Ktot;
+  int64_t per = (g.M + max_splits - 1) / max_splits;
+  per = (per + WG_PIX - 1) / WG_PIX * WG_PIX;
   const int splits = (int)((g.M + per - 1) / per);
-  const dim3 grid((g.Ktot + BK - 1) / BK, splits);
+  const int nc = wgrad_ntw(Cout) * 32;
+  const dim3 grid((g.Ktot + nc - 1) / nc, splits);
   const bf16_t* x = (const bf16_t*)X;
   const bf16_t* dz = (const bf16_t*)dZ;
-  if (Cout == 32) LR_LAUNCH(conv3d_wgrad_kernel<1>, grid, dim3(256), 0, stream, g, x, dz, slabs, per);
-  else if (Cout == 64) LR_LAUNCH(conv3d_wgrad_kernel<2>, grid, dim3(256), 0, stream, g, x, dz, slabs, per);
-  else LR_LAUNCH(conv3d_wgrad_kernel<3>, grid, dim3(256), 0, stream, g, x, dz, slabs, per);
+#define LR_WGRAD(CI, MTT, NTT) LR_LAUNCH((conv3d_wgrad_kernel<CI, MTT, NTT>), grid, dim3(256), 0, stream, g, x, dz, slabs, per)
+  if (Cin_pad == 4 && Cout == 32) LR_WGRAD(4, 1, 5);
+  else if (Cin_pad == 32 && Cout == 64) LR_WGRAD(32, 2, 4);
+  else if (Cin_pad == 64 && Cout == 96) LR_WGRAD(64, 3, 2);
+  else if (Cin_pad == 32 && Cout == 32) LR_WGRAD(32, 1, 5);
+  else if (Cin_pad == 64 && Cout == 64) LR_WGRAD(64, 2, 4);
+  else if (Cin_pad == 32 && Cout == 96) LR_WGRAD(32, 3, 2);
+  else if (Cin_pad == 64 && Cout == 32) LR_WGRAD(64, 1, 5);
+  else return LR_ERR_UNSUPPORTED;
+#undef LR_WGRAD
   int st = lr_launch_status();
   if (st != LR_OK) return st;
   const int taps = KT * KH * KW;
