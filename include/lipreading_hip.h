@@ -143,9 +143,11 @@ int lr_rnn_layer_backward(int mode, const float* x, const int32_t* lens,
  * clock).  While enabled, every lr_rnn_layer_forward / _backward call issues ONE of its step
  * launches (the middle one) with a hipEvent pair that stamps that dispatch's begin and end on
  * the stream the kernel runs on.
- * lr_profile_read(which: 0 = forward step kernel, 1 = backward step kernel) WAITS for the
- * recorded events, returns the summed elapsed milliseconds and the number of samples in HOST
- * memory, and clears the ring (2048 samples per kind; later samples are dropped). */
+ * The conv entry points do the same for every call.  lr_profile_read(which) WAITS for the recorded
+ * events, returns the summed elapsed milliseconds and the number of samples in HOST memory, and
+ * clears the ring (1024 samples per slot; later samples are dropped).  Slots: 0/1 recurrent
+ * forward/backward step kernel; 2,3,4 conv1..3 forward; 5,6 conv2/conv3 data gradient; 7,8,9
+ * conv1..3 weight gradient. */
 int lr_profile_enable(int on);
 int lr_profile_read(int which, float* total_ms_host, int* samples_host);
 

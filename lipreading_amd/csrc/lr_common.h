@@ -72,3 +72,16 @@ __device__ __forceinline__ float lr_wave_sum(float v) {
 // stage 2 (caller specific): out[col] = sum_rs partial[rs][col] in fixed order.
 constexpr int LR_COLSUM_SPLITS = 32;
 int lr_colsum_partial(const float* x, int ld, int rows, int ncol, float* partial, hipStream_t stream);
+
+// ---- optional instrumentation (bench.py roofline leg; lr_misc.hip) ------------------------------
+// While enabled, selected launches are issued through hipExtLaunchKernelGGL with a hipEvent pair
+// that stamps the dispatch's own begin/end on the stream it runs on (what rocprofv3's kernel trace
+// reports).  lr_prof_next hands out the pair for the next sample of a slot, or returns false.
+enum {
+  LR_PROF_RNN_FWD = 0, LR_PROF_RNN_BWD = 1,
+  LR_PROF_CONV1_FWD = 2, LR_PROF_CONV2_FWD = 3, LR_PROF_CONV3_FWD = 4,
+  LR_PROF_CONV2_DGRAD = 5, LR_PROF_CONV3_DGRAD = 6,
+  LR_PROF_CONV1_WGRAD = 7, LR_PROF_CONV2_WGRAD = 8, LR_PROF_CONV3_WGRAD = 9,
+  LR_PROF_SLOTS = 10
+};
+bool lr_prof_next(int slot, hipEvent_t* start, hipEvent_t* stop);

@@ -19,6 +19,7 @@
 // down the columns (ds_read_u16).  K is split over workgroups into fp32 slabs that a second kernel
 // reduces in fixed order (deterministic) into the torch-layout gradient.
 #include "lr_common.h"
+#include <hip/hip_ext.h>
 #include <type_traits>
 
 namespace {
@@ -44,9 +45,6 @@ struct ConvGeom {
   int64_t M;                 // B*T*Ho*Wo
 };
 
-constexpr int BM = 128;   // output pixels per workgroup
-constexpr int BK = 32;    // k per LDS stage
-constexpr int LDS_LD = BK + 8;  // bf16 elements per LDS row (80 B: 16-B aligned rows)
 
 // Gather one 8-byte unit (4 consecutive k) of im2col row `m` at k index `k` (k % 4 == 0).
 // The row's output coordinates are pre-decoded into (b*T + t, hi0, wi0).
@@ -575,7 +573,20 @@ extern "C" int lr_conv3d_forward(const void* X, const void* Wp, const float* bia
   const bf16_t* x = (const bf16_t*)X;
   const bf16_t* w = (const bf16_t*)Wp;
   bf16_t* y = (bf16_t*)Y;
-#define LR_IGEMM(CI, NTT) LR_LAUNCH((conv3d_igemm_kernel<CI, NTT>), grid, dim3(256), 0, stream, g, x, w, bias, y, relu)
+  // instrumentation slot: forward layers by input channels, data gradients by (Cin, relu == 0)
+  int slot = -1;
+  if (relu) slot = Cin == 4 ? LR_PROF_CONV1_FWD : (Cin == 32 ? LR_PROF_CONV2_FWD : LR_PROF_CONV3_FWD);
+  else if (!bias) slot = Cin == 64 ? LR_PROF_CONV2_DGRAD : (Cin == 96 ? LR_PROF_CONV3_DGRAD : -1);
+  hipEvent_t e0, e1;
+  const bool sample = lr_prof_next(slot, &e0, &e1);
+#define LR_IGEMM(CI, NTT)                                                                              \
+  do {                                                                                                 \
+    lr_clear_error();                                                                                  \
+    if (sample) hipExtLaunchKernelGGL((conv3d_igemm_kernel<CI, NTT>), grid, dim3(256), 0,               \
+                                      (hipStream_t)stream, e0, e1, 0, g, x, w, bias, y, relu);         \
+    else hipLaunchKernelGGL((conv3d_igemm_kernel<CI, NTT>), grid, dim3(256), 0, (hipStream_t)stream, g, \
+                            x, w, bias, y, relu);                                                      \
+  } while (0)
   const int nt = Cout / 32;
   if (Cin == 4 && nt == 1) LR_IGEMM(4, 1);
   else if (Cin == 32 && nt == 2) LR_IGEMM(32, 2);
@@ -616,7 +627,18 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
   const dim3 grid((g.Ktot + nc - 1) / nc, splits);
   const bf16_t* x = (const bf16_t*)X;
   const bf16_t* dz = (const bf16_t*)dZ;
-#define LR_WGRAD(CI, MTT, NTT) LR_LAUNCH((conv3d_wgrad_kernel<CI, MTT, NTT>), grid, dim3(256), 0, stream, g, x, dz, slabs, per)
+  hipEvent_t e0, e1;
+  const bool sample = lr_prof_next(Cin_pad == 4 ? LR_PROF_CONV1_WGRAD
+                                                : (Cin_pad == 32 ? LR_PROF_CONV2_WGRAD : LR_PROF_CONV3_WGRAD),
+                                   &e0, &e1);
+#define LR_WGRAD(CI, MTT, NTT)                                                                          \
+  do {                                                                                                  \
+    lr_clear_error();                                                                                   \
+    if (sample) hipExtLaunchKernelGGL((conv3d_wgrad_kernel<CI, MTT, NTT>), grid, dim3(256), 0,           \
+                                      (hipStream_t)stream, e0, e1, 0, g, x, dz, slabs, per);            \
+    else hipLaunchKernelGGL((conv3d_wgrad_kernel<CI, MTT, NTT>), grid, dim3(256), 0, (hipStream_t)stream, \
+                            g, x, dz, slabs, per);                                                      \
+  } while (0)
   if (Cin_pad == 4 && Cout == 32) LR_WGRAD(4, 1, 5);
   else if (Cin_pad == 32 && Cout == 64) LR_WGRAD(32, 2, 4);
   else if (Cin_pad == 64 && Cout == 96) LR_WGRAD(64, 3, 2);

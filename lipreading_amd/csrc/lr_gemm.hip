@@ -246,20 +246,22 @@ struct GemmPlan {
 GemmPlan plan_gemm(int M, int N, int K, size_t ws_bytes) {
   GemmPlan p;
   const long tiles_big = (long)((M + 127) / 128) * ((N + 127) / 128);
-  p.big = tiles_big >= 48;   // 128x128 tiles (4 MFMA tiles per wave) unless the output is tiny;
-                             // split-K below tops the grid up to the CU count
-  const int bm = p.big ? 128 : 64;
-  const long tiles = (long)((M + bm - 1) / bm) * ((N + bm - 1) / bm);
+  const long tiles_small = (long)((M + 63) / 64) * ((N + 63) / 64);
+  // how far split-K may go: >= 64 k per split, slabs must fit the caller's workspace
+  long max_split = K / (4 * BK);
+  const long max_by_ws = (long)(ws_bytes / ((size_t)M * N * sizeof(float)));
+  if (max_split > max_by_ws) max_split = max_by_ws;
+  if (max_split > 64) max_split = 64;
+  if (max_split < 1) max_split = 1;
+  // 128x128 tiles (4 MFMA tiles per wave) are ~2x as efficient per workgroup as 64x64, but only
+  // pay off when tiles x splits can cover the 256 CUs; otherwise take the finer tiling.
+  p.big = tiles_big * max_split >= 200;
+  const long tiles = p.big ? tiles_big : tiles_small;
   p.splits = 1;
-  if (tiles < 256 && K >= 8 * BK) {
+  if (tiles < 256 && max_split >= 2) {
     long want = (512 + tiles - 1) / tiles;            // aim at ~2 workgroups per CU
-    long max_by_k = K / (4 * BK);                     // keep >= 64 k per split
-    long max_by_ws = (long)(ws_bytes / ((size_t)M * N * sizeof(float)));
-    long s = want;
-    if (s > max_by_k) s = max_by_k;
-    if (s > max_by_ws) s = max_by_ws;
-    if (s > 64) s = 64;
-    if (s >= 2) p.splits = (int)s;
+    if (want > max_split) want = max_split;
+    if (want >= 2) p.splits = (int)want;
   }
   int chunk = (K + p.splits - 1) / p.splits;
   chunk = (chunk + BK - 1) / BK * BK;

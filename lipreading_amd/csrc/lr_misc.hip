@@ -8,6 +8,7 @@
 //   src/utils/data/face.py:164-175    getFace (translate x,y by the padded rect origin)
 //   src/train/train_better_model.py:78-80  clip_grad_norm_ + Adam.step
 #include "lr_common.h"
+#include <hip/hip_ext.h>
 
 extern "C" int lr_version(void) { return 100; /* 0.1.0 */ }
 
@@ -238,4 +239,66 @@ int lr_colsum_partial(const float* x, int ld, int rows, int ncol, float* partial
   LR_LAUNCH(colsum_partial_kernel, dim3((ncol + 63) / 64, LR_COLSUM_SPLITS), dim3(256), 0, stream, x,
             ld, rows, ncol, partial);
   return lr_launch_status();
+}
+
+// ---- instrumentation ----------------------------------------------------------------------------
+namespace {
+constexpr int kProfRing = 1024;
+struct ProfSlot {
+  hipEvent_t start[kProfRing], stop[kProfRing];
+  int count;
+  bool ready;
+};
+ProfSlot g_prof[LR_PROF_SLOTS];
+bool g_prof_on = false;
+}  // namespace
+
+bool lr_prof_next(int slot, hipEvent_t* start, hipEvent_t* stop) {
+  if (!g_prof_on || slot < 0 || slot >= LR_PROF_SLOTS) return false;
+  ProfSlot& p = g_prof[slot];
+  if (!p.ready || p.count >= kProfRing) return false;
+  *start = p.start[p.count];
+  *stop = p.stop[p.count];
+  ++p.count;
+  return true;
+}
+
+extern "C" int lr_profile_enable(int on) {
+  if (on && !g_prof_on) {
+    for (int w = 0; w < LR_PROF_SLOTS; ++w) {
+      ProfSlot& p = g_prof[w];
+      if (!p.ready) {
+        for (int i = 0; i < kProfRing; ++i) {
+          if (hipEventCreate(&p.start[i]) != hipSuccess || hipEventCreate(&p.stop[i]) != hipSuccess) {
+            (void)hipGetLastError();
+            return LR_ERR_NO_DEVICE;
+          }
+        }
+        p.ready = true;
+      }
+      p.count = 0;
+    }
+  }
+  g_prof_on = on != 0;
+  return LR_OK;
+}
+
+extern "C" int lr_profile_read(int which, float* total_ms_host, int* samples_host) {
+  LR_CHECK_ARG(which >= 0 && which < LR_PROF_SLOTS && total_ms_host && samples_host);
+  ProfSlot& p = g_prof[which];
+  float total = 0.f;
+  int n = 0;
+  for (int i = 0; i < p.count; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.stop[i]) == hipSuccess &&
+        hipEventElapsedTime(&ms, p.start[i], p.stop[i]) == hipSuccess) {
+      total += ms;
+      ++n;
+    }
+  }
+  (void)hipGetLastError();
+  p.count = 0;
+  *total_ms_host = total;
+  *samples_host = n;
+  return LR_OK;
 }

@@ -464,75 +464,12 @@ WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
   return l;
 }
 
-// ---- optional instrumentation (bench.py roofline leg) -----------------------------------------
-// One step launch per layer call (the middle one) is issued through hipExtLaunchKernelGGL with a
-// hipEvent pair, which stamps the dispatch's own begin/end times on the stream the kernel runs
-// on (what rocprofv3's kernel trace reports); lr_profile_read averages the pairs.
-constexpr int kProfRing = 2048;
-struct ProfSlot {
-  hipEvent_t start[kProfRing], stop[kProfRing];
-  int count;
-  bool ready;
-};
-ProfSlot g_prof[2];
-bool g_prof_on = false;
-
-// Returns the event pair for the next sample of `which`, or false when not sampling.
-bool prof_next(int which, hipEvent_t* start, hipEvent_t* stop) {
-  ProfSlot& p = g_prof[which];
-  if (!g_prof_on || !p.ready || p.count >= kProfRing) return false;
-  *start = p.start[p.count];
-  *stop = p.stop[p.count];
-  ++p.count;
-  return true;
-}
-
 bool dims_ok(int mode, int B, int T, int I, int H, int D) {
   return (mode == LR_RNN_GRU || mode == LR_RNN_LSTM) && B > 0 && T > 0 && I > 0 && H > 0 &&
          (D == 1 || D == 2);
 }
 
 }  // namespace
-
-extern "C" int lr_profile_enable(int on) {
-  if (on && !g_prof_on) {
-    for (int w = 0; w < 2; ++w) {
-      ProfSlot& p = g_prof[w];
-      if (!p.ready) {
-        for (int i = 0; i < kProfRing; ++i) {
-          if (hipEventCreate(&p.start[i]) != hipSuccess || hipEventCreate(&p.stop[i]) != hipSuccess) {
-            (void)hipGetLastError();
-            return LR_ERR_NO_DEVICE;
-          }
-        }
-        p.ready = true;
-      }
-      p.count = 0;
-    }
-  }
-  g_prof_on = on != 0;
-  return LR_OK;
-}
-
-extern "C" int lr_profile_read(int which, float* total_ms_host, int* samples_host) {
-  LR_CHECK_ARG((which == 0 || which == 1) && total_ms_host && samples_host);
-  ProfSlot& p = g_prof[which];
-  float total = 0.f;
-  int n = 0;
-  for (int i = 0; i < p.count; ++i) {
-    float ms = 0.f;
-    if (hipEventSynchronize(p.stop[i]) == hipSuccess &&
-        hipEventElapsedTime(&ms, p.start[i], p.stop[i]) == hipSuccess) {
-      total += ms;
-      ++n;
-    }
-  }
-  (void)hipGetLastError();
-  p.count = 0;
-  *total_ms_host = total;
-  *samples_host = n;
-  return LR_OK;
-}
 
 extern "C" size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D)) return 0;
@@ -591,7 +528,7 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
   const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, D);
   for (int s = 0; s < T; ++s) {
     hipEvent_t e0, e1;
-    if (s == T / 2 && prof_next(0, &e0, &e1)) {
+    if (s == T / 2 && lr_prof_next(LR_PROF_RNN_FWD, &e0, &e1)) {
       // sampled launch: the events carry the dispatch's own begin/end timestamps
       lr_clear_error();
       if (G == 3) hipExtLaunchKernelGGL(rnn_fwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, hp, lens, p, B, T, H, D, s);
@@ -663,7 +600,7 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
   const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, D);
   for (int s = 0; s < T; ++s) {
     hipEvent_t e0, e1;
-    if (s == T / 2 && prof_next(1, &e0, &e1)) {
+    if (s == T / 2 && lr_prof_next(LR_PROF_RNN_BWD, &e0, &e1)) {
       lr_clear_error();
       if (G == 3) hipExtLaunchKernelGGL(rnn_bwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
       else hipExtLaunchKernelGGL(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
