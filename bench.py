@@ -193,17 +193,35 @@ def run_regime(args, regime, world, rank, dev):
     return loss.detach(), status
 
   graph = None
+  graph_note = None
   if use_graph:
-    # one hipGraph for the few hundred launches of forward+backward
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-      for _ in range(2):
-        fwd_bwd()
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-      g_loss, g_status = fwd_bwd()
+    # one hipGraph for the few hundred launches of forward+backward.  thread_local capture mode:
+    # RCCL's watchdog thread may touch the runtime while this thread captures.
+    try:
+      torch.cuda.synchronize()
+      if world > 1:
+        dist.barrier()
+      side = torch.cuda.Stream()
+      side.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(side):
+        for _ in range(2):
+          fwd_bwd()
+      torch.cuda.current_stream().wait_stream(side)
+      torch.cuda.synchronize()
+      graph = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        g_loss, g_status = fwd_bwd()
+    except Exception as e:   # fall back to eager launches rather than lose the measurement
+      graph = None
+      graph_note = "hipGraph capture failed (%s); eager launches" % type(e).__name__
+      torch.cuda.synchronize()
+    # every rank must take the same path (a collective follows each step either way)
+    if world > 1:
+      ok = torch.tensor([1 if graph is not None else 0], device=dev)
+      dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+      if int(ok.item()) == 0:
+        graph = None
+    use_graph = graph is not None
 
   def step():
     if graph is not None:
@@ -249,7 +267,7 @@ def run_regime(args, regime, world, rank, dev):
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
   elapsed = float(el.item())
   res = {"regime": regime, "elapsed": elapsed, "loss": float(loss.item()), "skipped": int(status.item()),
-         "layers": layers, "use_graph": use_graph}
+         "layers": layers, "use_graph": use_graph, "graph_note": graph_note}
   if rank != 0:
     return res
 
@@ -358,7 +376,8 @@ def main():
         "config": {"workload": head["workload"], "regime": head["regime"], "model": args.model,
                    "recurrent_layers": head["layers"], "per_gpu_batch": args.batch,
                    "global_batch": world * args.batch, "seq_len": T_FRAMES, "parallelism": "dp%d" % world,
-                   "launch": "hipGraph replay of forward+backward" if head["use_graph"] else "eager"},
+                   "launch": "hipGraph replay of forward+backward" if head["use_graph"]
+                             else (head.get("graph_note") or "eager")},
         "final_loss": round(head["loss"], 6), "skipped_last": head["skipped"],
         "roofline": head["roofline"],
     }

@@ -80,6 +80,14 @@ int lr_lmk_apply_padding(const int32_t* rects_in, const int32_t* dims, int32_t* 
 int lr_lmk_translate(const float* lmk_in, const int32_t* rects, float* lmk_out, int n,
                      int npts, lr_stream_t stream);
 
+/* A9 (BUILD-DEFINED, no reference symbol: face.py:21 defines `_mouth = slice(48,68)` and never uses
+ * it): crop the mouth region and resample it to S x S.  Per frame: bounding box of landmarks
+ * [lo,hi) (x = lmk[..,0], y = lmk[..,1], image pixels) -> centre, side = max(w,h)*(1+2*margin)
+ * (>= 2 px) -> bilinear resize with half-pixel centres and edge clamping, rounded to uint8.
+ *   frames uint8 [n][3][H][W], lmk f32 [n][npts][3], out uint8 [n][3][S][S]. */
+int lr_lip_crop_u8(const void* frames, const float* lmk, void* out, int n, int H, int W, int S, int npts,
+                   int lo, int hi, float margin, lr_stream_t stream);
+
 /* ---- dense fp32 contraction (MFMA f32 16x16x4 / 32x32x2), used by A3 ------------------- */
 
 /* C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C + bias[N]   (row-major, fp32)

@@ -21,6 +21,7 @@ SIGNATURES = {
     "lr_collate_pad_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "lr_lmk_apply_padding": (c_int, [P, P, P, c_int, c_float, P]),
     "lr_lmk_translate": (c_int, [P, P, P, c_int, c_int, P]),
+    "lr_lip_crop_u8": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     "lr_sgemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "lr_sgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, P, c_int, P, c_int, c_float,
                           P, c_int, P, c_int, c_int, P, c_size_t, P]),

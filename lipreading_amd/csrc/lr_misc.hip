@@ -241,6 +241,62 @@ int lr_colsum_partial(const float* x, int ld, int rows, int ncol, float* partial
   return lr_launch_status();
 }
 
+// ---- A9 (BUILD-DEFINED): mouth crop + bilinear resize ------------------------------------------------
+// The reference defines `_mouth = slice(48, 68)` (src/utils/data/face.py:21) and never uses it; it
+// has no pixel lip crop.  Specification of this build: per frame, the bounding box
+// of landmarks [lo,hi) in image coordinates -> centre (cx,cy), side = max(w,h)*(1+2*margin), at least
+// 2 px -> square window resampled to S x S with bilinear interpolation, half-pixel centres, source
+// coordinates clamped to the image (edge replication), result rounded to nearest uint8.
+__global__ void lip_crop_kernel(const unsigned char* __restrict__ frames, const float* __restrict__ lmk,
+                                unsigned char* __restrict__ out, int H, int W, int S, int npts, int lo,
+                                int hi, float margin) {
+  __shared__ float box[4];
+  const int n = blockIdx.x;
+  const float* L = lmk + (int64_t)n * npts * 3;
+  if (threadIdx.x == 0) {
+    float x0 = L[lo * 3], x1 = x0, y0 = L[lo * 3 + 1], y1 = y0;
+    for (int p = lo + 1; p < hi; ++p) {
+      const float x = L[p * 3], y = L[p * 3 + 1];
+      x0 = fminf(x0, x); x1 = fmaxf(x1, x); y0 = fminf(y0, y); y1 = fmaxf(y1, y);
+    }
+    float side = fmaxf(x1 - x0, y1 - y0) * (1.f + 2.f * margin);
+    side = fmaxf(side, 2.f);
+    box[0] = 0.5f * (x0 + x1) - 0.5f * side;   // left
+    box[1] = 0.5f * (y0 + y1) - 0.5f * side;   // top
+    box[2] = side / (float)S;                  // source pixels per output pixel
+  }
+  __syncthreads();
+  const float left = box[0], top = box[1], scale = box[2];
+  const unsigned char* F = frames + (int64_t)n * 3 * H * W;
+  unsigned char* O = out + (int64_t)n * 3 * S * S;
+  for (int i = threadIdx.x; i < 3 * S * S; i += blockDim.x) {
+    const int c = i / (S * S), r = i - c * S * S;
+    const int oy = r / S, ox = r - oy * S;
+    float sx = left + ((float)ox + 0.5f) * scale - 0.5f;
+    float sy = top + ((float)oy + 0.5f) * scale - 0.5f;
+    sx = fminf(fmaxf(sx, 0.f), (float)(W - 1));
+    sy = fminf(fmaxf(sy, 0.f), (float)(H - 1));
+    const int ix = (int)floorf(sx), iy = (int)floorf(sy);
+    const int ix1 = min(ix + 1, W - 1), iy1 = min(iy + 1, H - 1);
+    const float fx = sx - (float)ix, fy = sy - (float)iy;
+    const unsigned char* P = F + (int64_t)c * H * W;
+    const float a = (float)P[iy * W + ix], b = (float)P[iy * W + ix1];
+    const float d = (float)P[iy1 * W + ix], e = (float)P[iy1 * W + ix1];
+    const float top_v = a + (b - a) * fx, bot_v = d + (e - d) * fx;
+    const float v = top_v + (bot_v - top_v) * fy;
+    O[i] = (unsigned char)fminf(fmaxf(floorf(v + 0.5f), 0.f), 255.f);
+  }
+}
+
+extern "C" int lr_lip_crop_u8(const void* frames, const float* lmk, void* out, int n, int H, int W, int S,
+                              int npts, int lo, int hi, float margin, lr_stream_t stream) {
+  LR_CHECK_ARG(frames && lmk && out && n > 0 && H > 0 && W > 0 && S > 0);
+  LR_CHECK_ARG(npts > 0 && lo >= 0 && hi > lo && hi <= npts && margin >= 0.f);
+  LR_LAUNCH(lip_crop_kernel, dim3(n), dim3(256), 0, stream, (const unsigned char*)frames, lmk,
+            (unsigned char*)out, H, W, S, npts, lo, hi, margin);
+  return lr_launch_status();
+}
+
 // ---- instrumentation ----------------------------------------------------------------------------
 namespace {
 constexpr int kProfRing = 1024;

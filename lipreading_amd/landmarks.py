@@ -42,3 +42,21 @@ def get_face(lmks, rects):
   _C.check(_C.lib().lr_lmk_translate(x.data_ptr(), r.data_ptr(), out.data_ptr(), x.shape[0],
                                      x.shape[1], _C.stream_handle()), "lr_lmk_translate")
   return out
+
+
+def lip_crop(frames, lmks, size=96, margin=0.3, mouth=_mouth):
+  """BUILD-DEFINED (the reference never crops the mouth, face.py:21 is unused):
+  frames (n,3,H,W) uint8 + landmarks (n,68,3) in image pixels -> (n,3,size,size) uint8 mouth crops:
+  bounding box of landmarks `mouth` -> square window of side max(w,h)*(1+2*margin) about its centre
+  -> bilinear resize (half-pixel centres, edge clamping), rounded to nearest."""
+  _C.require_cuda(frames, lmks)
+  assert frames.dim() == 4 and frames.shape[1] == 3 and frames.dtype == torch.uint8
+  assert lmks.dim() == 3 and lmks.shape[2] == 3 and lmks.shape[0] == frames.shape[0]
+  f = frames.contiguous()
+  l = lmks.to(torch.float32).contiguous()
+  n, _, H, W = f.shape
+  out = torch.empty((n, 3, size, size), dtype=torch.uint8, device=f.device)
+  _C.check(_C.lib().lr_lip_crop_u8(f.data_ptr(), l.data_ptr(), out.data_ptr(), n, H, W, size, l.shape[1],
+                                   mouth.start, mouth.stop, float(margin), _C.stream_handle()),
+           "lr_lip_crop_u8")
+  return out

@@ -284,3 +284,36 @@ def conv_frontend(clips, params, emulate_bf16=True):
     x = F.max_pool3d(x, (1, 2, 2))
   B, C, T, h, w_ = x.shape
   return x.permute(0, 2, 3, 4, 1).reshape(B, T, h * w_ * C)
+
+
+# ------------------------------------------------------------------------------------------
+# A9: mouth crop — BUILD-DEFINED (the reference defines `_mouth = slice(48, 68)` at
+# src/utils/data/face.py:21 and never uses it).  Same formula as lr_lip_crop_u8, in float32 numpy.
+# ------------------------------------------------------------------------------------------
+def lip_crop(frames, lmks, size=96, margin=0.3, lo=48, hi=68):
+  frames = np.asarray(frames)
+  lmks = np.asarray(lmks, dtype=np.float32)
+  n, _, H, W = frames.shape
+  out = np.zeros((n, 3, size, size), dtype=np.uint8)
+  f32 = np.float32
+  for i in range(n):
+    x, y = lmks[i, lo:hi, 0], lmks[i, lo:hi, 1]
+    x0, x1, y0, y1 = x.min(), x.max(), y.min(), y.max()
+    side = max(f32(max(x1 - x0, y1 - y0)) * f32(f32(1) + f32(2) * f32(margin)), f32(2))
+    left = f32(0.5) * (x0 + x1) - f32(0.5) * side
+    top = f32(0.5) * (y0 + y1) - f32(0.5) * side
+    scale = f32(side / f32(size))
+    o = np.arange(size, dtype=np.float32)
+    sx = np.clip(left + (o + f32(0.5)) * scale - f32(0.5), 0, W - 1).astype(np.float32)
+    sy = np.clip(top + (o + f32(0.5)) * scale - f32(0.5), 0, H - 1).astype(np.float32)
+    ix, iy = np.floor(sx).astype(int), np.floor(sy).astype(int)
+    ix1, iy1 = np.minimum(ix + 1, W - 1), np.minimum(iy + 1, H - 1)
+    fx, fy = (sx - ix).astype(np.float32), (sy - iy).astype(np.float32)
+    img = frames[i].astype(np.float32)
+    a, b = img[:, iy][:, :, ix], img[:, iy][:, :, ix1]
+    d, e = img[:, iy1][:, :, ix], img[:, iy1][:, :, ix1]
+    tv = a + (b - a) * fx[None, None, :]
+    bv = d + (e - d) * fx[None, None, :]
+    v = tv + (bv - tv) * fy[None, :, None]
+    out[i] = np.clip(np.floor(v + f32(0.5)), 0, 255).astype(np.uint8)
+  return out

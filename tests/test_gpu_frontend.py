@@ -111,3 +111,26 @@ def test_pixel_lipreader_trains_end_to_end(dev):
     opt.step(grad_norm=50, skip=status)
     losses.append(float(loss))
   assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], losses
+
+
+def test_lip_crop_matches_oracle(dev):
+  """A9 (build-defined): mouth-landmark bounding box -> square window -> bilinear 96x96."""
+  from lipreading_amd.landmarks import lip_crop
+  rng = np.random.RandomState(123456)
+  n, H, W = 6, 120, 160
+  frames = rng.randint(0, 256, (n, 3, H, W)).astype(np.uint8)
+  lm = np.zeros((n, 68, 3), np.float32)
+  lm[:, :, 0] = rng.uniform(20, 140, (n, 68))
+  lm[:, :, 1] = rng.uniform(20, 100, (n, 68))
+  lm[0, 48:68, 0] = rng.uniform(60, 100, 20); lm[0, 48:68, 1] = rng.uniform(70, 90, 20)
+  lm[1, 48:68, 0] = rng.uniform(-5, 12, 20)                      # window hangs over the left edge
+  lm[2, 48:68, :2] = 50.0                                        # degenerate box -> minimum side
+  want = O.lip_crop(frames, lm)
+  got = lip_crop(torch.tensor(frames, device=dev), torch.tensor(lm, device=dev)).cpu().numpy()
+  assert got.shape == (n, 3, 96, 96) and got.dtype == np.uint8
+  diff = np.abs(got.astype(int) - want.astype(int))
+  assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (diff.max(), (diff > 0).mean())
+  # a crop of a constant image is constant; a crop feeds the frontend as-is
+  flat = lip_crop(torch.full((1, 3, 64, 64), 77, dtype=torch.uint8, device=dev),
+                  torch.tensor(lm[:1], device=dev))
+  assert int(flat.min()) == int(flat.max()) == 77
