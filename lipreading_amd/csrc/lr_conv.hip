@@ -343,6 +343,170 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(ConvGeom g, const bf1
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// tap-stationary weight gradient for stride-1 "same" layers with Cin in {32,64} (layers 2 and 3)
+// ---------------------------------------------------------------------------------------------
+// dW[n][tap][c] = sum_pixels dZ[pix][n] * X[pix + tap][c].  Instead of building im2col rows (each
+// input value would be gathered once per tap), a workgroup keeps the accumulators of ALL taps of
+// one temporal offset kt resident in registers and walks over spatial tiles: for every tile it
+// brings the dZ tile and ONE input patch (tile + halo, frame t+kt-pt) into LDS; every tap's
+// operand is then just a shifted window of that patch.  Work split: unit = (tap, 32-channel block
+// of Cin); wave w owns units w, w+4, ... with all MT row tiles, so each dZ fragment read from LDS
+// feeds UPW*MT MFMAs.  Tiles are TY rows x the full (8-padded) width, pixels row-major, so an
+// 8-pixel k group never straddles a row.  The next tile is prefetched into registers while the
+// current one is contracted.  Per-workgroup partials go to slabs, reduced in fixed order.
+template <int CIN, int MT, int UPW>
+__global__ __launch_bounds__(256) void conv3d_wgrad_ts_kernel(ConvGeom g, const bf16_t* __restrict__ X,
+                                                              const bf16_t* __restrict__ dZ,
+                                                              float* __restrict__ slabs, int TY, int TXP,
+                                                              int wgs_per_kt) {
+  constexpr int NTC = CIN / 32;
+  constexpr int ZLD = MT * 32 + 8;
+  constexpr int PLD = CIN + 8;
+  constexpr int ZU = MT * 4;        // 16-byte units per dZ pixel
+  constexpr int PU = CIN / 8;       // 16-byte units per patch pixel
+  constexpr int MAXU = 6;           // prefetch registers per operand (uint4 each)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int NPIX = TY * TXP;
+  const int PH = TY + g.KH - 1, PW = TXP + g.KW - 1;
+  bf16_t* Zs = reinterpret_cast<bf16_t*>(smem_raw);              // [NPIX][ZLD]
+  bf16_t* Ps = Zs + (size_t)NPIX * ZLD;                           // [PH][PW][PLD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lk = lane >> 5;
+  const int kt = blockIdx.x % g.KT, slot = blockIdx.x / g.KT;
+  const int H = g.Ho, W = g.Wo;
+  const int RB = (H + TY - 1) / TY;
+  const int64_t ntiles = (int64_t)g.B * g.T * RB;
+  const int khw = g.KH * g.KW, units = khw * NTC;
+  const int nz_units = NPIX * ZU, np_units = PH * PW * PU;
+
+  // this wave's units: (kh, kw, nt) -> patch offset of pixel (0,0) and column block
+  int u_off[UPW], u_tap[UPW], u_nt[UPW];
+#pragma unroll
+  for (int j = 0; j < UPW; ++j) {
+    const int u = wave + 4 * j;
+    const int tap = u < units ? u / NTC : 0;
+    u_tap[j] = tap;
+    u_nt[j] = u % NTC;
+    u_off[j] = ((tap / g.KW) * PW + (tap % g.KW)) * PLD + u_nt[j] * 32 + lr;
+  }
+  f32x16 acc[UPW][MT];
+#pragma unroll
+  for (int j = 0; j < UPW; ++j)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+  uint4 rz[MAXU], rp[MAXU];
+  auto tile_valid = [&](int64_t q) -> bool {
+    const int f = (int)(q / RB);
+    const int ti = f % g.T + kt - g.pt;
+    return ti >= 0 && ti < g.T;
+  };
+  auto load_tile = [&](int64_t q) {
+    const int f = (int)(q / RB), y0 = (int)(q % RB) * TY;
+    const int fi = f + kt - g.pt;
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+      const int e = tid + i * 256;
+      rz[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (e < nz_units) {
+        const int pix = e / ZU, u = e - pix * ZU;
+        const int yl = pix / TXP, x = pix - yl * TXP;
+        if (y0 + yl < H && x < W)
+          rz[i] = *reinterpret_cast<const uint4*>(dZ + (((int64_t)f * H + y0 + yl) * W + x) * g.Cout + u * 8);
+      }
+      rp[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (e < np_units) {
+        const int pp = e / PU, u = e - pp * PU;
+        const int r = pp / PW, cx = pp - r * PW;
+        const int yi = y0 + r - g.ph, xi = cx - g.pw;
+        if (yi >= 0 && yi < H && xi >= 0 && xi < W)
+          rp[i] = *reinterpret_cast<const uint4*>(X + (((int64_t)fi * H + yi) * W + xi) * CIN + u * 8);
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+      const int e = tid + i * 256;
+      if (e < nz_units) *reinterpret_cast<uint4*>(&Zs[(e / ZU) * ZLD + (e % ZU) * 8]) = rz[i];
+      if (e < np_units) *reinterpret_cast<uint4*>(&Ps[(e / PU) * PLD + (e % PU) * 8]) = rp[i];
+    }
+  };
+
+  // first valid tile of this workgroup
+  int64_t q = slot;
+  while (q < ntiles && !tile_valid(q)) q += wgs_per_kt;
+  if (q < ntiles) load_tile(q);
+  while (q < ntiles) {
+    __syncthreads();          // everyone is done reading the previous tile
+    store_tile();
+    __syncthreads();
+    int64_t qn = q + wgs_per_kt;
+    while (qn < ntiles && !tile_valid(qn)) qn += wgs_per_kt;
+    if (qn < ntiles) load_tile(qn);   // in flight while the MFMAs below run
+    const int nks = NPIX >> 4;
+    for (int ks = 0; ks < nks; ++ks) {
+      const int p0 = ks * 16 + lk * 8;
+      const int yl = p0 / TXP, x0 = p0 - yl * TXP;
+      bf16x8 a[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          a[i][e] = __builtin_bit_cast(__bf16, Zs[(p0 + e) * ZLD + i * 32 + lr]);
+      const int pbase = (yl * PW + x0) * PLD;
+#pragma unroll
+      for (int j = 0; j < UPW; ++j) {
+        if (wave + 4 * j < units) {
+          bf16x8 b;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            b[e] = __builtin_bit_cast(__bf16, Ps[pbase + e * PLD + u_off[j]]);
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b, acc[j][i], 0, 0, 0);
+        }
+      }
+    }
+    q = qn;
+  }
+  // partial result of this workgroup: slabs[wg][tap][n][c]
+  float* out = slabs + (int64_t)blockIdx.x * khw * g.Cout * CIN;
+#pragma unroll
+  for (int j = 0; j < UPW; ++j) {
+    if (wave + 4 * j < units) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          out[((int64_t)u_tap[j] * g.Cout + n) * CIN + u_nt[j] * 32 + lr] = acc[j][i][r];
+        }
+    }
+  }
+}
+
+// dW[n][c][kt][kh][kw] (+)= sum_slot slabs[slot*KT + kt][kh*KW + kw][n][c]
+__global__ void conv3d_wgrad_ts_reduce_kernel(const float* __restrict__ slabs, int wgs_per_kt,
+                                              float* __restrict__ dW, int Cout, int Cin, int KT, int khw,
+                                              int accumulate) {
+  const int64_t total = (int64_t)Cout * Cin * KT * khw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int t2 = (int)(i % khw);
+    const int kt = (int)((i / khw) % KT);
+    const int c = (int)((i / ((int64_t)khw * KT)) % Cin);
+    const int n = (int)(i / ((int64_t)khw * KT * Cin));
+    float s = 0.f;
+    for (int z = 0; z < wgs_per_kt; ++z)
+      s += slabs[((((int64_t)z * KT + kt) * khw + t2) * Cout + n) * Cin + c];
+    dW[i] = accumulate ? dW[i] + s : s;
+  }
+}
+
 // dW[n][c][kt][kh][kw] (fp32, torch layout) (+)= sum_splits slab[split][n][(tap, c)], c < Cin_real
 __global__ void conv3d_wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, float* __restrict__ dW,
                                            int Cout, int Cin_real, int Cin_pad, int taps, int accumulate) {
@@ -542,6 +706,7 @@ static int wgrad_splits(int Cout, int Ktot) {
   return s;
 }
 constexpr int kColsumSplits = 256;
+constexpr int kTsWgsPerKt = 85;   // 3 temporal offsets x 85 = 255 resident workgroups
 
 }  // namespace
 
@@ -606,7 +771,10 @@ extern "C" int lr_conv3d_forward(const void* X, const void* Wp, const float* bia
 extern "C" size_t lr_conv3d_wgrad_workspace_bytes(int Cout, int Cin_pad, int KT, int KH, int KW) {
   if (Cout <= 0 || Cin_pad <= 0) return 0;
   const int Ktot = KT * KH * KW * Cin_pad;
-  return ((size_t)wgrad_splits(Cout, Ktot) * Cout * Ktot + (size_t)kColsumSplits * Cout) * sizeof(float);
+  size_t slab = (size_t)wgrad_splits(Cout, Ktot) * Cout * Ktot;
+  const size_t ts = (size_t)KT * kTsWgsPerKt * KH * KW * Cout * Cin_pad;   // tap-stationary path
+  if (ts > slab) slab = ts;
+  return (slab + (size_t)kColsumSplits * Cout) * sizeof(float);
 }
 
 extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* dbias, void* workspace,
@@ -619,18 +787,69 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
   if (workspace_bytes < lr_conv3d_wgrad_workspace_bytes(Cout, Cin_pad, KT, KH, KW)) return LR_ERR_WORKSPACE;
   const int max_splits = wgrad_splits(Cout, g.Ktot);
   float* slabs = (float*)workspace;
-  float* cpart = slabs + (size_t)max_splits * Cout * g.Ktot;
-  int64_t per = (g.M + max_splits - 1) / max_splits;
-  per = (per + WG_PIX - 1) / WG_PIX * WG_PIX;
-  const int splits = (int)((g.M + per - 1) / per);
-  const int nc = wgrad_ntw(Cout) * 32;
-  const dim3 grid((g.Ktot + nc - 1) / nc, splits);
+  float* cpart = (float*)((char*)workspace + lr_conv3d_wgrad_workspace_bytes(Cout, Cin_pad, KT, KH, KW)) -
+                 (size_t)kColsumSplits * Cout;
   const bf16_t* x = (const bf16_t*)X;
   const bf16_t* dz = (const bf16_t*)dZ;
   hipEvent_t e0, e1;
   const bool sample = lr_prof_next(Cin_pad == 4 ? LR_PROF_CONV1_WGRAD
                                                 : (Cin_pad == 32 ? LR_PROF_CONV2_WGRAD : LR_PROF_CONV3_WGRAD),
                                    &e0, &e1);
+  const bool ts_path = stride == 1 && (Cin_pad == 32 || Cin_pad == 64) && Cin_real == Cin_pad &&
+                       2 * ph + 1 == KH && 2 * pw + 1 == KW && KH * KW * (Cin_pad / 32) <= 28;
+  if (ts_path) {
+    // tile: TY rows x the 8-padded width, at most 192 pixels (12 MFMA k steps) and <= 64 kB of LDS
+    const int TXP = (g.Wo + 7) / 8 * 8;
+    const int MTv = Cout / 32;
+    int TY = 192 / TXP;
+    if (TY > g.Ho) TY = g.Ho;
+    auto fits = [&](int ty) {
+      const size_t bytes = ((size_t)ty * TXP * (MTv * 32 + 8) + (size_t)(ty + KH - 1) * (TXP + KW - 1) * (Cin_pad + 8)) * 2;
+      return (ty * TXP) % 16 == 0 && bytes <= 60 * 1024 && ty * TXP * MTv * 4 <= 6 * 256 &&
+             (ty + KH - 1) * (TXP + KW - 1) * (Cin_pad / 8) <= 6 * 256;
+    };
+    while (TY > 1 && !fits(TY)) --TY;
+    const int npix = TY * TXP;
+    const size_t lds = ((size_t)npix * (MTv * 32 + 8) + (size_t)(TY + KH - 1) * (TXP + KW - 1) * (Cin_pad + 8)) * 2;
+    const int zu = npix * MTv * 4, pu = (TY + KH - 1) * (TXP + KW - 1) * (Cin_pad / 8);
+    const int units = KH * KW * (Cin_pad / 32);
+    const int upw = (units + 3) / 4;
+    if (fits(TY) && zu <= 6 * 256 && pu <= 6 * 256 && upw <= 7) {
+      const dim3 grid(KT * kTsWgsPerKt);
+#define LR_WGTS(CI, MTT, UP)                                                                                 \
+  do {                                                                                                       \
+    lr_clear_error();                                                                                        \
+    if (sample) hipExtLaunchKernelGGL((conv3d_wgrad_ts_kernel<CI, MTT, UP>), grid, dim3(256), lds,            \
+                                      (hipStream_t)stream, e0, e1, 0, g, x, dz, slabs, TY, TXP, kTsWgsPerKt); \
+    else hipLaunchKernelGGL((conv3d_wgrad_ts_kernel<CI, MTT, UP>), grid, dim3(256), lds, (hipStream_t)stream, \
+                            g, x, dz, slabs, TY, TXP, kTsWgsPerKt);                                          \
+  } while (0)
+      bool launched = true;
+      if (Cin_pad == 32 && MTv == 2 && upw == 7) LR_WGTS(32, 2, 7);
+      else if (Cin_pad == 64 && MTv == 3 && upw == 5) LR_WGTS(64, 3, 5);
+      else if (Cin_pad == 32 && MTv == 2 && upw == 3) LR_WGTS(32, 2, 3);
+      else launched = false;
+#undef LR_WGTS
+      if (launched) {
+        int st = lr_launch_status();
+        if (st != LR_OK) return st;
+        LR_LAUNCH(conv3d_wgrad_ts_reduce_kernel, dim3(grid1d((int64_t)Cout * Cin_pad * KT * KH * KW)), dim3(256),
+                  0, stream, (const float*)slabs, kTsWgsPerKt, dW, Cout, Cin_pad, KT, KH * KW, accumulate);
+        st = lr_launch_status();
+        if (st != LR_OK || !dbias) return st;
+        LR_LAUNCH(colsum_bf16_partial_kernel, dim3(kColsumSplits), dim3(256), 0, stream, dz, g.M, Cout, cpart,
+                  kColsumSplits);
+        LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(256), 0, stream, (const float*)cpart, kColsumSplits,
+                  dbias, Cout, accumulate);
+        return lr_launch_status();
+      }
+    }
+  }
+  int64_t per = (g.M + max_splits - 1) / max_splits;
+  per = (per + WG_PIX - 1) / WG_PIX * WG_PIX;
+  const int splits = (int)((g.M + per - 1) / per);
+  const int nc = wgrad_ntw(Cout) * 32;
+  const dim3 grid((g.Ktot + nc - 1) / nc, splits);
 #define LR_WGRAD(CI, MTT, NTT)                                                                          \
   do {                                                                                                  \
     lr_clear_error();                                                                                   \
