@@ -344,6 +344,185 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(ConvGeom g, const bf1
 }
 
 // ---------------------------------------------------------------------------------------------
+// first layer (4-channel padded RGB input, spatial stride 2): patch-resident kernels
+// ---------------------------------------------------------------------------------------------
+// With Cin = 4 an im2col row is 75 separate 8-byte gathers and neighbouring rows overlap almost
+// completely, so the generic implicit GEMM is gather-bound (82 TF/s forward, 36 TF/s weight
+// gradient).  Here a workgroup owns a 16x16 tile of output pixels of one frame and loads the
+// input patch it needs ONCE into LDS: 3 frames x 35 x 35 pixels x 4 channels (29 kB).  Every
+// operand of the forward product and of the weight gradient is then an LDS read at
+// (pixel offset + tap offset): no im2col staging, no barrier inside the K loop.
+constexpr int C1_T = 16;                       // output tile edge
+constexpr int C1_P = 2 * C1_T + 3;             // patch edge (stride 2, 5x5 taps): 35
+constexpr int C1_PIX = C1_T * C1_T;            // 256 output pixels = 8 MFMA row tiles
+constexpr int C1_K = 304;                      // 75 taps x 4 channels = 300, padded to 19 k steps of 16
+constexpr int C1_WLD = C1_K + 8;               // weight row in LDS (624 B: conflict-free b128 reads)
+constexpr int C1_PATCH = 3 * C1_P * C1_P * 4;  // bf16 elements of the patch
+
+// tap t = (kt*5 + kh)*5 + kw  ->  element offset inside the patch [3][35][35][4]
+__device__ __forceinline__ int c1_tap_off(int tap) {
+  if (tap >= 75) return -1;
+  const int kw = tap % 5, kh = (tap / 5) % 5, kt = tap / 25;
+  return ((kt * C1_P + kh) * C1_P + kw) * 4;
+}
+
+// Loads the patch of tile (f, ty, tx): frames t-1..t+1 of clip b, rows 2*y0-2.., cols 2*x0-2..
+__device__ __forceinline__ void c1_load_patch(const bf16_t* __restrict__ X, bf16_t* Ps, int f, int T,
+                                              int Hin, int Win, int y0, int x0, int tid) {
+  const int t = f % T;
+  for (int e = tid; e < 3 * C1_P * C1_P; e += 256) {
+    const int px = e % C1_P, py = (e / C1_P) % C1_P, kt = e / (C1_P * C1_P);
+    const int ti = t + kt - 1, yi = 2 * y0 - 2 + py, xi = 2 * x0 - 2 + px;
+    uint2 v = make_uint2(0u, 0u);
+    if (ti >= 0 && ti < T && yi >= 0 && yi < Hin && xi >= 0 && xi < Win)
+      v = *reinterpret_cast<const uint2*>(X + ((((int64_t)(f + kt - 1)) * Hin + yi) * Win + xi) * 4);
+    *reinterpret_cast<uint2*>(&Ps[e * 4]) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __restrict__ X,
+                                                              const bf16_t* __restrict__ Wp,  // [32][300]
+                                                              const float* __restrict__ bias,
+                                                              bf16_t* __restrict__ Y, int frames, int T,
+                                                              int Hin, int Win, int Ho, int Wo, int relu) {
+  __shared__ __attribute__((aligned(16))) bf16_t Ps[C1_PATCH + 8];
+  __shared__ __attribute__((aligned(16))) bf16_t Ws[32 * C1_WLD];
+  __shared__ int tapoff[80];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lk = lane >> 5;
+  const int tiles_x = (Wo + C1_T - 1) / C1_T, tiles_y = (Ho + C1_T - 1) / C1_T;
+  const int tile = blockIdx.x;
+  const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, f = tile / (tiles_x * tiles_y);
+  const int y0 = ty * C1_T, x0 = tx * C1_T;
+  if (tid < 80) tapoff[tid] = c1_tap_off(tid);
+  for (int e = tid; e < 32 * C1_WLD; e += 256) {
+    const int n = e / C1_WLD, k = e - n * C1_WLD;
+    Ws[e] = k < 300 ? Wp[n * 300 + k] : (bf16_t)0;
+  }
+  c1_load_patch(X, Ps, f, T, Hin, Win, y0, x0, tid);
+  if (tid < 8) Ps[C1_PATCH + tid] = 0;   // landing zone for the padded taps (k >= 300)
+  __syncthreads();
+
+  // wave w: row tiles 2w, 2w+1; row tile m covers pixels (y = 2m + (lr>>4), x = lr & 15)
+  f32x16 acc[2];
+  int pixoff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int yl = 2 * (2 * wave + i) + (lr >> 4), xl = lr & 15;
+    pixoff[i] = ((2 * yl) * C1_P + 2 * xl) * 4;
+  }
+#pragma unroll 1
+  for (int ks = 0; ks < C1_K / 16; ++ks) {
+    const int tap0 = ks * 4 + lk * 2;
+    const int o0 = tapoff[tap0], o1 = tapoff[tap0 + 1];
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(&Ws[lr * C1_WLD + ks * 16 + lk * 8]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint2 lo = *reinterpret_cast<const uint2*>(&Ps[o0 >= 0 ? pixoff[i] + o0 : C1_PATCH]);
+      const uint2 hi = *reinterpret_cast<const uint2*>(&Ps[o1 >= 0 ? pixoff[i] + o1 : C1_PATCH]);
+      const uint4 av = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b, acc[i], 0, 0, 0);
+    }
+  }
+  const float bv = bias ? bias[lr] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int prow = (r & 3) + 8 * (r >> 2) + 4 * lk;         // pixel index inside the row tile
+      const int y = y0 + 2 * (2 * wave + i) + (prow >> 4), x = x0 + (prow & 15);
+      if (y >= Ho || x >= Wo) continue;
+      float v = acc[i][r] + bv;
+      if (relu) v = fmaxf(v, 0.f);
+      Y[(((int64_t)f * Ho + y) * Wo + x) * 32 + lr] = f2bf(v);
+    }
+}
+
+// weight gradient of the first layer: slab[wg][n][k] = sum over the workgroup's tiles of
+// dZ[pix][n] * patch(pix, k).  Wave w owns column tiles w, w+4, w+8 of the 10 (320 columns).
+__global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __restrict__ X,
+                                                                const bf16_t* __restrict__ dZ,
+                                                                float* __restrict__ slabs, int frames,
+                                                                int T, int Hin, int Win, int Ho, int Wo) {
+  constexpr int ZLD = 32 + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t Ps[C1_PATCH + 8];
+  __shared__ __attribute__((aligned(16))) bf16_t Zs[C1_PIX * ZLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lk = lane >> 5;
+  const int tiles_x = (Wo + C1_T - 1) / C1_T, tiles_y = (Ho + C1_T - 1) / C1_T;
+  const int64_t ntiles = (int64_t)frames * tiles_x * tiles_y;
+  // this lane's column of each owned column tile: k = (tap, c) -> patch offset (or the zero zone)
+  int coloff[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int k = (wave + 4 * j) * 32 + lr;
+    const int o = (wave + 4 * j) < 10 && k < 300 ? c1_tap_off(k >> 2) + (k & 3) : -1;
+    coloff[j] = o;
+  }
+  f32x16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  if (tid < 8) Ps[C1_PATCH + tid] = 0;
+
+  for (int64_t q = blockIdx.x; q < ntiles; q += gridDim.x) {
+    const int tx = (int)(q % tiles_x), ty = (int)((q / tiles_x) % tiles_y), f = (int)(q / (tiles_x * tiles_y));
+    const int y0 = ty * C1_T, x0 = tx * C1_T;
+    __syncthreads();
+    c1_load_patch(X, Ps, f, T, Hin, Win, y0, x0, tid);
+    for (int e = tid; e < C1_PIX * 4; e += 256) {   // dZ tile: 256 pixels x 32 channels, 16-byte units
+      const int pix = e >> 2, u = e & 3;
+      const int y = y0 + (pix >> 4), x = x0 + (pix & 15);
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (y < Ho && x < Wo) v = *reinterpret_cast<const uint4*>(dZ + (((int64_t)f * Ho + y) * Wo + x) * 32 + u * 8);
+      *reinterpret_cast<uint4*>(&Zs[pix * ZLD + u * 8]) = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int ks = 0; ks < C1_PIX / 16; ++ks) {
+      const int p0 = ks * 16 + lk * 8;                 // 8 consecutive pixels of one tile row
+      const int ppix = ((2 * (p0 >> 4)) * C1_P + 2 * (p0 & 15)) * 4;
+      bf16x8 a;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = __builtin_bit_cast(__bf16, Zs[(p0 + e) * ZLD + lr]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (wave + 4 * j < 10) {
+          bf16x8 b;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            b[e] = __builtin_bit_cast(__bf16, Ps[coloff[j] >= 0 ? ppix + e * 8 + coloff[j] : C1_PATCH]);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* out = slabs + (int64_t)blockIdx.x * 32 * 320;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (wave + 4 * j < 10) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        out[((r & 3) + 8 * (r >> 2) + 4 * lk) * 320 + (wave + 4 * j) * 32 + lr] = acc[j][r];
+    }
+  }
+}
+
+// dW1[n][c][tap] (torch layout [32][3][3][5][5]) (+)= sum_wg slabs[wg][n][tap*4 + c]
+__global__ void conv1_wgrad_reduce_kernel(const float* __restrict__ slabs, int nwg, float* __restrict__ dW,
+                                          int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 32 * 3 * 75) return;
+  const int tap = i % 75, c = (i / 75) % 3, n = i / 225;
+  float s = 0.f;
+  for (int z = 0; z < nwg; ++z) s += slabs[((int64_t)z * 32 + n) * 320 + tap * 4 + c];
+  dW[i] = accumulate ? dW[i] + s : s;
+}
+
+// ---------------------------------------------------------------------------------------------
 // tap-stationary weight gradient for stride-1 "same" layers with Cin in {32,64} (layers 2 and 3)
 // ---------------------------------------------------------------------------------------------
 // dW[n][tap][c] = sum_pixels dZ[pix][n] * X[pix + tap][c].  Instead of building im2col rows (each
@@ -738,6 +917,18 @@ extern "C" int lr_conv3d_forward(const void* X, const void* Wp, const float* bia
   const bf16_t* x = (const bf16_t*)X;
   const bf16_t* w = (const bf16_t*)Wp;
   bf16_t* y = (bf16_t*)Y;
+  if (Cin == 4 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 && ph == 2 && pw == 2) {
+    // first layer: patch-resident kernel (one 16x16 output tile of one frame per workgroup)
+    hipEvent_t e0, e1;
+    const bool sample = relu && lr_prof_next(LR_PROF_CONV1_FWD, &e0, &e1);
+    const int tiles = B * T * ((g.Ho + C1_T - 1) / C1_T) * ((g.Wo + C1_T - 1) / C1_T);
+    lr_clear_error();
+    if (sample) hipExtLaunchKernelGGL(conv1_fwd_patch_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, e0,
+                                      e1, 0, x, w, bias, y, B * T, T, Hin, Win, g.Ho, g.Wo, relu);
+    else hipLaunchKernelGGL(conv1_fwd_patch_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x, w, bias, y,
+                            B * T, T, Hin, Win, g.Ho, g.Wo, relu);
+    return lr_launch_status();
+  }
   // instrumentation slot: forward layers by input channels, data gradients by (Cin, relu == 0)
   int slot = -1;
   if (relu) slot = Cin == 4 ? LR_PROF_CONV1_FWD : (Cin == 32 ? LR_PROF_CONV2_FWD : LR_PROF_CONV3_FWD);
@@ -774,6 +965,7 @@ extern "C" size_t lr_conv3d_wgrad_workspace_bytes(int Cout, int Cin_pad, int KT,
   size_t slab = (size_t)wgrad_splits(Cout, Ktot) * Cout * Ktot;
   const size_t ts = (size_t)KT * kTsWgsPerKt * KH * KW * Cout * Cin_pad;   // tap-stationary path
   if (ts > slab) slab = ts;
+  if (slab < (size_t)512 * 32 * 320) slab = (size_t)512 * 32 * 320;   // first-layer patch kernel
   return (slab + (size_t)kColsumSplits * Cout) * sizeof(float);
 }
 
@@ -795,6 +987,26 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
   const bool sample = lr_prof_next(Cin_pad == 4 ? LR_PROF_CONV1_WGRAD
                                                 : (Cin_pad == 32 ? LR_PROF_CONV2_WGRAD : LR_PROF_CONV3_WGRAD),
                                    &e0, &e1);
+  if (Cin_pad == 4 && Cin_real == 3 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 &&
+      ph == 2 && pw == 2) {
+    const int nwg = 512;   // persistent workgroups, partial sums reduced in fixed order
+    lr_clear_error();
+    if (sample) hipExtLaunchKernelGGL(conv1_wgrad_patch_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, e0,
+                                      e1, 0, x, dz, slabs, B * T, T, Hin, Win, g.Ho, g.Wo);
+    else hipLaunchKernelGGL(conv1_wgrad_patch_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, x, dz, slabs,
+                            B * T, T, Hin, Win, g.Ho, g.Wo);
+    int st = lr_launch_status();
+    if (st != LR_OK) return st;
+    LR_LAUNCH(conv1_wgrad_reduce_kernel, dim3((32 * 225 + 255) / 256), dim3(256), 0, stream, (const float*)slabs,
+              nwg, dW, accumulate);
+    st = lr_launch_status();
+    if (st != LR_OK || !dbias) return st;
+    LR_LAUNCH(colsum_bf16_partial_kernel, dim3(kColsumSplits), dim3(256), 0, stream, dz, g.M, Cout, cpart,
+              kColsumSplits);
+    LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(256), 0, stream, (const float*)cpart, kColsumSplits, dbias,
+              Cout, accumulate);
+    return lr_launch_status();
+  }
   const bool ts_path = stride == 1 && (Cin_pad == 32 || Cin_pad == 64) && Cin_real == Cin_pad &&
                        2 * ph + 1 == KH && 2 * pw + 1 == KW && KH * KW * (Cin_pad / 32) <= 28;
   if (ts_path) {
