@@ -366,20 +366,33 @@ __device__ __forceinline__ int c1_tap_off(int tap) {
   return ((kt * C1_P + kh) * C1_P + kw) * 4;
 }
 
-// Loads the patch of tile (f, ty, tx): frames t-1..t+1 of clip b, rows 2*y0-2.., cols 2*x0-2..
-__device__ __forceinline__ void c1_load_patch(const bf16_t* __restrict__ X, bf16_t* Ps, int f, int T,
-                                              int Hin, int Win, int y0, int x0, int tid) {
+// The patch of tile (f, ty, tx): frames t-1..t+1 of clip b, rows 2*y0-2.., cols 2*x0-2.. — 3675
+// 8-byte pixels, 15 per thread.  Split into "issue every global load" and "write to LDS" so that a
+// tile's loads are all in flight at once (a load->store loop would serialise ~15 round trips) and
+// the NEXT tile's loads can overlap the current tile's MFMAs.
+constexpr int C1_NPU = (3 * C1_P * C1_P + 255) / 256;   // 15
+__device__ __forceinline__ void c1_patch_issue(const bf16_t* __restrict__ X, uint2 (&rp)[C1_NPU], int f, int T,
+                                               int Hin, int Win, int y0, int x0, int tid) {
   const int t = f % T;
-  for (int e = tid; e < 3 * C1_P * C1_P; e += 256) {
+#pragma unroll
+  for (int i = 0; i < C1_NPU; ++i) {
+    const int e = tid + i * 256;
     const int px = e % C1_P, py = (e / C1_P) % C1_P, kt = e / (C1_P * C1_P);
     const int ti = t + kt - 1, yi = 2 * y0 - 2 + py, xi = 2 * x0 - 2 + px;
-    uint2 v = make_uint2(0u, 0u);
-    if (ti >= 0 && ti < T && yi >= 0 && yi < Hin && xi >= 0 && xi < Win)
-      v = *reinterpret_cast<const uint2*>(X + ((((int64_t)(f + kt - 1)) * Hin + yi) * Win + xi) * 4);
-    *reinterpret_cast<uint2*>(&Ps[e * 4]) = v;
+    rp[i] = make_uint2(0u, 0u);
+    if (kt < 3 && ti >= 0 && ti < T && yi >= 0 && yi < Hin && xi >= 0 && xi < Win)
+      rp[i] = *reinterpret_cast<const uint2*>(X + ((((int64_t)(f + kt - 1)) * Hin + yi) * Win + xi) * 4);
+  }
+}
+__device__ __forceinline__ void c1_patch_store(bf16_t* Ps, const uint2 (&rp)[C1_NPU], int tid) {
+#pragma unroll
+  for (int i = 0; i < C1_NPU; ++i) {
+    const int e = tid + i * 256;
+    if (e < 3 * C1_P * C1_P) *reinterpret_cast<uint2*>(&Ps[e * 4]) = rp[i];
   }
 }
 
+// Persistent workgroups: the 32 x 300 weights are staged once, then tiles are streamed.
 __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __restrict__ X,
                                                               const bf16_t* __restrict__ Wp,  // [32][300]
                                                               const float* __restrict__ bias,
@@ -391,53 +404,72 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lk = lane >> 5;
   const int tiles_x = (Wo + C1_T - 1) / C1_T, tiles_y = (Ho + C1_T - 1) / C1_T;
-  const int tile = blockIdx.x;
-  const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, f = tile / (tiles_x * tiles_y);
-  const int y0 = ty * C1_T, x0 = tx * C1_T;
+  const int64_t ntiles = (int64_t)frames * tiles_x * tiles_y;
   if (tid < 80) tapoff[tid] = c1_tap_off(tid);
-  for (int e = tid; e < 32 * C1_WLD; e += 256) {
-    const int n = e / C1_WLD, k = e - n * C1_WLD;
-    Ws[e] = k < 300 ? Wp[n * 300 + k] : (bf16_t)0;
+  // weights: row n = 300 bf16 = 75 x 8 bytes; pad columns 300..311 with zeros
+  for (int e = tid; e < 32 * (C1_WLD / 4); e += 256) {
+    const int n = e / (C1_WLD / 4), u = e - n * (C1_WLD / 4);
+    uint2 v = make_uint2(0u, 0u);
+    if (u < 75) v = *reinterpret_cast<const uint2*>(Wp + n * 300 + u * 4);
+    *reinterpret_cast<uint2*>(&Ws[n * C1_WLD + u * 4]) = v;
   }
-  c1_load_patch(X, Ps, f, T, Hin, Win, y0, x0, tid);
   if (tid < 8) Ps[C1_PATCH + tid] = 0;   // landing zone for the padded taps (k >= 300)
-  __syncthreads();
 
   // wave w: row tiles 2w, 2w+1; row tile m covers pixels (y = 2m + (lr>>4), x = lr & 15)
-  f32x16 acc[2];
   int pixoff[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int yl = 2 * (2 * wave + i) + (lr >> 4), xl = lr & 15;
     pixoff[i] = ((2 * yl) * C1_P + 2 * xl) * 4;
   }
-#pragma unroll 1
-  for (int ks = 0; ks < C1_K / 16; ++ks) {
-    const int tap0 = ks * 4 + lk * 2;
-    const int o0 = tapoff[tap0], o1 = tapoff[tap0 + 1];
-    const bf16x8 b = *reinterpret_cast<const bf16x8*>(&Ws[lr * C1_WLD + ks * 16 + lk * 8]);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const uint2 lo = *reinterpret_cast<const uint2*>(&Ps[o0 >= 0 ? pixoff[i] + o0 : C1_PATCH]);
-      const uint2 hi = *reinterpret_cast<const uint2*>(&Ps[o1 >= 0 ? pixoff[i] + o1 : C1_PATCH]);
-      const uint4 av = make_uint4(lo.x, lo.y, hi.x, hi.y);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b, acc[i], 0, 0, 0);
-    }
-  }
   const float bv = bias ? bias[lr] : 0.f;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int prow = (r & 3) + 8 * (r >> 2) + 4 * lk;         // pixel index inside the row tile
-      const int y = y0 + 2 * (2 * wave + i) + (prow >> 4), x = x0 + (prow & 15);
-      if (y >= Ho || x >= Wo) continue;
-      float v = acc[i][r] + bv;
-      if (relu) v = fmaxf(v, 0.f);
-      Y[(((int64_t)f * Ho + y) * Wo + x) * 32 + lr] = f2bf(v);
+  uint2 rp[C1_NPU];
+  int64_t q = blockIdx.x;
+  if (q < ntiles) {
+    const int tx = (int)(q % tiles_x), ty = (int)((q / tiles_x) % tiles_y), f = (int)(q / (tiles_x * tiles_y));
+    c1_patch_issue(X, rp, f, T, Hin, Win, ty * C1_T, tx * C1_T, tid);
+  }
+  for (; q < ntiles; q += gridDim.x) {
+    const int tx = (int)(q % tiles_x), ty = (int)((q / tiles_x) % tiles_y), f = (int)(q / (tiles_x * tiles_y));
+    const int y0 = ty * C1_T, x0 = tx * C1_T;
+    __syncthreads();            // previous tile's fragments are no longer being read
+    c1_patch_store(Ps, rp, tid);
+    __syncthreads();
+    const int64_t qn = q + gridDim.x;
+    if (qn < ntiles) {          // next tile's loads fly while this tile's MFMAs run
+      const int txn = (int)(qn % tiles_x), tyn = (int)((qn / tiles_x) % tiles_y);
+      c1_patch_issue(X, rp, (int)(qn / (tiles_x * tiles_y)), T, Hin, Win, tyn * C1_T, txn * C1_T, tid);
     }
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll 1
+    for (int ks = 0; ks < C1_K / 16; ++ks) {
+      const int tap0 = ks * 4 + lk * 2;
+      const int o0 = tapoff[tap0], o1 = tapoff[tap0 + 1];
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(&Ws[lr * C1_WLD + ks * 16 + lk * 8]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(&Ps[o0 >= 0 ? pixoff[i] + o0 : C1_PATCH]);
+        const uint2 hi = *reinterpret_cast<const uint2*>(&Ps[o1 >= 0 ? pixoff[i] + o1 : C1_PATCH]);
+        const uint4 av = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b, acc[i], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int prow = (r & 3) + 8 * (r >> 2) + 4 * lk;         // pixel index inside the row tile
+        const int y = y0 + 2 * (2 * wave + i) + (prow >> 4), x = x0 + (prow & 15);
+        if (y >= Ho || x >= Wo) continue;
+        float v = acc[i][r] + bv;
+        if (relu) v = fmaxf(v, 0.f);
+        Y[(((int64_t)f * Ho + y) * Wo + x) * 32 + lr] = f2bf(v);
+      }
+  }
 }
 
 // weight gradient of the first layer: slab[wg][n][k] = sum over the workgroup's tiles of
@@ -458,8 +490,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int k = (wave + 4 * j) * 32 + lr;
-    const int o = (wave + 4 * j) < 10 && k < 300 ? c1_tap_off(k >> 2) + (k & 3) : -1;
-    coloff[j] = o;
+    coloff[j] = (wave + 4 * j) < 10 && k < 300 ? c1_tap_off(k >> 2) + (k & 3) : -1;
   }
   f32x16 acc[3];
 #pragma unroll
@@ -468,19 +499,33 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   if (tid < 8) Ps[C1_PATCH + tid] = 0;
 
-  for (int64_t q = blockIdx.x; q < ntiles; q += gridDim.x) {
-    const int tx = (int)(q % tiles_x), ty = (int)((q / tiles_x) % tiles_y), f = (int)(q / (tiles_x * tiles_y));
+  uint2 rp[C1_NPU];
+  uint4 rz[4];
+  auto issue = [&](int64_t qq) {
+    const int tx = (int)(qq % tiles_x), ty = (int)((qq / tiles_x) % tiles_y), f = (int)(qq / (tiles_x * tiles_y));
     const int y0 = ty * C1_T, x0 = tx * C1_T;
-    __syncthreads();
-    c1_load_patch(X, Ps, f, T, Hin, Win, y0, x0, tid);
-    for (int e = tid; e < C1_PIX * 4; e += 256) {   // dZ tile: 256 pixels x 32 channels, 16-byte units
+    c1_patch_issue(X, rp, f, T, Hin, Win, y0, x0, tid);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // dZ tile: 256 pixels x 32 channels in 16-byte units
+      const int e = tid + i * 256;
       const int pix = e >> 2, u = e & 3;
       const int y = y0 + (pix >> 4), x = x0 + (pix & 15);
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (y < Ho && x < Wo) v = *reinterpret_cast<const uint4*>(dZ + (((int64_t)f * Ho + y) * Wo + x) * 32 + u * 8);
-      *reinterpret_cast<uint4*>(&Zs[pix * ZLD + u * 8]) = v;
+      rz[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (y < Ho && x < Wo) rz[i] = *reinterpret_cast<const uint4*>(dZ + (((int64_t)f * Ho + y) * Wo + x) * 32 + u * 8);
+    }
+  };
+  int64_t q = blockIdx.x;
+  if (q < ntiles) issue(q);
+  for (; q < ntiles; q += gridDim.x) {
+    __syncthreads();
+    c1_patch_store(Ps, rp, tid);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      *reinterpret_cast<uint4*>(&Zs[(e >> 2) * ZLD + (e & 3) * 8]) = rz[i];
     }
     __syncthreads();
+    if (q + gridDim.x < ntiles) issue(q + gridDim.x);
 #pragma unroll 1
     for (int ks = 0; ks < C1_PIX / 16; ++ks) {
       const int p0 = ks * 16 + lk * 8;                 // 8 consecutive pixels of one tile row
@@ -921,7 +966,8 @@ extern "C" int lr_conv3d_forward(const void* X, const void* Wp, const float* bia
     // first layer: patch-resident kernel (one 16x16 output tile of one frame per workgroup)
     hipEvent_t e0, e1;
     const bool sample = relu && lr_prof_next(LR_PROF_CONV1_FWD, &e0, &e1);
-    const int tiles = B * T * ((g.Ho + C1_T - 1) / C1_T) * ((g.Wo + C1_T - 1) / C1_T);
+    int tiles = B * T * ((g.Ho + C1_T - 1) / C1_T) * ((g.Wo + C1_T - 1) / C1_T);
+    if (tiles > 768) tiles = 768;   // persistent: 3 workgroups per CU, each streams its share of tiles
     lr_clear_error();
     if (sample) hipExtLaunchKernelGGL(conv1_fwd_patch_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, e0,
                                       e1, 0, x, w, bias, y, B * T, T, Hin, Win, g.Ho, g.Wo, relu);
@@ -989,7 +1035,7 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
                                    &e0, &e1);
   if (Cin_pad == 4 && Cin_real == 3 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 &&
       ph == 2 && pw == 2) {
-    const int nwg = 512;   // persistent workgroups, partial sums reduced in fixed order
+    const int nwg = 512;   // persistent workgroups (2 per CU), partial sums reduced in fixed order
     lr_clear_error();
     if (sample) hipExtLaunchKernelGGL(conv1_wgrad_patch_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, e0,
                                       e1, 0, x, dz, slabs, B * T, T, Hin, Win, g.Ho, g.Wo);
