@@ -36,6 +36,19 @@ __device__ __forceinline__ float bf2f(bf16_t v) {
   return __builtin_bit_cast(float, (unsigned)v << 16);
 }
 
+// sum_{z<n} p[z*stride] with 8 loads in flight; the 8 partial sums are combined in a fixed order, so
+// the result is deterministic (it does not depend on scheduling).
+__device__ __forceinline__ float strided_sum8(const float* __restrict__ p, int n, int64_t stride) {
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int z = 0;
+  for (; z + 8 <= n; z += 8) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] += p[(int64_t)(z + i) * stride];
+  }
+  for (; z < n; ++z) a[z & 7] += p[(int64_t)z * stride];
+  return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
 struct ConvGeom {
   int B, T, Hin, Win, Cin;   // Cin = stored (padded) input channels
   int Ho, Wo, Cout;
@@ -562,8 +575,7 @@ __global__ void conv1_wgrad_reduce_kernel(const float* __restrict__ slabs, int n
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 32 * 3 * 75) return;
   const int tap = i % 75, c = (i / 75) % 3, n = i / 225;
-  float s = 0.f;
-  for (int z = 0; z < nwg; ++z) s += slabs[((int64_t)z * 32 + n) * 320 + tap * 4 + c];
+  const float s = strided_sum8(slabs + (int64_t)n * 320 + tap * 4 + c, nwg, 32 * 320);
   dW[i] = accumulate ? dW[i] + s : s;
 }
 
@@ -724,9 +736,8 @@ __global__ void conv3d_wgrad_ts_reduce_kernel(const float* __restrict__ slabs, i
     const int kt = (int)((i / khw) % KT);
     const int c = (int)((i / ((int64_t)khw * KT)) % Cin);
     const int n = (int)(i / ((int64_t)khw * KT * Cin));
-    float s = 0.f;
-    for (int z = 0; z < wgs_per_kt; ++z)
-      s += slabs[((((int64_t)z * KT + kt) * khw + t2) * Cout + n) * Cin + c];
+    const float s = strided_sum8(slabs + (((int64_t)kt * khw + t2) * Cout + n) * Cin + c, wgs_per_kt,
+                                 (int64_t)KT * khw * Cout * Cin);
     dW[i] = accumulate ? dW[i] + s : s;
   }
 }
@@ -741,8 +752,7 @@ __global__ void conv3d_wgrad_reduce_kernel(const float* __restrict__ slabs, int 
     const int tap = (int)(i % taps);
     const int c = (int)((i / taps) % Cin_real);
     const int n = (int)(i / ((int64_t)taps * Cin_real));
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += slabs[((int64_t)z * Cout + n) * Ktot + tap * Cin_pad + c];
+    const float s = strided_sum8(slabs + (int64_t)n * Ktot + tap * Cin_pad + c, splits, (int64_t)Cout * Ktot);
     dW[i] = accumulate ? dW[i] + s : s;
   }
 }
@@ -894,8 +904,7 @@ __global__ void colsum_final_acc_kernel(const float* __restrict__ partial, int s
                                         int C, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * C + c];
+  const float s = strided_sum8(partial + c, splits, C);
   out[c] = accumulate ? out[c] + s : s;
 }
 

@@ -8,10 +8,10 @@
 // in lr_rnn.hip.
 //
 // Tiling: 256 threads = 2x2 waves; workgroup tile BM x BN (128x128 or 64x64), wave tile
-// (BM/2)x(BN/2) made of 32x32 MFMA tiles, BK = 16 per LDS stage.  Operands are staged through
+// (BM/2)x(BN/2) made of 32x32 MFMA tiles, BK = 32 per LDS stage.  Operands are staged through
 // LDS in the orientation that keeps BOTH the global loads coalesced and the per-lane MFMA operand
 // reads bank-conflict free:
-//   K-contiguous operand  -> tile[row][BK+1]   (lane reads row*(BK+1)+k, 17 is odd: no conflict)
+//   K-contiguous operand  -> tile[row][BK+1]   (lane reads row*(BK+1)+k, 33 is odd: no conflict)
 //   M/N-contiguous operand -> tile[k][BM+4]    (lane reads k*(BM+4)+row, consecutive lanes)
 // Small M*N with long K (the weight gradients: K = B*T) is split along K into slabs in the
 // caller's workspace and reduced deterministically (fixed order) by a second kernel.
@@ -21,7 +21,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
+constexpr int BK = 32;   // k per LDS stage: 128 B per operand row per stage, 2x the MFMA work per barrier pair
 
 struct GemmArgs {
   const float* A;
@@ -248,7 +248,7 @@ GemmPlan plan_gemm(int M, int N, int K, size_t ws_bytes) {
   const long tiles_big = (long)((M + 127) / 128) * ((N + 127) / 128);
   const long tiles_small = (long)((M + 63) / 64) * ((N + 63) / 64);
   // how far split-K may go: >= 64 k per split, slabs must fit the caller's workspace
-  long max_split = K / (4 * BK);
+  long max_split = K / (2 * BK);
   const long max_by_ws = (long)(ws_bytes / ((size_t)M * N * sizeof(float)));
   if (max_split > max_by_ws) max_split = max_by_ws;
   if (max_split > 64) max_split = 64;

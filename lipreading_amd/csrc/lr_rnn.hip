@@ -419,10 +419,10 @@ __global__ void bias_grad_final_kernel(const float* __restrict__ partial, BiasPt
 }
 
 struct Layout {
-  size_t gates, extra, bias, wp, hp, total;  // float offsets / total floats
-  size_t wp_per_dir, hp_floats;
+  size_t gates, extra, bias, wp, hp, gemm, total;  // float offsets / total floats
+  size_t wp_per_dir, hp_floats, gemm_bytes;
 };
-Layout reserve_layout(int G, int B, int T, int H, int D) {
+Layout reserve_layout(int G, int B, int T, int I, int H, int D) {
   Layout l;
   const size_t nchunk = (H + 15) / 16, nbt = (B + 15) / 16;
   l.gates = 0;
@@ -432,7 +432,9 @@ Layout reserve_layout(int G, int B, int T, int H, int D) {
   l.wp_per_dir = nchunk * G * nchunk * FRAG;
   l.hp = l.wp + (size_t)D * l.wp_per_dir;
   l.hp_floats = 2 * (size_t)D * nbt * nchunk * FRAG;
-  l.total = l.hp + l.hp_floats;
+  l.gemm = l.hp + l.hp_floats;                               // split-K slabs of the input projection
+  l.gemm_bytes = lr_sgemm_workspace_bytes(B * T, G * H, I);
+  l.total = l.gemm + (l.gemm_bytes + 3) / 4;
   return l;
 }
 struct WsLayout {
@@ -473,7 +475,7 @@ bool dims_ok(int mode, int B, int T, int I, int H, int D) {
 
 extern "C" size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D)) return 0;
-  return reserve_layout(mode == LR_RNN_GRU ? 3 : 4, B, T, H, D).total * sizeof(float);
+  return reserve_layout(mode == LR_RNN_GRU ? 3 : 4, B, T, I, H, D).total * sizeof(float);
 }
 
 extern "C" size_t lr_rnn_workspace_bytes(int mode, int B, int T, int I, int H, int D) {
@@ -492,7 +494,7 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
   const int G = mode == LR_RNN_GRU ? 3 : 4;
   LR_CHECK_ARG(G == 3 || c_n);
   for (int d = 0; d < D; ++d) LR_CHECK_ARG(w_ih[d] && w_hh[d] && b_ih[d] && b_hh[d]);
-  const Layout l = reserve_layout(G, B, T, H, D);
+  const Layout l = reserve_layout(G, B, T, I, H, D);
   if (reserve_bytes < l.total * sizeof(float)) return LR_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   float* base = (float*)reserve;
@@ -508,7 +510,8 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
     if (st != LR_OK) return st;
     // gates[b,t,d,:] = x[b,t,:] @ W_ih[d]^T + folded bias
     st = lr_sgemm_impl(0, 1, B * T, GH, I, 1.f, x, I, w_ih[d], I, 0.f, gates + (size_t)d * GH,
-                       D * GH, bias + (size_t)d * GH, 0, 0, nullptr, 0, stream);
+                       D * GH, bias + (size_t)d * GH, 0, 0, l.gemm_bytes ? (void*)(base + l.gemm) : nullptr,
+                       l.gemm_bytes, stream);
     if (st != LR_OK) return st;
   }
   StepPtrs p;
@@ -567,7 +570,7 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
     LR_CHECK_ARG(w_ih[d] && w_hh[d] && dw_ih[d] && dw_hh[d] && db_ih[d] && db_hh[d]);
   (void)b_ih;
   (void)b_hh;
-  const Layout rl = reserve_layout(G, B, T, H, D);
+  const Layout rl = reserve_layout(G, B, T, I, H, D);
   if (reserve_bytes < rl.total * sizeof(float)) return LR_ERR_WORKSPACE;
   const WsLayout wl = ws_layout(G, B, T, I, H, D);
   if (workspace_bytes < wl.total * sizeof(float)) return LR_ERR_WORKSPACE;
