@@ -317,3 +317,82 @@ def lip_crop(frames, lmks, size=96, margin=0.3, lo=48, hi=68):
     v = tv + (bv - tv) * fy[None, :, None]
     out[i] = np.clip(np.floor(v + f32(0.5)), 0, 255).astype(np.uint8)
   return out
+
+
+# ------------------------------------------------------------------------------------------
+# N1: attention decoder — src/models/lipreader/better_model.py:124-235 (CharDecodingStep) and
+# the decoder loop of src/train/train_better_model.py:54-65 (train) / :121-135 (eval).
+# masked_softmax is allennlp.nn.util's published (non memory-efficient) definition, the same
+# unpinned third-party boundary as masked_log_softmax (SHIMMED pin, see header).
+# ------------------------------------------------------------------------------------------
+def masked_softmax(vector, mask, dim=-1):
+  mask = mask.float()
+  while mask.dim() < vector.dim():
+    mask = mask.unsqueeze(1)
+  result = F.softmax(vector * mask, dim=dim) * mask
+  return result / (result.sum(dim=dim, keepdim=True) + 1e-13)
+
+
+class OracleCharDecodingStep(nn.Module):
+  """Same parameters / state_dict keys as the reference CharDecodingStep (better_model.py:125-159)."""
+
+  def __init__(self, hidden_size, rnn_type, num_layers, char_dim, vocab_size, char2idx,
+               attention_type='none', attn_hidden_size=-1, rnn_dropout=0):
+    super().__init__()
+    self.hidden_size, self.rnn_type, self.num_layers = hidden_size, rnn_type, num_layers
+    self.char_dim, self.vocab_size, self.attention_type = char_dim, vocab_size, attention_type
+    mask = torch.ones(vocab_size)
+    mask[char2idx[PAD]] = 0                                        # :143
+    mask[char2idx[BOS]] = 0                                        # :144
+    self.output_mask = mask
+    self.embedding = nn.Embedding(vocab_size, char_dim, padding_idx=char2idx[PAD])   # :145
+    self.rnn = getattr(nn, rnn_type)(char_dim, hidden_size, num_layers=num_layers, batch_first=True,
+                                     dropout=rnn_dropout)         # :146-147
+    if attention_type == '1_layer_nn':
+      self.attn_proj_1_layer_nn = nn.Linear(2 * hidden_size, 1)    # :149
+    elif attention_type == 'general':
+      self.attn_proj_general = nn.Linear(hidden_size, hidden_size)  # :151
+    elif attention_type == 'concat':
+      self.attn_proj_layer1 = nn.Linear(2 * hidden_size, attn_hidden_size)   # :153
+      self.attn_proj_layer2 = nn.Linear(attn_hidden_size, 1)       # :154
+    self.concat_layer = nn.Linear(2 * hidden_size, hidden_size)    # :155
+    self.output_proj = nn.Linear(hidden_size, vocab_size)          # :156
+
+  def forward(self, input_, previous_state, encoder_lens, enc):
+    B, T = input_.shape[0], enc.shape[1]
+    enc_mask = torch.arange(T).expand(B, T) < encoder_lens.unsqueeze(1)       # :173
+    emb = self.embedding(input_).unsqueeze(1)                                 # :175-177
+    hidden_state, final_state = self.rnn(emb, previous_state)                  # :181
+    h = hidden_state.squeeze(1)
+    he = hidden_state.expand_as(enc)                                           # :184
+    at = self.attention_type
+    if at == '1_layer_nn':
+      logits = self.attn_proj_1_layer_nn(torch.cat([enc, he], dim=2)).squeeze(-1)      # :186-190
+    elif at == 'general':
+      logits = (self.attn_proj_general(he) * enc).sum(-1)                      # :191-205
+    elif at == 'dot':
+      logits = (he * enc).sum(-1)                                              # :206-208
+    elif at == 'concat':
+      logits = self.attn_proj_layer2(self.attn_proj_layer1(torch.cat([enc, he], dim=2)).tanh()).squeeze(-1)  # :209-215
+    if at != 'none':
+      w = masked_softmax(logits, enc_mask, dim=-1).unsqueeze(1)                # :219
+      ctx = w.bmm(enc).squeeze(1)                                              # :221
+      new_h = self.concat_layer(torch.cat([ctx, h], dim=1)).tanh()             # :223-224
+      out = self.output_proj(new_h)                                            # :226
+    else:
+      out = self.output_proj(h)                                                # :228
+    return masked_log_softmax(out, self.output_mask.expand(B, self.vocab_size)), final_state   # :229
+
+
+def decoder_loop(dec, chars, char_lens, enc, enc_lens, prev_state, pad=0):
+  """Teacher-forced decoder loop (train_better_model.py:56-65 with teacher_forcing_ratio=1; the
+  multinomial draws of :63 do not influence the loss then).  Returns (decoder_loss, log_probs)."""
+  labels = chars[:, 1:]
+  max_label_len = int((char_lens - 1).max())
+  loss, outs = 0, []
+  for i in range(max_label_len):
+    lp, prev_state = dec(chars[:, i], prev_state, enc_lens, enc)
+    loss = loss + F.nll_loss(lp, labels[:, i], ignore_index=pad, reduction='sum')
+    outs.append(lp)
+  loss = loss / (labels != pad).sum()
+  return loss, torch.stack(outs, 1)

@@ -58,3 +58,8 @@ def has_gpu():
     return torch.cuda.is_available()
   except Exception:
     return False
+
+
+@pytest.fixture(scope="session")
+def golden_dec():
+  return load_golden("dec_cases.npz")

@@ -18,6 +18,9 @@ Pins (see oracle/torch_oracle.py header):
                     masked_log_softmax's 1e-45 constant is the only observable part.  SHIMMED
   step_cases.npz    reference VideoEncoder + reference ctc_loss composed as
                     train_better_model.py:31-32,46-48,74-80 (CTC-only step)            SHIMMED
+  dec_cases.npz     reference VideoEncoder + CharDecodingStep (five attention types) driven as
+                    train_better_model.py:46-74 does at teacher_forcing_ratio = 1; needs the
+                    allennlp stand-ins incl. masked_softmax                              SHIMMED
   lmk_cases.npz     hand-computed from face.py:76-90,164-175 (face.py needs dlib to import)
                     -> parity unpinned for the landmark row
 """
@@ -264,6 +267,62 @@ def gen_step(bm, ref_ctc, char2idx):
   np.savez_compressed(os.path.join(OUT, "step_cases.npz"), **cases)
 
 
+def gen_dec(bm, ref_ctc, char2idx):
+  """Reference VideoEncoder -> reference CharDecodingStep, driven as train_better_model.py:46-65
+  does with teacher_forcing_ratio=1 (decoder loss), plus the CTC loss; gradients of
+  decoder_loss.backward(retain_graph) followed by ctc_loss.backward() (:69,:74).  SHIMMED."""
+  g = torch.Generator().manual_seed(123456)
+  cases = {}
+  cfgs = [("gru_1layernn", "GRU", True, "1_layer_nn", -1), ("lstm_dot", "LSTM", True, "dot", -1),
+          ("gru_general", "GRU", False, "general", -1), ("lstm_concat", "LSTM", False, "concat", 10),
+          ("gru_none", "GRU", True, "none", -1)]
+  for name, rnn_type, bi, attn, ah in cfgs:
+    torch.manual_seed(123456)
+    H = 8
+    enc = bm.VideoEncoder(204, H, rnn_type=rnn_type, num_layers=1, bidirectional=bi, enable_ctc=True,
+                          vocab_size=V, char2idx=char2idx)
+    dec = bm.CharDecodingStep(enc, char_dim=12, vocab_size=V, char2idx=char2idx, attention_type=attn,
+                              attn_hidden_size=ah)
+    enc.train(); dec.train()
+    lens = [9, 11, 14, 14]
+    frames = enc_inputs(g, 4, 14, lens, 1.0)
+    cl = [5, 7, 6, 8]
+    chars = torch.zeros(4, max(cl), dtype=torch.long)
+    for i, n in enumerate(cl):
+      chars[i, 0] = 1
+      chars[i, 1:n - 1] = torch.randint(4, V, (n - 2,), generator=g)
+      chars[i, n - 1] = 2
+    char_lens = torch.tensor(cl)
+    labels, label_lens = chars[:, 1:], char_lens - 1
+    lp_enc, hid, prev_state = enc(frames, torch.tensor(lens))
+    ctc = ref_ctc(lp_enc, labels, torch.tensor(lens), label_lens, 'mean', 'cpu')
+    dec_loss, outs = 0, []
+    for i in range(int(label_lens.max())):
+      out, prev_state = dec(chars[:, i], prev_state, torch.tensor(lens), hid)
+      dec_loss = dec_loss + torch.nn.functional.nll_loss(out, labels[:, i], ignore_index=0, reduction='sum')
+      outs.append(out)
+    dec_loss = dec_loss / (labels != 0).sum()
+    dec_loss.backward(retain_graph=True)
+    ctc.backward()
+    for k, v in enc.state_dict().items():
+      cases["%s/enc_sd/%s" % (name, k)] = v.clone().numpy()
+    for k, v in dec.state_dict().items():
+      cases["%s/dec_sd/%s" % (name, k)] = v.clone().numpy()
+    for k, p in enc.named_parameters():
+      cases["%s/enc_grad/%s" % (name, k)] = p.grad.clone().numpy()
+    for k, p in dec.named_parameters():
+      cases["%s/dec_grad/%s" % (name, k)] = (p.grad.clone() if p.grad is not None else torch.zeros_like(p)).numpy()
+    cases[name + "/frames"] = frames.numpy()
+    cases[name + "/lens"] = np.asarray(lens)
+    cases[name + "/chars"] = chars.numpy()
+    cases[name + "/char_lens"] = np.asarray(cl)
+    cases[name + "/dec_loss"] = dec_loss.detach().numpy()
+    cases[name + "/ctc_loss"] = ctc.detach().numpy()
+    cases[name + "/dec_log_probs"] = torch.stack(outs, 1).detach().numpy()
+    cases[name + "/cfg"] = np.array([H, int(bi), 12, ah])
+  np.savez_compressed(os.path.join(OUT, "dec_cases.npz"), **cases)
+
+
 def gen_lmk():
   """Hand-computed from the formulas at face.py:76-90 and :164-175 (not produced by running
   the reference: face.py imports dlib)."""
@@ -301,6 +360,7 @@ def main():
   gen_greedy(ref_decoder, char2idx)
   gen_enc(bm, char2idx)
   gen_step(bm, ref_ctc, char2idx)
+  gen_dec(bm, ref_ctc, char2idx)
   gen_lmk()
   for f in sorted(os.listdir(OUT)):
     if f.endswith(".npz"):

@@ -126,3 +126,41 @@ def test_collate_pads_with_zeros():
   assert fl.tolist() == [3, 5, 4] and cl.tolist() == [2, 4, 3]
   assert float(f[0, 3:].abs().sum()) == 0 and c[0, 2:].tolist() == [0, 0]
   np.testing.assert_allclose(f[2, :4].numpy(), frames[2].astype(np.float32))
+
+
+DEC_CASES = {"gru_1layernn": ("GRU", "1_layer_nn"), "lstm_dot": ("LSTM", "dot"), "gru_general": ("GRU", "general"),
+             "lstm_concat": ("LSTM", "concat"), "gru_none": ("GRU", "none")}
+
+
+def build_oracle_pair(case, rnn_type, attn):
+  H, bi, char_dim, ah = [int(x) for x in case["cfg"]]
+  enc = O.OracleVideoEncoder(204, H, rnn_type=rnn_type, num_layers=1, bidirectional=bool(bi),
+                             enable_ctc=True, vocab_size=64, char2idx=O.default_char2idx())
+  enc.load_state_dict({k: torch.tensor(v) for k, v in _flatten(case["enc_sd"]).items()})
+  dec = O.OracleCharDecodingStep(H * (2 if bi else 1), rnn_type, 1, char_dim, 64, O.default_char2idx(),
+                                 attention_type=attn, attn_hidden_size=ah)
+  dec.load_state_dict({k: torch.tensor(v) for k, v in _flatten(case["dec_sd"]).items()})
+  return enc.train(), dec.train()
+
+
+@pytest.mark.parametrize("name", sorted(DEC_CASES))
+def test_decoder_oracle_matches_reference(golden_dec, name):
+  """Encoder -> attention decoder loop (tfr = 1) + CTC; decoder_loss.backward(retain_graph) then
+  ctc_loss.backward(), as train_better_model.py:46-74."""
+  case = golden_dec[name]
+  enc, dec = build_oracle_pair(case, *DEC_CASES[name])
+  lens = torch.tensor(case["lens"])
+  chars, char_lens = torch.tensor(case["chars"]), torch.tensor(case["char_lens"])
+  lp_enc, hid, final = enc(torch.tensor(case["frames"]), lens)
+  ctc = O.ctc_loss(lp_enc, chars[:, 1:], lens, char_lens - 1, 'mean')
+  dec_loss, outs = O.decoder_loop(dec, chars, char_lens, hid, lens, final)
+  np.testing.assert_allclose(dec_loss.item(), float(case["dec_loss"]), rtol=1e-5)
+  np.testing.assert_allclose(ctc.item(), float(case["ctc_loss"]), rtol=1e-5)
+  np.testing.assert_allclose(outs.detach().numpy(), case["dec_log_probs"], rtol=1e-4, atol=1e-5)
+  dec_loss.backward(retain_graph=True)
+  ctc.backward()
+  for mod, key in ((enc, "enc_grad"), (dec, "dec_grad")):
+    want = _flatten(case[key])
+    for k, p in mod.named_parameters():
+      g = p.grad if p.grad is not None else torch.zeros_like(p)
+      np.testing.assert_allclose(g.numpy(), want[k], rtol=2e-4, atol=2e-6, err_msg=k)
