@@ -179,6 +179,73 @@ int lr_proj_logsoftmax_backward(const float* g, const float* log_probs, const fl
                                 float* dbias, void* workspace, size_t workspace_bytes, int accumulate,
                                 int R, int K, int C, lr_stream_t stream);
 
+/* ---- N1: attention character decoder — better_model.py:124-235, train_better_model.py:54-65 - */
+
+typedef enum lr_attention_type {
+  LR_ATT_NONE = 0,    /* output_proj(rnn state)                                   (:228)      */
+  LR_ATT_DOT = 1,     /* logit[t] = h . enc[t]                                     (:206-208)  */
+  LR_ATT_GENERAL = 2, /* logit[t] = (W_g h + b_g) . enc[t]                         (:191-205)  */
+  LR_ATT_1LNN = 3,    /* logit[t] = w . [enc[t]; h] + b                            (:185-190)  */
+  LR_ATT_CONCAT = 4   /* logit[t] = w2 . tanh(W1 [enc[t]; h] + b1) + b2            (:209-215)  */
+} lr_attention_type;
+
+/* Device pointers to the parameters of CharDecodingStep (torch layouts, fp32). */
+typedef struct lr_decoder_params {
+  const float* emb;     /* embedding.weight      [V][Cd]                                        */
+  const float* w_ih;    /* rnn.weight_ih_l0      [G*Hd][Cd]                                     */
+  const float* w_hh;    /* rnn.weight_hh_l0      [G*Hd][Hd]                                     */
+  const float* b_ih;    /* rnn.bias_ih_l0        [G*Hd]                                         */
+  const float* b_hh;    /* rnn.bias_hh_l0        [G*Hd]                                         */
+  const float* attn_w1; /* general: W_g [Hd][Hd]; 1_layer_nn: w [1][2Hd]; concat: W1 [A][2Hd]   */
+  const float* attn_b1; /* general: b_g [Hd];     1_layer_nn: b [1];      concat: b1 [A]        */
+  const float* attn_w2; /* concat: attn_proj_layer2.weight [1][A]                               */
+  const float* attn_b2; /* concat: attn_proj_layer2.bias   [1]                                  */
+  const float* w_c;     /* concat_layer.weight   [Hd][2Hd]   (unused for LR_ATT_NONE)           */
+  const float* b_c;     /* concat_layer.bias     [Hd]                                           */
+  const float* w_o;     /* output_proj.weight    [V][Hd]                                        */
+  const float* b_o;     /* output_proj.bias      [V]                                            */
+  const float* out_mask;/* [V] 0/1 floats: PAD and BOS masked (better_model.py:142-144)         */
+} lr_decoder_params;
+
+/* Gradients, same layouts; overwritten, or added to when `accumulate` != 0. */
+typedef struct lr_decoder_grads {
+  float* emb; float* w_ih; float* w_hh; float* b_ih; float* b_hh;
+  float* attn_w1; float* attn_b1; float* attn_w2; float* attn_b2;
+  float* w_c; float* b_c; float* w_o; float* b_o;
+  int emb_padding_idx;  /* nn.Embedding(padding_idx): that row receives no gradient; -1 = none    */
+} lr_decoder_grads;
+
+/* The whole decoder loop of one batch (max_label_len = L steps), single-layer RNN of hidden size
+ * Hd started from the encoder's final state (h0 [B][Hd], c0 for the LSTM).
+ *   tokens [B][L] int32    teacher inputs chars[:, i] (device)
+ *   teacher_forced_host[L] HOST bytes: 1 = step i is fed tokens[:, i], 0 = fed the previous step's
+ *                          multinomial sample (train_better_model.py:57-58; step 0 always uses tokens)
+ *   enc [B][T][Hd], enc_lens [B] int32; step_lens [B] int32, every entry = L
+ *   log_probs [B][L][V]    masked log-softmax outputs of every step (better_model.py:229)
+ *   sampled [B][L] int32   multinomial(exp(log_probs)) of every step (counter-based RNG on `seed`;
+ *                          equal to torch's sampler in distribution only)
+ * The caller derives the loss (nll_loss, ignore_index = PAD, train_better_model.py:62) and the
+ * accuracy counts (:131-133) from log_probs / sampled.  h_n / c_n [B][Hd] (may be NULL) receive
+ * the RNN state after the last step (the final_state a single reference step returns).           */
+size_t lr_decoder_reserve_bytes(int mode, int attn_type, int B, int L, int T, int Hd, int Cd, int V, int A);
+size_t lr_decoder_workspace_bytes(int mode, int attn_type, int B, int L, int T, int Hd, int Cd, int V, int A);
+int lr_decoder_forward(int mode, int attn_type, const lr_decoder_params* params_host, const int32_t* tokens,
+                       const uint8_t* teacher_forced_host, const float* enc, const int32_t* enc_lens,
+                       const float* h0, const float* c0, const int32_t* step_lens, uint64_t seed,
+                       float* log_probs, int32_t* sampled, float* h_n, float* c_n, void* reserve,
+                       size_t reserve_bytes, int B, int L, int T, int Hd, int Cd, int V, int A,
+                       lr_stream_t stream);
+/* Backward of the loop: d_log_probs [B][L][V] (+ dh_n / dc_n [B][Hd], gradient arriving through the
+ * returned final state; may be NULL) -> d_enc [B][T][Hd] (overwritten), dh0 / dc0 [B][Hd] (gradient
+ * into the encoder's final state) and every parameter gradient.                                    */
+int lr_decoder_backward(int mode, int attn_type, const lr_decoder_params* params_host,
+                        const lr_decoder_grads* grads_host, const float* enc, const int32_t* enc_lens,
+                        const float* h0, const float* c0, const int32_t* step_lens, const float* log_probs,
+                        const float* d_log_probs, const float* dh_n, const float* dc_n, float* d_enc,
+                        float* dh0, float* dc0, const void* reserve, size_t reserve_bytes, void* workspace,
+                        size_t workspace_bytes, int accumulate, int B, int L, int T, int Hd, int Cd, int V,
+                        int A, lr_stream_t stream);
+
 /* ---- A4: CTC loss — src/train/ctc_loss.py:28-114 ---------------------------------------- */
 
 /* Per-sample CTC negative log-likelihood and its gradient, blank = 0, the same recursion as

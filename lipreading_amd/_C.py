@@ -5,7 +5,7 @@ error, the call raises.  Nothing in this module imports from oracle/.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 from . import _build
 
@@ -38,6 +38,12 @@ SIGNATURES = {
     "lr_proj_logsoftmax_forward": (c_int, [P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, P]),
     "lr_proj_logsoftmax_backward": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int, c_int,
                                              c_int, P]),
+    "lr_decoder_reserve_bytes": (c_size_t, [c_int] * 9),
+    "lr_decoder_workspace_bytes": (c_size_t, [c_int] * 9),
+    "lr_decoder_forward": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, c_uint64, P, P, P, P, P, c_size_t] +
+                           [c_int] * 7 + [P]),
+    "lr_decoder_backward": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P,
+                                     c_size_t, c_int] + [c_int] * 7 + [P]),
     "lr_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "lr_ctc_nll": (c_int, [P, c_int64, c_int64, P, c_int, P, P, P, P, c_size_t, c_int, c_int,
                             c_int, c_int, P]),
@@ -59,6 +65,18 @@ SIGNATURES = {
     "lr_adam_step": (c_int, [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_float,
                               c_float, P, P, P, P]),
 }
+
+
+class DecoderParams(ctypes.Structure):
+  """lr_decoder_params (include/lipreading_hip.h)."""
+  _fields_ = [(n, c_void_p) for n in ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "attn_w1", "attn_b1", "attn_w2",
+                                      "attn_b2", "w_c", "b_c", "w_o", "b_o", "out_mask")]
+
+
+class DecoderGrads(ctypes.Structure):
+  """lr_decoder_grads."""
+  _fields_ = [(n, c_void_p) for n in ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "attn_w1", "attn_b1", "attn_w2",
+                                      "attn_b2", "w_c", "b_c", "w_o", "b_o")] + [("emb_padding_idx", c_int)]
 
 
 class LipReadingHipError(RuntimeError):

@@ -85,3 +85,25 @@ enum {
   LR_PROF_SLOTS = 10
 };
 bool lr_prof_next(int slot, hipEvent_t* start, hipEvent_t* stop);
+
+// ---- recurrent layer pieces shared with lr_decoder.hip (implemented in lr_rnn.hip) --------------------
+size_t lr_rnn_packed_w_floats(int G, int H);
+size_t lr_rnn_packed_state_floats(int B, int H);
+int lr_rnn_fold_bias(const float* b_ih, const float* b_hh, float* out, int G, int H, hipStream_t stream);
+int lr_rnn_pack_w(const float* W, float* out, int G, int H, int transposed, hipStream_t stream);
+int lr_rnn_pack_state(const float* h, float* slot, int B, int H, hipStream_t stream);
+int lr_rnn_step_fwd(int G, float* gates, float* extra, float* y, float* hp, const int32_t* lens,
+                    const float* wp, const float* b_hh, const float* h0, const float* c0, int B, int T,
+                    int H, int step, hipStream_t stream);
+int lr_rnn_step_bwd(int G, const float* gates, const float* extra, const float* y, const float* dy,
+                    const float* dh_n, const float* dc_n, float* dG, float* dcar, float* dgp, const int32_t* lens,
+                    const float* wpT, const float* h0, const float* c0, int B, int T, int H, int step,
+                    hipStream_t stream);
+int lr_rnn_dh0(int G, const float* dcar, const float* dgp_slot, const float* wpT, float* dh0, float* dc0, int B,
+               int T, int H, hipStream_t stream);
+int lr_rnn_bias_grads(const float* dG, float* partial, float* db_ih, float* db_hh, int rows, int H, int G,
+                      int accumulate, hipStream_t stream);
+int lr_sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                  const float* B, int ldb, float beta, float* C, int ldc, const float* bias, int row_shift,
+                  int period, void* workspace, size_t workspace_bytes, hipStream_t stream);
+extern "C" size_t lr_sgemm_workspace_bytes(int M, int N, int K);

@@ -55,6 +55,10 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 struct StepPtrs {
   const float* w[2];   // per direction: packed W_hh (forward) / packed W_hh^T (backward)
   const float* b[2];   // per direction: b_hh [G*H]
+  // optional initial state [D][B][H] (decoder: the encoder's final state, better_model.py:181):
+  // step 0 then reads its "previous" h / c from here (and the packed copy already sits in hp).
+  const float* h0;
+  const float* c0;
 };
 constexpr int FRAG = 256;  // floats per 16x16 operand fragment
 
@@ -89,7 +93,8 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(float* gates, flo
   const int d = blockIdx.z;
   const int t = d == 0 ? step : T - 1 - step;
   const int tp = d == 0 ? t - 1 : t + 1;
-  const bool has_prev = tp >= 0 && tp < T;
+  const bool in_seq = tp >= 0 && tp < T;
+  const bool has_prev = in_seq || (p.h0 != nullptr && step == 0);
   const int j0 = blockIdx.x * TILE, b0 = blockIdx.y * TILE;
   const int DH = D * H;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -109,9 +114,11 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(float* gates, flo
     for (int g = 0; g < G; ++g) gx[g] = go[g * H];
     if (G == 3) {
       bhn = p.b[d][2 * H + j];
-      if (has_prev) prev_own = y[btp * DH + d * H + j];            // h_{t-1}
+      if (in_seq) prev_own = y[btp * DH + d * H + j];              // h_{t-1}
+      else if (has_prev) prev_own = p.h0[((int64_t)d * B + b) * H + j];
     } else {
-      if (has_prev) prev_own = extra[(btp * D + d) * H + j];       // c_{t-1}
+      if (in_seq) prev_own = extra[(btp * D + d) * H + j];         // c_{t-1}
+      else if (has_prev && p.c0) prev_own = p.c0[((int64_t)d * B + b) * H + j];
     }
   }
 
@@ -221,6 +228,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(
   const int tp = d == 0 ? t - 1 : t + 1;        // where h_prev / c_prev of step t live
   const bool has_next = tn >= 0 && tn < T;
   const bool has_prev = tp >= 0 && tp < T;
+  const bool init_prev = !has_prev && p.h0 != nullptr;   // step 0 of a layer with an initial state
   const int j0 = blockIdx.x * TILE, b0 = blockIdx.y * TILE;
   const int DH = D * H, GH = G * H;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -242,6 +250,10 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(
     for (int g = 0; g < G; ++g) gv[g] = gi[g * H];
     ex = extra[(bt * D + d) * H + j];                       // GRU: W_hn h + b_hn ; LSTM: c_t
     if (has_prev) prev = G == 3 ? y[btp * DH + d * H + j] : extra[(btp * D + d) * H + j];
+    else if (init_prev) {
+      const float* src = G == 3 ? p.h0 : p.c0;
+      if (src) prev = src[((int64_t)d * B + b) * H + j];
+    }
     if (dh_n) inj_h = dh_n[((int64_t)d * B + b) * H + j];
     if (G == 4 && dc_n) inj_c = dc_n[((int64_t)d * B + b) * H + j];
   }
@@ -418,6 +430,66 @@ __global__ void bias_grad_final_kernel(const float* __restrict__ partial, BiasPt
   if (hh) *hh = accumulate ? *hh + s : s;
 }
 
+// h [B][H] -> one packed state slot [batch tile][chunk][64][4] (rows past B / k past H stay zero)
+__global__ void pack_state_kernel(const float* __restrict__ h, float* __restrict__ slot, int B, int H) {
+  const int nchunk = (H + 15) >> 4;
+  const int64_t total = (int64_t)B * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / H), k = (int)(i - (int64_t)b * H);
+    const int kk = k & 15;
+    slot[(((int64_t)(b >> 4) * nchunk + (k >> 4)) * 64 + (b & 15) + 16 * (kk >> 2)) * 4 + (kk & 3)] = h[i];
+  }
+}
+
+// Gradient that leaves a layer through its initial state (single direction, forward in time):
+//   dh0[b][j] = (GRU: dh_0 * z_0) + sum_{g,k} dG_h[b][t=0][g][k] * W_hh[g*H+k][j],   dc0 = dc_0 * f_0 (LSTM)
+// i.e. one more recurrent product after the last backward step, without a gate stage.
+template <int G>
+__global__ __launch_bounds__(NW * 64) void rnn_dh0_kernel(const float* __restrict__ dcar,
+                                                         const float* __restrict__ dgp_slot,
+                                                         const float* __restrict__ wpT, float* __restrict__ dh0,
+                                                         float* __restrict__ dc0, int B, int T, int H) {
+  __shared__ float red[NW * TILE * RED_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nchunk = (H + 15) >> 4, total = G * nchunk;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* asrc = dgp_slot + ((int64_t)blockIdx.y * total) * FRAG + lane * 4;
+  const float* wsrc = wpT + ((int64_t)blockIdx.x * total) * FRAG + lane * 4;
+  for (int f0 = wave; f0 < total; f0 += NW * UF_BWD_GRU) {
+    float4 a[UF_BWD_GRU], w[UF_BWD_GRU];
+#pragma unroll
+    for (int u = 0; u < UF_BWD_GRU; ++u) {
+      const int f = f0 + u * NW;
+      const bool ok = f < total;
+      a[u] = ok ? ld4(asrc + (int64_t)f * FRAG) : zero4;
+      w[u] = ok ? ld4(wsrc + (int64_t)f * FRAG) : zero4;
+    }
+#pragma unroll
+    for (int u = 0; u < UF_BWD_GRU; ++u) {
+      if (f0 + u * NW < total) { LR_MFMA4(acc, a[u], w[u]); }
+    }
+  }
+  const int rowi = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[(wave * TILE + kq * 4 + r) * RED_LD + rowi] = acc[r];
+  __syncthreads();
+  const int bl = (tid >> 4) & 15, jl = tid & 15;
+  const int b = blockIdx.y * TILE + bl, j = blockIdx.x * TILE + jl;
+  if (tid >= 256 || b >= B || j >= H) return;
+  float dh = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) dh += red[(w * TILE + bl) * RED_LD + jl];
+  const float car = dcar[((int64_t)b * T) * H + j];   // t = 0, D = 1
+  if (G == 3) {
+    dh0[(int64_t)b * H + j] = dh + car;
+  } else {
+    dh0[(int64_t)b * H + j] = dh;
+    if (dc0) dc0[(int64_t)b * H + j] = car;
+  }
+}
+
 struct Layout {
   size_t gates, extra, bias, wp, hp, gemm, total;  // float offsets / total floats
   size_t wp_per_dir, hp_floats, gemm_bytes;
@@ -515,6 +587,8 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
     if (st != LR_OK) return st;
   }
   StepPtrs p;
+  p.h0 = nullptr;
+  p.c0 = nullptr;
   float* wp = base + l.wp;
   float* hp = base + l.hp;
   for (int d = 0; d < D; ++d) {
@@ -586,6 +660,8 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
   const int GH = G * H;
 
   StepPtrs p;
+  p.h0 = nullptr;
+  p.c0 = nullptr;
   float* dgp = wbase + wl.dgp;
   for (int d = 0; d < D; ++d) {
     float* out = wT + (size_t)d * wl.wp_per_dir;
@@ -654,5 +730,76 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
   if (st != LR_OK) return st;
   LR_LAUNCH(bias_grad_final_kernel, dim3((ldg + 255) / 256), dim3(256), 0, stream,
             (const float*)partial, bp, H, D, G, accumulate);
+  return lr_launch_status();
+}
+
+// ---- internal entry points for lr_decoder.hip (single direction, one step per call) -------------
+size_t lr_rnn_packed_w_floats(int G, int H) {
+  const size_t nchunk = (H + 15) / 16;
+  return nchunk * G * nchunk * FRAG;
+}
+size_t lr_rnn_packed_state_floats(int B, int H) {   // one parity slot, one direction
+  return (size_t)((B + 15) / 16) * ((H + 15) / 16) * FRAG;
+}
+int lr_rnn_fold_bias(const float* b_ih, const float* b_hh, float* out, int G, int H, hipStream_t stream) {
+  LR_LAUNCH(fold_bias_kernel, dim3((G * H + 255) / 256), dim3(256), 0, stream, b_ih, b_hh, out, G, H);
+  return lr_launch_status();
+}
+int lr_rnn_pack_w(const float* W, float* out, int G, int H, int transposed, hipStream_t stream) {
+  int blocks = (int)((lr_rnn_packed_w_floats(G, H) + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  LR_LAUNCH(pack_w_kernel, dim3(blocks), dim3(256), 0, stream, W, out, G, H, transposed);
+  return lr_launch_status();
+}
+int lr_rnn_pack_state(const float* h, float* slot, int B, int H, hipStream_t stream) {
+  int blocks = (int)(((int64_t)B * H + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  LR_LAUNCH(pack_state_kernel, dim3(blocks), dim3(256), 0, stream, h, slot, B, H);
+  return lr_launch_status();
+}
+int lr_rnn_step_fwd(int G, float* gates, float* extra, float* y, float* hp, const int32_t* lens,
+                    const float* wp, const float* b_hh, const float* h0, const float* c0, int B, int T,
+                    int H, int step, hipStream_t stream) {
+  StepPtrs p;
+  p.w[0] = p.w[1] = wp;
+  p.b[0] = p.b[1] = b_hh;
+  p.h0 = h0;
+  p.c0 = c0;
+  const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, 1);
+  if (G == 3) LR_LAUNCH(rnn_fwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, 1, step);
+  else LR_LAUNCH(rnn_fwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, 1, step);
+  return lr_launch_status();
+}
+int lr_rnn_step_bwd(int G, const float* gates, const float* extra, const float* y, const float* dy,
+                    const float* dh_n, const float* dc_n, float* dG, float* dcar, float* dgp, const int32_t* lens,
+                    const float* wpT, const float* h0, const float* c0, int B, int T, int H, int step,
+                    hipStream_t stream) {
+  StepPtrs p;
+  p.w[0] = p.w[1] = wpT;
+  p.b[0] = p.b[1] = nullptr;
+  p.h0 = h0;
+  p.c0 = c0;
+  const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, 1);
+  if (G == 3) LR_LAUNCH(rnn_bwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, 1, step);
+  else LR_LAUNCH(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, 1, step);
+  return lr_launch_status();
+}
+int lr_rnn_dh0(int G, const float* dcar, const float* dgp_slot, const float* wpT, float* dh0, float* dc0, int B,
+               int T, int H, hipStream_t stream) {
+  const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, 1);
+  if (G == 3) LR_LAUNCH(rnn_dh0_kernel<3>, grid, dim3(NW * 64), 0, stream, dcar, dgp_slot, wpT, dh0, dc0, B, T, H);
+  else LR_LAUNCH(rnn_dh0_kernel<4>, grid, dim3(NW * 64), 0, stream, dcar, dgp_slot, wpT, dh0, dc0, B, T, H);
+  return lr_launch_status();
+}
+int lr_rnn_bias_grads(const float* dG, float* partial, float* db_ih, float* db_hh, int rows, int H, int G,
+                      int accumulate, hipStream_t stream) {
+  const int ldg = 4 * H;
+  int st = lr_colsum_partial(dG, ldg, rows, ldg, partial, stream);
+  if (st != LR_OK) return st;
+  BiasPtrs bp;
+  bp.db_ih[0] = bp.db_ih[1] = db_ih;
+  bp.db_hh[0] = bp.db_hh[1] = db_hh;
+  LR_LAUNCH(bias_grad_final_kernel, dim3((ldg + 255) / 256), dim3(256), 0, stream, (const float*)partial, bp, H,
+            1, G, accumulate);
   return lr_launch_status();
 }

@@ -1,0 +1,142 @@
+"""GPU parity: the attention decoder loop (N1) through the C ABI against the vectors captured from
+the reference's CharDecodingStep (five attention types) and against the oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import torch_oracle as O
+from tests.test_oracle_golden import DEC_CASES, _flatten, build_oracle_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+  assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+  return torch.device("cuda:0")
+
+
+def hip_pair(case, rnn_type, attn, dev):
+  from lipreading_amd.attention_decoder import CharDecodingStep
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.encoder import VideoEncoder
+  H, bi, char_dim, ah = [int(x) for x in case["cfg"]]
+  enc = VideoEncoder(204, H, rnn_type=rnn_type, num_layers=1, bidirectional=bool(bi), enable_ctc=True,
+                     vocab_size=64, char2idx=default_char2idx())
+  dec = CharDecodingStep(enc, char_dim=char_dim, vocab_size=64, char2idx=default_char2idx(),
+                         attention_type=attn, attn_hidden_size=ah)
+  r1 = enc.load_state_dict({k: torch.tensor(v) for k, v in _flatten(case["enc_sd"]).items()})
+  r2 = dec.load_state_dict({k: torch.tensor(v) for k, v in _flatten(case["dec_sd"]).items()})
+  assert not (r1.missing_keys or r1.unexpected_keys or r2.missing_keys or r2.unexpected_keys)
+  return enc.to(dev).train(), dec.to(dev).train()
+
+
+def grads_close(mod, want, tol=3e-4):
+  for k, p in mod.named_parameters():
+    ref = want[k]
+    got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(ref)
+    scale = max(1e-4, float(np.abs(ref).max()))
+    assert np.abs(got - ref).max() / scale < tol, (k, np.abs(got - ref).max(), scale)
+
+
+@pytest.mark.parametrize("name", sorted(DEC_CASES))
+def test_decoder_matches_reference_vectors(golden_dec, dev, name):
+  """encoder -> decoder loop at teacher_forcing_ratio 1 + CTC, decoder_loss.backward(retain_graph)
+  then ctc_loss.backward() (train_better_model.py:46-74)."""
+  from lipreading_amd.ctc import ctc_loss
+  case = golden_dec[name]
+  enc, dec = hip_pair(case, *DEC_CASES[name], dev)
+  lens = torch.tensor(case["lens"])
+  chars = torch.tensor(case["chars"], device=dev)
+  char_lens = torch.tensor(case["char_lens"])
+  labels, label_lens = chars[:, 1:], char_lens - 1
+  L = int(label_lens.max())
+  lp_enc, hid, final = enc(torch.tensor(case["frames"], device=dev), lens)
+  ctc = ctc_loss(lp_enc, labels, lens.to(dev), label_lens.to(dev), 'mean', dev)
+  lp, sampled, _ = dec.decode_sequence(chars[:, :L], final, lens, hid)
+  dec_loss = F.nll_loss(lp.reshape(-1, 64), labels[:, :L].reshape(-1), ignore_index=0, reduction='sum')
+  dec_loss = dec_loss / (labels != 0).sum()
+  np.testing.assert_allclose(lp.detach().cpu().numpy(), case["dec_log_probs"], rtol=1e-4, atol=2e-5)
+  assert abs(dec_loss.item() - float(case["dec_loss"])) < 1e-4
+  assert abs(ctc.item() - float(case["ctc_loss"])) < 1e-4
+  dec_loss.backward(retain_graph=True)
+  ctc.backward()
+  grads_close(dec, _flatten(case["dec_grad"]))
+  grads_close(enc, _flatten(case["enc_grad"]))
+  # samples come from exp(log_probs): never the masked PAD/BOS classes
+  s = sampled.cpu().numpy()
+  assert s.shape == (4, L) and ((s >= 2) & (s < 64)).all()
+
+
+@pytest.mark.parametrize("name", ["gru_1layernn", "lstm_concat"])
+def test_single_step_api_equals_fused_loop(golden_dec, dev, name):
+  """CharDecodingStep.forward (the reference's per-step contract) chained L times gives the fused
+  decode_sequence result, values and gradients."""
+  case = golden_dec[name]
+  enc, dec = hip_pair(case, *DEC_CASES[name], dev)
+  lens = torch.tensor(case["lens"])
+  chars = torch.tensor(case["chars"], device=dev)
+  L = int(case["char_lens"].max()) - 1
+  outs = {}
+  for mode in ("fused", "steps"):
+    enc.zero_grad(); dec.zero_grad()
+    _, hid, state = enc(torch.tensor(case["frames"], device=dev), lens)
+    if mode == "fused":
+      lp, _, _ = dec.decode_sequence(chars[:, :L], state, lens, hid)
+    else:
+      rows = []
+      for i in range(L):
+        o, state = dec(chars[:, i], state, lens.to(dev), hid)
+        rows.append(o)
+      lp = torch.stack(rows, 1)
+    (lp * torch.linspace(-1, 1, lp.numel(), device=dev).reshape(lp.shape)).sum().backward()
+    outs[mode] = (lp.detach().cpu().numpy(),
+                  {k: p.grad.detach().cpu().numpy().copy() for k, p in list(dec.named_parameters()) + list(enc.named_parameters()) if p.grad is not None})
+  np.testing.assert_allclose(outs["steps"][0], outs["fused"][0], rtol=1e-5, atol=1e-6)
+  for k, g in outs["fused"][1].items():
+    scale = max(1e-5, float(np.abs(g).max()))
+    assert np.abs(outs["steps"][1][k] - g).max() / scale < 2e-4, k
+
+
+def test_sampled_inputs_and_bench_sizes_match_oracle(dev):
+  """BASELINE-size decoder (B=32, T=75, Hd=512, L=31) with a mixed teacher-forcing pattern: the
+  HIP loop's own samples are replayed through the oracle step by step."""
+  from lipreading_amd.attention_decoder import CharDecodingStep
+  from lipreading_amd.data import default_char2idx
+
+  class Enc:   # only what CharDecodingStep reads from the encoder (better_model.py:134-136)
+    hidden_size, bidirectional, rnn_type, num_layers = 256, True, 'GRU', 1
+
+  torch.manual_seed(5)
+  ref = O.OracleCharDecodingStep(512, 'GRU', 1, 300, 64, O.default_char2idx(), attention_type='1_layer_nn')
+  dec = CharDecodingStep(Enc(), 300, 64, default_char2idx(), attention_type='1_layer_nn')
+  dec.load_state_dict(ref.state_dict())
+  dec = dec.to(dev)
+  g = torch.Generator().manual_seed(6)
+  B, T, L = 32, 75, 31
+  enc = torch.randn(B, T, 512, generator=g) * 0.5
+  lens = torch.sort(torch.randint(40, T + 1, (B,), generator=g))[0]
+  h0 = torch.randn(1, B, 512, generator=g) * 0.5
+  chars = torch.randint(4, 64, (B, L), generator=g)
+  tf = [True] + [bool(i % 3) for i in range(1, L)]
+  encd = enc.to(dev).requires_grad_(True)
+  lp, sampled, _ = dec.decode_sequence(chars.to(dev), h0.to(dev), lens, encd, teacher_forced=tf, seed=11)
+  s = sampled.cpu().long()
+  encr = enc.clone().requires_grad_(True)
+  state, rows = h0, []
+  for i in range(L):
+    inp = chars[:, i] if tf[i] else s[:, i - 1]
+    o, state = ref(inp, state, lens, encr)
+    rows.append(o)
+  want = torch.stack(rows, 1)
+  np.testing.assert_allclose(lp.detach().cpu().numpy(), want.detach().numpy(), rtol=2e-4, atol=5e-5)
+  wgt = torch.randn(B, L, 64, generator=g) / 100
+  (lp * wgt.to(dev)).sum().backward()
+  (want * wgt).sum().backward()
+  a, b = encd.grad.cpu().numpy(), encr.grad.numpy()
+  assert np.abs(a - b).max() / np.abs(b).max() < 5e-4
+  gr = dict(ref.named_parameters())
+  for k, p in dec.named_parameters():
+    r = gr[k].grad.numpy()
+    assert np.abs(p.grad.cpu().numpy() - r).max() / max(1e-5, np.abs(r).max()) < 5e-4, k

@@ -89,3 +89,23 @@ def test_checkpoint_round_trip_with_reference_format(tmp_path):
   ref2 = O.OracleVideoEncoder(204, 12, rnn_type="LSTM", num_layers=2, bidirectional=True,
                               enable_ctc=True, vocab_size=64, char2idx=O.default_char2idx())
   ref2.load_state_dict(torch.load(str(out)), strict=True)
+
+
+@pytest.mark.parametrize("attn,ah", [("none", -1), ("dot", -1), ("general", -1), ("1_layer_nn", -1), ("concat", 10)])
+def test_decoder_state_dict_and_init_match_reference_shape(attn, ah):
+  """CharDecodingStep: same keys, shapes and (given the seed) initial weights as the reference
+  module structure (better_model.py:145-156)."""
+  from lipreading_amd.attention_decoder import CharDecodingStep
+  from lipreading_amd.encoder import VideoEncoder
+  enc = VideoEncoder(204, 8, rnn_type='LSTM', bidirectional=True, enable_ctc=True, vocab_size=64,
+                     char2idx=default_char2idx())
+  torch.manual_seed(99)
+  ref = O.OracleCharDecodingStep(16, 'LSTM', 1, 12, 64, O.default_char2idx(), attention_type=attn,
+                                 attn_hidden_size=ah)
+  torch.manual_seed(99)
+  dec = CharDecodingStep(enc, 12, 64, default_char2idx(), attention_type=attn, attn_hidden_size=ah)
+  a, b = ref.state_dict(), dec.state_dict()
+  assert list(a.keys()) == list(b.keys())
+  for k in a:
+    assert torch.equal(a[k], b[k]), k
+  assert dec.output_mask.tolist() == ref.output_mask.tolist() and dec.hidden_size == 16
