@@ -7,7 +7,8 @@ GPU: the framing asserts (:26-33) run on the host copies the loader hands over; 
 uses the device-side status flag instead of a `None` return, so a skipped batch costs no
 device->host round trip (the optimiser kernel honours the flag); losses are accumulated on the
 device and read once per epoch.  `decoding_step=None` runs the encoder+CTC path alone — the
-path BASELINE.json's north_star names; the attention decoder loop (:56-65) is the "next" row.
+path BASELINE.json's north_star names; with a `CharDecodingStep` the attention decoder loop
+(:56-65) runs as one fused enqueue per batch (lipreading_amd/attention_decoder.py).
 """
 import torch
 import torch.nn.functional as F
@@ -52,49 +53,133 @@ def ctc_step(encoder, opt, frames, frame_lens, chars, char_lens, grad_norm=None,
   return loss.detach(), status
 
 
+def _decoder_losses(decoding_step, chars, labels, label_lens_host, frame_lens, hidden, state,
+                    teacher_forcing_ratio, pad):
+  """train_better_model.py:54-65: the decoder loop and its summed NLL.  The teacher-forcing coin
+  of every step (:57) is drawn up front from the same host generator (torch.rand(1) per step), so
+  all L steps go out as one enqueue; prev_output's multinomial (:63) is drawn on the device."""
+  L = int(label_lens_host.max())
+  flags = [bool(torch.rand(1) < teacher_forcing_ratio) for _ in range(L)]
+  log_probs, sampled, _ = decoding_step.decode_sequence(chars[:, :L], state, frame_lens, hidden,
+                                                        teacher_forced=flags)
+  V = log_probs.shape[-1]
+  nll = F.nll_loss(log_probs.reshape(-1, V), labels[:, :L].reshape(-1), ignore_index=pad, reduction='sum')
+  return nll, sampled, L
+
+
 def train(encoder, decoding_step, data_loader, opt, device, char2idx,
           teacher_forcing_ratio=1, grad_norm=None, grad_sync=None):
   """Assumes sequences begin with BOS and end with EOS; data_loader yields
-  (frames f32, frame_lens i64, chars i64, char_lens i64) — train_better_model.py:7-16."""
+  (frames f32, frame_lens i64, chars i64, char_lens i64) — train_better_model.py:7-86.
+
+  decoding_step=None: encoder+CTC alone, `opt` a FusedAdam over the encoder.  With a
+  CharDecodingStep `opt` is (encoder FusedAdam, decoder FusedAdam): the reference clips the two
+  modules separately (:77-79) and one Adam over both is the same update as two Adams.  The
+  reference runs decoder_loss.backward(retain_graph) and then ctc_loss.backward() (:70,:74): two
+  traversals of the encoder graph whose gradients add; here the two losses are summed and the
+  encoder is traversed once — the same gradients up to fp32 addition order."""
   use_ctc = encoder.enable_ctc
-  if decoding_step is not None:
-    raise NotImplementedError("the attention CharDecodingStep loop (train_better_model.py:56-65) "
-                              "is the N1 'next' row; pass decoding_step=None for encoder+CTC")
-  assert use_ctc, "without a decoding step the encoder must have enable_ctc=True"
-  assert isinstance(opt, FusedAdam), "opt must be lipreading_amd.optim.FusedAdam"
+  pad = char2idx[PAD]
+  if decoding_step is None:
+    assert use_ctc, "without a decoding step the encoder must have enable_ctc=True"
+    assert isinstance(opt, FusedAdam), "opt must be lipreading_amd.optim.FusedAdam"
+    opts = (opt,)
+  else:
+    assert grad_sync is None, "data-parallel training of the decoder loop is not wired yet"
+    opts = tuple(opt)
+    assert len(opts) == 2 and all(isinstance(o, FusedAdam) for o in opts), \
+        "opt must be (encoder FusedAdam, decoder FusedAdam)"
+    decoding_step.train()
   encoder.train()
   ctc_sum = torch.zeros((), dtype=torch.float32, device=device)
+  dec_sum = torch.zeros((), dtype=torch.float32, device=device)
   for frames, frame_lens, chars, char_lens in data_loader:
     _check_framing(chars, char_lens, frame_lens, char2idx, use_ctc)
     max_len = int(frame_lens.max()) if not frame_lens.is_cuda else None
+    label_lens_host = (char_lens - 1).cpu()
     frames, chars = frames.to(device), chars.to(device)
     frame_lens_d, char_lens_d = frame_lens.to(device), char_lens.to(device)
-    loss, _ = ctc_step(encoder, opt, frames, frame_lens_d, chars, char_lens_d, grad_norm=grad_norm,
-                       max_len=max_len, grad_sync=grad_sync)
-    ctc_sum += loss  # a skipped batch contributes 0, as `continue` does at :49-50
+    if decoding_step is None:
+      loss, _ = ctc_step(encoder, opt, frames, frame_lens_d, chars, char_lens_d, grad_norm=grad_norm,
+                         max_len=max_len, grad_sync=grad_sync)
+      ctc_sum += loss  # a skipped batch contributes 0, as `continue` does at :49-50
+      continue
+    labels = chars[:, 1:]
+    for o in opts:
+      o.zero_grad()
+    status = None
+    total = 0
+    if use_ctc:
+      log_probs, hidden, state = encoder(frames, frame_lens_d, max_len=max_len)
+      ctc, status, _ = ctc_loss_with_status(log_probs, labels, frame_lens_d, char_lens_d - 1, 'mean')
+      total = ctc
+    else:
+      hidden, state = encoder(frames, frame_lens_d, max_len=max_len)
+    nll, _, _ = _decoder_losses(decoding_step, chars, labels, label_lens_host, frame_lens_d, hidden,
+                                state, teacher_forcing_ratio, pad)
+    decoder_loss = nll / (labels != pad).sum()
+    (decoder_loss + total).backward()
+    for o in opts:  # per-module clip (:77-79); a batch the reference skips (:49-50) updates nothing
+      o.step(grad_norm=grad_norm, skip=status)
+    if status is None:
+      dec_sum += decoder_loss.detach()
+    else:
+      dec_sum += decoder_loss.detach() * (status.reshape(()) == 0)
+      ctc_sum += ctc.detach()
   avg_ctc_loss = (ctc_sum / len(data_loader)).item()  # :84 divides by len(data_loader)
-  print(f'\tTraining ctc_loss: {avg_ctc_loss}')
-  return 0.0, avg_ctc_loss
+  avg_decoder_loss = (dec_sum / len(data_loader)).item()
+  if decoding_step is not None:
+    print(f'\tTraining decoder_loss: {avg_decoder_loss}')
+  if use_ctc:
+    print(f'\tTraining ctc_loss: {avg_ctc_loss}')
+  return avg_decoder_loss, avg_ctc_loss
 
 
 def eval(encoder, decoding_step, data_loader, device, char2idx):
-  """train_better_model.py:89-143 for the encoder+CTC path: CTC 'sum' per batch (:116) averaged
-  over len(data_loader) (:141).  Returns (decoder_loss, correct, count, ctc_loss); the first
-  three are the reference's tuple and stay 0 without a decoding step."""
-  if decoding_step is not None:
-    raise NotImplementedError("CharDecodingStep evaluation is the N1 'next' row")
+  """train_better_model.py:89-143: CTC 'sum' per batch (:116) averaged over len(data_loader)
+  (:141); decoder loop teacher-forced on every step (:125), NLL summed and divided by the count of
+  non-PAD labels (:138), `correct` counts multinomial samples equal to the label (:129-133).
+  Returns (decoder_loss, correct, count, ctc_loss) — the reference's tuple plus the CTC average
+  it computes and drops."""
+  pad = char2idx[PAD]
+  use_ctc = encoder.enable_ctc
   encoder.eval()
+  if decoding_step is not None:
+    decoding_step.eval()
   ctc_sum = torch.zeros((), dtype=torch.float32, device=device)
+  dec_sum = torch.zeros((), dtype=torch.float32, device=device)
+  correct = torch.zeros((), dtype=torch.int64, device=device)
+  count = torch.zeros((), dtype=torch.float32, device=device)
   with torch.no_grad():
     for frames, frame_lens, chars, char_lens in data_loader:
       _check_framing(chars, char_lens, frame_lens, char2idx, False)
       max_len = int(frame_lens.max()) if not frame_lens.is_cuda else None
+      label_lens_host = (char_lens - 1).cpu()
       frames, chars = frames.to(device), chars.to(device)
-      log_probs, _, _ = encoder(frames, frame_lens.to(device), max_len=max_len)
-      loss, _, _ = ctc_loss_with_status(log_probs, chars[:, 1:], frame_lens.to(device),
-                                        (char_lens - 1).to(device), 'sum')
-      ctc_sum += loss
-  return 0.0, 0, 0, (ctc_sum / len(data_loader)).item()
+      frame_lens_d = frame_lens.to(device)
+      labels = chars[:, 1:]
+      keep = 1
+      if use_ctc:
+        log_probs, hidden, state = encoder(frames, frame_lens_d, max_len=max_len)
+        loss, status, _ = ctc_loss_with_status(log_probs, labels, frame_lens_d,
+                                               (char_lens - 1).to(device), 'sum')
+        ctc_sum += loss
+        keep = (status.reshape(()) == 0)  # :117-118 `continue`s past the decoder on a skipped batch
+      else:
+        hidden, state = encoder(frames, frame_lens_d, max_len=max_len)
+      if decoding_step is None:
+        continue
+      nll, sampled, L = _decoder_losses(decoding_step, chars, labels, label_lens_host, frame_lens_d,
+                                        hidden, state, 2.0, pad)
+      mask = labels[:, :L] != pad
+      dec_sum += nll * keep
+      correct += ((sampled.long() == labels[:, :L]) & mask).sum() * keep
+      count += mask.sum().float() * keep
+  ctc_avg = (ctc_sum / len(data_loader)).item()
+  if decoding_step is None:
+    return 0.0, 0, 0, ctc_avg
+  count_h = count.item()
+  return (dec_sum / count).item() if count_h else float('nan'), int(correct.item()), count_h, ctc_avg
 
 
 def greedy_cer(encoder, data_loader, device, char2idx):
