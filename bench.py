@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the video->characters hot path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--regime pixels|landmarks|both]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--regime pixels|landmarks|landmarks_attn|all]
                   [--model gru256|lstm768] [--batch B]
 
 One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
@@ -16,6 +16,9 @@ Two input regimes (SURVEY.md section 8d says they must be reported separately):
   landmarks  reference-faithful: landmarks (B,75,68,3) f32 -> 1-layer BiGRU-256 (or BiLSTM-768) ->
              CTC; the only regime whose every stage is pinned to the reference.  Reported under
              "regimes" on the same line (and as the headline with --regime landmarks).
+  landmarks_attn  the reference's WHOLE train step (train_better_model.py:46-80): the landmarks
+             regime plus the CharDecodingStep loop (char_dim 300, '1_layer_nn' attention,
+             teacher_forcing_ratio 1, L=31 steps), decoder NLL + CTC, per-module clip, Adam.
 
 Extra objects: `roofline` for the regime's dominant kernel (average launch duration measured live
 with hipEvent pairs that stamp the dispatch on its own stream, in an eager pass right after the
@@ -105,7 +108,12 @@ def cpu_baseline(regime, model, layers, B, budget_s=20.0):
       c = torch.nn.Conv3d(cin, cout, k, stride=(1, stride, stride), padding=pad)
       convs += [c.weight, c.bias]
     params = convs + params
-  opt = torch.optim.Adam(params, lr=1e-4)
+  attn = regime == "landmarks_attn"
+  dec = None
+  if attn:
+    dec = O.OracleCharDecodingStep(H * (2 if bi else 1), rnn_type, 1, 300, VOCAB, O.default_char2idx(),
+                                   attention_type='1_layer_nn').train()
+  opt = torch.optim.Adam(params + (list(dec.parameters()) if attn else []), lr=1e-4)
   frames, frame_lens, chars, char_lens = synth_batch(B, 123456)
   clips = synth_clips(B, 123456) if pixels else None
 
@@ -114,11 +122,16 @@ def cpu_baseline(regime, model, layers, B, budget_s=20.0):
     if pixels:
       feats = O.conv_frontend(clips, convs, emulate_bf16=False)
       x = feats.reshape(B, T_FRAMES, -1, 1)
-    lp, _, _ = enc(x, frame_lens)
+    lp, hid, st = enc(x, frame_lens)
     loss = O.ctc_loss(lp, chars[:, 1:], frame_lens, char_lens - 1, 'mean')
     opt.zero_grad()
+    if attn:   # train_better_model.py:56-74, both backward calls as the reference makes them
+      dl, _ = O.decoder_loop(dec, chars, char_lens, hid, frame_lens, st)
+      dl.backward(retain_graph=True)
     loss.backward()
     torch.nn.utils.clip_grad_norm_(params, 50)
+    if attn:
+      torch.nn.utils.clip_grad_norm_(dec.parameters(), 50)
     opt.step()
 
   step()  # warm-up
@@ -151,7 +164,10 @@ def run_regime(args, regime, world, rank, dev):
 
   rnn_type, H, bi = MODELS[args.model]
   pixels = regime == "pixels"
+  attn = regime == "landmarks_attn"
   layers = args.layers if args.layers is not None else (2 if pixels else 1)
+  if attn:
+    layers = 1   # better_model.py:134-136: the decoder takes the encoder's layer count; shipped configs use 1
   D, G = (2 if bi else 1), (3 if rnn_type == "GRU" else 4)
   B = args.batch
   torch.manual_seed(123456)
@@ -166,6 +182,14 @@ def run_regime(args, regime, world, rank, dev):
   enc = model.encoder if pixels else model
   flat = FlatParameters(model)
   opt = FusedAdam(flat, lr=1e-4)
+  dec = dec_opt = dec_sync = None
+  if attn:
+    import torch.nn.functional as F
+    from lipreading_amd.attention_decoder import CharDecodingStep
+    dec = CharDecodingStep(enc, char_dim=300, vocab_size=VOCAB, char2idx=default_char2idx(),
+                           attention_type='1_layer_nn').to(dev).train()
+    dec_flat = FlatParameters(dec)
+    dec_opt = FusedAdam(dec_flat, lr=1e-4)
   use_graph = not args.no_graph
   sync = None
   if world > 1:
@@ -178,18 +202,30 @@ def run_regime(args, regime, world, rank, dev):
       groups = [list(range(min(min(g) for g in groups)))] + groups
     sync = GradSync(flat, groups=groups, overlap=not use_graph)
     sync.broadcast_parameters(0)
+    if attn:
+      dec_sync = GradSync(dec_flat, overlap=False)   # one bucket, exchanged after backward
+      dec_sync.broadcast_parameters(0)
   # every rank gets its own shard of the global batch (weak scaling: B per GPU)
   frames, frame_lens, chars, char_lens = synth_batch(B, 123456 + rank, dev)
   labels, label_lens = chars[:, 1:], char_lens - 1
   if pixels:
     frames = synth_clips(B, 123456 + rank, dev)
+  n_labels = (labels != 0).sum()
 
   def fwd_bwd():
     # train_better_model.py:46-48,67,74 — everything up to and including backward
     opt.zero_grad()
-    log_probs, _, _ = model(frames, frame_lens, max_len=T_FRAMES)
+    log_probs, hidden, state = model(frames, frame_lens, max_len=T_FRAMES)
     loss, status, _ = ctc_loss_with_status(log_probs, labels, frame_lens, label_lens, 'mean')
-    loss.backward()
+    if attn:
+      # :54-65 at teacher_forcing_ratio 1; :70/:74's two backward calls as one traversal of the sum
+      dec_opt.zero_grad()
+      Ld = LABEL_LEN + 1
+      lp, _, _ = dec.decode_sequence(chars[:, :Ld], state, frame_lens, hidden, seed=1)
+      nll = F.nll_loss(lp.reshape(-1, VOCAB), labels[:, :Ld].reshape(-1), ignore_index=0, reduction='sum')
+      (nll / n_labels + loss).backward()
+    else:
+      loss.backward()
     return loss.detach(), status
 
   graph = None
@@ -231,6 +267,9 @@ def run_regime(args, regime, world, rank, dev):
       loss, status = fwd_bwd()
     scale = sync(status) if sync is not None else 1.0          # RCCL all-reduce of the flat grads
     opt.step(grad_norm=50, grad_scale=scale, skip=status)      # :78 clip + :80 Adam
+    if attn:
+      dscale = dec_sync() if dec_sync is not None else 1.0
+      dec_opt.step(grad_norm=50, grad_scale=dscale, skip=status)   # :79: the decoder is clipped separately
     return loss, status
 
   def fence():
@@ -321,6 +360,12 @@ def run_regime(args, regime, world, rank, dev):
                        "accumulate) -> %d-layer Bi%s-%d (fp32) -> Linear(%d,65) -> masked log-softmax -> CTC "
                        "'mean' (L=30+EOS) -> backward -> clip_grad_norm 50 -> Adam 1e-4"
                        % (B, layers, rnn_type, H, D * H))
+  elif attn:
+    res["workload"] = ("regime R+decoder (the reference's whole train step): landmarks (B=%d,T=75,68,3) f32 -> "
+                       "1-layer Bi%s-%d -> Linear(%d,65) + CTC 'mean' (L=30+EOS) AND CharDecodingStep x31 "
+                       "(%s-%d, char_dim 300, 1_layer_nn attention over the 75 encoder states, teacher forced, "
+                       "multinomial sample per step) + NLL -> backward -> per-module clip_grad_norm 50 -> Adam 1e-4"
+                       % (B, rnn_type, H, D * H, rnn_type, D * H))
   else:
     res["workload"] = ("regime R (reference-faithful): landmarks (B=%d,T=75,68,3) f32 -> %d-layer Bi%s-%d -> "
                        "Linear(%d,65) -> masked log-softmax -> CTC 'mean' (L=30+EOS) -> backward -> "
@@ -335,9 +380,10 @@ def main():
   ap.add_argument("--warmup", type=int, default=3)
   ap.add_argument("--model", choices=sorted(MODELS), default="gru256")
   ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
-  ap.add_argument("--regime", choices=["pixels", "landmarks", "both"], default="both",
-                  help="both (default): headline = pixels (the metric's (B,75,3,96,96) shape), the "
-                       "reference-faithful landmarks regime is reported under 'regimes'")
+  ap.add_argument("--regime", choices=["pixels", "landmarks", "landmarks_attn", "both", "all"], default="all",
+                  help="all (default): headline = pixels (the metric's (B,75,3,96,96) shape); the "
+                       "reference-faithful landmarks regimes (encoder+CTC, and the whole step with the "
+                       "attention decoder) are reported under 'regimes'")
   ap.add_argument("--layers", type=int, default=None, help="recurrent layers (default 1; 2 for pixels)")
   ap.add_argument("--no-graph", action="store_true",
                   help="launch every kernel eagerly instead of replaying a captured hipGraph")
@@ -361,7 +407,7 @@ def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(backend="nccl", device_id=dev)
 
-  order = ["pixels", "landmarks"] if args.regime == "both" else [args.regime]
+  order = {"both": ["pixels", "landmarks"], "all": ["pixels", "landmarks", "landmarks_attn"]}.get(args.regime, [args.regime])
   results = [run_regime(args, r, world, rank, dev) for r in order]
   if rank == 0:
     head = results[0]

@@ -106,4 +106,7 @@ int lr_rnn_bias_grads(const float* dG, float* partial, float* db_ih, float* db_h
 int lr_sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                   const float* B, int ldb, float beta, float* C, int ldc, const float* bias, int row_shift,
                   int period, void* workspace, size_t workspace_bytes, hipStream_t stream);
+int lr_sgemm_batched_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                          int64_t sA, const float* B, int ldb, int64_t sB, float beta, float* C, int ldc,
+                          int64_t sC, const float* bias, int batch, hipStream_t stream);
 extern "C" size_t lr_sgemm_workspace_bytes(int M, int N, int K);

@@ -7,21 +7,24 @@
 //   src/train/train_better_model.py:54-65 (train) / :121-135 (eval): the loop over max_label_len
 //       steps with teacher forcing or the previous step's multinomial sample as input.
 //
-// Structure.  The loop is a strictly sequential chain of small ops at batch 32; the whole of it
-// (all L steps, forward or backward) is enqueued by ONE C call, so the host pays one ctypes call
-// per pass and the chain is hipGraph-capturable when the teacher-forcing pattern is fixed.
-//   * embedding + input projection collapse into a V x (G*Hd) table EW = E W_ih^T + b, one GEMM
-//     per pass (V = 64 tokens); a step's gate pre-activations are a row gather by token id;
-//   * the recurrent cell is the encoder's fused step kernel (lr_rnn.hip: packed W_hh, MFMA
-//     16x16x4 f32, one memory round trip), started from the encoder's final state;
-//   * attention runs one workgroup per sample: logits (lanes along the hidden axis, one wave per
-//     encoder frame), allennlp masked_softmax, context; the parts of each attention type that do
-//     not depend on the step (W_g applied to the encoder states, w_e . enc, W1e enc + b1) are
-//     computed once per pass as GEMMs;
-//   * concat_layer is an M = B GEMM (split-K); tanh, output_proj (V = 64), masked log-softmax and
-//     the multinomial draw are one workgroup per sample.
-// Backward walks the chain in reverse with per-step kernels for everything on the dependency
-// chain and defers every weight gradient to one batched GEMM over all (step, sample) rows.
+// Structure.  In the reference's step only the RNN state is carried from step to step: the
+// attention, concat_layer and output_proj of step i read h_i and feed nothing back (the next
+// input is a token id).  So the recurrence that has to run step by step is just the RNN cell —
+// the encoder's fused step kernel (lr_rnn.hip: packed W_hh, MFMA 16x16x4 f32, one memory round
+// trip per step) started from the encoder's final state — and everything else is batched over
+// all (sample, step) rows, row = b*L + i:
+//   * embedding + input projection collapse into a V x (G*Hd) table EW = E W_ih^T + b (one GEMM);
+//     a step's gate pre-activations are a row gather by token id;
+//   * attention logits / context are per-sample GEMMs (L x Hd)(Hd x T) and (L x T)(T x Hd) on the
+//     matrix cores (lr_sgemm_batched_impl); the step-independent halves of each attention type
+//     (W_g applied to the encoder states, w_e . enc, W1e enc + b1) are computed once per pass;
+//   * concat_layer is two (B*L) x Hd x Hd GEMMs (context half, state half: no concatenated copy);
+//   * tanh, output_proj (V = 64), masked log-softmax and the multinomial draw are one kernel,
+//     8 rows per workgroup so W_o is read once per 8 rows.
+// A step that is NOT teacher forced needs the previous step's sample: the batched head is then
+// flushed for the steps finished so far before that step's gather (teacher_forcing_ratio = 1, the
+// shipped configs and eval, is a single flush).  Backward has no such dependency at all: the head,
+// the attention and every weight gradient are batched; only the RNN backward walks the steps.
 //
 // The multinomial draw uses a counter-based hash (seed, step, sample); it matches torch's sampler
 // in distribution only (the reference's draws are RNG-dependent as well).
@@ -30,124 +33,86 @@
 namespace {
 
 enum { ATT_NONE = 0, ATT_DOT = 1, ATT_GENERAL = 2, ATT_1LNN = 3, ATT_CONCAT = 4 };
+constexpr int OUT_ROWS = 8;   // rows per workgroup of dec_out_fwd_kernel
 
-__device__ __forceinline__ float block_sum(float v, float* scratch) {
-  v = lr_wave_sum(v);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) scratch[wave] = v;
-  __syncthreads();
-  float s = 0.f;
-  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += scratch[w];
-  return s;
-}
-
-// gates[b][i][:] = EW[id][:], id = teacher-forced token or the previous step's sample
-__global__ void dec_gather_kernel(const float* __restrict__ EW, const int32_t* __restrict__ tokens,
-                                  const int32_t* __restrict__ sampled, int32_t* __restrict__ ids_used,
-                                  float* __restrict__ gates, int L, int GH, int V, int i, int teacher) {
-  const int b = blockIdx.x;
+// gates[b][i][:] = EW[id][:] for steps i0 + blockIdx.x; id = teacher-forced token or the previous
+// step's sample (step 0 always reads tokens: the reference feeds BOS)
+__global__ __launch_bounds__(256) void dec_gather_kernel(const float* __restrict__ EW,
+                                                         const int32_t* __restrict__ tokens,
+                                                         const int32_t* __restrict__ sampled,
+                                                         int32_t* __restrict__ ids_used,
+                                                         float* __restrict__ gates, int L, int GH, int V, int i0,
+                                                         int teacher) {
+  const int i = i0 + blockIdx.x, b = blockIdx.y;
   int id = (teacher || i == 0) ? tokens[(int64_t)b * L + i] : sampled[(int64_t)b * L + i - 1];
   if (id < 0 || id >= V) id = 0;
   if (threadIdx.x == 0) ids_used[(int64_t)b * L + i] = id;
-  const float* src = EW + (int64_t)id * GH;
-  float* dst = gates + ((int64_t)b * L + i) * GH;
-  for (int c = threadIdx.x; c < GH; c += blockDim.x) dst[c] = src[c];
+  const float4* src = reinterpret_cast<const float4*>(EW + (int64_t)id * GH);
+  float4* dst = reinterpret_cast<float4*>(gates + ((int64_t)b * L + i) * GH);
+  for (int c = threadIdx.x; c < GH / 4; c += blockDim.x) dst[c] = src[c];
 }
 
-struct AttnAux {
-  const float* src;     // dot: enc; general: GE = enc W_g            [B][T][Hd]
-  const float* cterm;   // general: cE = enc . b_g ; 1_layer_nn: se = enc . w_e   [B][T]
-  const float* wvec;    // 1_layer_nn: w_h [Hd] ; concat: W1 (row a: [2Hd], the h part starts at Hd)
-  const float* w2;      // concat: w2 [A]
-  const float* PE;      // concat: W1e enc + b1   [B][T][A]
-  float bias;           // 1_layer_nn: b ; concat: b2   (read on the host? no: passed as pointers)
-  const float* bias_p;  // pointer to that scalar
-};
-
-// One workgroup per sample: attention of step i.
-//   logits_out [B][T] (raw, before masking), cat_out [B][2Hd] = (context | h), ph_out [B][A] (concat)
-__global__ __launch_bounds__(256) void dec_attn_fwd_kernel(int type, const float* __restrict__ hs,
-                                                           const float* __restrict__ enc,
-                                                           const int32_t* __restrict__ enc_lens, AttnAux a,
-                                                           float* __restrict__ logits_out,
-                                                           float* __restrict__ cat_out,
-                                                           float* __restrict__ ph_out, int L, int T, int Hd,
-                                                           int A, int i) {
+// concat attention: logits[b][i][t] = w2 . tanh(PE[b][t][:] + ph[b][i][:]) + b2.  grid (steps, B)
+__global__ __launch_bounds__(256) void dec_concat_logits_kernel(const float* __restrict__ PE,
+                                                                const float* __restrict__ ph,
+                                                                const float* __restrict__ w2,
+                                                                const float* __restrict__ b2,
+                                                                float* __restrict__ logits, int L, int T, int A,
+                                                                int i0) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* h = reinterpret_cast<float*>(smem_raw);   // [Hd]
-  float* lg = h + Hd;                              // [T]
-  float* ph = lg + T;                              // [A]
-  __shared__ float scratch[16];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const float* hrow = hs + ((int64_t)b * L + i) * Hd;
-  for (int k = tid; k < Hd; k += blockDim.x) h[k] = hrow[k];
+  float* phs = reinterpret_cast<float*>(smem_raw);   // [A]
+  float* w2s = phs + A;                              // [A]
+  const int i = i0 + blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row = (int64_t)b * L + i;
+  for (int r = tid; r < A; r += 256) { phs[r] = ph[row * A + r]; w2s[r] = w2[r]; }
   __syncthreads();
-  const float* encb = enc + (int64_t)b * T * Hd;
-  if (type == ATT_DOT || type == ATT_GENERAL) {
-    const float* srcb = a.src + (int64_t)b * T * Hd;
-    for (int t = wave; t < T; t += nw) {
-      float s = 0.f;
-      for (int k = lane; k < Hd; k += 64) s += h[k] * srcb[(int64_t)t * Hd + k];
-      s = lr_wave_sum(s);
-      if (lane == 0) lg[t] = s + (type == ATT_GENERAL ? a.cterm[(int64_t)b * T + t] : 0.f);
-    }
-  } else if (type == ATT_1LNN) {
+  const float* peb = PE + (int64_t)b * T * A;
+  for (int t = wave; t < T; t += 4) {
     float s = 0.f;
-    for (int k = tid; k < Hd; k += blockDim.x) s += h[k] * a.wvec[k];
-    const float sh = block_sum(s, scratch) + a.bias_p[0];
-    for (int t = tid; t < T; t += blockDim.x) lg[t] = a.cterm[(int64_t)b * T + t] + sh;
-  } else {  // ATT_CONCAT
-    for (int r = wave; r < A; r += nw) {            // ph[r] = W1h[r] . h
-      const float* wrow = a.wvec + (int64_t)r * 2 * Hd + Hd;
-      float s = 0.f;
-      for (int k = lane; k < Hd; k += 64) s += wrow[k] * h[k];
-      s = lr_wave_sum(s);
-      if (lane == 0) { ph[r] = s; ph_out[(int64_t)b * A + r] = s; }
-    }
-    __syncthreads();
-    const float* peb = a.PE + (int64_t)b * T * A;
-    for (int t = wave; t < T; t += nw) {
-      float s = 0.f;
-      for (int r = lane; r < A; r += 64) s += a.w2[r] * tanhf(peb[(int64_t)t * A + r] + ph[r]);
-      s = lr_wave_sum(s);
-      if (lane == 0) lg[t] = s + a.bias_p[0];
-    }
+    for (int r = lane; r < A; r += 64) s += w2s[r] * tanhf(peb[(int64_t)t * A + r] + phs[r]);
+    s = lr_wave_sum(s);
+    if (lane == 0) logits[row * T + t] = s + b2[0];
   }
-  __syncthreads();
-  // allennlp masked_softmax: softmax(logits * mask) * mask / (sum + 1e-13)
-  const int len = enc_lens[b];
+}
+
+// One wave per (sample, step) row: finish the raw logits (1_layer_nn: se[b][t] + w_h . h + b;
+// general: + cE[b][t]), then allennlp masked_softmax: softmax(logits * mask) * mask / (sum + 1e-13).
+// grid (steps, B), 64 threads.
+__global__ __launch_bounds__(64) void dec_attn_softmax_kernel(int type, const float* __restrict__ hs,
+                                                              const int32_t* __restrict__ enc_lens,
+                                                              const float* __restrict__ cterm,
+                                                              const float* __restrict__ wvec,
+                                                              const float* __restrict__ bias_p,
+                                                              float* __restrict__ logits,
+                                                              float* __restrict__ wts, int L, int T, int Hd,
+                                                              int i0) {
+  const int i = i0 + blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int64_t row = (int64_t)b * L + i;
+  float* lg = logits + row * T;
+  if (type == ATT_1LNN) {
+    const float* h = hs + row * Hd;
+    float s = 0.f;
+    for (int k = lane; k < Hd; k += 64) s += h[k] * wvec[k];
+    const float sh = lr_wave_sum(s) + bias_p[0];
+    for (int t = lane; t < T; t += 64) lg[t] = cterm[(int64_t)b * T + t] + sh;
+  } else if (type == ATT_GENERAL) {
+    for (int t = lane; t < T; t += 64) lg[t] += cterm[(int64_t)b * T + t];
+  }
+  // (each lane re-reads only the entries it wrote)
+  const int len = min(enc_lens[b], T);
   float mx = LR_NEG_INF;
-  for (int t = tid; t < T; t += blockDim.x) {
-    logits_out[(int64_t)b * T + t] = lg[t];
-    const float x = t < len ? lg[t] : 0.f;
-    mx = fmaxf(mx, x);
-  }
+  for (int t = lane; t < T; t += 64) mx = fmaxf(mx, t < len ? lg[t] : 0.f);
   mx = lr_wave_max(mx);
-  __syncthreads();
-  if (lane == 0) scratch[wave] = mx;
-  __syncthreads();
-  mx = scratch[0];
-  for (int w = 1; w < nw; ++w) mx = fmaxf(mx, scratch[w]);
   float se = 0.f, sv = 0.f;
-  for (int t = tid; t < T; t += blockDim.x) {
+  for (int t = lane; t < T; t += 64) {
     const float e = expf((t < len ? lg[t] : 0.f) - mx);
     se += e;
     if (t < len) sv += e;
   }
-  const float Z = block_sum(se, scratch);
-  const float S = block_sum(sv, scratch) / Z;       // sum of the masked probabilities
-  __syncthreads();
-  for (int t = tid; t < T; t += blockDim.x)
-    lg[t] = t < len ? (expf(lg[t] - mx) / Z) / (S + 1e-13f) : 0.f;   // attention weights
-  __syncthreads();
-  float* cat = cat_out + (int64_t)b * 2 * Hd;
-  for (int k = tid; k < Hd; k += blockDim.x) {
-    float c = 0.f;
-    for (int t = 0; t < len && t < T; ++t) c += lg[t] * encb[(int64_t)t * Hd + k];
-    cat[k] = c;
-    cat[Hd + k] = h[k];
-  }
+  const float Z = lr_wave_sum(se);
+  const float S = lr_wave_sum(sv) / Z;   // sum of the masked probabilities
+  float* w = wts + row * T;
+  for (int t = lane; t < T; t += 64) w[t] = t < len ? (expf(lg[t] - mx) / Z) / (S + 1e-13f) : 0.f;
 }
 
 __device__ __forceinline__ float hash_uniform(uint64_t seed, uint32_t step, uint32_t sample) {
@@ -158,276 +123,312 @@ __device__ __forceinline__ float hash_uniform(uint64_t seed, uint32_t step, uint
   return (float)(x >> 40) * (1.f / 16777216.f);   // 24 random bits -> [0,1)
 }
 
-// One workgroup per sample: new_h = tanh(pre) (stored back), logits = W_o new_h + b_o,
-// masked log-softmax, multinomial draw.  With has_attn == 0 the input is h itself (no tanh).
+// `nrows` (<= OUT_ROWS) rows per workgroup: new_h = tanh(pre) (stored back), logits = W_o new_h +
+// b_o + log(mask + 1e-45), log-softmax, multinomial draw.  With has_attn == 0 the input rows are
+// the RNN states themselves (no tanh).  Rows of the segment [i0, i0 + n): q -> (b = q / n, i = i0 + q % n).
 __global__ __launch_bounds__(256) void dec_out_fwd_kernel(float* __restrict__ nh, const float* __restrict__ w_o,
                                                           const float* __restrict__ b_o,
                                                           const float* __restrict__ mask,
                                                           float* __restrict__ log_probs,
                                                           int32_t* __restrict__ sampled, int L, int Hd, int V,
-                                                          int i, int has_attn, uint64_t seed) {
+                                                          int i0, int n, int total, int nrows, int has_attn,
+                                                          uint64_t seed) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* x = reinterpret_cast<float*>(smem_raw);   // [Hd]
-  float* lg = x + Hd;                              // [V]
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  float* row = nh + (int64_t)b * Hd;
-  for (int k = tid; k < Hd; k += blockDim.x) {
-    float v = row[k];
-    if (has_attn) { v = tanhf(v); row[k] = v; }
-    x[k] = v;
+  float* x = reinterpret_cast<float*>(smem_raw);   // [nrows][Hd]
+  float* lg = x + (size_t)nrows * Hd;              // [nrows][V]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q0 = blockIdx.x * nrows;
+  const int H4 = Hd >> 2;
+  for (int idx = tid; idx < nrows * H4; idx += 256) {
+    const int r = idx / H4, k4 = idx - r * H4;
+    const int q = q0 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < total) {
+      const int64_t row = (int64_t)(q / n) * L + i0 + q % n;
+      float4* src = reinterpret_cast<float4*>(nh + row * Hd) + k4;
+      v = *src;
+      if (has_attn) {
+        v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+        *src = v;
+      }
+    }
+    *reinterpret_cast<float4*>(&x[(size_t)r * Hd + 4 * k4]) = v;
   }
   __syncthreads();
-  for (int v = wave; v < V; v += nw) {
-    const float* wrow = w_o + (int64_t)v * Hd;
-    float s = 0.f;
-    for (int k = lane; k < Hd; k += 64) s += wrow[k] * x[k];
-    s = lr_wave_sum(s);
-    if (lane == 0) lg[v] = s + b_o[v] + logf(mask[v] + 1e-45f);
+  // 4 lanes per output class, each a quarter of the k range in 16-byte pieces; all loads of a
+  // class row are independent, so they are in flight together
+  const int q4 = tid & 3;
+  for (int vc = 0; vc < V; vc += 64) {
+    const int v = vc + (tid >> 2);
+    float acc[OUT_ROWS];
+#pragma unroll
+    for (int r = 0; r < OUT_ROWS; ++r) acc[r] = 0.f;
+    if (v < V) {
+      const float* wrow = w_o + (int64_t)v * Hd;
+      for (int k = q4 * 4; k < Hd; k += 16) {
+        const float4 w4 = *reinterpret_cast<const float4*>(wrow + k);
+#pragma unroll
+        for (int r = 0; r < OUT_ROWS; ++r) {
+          if (r < nrows) {
+            const float4 x4 = *reinterpret_cast<const float4*>(&x[(size_t)r * Hd + k]);
+            acc[r] += w4.x * x4.x + w4.y * x4.y + w4.z * x4.z + w4.w * x4.w;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < OUT_ROWS; ++r) {
+      acc[r] += __shfl_xor(acc[r], 1, 64);
+      acc[r] += __shfl_xor(acc[r], 2, 64);
+    }
+    if (q4 == 0 && v < V) {
+      const float add = b_o[v] + logf(mask[v] + 1e-45f);
+#pragma unroll
+      for (int r = 0; r < OUT_ROWS; ++r)
+        if (r < nrows) lg[(size_t)r * V + v] = acc[r] + add;
+    }
   }
   __syncthreads();
-  if (wave == 0) {
+  for (int r = wave; r < nrows; r += 4) {
+    const int q = q0 + r;
+    if (q >= total) continue;   // wave-uniform
+    const int b = q / n, i = i0 + q % n;
+    const int64_t row = (int64_t)b * L + i;
+    float* l = lg + (size_t)r * V;
     float m = LR_NEG_INF;
-    for (int v = lane; v < V; v += 64) m = fmaxf(m, lg[v]);
+    for (int v = lane; v < V; v += 64) m = fmaxf(m, l[v]);
     m = lr_wave_max(m);
     float s = 0.f;
-    for (int v = lane; v < V; v += 64) s += expf(lg[v] - m);
+    for (int v = lane; v < V; v += 64) s += expf(l[v] - m);
     s = lr_wave_sum(s);
     const float lse = m + logf(s);
-    float* out = log_probs + ((int64_t)b * L + i) * V;
-    for (int v = lane; v < V; v += 64) { lg[v] -= lse; out[v] = lg[v]; }
-  }
-  __syncthreads();
-  if (tid == 0) {   // multinomial(1) over exp(log_probs)
+    float* out = log_probs + row * V;
+    float tot = 0.f;
+    for (int v = lane; v < V; v += 64) {
+      const float lp = l[v] - lse;
+      l[v] = lp;
+      out[v] = lp;
+      tot += expf(lp);
+    }
+    tot = lr_wave_sum(tot);
+    // multinomial(1) over exp(log_probs): first class whose cumulative mass exceeds u * total
     const float u = hash_uniform(seed, (uint32_t)i, (uint32_t)b);
-    float total = 0.f;
-    for (int v = 0; v < V; ++v) total += expf(lg[v]);
-    float cum = 0.f;
+    float running = 0.f;
     int pick = V - 1;
-    for (int v = 0; v < V; ++v) {
-      cum += expf(lg[v]);
-      if (u * total < cum) { pick = v; break; }
+    bool found = false;
+    for (int vc = 0; vc < V; vc += 64) {
+      const int v = vc + lane;
+      float c = v < V ? expf(l[v]) : 0.f;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const float t = __shfl_up(c, d, 64);
+        if (lane >= d) c += t;
+      }
+      const unsigned long long hit = __ballot(v < V && u * tot < running + c);
+      if (!found && hit) {
+        pick = vc + __ffsll((long long)hit) - 1;
+        found = true;
+      }
+      running += __shfl(c, 63, 64);
     }
-    sampled[(int64_t)b * L + i] = pick;
+    if (lane == 0) sampled[row] = pick;
   }
 }
 
-// backward of dec_out_fwd: dlogits = g - exp(lp) sum(g); d new_h = dlogits W_o; dpre = d new_h (1 - new_h^2)
-__global__ __launch_bounds__(256) void dec_out_bwd_kernel(const float* __restrict__ g_lp,
-                                                          const float* __restrict__ log_probs,
-                                                          const float* __restrict__ nh,
-                                                          const float* __restrict__ w_o,
-                                                          float* __restrict__ dlogits, float* __restrict__ dpre,
-                                                          int L, int Hd, int V, int i, int has_attn) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* dl = reinterpret_cast<float*>(smem_raw);   // [V]
-  __shared__ float scratch[16];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const float* g = g_lp + ((int64_t)b * L + i) * V;
-  const float* lp = log_probs + ((int64_t)b * L + i) * V;
+// one wave per row: dlogits = g - exp(lp) * sum(g)   (backward of log_softmax)
+__global__ __launch_bounds__(256) void dec_out_bwd_rows_kernel(const float* __restrict__ g_lp,
+                                                               const float* __restrict__ log_probs,
+                                                               float* __restrict__ dlogits, int rows, int V) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* g = g_lp + (int64_t)row * V;
+  const float* lp = log_probs + (int64_t)row * V;
   float s = 0.f;
-  for (int v = tid; v < V; v += blockDim.x) s += g[v];
-  const float gs = block_sum(s, scratch);
-  for (int v = tid; v < V; v += blockDim.x) {
-    const float d = g[v] - expf(lp[v]) * gs;
-    dl[v] = d;
-    dlogits[(int64_t)b * V + v] = d;
-  }
-  __syncthreads();
-  for (int k = tid; k < Hd; k += blockDim.x) {
-    float acc = 0.f;
-    for (int v = 0; v < V; ++v) acc += dl[v] * w_o[(int64_t)v * Hd + k];
-    if (has_attn) {
-      const float y = nh[(int64_t)b * Hd + k];
-      acc *= 1.f - y * y;
-    }
-    dpre[(int64_t)b * Hd + k] = acc;
+  for (int v = lane; v < V; v += 64) s += g[v];
+  s = lr_wave_sum(s);
+  for (int v = lane; v < V; v += 64) dlogits[(int64_t)row * V + v] = g[v] - expf(lp[v]) * s;
+}
+
+// d(pre) = d(new_h) * (1 - new_h^2), in place
+__global__ void dec_tanh_bwd_kernel(float* __restrict__ d, const float* __restrict__ y, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 a = reinterpret_cast<float4*>(d)[i];
+    const float4 t = reinterpret_cast<const float4*>(y)[i];
+    a.x *= 1.f - t.x * t.x; a.y *= 1.f - t.y * t.y; a.z *= 1.f - t.z * t.z; a.w *= 1.f - t.w * t.w;
+    reinterpret_cast<float4*>(d)[i] = a;
   }
 }
 
-struct AttnGrad {
-  float* d_enc;   // [B][T][Hd]  accumulated over steps
-  float* d_src;   // general: dGE [B][T][Hd]
-  float* d_cterm; // general: dcE [B][T]; 1_layer_nn: dse [B][T]
-  float* d_sh;    // 1_layer_nn: [B] for this step (dsh)
-  float* d_ph;    // concat: [B][A] for this step
-  float* d_PE;    // concat: [B][T][A] accumulated
-  float* d_w2;    // concat: [B][A] per-sample partial of dw2 for this step
-  float* d_b2;    // concat / 1_layer_nn bias: [B] per-sample partial (sum_t dlogit)
-};
-
-// One workgroup per sample: backward of the attention of step i.
-//   in: dcat [B][2Hd] (d context | d h through concat_layer); out: dy [B][L][Hd] row i = total external dh
-__global__ __launch_bounds__(256) void dec_attn_bwd_kernel(int type, const float* __restrict__ hs,
-                                                           const float* __restrict__ enc,
-                                                           const int32_t* __restrict__ enc_lens, AttnAux a,
-                                                           const float* __restrict__ logits_in,
-                                                           const float* __restrict__ ph_in,
-                                                           const float* __restrict__ dcat, AttnGrad gr,
-                                                           float* __restrict__ dy, int L, int T, int Hd, int A,
-                                                           int i) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* h = reinterpret_cast<float*>(smem_raw);   // [Hd]
-  float* dctx = h + Hd;                            // [Hd]
-  float* wt = dctx + Hd;                           // [T] attention weights
-  float* pt = wt + T;                              // [T] full softmax p
-  float* dlg = pt + T;                             // [T] d logits
-  float* ph = dlg + T;                             // [A]
-  float* dph = ph + A;                             // [A]
-  __shared__ float scratch[16];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const int len = min(enc_lens[b], T);
-  const float* hrow = hs + ((int64_t)b * L + i) * Hd;
-  const float* dc = dcat + (int64_t)b * 2 * Hd;
-  for (int k = tid; k < Hd; k += blockDim.x) { h[k] = hrow[k]; dctx[k] = dc[k]; }
-  if (type == ATT_CONCAT)
-    for (int r = tid; r < A; r += blockDim.x) { ph[r] = ph_in[(int64_t)b * A + r]; dph[r] = 0.f; }
-  // recompute p (softmax over all T of logits*mask), S and the weights
-  const float* lgin = logits_in + (int64_t)b * T;
+// One wave per (sample, step) row: backward of masked_softmax.  in: dlg = d weights (d ctx . enc[t]);
+// out: dlg = d logits (0 past the sample's length), dsum[row] = sum_t d logits.
+__global__ __launch_bounds__(256) void dec_attn_softmax_bwd_kernel(const float* __restrict__ logits,
+                                                                   const float* __restrict__ wts,
+                                                                   const int32_t* __restrict__ enc_lens,
+                                                                   float* __restrict__ dlg,
+                                                                   float* __restrict__ dsum, int rows, int L,
+                                                                   int T) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int len = min(enc_lens[row / L], T);
+  const float* lg = logits + (int64_t)row * T;
+  const float* w = wts + (int64_t)row * T;
+  float* d = dlg + (int64_t)row * T;
   float mx = LR_NEG_INF;
-  for (int t = tid; t < T; t += blockDim.x) mx = fmaxf(mx, t < len ? lgin[t] : 0.f);
+  for (int t = lane; t < T; t += 64) mx = fmaxf(mx, t < len ? lg[t] : 0.f);
   mx = lr_wave_max(mx);
-  __syncthreads();
-  if (lane == 0) scratch[wave] = mx;
-  __syncthreads();
-  mx = scratch[0];
-  for (int w = 1; w < nw; ++w) mx = fmaxf(mx, scratch[w]);
-  float se = 0.f, sv = 0.f;
-  for (int t = tid; t < T; t += blockDim.x) {
-    const float e = expf((t < len ? lgin[t] : 0.f) - mx);
-    pt[t] = e;
+  float se = 0.f, sv = 0.f, s1 = 0.f;
+  for (int t = lane; t < T; t += 64) {
+    const float e = expf((t < len ? lg[t] : 0.f) - mx);
     se += e;
-    if (t < len) sv += e;
+    if (t < len) { sv += e; s1 += d[t] * w[t]; }
   }
-  const float Z = block_sum(se, scratch);
-  const float S = block_sum(sv, scratch) / Z;
-  __syncthreads();
-  for (int t = tid; t < T; t += blockDim.x) {
-    pt[t] /= Z;
-    wt[t] = t < len ? pt[t] / (S + 1e-13f) : 0.f;
-  }
-  __syncthreads();
-  // d weights: dw[t] = dctx . enc[b,t];   d_enc[b,t] += w[t] * dctx
-  const float* encb = enc + (int64_t)b * T * Hd;
-  float* dencb = gr.d_enc + (int64_t)b * T * Hd;
-  for (int t = wave; t < T; t += nw) {
-    float s = 0.f;
-    if (t < len) {
-      for (int k = lane; k < Hd; k += 64) {
-        s += dctx[k] * encb[(int64_t)t * Hd + k];
-        dencb[(int64_t)t * Hd + k] += wt[t] * dctx[k];
-      }
-    }
-    s = lr_wave_sum(s);
-    if (lane == 0) dlg[t] = s;   // holds dw[t] for now
-  }
-  __syncthreads();
-  // masked_softmax backward
-  float s1 = 0.f;
-  for (int t = tid; t < T; t += blockDim.x) s1 += dlg[t] * wt[t];
-  const float dot_w = block_sum(s1, scratch);
-  __syncthreads();
+  const float Z = lr_wave_sum(se);
+  const float S = lr_wave_sum(sv) / Z;
+  const float dot_w = lr_wave_sum(s1);
   float s2 = 0.f;
-  for (int t = tid; t < T; t += blockDim.x) {
-    const float dp = t < len ? (dlg[t] - dot_w) / (S + 1e-13f) : 0.f;   // d p[t] (through r = p*m)
-    dlg[t] = dp;
-    s2 += dp * pt[t];
+  for (int t = lane; t < len; t += 64) {
+    const float p = expf(lg[t] - mx) / Z;
+    s2 += (d[t] - dot_w) / (S + 1e-13f) * p;   // d p[t] (through r = p * mask), times p[t]
   }
-  const float dot_p = block_sum(s2, scratch);
-  __syncthreads();
+  const float dot_p = lr_wave_sum(s2);
   float s3 = 0.f;
-  for (int t = tid; t < T; t += blockDim.x) {
-    const float dx = pt[t] * (dlg[t] - dot_p);
-    const float d = t < len ? dx : 0.f;     // x = logits * mask
-    dlg[t] = d;
-    s3 += d;
+  for (int t = lane; t < T; t += 64) {
+    float dx = 0.f;
+    if (t < len) {
+      const float p = expf(lg[t] - mx) / Z;
+      dx = p * ((d[t] - dot_w) / (S + 1e-13f) - dot_p);   // x = logits * mask
+    }
+    d[t] = dx;
+    s3 += dx;
   }
-  const float dsum = block_sum(s3, scratch);   // sum_t dlogit[t]
-  __syncthreads();
-  // back through the logits
-  float* dyrow = dy + ((int64_t)b * L + i) * Hd;
-  if (type == ATT_DOT || type == ATT_GENERAL) {
-    const float* srcb = a.src + (int64_t)b * T * Hd;
-    float* dsrcb = (type == ATT_GENERAL ? gr.d_src : gr.d_enc) + (int64_t)b * T * Hd;
-    for (int k = tid; k < Hd; k += blockDim.x) {
-      float acc = 0.f;
-      for (int t = 0; t < len; ++t) {
-        acc += dlg[t] * srcb[(int64_t)t * Hd + k];
-        dsrcb[(int64_t)t * Hd + k] += dlg[t] * h[k];
-      }
-      dyrow[k] = dc[Hd + k] + acc;
-    }
-    if (type == ATT_GENERAL)
-      for (int t = tid; t < len; t += blockDim.x) gr.d_cterm[(int64_t)b * T + t] += dlg[t];
-  } else if (type == ATT_1LNN) {
-    for (int t = tid; t < len; t += blockDim.x) gr.d_cterm[(int64_t)b * T + t] += dlg[t];
-    if (tid == 0) gr.d_sh[b] = dsum;   // also the bias gradient of this (step, sample)
-    for (int k = tid; k < Hd; k += blockDim.x) dyrow[k] = dc[Hd + k] + dsum * a.wvec[k];
-  } else {  // ATT_CONCAT
-    const float* peb = a.PE + (int64_t)b * T * A;
-    float* dpeb = gr.d_PE + (int64_t)b * T * A;
-    for (int r = tid; r < A; r += blockDim.x) {
-      float accp = 0.f, accw = 0.f;
-      const float w2r = a.w2[r];
-      for (int t = 0; t < len; ++t) {
-        const float u = tanhf(peb[(int64_t)t * A + r] + ph[r]);
-        const float du = dlg[t] * w2r * (1.f - u * u);
-        dpeb[(int64_t)t * A + r] += du;
-        accp += du;
-        accw += dlg[t] * u;
-      }
-      dph[r] = accp;
-      gr.d_ph[(int64_t)b * A + r] = accp;
-      gr.d_w2[(int64_t)b * A + r] = accw;
-    }
-    if (tid == 0) gr.d_b2[b] = dsum;
-    __syncthreads();
-    for (int k = tid; k < Hd; k += blockDim.x) {   // dh += W1h^T dph
-      float acc = 0.f;
-      for (int r = 0; r < A; ++r) acc += a.wvec[(int64_t)r * 2 * Hd + Hd + k] * dph[r];
-      dyrow[k] = dc[Hd + k] + acc;
-    }
+  s3 = lr_wave_sum(s3);
+  if (lane == 0) dsum[row] = s3;
+}
+
+// out[b][t] = sum_i x[b][i][t]   (step-independent logit terms: cE of 'general', se of '1_layer_nn')
+__global__ void dec_sum_steps_kernel(const float* __restrict__ x, float* __restrict__ out, int L, int T) {
+  const int b = blockIdx.x;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    float s = 0.f;
+    for (int i = 0; i < L; ++i) s += x[((int64_t)b * L + i) * T + t];
+    out[(int64_t)b * T + t] = s;
   }
 }
 
-// dEW[v][:] = sum over (b,i) with ids_used == v of dG[b][i][slot(c)][j]   (fixed order: deterministic)
-__global__ void dec_scatter_dew_kernel(const float* __restrict__ dG, const int32_t* __restrict__ ids,
-                                       float* __restrict__ dEW, int rows, int G, int Hd) {
-  const int v = blockIdx.x;
-  const int GH = G * Hd;
-  for (int c = threadIdx.x; c < GH; c += blockDim.x) {
-    float s = 0.f;
-    for (int r = 0; r < rows; ++r)
-      if (ids[r] == v) s += dG[(int64_t)r * 4 * Hd + c];   // slots 0..G-1 are the first G*Hd columns
-    dEW[(int64_t)v * GH + c] = s;
+// concat attention backward through u = tanh(PE[b][t][r] + ph[b][i][r]), logit = w2 . u + b2:
+//   dph[b][i][r] = sum_t du, dPE[b][t][r] = sum_i du, dw2p[b][r] = sum_{i,t} dlogit u,
+//   du = dlogit[b][i][t] w2[r] (1 - u^2).  grid (ceil(A/64), B), one lane per r; tanh is recomputed
+//   in a second sweep rather than holding L (or T) accumulators per lane.
+__global__ __launch_bounds__(64) void dec_concat_bwd_kernel(const float* __restrict__ PE,
+                                                            const float* __restrict__ ph,
+                                                            const float* __restrict__ w2,
+                                                            const float* __restrict__ dlg,
+                                                            const int32_t* __restrict__ enc_lens,
+                                                            float* __restrict__ dPE, float* __restrict__ dph,
+                                                            float* __restrict__ dw2p, int L, int T, int A) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* dl = reinterpret_cast<float*>(smem_raw);   // [L][T]
+  const int b = blockIdx.y, r = blockIdx.x * 64 + threadIdx.x;
+  const float* src = dlg + (int64_t)b * L * T;
+  for (int e = threadIdx.x; e < L * T; e += 64) dl[e] = src[e];
+  __syncthreads();
+  if (r >= A) return;
+  const int len = min(enc_lens[b], T);
+  const float w2r = w2[r];
+  const float* peb = PE + (int64_t)b * T * A + r;
+  const float* phb = ph + (int64_t)b * L * A + r;
+  float accw = 0.f;
+  for (int i = 0; i < L; ++i) {
+    const float phv = phb[(int64_t)i * A];
+    float acc = 0.f;
+    for (int t = 0; t < len; ++t) {
+      const float u = tanhf(peb[(int64_t)t * A] + phv);
+      const float g = dl[i * T + t];
+      acc += g * w2r * (1.f - u * u);
+      accw += g * u;
+    }
+    dph[((int64_t)b * L + i) * A + r] = acc;
   }
+  for (int t = 0; t < T; ++t) {
+    float acc = 0.f;
+    if (t < len) {
+      const float pe = peb[(int64_t)t * A];
+      for (int i = 0; i < L; ++i) {
+        const float u = tanhf(pe + phb[(int64_t)i * A]);
+        acc += dl[i * T + t] * w2r * (1.f - u * u);
+      }
+    }
+    dPE[((int64_t)b * T + t) * A + r] = acc;
+  }
+  dw2p[(int64_t)b * A + r] = accw;
+}
+
+// dEW[v][c] = sum over the rows (b,i) that used token v of dG[row][c], rows in ascending order
+// (deterministic).  grid (V, ceil(G*Hd / 256)); the matching rows of each 256-row chunk are compacted
+// in order into LDS, then every lane adds its column over that list.
+__global__ __launch_bounds__(256) void dec_scatter_dew_kernel(const float* __restrict__ dG,
+                                                              const int32_t* __restrict__ ids,
+                                                              float* __restrict__ dEW, int rows, int G, int Hd) {
+  __shared__ int list[256];
+  __shared__ int wcount[4];
+  const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int GH = G * Hd;
+  const int c = blockIdx.y * 256 + tid;
+  float s = 0.f;
+  for (int r0 = 0; r0 < rows; r0 += 256) {
+    const int r = r0 + tid;
+    const bool hit = r < rows && ids[r] == v;
+    const unsigned long long m = __ballot(hit);
+    __syncthreads();   // previous chunk's list fully consumed
+    if (lane == 0) wcount[wave] = __popcll(m);
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wcount[w];
+    if (hit) list[base + __popcll(m & ((1ull << lane) - 1ull))] = r;
+    __syncthreads();
+    const int cnt = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    if (c < GH)
+      for (int j = 0; j < cnt; ++j) s += dG[(int64_t)list[j] * 4 * Hd + c];   // slots 0..G-1 = first G*Hd columns
+  }
+  if (c < GH) dEW[(int64_t)v * GH + c] = s;
 }
 
 __global__ void zero_row_kernel(float* __restrict__ x, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) x[i] = 0.f;
 }
 
-// out[i] (+)= sum_r x[r*ld + i] for i < n   (small: one block)
-__global__ void rowsum_acc_kernel(const float* __restrict__ x, int rows, int ld, int n, float* __restrict__ out,
-                                  int accumulate) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += x[(int64_t)r * ld + i];
-    out[i] = accumulate ? out[i] + s : s;
-  }
+// out[c] (+)= fixed-order sum of the LR_COLSUM_SPLITS partial column sums (lr_colsum_partial)
+__global__ void dec_colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int C,
+                                        int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = 0; r < LR_COLSUM_SPLITS; ++r) s += partial[(int64_t)r * C + c];
+  out[c] = accumulate ? out[c] + s : s;
 }
 
 struct Sizes {
   int B, L, T, Hd, Cd, V, A, G, type;
 };
 
-// ---- reserve (forward -> backward) layout, in floats ------------------------------------------------
+size_t max_gemm_ws(const int (*dims)[3], int n) {
+  size_t gb = 0;
+  for (int i = 0; i < n; ++i) {
+    const size_t g = lr_sgemm_workspace_bytes(dims[i][0], dims[i][1], dims[i][2]);
+    if (g > gb) gb = g;
+  }
+  return gb;
+}
+
+// ---- reserve (forward -> backward) layout, in floats; per-(sample, step) buffers are [B][L][...] ------
 struct Res {
-  size_t EW, biasf, gates, extra, hs, hp, wp, ids, logits, cat, pre, aux1, aux2, ph, gemm, total;
+  size_t EW, biasf, gates, extra, hs, hp, wp, ids, logits, wts, ctx, pre, aux1, aux2, ph, gemm, total;
   size_t hp_slot, gemm_bytes;
 };
 Res res_layout(const Sizes& z) {
   Res r;
   const size_t GH = (size_t)z.G * z.Hd, BL = (size_t)z.B * z.L, BT = (size_t)z.B * z.T;
+  const bool attn = z.type != ATT_NONE;
   size_t o = 0;
   auto take = [&](size_t n) { size_t at = o; o += (n + 63) / 64 * 64; return at; };
   r.EW = take((size_t)z.V * GH);
@@ -439,30 +440,31 @@ Res res_layout(const Sizes& z) {
   r.hp = take(2 * r.hp_slot);
   r.wp = take(lr_rnn_packed_w_floats(z.G, z.Hd));
   r.ids = take(BL);
-  r.logits = take((size_t)z.L * z.B * z.T);
-  r.cat = take(BL * 2 * z.Hd);
-  r.pre = take(BL * z.Hd);
+  r.logits = take(attn ? BL * z.T : 0);    // raw attention logits
+  r.wts = take(attn ? BL * z.T : 0);       // attention weights
+  r.ctx = take(attn ? BL * z.Hd : 0);      // context vectors
+  r.pre = take(attn ? BL * z.Hd : 0);      // concat_layer output, overwritten by its tanh
   r.aux1 = take(z.type == ATT_GENERAL ? BT * z.Hd : (z.type == ATT_CONCAT ? BT * z.A : 0));   // GE | PE
   r.aux2 = take((z.type == ATT_GENERAL || z.type == ATT_1LNN) ? BT : 0);                       // cE | se
   r.ph = take(z.type == ATT_CONCAT ? BL * z.A : 0);
-  size_t gb = lr_sgemm_workspace_bytes(z.B, z.Hd, 2 * z.Hd);
-  size_t g2 = lr_sgemm_workspace_bytes(z.V, (int)GH, z.Cd);
-  if (g2 > gb) gb = g2;
-  g2 = lr_sgemm_workspace_bytes((int)BT, z.Hd, z.Hd);
-  if (g2 > gb) gb = g2;
-  r.gemm_bytes = gb;
-  r.gemm = take((gb + 3) / 4);
+  const int a = z.A > 0 ? z.A : 1;
+  const int dims[][3] = {{z.V, (int)GH, z.Cd}, {(int)BT, z.Hd, z.Hd}, {(int)BT, a, z.Hd}, {(int)BL, z.Hd, z.Hd},
+                         {(int)BL, a, z.Hd}};
+  r.gemm_bytes = max_gemm_ws(dims, 5);
+  r.gemm = take((r.gemm_bytes + 3) / 4);
   r.total = o;
   return r;
 }
 
 struct Wsp {
-  size_t wpT, dG, dcar, dgp, dy, dlogits, dpre, dcat, dEW, dsrc, dcterm, dsh, dPE, dph, dw2, db2, colsum, gemm, total;
+  size_t wpT, dG, dcar, dgp, dy, dlogits, dpre, dctx, dlg, dsum, dEW, dsrc, dcterm, dPE, dph, dw2p, colsum, gemm,
+      total;
   size_t dgp_slot, gemm_bytes;
 };
 Wsp ws_layout(const Sizes& z) {
   Wsp w;
   const size_t GH = (size_t)z.G * z.Hd, BL = (size_t)z.B * z.L, BT = (size_t)z.B * z.T;
+  const bool attn = z.type != ATT_NONE;
   size_t o = 0;
   auto take = [&](size_t n) { size_t at = o; o += (n + 63) / 64 * 64; return at; };
   w.wpT = take(lr_rnn_packed_w_floats(z.G, z.Hd));
@@ -472,35 +474,34 @@ Wsp ws_layout(const Sizes& z) {
   w.dgp = take(2 * w.dgp_slot);
   w.dy = take(BL * z.Hd);
   w.dlogits = take(BL * z.V);
-  w.dpre = take(BL * z.Hd);
-  w.dcat = take((size_t)z.B * 2 * z.Hd);
+  w.dpre = take(attn ? BL * z.Hd : 0);
+  w.dctx = take(attn ? BL * z.Hd : 0);
+  w.dlg = take(attn ? BL * z.T : 0);
+  w.dsum = take(attn ? BL : 0);
   w.dEW = take((size_t)z.V * GH);
   w.dsrc = take(z.type == ATT_GENERAL ? BT * z.Hd : 0);
   w.dcterm = take((z.type == ATT_GENERAL || z.type == ATT_1LNN) ? BT : 0);
-  w.dsh = take(z.type == ATT_1LNN ? BL : 0);
   w.dPE = take(z.type == ATT_CONCAT ? BT * z.A : 0);
   w.dph = take(z.type == ATT_CONCAT ? BL * z.A : 0);
-  w.dw2 = take(z.type == ATT_CONCAT ? BL * z.A : 0);
-  w.db2 = take((z.type == ATT_CONCAT || z.type == ATT_1LNN) ? BL : 0);
-  w.colsum = take((size_t)LR_COLSUM_SPLITS * 4 * z.Hd);
-  size_t gb = 0;
-  const int dims[][3] = {{z.B, 2 * z.Hd, z.Hd}, {z.Hd, 2 * z.Hd, (int)BL}, {z.V, z.Hd, (int)BL},
+  w.dw2p = take(z.type == ATT_CONCAT ? (size_t)z.B * z.A : 0);
+  size_t widest = (size_t)4 * z.Hd;
+  if ((size_t)z.V > widest) widest = z.V;
+  if ((size_t)z.A > widest) widest = z.A;
+  w.colsum = take((size_t)LR_COLSUM_SPLITS * widest);
+  const int a = z.A > 0 ? z.A : 1;
+  const int dims[][3] = {{(int)BL, z.Hd, z.V}, {(int)BL, z.Hd, z.Hd}, {z.Hd, z.Hd, (int)BL}, {z.V, z.Hd, (int)BL},
                          {(int)GH, z.Hd, (int)BL}, {(int)GH, z.Cd, z.V}, {z.V, z.Cd, (int)GH},
-                         {(int)BT, z.Hd, z.Hd}, {z.Hd, z.Hd, (int)BT}, {z.A > 0 ? z.A : 1, z.Hd, (int)BT},
-                         {(int)BT, z.Hd, z.A > 0 ? z.A : 1}, {z.A > 0 ? z.A : 1, z.Hd, (int)BL}};
-  for (auto& d : dims) {
-    const size_t g = lr_sgemm_workspace_bytes(d[0], d[1], d[2]);
-    if (g > gb) gb = g;
-  }
-  w.gemm_bytes = gb;
-  w.gemm = take((gb + 3) / 4);
+                         {(int)BT, z.Hd, z.Hd}, {z.Hd, z.Hd, (int)BT}, {a, z.Hd, (int)BT}, {(int)BT, z.Hd, a},
+                         {a, z.Hd, (int)BL}, {(int)BL, z.Hd, a}, {z.Hd, 1, (int)BL}, {z.Hd, 1, (int)BT}};
+  w.gemm_bytes = max_gemm_ws(dims, 15);
+  w.gemm = take((w.gemm_bytes + 3) / 4);
   w.total = o;
   return w;
 }
 
 bool sizes_ok(int mode, int type, int B, int L, int T, int Hd, int Cd, int V, int A) {
   return (mode == LR_RNN_GRU || mode == LR_RNN_LSTM) && type >= ATT_NONE && type <= ATT_CONCAT && B > 0 &&
-         L > 0 && T > 0 && Hd > 0 && Hd % 4 == 0 && Cd > 0 && V > 0 && V <= 1024 &&
+         B <= 65535 && L > 0 && L <= 65535 && T > 0 && Hd > 0 && Hd % 4 == 0 && Cd > 0 && V > 0 && V <= 1024 &&
          (type != ATT_CONCAT || A > 0);
 }
 
@@ -509,6 +510,15 @@ bool sizes_ok(int mode, int type, int B, int L, int T, int Hd, int Cd, int V, in
     const int st__ = (expr);      \
     if (st__ != LR_OK) return st__; \
   } while (0)
+
+// two-stage deterministic column sum of x [rows][ld] -> out[ncol] (+= when accumulate)
+int colsum_into(const float* x, int ld, int rows, int ncol, float* scratch, float* out, int accumulate,
+                hipStream_t stream) {
+  LR_TRY(lr_colsum_partial(x, ld, rows, ncol, scratch, stream));
+  LR_LAUNCH(dec_colsum_final_kernel, dim3((ncol + 255) / 256), dim3(256), 0, stream, (const float*)scratch, out, ncol,
+            accumulate);
+  return lr_launch_status();
+}
 
 }  // namespace
 
@@ -543,11 +553,17 @@ extern "C" int lr_decoder_forward(int mode, int attn_type, const lr_decoder_para
   if (reserve_bytes < r.total * sizeof(float)) return LR_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   float* base = (float*)reserve;
-  const int G = z.G, GH = G * Hd;
+  const int G = z.G, GH = G * Hd, BL = B * L, R = B * T;
+  const bool attn = attn_type != ATT_NONE;
   float* EW = base + r.EW;
   float* gates = base + r.gates;
   float* hs = base + r.hs;
   float* hp = base + r.hp;
+  float* logits = base + r.logits;
+  float* wts = base + r.wts;
+  float* ctx = base + r.ctx;
+  float* pre = base + r.pre;
+  float* ph = base + r.ph;
   void* gws = base + r.gemm;
   int32_t* ids = (int32_t*)(base + r.ids);
 
@@ -560,65 +576,98 @@ extern "C" int lr_decoder_forward(int mode, int attn_type, const lr_decoder_para
   if (hipMemsetAsync(hp, 0, 2 * r.hp_slot * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
   LR_TRY(lr_rnn_pack_state(h0, hp + r.hp_slot, B, Hd, stream));   // step 0 reads parity (0+1)&1 = 1
 
-  AttnAux aux = {};
-  const int R = B * T;
+  // step-independent halves of the attention logits
+  const float* src = nullptr;     // dot: enc; general: GE = enc W_g        [B][T][Hd]
+  const float* cterm = nullptr;   // general: cE = enc . b_g; 1_layer_nn: se = enc . w_e   [B][T]
   if (attn_type == ATT_DOT) {
-    aux.src = enc;
+    src = enc;
   } else if (attn_type == ATT_GENERAL) {
     LR_CHECK_ARG(p->attn_w1 && p->attn_b1);
-    // GE = enc @ W_g (so that (W_g h + b_g) . enc = h . GE + enc . b_g)
+    // (W_g h + b_g) . enc[t] = h . (enc[t] W_g) + enc[t] . b_g
     LR_TRY(lr_sgemm_impl(0, 0, R, Hd, Hd, 1.f, enc, Hd, p->attn_w1, Hd, 0.f, base + r.aux1, Hd, nullptr, 0, 0, gws,
                          r.gemm_bytes, stream));
     LR_TRY(lr_sgemm_impl(0, 1, R, 1, Hd, 1.f, enc, Hd, p->attn_b1, Hd, 0.f, base + r.aux2, 1, nullptr, 0, 0,
                          nullptr, 0, stream));
-    aux.src = base + r.aux1;
-    aux.cterm = base + r.aux2;
+    src = base + r.aux1;
+    cterm = base + r.aux2;
   } else if (attn_type == ATT_1LNN) {
     LR_CHECK_ARG(p->attn_w1 && p->attn_b1);
     LR_TRY(lr_sgemm_impl(0, 1, R, 1, Hd, 1.f, enc, Hd, p->attn_w1, 2 * Hd, 0.f, base + r.aux2, 1, nullptr, 0, 0,
-                         nullptr, 0, stream));   // se = enc . w_e  (w_e = first Hd entries)
-    aux.cterm = base + r.aux2;
-    aux.wvec = p->attn_w1 + Hd;                  // w_h
-    aux.bias_p = p->attn_b1;
+                         nullptr, 0, stream));   // se = enc . w_e  (w_e = first Hd entries of w)
+    cterm = base + r.aux2;
   } else if (attn_type == ATT_CONCAT) {
     LR_CHECK_ARG(p->attn_w1 && p->attn_b1 && p->attn_w2 && p->attn_b2);
     LR_TRY(lr_sgemm_impl(0, 1, R, A, Hd, 1.f, enc, Hd, p->attn_w1, 2 * Hd, 0.f, base + r.aux1, A, p->attn_b1, 0, 0,
                          gws, r.gemm_bytes, stream));   // PE = enc @ W1e^T + b1
-    aux.PE = base + r.aux1;
-    aux.wvec = p->attn_w1;
-    aux.w2 = p->attn_w2;
-    aux.bias_p = p->attn_b2;
   }
-  const size_t attn_lds = ((size_t)Hd + T + (A > 0 ? A : 0) + 8) * sizeof(float);
-  const size_t out_lds = ((size_t)Hd + V + 8) * sizeof(float);
-  if (attn_lds > 60 * 1024 || out_lds > 60 * 1024) return LR_ERR_UNSUPPORTED;
+  int out_rows = OUT_ROWS;
+  while (out_rows > 1 && (size_t)out_rows * (Hd + V) * sizeof(float) > 60 * 1024) out_rows >>= 1;
+  const size_t out_lds = (size_t)out_rows * (Hd + V) * sizeof(float);
+  if (out_lds > 60 * 1024 || (size_t)2 * A * sizeof(float) > 60 * 1024) return LR_ERR_UNSUPPORTED;
 
-  for (int i = 0; i < L; ++i) {
-    LR_LAUNCH(dec_gather_kernel, dim3(B), dim3(256), 0, stream, (const float*)EW, tokens, (const int32_t*)sampled,
-              ids, gates, L, GH, V, i, (int)teacher_forced_host[i]);
-    LR_TRY(lr_launch_status());
-    LR_TRY(lr_rnn_step_fwd(G, gates, base + r.extra, hs, hp, step_lens, base + r.wp, p->b_hh, h0, c0, B, L, Hd, i,
-                           stream));
-    float* nh = base + r.pre + (size_t)i * B * Hd;
-    if (attn_type != ATT_NONE) {
-      float* cat = base + r.cat + (size_t)i * B * 2 * Hd;
-      LR_LAUNCH(dec_attn_fwd_kernel, dim3(B), dim3(256), attn_lds, stream, attn_type, (const float*)hs, enc,
-                enc_lens, aux, base + r.logits + (size_t)i * B * T, cat,
-                attn_type == ATT_CONCAT ? base + r.ph + (size_t)i * B * A : (float*)nullptr, L, T, Hd, A, i);
+  // rows (b, i), i in [i0, i1), of a [B][L][ld] buffer times a torch-layout weight [N][K] (+ bias)
+  auto rows_gemm = [&](int N, int K, const float* Am, int lda, const float* W, int ldw, float beta, float* C,
+                       int ldc, const float* bias, int i0, int i1) -> int {
+    if (i0 == 0 && i1 == L)
+      return lr_sgemm_impl(0, 1, BL, N, K, 1.f, Am, lda, W, ldw, beta, C, ldc, bias, 0, 0, gws, r.gemm_bytes, stream);
+    return lr_sgemm_batched_impl(0, 1, i1 - i0, N, K, 1.f, Am + (size_t)i0 * lda, lda, (int64_t)L * lda, W, ldw, 0,
+                                 beta, C + (size_t)i0 * ldc, ldc, (int64_t)L * ldc, bias, B, stream);
+  };
+  // attention + concat_layer + output head of steps [i0, i1), whose RNN states are in hs
+  auto flush = [&](int i0, int i1) -> int {
+    const int n = i1 - i0;
+    if (n <= 0) return LR_OK;
+    if (attn) {
+      if (attn_type == ATT_DOT || attn_type == ATT_GENERAL) {
+        // logits[b] (n x T) = hs[b] (n x Hd) . src[b]^T
+        LR_TRY(lr_sgemm_batched_impl(0, 1, n, T, Hd, 1.f, hs + (size_t)i0 * Hd, Hd, (int64_t)L * Hd, src, Hd,
+                                     (int64_t)T * Hd, 0.f, logits + (size_t)i0 * T, T, (int64_t)L * T, nullptr, B,
+                                     stream));
+      } else if (attn_type == ATT_CONCAT) {
+        LR_TRY(rows_gemm(A, Hd, hs, Hd, p->attn_w1 + Hd, 2 * Hd, 0.f, ph, A, nullptr, i0, i1));   // ph = W1h h
+        LR_LAUNCH(dec_concat_logits_kernel, dim3(n, B), dim3(256), (size_t)2 * A * sizeof(float), stream,
+                  (const float*)(base + r.aux1), (const float*)ph, p->attn_w2, p->attn_b2, logits, L, T, A, i0);
+        LR_TRY(lr_launch_status());
+      }
+      LR_LAUNCH(dec_attn_softmax_kernel, dim3(n, B), dim3(64), 0, stream, attn_type, (const float*)hs, enc_lens, cterm,
+                attn_type == ATT_1LNN ? p->attn_w1 + Hd : (const float*)nullptr,
+                attn_type == ATT_1LNN ? p->attn_b1 : (const float*)nullptr, logits, wts, L, T, Hd, i0);
       LR_TRY(lr_launch_status());
-      LR_TRY(lr_sgemm_impl(0, 1, B, Hd, 2 * Hd, 1.f, cat, 2 * Hd, p->w_c, 2 * Hd, 0.f, nh, Hd, p->b_c, 0, 0, gws,
-                           r.gemm_bytes, stream));
-    } else {
-      // no attention: output_proj acts on the RNN state itself (better_model.py:228)
-      lr_clear_error();
-      if (hipMemcpy2DAsync(nh, (size_t)Hd * sizeof(float), hs + (size_t)i * Hd, (size_t)L * Hd * sizeof(float),
-                           (size_t)Hd * sizeof(float), B, hipMemcpyDeviceToDevice, stream) != hipSuccess)
-        return LR_ERR_LAUNCH;
+      // ctx[b] (n x Hd) = wts[b] (n x T) . enc[b] (T x Hd)
+      LR_TRY(lr_sgemm_batched_impl(0, 0, n, Hd, T, 1.f, wts + (size_t)i0 * T, T, (int64_t)L * T, enc, Hd,
+                                   (int64_t)T * Hd, 0.f, ctx + (size_t)i0 * Hd, Hd, (int64_t)L * Hd, nullptr, B,
+                                   stream));
+      // concat_layer([ctx; h]) = W_c[:, :Hd] ctx + W_c[:, Hd:] h + b_c
+      LR_TRY(rows_gemm(Hd, Hd, ctx, Hd, p->w_c, 2 * Hd, 0.f, pre, Hd, p->b_c, i0, i1));
+      LR_TRY(rows_gemm(Hd, Hd, hs, Hd, p->w_c + Hd, 2 * Hd, 1.f, pre, Hd, nullptr, i0, i1));
     }
-    LR_LAUNCH(dec_out_fwd_kernel, dim3(B), dim3(256), out_lds, stream, nh, p->w_o, p->b_o, p->out_mask, log_probs,
-              sampled, L, Hd, V, i, attn_type != ATT_NONE ? 1 : 0, seed);
+    const int total = n * B;
+    LR_LAUNCH(dec_out_fwd_kernel, dim3((total + out_rows - 1) / out_rows), dim3(256), out_lds, stream,
+              attn ? pre : hs, p->w_o, p->b_o, p->out_mask, log_probs, sampled, L, Hd, V, i0, n, total, out_rows,
+              attn ? 1 : 0, seed);
+    return lr_launch_status();
+  };
+
+  int done = 0;   // steps whose head has been computed
+  for (int i = 0; i < L;) {
+    int run = 1;
+    if (teacher_forced_host[i] || i == 0) {
+      while (i + run < L && teacher_forced_host[i + run]) ++run;
+      LR_LAUNCH(dec_gather_kernel, dim3(run, B), dim3(256), 0, stream, (const float*)EW, tokens,
+                (const int32_t*)sampled, ids, gates, L, GH, V, i, 1);
+    } else {
+      LR_TRY(flush(done, i));   // the input of step i is the sample drawn from step i-1's output
+      done = i;
+      LR_LAUNCH(dec_gather_kernel, dim3(1, B), dim3(256), 0, stream, (const float*)EW, tokens,
+                (const int32_t*)sampled, ids, gates, L, GH, V, i, 0);
+    }
     LR_TRY(lr_launch_status());
+    for (int s = i; s < i + run; ++s)
+      LR_TRY(lr_rnn_step_fwd(G, gates, base + r.extra, hs, hp, step_lens, base + r.wp, p->b_hh, h0, c0, B, L, Hd, s,
+                             stream));
+    i += run;
   }
+  LR_TRY(flush(done, L));
   // state after the last step (what the reference's step returns as final_state, better_model.py:181)
   lr_clear_error();
   if (h_n && hipMemcpy2DAsync(h_n, (size_t)Hd * sizeof(float), hs + (size_t)(L - 1) * Hd,
@@ -653,82 +702,124 @@ extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_par
   const float* rb = (const float*)reserve;
   float* wb = (float*)workspace;
   const int G = z.G, GH = G * Hd, R = B * T, BL = B * L;
+  const bool attn = attn_type != ATT_NONE;
   const float beta = accumulate ? 1.f : 0.f;
   void* gws = wb + w.gemm;
   const float* hs = rb + r.hs;
+  const float* wts = rb + r.wts;
+  const float* ctx = rb + r.ctx;
+  const float* nh = attn ? rb + r.pre : hs;   // what output_proj was applied to
   const int32_t* ids = (const int32_t*)(rb + r.ids);
   float* dG = wb + w.dG;
   float* dy = wb + w.dy;
+  float* dlogits = wb + w.dlogits;
+  float* dpre = wb + w.dpre;
+  float* dctx = wb + w.dctx;
+  float* dlg = wb + w.dlg;
+  float* dsum = wb + w.dsum;
+  float* colsum = wb + w.colsum;
+  if ((size_t)L * T * sizeof(float) > 60 * 1024 && attn_type == ATT_CONCAT) return LR_ERR_UNSUPPORTED;
 
   LR_TRY(lr_rnn_pack_w(p->w_hh, wb + w.wpT, G, Hd, 1, stream));
   lr_clear_error();
   if (hipMemsetAsync(wb + w.dgp, 0, 2 * w.dgp_slot * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
-  if (hipMemsetAsync(d_enc, 0, (size_t)R * Hd * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
-  AttnAux aux = {};
-  AttnGrad gr = {};
-  gr.d_enc = d_enc;
-  if (attn_type == ATT_DOT) {
-    aux.src = enc;
-  } else if (attn_type == ATT_GENERAL) {
-    aux.src = rb + r.aux1;
-    aux.cterm = rb + r.aux2;
-    gr.d_src = wb + w.dsrc;
-    gr.d_cterm = wb + w.dcterm;
-    if (hipMemsetAsync(gr.d_src, 0, (size_t)R * Hd * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
-    if (hipMemsetAsync(gr.d_cterm, 0, (size_t)R * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
-  } else if (attn_type == ATT_1LNN) {
-    aux.cterm = rb + r.aux2;
-    aux.wvec = p->attn_w1 + Hd;
-    aux.bias_p = p->attn_b1;
-    gr.d_cterm = wb + w.dcterm;
-    if (hipMemsetAsync(gr.d_cterm, 0, (size_t)R * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
-  } else if (attn_type == ATT_CONCAT) {
-    aux.PE = rb + r.aux1;
-    aux.wvec = p->attn_w1;
-    aux.w2 = p->attn_w2;
-    aux.bias_p = p->attn_b2;
-    gr.d_PE = wb + w.dPE;
-    if (hipMemsetAsync(gr.d_PE, 0, (size_t)R * A * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
-  }
-  const size_t attn_lds = ((size_t)2 * Hd + 3 * T + 2 * (A > 0 ? A : 0) + 8) * sizeof(float);
-  const size_t out_lds = ((size_t)V + 8) * sizeof(float);
-  if (attn_lds > 60 * 1024) return LR_ERR_UNSUPPORTED;
 
-  for (int i = L - 1; i >= 0; --i) {
-    const float* nh = rb + r.pre + (size_t)i * B * Hd;
-    float* dpre = wb + w.dpre + (size_t)i * B * Hd;
-    LR_LAUNCH(dec_out_bwd_kernel, dim3(B), dim3(256), out_lds, stream, d_log_probs, log_probs, nh, p->w_o,
-              wb + w.dlogits + (size_t)i * B * V, dpre, L, Hd, V, i, attn_type != ATT_NONE ? 1 : 0);
+  // ---- output head, all (sample, step) rows at once -------------------------------------------------
+  LR_LAUNCH(dec_out_bwd_rows_kernel, dim3((BL + 3) / 4), dim3(256), 0, stream, d_log_probs, log_probs, dlogits, BL, V);
+  LR_TRY(lr_launch_status());
+  // d(new_h) = dlogits @ W_o; without attention new_h is the RNN state itself
+  LR_TRY(lr_sgemm_impl(0, 0, BL, Hd, V, 1.f, dlogits, V, p->w_o, Hd, 0.f, attn ? dpre : dy, Hd, nullptr, 0, 0, gws,
+                       w.gemm_bytes, stream));
+  if (!attn) {
+    lr_clear_error();
+    if (hipMemsetAsync(d_enc, 0, (size_t)R * Hd * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
+  } else {
+    const int64_t n4 = (int64_t)BL * Hd / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    LR_LAUNCH(dec_tanh_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dpre, nh, n4);
     LR_TRY(lr_launch_status());
-    if (attn_type != ATT_NONE) {
-      // d(cat) = dpre @ W_c
-      LR_TRY(lr_sgemm_impl(0, 0, B, 2 * Hd, Hd, 1.f, dpre, Hd, p->w_c, 2 * Hd, 0.f, wb + w.dcat, 2 * Hd, nullptr, 0,
-                           0, gws, w.gemm_bytes, stream));
-      if (attn_type == ATT_1LNN) gr.d_sh = wb + w.dsh + (size_t)i * B;
-      if (attn_type == ATT_CONCAT) {
-        gr.d_ph = wb + w.dph + (size_t)i * B * A;
-        gr.d_w2 = wb + w.dw2 + (size_t)i * B * A;
-        gr.d_b2 = wb + w.db2 + (size_t)i * B;
-      }
-      LR_LAUNCH(dec_attn_bwd_kernel, dim3(B), dim3(256), attn_lds, stream, attn_type, hs, enc, enc_lens, aux,
-                rb + r.logits + (size_t)i * B * T,
-                attn_type == ATT_CONCAT ? rb + r.ph + (size_t)i * B * A : (const float*)nullptr,
-                (const float*)(wb + w.dcat), gr, dy, L, T, Hd, A, i);
-      LR_TRY(lr_launch_status());
-    } else {
-      lr_clear_error();
-      if (hipMemcpy2DAsync(dy + (size_t)i * Hd, (size_t)L * Hd * sizeof(float), dpre, (size_t)Hd * sizeof(float),
-                           (size_t)Hd * sizeof(float), B, hipMemcpyDeviceToDevice, stream) != hipSuccess)
-        return LR_ERR_LAUNCH;
+    // concat_layer: d ctx = dpre @ W_c[:, :Hd];  dh (direct part) = dpre @ W_c[:, Hd:]
+    LR_TRY(lr_sgemm_impl(0, 0, BL, Hd, Hd, 1.f, dpre, Hd, p->w_c, 2 * Hd, 0.f, dctx, Hd, nullptr, 0, 0, gws,
+                         w.gemm_bytes, stream));
+    LR_TRY(lr_sgemm_impl(0, 0, BL, Hd, Hd, 1.f, dpre, Hd, p->w_c + Hd, 2 * Hd, 0.f, dy, Hd, nullptr, 0, 0, gws,
+                         w.gemm_bytes, stream));
+    // ---- attention, per sample: d weights = dctx[b] (L x Hd) . enc[b]^T -> masked_softmax backward ----
+    LR_TRY(lr_sgemm_batched_impl(0, 1, L, T, Hd, 1.f, dctx, Hd, (int64_t)L * Hd, enc, Hd, (int64_t)T * Hd, 0.f, dlg,
+                                 T, (int64_t)L * T, nullptr, B, stream));
+    LR_LAUNCH(dec_attn_softmax_bwd_kernel, dim3((BL + 3) / 4), dim3(256), 0, stream, rb + r.logits, wts, enc_lens,
+              dlg, dsum, BL, L, T);
+    LR_TRY(lr_launch_status());
+    // d_enc[b] (T x Hd) = wts[b]^T (T x L) . dctx[b] (L x Hd)
+    LR_TRY(lr_sgemm_batched_impl(1, 0, T, Hd, L, 1.f, wts, T, (int64_t)L * T, dctx, Hd, (int64_t)L * Hd, 0.f, d_enc,
+                                 Hd, (int64_t)T * Hd, nullptr, B, stream));
+    if (attn_type == ATT_DOT || attn_type == ATT_GENERAL) {
+      const float* src = attn_type == ATT_DOT ? enc : rb + r.aux1;
+      float* dsrc = attn_type == ATT_DOT ? d_enc : wb + w.dsrc;
+      // logit[b] = hs[b] . src[b]^T:  dh += dlg[b] (L x T) . src[b];  dsrc[b] (+)= dlg[b]^T . hs[b]
+      LR_TRY(lr_sgemm_batched_impl(0, 0, L, Hd, T, 1.f, dlg, T, (int64_t)L * T, src, Hd, (int64_t)T * Hd, 1.f, dy, Hd,
+                                   (int64_t)L * Hd, nullptr, B, stream));
+      LR_TRY(lr_sgemm_batched_impl(1, 0, T, Hd, L, 1.f, dlg, T, (int64_t)L * T, hs, Hd, (int64_t)L * Hd,
+                                   attn_type == ATT_DOT ? 1.f : 0.f, dsrc, Hd, (int64_t)T * Hd, nullptr, B, stream));
     }
-    LR_TRY(lr_rnn_step_bwd(G, rb + r.gates, rb + r.extra, hs, dy, dh_n, dc_n, dG, wb + w.dcar, wb + w.dgp,
-                           step_lens, wb + w.wpT, h0, c0, B, L, Hd, L - 1 - i, stream));
+    if (attn_type == ATT_GENERAL || attn_type == ATT_1LNN) {
+      LR_LAUNCH(dec_sum_steps_kernel, dim3(B), dim3(128), 0, stream, (const float*)dlg, wb + w.dcterm, L, T);
+      LR_TRY(lr_launch_status());
+    }
+    if (attn_type == ATT_GENERAL) {
+      LR_CHECK_ARG(g->attn_w1 && g->attn_b1);
+      // GE = enc @ W_g: dW_g = enc^T @ dGE, d_enc += dGE @ W_g^T; cE = enc . b_g: db_g = enc^T dcE, d_enc += dcE b_g^T
+      LR_TRY(lr_sgemm_impl(1, 0, Hd, Hd, R, 1.f, enc, Hd, wb + w.dsrc, Hd, beta, g->attn_w1, Hd, nullptr, 0, 0, gws,
+                           w.gemm_bytes, stream));
+      LR_TRY(lr_sgemm_impl(0, 1, R, Hd, Hd, 1.f, wb + w.dsrc, Hd, p->attn_w1, Hd, 1.f, d_enc, Hd, nullptr, 0, 0, gws,
+                           w.gemm_bytes, stream));
+      LR_TRY(lr_sgemm_impl(1, 0, Hd, 1, R, 1.f, enc, Hd, wb + w.dcterm, 1, beta, g->attn_b1, 1, nullptr, 0, 0, gws,
+                           w.gemm_bytes, stream));
+      LR_TRY(lr_sgemm_impl(0, 0, R, Hd, 1, 1.f, wb + w.dcterm, 1, p->attn_b1, Hd, 1.f, d_enc, Hd, nullptr, 0, 0,
+                           nullptr, 0, stream));
+    } else if (attn_type == ATT_1LNN) {
+      LR_CHECK_ARG(g->attn_w1 && g->attn_b1);
+      // logit = w_e . enc[t] + w_h . h + b:  dw_e = enc^T dse, d_enc += dse w_e^T,
+      // dh += dsum w_h, dw_h = hs^T dsum, db = sum dsum
+      LR_TRY(lr_sgemm_impl(1, 0, Hd, 1, R, 1.f, enc, Hd, wb + w.dcterm, 1, beta, g->attn_w1, 1, nullptr, 0, 0, gws,
+                           w.gemm_bytes, stream));
+      LR_TRY(lr_sgemm_impl(0, 1, R, Hd, 1, 1.f, wb + w.dcterm, 1, p->attn_w1, 1, 1.f, d_enc, Hd, nullptr, 0, 0,
+                           nullptr, 0, stream));
+      LR_TRY(lr_sgemm_impl(0, 0, BL, Hd, 1, 1.f, dsum, 1, p->attn_w1 + Hd, Hd, 1.f, dy, Hd, nullptr, 0, 0, nullptr, 0,
+                           stream));
+      LR_TRY(lr_sgemm_impl(1, 0, Hd, 1, BL, 1.f, hs, Hd, dsum, 1, beta, g->attn_w1 + Hd, 1, nullptr, 0, 0, gws,
+                           w.gemm_bytes, stream));
+      LR_TRY(colsum_into(dsum, 1, BL, 1, colsum, g->attn_b1, accumulate, stream));
+    } else if (attn_type == ATT_CONCAT) {
+      LR_CHECK_ARG(g->attn_w1 && g->attn_b1 && g->attn_w2 && g->attn_b2);
+      LR_LAUNCH(dec_concat_bwd_kernel, dim3((A + 63) / 64, B), dim3(64), (size_t)L * T * sizeof(float), stream,
+                rb + r.aux1, rb + r.ph, p->attn_w2, (const float*)dlg, enc_lens, wb + w.dPE, wb + w.dph, wb + w.dw2p,
+                L, T, A);
+      LR_TRY(lr_launch_status());
+      // W1 = [W1e | W1h] (A x 2Hd): PE = enc W1e^T + b1, ph = hs W1h^T
+      LR_TRY(lr_sgemm_impl(0, 0, BL, Hd, A, 1.f, wb + w.dph, A, p->attn_w1 + Hd, 2 * Hd, 1.f, dy, Hd, nullptr, 0, 0,
+                           gws, w.gemm_bytes, stream));                                  // dh += dph W1h
+      LR_TRY(lr_sgemm_impl(1, 0, A, Hd, BL, 1.f, wb + w.dph, A, hs, Hd, beta, g->attn_w1 + Hd, 2 * Hd, nullptr, 0, 0,
+                           gws, w.gemm_bytes, stream));                                  // dW1h = dph^T hs
+      LR_TRY(lr_sgemm_impl(1, 0, A, Hd, R, 1.f, wb + w.dPE, A, enc, Hd, beta, g->attn_w1, 2 * Hd, nullptr, 0, 0, gws,
+                           w.gemm_bytes, stream));                                       // dW1e = dPE^T enc
+      LR_TRY(lr_sgemm_impl(0, 0, R, Hd, A, 1.f, wb + w.dPE, A, p->attn_w1, 2 * Hd, 1.f, d_enc, Hd, nullptr, 0, 0, gws,
+                           w.gemm_bytes, stream));                                       // d_enc += dPE W1e
+      LR_TRY(colsum_into(wb + w.dPE, A, R, A, colsum, g->attn_b1, accumulate, stream));
+      LR_TRY(colsum_into(wb + w.dw2p, A, B, A, colsum, g->attn_w2, accumulate, stream));
+      LR_TRY(colsum_into(dsum, 1, BL, 1, colsum, g->attn_b2, accumulate, stream));
+    }
   }
+
+  // ---- the only sequential part: the RNN backward over the L steps --------------------------------
+  for (int s = 0; s < L; ++s)
+    LR_TRY(lr_rnn_step_bwd(G, rb + r.gates, rb + r.extra, hs, dy, dh_n, dc_n, dG, wb + w.dcar, wb + w.dgp, step_lens,
+                           wb + w.wpT, h0, c0, B, L, Hd, s, stream));
   // gradient into the initial state (the encoder's final state)
   LR_TRY(lr_rnn_dh0(G, wb + w.dcar, wb + w.dgp + (size_t)((L - 1) & 1) * w.dgp_slot, wb + w.wpT, dh0, dc0, B, L, Hd,
                     stream));
 
-  // ---- deferred weight gradients: one GEMM each over all (sample, step) rows ----------------------
+  // ---- weight gradients: one GEMM each over all (sample, step) rows ---------------------------------
   const int ldg = 4 * Hd;
   // W_hh: h_prev of step t is hs[b][t-1]; step 0 used h0
   if (G == 3) {
@@ -746,9 +837,10 @@ extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_par
     LR_TRY(lr_sgemm_impl(1, 0, GH, Hd, B, 1.f, dG, L * ldg, h0, Hd, 1.f, g->w_hh, Hd, nullptr, 0, 0, nullptr, 0,
                          stream));
   }
-  LR_TRY(lr_rnn_bias_grads(dG, wb + w.colsum, g->b_ih, g->b_hh, BL, Hd, G, accumulate, stream));
+  LR_TRY(lr_rnn_bias_grads(dG, colsum, g->b_ih, g->b_hh, BL, Hd, G, accumulate, stream));
   // embedding / W_ih through the table: dEW[v] = sum of the dG_x rows that used token v
-  LR_LAUNCH(dec_scatter_dew_kernel, dim3(V), dim3(256), 0, stream, (const float*)dG, ids, wb + w.dEW, BL, G, Hd);
+  LR_LAUNCH(dec_scatter_dew_kernel, dim3(V, (GH + 255) / 256), dim3(256), 0, stream, (const float*)dG, ids,
+            wb + w.dEW, BL, G, Hd);
   LR_TRY(lr_launch_status());
   if (g->emb_padding_idx >= 0 && g->emb_padding_idx < V) {
     // nn.Embedding(padding_idx): that row receives no gradient (its W_ih contribution is x = 0 anyway)
@@ -761,62 +853,16 @@ extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_par
                        w.gemm_bytes, stream));
 
   // output projection and concat layer
-  LR_TRY(lr_sgemm_impl(1, 0, V, Hd, BL, 1.f, wb + w.dlogits, V, rb + r.pre, Hd, beta, g->w_o, Hd, nullptr, 0, 0, gws,
-                       w.gemm_bytes, stream));
-  LR_LAUNCH(rowsum_acc_kernel, dim3(1), dim3(256), 0, stream, (const float*)(wb + w.dlogits), BL, V, V, g->b_o,
-            accumulate);
-  LR_TRY(lr_launch_status());
-  if (attn_type != ATT_NONE) {
+  LR_TRY(lr_sgemm_impl(1, 0, V, Hd, BL, 1.f, dlogits, V, nh, Hd, beta, g->w_o, Hd, nullptr, 0, 0, gws, w.gemm_bytes,
+                       stream));
+  LR_TRY(colsum_into(dlogits, V, BL, V, colsum, g->b_o, accumulate, stream));
+  if (attn) {
     LR_CHECK_ARG(g->w_c && g->b_c);
-    LR_TRY(lr_sgemm_impl(1, 0, Hd, 2 * Hd, BL, 1.f, wb + w.dpre, Hd, rb + r.cat, 2 * Hd, beta, g->w_c, 2 * Hd,
-                         nullptr, 0, 0, gws, w.gemm_bytes, stream));
-    LR_LAUNCH(rowsum_acc_kernel, dim3((Hd + 255) / 256), dim3(256), 0, stream, (const float*)(wb + w.dpre), BL, Hd,
-              Hd, g->b_c, accumulate);
-    LR_TRY(lr_launch_status());
-  }
-  // attention parameters and the step-independent parts of d_enc
-  if (attn_type == ATT_GENERAL) {
-    LR_CHECK_ARG(g->attn_w1 && g->attn_b1);
-    // GE = enc @ W_g: dW_g = enc^T @ dGE, d_enc += dGE @ W_g^T; cE = enc . b_g: db_g = enc^T dcE, d_enc += dcE b_g^T
-    LR_TRY(lr_sgemm_impl(1, 0, Hd, Hd, R, 1.f, enc, Hd, wb + w.dsrc, Hd, beta, g->attn_w1, Hd, nullptr, 0, 0, gws,
+    LR_TRY(lr_sgemm_impl(1, 0, Hd, Hd, BL, 1.f, dpre, Hd, ctx, Hd, beta, g->w_c, 2 * Hd, nullptr, 0, 0, gws,
                          w.gemm_bytes, stream));
-    LR_TRY(lr_sgemm_impl(0, 1, R, Hd, Hd, 1.f, wb + w.dsrc, Hd, p->attn_w1, Hd, 1.f, d_enc, Hd, nullptr, 0, 0, gws,
+    LR_TRY(lr_sgemm_impl(1, 0, Hd, Hd, BL, 1.f, dpre, Hd, hs, Hd, beta, g->w_c + Hd, 2 * Hd, nullptr, 0, 0, gws,
                          w.gemm_bytes, stream));
-    LR_TRY(lr_sgemm_impl(1, 0, Hd, 1, R, 1.f, enc, Hd, wb + w.dcterm, 1, beta, g->attn_b1, 1, nullptr, 0, 0, nullptr,
-                         0, stream));
-    LR_TRY(lr_sgemm_impl(0, 0, R, Hd, 1, 1.f, wb + w.dcterm, 1, p->attn_b1, Hd, 1.f, d_enc, Hd, nullptr, 0, 0, nullptr,
-                         0, stream));
-  } else if (attn_type == ATT_1LNN) {
-    LR_CHECK_ARG(g->attn_w1 && g->attn_b1);
-    // w = [w_e | w_h]: dw_e = enc^T dse, dw_h = sum_{i,b} dsh[i][b] hs[b][i], db = sum dsh; d_enc += dse w_e^T
-    LR_TRY(lr_sgemm_impl(1, 0, Hd, 1, R, 1.f, enc, Hd, wb + w.dcterm, 1, beta, g->attn_w1, 1, nullptr, 0, 0, nullptr,
-                         0, stream));
-    LR_TRY(lr_sgemm_impl(0, 1, R, Hd, 1, 1.f, wb + w.dcterm, 1, p->attn_w1, 1, 1.f, d_enc, Hd, nullptr, 0, 0, nullptr,
-                         0, stream));
-    // dsh is stored [L][B]; hs is [B][L][Hd]: per step a (Hd x B)·(B x 1) product, accumulated
-    for (int i = 0; i < L; ++i)
-      LR_TRY(lr_sgemm_impl(1, 0, Hd, 1, B, 1.f, hs + (size_t)i * Hd, L * Hd, wb + w.dsh + (size_t)i * B, 1,
-                           (i == 0 ? beta : 1.f), g->attn_w1 + Hd, 1, nullptr, 0, 0, nullptr, 0, stream));
-    LR_LAUNCH(rowsum_acc_kernel, dim3(1), dim3(64), 0, stream, (const float*)(wb + w.dsh), BL, 1, 1, g->attn_b1,
-              accumulate);
-    LR_TRY(lr_launch_status());
-  } else if (attn_type == ATT_CONCAT) {
-    LR_CHECK_ARG(g->attn_w1 && g->attn_b1 && g->attn_w2 && g->attn_b2);
-    // W1 = [W1e | W1h] (A x 2Hd): dW1e = dPE^T enc, dW1h = sum_i dph_i^T hs_i, db1 = colsum(dPE)
-    LR_TRY(lr_sgemm_impl(1, 0, A, Hd, R, 1.f, wb + w.dPE, A, enc, Hd, beta, g->attn_w1, 2 * Hd, nullptr, 0, 0, gws,
-                         w.gemm_bytes, stream));
-    for (int i = 0; i < L; ++i)
-      LR_TRY(lr_sgemm_impl(1, 0, A, Hd, B, 1.f, wb + w.dph + (size_t)i * B * A, A, hs + (size_t)i * Hd, L * Hd,
-                           (i == 0 ? beta : 1.f), g->attn_w1 + Hd, 2 * Hd, nullptr, 0, 0, nullptr, 0, stream));
-    LR_TRY(lr_sgemm_impl(0, 0, R, Hd, A, 1.f, wb + w.dPE, A, p->attn_w1, 2 * Hd, 1.f, d_enc, Hd, nullptr, 0, 0, gws,
-                         w.gemm_bytes, stream));
-    LR_LAUNCH(rowsum_acc_kernel, dim3(1), dim3(256), 0, stream, (const float*)(wb + w.dPE), R, A, A, g->attn_b1,
-              accumulate);
-    LR_LAUNCH(rowsum_acc_kernel, dim3(1), dim3(256), 0, stream, (const float*)(wb + w.dw2), BL, A, A, g->attn_w2,
-              accumulate);
-    LR_LAUNCH(rowsum_acc_kernel, dim3(1), dim3(64), 0, stream, (const float*)(wb + w.db2), BL, 1, 1, g->attn_b2,
-              accumulate);
-    LR_TRY(lr_launch_status());
+    LR_TRY(colsum_into(dpre, Hd, BL, Hd, colsum, g->b_c, accumulate, stream));
   }
   return LR_OK;
 }

@@ -35,10 +35,17 @@ struct GemmArgs {
   int k_chunk;            // K range per blockIdx.z (multiple of BK)
   float* slabs;           // split-K partial sums [splits][M][N] or nullptr
   bool vecA, vecB;        // operand base + leading dimension allow 16-byte loads
+  int batch;              // > 1: blockIdx.z indexes independent problems (no split-K)
+  int64_t sA, sB, sC;     // element strides between the problems of a batch
 };
 
 template <int BM, int BN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
+  if (g.batch > 1) {   // batched: one problem per blockIdx.z, the whole K range
+    g.A += (int64_t)blockIdx.z * g.sA;
+    g.B += (int64_t)blockIdx.z * g.sB;
+    g.C += (int64_t)blockIdx.z * g.sC;
+  }
   constexpr int WM = BM / 64;  // 32x32 tiles per wave along M
   constexpr int WN = BN / 64;
   constexpr int LDA_S = TA ? (BM + 4) : (BK + 1);
@@ -55,7 +62,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * g.k_chunk;
+  const int kbeg = g.batch > 1 ? 0 : blockIdx.z * g.k_chunk;
   const int kend = min(g.K, kbeg + g.k_chunk);
 
   // per-thread staging registers: BM*BK/1024 float4 of A, BN*BK/1024 float4 of B
@@ -288,6 +295,7 @@ int lr_sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, cons
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.alpha = alpha; g.beta = beta;
   g.row_shift = row_shift; g.period = period;
+  g.batch = 1; g.sA = g.sB = g.sC = 0;
   g.vecA = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0;
   g.vecB = (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0;
   const GemmPlan p = plan_gemm(M, N, K, workspace ? workspace_bytes : 0);
@@ -308,6 +316,30 @@ int lr_sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, cons
     st = lr_launch_status();
   }
   return st;
+}
+
+// `batch` independent products C_z = alpha * op(A_z) op(B_z) + beta * C_z + bias with element
+// strides sA/sB/sC between them (0 = shared operand); 64x64 tiles, no split-K.
+int lr_sgemm_batched_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                          int64_t sA, const float* B, int ldb, int64_t sB, float beta, float* C, int ldc,
+                          int64_t sC, const float* bias, int batch, hipStream_t stream) {
+  LR_CHECK_ARG(A && B && C);
+  LR_CHECK_ARG(M > 0 && N > 0 && K >= 0 && lda > 0 && ldb > 0 && ldc >= N && batch > 0 && batch <= 65535);
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.bias = bias;
+  g.M = M; g.N = N; g.K = K;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.alpha = alpha; g.beta = beta;
+  g.row_shift = 0; g.period = 0;
+  g.batch = batch > 1 ? batch : 1; g.sA = sA; g.sB = sB; g.sC = sC;
+  g.vecA = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0 && (sA & 3) == 0;
+  g.vecB = (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0 && (sB & 3) == 0;
+  g.k_chunk = (K + BK - 1) / BK * BK;
+  if (g.k_chunk < BK) g.k_chunk = BK;
+  g.slabs = nullptr;
+  dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
+  launch_tile<64, 64>(transA, transB, g, grid, stream);
+  return lr_launch_status();
 }
 
 extern "C" size_t lr_sgemm_workspace_bytes(int M, int N, int K) {
