@@ -1,0 +1,216 @@
+"""The caller on the other side of the hot path: what `src/scripts/train.py` does around
+`train()` / `eval()`, so the reference's `config/` flag files drive the MI355X path unchanged.
+
+  python -m lipreading_amd.driver config/train/attn/attention_type --data=<name> [--flag=value ...]
+
+Mirrors (reference file:line, read for behaviour only):
+  _init_models   train.py:57-79    VideoEncoder(...) + CharDecodingStep(...), same keyword arguments
+  restore        train.py:82-132   name-and-shape tolerant checkpoint load
+  train          train.py:134-320  flags and defaults :134-167; epoch loop: patience / annealing
+                                   (lr /= 5, reload best weights) :256-268, linear teacher-forcing
+                                   decay :270-272, Adam re-created every epoch :275-276, eval on
+                                   val/train, best_{encoder,decoder}.pth :287-288
+  flag files     utils/cmd_line.py: one `--name=value` per line; booleans as `--flag=True|False`
+Out of scope here (the reference's control plane, not the path): tensorboard logging, sample
+printing and confusion-matrix plots (train.py:296-318), sentence re-segmentation (needs spaCy).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+DEFAULTS = dict(  # train.py:134-167
+    data="StephenColbert/medium_no_vtx1", labels="labels.json", sentence_dataset=False,
+    occlussion_threshold=0.8, train_split=0.8, num_workers=1, refresh=False,
+    patience=10, batch_size=4, learning_rate=1e-4, annealings=2, enable_ctc=False, grad_norm=50,
+    tr_epochs=50, max_tfr=0.9, min_tfr=0.0,
+    num_layers=1, frame_dim=68 * 3, hidden_size=700, char_dim=300,
+    rnn_type='LSTM', attention_type='1_layer_nn', attn_hidden_size=-1, bidirectional=False,
+    rnn_dropout=0.0, seed=123456, cuda=False,
+    # not reference flags: where data/ and weights/ live, and a cap for smoke runs
+    root=".", max_epochs=None,
+)
+
+
+def _coerce(name, text, like):
+  if isinstance(like, bool):
+    if text.lower() in ("true", "1", "yes", ""):
+      return True
+    if text.lower() in ("false", "0", "no"):
+      return False
+    raise ValueError("--%s expects True/False, got %r" % (name, text))
+  if like is None:
+    return None if text.lower() == "none" else int(text)
+  if isinstance(like, int):
+    return int(float(text)) if text.lower() != "none" else None
+  if isinstance(like, float):
+    return float(text)
+  return text
+
+
+def parse_flags(argv, defaults=DEFAULTS):
+  """Positional arguments are flag files (one or several `--name=value` tokens per line, as under
+  the reference's config/); later `--name=value` arguments override them.  Unknown flags are an
+  error, as in the reference's argument parser."""
+  tokens = []
+  for a in argv:
+    if a.startswith("--"):
+      tokens.append(a)
+    else:
+      with open(a) as f:
+        tokens += [t for t in f.read().replace("\n", " ").split(" ") if t.startswith("--")]
+  out = dict(defaults)
+  for t in tokens:
+    name, _, text = t[2:].partition("=")
+    if name not in out:
+      raise SystemExit("unknown flag --%s" % name)
+    out[name] = _coerce(name, text, defaults[name])
+  return out
+
+
+def init_models(char2idx, num_layers, frame_dim, hidden_size, char_dim, enable_ctc, rnn_type,
+                attention_type, attn_hidden_size, bidirectional, rnn_dropout, device):
+  """train.py:57-79 with the HIP-backed modules."""
+  from .attention_decoder import CharDecodingStep
+  from .encoder import VideoEncoder
+  encoder = VideoEncoder(frame_dim, hidden_size, rnn_type=rnn_type, num_layers=num_layers,
+                         bidirectional=bidirectional, rnn_dropout=rnn_dropout, enable_ctc=enable_ctc,
+                         vocab_size=len(char2idx), char2idx=char2idx, device=device).to(device)
+  decoding_step = CharDecodingStep(encoder, char_dim=char_dim, vocab_size=len(char2idx), char2idx=char2idx,
+                                   rnn_dropout=rnn_dropout, attention_type=attention_type,
+                                   attn_hidden_size=attn_hidden_size, device=device).to(device)
+  return encoder, decoding_step
+
+
+def restore(net, save_file, verbose=True):
+  """Load every tensor of the checkpoint whose name exists in `net` with the same shape; report
+  (not raise on) the rest — train.py:82-132.  Accepts the reference's `best_encoder.pth` /
+  `best_decoder.pth` state_dicts: the HIP-backed modules keep the reference's key names
+  (SURVEY.md 8b).  Returns (restored, ignored, untouched) name lists."""
+  own = net.state_dict()
+  ckpt = torch.load(save_file, map_location="cpu")
+  restored, mismatched = [], []
+  with torch.no_grad():
+    for name, value in ckpt.items():
+      if name not in own:
+        continue
+      if tuple(own[name].shape) != tuple(value.shape):
+        mismatched.append(name)
+        if verbose:
+          print('\t\tShape mismatch for var', name, 'expected', tuple(own[name].shape), 'got', tuple(value.shape))
+        continue
+      own[name].copy_(value.data if isinstance(value, torch.nn.Parameter) else value)
+      restored.append(name)
+  ignored = sorted(set(ckpt.keys()) - set(restored))
+  untouched = sorted(set(own.keys()) - set(restored))
+  if verbose:
+    print('\t\tRestored all variables' if not ignored else '\t\tDid not restore:\n\t' + '\n\t'.join(ignored))
+    print('\t\tNo new variables' if not untouched
+          else '\t\tInitialized but did not modify:\n\t' + '\n\t'.join(untouched))
+    print('\tRestored %s' % save_file)
+  return restored, ignored, untouched
+
+
+def weights_path(root, data):
+  """weights/<data>/<n>: a fresh numbered directory per run (utility.py getRelWeightsPath)."""
+  base = os.path.join(root, "weights", data)
+  os.makedirs(base, exist_ok=True)
+  taken = [int(d) for d in os.listdir(base) if d.isdigit()]
+  path = os.path.join(base, str(max(taken) + 1 if taken else 0))
+  os.makedirs(path)
+  return path
+
+
+def _cer(correct, count):
+  return float(count - correct) / count if count else 1.0
+
+
+def run(**flags):
+  """The training loop of train.py:134-320 on one MI355X.  Returns a summary dict."""
+  from . import train as T
+  from .data import make_collate_fn
+  from .dataset import FrameCaptionDataset, make_loader, split_dataset
+  from .optim import FlatParameters, FusedAdam
+  f = dict(DEFAULTS)
+  f.update(flags)
+  torch.manual_seed(f["seed"])
+  rand = np.random.RandomState(seed=f["seed"])
+  assert torch.cuda.is_available(), "the driver runs the HIP path: an MI355X is required (no CPU fallback)"
+  device = torch.device("cuda")
+  if not f["cuda"]:
+    print("note: --cuda=False is ignored: this build has no CPU execution path")
+  print("Initializing dataset '{}'".format(f["data"]))
+  splits = split_dataset(f["root"], f["data"], f["train_split"], rand=rand)
+  sets = [FrameCaptionDataset(f["root"], f["data"], name, ids, labels=f["labels"],
+                              threshold=f["occlussion_threshold"], sentence_dataset=f["sentence_dataset"],
+                              refresh=f["refresh"])
+          for name, ids in zip(("train", "val", "test"), splits)]
+  char2idx = sets[0].char2idx
+  collate = make_collate_fn(device)   # padded on the GPU (lr_collate_pad_f32); lengths stay on the host
+  train_loader, val_loader, test_loader = (make_loader(d, f["batch_size"], collate) for d in sets)
+  print("Initializing model")
+  encoder, decoding_step = init_models(char2idx, f["num_layers"], f["frame_dim"], f["hidden_size"], f["char_dim"],
+                                       f["enable_ctc"], f["rnn_type"], f["attention_type"], f["attn_hidden_size"],
+                                       f["bidirectional"], f["rnn_dropout"], device)
+  flats = (FlatParameters(encoder), FlatParameters(decoding_step))
+  weights_dir = weights_path(f["root"], f["data"])
+  encoder_path = os.path.join(weights_dir, "best_encoder.pth")
+  decoder_path = os.path.join(weights_dir, "best_decoder.pth")
+
+  print("Initial evaluation...")
+  _, correct, count, _ = T.eval(encoder, decoding_step, val_loader, device, char2idx)
+  val_cer = _cer(correct, count)
+  print("\tCER: ", val_cer)
+  best_val_cer, best_idx = 1.0, -1
+  lr = f["learning_rate"]
+  epochs, annealings = 0, 0
+  history = []
+  t0 = time.time()
+  print("Beginning training loop")
+  while val_cer < best_val_cer or annealings < f["annealings"]:
+    if f["max_epochs"] is not None and epochs >= f["max_epochs"]:
+      break
+    print("Epoch {}:".format(epochs + 1))
+    if epochs - best_idx > f["patience"]:
+      annealings += 1
+      lr /= 5
+      print(f'\tAnnealing to {lr}')
+      if os.path.isfile(encoder_path):
+        restore(encoder, encoder_path)
+        restore(decoding_step, decoder_path)
+      best_idx = epochs
+    tfr = max(f["min_tfr"], f["max_tfr"] - epochs / f["tr_epochs"])
+    assert 0.0 <= tfr <= 1.0
+    print(f'\tCurrent Teacher Forcing Ratio: {tfr}')
+    opt = tuple(FusedAdam(fl, lr=lr) for fl in flats)   # Adam state is rebuilt every epoch (:275-276)
+    dec_loss, ctc_loss = T.train(encoder, decoding_step, train_loader, opt, device, char2idx,
+                                 teacher_forcing_ratio=tfr, grad_norm=f["grad_norm"])
+    print(f'\tAVG Decoder Loss: {dec_loss}')
+    print(f'\tAVG CTC Loss: {ctc_loss}')
+    _, vc, vn, _ = T.eval(encoder, decoding_step, val_loader, device, char2idx)
+    _, tc, tn, _ = T.eval(encoder, decoding_step, train_loader, device, char2idx)
+    val_cer, train_cer = _cer(vc, vn), _cer(tc, tn)
+    encoder.save_best_model(val_cer, encoder_path)
+    decoding_step.save_best_model(val_cer, decoder_path)
+    _, sc, sn, _ = T.eval(encoder, decoding_step, test_loader, device, char2idx)
+    print(f'\tTrain CER: {train_cer}')
+    print(f'\tVal CER: {val_cer}')
+    print(f'\tTest CER: {_cer(sc, sn)}')
+    history.append(dict(epoch=epochs, decoder_loss=dec_loss, ctc_loss=ctc_loss, train_cer=train_cer,
+                        val_cer=val_cer, test_cer=_cer(sc, sn), lr=lr, tfr=tfr))
+    if val_cer < best_val_cer:   # :339-341
+      best_val_cer, best_idx = val_cer, epochs
+    epochs += 1
+  return dict(history=history, weights_dir=weights_dir, seconds=time.time() - t0, epochs=epochs)
+
+
+def main(argv=None):
+  flags = parse_flags(sys.argv[1:] if argv is None else argv)
+  out = run(**flags)
+  print("done: %d epochs in %.1f s, weights in %s" % (out["epochs"], out["seconds"], out["weights_dir"]))
+
+
+if __name__ == "__main__":
+  main()

@@ -152,3 +152,28 @@ def test_nano_dataset_end_to_end(dev, tmp_path):
   assert all(np.isfinite(losses)) and losses[-1] < 0.8 * losses[0], losses
   assert np.isfinite(T.eval(enc, None, loader, dev, ds.char2idx)[3])
   assert 0.0 <= T.greedy_cer(enc, loader, dev, ds.char2idx) <= 2.0
+
+
+def test_driver_trains_from_a_flag_file_on_a_synthetic_dataview(dev, tmp_path):
+  """train.py's loop (flag file -> datasets -> models -> epochs -> best_*.pth) on the HIP path,
+  over a synthetic dataview in the reference's on-disk format."""
+  from lipreading_amd import driver
+  from lipreading_amd.dataset import write_synthetic_dataview
+  root = str(tmp_path)
+  write_synthetic_dataview(root, "synth/micro", n_videos=10, captions_per_video=6, seed=7)
+  cfg = tmp_path / "flags"
+  cfg.write_text("--data=synth/micro\n--batch_size=8\n--enable_ctc=True\n--rnn_type=GRU\n--hidden_size=32\n"
+                 "--bidirectional=True\n--char_dim=16\n--attention_type=1_layer_nn\n--learning_rate=3e-3\n"
+                 "--grad_norm=50\n--max_tfr=0.9\n--tr_epochs=50\n--cuda=True\n")
+  flags = driver.parse_flags([str(cfg), "--root=" + root, "--max_epochs=3"])
+  out = driver.run(**flags)
+  h = out["history"]
+  assert len(h) == 3 and all(np.isfinite([e["decoder_loss"], e["ctc_loss"]]).all() for e in h)
+  assert h[-1]["decoder_loss"] < h[0]["decoder_loss"] and h[-1]["ctc_loss"] < h[0]["ctc_loss"]
+  assert h[0]["tfr"] == 0.9 and abs(h[2]["tfr"] - (0.9 - 2 / 50)) < 1e-12
+  import os
+  enc_path = os.path.join(out["weights_dir"], "best_encoder.pth")
+  assert os.path.isfile(enc_path) and os.path.isfile(os.path.join(out["weights_dir"], "best_decoder.pth"))
+  # the checkpoint is a plain state_dict with the reference's key names
+  sd = torch.load(enc_path, map_location="cpu")
+  assert {"rnn.weight_ih_l0", "rnn.weight_hh_l0_reverse", "output_proj.weight"} <= set(sd)

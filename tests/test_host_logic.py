@@ -109,3 +109,38 @@ def test_decoder_state_dict_and_init_match_reference_shape(attn, ah):
   for k in a:
     assert torch.equal(a[k], b[k]), k
   assert dec.output_mask.tolist() == ref.output_mask.tolist() and dec.hidden_size == 16
+
+
+def test_driver_flag_files_and_restore(tmp_path):
+  """The reference's config/ flag-file format and its tolerant checkpoint restore (train.py:82-132)."""
+  from lipreading_amd import driver
+  from lipreading_amd.encoder import VideoEncoder
+  cfg = tmp_path / "flags"
+  cfg.write_text("--batch_size=16\n--enable_ctc=True\n--rnn_type=GRU --hidden_size=256\n--bidirectional=True\n"
+                 "--learning_rate=3e-4\n--attention_type=dot\n")
+  f = driver.parse_flags([str(cfg), "--hidden_size=128", "--grad_norm=5"])
+  assert (f["batch_size"], f["enable_ctc"], f["rnn_type"], f["hidden_size"], f["bidirectional"]) == \
+         (16, True, "GRU", 128, True)
+  assert f["learning_rate"] == 3e-4 and f["grad_norm"] == 5 and f["attention_type"] == "dot"
+  assert f["char_dim"] == 300 and f["seed"] == 123456          # untouched defaults of train.py:134-167
+  with pytest.raises(SystemExit):
+    driver.parse_flags(["--no_such_flag=1"])
+  # restore(): a checkpoint written by the reference-shaped module (same keys), one tensor with the
+  # wrong shape and one unknown name
+  torch.manual_seed(0)
+  ref = O.OracleVideoEncoder(204, 8, rnn_type='GRU', bidirectional=True, enable_ctc=True, vocab_size=64,
+                             char2idx=O.default_char2idx())
+  sd = dict(ref.state_dict())
+  sd["output_proj.bias"] = torch.zeros(3)
+  sd["extra.weight"] = torch.zeros(2)
+  path = str(tmp_path / "best_encoder.pth")
+  torch.save(sd, path)
+  enc = VideoEncoder(204, 8, rnn_type='GRU', bidirectional=True, enable_ctc=True, vocab_size=64,
+                     char2idx=default_char2idx())
+  before = enc.output_proj.bias.detach().clone()
+  restored, ignored, untouched = driver.restore(enc, path, verbose=False)
+  assert "extra.weight" in ignored and "output_proj.bias" in ignored and untouched == ["output_proj.bias"]
+  assert torch.equal(enc.output_proj.bias, before)
+  for k, v in ref.state_dict().items():
+    if k != "output_proj.bias":
+      assert torch.equal(enc.state_dict()[k], v), k
