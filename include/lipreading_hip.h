@@ -39,7 +39,17 @@ typedef enum lr_status {
 
 typedef enum lr_rnn_mode {
   LR_RNN_GRU = 0, /* torch.nn.GRU  gate order r,z,n   (3 gates) */
-  LR_RNN_LSTM = 1 /* torch.nn.LSTM gate order i,f,g,o (4 gates) */
+  LR_RNN_LSTM = 1, /* torch.nn.LSTM gate order i,f,g,o (4 gates) */
+  LR_RNN_CELL_MASK = 0xff,
+  /* Optional flags OR-ed into `mode` of lr_rnn_layer_* / lr_rnn_*_bytes (build-defined, used by
+   * the pixel regime only; the reference-faithful path passes none and stays on exact fp32 MFMA):
+   * contract the layer's INPUT projection (x W_ih^T, and its two gradients) on the bf16 matrix
+   * cores with every fp32 operand split into bf16 hi + lo terms (~1e-5 relative, lr_xgemm). */
+  LR_RNN_PROJ_BF16X3 = 0x100,
+  /* with LR_RNN_PROJ_BF16X3: the layer input is the bf16 conv frontend's output — every element
+   * of x is already a bf16 value, so x needs no lo term, and dx goes to a bf16 consumer (the
+   * frontend's backward), so dx is contracted from the hi terms only. */
+  LR_RNN_INPUT_BF16_EXACT = 0x200
 } lr_rnn_mode;
 
 typedef enum lr_ctc_reduction {
@@ -158,6 +168,15 @@ int lr_rnn_layer_backward(int mode, const float* x, const int32_t* lens,
  * conv1..3 weight gradient. */
 int lr_profile_enable(int on);
 int lr_profile_read(int which, float* total_ms_host, int* samples_host);
+
+/* fp32 GEMM on the bf16 matrix cores by operand splitting (hi = bf16(x), lo = bf16(x - hi);
+ * a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulate): same conventions as lr_sgemm; a_exact /
+ * b_exact declare an operand whose elements are bf16 values already (no lo term).  Build-defined
+ * (no reference counterpart); ~1e-5 relative accuracy. */
+size_t lr_xgemm_workspace_bytes(int transA, int transB, int M, int N, int K);
+int lr_xgemm(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+             const float* B, int ldb, float beta, float* C, int ldc, const float* bias, int a_exact,
+             int b_exact, void* workspace, size_t workspace_bytes, lr_stream_t stream);
 
 /* ---- A3 tail: output_proj + masked_log_softmax — better_model.py:92-93 ------------------ */
 

@@ -25,6 +25,9 @@ SIGNATURES = {
     "lr_sgemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "lr_sgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, P, c_int, P, c_int, c_float,
                           P, c_int, P, c_int, c_int, P, c_size_t, P]),
+    "lr_xgemm_workspace_bytes": (c_size_t, [c_int] * 5),
+    "lr_xgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, P, c_int, P, c_int, c_float,
+                          P, c_int, P, c_int, c_int, P, c_size_t, P]),
     "lr_rnn_reserve_bytes": (c_size_t, [c_int] * 6),
     "lr_rnn_workspace_bytes": (c_size_t, [c_int] * 6),
     "lr_rnn_layer_forward": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int,

@@ -110,3 +110,9 @@ int lr_sgemm_batched_impl(int transA, int transB, int M, int N, int K, float alp
                           int64_t sA, const float* B, int ldb, int64_t sB, float beta, float* C, int ldc,
                           int64_t sC, const float* bias, int batch, hipStream_t stream);
 extern "C" size_t lr_sgemm_workspace_bytes(int M, int N, int K);
+// lr_xgemm.hip: fp32 GEMM on the bf16 matrix cores by hi/lo operand splitting (same operand
+// conventions; a_exact / b_exact: the operand's elements are bf16 values already)
+int lr_xgemm_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                  const float* B, int ldb, float beta, float* C, int ldc, const float* bias, int a_exact,
+                  int b_exact, void* workspace, size_t workspace_bytes, hipStream_t stream);
+extern "C" size_t lr_xgemm_workspace_bytes(int transA, int transB, int M, int N, int K);

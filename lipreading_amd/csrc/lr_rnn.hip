@@ -494,7 +494,7 @@ struct Layout {
   size_t gates, extra, bias, wp, hp, gemm, total;  // float offsets / total floats
   size_t wp_per_dir, hp_floats, gemm_bytes;
 };
-Layout reserve_layout(int G, int B, int T, int I, int H, int D) {
+Layout reserve_layout(int G, int B, int T, int I, int H, int D, bool x3 = false) {
   Layout l;
   const size_t nchunk = (H + 15) / 16, nbt = (B + 15) / 16;
   l.gates = 0;
@@ -505,7 +505,7 @@ Layout reserve_layout(int G, int B, int T, int I, int H, int D) {
   l.hp = l.wp + (size_t)D * l.wp_per_dir;
   l.hp_floats = 2 * (size_t)D * nbt * nchunk * FRAG;
   l.gemm = l.hp + l.hp_floats;                               // split-K slabs of the input projection
-  l.gemm_bytes = lr_sgemm_workspace_bytes(B * T, G * H, I);
+  l.gemm_bytes = x3 ? lr_xgemm_workspace_bytes(0, 1, B * T, G * H, I) : lr_sgemm_workspace_bytes(B * T, G * H, I);
   l.total = l.gemm + (l.gemm_bytes + 3) / 4;
   return l;
 }
@@ -538,21 +538,36 @@ WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
   return l;
 }
 
+inline int cell_of(int mode) { return mode & LR_RNN_CELL_MASK; }
+inline bool proj_x3(int mode) { return (mode & LR_RNN_PROJ_BF16X3) != 0; }
+inline bool x_exact(int mode) { return (mode & LR_RNN_INPUT_BF16_EXACT) != 0; }
 bool dims_ok(int mode, int B, int T, int I, int H, int D) {
-  return (mode == LR_RNN_GRU || mode == LR_RNN_LSTM) && B > 0 && T > 0 && I > 0 && H > 0 &&
-         (D == 1 || D == 2);
+  return (cell_of(mode) == LR_RNN_GRU || cell_of(mode) == LR_RNN_LSTM) &&
+         (mode & ~(LR_RNN_CELL_MASK | LR_RNN_PROJ_BF16X3 | LR_RNN_INPUT_BF16_EXACT)) == 0 && B > 0 && T > 0 &&
+         I > 0 && H > 0 && (D == 1 || D == 2);
+}
+// extra workspace floats of the bf16x3 input projection's backward (operand planes + split-K slabs
+// of the larger of its two products)
+size_t x3_ws_floats(int G, int B, int T, int I, int H) {
+  const int R = B * T, GH = G * H;
+  size_t a = lr_xgemm_workspace_bytes(1, 0, GH, I, R);
+  const size_t b = lr_xgemm_workspace_bytes(0, 0, R, I, GH);
+  if (b > a) a = b;
+  return (a / sizeof(float) + 63) / 64 * 64;
 }
 
 }  // namespace
 
 extern "C" size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D)) return 0;
-  return reserve_layout(mode == LR_RNN_GRU ? 3 : 4, B, T, I, H, D).total * sizeof(float);
+  return reserve_layout(cell_of(mode) == LR_RNN_GRU ? 3 : 4, B, T, I, H, D, proj_x3(mode)).total * sizeof(float);
 }
 
 extern "C" size_t lr_rnn_workspace_bytes(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D)) return 0;
-  return ws_layout(mode == LR_RNN_GRU ? 3 : 4, B, T, I, H, D).total * sizeof(float);
+  const int G = cell_of(mode) == LR_RNN_GRU ? 3 : 4;
+  return ((ws_layout(G, B, T, I, H, D).total + 63) / 64 * 64 + (proj_x3(mode) ? x3_ws_floats(G, B, T, I, H) : 0)) *
+         sizeof(float);
 }
 
 extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* lens,
@@ -563,10 +578,10 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
   LR_CHECK_ARG(dims_ok(mode, B, T, I, H, D));
   LR_CHECK_ARG(x && lens && w_ih && w_hh && b_ih && b_hh && y && h_n && reserve);
   if (H % 4 != 0) return LR_ERR_UNSUPPORTED;  // float4 operand loads along K
-  const int G = mode == LR_RNN_GRU ? 3 : 4;
+  const int G = cell_of(mode) == LR_RNN_GRU ? 3 : 4;
   LR_CHECK_ARG(G == 3 || c_n);
   for (int d = 0; d < D; ++d) LR_CHECK_ARG(w_ih[d] && w_hh[d] && b_ih[d] && b_hh[d]);
-  const Layout l = reserve_layout(G, B, T, I, H, D);
+  const Layout l = reserve_layout(G, B, T, I, H, D, proj_x3(mode));
   if (reserve_bytes < l.total * sizeof(float)) return LR_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   float* base = (float*)reserve;
@@ -581,9 +596,14 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
     int st = lr_launch_status();
     if (st != LR_OK) return st;
     // gates[b,t,d,:] = x[b,t,:] @ W_ih[d]^T + folded bias
-    st = lr_sgemm_impl(0, 1, B * T, GH, I, 1.f, x, I, w_ih[d], I, 0.f, gates + (size_t)d * GH,
-                       D * GH, bias + (size_t)d * GH, 0, 0, l.gemm_bytes ? (void*)(base + l.gemm) : nullptr,
-                       l.gemm_bytes, stream);
+    if (proj_x3(mode))
+      st = lr_xgemm_impl(0, 1, B * T, GH, I, 1.f, x, I, w_ih[d], I, 0.f, gates + (size_t)d * GH, D * GH,
+                         bias + (size_t)d * GH, x_exact(mode) ? 1 : 0, 0,
+                         l.gemm_bytes ? (void*)(base + l.gemm) : nullptr, l.gemm_bytes, stream);
+    else
+      st = lr_sgemm_impl(0, 1, B * T, GH, I, 1.f, x, I, w_ih[d], I, 0.f, gates + (size_t)d * GH,
+                         D * GH, bias + (size_t)d * GH, 0, 0, l.gemm_bytes ? (void*)(base + l.gemm) : nullptr,
+                         l.gemm_bytes, stream);
     if (st != LR_OK) return st;
   }
   StepPtrs p;
@@ -639,15 +659,17 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
   const float wbeta = accumulate ? 1.f : 0.f;
   LR_CHECK_ARG(dw_ih && dw_hh && db_ih && db_hh);
   if (H % 4 != 0) return LR_ERR_UNSUPPORTED;
-  const int G = mode == LR_RNN_GRU ? 3 : 4;
+  const int G = cell_of(mode) == LR_RNN_GRU ? 3 : 4;
   for (int d = 0; d < D; ++d)
     LR_CHECK_ARG(w_ih[d] && w_hh[d] && dw_ih[d] && dw_hh[d] && db_ih[d] && db_hh[d]);
   (void)b_ih;
   (void)b_hh;
-  const Layout rl = reserve_layout(G, B, T, I, H, D);
+  const Layout rl = reserve_layout(G, B, T, I, H, D, proj_x3(mode));
   if (reserve_bytes < rl.total * sizeof(float)) return LR_ERR_WORKSPACE;
   const WsLayout wl = ws_layout(G, B, T, I, H, D);
-  if (workspace_bytes < wl.total * sizeof(float)) return LR_ERR_WORKSPACE;
+  const bool x3 = proj_x3(mode);
+  const size_t xws_off = (wl.total + 63) / 64 * 64;   // floats; keeps the bf16 planes 16-byte aligned
+  if (workspace_bytes < (x3 ? xws_off + x3_ws_floats(G, B, T, I, H) : wl.total) * sizeof(float)) return LR_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   const float* rbase = (const float*)reserve;
   const float* gates = rbase + rl.gates;
@@ -693,11 +715,18 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
 
   const int R = B * T;
   const int ldg = D * 4 * H;
+  void* xws = wbase + xws_off;   // bf16x3 input projection: operand planes + split-K slabs
+  const size_t xws_bytes = x3 ? x3_ws_floats(G, B, T, I, H) * sizeof(float) : 0;
   for (int d = 0; d < D; ++d) {
     const float* dGd = dG + (size_t)d * 4 * H;
     // dW_ih[d] (G*H x I) = dGx^T (slots 0..G-1 are contiguous rows) @ x
-    st = lr_sgemm_impl(1, 0, GH, I, R, 1.f, dGd, ldg, x, I, wbeta, dw_ih[d], I, nullptr, 0, 0, gws,
-                       wl.gemm_bytes, stream);
+    if (x3) {
+      st = lr_xgemm_impl(1, 0, GH, I, R, 1.f, dGd, ldg, x, I, wbeta, dw_ih[d], I, nullptr, 0, x_exact(mode) ? 1 : 0,
+                         xws, xws_bytes, stream);
+    } else {
+      st = lr_sgemm_impl(1, 0, GH, I, R, 1.f, dGd, ldg, x, I, wbeta, dw_ih[d], I, nullptr, 0, 0, gws,
+                         wl.gemm_bytes, stream);
+    }
     if (st != LR_OK) return st;
     // dW_hh[d] = dGh^T @ h_prev, h_prev[b,t] = y[b,t-1] (forward dir) / y[b,t+1] (reverse dir)
     const float* yd = y + (size_t)d * H;
@@ -714,7 +743,13 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
                          T, gws, wl.gemm_bytes, stream);
     }
     if (st != LR_OK) return st;
-    if (dx) {
+    if (dx && x3) {
+      // a bf16 input's gradient goes to a bf16 consumer (the conv frontend's backward): hi terms only
+      const int hi_only = x_exact(mode) ? 1 : 0;
+      st = lr_xgemm_impl(0, 0, R, I, GH, 1.f, dGd, ldg, w_ih[d], I, d == 0 ? 0.f : 1.f, dx, I, nullptr, hi_only,
+                         hi_only, xws, xws_bytes, stream);
+      if (st != LR_OK) return st;
+    } else if (dx) {
       st = lr_sgemm_impl(0, 0, R, I, GH, 1.f, dGd, ldg, w_ih[d], I, d == 0 ? 0.f : 1.f, dx, I,
                          nullptr, 0, 0, gws, wl.gemm_bytes, stream);
       if (st != LR_OK) return st;

@@ -1,0 +1,344 @@
+// lr_xgemm.hip — fp32 GEMM contracted on the gfx950 bf16 matrix cores by operand splitting.
+//
+// C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C + bias[N], fp32 in memory, where each fp32
+// operand element x is split into two bf16 terms, hi = bf16(x) and lo = bf16(x - hi) (16 mantissa
+// bits together), and the product is accumulated in fp32 as
+//     a_hi b_hi + a_hi b_lo + a_lo b_hi          (the lo*lo term, 2^-16 of the result, is dropped)
+// with v_mfma_f32_32x32x16_bf16: 3 MFMAs at the bf16 rate (2.5 PF dense) instead of one at the fp32
+// rate (157 TF) — a 5x higher ceiling at ~1e-5 relative accuracy.  An operand the caller declares
+// bf16-exact (every element already a bf16 value, e.g. features produced by the bf16 conv frontend)
+// has no lo term: 2 MFMAs.
+//
+// Used ONLY where the caller asks for it (lr_rnn_layer_* with LR_RNN_PROJ_BF16X3: the input
+// projection of the recurrent layers in the pixel regime, whose input is the bf16 frontend's
+// output).  The reference-faithful landmark regime keeps the exact fp32 MFMA path (lr_gemm.hip)
+// for its 1e-4 loss parity.  No reference counterpart: the reference's input projection is inside
+// nn.GRU/nn.LSTM (better_model.py:74).
+//
+// Two passes.  (1) pack: each operand is split ONCE into bf16 planes in the caller's workspace,
+// K-contiguous ([rows][K]; operands that are row-contiguous in memory are transposed on the way,
+// 32x32 tiles through LDS).  Splitting inside the contraction instead costs ~8 VALU lane-ops per
+// element per tile that uses it — measured 2x the MFMA time at 128x128 tiles.  (2) contract: 256
+// threads = 2x2 waves, workgroup tile 128x128, wave tile 64x64 (2x2 MFMA tiles), BK = 32 per LDS
+// stage; plane tiles are staged as bf16 [row][32 + 8] (80-byte rows: the 16-byte fragment reads of
+// 16 consecutive rows cover all 64 banks exactly once); three stages of 16-byte global loads stay
+// in flight per workgroup (register ring) behind LDS-only barriers; K is split over workgroups
+// until ~2 are resident per CU, partial sums reduced in fixed order (deterministic); tiles are
+// ordered so that the ~64 resident on one XCD share operand panels in its L2.
+#include "lr_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short bf16_t;
+
+constexpr int XBM = 128, XBN = 128, XBK = 32, XLD = XBK + 8;
+constexpr int XDEPTH = 3;     // stages of global loads in flight
+constexpr int XGROUP_M = 4;   // m-panels per group of the tile order
+
+struct XArgs {
+  const bf16_t* Ah;   // [M][K] planes, leading dimension ldp (multiple of 8: 16-byte rows)
+  const bf16_t* Al;
+  const bf16_t* Bh;   // [N][K]
+  const bf16_t* Bl;
+  float* C;
+  const float* bias;
+  int M, N, K, ldp, ldc;
+  float alpha, beta;
+  int k_chunk;     // K range per split (multiple of XBK)
+  float* slabs;    // split-K partial sums [splits][M][N], or nullptr
+  int nx, ny, splits, per_xcd;   // tile grid and the number of tiles each XCD takes
+};
+
+// ---- pass 1: fp32 [rows][cols] (or its transpose) -> bf16 hi (+ lo) planes [rows'][ldp] -------------
+// transpose == 0: out[r][c] = split(in[r][c]);  transpose == 1: out[c][r] = split(in[r][c]).
+// The K axis of the planes is zero-filled from its logical width up to ldp (the contraction reads
+// whole 16-byte units).  32x32 tiles, 256 threads; the grid covers the OUTPUT extent.
+__global__ __launch_bounds__(256) void xpack_kernel(const float* __restrict__ in, int ld_in, int rows, int cols,
+                                                    int transpose, bf16_t* __restrict__ hi,
+                                                    bf16_t* __restrict__ lo, int ldp) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  // tile origin in OUTPUT coordinates (orow, ocol); input origin is the same or swapped
+  const int or0 = blockIdx.y * 32, oc0 = blockIdx.x * 32;
+  const int ir0 = transpose ? oc0 : or0, ic0 = transpose ? or0 : oc0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = ir0 + ty + 8 * i, c = ic0 + tx;
+    tile[ty + 8 * i][tx] = (r < rows && c < cols) ? in[(int64_t)r * ld_in + c] : 0.f;
+  }
+  __syncthreads();
+  const int orows = transpose ? cols : rows;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int orow = or0 + ty + 8 * i, ocol = oc0 + tx;
+    if (orow >= orows || ocol >= ldp) continue;
+    const float v = transpose ? tile[tx][ty + 8 * i] : tile[ty + 8 * i][tx];
+    const __bf16 h = (__bf16)v;
+    hi[(int64_t)orow * ldp + ocol] = __builtin_bit_cast(bf16_t, h);
+    if (lo) {
+      const __bf16 l = (__bf16)(v - (float)h);
+      lo[(int64_t)orow * ldp + ocol] = __builtin_bit_cast(bf16_t, l);
+    }
+  }
+}
+
+// ---- pass 2: C = sum over the retained (hi, lo) products of A_plane . B_plane^T ------------------------
+// AX / BX: operand is bf16-exact, no lo plane.
+template <bool AX, bool BX>
+__global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
+  __shared__ __attribute__((aligned(16))) bf16_t Ah[XBM * XLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Al[AX ? 8 : XBM * XLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Bh[XBN * XLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Bl[BX ? 8 : XBN * XLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (observed placement; only speed depends
+  // on it): XCD x takes the contiguous range [x * per_xcd, (x + 1) * per_xcd) of an order in which
+  // neighbouring tiles share operand panels (split slowest; groups of XGROUP_M m-panels, n across a
+  // group, m fastest).
+  const int t = (int)(blockIdx.x & 7) * g.per_xcd + (int)(blockIdx.x >> 3);
+  const int tiles = g.nx * g.ny;
+  if ((int)(blockIdx.x >> 3) >= g.per_xcd || t >= tiles * g.splits) return;   // workgroup-uniform
+  const int zs = t / tiles, tt = t - zs * tiles;
+  const int grp = tt / (XGROUP_M * g.nx), first_m = grp * XGROUP_M;
+  const int gm = min(XGROUP_M, g.ny - first_m);
+  const int in_grp = tt - grp * XGROUP_M * g.nx;
+  const int m0 = (first_m + in_grp % gm) * XBM, n0 = (in_grp / gm) * XBN;
+  const int kbeg = zs * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
+
+  // a plane tile is 128 rows x 32 k = 512 16-byte units: two per thread (row = e / 4, unit = e % 4)
+  auto fetch = [&](const bf16_t* p, int row, int row_lim, int k) -> uint4 {
+    if (row >= row_lim || k >= kend) return make_uint4(0u, 0u, 0u, 0u);   // planes are zero-padded to ldp
+    return *reinterpret_cast<const uint4*>(p + (int64_t)row * g.ldp + k);
+  };
+  constexpr int NPL = 2 + (AX ? 0 : 1) + (BX ? 0 : 1);
+  uint4 rr[XDEPTH][NPL][2];
+  auto load = [&](int slot, int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * 256, row = e >> 2, k = k0 + 8 * (e & 3);
+      int pl = 0;
+      rr[slot][pl++][i] = fetch(g.Ah, m0 + row, g.M, k);
+      if (!AX) rr[slot][pl++][i] = fetch(g.Al, m0 + row, g.M, k);
+      rr[slot][pl++][i] = fetch(g.Bh, n0 + row, g.N, k);
+      if (!BX) rr[slot][pl++][i] = fetch(g.Bl, n0 + row, g.N, k);
+    }
+  };
+  auto store = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * 256, o = (e >> 2) * XLD + 8 * (e & 3);
+      int pl = 0;
+      *reinterpret_cast<uint4*>(&Ah[o]) = rr[slot][pl++][i];
+      if (!AX) *reinterpret_cast<uint4*>(&Al[o]) = rr[slot][pl++][i];
+      *reinterpret_cast<uint4*>(&Bh[o]) = rr[slot][pl++][i];
+      if (!BX) *reinterpret_cast<uint4*>(&Bl[o]) = rr[slot][pl++][i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lr = lane & 31, lk = lane >> 5;
+#pragma unroll
+  for (int sl = 0; sl < XDEPTH; ++sl)
+    if (kbeg + sl * XBK < kend) load(sl, kbeg + sl * XBK);
+  for (int kb = kbeg; kb < kend; kb += XDEPTH * XBK) {
+#pragma unroll
+    for (int sl = 0; sl < XDEPTH; ++sl) {   // fully unrolled: the ring slots are static registers
+      const int k0 = kb + sl * XBK;
+      if (k0 < kend) {                     // workgroup-uniform
+        // LDS-only barriers: __syncthreads() would also drain vmcnt, i.e. wait for the two younger
+        // stages still in flight, and put the whole memory latency back on every stage
+        lr_lds_barrier();
+        store(sl);
+        lr_lds_barrier();
+        if (k0 + XDEPTH * XBK < kend) load(sl, k0 + XDEPTH * XBK);
+#pragma unroll
+        for (int kk = 0; kk < XBK; kk += 16) {
+          bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int o = (wm * 64 + i * 32 + lr) * XLD + kk + lk * 8;
+            ah[i] = *reinterpret_cast<const bf16x8*>(&Ah[o]);
+            if (!AX) al[i] = *reinterpret_cast<const bf16x8*>(&Al[o]);
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int o = (wn * 64 + j * 32 + lr) * XLD + kk + lk * 8;
+            bh[j] = *reinterpret_cast<const bf16x8*>(&Bh[o]);
+            if (!BX) bl[j] = *reinterpret_cast<const bf16x8*>(&Bl[o]);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              // small terms first, so they are not absorbed by a large partial sum
+              if (!BX) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+              if (!AX) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+        }
+      }
+    }
+  }
+  // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + lr;
+      if (col >= g.N) continue;
+      const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= g.M) continue;
+        if (g.slabs) {
+          g.slabs[((int64_t)zs * g.M + row) * g.N + col] = acc[i][j][r];
+          continue;
+        }
+        float out = g.alpha * acc[i][j][r] + bv;
+        float* c = g.C + (int64_t)row * g.ldc + col;
+        if (g.beta != 0.f) out += g.beta * *c;
+        *c = out;
+      }
+    }
+}
+
+// deterministic split-K combine (fixed order over the slabs), then alpha / beta / bias
+__global__ void xsplitk_reduce_kernel(const float* __restrict__ slabs, int splits, float* __restrict__ C, int ldc,
+                                      const float* __restrict__ bias, int M, int N, float alpha, float beta) {
+  const int64_t total = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slabs[(int64_t)z * total + i];
+    const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
+    float out = alpha * s;
+    if (bias) out += bias[col];
+    float* c = C + (int64_t)row * ldc + col;
+    if (beta != 0.f) out += beta * *c;
+    *c = out;
+  }
+}
+
+size_t pad64(size_t n) { return (n + 63) / 64 * 64; }
+int ldp_of(int K) { return (K + 7) / 8 * 8; }
+// floats of workspace taken by one operand's planes ([rows][ldp] bf16, hi + optionally lo)
+size_t plane_floats(int rows, int K, bool exact) {
+  return pad64(((size_t)rows * ldp_of(K) * (exact ? 1 : 2) + 1) / 2);
+}
+
+// Split K so that the workgroups fill the 512 resident slots (2 per CU) in as few rounds as possible:
+// cost(s) = rounds(s) * (K / s + fixed per-workgroup overhead), >= 4 stages per split.  Large tile
+// grids are never split (the fp32 slabs would cost more than the tail they remove).
+int want_splits(int M, int N, int K) {
+  const long tiles = (long)((M + XBM - 1) / XBM) * ((N + XBN - 1) / XBN);
+  if (tiles >= 384) return 1;
+  long max_split = K / (4 * XBK);
+  if (max_split > 16) max_split = 16;
+  long best = 1, best_cost = -1;
+  for (long sp = 1; sp <= max_split; ++sp) {
+    const long rounds = (tiles * sp + 511) / 512;
+    const long cost = rounds * (K / sp + 96);
+    if (best_cost < 0 || cost < best_cost) { best = sp; best_cost = cost; }
+  }
+  return (int)best;
+}
+
+// planes [orows][ldp] of an operand stored [rows][cols] (transpose: planes are [cols][rows -> ldp])
+int pack_operand(const float* in, int ld_in, int rows, int cols, int transpose, bf16_t* hi, bf16_t* lo, int ldp,
+                 hipStream_t stream) {
+  const int orows = transpose ? cols : rows;
+  LR_LAUNCH(xpack_kernel, dim3((ldp + 31) / 32, (orows + 31) / 32), dim3(256), 0, stream, in, ld_in, rows, cols,
+            transpose, hi, lo, ldp);
+  return lr_launch_status();
+}
+
+}  // namespace
+
+// bytes of workspace lr_xgemm needs: the operands' bf16 planes + split-K slabs
+extern "C" size_t lr_xgemm_workspace_bytes(int transA, int transB, int M, int N, int K) {
+  (void)transA;
+  (void)transB;
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  size_t f = plane_floats(M, K, false) + plane_floats(N, K, false);
+  const int sp = want_splits(M, N, K);
+  if (sp > 1) f += pad64((size_t)sp * M * N);
+  return f * sizeof(float);
+}
+
+// Internal entry: same operand conventions as lr_sgemm_impl (transA: A stored [K][M]; transB: B
+// stored [N][K]).
+int lr_xgemm_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                  const float* B, int ldb, float beta, float* C, int ldc, const float* bias, int a_exact,
+                  int b_exact, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  LR_CHECK_ARG(A && B && C && workspace);
+  LR_CHECK_ARG(M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N);
+  const int ldp = ldp_of(K);
+  const size_t fa = plane_floats(M, K, a_exact != 0), fb = plane_floats(N, K, b_exact != 0);
+  size_t avail = workspace_bytes / sizeof(float);
+  if (avail < fa + fb) return LR_ERR_WORKSPACE;
+  avail -= fa + fb;
+  float* ws = (float*)workspace;
+  bf16_t* Ahp = (bf16_t*)ws;
+  bf16_t* Alp = a_exact ? nullptr : Ahp + (size_t)M * ldp;
+  bf16_t* Bhp = (bf16_t*)(ws + fa);
+  bf16_t* Blp = b_exact ? nullptr : Bhp + (size_t)N * ldp;
+  float* slabs = ws + fa + fb;
+  // A planes [M][K]: stored [K][M] when transA (rows = K, cols = M, transposed), else [M][K]
+  int st = transA ? pack_operand(A, lda, K, M, 1, Ahp, Alp, ldp, stream)
+                  : pack_operand(A, lda, M, K, 0, Ahp, Alp, ldp, stream);
+  if (st != LR_OK) return st;
+  // B planes [N][K]: stored [N][K] when transB, else [K][N] (transposed)
+  st = transB ? pack_operand(B, ldb, N, K, 0, Bhp, Blp, ldp, stream)
+              : pack_operand(B, ldb, K, N, 1, Bhp, Blp, ldp, stream);
+  if (st != LR_OK) return st;
+
+  // split-K as far as the remaining workspace allows (none: a single pass, just slower)
+  int splits = want_splits(M, N, K);
+  while (splits > 1 && (size_t)splits * M * N > avail) --splits;
+  int chunk = (K + splits - 1) / splits;
+  chunk = (chunk + XBK - 1) / XBK * XBK;
+  splits = (K + chunk - 1) / chunk;
+  XArgs g;
+  g.Ah = Ahp; g.Al = Alp; g.Bh = Bhp; g.Bl = Blp;
+  g.C = C; g.bias = bias;
+  g.M = M; g.N = N; g.K = K; g.ldp = ldp; g.ldc = ldc;
+  g.alpha = alpha; g.beta = beta;
+  g.k_chunk = chunk;
+  g.slabs = splits > 1 ? slabs : nullptr;
+  g.nx = (N + XBN - 1) / XBN;
+  g.ny = (M + XBM - 1) / XBM;
+  g.splits = splits;
+  const int ntile = g.nx * g.ny * splits;
+  g.per_xcd = (ntile + 7) / 8;
+  dim3 grid(8 * g.per_xcd);
+  lr_clear_error();
+  if (a_exact && b_exact) hipLaunchKernelGGL((xgemm_kernel<true, true>), grid, dim3(256), 0, stream, g);
+  else if (a_exact) hipLaunchKernelGGL((xgemm_kernel<true, false>), grid, dim3(256), 0, stream, g);
+  else if (b_exact) hipLaunchKernelGGL((xgemm_kernel<false, true>), grid, dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((xgemm_kernel<false, false>), grid, dim3(256), 0, stream, g);
+  st = lr_launch_status();
+  if (st != LR_OK || splits == 1) return st;
+  const int64_t total = (int64_t)M * N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  LR_LAUNCH(xsplitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)g.slabs, splits, C, ldc, bias, M,
+            N, alpha, beta);
+  return lr_launch_status();
+}
+
+extern "C" int lr_xgemm(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                        const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
+                        int a_exact, int b_exact, void* workspace, size_t workspace_bytes, lr_stream_t stream) {
+  return lr_xgemm_impl(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, a_exact, b_exact,
+                       workspace, workspace_bytes, (hipStream_t)stream);
+}

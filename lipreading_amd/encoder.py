@@ -22,6 +22,7 @@ from .data import BOS, PAD
 _ALLOWED_RNN_TYPES = {'LSTM', 'GRU', 'RNN'}          # better_model.py:9
 _ALLOWED_FRAME_PROCESSING = {'flatten'}              # better_model.py:10
 _MODES = {'GRU': 0, 'LSTM': 1}
+_PROJ_BF16X3, _INPUT_BF16_EXACT = 0x100, 0x200   # lr_rnn_mode flags
 _GATES = {'GRU': 3, 'LSTM': 4}
 
 
@@ -65,7 +66,7 @@ class _RNNLayerFunction(torch.autograd.Function):
     b_ih, b_hh = list(weights[2::4]), list(weights[3::4])
     y = torch.empty((B, T, D * H), dtype=torch.float32, device=dev)
     h_n = torch.empty((D, B, H), dtype=torch.float32, device=dev)
-    c_n = torch.empty((D, B, H), dtype=torch.float32, device=dev) if mode == 1 else None
+    c_n = torch.empty((D, B, H), dtype=torch.float32, device=dev) if (mode & 0xff) == 1 else None
     rbytes = L.lr_rnn_reserve_bytes(mode, B, T, I, H, D)
     reserve = torch.empty(rbytes, dtype=torch.uint8, device=dev)
     _C.check(L.lr_rnn_layer_forward(mode, x.data_ptr(), lens.data_ptr(), _ptr_array(w_ih),
@@ -92,7 +93,7 @@ class _RNNLayerFunction(torch.autograd.Function):
     b_ih, b_hh = list(weights[2::4]), list(weights[3::4])
     dy = dy.contiguous() if dy is not None else torch.zeros_like(y)
     dh_n = dh_n.contiguous() if dh_n is not None else None
-    dc_n = dc_n.contiguous() if (mode == 1 and dc_n is not None) else None
+    dc_n = dc_n.contiguous() if ((mode & 0xff) == 1 and dc_n is not None) else None
     direct = _direct_grads(weights)
     grads = [w.grad for w in weights] if direct else [torch.empty_like(w) for w in weights]
     dx = torch.empty_like(x) if need_dx else None
@@ -209,6 +210,10 @@ class VideoEncoder(nn.Module):
     self.enable_ctc = enable_ctc
     self.best_error = 1
     self.num_dirs = 2 if self.bidirectional else 1
+    # not in the reference: 'f32' = exact fp32 MFMA input projection (reference-faithful regime);
+    # 'bf16x3' is set by frontend.PixelLipReader for the build-defined pixel regime
+    self.input_projection = 'f32'
+    self.input_is_bf16 = False
     if self.enable_ctc:
       self.vocab_size = vocab_size
       self.adj_vocab_size = self.vocab_size + 1      # idx 0 is reserved for the CTC blank
@@ -249,7 +254,13 @@ class VideoEncoder(nn.Module):
     for layer in range(self.num_layers):
       weights = self.rnn.layer_weights(layer, D)
       need_dx = layer > 0 or x.requires_grad
-      y, h_n, c_n = _RNNLayerFunction.apply(x, lens, mode, H, need_dx, *weights)
+      lmode = mode
+      if self.input_projection == 'bf16x3':
+        # build-defined (pixel regime): input projection on the bf16 matrix cores with hi/lo split
+        # operands (include/lipreading_hip.h LR_RNN_PROJ_BF16X3); layer 0's input is bf16-exact
+        # when it comes from the bf16 conv frontend
+        lmode |= _PROJ_BF16X3 | (_INPUT_BF16_EXACT if (layer == 0 and self.input_is_bf16) else 0)
+      y, h_n, c_n = _RNNLayerFunction.apply(x, lens, lmode, H, need_dx, *weights)
       # (D,B,H) -> (B, D*H): forward direction first, as _cat_directions (better_model.py:98-112)
       h_fin.append(h_n.permute(1, 0, 2).reshape(B, D * H))
       if mode == 1:

@@ -153,6 +153,10 @@ class PixelLipReader(nn.Module):
     self.frontend = frontend if frontend is not None else ConvFrontend3D()
     self.encoder = encoder
     self.enable_ctc = encoder.enable_ctc
+    # the frontend's features are bf16 values: contract the encoder's input projections
+    # (K = 3456 features) on the bf16 matrix cores with hi/lo split fp32 operands
+    encoder.input_projection = 'bf16x3'
+    encoder.input_is_bf16 = True
 
   def forward(self, clips, frame_lens, max_len=None):
     feats = self.frontend(clips)
