@@ -341,19 +341,28 @@ int lr_clip_to_ndhwc_bf16(const void* clips, int is_u8, void* out, int64_t frame
                           lr_stream_t stream);
 
 /* fp32 torch Conv3d weight [Cout][Cin_real][KT][KH][KW] -> bf16 operand of the implicit GEMM:
- *   dgrad == 0: out[Cout][taps][Cin_pad]          (forward; channels >= Cin_real are zero)
- *   dgrad == 1: out[Cin_real][taps][Cout], taps flipped (data gradient of a stride-1 "same" conv
- *               becomes lr_conv3d_forward on dZ with this operand).                             */
+ *   dgrad & 1 == 0: out[Cout][taps][Cin_pad]          (forward; channels >= Cin_real are zero)
+ *   dgrad & 1 == 1: out[Cin_real][taps][Cout], taps flipped (data gradient of a stride-1 "same" conv
+ *                   becomes lr_conv3d_forward on dZ with this operand).
+ *   dgrad & 2: the same elements in the fragment-major order of the patch-resident kernel (every
+ *              32-output-channel x 16-k MFMA operand 1 KB contiguous); only for layers for which
+ *              lr_conv3d_patch_supported() is 1, to be passed to lr_conv3d_forward with flags & 2. */
 int lr_conv3d_pack_weights(const float* W, void* out, int Cout, int Cin_real, int Cin_pad, int KT,
                            int KH, int KW, int dgrad, lr_stream_t stream);
 
 /* Y[b,t,ho,wo,n] = act( sum_{kt,kh,kw,c} X[b,t+kt-pt,ho*s+kh-ph,wo*s+kw-pw,c] * Wp[n][(kt,kh,kw)][c]
  *                       + bias[n] ),  zero padding, temporal stride 1 and KT = 2*pt+1, spatial stride s.
  *   X bf16 [B][T][Hin][Win][Cin] (Cin % 4 == 0), Wp from lr_conv3d_pack_weights, bias fp32 or NULL,
- *   Y bf16 [B][T][Ho][Wo][Cout] (Cout in {32,64,96}); relu != 0 applies max(.,0).                */
+ *   Y bf16 [B][T][Ho][Wo][Cout] (Cout in {32,64,96}); flags & 1 applies max(.,0) (ReLU);
+ *   flags & 2: Wp is fragment-major (lr_conv3d_pack_weights dgrad & 2).                            */
 int lr_conv3d_forward(const void* X, const void* Wp, const float* bias, void* Y, int B, int T, int Hin,
                       int Win, int Cin, int Cout, int KT, int KH, int KW, int stride, int pt, int ph,
-                      int pw, int relu, lr_stream_t stream);
+                      int pw, int flags, lr_stream_t stream);
+/* 1 when the layer (as lr_conv3d_forward sees it: Cin = contraction channels, Cout = output
+ * channels) has a patch-resident kernel: the input patch of an output tile is loaded into LDS
+ * once and all taps run out of LDS, instead of re-gathering it per tap. */
+int lr_conv3d_patch_supported(int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW, int stride,
+                              int pt, int ph, int pw);
 
 /* dW[Cout][Cin_real][KT][KH][KW] (fp32) (+)= sum_pixels dZ[pixel][n] * im2col(X)[pixel][(tap,c)];
  * dbias[n] (+)= sum_pixels dZ[pixel][n] (NULL to skip).  dZ bf16 [B][T][Ho][Wo][Cout].          */

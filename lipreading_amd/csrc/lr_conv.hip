@@ -762,27 +762,174 @@ __global__ void conv3d_wgrad_reduce_kernel(const float* __restrict__ slabs, int 
 // ---------------------------------------------------------------------------------------------
 // forward:  Wp[n][tap][c]  = W[n][c][tap]                      (c >= Cin_real -> 0)
 // dgrad:    Wd[c][tap'][n] = W[n][c][flip(tap')]               rows = Cin_real (multiple of 32)
+// Both are [N_out][taps][K_ch] (N_out = GEMM output channel, K_ch = contraction channel).  With
+// frag != 0 the same elements are written fragment-major for conv_patch_kernel,
+//   Wf[cg][tap][kc][nt][lane = kg*32 + n%32][j] = Wp[nt*32 + n%32][tap][cg*32 + kc*16 + kg*8 + j],
+// i.e. every MFMA B fragment (32 output channels x 16 k) is 1 KB contiguous, 16 bytes per lane.
 __global__ void conv3d_pack_weights_kernel(const float* __restrict__ W, bf16_t* __restrict__ out, int Cout,
                                            int Cin_real, int Cin_pad, int KT, int KH, int KW,
-                                           int dgrad) {
+                                           int dgrad, int frag) {
   const int taps = KT * KH * KW;
-  const int64_t total = dgrad ? (int64_t)Cin_real * taps * Cout : (int64_t)Cout * taps * Cin_pad;
+  const int Nout = dgrad ? Cin_real : Cout, Kch = dgrad ? Cout : Cin_pad;
+  const int64_t total = (int64_t)Nout * taps * Kch;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
+    const int kch = (int)(i % Kch);
+    const int tp = (int)((i / Kch) % taps);
+    const int nout = (int)(i / ((int64_t)Kch * taps));
     float v = 0.f;
     if (!dgrad) {
-      const int c = (int)(i % Cin_pad);
-      const int tap = (int)((i / Cin_pad) % taps);
-      const int n = (int)(i / ((int64_t)Cin_pad * taps));
-      if (c < Cin_real) v = W[((int64_t)n * Cin_real + c) * taps + tap];
+      if (kch < Cin_real) v = W[((int64_t)nout * Cin_real + kch) * taps + tp];
     } else {
-      const int n = (int)(i % Cout);
-      const int tp = (int)((i / Cout) % taps);
-      const int c = (int)(i / ((int64_t)Cout * taps));
       const int tap = taps - 1 - tp;  // flip kt, kh and kw together
-      v = W[((int64_t)n * Cin_real + c) * taps + tap];
+      v = W[((int64_t)kch * Cin_real + nout) * taps + tap];
     }
-    out[i] = f2bf(v);
+    int64_t dst = i;
+    if (frag) {
+      const int cg = kch >> 5, kc = (kch >> 4) & 1, kg = (kch >> 3) & 1, j = kch & 7;
+      const int nt = nout >> 5, nl = nout & 31, NT = Nout >> 5;
+      dst = ((((((int64_t)cg * taps + tp) * 2 + kc) * NT + nt) * 64 + kg * 32 + nl) << 3) + j;
+    }
+    out[dst] = f2bf(v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// patch-resident forward / data-gradient kernel for the 24-wide stride-1 (3,5,5) layer
+// ---------------------------------------------------------------------------------------------
+// The implicit-GEMM kernel above re-gathers every input element once per tap it feeds (75x for this
+// layer): 6.6 GB of L2 -> LDS traffic and ~30 VALU operations per 16-byte unit.  Here a workgroup
+// loads the input patch of its output tile ONCE (4 frames x 8 rows x 24 columns of outputs, i.e.
+// 6 x 12 x 28 input positions of 32 channels = 126 KB of LDS) and then runs all 75 taps out of LDS:
+// an A fragment (32 positions x 16 channels of one tap) is one ds_read_b128 per lane at
+// patch[position + tap offset]; B fragments (32 output channels x 16 channels of one tap) come
+// straight from global memory in the fragment-major packing above, 1 KB contiguous per wave load,
+// prefetched one tap ahead.  Inputs with 64 channels (the data gradient: dZ has 64) take two passes
+// of 32 channels with the accumulators kept.
+//   Wave w owns output frame f0 + w: 6 MFMA row tiles of 8 rows x 4 columns x NT column tiles ->
+//   6*NT accumulators; taps reaching across a clip boundary are skipped (wave-uniform).
+//   LDS layout: position p = (slot*12 + row)*28 + col holds 4 chunks of 16 bytes, chunk c stored at
+//   c ^ ((p >> 2) & 3).  With 28 positions per row the 16 lanes that ds_read_b128 serves together
+//   (4 columns x 4 of the 8 rows, rows distinct mod 4) then hit 16 different 16-byte bank slots.
+constexpr int P2_TT = 4, P2_TH = 8, P2_W = 24, P2_PW = P2_W + 4, P2_PH = P2_TH + 4, P2_SLOTS = P2_TT + 2;
+constexpr int P2_POS = P2_SLOTS * P2_PH * P2_PW;   // 2016 positions
+constexpr int P2_LDS = P2_POS * 64;                // 129,024 bytes
+constexpr int P2_UNITS = P2_POS * 4;               // 16-byte units
+constexpr int P2_UPT = (P2_UNITS + 255) / 256;     // units per thread: 32 (31.5)
+
+template <int CG, int NT>
+__global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __restrict__ X,
+                                                            const bf16_t* __restrict__ Wf,
+                                                            const float* __restrict__ bias,
+                                                            bf16_t* __restrict__ Y, int F, int T, int H,
+                                                            int relu) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char patch[];
+  constexpr int C = 32 * CG, N = 32 * NT, TAPS = 75;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int htiles = H / P2_TH;
+  const int f0 = (int)(blockIdx.x / htiles) * P2_TT, h0 = (int)(blockIdx.x % htiles) * P2_TH;
+  const int lr = lane & 31, kg = lane >> 5;
+  const int f = f0 + wave;
+  const bool fvalid = f < F;
+  const int t = f % T;
+
+  f32x16 acc[6][NT];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int base_p = (wave * P2_PH + (lr >> 2)) * P2_PW + (lr & 3);
+  for (int cg = 0; cg < CG; ++cg) {
+    if (cg > 0) __syncthreads();   // every wave is done with the previous channel group's patch
+    // ---- load the patch: all of a thread's units are issued before the first is stored ----------
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      uint4 v[P2_UPT / 2];
+#pragma unroll
+      for (int i = 0; i < P2_UPT / 2; ++i) {
+        const int u = tid + 256 * (half * (P2_UPT / 2) + i);
+        v[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (u < P2_UNITS) {
+          const int p = u >> 2, c = u & 3;
+          const int s = p / (P2_PH * P2_PW), rem = p - s * (P2_PH * P2_PW);
+          const int ph = rem / P2_PW, pw = rem - ph * P2_PW;
+          const int ff = f0 - 1 + s, hh = h0 - 2 + ph, ww = pw - 2;
+          if (ff >= 0 && ff < F && hh >= 0 && hh < H && ww >= 0 && ww < P2_W)
+            v[i] = *reinterpret_cast<const uint4*>(X + (((int64_t)ff * H + hh) * P2_W + ww) * C + cg * 32 + c * 8);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < P2_UPT / 2; ++i) {
+        const int u = tid + 256 * (half * (P2_UPT / 2) + i);
+        if (u < P2_UNITS) {
+          const int p = u >> 2, c = u & 3;
+          *reinterpret_cast<uint4*>(patch + p * 64 + ((c ^ ((p >> 2) & 3)) << 4)) = v[i];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 75 taps out of LDS ----------------------------------------------------------------------
+    const bf16_t* wf = Wf + (int64_t)cg * TAPS * (2 * NT) * 512 + lane * 8;
+    bf16x8 bcur[2][NT], bnext[2][NT];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bcur[kc][j] = *reinterpret_cast<const bf16x8*>(wf + (kc * NT + j) * 512);
+    int tap = 0;
+    for (int dt = 0; dt < 3; ++dt) {
+      const bool valid = fvalid && t + dt - 1 >= 0 && t + dt - 1 < T;   // wave-uniform
+      for (int dh = 0; dh < 5; ++dh) {
+#pragma unroll
+        for (int dw = 0; dw < 5; ++dw, ++tap) {
+          if (tap + 1 < TAPS) {
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+              for (int j = 0; j < NT; ++j)
+                bnext[kc][j] = *reinterpret_cast<const bf16x8*>(wf + ((int64_t)(tap + 1) * 2 * NT + kc * NT + j) * 512);
+          }
+          if (valid) {
+            const int to = (dt * P2_PH + dh) * P2_PW + dw;
+#pragma unroll
+            for (int wb = 0; wb < 6; ++wb) {
+              const int p = base_p + 4 * wb + to;
+              const int sw = (p >> 2) & 3;
+#pragma unroll
+              for (int kc = 0; kc < 2; ++kc) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(patch + p * 64 + (((kc * 2 + kg) ^ sw) << 4));
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                  acc[wb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bcur[kc][j], acc[wb][j], 0, 0, 0);
+              }
+            }
+          }
+#pragma unroll
+          for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bcur[kc][j] = bnext[kc][j];
+        }
+      }
+    }
+  }
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -------------------
+  if (!fvalid) return;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = j * 32 + lr;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int wb = 0; wb < 6; ++wb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = (r & 3) + 8 * (r >> 2) + 4 * kg;   // row of the MFMA tile: 8 rows x 4 columns
+        const int hh = h0 + (q >> 2), ww = 4 * wb + (q & 3);
+        float v = acc[wb][j][r] + bv;
+        if (relu) v = fmaxf(v, 0.f);
+        Y[(((int64_t)f * H + hh) * P2_W + ww) * N + n] = f2bf(v);
+      }
   }
 }
 
@@ -954,23 +1101,67 @@ extern "C" int lr_clip_to_ndhwc_bf16(const void* clips, int is_u8, void* out, in
 extern "C" int lr_conv3d_pack_weights(const float* W, void* out, int Cout, int Cin_real, int Cin_pad,
                                       int KT, int KH, int KW, int dgrad, lr_stream_t stream) {
   LR_CHECK_ARG(W && out && Cout > 0 && Cin_real > 0 && Cin_pad >= Cin_real);
-  const int64_t total = dgrad ? (int64_t)Cin_real * KT * KH * KW * Cout
-                              : (int64_t)Cout * KT * KH * KW * Cin_pad;
+  const int flip = dgrad & 1, frag = (dgrad >> 1) & 1;
+  // fragment-major needs whole 32-channel groups on both axes
+  if (frag && ((flip ? Cin_real : Cout) % 32 != 0 || (flip ? Cout : Cin_pad) % 32 != 0)) return LR_ERR_UNSUPPORTED;
+  const int64_t total = flip ? (int64_t)Cin_real * KT * KH * KW * Cout
+                             : (int64_t)Cout * KT * KH * KW * Cin_pad;
   LR_LAUNCH(conv3d_pack_weights_kernel, dim3(grid1d(total)), dim3(256), 0, stream, W, (bf16_t*)out,
-            Cout, Cin_real, Cin_pad, KT, KH, KW, dgrad);
+            Cout, Cin_real, Cin_pad, KT, KH, KW, flip, frag);
   return lr_launch_status();
+}
+
+extern "C" int lr_conv3d_patch_supported(int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW,
+                                         int stride, int pt, int ph, int pw) {
+  const bool shape = KT == 3 && KH == 5 && KW == 5 && stride == 1 && pt == 1 && ph == 2 && pw == 2 &&
+                     Win == P2_W && Hin > 0 && Hin % P2_TH == 0;
+  return shape && ((Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 32)) ? 1 : 0;
 }
 
 extern "C" int lr_conv3d_forward(const void* X, const void* Wp, const float* bias, void* Y, int B,
                                  int T, int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW,
-                                 int stride, int pt, int ph, int pw, int relu, lr_stream_t stream) {
+                                 int stride, int pt, int ph, int pw, int flags, lr_stream_t stream) {
   LR_CHECK_ARG(X && Wp && Y);
+  const int relu = flags & 1;
   ConvGeom g;
   if (!fill_geom(&g, B, T, Hin, Win, Cin, Cout, KT, KH, KW, stride, pt, ph, pw)) return LR_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)((g.M + IG_BM - 1) / IG_BM));
   const bf16_t* x = (const bf16_t*)X;
   const bf16_t* w = (const bf16_t*)Wp;
   bf16_t* y = (bf16_t*)Y;
+  if (flags & 2) {
+    // fragment-major weights: the patch-resident kernel (no other kernel reads that packing)
+    if (!lr_conv3d_patch_supported(Hin, Win, Cin, Cout, KT, KH, KW, stride, pt, ph, pw)) return LR_ERR_UNSUPPORTED;
+    const int F = B * T;
+    const dim3 pgrid((unsigned)(((F + P2_TT - 1) / P2_TT) * (Hin / P2_TH)));
+    hipEvent_t e0, e1;
+    const bool fwd = Cin == 32;
+    const bool sample = lr_prof_next(fwd ? LR_PROF_CONV2_FWD : LR_PROF_CONV2_DGRAD, &e0, &e1);
+    static bool attr_set[2] = {false, false};
+    lr_clear_error();
+    if (fwd) {
+      if (!attr_set[0]) {
+        if (hipFuncSetAttribute((const void*)conv_patch_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                P2_LDS) != hipSuccess) return LR_ERR_LAUNCH;
+        attr_set[0] = true;
+      }
+      if (sample) hipExtLaunchKernelGGL((conv_patch_kernel<1, 2>), pgrid, dim3(256), P2_LDS, (hipStream_t)stream, e0,
+                                        e1, 0, x, w, bias, y, F, T, Hin, relu);
+      else hipLaunchKernelGGL((conv_patch_kernel<1, 2>), pgrid, dim3(256), P2_LDS, (hipStream_t)stream, x, w, bias, y,
+                              F, T, Hin, relu);
+    } else {
+      if (!attr_set[1]) {
+        if (hipFuncSetAttribute((const void*)conv_patch_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                P2_LDS) != hipSuccess) return LR_ERR_LAUNCH;
+        attr_set[1] = true;
+      }
+      if (sample) hipExtLaunchKernelGGL((conv_patch_kernel<2, 1>), pgrid, dim3(256), P2_LDS, (hipStream_t)stream, e0,
+                                        e1, 0, x, w, bias, y, F, T, Hin, relu);
+      else hipLaunchKernelGGL((conv_patch_kernel<2, 1>), pgrid, dim3(256), P2_LDS, (hipStream_t)stream, x, w, bias, y,
+                              F, T, Hin, relu);
+    }
+    return lr_launch_status();
+  }
   if (Cin == 4 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 && ph == 2 && pw == 2) {
     // first layer: patch-resident kernel (one 16x16 output tile of one frame per workgroup)
     hipEvent_t e0, e1;

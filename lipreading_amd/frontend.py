@@ -29,6 +29,10 @@ LAYERS = ((3, 32, (3, 5, 5), 2, (1, 2, 2)),
           (64, 96, (3, 3, 3), 1, (1, 1, 1)))
 
 
+# tests switch this off to compare the patch-resident kernels with the implicit-GEMM kernels
+_PATCH_KERNELS = True
+
+
 def _pad4(c):
   return (c + 3) // 4 * 4
 
@@ -59,12 +63,15 @@ class _ConvFrontendFunction(torch.autograd.Function):
       weight, bias = params[2 * li], params[2 * li + 1]
       cin_p = _pad4(cin)
       wp = torch.empty((cout, kt * kh * kw, cin_p), dtype=bf, device=dev)
-      _C.check(L.lr_conv3d_pack_weights(weight.data_ptr(), wp.data_ptr(), cout, cin, cin_p, kt, kh, kw, 0,
+      # layers with a patch-resident kernel take their weights in its fragment-major order
+      frag = 2 if _PATCH_KERNELS and L.lr_conv3d_patch_supported(h, w, cin_p, cout, kt, kh, kw, stride, pt, ph,
+                                                                 pw) else 0
+      _C.check(L.lr_conv3d_pack_weights(weight.data_ptr(), wp.data_ptr(), cout, cin, cin_p, kt, kh, kw, frag,
                                         st), "lr_conv3d_pack_weights")
       ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
       act = torch.empty((frames, ho, wo, cout), dtype=bf, device=dev)
       _C.check(L.lr_conv3d_forward(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), act.data_ptr(), B, T, h,
-                                   w, cin_p, cout, kt, kh, kw, stride, pt, ph, pw, 1, st),
+                                   w, cin_p, cout, kt, kh, kw, stride, pt, ph, pw, 1 | frag, st),
                "lr_conv3d_forward")
       pooled = torch.empty((frames, ho // 2, wo // 2, cout), dtype=bf, device=dev)
       _C.check(L.lr_maxpool_hw2_bf16(act.data_ptr(), pooled.data_ptr(), frames, ho, wo, cout, st),
@@ -117,11 +124,13 @@ class _ConvFrontendFunction(torch.autograd.Function):
         # data gradient of a stride-1 "same" convolution = the forward kernel on dZ with the
         # flipped, channel-transposed weights
         wd = torch.empty((cin, kt * kh * kw, cout), dtype=bf, device=dev)
+        frag = 2 if _PATCH_KERNELS and L.lr_conv3d_patch_supported(ho, wo, cout, cin, kt, kh, kw, 1, pt, ph,
+                                                                   pw) else 0
         _C.check(L.lr_conv3d_pack_weights(params[2 * li].data_ptr(), wd.data_ptr(), cout, cin, cin_p, kt,
-                                          kh, kw, 1, st), "lr_conv3d_pack_weights")
+                                          kh, kw, 1 | frag, st), "lr_conv3d_pack_weights")
         dP = torch.empty((frames, h, w, cin), dtype=bf, device=dev)
         _C.check(L.lr_conv3d_forward(dZ.data_ptr(), wd.data_ptr(), None, dP.data_ptr(), B, T, ho, wo, cout,
-                                     cin, kt, kh, kw, 1, pt, ph, pw, 0, st), "lr_conv3d_forward(dgrad)")
+                                     cin, kt, kh, kw, 1, pt, ph, pw, frag, st), "lr_conv3d_forward(dgrad)")
     if direct:
       _notify(params)
       return (None,) * (1 + len(params))

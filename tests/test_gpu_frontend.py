@@ -134,3 +134,35 @@ def test_lip_crop_matches_oracle(dev):
   flat = lip_crop(torch.full((1, 3, 64, 64), 77, dtype=torch.uint8, device=dev),
                   torch.tensor(lm[:1], device=dev))
   assert int(flat.min()) == int(flat.max()) == 77
+
+
+def test_patch_resident_layer2_matches_implicit_gemm_and_oracle(dev):
+  """At the metric's 96x96 size layer 2 (24x24, 32->64, taps 3x5x5) runs the patch-resident kernels
+  (forward and data gradient).  They must agree with the implicit-GEMM kernels they replace (same
+  bf16 operands, fp32 accumulation in another order) and with the torch-CPU oracle.  T=7 makes the
+  4-frame tiles ragged and puts a clip boundary inside a tile (taps across it are skipped)."""
+  from lipreading_amd import frontend as FE
+  torch.manual_seed(5)
+  fe = FE.ConvFrontend3D().to(dev)
+  g = torch.Generator().manual_seed(6)
+  B, T, H = 3, 7, 96
+  clips = torch.randint(0, 256, (B, T, 3, H, H), generator=g, dtype=torch.uint8)
+  wgt = torch.randn(B, T, FE.feature_dim(H, H), generator=g)
+  res = {}
+  for patch in (True, False):
+    FE._PATCH_KERNELS = patch
+    try:
+      fe.zero_grad()
+      out = fe(clips.to(dev))
+      (out * wgt.to(dev)).sum().backward()
+      res[patch] = [out.detach().cpu().numpy()] + [p.grad.cpu().numpy().copy() for p in fe.parameters_in_order()]
+    finally:
+      FE._PATCH_KERNELS = True
+  for a, b in zip(res[True], res[False]):
+    assert rel_err(a, b) < 6e-3     # bf16 rounding of intermediate activations differs by <= 1 ulp
+  params_cpu = [p.detach().cpu().clone().requires_grad_(True) for p in fe.parameters_in_order()]
+  ref = O.conv_frontend(clips, params_cpu)
+  (ref * wgt).sum().backward()
+  assert rel_err(res[True][0], ref.detach().numpy()) < 2e-2
+  for a, q in zip(res[True][1:], params_cpu):
+    assert rel_err(a, q.grad.numpy()) < 4e-2, tuple(q.shape)
