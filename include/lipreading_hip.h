@@ -376,8 +376,12 @@ int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* dbias, void
  * a window goes to its FIRST maximum (row-major, torch's rule) if the activation there is > 0.   */
 int lr_maxpool_hw2_bf16(const void* in, void* out, int64_t frames, int H, int W, int C,
                         lr_stream_t stream);
-int lr_unpool_relu_mask_bf16(const void* act, const void* dP, void* dZ, int64_t frames, int H, int W,
-                             int C, lr_stream_t stream);
+/* dbias (may be NULL) receives the layer's bias gradient sum_pos dZ[pos][n] (fp32 [C]; added to
+ * when accumulate != 0), computed in the same pass; it needs lr_unpool_workspace_bytes(C) bytes. */
+size_t lr_unpool_workspace_bytes(int C);
+int lr_unpool_relu_mask_bf16(const void* act, const void* dP, void* dZ, float* dbias, int accumulate,
+                             void* workspace, size_t workspace_bytes, int64_t frames, int H, int W, int C,
+                             lr_stream_t stream);
 int lr_bf16_to_f32(const void* in, float* out, int64_t n, lr_stream_t stream);
 int lr_f32_to_bf16(const float* in, void* out, int64_t n, lr_stream_t stream);
 

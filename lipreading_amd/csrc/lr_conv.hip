@@ -978,30 +978,66 @@ __global__ void maxpool_hw2_kernel(const bf16_t* __restrict__ in, bf16_t* __rest
 
 // Backward of ReLU -> MaxPool((1,2,2)):  dZ[pos] = dP[window] if pos is the FIRST maximum of its
 // window (row-major scan, torch's max_pool backward) and the activation there is > 0, else 0.
-__global__ void unpool_relu_mask_kernel(const bf16_t* __restrict__ act, const bf16_t* __restrict__ dP,
-                                        bf16_t* __restrict__ dZ, int64_t frames, int H, int W, int C) {
-  const int Ho = H / 2, Wo = W / 2;
-  const int64_t total = frames * Ho * Wo * C;
+// One thread = 8 channels (16 bytes) of one pooled element.  The bias gradient of the layer,
+// dbias[n] = sum_pos dZ[pos][n], is the sum of the routed gradients, so it is accumulated here per
+// thread (the launch keeps gridDim * 256 a multiple of C/8, so a thread's channel group is fixed),
+// reduced per workgroup in fixed order and written as one partial row per workgroup.
+constexpr int kUnpoolBlocks = 768;   // 3 per CU; a multiple of 3, so 768 * 256 % (C/8) == 0 for C in {32,64,96}
+__global__ __launch_bounds__(256) void unpool_relu_mask_kernel(const bf16_t* __restrict__ act,
+                                                               const bf16_t* __restrict__ dP,
+                                                               bf16_t* __restrict__ dZ, int64_t frames, int H, int W,
+                                                               int C, float* __restrict__ partial) {
+  __shared__ float red[256][9];
+  const int Ho = H / 2, Wo = W / 2, G = C / 8;
+  const int64_t total = frames * Ho * Wo * G;
+  float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    int64_t q = i / C;
+    const int cg = (int)(i % G);
+    int64_t q = i / G;
     const int wo = (int)(q % Wo);
     q /= Wo;
     const int ho = (int)(q % Ho);
     const int64_t f = q / Ho;
-    const int64_t base = (((f * H + 2 * ho) * W) + 2 * wo) * C + c;
+    const int64_t base = (((f * H + 2 * ho) * W) + 2 * wo) * C + cg * 8;
     const int64_t offs[4] = {0, C, (int64_t)W * C, (int64_t)W * C + C};
-    float best = -__builtin_inff();
-    int arg = 0;
+    uint4 a[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float v = bf2f(act[base + offs[j]]);
-      if (v > best) { best = v; arg = j; }
+    for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const uint4*>(act + base + offs[j]);
+    const uint4 gp = *reinterpret_cast<const uint4*>(dP + (q * Wo + wo) * C + cg * 8);
+    const unsigned gw[4] = {gp.x, gp.y, gp.z, gp.w};
+    unsigned o[4][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int wd = e >> 1, sh = (e & 1) * 16;
+      float best = -__builtin_inff();
+      int arg = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned wv = wd == 0 ? a[j].x : (wd == 1 ? a[j].y : (wd == 2 ? a[j].z : a[j].w));
+        const float v = bf2f((bf16_t)((wv >> sh) & 0xffffu));
+        if (v > best) { best = v; arg = j; }
+      }
+      const unsigned g = best > 0.f ? ((gw[wd] >> sh) & 0xffffu) : 0u;
+      sum[e] += bf2f((bf16_t)g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j == arg) o[j][wd] |= g << sh;
     }
-    const bf16_t g = best > 0.f ? dP[i] : (bf16_t)0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dZ[base + offs[j]] = j == arg ? g : (bf16_t)0;
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<uint4*>(dZ + base + offs[j]) = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
+  }
+  if (!partial) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = sum[e];
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    const int c = threadIdx.x, gq = c >> 3, e = c & 7;
+    const int b0 = (int)(((int64_t)blockIdx.x * blockDim.x) % G);
+    float s = 0.f;
+    for (int tt = ((gq - b0) % G + G) % G; tt < 256; tt += G) s += red[tt][e];   // threads of channel group gq
+    partial[(int64_t)blockIdx.x * C + c] = s;
   }
 }
 
@@ -1347,11 +1383,22 @@ extern "C" int lr_maxpool_hw2_bf16(const void* in, void* out, int64_t frames, in
   return lr_launch_status();
 }
 
-extern "C" int lr_unpool_relu_mask_bf16(const void* act, const void* dP, void* dZ, int64_t frames, int H,
-                                        int W, int C, lr_stream_t stream) {
+extern "C" size_t lr_unpool_workspace_bytes(int C) {
+  return C > 0 ? (size_t)kUnpoolBlocks * C * sizeof(float) : 0;
+}
+
+extern "C" int lr_unpool_relu_mask_bf16(const void* act, const void* dP, void* dZ, float* dbias, int accumulate,
+                                        void* workspace, size_t workspace_bytes, int64_t frames, int H, int W,
+                                        int C, lr_stream_t stream) {
   LR_CHECK_ARG(act && dP && dZ && frames > 0 && H > 1 && W > 1 && C > 0 && H % 2 == 0 && W % 2 == 0);
-  LR_LAUNCH(unpool_relu_mask_kernel, dim3(grid1d(frames * (H / 2) * (W / 2) * C)), dim3(256), 0, stream,
-            (const bf16_t*)act, (const bf16_t*)dP, (bf16_t*)dZ, frames, H, W, C);
+  if (C % 8 != 0 || C > 256 || (kUnpoolBlocks * 256) % (C / 8) != 0) return LR_ERR_UNSUPPORTED;
+  if (dbias && (!workspace || workspace_bytes < lr_unpool_workspace_bytes(C))) return LR_ERR_WORKSPACE;
+  LR_LAUNCH(unpool_relu_mask_kernel, dim3(kUnpoolBlocks), dim3(256), 0, stream, (const bf16_t*)act,
+            (const bf16_t*)dP, (bf16_t*)dZ, frames, H, W, C, dbias ? (float*)workspace : (float*)nullptr);
+  int st = lr_launch_status();
+  if (st != LR_OK || !dbias) return st;
+  LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, kUnpoolBlocks, dbias, C,
+            accumulate);
   return lr_launch_status();
 }
 

@@ -112,12 +112,14 @@ class _ConvFrontendFunction(torch.autograd.Function):
       h, w = sizes[li]
       ho, wo = act.shape[1], act.shape[2]
       dZ = torch.empty(act.shape, dtype=bf, device=dev)
-      _C.check(L.lr_unpool_relu_mask_bf16(act.data_ptr(), dP.data_ptr(), dZ.data_ptr(), frames, ho, wo,
-                                          cout, st), "lr_unpool_relu_mask_bf16")
-      wbytes = L.lr_conv3d_wgrad_workspace_bytes(cout, cin_p, kt, kh, kw)
+      wbytes = max(L.lr_conv3d_wgrad_workspace_bytes(cout, cin_p, kt, kh, kw), L.lr_unpool_workspace_bytes(cout))
       ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+      # the bias gradient (sum of the routed gradients) falls out of the un-pooling pass
+      _C.check(L.lr_unpool_relu_mask_bf16(act.data_ptr(), dP.data_ptr(), dZ.data_ptr(),
+                                          grads[2 * li + 1].data_ptr(), 1 if direct else 0, ws.data_ptr(), wbytes,
+                                          frames, ho, wo, cout, st), "lr_unpool_relu_mask_bf16")
       _C.check(L.lr_conv3d_wgrad(x_in.data_ptr(), dZ.data_ptr(), grads[2 * li].data_ptr(),
-                                 grads[2 * li + 1].data_ptr(), ws.data_ptr(), wbytes, 1 if direct else 0,
+                                 None, ws.data_ptr(), wbytes, 1 if direct else 0,
                                  B, T, h, w, cin_p, cin, cout, kt, kh, kw, stride, pt, ph, pw, st),
                "lr_conv3d_wgrad")
       if li > 0:
