@@ -725,6 +725,170 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_ts_kernel(ConvGeom g, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// weight gradient with LDS transpose reads (stride-1 layers):  dW[n][kt][kh][kw][c] =
+//     sum_pos dZ[pos][n] * X[pos + tap][c]
+// ---------------------------------------------------------------------------------------------
+// The contraction runs over POSITIONS, the slow axis of both channels-last operands, while an MFMA
+// operand wants 8 consecutive k per lane.  gfx950's ds_read_b64_tr_b16 does that transpose on the
+// way out of LDS: 16 lanes read a [4 positions][16 channels] block (8 bytes each: lane s -> position
+// s>>2, channels 4(s&3)..) and lane L receives channel L of the 4 positions.  Two such reads give
+// the 8 k values of a lane, for A (dZ: rows = output channels) and B (X at a tap offset: columns =
+// input channels) alike, so both stay in their natural channels-last order in LDS, as planes of
+// [position][32 channels] (64 B per position: the 4 positions x 64 B of a read are 256 contiguous
+// bytes — every bank once — whatever the tap shift).
+//   Workgroup = (temporal tap kt, slot): it keeps dW[:, kt, :, :, :] (MT x KH*KW*CIN/32 MFMA tiles,
+//   split over 4 waves by tap) in registers while it walks its share of (2-frame x TH-row) tiles;
+//   the X patch is loaded already shifted by kt - 1 frames (zero across clip boundaries).  The next
+//   tile's 16-byte units are issued into registers before the current tile's MFMAs and stored to the
+//   other LDS buffer after them.  The three kt siblings of a slot sit on one XCD (block b runs on
+//   XCD b % 8) and walk the same tiles, so dZ comes out of HBM once.  Slabs and the fixed-order
+//   reduction are those of the tap-stationary kernel above.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_tr_pair(const unsigned char* lds, int a0, int a1) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a1));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+constexpr int kTrSlots = 80;   // slots per temporal tap: 3 x 80 = 240 workgroups = 30 per XCD
+
+template <int CIN, int MT, int KH, int KW, int W, int TT, int TH>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(const bf16_t* __restrict__ X,
+                                                               const bf16_t* __restrict__ dZ,
+                                                               float* __restrict__ slabs, int F, int T, int H) {
+  constexpr int CH = CIN / 32, PH = TH + KH - 1, PW = W + KW - 1;
+  constexpr int XPOS = TT * PH * PW, ZPOS = TT * TH * W;
+  constexpr int XBYTES = CH * XPOS * 64, ZBYTES = MT * ZPOS * 64, BUF = XBYTES + ZBYTES;
+  constexpr int XUNITS = XBYTES / 16, UNITS = BUF / 16, UPT = (UNITS + 255) / 256;
+  constexpr int W4 = W / 4, GPS = TH * W4;   // position groups (4 columns) per row band of one frame
+  constexpr int STEPS = TT * GPS / 4;        // k16 steps per tile
+  constexpr int NU = KH * KW * CH, UPW = (NU + 3) / 4, COUT = MT * 32;
+  static_assert(W % 4 == 0 && (TT * GPS) % 4 == 0, "tile must be a whole number of k16 steps");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // block b -> XCD b % 8; the kt siblings of a slot are blocks 8(3i + kt) + x
+  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+  const int kt = kq % 3, slot = (kq / 3) * 8 + xcd;
+  const int htiles = H / TH;
+  const int ntile = ((F + TT - 1) / TT) * htiles;
+
+  f32x16 acc[UPW][MT];
+#pragma unroll
+  for (int j = 0; j < UPW; ++j)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+  // this wave's n-units (tap, 32-channel plane): LDS offset of the tap shift
+  int uoff[UPW];
+#pragma unroll
+  for (int j = 0; j < UPW; ++j) {
+    const int u = wave + 4 * j, tap = u / CH, plane = u - tap * CH;
+    uoff[j] = plane * XPOS * 64 + ((tap / KW) * PW + tap % KW) * 64;
+  }
+  const int sl = lane & 15, kg = lane >> 5;
+  const int laneoff = ((lane >> 4) & 1) * 32 + (sl & 3) * 8 + (sl >> 2) * 64;
+
+  uint4 pre[UPT];
+  auto issue = [&](int tile) {   // global -> registers: every 16-byte unit of a tile
+    const int f0 = (tile / htiles) * TT, h0 = (tile % htiles) * TH;
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+      const int u = tid + 256 * i;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (u < XUNITS) {
+        const int plane = u / (XPOS * 4), rem = u - plane * (XPOS * 4);
+        const int pos = rem >> 2, c8 = rem & 3;
+        const int sf = pos / (PH * PW), r2 = pos - sf * (PH * PW);
+        const int ph = r2 / PW, pw = r2 - ph * PW;
+        const int f = f0 + sf, tt = f % T + kt - 1;
+        const int h = h0 - (KH - 1) / 2 + ph, w = pw - (KW - 1) / 2;
+        if (f < F && tt >= 0 && tt < T && h >= 0 && h < H && w >= 0 && w < W)
+          v = *reinterpret_cast<const uint4*>(X + (((int64_t)(f + kt - 1) * H + h) * W + w) * CIN + plane * 32 + c8 * 8);
+      } else if (u < UNITS) {
+        const int uz = u - XUNITS;
+        const int mt = uz / (ZPOS * 4), rem = uz - mt * (ZPOS * 4);
+        const int pos = rem >> 2, c8 = rem & 3;
+        const int sf = pos / (TH * W), r2 = pos - sf * (TH * W);
+        const int h = r2 / W, w = r2 - h * W;
+        const int f = f0 + sf;
+        if (f < F)
+          v = *reinterpret_cast<const uint4*>(dZ + (((int64_t)f * H + h0 + h) * W + w) * COUT + mt * 32 + c8 * 8);
+      }
+      pre[i] = v;
+    }
+  };
+  auto deposit = [&](int buf) {   // registers -> LDS buffer (planes of [position][32 channels])
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+      const int u = tid + 256 * i;
+      if (u < UNITS) *reinterpret_cast<uint4*>(lds + buf * BUF + u * 16) = pre[i];
+    }
+  };
+
+  int tile = slot;
+  if (tile < ntile) {
+    issue(tile);
+    deposit(0);
+  }
+  __syncthreads();
+  for (int it = 0; tile < ntile; tile += kTrSlots, ++it) {
+    const int cur = it & 1;
+    const bool has_next = tile + kTrSlots < ntile;
+    if (has_next) issue(tile + kTrSlots);
+    const unsigned char* base = lds + cur * BUF;
+#pragma unroll 1
+    for (int st = 0; st < STEPS; ++st) {
+      // the lane's two position groups of this k16 step: g = 4 st + 2 kg + {0, 1}
+      int za[2], xa[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int g = 4 * st + 2 * kg + hh;
+        const int sf = g / GPS, r = g - sf * GPS;
+        const int h = r / W4, w0 = 4 * (r - h * W4);
+        za[hh] = XBYTES + ((sf * TH + h) * W + w0) * 64 + laneoff;
+        xa[hh] = ((sf * PH + h) * PW + w0) * 64 + laneoff;
+      }
+      bf16x8 a[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = lds_tr_pair(base, za[0] + i * ZPOS * 64, za[1] + i * ZPOS * 64);
+#pragma unroll
+      for (int j = 0; j < UPW; ++j) {
+        if (wave + 4 * j < NU) {   // wave-uniform
+          const bf16x8 b = lds_tr_pair(base, xa[0] + uoff[j], xa[1] + uoff[j]);
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b, acc[j][i], 0, 0, 0);
+        }
+      }
+    }
+    if (has_next) deposit(cur ^ 1);
+    __syncthreads();   // buffer `cur` is free again; the next tile is in place
+  }
+  // partial result of this workgroup: slabs[slot*3 + kt][tap][n][c]
+  const int lr = lane & 31, lk = lane >> 5;
+  float* out = slabs + (int64_t)(slot * 3 + kt) * (KH * KW) * COUT * CIN;
+#pragma unroll
+  for (int j = 0; j < UPW; ++j) {
+    const int u = wave + 4 * j;
+    if (u < NU) {
+      const int tap = u / CH, plane = u - tap * CH;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          out[((int64_t)tap * COUT + n) * CIN + plane * 32 + lr] = acc[j][i][r];
+        }
+    }
+  }
+}
+
 // dW[n][c][kt][kh][kw] (+)= sum_slot slabs[slot*KT + kt][kh*KW + kw][n][c]
 __global__ void conv3d_wgrad_ts_reduce_kernel(const float* __restrict__ slabs, int wgs_per_kt,
                                               float* __restrict__ dW, int Cout, int Cin, int KT, int khw,
@@ -1288,6 +1452,50 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
     LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(256), 0, stream, (const float*)cpart, kColsumSplits, dbias,
               Cout, accumulate);
     return lr_launch_status();
+  }
+  // stride-1 layers of the frontend: LDS-transpose-read kernel (dZ and X stay channels-last in LDS)
+  {
+    const bool l2 = Cin_pad == 32 && Cout == 64 && KH == 5 && KW == 5 && Win == 24 && Hin % 4 == 0;
+    const bool l3 = Cin_pad == 64 && Cout == 96 && KH == 3 && KW == 3 && Win == 12 && Hin % 6 == 0;
+    if (stride == 1 && KT == 3 && pt == 1 && 2 * ph + 1 == KH && 2 * pw + 1 == KW && Cin_real == Cin_pad &&
+        (l2 || l3)) {
+      hipEvent_t e0, e1;
+      const bool sample = lr_prof_next(l2 ? LR_PROF_CONV2_WGRAD : LR_PROF_CONV3_WGRAD, &e0, &e1);
+      const bf16_t* x = (const bf16_t*)X;
+      const bf16_t* dz = (const bf16_t*)dZ;
+      float* slabs = (float*)workspace;
+      const int F = B * T;
+      static bool attr_set[2] = {false, false};
+      lr_clear_error();
+#define LR_WGTR(IDX, LDSB, ...)                                                                              \
+  do {                                                                                                      \
+    if (!attr_set[IDX]) {                                                                                   \
+      if (hipFuncSetAttribute((const void*)conv_wgrad_tr_kernel<__VA_ARGS__>,                                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)              \
+        return LR_ERR_LAUNCH;                                                                               \
+      attr_set[IDX] = true;                                                                                 \
+    }                                                                                                       \
+    if (sample) hipExtLaunchKernelGGL((conv_wgrad_tr_kernel<__VA_ARGS__>), dim3(3 * kTrSlots), dim3(256), LDSB, \
+                                      (hipStream_t)stream, e0, e1, 0, x, dz, slabs, F, T, Hin);             \
+    else hipLaunchKernelGGL((conv_wgrad_tr_kernel<__VA_ARGS__>), dim3(3 * kTrSlots), dim3(256), LDSB,        \
+                            (hipStream_t)stream, x, dz, slabs, F, T, Hin);                                  \
+  } while (0)
+      if (l2) LR_WGTR(0, 2 * (2 * 8 * 28 * 64 + 2 * 2 * 4 * 24 * 64), 32, 2, 5, 5, 24, 2, 4);
+      else LR_WGTR(1, 2 * (2 * 2 * 8 * 14 * 64 + 3 * 2 * 6 * 12 * 64), 64, 3, 3, 3, 12, 2, 6);
+#undef LR_WGTR
+      int st = lr_launch_status();
+      if (st != LR_OK) return st;
+      LR_LAUNCH(conv3d_wgrad_ts_reduce_kernel, dim3(grid1d((int64_t)Cout * Cin_pad * KT * KH * KW)), dim3(256), 0,
+                stream, (const float*)slabs, kTrSlots, dW, Cout, Cin_pad, KT, KH * KW, accumulate);
+      st = lr_launch_status();
+      if (st != LR_OK || !dbias) return st;
+      float* cpart2 = slabs + (size_t)3 * kTrSlots * KH * KW * Cout * Cin_pad;
+      LR_LAUNCH(colsum_bf16_partial_kernel, dim3(kColsumSplits), dim3(256), 0, stream, dz, g.M, Cout, cpart2,
+                kColsumSplits);
+      LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(256), 0, stream, (const float*)cpart2, kColsumSplits, dbias,
+                Cout, accumulate);
+      return lr_launch_status();
+    }
   }
   const bool ts_path = stride == 1 && (Cin_pad == 32 || Cin_pad == 64) && Cin_real == Cin_pad &&
                        2 * ph + 1 == KH && 2 * pw + 1 == KW && KH * KW * (Cin_pad / 32) <= 28;
