@@ -794,32 +794,52 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(const bf16_t* __r
   const int sl = lane & 15, kg = lane >> 5;
   const int laneoff = ((lane >> 4) & 1) * 32 + (sl & 3) * 8 + (sl >> 2) * 64;
 
+  // A thread moves the same 16-byte units of every tile: decode them once.  urel = element offset
+  // from the tile origin (frame f0, row h0), umeta = frame slot | X-or-dZ | statically valid | row offset.
+  int urel[UPT], umeta[UPT];
+#pragma unroll
+  for (int i = 0; i < UPT; ++i) {
+    const int u = tid + 256 * i;
+    urel[i] = 0;
+    umeta[i] = 0;
+    if (u < XUNITS) {
+      const int plane = u / (XPOS * 4), rem = u - plane * (XPOS * 4);
+      const int pos = rem >> 2, c8 = rem & 3;
+      const int sf = pos / (PH * PW), r2 = pos - sf * (PH * PW);
+      const int ph = r2 / PW, pw = r2 - ph * PW;
+      const int dh = ph - (KH - 1) / 2, w = pw - (KW - 1) / 2;
+      urel[i] = (((sf + kt - 1) * H + dh) * W + w) * CIN + plane * 32 + c8 * 8;
+      umeta[i] = sf | 4 | ((w >= 0 && w < W) ? 8 : 0) | ((dh + 16) << 8);
+    } else if (u < UNITS) {
+      const int uz = u - XUNITS;
+      const int mt = uz / (ZPOS * 4), rem = uz - mt * (ZPOS * 4);
+      const int pos = rem >> 2, c8 = rem & 3;
+      const int sf = pos / (TH * W), r2 = pos - sf * (TH * W);
+      const int h = r2 / W, w = r2 - h * W;
+      urel[i] = ((sf * H + h) * W + w) * COUT + mt * 32 + c8 * 8;
+      umeta[i] = sf | 8 | ((h + 16) << 8);
+    }
+  }
   uint4 pre[UPT];
   auto issue = [&](int tile) {   // global -> registers: every 16-byte unit of a tile
     const int f0 = (tile / htiles) * TT, h0 = (tile % htiles) * TH;
+    unsigned okx = 0, okz = 0;   // per frame slot: X frame (shifted by kt - 1, same clip) / dZ frame exists
+#pragma unroll
+    for (int sf = 0; sf < TT; ++sf) {
+      const int f = f0 + sf, tt = f % T + kt - 1;
+      if (f < F) okz |= 1u << sf;
+      if (f < F && tt >= 0 && tt < T) okx |= 1u << sf;
+    }
+    const bf16_t* xb = X + ((int64_t)f0 * H + h0) * W * CIN;
+    const bf16_t* zb = dZ + ((int64_t)f0 * H + h0) * W * COUT;
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
-      const int u = tid + 256 * i;
+      const int m = umeta[i], sf = m & 3;
+      const bool isx = (m & 4) != 0;
+      const unsigned hh = (unsigned)(h0 + ((m >> 8) & 0xff) - 16);
+      const bool ok = (m & 8) && (((isx ? okx : okz) >> sf) & 1u) && (!isx || hh < (unsigned)H);
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (u < XUNITS) {
-        const int plane = u / (XPOS * 4), rem = u - plane * (XPOS * 4);
-        const int pos = rem >> 2, c8 = rem & 3;
-        const int sf = pos / (PH * PW), r2 = pos - sf * (PH * PW);
-        const int ph = r2 / PW, pw = r2 - ph * PW;
-        const int f = f0 + sf, tt = f % T + kt - 1;
-        const int h = h0 - (KH - 1) / 2 + ph, w = pw - (KW - 1) / 2;
-        if (f < F && tt >= 0 && tt < T && h >= 0 && h < H && w >= 0 && w < W)
-          v = *reinterpret_cast<const uint4*>(X + (((int64_t)(f + kt - 1) * H + h) * W + w) * CIN + plane * 32 + c8 * 8);
-      } else if (u < UNITS) {
-        const int uz = u - XUNITS;
-        const int mt = uz / (ZPOS * 4), rem = uz - mt * (ZPOS * 4);
-        const int pos = rem >> 2, c8 = rem & 3;
-        const int sf = pos / (TH * W), r2 = pos - sf * (TH * W);
-        const int h = r2 / W, w = r2 - h * W;
-        const int f = f0 + sf;
-        if (f < F)
-          v = *reinterpret_cast<const uint4*>(dZ + (((int64_t)f * H + h0 + h) * W + w) * COUT + mt * 32 + c8 * 8);
-      }
+      if (ok) v = *reinterpret_cast<const uint4*>((isx ? xb : zb) + urel[i]);
       pre[i] = v;
     }
   };
@@ -842,8 +862,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(const bf16_t* __r
     const bool has_next = tile + kTrSlots < ntile;
     if (has_next) issue(tile + kTrSlots);
     const unsigned char* base = lds + cur * BUF;
-#pragma unroll 1
-    for (int st = 0; st < STEPS; ++st) {
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {   // unrolled: addresses fold to constants, reads of step st+1 overlap MFMAs of st
       // the lane's two position groups of this k16 step: g = 4 st + 2 kg + {0, 1}
       int za[2], xa[2];
 #pragma unroll
