@@ -358,6 +358,16 @@ int lr_conv3d_pack_weights(const float* W, void* out, int Cout, int Cin_real, in
 int lr_conv3d_forward(const void* X, const void* Wp, const float* bias, void* Y, int B, int T, int Hin,
                       int Win, int Cin, int Cout, int KT, int KH, int KW, int stride, int pt, int ph,
                       int pw, int flags, lr_stream_t stream);
+/* Forward with the ReLU -> MaxPool3d((1,2,2)) that follows it fused into the epilogue, for layers
+ * with lr_conv3d_pool_fusion_supported() == 1: P bf16 [B][T][Ho/2][Wo/2][Cout] receives the pooled
+ * activation and code (uint8, same shape) the position 0..3 (row-major in the 2x2 window) of each
+ * window's first maximum; the full-resolution activation is never written.  Backward of the pair:
+ * lr_unpool_code_bf16. */
+int lr_conv3d_pool_fusion_supported(int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW, int stride,
+                                    int pt, int ph, int pw);
+int lr_conv3d_forward_pooled(const void* X, const void* Wp, const float* bias, void* P, void* code, int B,
+                             int T, int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW, int stride,
+                             int pt, int ph, int pw, int flags, lr_stream_t stream);
 /* 1 when the layer (as lr_conv3d_forward sees it: Cin = contraction channels, Cout = output
  * channels) has a patch-resident kernel: the input patch of an output tile is loaded into LDS
  * once and all taps run out of LDS, instead of re-gathering it per tap. */
@@ -382,6 +392,11 @@ size_t lr_unpool_workspace_bytes(int C);
 int lr_unpool_relu_mask_bf16(const void* act, const void* dP, void* dZ, float* dbias, int accumulate,
                              void* workspace, size_t workspace_bytes, int64_t frames, int H, int W, int C,
                              lr_stream_t stream);
+/* the same from the pooled activation and the window codes of lr_conv3d_forward_pooled (H, W: the
+ * UN-pooled extent of dZ) */
+int lr_unpool_code_bf16(const void* pooled, const void* code, const void* dP, void* dZ, float* dbias,
+                        int accumulate, void* workspace, size_t workspace_bytes, int64_t frames, int H, int W,
+                        int C, lr_stream_t stream);
 int lr_bf16_to_f32(const void* in, float* out, int64_t n, lr_stream_t stream);
 int lr_f32_to_bf16(const float* in, void* out, int64_t n, lr_stream_t stream);
 

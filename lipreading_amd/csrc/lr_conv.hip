@@ -406,10 +406,15 @@ __device__ __forceinline__ void c1_patch_store(bf16_t* Ps, const uint2 (&rp)[C1_
 }
 
 // Persistent workgroups: the 32 x 300 weights are staged once, then tiles are streamed.
+// POOL: the epilogue applies ReLU -> MaxPool((1,2,2)) in registers (a lane holds all four pixels of
+// its windows) and writes the pooled activation + the 2-bit position of the window's first maximum
+// (row-major scan, torch's rule) instead of the full-resolution activation.
+template <bool POOL>
 __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __restrict__ X,
                                                               const bf16_t* __restrict__ Wp,  // [32][300]
                                                               const float* __restrict__ bias,
-                                                              bf16_t* __restrict__ Y, int frames, int T,
+                                                              bf16_t* __restrict__ Y, unsigned char* __restrict__ code,
+                                                              int frames, int T,
                                                               int Hin, int Win, int Ho, int Wo, int relu) {
   __shared__ __attribute__((aligned(16))) bf16_t Ps[C1_PATCH + 8];
   __shared__ __attribute__((aligned(16))) bf16_t Ws[32 * C1_WLD];
@@ -471,17 +476,44 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b, acc[i], 0, 0, 0);
       }
     }
+    if (POOL) {
+      // row tile = 2 output rows x 16 columns: registers r and r + 8 are vertical neighbours,
+      // r and r + 1 (r even) horizontal ones
+      const int Hp = Ho >> 1, Wp2 = Wo >> 1;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int prow = (r & 3) + 8 * (r >> 2) + 4 * lk;         // pixel index inside the row tile
-        const int y = y0 + 2 * (2 * wave + i) + (prow >> 4), x = x0 + (prow & 15);
-        if (y >= Ho || x >= Wo) continue;
-        float v = acc[i][r] + bv;
-        if (relu) v = fmaxf(v, 0.f);
-        Y[(((int64_t)f * Ho + y) * Wo + x) * 32 + lr] = f2bf(v);
-      }
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int pp = 0; pp < 2; ++pp) {
+            const int r0 = 4 * a + 2 * pp;
+            const int yp = (y0 >> 1) + 2 * wave + i, xp = (x0 >> 1) + pp + 4 * a + 2 * lk;
+            if (yp >= Hp || xp >= Wp2) continue;
+            float best = -__builtin_inff();
+            int arg = 0;
+            const int rr[4] = {r0, r0 + 1, r0 + 8, r0 + 9};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float v = bf2f(f2bf(fmaxf(acc[i][rr[j]] + bv, 0.f)));   // compare what would have been stored
+              if (v > best) { best = v; arg = j; }
+            }
+            const int64_t o = (((int64_t)f * Hp + yp) * Wp2 + xp) * 32 + lr;
+            Y[o] = f2bf(best);
+            code[o] = (unsigned char)arg;
+          }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int prow = (r & 3) + 8 * (r >> 2) + 4 * lk;         // pixel index inside the row tile
+          const int y = y0 + 2 * (2 * wave + i) + (prow >> 4), x = x0 + (prow & 15);
+          if (y >= Ho || x >= Wo) continue;
+          float v = acc[i][r] + bv;
+          if (relu) v = fmaxf(v, 0.f);
+          Y[(((int64_t)f * Ho + y) * Wo + x) * 32 + lr] = f2bf(v);
+        }
+    }
   }
 }
 
@@ -1001,12 +1033,12 @@ constexpr int P2_LDS = P2_POS * 64;                // 129,024 bytes
 constexpr int P2_UNITS = P2_POS * 4;               // 16-byte units
 constexpr int P2_UPT = (P2_UNITS + 255) / 256;     // units per thread: 32 (31.5)
 
-template <int CG, int NT>
+template <int CG, int NT, bool POOL>
 __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __restrict__ X,
                                                             const bf16_t* __restrict__ Wf,
                                                             const float* __restrict__ bias,
-                                                            bf16_t* __restrict__ Y, int F, int T, int H,
-                                                            int relu) {
+                                                            bf16_t* __restrict__ Y, unsigned char* __restrict__ code,
+                                                            int F, int T, int H, int relu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char patch[];
   constexpr int C = 32 * CG, N = 32 * NT, TAPS = 75;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1099,6 +1131,38 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
     }
   }
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -------------------
+  if (POOL) {
+    // ReLU -> MaxPool((1,2,2)) in registers: tile row q = (r&3) + 8(r>>2) + 4kg is pixel
+    // (h = q>>2, w = q&3), so a window's two rows are the same register of lanes l and l^32 and its
+    // two columns registers r, r+1 (r even).  Output: pooled value + position of the first maximum.
+    const int Hp = H >> 1;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = j * 32 + lr;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int wb = 0; wb < 6; ++wb)
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+          for (int pp = 0; pp < 2; ++pp) {
+            const int r0 = 4 * i4 + 2 * pp;
+            const float v0 = bf2f(f2bf(fmaxf(acc[wb][j][r0] + bv, 0.f)));
+            const float v1 = bf2f(f2bf(fmaxf(acc[wb][j][r0 + 1] + bv, 0.f)));
+            const float mine = v1 > v0 ? v1 : v0;
+            const int marg = v1 > v0 ? 1 : 0;
+            const float other = __shfl_xor(mine, 32, 64);    // the other row of the window
+            const int oarg = __shfl_xor(marg, 32, 64);
+            if (kg == 0 && fvalid) {                          // kg = 0 holds the even row: scan order first
+              const bool low = other > mine;
+              const int64_t o = ((((int64_t)f * Hp + (h0 >> 1) + i4) * (P2_W / 2)) + 2 * wb + pp) * N + n;
+              Y[o] = f2bf(low ? other : mine);
+              code[o] = (unsigned char)(low ? 2 + oarg : marg);
+            }
+          }
+    }
+    return;
+  }
   if (!fvalid) return;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -1225,6 +1289,61 @@ __global__ __launch_bounds__(256) void unpool_relu_mask_kernel(const bf16_t* __r
   }
 }
 
+// The same backward for layers whose forward fused the pooling (lr_conv3d_forward_pooled): the
+// window's gradient goes to position code (0..3, row-major) if the pooled activation is > 0.
+__global__ __launch_bounds__(256) void unpool_code_kernel(const bf16_t* __restrict__ pooled,
+                                                          const unsigned char* __restrict__ code,
+                                                          const bf16_t* __restrict__ dP, bf16_t* __restrict__ dZ,
+                                                          int64_t frames, int H, int W, int C,
+                                                          float* __restrict__ partial) {
+  __shared__ float red[256][9];
+  const int Ho = H / 2, Wo = W / 2, G = C / 8;
+  const int64_t total = frames * Ho * Wo * G;
+  float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % G);
+    int64_t q = i / G;
+    const int wo = (int)(q % Wo);
+    q /= Wo;
+    const int ho = (int)(q % Ho);
+    const int64_t f = q / Ho;
+    const int64_t base = (((f * H + 2 * ho) * W) + 2 * wo) * C + cg * 8;
+    const int64_t offs[4] = {0, C, (int64_t)W * C, (int64_t)W * C + C};
+    const int64_t pi = (q * Wo + wo) * C + cg * 8;
+    const uint4 pv = *reinterpret_cast<const uint4*>(pooled + pi);
+    const uint4 gp = *reinterpret_cast<const uint4*>(dP + pi);
+    const uint2 cv = *reinterpret_cast<const uint2*>(code + pi);
+    const unsigned pw_[4] = {pv.x, pv.y, pv.z, pv.w}, gw[4] = {gp.x, gp.y, gp.z, gp.w};
+    unsigned o[4][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int wd = e >> 1, sh = (e & 1) * 16;
+      const float act = bf2f((bf16_t)((pw_[wd] >> sh) & 0xffffu));
+      const int arg = (int)(((e < 4 ? cv.x : cv.y) >> (8 * (e & 3))) & 3u);
+      const unsigned g = act > 0.f ? ((gw[wd] >> sh) & 0xffffu) : 0u;
+      sum[e] += bf2f((bf16_t)g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j == arg) o[j][wd] |= g << sh;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<uint4*>(dZ + base + offs[j]) = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
+  }
+  if (!partial) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = sum[e];
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    const int c = threadIdx.x, gq = c >> 3, e = c & 7;
+    const int b0 = (int)(((int64_t)blockIdx.x * blockDim.x) % G);
+    float s = 0.f;
+    for (int tt = ((gq - b0) % G + G) % G; tt < 256; tt += G) s += red[tt][e];
+    partial[(int64_t)blockIdx.x * C + c] = s;
+  }
+}
+
 __global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x)
@@ -1269,10 +1388,19 @@ __global__ void colsum_bf16_partial_kernel(const bf16_t* __restrict__ x, int64_t
 }
 __global__ void colsum_final_acc_kernel(const float* __restrict__ partial, int splits, float* __restrict__ out,
                                         int C, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float s = strided_sum8(partial + c, splits, C);
-  out[c] = accumulate ? out[c] + s : s;
+  // blockDim / C row lanes per channel, each a fixed subsequence of the partial rows; the lanes'
+  // sums are combined in lane order (deterministic)
+  __shared__ float red[1024];
+  const int RL = blockDim.x / C, c = threadIdx.x % C, rl = threadIdx.x / C;
+  float s = 0.f;
+  if (rl < RL) s = strided_sum8(partial + (int64_t)rl * C + c, (splits - rl + RL - 1) / RL, (int64_t)RL * C);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float t = 0.f;
+    for (int r = 0; r < RL; ++r) t += red[r * C + c];
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 inline int grid1d(int64_t n) {
@@ -1338,9 +1466,20 @@ extern "C" int lr_conv3d_patch_supported(int Hin, int Win, int Cin, int Cout, in
   return shape && ((Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 32)) ? 1 : 0;
 }
 
-extern "C" int lr_conv3d_forward(const void* X, const void* Wp, const float* bias, void* Y, int B,
-                                 int T, int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW,
-                                 int stride, int pt, int ph, int pw, int flags, lr_stream_t stream) {
+extern "C" int lr_conv3d_pool_fusion_supported(int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW,
+                                               int stride, int pt, int ph, int pw) {
+  const bool first = Cin == 4 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 && ph == 2 &&
+                     pw == 2 && Hin % 4 == 0 && Win % 4 == 0;
+  const bool second = Cin == 32 && Cout == 64 &&
+                      lr_conv3d_patch_supported(Hin, Win, Cin, Cout, KT, KH, KW, stride, pt, ph, pw);
+  return first || second ? 1 : 0;
+}
+
+// code == nullptr: Y = full-resolution activation; else Y = ReLU -> MaxPool((1,2,2)) of it and code =
+// position of each window's first maximum (layers with lr_conv3d_pool_fusion_supported only)
+static int conv_forward_impl(const void* X, const void* Wp, const float* bias, void* Y, unsigned char* code, int B,
+                             int T, int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW, int stride, int pt,
+                             int ph, int pw, int flags, lr_stream_t stream) {
   LR_CHECK_ARG(X && Wp && Y);
   const int relu = flags & 1;
   ConvGeom g;
@@ -1349,6 +1488,8 @@ extern "C" int lr_conv3d_forward(const void* X, const void* Wp, const float* bia
   const bf16_t* x = (const bf16_t*)X;
   const bf16_t* w = (const bf16_t*)Wp;
   bf16_t* y = (bf16_t*)Y;
+  if (code && (!relu || !lr_conv3d_pool_fusion_supported(Hin, Win, Cin, Cout, KT, KH, KW, stride, pt, ph, pw)))
+    return LR_ERR_UNSUPPORTED;
   if (flags & 2) {
     // fragment-major weights: the patch-resident kernel (no other kernel reads that packing)
     if (!lr_conv3d_patch_supported(Hin, Win, Cin, Cout, KT, KH, KW, stride, pt, ph, pw)) return LR_ERR_UNSUPPORTED;
@@ -1357,31 +1498,28 @@ extern "C" int lr_conv3d_forward(const void* X, const void* Wp, const float* bia
     hipEvent_t e0, e1;
     const bool fwd = Cin == 32;
     const bool sample = lr_prof_next(fwd ? LR_PROF_CONV2_FWD : LR_PROF_CONV2_DGRAD, &e0, &e1);
-    static bool attr_set[2] = {false, false};
+    static bool attr_set[3] = {false, false, false};
     lr_clear_error();
-    if (fwd) {
-      if (!attr_set[0]) {
-        if (hipFuncSetAttribute((const void*)conv_patch_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                P2_LDS) != hipSuccess) return LR_ERR_LAUNCH;
-        attr_set[0] = true;
-      }
-      if (sample) hipExtLaunchKernelGGL((conv_patch_kernel<1, 2>), pgrid, dim3(256), P2_LDS, (hipStream_t)stream, e0,
-                                        e1, 0, x, w, bias, y, F, T, Hin, relu);
-      else hipLaunchKernelGGL((conv_patch_kernel<1, 2>), pgrid, dim3(256), P2_LDS, (hipStream_t)stream, x, w, bias, y,
-                              F, T, Hin, relu);
-    } else {
-      if (!attr_set[1]) {
-        if (hipFuncSetAttribute((const void*)conv_patch_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                P2_LDS) != hipSuccess) return LR_ERR_LAUNCH;
-        attr_set[1] = true;
-      }
-      if (sample) hipExtLaunchKernelGGL((conv_patch_kernel<2, 1>), pgrid, dim3(256), P2_LDS, (hipStream_t)stream, e0,
-                                        e1, 0, x, w, bias, y, F, T, Hin, relu);
-      else hipLaunchKernelGGL((conv_patch_kernel<2, 1>), pgrid, dim3(256), P2_LDS, (hipStream_t)stream, x, w, bias, y,
-                              F, T, Hin, relu);
-    }
+#define LR_PATCH(IDX, ...)                                                                                     \
+  do {                                                                                                        \
+    if (!attr_set[IDX]) {                                                                                     \
+      if (hipFuncSetAttribute((const void*)conv_patch_kernel<__VA_ARGS__>,                                     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS) != hipSuccess)              \
+        return LR_ERR_LAUNCH;                                                                                 \
+      attr_set[IDX] = true;                                                                                   \
+    }                                                                                                         \
+    if (sample) hipExtLaunchKernelGGL((conv_patch_kernel<__VA_ARGS__>), pgrid, dim3(256), P2_LDS,              \
+                                      (hipStream_t)stream, e0, e1, 0, x, w, bias, y, code, F, T, Hin, relu);  \
+    else hipLaunchKernelGGL((conv_patch_kernel<__VA_ARGS__>), pgrid, dim3(256), P2_LDS, (hipStream_t)stream,   \
+                            x, w, bias, y, code, F, T, Hin, relu);                                            \
+  } while (0)
+    if (fwd && code) LR_PATCH(2, 1, 2, true);
+    else if (fwd) LR_PATCH(0, 1, 2, false);
+    else LR_PATCH(1, 2, 1, false);
+#undef LR_PATCH
     return lr_launch_status();
   }
+  if (code && Cin != 4) return LR_ERR_UNSUPPORTED;   // the second layer's fused pooling lives in the patch kernel
   if (Cin == 4 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 && ph == 2 && pw == 2) {
     // first layer: patch-resident kernel (one 16x16 output tile of one frame per workgroup)
     hipEvent_t e0, e1;
@@ -1389,10 +1527,16 @@ extern "C" int lr_conv3d_forward(const void* X, const void* Wp, const float* bia
     int tiles = B * T * ((g.Ho + C1_T - 1) / C1_T) * ((g.Wo + C1_T - 1) / C1_T);
     if (tiles > 768) tiles = 768;   // persistent: 3 workgroups per CU, each streams its share of tiles
     lr_clear_error();
-    if (sample) hipExtLaunchKernelGGL(conv1_fwd_patch_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, e0,
-                                      e1, 0, x, w, bias, y, B * T, T, Hin, Win, g.Ho, g.Wo, relu);
-    else hipLaunchKernelGGL(conv1_fwd_patch_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x, w, bias, y,
-                            B * T, T, Hin, Win, g.Ho, g.Wo, relu);
+#define LR_C1(POOLV)                                                                                              \
+  do {                                                                                                           \
+    if (sample) hipExtLaunchKernelGGL(conv1_fwd_patch_kernel<POOLV>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, \
+                                      e0, e1, 0, x, w, bias, y, code, B * T, T, Hin, Win, g.Ho, g.Wo, relu);     \
+    else hipLaunchKernelGGL(conv1_fwd_patch_kernel<POOLV>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x, w,  \
+                            bias, y, code, B * T, T, Hin, Win, g.Ho, g.Wo, relu);                                \
+  } while (0)
+    if (code) LR_C1(true);
+    else LR_C1(false);
+#undef LR_C1
     return lr_launch_status();
   }
   // instrumentation slot: forward layers by input channels, data gradients by (Cin, relu == 0)
@@ -1423,6 +1567,21 @@ extern "C" int lr_conv3d_forward(const void* X, const void* Wp, const float* bia
   else return LR_ERR_UNSUPPORTED;
 #undef LR_IGEMM
   return lr_launch_status();
+}
+
+extern "C" int lr_conv3d_forward(const void* X, const void* Wp, const float* bias, void* Y, int B,
+                                 int T, int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW,
+                                 int stride, int pt, int ph, int pw, int flags, lr_stream_t stream) {
+  return conv_forward_impl(X, Wp, bias, Y, nullptr, B, T, Hin, Win, Cin, Cout, KT, KH, KW, stride, pt, ph, pw, flags,
+                           stream);
+}
+
+extern "C" int lr_conv3d_forward_pooled(const void* X, const void* Wp, const float* bias, void* P, void* code,
+                                        int B, int T, int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW,
+                                        int stride, int pt, int ph, int pw, int flags, lr_stream_t stream) {
+  LR_CHECK_ARG(code);
+  return conv_forward_impl(X, Wp, bias, P, (unsigned char*)code, B, T, Hin, Win, Cin, Cout, KT, KH, KW, stride, pt,
+                           ph, pw, flags | 1, stream);
 }
 
 extern "C" size_t lr_conv3d_wgrad_workspace_bytes(int Cout, int Cin_pad, int KT, int KH, int KW) {
@@ -1469,7 +1628,7 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
     if (st != LR_OK || !dbias) return st;
     LR_LAUNCH(colsum_bf16_partial_kernel, dim3(kColsumSplits), dim3(256), 0, stream, dz, g.M, Cout, cpart,
               kColsumSplits);
-    LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(256), 0, stream, (const float*)cpart, kColsumSplits, dbias,
+    LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(1024), 0, stream, (const float*)cpart, kColsumSplits, dbias,
               Cout, accumulate);
     return lr_launch_status();
   }
@@ -1512,7 +1671,7 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
       float* cpart2 = slabs + (size_t)3 * kTrSlots * KH * KW * Cout * Cin_pad;
       LR_LAUNCH(colsum_bf16_partial_kernel, dim3(kColsumSplits), dim3(256), 0, stream, dz, g.M, Cout, cpart2,
                 kColsumSplits);
-      LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(256), 0, stream, (const float*)cpart2, kColsumSplits, dbias,
+      LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(1024), 0, stream, (const float*)cpart2, kColsumSplits, dbias,
                 Cout, accumulate);
       return lr_launch_status();
     }
@@ -1561,7 +1720,7 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
         if (st != LR_OK || !dbias) return st;
         LR_LAUNCH(colsum_bf16_partial_kernel, dim3(kColsumSplits), dim3(256), 0, stream, dz, g.M, Cout, cpart,
                   kColsumSplits);
-        LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(256), 0, stream, (const float*)cpart, kColsumSplits,
+        LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(1024), 0, stream, (const float*)cpart, kColsumSplits,
                   dbias, Cout, accumulate);
         return lr_launch_status();
       }
@@ -1598,7 +1757,7 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
   if (st != LR_OK || !dbias) return st;
   LR_LAUNCH(colsum_bf16_partial_kernel, dim3(kColsumSplits), dim3(256), 0, stream, dz, g.M, Cout, cpart,
             kColsumSplits);
-  LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(256), 0, stream, (const float*)cpart, kColsumSplits,
+  LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(1024), 0, stream, (const float*)cpart, kColsumSplits,
             dbias, Cout, accumulate);
   return lr_launch_status();
 }
@@ -1625,7 +1784,23 @@ extern "C" int lr_unpool_relu_mask_bf16(const void* act, const void* dP, void* d
             (const bf16_t*)dP, (bf16_t*)dZ, frames, H, W, C, dbias ? (float*)workspace : (float*)nullptr);
   int st = lr_launch_status();
   if (st != LR_OK || !dbias) return st;
-  LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, kUnpoolBlocks, dbias, C,
+  LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(1024), 0, stream, (const float*)workspace, kUnpoolBlocks, dbias, C,
+            accumulate);
+  return lr_launch_status();
+}
+
+extern "C" int lr_unpool_code_bf16(const void* pooled, const void* code, const void* dP, void* dZ, float* dbias,
+                                   int accumulate, void* workspace, size_t workspace_bytes, int64_t frames, int H,
+                                   int W, int C, lr_stream_t stream) {
+  LR_CHECK_ARG(pooled && code && dP && dZ && frames > 0 && H > 1 && W > 1 && C > 0 && H % 2 == 0 && W % 2 == 0);
+  if (C % 8 != 0 || C > 256 || (kUnpoolBlocks * 256) % (C / 8) != 0) return LR_ERR_UNSUPPORTED;
+  if (dbias && (!workspace || workspace_bytes < lr_unpool_workspace_bytes(C))) return LR_ERR_WORKSPACE;
+  LR_LAUNCH(unpool_code_kernel, dim3(kUnpoolBlocks), dim3(256), 0, stream, (const bf16_t*)pooled,
+            (const unsigned char*)code, (const bf16_t*)dP, (bf16_t*)dZ, frames, H, W, C,
+            dbias ? (float*)workspace : (float*)nullptr);
+  int st = lr_launch_status();
+  if (st != LR_OK || !dbias) return st;
+  LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(1024), 0, stream, (const float*)workspace, kUnpoolBlocks, dbias, C,
             accumulate);
   return lr_launch_status();
 }

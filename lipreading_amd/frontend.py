@@ -69,14 +69,25 @@ class _ConvFrontendFunction(torch.autograd.Function):
       _C.check(L.lr_conv3d_pack_weights(weight.data_ptr(), wp.data_ptr(), cout, cin, cin_p, kt, kh, kw, frag,
                                         st), "lr_conv3d_pack_weights")
       ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
-      act = torch.empty((frames, ho, wo, cout), dtype=bf, device=dev)
-      _C.check(L.lr_conv3d_forward(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), act.data_ptr(), B, T, h,
-                                   w, cin_p, cout, kt, kh, kw, stride, pt, ph, pw, 1 | frag, st),
-               "lr_conv3d_forward")
       pooled = torch.empty((frames, ho // 2, wo // 2, cout), dtype=bf, device=dev)
-      _C.check(L.lr_maxpool_hw2_bf16(act.data_ptr(), pooled.data_ptr(), frames, ho, wo, cout, st),
-               "lr_maxpool_hw2_bf16")
-      saved += [act, pooled]
+      fuse = _PATCH_KERNELS and (frag or cin_p == 4) and L.lr_conv3d_pool_fusion_supported(
+          h, w, cin_p, cout, kt, kh, kw, stride, pt, ph, pw)
+      if fuse:
+        # ReLU + max-pool in the conv epilogue: the full-resolution activation is never written; the
+        # backward gets the pooled activation and each window's argmax code (uint8) instead
+        code = torch.empty(pooled.shape, dtype=torch.uint8, device=dev)
+        _C.check(L.lr_conv3d_forward_pooled(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), pooled.data_ptr(),
+                                            code.data_ptr(), B, T, h, w, cin_p, cout, kt, kh, kw, stride, pt, ph,
+                                            pw, 1 | frag, st), "lr_conv3d_forward_pooled")
+        saved += [code, pooled]
+      else:
+        act = torch.empty((frames, ho, wo, cout), dtype=bf, device=dev)
+        _C.check(L.lr_conv3d_forward(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), act.data_ptr(), B, T, h,
+                                     w, cin_p, cout, kt, kh, kw, stride, pt, ph, pw, 1 | frag, st),
+                 "lr_conv3d_forward")
+        _C.check(L.lr_maxpool_hw2_bf16(act.data_ptr(), pooled.data_ptr(), frames, ho, wo, cout, st),
+                 "lr_maxpool_hw2_bf16")
+        saved += [act, pooled]
       x, h, w = pooled, ho // 2, wo // 2
     feats = torch.empty((B, T, h * w * 96), dtype=torch.float32, device=dev)
     _C.check(L.lr_bf16_to_f32(x.data_ptr(), feats.data_ptr(), feats.numel(), st), "lr_bf16_to_f32")
@@ -91,7 +102,7 @@ class _ConvFrontendFunction(torch.autograd.Function):
     B, T, H, W = ctx.dims
     frames = B * T
     saved = ctx.saved_tensors
-    acts = saved[:7]            # x0, act1, pool1, act2, pool2, act3, pool3
+    acts = saved[:7]            # x0, act1|code1, pool1, act2|code2, pool2, act3|code3, pool3
     params = saved[7:]
     dev = dfeat.device
     bf = torch.bfloat16
@@ -108,16 +119,21 @@ class _ConvFrontendFunction(torch.autograd.Function):
     for li in (2, 1, 0):
       cin, cout, (kt, kh, kw), stride, (pt, ph, pw) = LAYERS[li]
       cin_p = _pad4(cin)
-      x_in, act = acts[2 * li], acts[2 * li + 1]
+      x_in, act, pooled = acts[2 * li], acts[2 * li + 1], acts[2 * li + 2]
       h, w = sizes[li]
-      ho, wo = act.shape[1], act.shape[2]
-      dZ = torch.empty(act.shape, dtype=bf, device=dev)
+      ho, wo = 2 * pooled.shape[1], 2 * pooled.shape[2]
+      dZ = torch.empty((frames, ho, wo, cout), dtype=bf, device=dev)
       wbytes = max(L.lr_conv3d_wgrad_workspace_bytes(cout, cin_p, kt, kh, kw), L.lr_unpool_workspace_bytes(cout))
       ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
       # the bias gradient (sum of the routed gradients) falls out of the un-pooling pass
-      _C.check(L.lr_unpool_relu_mask_bf16(act.data_ptr(), dP.data_ptr(), dZ.data_ptr(),
-                                          grads[2 * li + 1].data_ptr(), 1 if direct else 0, ws.data_ptr(), wbytes,
-                                          frames, ho, wo, cout, st), "lr_unpool_relu_mask_bf16")
+      if act.dtype == torch.uint8:   # the forward fused the pooling: act holds the window codes
+        _C.check(L.lr_unpool_code_bf16(pooled.data_ptr(), act.data_ptr(), dP.data_ptr(), dZ.data_ptr(),
+                                       grads[2 * li + 1].data_ptr(), 1 if direct else 0, ws.data_ptr(), wbytes,
+                                       frames, ho, wo, cout, st), "lr_unpool_code_bf16")
+      else:
+        _C.check(L.lr_unpool_relu_mask_bf16(act.data_ptr(), dP.data_ptr(), dZ.data_ptr(),
+                                            grads[2 * li + 1].data_ptr(), 1 if direct else 0, ws.data_ptr(), wbytes,
+                                            frames, ho, wo, cout, st), "lr_unpool_relu_mask_bf16")
       _C.check(L.lr_conv3d_wgrad(x_in.data_ptr(), dZ.data_ptr(), grads[2 * li].data_ptr(),
                                  None, ws.data_ptr(), wbytes, 1 if direct else 0,
                                  B, T, h, w, cin_p, cin, cout, kt, kh, kw, stride, pt, ph, pw, st),
