@@ -365,6 +365,19 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(ConvGeom g, const bf1
 // input patch it needs ONCE into LDS: 3 frames x 35 x 35 pixels x 4 channels (29 kB).  Every
 // operand of the forward product and of the weight gradient is then an LDS read at
 // (pixel offset + tap offset): no im2col staging, no barrier inside the K loop.
+// Two ds_read_b64_tr_b16 (gfx950 LDS transpose read) -> one MFMA operand.  16 lanes read a
+// [4 k][16 columns] block, 8 bytes each (lane s: row s>>2, columns 4(s&3)..4(s&3)+3), and lane L gets
+// column L of the 4 rows; a0 / a1 address the lane's 8 bytes of k 0..3 / 4..7.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_tr_pair(const unsigned char* lds, int a0, int a1) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a1));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 constexpr int C1_T = 16;                       // output tile edge
 constexpr int C1_P = 2 * C1_T + 3;             // patch edge (stride 2, 5x5 taps): 35
 constexpr int C1_PIX = C1_T * C1_T;            // 256 output pixels = 8 MFMA row tiles
@@ -523,19 +536,24 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
                                                                 const bf16_t* __restrict__ dZ,
                                                                 float* __restrict__ slabs, int frames,
                                                                 int T, int Hin, int Win, int Ho, int Wo) {
-  constexpr int ZLD = 32 + 8;
+  // Both operands are read with LDS transpose reads: the contraction runs over PIXELS, the slow axis
+  // of the channels-last dZ tile and of the patch.  dZ tile: [pixel][32 channels], 64 B per pixel (4
+  // pixels = 256 contiguous bytes per read).  im2col column (tap, c): a lane's 8 bytes are the 4
+  // channels of one tap at one pixel, so the 16 source lanes of a read cover 4 pixels x 4 taps.
+  constexpr int ZLD = 32;
   __shared__ __attribute__((aligned(16))) bf16_t Ps[C1_PATCH + 8];
   __shared__ __attribute__((aligned(16))) bf16_t Zs[C1_PIX * ZLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lk = lane >> 5;
+  const int sl = lane & 15, colhalf = (lane >> 4) & 1;
   const int tiles_x = (Wo + C1_T - 1) / C1_T, tiles_y = (Ho + C1_T - 1) / C1_T;
   const int64_t ntiles = (int64_t)frames * tiles_x * tiles_y;
-  // this lane's column of each owned column tile: k = (tap, c) -> patch offset (or the zero zone)
-  int coloff[3];
+  // column tile jt = wave + 4j covers taps 8jt..8jt+7; this lane sources tap 8jt + 4 colhalf + (sl & 3)
+  int tapoff[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const int k = (wave + 4 * j) * 32 + lr;
-    coloff[j] = (wave + 4 * j) < 10 && k < 300 ? c1_tap_off(k >> 2) + (k & 3) : -1;
+    const int tap = (wave + 4 * j) * 8 + 4 * colhalf + (sl & 3);
+    tapoff[j] = (wave + 4 * j) < 10 ? c1_tap_off(tap) : -1;   // -1: padded column -> the zero zone
   }
   f32x16 acc[3];
 #pragma unroll
@@ -559,6 +577,8 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
       if (y < Ho && x < Wo) rz[i] = *reinterpret_cast<const uint4*>(dZ + (((int64_t)f * Ho + y) * Wo + x) * 32 + u * 8);
     }
   };
+  const unsigned char* PsB = reinterpret_cast<const unsigned char*>(Ps);
+  const unsigned char* ZsB = reinterpret_cast<const unsigned char*>(Zs);
   int64_t q = blockIdx.x;
   if (q < ntiles) issue(q);
   for (; q < ntiles; q += gridDim.x) {
@@ -571,20 +591,23 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
     }
     __syncthreads();
     if (q + gridDim.x < ntiles) issue(q + gridDim.x);
-#pragma unroll 1
+#pragma unroll 4
     for (int ks = 0; ks < C1_PIX / 16; ++ks) {
-      const int p0 = ks * 16 + lk * 8;                 // 8 consecutive pixels of one tile row
-      const int ppix = ((2 * (p0 >> 4)) * C1_P + 2 * (p0 & 15)) * 4;
-      bf16x8 a;
+      // this lane's source pixel of the two 4-pixel groups: k = lk*8 + {0..3 | 4..7}
+      int za[2], pa[2];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] = __builtin_bit_cast(__bf16, Zs[(p0 + e) * ZLD + lr]);
+      for (int hh = 0; hh < 2; ++hh) {
+        const int pix = ks * 16 + lk * 8 + hh * 4 + (sl >> 2);
+        za[hh] = pix * 64 + colhalf * 32 + (sl & 3) * 8;
+        pa[hh] = ((2 * (pix >> 4)) * C1_P + 2 * (pix & 15)) * 8;
+      }
+      const bf16x8 a = lds_tr_pair(ZsB, za[0], za[1]);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         if (wave + 4 * j < 10) {
-          bf16x8 b;
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            b[e] = __builtin_bit_cast(__bf16, Ps[coloff[j] >= 0 ? ppix + e * 8 + coloff[j] : C1_PATCH]);
+          const int o0 = tapoff[j] >= 0 ? pa[0] + tapoff[j] * 2 : C1_PATCH * 2;
+          const int o1 = tapoff[j] >= 0 ? pa[1] + tapoff[j] * 2 : C1_PATCH * 2;
+          const bf16x8 b = lds_tr_pair(PsB, o0, o1);
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
         }
       }
@@ -776,16 +799,6 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_ts_kernel(ConvGeom g, const 
 //   other LDS buffer after them.  The three kt siblings of a slot sit on one XCD (block b runs on
 //   XCD b % 8) and walk the same tiles, so dZ comes out of HBM once.  Slabs and the fixed-order
 //   reduction are those of the tap-stationary kernel above.
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 lds_tr_pair(const unsigned char* lds, int a0, int a1) {
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a0));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a1));
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);
-}
-
 constexpr int kTrSlots = 80;   // slots per temporal tap: 3 x 80 = 240 workgroups = 30 per XCD
 
 template <int CIN, int MT, int KH, int KW, int W, int TT, int TH>
