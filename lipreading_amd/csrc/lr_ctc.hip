@@ -172,6 +172,131 @@ __global__ void ctc_alpha_beta_kernel(const float* __restrict__ lp, int64_t stri
   }
 }
 
+// log(exp(a)+exp(b)+exp(c)) with the fast exp/log forms (v_exp_f32 / v_log_f32 based, ~1-2 ulp):
+// the recursion is a chain of T dependent evaluations and the libm sequences are several times
+// longer; the parity tests (loss 1e-4, gradient 1e-4 of max) hold with them.
+__device__ __forceinline__ float lse3_fast(float a, float b, float c) {
+  float m = fmaxf(fmaxf(a, b), c);
+  if (m == LR_NEG_INF) m = 0.f;
+  return __logf(__expf(a - m) + __expf(b - m) + __expf(c - m)) + m;
+}
+
+// The same recursions when all 2L+1 states fit ONE wave (L <= 31: every shipped caption config at
+// the bench's label length): wave 0 runs alpha, wave 1 beta, a state per lane, and the previous
+// row's neighbours come from lane shuffles — no LDS exchange row and no barrier per time step
+// (the T-step chain is then ~T x (2 shuffles + one log-sum-exp) instead of T barriers).
+__global__ __launch_bounds__(128) void ctc_alpha_beta_wave_kernel(const float* __restrict__ lp, int64_t stride_b,
+                                                                  int64_t stride_t,
+                                                                  const int32_t* __restrict__ labels,
+                                                                  int label_stride,
+                                                                  const int32_t* __restrict__ frame_lens,
+                                                                  const int32_t* __restrict__ label_lens,
+                                                                  float* __restrict__ nll, CtcWs ws, int T, int C,
+                                                                  int max_label_len) {
+  constexpr int sst = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int* lab_s = reinterpret_cast<int*>(smem_raw);                  // [32]
+  float* lat = reinterpret_cast<float*>(lab_s + 32);              // [T][C]
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = label_lens[b];
+  int Tb = frame_lens[b];
+  if (Tb > T) Tb = T;
+  if (L > max_label_len || L < 0 || L > 31 || Tb <= 0) {
+    if (tid == 0) nll[b] = __builtin_inff();
+    return;
+  }
+  const int S = 2 * L + 1;
+  const int32_t* lab = labels + (int64_t)b * label_stride;
+  const float* lpb = lp + (int64_t)b * stride_b;
+  float* al = ws.alpha + ((int64_t)b * T) * sst;
+  float* be = ws.beta + ((int64_t)b * T) * sst;
+  for (int i = tid; i < L; i += 128) {
+    int c = lab[i];
+    if (c < 0 || c >= C) c = 0;
+    lab_s[i] = c;
+  }
+  for (int c = tid; c < C; c += 128) ws.first[(int64_t)b * C + c] = -1;
+  const int n = Tb * C;
+  // The LDS image is shifted by the sample's misalignment (in floats) so that global and LDS 16-byte
+  // boundaries coincide: the dense lattice then moves as 16-byte loads, all of a thread's loads in
+  // flight at once (a scalar load -> store loop serialises ~38 memory round trips here).
+  const int mis = stride_t == C ? (int)((reinterpret_cast<uintptr_t>(lpb) >> 2) & 3) : 0;
+  float* latp = lat + mis;
+  if (stride_t == C) {
+    const float4* g4 = reinterpret_cast<const float4*>(lpb - mis);   // aligned; quads below qlo are not touched
+    const int total = n + mis, qlo = (mis + 3) >> 2, qhi = total >> 2;
+    for (int e = mis + tid; e < 4 * qlo && e < total; e += 128) lat[e] = lpb[e - mis];   // head
+    for (int q0 = qlo; q0 < qhi; q0 += 128 * 10) {   // (qhi > qlo here, so qhi - 1 is a valid quad)
+      float4 v4[10];
+#pragma unroll
+      for (int u = 0; u < 10; ++u) {   // unconditional (clamped) loads: a load under a branch is waited for
+        const int q = q0 + u * 128 + tid;  // inside its branch, which would serialise the ten round trips
+        v4[u] = g4[q < qhi ? q : qhi - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 10; ++u) {
+        const int q = q0 + u * 128 + tid;
+        if (q < qhi) reinterpret_cast<float4*>(lat)[q] = v4[u];
+      }
+    }
+    for (int e = (qhi > qlo ? 4 * qhi : 4 * qlo) + tid; e < total; e += 128) lat[e] = lpb[e - mis];   // tail
+  } else {
+    for (int i = tid; i < n; i += 128) {
+      const int t = i / C, c = i - t * C;
+      latp[i] = lpb[(int64_t)t * stride_t + c];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < L; i += 128) {   // next / first occurrence chains per class (gradient kernel)
+    const int c = lab_s[i];
+    int nx = -1;
+    for (int j = i + 1; j < L; ++j)
+      if (lab_s[j] == c) { nx = j; break; }
+    ws.nxt[(int64_t)b * max_label_len + i] = nx;
+    bool first = true;
+    for (int j = 0; j < i; ++j)
+      if (lab_s[j] == c) { first = false; break; }
+    if (first) ws.first[(int64_t)b * C + c] = i;
+  }
+  const int s = lane;
+  const bool live = s < S;
+  int cls = 0;
+  bool skip_a = false, skip_b = false;
+  if (live && (s & 1)) {
+    cls = lab_s[s >> 1];
+    if (s >= 3) skip_a = lab_s[(s >> 1) - 1] != cls;
+    if (s + 2 < S) skip_b = lab_s[(s >> 1) + 1] != cls;
+  }
+  float v = LR_NEG_INF;
+  if (wave == 0) {
+    if (live && s < 2) v = latp[cls];
+    if (live) al[s] = v;
+    for (int t = 1; t < Tb; ++t) {
+      const float lp_t = latp[t * C + cls];
+      const float up1 = __shfl_up(v, 1, 64), up2 = __shfl_up(v, 2, 64);
+      const float a2 = s >= 1 ? up1 : LR_NEG_INF;                          // alpha_{t-1}(s-1)
+      const float a3 = skip_a ? up2 : LR_NEG_INF;                          // alpha_{t-1}(s-2)
+      v = live ? lse3_fast(v, a2, a3) + lp_t : LR_NEG_INF;
+      if (live) al[(int64_t)t * sst + s] = v;
+    }
+    const float l1 = __shfl(v, S - 1, 64);
+    const float l2 = S > 1 ? __shfl(v, S - 2, 64) : LR_NEG_INF;
+    if (lane == 0) nll[b] = -lr_lse2(l1, l2);
+  } else {
+    if (live && s >= S - 2) v = latp[(Tb - 1) * C + cls];
+    if (live) be[(int64_t)(Tb - 1) * sst + s] = v;
+    for (int t = Tb - 2; t >= 0; --t) {
+      const float lp_t = latp[t * C + cls];
+      const float dn1 = __shfl_down(v, 1, 64), dn2 = __shfl_down(v, 2, 64);
+      const float b2 = s + 1 < S ? dn1 : LR_NEG_INF;                     // beta_{t+1}(s+1)
+      const float b3 = skip_b ? dn2 : LR_NEG_INF;                         // beta_{t+1}(s+2)
+      v = live ? lse3_fast(v, b2, b3) + lp_t : LR_NEG_INF;
+      if (live) be[(int64_t)t * sst + s] = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // gradient rows: one wave per (sample, frame), lanes along the class axis
 // ---------------------------------------------------------------------------------------
@@ -435,7 +560,11 @@ extern "C" int lr_ctc_nll(const float* log_probs, int64_t stride_b, int64_t stri
   const int nthr = concurrent ? 2 * sst : sst;
   const size_t base = 4 * (size_t)sst * sizeof(float) + (size_t)max_label_len * sizeof(int);
   const size_t lat = (size_t)T * C * sizeof(float);
-  if (base + lat <= 60 * 1024) {
+  if (sst == 64 && max_label_len <= 31 && 32 * sizeof(int) + lat + 16 <= 60 * 1024) {
+    // every state fits one wave: shuffle recursion, no per-step barrier
+    LR_LAUNCH(ctc_alpha_beta_wave_kernel, dim3(B), dim3(128), 32 * sizeof(int) + lat + 16, stream, log_probs, stride_b,
+              stride_t, labels, label_stride, frame_lens, label_lens, nll, ws, T, C, max_label_len);
+  } else if (base + lat <= 60 * 1024) {
     LR_LAUNCH(ctc_alpha_beta_kernel<true>, dim3(B), dim3(nthr), base + lat, stream, log_probs,
               stride_b, stride_t, labels, label_stride, frame_lens, label_lens, nll, ws, T, C, sst,
               max_label_len, concurrent);
