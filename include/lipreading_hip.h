@@ -265,6 +265,37 @@ int lr_decoder_backward(int mode, int attn_type, const lr_decoder_params* params
                         size_t workspace_bytes, int accumulate, int B, int L, int T, int Hd, int Cd, int V,
                         int A, lr_stream_t stream);
 
+/* ---- A10 (build-defined): transformer encoder blocks — no reference symbol ------ *
+ * torch.nn.TransformerEncoderLayer(norm_first=False, activation=relu, dropout=0) arithmetic; the
+ * host composition is lipreading_amd/transformer.py.  Contractions use lr_sgemm / lr_sgemm_batched. */
+
+/* batch_outer x batch_inner independent fp32 products C_z = alpha op(A_z) op(B_z) + beta C_z, problem
+ * z = (o, i) at element offsets o*s?_outer + i*s?_inner from the base pointers (0: shared operand).
+ * Per (sample, head) attention products read Q/K/V straight out of the fused [R][3D] projection. */
+int lr_sgemm_batched(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                     int64_t sA_outer, int64_t sA_inner, const float* B, int ldb, int64_t sB_outer,
+                     int64_t sB_inner, float beta, float* C, int ldc, int64_t sC_outer, int64_t sC_inner,
+                     int batch_outer, int batch_inner, lr_stream_t stream);
+/* y = LayerNorm(x + residual) * gamma + beta over rows of D (residual may be NULL); stats [R][2] =
+ * (mean, rstd) for the backward.  Backward: dx is the gradient of BOTH x and residual; dgamma / dbeta
+ * overwritten or (accumulate != 0) added to. */
+int lr_layernorm_forward(const float* x, const float* residual, const float* gamma, const float* beta,
+                         float* y, float* stats, int R, int D, float eps, lr_stream_t stream);
+size_t lr_layernorm_workspace_bytes(int D);
+int lr_layernorm_backward(const float* x, const float* residual, const float* gamma, const float* stats,
+                          const float* dy, float* dx, float* dgamma, float* dbeta, void* workspace,
+                          size_t workspace_bytes, int accumulate, int R, int D, lr_stream_t stream);
+/* In place: scores [B][Hh][T][T] -> softmax over keys of scale*scores with keys >= key_lens[b] masked
+ * (probability 0).  Backward, in place over dprobs: dscores = scale * P * (dP - sum_k dP P). */
+int lr_attn_softmax_forward(float* scores, const int32_t* key_lens, float scale, int B, int Hh, int T,
+                            lr_stream_t stream);
+int lr_attn_softmax_backward(const float* probs, float* dprobs, float scale, int B, int Hh, int T,
+                             lr_stream_t stream);
+int lr_relu_forward(const float* x, float* y, int64_t n, lr_stream_t stream);
+int lr_relu_backward(const float* y, const float* dy, float* dx, int64_t n, lr_stream_t stream);
+/* x[b][t][:] += pe[t][:]  (positional encoding) */
+int lr_add_rows(float* x, const float* pe, int B, int T, int D, lr_stream_t stream);
+
 /* ---- A4: CTC loss — src/train/ctc_loss.py:28-114 ---------------------------------------- */
 
 /* Per-sample CTC negative log-likelihood and its gradient, blank = 0, the same recursion as

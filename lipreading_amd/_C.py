@@ -28,6 +28,16 @@ SIGNATURES = {
     "lr_xgemm_workspace_bytes": (c_size_t, [c_int] * 5),
     "lr_xgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, P, c_int, P, c_int, c_float,
                           P, c_int, P, c_int, c_int, P, c_size_t, P]),
+    "lr_sgemm_batched": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, P, c_int, c_int64, c_int64, P, c_int,
+                                  c_int64, c_int64, c_float, P, c_int, c_int64, c_int64, c_int, c_int, P]),
+    "lr_layernorm_forward": (c_int, [P, P, P, P, P, P, c_int, c_int, c_float, P]),
+    "lr_layernorm_workspace_bytes": (c_size_t, [c_int]),
+    "lr_layernorm_backward": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, P]),
+    "lr_attn_softmax_forward": (c_int, [P, P, c_float, c_int, c_int, c_int, P]),
+    "lr_attn_softmax_backward": (c_int, [P, P, c_float, c_int, c_int, c_int, P]),
+    "lr_relu_forward": (c_int, [P, P, c_int64, P]),
+    "lr_relu_backward": (c_int, [P, P, P, c_int64, P]),
+    "lr_add_rows": (c_int, [P, P, c_int, c_int, c_int, P]),
     "lr_rnn_reserve_bytes": (c_size_t, [c_int] * 6),
     "lr_rnn_workspace_bytes": (c_size_t, [c_int] * 6),
     "lr_rnn_layer_forward": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int,

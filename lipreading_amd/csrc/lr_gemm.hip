@@ -36,15 +36,18 @@ struct GemmArgs {
   float* slabs;           // split-K partial sums [splits][M][N] or nullptr
   bool vecA, vecB;        // operand base + leading dimension allow 16-byte loads
   int batch;              // > 1: blockIdx.z indexes independent problems (no split-K)
-  int64_t sA, sB, sC;     // element strides between the problems of a batch
+  int64_t sA, sB, sC;     // element strides between the problems of a batch (outer index)
+  int batch_inner;        // problems per outer index (blockIdx.z = outer * batch_inner + inner)
+  int64_t sA2, sB2, sC2;  // element strides of the inner index
 };
 
 template <int BM, int BN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
   if (g.batch > 1) {   // batched: one problem per blockIdx.z, the whole K range
-    g.A += (int64_t)blockIdx.z * g.sA;
-    g.B += (int64_t)blockIdx.z * g.sB;
-    g.C += (int64_t)blockIdx.z * g.sC;
+    const int zo = blockIdx.z / g.batch_inner, zi = blockIdx.z - zo * g.batch_inner;
+    g.A += (int64_t)zo * g.sA + (int64_t)zi * g.sA2;
+    g.B += (int64_t)zo * g.sB + (int64_t)zi * g.sB2;
+    g.C += (int64_t)zo * g.sC + (int64_t)zi * g.sC2;
   }
   constexpr int WM = BM / 64;  // 32x32 tiles per wave along M
   constexpr int WN = BN / 64;
@@ -296,6 +299,7 @@ int lr_sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, cons
   g.alpha = alpha; g.beta = beta;
   g.row_shift = row_shift; g.period = period;
   g.batch = 1; g.sA = g.sB = g.sC = 0;
+  g.batch_inner = 1; g.sA2 = g.sB2 = g.sC2 = 0;
   g.vecA = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0;
   g.vecB = (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0;
   const GemmPlan p = plan_gemm(M, N, K, workspace ? workspace_bytes : 0);
@@ -318,28 +322,48 @@ int lr_sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, cons
   return st;
 }
 
-// `batch` independent products C_z = alpha * op(A_z) op(B_z) + beta * C_z + bias with element
-// strides sA/sB/sC between them (0 = shared operand); 64x64 tiles, no split-K.
-int lr_sgemm_batched_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
-                          int64_t sA, const float* B, int ldb, int64_t sB, float beta, float* C, int ldc,
-                          int64_t sC, const float* bias, int batch, hipStream_t stream) {
+// batch_outer x batch_inner independent products C_z = alpha * op(A_z) op(B_z) + beta * C_z + bias, problem
+// z = (o, i) at element offsets o * s?_outer + i * s?_inner (0 = shared operand); 64x64 tiles, no split-K.
+int lr_sgemm_batched2_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                           int64_t sA, int64_t sA2, const float* B, int ldb, int64_t sB, int64_t sB2, float beta,
+                           float* C, int ldc, int64_t sC, int64_t sC2, const float* bias, int batch_outer,
+                           int batch_inner, hipStream_t stream) {
   LR_CHECK_ARG(A && B && C);
-  LR_CHECK_ARG(M > 0 && N > 0 && K >= 0 && lda > 0 && ldb > 0 && ldc >= N && batch > 0 && batch <= 65535);
+  LR_CHECK_ARG(M > 0 && N > 0 && K >= 0 && lda > 0 && ldb > 0 && ldc >= N && batch_outer > 0 && batch_inner > 0 &&
+               (int64_t)batch_outer * batch_inner <= 65535);
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias;
   g.M = M; g.N = N; g.K = K;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.alpha = alpha; g.beta = beta;
   g.row_shift = 0; g.period = 0;
+  const int batch = batch_outer * batch_inner;
   g.batch = batch > 1 ? batch : 1; g.sA = sA; g.sB = sB; g.sC = sC;
-  g.vecA = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0 && (sA & 3) == 0;
-  g.vecB = (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0 && (sB & 3) == 0;
+  g.batch_inner = batch_inner; g.sA2 = sA2; g.sB2 = sB2; g.sC2 = sC2;
+  g.vecA = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0 && (sA & 3) == 0 && (sA2 & 3) == 0;
+  g.vecB = (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0 && (sB & 3) == 0 && (sB2 & 3) == 0;
   g.k_chunk = (K + BK - 1) / BK * BK;
   if (g.k_chunk < BK) g.k_chunk = BK;
   g.slabs = nullptr;
   dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
   launch_tile<64, 64>(transA, transB, g, grid, stream);
   return lr_launch_status();
+}
+
+int lr_sgemm_batched_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                          int64_t sA, const float* B, int ldb, int64_t sB, float beta, float* C, int ldc,
+                          int64_t sC, const float* bias, int batch, hipStream_t stream) {
+  return lr_sgemm_batched2_impl(transA, transB, M, N, K, alpha, A, lda, sA, 0, B, ldb, sB, 0, beta, C, ldc, sC, 0,
+                                bias, batch, 1, stream);
+}
+
+extern "C" int lr_sgemm_batched(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                                int64_t sA_outer, int64_t sA_inner, const float* B, int ldb, int64_t sB_outer,
+                                int64_t sB_inner, float beta, float* C, int ldc, int64_t sC_outer, int64_t sC_inner,
+                                int batch_outer, int batch_inner, lr_stream_t stream) {
+  return lr_sgemm_batched2_impl(transA, transB, M, N, K, alpha, A, lda, sA_outer, sA_inner, B, ldb, sB_outer,
+                                sB_inner, beta, C, ldc, sC_outer, sC_inner, nullptr, batch_outer, batch_inner,
+                                (hipStream_t)stream);
 }
 
 extern "C" size_t lr_sgemm_workspace_bytes(int M, int N, int K) {

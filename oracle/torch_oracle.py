@@ -396,3 +396,39 @@ def decoder_loop(dec, chars, char_lens, enc, enc_lens, prev_state, pad=0):
     outs.append(lp)
   loss = loss / (labels != pad).sum()
   return loss, torch.stack(outs, 1)
+
+
+# ---- A10 (build-defined): transformer encoder — NO reference symbol --------------------
+class OracleTransformerEncoder(nn.Module):
+  """CPU oracle of lipreading_amd/transformer.py: Linear + sinusoidal positions -> torch's own
+  nn.TransformerEncoder (post-LN, ReLU, dropout 0, key padding mask) -> the reference's CTC head
+  (better_model.py:92-93).  Parity unpinned: nothing in the reference to match."""
+
+  def __init__(self, frame_dim, d_model, nhead, num_layers, dim_feedforward, vocab_size, char2idx, max_len=512):
+    super().__init__()
+    import math
+    self.input_proj = nn.Linear(frame_dim, d_model)
+    layer = nn.TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout=0.0, activation='relu',
+                                       batch_first=True, norm_first=False)
+    self.encoder = nn.TransformerEncoder(layer, num_layers, enable_nested_tensor=False)
+    self.layers = self.encoder.layers          # same state_dict names as the HIP-backed module
+    pos = torch.arange(max_len, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float32) * (-math.log(10000.0) / d_model))
+    pe = torch.zeros(max_len, d_model)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    self.register_buffer("pe", pe, persistent=False)
+    self.output_proj = nn.Linear(d_model, vocab_size + 1)
+    mask = torch.ones(vocab_size + 1)
+    mask[char2idx[PAD] + 1] = 0
+    mask[char2idx[BOS] + 1] = 0
+    self.register_buffer("output_mask", mask, persistent=False)
+
+  def forward(self, frames, frame_lens):
+    B, T = frames.shape[0], int(frame_lens.max())
+    x = frames.reshape(B, frames.shape[1], -1)[:, :T]
+    h = self.input_proj(x) + self.pe[:T]
+    pad = torch.arange(T).unsqueeze(0) >= frame_lens.unsqueeze(1)
+    h = self.encoder(h, src_key_padding_mask=pad)
+    logits = self.output_proj(h)
+    return masked_log_softmax(logits, self.output_mask.expand_as(logits)), h
