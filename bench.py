@@ -16,6 +16,8 @@ Two input regimes (SURVEY.md section 8d says they must be reported separately):
   landmarks  reference-faithful: landmarks (B,75,68,3) f32 -> 1-layer BiGRU-256 (or BiLSTM-768) ->
              CTC; the only regime whose every stage is pinned to the reference.  Reported under
              "regimes" on the same line (and as the headline with --regime landmarks).
+  pixels_tfm (opt-in) BASELINE configs[4]: the conv frontend feeding a 4-layer transformer encoder (256, 4
+             heads) + CTC; frontend and encoder are both build-defined (no reference symbol).
   landmarks_attn  the reference's WHOLE train step (train_better_model.py:46-80): the landmarks
              regime plus the CharDecodingStep loop (char_dim 300, '1_layer_nn' attention,
              teacher_forcing_ratio 1, L=31 steps), decoder NLL + CTC, per-module clip, Adam.
@@ -97,10 +99,16 @@ def cpu_baseline(regime, model, layers, B, budget_s=20.0):
   from oracle import torch_oracle as O   # checker/baseline only — never on the product path
   rnn_type, H, bi = MODELS[model]
   torch.manual_seed(123456)
-  pixels = regime == "pixels"
+  tfm = regime == "pixels_tfm"
+  pixels = regime == "pixels" or tfm
   frame_dim = 96 * (IMG // 16) ** 2 if pixels else N_LMK * LMK_DIM
-  enc = O.OracleVideoEncoder(frame_dim, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
-                             enable_ctc=True, vocab_size=VOCAB, char2idx=O.default_char2idx()).train()
+  if tfm:
+    tenc = O.OracleTransformerEncoder(frame_dim, 256, 4, 4, 1024, VOCAB, O.default_char2idx()).train()
+    enc = lambda x, lens: tenc(x, lens) + (None,)   # (log_probs, hidden, final_state)
+    enc.parameters = tenc.parameters
+  else:
+    enc = O.OracleVideoEncoder(frame_dim, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
+                               enable_ctc=True, vocab_size=VOCAB, char2idx=O.default_char2idx()).train()
   params = list(enc.parameters())
   convs = []
   if pixels:
@@ -163,7 +171,8 @@ def run_regime(args, regime, world, rank, dev):
   from lipreading_amd.optim import FlatParameters, FusedAdam
 
   rnn_type, H, bi = MODELS[args.model]
-  pixels = regime == "pixels"
+  tfm = regime == "pixels_tfm"     # BASELINE configs[4]: conv features -> transformer encoder -> CTC (build-defined)
+  pixels = regime == "pixels" or tfm
   attn = regime == "landmarks_attn"
   layers = args.layers if args.layers is not None else (2 if pixels else 1)
   if attn:
@@ -175,8 +184,13 @@ def run_regime(args, regime, world, rank, dev):
   if pixels:
     from lipreading_amd.frontend import ConvFrontend3D, PixelLipReader, feature_dim
     frame_dim = feature_dim(IMG, IMG)
-  enc = VideoEncoder(frame_dim, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
-                     enable_ctc=True, vocab_size=VOCAB, char2idx=default_char2idx())
+  if tfm:
+    from lipreading_amd.transformer import TransformerVideoEncoder
+    enc = TransformerVideoEncoder(frame_dim, d_model=256, nhead=4, num_layers=4, dim_feedforward=1024,
+                                  enable_ctc=True, vocab_size=VOCAB, char2idx=default_char2idx())
+  else:
+    enc = VideoEncoder(frame_dim, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
+                       enable_ctc=True, vocab_size=VOCAB, char2idx=default_char2idx())
   model = PixelLipReader(enc, ConvFrontend3D()) if pixels else enc
   model = model.to(dev).train()
   enc = model.encoder if pixels else model
@@ -197,9 +211,11 @@ def run_regime(args, regime, world, rank, dev):
     # eager: all-reduce each bucket the moment its gradients are final, overlapped with the rest
     # of backward.  graph: forward+backward replay as one hipGraph and the exchange follows it
     # (hooks do not fire on replay, and no collective is ever captured).
-    groups = GradSync.groups_for_encoder(enc, flat)
-    if pixels:   # conv parameters come first in the flat buffer: one more bucket
-      groups = [list(range(min(min(g) for g in groups)))] + groups
+    groups = None   # one bucket
+    if not tfm:
+      groups = GradSync.groups_for_encoder(enc, flat)
+      if pixels:   # conv parameters come first in the flat buffer: one more bucket
+        groups = [list(range(min(min(g) for g in groups)))] + groups
     sync = GradSync(flat, groups=groups, overlap=not use_graph)
     sync.broadcast_parameters(0)
     if attn:
@@ -354,7 +370,13 @@ def run_regime(args, regime, world, rank, dev):
                   "mfma_f32_tflops": round(flops_per_launch / (us * 1e-6) / 1e12, 2),
                   "mfma_f32_frac": round(flops_per_launch / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
   res["roofline"] = roofline
-  if pixels:
+  if tfm:
+    res["workload"] = ("regime X-transformer (BASELINE configs[4]; frontend AND encoder build-defined, no reference "
+                       "symbol): uint8 clips (B=%d,T=75,3,96,96) -> STCNN x3 (bf16 MFMA) -> Linear(3456,256) + "
+                       "sinusoidal positions -> 4 x TransformerEncoderLayer(256, 4 heads, ff 1024, post-LN, fp32) -> "
+                       "Linear(256,65) -> masked log-softmax -> CTC 'mean' (L=30+EOS) -> backward -> clip 50 -> "
+                       "Adam 1e-4" % B)
+  elif pixels:
     res["workload"] = ("regime X (BASELINE metric shape, frontend build-defined: the reference has no conv "
                        "stage): uint8 clips (B=%d,T=75,3,96,96) -> STCNN x3 (bf16 MFMA implicit GEMM, fp32 "
                        "accumulate) -> %d-layer Bi%s-%d (fp32) -> Linear(%d,65) -> masked log-softmax -> CTC "
@@ -380,7 +402,7 @@ def main():
   ap.add_argument("--warmup", type=int, default=3)
   ap.add_argument("--model", choices=sorted(MODELS), default="gru256")
   ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
-  ap.add_argument("--regime", choices=["pixels", "landmarks", "landmarks_attn", "both", "all"], default="all",
+  ap.add_argument("--regime", choices=["pixels", "landmarks", "landmarks_attn", "pixels_tfm", "both", "all"], default="all",
                   help="all (default): headline = pixels (the metric's (B,75,3,96,96) shape); the "
                        "reference-faithful landmarks regimes (encoder+CTC, and the whole step with the "
                        "attention decoder) are reported under 'regimes'")
