@@ -375,9 +375,10 @@ int lr_clip_to_ndhwc_bf16(const void* clips, int is_u8, void* out, int64_t frame
  *   dgrad & 1 == 0: out[Cout][taps][Cin_pad]          (forward; channels >= Cin_real are zero)
  *   dgrad & 1 == 1: out[Cin_real][taps][Cout], taps flipped (data gradient of a stride-1 "same" conv
  *                   becomes lr_conv3d_forward on dZ with this operand).
- *   dgrad & 2: the same elements in the fragment-major order of the patch-resident kernel (every
- *              32-output-channel x 16-k MFMA operand 1 KB contiguous); only for layers for which
- *              lr_conv3d_patch_supported() is 1, to be passed to lr_conv3d_forward with flags & 2. */
+ *   dgrad & 2 / dgrad & 4: the same elements in the fragment-major order of a patch-resident kernel
+ *              (every 32-output-channel x 16-k, resp. 16-output-channel x 32-k, MFMA operand 1 KB
+ *              contiguous); the bit is what lr_conv3d_patch_supported() returns for the layer and
+ *              is passed on to lr_conv3d_forward in `flags`. */
 int lr_conv3d_pack_weights(const float* W, void* out, int Cout, int Cin_real, int Cin_pad, int KT,
                            int KH, int KW, int dgrad, lr_stream_t stream);
 
@@ -385,7 +386,7 @@ int lr_conv3d_pack_weights(const float* W, void* out, int Cout, int Cin_real, in
  *                       + bias[n] ),  zero padding, temporal stride 1 and KT = 2*pt+1, spatial stride s.
  *   X bf16 [B][T][Hin][Win][Cin] (Cin % 4 == 0), Wp from lr_conv3d_pack_weights, bias fp32 or NULL,
  *   Y bf16 [B][T][Ho][Wo][Cout] (Cout in {32,64,96}); flags & 1 applies max(.,0) (ReLU);
- *   flags & 2: Wp is fragment-major (lr_conv3d_pack_weights dgrad & 2).                            */
+ *   flags & 2 / flags & 4: Wp is fragment-major (lr_conv3d_pack_weights dgrad & 2 / & 4).          */
 int lr_conv3d_forward(const void* X, const void* Wp, const float* bias, void* Y, int B, int T, int Hin,
                       int Win, int Cin, int Cout, int KT, int KH, int KW, int stride, int pt, int ph,
                       int pw, int flags, lr_stream_t stream);
@@ -399,9 +400,10 @@ int lr_conv3d_pool_fusion_supported(int Hin, int Win, int Cin, int Cout, int KT,
 int lr_conv3d_forward_pooled(const void* X, const void* Wp, const float* bias, void* P, void* code, int B,
                              int T, int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW, int stride,
                              int pt, int ph, int pw, int flags, lr_stream_t stream);
-/* 1 when the layer (as lr_conv3d_forward sees it: Cin = contraction channels, Cout = output
- * channels) has a patch-resident kernel: the input patch of an output tile is loaded into LDS
- * once and all taps run out of LDS, instead of re-gathering it per tap. */
+/* Non-zero when the layer (as lr_conv3d_forward sees it: Cin = contraction channels, Cout = output
+ * channels) has a patch-resident kernel — the input patch of an output tile is loaded into LDS
+ * once and all taps run out of LDS, instead of re-gathering it per tap.  The value is the weight
+ * packing bit that kernel reads: 2 (24x24, taps 3x5x5) or 4 (12x12, taps 3x3x3). */
 int lr_conv3d_patch_supported(int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW, int stride,
                               int pt, int ph, int pw);
 

@@ -26,6 +26,7 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;  // storage type
 
 __device__ __forceinline__ bf16_t f2bf(float f) {
@@ -781,6 +782,152 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_ts_kernel(ConvGeom g, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// patch-resident forward / data-gradient kernel for the 12x12 stride-1 (3,3,3) layer
+// ---------------------------------------------------------------------------------------------
+// Same idea as conv_patch_kernel, shaped for 12x12 frames: a wave owns a whole frame as nine
+// 4x4-position row tiles of v_mfma_f32_16x16x32_bf16 (16 rows x 32 k: one MFMA consumes a whole
+// 32-channel group of a tap), a workgroup 4 consecutive frames; the 6 x 14 x 14-position patch of
+// one 32-channel group sits in LDS with rows padded to 16 positions and 16-byte chunks stored at
+// c ^ ((p >> 3) & 3) — with that the four 16-lane groups of ds_read_b128 each hit 16 different
+// bank slots for any tap shift (found by exhaustive search over row paddings and swizzles).  Inputs
+// with 64 / 96 channels take 2 / 3 passes.  B fragments (16 output channels x 32 k) come from
+// global in the 16-column fragment-major packing.
+constexpr int P3_TT = 4, P3_H = 12, P3_W = 12, P3_PH = P3_H + 2, P3_PW = 16, P3_SLOTS = P3_TT + 2;
+constexpr int P3_POS = P3_SLOTS * P3_PH * P3_PW;   // 1344 positions (2 padding columns per row)
+constexpr int P3_LDS = P3_POS * 64;                // 86,016 bytes
+constexpr int P3_UNITS = P3_POS * 4;
+constexpr int P3_UPT = (P3_UNITS + 255) / 256;     // 21
+
+template <int CG, int NT16, bool POOL>
+__global__ __launch_bounds__(256, 1) void conv_patch16_kernel(const bf16_t* __restrict__ X,
+                                                              const bf16_t* __restrict__ Wf,
+                                                              const float* __restrict__ bias,
+                                                              bf16_t* __restrict__ Y, unsigned char* __restrict__ code,
+                                                              int F, int T, int relu) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char patch[];
+  constexpr int C = 32 * CG, N = 16 * NT16, TAPS = 27;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f0 = (int)blockIdx.x * P3_TT;
+  const int rl = lane & 15, kg = lane >> 4;
+  const int f = f0 + wave;
+  const bool fvalid = f < F;
+  const int t = f % T;
+
+  f32x4 acc[9][NT16];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int j = 0; j < NT16; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // row tile mb = (hb, wb): rows r -> (h = 4hb + r/4, w = 4wb + r%4)
+  const int base_p = (wave * P3_PH + (rl >> 2)) * P3_PW + (rl & 3);
+  for (int cg = 0; cg < CG; ++cg) {
+    if (cg > 0) __syncthreads();
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {   // 3 x 7 units per thread, each batch fully in flight
+      uint4 v[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int u = tid + 256 * (part * 7 + i);
+        v[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (u < P3_UNITS) {
+          const int p = u >> 2, c = u & 3;
+          const int s = p / (P3_PH * P3_PW), rem = p - s * (P3_PH * P3_PW);
+          const int ph = rem / P3_PW, pw = rem - ph * P3_PW;
+          const int ff = f0 - 1 + s, hh = ph - 1, ww = pw - 1;
+          if (ff >= 0 && ff < F && hh >= 0 && hh < P3_H && ww >= 0 && ww < P3_W)
+            v[i] = *reinterpret_cast<const uint4*>(X + (((int64_t)ff * P3_H + hh) * P3_W + ww) * C + cg * 32 + c * 8);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int u = tid + 256 * (part * 7 + i);
+        if (u < P3_UNITS) {
+          const int p = u >> 2, c = u & 3;
+          *reinterpret_cast<uint4*>(patch + p * 64 + ((c ^ ((p >> 3) & 3)) << 4)) = v[i];
+        }
+      }
+    }
+    __syncthreads();
+    const bf16_t* wf = Wf + (int64_t)cg * TAPS * NT16 * 512 + lane * 8;
+    bf16x8 bcur[NT16], bnext[NT16];
+#pragma unroll
+    for (int j = 0; j < NT16; ++j) bcur[j] = *reinterpret_cast<const bf16x8*>(wf + j * 512);
+    int tap = 0;
+    for (int dt = 0; dt < 3; ++dt) {
+      const bool valid = fvalid && t + dt - 1 >= 0 && t + dt - 1 < T;   // wave-uniform
+      for (int dh = 0; dh < 3; ++dh) {
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw, ++tap) {
+          if (tap + 1 < TAPS) {
+#pragma unroll
+            for (int j = 0; j < NT16; ++j)
+              bnext[j] = *reinterpret_cast<const bf16x8*>(wf + ((int64_t)(tap + 1) * NT16 + j) * 512);
+          }
+          if (valid) {
+            const int to = (dt * P3_PH + dh) * P3_PW + dw;
+#pragma unroll
+            for (int mb = 0; mb < 9; ++mb) {
+              const int p = base_p + (4 * (mb / 3)) * P3_PW + 4 * (mb % 3) + to;
+              const bf16x8 a = *reinterpret_cast<const bf16x8*>(patch + p * 64 + ((kg ^ ((p >> 3) & 3)) << 4));
+#pragma unroll
+              for (int j = 0; j < NT16; ++j)
+                acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[j], acc[mb][j], 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < NT16; ++j) bcur[j] = bnext[j];
+        }
+      }
+    }
+  }
+  // ---- epilogue: D layout of 16x16: col = lane & 15, rows 4*(lane >> 4) + i -> (h = 4hb + (lane>>4), w = 4wb + i)
+  if (POOL) {
+    // ReLU -> MaxPool((1,2,2)): a window's two columns are registers i, i+1 (i even), its two rows the
+    // same registers of lanes l and l ^ 16
+#pragma unroll
+    for (int j = 0; j < NT16; ++j) {
+      const int n = j * 16 + rl;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int mb = 0; mb < 9; ++mb)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          const float v0 = bf2f(f2bf(fmaxf(acc[mb][j][2 * pp] + bv, 0.f)));
+          const float v1 = bf2f(f2bf(fmaxf(acc[mb][j][2 * pp + 1] + bv, 0.f)));
+          const float mine = v1 > v0 ? v1 : v0;
+          const int marg = v1 > v0 ? 1 : 0;
+          const float other = __shfl_xor(mine, 16, 64);
+          const int oarg = __shfl_xor(marg, 16, 64);
+          if ((kg & 1) == 0 && fvalid) {   // even row of the window: first in scan order
+            const bool low = other > mine;
+            const int hp = 2 * (mb / 3) + (kg >> 1), wp = 2 * (mb % 3) + pp;
+            const int64_t o = (((int64_t)f * (P3_H / 2) + hp) * (P3_W / 2) + wp) * N + n;
+            Y[o] = f2bf(low ? other : mine);
+            code[o] = (unsigned char)(low ? 2 + oarg : marg);
+          }
+        }
+    }
+    return;
+  }
+  if (!fvalid) return;
+#pragma unroll
+  for (int j = 0; j < NT16; ++j) {
+    const int n = j * 16 + rl;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int mb = 0; mb < 9; ++mb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int hh = 4 * (mb / 3) + kg, ww = 4 * (mb % 3) + i;
+        float v = acc[mb][j][i] + bv;
+        if (relu) v = fmaxf(v, 0.f);
+        Y[(((int64_t)f * P3_H + hh) * P3_W + ww) * N + n] = f2bf(v);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight gradient with LDS transpose reads (stride-1 layers):  dW[n][kt][kh][kw][c] =
 //     sum_pos dZ[pos][n] * X[pos + tap][c]
 // ---------------------------------------------------------------------------------------------
@@ -1014,10 +1161,16 @@ __global__ void conv3d_pack_weights_kernel(const float* __restrict__ W, bf16_t* 
       v = W[((int64_t)kch * Cin_real + nout) * taps + tap];
     }
     int64_t dst = i;
-    if (frag) {
+    if (frag == 1) {
       const int cg = kch >> 5, kc = (kch >> 4) & 1, kg = (kch >> 3) & 1, j = kch & 7;
       const int nt = nout >> 5, nl = nout & 31, NT = Nout >> 5;
       dst = ((((((int64_t)cg * taps + tp) * 2 + kc) * NT + nt) * 64 + kg * 32 + nl) << 3) + j;
+    } else if (frag == 2) {
+      // 16-column fragments of v_mfma_f32_16x16x32_bf16: Wf[cg][tap][n16][lane = kg*16 + n%16][j],
+      // k = cg*32 + kg*8 + j  (conv_patch16_kernel)
+      const int cg = kch >> 5, kg = (kch >> 3) & 3, j = kch & 7;
+      const int n16 = nout >> 4, nl = nout & 15, NT16 = Nout >> 4;
+      dst = (((((int64_t)cg * taps + tp) * NT16 + n16) * 64 + kg * 16 + nl) << 3) + j;
     }
     out[dst] = f2bf(v);
   }
@@ -1462,7 +1615,7 @@ extern "C" int lr_clip_to_ndhwc_bf16(const void* clips, int is_u8, void* out, in
 extern "C" int lr_conv3d_pack_weights(const float* W, void* out, int Cout, int Cin_real, int Cin_pad,
                                       int KT, int KH, int KW, int dgrad, lr_stream_t stream) {
   LR_CHECK_ARG(W && out && Cout > 0 && Cin_real > 0 && Cin_pad >= Cin_real);
-  const int flip = dgrad & 1, frag = (dgrad >> 1) & 1;
+  const int flip = dgrad & 1, frag = (dgrad & 2) ? 1 : ((dgrad & 4) ? 2 : 0);
   // fragment-major needs whole 32-channel groups on both axes
   if (frag && ((flip ? Cin_real : Cout) % 32 != 0 || (flip ? Cout : Cin_pad) % 32 != 0)) return LR_ERR_UNSUPPORTED;
   const int64_t total = flip ? (int64_t)Cin_real * KT * KH * KW * Cout
@@ -1474,9 +1627,13 @@ extern "C" int lr_conv3d_pack_weights(const float* W, void* out, int Cout, int C
 
 extern "C" int lr_conv3d_patch_supported(int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW,
                                          int stride, int pt, int ph, int pw) {
-  const bool shape = KT == 3 && KH == 5 && KW == 5 && stride == 1 && pt == 1 && ph == 2 && pw == 2 &&
-                     Win == P2_W && Hin > 0 && Hin % P2_TH == 0;
-  return shape && ((Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 32)) ? 1 : 0;
+  const bool shape2 = KT == 3 && KH == 5 && KW == 5 && stride == 1 && pt == 1 && ph == 2 && pw == 2 &&
+                      Win == P2_W && Hin > 0 && Hin % P2_TH == 0;
+  if (shape2 && ((Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 32))) return 2;   // 32-column fragments
+  const bool shape3 = KT == 3 && KH == 3 && KW == 3 && stride == 1 && pt == 1 && ph == 1 && pw == 1 &&
+                      Win == P3_W && Hin == P3_H;
+  if (shape3 && ((Cin == 64 && Cout == 96) || (Cin == 96 && Cout == 64))) return 4;   // 16-column fragments
+  return 0;
 }
 
 extern "C" int lr_conv3d_pool_fusion_supported(int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW,
@@ -1485,7 +1642,9 @@ extern "C" int lr_conv3d_pool_fusion_supported(int Hin, int Win, int Cin, int Co
                      pw == 2 && Hin % 4 == 0 && Win % 4 == 0;
   const bool second = Cin == 32 && Cout == 64 &&
                       lr_conv3d_patch_supported(Hin, Win, Cin, Cout, KT, KH, KW, stride, pt, ph, pw);
-  return first || second ? 1 : 0;
+  const bool third = Cin == 64 && Cout == 96 &&
+                     lr_conv3d_patch_supported(Hin, Win, Cin, Cout, KT, KH, KW, stride, pt, ph, pw);
+  return first || second || third ? 1 : 0;
 }
 
 // code == nullptr: Y = full-resolution activation; else Y = ReLU -> MaxPool((1,2,2)) of it and code =
@@ -1503,9 +1662,38 @@ static int conv_forward_impl(const void* X, const void* Wp, const float* bias, v
   bf16_t* y = (bf16_t*)Y;
   if (code && (!relu || !lr_conv3d_pool_fusion_supported(Hin, Win, Cin, Cout, KT, KH, KW, stride, pt, ph, pw)))
     return LR_ERR_UNSUPPORTED;
+  if (flags & 4) {
+    // 16-column fragment-major weights: the 12x12 patch-resident kernel
+    if (lr_conv3d_patch_supported(Hin, Win, Cin, Cout, KT, KH, KW, stride, pt, ph, pw) != 4) return LR_ERR_UNSUPPORTED;
+    const int F = B * T;
+    const dim3 pgrid((unsigned)((F + P3_TT - 1) / P3_TT));
+    hipEvent_t e0, e1;
+    const bool fwd = Cin == 64;
+    const bool sample = lr_prof_next(fwd ? LR_PROF_CONV3_FWD : LR_PROF_CONV3_DGRAD, &e0, &e1);
+    static bool attr16[3] = {false, false, false};
+    lr_clear_error();
+#define LR_PATCH16(IDX, ...)                                                                                    \
+  do {                                                                                                         \
+    if (!attr16[IDX]) {                                                                                        \
+      if (hipFuncSetAttribute((const void*)conv_patch16_kernel<__VA_ARGS__>,                                    \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, P3_LDS) != hipSuccess)               \
+        return LR_ERR_LAUNCH;                                                                                  \
+      attr16[IDX] = true;                                                                                      \
+    }                                                                                                          \
+    if (sample) hipExtLaunchKernelGGL((conv_patch16_kernel<__VA_ARGS__>), pgrid, dim3(256), P3_LDS,             \
+                                      (hipStream_t)stream, e0, e1, 0, x, w, bias, y, code, F, T, relu);        \
+    else hipLaunchKernelGGL((conv_patch16_kernel<__VA_ARGS__>), pgrid, dim3(256), P3_LDS, (hipStream_t)stream,  \
+                            x, w, bias, y, code, F, T, relu);                                                  \
+  } while (0)
+    if (fwd && code) LR_PATCH16(2, 2, 6, true);
+    else if (fwd) LR_PATCH16(0, 2, 6, false);
+    else LR_PATCH16(1, 3, 4, false);
+#undef LR_PATCH16
+    return lr_launch_status();
+  }
   if (flags & 2) {
     // fragment-major weights: the patch-resident kernel (no other kernel reads that packing)
-    if (!lr_conv3d_patch_supported(Hin, Win, Cin, Cout, KT, KH, KW, stride, pt, ph, pw)) return LR_ERR_UNSUPPORTED;
+    if (lr_conv3d_patch_supported(Hin, Win, Cin, Cout, KT, KH, KW, stride, pt, ph, pw) != 2) return LR_ERR_UNSUPPORTED;
     const int F = B * T;
     const dim3 pgrid((unsigned)(((F + P2_TT - 1) / P2_TT) * (Hin / P2_TH)));
     hipEvent_t e0, e1;

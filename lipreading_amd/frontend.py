@@ -64,8 +64,7 @@ class _ConvFrontendFunction(torch.autograd.Function):
       cin_p = _pad4(cin)
       wp = torch.empty((cout, kt * kh * kw, cin_p), dtype=bf, device=dev)
       # layers with a patch-resident kernel take their weights in its fragment-major order
-      frag = 2 if _PATCH_KERNELS and L.lr_conv3d_patch_supported(h, w, cin_p, cout, kt, kh, kw, stride, pt, ph,
-                                                                 pw) else 0
+      frag = L.lr_conv3d_patch_supported(h, w, cin_p, cout, kt, kh, kw, stride, pt, ph, pw) if _PATCH_KERNELS else 0
       _C.check(L.lr_conv3d_pack_weights(weight.data_ptr(), wp.data_ptr(), cout, cin, cin_p, kt, kh, kw, frag,
                                         st), "lr_conv3d_pack_weights")
       ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
@@ -142,8 +141,7 @@ class _ConvFrontendFunction(torch.autograd.Function):
         # data gradient of a stride-1 "same" convolution = the forward kernel on dZ with the
         # flipped, channel-transposed weights
         wd = torch.empty((cin, kt * kh * kw, cout), dtype=bf, device=dev)
-        frag = 2 if _PATCH_KERNELS and L.lr_conv3d_patch_supported(ho, wo, cout, cin, kt, kh, kw, 1, pt, ph,
-                                                                   pw) else 0
+        frag = L.lr_conv3d_patch_supported(ho, wo, cout, cin, kt, kh, kw, 1, pt, ph, pw) if _PATCH_KERNELS else 0
         _C.check(L.lr_conv3d_pack_weights(params[2 * li].data_ptr(), wd.data_ptr(), cout, cin, cin_p, kt,
                                           kh, kw, 1 | frag, st), "lr_conv3d_pack_weights")
         dP = torch.empty((frames, h, w, cin), dtype=bf, device=dev)
