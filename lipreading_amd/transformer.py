@@ -28,8 +28,16 @@ from .data import BOS, PAD
 from .encoder import _ProjLogSoftmaxFunction
 
 
-def _gemm(ta, tb, M, N, K, A, lda, Bm, ldb, C, ldc, bias=None, alpha=1.0, beta=0.0):
+def _gemm(ta, tb, M, N, K, A, lda, Bm, ldb, C, ldc, bias=None, alpha=1.0, beta=0.0, x3=False):
+  """fp32 GEMM on the fp32 matrix cores (lr_sgemm) or, x3, on the bf16 matrix cores with hi/lo split
+  operands (lr_xgemm, ~1e-5 relative): the pixel regime's choice, as for the recurrent encoder."""
   L = _C.lib()
+  if x3:
+    wsb = L.lr_xgemm_workspace_bytes(int(ta), int(tb), M, N, K)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=C.device)
+    _C.check(L.lr_xgemm(int(ta), int(tb), M, N, K, alpha, A.data_ptr(), lda, Bm.data_ptr(), ldb, beta, C.data_ptr(),
+                        ldc, _C.ptr(bias), 0, 0, ws.data_ptr(), wsb, _C.stream_handle()), "lr_xgemm")
+    return
   wsb = L.lr_sgemm_workspace_bytes(M, N, K)
   ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=C.device)
   _C.check(L.lr_sgemm(int(ta), int(tb), M, N, K, alpha, A.data_ptr(), lda, Bm.data_ptr(), ldb, beta, C.data_ptr(),
@@ -40,15 +48,17 @@ class _LinearFunction(torch.autograd.Function):
   """y[R,N] = x[R,K] W[N,K]^T + b — torch.nn.Linear on the matrix cores."""
 
   @staticmethod
-  def forward(ctx, x, weight, bias):
+  def forward(ctx, x, weight, bias, x3=False):
     shape = x.shape
     x2 = x.reshape(-1, shape[-1]).contiguous()
     R, K = x2.shape
     N = weight.shape[0]
+    x3 = bool(x3) and R >= 256 and K >= 128   # the split path pays only for real contractions
     y = torch.empty((R, N), dtype=torch.float32, device=x.device)
-    _gemm(0, 1, R, N, K, x2, K, weight, K, y, N, bias=bias)
+    _gemm(0, 1, R, N, K, x2, K, weight, K, y, N, bias=bias, x3=x3)
     ctx.save_for_backward(x2, weight)
     ctx.shape = shape
+    ctx.x3 = x3
     return y.reshape(shape[:-1] + (N,))
 
   @staticmethod
@@ -58,13 +68,13 @@ class _LinearFunction(torch.autograd.Function):
     N = weight.shape[0]
     dy2 = dy.reshape(R, N).contiguous()
     dx = torch.empty_like(x2)
-    _gemm(0, 0, R, K, N, dy2, N, weight, K, dx, K)                    # dx = dy W
+    _gemm(0, 0, R, K, N, dy2, N, weight, K, dx, K, x3=ctx.x3)         # dx = dy W
     dW = torch.empty_like(weight)
-    _gemm(1, 0, N, K, R, dy2, N, x2, K, dW, K)                        # dW = dy^T x
+    _gemm(1, 0, N, K, R, dy2, N, x2, K, dW, K, x3=ctx.x3)             # dW = dy^T x
     ones = torch.ones((R, 1), dtype=torch.float32, device=dy.device)
     db = torch.empty((N,), dtype=torch.float32, device=dy.device)
     _gemm(1, 0, N, 1, R, dy2, N, ones, 1, db, 1)                      # db = dy^T 1
-    return dx.reshape(ctx.shape), dW, db
+    return dx.reshape(ctx.shape), dW, db, None
 
 
 class _LayerNormFunction(torch.autograd.Function):
@@ -212,6 +222,9 @@ class TransformerVideoEncoder(nn.Module):
     self.frame_dim, self.d_model, self.nhead, self.num_layers = frame_dim, d_model, nhead, num_layers
     self.enable_ctc = enable_ctc
     self.best_error = 1
+    # 'f32': exact fp32 MFMA linears; 'bf16x3' (set by frontend.PixelLipReader): hi/lo split bf16 MFMA
+    self.input_projection = 'f32'
+    self.input_is_bf16 = False
     self.input_proj = nn.Linear(frame_dim, d_model)
     layer = nn.TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout=0.0, activation='relu',
                                        batch_first=True, norm_first=False)
@@ -239,16 +252,17 @@ class TransformerVideoEncoder(nn.Module):
     assert 1 <= max_len <= min(T, self.pe.shape[0])
     x = frames[:, :max_len].to(torch.float32).contiguous()
     lens = frame_lens.to(device=x.device, dtype=torch.int32).contiguous()
-    h = _LinearFunction.apply(x, self.input_proj.weight, self.input_proj.bias)
+    x3 = self.input_projection == 'bf16x3'
+    h = _LinearFunction.apply(x, self.input_proj.weight, self.input_proj.bias, x3)
     h = _AddPositionalFunction.apply(h, self.pe[:max_len].contiguous())
     for layer in self.layers:
       at = layer.self_attn
-      qkv = _LinearFunction.apply(h, at.in_proj_weight, at.in_proj_bias)
+      qkv = _LinearFunction.apply(h, at.in_proj_weight, at.in_proj_bias, x3)
       a = _AttentionFunction.apply(qkv, lens, self.nhead)
-      o = _LinearFunction.apply(a, at.out_proj.weight, at.out_proj.bias)
+      o = _LinearFunction.apply(a, at.out_proj.weight, at.out_proj.bias, x3)
       h = _LayerNormFunction.apply(o, h, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
-      f = _ReluFunction.apply(_LinearFunction.apply(h, layer.linear1.weight, layer.linear1.bias))
-      f = _LinearFunction.apply(f, layer.linear2.weight, layer.linear2.bias)
+      f = _ReluFunction.apply(_LinearFunction.apply(h, layer.linear1.weight, layer.linear1.bias, x3))
+      f = _LinearFunction.apply(f, layer.linear2.weight, layer.linear2.bias, x3)
       h = _LayerNormFunction.apply(f, h, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
     if self.enable_ctc:
       lp = _ProjLogSoftmaxFunction.apply(h, self.output_proj.weight, self.output_proj.bias, self.output_mask)

@@ -50,6 +50,26 @@ def test_transformer_forward_backward_matches_torch(dev, lens):
     assert np.abs(p.grad.cpu().numpy() - r).max() / max(1e-5, np.abs(r).max()) < 3e-4, k
 
 
+def test_transformer_bf16x3_linears_track_fp32(dev):
+  """Pixel-regime option: every projection on the bf16 matrix cores with hi/lo split operands."""
+  _, enc = make_pair(dev, frame_dim=864, d_model=128, ff=256, seed=5)
+  g = torch.Generator().manual_seed(6)
+  x = torch.randn(8, 40, 864, 1, generator=g).to(dev)
+  lens = torch.full((8,), 40)
+  wgt = torch.randn(8, 40, 65, generator=g).to(dev)
+  res = {}
+  for mode in ("f32", "bf16x3"):
+    enc.input_projection = mode
+    enc.zero_grad()
+    lp, h, _ = enc(x, lens, max_len=40)
+    ((lp * wgt).sum() + h.pow(2).sum()).backward()
+    res[mode] = [lp.detach().cpu(), h.detach().cpu()] + [p.grad.cpu().clone() for p in enc.parameters()]
+  enc.input_projection = "f32"
+  # every product carries ~1e-5 relative error; 13 projections and 4 LayerNorms deep it stays ~1e-3
+  for a, b in zip(res["f32"], res["bf16x3"]):
+    assert float((a - b).abs().max()) / max(1e-6, float(a.abs().max())) < 3e-3
+
+
 def test_transformer_ctc_training_step_runs_and_learns(dev):
   from lipreading_amd.ctc import ctc_loss_with_status
   from lipreading_amd.optim import FlatParameters, FusedAdam
