@@ -65,9 +65,11 @@ def test_transformer_bf16x3_linears_track_fp32(dev):
     ((lp * wgt).sum() + h.pow(2).sum()).backward()
     res[mode] = [lp.detach().cpu(), h.detach().cpu()] + [p.grad.cpu().clone() for p in enc.parameters()]
   enc.input_projection = "f32"
-  # every product carries ~1e-5 relative error; 13 projections and 4 LayerNorms deep it stays ~1e-3
+  # every product carries ~1e-5 relative error (~1e-3 after 13 projections and 4 LayerNorms); a ReLU
+  # whose pre-activation sits within that of zero may switch, which moves single entries of the
+  # feed-forward gradients by a sample's worth — so the comparison is norm-wise
   for a, b in zip(res["f32"], res["bf16x3"]):
-    assert float((a - b).abs().max()) / max(1e-6, float(a.abs().max())) < 3e-3
+    assert float((a - b).norm()) / max(1e-6, float(a.norm())) < 3e-3
 
 
 def test_transformer_ctc_training_step_runs_and_learns(dev):
