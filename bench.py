@@ -205,6 +205,12 @@ def run_regime(args, regime, world, rank, dev):
     dec_flat = FlatParameters(dec)
     dec_opt = FusedAdam(dec_flat, lr=1e-4)
   use_graph = not args.no_graph
+  if world > 1 and pixels:
+    # the pixel step is GPU-bound either way (eager and hipGraph replay agree within 0.2 %), and eager
+    # launches let the gradient buckets go out from the gradient-ready hooks: the big bucket (first
+    # recurrent layer, 21 MB) is final before the conv backward starts and rides under it on the side
+    # stream.  A hipGraph replay would put the whole exchange after backward.
+    use_graph = False
   sync = None
   if world > 1:
     from lipreading_amd.distributed import GradSync
@@ -445,7 +451,9 @@ def main():
                    "recurrent_layers": head["layers"], "per_gpu_batch": args.batch,
                    "global_batch": world * args.batch, "seq_len": T_FRAMES, "parallelism": "dp%d" % world,
                    "launch": "hipGraph replay of forward+backward" if head["use_graph"]
-                             else (head.get("graph_note") or "eager")},
+                             else (head.get("graph_note") or
+                                   ("eager launches; gradient all-reduce overlapped with backward on a side stream"
+                                    if world > 1 else "eager"))},
         "final_loss": round(head["loss"], 6), "skipped_last": head["skipped"],
         "roofline": head["roofline"],
     }

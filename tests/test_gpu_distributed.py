@@ -1,0 +1,84 @@
+"""GPU checks of the data-parallel machinery on ONE rank (an RCCL process group of size 1): the
+stream / hook mechanics of GradSync's overlapped path — the part the gloo CPU tests cannot run."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+  assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+  return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def pg(dev):
+  os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+  os.environ.setdefault("MASTER_PORT", "29631")
+  torch.cuda.set_device(dev)
+  dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+  yield
+  dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pixels", [False, True])
+def test_overlapped_gradient_exchange_matches_plain_step(dev, pg, pixels):
+  """Buckets are all-reduced on the side stream from the gradient-ready hooks (including the hooks
+  of gradients the HIP backward writes in place); the step must equal the one without GradSync."""
+  from lipreading_amd.ctc import ctc_loss_with_status
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.distributed import GradSync
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.optim import FlatParameters, FusedAdam
+  g = torch.Generator().manual_seed(2)
+  B, T = 4, 12
+  lens = torch.full((B,), T, device=dev)
+  labels = torch.randint(4, 64, (B, 5), generator=g).to(dev)
+  ll = torch.full((B,), 5, device=dev)
+  results = []
+  for use_sync in (False, True):
+    torch.manual_seed(7)
+    if pixels:
+      from lipreading_amd.frontend import ConvFrontend3D, PixelLipReader, feature_dim
+      enc = VideoEncoder(feature_dim(32, 32), 16, rnn_type='GRU', num_layers=2, bidirectional=True, enable_ctc=True,
+                         vocab_size=64, char2idx=default_char2idx())
+      model = PixelLipReader(enc, ConvFrontend3D()).to(dev).train()
+      x = torch.randint(0, 256, (B, T, 3, 32, 32), generator=torch.Generator().manual_seed(3), dtype=torch.uint8).to(dev)
+    else:
+      enc = VideoEncoder(204, 16, rnn_type='LSTM', num_layers=2, bidirectional=True, enable_ctc=True,
+                         vocab_size=64, char2idx=default_char2idx())
+      model = enc.to(dev).train()
+      x = torch.randn(B, T, 68, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+    flat = FlatParameters(model)
+    opt = FusedAdam(flat, lr=1e-3)
+    sync = None
+    if use_sync:
+      groups = GradSync.groups_for_encoder(enc, flat)
+      if pixels:
+        groups = [list(range(min(min(gr) for gr in groups)))] + groups
+      sync = GradSync(flat, groups=groups, overlap=True)
+      sync.broadcast_parameters(0)
+    for _ in range(3):
+      opt.zero_grad()
+      lp, _, _ = model(x, lens, max_len=T)
+      loss, status, _ = ctc_loss_with_status(lp, labels, lens, ll, 'mean')
+      loss.backward()
+      scale = 1.0
+      if sync is not None:
+        assert any(sync._launched)      # buckets went out from the hooks, during backward
+        scale = sync(status)
+        assert scale == 1.0 and not any(sync._launched)
+      opt.step(grad_norm=50, grad_scale=scale, skip=status)
+    torch.cuda.synchronize()
+    results.append(flat.data.detach().cpu().numpy().copy())
+    if sync is not None:
+      for h in sync._hooks:
+        h.remove()
+      from lipreading_amd import encoder as _enc
+      _enc.grad_ready_hooks.remove(sync._direct_hook)
+  np.testing.assert_allclose(results[1], results[0], rtol=1e-6, atol=1e-7)
