@@ -54,6 +54,11 @@ SLOTS = {0: "rnn_fwd_step_kernel", 1: "rnn_bwd_step_kernel", 2: "conv1_fwd_igemm
          8: "conv2_wgrad", 9: "conv3_wgrad"}
 
 
+# multi-rank code path on: WORLD_SIZE > 1, or LIPREADING_BENCH_FORCE_DIST=1 to run the very same path
+# (process group, broadcast, bucketed all-reduce, barriers) as a 1-rank RCCL group on a single GPU
+DIST_ON = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("LIPREADING_BENCH_FORCE_DIST", "0") == "1"
+
+
 def synth_batch(B, seed, device=None):
   """Synthetic batch of SURVEY.md 8d: frames ~ N(0,1) (B,75,68,3), all lengths 75, labels L=30
   uniform in [4,64) + EOS, framed with BOS."""
@@ -205,14 +210,14 @@ def run_regime(args, regime, world, rank, dev):
     dec_flat = FlatParameters(dec)
     dec_opt = FusedAdam(dec_flat, lr=1e-4)
   use_graph = not args.no_graph
-  if world > 1 and pixels:
+  if DIST_ON and pixels:
     # the pixel step is GPU-bound either way (eager and hipGraph replay agree within 0.2 %), and eager
     # launches let the gradient buckets go out from the gradient-ready hooks: the big bucket (first
     # recurrent layer, 21 MB) is final before the conv backward starts and rides under it on the side
     # stream.  A hipGraph replay would put the whole exchange after backward.
     use_graph = False
   sync = None
-  if world > 1:
+  if DIST_ON:
     from lipreading_amd.distributed import GradSync
     # eager: all-reduce each bucket the moment its gradients are final, overlapped with the rest
     # of backward.  graph: forward+backward replay as one hipGraph and the exchange follows it
@@ -257,7 +262,7 @@ def run_regime(args, regime, world, rank, dev):
     # RCCL's watchdog thread may touch the runtime while this thread captures.
     try:
       torch.cuda.synchronize()
-      if world > 1:
+      if DIST_ON:
         dist.barrier()
       side = torch.cuda.Stream()
       side.wait_stream(torch.cuda.current_stream())
@@ -274,7 +279,7 @@ def run_regime(args, regime, world, rank, dev):
       graph_note = "hipGraph capture failed (%s); eager launches" % type(e).__name__
       torch.cuda.synchronize()
     # every rank must take the same path (a collective follows each step either way)
-    if world > 1:
+    if DIST_ON:
       ok = torch.tensor([1 if graph is not None else 0], device=dev)
       dist.all_reduce(ok, op=dist.ReduceOp.MIN)
       if int(ok.item()) == 0:
@@ -295,7 +300,7 @@ def run_regime(args, regime, world, rank, dev):
     return loss, status
 
   def fence():
-    if world > 1:
+    if DIST_ON:
       dist.barrier()
     torch.cuda.synchronize()
 
@@ -324,7 +329,7 @@ def run_regime(args, regime, world, rank, dev):
       prof[name] = (ms.value / n.value * 1e3, n.value / n_prof)   # us per launch, samples per step
 
   el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-  if world > 1:
+  if DIST_ON:
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
   elapsed = float(el.item())
   res = {"regime": regime, "elapsed": elapsed, "loss": float(loss.item()), "skipped": int(status.item()),
@@ -431,9 +436,10 @@ def main():
   assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
-  if world > 1:
+  if DIST_ON:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend="nccl", device_id=dev)
+    os.environ.setdefault("MASTER_PORT", "29617")
+    dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
   order = {"both": ["pixels", "landmarks"], "all": ["pixels", "landmarks", "landmarks_attn"]}.get(args.regime, [args.regime])
   results = [run_regime(args, r, world, rank, dev) for r in order]
@@ -453,7 +459,7 @@ def main():
                    "launch": "hipGraph replay of forward+backward" if head["use_graph"]
                              else (head.get("graph_note") or
                                    ("eager launches; gradient all-reduce overlapped with backward on a side stream"
-                                    if world > 1 else "eager"))},
+                                    if DIST_ON else "eager"))},
         "final_loss": round(head["loss"], 6), "skipped_last": head["skipped"],
         "roofline": head["roofline"],
     }
@@ -463,9 +469,17 @@ def main():
                                       "roofline": r["roofline"]} for r in results[1:]}
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline(head["regime"], args.model, head["layers"], args.batch, args.cpu_budget)
-    print(json.dumps(out))
-  if world > 1:
+  if DIST_ON:
     dist.destroy_process_group()
+  # the JSON line is the LAST thing on stdout: RCCL's version banner sits in the C stdio buffer until
+  # it is flushed, which otherwise happens at exit, after Python's own prints
+  sys.stdout.flush()
+  try:
+    ctypes.CDLL(None).fflush(None)
+  except Exception:
+    pass
+  if rank == 0:
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
