@@ -49,7 +49,13 @@ typedef enum lr_rnn_mode {
   /* with LR_RNN_PROJ_BF16X3: the layer input is the bf16 conv frontend's output — every element
    * of x is already a bf16 value, so x needs no lo term, and dx goes to a bf16 consumer (the
    * frontend's backward), so dx is contracted from the hi terms only. */
-  LR_RNN_INPUT_BF16_EXACT = 0x200
+  LR_RNN_INPUT_BF16_EXACT = 0x200,
+  /* Run the recurrence of a GRU layer with H = 256 and B <= 32 as ONE launch per pass: W_hh rounded
+   * to bf16 lives in the registers + LDS of one compute unit per (direction, 16-sample group), the
+   * recurrent product runs on the bf16 matrix cores with fp32 accumulation, gate math and carried
+   * state (lr_rnn_persist.hip).  Build-defined (pixel regime, BASELINE configs[1] "bf16"); other
+   * shapes return LR_ERR_UNSUPPORTED — query lr_rnn_persistent_supported first. */
+  LR_RNN_RECUR_BF16 = 0x400
 } lr_rnn_mode;
 
 typedef enum lr_ctc_reduction {
@@ -131,6 +137,7 @@ int lr_sgemm(int transA, int transB, int M, int N, int K, float alpha, const flo
  *   h_n    [D,B,H]        final hidden state; c_n [D,B,H] (LSTM; may be NULL for GRU)
  *   reserve               saved activations for the backward pass (lr_rnn_reserve_bytes)
  * Pointer arrays (w_ih ...) are HOST arrays of D device pointers. */
+int lr_rnn_persistent_supported(int mode, int B, int T, int I, int H, int D);   /* see LR_RNN_RECUR_BF16 */
 size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D);
 size_t lr_rnn_workspace_bytes(int mode, int B, int T, int I, int H, int D);
 

@@ -110,6 +110,10 @@ int lr_sgemm_batched_impl(int transA, int transB, int M, int N, int K, float alp
                           int64_t sA, const float* B, int ldb, int64_t sB, float beta, float* C, int ldc,
                           int64_t sC, const float* bias, int batch, hipStream_t stream);
 extern "C" size_t lr_sgemm_workspace_bytes(int M, int N, int K);
+// lr_rnn_persist.hip: the GRU-256 recurrence as one launch per layer pass (bf16 recurrent operands)
+int lr_gru256_persist_supported(int G, int B, int H);
+int lr_gru256_persist_forward(float* gates, float* extra, float* y, const float* const* w_hh, const float* const* b_hh,
+                              const int32_t* lens, int B, int T, int D, hipStream_t stream);
 // lr_xgemm.hip: fp32 GEMM on the bf16 matrix cores by hi/lo operand splitting (same operand
 // conventions; a_exact / b_exact: the operand's elements are bf16 values already)
 int lr_xgemm_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,

@@ -541,9 +541,10 @@ WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
 inline int cell_of(int mode) { return mode & LR_RNN_CELL_MASK; }
 inline bool proj_x3(int mode) { return (mode & LR_RNN_PROJ_BF16X3) != 0; }
 inline bool x_exact(int mode) { return (mode & LR_RNN_INPUT_BF16_EXACT) != 0; }
+inline bool recur_bf16(int mode) { return (mode & LR_RNN_RECUR_BF16) != 0; }
 bool dims_ok(int mode, int B, int T, int I, int H, int D) {
   return (cell_of(mode) == LR_RNN_GRU || cell_of(mode) == LR_RNN_LSTM) &&
-         (mode & ~(LR_RNN_CELL_MASK | LR_RNN_PROJ_BF16X3 | LR_RNN_INPUT_BF16_EXACT)) == 0 && B > 0 && T > 0 &&
+         (mode & ~(LR_RNN_CELL_MASK | LR_RNN_PROJ_BF16X3 | LR_RNN_INPUT_BF16_EXACT | LR_RNN_RECUR_BF16)) == 0 && B > 0 && T > 0 &&
          I > 0 && H > 0 && (D == 1 || D == 2);
 }
 // extra workspace floats of the bf16x3 input projection's backward (operand planes + split-K slabs
@@ -557,6 +558,11 @@ size_t x3_ws_floats(int G, int B, int T, int I, int H) {
 }
 
 }  // namespace
+
+extern "C" int lr_rnn_persistent_supported(int mode, int B, int T, int I, int H, int D) {
+  if (!dims_ok(mode, B, T, I, H, D)) return 0;
+  return lr_gru256_persist_supported(cell_of(mode) == LR_RNN_GRU ? 3 : 4, B, H);
+}
 
 extern "C" size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D)) return 0;
@@ -605,6 +611,18 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
                          D * GH, bias + (size_t)d * GH, 0, 0, l.gemm_bytes ? (void*)(base + l.gemm) : nullptr,
                          l.gemm_bytes, stream);
     if (st != LR_OK) return st;
+  }
+  if (recur_bf16(mode)) {
+    // one launch for all T steps (lr_rnn_persist.hip); same interface buffers as the step kernels
+    if (!lr_gru256_persist_supported(G, B, H)) return LR_ERR_UNSUPPORTED;
+    int st = lr_gru256_persist_forward(gates, extra, y, w_hh, b_hh, lens, B, T, D, stream);
+    if (st != LR_OK) return st;
+    const int64_t total = (int64_t)D * B * H;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    LR_LAUNCH(final_state_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)y, (const float*)extra, lens, h_n,
+              (float*)nullptr, B, T, H, D);
+    return lr_launch_status();
   }
   StepPtrs p;
   p.h0 = nullptr;

@@ -22,7 +22,7 @@ from .data import BOS, PAD
 _ALLOWED_RNN_TYPES = {'LSTM', 'GRU', 'RNN'}          # better_model.py:9
 _ALLOWED_FRAME_PROCESSING = {'flatten'}              # better_model.py:10
 _MODES = {'GRU': 0, 'LSTM': 1}
-_PROJ_BF16X3, _INPUT_BF16_EXACT = 0x100, 0x200   # lr_rnn_mode flags
+_PROJ_BF16X3, _INPUT_BF16_EXACT, _RECUR_BF16 = 0x100, 0x200, 0x400   # lr_rnn_mode flags
 _GATES = {'GRU': 3, 'LSTM': 4}
 
 
@@ -214,6 +214,9 @@ class VideoEncoder(nn.Module):
     # 'bf16x3' is set by frontend.PixelLipReader for the build-defined pixel regime
     self.input_projection = 'f32'
     self.input_is_bf16 = False
+    # 'f32': one launch per time step, exact fp32 (reference-faithful); 'bf16' (pixel regime): the
+    # whole recurrence of a supported layer (GRU, H = 256, B <= 32) in one launch with bf16 W_hh
+    self.recurrence = 'f32'
     if self.enable_ctc:
       self.vocab_size = vocab_size
       self.adj_vocab_size = self.vocab_size + 1      # idx 0 is reserved for the CTC blank
@@ -260,6 +263,8 @@ class VideoEncoder(nn.Module):
         # operands (include/lipreading_hip.h LR_RNN_PROJ_BF16X3); layer 0's input is bf16-exact
         # when it comes from the bf16 conv frontend
         lmode |= _PROJ_BF16X3 | (_INPUT_BF16_EXACT if (layer == 0 and self.input_is_bf16) else 0)
+      if self.recurrence == 'bf16' and _C.lib().lr_rnn_persistent_supported(mode, B, max_len, x.shape[2], H, D):
+        lmode |= _RECUR_BF16
       y, h_n, c_n = _RNNLayerFunction.apply(x, lens, lmode, H, need_dx, *weights)
       # (D,B,H) -> (B, D*H): forward direction first, as _cat_directions (better_model.py:98-112)
       h_fin.append(h_n.permute(1, 0, 2).reshape(B, D * H))

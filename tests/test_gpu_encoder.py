@@ -267,3 +267,34 @@ def test_bf16x3_input_projection_tracks_the_fp32_path(dev, rnn_type):
     # the gradient w.r.t. a bf16 input is contracted from the hi terms only (its consumer, the conv
     # frontend's backward, stores it as bf16 anyway): bf16-level agreement there, 1e-4 elsewhere
     assert float((a - b).abs().max()) / scale < (1e-2 if i == 2 else 1e-4), i
+
+
+@pytest.mark.parametrize("B,lens", [(32, None), (20, [5, 9, 9, 12, 17, 20, 23, 23, 30, 30, 30, 31, 33, 36, 36, 38, 40, 40, 40, 40])])
+def test_persistent_bf16_recurrence_tracks_the_step_kernels(dev, B, lens):
+  """Pixel-regime option (LR_RNN_RECUR_BF16): all T steps of a GRU-256 layer in one launch with W_hh
+  in bf16 registers/LDS.  Same interface buffers as the step kernels; results agree to bf16 level."""
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.encoder import VideoEncoder
+  torch.manual_seed(21)
+  enc = VideoEncoder(96, 256, rnn_type='GRU', num_layers=2, bidirectional=True, enable_ctc=True,
+                     vocab_size=64, char2idx=default_char2idx()).to(dev)
+  g = torch.Generator().manual_seed(22)
+  T = 40
+  x = torch.randn(B, T, 96, 1, generator=g)
+  lens = torch.tensor(lens) if lens is not None else torch.full((B,), T)
+  wgt = torch.randn(B, T, 65, generator=g).to(dev)
+  valid = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).float().unsqueeze(-1).to(dev)
+  res = {}
+  for mode in ("f32", "bf16"):
+    enc.recurrence = mode
+    enc.zero_grad()
+    lp, hid, fin = enc(x.to(dev), lens, max_len=T)
+    ((lp * wgt * valid).sum() + hid.pow(2).sum()).backward()
+    res[mode] = [lp.detach().cpu() * valid.cpu(), hid.detach().cpu(), fin.detach().cpu()] + \
+                [p.grad.cpu().clone() for p in enc.parameters()]
+  enc.recurrence = "f32"
+  assert float((res["f32"][1] - res["bf16"][1]).abs().max()) > 0      # the other path really ran
+  for a, b in zip(res["f32"], res["bf16"]):
+    assert float((a - b).norm()) / max(1e-6, float(a.norm())) < 2e-2
+  # padded positions are exactly zero in both
+  assert float((res["bf16"][1] * (1 - valid.cpu())).abs().max()) == 0.0
