@@ -14,6 +14,14 @@
 // one-shot GEMMs around the recurrence (input projection, weight gradients) are unchanged, and so
 // is the reference-faithful fp32 path, which never comes here.  No reference counterpart beyond
 // better_model.py:74 (nn.GRU); precision: bf16 operands in the recurrent product only.
+//
+// STATUS: opt-in (VideoEncoder.recurrence = 'bf16'), correct (tests/test_gpu_encoder.py) but NOT a
+// win as measured on MI355X at B = 32, T = 75: 6.7 us per step against 6.0 us for the step kernels.
+// Concentrating a direction on 2 compute units also concentrates its per-step interface traffic
+// there (48 KB of pre-activations in, 80 KB of saved activations out per CU per step: ~1.7 us of
+// the step by itself) and the gate non-linearities of 16 x 256 states on 4 waves (16 elements per
+// lane: ~1.5 us of exp/rcp), so the ~0.65 us of MFMA time is not what bounds it.  DESIGN.md section 9
+// lists what it would take (bf16 interface buffers, 8 waves per workgroup, a matching backward).
 #include "lr_common.h"
 #include <hip/hip_ext.h>
 
@@ -97,25 +105,29 @@ __global__ __launch_bounds__(256, 1) void gru256_fwd_persist_kernel(float* __res
     for (int i = 0; i < 4; ++i) hreg[nt][i] = 0.f;
   __syncthreads();
 
+  // input-projection pre-activations: loaded one step AHEAD — each value is re-fetched for step s+1
+  // right after step s consumed it, so the memory latency hides behind a whole step
+  float gx[3][4][4];
+  auto fetch_gx = [&](int t, int nt, int i) {
+    const int b = PBH * bh + 4 * kg + i;
+    const float* gp = gates + (((int64_t)(b < B ? b : 0) * T + t) * D + d) * (3 * PH) + unit[nt];
+    gx[0][nt][i] = gp[0];
+    gx[1][nt][i] = gp[PH];
+    gx[2][nt][i] = gp[2 * PH];
+  };
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fetch_gx(d == 0 ? 0 : T - 1, nt, i);
+
   for (int s = 0; s < T; ++s) {
     const int t = d == 0 ? s : T - 1 - s;
+    const int tnext = d == 0 ? (s + 1 < T ? s + 1 : s) : (s + 1 < T ? T - 2 - s : 0);
     const bf16_t* hcur = hS + (s & 1) * PBH * PHLD;
     bf16_t* hnxt = hS + ((s + 1) & 1) * PBH * PHLD;
-    // The accumulators START from the input-projection pre-activations (r, z) and from b_hn (n gate's
-    // recurrent part), so those never occupy registers of their own; only W_in x + b_in is kept aside.
-    f32x4 acc[PNT], gxn[4];
+    f32x4 acc[PNT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int b = PBH * bh + 4 * kg + i;
-      const float* gp = gates + (((int64_t)(b < B ? b : 0) * T + t) * D + d) * (3 * PH);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        acc[nt][i] = gp[unit[nt]];
-        acc[4 + nt][i] = gp[PH + unit[nt]];
-        gxn[nt][i] = gp[2 * PH + unit[nt]];
-        acc[8 + nt][i] = bhn[nt];
-      }
-    }
+    for (int tl = 0; tl < PNT; ++tl) acc[tl] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < PKS; ++ks) {
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(hcur + col * PHLD + ks * 32 + kg * 8);   // row = batch
@@ -127,6 +139,7 @@ __global__ __launch_bounds__(256, 1) void gru256_fwd_persist_kernel(float* __res
       }
     }
     // ---- gate math: lane holds column = unit, rows = batch 4 kg + i ---------------------------------
+    // (fast exp / reciprocal forms: ~1e-6 relative, far inside the bf16 operands' own rounding)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -134,10 +147,11 @@ __global__ __launch_bounds__(256, 1) void gru256_fwd_persist_kernel(float* __res
         const int b = PBH * bh + 4 * kg + i;
         const bool row_ok = b < B;
         const bool live = row_ok && t < len[i];
-        const float hn = acc[8 + nt][i];
-        const float r = lr_sigmoid(acc[nt][i]);
-        const float z = lr_sigmoid(acc[4 + nt][i]);
-        const float n = tanhf(gxn[nt][i] + r * hn);
+        const float hn = acc[8 + nt][i] + bhn[nt];
+        const float r = __frcp_rn(1.f + __expf(-(gx[0][nt][i] + acc[nt][i])));
+        const float z = __frcp_rn(1.f + __expf(-(gx[1][nt][i] + acc[4 + nt][i])));
+        const float n = 2.f * __frcp_rn(1.f + __expf(-2.f * (gx[2][nt][i] + r * hn))) - 1.f;
+        fetch_gx(tnext, nt, i);
         const float h = live ? (1.f - z) * n + z * hreg[nt][i] : 0.f;
         hreg[nt][i] = h;
         hnxt[(4 * kg + i) * PHLD + unit[nt]] = f2bf(h);

@@ -182,9 +182,6 @@ class PixelLipReader(nn.Module):
     # (K = 3456 features) on the bf16 matrix cores with hi/lo split fp32 operands
     encoder.input_projection = 'bf16x3'
     encoder.input_is_bf16 = True
-    # ... and run each supported recurrent layer pass as one launch with bf16 W_hh (BASELINE configs[1]:
-    # "3Dconv+BiGRU+CTC bf16"); unsupported shapes keep the step-per-launch fp32 kernels
-    encoder.recurrence = 'bf16'
   def forward(self, clips, frame_lens, max_len=None):
     feats = self.frontend(clips)
     B, T, F = feats.shape
