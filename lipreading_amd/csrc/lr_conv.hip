@@ -386,37 +386,70 @@ constexpr int C1_K = 304;                      // 75 taps x 4 channels = 300, pa
 constexpr int C1_WLD = C1_K + 8;               // weight row in LDS (624 B: conflict-free b128 reads)
 constexpr int C1_PATCH = 3 * C1_P * C1_P * 4;  // bf16 elements of the patch
 
-// tap t = (kt*5 + kh)*5 + kw  ->  element offset inside the patch [3][35][35][4]
-__device__ __forceinline__ int c1_tap_off(int tap) {
+constexpr int C1_FPIX = C1_P * C1_P;          // pixels of one patch frame (1225)
+constexpr int kC1WgradWgs = 768;              // persistent workgroups of the first layer's weight gradient
+
+// The patch is a RING of three frames: a workgroup walks the tiles (t = 0, 1, 2, ...) of one spatial
+// window of one clip in order, so tile t only has to bring frame t+1 — frames t-1 and t are already
+// in LDS (FETCH_SIZE with a fresh 3-frame patch per tile: 3.4x the input; with the ring ~1.25x).
+// Frame ti of the clip lives in slot (ti + 1) % 3, i.e. temporal tap kt of tile t in slot (t + kt) % 3.
+// tap = (kt*5 + kh)*5 + kw  ->  element offset inside the patch [3 slots][35][35][4]
+__device__ __forceinline__ int c1_tap_off(int tap, int t) {
   if (tap >= 75) return -1;
   const int kw = tap % 5, kh = (tap / 5) % 5, kt = tap / 25;
-  return ((kt * C1_P + kh) * C1_P + kw) * 4;
+  return ((((t + kt) % 3) * C1_P + kh) * C1_P + kw) * 4;
 }
 
-// The patch of tile (f, ty, tx): frames t-1..t+1 of clip b, rows 2*y0-2.., cols 2*x0-2.. — 3675
-// 8-byte pixels, 15 per thread.  Split into "issue every global load" and "write to LDS" so that a
-// tile's loads are all in flight at once (a load->store loop would serialise ~15 round trips) and
-// the NEXT tile's loads can overlap the current tile's MFMAs.
-constexpr int C1_NPU = (3 * C1_P * C1_P + 255) / 256;   // 15
-__device__ __forceinline__ void c1_patch_issue(const bf16_t* __restrict__ X, uint2 (&rp)[C1_NPU], int f, int T,
-                                               int Hin, int Win, int y0, int x0, int tid) {
-  const int t = f % T;
+// Frame kt (0..2) of tile (f = b*T + t, rows 2*y0-2.., cols 2*x0-2..): 1225 8-byte pixels, 5 per
+// thread.  Split into "issue every global load" and "write to LDS" so that the NEXT tile's new frame
+// (kt = 2) flies while the current tile's MFMAs run; only 5 staging registers stay live across the
+// MFMA loop (15 for a whole patch cost a wave of occupancy).
+constexpr int C1_NPU = (C1_FPIX + 255) / 256;   // 5
+__device__ __forceinline__ void c1_frame_issue(const bf16_t* __restrict__ X, uint2 (&rp)[C1_NPU], int f, int T,
+                                               int Hin, int Win, int y0, int x0, int tid, int kt) {
+  const int ti = f % T + kt - 1;
+  const bool frame_ok = ti >= 0 && ti < T;
 #pragma unroll
   for (int i = 0; i < C1_NPU; ++i) {
     const int e = tid + i * 256;
-    const int px = e % C1_P, py = (e / C1_P) % C1_P, kt = e / (C1_P * C1_P);
-    const int ti = t + kt - 1, yi = 2 * y0 - 2 + py, xi = 2 * x0 - 2 + px;
+    const int px = e % C1_P, py = e / C1_P;
+    const int yi = 2 * y0 - 2 + py, xi = 2 * x0 - 2 + px;
     rp[i] = make_uint2(0u, 0u);
-    if (kt < 3 && ti >= 0 && ti < T && yi >= 0 && yi < Hin && xi >= 0 && xi < Win)
+    if (frame_ok && e < C1_FPIX && yi >= 0 && yi < Hin && xi >= 0 && xi < Win)
       rp[i] = *reinterpret_cast<const uint2*>(X + ((((int64_t)(f + kt - 1)) * Hin + yi) * Win + xi) * 4);
   }
 }
-__device__ __forceinline__ void c1_patch_store(bf16_t* Ps, const uint2 (&rp)[C1_NPU], int tid) {
+__device__ __forceinline__ void c1_frame_store(bf16_t* Ps, const uint2 (&rp)[C1_NPU], int tid, int t, int kt) {
+  bf16_t* slot = Ps + ((t + kt) % 3) * C1_FPIX * 4;
 #pragma unroll
   for (int i = 0; i < C1_NPU; ++i) {
     const int e = tid + i * 256;
-    if (e < 3 * C1_P * C1_P) *reinterpret_cast<uint2*>(&Ps[e * 4]) = rp[i];
+    if (e < C1_FPIX) *reinterpret_cast<uint2*>(&slot[e * 4]) = rp[i];
   }
+}
+// first tile of a walk: frames t-1 and t are fetched synchronously (once per ~28 tiles)
+__device__ __forceinline__ void c1_walk_start(const bf16_t* __restrict__ X, bf16_t* Ps, int f, int T, int Hin,
+                                              int Win, int y0, int x0, int tid) {
+#pragma unroll 1
+  for (int kt = 0; kt < 2; ++kt) {
+    uint2 r[C1_NPU];
+    c1_frame_issue(X, r, f, T, Hin, Win, y0, x0, tid, kt);
+    c1_frame_store(Ps, r, tid, f % T, kt);
+  }
+}
+
+// Walk order of the persistent first-layer kernels: tile q = seq*T + t with seq = (clip, ty, tx);
+// workgroup w owns the contiguous range [w*N/G, (w+1)*N/G).
+struct C1Tile { int f, t, y0, x0; };
+__device__ __forceinline__ C1Tile c1_tile(int64_t q, int T, int tiles_x, int tiles_y) {
+  C1Tile r;
+  const int64_t seq = q / T;
+  r.t = (int)(q - seq * T);
+  const int tx = (int)(seq % tiles_x), ty = (int)((seq / tiles_x) % tiles_y);
+  r.f = (int)(seq / ((int64_t)tiles_x * tiles_y)) * T + r.t;
+  r.y0 = ty * C1_T;
+  r.x0 = tx * C1_T;
+  return r;
 }
 
 // Persistent workgroups: the 32 x 300 weights are staged once, then tiles are streamed.
@@ -437,7 +470,6 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
   const int lr = lane & 31, lk = lane >> 5;
   const int tiles_x = (Wo + C1_T - 1) / C1_T, tiles_y = (Ho + C1_T - 1) / C1_T;
   const int64_t ntiles = (int64_t)frames * tiles_x * tiles_y;
-  if (tid < 80) tapoff[tid] = c1_tap_off(tid);
   // weights: row n = 300 bf16 = 75 x 8 bytes; pad columns 300..311 with zeros
   for (int e = tid; e < 32 * (C1_WLD / 4); e += 256) {
     const int n = e / (C1_WLD / 4), u = e - n * (C1_WLD / 4);
@@ -455,22 +487,25 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
     pixoff[i] = ((2 * yl) * C1_P + 2 * xl) * 4;
   }
   const float bv = bias ? bias[lr] : 0.f;
-  uint2 rp[C1_NPU];
-  int64_t q = blockIdx.x;
-  if (q < ntiles) {
-    const int tx = (int)(q % tiles_x), ty = (int)((q / tiles_x) % tiles_y), f = (int)(q / (tiles_x * tiles_y));
-    c1_patch_issue(X, rp, f, T, Hin, Win, ty * C1_T, tx * C1_T, tid);
+  uint2 rp[C1_NPU];             // frame t+1 of the tile about to be computed
+  const int64_t q_end = ntiles * (blockIdx.x + 1) / gridDim.x;
+  const int64_t q_begin = ntiles * blockIdx.x / gridDim.x;
+  int64_t q = q_begin;
+  if (q < q_end) {
+    const C1Tile c = c1_tile(q, T, tiles_x, tiles_y);
+    c1_frame_issue(X, rp, c.f, T, Hin, Win, c.y0, c.x0, tid, 2);
   }
-  for (; q < ntiles; q += gridDim.x) {
-    const int tx = (int)(q % tiles_x), ty = (int)((q / tiles_x) % tiles_y), f = (int)(q / (tiles_x * tiles_y));
-    const int y0 = ty * C1_T, x0 = tx * C1_T;
+  for (; q < q_end; ++q) {
+    const C1Tile c = c1_tile(q, T, tiles_x, tiles_y);
+    const int f = c.f, y0 = c.y0, x0 = c.x0;
     __syncthreads();            // previous tile's fragments are no longer being read
-    c1_patch_store(Ps, rp, tid);
+    if (q == q_begin || c.t == 0) c1_walk_start(X, Ps, f, T, Hin, Win, y0, x0, tid);
+    c1_frame_store(Ps, rp, tid, c.t, 2);
+    if (tid < 80) tapoff[tid] = c1_tap_off(tid, c.t);
     __syncthreads();
-    const int64_t qn = q + gridDim.x;
-    if (qn < ntiles) {          // next tile's loads fly while this tile's MFMAs run
-      const int txn = (int)(qn % tiles_x), tyn = (int)((qn / tiles_x) % tiles_y);
-      c1_patch_issue(X, rp, (int)(qn / (tiles_x * tiles_y)), T, Hin, Win, tyn * C1_T, txn * C1_T, tid);
+    if (q + 1 < q_end) {        // next tile's new frame flies while this tile's MFMAs run
+      const C1Tile n = c1_tile(q + 1, T, tiles_x, tiles_y);
+      c1_frame_issue(X, rp, n.f, T, Hin, Win, n.y0, n.x0, tid, 2);
     }
     f32x16 acc[2];
 #pragma unroll
@@ -551,11 +586,6 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
   const int64_t ntiles = (int64_t)frames * tiles_x * tiles_y;
   // column tile jt = wave + 4j covers taps 8jt..8jt+7; this lane sources tap 8jt + 4 colhalf + (sl & 3)
   int tapoff[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int tap = (wave + 4 * j) * 8 + 4 * colhalf + (sl & 3);
-    tapoff[j] = (wave + 4 * j) < 10 ? c1_tap_off(tap) : -1;   // -1: padded column -> the zero zone
-  }
   f32x16 acc[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
@@ -565,10 +595,9 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
 
   uint2 rp[C1_NPU];
   uint4 rz[4];
-  auto issue = [&](int64_t qq) {
-    const int tx = (int)(qq % tiles_x), ty = (int)((qq / tiles_x) % tiles_y), f = (int)(qq / (tiles_x * tiles_y));
-    const int y0 = ty * C1_T, x0 = tx * C1_T;
-    c1_patch_issue(X, rp, f, T, Hin, Win, y0, x0, tid);
+  auto issue = [&](const C1Tile& c) {
+    const int f = c.f, y0 = c.y0, x0 = c.x0;
+    c1_frame_issue(X, rp, f, T, Hin, Win, y0, x0, tid, 2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {   // dZ tile: 256 pixels x 32 channels in 16-byte units
       const int e = tid + i * 256;
@@ -580,18 +609,27 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
   };
   const unsigned char* PsB = reinterpret_cast<const unsigned char*>(Ps);
   const unsigned char* ZsB = reinterpret_cast<const unsigned char*>(Zs);
-  int64_t q = blockIdx.x;
-  if (q < ntiles) issue(q);
-  for (; q < ntiles; q += gridDim.x) {
+  const int64_t q_end = ntiles * (blockIdx.x + 1) / gridDim.x;
+  const int64_t q_begin = ntiles * blockIdx.x / gridDim.x;
+  int64_t q = q_begin;
+  if (q < q_end) issue(c1_tile(q, T, tiles_x, tiles_y));
+  for (; q < q_end; ++q) {
+    const C1Tile c = c1_tile(q, T, tiles_x, tiles_y);
     __syncthreads();
-    c1_patch_store(Ps, rp, tid);
+    if (q == q_begin || c.t == 0) c1_walk_start(X, Ps, c.f, T, Hin, Win, c.y0, c.x0, tid);
+    c1_frame_store(Ps, rp, tid, c.t, 2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = tid + i * 256;
       *reinterpret_cast<uint4*>(&Zs[(e >> 2) * ZLD + (e & 3) * 8]) = rz[i];
     }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int tap = (wave + 4 * j) * 8 + 4 * colhalf + (sl & 3);
+      tapoff[j] = (wave + 4 * j) < 10 ? c1_tap_off(tap, c.t) : -1;   // -1: padded column -> the zero zone
+    }
     __syncthreads();
-    if (q + gridDim.x < ntiles) issue(q + gridDim.x);
+    if (q + 1 < q_end) issue(c1_tile(q + 1, T, tiles_x, tiles_y));
 #pragma unroll 4
     for (int ks = 0; ks < C1_PIX / 16; ++ks) {
       // this lane's source pixel of the two 4-pixel groups: k = lk*8 + {0..3 | 4..7}
@@ -623,16 +661,6 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
         out[((r & 3) + 8 * (r >> 2) + 4 * lk) * 320 + (wave + 4 * j) * 32 + lr] = acc[j][r];
     }
   }
-}
-
-// dW1[n][c][tap] (torch layout [32][3][3][5][5]) (+)= sum_wg slabs[wg][n][tap*4 + c]
-__global__ void conv1_wgrad_reduce_kernel(const float* __restrict__ slabs, int nwg, float* __restrict__ dW,
-                                          int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 32 * 3 * 75) return;
-  const int tap = i % 75, c = (i / 75) % 3, n = i / 225;
-  const float s = strided_sum8(slabs + (int64_t)n * 320 + tap * 4 + c, nwg, 32 * 320);
-  dW[i] = accumulate ? dW[i] + s : s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1101,36 +1129,47 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(const bf16_t* __r
   }
 }
 
-// dW[n][c][kt][kh][kw] (+)= sum_slot slabs[slot*KT + kt][kh*KW + kw][n][c]
-__global__ void conv3d_wgrad_ts_reduce_kernel(const float* __restrict__ slabs, int wgs_per_kt,
-                                              float* __restrict__ dW, int Cout, int Cin, int KT, int khw,
-                                              int accumulate) {
-  const int64_t total = (int64_t)Cout * Cin * KT * khw;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int t2 = (int)(i % khw);
-    const int kt = (int)((i / khw) % KT);
-    const int c = (int)((i / ((int64_t)khw * KT)) % Cin);
-    const int n = (int)(i / ((int64_t)khw * KT * Cin));
-    const float s = strided_sum8(slabs + (((int64_t)kt * khw + t2) * Cout + n) * Cin + c, wgs_per_kt,
-                                 (int64_t)KT * khw * Cout * Cin);
-    dW[i] = accumulate ? dW[i] + s : s;
+// Reduction of the per-workgroup weight-gradient slabs into dW (fp32, torch layout [n][c][kt][kh][kw]).
+// Lanes run over CONSECUTIVE slab elements, so every slab read is a coalesced 256-byte wave load
+// (indexing the threads in dW order instead makes neighbouring lanes 8 kB apart: 5x the bytes and
+// 7x the time, measured with FETCH_SIZE); the scatter is on the small dW side.  blockDim = (64, P):
+// wave y sums slabs y, y+P, ... (8 loads in flight), the P partial sums are combined through LDS in
+// a fixed order, so the result is deterministic.  Slab element e maps to dW as
+//   ts   = 1:  e = ((kt*khw + tap)*Cout + n)*Cin + c           (tap-stationary / transpose-read kernels)
+//   ts   = 0:  e = n*pitch + tap*Cin + c, tap = kt*khw + ...   (im2col-split and conv1 kernels; k >= taps*Cin
+//              and c >= Cin_real are padding and are skipped)
+__global__ __launch_bounds__(1024) void conv_wgrad_slab_reduce_kernel(const float* __restrict__ slabs, int nslabs,
+                                                                      int64_t slab_elems, float* __restrict__ dW,
+                                                                      int ts, int Cout, int Cin, int Cin_real,
+                                                                      int taps, int khw, int pitch,
+                                                                      int accumulate) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x, y = threadIdx.y, P = blockDim.y;
+  const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (e < slab_elems) {
+    const int mine = (nslabs - y + P - 1) / P;   // slabs y, y+P, ...
+    s = strided_sum8(slabs + (int64_t)y * slab_elems + e, mine, (int64_t)P * slab_elems);
   }
-}
-
-// dW[n][c][kt][kh][kw] (fp32, torch layout) (+)= sum_splits slab[split][n][(tap, c)], c < Cin_real
-__global__ void conv3d_wgrad_reduce_kernel(const float* __restrict__ slabs, int splits, float* __restrict__ dW,
-                                           int Cout, int Cin_real, int Cin_pad, int taps, int accumulate) {
-  const int64_t total = (int64_t)Cout * Cin_real * taps;
-  const int Ktot = taps * Cin_pad;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int tap = (int)(i % taps);
-    const int c = (int)((i / taps) % Cin_real);
-    const int n = (int)(i / ((int64_t)taps * Cin_real));
-    const float s = strided_sum8(slabs + (int64_t)n * Ktot + tap * Cin_pad + c, splits, (int64_t)Cout * Ktot);
-    dW[i] = accumulate ? dW[i] + s : s;
+  part[y][lane] = s;
+  __syncthreads();
+  if (y != 0 || e >= slab_elems) return;
+  float tot = part[0][lane];
+  for (int i = 1; i < P; ++i) tot += part[i][lane];
+  int64_t o;
+  if (ts) {
+    const int c = (int)(e % Cin);
+    const int n = (int)((e / Cin) % Cout);
+    const int tap = (int)(e / ((int64_t)Cin * Cout));       // kt*khw + t2: dW's own tap order
+    o = ((int64_t)n * Cin + c) * taps + tap;
+  } else {
+    const int k = (int)(e % pitch);
+    const int n = (int)(e / pitch);
+    const int c = k % Cin, tap = k / Cin;
+    if (tap >= taps || c >= Cin_real) return;
+    o = ((int64_t)n * Cin_real + c) * taps + tap;
   }
+  dW[o] = accumulate ? dW[o] + tot : tot;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1791,7 +1830,7 @@ extern "C" size_t lr_conv3d_wgrad_workspace_bytes(int Cout, int Cin_pad, int KT,
   size_t slab = (size_t)wgrad_splits(Cout, Ktot) * Cout * Ktot;
   const size_t ts = (size_t)KT * kTsWgsPerKt * KH * KW * Cout * Cin_pad;   // tap-stationary path
   if (ts > slab) slab = ts;
-  if (slab < (size_t)512 * 32 * 320) slab = (size_t)512 * 32 * 320;   // first-layer patch kernel
+  if (slab < (size_t)kC1WgradWgs * 32 * 320) slab = (size_t)kC1WgradWgs * 32 * 320;   // first-layer patch kernel
   return (slab + (size_t)kColsumSplits * Cout) * sizeof(float);
 }
 
@@ -1815,7 +1854,7 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
                                    &e0, &e1);
   if (Cin_pad == 4 && Cin_real == 3 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 &&
       ph == 2 && pw == 2) {
-    const int nwg = 512;   // persistent workgroups (2 per CU), partial sums reduced in fixed order
+    const int nwg = kC1WgradWgs;   // persistent workgroups (3 per CU), partial sums reduced in fixed order
     lr_clear_error();
     if (sample) hipExtLaunchKernelGGL(conv1_wgrad_patch_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, e0,
                                       e1, 0, x, dz, slabs, B * T, T, Hin, Win, g.Ho, g.Wo);
@@ -1823,8 +1862,8 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
                             B * T, T, Hin, Win, g.Ho, g.Wo);
     int st = lr_launch_status();
     if (st != LR_OK) return st;
-    LR_LAUNCH(conv1_wgrad_reduce_kernel, dim3((32 * 225 + 255) / 256), dim3(256), 0, stream, (const float*)slabs,
-              nwg, dW, accumulate);
+    LR_LAUNCH(conv_wgrad_slab_reduce_kernel, dim3(32 * 320 / 64), dim3(64, 16), 0, stream, (const float*)slabs, nwg,
+              (int64_t)32 * 320, dW, 0, 32, 4, 3, 75, 25, 320, accumulate);
     st = lr_launch_status();
     if (st != LR_OK || !dbias) return st;
     LR_LAUNCH(colsum_bf16_partial_kernel, dim3(kColsumSplits), dim3(256), 0, stream, dz, g.M, Cout, cpart,
@@ -1865,8 +1904,12 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
 #undef LR_WGTR
       int st = lr_launch_status();
       if (st != LR_OK) return st;
-      LR_LAUNCH(conv3d_wgrad_ts_reduce_kernel, dim3(grid1d((int64_t)Cout * Cin_pad * KT * KH * KW)), dim3(256), 0,
-                stream, (const float*)slabs, kTrSlots, dW, Cout, Cin_pad, KT, KH * KW, accumulate);
+      {
+        const int64_t se = (int64_t)Cout * Cin_pad * KT * KH * KW;
+        LR_LAUNCH(conv_wgrad_slab_reduce_kernel, dim3((unsigned)((se + 63) / 64)), dim3(64, 4), 0, stream,
+                  (const float*)slabs, kTrSlots, se, dW, 1, Cout, Cin_pad, Cin_pad, KT * KH * KW, KH * KW, 0,
+                  accumulate);
+      }
       st = lr_launch_status();
       if (st != LR_OK || !dbias) return st;
       float* cpart2 = slabs + (size_t)3 * kTrSlots * KH * KW * Cout * Cin_pad;
@@ -1915,8 +1958,12 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
       if (launched) {
         int st = lr_launch_status();
         if (st != LR_OK) return st;
-        LR_LAUNCH(conv3d_wgrad_ts_reduce_kernel, dim3(grid1d((int64_t)Cout * Cin_pad * KT * KH * KW)), dim3(256),
-                  0, stream, (const float*)slabs, kTsWgsPerKt, dW, Cout, Cin_pad, KT, KH * KW, accumulate);
+        {
+          const int64_t se = (int64_t)Cout * Cin_pad * KT * KH * KW;
+          LR_LAUNCH(conv_wgrad_slab_reduce_kernel, dim3((unsigned)((se + 63) / 64)), dim3(64, 4), 0, stream,
+                    (const float*)slabs, kTsWgsPerKt, se, dW, 1, Cout, Cin_pad, Cin_pad, KT * KH * KW, KH * KW, 0,
+                    accumulate);
+        }
         st = lr_launch_status();
         if (st != LR_OK || !dbias) return st;
         LR_LAUNCH(colsum_bf16_partial_kernel, dim3(kColsumSplits), dim3(256), 0, stream, dz, g.M, Cout, cpart,
@@ -1952,8 +1999,11 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
   int st = lr_launch_status();
   if (st != LR_OK) return st;
   const int taps = KT * KH * KW;
-  LR_LAUNCH(conv3d_wgrad_reduce_kernel, dim3(grid1d((int64_t)Cout * Cin_real * taps)), dim3(256), 0,
-            stream, (const float*)slabs, splits, dW, Cout, Cin_real, Cin_pad, taps, accumulate);
+  {
+    const int64_t se = (int64_t)Cout * g.Ktot;
+    LR_LAUNCH(conv_wgrad_slab_reduce_kernel, dim3((unsigned)((se + 63) / 64)), dim3(64, 4), 0, stream,
+              (const float*)slabs, splits, se, dW, 0, Cout, Cin_pad, Cin_real, taps, KH * KW, g.Ktot, accumulate);
+  }
   st = lr_launch_status();
   if (st != LR_OK || !dbias) return st;
   LR_LAUNCH(colsum_bf16_partial_kernel, dim3(kColsumSplits), dim3(256), 0, stream, dz, g.M, Cout, cpart,
