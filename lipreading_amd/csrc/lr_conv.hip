@@ -1237,6 +1237,7 @@ constexpr int P2_POS = P2_SLOTS * P2_PH * P2_PW;   // 2016 positions
 constexpr int P2_LDS = P2_POS * 64;                // 129,024 bytes
 constexpr int P2_UNITS = P2_POS * 4;               // 16-byte units
 constexpr int P2_UPT = (P2_UNITS + 255) / 256;     // units per thread: 32 (31.5)
+constexpr int P2_BDIST = 2;                        // taps between a B fragment's load and its use
 
 template <int CG, int NT, bool POOL>
 __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __restrict__ X,
@@ -1246,13 +1247,18 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
                                                             int F, int T, int H, int relu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char patch[];
   constexpr int C = 32 * CG, N = 32 * NT, TAPS = 75;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int htiles = H / P2_TH;
   const int f0 = (int)(blockIdx.x / htiles) * P2_TT, h0 = (int)(blockIdx.x % htiles) * P2_TH;
   const int lr = lane & 31, kg = lane >> 5;
   const int f = f0 + wave;
   const bool fvalid = f < F;
   const int t = f % T;
+  // temporal taps reaching across the clip boundary are skipped: this wave runs tap rows
+  // (dt, dh) = row0 .. row0 + nrow - 1, whole temporal offsets only (wave-uniform, in SGPRs)
+  const int dt_lo = t == 0 ? 1 : 0, dt_hi = t == T - 1 ? 1 : 2;
+  const int row0 = 5 * dt_lo;
+  const int nrow = fvalid ? 5 * (dt_hi - dt_lo + 1) : 0;
 
   f32x16 acc[6][NT];
 #pragma unroll
@@ -1292,45 +1298,75 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
       }
     }
     __syncthreads();
-    // ---- 75 taps out of LDS ----------------------------------------------------------------------
-    const bf16_t* wf = Wf + (int64_t)cg * TAPS * (2 * NT) * 512 + lane * 8;
-    bf16x8 bcur[2][NT], bnext[2][NT];
+    // ---- the taps out of LDS ---------------------------------------------------------------------
+    // One wave per SIMD: nothing hides a latency unless the code does.  The loop body is one row of
+    // five taps (dt, dh fixed; 25 taps per temporal offset, so no remainder and no branch), software
+    // pipelined with static register indices: A fragments are double-buffered per HALF tap (m-tiles
+    // 0-2 / 3-5: one half's reads fly during the other half's 6*NT MFMAs), B fragments sit in a ring
+    // of five taps and are loaded P2_BDIST taps ahead of their use.
+    if (nrow > 0) {
+      const bf16_t* wfb = Wf + ((int64_t)cg * TAPS + 5 * row0) * (2 * NT) * 512 + lane * 8;
+      const int last = 5 * nrow - 1;
+      bf16x8 bq[5][2][NT];
+      bf16x8 a0[6], a1[6];
+      auto load_b = [&](bf16x8 (&bb)[2][NT], int i) {
+        const int ii = i < last ? i : last;
 #pragma unroll
-    for (int kc = 0; kc < 2; ++kc)
+        for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bcur[kc][j] = *reinterpret_cast<const bf16x8*>(wf + (kc * NT + j) * 512);
-    int tap = 0;
-    for (int dt = 0; dt < 3; ++dt) {
-      const bool valid = fvalid && t + dt - 1 >= 0 && t + dt - 1 < T;   // wave-uniform
-      for (int dh = 0; dh < 5; ++dh) {
+          for (int j = 0; j < NT; ++j)
+            bb[kc][j] = *reinterpret_cast<const bf16x8*>(wfb + ((int64_t)ii * 2 * NT + kc * NT + j) * 512);
+      };
+      auto load_a = [&](bf16x8 (&aa)[6], int x, int grp) {   // x = base position + tap offset
+        const int X = x >> 2;
 #pragma unroll
-        for (int dw = 0; dw < 5; ++dw, ++tap) {
-          if (tap + 1 < TAPS) {
+        for (int w3 = 0; w3 < 3; ++w3) {
+          const int wb = 3 * grp + w3;
+          const int sw = (X + wb) & 3;
 #pragma unroll
-            for (int kc = 0; kc < 2; ++kc)
+          for (int kc = 0; kc < 2; ++kc)
+            aa[w3 * 2 + kc] =
+                *reinterpret_cast<const bf16x8*>(patch + (x + 4 * wb) * 64 + (((kc * 2 + kg) ^ sw) << 4));
+        }
+      };
+      auto run = [&](const bf16x8 (&aa)[6], const bf16x8 (&bb)[2][NT], int grp) {
 #pragma unroll
-              for (int j = 0; j < NT; ++j)
-                bnext[kc][j] = *reinterpret_cast<const bf16x8*>(wf + ((int64_t)(tap + 1) * 2 * NT + kc * NT + j) * 512);
-          }
-          if (valid) {
-            const int to = (dt * P2_PH + dh) * P2_PW + dw;
-#pragma unroll
-            for (int wb = 0; wb < 6; ++wb) {
-              const int p = base_p + 4 * wb + to;
-              const int sw = (p >> 2) & 3;
-#pragma unroll
-              for (int kc = 0; kc < 2; ++kc) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(patch + p * 64 + (((kc * 2 + kg) ^ sw) << 4));
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                  acc[wb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bcur[kc][j], acc[wb][j], 0, 0, 0);
-              }
-            }
-          }
+        for (int w3 = 0; w3 < 3; ++w3)
 #pragma unroll
           for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bcur[kc][j] = bnext[kc][j];
+            for (int j = 0; j < NT; ++j)
+              acc[3 * grp + w3][j] =
+                  __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[w3 * 2 + kc], bb[kc][j], acc[3 * grp + w3][j], 0, 0, 0);
+      };
+      auto row_off = [&](int r) {   // patch offset of row r's first tap: r = dt*5 + dh
+        const int rr = row0 + (r < nrow ? r : nrow - 1);
+        return ((rr / 5) * P2_PH + rr % 5) * P2_PW;
+      };
+#pragma unroll
+      for (int d = 0; d < P2_BDIST; ++d) load_b(bq[d], d);
+      load_a(a0, base_p + row_off(0), 0);
+#pragma unroll 1
+      for (int r = 0; r < nrow; ++r) {
+        const int x0 = base_p + row_off(r), xn = base_p + row_off(r + 1);
+#pragma unroll
+        for (int dw = 0; dw < 5; ++dw) {
+          load_b(bq[(dw + P2_BDIST) % 5], 5 * r + dw + P2_BDIST);
+          load_a(a1, x0 + dw, 1);
+          run(a0, bq[dw], 0);
+          load_a(a0, dw < 4 ? x0 + dw + 1 : xn, 0);
+          run(a1, bq[dw], 1);
+        }
+        // The machine scheduler would sink every load next to its use (lowest register pressure);
+        // pin the interleave instead: per half tap, [B loads] then 6 x {1 LDS read, NT MFMAs}.
+#pragma unroll
+        for (int st = 0; st < 10; ++st) {
+          if ((st & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 2 * NT, 0);   // VMEM reads
+#pragma unroll
+          for (int g = 0; g < 6; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);   // MFMA
+          }
         }
       }
     }
