@@ -1268,32 +1268,45 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int base_p = (wave * P2_PH + (lr >> 2)) * P2_PW + (lr & 3);
+  // A row i = lane & 31 of an m-tile is pixel (h, w) = (b1 + 2 b3 + 4 b4, b0 + 2 b2) of the 8 x 4 block
+  // (b_k = bit k of i): the four C/D rows r & 3 a lane holds per register group r >> 2 are then the
+  // 2 x 2 pooling window (h = 2(r>>2) + {0,1}, w = 2 kg + {0,1}) in scan order, so the pooled
+  // epilogue is lane-local.  Lanes that ds_read_b128 serves together still touch 16 different 16-byte
+  // slots of a 256-byte bank line: same-w lanes of a group sit on rows {0,1,6,7} or {2,3,4,5},
+  // 3*row mod 4 all different.
+  const int a_h = ((lr >> 1) & 1) + 2 * (lr >> 3), a_w = (lr & 1) + 2 * ((lr >> 2) & 1);
+  const int base_p = (wave * P2_PH + a_h) * P2_PW + a_w;
   for (int cg = 0; cg < CG; ++cg) {
     if (cg > 0) __syncthreads();   // every wave is done with the previous channel group's patch
-    // ---- load the patch: all of a thread's units are issued before the first is stored ----------
+    // ---- load the patch -------------------------------------------------------------------------
+    // 224 threads cover two patch rows (28 positions x 4 sixteen-byte chunks each) per pass, 36
+    // passes: slot and row of a pass are compile-time, so a unit costs a handful of VALU operations
+    // (decoding a flat unit index cost ~60 and a third of the kernel's VALU work).  Two batches of 18
+    // loads, each issued completely before its first store.
+    {
+      const int rp = tid >= 112 ? 1 : 0, un = tid - 112 * rp;   // row of the pair, unit in the row
+      const int pw = un >> 2, c = un & 3;
+      const bool tvalid = tid < 224 && pw >= 2 && pw < P2_W + 2;
+      const bf16_t* xt = X + ((int64_t)(pw - 2)) * C + cg * 32 + c * 8;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      uint4 v[P2_UPT / 2];
+      for (int half = 0; half < 2; ++half) {
+        uint4 v[18];
 #pragma unroll
-      for (int i = 0; i < P2_UPT / 2; ++i) {
-        const int u = tid + 256 * (half * (P2_UPT / 2) + i);
-        v[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (u < P2_UNITS) {
-          const int p = u >> 2, c = u & 3;
-          const int s = p / (P2_PH * P2_PW), rem = p - s * (P2_PH * P2_PW);
-          const int ph = rem / P2_PW, pw = rem - ph * P2_PW;
-          const int ff = f0 - 1 + s, hh = h0 - 2 + ph, ww = pw - 2;
-          if (ff >= 0 && ff < F && hh >= 0 && hh < H && ww >= 0 && ww < P2_W)
-            v[i] = *reinterpret_cast<const uint4*>(X + (((int64_t)ff * H + hh) * P2_W + ww) * C + cg * 32 + c * 8);
+        for (int i = 0; i < 18; ++i) {
+          const int k = half * 18 + i;            // pass: patch rows 2k, 2k+1
+          const int s = k / 6, ph = 2 * (k % 6) + rp;
+          const int ff = f0 - 1 + s, hh = h0 - 2 + ph;
+          v[i] = make_uint4(0u, 0u, 0u, 0u);
+          if (tvalid && ff >= 0 && ff < F && hh >= 0 && hh < H)
+            v[i] = *reinterpret_cast<const uint4*>(xt + ((int64_t)ff * H + hh) * (P2_W * C));
         }
-      }
+        if (tid < 224) {
 #pragma unroll
-      for (int i = 0; i < P2_UPT / 2; ++i) {
-        const int u = tid + 256 * (half * (P2_UPT / 2) + i);
-        if (u < P2_UNITS) {
-          const int p = u >> 2, c = u & 3;
-          *reinterpret_cast<uint4*>(patch + p * 64 + ((c ^ ((p >> 2) & 3)) << 4)) = v[i];
+          for (int i = 0; i < 18; ++i) {
+            const int k = half * 18 + i;
+            const int pp = (2 * k + rp) * P2_PW + pw;
+            *reinterpret_cast<uint4*>(patch + pp * 64 + ((c ^ ((pp >> 2) & 3)) << 4)) = v[i];
+          }
         }
       }
     }
@@ -1371,11 +1384,12 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
       }
     }
   }
-  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -------------------
+  // ---- epilogue: C/D layout col = lane&31, row i = (r&3) + 8*(r>>2) + 4*kg -> pixel (h, w) above ----
   if (POOL) {
-    // ReLU -> MaxPool((1,2,2)) in registers: tile row q = (r&3) + 8(r>>2) + 4kg is pixel
-    // (h = q>>2, w = q&3), so a window's two rows are the same register of lanes l and l^32 and its
-    // two columns registers r, r+1 (r even).  Output: pooled value + position of the first maximum.
+    // ReLU -> MaxPool((1,2,2)) in registers: registers 4g .. 4g+3 of an accumulator are the window
+    // (h = 2g + {0,1}, w = 2kg + {0,1}) in row-major scan order.  Output: pooled value + position of
+    // the first maximum (torch's rule), compared on the values that would have been stored.
+    if (!fvalid) return;
     const int Hp = H >> 1;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -1384,23 +1398,18 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
 #pragma unroll
       for (int wb = 0; wb < 6; ++wb)
 #pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4)
+        for (int g = 0; g < 4; ++g) {
+          float best = bf2f(f2bf(fmaxf(acc[wb][j][4 * g] + bv, 0.f)));
+          int arg = 0;
 #pragma unroll
-          for (int pp = 0; pp < 2; ++pp) {
-            const int r0 = 4 * i4 + 2 * pp;
-            const float v0 = bf2f(f2bf(fmaxf(acc[wb][j][r0] + bv, 0.f)));
-            const float v1 = bf2f(f2bf(fmaxf(acc[wb][j][r0 + 1] + bv, 0.f)));
-            const float mine = v1 > v0 ? v1 : v0;
-            const int marg = v1 > v0 ? 1 : 0;
-            const float other = __shfl_xor(mine, 32, 64);    // the other row of the window
-            const int oarg = __shfl_xor(marg, 32, 64);
-            if (kg == 0 && fvalid) {                          // kg = 0 holds the even row: scan order first
-              const bool low = other > mine;
-              const int64_t o = ((((int64_t)f * Hp + (h0 >> 1) + i4) * (P2_W / 2)) + 2 * wb + pp) * N + n;
-              Y[o] = f2bf(low ? other : mine);
-              code[o] = (unsigned char)(low ? 2 + oarg : marg);
-            }
+          for (int q = 1; q < 4; ++q) {
+            const float v = bf2f(f2bf(fmaxf(acc[wb][j][4 * g + q] + bv, 0.f)));
+            if (v > best) { best = v; arg = q; }
           }
+          const int64_t o = ((((int64_t)f * Hp + (h0 >> 1) + g) * (P2_W / 2)) + 2 * wb + kg) * N + n;
+          Y[o] = (bf16_t)(__builtin_bit_cast(unsigned, best) >> 16);
+          code[o] = (unsigned char)arg;
+        }
     }
     return;
   }
@@ -1413,8 +1422,7 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
     for (int wb = 0; wb < 6; ++wb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int q = (r & 3) + 8 * (r >> 2) + 4 * kg;   // row of the MFMA tile: 8 rows x 4 columns
-        const int hh = h0 + (q >> 2), ww = 4 * wb + (q & 3);
+        const int hh = h0 + ((r >> 1) & 1) + 2 * (r >> 2), ww = 4 * wb + (r & 1) + 2 * kg;
         float v = acc[wb][j][r] + bv;
         if (relu) v = fmaxf(v, 0.f);
         Y[(((int64_t)f * H + hh) * P2_W + ww) * N + n] = f2bf(v);
