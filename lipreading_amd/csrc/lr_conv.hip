@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256, 1) void conv_patch16_kernel(const bf16_t* __re
                                                               int F, int T, int relu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char patch[];
   constexpr int C = 32 * CG, N = 16 * NT16, TAPS = 27;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int f0 = (int)blockIdx.x * P3_TT;
   const int rl = lane & 15, kg = lane >> 4;
   const int f = f0 + wave;
@@ -847,32 +847,36 @@ __global__ __launch_bounds__(256, 1) void conv_patch16_kernel(const bf16_t* __re
 #pragma unroll
     for (int j = 0; j < NT16; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // row tile mb = (hb, wb): rows r -> (h = 4hb + r/4, w = 4wb + r%4)
-  const int base_p = (wave * P3_PH + (rl >> 2)) * P3_PW + (rl & 3);
+  // row tile mb = (hb, wb); A row i = lane & 15 is pixel (h, w) = (4hb + b1 + 2 b3, 4wb + b0 + 2 b2)
+  // (b_k = bit k of i), so the four D rows 4kg .. 4kg+3 a lane holds are the 2 x 2 pooling window
+  // (h = 2(kg>>1) + {0,1}, w = 2(kg&1) + {0,1}) in scan order and the pooled epilogue is lane-local.
+  // The 16 lanes ds_read_b128 serves together still cover the 4 x 4 block once, and same-column
+  // lanes land on 4 different chunks for any tap shift.
+  const int base_p = (wave * P3_PH + ((rl >> 1) & 1) + 2 * (rl >> 3)) * P3_PW + (rl & 1) + 2 * ((rl >> 2) & 1);
   for (int cg = 0; cg < CG; ++cg) {
     if (cg > 0) __syncthreads();
+    // patch load: a wave covers one 16-position patch row (64 sixteen-byte units) per pass, so the
+    // row / slot decode is wave-uniform scalar work; 21 passes in 3 batches, each fully in flight
+    {
+      const int pw = (tid & 63) >> 2, c = tid & 3;
+      const bool tvalid = pw >= 1 && pw <= P3_W;
+      const bf16_t* xt = X + ((int64_t)(pw - 1)) * C + cg * 32 + c * 8;
 #pragma unroll
-    for (int part = 0; part < 3; ++part) {   // 3 x 7 units per thread, each batch fully in flight
-      uint4 v[7];
+      for (int part = 0; part < 3; ++part) {
+        uint4 v[7];
 #pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        const int u = tid + 256 * (part * 7 + i);
-        v[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (u < P3_UNITS) {
-          const int p = u >> 2, c = u & 3;
-          const int s = p / (P3_PH * P3_PW), rem = p - s * (P3_PH * P3_PW);
-          const int ph = rem / P3_PW, pw = rem - ph * P3_PW;
-          const int ff = f0 - 1 + s, hh = ph - 1, ww = pw - 1;
-          if (ff >= 0 && ff < F && hh >= 0 && hh < P3_H && ww >= 0 && ww < P3_W)
-            v[i] = *reinterpret_cast<const uint4*>(X + (((int64_t)ff * P3_H + hh) * P3_W + ww) * C + cg * 32 + c * 8);
+        for (int i = 0; i < 7; ++i) {
+          const int R = 4 * (part * 7 + i) + wave;          // patch row 0..83
+          const int s = R / P3_PH, ph = R - s * P3_PH;
+          const int ff = f0 - 1 + s, hh = ph - 1;
+          v[i] = make_uint4(0u, 0u, 0u, 0u);
+          if (tvalid && ff >= 0 && ff < F && hh >= 0 && hh < P3_H)
+            v[i] = *reinterpret_cast<const uint4*>(xt + ((int64_t)ff * P3_H + hh) * (P3_W * C));
         }
-      }
 #pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        const int u = tid + 256 * (part * 7 + i);
-        if (u < P3_UNITS) {
-          const int p = u >> 2, c = u & 3;
-          *reinterpret_cast<uint4*>(patch + p * 64 + ((c ^ ((p >> 3) & 3)) << 4)) = v[i];
+        for (int i = 0; i < 7; ++i) {
+          const int pp = (4 * (part * 7 + i) + wave) * P3_PW + pw;
+          *reinterpret_cast<uint4*>(patch + pp * 64 + ((c ^ ((pp >> 3) & 3)) << 4)) = v[i];
         }
       }
     }
@@ -909,36 +913,31 @@ __global__ __launch_bounds__(256, 1) void conv_patch16_kernel(const bf16_t* __re
       }
     }
   }
-  // ---- epilogue: D layout of 16x16: col = lane & 15, rows 4*(lane >> 4) + i -> (h = 4hb + (lane>>4), w = 4wb + i)
+  // ---- epilogue: D layout of 16x16: col = lane & 15, rows 4kg + i -> pixel (h, w) of the mapping above
+  if (!fvalid) return;
   if (POOL) {
-    // ReLU -> MaxPool((1,2,2)): a window's two columns are registers i, i+1 (i even), its two rows the
-    // same registers of lanes l and l ^ 16
+    // ReLU -> MaxPool((1,2,2)) in registers: the lane's four rows are one window in scan order
 #pragma unroll
     for (int j = 0; j < NT16; ++j) {
       const int n = j * 16 + rl;
       const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-      for (int mb = 0; mb < 9; ++mb)
+      for (int mb = 0; mb < 9; ++mb) {
+        float best = bf2f(f2bf(fmaxf(acc[mb][j][0] + bv, 0.f)));
+        int arg = 0;
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-          const float v0 = bf2f(f2bf(fmaxf(acc[mb][j][2 * pp] + bv, 0.f)));
-          const float v1 = bf2f(f2bf(fmaxf(acc[mb][j][2 * pp + 1] + bv, 0.f)));
-          const float mine = v1 > v0 ? v1 : v0;
-          const int marg = v1 > v0 ? 1 : 0;
-          const float other = __shfl_xor(mine, 16, 64);
-          const int oarg = __shfl_xor(marg, 16, 64);
-          if ((kg & 1) == 0 && fvalid) {   // even row of the window: first in scan order
-            const bool low = other > mine;
-            const int hp = 2 * (mb / 3) + (kg >> 1), wp = 2 * (mb % 3) + pp;
-            const int64_t o = (((int64_t)f * (P3_H / 2) + hp) * (P3_W / 2) + wp) * N + n;
-            Y[o] = f2bf(low ? other : mine);
-            code[o] = (unsigned char)(low ? 2 + oarg : marg);
-          }
+        for (int q = 1; q < 4; ++q) {
+          const float v = bf2f(f2bf(fmaxf(acc[mb][j][q] + bv, 0.f)));
+          if (v > best) { best = v; arg = q; }
         }
+        const int hp = 2 * (mb / 3) + (kg >> 1), wp = 2 * (mb % 3) + (kg & 1);
+        const int64_t o = (((int64_t)f * (P3_H / 2) + hp) * (P3_W / 2) + wp) * N + n;
+        Y[o] = (bf16_t)(__builtin_bit_cast(unsigned, best) >> 16);
+        code[o] = (unsigned char)arg;
+      }
     }
     return;
   }
-  if (!fvalid) return;
 #pragma unroll
   for (int j = 0; j < NT16; ++j) {
     const int n = j * 16 + rl;
@@ -947,7 +946,7 @@ __global__ __launch_bounds__(256, 1) void conv_patch16_kernel(const bf16_t* __re
     for (int mb = 0; mb < 9; ++mb)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int hh = 4 * (mb / 3) + kg, ww = 4 * (mb % 3) + i;
+        const int hh = 4 * (mb / 3) + 2 * (kg >> 1) + (i >> 1), ww = 4 * (mb % 3) + 2 * (kg & 1) + (i & 1);
         float v = acc[mb][j][i] + bv;
         if (relu) v = fmaxf(v, 0.f);
         Y[(((int64_t)f * P3_H + hh) * P3_W + ww) * N + n] = f2bf(v);
