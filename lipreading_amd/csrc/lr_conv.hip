@@ -1003,11 +1003,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(const bf16_t* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
-  // this wave's n-units (tap, 32-channel plane): LDS offset of the tap shift
+  // this wave's n-units (tap, 32-channel plane): LDS offset of the tap shift.  Every wave runs UPW
+  // units; where NU is not a multiple of 4 the waves that would idle at the tile barrier anyway
+  // repeat the last unit instead (result not stored), which keeps the step loop free of branches.
   int uoff[UPW];
 #pragma unroll
   for (int j = 0; j < UPW; ++j) {
-    const int u = wave + 4 * j, tap = u / CH, plane = u - tap * CH;
+    const int u = wave + 4 * j < NU ? wave + 4 * j : NU - 1;
+    const int tap = u / CH, plane = u - tap * CH;
     uoff[j] = plane * XPOS * 64 + ((tap / KW) * PW + tap % KW) * 64;
   }
   const int sl = lane & 15, kg = lane >> 5;
@@ -1081,8 +1084,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(const bf16_t* __r
     const bool has_next = tile + kTrSlots < ntile;
     if (has_next) issue(tile + kTrSlots);
     const unsigned char* base = lds + cur * BUF;
-#pragma unroll
-    for (int st = 0; st < STEPS; ++st) {   // unrolled: addresses fold to constants, reads of step st+1 overlap MFMAs of st
+    // One wave per SIMD: the fragment reads of step st+1 must be in flight during the MFMAs of step
+    // st, or every MFMA pair waits out an LDS round trip (SQ_WAIT_ANY was 40% of the wave cycles with
+    // the reads where the compiler puts them, next to their use).  Fully unrolled, fragments double
+    // buffered by step parity, and the interleave pinned with sched_group_barrier: one transpose
+    // read between consecutive MFMAs.
+    constexpr int NM = UPW * MT, ND = 2 * (MT + UPW);   // MFMAs / LDS reads per step
+    static_assert(ND >= NM, "the pinned interleave assumes at least one read per MFMA");
+    bf16x8 fa[2][MT], fb[2][UPW];
+    auto load_step = [&](int st, bf16x8 (&aa)[MT], bf16x8 (&bb)[UPW]) {
       // the lane's two position groups of this k16 step: g = 4 st + 2 kg + {0, 1}
       int za[2], xa[2];
 #pragma unroll
@@ -1093,19 +1103,32 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(const bf16_t* __r
         za[hh] = XBYTES + ((sf * TH + h) * W + w0) * 64 + laneoff;
         xa[hh] = ((sf * PH + h) * PW + w0) * 64 + laneoff;
       }
-      bf16x8 a[MT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = lds_tr_pair(base, za[0] + i * ZPOS * 64, za[1] + i * ZPOS * 64);
+      for (int i = 0; i < MT; ++i) aa[i] = lds_tr_pair(base, za[0] + i * ZPOS * 64, za[1] + i * ZPOS * 64);
 #pragma unroll
-      for (int j = 0; j < UPW; ++j) {
-        if (wave + 4 * j < NU) {   // wave-uniform
-          const bf16x8 b = lds_tr_pair(base, xa[0] + uoff[j], xa[1] + uoff[j]);
+      for (int j = 0; j < UPW; ++j) bb[j] = lds_tr_pair(base, xa[0] + uoff[j], xa[1] + uoff[j]);
+    };
+    load_step(0, fa[0], fb[0]);
 #pragma unroll
-          for (int i = 0; i < MT; ++i)
-            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b, acc[j][i], 0, 0, 0);
-        }
+    for (int st = 0; st < STEPS; ++st) {
+      if (st + 1 < STEPS) load_step(st + 1, fa[(st + 1) & 1], fb[(st + 1) & 1]);
+#pragma unroll
+      for (int j = 0; j < UPW; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st & 1][i], fb[st & 1][j], acc[j][i], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);          // step 0's fragments
+#pragma unroll
+    for (int st = 0; st + 1 < STEPS; ++st) {
+      __builtin_amdgcn_sched_group_barrier(0x100, ND - NM, 0);
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA of step st
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // a read of step st + 1
       }
     }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);          // last step
     if (has_next) deposit(cur ^ 1);
     __syncthreads();   // buffer `cur` is free again; the next tile is in place
   }
