@@ -441,12 +441,13 @@ __device__ __forceinline__ void c1_walk_start(const bf16_t* __restrict__ X, bf16
 // Walk order of the persistent first-layer kernels: tile q = seq*T + t with seq = (clip, ty, tx);
 // workgroup w owns the contiguous range [w*N/G, (w+1)*N/G).
 struct C1Tile { int f, t, y0, x0; };
-__device__ __forceinline__ C1Tile c1_tile(int64_t q, int T, int tiles_x, int tiles_y) {
+__device__ __forceinline__ C1Tile c1_tile(int64_t q64, int T, int tiles_x, int tiles_y) {
   C1Tile r;
-  const int64_t seq = q / T;
-  r.t = (int)(q - seq * T);
-  const int tx = (int)(seq % tiles_x), ty = (int)((seq / tiles_x) % tiles_y);
-  r.f = (int)(seq / ((int64_t)tiles_x * tiles_y)) * T + r.t;
+  const unsigned q = (unsigned)q64;   // tile counts stay far below 2^31: 32-bit divisions
+  const unsigned seq = q / (unsigned)T;
+  r.t = (int)(q - seq * (unsigned)T);
+  const int tx = (int)(seq % (unsigned)tiles_x), ty = (int)((seq / (unsigned)tiles_x) % (unsigned)tiles_y);
+  r.f = (int)(seq / (unsigned)(tiles_x * tiles_y)) * T + r.t;
   r.y0 = ty * C1_T;
   r.x0 = tx * C1_T;
   return r;
@@ -465,7 +466,6 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
                                                               int Hin, int Win, int Ho, int Wo, int relu) {
   __shared__ __attribute__((aligned(16))) bf16_t Ps[C1_PATCH + 8];
   __shared__ __attribute__((aligned(16))) bf16_t Ws[32 * C1_WLD];
-  __shared__ int tapoff[80];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lk = lane >> 5;
   const int tiles_x = (Wo + C1_T - 1) / C1_T, tiles_y = (Ho + C1_T - 1) / C1_T;
@@ -501,7 +501,6 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
     __syncthreads();            // previous tile's fragments are no longer being read
     if (q == q_begin || c.t == 0) c1_walk_start(X, Ps, f, T, Hin, Win, y0, x0, tid);
     c1_frame_store(Ps, rp, tid, c.t, 2);
-    if (tid < 80) tapoff[tid] = c1_tap_off(tid, c.t);
     __syncthreads();
     if (q + 1 < q_end) {        // next tile's new frame flies while this tile's MFMAs run
       const C1Tile n = c1_tile(q + 1, T, tiles_x, tiles_y);
@@ -512,19 +511,49 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-#pragma unroll 1
-    for (int ks = 0; ks < C1_K / 16; ++ks) {
-      const int tap0 = ks * 4 + lk * 2;
-      const int o0 = tapoff[tap0], o1 = tapoff[tap0 + 1];
-      const bf16x8 b = *reinterpret_cast<const bf16x8*>(&Ws[lr * C1_WLD + ks * 16 + lk * 8]);
+    // 19 k steps of 16 (4 taps x 4 channels), fully unrolled: a step's taps are compile-time for
+    // each half of the wave (lk), so a fragment address is one select + one add (no table lookup
+    // in front of every read), and the fragments of step ks+1 are read during the MFMAs of step ks.
+    const int so0 = ((c.t + 0) % 3) * C1_FPIX * 4, so1 = ((c.t + 1) % 3) * C1_FPIX * 4,
+              so2 = ((c.t + 2) % 3) * C1_FPIX * 4;   // ring slot of temporal tap kt (elements)
+    auto tap_elem = [&](int tap) {   // compile-time tap -> element offset in the patch (uniform)
+      const int kw = tap % 5, kh = (tap / 5) % 5, kt = tap / 25;
+      return (kt == 0 ? so0 : kt == 1 ? so1 : so2) + (kh * C1_P + kw) * 4;
+    };
+    uint2 alo[2][2], ahi[2][2];
+    bf16x8 bw[2];
+    auto load_k = [&](int ks, uint2 (&lo)[2], uint2 (&hi)[2], bf16x8& b) {
+      // lk = 0: taps 4ks, 4ks+1;  lk = 1: taps 4ks+2, 4ks+3 (tap 75 = zero padding)
+      const int e0 = lk ? tap_elem(4 * ks + 2) : tap_elem(4 * ks);
+      const bool pad1 = 4 * ks + 3 >= 75;
+      const int e1 = lk ? (pad1 ? 0 : tap_elem(pad1 ? 0 : 4 * ks + 3)) : tap_elem(4 * ks + 1);
+      b = *reinterpret_cast<const bf16x8*>(&Ws[lr * C1_WLD + ks * 16 + lk * 8]);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const uint2 lo = *reinterpret_cast<const uint2*>(&Ps[o0 >= 0 ? pixoff[i] + o0 : C1_PATCH]);
-        const uint2 hi = *reinterpret_cast<const uint2*>(&Ps[o1 >= 0 ? pixoff[i] + o1 : C1_PATCH]);
-        const uint4 av = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b, acc[i], 0, 0, 0);
+        lo[i] = *reinterpret_cast<const uint2*>(&Ps[pixoff[i] + e0]);
+        hi[i] = *reinterpret_cast<const uint2*>(&Ps[(pad1 && lk) ? C1_PATCH : pixoff[i] + e1]);
+      }
+    };
+    constexpr int KS = C1_K / 16;
+    load_k(0, alo[0], ahi[0], bw[0]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) load_k(ks + 1, alo[(ks + 1) & 1], ahi[(ks + 1) & 1], bw[(ks + 1) & 1]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint4 av = make_uint4(alo[ks & 1][i].x, alo[ks & 1][i].y, ahi[ks & 1][i].x, ahi[ks & 1][i].y);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bw[ks & 1], acc[i], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+#pragma unroll
+    for (int ks = 0; ks + 1 < KS; ++ks) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
     if (POOL) {
       // row tile = 2 output rows x 16 columns: registers r and r + 8 are vertical neighbours,
       // r and r + 1 (r even) horizontal ones
