@@ -387,7 +387,7 @@ constexpr int C1_WLD = C1_K + 8;               // weight row in LDS (624 B: conf
 constexpr int C1_PATCH = 3 * C1_P * C1_P * 4;  // bf16 elements of the patch
 
 constexpr int C1_FPIX = C1_P * C1_P;          // pixels of one patch frame (1225)
-constexpr int kC1WgradWgs = 768;              // persistent workgroups of the first layer's weight gradient
+constexpr int kC1WgradWgs = 512;              // persistent workgroups of the first layer's weight gradient
 
 // The patch is a RING of three frames: a workgroup walks the tiles (t = 0, 1, 2, ...) of one spatial
 // window of one clip in order, so tile t only has to bring frame t+1 — frames t-1 and t are already
@@ -614,7 +614,6 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
   const int tiles_x = (Wo + C1_T - 1) / C1_T, tiles_y = (Ho + C1_T - 1) / C1_T;
   const int64_t ntiles = (int64_t)frames * tiles_x * tiles_y;
   // column tile jt = wave + 4j covers taps 8jt..8jt+7; this lane sources tap 8jt + 4 colhalf + (sl & 3)
-  int tapoff[3];
   f32x16 acc[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
@@ -652,15 +651,23 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
       const int e = tid + i * 256;
       *reinterpret_cast<uint4*>(&Zs[(e >> 2) * ZLD + (e & 3) * 8]) = rz[i];
     }
+    // byte offset of this lane's tap per column tile, and a mask that drops the pixel offset for the
+    // padded columns (taps >= 75, and the third tile of waves 2 and 3, which run it on zeros rather
+    // than branch: they would wait at the tile barrier anyway) so those read the zero zone
+    int tbase[3], tmask[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int tap = (wave + 4 * j) * 8 + 4 * colhalf + (sl & 3);
-      tapoff[j] = (wave + 4 * j) < 10 ? c1_tap_off(tap, c.t) : -1;   // -1: padded column -> the zero zone
+      const int o = (wave + 4 * j) < 10 ? c1_tap_off(tap, c.t) : -1;
+      tbase[j] = o >= 0 ? o * 2 : C1_PATCH * 2;
+      tmask[j] = o >= 0 ? -1 : 0;
     }
     __syncthreads();
     if (q + 1 < q_end) issue(c1_tile(q + 1, T, tiles_x, tiles_y));
-#pragma unroll 4
-    for (int ks = 0; ks < C1_PIX / 16; ++ks) {
+    // 16 k steps (16 pixels each), fully unrolled; the transpose reads of step ks+1 fly during the
+    // MFMAs of step ks (fragments double buffered by parity, interleave pinned below)
+    bf16x8 fa[2], fb[2][3];
+    auto load_k = [&](int ks, bf16x8& a, bf16x8 (&b)[3]) {
       // this lane's source pixel of the two 4-pixel groups: k = lk*8 + {0..3 | 4..7}
       int za[2], pa[2];
 #pragma unroll
@@ -669,17 +676,30 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
         za[hh] = pix * 64 + colhalf * 32 + (sl & 3) * 8;
         pa[hh] = ((2 * (pix >> 4)) * C1_P + 2 * (pix & 15)) * 8;
       }
-      const bf16x8 a = lds_tr_pair(ZsB, za[0], za[1]);
+      a = lds_tr_pair(ZsB, za[0], za[1]);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        if (wave + 4 * j < 10) {
-          const int o0 = tapoff[j] >= 0 ? pa[0] + tapoff[j] * 2 : C1_PATCH * 2;
-          const int o1 = tapoff[j] >= 0 ? pa[1] + tapoff[j] * 2 : C1_PATCH * 2;
-          const bf16x8 b = lds_tr_pair(PsB, o0, o1);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
-        }
-      }
+      for (int j = 0; j < 3; ++j) b[j] = lds_tr_pair(PsB, (pa[0] & tmask[j]) + tbase[j], (pa[1] & tmask[j]) + tbase[j]);
+    };
+    constexpr int KS = C1_PIX / 16;
+    load_k(0, fa[0], fb[0]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) load_k(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1], fb[ks & 1][j], acc[j], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+    for (int ks = 0; ks + 1 < KS; ++ks) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
   }
   float* out = slabs + (int64_t)blockIdx.x * 32 * 320;
 #pragma unroll
@@ -1949,7 +1969,7 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
                                    &e0, &e1);
   if (Cin_pad == 4 && Cin_real == 3 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 &&
       ph == 2 && pw == 2) {
-    const int nwg = kC1WgradWgs;   // persistent workgroups (3 per CU), partial sums reduced in fixed order
+    const int nwg = kC1WgradWgs;   // persistent workgroups (2 per CU: 194 registers), partial sums reduced in fixed order
     lr_clear_error();
     if (sample) hipExtLaunchKernelGGL(conv1_wgrad_patch_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, e0,
                                       e1, 0, x, dz, slabs, B * T, T, Hin, Win, g.Ho, g.Wo);
