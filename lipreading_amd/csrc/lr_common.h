@@ -120,3 +120,14 @@ int lr_xgemm_impl(int transA, int transB, int M, int N, int K, float alpha, cons
                   const float* B, int ldb, float beta, float* C, int ldc, const float* bias, int a_exact,
                   int b_exact, void* workspace, size_t workspace_bytes, hipStream_t stream);
 extern "C" size_t lr_xgemm_workspace_bytes(int transA, int transB, int M, int N, int K);
+// the three products of a recurrent layer's input projection with all D directions in one
+// contraction each (gates / dG hold the directions side by side in a row; dstride = floats between
+// the directions' blocks of a dG row)
+size_t lr_xproj_workspace_bytes(int R, int I, int GH, int D);
+int lr_xproj_forward(const float* x, int R, int I, const float* const* w_ih, int GH, int D, const float* bias,
+                     float* gates, int x_exact, void* workspace, size_t workspace_bytes, hipStream_t stream);
+int lr_xproj_dw(const float* dG, int ldg, int dstride, const float* x, int R, int I, int GH, int D,
+                float* const* dw_ih, float beta, int x_exact, void* workspace, size_t workspace_bytes,
+                hipStream_t stream);
+int lr_xproj_dx(const float* dG, int ldg, int dstride, const float* const* w_ih, int R, int I, int GH, int D,
+                float* dx, int hi_only, void* workspace, size_t workspace_bytes, hipStream_t stream);

@@ -505,7 +505,7 @@ Layout reserve_layout(int G, int B, int T, int I, int H, int D, bool x3 = false)
   l.hp = l.wp + (size_t)D * l.wp_per_dir;
   l.hp_floats = 2 * (size_t)D * nbt * nchunk * FRAG;
   l.gemm = l.hp + l.hp_floats;                               // split-K slabs of the input projection
-  l.gemm_bytes = x3 ? lr_xgemm_workspace_bytes(0, 1, B * T, G * H, I) : lr_sgemm_workspace_bytes(B * T, G * H, I);
+  l.gemm_bytes = x3 ? lr_xproj_workspace_bytes(B * T, I, G * H, D) : lr_sgemm_workspace_bytes(B * T, G * H, I);
   l.total = l.gemm + (l.gemm_bytes + 3) / 4;
   return l;
 }
@@ -548,13 +548,9 @@ bool dims_ok(int mode, int B, int T, int I, int H, int D) {
          I > 0 && H > 0 && (D == 1 || D == 2);
 }
 // extra workspace floats of the bf16x3 input projection's backward (operand planes + split-K slabs
-// of the larger of its two products)
-size_t x3_ws_floats(int G, int B, int T, int I, int H) {
-  const int R = B * T, GH = G * H;
-  size_t a = lr_xgemm_workspace_bytes(1, 0, GH, I, R);
-  const size_t b = lr_xgemm_workspace_bytes(0, 0, R, I, GH);
-  if (b > a) a = b;
-  return (a / sizeof(float) + 63) / 64 * 64;
+// of the larger of its products, all directions in one contraction)
+size_t x3_ws_floats(int G, int B, int T, int I, int H, int D) {
+  return (lr_xproj_workspace_bytes(B * T, I, G * H, D) / sizeof(float) + 63) / 64 * 64;
 }
 
 }  // namespace
@@ -572,7 +568,7 @@ extern "C" size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int
 extern "C" size_t lr_rnn_workspace_bytes(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D)) return 0;
   const int G = cell_of(mode) == LR_RNN_GRU ? 3 : 4;
-  return ((ws_layout(G, B, T, I, H, D).total + 63) / 64 * 64 + (proj_x3(mode) ? x3_ws_floats(G, B, T, I, H) : 0)) *
+  return ((ws_layout(G, B, T, I, H, D).total + 63) / 64 * 64 + (proj_x3(mode) ? x3_ws_floats(G, B, T, I, H, D) : 0)) *
          sizeof(float);
 }
 
@@ -601,16 +597,20 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
               bias + (size_t)d * GH, G, H);
     int st = lr_launch_status();
     if (st != LR_OK) return st;
-    // gates[b,t,d,:] = x[b,t,:] @ W_ih[d]^T + folded bias
-    if (proj_x3(mode))
-      st = lr_xgemm_impl(0, 1, B * T, GH, I, 1.f, x, I, w_ih[d], I, 0.f, gates + (size_t)d * GH, D * GH,
-                         bias + (size_t)d * GH, x_exact(mode) ? 1 : 0, 0,
-                         l.gemm_bytes ? (void*)(base + l.gemm) : nullptr, l.gemm_bytes, stream);
-    else
-      st = lr_sgemm_impl(0, 1, B * T, GH, I, 1.f, x, I, w_ih[d], I, 0.f, gates + (size_t)d * GH,
-                         D * GH, bias + (size_t)d * GH, 0, 0, l.gemm_bytes ? (void*)(base + l.gemm) : nullptr,
-                         l.gemm_bytes, stream);
+  }
+  if (proj_x3(mode)) {
+    // gates[b,t,:,:] = x[b,t,:] @ [W_ih[0]; W_ih[1]]^T + folded bias: both directions in one product
+    int st = lr_xproj_forward(x, B * T, I, w_ih, GH, D, bias, gates, x_exact(mode) ? 1 : 0,
+                              l.gemm_bytes ? (void*)(base + l.gemm) : nullptr, l.gemm_bytes, stream);
     if (st != LR_OK) return st;
+  } else {
+    for (int d = 0; d < D; ++d) {
+      // gates[b,t,d,:] = x[b,t,:] @ W_ih[d]^T + folded bias
+      int st = lr_sgemm_impl(0, 1, B * T, GH, I, 1.f, x, I, w_ih[d], I, 0.f, gates + (size_t)d * GH, D * GH,
+                             bias + (size_t)d * GH, 0, 0, l.gemm_bytes ? (void*)(base + l.gemm) : nullptr,
+                             l.gemm_bytes, stream);
+      if (st != LR_OK) return st;
+    }
   }
   if (recur_bf16(mode)) {
     // one launch for all T steps (lr_rnn_persist.hip); same interface buffers as the step kernels
@@ -687,7 +687,7 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
   const WsLayout wl = ws_layout(G, B, T, I, H, D);
   const bool x3 = proj_x3(mode);
   const size_t xws_off = (wl.total + 63) / 64 * 64;   // floats; keeps the bf16 planes 16-byte aligned
-  if (workspace_bytes < (x3 ? xws_off + x3_ws_floats(G, B, T, I, H) : wl.total) * sizeof(float)) return LR_ERR_WORKSPACE;
+  if (workspace_bytes < (x3 ? xws_off + x3_ws_floats(G, B, T, I, H, D) : wl.total) * sizeof(float)) return LR_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   const float* rbase = (const float*)reserve;
   const float* gates = rbase + rl.gates;
@@ -734,18 +734,25 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
   const int R = B * T;
   const int ldg = D * 4 * H;
   void* xws = wbase + xws_off;   // bf16x3 input projection: operand planes + split-K slabs
-  const size_t xws_bytes = x3 ? x3_ws_floats(G, B, T, I, H) * sizeof(float) : 0;
+  const size_t xws_bytes = x3 ? x3_ws_floats(G, B, T, I, H, D) * sizeof(float) : 0;
+  if (x3) {
+    // input projection: all directions in one contraction per product (lr_xgemm.hip)
+    st = lr_xproj_dw(dG, ldg, 4 * H, x, R, I, GH, D, dw_ih, wbeta, x_exact(mode) ? 1 : 0, xws, xws_bytes, stream);
+    if (st != LR_OK) return st;
+    if (dx) {
+      // a bf16 input's gradient goes to a bf16 consumer (the conv frontend's backward): hi terms only
+      st = lr_xproj_dx(dG, ldg, 4 * H, w_ih, R, I, GH, D, dx, x_exact(mode) ? 1 : 0, xws, xws_bytes, stream);
+      if (st != LR_OK) return st;
+    }
+  }
   for (int d = 0; d < D; ++d) {
     const float* dGd = dG + (size_t)d * 4 * H;
     // dW_ih[d] (G*H x I) = dGx^T (slots 0..G-1 are contiguous rows) @ x
-    if (x3) {
-      st = lr_xgemm_impl(1, 0, GH, I, R, 1.f, dGd, ldg, x, I, wbeta, dw_ih[d], I, nullptr, 0, x_exact(mode) ? 1 : 0,
-                         xws, xws_bytes, stream);
-    } else {
+    if (!x3) {
       st = lr_sgemm_impl(1, 0, GH, I, R, 1.f, dGd, ldg, x, I, wbeta, dw_ih[d], I, nullptr, 0, 0, gws,
                          wl.gemm_bytes, stream);
+      if (st != LR_OK) return st;
     }
-    if (st != LR_OK) return st;
     // dW_hh[d] = dGh^T @ h_prev, h_prev[b,t] = y[b,t-1] (forward dir) / y[b,t+1] (reverse dir)
     const float* yd = y + (size_t)d * H;
     const int shift = d == 0 ? -1 : 1;
@@ -761,13 +768,7 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
                          T, gws, wl.gemm_bytes, stream);
     }
     if (st != LR_OK) return st;
-    if (dx && x3) {
-      // a bf16 input's gradient goes to a bf16 consumer (the conv frontend's backward): hi terms only
-      const int hi_only = x_exact(mode) ? 1 : 0;
-      st = lr_xgemm_impl(0, 0, R, I, GH, 1.f, dGd, ldg, w_ih[d], I, d == 0 ? 0.f : 1.f, dx, I, nullptr, hi_only,
-                         hi_only, xws, xws_bytes, stream);
-      if (st != LR_OK) return st;
-    } else if (dx) {
+    if (dx && !x3) {
       st = lr_sgemm_impl(0, 0, R, I, GH, 1.f, dGd, ldg, w_ih[d], I, d == 0 ? 0.f : 1.f, dx, I,
                          nullptr, 0, 0, gws, wl.gemm_bytes, stream);
       if (st != LR_OK) return st;

@@ -43,6 +43,8 @@ struct XArgs {
   const bf16_t* Bh;   // [N][K]
   const bf16_t* Bl;
   float* C;
+  float* C1;          // rows >= split_row go to C1 + (row - split_row) * ldc (two stacked outputs)
+  int split_row;
   const float* bias;
   int M, N, K, ldp, ldc;
   float alpha, beta;
@@ -53,11 +55,12 @@ struct XArgs {
 
 // ---- pass 1: fp32 [rows][cols] (or its transpose) -> bf16 hi (+ lo) planes [rows'][ldp] -------------
 // transpose == 0: out[r][c] = split(in[r][c]);  transpose == 1: out[c][r] = split(in[r][c]).
-// The K axis of the planes is zero-filled from its logical width up to ldp (the contraction reads
-// whole 16-byte units).  32x32 tiles, 256 threads; the grid covers the OUTPUT extent.
+// Output columns [0, owidth) are written, zero beyond the logical width (the contraction reads whole
+// 16-byte units up to ldp); hi / lo may point into the middle of a larger plane (an operand assembled
+// from several blocks).  32x32 tiles, 256 threads; the grid covers the OUTPUT extent.
 __global__ __launch_bounds__(256) void xpack_kernel(const float* __restrict__ in, int ld_in, int rows, int cols,
                                                     int transpose, bf16_t* __restrict__ hi,
-                                                    bf16_t* __restrict__ lo, int ldp) {
+                                                    bf16_t* __restrict__ lo, int ldp, int owidth) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   // tile origin in OUTPUT coordinates (orow, ocol); input origin is the same or swapped
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void xpack_kernel(const float* __restrict__ in
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int orow = or0 + ty + 8 * i, ocol = oc0 + tx;
-    if (orow >= orows || ocol >= ldp) continue;
+    if (orow >= orows || ocol >= owidth) continue;
     const float v = transpose ? tile[tx][ty + 8 * i] : tile[ty + 8 * i][tx];
     const __bf16 h = (__bf16)v;
     hi[(int64_t)orow * ldp + ocol] = __builtin_bit_cast(bf16_t, h);
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
           continue;
         }
         float out = g.alpha * acc[i][j][r] + bv;
-        float* c = g.C + (int64_t)row * g.ldc + col;
+        float* c = (row < g.split_row ? g.C + (int64_t)row * g.ldc : g.C1 + (int64_t)(row - g.split_row) * g.ldc) + col;
         if (g.beta != 0.f) out += g.beta * *c;
         *c = out;
       }
@@ -214,7 +217,8 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
 }
 
 // deterministic split-K combine (fixed order over the slabs), then alpha / beta / bias
-__global__ void xsplitk_reduce_kernel(const float* __restrict__ slabs, int splits, float* __restrict__ C, int ldc,
+__global__ void xsplitk_reduce_kernel(const float* __restrict__ slabs, int splits, float* __restrict__ C,
+                                      float* __restrict__ C1, int split_row, int ldc,
                                       const float* __restrict__ bias, int M, int N, float alpha, float beta) {
   const int64_t total = (int64_t)M * N;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -223,7 +227,7 @@ __global__ void xsplitk_reduce_kernel(const float* __restrict__ slabs, int split
     const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
     float out = alpha * s;
     if (bias) out += bias[col];
-    float* c = C + (int64_t)row * ldc + col;
+    float* c = (row < split_row ? C + (int64_t)row * ldc : C1 + (int64_t)(row - split_row) * ldc) + col;
     if (beta != 0.f) out += beta * *c;
     *c = out;
   }
@@ -253,13 +257,75 @@ int want_splits(int M, int N, int K) {
   return (int)best;
 }
 
-// planes [orows][ldp] of an operand stored [rows][cols] (transpose: planes are [cols][rows -> ldp])
+// planes [orows][owidth of ldp] of an operand block stored [rows][cols] (transpose: planes are
+// [cols][rows]); hi / lo may be offset into a larger plane
 int pack_operand(const float* in, int ld_in, int rows, int cols, int transpose, bf16_t* hi, bf16_t* lo, int ldp,
-                 hipStream_t stream) {
+                 int owidth, hipStream_t stream) {
   const int orows = transpose ? cols : rows;
-  LR_LAUNCH(xpack_kernel, dim3((ldp + 31) / 32, (orows + 31) / 32), dim3(256), 0, stream, in, ld_in, rows, cols,
-            transpose, hi, lo, ldp);
+  LR_LAUNCH(xpack_kernel, dim3((owidth + 31) / 32, (orows + 31) / 32), dim3(256), 0, stream, in, ld_in, rows, cols,
+            transpose, hi, lo, ldp, owidth);
   return lr_launch_status();
+}
+
+// C (+ C1 below split_row) = alpha * A_planes . B_planes^T + beta * C + bias; slabs: split-K workspace
+int contract(const bf16_t* Ahp, const bf16_t* Alp, const bf16_t* Bhp, const bf16_t* Blp, int M, int N, int K,
+             float alpha, float beta, float* C, float* C1, int split_row, int ldc, const float* bias, float* slabs,
+             size_t slab_floats, hipStream_t stream) {
+  const int ldp = ldp_of(K);
+  // split-K as far as the remaining workspace allows (none: a single pass, just slower)
+  int splits = want_splits(M, N, K);
+  while (splits > 1 && (size_t)splits * M * N > slab_floats) --splits;
+  int chunk = (K + splits - 1) / splits;
+  chunk = (chunk + XBK - 1) / XBK * XBK;
+  splits = (K + chunk - 1) / chunk;
+  XArgs g;
+  g.Ah = Ahp; g.Al = Alp; g.Bh = Bhp; g.Bl = Blp;
+  g.C = C; g.C1 = C1 ? C1 : C; g.split_row = C1 ? split_row : M; g.bias = bias;
+  g.M = M; g.N = N; g.K = K; g.ldp = ldp; g.ldc = ldc;
+  g.alpha = alpha; g.beta = beta;
+  g.k_chunk = chunk;
+  g.slabs = splits > 1 ? slabs : nullptr;
+  g.nx = (N + XBN - 1) / XBN;
+  g.ny = (M + XBM - 1) / XBM;
+  g.splits = splits;
+  const int ntile = g.nx * g.ny * splits;
+  g.per_xcd = (ntile + 7) / 8;
+  dim3 grid(8 * g.per_xcd);
+  lr_clear_error();
+  const bool ax = Alp == nullptr, bx = Blp == nullptr;
+  if (ax && bx) hipLaunchKernelGGL((xgemm_kernel<true, true>), grid, dim3(256), 0, stream, g);
+  else if (ax) hipLaunchKernelGGL((xgemm_kernel<true, false>), grid, dim3(256), 0, stream, g);
+  else if (bx) hipLaunchKernelGGL((xgemm_kernel<false, true>), grid, dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((xgemm_kernel<false, false>), grid, dim3(256), 0, stream, g);
+  int st = lr_launch_status();
+  if (st != LR_OK || splits == 1) return st;
+  const int64_t total = (int64_t)M * N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  LR_LAUNCH(xsplitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)g.slabs, splits, C, g.C1,
+            g.split_row, ldc, bias, M, N, alpha, beta);
+  return lr_launch_status();
+}
+
+// carve the two operands' planes out of a workspace; returns false when it is too small
+struct Planes {
+  bf16_t *Ah, *Al, *Bh, *Bl;
+  float* slabs;
+  size_t slab_floats;
+};
+bool carve(void* workspace, size_t workspace_bytes, int M, int N, int K, bool a_exact, bool b_exact, Planes* p) {
+  const int ldp = ldp_of(K);
+  const size_t fa = plane_floats(M, K, a_exact), fb = plane_floats(N, K, b_exact);
+  const size_t avail = workspace_bytes / sizeof(float);
+  if (avail < fa + fb) return false;
+  float* ws = (float*)workspace;
+  p->Ah = (bf16_t*)ws;
+  p->Al = a_exact ? nullptr : p->Ah + (size_t)M * ldp;
+  p->Bh = (bf16_t*)(ws + fa);
+  p->Bl = b_exact ? nullptr : p->Bh + (size_t)N * ldp;
+  p->slabs = ws + fa + fb;
+  p->slab_floats = avail - fa - fb;
+  return true;
 }
 
 }  // namespace
@@ -283,57 +349,82 @@ int lr_xgemm_impl(int transA, int transB, int M, int N, int K, float alpha, cons
   LR_CHECK_ARG(A && B && C && workspace);
   LR_CHECK_ARG(M > 0 && N > 0 && K > 0 && lda > 0 && ldb > 0 && ldc >= N);
   const int ldp = ldp_of(K);
-  const size_t fa = plane_floats(M, K, a_exact != 0), fb = plane_floats(N, K, b_exact != 0);
-  size_t avail = workspace_bytes / sizeof(float);
-  if (avail < fa + fb) return LR_ERR_WORKSPACE;
-  avail -= fa + fb;
-  float* ws = (float*)workspace;
-  bf16_t* Ahp = (bf16_t*)ws;
-  bf16_t* Alp = a_exact ? nullptr : Ahp + (size_t)M * ldp;
-  bf16_t* Bhp = (bf16_t*)(ws + fa);
-  bf16_t* Blp = b_exact ? nullptr : Bhp + (size_t)N * ldp;
-  float* slabs = ws + fa + fb;
+  Planes pl;
+  if (!carve(workspace, workspace_bytes, M, N, K, a_exact != 0, b_exact != 0, &pl)) return LR_ERR_WORKSPACE;
   // A planes [M][K]: stored [K][M] when transA (rows = K, cols = M, transposed), else [M][K]
-  int st = transA ? pack_operand(A, lda, K, M, 1, Ahp, Alp, ldp, stream)
-                  : pack_operand(A, lda, M, K, 0, Ahp, Alp, ldp, stream);
+  int st = transA ? pack_operand(A, lda, K, M, 1, pl.Ah, pl.Al, ldp, ldp, stream)
+                  : pack_operand(A, lda, M, K, 0, pl.Ah, pl.Al, ldp, ldp, stream);
   if (st != LR_OK) return st;
   // B planes [N][K]: stored [N][K] when transB, else [K][N] (transposed)
-  st = transB ? pack_operand(B, ldb, N, K, 0, Bhp, Blp, ldp, stream)
-              : pack_operand(B, ldb, K, N, 1, Bhp, Blp, ldp, stream);
+  st = transB ? pack_operand(B, ldb, N, K, 0, pl.Bh, pl.Bl, ldp, ldp, stream)
+              : pack_operand(B, ldb, K, N, 1, pl.Bh, pl.Bl, ldp, ldp, stream);
   if (st != LR_OK) return st;
+  return contract(pl.Ah, pl.Al, pl.Bh, pl.Bl, M, N, K, alpha, beta, C, nullptr, M, ldc, bias, pl.slabs,
+                  pl.slab_floats, stream);
+}
 
-  // split-K as far as the remaining workspace allows (none: a single pass, just slower)
-  int splits = want_splits(M, N, K);
-  while (splits > 1 && (size_t)splits * M * N > avail) --splits;
-  int chunk = (K + splits - 1) / splits;
-  chunk = (chunk + XBK - 1) / XBK * XBK;
-  splits = (K + chunk - 1) / chunk;
-  XArgs g;
-  g.Ah = Ahp; g.Al = Alp; g.Bh = Bhp; g.Bl = Blp;
-  g.C = C; g.bias = bias;
-  g.M = M; g.N = N; g.K = K; g.ldp = ldp; g.ldc = ldc;
-  g.alpha = alpha; g.beta = beta;
-  g.k_chunk = chunk;
-  g.slabs = splits > 1 ? slabs : nullptr;
-  g.nx = (N + XBN - 1) / XBN;
-  g.ny = (M + XBM - 1) / XBM;
-  g.splits = splits;
-  const int ntile = g.nx * g.ny * splits;
-  g.per_xcd = (ntile + 7) / 8;
-  dim3 grid(8 * g.per_xcd);
-  lr_clear_error();
-  if (a_exact && b_exact) hipLaunchKernelGGL((xgemm_kernel<true, true>), grid, dim3(256), 0, stream, g);
-  else if (a_exact) hipLaunchKernelGGL((xgemm_kernel<true, false>), grid, dim3(256), 0, stream, g);
-  else if (b_exact) hipLaunchKernelGGL((xgemm_kernel<false, true>), grid, dim3(256), 0, stream, g);
-  else hipLaunchKernelGGL((xgemm_kernel<false, false>), grid, dim3(256), 0, stream, g);
-  st = lr_launch_status();
-  if (st != LR_OK || splits == 1) return st;
-  const int64_t total = (int64_t)M * N;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  LR_LAUNCH(xsplitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)g.slabs, splits, C, ldc, bias, M,
-            N, alpha, beta);
-  return lr_launch_status();
+// ---- the three products of a recurrent layer's input projection, all directions in ONE contraction ----
+// (lr_rnn.hip, LR_RNN_PROJ_BF16X3).  R = B*T rows, I input features, GH gate rows per direction, D
+// directions; gates / dG keep the directions side by side in a row (leading dimensions ldgates, ldg).
+size_t lr_xproj_workspace_bytes(int R, int I, int GH, int D) {
+  if (R <= 0 || I <= 0 || GH <= 0 || D <= 0) return 0;
+  size_t a = lr_xgemm_workspace_bytes(0, 1, R, D * GH, I);
+  size_t b = lr_xgemm_workspace_bytes(1, 0, D * GH, I, R);
+  if (b > a) a = b;
+  b = lr_xgemm_workspace_bytes(0, 0, R, I, D * GH);
+  if (b > a) a = b;
+  return a;
+}
+
+// gates[R][D*GH] = x[R][I] . [W_ih[0]; W_ih[1]]^T + bias[D*GH]
+int lr_xproj_forward(const float* x, int R, int I, const float* const* w_ih, int GH, int D, const float* bias,
+                     float* gates, int x_exact, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  const int N = D * GH, ldp = ldp_of(I);
+  Planes pl;
+  if (!carve(workspace, workspace_bytes, R, N, I, x_exact != 0, false, &pl)) return LR_ERR_WORKSPACE;
+  int st = pack_operand(x, I, R, I, 0, pl.Ah, pl.Al, ldp, ldp, stream);
+  for (int d = 0; d < D && st == LR_OK; ++d)
+    st = pack_operand(w_ih[d], I, GH, I, 0, pl.Bh + (size_t)d * GH * ldp, pl.Bl + (size_t)d * GH * ldp, ldp, ldp,
+                      stream);
+  if (st != LR_OK) return st;
+  return contract(pl.Ah, pl.Al, pl.Bh, pl.Bl, R, N, I, 1.f, 0.f, gates, nullptr, R, N, bias, pl.slabs, pl.slab_floats,
+                  stream);
+}
+
+// dW_ih[d][GH][I] (beta) = dG[:, d, :GH]^T . x   — rows d*GH.. of one (D*GH) x I product over K = R
+int lr_xproj_dw(const float* dG, int ldg, int dstride, const float* x, int R, int I, int GH, int D,
+                float* const* dw_ih, float beta, int x_exact, void* workspace, size_t workspace_bytes,
+                hipStream_t stream) {
+  const int M = D * GH, ldp = ldp_of(R);
+  Planes pl;
+  if (!carve(workspace, workspace_bytes, M, I, R, false, x_exact != 0, &pl)) return LR_ERR_WORKSPACE;
+  int st = LR_OK;
+  for (int d = 0; d < D && st == LR_OK; ++d)
+    st = pack_operand(dG + (size_t)d * dstride, ldg, R, GH, 1, pl.Ah + (size_t)d * GH * ldp,
+                      pl.Al + (size_t)d * GH * ldp, ldp, ldp, stream);
+  if (st == LR_OK) st = pack_operand(x, I, R, I, 1, pl.Bh, pl.Bl, ldp, ldp, stream);
+  if (st != LR_OK) return st;
+  return contract(pl.Ah, pl.Al, pl.Bh, pl.Bl, M, I, R, 1.f, beta, dw_ih[0], D > 1 ? dw_ih[1] : nullptr, GH, I, nullptr,
+                  pl.slabs, pl.slab_floats, stream);
+}
+
+// dx[R][I] = sum_d dG[:, d, :GH] . W_ih[d]   — one product over K = D*GH
+int lr_xproj_dx(const float* dG, int ldg, int dstride, const float* const* w_ih, int R, int I, int GH, int D,
+                float* dx, int hi_only, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  const int K = D * GH, ldp = ldp_of(K);
+  Planes pl;
+  if (!carve(workspace, workspace_bytes, R, I, K, hi_only != 0, hi_only != 0, &pl)) return LR_ERR_WORKSPACE;
+  int st = LR_OK;
+  for (int d = 0; d < D && st == LR_OK; ++d) {
+    const int ow = d == D - 1 ? ldp - d * GH : GH;
+    st = pack_operand(dG + (size_t)d * dstride, ldg, R, GH, 0, pl.Ah + d * GH, pl.Al ? pl.Al + d * GH : nullptr, ldp,
+                      ow, stream);
+    if (st == LR_OK)
+      st = pack_operand(w_ih[d], I, GH, I, 1, pl.Bh + d * GH, pl.Bl ? pl.Bl + d * GH : nullptr, ldp, ow, stream);
+  }
+  if (st != LR_OK) return st;
+  return contract(pl.Ah, pl.Al, pl.Bh, pl.Bl, R, I, K, 1.f, 0.f, dx, nullptr, R, I, nullptr, pl.slabs, pl.slab_floats,
+                  stream);
 }
 
 extern "C" int lr_xgemm(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
