@@ -422,6 +422,20 @@ int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* dbias, void
                     int Cin_real, int Cout, int KT, int KH, int KW, int stride, int pt, int ph, int pw,
                     lr_stream_t stream);
 
+/* The same weight (and bias) gradient for a layer whose forward fused ReLU + MaxPool
+ * (lr_conv3d_forward_pooled), taken straight from the pooled gradient dP, the pooled activation and
+ * the window codes: the un-pooled dZ is rebuilt tile by tile inside the kernel and never touches
+ * memory.  Build-defined like the rest of the frontend (the reference has no conv
+ * stage; its only trace is the commented-out stack at src/models/lipreader/model.py:122,153-156).
+ * `_supported` is non-zero for the layers that have this kernel (the first STCNN layer);
+ * workspace as for lr_conv3d_wgrad.                                                            */
+int lr_conv3d_wgrad_pooled_supported(int Hin, int Win, int Cin_pad, int Cin_real, int Cout, int KT, int KH,
+                                     int KW, int stride, int pt, int ph, int pw);
+int lr_conv3d_wgrad_pooled(const void* X, const void* pooled, const void* code, const void* dP, float* dW,
+                           float* dbias, void* workspace, size_t workspace_bytes, int accumulate, int B, int T,
+                           int Hin, int Win, int Cin_pad, int Cin_real, int Cout, int KT, int KH, int KW,
+                           int stride, int pt, int ph, int pw, lr_stream_t stream);
+
 /* MaxPool3d((1,2,2)) on channels-last bf16, and the backward of ReLU -> that pool: the gradient of
  * a window goes to its FIRST maximum (row-major, torch's rule) if the activation there is > 0.   */
 int lr_maxpool_hw2_bf16(const void* in, void* out, int64_t frames, int H, int W, int C,

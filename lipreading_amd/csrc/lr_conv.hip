@@ -597,9 +597,18 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
 
 // weight gradient of the first layer: slab[wg][n][k] = sum over the workgroup's tiles of
 // dZ[pix][n] * patch(pix, k).  Wave w owns column tiles w, w+4, w+8 of the 10 (320 columns).
+// POOLED: the layer's forward fused ReLU + MaxPool (lr_conv3d_forward_pooled), and instead of a
+// materialised dZ the kernel takes the pooled gradient dP, the pooled activation and the window
+// codes and rebuilds its dZ tile on the way into LDS (a window's gradient goes to position `code` if
+// the pooled activation is > 0) — the 354 MB dZ of this layer is never written or read.  The bias
+// gradient (column sums of dZ) falls out of the same pass: bias_part[wg][32].
+template <bool POOLED>
 __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __restrict__ X,
                                                                 const bf16_t* __restrict__ dZ,
-                                                                float* __restrict__ slabs, int frames,
+                                                                const bf16_t* __restrict__ pooled,
+                                                                const unsigned char* __restrict__ code,
+                                                                float* __restrict__ slabs,
+                                                                float* __restrict__ bias_part, int frames,
                                                                 int T, int Hin, int Win, int Ho, int Wo) {
   // Both operands are read with LDS transpose reads: the contraction runs over PIXELS, the slow axis
   // of the channels-last dZ tile and of the patch.  dZ tile: [pixel][32 channels], 64 B per pixel (4
@@ -622,17 +631,33 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
   if (tid < 8) Ps[C1_PATCH + tid] = 0;
 
   uint2 rp[C1_NPU];
-  uint4 rz[4];
+  uint4 rz[POOLED ? 2 : 4];   // POOLED: pooled gradient and activation of this thread's window
+  uint2 rc = make_uint2(0u, 0u);
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int wpy = tid >> 5, wpx = (tid >> 2) & 7, wcg = tid & 3;   // POOLED: window (py, px) of the 8 x 8, 8 channels
   auto issue = [&](const C1Tile& c) {
     const int f = c.f, y0 = c.y0, x0 = c.x0;
     c1_frame_issue(X, rp, f, T, Hin, Win, y0, x0, tid, 2);
+    if (POOLED) {
+      const int Hp = Ho >> 1, Wp = Wo >> 1;
+      const int yp = (y0 >> 1) + wpy, xp = (x0 >> 1) + wpx;
+      rz[0] = rz[1] = make_uint4(0u, 0u, 0u, 0u);
+      rc = make_uint2(0u, 0u);
+      if (yp < Hp && xp < Wp) {
+        const int64_t pi = (((int64_t)f * Hp + yp) * Wp + xp) * 32 + wcg * 8;
+        rz[0] = *reinterpret_cast<const uint4*>(dZ + pi);       // dP
+        rz[1] = *reinterpret_cast<const uint4*>(pooled + pi);
+        rc = *reinterpret_cast<const uint2*>(code + pi);
+      }
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {   // dZ tile: 256 pixels x 32 channels in 16-byte units
-      const int e = tid + i * 256;
-      const int pix = e >> 2, u = e & 3;
-      const int y = y0 + (pix >> 4), x = x0 + (pix & 15);
-      rz[i] = make_uint4(0u, 0u, 0u, 0u);
-      if (y < Ho && x < Wo) rz[i] = *reinterpret_cast<const uint4*>(dZ + (((int64_t)f * Ho + y) * Wo + x) * 32 + u * 8);
+      for (int i = 0; i < 4; ++i) {   // dZ tile: 256 pixels x 32 channels in 16-byte units
+        const int e = tid + i * 256;
+        const int pix = e >> 2, u = e & 3;
+        const int y = y0 + (pix >> 4), x = x0 + (pix & 15);
+        rz[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (y < Ho && x < Wo) rz[i] = *reinterpret_cast<const uint4*>(dZ + (((int64_t)f * Ho + y) * Wo + x) * 32 + u * 8);
+      }
     }
   };
   const unsigned char* PsB = reinterpret_cast<const unsigned char*>(Ps);
@@ -646,10 +671,33 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
     __syncthreads();
     if (q == q_begin || c.t == 0) c1_walk_start(X, Ps, c.f, T, Hin, Win, c.y0, c.x0, tid);
     c1_frame_store(Ps, rp, tid, c.t, 2);
+    if (POOLED) {
+      // rebuild the window's four dZ units (8 channels each): gradient at position `code`, if the
+      // pooled activation is positive
+      const unsigned gw[4] = {rz[0].x, rz[0].y, rz[0].z, rz[0].w}, pw_[4] = {rz[1].x, rz[1].y, rz[1].z, rz[1].w};
+      unsigned o[4][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + i * 256;
-      *reinterpret_cast<uint4*>(&Zs[(e >> 2) * ZLD + (e & 3) * 8]) = rz[i];
+      for (int e = 0; e < 8; ++e) {
+        const int wd = e >> 1, sh = (e & 1) * 16;
+        const float act = bf2f((bf16_t)((pw_[wd] >> sh) & 0xffffu));
+        const int arg = (int)(((e < 4 ? rc.x : rc.y) >> (8 * (e & 3))) & 3u);
+        const unsigned g = act > 0.f ? ((gw[wd] >> sh) & 0xffffu) : 0u;
+        bsum[e] += bf2f((bf16_t)g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j == arg) o[j][wd] |= g << sh;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pix = (2 * wpy + (j >> 1)) * 16 + 2 * wpx + (j & 1);
+        *reinterpret_cast<uint4*>(&Zs[pix * ZLD + wcg * 8]) = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = tid + i * 256;
+        *reinterpret_cast<uint4*>(&Zs[(e >> 2) * ZLD + (e & 3) * 8]) = rz[i];
+      }
     }
     // byte offset of this lane's tap per column tile, and a mask that drops the pixel offset for the
     // padded columns (taps >= 75, and the third tile of waves 2 and 3, which run it on zeros rather
@@ -708,6 +756,19 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         out[((r & 3) + 8 * (r >> 2) + 4 * lk) * 320 + (wave + 4 * j) * 32 + lr] = acc[j][r];
+    }
+  }
+  if (POOLED && bias_part) {   // column sums of this workgroup's dZ tiles, fixed order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(Zs);   // 256 x 8 floats
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 32) {
+      const int gq = tid >> 3, e = tid & 7;
+      float sacc = 0.f;
+      for (int w = 0; w < 64; ++w) sacc += red[(w * 4 + gq) * 8 + e];
+      bias_part[(int64_t)blockIdx.x * 32 + tid] = sacc;
     }
   }
 }
@@ -1946,7 +2007,50 @@ extern "C" size_t lr_conv3d_wgrad_workspace_bytes(int Cout, int Cin_pad, int KT,
   const size_t ts = (size_t)KT * kTsWgsPerKt * KH * KW * Cout * Cin_pad;   // tap-stationary path
   if (ts > slab) slab = ts;
   if (slab < (size_t)kC1WgradWgs * 32 * 320) slab = (size_t)kC1WgradWgs * 32 * 320;   // first-layer patch kernel
-  return (slab + (size_t)kColsumSplits * Cout) * sizeof(float);
+  const size_t colparts = kColsumSplits > kC1WgradWgs ? kColsumSplits : kC1WgradWgs;
+  return (slab + colparts * Cout) * sizeof(float);
+}
+
+extern "C" int lr_conv3d_wgrad_pooled_supported(int Hin, int Win, int Cin_pad, int Cin_real, int Cout, int KT,
+                                               int KH, int KW, int stride, int pt, int ph, int pw) {
+  const int Ho = (Hin + 2 * ph - KH) / (stride > 0 ? stride : 1) + 1, Wo = (Win + 2 * pw - KW) / (stride > 0 ? stride : 1) + 1;
+  return Cin_pad == 4 && Cin_real == 3 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 &&
+         ph == 2 && pw == 2 && Ho % 2 == 0 && Wo % 2 == 0;
+}
+
+extern "C" int lr_conv3d_wgrad_pooled(const void* X, const void* pooled, const void* code, const void* dP, float* dW,
+                                      float* dbias, void* workspace, size_t workspace_bytes, int accumulate, int B,
+                                      int T, int Hin, int Win, int Cin_pad, int Cin_real, int Cout, int KT, int KH,
+                                      int KW, int stride, int pt, int ph, int pw, lr_stream_t stream) {
+  LR_CHECK_ARG(X && pooled && code && dP && dW && workspace);
+  if (!lr_conv3d_wgrad_pooled_supported(Hin, Win, Cin_pad, Cin_real, Cout, KT, KH, KW, stride, pt, ph, pw))
+    return LR_ERR_UNSUPPORTED;
+  ConvGeom g;
+  if (!fill_geom(&g, B, T, Hin, Win, Cin_pad, Cout, KT, KH, KW, stride, pt, ph, pw)) return LR_ERR_UNSUPPORTED;
+  const size_t need = lr_conv3d_wgrad_workspace_bytes(Cout, Cin_pad, KT, KH, KW);
+  if (workspace_bytes < need) return LR_ERR_WORKSPACE;
+  float* slabs = (float*)workspace;
+  float* bpart = (float*)((char*)workspace + need) - (size_t)kC1WgradWgs * Cout;
+  hipEvent_t e0, e1;
+  const bool sample = lr_prof_next(LR_PROF_CONV1_WGRAD, &e0, &e1);
+  const int nwg = kC1WgradWgs;
+  lr_clear_error();
+  if (sample) hipExtLaunchKernelGGL(conv1_wgrad_patch_kernel<true>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, e0,
+                                    e1, 0, (const bf16_t*)X, (const bf16_t*)dP, (const bf16_t*)pooled,
+                                    (const unsigned char*)code, slabs, dbias ? bpart : (float*)nullptr, B * T, T, Hin,
+                                    Win, g.Ho, g.Wo);
+  else hipLaunchKernelGGL(conv1_wgrad_patch_kernel<true>, dim3(nwg), dim3(256), 0, (hipStream_t)stream,
+                          (const bf16_t*)X, (const bf16_t*)dP, (const bf16_t*)pooled, (const unsigned char*)code, slabs,
+                          dbias ? bpart : (float*)nullptr, B * T, T, Hin, Win, g.Ho, g.Wo);
+  int st = lr_launch_status();
+  if (st != LR_OK) return st;
+  LR_LAUNCH(conv_wgrad_slab_reduce_kernel, dim3(32 * 320 / 64), dim3(64, 16), 0, stream, (const float*)slabs, nwg,
+            (int64_t)32 * 320, dW, 0, 32, 4, 3, 75, 25, 320, accumulate);
+  st = lr_launch_status();
+  if (st != LR_OK || !dbias) return st;
+  LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(1024), 0, stream, (const float*)bpart, nwg, dbias, Cout,
+            accumulate);
+  return lr_launch_status();
 }
 
 extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* dbias, void* workspace,
@@ -1971,10 +2075,12 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
       ph == 2 && pw == 2) {
     const int nwg = kC1WgradWgs;   // persistent workgroups (2 per CU: 194 registers), partial sums reduced in fixed order
     lr_clear_error();
-    if (sample) hipExtLaunchKernelGGL(conv1_wgrad_patch_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, e0,
-                                      e1, 0, x, dz, slabs, B * T, T, Hin, Win, g.Ho, g.Wo);
-    else hipLaunchKernelGGL(conv1_wgrad_patch_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, x, dz, slabs,
-                            B * T, T, Hin, Win, g.Ho, g.Wo);
+    if (sample) hipExtLaunchKernelGGL(conv1_wgrad_patch_kernel<false>, dim3(nwg), dim3(256), 0, (hipStream_t)stream,
+                                      e0, e1, 0, x, dz, (const bf16_t*)nullptr, (const unsigned char*)nullptr, slabs,
+                                      (float*)nullptr, B * T, T, Hin, Win, g.Ho, g.Wo);
+    else hipLaunchKernelGGL(conv1_wgrad_patch_kernel<false>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, x, dz,
+                            (const bf16_t*)nullptr, (const unsigned char*)nullptr, slabs, (float*)nullptr, B * T, T,
+                            Hin, Win, g.Ho, g.Wo);
     int st = lr_launch_status();
     if (st != LR_OK) return st;
     LR_LAUNCH(conv_wgrad_slab_reduce_kernel, dim3(32 * 320 / 64), dim3(64, 16), 0, stream, (const float*)slabs, nwg,

@@ -121,9 +121,17 @@ class _ConvFrontendFunction(torch.autograd.Function):
       x_in, act, pooled = acts[2 * li], acts[2 * li + 1], acts[2 * li + 2]
       h, w = sizes[li]
       ho, wo = 2 * pooled.shape[1], 2 * pooled.shape[2]
-      dZ = torch.empty((frames, ho, wo, cout), dtype=bf, device=dev)
       wbytes = max(L.lr_conv3d_wgrad_workspace_bytes(cout, cin_p, kt, kh, kw), L.lr_unpool_workspace_bytes(cout))
       ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+      if act.dtype == torch.uint8 and _PATCH_KERNELS and li == 0 and L.lr_conv3d_wgrad_pooled_supported(
+          h, w, cin_p, cin, cout, kt, kh, kw, stride, pt, ph, pw):
+        # first layer (no data gradient needed): the weight-gradient kernel un-pools on the fly
+        _C.check(L.lr_conv3d_wgrad_pooled(x_in.data_ptr(), pooled.data_ptr(), act.data_ptr(), dP.data_ptr(),
+                                          grads[0].data_ptr(), grads[1].data_ptr(), ws.data_ptr(), wbytes,
+                                          1 if direct else 0, B, T, h, w, cin_p, cin, cout, kt, kh, kw, stride, pt,
+                                          ph, pw, st), "lr_conv3d_wgrad_pooled")
+        continue
+      dZ = torch.empty((frames, ho, wo, cout), dtype=bf, device=dev)
       # the bias gradient (sum of the routed gradients) falls out of the un-pooling pass
       if act.dtype == torch.uint8:   # the forward fused the pooling: act holds the window codes
         _C.check(L.lr_unpool_code_bf16(pooled.data_ptr(), act.data_ptr(), dP.data_ptr(), dZ.data_ptr(),
