@@ -393,7 +393,10 @@ int lr_conv3d_pack_weights(const float* W, void* out, int Cout, int Cin_real, in
  *                       + bias[n] ),  zero padding, temporal stride 1 and KT = 2*pt+1, spatial stride s.
  *   X bf16 [B][T][Hin][Win][Cin] (Cin % 4 == 0), Wp from lr_conv3d_pack_weights, bias fp32 or NULL,
  *   Y bf16 [B][T][Ho][Wo][Cout] (Cout in {32,64,96}); flags & 1 applies max(.,0) (ReLU);
- *   flags & 2 / flags & 4: Wp is fragment-major (lr_conv3d_pack_weights dgrad & 2 / & 4).          */
+ *   flags & 2 / flags & 4: Wp is fragment-major (lr_conv3d_pack_weights dgrad & 2 / & 4);
+ *   flags & 8 (first STCNN layer only, LR_ERR_UNSUPPORTED elsewhere): X is the raw clip, uint8
+ *   [B][T][3][Hin][Win], scaled by 1/255 on the way into LDS exactly as lr_clip_to_ndhwc_bf16
+ *   would have — no bf16 copy of the clip is made.                                               */
 int lr_conv3d_forward(const void* X, const void* Wp, const float* bias, void* Y, int B, int T, int Hin,
                       int Win, int Cin, int Cout, int KT, int KH, int KW, int stride, int pt, int ph,
                       int pw, int flags, lr_stream_t stream);
@@ -428,13 +431,14 @@ int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* dbias, void
  * memory.  Build-defined like the rest of the frontend (the reference has no conv
  * stage; its only trace is the commented-out stack at src/models/lipreader/model.py:122,153-156).
  * `_supported` is non-zero for the layers that have this kernel (the first STCNN layer);
- * workspace as for lr_conv3d_wgrad.                                                            */
+ * workspace as for lr_conv3d_wgrad.  flags bit 0: X is the raw clip, uint8 [B][T][3][Hin][Win]
+ * (scaled by 1/255 on the way into LDS, as lr_clip_to_ndhwc_bf16 would), not bf16 NDHWC.                                                            */
 int lr_conv3d_wgrad_pooled_supported(int Hin, int Win, int Cin_pad, int Cin_real, int Cout, int KT, int KH,
                                      int KW, int stride, int pt, int ph, int pw);
 int lr_conv3d_wgrad_pooled(const void* X, const void* pooled, const void* code, const void* dP, float* dW,
                            float* dbias, void* workspace, size_t workspace_bytes, int accumulate, int B, int T,
                            int Hin, int Win, int Cin_pad, int Cin_real, int Cout, int KT, int KH, int KW,
-                           int stride, int pt, int ph, int pw, lr_stream_t stream);
+                           int stride, int pt, int ph, int pw, int flags, lr_stream_t stream);
 
 /* MaxPool3d((1,2,2)) on channels-last bf16, and the backward of ReLU -> that pool: the gradient of
  * a window goes to its FIRST maximum (row-major, torch's rule) if the activation there is > 0.   */

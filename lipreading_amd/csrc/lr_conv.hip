@@ -405,8 +405,13 @@ __device__ __forceinline__ int c1_tap_off(int tap, int t) {
 // (kt = 2) flies while the current tile's MFMAs run; only 5 staging registers stay live across the
 // MFMA loop (15 for a whole patch cost a wave of occupancy).
 constexpr int C1_NPU = (C1_FPIX + 255) / 256;   // 5
-__device__ __forceinline__ void c1_frame_issue(const bf16_t* __restrict__ X, uint2 (&rp)[C1_NPU], int f, int T,
-                                               int Hin, int Win, int y0, int x0, int tid, int kt) {
+// U8: X is the raw clip, uint8 planar [frame][3][Hin][Win] — the three bytes of a pixel are loaded as
+// they are (rp.x, rp.y, rb) and turned into the bf16 pixel (value / 255, 4th channel 0) when they are
+// written to LDS, exactly as lr_clip_to_ndhwc_bf16 would have: no bf16 copy of the clip exists.
+template <bool U8>
+__device__ __forceinline__ void c1_frame_issue(const bf16_t* __restrict__ X, uint2 (&rp)[C1_NPU],
+                                               unsigned (&rb)[C1_NPU], int f, int T, int Hin, int Win, int y0,
+                                               int x0, int tid, int kt) {
   const int ti = f % T + kt - 1;
   const bool frame_ok = ti >= 0 && ti < T;
 #pragma unroll
@@ -415,26 +420,47 @@ __device__ __forceinline__ void c1_frame_issue(const bf16_t* __restrict__ X, uin
     const int px = e % C1_P, py = e / C1_P;
     const int yi = 2 * y0 - 2 + py, xi = 2 * x0 - 2 + px;
     rp[i] = make_uint2(0u, 0u);
-    if (frame_ok && e < C1_FPIX && yi >= 0 && yi < Hin && xi >= 0 && xi < Win)
-      rp[i] = *reinterpret_cast<const uint2*>(X + ((((int64_t)(f + kt - 1)) * Hin + yi) * Win + xi) * 4);
+    rb[i] = 0u;
+    if (frame_ok && e < C1_FPIX && yi >= 0 && yi < Hin && xi >= 0 && xi < Win) {
+      if (U8) {
+        const int64_t plane = (int64_t)Hin * Win;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(X) + (int64_t)(f + kt - 1) * 3 * plane +
+                                   (int64_t)yi * Win + xi;
+        rp[i].x = src[0];
+        rp[i].y = src[plane];
+        rb[i] = src[2 * plane];
+      } else {
+        rp[i] = *reinterpret_cast<const uint2*>(X + ((((int64_t)(f + kt - 1)) * Hin + yi) * Win + xi) * 4);
+      }
+    }
   }
 }
-__device__ __forceinline__ void c1_frame_store(bf16_t* Ps, const uint2 (&rp)[C1_NPU], int tid, int t, int kt) {
+template <bool U8>
+__device__ __forceinline__ void c1_frame_store(bf16_t* Ps, const uint2 (&rp)[C1_NPU], const unsigned (&rb)[C1_NPU],
+                                               int tid, int t, int kt) {
   bf16_t* slot = Ps + ((t + kt) % 3) * C1_FPIX * 4;
 #pragma unroll
   for (int i = 0; i < C1_NPU; ++i) {
     const int e = tid + i * 256;
-    if (e < C1_FPIX) *reinterpret_cast<uint2*>(&slot[e * 4]) = rp[i];
+    if (e >= C1_FPIX) continue;
+    uint2 v = rp[i];
+    if (U8) {
+      v.x = (unsigned)f2bf((float)rp[i].x * (1.f / 255.f)) | ((unsigned)f2bf((float)rp[i].y * (1.f / 255.f)) << 16);
+      v.y = (unsigned)f2bf((float)rb[i] * (1.f / 255.f));
+    }
+    *reinterpret_cast<uint2*>(&slot[e * 4]) = v;
   }
 }
 // first tile of a walk: frames t-1 and t are fetched synchronously (once per ~28 tiles)
+template <bool U8>
 __device__ __forceinline__ void c1_walk_start(const bf16_t* __restrict__ X, bf16_t* Ps, int f, int T, int Hin,
                                               int Win, int y0, int x0, int tid) {
 #pragma unroll 1
   for (int kt = 0; kt < 2; ++kt) {
     uint2 r[C1_NPU];
-    c1_frame_issue(X, r, f, T, Hin, Win, y0, x0, tid, kt);
-    c1_frame_store(Ps, r, tid, f % T, kt);
+    unsigned r3[C1_NPU];
+    c1_frame_issue<U8>(X, r, r3, f, T, Hin, Win, y0, x0, tid, kt);
+    c1_frame_store<U8>(Ps, r, r3, tid, f % T, kt);
   }
 }
 
@@ -457,7 +483,7 @@ __device__ __forceinline__ C1Tile c1_tile(int64_t q64, int T, int tiles_x, int t
 // POOL: the epilogue applies ReLU -> MaxPool((1,2,2)) in registers (a lane holds all four pixels of
 // its windows) and writes the pooled activation + the 2-bit position of the window's first maximum
 // (row-major scan, torch's rule) instead of the full-resolution activation.
-template <bool POOL>
+template <bool POOL, bool U8>
 __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __restrict__ X,
                                                               const bf16_t* __restrict__ Wp,  // [32][300]
                                                               const float* __restrict__ bias,
@@ -488,23 +514,24 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
   }
   const float bv = bias ? bias[lr] : 0.f;
   uint2 rp[C1_NPU];             // frame t+1 of the tile about to be computed
+  unsigned rb[C1_NPU];
   const int64_t q_end = ntiles * (blockIdx.x + 1) / gridDim.x;
   const int64_t q_begin = ntiles * blockIdx.x / gridDim.x;
   int64_t q = q_begin;
   if (q < q_end) {
     const C1Tile c = c1_tile(q, T, tiles_x, tiles_y);
-    c1_frame_issue(X, rp, c.f, T, Hin, Win, c.y0, c.x0, tid, 2);
+    c1_frame_issue<U8>(X, rp, rb, c.f, T, Hin, Win, c.y0, c.x0, tid, 2);
   }
   for (; q < q_end; ++q) {
     const C1Tile c = c1_tile(q, T, tiles_x, tiles_y);
     const int f = c.f, y0 = c.y0, x0 = c.x0;
     __syncthreads();            // previous tile's fragments are no longer being read
-    if (q == q_begin || c.t == 0) c1_walk_start(X, Ps, f, T, Hin, Win, y0, x0, tid);
-    c1_frame_store(Ps, rp, tid, c.t, 2);
+    if (q == q_begin || c.t == 0) c1_walk_start<U8>(X, Ps, f, T, Hin, Win, y0, x0, tid);
+    c1_frame_store<U8>(Ps, rp, rb, tid, c.t, 2);
     __syncthreads();
     if (q + 1 < q_end) {        // next tile's new frame flies while this tile's MFMAs run
       const C1Tile n = c1_tile(q + 1, T, tiles_x, tiles_y);
-      c1_frame_issue(X, rp, n.f, T, Hin, Win, n.y0, n.x0, tid, 2);
+      c1_frame_issue<U8>(X, rp, rb, n.f, T, Hin, Win, n.y0, n.x0, tid, 2);
     }
     f32x16 acc[2];
 #pragma unroll
@@ -602,7 +629,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
 // codes and rebuilds its dZ tile on the way into LDS (a window's gradient goes to position `code` if
 // the pooled activation is > 0) — the 354 MB dZ of this layer is never written or read.  The bias
 // gradient (column sums of dZ) falls out of the same pass: bias_part[wg][32].
-template <bool POOLED>
+template <bool POOLED, bool U8>
 __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __restrict__ X,
                                                                 const bf16_t* __restrict__ dZ,
                                                                 const bf16_t* __restrict__ pooled,
@@ -631,13 +658,14 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
   if (tid < 8) Ps[C1_PATCH + tid] = 0;
 
   uint2 rp[C1_NPU];
+  unsigned rb[C1_NPU];
   uint4 rz[POOLED ? 2 : 4];   // POOLED: pooled gradient and activation of this thread's window
   uint2 rc = make_uint2(0u, 0u);
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int wpy = tid >> 5, wpx = (tid >> 2) & 7, wcg = tid & 3;   // POOLED: window (py, px) of the 8 x 8, 8 channels
   auto issue = [&](const C1Tile& c) {
     const int f = c.f, y0 = c.y0, x0 = c.x0;
-    c1_frame_issue(X, rp, f, T, Hin, Win, y0, x0, tid, 2);
+    c1_frame_issue<U8>(X, rp, rb, f, T, Hin, Win, y0, x0, tid, 2);
     if (POOLED) {
       const int Hp = Ho >> 1, Wp = Wo >> 1;
       const int yp = (y0 >> 1) + wpy, xp = (x0 >> 1) + wpx;
@@ -669,8 +697,8 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
   for (; q < q_end; ++q) {
     const C1Tile c = c1_tile(q, T, tiles_x, tiles_y);
     __syncthreads();
-    if (q == q_begin || c.t == 0) c1_walk_start(X, Ps, c.f, T, Hin, Win, c.y0, c.x0, tid);
-    c1_frame_store(Ps, rp, tid, c.t, 2);
+    if (q == q_begin || c.t == 0) c1_walk_start<U8>(X, Ps, c.f, T, Hin, Win, c.y0, c.x0, tid);
+    c1_frame_store<U8>(Ps, rp, rb, tid, c.t, 2);
     if (POOLED) {
       // rebuild the window's four dZ units (8 channels each): gradient at position `code`, if the
       // pooled activation is positive
@@ -1869,6 +1897,9 @@ static int conv_forward_impl(const void* X, const void* Wp, const float* bias, v
                              int ph, int pw, int flags, lr_stream_t stream) {
   LR_CHECK_ARG(X && Wp && Y);
   const int relu = flags & 1;
+  const bool u8 = (flags & 8) != 0;   // X is the raw uint8 planar clip: first-layer patch kernel only
+  if (u8 && !(Cin == 4 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 && ph == 2 && pw == 2))
+    return LR_ERR_UNSUPPORTED;
   ConvGeom g;
   if (!fill_geom(&g, B, T, Hin, Win, Cin, Cout, KT, KH, KW, stride, pt, ph, pw)) return LR_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)((g.M + IG_BM - 1) / IG_BM));
@@ -1943,15 +1974,18 @@ static int conv_forward_impl(const void* X, const void* Wp, const float* bias, v
     int tiles = B * T * ((g.Ho + C1_T - 1) / C1_T) * ((g.Wo + C1_T - 1) / C1_T);
     if (tiles > 768) tiles = 768;   // persistent: 3 workgroups per CU, each streams its share of tiles
     lr_clear_error();
-#define LR_C1(POOLV)                                                                                              \
+#define LR_C1(POOLV, U8V)                                                                                         \
   do {                                                                                                           \
-    if (sample) hipExtLaunchKernelGGL(conv1_fwd_patch_kernel<POOLV>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, \
-                                      e0, e1, 0, x, w, bias, y, code, B * T, T, Hin, Win, g.Ho, g.Wo, relu);     \
-    else hipLaunchKernelGGL(conv1_fwd_patch_kernel<POOLV>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x, w,  \
-                            bias, y, code, B * T, T, Hin, Win, g.Ho, g.Wo, relu);                                \
+    if (sample) hipExtLaunchKernelGGL((conv1_fwd_patch_kernel<POOLV, U8V>), dim3(tiles), dim3(256), 0,            \
+                                      (hipStream_t)stream, e0, e1, 0, x, w, bias, y, code, B * T, T, Hin, Win,    \
+                                      g.Ho, g.Wo, relu);                                                         \
+    else hipLaunchKernelGGL((conv1_fwd_patch_kernel<POOLV, U8V>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, \
+                            x, w, bias, y, code, B * T, T, Hin, Win, g.Ho, g.Wo, relu);                          \
   } while (0)
-    if (code) LR_C1(true);
-    else LR_C1(false);
+    if (code && u8) LR_C1(true, true);
+    else if (code) LR_C1(true, false);
+    else if (u8) LR_C1(false, true);
+    else LR_C1(false, false);
 #undef LR_C1
     return lr_launch_status();
   }
@@ -2021,8 +2055,9 @@ extern "C" int lr_conv3d_wgrad_pooled_supported(int Hin, int Win, int Cin_pad, i
 extern "C" int lr_conv3d_wgrad_pooled(const void* X, const void* pooled, const void* code, const void* dP, float* dW,
                                       float* dbias, void* workspace, size_t workspace_bytes, int accumulate, int B,
                                       int T, int Hin, int Win, int Cin_pad, int Cin_real, int Cout, int KT, int KH,
-                                      int KW, int stride, int pt, int ph, int pw, lr_stream_t stream) {
+                                      int KW, int stride, int pt, int ph, int pw, int flags, lr_stream_t stream) {
   LR_CHECK_ARG(X && pooled && code && dP && dW && workspace);
+  const bool u8 = (flags & 1) != 0;   // X is the raw uint8 planar clip
   if (!lr_conv3d_wgrad_pooled_supported(Hin, Win, Cin_pad, Cin_real, Cout, KT, KH, KW, stride, pt, ph, pw))
     return LR_ERR_UNSUPPORTED;
   ConvGeom g;
@@ -2035,13 +2070,20 @@ extern "C" int lr_conv3d_wgrad_pooled(const void* X, const void* pooled, const v
   const bool sample = lr_prof_next(LR_PROF_CONV1_WGRAD, &e0, &e1);
   const int nwg = kC1WgradWgs;
   lr_clear_error();
-  if (sample) hipExtLaunchKernelGGL(conv1_wgrad_patch_kernel<true>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, e0,
-                                    e1, 0, (const bf16_t*)X, (const bf16_t*)dP, (const bf16_t*)pooled,
-                                    (const unsigned char*)code, slabs, dbias ? bpart : (float*)nullptr, B * T, T, Hin,
-                                    Win, g.Ho, g.Wo);
-  else hipLaunchKernelGGL(conv1_wgrad_patch_kernel<true>, dim3(nwg), dim3(256), 0, (hipStream_t)stream,
-                          (const bf16_t*)X, (const bf16_t*)dP, (const bf16_t*)pooled, (const unsigned char*)code, slabs,
-                          dbias ? bpart : (float*)nullptr, B * T, T, Hin, Win, g.Ho, g.Wo);
+#define LR_C1W(U8V)                                                                                              \
+  do {                                                                                                           \
+    if (sample) hipExtLaunchKernelGGL((conv1_wgrad_patch_kernel<true, U8V>), dim3(nwg), dim3(256), 0,             \
+                                      (hipStream_t)stream, e0, e1, 0, (const bf16_t*)X, (const bf16_t*)dP,        \
+                                      (const bf16_t*)pooled, (const unsigned char*)code, slabs,                   \
+                                      dbias ? bpart : (float*)nullptr, B * T, T, Hin, Win, g.Ho, g.Wo);           \
+    else hipLaunchKernelGGL((conv1_wgrad_patch_kernel<true, U8V>), dim3(nwg), dim3(256), 0, (hipStream_t)stream,  \
+                            (const bf16_t*)X, (const bf16_t*)dP, (const bf16_t*)pooled,                           \
+                            (const unsigned char*)code, slabs, dbias ? bpart : (float*)nullptr, B * T, T, Hin,    \
+                            Win, g.Ho, g.Wo);                                                                     \
+  } while (0)
+  if (u8) LR_C1W(true);
+  else LR_C1W(false);
+#undef LR_C1W
   int st = lr_launch_status();
   if (st != LR_OK) return st;
   LR_LAUNCH(conv_wgrad_slab_reduce_kernel, dim3(32 * 320 / 64), dim3(64, 16), 0, stream, (const float*)slabs, nwg,
@@ -2075,10 +2117,10 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
       ph == 2 && pw == 2) {
     const int nwg = kC1WgradWgs;   // persistent workgroups (2 per CU: 194 registers), partial sums reduced in fixed order
     lr_clear_error();
-    if (sample) hipExtLaunchKernelGGL(conv1_wgrad_patch_kernel<false>, dim3(nwg), dim3(256), 0, (hipStream_t)stream,
+    if (sample) hipExtLaunchKernelGGL((conv1_wgrad_patch_kernel<false, false>), dim3(nwg), dim3(256), 0, (hipStream_t)stream,
                                       e0, e1, 0, x, dz, (const bf16_t*)nullptr, (const unsigned char*)nullptr, slabs,
                                       (float*)nullptr, B * T, T, Hin, Win, g.Ho, g.Wo);
-    else hipLaunchKernelGGL(conv1_wgrad_patch_kernel<false>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, x, dz,
+    else hipLaunchKernelGGL((conv1_wgrad_patch_kernel<false, false>), dim3(nwg), dim3(256), 0, (hipStream_t)stream, x, dz,
                             (const bf16_t*)nullptr, (const unsigned char*)nullptr, slabs, (float*)nullptr, B * T, T,
                             Hin, Win, g.Ho, g.Wo);
     int st = lr_launch_status();

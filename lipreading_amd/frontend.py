@@ -51,12 +51,21 @@ class _ConvFrontendFunction(torch.autograd.Function):
     dev = clips.device
     frames = B * T
     bf = torch.bfloat16
-    x = torch.empty((frames, H, W, 4), dtype=bf, device=dev)
     is_u8 = clips.dtype == torch.uint8
     src = clips if is_u8 else clips.to(torch.float32)
     src = src.contiguous()
-    _C.check(L.lr_clip_to_ndhwc_bf16(src.data_ptr(), 1 if is_u8 else 0, x.data_ptr(), frames, H, W, st),
-             "lr_clip_to_ndhwc_bf16")
+    cin0, cout0, (kt0, kh0, kw0), s0, (pt0, ph0, pw0) = LAYERS[0]
+    # uint8 clips go straight into the first layer's patch kernels (forward and weight gradient), which
+    # scale and convert while they fill LDS: no bf16 copy of the clip is written or kept
+    raw_u8 = bool(is_u8 and _PATCH_KERNELS and L.lr_conv3d_pool_fusion_supported(
+        H, W, 4, cout0, kt0, kh0, kw0, s0, pt0, ph0, pw0) and L.lr_conv3d_wgrad_pooled_supported(
+        H, W, 4, cin0, cout0, kt0, kh0, kw0, s0, pt0, ph0, pw0))
+    if raw_u8:
+      x = src.reshape(frames, 3, H, W)
+    else:
+      x = torch.empty((frames, H, W, 4), dtype=bf, device=dev)
+      _C.check(L.lr_clip_to_ndhwc_bf16(src.data_ptr(), 1 if is_u8 else 0, x.data_ptr(), frames, H, W, st),
+               "lr_clip_to_ndhwc_bf16")
     saved = [x]
     h, w = H, W
     for li, (cin, cout, (kt, kh, kw), stride, (pt, ph, pw)) in enumerate(LAYERS):
@@ -77,7 +86,8 @@ class _ConvFrontendFunction(torch.autograd.Function):
         code = torch.empty(pooled.shape, dtype=torch.uint8, device=dev)
         _C.check(L.lr_conv3d_forward_pooled(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), pooled.data_ptr(),
                                             code.data_ptr(), B, T, h, w, cin_p, cout, kt, kh, kw, stride, pt, ph,
-                                            pw, 1 | frag, st), "lr_conv3d_forward_pooled")
+                                            pw, 1 | frag | (8 if (li == 0 and raw_u8) else 0), st),
+                 "lr_conv3d_forward_pooled")
         saved += [code, pooled]
       else:
         act = torch.empty((frames, ho, wo, cout), dtype=bf, device=dev)
@@ -123,13 +133,13 @@ class _ConvFrontendFunction(torch.autograd.Function):
       ho, wo = 2 * pooled.shape[1], 2 * pooled.shape[2]
       wbytes = max(L.lr_conv3d_wgrad_workspace_bytes(cout, cin_p, kt, kh, kw), L.lr_unpool_workspace_bytes(cout))
       ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-      if act.dtype == torch.uint8 and _PATCH_KERNELS and li == 0 and L.lr_conv3d_wgrad_pooled_supported(
+      if act.dtype == torch.uint8 and li == 0 and (_PATCH_KERNELS or x_in.dtype == torch.uint8) and L.lr_conv3d_wgrad_pooled_supported(
           h, w, cin_p, cin, cout, kt, kh, kw, stride, pt, ph, pw):
         # first layer (no data gradient needed): the weight-gradient kernel un-pools on the fly
         _C.check(L.lr_conv3d_wgrad_pooled(x_in.data_ptr(), pooled.data_ptr(), act.data_ptr(), dP.data_ptr(),
                                           grads[0].data_ptr(), grads[1].data_ptr(), ws.data_ptr(), wbytes,
                                           1 if direct else 0, B, T, h, w, cin_p, cin, cout, kt, kh, kw, stride, pt,
-                                          ph, pw, st), "lr_conv3d_wgrad_pooled")
+                                          ph, pw, 1 if x_in.dtype == torch.uint8 else 0, st), "lr_conv3d_wgrad_pooled")
         continue
       dZ = torch.empty((frames, ho, wo, cout), dtype=bf, device=dev)
       # the bias gradient (sum of the routed gradients) falls out of the un-pooling pass
