@@ -197,6 +197,8 @@ def run_regime(args, regime, world, rank, dev):
     enc = VideoEncoder(frame_dim, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
                        enable_ctc=True, vocab_size=VOCAB, char2idx=default_char2idx())
   model = PixelLipReader(enc, ConvFrontend3D()) if pixels else enc
+  if pixels and os.environ.get("LIPREADING_RECURRENCE"):   # experiment switch: 'bf16' = persistent recurrence
+    enc.recurrence = os.environ["LIPREADING_RECURRENCE"]
   model = model.to(dev).train()
   enc = model.encoder if pixels else model
   flat = FlatParameters(model)

@@ -112,8 +112,13 @@ int lr_sgemm_batched_impl(int transA, int transB, int M, int N, int K, float alp
 extern "C" size_t lr_sgemm_workspace_bytes(int M, int N, int K);
 // lr_rnn_persist.hip: the GRU-256 recurrence as one launch per layer pass (bf16 recurrent operands)
 int lr_gru256_persist_supported(int G, int B, int H);
+size_t lr_gru256_persist_pack_bytes(int D);
+size_t lr_gru256_persist_bwd_pack_bytes(int D);
+int lr_gru256_persist_backward(const float* gates, const float* extra, const float* y, const float* dy,
+                               const float* dh_n, float* dG, const float* const* w_hh, const int32_t* lens,
+                               void* wpack, int B, int T, int D, hipStream_t stream);
 int lr_gru256_persist_forward(float* gates, float* extra, float* y, const float* const* w_hh, const float* const* b_hh,
-                              const int32_t* lens, int B, int T, int D, hipStream_t stream);
+                              const int32_t* lens, void* wpack, int B, int T, int D, hipStream_t stream);
 // lr_xgemm.hip: fp32 GEMM on the bf16 matrix cores by hi/lo operand splitting (same operand
 // conventions; a_exact / b_exact: the operand's elements are bf16 values already)
 int lr_xgemm_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,

@@ -615,7 +615,9 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
   if (recur_bf16(mode)) {
     // one launch for all T steps (lr_rnn_persist.hip); same interface buffers as the step kernels
     if (!lr_gru256_persist_supported(G, B, H)) return LR_ERR_UNSUPPORTED;
-    int st = lr_gru256_persist_forward(gates, extra, y, w_hh, b_hh, lens, B, T, D, stream);
+    // the step kernels' packed-W_hh area of the reserve holds the bf16 fragments instead
+    if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_gru256_persist_pack_bytes(D)) return LR_ERR_WORKSPACE;
+    int st = lr_gru256_persist_forward(gates, extra, y, w_hh, b_hh, lens, base + l.wp, B, T, D, stream);
     if (st != LR_OK) return st;
     const int64_t total = (int64_t)D * B * H;
     int blocks = (int)((total + 255) / 256);
@@ -699,6 +701,15 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
   void* gws = wbase + wl.gemm;
   const int GH = G * H;
 
+  int st = LR_OK;
+  if (recur_bf16(mode)) {
+    // one launch for all T steps (lr_rnn_persist.hip); dG comes out in the step kernels' layout.  The
+    // packed-W_hh^T area of the workspace holds the bf16 fragments.
+    if (!lr_gru256_persist_supported(G, B, H) || dc_n) return LR_ERR_UNSUPPORTED;
+    if ((size_t)D * wl.wp_per_dir * sizeof(float) < lr_gru256_persist_bwd_pack_bytes(D)) return LR_ERR_WORKSPACE;
+    st = lr_gru256_persist_backward(gates, extra, y, dy, dh_n, dG, w_hh, lens, wT, B, T, D, stream);
+    if (st != LR_OK) return st;
+  } else {
   StepPtrs p;
   p.h0 = nullptr;
   p.c0 = nullptr;
@@ -712,7 +723,7 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
     p.b[d] = nullptr;
   }
   if (D == 1) { p.w[1] = p.w[0]; p.b[1] = nullptr; }
-  int st = lr_launch_status();
+  st = lr_launch_status();
   if (st != LR_OK) return st;
   if (hipMemsetAsync(dgp, 0, wl.dgp_floats * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
 
@@ -730,6 +741,7 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
   }
   st = lr_launch_status();
   if (st != LR_OK) return st;
+  }
 
   const int R = B * T;
   const int ldg = D * 4 * H;
