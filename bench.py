@@ -197,7 +197,7 @@ def run_regime(args, regime, world, rank, dev):
     enc = VideoEncoder(frame_dim, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
                        enable_ctc=True, vocab_size=VOCAB, char2idx=default_char2idx())
   model = PixelLipReader(enc, ConvFrontend3D()) if pixels else enc
-  if pixels and os.environ.get("LIPREADING_RECURRENCE"):   # experiment switch: 'bf16' = persistent recurrence
+  if pixels and os.environ.get("LIPREADING_RECURRENCE"):   # 'f32': step kernels instead of the persistent bf16 recurrence
     enc.recurrence = os.environ["LIPREADING_RECURRENCE"]
   model = model.to(dev).train()
   enc = model.encoder if pixels else model
@@ -343,6 +343,12 @@ def run_regime(args, regime, world, rank, dev):
   res["value"] = round(frames_per_step * args.steps / elapsed, 1)
   res["ms_per_step"] = round(elapsed / args.steps * 1e3, 4)
   by_kernel = {k: round(v[0], 3) for k, v in prof.items()}
+  if pixels and getattr(enc, "recurrence", "f32") == "bf16" and rnn_type == "GRU" and H == 256:
+    # the recurrence slots carry ONE launch per layer pass (all 75 steps), not a step
+    for old_k, new_k in (("rnn_fwd_step_kernel", "gru256_fwd_persist_kernel (layer pass)"),
+                         ("rnn_bwd_step_kernel", "gru256_bwd_persist_kernel (layer pass)")):
+      if old_k in by_kernel:
+        by_kernel[new_k] = by_kernel.pop(old_k)
   roofline = None
   if pixels:
     flops = conv_flops(B)
@@ -392,9 +398,13 @@ def run_regime(args, regime, world, rank, dev):
   elif pixels:
     res["workload"] = ("regime X (BASELINE metric shape, frontend build-defined: the reference has no conv "
                        "stage): uint8 clips (B=%d,T=75,3,96,96) -> STCNN x3 (bf16 MFMA implicit GEMM, fp32 "
-                       "accumulate) -> %d-layer Bi%s-%d (fp32) -> Linear(%d,65) -> masked log-softmax -> CTC "
+                       "accumulate) -> %d-layer Bi%s-%d (%s) -> Linear(%d,65) -> masked log-softmax -> CTC "
                        "'mean' (L=30+EOS) -> backward -> clip_grad_norm 50 -> Adam 1e-4"
-                       % (B, layers, rnn_type, H, D * H))
+                       % (B, layers, rnn_type, H,
+                          "input projection bf16x3; recurrence in one launch per pass, bf16 operands, fp32 "
+                          "accumulation and state" if getattr(enc, "recurrence", "f32") == "bf16" and rnn_type == "GRU"
+                          and H == 256 else "input projection bf16x3, fp32 recurrence", D * H))
+    res["recurrence"] = getattr(enc, "recurrence", "f32")
   elif attn:
     res["workload"] = ("regime R+decoder (the reference's whole train step): landmarks (B=%d,T=75,68,3) f32 -> "
                        "1-layer Bi%s-%d -> Linear(%d,65) + CTC 'mean' (L=30+EOS) AND CharDecodingStep x31 "
@@ -453,7 +463,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16 (conv frontend, fp32 accumulate) + f32 (encoder, CTC)" if head["regime"] == "pixels" else "f32",
+        "dtype": ("bf16 (conv frontend, recurrent and input-projection operands; fp32 accumulation, state, CTC)"
+                  if head.get("recurrence") == "bf16" else "bf16 (conv frontend, fp32 accumulate) + f32 (encoder, CTC)")
+                 if head["regime"] == "pixels" else "f32",
         "data": "synthetic",
         "config": {"workload": head["workload"], "regime": head["regime"], "model": args.model,
                    "recurrent_layers": head["layers"], "per_gpu_batch": args.batch,

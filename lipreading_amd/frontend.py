@@ -200,6 +200,11 @@ class PixelLipReader(nn.Module):
     # (K = 3456 features) on the bf16 matrix cores with hi/lo split fp32 operands
     encoder.input_projection = 'bf16x3'
     encoder.input_is_bf16 = True
+    # ... and run the recurrence of every layer that has the kernel (GRU, H = 256) as ONE launch per
+    # pass with bf16 recurrent operands (W_hh in registers, fp32 accumulation, fp32 carried state):
+    # BASELINE configs[1] names this regime "bf16".  Other shapes keep the fp32 step kernels;
+    # `encoder.recurrence = 'f32'` switches it off.
+    encoder.recurrence = 'bf16'
   def forward(self, clips, frame_lens, max_len=None):
     feats = self.frontend(clips)
     B, T, F = feats.shape
