@@ -358,8 +358,19 @@ def run_regime(args, regime, world, rank, dev):
       dom = max(cand, key=lambda k: cand[k][0])
       us = cand[dom][0]
       ach = flops[dom] / (us * 1e-6) / 1e12
+      traffic, traffic_src = None, None
+      try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+          pmc = json.load(f)
+        if B == 32:
+          traffic = pmc["pixels"][dom]["traffic_bytes"]
+          traffic_src = ("profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                         "64-byte gathers: fetch not doubled, see its note)")
+      except Exception:
+        pass
       roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                  "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                  "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                  "traffic_source": traffic_src,
                   "avg_launch_us": round(us, 1), "algorithmic_flops_per_launch": flops[dom],
                   "avg_launch_us_by_kernel": by_kernel,
                   "tflops_by_kernel": {k: round(flops[k] / (v[0] * 1e-6) / 1e12, 1) for k, v in cand.items()}}
