@@ -50,11 +50,11 @@ typedef enum lr_rnn_mode {
    * of x is already a bf16 value, so x needs no lo term, and dx goes to a bf16 consumer (the
    * frontend's backward), so dx is contracted from the hi terms only. */
   LR_RNN_INPUT_BF16_EXACT = 0x200,
-  /* Run the recurrence of a GRU layer with H = 256 and B <= 32 as ONE launch per pass: W_hh rounded
-   * to bf16 lives in the registers + LDS of one compute unit per (direction, 16-sample group), the
-   * recurrent product runs on the bf16 matrix cores with fp32 accumulation, gate math and carried
-   * state (lr_rnn_persist.hip).  Build-defined (pixel regime, BASELINE configs[1] "bf16"); other
-   * shapes return LR_ERR_UNSUPPORTED — query lr_rnn_persistent_supported first. */
+  /* Run the recurrence of a GRU layer with H = 256 as ONE launch per pass (forward and backward):
+   * W_hh rounded to bf16 lives in the registers + LDS of one compute unit per (sample, direction),
+   * the recurrent product runs on the bf16 matrix cores with fp32 accumulation, gate math and
+   * carried state (lr_rnn_persist.hip).  Build-defined (pixel regime, BASELINE configs[1] "bf16");
+   * other shapes return LR_ERR_UNSUPPORTED — query lr_rnn_persistent_supported first. */
   LR_RNN_RECUR_BF16 = 0x400
 } lr_rnn_mode;
 

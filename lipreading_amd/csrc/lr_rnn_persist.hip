@@ -1,28 +1,30 @@
 // lr_rnn_persist.hip — the GRU-256 recurrence as ONE launch per layer pass (pixel regime).
 //
 // The step-per-launch recurrence of lr_rnn.hip is bound by launch boundaries and memory round trips
-// (~6 us per step whatever the arithmetic), because fp32 W_hh (768 KB per direction) has to be
+// (~5 us per step whatever the arithmetic), because fp32 W_hh (768 KB per direction) has to be
 // re-streamed from the fabric every step.  BASELINE.json's configs[1] (the pixel regime: conv
 // frontend + BiGRU-256, "bf16") allows a different trade: with W_hh rounded to bf16 (384 KB per
 // direction) the whole matrix fits ONE compute unit — 288 KB as MFMA operand fragments held in
-// the registers of 4 waves, 96 KB in LDS — and batch rows are independent, so a direction's 32
-// samples split into two groups of 16 that never communicate.  A layer pass is then 2 x D
-// workgroups that each run all T steps with nothing but a workgroup barrier per step:
-//   state (16 x 256, bf16, double-buffered in LDS) x W_hh^T on v_mfma_f32_16x16x32_bf16 (96 per wave
-//   per step), fp32 accumulation, fp32 gate math and fp32 carried state in registers.
+// the registers of 4 waves (240 of each wave's 256 AGPRs + 48 VGPRs), 96 KB in LDS — and batch rows
+// are independent, so every (sample, direction) gets its own workgroup that runs all T steps with
+// nothing but one workgroup barrier per step:
+//   state (bf16, double-buffered in LDS, row 0 of the 16-row MFMA operand) x W_hh^T on
+//   v_mfma_f32_16x16x32_bf16 (96 per wave per step), fp32 accumulation, fp32 gate math and fp32
+//   carried state in registers.  The backward kernel is the mirror image (dGh x W_hh over K = 768).
+// The AGPR-resident fragments are read by the matrix core directly: the MFMAs are inline asm with an
+// "a" operand (the compiler's own MFMA selection first copies AGPR-resident operands to VGPRs — 57
+// cycles per MFMA instead of ~17).  Fragments are pre-packed (gru256_pack_whh*_kernel) so the prologue
+// is 1 KB-per-wave loads: reading row-major fp32 W_hh in the prologue cost 85 us per launch.
 // The interface buffers are those of the step kernels (gates in/out, extra, y, dG: fp32), so the
 // one-shot GEMMs around the recurrence (input projection, weight gradients) are unchanged, and so
 // is the reference-faithful fp32 path, which never comes here.  No reference counterpart beyond
 // better_model.py:74 (nn.GRU); precision: bf16 operands in the recurrent product only.
 //
-// STATUS: opt-in (VideoEncoder.recurrence = 'bf16'), correct (tests/test_gpu_encoder.py), measured
-// on MI355X at B = 32, T = 75: 4.0 us per step (a layer pass 301 us) against ~5.3-6.0 us for the step
-// kernels — the pixel step only moves from 5.32 to ~5.2 ms with both forward passes on it, because a
-// workgroup's product phase is ~2.3 us (96 v_mfma_f32_16x16x32_bf16 with half of their B operands
-// staged out of AGPRs, ~57 cycles apiece) and the gate phase + interface traffic another ~1.7 us.
-// Sample groups of 4 (not 16) per workgroup keep the gate phase and the per-CU interface traffic
-// small: the first cut with 16 samples per workgroup ran 6.7 us per step.  Not enabled by default:
-// a matching persistent backward would be needed for a ~6 % gain, at bf16 recurrent precision.
+// STATUS: what PixelLipReader runs (VideoEncoder.recurrence = 'bf16'; tests/test_gpu_encoder.py
+// checks it against the step kernels, ragged lengths included).  MI355X, B = 32, T = 75: 111 us per
+// forward layer pass (1.5 us per step), 153 us per backward pass (2.0 us), against 5.4 / 4.8 us per
+// step for the step kernels.  History: 16 samples per workgroup 6.7 us/step; 4 samples 4.0; AGPR
+// operands 3.4; one sample per workgroup 2.7; pre-packed fragments 1.5.
 #include "lr_common.h"
 #include <hip/hip_ext.h>
 
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(256, 1) void gru256_bwd_persist_kernel(
 
 }  // namespace
 
-int lr_gru256_persist_supported(int G, int B, int H) { return G == 3 && H == PH && B >= 1 && B <= 64 ? 1 : 0; }
+int lr_gru256_persist_supported(int G, int B, int H) { return G == 3 && H == PH && B >= 1 ? 1 : 0; }
 
 // bytes of packed-weight workspace lr_gru256_persist_forward needs (bf16 fragments of every direction)
 size_t lr_gru256_persist_pack_bytes(int D) { return (size_t)D * 4 * PNT * PKS * 64 * sizeof(bf16x8); }

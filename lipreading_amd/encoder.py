@@ -215,7 +215,7 @@ class VideoEncoder(nn.Module):
     self.input_projection = 'f32'
     self.input_is_bf16 = False
     # 'f32': one launch per time step, exact fp32 (reference-faithful); 'bf16' (pixel regime): the
-    # whole recurrence of a supported layer (GRU, H = 256, B <= 32) in one launch with bf16 W_hh
+    # whole recurrence of a supported layer (GRU, H = 256) in one launch per pass with bf16 W_hh
     self.recurrence = 'f32'
     if self.enable_ctc:
       self.vocab_size = vocab_size
