@@ -136,3 +136,5 @@ int lr_xproj_dw(const float* dG, int ldg, int dstride, const float* x, int R, in
                 hipStream_t stream);
 int lr_xproj_dx(const float* dG, int ldg, int dstride, const float* const* w_ih, int R, int I, int GH, int D,
                 float* dx, int hi_only, void* workspace, size_t workspace_bytes, hipStream_t stream);
+int lr_xproj_dwhh(const float* dG, int ldg, const float* y, int ldy, int R, int T, int H, int G, int D,
+                  float* const* dw_hh, float beta, void* workspace, size_t workspace_bytes, hipStream_t stream);

@@ -756,8 +756,11 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
       st = lr_xproj_dx(dG, ldg, 4 * H, w_ih, R, I, GH, D, dx, x_exact(mode) ? 1 : 0, xws, xws_bytes, stream);
       if (st != LR_OK) return st;
     }
+    // recurrent weight gradient on the same split-bf16 path (one contraction per direction)
+    st = lr_xproj_dwhh(dG, ldg, y, D * H, R, T, H, G, D, dw_hh, wbeta, xws, xws_bytes, stream);
+    if (st != LR_OK) return st;
   }
-  for (int d = 0; d < D; ++d) {
+  for (int d = 0; d < D && !x3; ++d) {
     const float* dGd = dG + (size_t)d * 4 * H;
     // dW_ih[d] (G*H x I) = dGx^T (slots 0..G-1 are contiguous rows) @ x
     if (!x3) {

@@ -58,9 +58,12 @@ struct XArgs {
 // Output columns [0, owidth) are written, zero beyond the logical width (the contraction reads whole
 // 16-byte units up to ldp); hi / lo may point into the middle of a larger plane (an operand assembled
 // from several blocks).  32x32 tiles, 256 threads; the grid covers the OUTPUT extent.
+// shift / period: input row r is read from row r + shift, or as zero when (r % period) + shift leaves
+// [0, period) — the previous / next time step of a [B*T][cols] sequence tensor (period = T).
 __global__ __launch_bounds__(256) void xpack_kernel(const float* __restrict__ in, int ld_in, int rows, int cols,
                                                     int transpose, bf16_t* __restrict__ hi,
-                                                    bf16_t* __restrict__ lo, int ldp, int owidth) {
+                                                    bf16_t* __restrict__ lo, int ldp, int owidth, int shift,
+                                                    int period) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   // tile origin in OUTPUT coordinates (orow, ocol); input origin is the same or swapped
@@ -69,7 +72,12 @@ __global__ __launch_bounds__(256) void xpack_kernel(const float* __restrict__ in
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = ir0 + ty + 8 * i, c = ic0 + tx;
-    tile[ty + 8 * i][tx] = (r < rows && c < cols) ? in[(int64_t)r * ld_in + c] : 0.f;
+    bool ok = r < rows && c < cols;
+    if (ok && shift != 0) {
+      const int tt = r % period + shift;
+      ok = tt >= 0 && tt < period;
+    }
+    tile[ty + 8 * i][tx] = ok ? in[(int64_t)(r + shift) * ld_in + c] : 0.f;
   }
   __syncthreads();
   const int orows = transpose ? cols : rows;
@@ -260,10 +268,10 @@ int want_splits(int M, int N, int K) {
 // planes [orows][owidth of ldp] of an operand block stored [rows][cols] (transpose: planes are
 // [cols][rows]); hi / lo may be offset into a larger plane
 int pack_operand(const float* in, int ld_in, int rows, int cols, int transpose, bf16_t* hi, bf16_t* lo, int ldp,
-                 int owidth, hipStream_t stream) {
+                 int owidth, hipStream_t stream, int shift = 0, int period = 1) {
   const int orows = transpose ? cols : rows;
   LR_LAUNCH(xpack_kernel, dim3((owidth + 31) / 32, (orows + 31) / 32), dim3(256), 0, stream, in, ld_in, rows, cols,
-            transpose, hi, lo, ldp, owidth);
+            transpose, hi, lo, ldp, owidth, shift, period);
   return lr_launch_status();
 }
 
@@ -373,6 +381,8 @@ size_t lr_xproj_workspace_bytes(int R, int I, int GH, int D) {
   if (b > a) a = b;
   b = lr_xgemm_workspace_bytes(0, 0, R, I, D * GH);
   if (b > a) a = b;
+  b = lr_xgemm_workspace_bytes(1, 0, GH, GH, R);   // recurrent weight gradient: GH x H over K = R (H <= GH)
+  if (b > a) a = b;
   return a;
 }
 
@@ -432,4 +442,32 @@ extern "C" int lr_xgemm(int transA, int transB, int M, int N, int K, float alpha
                         int a_exact, int b_exact, void* workspace, size_t workspace_bytes, lr_stream_t stream) {
   return lr_xgemm_impl(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, a_exact, b_exact,
                        workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// dW_hh[d][G*H][H] (beta) = dGh[:, d]^T . h_prev[:, d], h_prev[b,t] = y[b,t-1] (d = 0) / y[b,t+1] (d = 1), zero
+// across sequence ends.  dG rows hold 4 slots of H per direction; the recurrent side reads slots
+// (0, 1, 3) for the GRU (dr, dz, d(W_hn h + b_hn)) and (0..3) for the LSTM.
+int lr_xproj_dwhh(const float* dG, int ldg, const float* y, int ldy, int R, int T, int H, int G, int D,
+                  float* const* dw_hh, float beta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  const int GH = G * H, ldp = ldp_of(R);
+  Planes pl;
+  if (!carve(workspace, workspace_bytes, GH, H, R, false, false, &pl)) return LR_ERR_WORKSPACE;
+  for (int d = 0; d < D; ++d) {
+    const float* g = dG + (size_t)d * 4 * H;
+    int st;
+    if (G == 3) {
+      st = pack_operand(g, ldg, R, 2 * H, 1, pl.Ah, pl.Al, ldp, ldp, stream);
+      if (st == LR_OK)
+        st = pack_operand(g + 3 * H, ldg, R, H, 1, pl.Ah + (size_t)2 * H * ldp, pl.Al + (size_t)2 * H * ldp, ldp, ldp,
+                          stream);
+    } else {
+      st = pack_operand(g, ldg, R, GH, 1, pl.Ah, pl.Al, ldp, ldp, stream);
+    }
+    if (st == LR_OK) st = pack_operand(y + (size_t)d * H, ldy, R, H, 1, pl.Bh, pl.Bl, ldp, ldp, stream, d == 0 ? -1 : 1, T);
+    if (st == LR_OK)
+      st = contract(pl.Ah, pl.Al, pl.Bh, pl.Bl, GH, H, R, 1.f, beta, dw_hh[d], nullptr, GH, H, nullptr, pl.slabs,
+                    pl.slab_floats, stream);
+    if (st != LR_OK) return st;
+  }
+  return LR_OK;
 }
