@@ -51,6 +51,10 @@ struct XArgs {
   int k_chunk;     // K range per split (multiple of XBK)
   float* slabs;    // split-K partial sums [splits][M][N], or nullptr
   int nx, ny, splits, per_xcd;   // tile grid and the number of tiles each XCD takes
+  // batch (blockIdx.y): independent products of one shape sharing a launch
+  int64_t a_bstride, b_bstride;  // bf16 elements between the batches' planes (hi and lo alike)
+  int64_t slab_bstride;          // floats between the batches' split-K slabs
+  float* Cb;                     // C of batch 1 (batch 0 writes C); no C1 split when batched
 };
 
 // ---- pass 1: fp32 [rows][cols] (or its transpose) -> bf16 hi (+ lo) planes [rows'][ldp] -------------
@@ -95,6 +99,51 @@ __global__ __launch_bounds__(256) void xpack_kernel(const float* __restrict__ in
   }
 }
 
+// Several pack blocks in one launch (blockIdx.z): the operands of one product — and of the products
+// of both directions — are each a handful of small blocks, and a launch per block cost ~5 us apiece.
+struct XPackBlock {
+  const float* in;
+  bf16_t* hi;
+  bf16_t* lo;
+  int ld_in, rows, cols, transpose, ldp, owidth, shift, period;
+};
+constexpr int XPACK_MAX = 8;
+struct XPackArgs {
+  XPackBlock b[XPACK_MAX];
+};
+__global__ __launch_bounds__(256) void xpack_multi_kernel(XPackArgs a) {
+  __shared__ float tile[32][33];
+  const XPackBlock& k = a.b[blockIdx.z];
+  const int orows = k.transpose ? k.cols : k.rows;
+  const int or0 = blockIdx.y * 32, oc0 = blockIdx.x * 32;
+  if (or0 >= orows || oc0 >= k.owidth) return;   // workgroup-uniform
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int ir0 = k.transpose ? oc0 : or0, ic0 = k.transpose ? or0 : oc0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = ir0 + ty + 8 * i, c = ic0 + tx;
+    bool ok = r < k.rows && c < k.cols;
+    if (ok && k.shift != 0) {
+      const int tt = r % k.period + k.shift;
+      ok = tt >= 0 && tt < k.period;
+    }
+    tile[ty + 8 * i][tx] = ok ? k.in[(int64_t)(r + k.shift) * k.ld_in + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int orow = or0 + ty + 8 * i, ocol = oc0 + tx;
+    if (orow >= orows || ocol >= k.owidth) continue;
+    const float v = k.transpose ? tile[tx][ty + 8 * i] : tile[ty + 8 * i][tx];
+    const __bf16 h = (__bf16)v;
+    k.hi[(int64_t)orow * k.ldp + ocol] = __builtin_bit_cast(bf16_t, h);
+    if (k.lo) {
+      const __bf16 l = (__bf16)(v - (float)h);
+      k.lo[(int64_t)orow * k.ldp + ocol] = __builtin_bit_cast(bf16_t, l);
+    }
+  }
+}
+
 // ---- pass 2: C = sum over the retained (hi, lo) products of A_plane . B_plane^T ------------------------
 // AX / BX: operand is bf16-exact, no lo plane.
 template <bool AX, bool BX>
@@ -118,6 +167,16 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
   const int in_grp = tt - grp * XGROUP_M * g.nx;
   const int m0 = (first_m + in_grp % gm) * XBM, n0 = (in_grp / gm) * XBN;
   const int kbeg = zs * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
+  const int bz = blockIdx.y;
+  if (bz) {   // workgroup-uniform
+    g.Ah += (int64_t)bz * g.a_bstride;
+    if (!AX) g.Al += (int64_t)bz * g.a_bstride;
+    g.Bh += (int64_t)bz * g.b_bstride;
+    if (!BX) g.Bl += (int64_t)bz * g.b_bstride;
+    if (g.slabs) g.slabs += (int64_t)bz * g.slab_bstride;
+    g.C = g.Cb;
+    g.C1 = g.Cb;
+  }
 
   // a plane tile is 128 rows x 32 k = 512 16-byte units: two per thread (row = e / 4, unit = e % 4)
   auto fetch = [&](const bf16_t* p, int row, int row_lim, int k) -> uint4 {
@@ -227,8 +286,14 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
 // deterministic split-K combine (fixed order over the slabs), then alpha / beta / bias
 __global__ void xsplitk_reduce_kernel(const float* __restrict__ slabs, int splits, float* __restrict__ C,
                                       float* __restrict__ C1, int split_row, int ldc,
-                                      const float* __restrict__ bias, int M, int N, float alpha, float beta) {
+                                      const float* __restrict__ bias, int M, int N, float alpha, float beta,
+                                      float* __restrict__ Cb, int64_t slab_bstride) {
   const int64_t total = (int64_t)M * N;
+  if (blockIdx.y) {   // batch 1
+    slabs += slab_bstride;
+    C = Cb;
+    C1 = Cb;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int z = 0; z < splits; ++z) s += slabs[(int64_t)z * total + i];
@@ -275,14 +340,37 @@ int pack_operand(const float* in, int ld_in, int rows, int cols, int transpose, 
   return lr_launch_status();
 }
 
-// C (+ C1 below split_row) = alpha * A_planes . B_planes^T + beta * C + bias; slabs: split-K workspace
+// a list of pack blocks launched together
+struct PackList {
+  XPackArgs a;
+  int n = 0, gx = 0, gy = 0;
+  void add(const float* in, int ld_in, int rows, int cols, int transpose, bf16_t* hi, bf16_t* lo, int ldp, int owidth,
+           int shift = 0, int period = 1) {
+    XPackBlock& k = a.b[n++];
+    k.in = in; k.hi = hi; k.lo = lo;
+    k.ld_in = ld_in; k.rows = rows; k.cols = cols; k.transpose = transpose; k.ldp = ldp; k.owidth = owidth;
+    k.shift = shift; k.period = period;
+    const int orows = transpose ? cols : rows;
+    if ((owidth + 31) / 32 > gx) gx = (owidth + 31) / 32;
+    if ((orows + 31) / 32 > gy) gy = (orows + 31) / 32;
+  }
+  int launch(hipStream_t stream) {
+    LR_LAUNCH(xpack_multi_kernel, dim3(gx, gy, n), dim3(256), 0, stream, a);
+    return lr_launch_status();
+  }
+};
+
+// C (+ C1 below split_row) = alpha * A_planes . B_planes^T + beta * C + bias; slabs: split-K workspace.
+// nbatch = 2: a second product of the same shape in the same launch (planes a_bstride / b_bstride
+// bf16 elements further, output Cb, its slabs behind the first batch's).
 int contract(const bf16_t* Ahp, const bf16_t* Alp, const bf16_t* Bhp, const bf16_t* Blp, int M, int N, int K,
              float alpha, float beta, float* C, float* C1, int split_row, int ldc, const float* bias, float* slabs,
-             size_t slab_floats, hipStream_t stream) {
+             size_t slab_floats, hipStream_t stream, int nbatch = 1, int64_t a_bstride = 0, int64_t b_bstride = 0,
+             float* Cb = nullptr) {
   const int ldp = ldp_of(K);
   // split-K as far as the remaining workspace allows (none: a single pass, just slower)
-  int splits = want_splits(M, N, K);
-  while (splits > 1 && (size_t)splits * M * N > slab_floats) --splits;
+  int splits = want_splits(M, N * nbatch, K);
+  while (splits > 1 && (size_t)splits * M * N * nbatch > slab_floats) --splits;
   int chunk = (K + splits - 1) / splits;
   chunk = (chunk + XBK - 1) / XBK * XBK;
   splits = (K + chunk - 1) / chunk;
@@ -296,9 +384,12 @@ int contract(const bf16_t* Ahp, const bf16_t* Alp, const bf16_t* Bhp, const bf16
   g.nx = (N + XBN - 1) / XBN;
   g.ny = (M + XBM - 1) / XBM;
   g.splits = splits;
+  g.a_bstride = a_bstride; g.b_bstride = b_bstride;
+  g.slab_bstride = (int64_t)splits * M * N;
+  g.Cb = Cb ? Cb : C;
   const int ntile = g.nx * g.ny * splits;
   g.per_xcd = (ntile + 7) / 8;
-  dim3 grid(8 * g.per_xcd);
+  dim3 grid(8 * g.per_xcd, nbatch);
   lr_clear_error();
   const bool ax = Alp == nullptr, bx = Blp == nullptr;
   if (ax && bx) hipLaunchKernelGGL((xgemm_kernel<true, true>), grid, dim3(256), 0, stream, g);
@@ -310,8 +401,8 @@ int contract(const bf16_t* Ahp, const bf16_t* Alp, const bf16_t* Bhp, const bf16
   const int64_t total = (int64_t)M * N;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  LR_LAUNCH(xsplitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)g.slabs, splits, C, g.C1,
-            g.split_row, ldc, bias, M, N, alpha, beta);
+  LR_LAUNCH(xsplitk_reduce_kernel, dim3(blocks, nbatch), dim3(256), 0, stream, (const float*)g.slabs, splits, C, g.C1,
+            g.split_row, ldc, bias, M, N, alpha, beta, g.Cb, g.slab_bstride);
   return lr_launch_status();
 }
 
@@ -371,9 +462,10 @@ int lr_xgemm_impl(int transA, int transB, int M, int N, int K, float alpha, cons
                   pl.slab_floats, stream);
 }
 
-// ---- the three products of a recurrent layer's input projection, all directions in ONE contraction ----
+// ---- the products of a recurrent layer around its recurrence, all directions in ONE contraction -------
 // (lr_rnn.hip, LR_RNN_PROJ_BF16X3).  R = B*T rows, I input features, GH gate rows per direction, D
 // directions; gates / dG keep the directions side by side in a row (leading dimensions ldgates, ldg).
+// Every product packs all of its operand blocks in one launch (PackList).
 size_t lr_xproj_workspace_bytes(int R, int I, int GH, int D) {
   if (R <= 0 || I <= 0 || GH <= 0 || D <= 0) return 0;
   size_t a = lr_xgemm_workspace_bytes(0, 1, R, D * GH, I);
@@ -381,7 +473,8 @@ size_t lr_xproj_workspace_bytes(int R, int I, int GH, int D) {
   if (b > a) a = b;
   b = lr_xgemm_workspace_bytes(0, 0, R, I, D * GH);
   if (b > a) a = b;
-  b = lr_xgemm_workspace_bytes(1, 0, GH, GH, R);   // recurrent weight gradient: GH x H over K = R (H <= GH)
+  // recurrent weight gradient: D batched products GH x H' over K = R, H' <= GH
+  b = (size_t)D * (plane_floats(GH, R, false) + plane_floats(GH, R, false) + pad64((size_t)16 * GH * GH)) * sizeof(float);
   if (b > a) a = b;
   return a;
 }
@@ -390,12 +483,14 @@ size_t lr_xproj_workspace_bytes(int R, int I, int GH, int D) {
 int lr_xproj_forward(const float* x, int R, int I, const float* const* w_ih, int GH, int D, const float* bias,
                      float* gates, int x_exact, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   const int N = D * GH, ldp = ldp_of(I);
+  if (1 + D > XPACK_MAX) return LR_ERR_UNSUPPORTED;
   Planes pl;
   if (!carve(workspace, workspace_bytes, R, N, I, x_exact != 0, false, &pl)) return LR_ERR_WORKSPACE;
-  int st = pack_operand(x, I, R, I, 0, pl.Ah, pl.Al, ldp, ldp, stream);
-  for (int d = 0; d < D && st == LR_OK; ++d)
-    st = pack_operand(w_ih[d], I, GH, I, 0, pl.Bh + (size_t)d * GH * ldp, pl.Bl + (size_t)d * GH * ldp, ldp, ldp,
-                      stream);
+  PackList pk;
+  pk.add(x, I, R, I, 0, pl.Ah, pl.Al, ldp, ldp);
+  for (int d = 0; d < D; ++d)
+    pk.add(w_ih[d], I, GH, I, 0, pl.Bh + (size_t)d * GH * ldp, pl.Bl + (size_t)d * GH * ldp, ldp, ldp);
+  int st = pk.launch(stream);
   if (st != LR_OK) return st;
   return contract(pl.Ah, pl.Al, pl.Bh, pl.Bl, R, N, I, 1.f, 0.f, gates, nullptr, R, N, bias, pl.slabs, pl.slab_floats,
                   stream);
@@ -406,13 +501,14 @@ int lr_xproj_dw(const float* dG, int ldg, int dstride, const float* x, int R, in
                 float* const* dw_ih, float beta, int x_exact, void* workspace, size_t workspace_bytes,
                 hipStream_t stream) {
   const int M = D * GH, ldp = ldp_of(R);
+  if (1 + D > XPACK_MAX) return LR_ERR_UNSUPPORTED;
   Planes pl;
   if (!carve(workspace, workspace_bytes, M, I, R, false, x_exact != 0, &pl)) return LR_ERR_WORKSPACE;
-  int st = LR_OK;
-  for (int d = 0; d < D && st == LR_OK; ++d)
-    st = pack_operand(dG + (size_t)d * dstride, ldg, R, GH, 1, pl.Ah + (size_t)d * GH * ldp,
-                      pl.Al + (size_t)d * GH * ldp, ldp, ldp, stream);
-  if (st == LR_OK) st = pack_operand(x, I, R, I, 1, pl.Bh, pl.Bl, ldp, ldp, stream);
+  PackList pk;
+  for (int d = 0; d < D; ++d)
+    pk.add(dG + (size_t)d * dstride, ldg, R, GH, 1, pl.Ah + (size_t)d * GH * ldp, pl.Al + (size_t)d * GH * ldp, ldp, ldp);
+  pk.add(x, I, R, I, 1, pl.Bh, pl.Bl, ldp, ldp);
+  int st = pk.launch(stream);
   if (st != LR_OK) return st;
   return contract(pl.Ah, pl.Al, pl.Bh, pl.Bl, M, I, R, 1.f, beta, dw_ih[0], D > 1 ? dw_ih[1] : nullptr, GH, I, nullptr,
                   pl.slabs, pl.slab_floats, stream);
@@ -422,19 +518,56 @@ int lr_xproj_dw(const float* dG, int ldg, int dstride, const float* x, int R, in
 int lr_xproj_dx(const float* dG, int ldg, int dstride, const float* const* w_ih, int R, int I, int GH, int D,
                 float* dx, int hi_only, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   const int K = D * GH, ldp = ldp_of(K);
+  if (2 * D > XPACK_MAX) return LR_ERR_UNSUPPORTED;
   Planes pl;
   if (!carve(workspace, workspace_bytes, R, I, K, hi_only != 0, hi_only != 0, &pl)) return LR_ERR_WORKSPACE;
-  int st = LR_OK;
-  for (int d = 0; d < D && st == LR_OK; ++d) {
+  PackList pk;
+  for (int d = 0; d < D; ++d) {
     const int ow = d == D - 1 ? ldp - d * GH : GH;
-    st = pack_operand(dG + (size_t)d * dstride, ldg, R, GH, 0, pl.Ah + d * GH, pl.Al ? pl.Al + d * GH : nullptr, ldp,
-                      ow, stream);
-    if (st == LR_OK)
-      st = pack_operand(w_ih[d], I, GH, I, 1, pl.Bh + d * GH, pl.Bl ? pl.Bl + d * GH : nullptr, ldp, ow, stream);
+    pk.add(dG + (size_t)d * dstride, ldg, R, GH, 0, pl.Ah + d * GH, pl.Al ? pl.Al + d * GH : nullptr, ldp, ow);
+    pk.add(w_ih[d], I, GH, I, 1, pl.Bh + d * GH, pl.Bl ? pl.Bl + d * GH : nullptr, ldp, ow);
   }
+  int st = pk.launch(stream);
   if (st != LR_OK) return st;
   return contract(pl.Ah, pl.Al, pl.Bh, pl.Bl, R, I, K, 1.f, 0.f, dx, nullptr, R, I, nullptr, pl.slabs, pl.slab_floats,
                   stream);
+}
+
+// dW_hh[d][G*H][H] (beta) = dGh[:, d]^T . h_prev[:, d], h_prev[b,t] = y[b,t-1] (d = 0) / y[b,t+1] (d = 1), zero
+// across sequence ends.  dG rows hold 4 slots of H per direction; the recurrent side reads slots
+// (0, 1, 3) for the GRU (dr, dz, d(W_hn h + b_hn)) and (0..3) for the LSTM.  The directions are two
+// batches of one launch (operands packed together, one contraction, one split-K combine).
+int lr_xproj_dwhh(const float* dG, int ldg, const float* y, int ldy, int R, int T, int H, int G, int D,
+                  float* const* dw_hh, float beta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  const int GH = G * H, ldp = ldp_of(R);
+  if (D > 2 || 3 * D > XPACK_MAX) return LR_ERR_UNSUPPORTED;
+  const size_t fa = plane_floats(GH, R, false), fb = plane_floats(H, R, false);
+  const size_t avail = workspace_bytes / sizeof(float);
+  if (avail < D * (fa + fb)) return LR_ERR_WORKSPACE;
+  float* ws = (float*)workspace;
+  bf16_t* A0 = (bf16_t*)ws;
+  bf16_t* B0 = (bf16_t*)(ws + D * fa);
+  float* slabs = ws + D * (fa + fb);
+  const size_t slab_floats = avail - D * (fa + fb);
+  PackList pk;
+  for (int d = 0; d < D; ++d) {
+    const float* g = dG + (size_t)d * 4 * H;
+    bf16_t* Ah = A0 + (size_t)d * fa * 2;           // fa floats = 2 fa bf16 per batch
+    bf16_t* Al = Ah + (size_t)GH * ldp;
+    bf16_t* Bh = B0 + (size_t)d * fb * 2;
+    bf16_t* Bl = Bh + (size_t)H * ldp;
+    if (G == 3) {
+      pk.add(g, ldg, R, 2 * H, 1, Ah, Al, ldp, ldp);
+      pk.add(g + 3 * H, ldg, R, H, 1, Ah + (size_t)2 * H * ldp, Al + (size_t)2 * H * ldp, ldp, ldp);
+    } else {
+      pk.add(g, ldg, R, GH, 1, Ah, Al, ldp, ldp);
+    }
+    pk.add(y + (size_t)d * H, ldy, R, H, 1, Bh, Bl, ldp, ldp, d == 0 ? -1 : 1, T);
+  }
+  int st = pk.launch(stream);
+  if (st != LR_OK) return st;
+  return contract(A0, A0 + (size_t)GH * ldp, B0, B0 + (size_t)H * ldp, GH, H, R, 1.f, beta, dw_hh[0], nullptr, GH, H,
+                  nullptr, slabs, slab_floats, stream, D, (int64_t)fa * 2, (int64_t)fb * 2, D > 1 ? dw_hh[1] : nullptr);
 }
 
 extern "C" int lr_xgemm(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
@@ -442,32 +575,4 @@ extern "C" int lr_xgemm(int transA, int transB, int M, int N, int K, float alpha
                         int a_exact, int b_exact, void* workspace, size_t workspace_bytes, lr_stream_t stream) {
   return lr_xgemm_impl(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, a_exact, b_exact,
                        workspace, workspace_bytes, (hipStream_t)stream);
-}
-
-// dW_hh[d][G*H][H] (beta) = dGh[:, d]^T . h_prev[:, d], h_prev[b,t] = y[b,t-1] (d = 0) / y[b,t+1] (d = 1), zero
-// across sequence ends.  dG rows hold 4 slots of H per direction; the recurrent side reads slots
-// (0, 1, 3) for the GRU (dr, dz, d(W_hn h + b_hn)) and (0..3) for the LSTM.
-int lr_xproj_dwhh(const float* dG, int ldg, const float* y, int ldy, int R, int T, int H, int G, int D,
-                  float* const* dw_hh, float beta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  const int GH = G * H, ldp = ldp_of(R);
-  Planes pl;
-  if (!carve(workspace, workspace_bytes, GH, H, R, false, false, &pl)) return LR_ERR_WORKSPACE;
-  for (int d = 0; d < D; ++d) {
-    const float* g = dG + (size_t)d * 4 * H;
-    int st;
-    if (G == 3) {
-      st = pack_operand(g, ldg, R, 2 * H, 1, pl.Ah, pl.Al, ldp, ldp, stream);
-      if (st == LR_OK)
-        st = pack_operand(g + 3 * H, ldg, R, H, 1, pl.Ah + (size_t)2 * H * ldp, pl.Al + (size_t)2 * H * ldp, ldp, ldp,
-                          stream);
-    } else {
-      st = pack_operand(g, ldg, R, GH, 1, pl.Ah, pl.Al, ldp, ldp, stream);
-    }
-    if (st == LR_OK) st = pack_operand(y + (size_t)d * H, ldy, R, H, 1, pl.Bh, pl.Bl, ldp, ldp, stream, d == 0 ? -1 : 1, T);
-    if (st == LR_OK)
-      st = contract(pl.Ah, pl.Al, pl.Bh, pl.Bl, GH, H, R, 1.f, beta, dw_hh[d], nullptr, GH, H, nullptr, pl.slabs,
-                    pl.slab_floats, stream);
-    if (st != LR_OK) return st;
-  }
-  return LR_OK;
 }
