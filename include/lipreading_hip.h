@@ -55,7 +55,11 @@ typedef enum lr_rnn_mode {
    * the recurrent product runs on the bf16 matrix cores with fp32 accumulation, gate math and
    * carried state (lr_rnn_persist.hip).  Build-defined (pixel regime, BASELINE configs[1] "bf16");
    * other shapes return LR_ERR_UNSUPPORTED — query lr_rnn_persistent_supported first. */
-  LR_RNN_RECUR_BF16 = 0x400
+  LR_RNN_RECUR_BF16 = 0x400,
+  /* with LR_RNN_PROJ_BF16X3 | LR_RNN_INPUT_BF16_EXACT and I % 8 == 0: x (and dx) are STORED as bf16
+   * matrices [B*T][I] — the conv frontend's features as they are; x is then the hi plane of the
+   * projection's operand and is never converted or packed. */
+  LR_RNN_INPUT_STORED_BF16 = 0x800
 } lr_rnn_mode;
 
 typedef enum lr_ctc_reduction {

@@ -130,11 +130,12 @@ extern "C" size_t lr_xgemm_workspace_bytes(int transA, int transB, int M, int N,
 // the directions' blocks of a dG row)
 size_t lr_xproj_workspace_bytes(int R, int I, int GH, int D);
 int lr_xproj_forward(const float* x, int R, int I, const float* const* w_ih, int GH, int D, const float* bias,
-                     float* gates, int x_exact, void* workspace, size_t workspace_bytes, hipStream_t stream);
+                     float* gates, int x_exact, int x_bf16, void* workspace, size_t workspace_bytes,
+                     hipStream_t stream);
 int lr_xproj_dw(const float* dG, int ldg, int dstride, const float* x, int R, int I, int GH, int D,
-                float* const* dw_ih, float beta, int x_exact, void* workspace, size_t workspace_bytes,
+                float* const* dw_ih, float beta, int x_exact, int x_bf16, void* workspace, size_t workspace_bytes,
                 hipStream_t stream);
 int lr_xproj_dx(const float* dG, int ldg, int dstride, const float* const* w_ih, int R, int I, int GH, int D,
-                float* dx, int hi_only, void* workspace, size_t workspace_bytes, hipStream_t stream);
+                float* dx, int hi_only, int dx_bf16, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int lr_xproj_dwhh(const float* dG, int ldg, const float* y, int ldy, int R, int T, int H, int G, int D,
                   float* const* dw_hh, float beta, void* workspace, size_t workspace_bytes, hipStream_t stream);

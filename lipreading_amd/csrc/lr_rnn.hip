@@ -542,10 +542,14 @@ inline int cell_of(int mode) { return mode & LR_RNN_CELL_MASK; }
 inline bool proj_x3(int mode) { return (mode & LR_RNN_PROJ_BF16X3) != 0; }
 inline bool x_exact(int mode) { return (mode & LR_RNN_INPUT_BF16_EXACT) != 0; }
 inline bool recur_bf16(int mode) { return (mode & LR_RNN_RECUR_BF16) != 0; }
+inline bool x_stored_bf16(int mode) { return (mode & LR_RNN_INPUT_STORED_BF16) != 0; }
 bool dims_ok(int mode, int B, int T, int I, int H, int D) {
   return (cell_of(mode) == LR_RNN_GRU || cell_of(mode) == LR_RNN_LSTM) &&
-         (mode & ~(LR_RNN_CELL_MASK | LR_RNN_PROJ_BF16X3 | LR_RNN_INPUT_BF16_EXACT | LR_RNN_RECUR_BF16)) == 0 && B > 0 && T > 0 &&
-         I > 0 && H > 0 && (D == 1 || D == 2);
+         (mode & ~(LR_RNN_CELL_MASK | LR_RNN_PROJ_BF16X3 | LR_RNN_INPUT_BF16_EXACT | LR_RNN_RECUR_BF16 |
+                   LR_RNN_INPUT_STORED_BF16)) == 0 &&
+         // a bf16-stored input only makes sense on the split-bf16 projection, as an exact operand
+         (!x_stored_bf16(mode) || (proj_x3(mode) && x_exact(mode) && I % 8 == 0)) &&
+         B > 0 && T > 0 && I > 0 && H > 0 && (D == 1 || D == 2);
 }
 // extra workspace floats of the bf16x3 input projection's backward (operand planes + split-K slabs
 // of the larger of its products, all directions in one contraction)
@@ -600,7 +604,7 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
   }
   if (proj_x3(mode)) {
     // gates[b,t,:,:] = x[b,t,:] @ [W_ih[0]; W_ih[1]]^T + folded bias: both directions in one product
-    int st = lr_xproj_forward(x, B * T, I, w_ih, GH, D, bias, gates, x_exact(mode) ? 1 : 0,
+    int st = lr_xproj_forward(x, B * T, I, w_ih, GH, D, bias, gates, x_exact(mode) ? 1 : 0, x_stored_bf16(mode) ? 1 : 0,
                               l.gemm_bytes ? (void*)(base + l.gemm) : nullptr, l.gemm_bytes, stream);
     if (st != LR_OK) return st;
   } else {
@@ -749,11 +753,13 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
   const size_t xws_bytes = x3 ? x3_ws_floats(G, B, T, I, H, D) * sizeof(float) : 0;
   if (x3) {
     // input projection: all directions in one contraction per product (lr_xgemm.hip)
-    st = lr_xproj_dw(dG, ldg, 4 * H, x, R, I, GH, D, dw_ih, wbeta, x_exact(mode) ? 1 : 0, xws, xws_bytes, stream);
+    st = lr_xproj_dw(dG, ldg, 4 * H, x, R, I, GH, D, dw_ih, wbeta, x_exact(mode) ? 1 : 0, x_stored_bf16(mode) ? 1 : 0,
+                     xws, xws_bytes, stream);
     if (st != LR_OK) return st;
     if (dx) {
       // a bf16 input's gradient goes to a bf16 consumer (the conv frontend's backward): hi terms only
-      st = lr_xproj_dx(dG, ldg, 4 * H, w_ih, R, I, GH, D, dx, x_exact(mode) ? 1 : 0, xws, xws_bytes, stream);
+      st = lr_xproj_dx(dG, ldg, 4 * H, w_ih, R, I, GH, D, dx, x_exact(mode) ? 1 : 0, x_stored_bf16(mode) ? 1 : 0, xws,
+                       xws_bytes, stream);
       if (st != LR_OK) return st;
     }
     // recurrent weight gradient on the same split-bf16 path (one contraction per direction)

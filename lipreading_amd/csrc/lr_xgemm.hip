@@ -55,6 +55,7 @@ struct XArgs {
   int64_t a_bstride, b_bstride;  // bf16 elements between the batches' planes (hi and lo alike)
   int64_t slab_bstride;          // floats between the batches' split-K slabs
   float* Cb;                     // C of batch 1 (batch 0 writes C); no C1 split when batched
+  int c_bf16;                    // C is a bf16 matrix (ldc in elements; beta must be 0, no C1 split)
 };
 
 // ---- pass 1: fp32 [rows][cols] (or its transpose) -> bf16 hi (+ lo) planes [rows'][ldp] -------------
@@ -106,6 +107,7 @@ struct XPackBlock {
   bf16_t* hi;
   bf16_t* lo;
   int ld_in, rows, cols, transpose, ldp, owidth, shift, period;
+  int in_bf16;   // the source is a bf16 matrix (ld_in in elements), e.g. the conv frontend's features
 };
 constexpr int XPACK_MAX = 8;
 struct XPackArgs {
@@ -127,7 +129,12 @@ __global__ __launch_bounds__(256) void xpack_multi_kernel(XPackArgs a) {
       const int tt = r % k.period + k.shift;
       ok = tt >= 0 && tt < k.period;
     }
-    tile[ty + 8 * i][tx] = ok ? k.in[(int64_t)(r + k.shift) * k.ld_in + c] : 0.f;
+    float v = 0.f;
+    if (ok) {
+      const int64_t idx = (int64_t)(r + k.shift) * k.ld_in + c;
+      v = k.in_bf16 ? __builtin_bit_cast(float, (unsigned)reinterpret_cast<const bf16_t*>(k.in)[idx] << 16) : k.in[idx];
+    }
+    tile[ty + 8 * i][tx] = v;
   }
   __syncthreads();
 #pragma unroll
@@ -276,6 +283,11 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
           continue;
         }
         float out = g.alpha * acc[i][j][r] + bv;
+        if (g.c_bf16) {
+          const __bf16 hb = (__bf16)out;
+          reinterpret_cast<bf16_t*>(g.C)[(int64_t)row * g.ldc + col] = __builtin_bit_cast(bf16_t, hb);
+          continue;
+        }
         float* c = (row < g.split_row ? g.C + (int64_t)row * g.ldc : g.C1 + (int64_t)(row - g.split_row) * g.ldc) + col;
         if (g.beta != 0.f) out += g.beta * *c;
         *c = out;
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
 __global__ void xsplitk_reduce_kernel(const float* __restrict__ slabs, int splits, float* __restrict__ C,
                                       float* __restrict__ C1, int split_row, int ldc,
                                       const float* __restrict__ bias, int M, int N, float alpha, float beta,
-                                      float* __restrict__ Cb, int64_t slab_bstride) {
+                                      float* __restrict__ Cb, int64_t slab_bstride, int c_bf16) {
   const int64_t total = (int64_t)M * N;
   if (blockIdx.y) {   // batch 1
     slabs += slab_bstride;
@@ -300,6 +312,11 @@ __global__ void xsplitk_reduce_kernel(const float* __restrict__ slabs, int split
     const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
     float out = alpha * s;
     if (bias) out += bias[col];
+    if (c_bf16) {
+      const __bf16 hb = (__bf16)out;
+      reinterpret_cast<bf16_t*>(C)[(int64_t)row * ldc + col] = __builtin_bit_cast(bf16_t, hb);
+      continue;
+    }
     float* c = (row < split_row ? C + (int64_t)row * ldc : C1 + (int64_t)(row - split_row) * ldc) + col;
     if (beta != 0.f) out += beta * *c;
     *c = out;
@@ -345,11 +362,11 @@ struct PackList {
   XPackArgs a;
   int n = 0, gx = 0, gy = 0;
   void add(const float* in, int ld_in, int rows, int cols, int transpose, bf16_t* hi, bf16_t* lo, int ldp, int owidth,
-           int shift = 0, int period = 1) {
+           int shift = 0, int period = 1, int in_bf16 = 0) {
     XPackBlock& k = a.b[n++];
     k.in = in; k.hi = hi; k.lo = lo;
     k.ld_in = ld_in; k.rows = rows; k.cols = cols; k.transpose = transpose; k.ldp = ldp; k.owidth = owidth;
-    k.shift = shift; k.period = period;
+    k.shift = shift; k.period = period; k.in_bf16 = in_bf16;
     const int orows = transpose ? cols : rows;
     if ((owidth + 31) / 32 > gx) gx = (owidth + 31) / 32;
     if ((orows + 31) / 32 > gy) gy = (orows + 31) / 32;
@@ -366,7 +383,7 @@ struct PackList {
 int contract(const bf16_t* Ahp, const bf16_t* Alp, const bf16_t* Bhp, const bf16_t* Blp, int M, int N, int K,
              float alpha, float beta, float* C, float* C1, int split_row, int ldc, const float* bias, float* slabs,
              size_t slab_floats, hipStream_t stream, int nbatch = 1, int64_t a_bstride = 0, int64_t b_bstride = 0,
-             float* Cb = nullptr) {
+             float* Cb = nullptr, int c_bf16 = 0) {
   const int ldp = ldp_of(K);
   // split-K as far as the remaining workspace allows (none: a single pass, just slower)
   int splits = want_splits(M, N * nbatch, K);
@@ -387,6 +404,7 @@ int contract(const bf16_t* Ahp, const bf16_t* Alp, const bf16_t* Bhp, const bf16
   g.a_bstride = a_bstride; g.b_bstride = b_bstride;
   g.slab_bstride = (int64_t)splits * M * N;
   g.Cb = Cb ? Cb : C;
+  g.c_bf16 = c_bf16;
   const int ntile = g.nx * g.ny * splits;
   g.per_xcd = (ntile + 7) / 8;
   dim3 grid(8 * g.per_xcd, nbatch);
@@ -402,7 +420,7 @@ int contract(const bf16_t* Ahp, const bf16_t* Alp, const bf16_t* Bhp, const bf16
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   LR_LAUNCH(xsplitk_reduce_kernel, dim3(blocks, nbatch), dim3(256), 0, stream, (const float*)g.slabs, splits, C, g.C1,
-            g.split_row, ldc, bias, M, N, alpha, beta, g.Cb, g.slab_bstride);
+            g.split_row, ldc, bias, M, N, alpha, beta, g.Cb, g.slab_bstride, c_bf16);
   return lr_launch_status();
 }
 
@@ -480,14 +498,19 @@ size_t lr_xproj_workspace_bytes(int R, int I, int GH, int D) {
 }
 
 // gates[R][D*GH] = x[R][I] . [W_ih[0]; W_ih[1]]^T + bias[D*GH]
+// x_bf16: x is stored as a bf16 matrix [R][I] (the conv frontend's features): with I % 8 == 0 it IS
+// the hi plane of the A operand and is not packed at all.
 int lr_xproj_forward(const float* x, int R, int I, const float* const* w_ih, int GH, int D, const float* bias,
-                     float* gates, int x_exact, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                     float* gates, int x_exact, int x_bf16, void* workspace, size_t workspace_bytes,
+                     hipStream_t stream) {
   const int N = D * GH, ldp = ldp_of(I);
-  if (1 + D > XPACK_MAX) return LR_ERR_UNSUPPORTED;
+  if (1 + D > XPACK_MAX || (x_bf16 && !x_exact)) return LR_ERR_UNSUPPORTED;
   Planes pl;
   if (!carve(workspace, workspace_bytes, R, N, I, x_exact != 0, false, &pl)) return LR_ERR_WORKSPACE;
   PackList pk;
-  pk.add(x, I, R, I, 0, pl.Ah, pl.Al, ldp, ldp);
+  const bool direct = x_bf16 && ldp == I;
+  if (direct) pl.Ah = (bf16_t*)x;
+  else pk.add(x, I, R, I, 0, pl.Ah, pl.Al, ldp, ldp, 0, 1, x_bf16);
   for (int d = 0; d < D; ++d)
     pk.add(w_ih[d], I, GH, I, 0, pl.Bh + (size_t)d * GH * ldp, pl.Bl + (size_t)d * GH * ldp, ldp, ldp);
   int st = pk.launch(stream);
@@ -498,7 +521,7 @@ int lr_xproj_forward(const float* x, int R, int I, const float* const* w_ih, int
 
 // dW_ih[d][GH][I] (beta) = dG[:, d, :GH]^T . x   — rows d*GH.. of one (D*GH) x I product over K = R
 int lr_xproj_dw(const float* dG, int ldg, int dstride, const float* x, int R, int I, int GH, int D,
-                float* const* dw_ih, float beta, int x_exact, void* workspace, size_t workspace_bytes,
+                float* const* dw_ih, float beta, int x_exact, int x_bf16, void* workspace, size_t workspace_bytes,
                 hipStream_t stream) {
   const int M = D * GH, ldp = ldp_of(R);
   if (1 + D > XPACK_MAX) return LR_ERR_UNSUPPORTED;
@@ -507,7 +530,7 @@ int lr_xproj_dw(const float* dG, int ldg, int dstride, const float* x, int R, in
   PackList pk;
   for (int d = 0; d < D; ++d)
     pk.add(dG + (size_t)d * dstride, ldg, R, GH, 1, pl.Ah + (size_t)d * GH * ldp, pl.Al + (size_t)d * GH * ldp, ldp, ldp);
-  pk.add(x, I, R, I, 1, pl.Bh, pl.Bl, ldp, ldp);
+  pk.add(x, I, R, I, 1, pl.Bh, pl.Bl, ldp, ldp, 0, 1, x_bf16);
   int st = pk.launch(stream);
   if (st != LR_OK) return st;
   return contract(pl.Ah, pl.Al, pl.Bh, pl.Bl, M, I, R, 1.f, beta, dw_ih[0], D > 1 ? dw_ih[1] : nullptr, GH, I, nullptr,
@@ -516,7 +539,7 @@ int lr_xproj_dw(const float* dG, int ldg, int dstride, const float* x, int R, in
 
 // dx[R][I] = sum_d dG[:, d, :GH] . W_ih[d]   — one product over K = D*GH
 int lr_xproj_dx(const float* dG, int ldg, int dstride, const float* const* w_ih, int R, int I, int GH, int D,
-                float* dx, int hi_only, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                float* dx, int hi_only, int dx_bf16, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   const int K = D * GH, ldp = ldp_of(K);
   if (2 * D > XPACK_MAX) return LR_ERR_UNSUPPORTED;
   Planes pl;
@@ -530,7 +553,7 @@ int lr_xproj_dx(const float* dG, int ldg, int dstride, const float* const* w_ih,
   int st = pk.launch(stream);
   if (st != LR_OK) return st;
   return contract(pl.Ah, pl.Al, pl.Bh, pl.Bl, R, I, K, 1.f, 0.f, dx, nullptr, R, I, nullptr, pl.slabs, pl.slab_floats,
-                  stream);
+                  stream, 1, 0, 0, nullptr, dx_bf16);
 }
 
 // dW_hh[d][G*H][H] (beta) = dGh[:, d]^T . h_prev[:, d], h_prev[b,t] = y[b,t-1] (d = 0) / y[b,t+1] (d = 1), zero

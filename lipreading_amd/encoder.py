@@ -22,7 +22,7 @@ from .data import BOS, PAD
 _ALLOWED_RNN_TYPES = {'LSTM', 'GRU', 'RNN'}          # better_model.py:9
 _ALLOWED_FRAME_PROCESSING = {'flatten'}              # better_model.py:10
 _MODES = {'GRU': 0, 'LSTM': 1}
-_PROJ_BF16X3, _INPUT_BF16_EXACT, _RECUR_BF16 = 0x100, 0x200, 0x400   # lr_rnn_mode flags
+_PROJ_BF16X3, _INPUT_BF16_EXACT, _RECUR_BF16, _INPUT_STORED_BF16 = 0x100, 0x200, 0x400, 0x800   # lr_rnn_mode flags
 _GATES = {'GRU': 3, 'LSTM': 4}
 
 
@@ -249,7 +249,10 @@ class VideoEncoder(nn.Module):
     if max_len is None:
       max_len = int(frame_lens.max())          # host read iff frame_lens lives on the device
     assert 1 <= max_len <= T
-    x = frames[:, :max_len].to(torch.float32).contiguous()
+    # the pixel regime hands the frontend's bf16 features over as they are (LR_RNN_INPUT_STORED_BF16)
+    stored_bf16 = (frames.dtype == torch.bfloat16 and self.input_projection == 'bf16x3' and self.input_is_bf16
+                   and I % 8 == 0)
+    x = frames[:, :max_len].contiguous() if stored_bf16 else frames[:, :max_len].to(torch.float32).contiguous()
     lens = frame_lens.to(device=x.device, dtype=torch.int32).contiguous()
     mode, H, D = _MODES[self.rnn_type], self.hidden_size, self.num_dirs
 
@@ -263,6 +266,8 @@ class VideoEncoder(nn.Module):
         # operands (include/lipreading_hip.h LR_RNN_PROJ_BF16X3); layer 0's input is bf16-exact
         # when it comes from the bf16 conv frontend
         lmode |= _PROJ_BF16X3 | (_INPUT_BF16_EXACT if (layer == 0 and self.input_is_bf16) else 0)
+        if layer == 0 and stored_bf16:
+          lmode |= _INPUT_STORED_BF16
       if self.recurrence == 'bf16' and _C.lib().lr_rnn_persistent_supported(mode, B, max_len, x.shape[2], H, D):
         lmode |= _RECUR_BF16
       y, h_n, c_n = _RNNLayerFunction.apply(x, lens, lmode, H, need_dx, *weights)

@@ -43,7 +43,7 @@ def feature_dim(H, W):
 
 class _ConvFrontendFunction(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, clips, *params):
+  def forward(ctx, clips, out_bf16, *params):
     L = _C.lib()
     st = _C.stream_handle()
     B, T, C, H, W = clips.shape
@@ -98,8 +98,11 @@ class _ConvFrontendFunction(torch.autograd.Function):
                  "lr_maxpool_hw2_bf16")
         saved += [act, pooled]
       x, h, w = pooled, ho // 2, wo // 2
-    feats = torch.empty((B, T, h * w * 96), dtype=torch.float32, device=dev)
-    _C.check(L.lr_bf16_to_f32(x.data_ptr(), feats.data_ptr(), feats.numel(), st), "lr_bf16_to_f32")
+    if out_bf16:   # the encoder's split-bf16 input projection takes the pooled activation as it is
+      feats = x.reshape(B, T, h * w * 96)
+    else:
+      feats = torch.empty((B, T, h * w * 96), dtype=torch.float32, device=dev)
+      _C.check(L.lr_bf16_to_f32(x.data_ptr(), feats.data_ptr(), feats.numel(), st), "lr_bf16_to_f32")
     ctx.save_for_backward(*saved, *params)
     ctx.dims = (B, T, H, W)
     return feats
@@ -117,9 +120,12 @@ class _ConvFrontendFunction(torch.autograd.Function):
     bf = torch.bfloat16
     direct = _direct_grads(params)
     grads = [p.grad for p in params] if direct else [torch.empty_like(p) for p in params]
-    dfeat = dfeat.contiguous().to(torch.float32)
-    dP = torch.empty(acts[6].shape, dtype=bf, device=dev)
-    _C.check(L.lr_f32_to_bf16(dfeat.data_ptr(), dP.data_ptr(), dfeat.numel(), st), "lr_f32_to_bf16")
+    if dfeat.dtype == bf:
+      dP = dfeat.contiguous().reshape(acts[6].shape)
+    else:
+      dfeat = dfeat.contiguous().to(torch.float32)
+      dP = torch.empty(acts[6].shape, dtype=bf, device=dev)
+      _C.check(L.lr_f32_to_bf16(dfeat.data_ptr(), dP.data_ptr(), dfeat.numel(), st), "lr_f32_to_bf16")
     # spatial size of each layer's input
     sizes = [(H, W)]
     for (_, _, (kt, kh, kw), stride, (pt, ph, pw)) in LAYERS:
@@ -167,8 +173,8 @@ class _ConvFrontendFunction(torch.autograd.Function):
                                      cin, kt, kh, kw, 1, pt, ph, pw, frag, st), "lr_conv3d_forward(dgrad)")
     if direct:
       _notify(params)
-      return (None,) * (1 + len(params))
-    return (None,) + tuple(grads)
+      return (None,) * (2 + len(params))
+    return (None, None) + tuple(grads)
 
 
 class ConvFrontend3D(nn.Module):
@@ -182,10 +188,11 @@ class ConvFrontend3D(nn.Module):
   def parameters_in_order(self):
     return [p for i in (1, 2, 3) for p in (getattr(self, "conv%d" % i).weight, getattr(self, "conv%d" % i).bias)]
 
-  def forward(self, clips):
+  def forward(self, clips, out_bf16=False):
+    """out_bf16: return the features as the bf16 tensor the last layer produced (no fp32 copy)."""
     _C.require_cuda(clips)
     assert clips.dim() == 5 and clips.shape[2] == 3, "clips must be (B, T, 3, H, W)"
-    return _ConvFrontendFunction.apply(clips, *self.parameters_in_order())
+    return _ConvFrontendFunction.apply(clips, bool(out_bf16), *self.parameters_in_order())
 
 
 class PixelLipReader(nn.Module):
@@ -206,6 +213,6 @@ class PixelLipReader(nn.Module):
     # `encoder.recurrence = 'f32'` switches it off.
     encoder.recurrence = 'bf16'
   def forward(self, clips, frame_lens, max_len=None):
-    feats = self.frontend(clips)
+    feats = self.frontend(clips, out_bf16=True)
     B, T, F = feats.shape
     return self.encoder(feats.reshape(B, T, F, 1), frame_lens, max_len=max_len)
