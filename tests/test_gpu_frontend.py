@@ -113,6 +113,52 @@ def test_pixel_lipreader_trains_end_to_end(dev):
   assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], losses
 
 
+def test_pixel_regime_fast_paths_track_the_plain_ones(dev):
+  """PixelLipReader's defaults at the metric's shape family (96x96, BiGRU-256 x2): bf16 features
+  handed to the encoder as stored, split-bf16 input projection and recurrent weight gradient, the
+  recurrence as one launch per pass with bf16 operands.  Against the same weights on the plain
+  paths (fp32 features, fp32 MFMA GEMMs, fp32 step kernels): losses and gradients agree to the
+  level of the bf16 operand rounding."""
+  from lipreading_amd.ctc import ctc_loss_with_status
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.frontend import ConvFrontend3D, PixelLipReader, feature_dim
+  torch.manual_seed(7)
+  H = 96
+  enc = VideoEncoder(feature_dim(H, H), 256, rnn_type='GRU', num_layers=2, bidirectional=True, enable_ctc=True,
+                     vocab_size=64, char2idx=default_char2idx())
+  model = PixelLipReader(enc, ConvFrontend3D()).to(dev).train()
+  assert enc.recurrence == 'bf16' and enc.input_projection == 'bf16x3'
+  g = torch.Generator().manual_seed(8)
+  B, T = 3, 11
+  clips = torch.randint(0, 256, (B, T, 3, H, H), generator=g, dtype=torch.uint8).to(dev)
+  lens = torch.tensor([11, 9, 6], device=dev)
+  labels = torch.randint(4, 64, (B, 3), generator=g).to(dev)
+  ll = torch.full((B,), 3, device=dev)
+  res = {}
+  for fast in (True, False):
+    model.zero_grad()
+    if fast:
+      lp, hid, _ = model(clips, lens, max_len=T)
+    else:   # the plain paths, same parameters
+      enc.recurrence, enc.input_projection, enc.input_is_bf16 = 'f32', 'f32', False
+      try:
+        feats = model.frontend(clips)
+        assert feats.dtype == torch.float32
+        lp, hid, _ = enc(feats.reshape(B, T, -1, 1), lens, max_len=T)
+      finally:
+        enc.recurrence, enc.input_projection, enc.input_is_bf16 = 'bf16', 'bf16x3', True
+    loss, status, _ = ctc_loss_with_status(lp, labels, lens, ll, 'mean')
+    assert int(status) == 0
+    loss.backward()
+    res[fast] = [loss.detach().cpu().reshape(1), hid.detach().cpu()] + [p.grad.cpu().clone() for p in model.parameters()]
+  # measured on MI355X (B = 8, T = 40): loss 4e-6, hidden 7e-4, gradients 4e-4 .. 2.4e-3 relative
+  assert abs(float(res[True][0]) - float(res[False][0])) < 1e-3 * abs(float(res[False][0]))
+  for a, b in zip(res[True][1:], res[False][1:]):
+    assert float((a - b).norm()) <= 1e-2 * max(1e-6, float(b.norm())), tuple(a.shape)
+  assert float((res[True][1] - res[False][1]).abs().max()) > 0   # the fast paths really ran
+
+
 def test_lip_crop_matches_oracle(dev):
   """A9 (build-defined): mouth-landmark bounding box -> square window -> bilinear 96x96."""
   from lipreading_amd.landmarks import lip_crop
