@@ -152,27 +152,36 @@ __global__ __launch_bounds__(256, 1) void gru256_fwd_persist_kernel(float* __res
   // gate phase: thread = hidden unit `tid`, loop over the group's samples
   const float bhn = bhh[2 * PH + tid];
   int len[PBH];
-  float hreg[PBH], gx[3][PBH];
+  float hreg[PBH];
+  struct Gx { float v[3][PBH]; };
+  Gx gxA, gxB;   // pre-activations of steps s (even) / s (odd): each set is fetched TWO steps ahead
 #pragma unroll
   for (int k = 0; k < PBH; ++k) {
     len[k] = b0 + k < B ? lens[b0 + k] : 0;
     hreg[k] = 0.f;
   }
   // input-projection pre-activations, fetched one step ahead
-  auto fetch_gx = [&](int t, int k) {
+  auto time_of = [&](int s) {   // time index of step s (clamped to the last step)
+    const int sc = s < T ? s : T - 1;
+    return d == 0 ? sc : T - 1 - sc;
+  };
+  auto fetch_gx = [&](Gx& gx, int t, int k) {
     const int b = b0 + k < B ? b0 + k : 0;
     const float* gp = gates + (((int64_t)b * T + t) * D + d) * (3 * PH) + tid;
-    gx[0][k] = gp[0];
-    gx[1][k] = gp[PH];
-    gx[2][k] = gp[2 * PH];
+    gx.v[0][k] = gp[0];
+    gx.v[1][k] = gp[PH];
+    gx.v[2][k] = gp[2 * PH];
   };
 #pragma unroll
-  for (int k = 0; k < PBH; ++k) fetch_gx(d == 0 ? 0 : T - 1, k);
+  for (int k = 0; k < PBH; ++k) {
+    fetch_gx(gxA, time_of(0), k);
+    fetch_gx(gxB, time_of(1), k);
+  }
   __syncthreads();
 
-  for (int s = 0; s < T; ++s) {
-    const int t = d == 0 ? s : T - 1 - s;
-    const int tnext = d == 0 ? (s + 1 < T ? s + 1 : s) : (s + 1 < T ? T - 2 - s : 0);
+  auto step = [&](int s, Gx& gx) {
+    const int t = time_of(s);
+    const int tnext = time_of(s + 2);
     const bf16_t* hcur = hS + (s & 1) * 16 * PHLD;
     bf16_t* hnxt = hS + ((s + 1) & 1) * 16 * PHLD;
     f32x4 acc[PNT];
@@ -218,10 +227,10 @@ __global__ __launch_bounds__(256, 1) void gru256_fwd_persist_kernel(float* __res
       const bool row_ok = b < B;
       const bool live = row_ok && t < len[k];
       const float hn = S[(2 * PBH + k) * PH + tid] + bhn;
-      const float r = __frcp_rn(1.f + __expf(-(gx[0][k] + S[(0 * PBH + k) * PH + tid])));
-      const float z = __frcp_rn(1.f + __expf(-(gx[1][k] + S[(1 * PBH + k) * PH + tid])));
-      const float n = 2.f * __frcp_rn(1.f + __expf(-2.f * (gx[2][k] + r * hn))) - 1.f;
-      fetch_gx(tnext, k);
+      const float r = __frcp_rn(1.f + __expf(-(gx.v[0][k] + S[(0 * PBH + k) * PH + tid])));
+      const float z = __frcp_rn(1.f + __expf(-(gx.v[1][k] + S[(1 * PBH + k) * PH + tid])));
+      const float n = 2.f * __frcp_rn(1.f + __expf(-2.f * (gx.v[2][k] + r * hn))) - 1.f;
+      fetch_gx(gx, tnext, k);
       const float h = live ? (1.f - z) * n + z * hreg[k] : 0.f;
       hreg[k] = h;
       hnxt[k * PHLD + tid] = f2bf(h);
@@ -238,6 +247,10 @@ __global__ __launch_bounds__(256, 1) void gru256_fwd_persist_kernel(float* __res
       }
     }
     lr_lds_barrier();   // hnxt complete, S free again
+  };
+  for (int s = 0; s < T; s += 2) {
+    step(s, gxA);
+    if (s + 1 < T) step(s + 1, gxB);
   }
 }
 
@@ -319,24 +332,30 @@ __global__ __launch_bounds__(256, 1) void gru256_bwd_persist_kernel(
   const int len = lens[b];
   const float inj = dh_n ? dh_n[((int64_t)d * B + b) * PH + tid] : 0.f;
   float car = 0.f;   // dh_{t'} * z_{t'}
-  float in_dy, in_r, in_z, in_n, in_hn, in_hp;
-  auto fetch = [&](int t) {   // operands of step t, one step ahead
+  struct In { float dy, r, z, n, hn, hp; };
+  In inA, inB;   // operands of even / odd steps: each set is fetched TWO steps ahead
+  auto time_of = [&](int s) {   // time index of step s (clamped to the last step)
+    const int sc = s < T ? s : T - 1;
+    return d == 0 ? T - 1 - sc : sc;
+  };
+  auto fetch = [&](In& in, int t) {
     const int tp = d == 0 ? t - 1 : t + 1;
     const int64_t bt = (int64_t)b * T + t;
-    in_dy = dy[bt * DH + d * PH + tid];
+    in.dy = dy[bt * DH + d * PH + tid];
     const float* gi = gates + (bt * D + d) * (int64_t)(3 * PH) + tid;
-    in_r = gi[0];
-    in_z = gi[PH];
-    in_n = gi[2 * PH];
-    in_hn = extra[(bt * D + d) * PH + tid];
-    in_hp = (tp >= 0 && tp < T) ? y[((int64_t)b * T + tp) * DH + d * PH + tid] : 0.f;
+    in.r = gi[0];
+    in.z = gi[PH];
+    in.n = gi[2 * PH];
+    in.hn = extra[(bt * D + d) * PH + tid];
+    in.hp = (tp >= 0 && tp < T) ? y[((int64_t)b * T + tp) * DH + d * PH + tid] : 0.f;
   };
-  fetch(d == 0 ? T - 1 : 0);
+  fetch(inA, time_of(0));
+  fetch(inB, time_of(1));
   __syncthreads();
 
-  for (int s = 0; s < T; ++s) {
-    const int t = d == 0 ? T - 1 - s : s;
-    const int tnext = d == 0 ? (s + 1 < T ? T - 2 - s : 0) : (s + 1 < T ? s + 1 : s);
+  auto step = [&](int s, In& in) {
+    const int t = time_of(s);
+    const int tnext = time_of(s + 2);
     const bf16_t* gcur = gS + (s & 1) * BGLD;      // dGh of the step processed before this one
     bf16_t* gnxt = gS + ((s + 1) & 1) * BGLD;
     // ---- product: rows other than 0 of the A operand are zero ----------------------------------
@@ -347,11 +366,15 @@ __global__ __launch_bounds__(256, 1) void gru256_bwd_persist_kernel(
       if (col == 0) v = *reinterpret_cast<const bf16x8*>(gcur + ks * 32 + kg * 8);
       return v;
     };
-    bf16x8 a_next = afrag(0);
+    // a k step is only 4 MFMAs (64 cycles), less than an LDS round trip: keep the A fragments of the
+    // next three k steps in flight
+    bf16x8 aring[4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) aring[i] = afrag(i);
 #pragma unroll
     for (int ks = 0; ks < BKS; ++ks) {
-      const bf16x8 a = a_next;
-      if (ks + 1 < BKS) a_next = afrag(ks + 1);
+      const bf16x8 a = aring[ks & 3];
+      if (ks + 3 < BKS) aring[(ks + 3) & 3] = afrag(ks + 3);
       // two accumulator sets (even / odd k steps): dependent MFMAs are 8 issues apart
       if (ks == 0) {
         LR_MFMA4_FIRST(acc0, a, Wa[0][0], Wa[1][0], Wa[2][0], Wa[3][0]);
@@ -380,11 +403,11 @@ __global__ __launch_bounds__(256, 1) void gru256_bwd_persist_kernel(
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local exchange: units 64w .. 64w+63
     // ---- gate gradients of step t -------------------------------------------------------------------
     {
-      const float r = in_r, z = in_z, n = in_n, hn = in_hn, hp = in_hp;
-      float dh = in_dy + S[tid] + car;
+      const float r = in.r, z = in.z, n = in.n, hn = in.hn, hp = in.hp;
+      float dh = in.dy + S[tid] + car;
       const bool is_last = d == 0 ? (t == len - 1) : (t == 0);
       if (is_last) dh += inj;
-      fetch(tnext);
+      fetch(in, tnext);
       float dr_pre = 0.f, dz_pre = 0.f, dn_pre = 0.f, dnr = 0.f;
       car = 0.f;
       if (t < len) {
@@ -404,6 +427,10 @@ __global__ __launch_bounds__(256, 1) void gru256_bwd_persist_kernel(
       gnxt[2 * PH + tid] = f2bf(dnr);
     }
     lr_lds_barrier();   // gnxt complete
+  };
+  for (int s = 0; s < T; s += 2) {
+    step(s, inA);
+    if (s + 1 < T) step(s + 1, inB);
   }
 }
 
