@@ -958,24 +958,30 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_ts_kernel(ConvGeom g, const 
 // bank slots for any tap shift (found by exhaustive search over row paddings and swizzles).  Inputs
 // with 64 / 96 channels take 2 / 3 passes.  B fragments (16 output channels x 32 k) come from
 // global in the 16-column fragment-major packing.
-constexpr int P3_TT = 4, P3_H = 12, P3_W = 12, P3_PH = P3_H + 2, P3_PW = 16, P3_SLOTS = P3_TT + 2;
-constexpr int P3_POS = P3_SLOTS * P3_PH * P3_PW;   // 1344 positions (2 padding columns per row)
-constexpr int P3_LDS = P3_POS * 64;                // 86,016 bytes
-constexpr int P3_UNITS = P3_POS * 4;
-constexpr int P3_UPT = (P3_UNITS + 255) / 256;     // 21
+// A workgroup covers P3_TT = 2 consecutive frames with TWO waves per frame (each takes half of the
+// output channels: NT16 sixteen-column tiles per wave), so its patch is 4 slots = 57 KB and two
+// workgroups share a CU: 8 waves per CU overlap each other's load phases and epilogues, and 1200
+// half-size tiles fill 256 CUs in 2.5 tile-times where 600 four-frame tiles took 3 (2.34 rounds).
+constexpr int P3_TT = 2, P3_NSPL = 4 / P3_TT, P3_H = 12, P3_W = 12, P3_PH = P3_H + 2, P3_PW = 16, P3_SLOTS = P3_TT + 2;
+constexpr int P3_POS = P3_SLOTS * P3_PH * P3_PW;   // 896 positions (2 padding columns per row)
+constexpr int P3_LDS = P3_POS * 64;                // 57,344 bytes
+constexpr int P3_ROWS = P3_SLOTS * P3_PH;          // 56 patch rows: one per wave and pass, 14 passes
+static_assert(P3_ROWS % 28 == 0, "patch rows are loaded in batches of 7 passes x 4 waves");
 
 template <int CG, int NT16, bool POOL>
-__global__ __launch_bounds__(256, 1) void conv_patch16_kernel(const bf16_t* __restrict__ X,
+__global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __restrict__ X,
                                                               const bf16_t* __restrict__ Wf,
                                                               const float* __restrict__ bias,
                                                               bf16_t* __restrict__ Y, unsigned char* __restrict__ code,
                                                               int F, int T, int relu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char patch[];
-  constexpr int C = 32 * CG, N = 16 * NT16, TAPS = 27;
+  constexpr int NTT = NT16 * P3_NSPL;   // sixteen-column tiles of the whole layer
+  constexpr int C = 32 * CG, N = 16 * NTT, TAPS = 27;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fw = wave % P3_TT, nh = wave / P3_TT;   // frame of the tile, slice of the output channels
   const int f0 = (int)blockIdx.x * P3_TT;
   const int rl = lane & 15, kg = lane >> 4;
-  const int f = f0 + wave;
+  const int f = f0 + fw;
   const bool fvalid = f < F;
   const int t = f % T;
 
@@ -990,17 +996,17 @@ __global__ __launch_bounds__(256, 1) void conv_patch16_kernel(const bf16_t* __re
   // (h = 2(kg>>1) + {0,1}, w = 2(kg&1) + {0,1}) in scan order and the pooled epilogue is lane-local.
   // The 16 lanes ds_read_b128 serves together still cover the 4 x 4 block once, and same-column
   // lanes land on 4 different chunks for any tap shift.
-  const int base_p = (wave * P3_PH + ((rl >> 1) & 1) + 2 * (rl >> 3)) * P3_PW + (rl & 1) + 2 * ((rl >> 2) & 1);
+  const int base_p = (fw * P3_PH + ((rl >> 1) & 1) + 2 * (rl >> 3)) * P3_PW + (rl & 1) + 2 * ((rl >> 2) & 1);
   for (int cg = 0; cg < CG; ++cg) {
     if (cg > 0) __syncthreads();
     // patch load: a wave covers one 16-position patch row (64 sixteen-byte units) per pass, so the
-    // row / slot decode is wave-uniform scalar work; 21 passes in 3 batches, each fully in flight
+    // row / slot decode is wave-uniform scalar work; batches of 7 passes, each fully in flight
     {
       const int pw = (tid & 63) >> 2, c = tid & 3;
       const bool tvalid = pw >= 1 && pw <= P3_W;
       const bf16_t* xt = X + ((int64_t)(pw - 1)) * C + cg * 32 + c * 8;
 #pragma unroll
-      for (int part = 0; part < 3; ++part) {
+      for (int part = 0; part < P3_ROWS / 28; ++part) {
         uint4 v[7];
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
@@ -1019,20 +1025,22 @@ __global__ __launch_bounds__(256, 1) void conv_patch16_kernel(const bf16_t* __re
       }
     }
     __syncthreads();
-    const bf16_t* wf = Wf + (int64_t)cg * TAPS * NT16 * 512 + lane * 8;
+    const bf16_t* wf = Wf + ((int64_t)cg * TAPS * NTT + nh * NT16) * 512 + lane * 8;
     bf16x8 bcur[NT16], bnext[NT16];
 #pragma unroll
     for (int j = 0; j < NT16; ++j) bcur[j] = *reinterpret_cast<const bf16x8*>(wf + j * 512);
     int tap = 0;
+#pragma unroll 1
     for (int dt = 0; dt < 3; ++dt) {
       const bool valid = fvalid && t + dt - 1 >= 0 && t + dt - 1 < T;   // wave-uniform
-      for (int dh = 0; dh < 3; ++dh) {
+#pragma unroll 1
+      for (int dh = 0; dh < 3; ++dh) {   // (unrolled further, the 243 fragment addresses get hoisted and spilled)
 #pragma unroll
         for (int dw = 0; dw < 3; ++dw, ++tap) {
           if (tap + 1 < TAPS) {
 #pragma unroll
             for (int j = 0; j < NT16; ++j)
-              bnext[j] = *reinterpret_cast<const bf16x8*>(wf + ((int64_t)(tap + 1) * NT16 + j) * 512);
+              bnext[j] = *reinterpret_cast<const bf16x8*>(wf + ((int64_t)(tap + 1) * NTT + j) * 512);
           }
           if (valid) {
             const int to = (dt * P3_PH + dh) * P3_PW + dw;
@@ -1057,7 +1065,7 @@ __global__ __launch_bounds__(256, 1) void conv_patch16_kernel(const bf16_t* __re
     // ReLU -> MaxPool((1,2,2)) in registers: the lane's four rows are one window in scan order
 #pragma unroll
     for (int j = 0; j < NT16; ++j) {
-      const int n = j * 16 + rl;
+      const int n = (nh * NT16 + j) * 16 + rl;
       const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
       for (int mb = 0; mb < 9; ++mb) {
@@ -1078,7 +1086,7 @@ __global__ __launch_bounds__(256, 1) void conv_patch16_kernel(const bf16_t* __re
   }
 #pragma unroll
   for (int j = 0; j < NT16; ++j) {
-    const int n = j * 16 + rl;
+    const int n = (nh * NT16 + j) * 16 + rl;
     const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
     for (int mb = 0; mb < 9; ++mb)
@@ -1931,9 +1939,9 @@ static int conv_forward_impl(const void* X, const void* Wp, const float* bias, v
     else hipLaunchKernelGGL((conv_patch16_kernel<__VA_ARGS__>), pgrid, dim3(256), P3_LDS, (hipStream_t)stream,  \
                             x, w, bias, y, code, F, T, relu);                                                  \
   } while (0)
-    if (fwd && code) LR_PATCH16(2, 2, 6, true);
-    else if (fwd) LR_PATCH16(0, 2, 6, false);
-    else LR_PATCH16(1, 3, 4, false);
+    if (fwd && code) LR_PATCH16(2, 2, 6 / P3_NSPL, true);
+    else if (fwd) LR_PATCH16(0, 2, 6 / P3_NSPL, false);
+    else LR_PATCH16(1, 3, 4 / P3_NSPL, false);
 #undef LR_PATCH16
     return lr_launch_status();
   }
