@@ -31,6 +31,9 @@ LAYERS = ((3, 32, (3, 5, 5), 2, (1, 2, 2)),
 
 # tests switch this off to compare the patch-resident kernels with the implicit-GEMM kernels
 _PATCH_KERNELS = True
+# ... and this one to compare the first layer's fused paths (raw uint8 clip into the kernels, weight
+# gradient that un-pools on the fly) with the staged ones (bf16 clip copy, materialised dZ)
+_FUSE_FIRST_LAYER = True
 
 
 def _pad4(c):
@@ -57,7 +60,7 @@ class _ConvFrontendFunction(torch.autograd.Function):
     cin0, cout0, (kt0, kh0, kw0), s0, (pt0, ph0, pw0) = LAYERS[0]
     # uint8 clips go straight into the first layer's patch kernels (forward and weight gradient), which
     # scale and convert while they fill LDS: no bf16 copy of the clip is written or kept
-    raw_u8 = bool(is_u8 and _PATCH_KERNELS and L.lr_conv3d_pool_fusion_supported(
+    raw_u8 = bool(is_u8 and _PATCH_KERNELS and _FUSE_FIRST_LAYER and L.lr_conv3d_pool_fusion_supported(
         H, W, 4, cout0, kt0, kh0, kw0, s0, pt0, ph0, pw0) and L.lr_conv3d_wgrad_pooled_supported(
         H, W, 4, cin0, cout0, kt0, kh0, kw0, s0, pt0, ph0, pw0))
     if raw_u8:
@@ -139,7 +142,7 @@ class _ConvFrontendFunction(torch.autograd.Function):
       ho, wo = 2 * pooled.shape[1], 2 * pooled.shape[2]
       wbytes = max(L.lr_conv3d_wgrad_workspace_bytes(cout, cin_p, kt, kh, kw), L.lr_unpool_workspace_bytes(cout))
       ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-      if act.dtype == torch.uint8 and li == 0 and (_PATCH_KERNELS or x_in.dtype == torch.uint8) and L.lr_conv3d_wgrad_pooled_supported(
+      if act.dtype == torch.uint8 and li == 0 and ((_PATCH_KERNELS and _FUSE_FIRST_LAYER) or x_in.dtype == torch.uint8) and L.lr_conv3d_wgrad_pooled_supported(
           h, w, cin_p, cin, cout, kt, kh, kw, stride, pt, ph, pw):
         # first layer (no data gradient needed): the weight-gradient kernel un-pools on the fly
         _C.check(L.lr_conv3d_wgrad_pooled(x_in.data_ptr(), pooled.data_ptr(), act.data_ptr(), dP.data_ptr(),

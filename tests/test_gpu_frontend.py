@@ -113,6 +113,36 @@ def test_pixel_lipreader_trains_end_to_end(dev):
   assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], losses
 
 
+def test_first_layer_fused_paths_equal_the_staged_ones(dev):
+  """The first layer's kernels read the raw uint8 clip and its weight gradient rebuilds dZ from the
+  pooled tensors on the fly (lr_conv3d_forward_pooled flags & 8, lr_conv3d_wgrad_pooled).  Staged
+  reference: lr_clip_to_ndhwc_bf16 copy, lr_unpool_code_bf16 + lr_conv3d_wgrad on the materialised
+  dZ.  Same arithmetic on the same bf16 values: features and conv1.weight.grad are bit-identical,
+  the bias gradient is the same sum in another order."""
+  from lipreading_amd import frontend as FE
+  torch.manual_seed(9)
+  fe = FE.ConvFrontend3D().to(dev)
+  g = torch.Generator().manual_seed(10)
+  B, T, H = 2, 9, 96
+  clips = torch.randint(0, 256, (B, T, 3, H, H), generator=g, dtype=torch.uint8).to(dev)
+  wgt = torch.randn(B, T, FE.feature_dim(H, H), generator=g).to(dev)
+  res = {}
+  for fused in (True, False):
+    FE._FUSE_FIRST_LAYER = fused
+    try:
+      fe.zero_grad()
+      out = fe(clips)
+      (out * wgt).sum().backward()
+      res[fused] = [out.detach().clone()] + [p.grad.detach().clone() for p in fe.parameters_in_order()]
+    finally:
+      FE._FUSE_FIRST_LAYER = True
+  assert torch.equal(res[True][0], res[False][0])
+  assert torch.equal(res[True][1], res[False][1])                  # conv1.weight.grad
+  assert float((res[True][2] - res[False][2]).abs().max()) <= 1e-5 * float(res[False][2].abs().max())   # conv1.bias.grad
+  for a, b in zip(res[True][3:], res[False][3:]):
+    assert torch.equal(a, b)
+
+
 def test_pixel_regime_fast_paths_track_the_plain_ones(dev):
   """PixelLipReader's defaults at the metric's shape family (96x96, BiGRU-256 x2): bf16 features
   handed to the encoder as stored, split-bf16 input projection and recurrent weight gradient, the
