@@ -476,7 +476,8 @@ def main():
         "vs_baseline": None,
         "dtype": ("bf16 (conv frontend, recurrent and input-projection operands; fp32 accumulation, state, CTC)"
                   if head.get("recurrence") == "bf16" else "bf16 (conv frontend, fp32 accumulate) + f32 (encoder, CTC)")
-                 if head["regime"] == "pixels" else "f32",
+                 if head["regime"] == "pixels" else
+                 ("bf16 (conv frontend, fp32 accumulate) + f32 (transformer encoder, CTC)" if head["regime"] == "pixels_tfm" else "f32"),
         "data": "synthetic",
         "config": {"workload": head["workload"], "regime": head["regime"], "model": args.model,
                    "recurrent_layers": head["layers"], "per_gpu_batch": args.batch,
