@@ -2155,7 +2155,7 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
       const bf16_t* dz = (const bf16_t*)dZ;
       float* slabs = (float*)workspace;
       const int F = B * T;
-      static bool attr_set[2] = {false, false};
+      static bool attr_set[3] = {false, false, false};
       lr_clear_error();
 #define LR_WGTR(IDX, LDSB, ...)                                                                              \
   do {                                                                                                      \
@@ -2170,7 +2170,10 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
     else hipLaunchKernelGGL((conv_wgrad_tr_kernel<__VA_ARGS__>), dim3(3 * kTrSlots), dim3(256), LDSB,        \
                             (hipStream_t)stream, x, dz, slabs, F, T, Hin);                                  \
   } while (0)
-      if (l2) LR_WGTR(0, 2 * (2 * 8 * 28 * 64 + 2 * 2 * 4 * 24 * 64), 32, 2, 5, 5, 24, 2, 4);
+      // 6-row tiles where the height allows (18 k16 steps per tile instead of 12 amortise the per-tile
+      // load / deposit / barrier better; 142 KB of the 160 KB of LDS for the two buffers)
+      if (l2 && Hin % 6 == 0) LR_WGTR(2, 2 * (2 * 10 * 28 * 64 + 2 * 2 * 6 * 24 * 64), 32, 2, 5, 5, 24, 2, 6);
+      else if (l2) LR_WGTR(0, 2 * (2 * 8 * 28 * 64 + 2 * 2 * 4 * 24 * 64), 32, 2, 5, 5, 24, 2, 4);
       else LR_WGTR(1, 2 * (2 * 2 * 8 * 14 * 64 + 3 * 2 * 6 * 12 * 64), 64, 3, 3, 3, 12, 2, 6);
 #undef LR_WGTR
       int st = lr_launch_status();
