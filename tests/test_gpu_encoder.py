@@ -269,8 +269,10 @@ def test_bf16x3_input_projection_tracks_the_fp32_path(dev, rnn_type):
     assert float((a - b).abs().max()) / scale < (1e-2 if i == 2 else 1e-4), i
 
 
-@pytest.mark.parametrize("B,lens", [(32, None), (20, [5, 9, 9, 12, 17, 20, 23, 23, 30, 30, 30, 31, 33, 36, 36, 38, 40, 40, 40, 40])])
-def test_persistent_bf16_recurrence_tracks_the_step_kernels(dev, B, lens):
+@pytest.mark.parametrize("B,T,lens", [(32, 40, None),
+                                      (20, 40, [5, 9, 9, 12, 17, 20, 23, 23, 30, 30, 30, 31, 33, 36, 36, 38, 40, 40, 40, 40]),
+                                      (5, 7, [7, 7, 4, 2, 1]), (2, 1, None)])
+def test_persistent_bf16_recurrence_tracks_the_step_kernels(dev, B, T, lens):
   """Pixel-regime option (LR_RNN_RECUR_BF16): all T steps of a GRU-256 layer in one launch with W_hh
   in bf16 registers/LDS.  Same interface buffers as the step kernels; results agree to bf16 level."""
   from lipreading_amd.data import default_char2idx
@@ -279,7 +281,6 @@ def test_persistent_bf16_recurrence_tracks_the_step_kernels(dev, B, lens):
   enc = VideoEncoder(96, 256, rnn_type='GRU', num_layers=2, bidirectional=True, enable_ctc=True,
                      vocab_size=64, char2idx=default_char2idx()).to(dev)
   g = torch.Generator().manual_seed(22)
-  T = 40
   x = torch.randn(B, T, 96, 1, generator=g)
   lens = torch.tensor(lens) if lens is not None else torch.full((B,), T)
   wgt = torch.randn(B, T, 65, generator=g).to(dev)
