@@ -714,37 +714,37 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
     st = lr_gru256_persist_backward(gates, extra, y, dy, dh_n, dG, w_hh, lens, wT, B, T, D, stream);
     if (st != LR_OK) return st;
   } else {
-  StepPtrs p;
-  p.h0 = nullptr;
-  p.c0 = nullptr;
-  float* dgp = wbase + wl.dgp;
-  for (int d = 0; d < D; ++d) {
-    float* out = wT + (size_t)d * wl.wp_per_dir;
-    int blocks = (int)((wl.wp_per_dir + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    LR_LAUNCH(pack_w_kernel, dim3(blocks), dim3(256), 0, stream, w_hh[d], out, G, H, 1);
-    p.w[d] = out;
-    p.b[d] = nullptr;
-  }
-  if (D == 1) { p.w[1] = p.w[0]; p.b[1] = nullptr; }
-  st = lr_launch_status();
-  if (st != LR_OK) return st;
-  if (hipMemsetAsync(dgp, 0, wl.dgp_floats * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
-
-  const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, D);
-  for (int s = 0; s < T; ++s) {
-    hipEvent_t e0, e1;
-    if (s == T / 2 && lr_prof_next(LR_PROF_RNN_BWD, &e0, &e1)) {
-      lr_clear_error();
-      if (G == 3) hipExtLaunchKernelGGL(rnn_bwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
-      else hipExtLaunchKernelGGL(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
-      continue;
+    StepPtrs p;
+    p.h0 = nullptr;
+    p.c0 = nullptr;
+    float* dgp = wbase + wl.dgp;
+    for (int d = 0; d < D; ++d) {
+      float* out = wT + (size_t)d * wl.wp_per_dir;
+      int blocks = (int)((wl.wp_per_dir + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      LR_LAUNCH(pack_w_kernel, dim3(blocks), dim3(256), 0, stream, w_hh[d], out, G, H, 1);
+      p.w[d] = out;
+      p.b[d] = nullptr;
     }
-    if (G == 3) LR_LAUNCH(rnn_bwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
-    else LR_LAUNCH(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
-  }
-  st = lr_launch_status();
-  if (st != LR_OK) return st;
+    if (D == 1) { p.w[1] = p.w[0]; p.b[1] = nullptr; }
+    st = lr_launch_status();
+    if (st != LR_OK) return st;
+    if (hipMemsetAsync(dgp, 0, wl.dgp_floats * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
+
+    const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, D);
+    for (int s = 0; s < T; ++s) {
+      hipEvent_t e0, e1;
+      if (s == T / 2 && lr_prof_next(LR_PROF_RNN_BWD, &e0, &e1)) {
+        lr_clear_error();
+        if (G == 3) hipExtLaunchKernelGGL(rnn_bwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
+        else hipExtLaunchKernelGGL(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
+        continue;
+      }
+      if (G == 3) LR_LAUNCH(rnn_bwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
+      else LR_LAUNCH(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
+    }
+    st = lr_launch_status();
+    if (st != LR_OK) return st;
   }
 
   const int R = B * T;
