@@ -49,8 +49,8 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3      # fp32-input MFMA
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA
 # lr_profile_read slots (include/lipreading_hip.h)
-SLOTS = {0: "rnn_fwd_step_kernel", 1: "rnn_bwd_step_kernel", 2: "conv1_fwd_igemm", 3: "conv2_fwd_igemm",
-         4: "conv3_fwd_igemm", 5: "conv2_dgrad_igemm", 6: "conv3_dgrad_igemm", 7: "conv1_wgrad",
+SLOTS = {0: "rnn_fwd_step_kernel", 1: "rnn_bwd_step_kernel", 2: "conv1_fwd", 3: "conv2_fwd",
+         4: "conv3_fwd", 5: "conv2_dgrad", 6: "conv3_dgrad", 7: "conv1_wgrad",
          8: "conv2_wgrad", 9: "conv3_wgrad"}
 
 
@@ -90,10 +90,10 @@ def conv_flops(B):
   for i, (cin, cout, (kt, kh, kw), stride, (pt, ph, pw)) in enumerate(LAYERS, 1):
     ho = (h + 2 * ph - kh) // stride + 1
     f = 2.0 * B * T_FRAMES * ho * ho * cout * cin * kt * kh * kw
-    out["conv%d_fwd_igemm" % i] = f
+    out["conv%d_fwd" % i] = f
     out["conv%d_wgrad" % i] = f
     if i > 1:
-      out["conv%d_dgrad_igemm" % i] = f
+      out["conv%d_dgrad" % i] = f
     h = ho // 2
   return out
 
