@@ -168,6 +168,23 @@ int lr_rnn_layer_backward(int mode, const float* x, const int32_t* lens,
                           size_t workspace_bytes, int accumulate, int B, int T, int I, int H, int D,
                           lr_stream_t stream);
 
+/* The same backward in two calls that may sit on two streams (build-defined, LR_RNN_PROJ_BF16X3
+ * layers only; LR_ERR_UNSUPPORTED otherwise unless parts == 3):
+ *   parts & 1: the recurrence and the data gradient dx (what the layer below waits for);
+ *   parts & 2: the weight and bias gradients, from the gate gradients the parts & 1 call left in
+ *              `workspace` — the caller orders it after that call (an event) and keeps the workspace
+ *              alive; it can then overlap the layer below's latency-bound recurrence.
+ * parts == 3 is lr_rnn_layer_backward. */
+int lr_rnn_layer_backward_parts(int mode, const float* x, const int32_t* lens,
+                                const float* const* w_ih_host, const float* const* w_hh_host,
+                                const float* const* b_ih_host, const float* const* b_hh_host,
+                                const float* y, const float* dy, const float* dh_n, const float* dc_n,
+                                float* dx, float* const* dw_ih_host, float* const* dw_hh_host,
+                                float* const* db_ih_host, float* const* db_hh_host,
+                                const void* reserve, size_t reserve_bytes, void* workspace,
+                                size_t workspace_bytes, int accumulate, int B, int T, int I, int H, int D,
+                                int parts, lr_stream_t stream);
+
 /* Instrumentation for the roofline leg of bench.py (the only entry points that touch the host
  * clock).  While enabled, every lr_rnn_layer_forward / _backward call issues ONE of its step
  * launches (the middle one) with a hipEvent pair that stamps that dispatch's begin and end on

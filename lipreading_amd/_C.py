@@ -46,6 +46,9 @@ SIGNATURES = {
     "lr_rnn_layer_backward": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                        c_size_t, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int,
                                        P]),
+    "lr_rnn_layer_backward_parts": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
+                                             c_size_t, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int,
+                                             c_int, P]),
     "lr_profile_enable": (c_int, [c_int]),
     "lr_profile_read": (c_int, [c_int, P, P]),
     "lr_proj_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -669,16 +669,21 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
   return lr_launch_status();
 }
 
-extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* lens,
-                                     const float* const* w_ih, const float* const* w_hh,
-                                     const float* const* b_ih, const float* const* b_hh,
-                                     const float* y, const float* dy, const float* dh_n,
-                                     const float* dc_n, float* dx, float* const* dw_ih,
-                                     float* const* dw_hh, float* const* db_ih, float* const* db_hh,
-                                     const void* reserve, size_t reserve_bytes, void* workspace,
-                                     size_t workspace_bytes, int accumulate, int B, int T, int I,
-                                     int H, int D, lr_stream_t stream_) {
+// parts & 1: the recurrence (dG into the workspace) and the data gradient dx;  parts & 2: weight and
+// bias gradients from the dG a parts & 1 call left in the same workspace (split calls: only on the
+// LR_RNN_PROJ_BF16X3 path, where the two halves touch disjoint outputs and may run on two streams)
+static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens,
+                                   const float* const* w_ih, const float* const* w_hh,
+                                   const float* const* b_ih, const float* const* b_hh,
+                                   const float* y, const float* dy, const float* dh_n,
+                                   const float* dc_n, float* dx, float* const* dw_ih,
+                                   float* const* dw_hh, float* const* db_ih, float* const* db_hh,
+                                   const void* reserve, size_t reserve_bytes, void* workspace,
+                                   size_t workspace_bytes, int accumulate, int B, int T, int I,
+                                   int H, int D, int parts, lr_stream_t stream_) {
   LR_CHECK_ARG(dims_ok(mode, B, T, I, H, D));
+  LR_CHECK_ARG((parts & ~3) == 0 && parts != 0);
+  if (parts != 3 && !proj_x3(mode)) return LR_ERR_UNSUPPORTED;
   LR_CHECK_ARG(x && lens && w_ih && w_hh && y && dy && reserve && workspace);
   const float wbeta = accumulate ? 1.f : 0.f;
   LR_CHECK_ARG(dw_ih && dw_hh && db_ih && db_hh);
@@ -706,7 +711,9 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
   const int GH = G * H;
 
   int st = LR_OK;
-  if (recur_bf16(mode)) {
+  if (!(parts & 1)) {
+    // dG is already in the workspace
+  } else if (recur_bf16(mode)) {
     // one launch for all T steps (lr_rnn_persist.hip); dG comes out in the step kernels' layout.  The
     // packed-W_hh^T area of the workspace holds the bf16 fragments.
     if (!lr_gru256_persist_supported(G, B, H) || dc_n) return LR_ERR_UNSUPPORTED;
@@ -753,15 +760,16 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
   const size_t xws_bytes = x3 ? x3_ws_floats(G, B, T, I, H, D) * sizeof(float) : 0;
   if (x3) {
     // input projection: all directions in one contraction per product (lr_xgemm.hip)
-    st = lr_xproj_dw(dG, ldg, 4 * H, x, R, I, GH, D, dw_ih, wbeta, x_exact(mode) ? 1 : 0, x_stored_bf16(mode) ? 1 : 0,
-                     xws, xws_bytes, stream);
-    if (st != LR_OK) return st;
-    if (dx) {
+    if ((parts & 1) && dx) {
       // a bf16 input's gradient goes to a bf16 consumer (the conv frontend's backward): hi terms only
       st = lr_xproj_dx(dG, ldg, 4 * H, w_ih, R, I, GH, D, dx, x_exact(mode) ? 1 : 0, x_stored_bf16(mode) ? 1 : 0, xws,
                        xws_bytes, stream);
       if (st != LR_OK) return st;
     }
+    if (!(parts & 2)) return LR_OK;
+    st = lr_xproj_dw(dG, ldg, 4 * H, x, R, I, GH, D, dw_ih, wbeta, x_exact(mode) ? 1 : 0, x_stored_bf16(mode) ? 1 : 0,
+                     xws, xws_bytes, stream);
+    if (st != LR_OK) return st;
     // recurrent weight gradient on the same split-bf16 path (one contraction per direction)
     st = lr_xproj_dwhh(dG, ldg, y, D * H, R, T, H, G, D, dw_hh, wbeta, xws, xws_bytes, stream);
     if (st != LR_OK) return st;
@@ -806,6 +814,34 @@ extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* le
   LR_LAUNCH(bias_grad_final_kernel, dim3((ldg + 255) / 256), dim3(256), 0, stream,
             (const float*)partial, bp, H, D, G, accumulate);
   return lr_launch_status();
+}
+
+extern "C" int lr_rnn_layer_backward(int mode, const float* x, const int32_t* lens,
+                                     const float* const* w_ih, const float* const* w_hh,
+                                     const float* const* b_ih, const float* const* b_hh,
+                                     const float* y, const float* dy, const float* dh_n,
+                                     const float* dc_n, float* dx, float* const* dw_ih,
+                                     float* const* dw_hh, float* const* db_ih, float* const* db_hh,
+                                     const void* reserve, size_t reserve_bytes, void* workspace,
+                                     size_t workspace_bytes, int accumulate, int B, int T, int I,
+                                     int H, int D, lr_stream_t stream) {
+  return rnn_layer_backward_impl(mode, x, lens, w_ih, w_hh, b_ih, b_hh, y, dy, dh_n, dc_n, dx, dw_ih, dw_hh, db_ih,
+                                 db_hh, reserve, reserve_bytes, workspace, workspace_bytes, accumulate, B, T, I, H, D,
+                                 3, stream);
+}
+
+extern "C" int lr_rnn_layer_backward_parts(int mode, const float* x, const int32_t* lens,
+                                           const float* const* w_ih, const float* const* w_hh,
+                                           const float* const* b_ih, const float* const* b_hh,
+                                           const float* y, const float* dy, const float* dh_n,
+                                           const float* dc_n, float* dx, float* const* dw_ih,
+                                           float* const* dw_hh, float* const* db_ih, float* const* db_hh,
+                                           const void* reserve, size_t reserve_bytes, void* workspace,
+                                           size_t workspace_bytes, int accumulate, int B, int T, int I,
+                                           int H, int D, int parts, lr_stream_t stream) {
+  return rnn_layer_backward_impl(mode, x, lens, w_ih, w_hh, b_ih, b_hh, y, dy, dh_n, dc_n, dx, dw_ih, dw_hh, db_ih,
+                                 db_hh, reserve, reserve_bytes, workspace, workspace_bytes, accumulate, B, T, I, H, D,
+                                 parts, stream);
 }
 
 // ---- internal entry points for lr_decoder.hip (single direction, one step per call) -------------

@@ -53,6 +53,33 @@ def _notify(weights):
     hook(list(weights))
 
 
+# Weight-gradient halves of layer backwards that were put on the side stream (see
+# _RNNLayerFunction.backward): (tensors kept alive, weights).  Joined by flush_deferred().
+overlap_weight_grads = False     # PixelLipReader switches it on; needs in-place (.grad) gradients
+_side_stream = None
+_deferred = []
+
+
+def _get_side_stream(device):
+  global _side_stream
+  if _side_stream is None or _side_stream.device != device:
+    _side_stream = torch.cuda.Stream(device=device)
+  return _side_stream
+
+
+def flush_deferred():
+  """Join the side stream: the current stream waits for every deferred weight-gradient half, then
+  the gradients are announced (grad_ready_hooks).  Called at the end of the next layer's backward,
+  by the conv frontend's backward and by FusedAdam.step; a no-op when nothing is pending."""
+  if not _deferred:
+    return
+  torch.cuda.current_stream().wait_stream(_side_stream)
+  pending = list(_deferred)
+  del _deferred[:]
+  for _keep, weights in pending:
+    _notify(weights)
+
+
 class _RNNLayerFunction(torch.autograd.Function):
   """One (bi)directional layer: lr_rnn_layer_forward / lr_rnn_layer_backward."""
 
@@ -99,12 +126,29 @@ class _RNNLayerFunction(torch.autograd.Function):
     dx = torch.empty_like(x) if need_dx else None
     wbytes = L.lr_rnn_workspace_bytes(mode, B, T, I, H, D)
     ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+    if overlap_weight_grads and direct and need_dx and (mode & _PROJ_BF16X3):
+      # An upper layer of the pixel regime: the layer below only waits for dx.  The recurrence and dx
+      # stay on this stream; the weight-gradient GEMMs go to a side stream, where they overlap the
+      # layer below's recurrence (one workgroup per sample and direction: most of the chip is idle).
+      args = (mode, x.data_ptr(), lens.data_ptr(), _ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(b_ih),
+              _ptr_array(b_hh), y.data_ptr(), dy.data_ptr(), _C.ptr(dh_n), _C.ptr(dc_n), _C.ptr(dx),
+              _ptr_array(grads[0::4]), _ptr_array(grads[1::4]), _ptr_array(grads[2::4]), _ptr_array(grads[3::4]),
+              reserve.data_ptr(), reserve.numel(), ws.data_ptr(), wbytes, 1, B, T, I, H, D)
+      _C.check(L.lr_rnn_layer_backward_parts(*args, 1, _C.stream_handle()), "lr_rnn_layer_backward_parts(data)")
+      flush_deferred()                      # at most one deferred half in flight
+      side = _get_side_stream(dev)
+      side.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(side):
+        _C.check(L.lr_rnn_layer_backward_parts(*args, 2, _C.stream_handle()), "lr_rnn_layer_backward_parts(weights)")
+      _deferred.append(((x, lens, y, dy, reserve, ws, grads, weights), weights))
+      return (dx, None, None, None, None) + (None,) * len(weights)
     _C.check(L.lr_rnn_layer_backward(
         mode, x.data_ptr(), lens.data_ptr(), _ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(b_ih),
         _ptr_array(b_hh), y.data_ptr(), dy.data_ptr(), _C.ptr(dh_n), _C.ptr(dc_n), _C.ptr(dx),
         _ptr_array(grads[0::4]), _ptr_array(grads[1::4]), _ptr_array(grads[2::4]),
         _ptr_array(grads[3::4]), reserve.data_ptr(), reserve.numel(), ws.data_ptr(), wbytes,
         1 if direct else 0, B, T, I, H, D, _C.stream_handle()), "lr_rnn_layer_backward")
+    flush_deferred()   # the layer above's weight-gradient half overlapped this layer's recurrence
     if direct:
       _notify(weights)
       return (dx, None, None, None, None) + (None,) * len(weights)

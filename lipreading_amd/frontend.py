@@ -112,6 +112,7 @@ class _ConvFrontendFunction(torch.autograd.Function):
 
   @staticmethod
   def backward(ctx, dfeat):
+    from . import encoder as _enc
     L = _C.lib()
     st = _C.stream_handle()
     B, T, H, W = ctx.dims
@@ -174,6 +175,8 @@ class _ConvFrontendFunction(torch.autograd.Function):
         dP = torch.empty((frames, h, w, cin), dtype=bf, device=dev)
         _C.check(L.lr_conv3d_forward(dZ.data_ptr(), wd.data_ptr(), None, dP.data_ptr(), B, T, ho, wo, cout,
                                      cin, kt, kh, kw, 1, pt, ph, pw, frag, st), "lr_conv3d_forward(dgrad)")
+    # the first recurrent layer's weight-gradient GEMMs ran on the side stream beside these kernels
+    _enc.flush_deferred()
     if direct:
       _notify(params)
       return (None,) * (2 + len(params))
@@ -215,6 +218,9 @@ class PixelLipReader(nn.Module):
     # BASELINE configs[1] names this regime "bf16".  Other shapes keep the fp32 step kernels;
     # `encoder.recurrence = 'f32'` switches it off.
     encoder.recurrence = 'bf16'
+    # weight-gradient GEMMs of upper recurrent layers overlap the recurrence of the layer below
+    from . import encoder as _enc
+    _enc.overlap_weight_grads = True
   def forward(self, clips, frame_lens, max_len=None):
     feats = self.frontend(clips, out_bf16=True)
     B, T, F = feats.shape

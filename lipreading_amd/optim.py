@@ -79,6 +79,8 @@ class FusedAdam(object):
     """grad_norm: max norm for clip_grad_norm_ (None = no clipping); grad_scale: multiplies the
     gradient first (1/world after an all-reduce sum); skip: int32[1] device flag — non-zero
     leaves parameters, moments and step count untouched (the reference's `continue`)."""
+    from .encoder import flush_deferred
+    flush_deferred()   # weight-gradient work still on the side stream (encoder.overlap_weight_grads)
     L = _C.lib()
     f = self.flat
     st = _C.stream_handle()
