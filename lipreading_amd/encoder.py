@@ -54,7 +54,7 @@ def _notify(weights):
 
 
 # Weight-gradient halves of layer backwards that were put on the side stream (see
-# _RNNLayerFunction.backward): (tensors kept alive, weights).  Joined by flush_deferred().
+# _RNNLayerFunction.backward): the tensors they use, kept alive until flush_deferred() joins the streams.
 overlap_weight_grads = False     # PixelLipReader switches it on; needs in-place (.grad) gradients
 _side_stream = None
 _deferred = []
@@ -68,16 +68,13 @@ def _get_side_stream(device):
 
 
 def flush_deferred():
-  """Join the side stream: the current stream waits for every deferred weight-gradient half, then
-  the gradients are announced (grad_ready_hooks).  Called at the end of the next layer's backward,
-  by the conv frontend's backward and by FusedAdam.step; a no-op when nothing is pending."""
+  """Join the side stream: the current stream waits for every deferred weight-gradient half.  Called
+  at the end of the next layer's backward, by the conv frontend's backward and by FusedAdam.step; a
+  no-op when nothing is pending."""
   if not _deferred:
     return
   torch.cuda.current_stream().wait_stream(_side_stream)
-  pending = list(_deferred)
-  del _deferred[:]
-  for _keep, weights in pending:
-    _notify(weights)
+  del _deferred[:]   # the tensors the side stream was using may be released now
 
 
 class _RNNLayerFunction(torch.autograd.Function):
@@ -140,7 +137,10 @@ class _RNNLayerFunction(torch.autograd.Function):
       side.wait_stream(torch.cuda.current_stream())
       with torch.cuda.stream(side):
         _C.check(L.lr_rnn_layer_backward_parts(*args, 2, _C.stream_handle()), "lr_rnn_layer_backward_parts(weights)")
-      _deferred.append(((x, lens, y, dy, reserve, ws, grads, weights), weights))
+        # announced from the side stream: a gradient all-reduce (distributed.GradSync) then waits for
+        # THIS stream, i.e. starts as soon as these gradients exist, not when the streams are joined
+        _notify(weights)
+      _deferred.append((x, lens, y, dy, reserve, ws, grads, weights))
       return (dx, None, None, None, None) + (None,) * len(weights)
     _C.check(L.lr_rnn_layer_backward(
         mode, x.data_ptr(), lens.data_ptr(), _ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(b_ih),
