@@ -143,6 +143,45 @@ def test_first_layer_fused_paths_equal_the_staged_ones(dev):
     assert torch.equal(a, b)
 
 
+def test_side_stream_weight_gradients_are_the_same_gradients(dev):
+  """encoder.overlap_weight_grads: the weight-gradient half of a recurrent layer's backward runs on a
+  side stream (lr_rnn_layer_backward_parts) beside the layer below.  Same kernels on the same data:
+  every gradient is bit-identical to the single-stream backward."""
+  from lipreading_amd import encoder as E
+  from lipreading_amd.ctc import ctc_loss_with_status
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.frontend import ConvFrontend3D, PixelLipReader, feature_dim
+  from lipreading_amd.optim import FlatParameters
+  torch.manual_seed(11)
+  H = 96
+  enc = E.VideoEncoder(feature_dim(H, H), 256, rnn_type='GRU', num_layers=2, bidirectional=True, enable_ctc=True,
+                       vocab_size=64, char2idx=default_char2idx())
+  model = PixelLipReader(enc, ConvFrontend3D()).to(dev).train()
+  flat = FlatParameters(model)          # dense .grad buffers: gradients are written in place
+  g = torch.Generator().manual_seed(12)
+  B, T = 4, 10
+  clips = torch.randint(0, 256, (B, T, 3, H, H), generator=g, dtype=torch.uint8).to(dev)
+  lens = torch.tensor([10, 10, 7, 3], device=dev)
+  labels = torch.randint(4, 64, (B, 3), generator=g).to(dev)
+  ll = torch.full((B,), 3, device=dev)
+  assert E.overlap_weight_grads
+  res = {}
+  for overlap in (True, False):
+    E.overlap_weight_grads = overlap
+    try:
+      flat.zero_grad()
+      lp, _, _ = model(clips, lens, max_len=T)
+      loss, _, _ = ctc_loss_with_status(lp, labels, lens, ll, 'mean')
+      loss.backward()
+      E.flush_deferred()
+      torch.cuda.synchronize()
+      res[overlap] = flat.grad.clone()
+    finally:
+      E.overlap_weight_grads = True
+  assert float(res[True].abs().max()) > 0
+  assert torch.equal(res[True], res[False])
+
+
 def test_pixel_regime_fast_paths_track_the_plain_ones(dev):
   """PixelLipReader's defaults at the metric's shape family (96x96, BiGRU-256 x2): bf16 features
   handed to the encoder as stored, split-bf16 input projection and recurrent weight gradient, the
