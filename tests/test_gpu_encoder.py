@@ -290,7 +290,8 @@ def test_persistent_bf16_recurrence_tracks_the_step_kernels(dev, B, T, lens):
     enc.recurrence = mode
     enc.zero_grad()
     lp, hid, fin = enc(x.to(dev), lens, max_len=T)
-    ((lp * wgt * valid).sum() + hid.pow(2).sum()).backward()
+    # the final state takes part in the loss: its gradient (dh_n) is injected at each sample's last step
+    ((lp * wgt * valid).sum() + hid.pow(2).sum() + 3.0 * fin.pow(2).sum()).backward()
     res[mode] = [lp.detach().cpu() * valid.cpu(), hid.detach().cpu(), fin.detach().cpu()] + \
                 [p.grad.cpu().clone() for p in enc.parameters()]
   enc.recurrence = "f32"
