@@ -4,8 +4,9 @@
 // (~5 us per step whatever the arithmetic), because fp32 W_hh (768 KB per direction) has to be
 // re-streamed from the fabric every step.  BASELINE.json's configs[1] (the pixel regime: conv
 // frontend + BiGRU-256, "bf16") allows a different trade: with W_hh rounded to bf16 (384 KB per
-// direction) the whole matrix fits ONE compute unit — 288 KB as MFMA operand fragments held in
-// the registers of 4 waves (240 of each wave's 256 AGPRs + 48 VGPRs), 96 KB in LDS — and batch rows
+// direction) the whole matrix fits ONE compute unit — as MFMA operand fragments held in the registers
+// of 4 waves (240 of each wave's 256 AGPRs + 96-144 VGPRs; the forward kernel keeps its last k step,
+// 48 KB, in LDS) — and batch rows
 // are independent, so every (sample, direction) gets its own workgroup that runs all T steps with
 // nothing but one workgroup barrier per step:
 //   state (bf16, double-buffered in LDS, row 0 of the 16-row MFMA operand) x W_hh^T on
@@ -21,10 +22,11 @@
 // better_model.py:74 (nn.GRU); precision: bf16 operands in the recurrent product only.
 //
 // STATUS: what PixelLipReader runs (VideoEncoder.recurrence = 'bf16'; tests/test_gpu_encoder.py
-// checks it against the step kernels, ragged lengths included).  MI355X, B = 32, T = 75: 111 us per
-// forward layer pass (1.5 us per step), 153 us per backward pass (2.0 us), against 5.4 / 4.8 us per
+// checks it against the step kernels, ragged lengths included).  MI355X, B = 32, T = 75: 104 us per
+// forward layer pass (1.4 us per step), 127 us per backward pass (1.7 us), against 5.4 / 4.8 us per
 // step for the step kernels.  History: 16 samples per workgroup 6.7 us/step; 4 samples 4.0; AGPR
-// operands 3.4; one sample per workgroup 2.7; pre-packed fragments 1.5.
+// operands 3.4; one sample per workgroup 2.7; pre-packed fragments 1.5; operands fetched two steps
+// ahead and (nearly) all fragments in registers 1.4.
 #include "lr_common.h"
 #include <hip/hip_ext.h>
 
@@ -37,7 +39,7 @@ typedef unsigned short bf16_t;
 constexpr int PH = 256;            // hidden size this kernel is built for
 constexpr int PKS = PH / 32;       // k steps of 32 (forward: k = previous state)
 constexpr int PKS_A = 5;           // k steps whose weight fragments live in AGPRs (12 x 5 x 4 = 240 of the 256)
-constexpr int PKS_REG = 6;         // k steps held in registers at all (AGPR + VGPR); the rest sit in LDS
+constexpr int PKS_REG = 7;         // k steps held in registers at all (AGPR + VGPR); the rest sit in LDS
 constexpr int PNT = 12;            // 16-unit column tiles per wave: 3 gates x 4
 constexpr int PHLD = PH + 8;       // bf16 per LDS row of the state (528 B: conflict-free b128 rows)
 constexpr int PBH = 1;             // samples per workgroup (rows >= PBH of the 16-row MFMA operand are zero)
@@ -262,10 +264,10 @@ __global__ __launch_bounds__(256, 1) void gru256_fwd_persist_kernel(float* __res
 // processed just before, kappa = (gate, k) over 3*256), then the gate gradients of step t — the
 // arithmetic of rnn_bwd_step_kernel<3> with the product's operands in bf16.  One workgroup per
 // (sample, direction); wave w owns output units 64w .. 64w+63 as 4 column tiles x 24 k steps = 96
-// weight fragments (k steps 0-14 in AGPRs, 15-17 in VGPRs, 18-23 in LDS); dGh of the previous step
+// weight fragments (k steps 0-14 in AGPRs, 15-23 in VGPRs, none in LDS); dGh of the previous step
 // (768 bf16, row 0 of the A operand) goes from the gate phase to the product through LDS.
 constexpr int BKS = 3 * PH / 32;   // 24 k steps
-constexpr int BKS_A = 15, BKS_REG = 18;
+constexpr int BKS_A = 15, BKS_REG = 24;
 constexpr int BGLD = 3 * PH + 8;   // bf16 per dGh buffer
 constexpr size_t PBWD_LDS = (size_t)2 * BGLD * 2 + 16 + (size_t)4 * 4 * (BKS - BKS_REG) * 1024 + (size_t)PH * 4;
 
