@@ -72,8 +72,9 @@ def train(encoder, decoding_step, data_loader, opt, device, char2idx,
   """Assumes sequences begin with BOS and end with EOS; data_loader yields
   (frames f32, frame_lens i64, chars i64, char_lens i64) — train_better_model.py:7-86.
 
-  decoding_step=None: encoder+CTC alone, `opt` a FusedAdam over the encoder.  With a
-  CharDecodingStep `opt` is (encoder FusedAdam, decoder FusedAdam): the reference clips the two
+  decoding_step=None: encoder+CTC alone, `opt` a FusedAdam over the encoder (`grad_sync`: one
+  distributed.GradSync or None).  With a CharDecodingStep `opt` is (encoder FusedAdam, decoder
+  FusedAdam) and `grad_sync`, if given, (encoder GradSync, decoder GradSync): the reference clips the two
   modules separately (:77-79) and one Adam over both is the same update as two Adams.  The
   reference runs decoder_loss.backward(retain_graph) and then ctc_loss.backward() (:70,:74): two
   traversals of the encoder graph whose gradients add; here the two losses are summed and the
@@ -85,7 +86,9 @@ def train(encoder, decoding_step, data_loader, opt, device, char2idx,
     assert isinstance(opt, FusedAdam), "opt must be lipreading_amd.optim.FusedAdam"
     opts = (opt,)
   else:
-    assert grad_sync is None, "data-parallel training of the decoder loop is not wired yet"
+    # data parallel: grad_sync = (encoder GradSync, decoder GradSync), one per flat buffer
+    syncs = (None, None) if grad_sync is None else tuple(grad_sync)
+    assert len(syncs) == 2, "with a decoding step grad_sync is (encoder GradSync, decoder GradSync)"
     opts = tuple(opt)
     assert len(opts) == 2 and all(isinstance(o, FusedAdam) for o in opts), \
         "opt must be (encoder FusedAdam, decoder FusedAdam)"
@@ -119,8 +122,11 @@ def train(encoder, decoding_step, data_loader, opt, device, char2idx,
                                 state, teacher_forcing_ratio, pad)
     decoder_loss = nll / (labels != pad).sum()
     (decoder_loss + total).backward()
-    for o in opts:  # per-module clip (:77-79); a batch the reference skips (:49-50) updates nothing
-      o.step(grad_norm=grad_norm, skip=status)
+    # per-module clip (:77-79) on the all-reduced gradients; a batch the reference skips (:49-50)
+    # updates nothing (with several ranks: only if every rank skipped, GradSync's MIN over ranks)
+    for o, sync in zip(opts, syncs):
+      scale = sync(status) if sync is not None else 1.0
+      o.step(grad_norm=grad_norm, grad_scale=scale, skip=status)
     if status is None:
       dec_sum += decoder_loss.detach()
     else:

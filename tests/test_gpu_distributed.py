@@ -82,3 +82,57 @@ def test_overlapped_gradient_exchange_matches_plain_step(dev, pg, pixels):
       from lipreading_amd import encoder as _enc
       _enc.grad_ready_hooks.remove(sync._direct_hook)
   np.testing.assert_allclose(results[1], results[0], rtol=1e-6, atol=1e-7)
+
+
+def test_train_loop_with_decoder_and_gradient_exchange(dev, pg):
+  """train() with a CharDecodingStep takes grad_sync = (encoder GradSync, decoder GradSync): per
+  batch both flat gradient buffers are all-reduced (the encoder's overlapped with backward), then
+  each module is clipped and stepped — on a 1-rank group the result equals the loop without it."""
+  from lipreading_amd import train as T
+  from lipreading_amd.attention_decoder import CharDecodingStep
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.distributed import GradSync
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.optim import FlatParameters, FusedAdam
+  c2i = default_char2idx()
+  g = torch.Generator().manual_seed(4)
+  batches = []
+  for _ in range(3):
+    lens = torch.sort(torch.randint(12, 21, (6,), generator=g))[0]
+    frames = torch.randn(6, int(lens.max()), 68, 3, generator=g)
+    for b in range(6):
+      frames[b, lens[b]:] = 0
+    cl = torch.randint(4, 9, (6,), generator=g)
+    chars = torch.zeros(6, int(cl.max()), dtype=torch.long)
+    for b in range(6):
+      n = int(cl[b])
+      chars[b, 0], chars[b, n - 1] = 1, 2
+      chars[b, 1:n - 1] = torch.randint(4, 64, (n - 2,), generator=g)
+    batches.append((frames, lens, chars, cl))
+  results = []
+  for use_sync in (False, True):
+    torch.manual_seed(9)
+    enc = VideoEncoder(204, 16, rnn_type='GRU', num_layers=1, bidirectional=True, enable_ctc=True,
+                       vocab_size=64, char2idx=c2i).to(dev)
+    dec = CharDecodingStep(enc, 12, 64, c2i, attention_type='1_layer_nn').to(dev)
+    fe, fd = FlatParameters(enc), FlatParameters(dec)
+    opt = (FusedAdam(fe, lr=1e-3), FusedAdam(fd, lr=1e-3))
+    syncs = None
+    if use_sync:
+      syncs = (GradSync(fe, groups=GradSync.groups_for_encoder(enc, fe), overlap=True), GradSync(fd, overlap=False))
+      for s in syncs:
+        s.broadcast_parameters(0)
+    torch.manual_seed(10)   # the teacher-forcing draws of the loop
+    dl, cl_ = T.train(enc, dec, batches, opt, dev, c2i, teacher_forcing_ratio=1, grad_norm=5.0, grad_sync=syncs)
+    torch.cuda.synchronize()
+    results.append((dl, cl_, fe.data.detach().cpu().numpy().copy(), fd.data.detach().cpu().numpy().copy()))
+    if syncs is not None:
+      from lipreading_amd import encoder as _enc
+      for s in syncs:
+        for h in s._hooks:
+          h.remove()
+        if getattr(s, "_direct_hook", None) in _enc.grad_ready_hooks:
+          _enc.grad_ready_hooks.remove(s._direct_hook)
+  assert abs(results[0][0] - results[1][0]) < 1e-6 and abs(results[0][1] - results[1][1]) < 1e-6
+  np.testing.assert_allclose(results[1][2], results[0][2], rtol=1e-6, atol=1e-7)
+  np.testing.assert_allclose(results[1][3], results[0][3], rtol=1e-6, atol=1e-7)
