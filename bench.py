@@ -48,10 +48,12 @@ T_FRAMES, N_LMK, LMK_DIM, VOCAB, LABEL_LEN, IMG = 75, 68, 3, 64, 30, 96
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3      # fp32-input MFMA
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA
+PARITY_TOL_LANDMARKS = 1e-4       # north_star: CTC loss within 1e-4 of the CPU reference (fp32, absolute)
+PARITY_TOL_PIXELS = 1e-3          # bf16 conv stack + bf16 recurrent operands vs the fp32 reference tail
 # lr_profile_read slots (include/lipreading_hip.h)
 SLOTS = {0: "rnn_fwd_step_kernel", 1: "rnn_bwd_step_kernel", 2: "conv1_fwd", 3: "conv2_fwd",
          4: "conv3_fwd", 5: "conv2_dgrad", 6: "conv3_dgrad", 7: "conv1_wgrad",
-         8: "conv2_wgrad", 9: "conv3_wgrad"}
+         8: "conv2_wgrad", 9: "conv3_wgrad", 10: "ctc_alpha_beta", 11: "ctc_grad_rows"}
 
 
 # multi-rank code path on: WORLD_SIZE > 1, or LIPREADING_BENCH_FORCE_DIST=1 to run the very same path
@@ -83,6 +85,17 @@ def synth_clips(B, seed, device=None):
   return clips if device is None else clips.to(device)
 
 
+def pmc_traffic():
+  """(dict, path) of the newest committed profiles/rNN_pmc_traffic.json (HBM bytes per launch from
+  separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; rocprofv3 cannot run inside bench.py)."""
+  import glob
+  cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+  if not cands:
+    return None, None
+  with open(cands[-1]) as f:
+    return json.load(f), os.path.relpath(cands[-1], ROOT)
+
+
 def conv_flops(B):
   """Algorithmic flops per launch of each conv kernel at (B,75,3,96,96) (frontend.LAYERS)."""
   from lipreading_amd.frontend import LAYERS
@@ -98,14 +111,19 @@ def conv_flops(B):
   return out
 
 
-def cpu_baseline(regime, model, layers, B, budget_s=20.0):
-  """The oracle's step on this host's cores, bounded to ~budget_s of CPU work (>= 1 step)."""
+def cpu_baseline(regime, model, layers, B, budget_s=20.0, warmup=3, min_steps=10):
+  """The oracle's step on this host's cores: `warmup` untimed steps, then >= `min_steps` timed ones
+  (BASELINE.md section 3), each timed on its own; median and min reported.  The sample is bounded:
+  when a full-batch step would blow the budget (the pixel regime's conv frontend on the CPU), the
+  same workload runs at a smaller batch, stated in `sample`."""
+  import statistics
   import torch
   from oracle import torch_oracle as O   # checker/baseline only — never on the product path
   rnn_type, H, bi = MODELS[model]
   torch.manual_seed(123456)
   tfm = regime == "pixels_tfm"
   pixels = regime == "pixels" or tfm
+  B_cpu = min(B, 4) if pixels else B     # ~1 s per step either way on a 100+-thread host
   frame_dim = 96 * (IMG // 16) ** 2 if pixels else N_LMK * LMK_DIM
   if tfm:
     tenc = O.OracleTransformerEncoder(frame_dim, 256, 4, 4, 1024, VOCAB, O.default_char2idx()).train()
@@ -127,14 +145,14 @@ def cpu_baseline(regime, model, layers, B, budget_s=20.0):
     dec = O.OracleCharDecodingStep(H * (2 if bi else 1), rnn_type, 1, 300, VOCAB, O.default_char2idx(),
                                    attention_type='1_layer_nn').train()
   opt = torch.optim.Adam(params + (list(dec.parameters()) if attn else []), lr=1e-4)
-  frames, frame_lens, chars, char_lens = synth_batch(B, 123456)
-  clips = synth_clips(B, 123456) if pixels else None
+  frames, frame_lens, chars, char_lens = synth_batch(B_cpu, 123456)
+  clips = synth_clips(B_cpu, 123456) if pixels else None
 
   def step():
     x = frames
     if pixels:
       feats = O.conv_frontend(clips, convs, emulate_bf16=False)
-      x = feats.reshape(B, T_FRAMES, -1, 1)
+      x = feats.reshape(B_cpu, T_FRAMES, -1, 1)
     lp, hid, st = enc(x, frame_lens)
     loss = O.ctc_loss(lp, chars[:, 1:], frame_lens, char_lens - 1, 'mean')
     opt.zero_grad()
@@ -147,22 +165,154 @@ def cpu_baseline(regime, model, layers, B, budget_s=20.0):
       torch.nn.utils.clip_grad_norm_(dec.parameters(), 50)
     opt.step()
 
-  step()  # warm-up
-  t0 = time.perf_counter()
-  n = 0
-  while True:
+  for _ in range(warmup):
     step()
-    n += 1
-    el = time.perf_counter() - t0
-    if el >= budget_s or n >= 50:
-      break
-  return {"value": round(n * B * T_FRAMES / el, 1), "unit": "frames/s",
-          "cores": torch.get_num_threads(), "kind": "port",
-          "sample": "%d steps of the same workload (%s regime, B=%d, T=%d, %s x%d) through oracle/torch_oracle.py "
-                    "(stock torch CPU ops in the reference's order%s), %d intra-op threads of %d host cores, %.1f s"
-                    % (n, regime, B, T_FRAMES, model, layers,
+  times = []
+  t_all = time.perf_counter()
+  while len(times) < min_steps or (time.perf_counter() - t_all < budget_s and len(times) < 50):
+    t0 = time.perf_counter()
+    step()
+    times.append(time.perf_counter() - t0)
+  med, best = statistics.median(times), min(times)
+  per = B_cpu * T_FRAMES
+  return {"value": round(per / med, 1), "unit": "frames/s", "value_best": round(per / best, 1),
+          "ms_per_step_median": round(med * 1e3, 2), "ms_per_step_min": round(best * 1e3, 2),
+          "steps": len(times), "warmup": warmup,
+          "cores": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
+          "sample": "%d timed steps after %d warm-ups of the same workload (%s regime, B=%d%s, T=%d, %s x%d) through "
+                    "oracle/torch_oracle.py (stock torch CPU ops in the reference's order%s), %d intra-op threads "
+                    "of %d host cores; value = frames / median step"
+                    % (len(times), warmup, regime, B_cpu,
+                       " — bounded sample, the GPU line is B=%d" % B if B_cpu != B else "", T_FRAMES, model, layers,
                        "; conv frontend = F.conv3d/max_pool3d fp32" if pixels else "",
-                       torch.get_num_threads(), os.cpu_count(), el)}
+                       torch.get_num_threads(), os.cpu_count())}
+
+
+def parity_block(regime, model_name, layers, B, dev):
+  """The metric's "+ CTC-loss parity": the HIP path and the oracle on IDENTICAL inputs and weights, one
+  forward + CTC 'mean' loss each (the caller contract of train_better_model.py:46-48), at the bench
+  shape.  Landmarks regime: every stage is pinned to the reference, tolerance 1e-4 absolute (fp32).
+  Pixels regime: the conv stage is build-defined; the oracle is F.conv3d with this repo's bf16 storage
+  points emulated, then the reference's encoder and CTC — tolerance stated in DESIGN.md section 7."""
+  import torch
+  from oracle import torch_oracle as O   # the checker
+  from lipreading_amd.ctc import ctc_loss_with_status
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.encoder import VideoEncoder
+  rnn_type, H, bi = MODELS[model_name]
+  pixels = regime == "pixels"
+  torch.manual_seed(123456)
+  frame_dim = 96 * (IMG // 16) ** 2 if pixels else N_LMK * LMK_DIM
+  ref = O.OracleVideoEncoder(frame_dim, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
+                             enable_ctc=True, vocab_size=VOCAB, char2idx=O.default_char2idx()).eval()
+  enc = VideoEncoder(frame_dim, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
+                     enable_ctc=True, vocab_size=VOCAB, char2idx=default_char2idx())
+  enc.load_state_dict(ref.state_dict())
+  frames, frame_lens, chars, char_lens = synth_batch(B, 123456)
+  labels, label_lens = chars[:, 1:], char_lens - 1
+  with torch.no_grad():
+    if pixels:
+      from lipreading_amd.frontend import ConvFrontend3D, PixelLipReader
+      fe = ConvFrontend3D()
+      convs = [p.detach().clone() for p in fe.parameters_in_order()]
+      model = PixelLipReader(enc, fe).to(dev).eval()
+      clips = synth_clips(B, 123456)
+      lp_hip, _, _ = model(clips.to(dev), frame_lens.to(dev), max_len=T_FRAMES)
+      feats = O.conv_frontend(clips, convs, emulate_bf16=True)
+      lp_ref, _, _ = ref(feats.reshape(B, T_FRAMES, -1, 1), frame_lens)
+      tol = PARITY_TOL_PIXELS
+      note = ("same uint8 clips and weights; oracle = F.conv3d/max_pool3d with bf16 rounding at this repo's "
+              "storage points -> reference VideoEncoder (fp32) -> reference ctc_loss; HIP = PixelLipReader "
+              "defaults (%s recurrence, %s input projection)" % (enc.recurrence, enc.input_projection))
+    else:
+      model = enc.to(dev).eval()
+      lp_hip, _, _ = model(frames.to(dev), frame_lens.to(dev), max_len=T_FRAMES)
+      lp_ref, _, _ = ref(frames, frame_lens)
+      tol = PARITY_TOL_LANDMARKS
+      note = "same landmarks and weights; oracle = reference VideoEncoder + ctc_loss on stock torch CPU ops (fp32)"
+    loss_hip, status, _ = ctc_loss_with_status(lp_hip, labels.to(dev), frame_lens.to(dev), label_lens.to(dev), 'mean')
+    loss_ref = O.ctc_loss(lp_ref, labels, frame_lens, label_lens, 'mean')
+    s_hip = GreedyStrings.hip(lp_hip, frame_lens.to(dev))
+    s_ref = GreedyStrings.oracle(lp_ref, frame_lens)
+  lh, lr = float(loss_hip.item()), float(loss_ref.item())
+  return {"regime": regime, "loss_hip": round(lh, 7), "loss_oracle": round(lr, 7), "abs_diff": float("%.3g" % abs(lh - lr)),
+          "tol": tol, "ok": bool(abs(lh - lr) <= tol and int(status.item()) == 0),
+          "max_abs_log_prob_diff": float("%.3g" % float((lp_hip.cpu() - lp_ref).abs().max())),
+          "greedy_strings_equal": s_hip == s_ref, "batch": B, "what": note}
+
+
+class GreedyStrings(object):
+  @staticmethod
+  def hip(lp, lens):
+    from lipreading_amd.data import default_char2idx
+    from lipreading_amd.decoder import GreedyDecoder, ctc_labels
+    return GreedyDecoder(ctc_labels(default_char2idx())).decode(lp, lens)[0]
+
+  @staticmethod
+  def oracle(lp, lens):
+    from oracle import torch_oracle as O
+    return O.greedy_decode(lp, lens, O.ctc_labels())[0]
+
+
+def launch_ranks(n, argv=None, timeout=None):
+  """`python bench.py --gpus N` without a launcher around it: re-execute this script as N ranks, one
+  process per GPU, with the environment torch.distributed.run would set (RANK, LOCAL_RANK,
+  WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT = a free port).  Rank 0's stdout is this process's
+  stdout (the ONE JSON line); the other ranks' stdout goes to stderr.  Returns the worst exit code;
+  if a rank dies the others are terminated (by PID) instead of hanging in a collective."""
+  import socket
+  import subprocess
+  argv = list(sys.argv[1:] if argv is None else argv)
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  procs = []
+  for r in range(n):
+    env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LIPREADING_BENCH_CHILD="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver (RCCL needs it)
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                  stdout=None if r == 0 else sys.stderr))
+  t0 = time.time()
+  rc = 0
+  live = list(procs)
+  while live:
+    for p in list(live):
+      code = p.poll()
+      if code is None:
+        continue
+      live.remove(p)
+      if code != 0:
+        rc = rc or code
+        for q in live:        # a dead rank would leave the others waiting in a collective forever
+          q.terminate()
+    if timeout is not None and time.time() - t0 > timeout:
+      for q in live:
+        q.terminate()
+      rc = rc or 124
+      timeout = None
+    time.sleep(0.05)
+  return rc
+
+
+def probe_main(args):
+  """LIPREADING_BENCH_PROBE=1: the rank plumbing of launch_ranks without a GPU — every rank joins a
+  gloo group from the environment it was given and rank 0 prints what the group saw
+  (tests/test_distributed_cpu.py)."""
+  import torch
+  import torch.distributed as dist
+  world, rank, local = (int(os.environ[k]) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"))
+  dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+  seen = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+  dist.all_gather(seen, torch.tensor([rank, local]))
+  total = torch.tensor([rank + 1.0])
+  dist.all_reduce(total)
+  dist.barrier()
+  dist.destroy_process_group()
+  if rank == 0:
+    print(json.dumps({"probe": True, "n_gpus": args.gpus, "world": world, "ranks": [int(t[0]) for t in seen],
+                      "local_ranks": [int(t[1]) for t in seen], "sum_rank_plus_1": float(total),
+                      "master": "%s:%s" % (os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"])}), flush=True)
 
 
 def run_regime(args, regime, world, rank, dev, recurrence=None):
@@ -313,18 +463,26 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
   L = _C.lib()
   for _ in range(args.warmup):
     loss, status = step()
-  fence()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    loss, status = step()
-  fence()
-  elapsed = time.perf_counter() - t0
+  # the timed region — EXACTLY args.steps steps between two fences — is repeated args.repeats times
+  # back to back; `value` comes from the median repeat, the fastest is reported beside it
+  elapsed_all = []
+  for _ in range(max(1, args.repeats)):
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+      loss, status = step()
+    fence()
+    elapsed_all.append(time.perf_counter() - t0)
 
   # roofline leg (after the timed region, same process, same tensors)
   _C.check(L.lr_profile_enable(1), "lr_profile_enable")
   n_prof = min(args.steps, 20 if not pixels else 5)
   for _ in range(n_prof):
-    fwd_bwd()
+    if sync is not None:
+      with sync.hold():       # no bucket goes out from the hooks: this leg only samples kernel durations
+        fwd_bwd()
+    else:
+      fwd_bwd()
   torch.cuda.synchronize()
   L.lr_profile_enable(0)
   prof = {}
@@ -334,18 +492,55 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
     if n.value:
       prof[name] = (ms.value / n.value * 1e3, n.value / n_prof)   # us per launch, samples per step
 
-  el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+  el = torch.tensor(elapsed_all, dtype=torch.float64, device=dev)
   if DIST_ON:
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
-  elapsed = float(el.item())
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)     # every repeat: the slowest rank's time
+  elapsed_all = sorted(float(v) for v in el.tolist())
+  elapsed = elapsed_all[(len(elapsed_all) - 1) // 2]   # median (lower middle for an even count)
+  elapsed_min = elapsed_all[0]
+
+  # the data-parallel exchange on its own: each bucket's all-reduce timed on the side stream it runs on
+  bucket_us = None
+  if sync is not None:
+    bucket_us = []
+    for lo, hi in sync.bounds:
+      buf = flat.grad[lo:hi]
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      for _ in range(3):
+        dist.all_reduce(buf)
+      fence()
+      e0.record()
+      for _ in range(10):
+        dist.all_reduce(buf)
+      e1.record()
+      torch.cuda.synchronize()
+      bucket_us.append({"bytes": int((hi - lo) * 4), "all_reduce_us": round(e0.elapsed_time(e1) * 100.0, 1)})
+    flat.grad.zero_()
   res = {"regime": regime, "elapsed": elapsed, "loss": float(loss.item()), "skipped": int(status.item()),
-         "layers": layers, "use_graph": use_graph, "graph_note": graph_note}
+         "layers": layers, "use_graph": use_graph, "graph_note": graph_note,
+         "rccl_ranks": dist.get_world_size() if DIST_ON else 1, "all_reduce_buckets": bucket_us}
+  if sync is not None:
+    sync.close()
+  if dec_sync is not None:
+    dec_sync.close()
   if rank != 0:
     return res
 
   frames_per_step = world * B * T_FRAMES
   res["value"] = round(frames_per_step * args.steps / elapsed, 1)
   res["ms_per_step"] = round(elapsed / args.steps * 1e3, 4)
+  res["ms_per_step_min"] = round(elapsed_min / args.steps * 1e3, 4)
+  res["repeats"] = len(elapsed_all)
+  # CTC kernels (HBM-bound by the survey's accounting, latency-bound in fact): 3*T*V'*4 B per sample
+  ctc_us = sum(prof[k][0] for k in ("ctc_alpha_beta", "ctc_grad_rows") if k in prof)
+  if "ctc_alpha_beta" in prof and "ctc_grad_rows" in prof:
+    ctc_bytes = 3 * T_FRAMES * (VOCAB + 1) * 4 * B
+    res["ctc"] = {"kernels": {"ctc_alpha_beta": round(prof["ctc_alpha_beta"][0], 2),
+                              "ctc_grad_rows": round(prof["ctc_grad_rows"][0], 2)},
+                  "unit": "us per launch", "algorithmic_bytes": ctc_bytes,
+                  "achieved_GBps": round(ctc_bytes / (ctc_us * 1e-6) / 1e9, 1),
+                  "frac_of_hbm_peak": round(ctc_bytes / (ctc_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                  "note": "one workgroup per sample: %d workgroups on 256 CUs — latency-bound, ~1%% of the step" % B}
   by_kernel = {k: round(v[0], 3) for k, v in prof.items()}
   if pixels and getattr(enc, "recurrence", "f32") == "bf16" and rnn_type == "GRU" and H == 256:
     # the recurrence slots carry ONE launch per layer pass (all 75 steps), not a step
@@ -363,13 +558,12 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
       us = cand[dom][0]
       ach = flops[dom] / (us * 1e-6) / 1e12
       traffic, traffic_src = None, None
-      try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-          pmc = json.load(f)
+      try:   # HBM bytes per launch from the newest committed PMC passes
+        pmc, pmc_path = pmc_traffic()
         if B == 32:
           traffic = pmc["pixels"][dom]["traffic_bytes"]
-          traffic_src = ("profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
-                         "64-byte gathers: fetch not doubled, see its note)")
+          traffic_src = ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                         "64-byte gathers: fetch not doubled, see its note)" % pmc_path)
       except Exception:
         pass
       roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
@@ -387,13 +581,12 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
       us = cand[dom][0]
       ach = bytes_per_launch / (us * 1e-6) / 1e9
       traffic, traffic_src = None, None
-      try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-          pmc = json.load(f)
+      try:   # HBM bytes per launch from the newest committed PMC passes
+        pmc, pmc_path = pmc_traffic()
         if B == 32 and layers == 1:
           traffic = pmc[args.model][dom]["traffic_bytes"]
-          traffic_src = ("profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                         "passes, gfx950 x2 fetch correction)")
+          traffic_src = ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch "
+                         "correction)" % pmc_path)
       except Exception:
         pass
       roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
@@ -447,9 +640,18 @@ def main():
   ap.add_argument("--layers", type=int, default=None, help="recurrent layers (default 1; 2 for pixels)")
   ap.add_argument("--no-graph", action="store_true",
                   help="launch every kernel eagerly instead of replaying a captured hipGraph")
+  ap.add_argument("--repeats", type=int, default=5,
+                  help="how many times the timed region of exactly --steps steps is repeated (median reported)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--cpu-budget", type=float, default=20.0)
+  ap.add_argument("--cpu-budget", type=float, default=12.0,
+                  help="seconds of timed CPU-oracle steps per regime (never fewer than 10 steps)")
   args = ap.parse_args()
+
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # started as plain `python bench.py --gpus N`: become the launcher of N ranks (one per GPU)
+    sys.exit(launch_ranks(args.gpus))
+  if os.environ.get("LIPREADING_BENCH_PROBE") == "1":
+    return probe_main(args)
 
   import torch
   import torch.distributed as dist
@@ -457,9 +659,9 @@ def main():
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-  if args.gpus > 1 and world != args.gpus:
-    sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-             % (args.gpus, args.gpus))
+  if world != args.gpus and not (args.gpus == 1 and world == 1):
+    sys.exit("bench.py --gpus %d was started inside a %d-rank group (WORLD_SIZE); the two must agree"
+             % (args.gpus, world))
   assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the product path)"
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
@@ -496,12 +698,18 @@ def main():
                                    ("eager launches; gradient all-reduce overlapped with backward on a side stream"
                                     if DIST_ON else "eager"))},
         "final_loss": round(head["loss"], 6), "skipped_last": head["skipped"],
-        "roofline": head["roofline"],
+        "timing": {"repeats": head["repeats"], "ms_per_step_median": head["ms_per_step"],
+                   "ms_per_step_min": head["ms_per_step_min"],
+                   "note": "the timed region of exactly `steps` steps is repeated back to back; value is the median repeat"},
+        "rccl_ranks": head["rccl_ranks"], "all_reduce_buckets": head["all_reduce_buckets"],
+        "roofline": head["roofline"], "ctc": head.get("ctc"),
     }
     if len(results) > 1:
       out["regimes"] = {r["regime"]: {"value": r["value"], "unit": "frames/s", "ms_per_step": r["ms_per_step"],
+                                      "ms_per_step_min": r["ms_per_step_min"],
                                       "workload": r["workload"], "final_loss": round(r["loss"], 6),
-                                      "roofline": r["roofline"]} for r in results[1:]}
+                                      "all_reduce_buckets": r["all_reduce_buckets"],
+                                      "roofline": r["roofline"], "ctc": r.get("ctc")} for r in results[1:]}
       if option is not None and "landmarks" in out["regimes"]:
         base = out["regimes"]["landmarks"]
         out["regimes"]["landmarks"]["option_bf16_recurrence"] = {
@@ -511,7 +719,20 @@ def main():
             "final_loss": round(option["loss"], 6),
             "final_loss_delta_vs_fp32": round(option["loss"] - results[order.index("landmarks")]["loss"], 7)}
     if world == 1 and not args.no_cpu_baseline:
+      # parity first (the metric's "+ CTC-loss parity"): HIP vs oracle on identical inputs and weights
+      by_regime = {r["regime"]: r for r in results}
+      par = {}
+      for rg in ("pixels", "landmarks"):
+        if rg in by_regime:
+          par[rg] = parity_block(rg, args.model, by_regime[rg]["layers"], args.batch, dev)
+      out["parity"] = par.get(head["regime"])
+      for rg, blk in par.items():
+        if rg != head["regime"] and "regimes" in out and rg in out["regimes"]:
+          out["regimes"][rg]["parity"] = blk
       out["cpu_baseline"] = cpu_baseline(head["regime"], args.model, head["layers"], args.batch, args.cpu_budget)
+      if "regimes" in out and "landmarks" in out["regimes"] and head["regime"] != "landmarks":
+        out["regimes"]["landmarks"]["cpu_baseline"] = cpu_baseline(
+            "landmarks", args.model, by_regime["landmarks"]["layers"], args.batch, args.cpu_budget)
   if DIST_ON:
     dist.destroy_process_group()
   # the JSON line is the LAST thing on stdout: RCCL's version banner sits in the C stdio buffer until

@@ -193,7 +193,8 @@ int lr_rnn_layer_backward_parts(int mode, const float* x, const int32_t* lens,
  * events, returns the summed elapsed milliseconds and the number of samples in HOST memory, and
  * clears the ring (1024 samples per slot; later samples are dropped).  Slots: 0/1 recurrent
  * forward/backward step kernel; 2,3,4 conv1..3 forward; 5,6 conv2/conv3 data gradient; 7,8,9
- * conv1..3 weight gradient. */
+ * conv1..3 weight gradient; 10 CTC alpha/beta kernel (lr_ctc_nll); 11 CTC gradient rows kernel
+ * (lr_ctc_grad). */
 int lr_profile_enable(int on);
 int lr_profile_read(int which, float* total_ms_host, int* samples_host);
 

@@ -143,7 +143,6 @@ class CharDecodingStep(nn.Module):
     self.concat_layer = nn.Linear(2 * self.hidden_size, self.hidden_size)
     self.output_proj = nn.Linear(self.hidden_size, self.vocab_size)
     self.best_error = 1
-    self._seed = 0
 
   def _params(self):
     at = self.attention_type
@@ -179,8 +178,9 @@ class CharDecodingStep(nn.Module):
     if teacher_forced is None:
       teacher_forced = [True] * L
     if seed is None:
-      self._seed += 1
-      seed = self._seed
+      # drawn from torch's (host) generator, so --seed / torch.manual_seed control the multinomial
+      # draws of the loop as they do in the reference (train_better_model.py:63); no device sync
+      seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     lp, sampled, h_n, c_n = _AttnDecoderFunction.apply(
         tokens.to(torch.int32).contiguous(), tuple(bool(t) for t in teacher_forced), int(seed), mode,
         _ATT_CODE[self.attention_type], self.attn_hidden_size, enc,

@@ -82,9 +82,21 @@ enum {
   LR_PROF_CONV1_FWD = 2, LR_PROF_CONV2_FWD = 3, LR_PROF_CONV3_FWD = 4,
   LR_PROF_CONV2_DGRAD = 5, LR_PROF_CONV3_DGRAD = 6,
   LR_PROF_CONV1_WGRAD = 7, LR_PROF_CONV2_WGRAD = 8, LR_PROF_CONV3_WGRAD = 9,
-  LR_PROF_SLOTS = 10
+  LR_PROF_CTC_ALPHA_BETA = 10, LR_PROF_CTC_GRAD = 11,
+  LR_PROF_SLOTS = 12
 };
 bool lr_prof_next(int slot, hipEvent_t* start, hipEvent_t* stop);
+// LR_LAUNCH that becomes a sampled (event-stamped) launch of `slot` while profiling is enabled;
+// needs <hip/hip_ext.h> in the including file
+#define LR_LAUNCH_PROF(slot, kernel, grid, block, lds, stream, ...)                                       \
+  do {                                                                                                    \
+    hipEvent_t lr_e0_, lr_e1_;                                                                            \
+    lr_clear_error();                                                                                     \
+    if (lr_prof_next(slot, &lr_e0_, &lr_e1_))                                                             \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)(stream), lr_e0_, lr_e1_, 0, __VA_ARGS__); \
+    else                                                                                                  \
+      hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)(stream), __VA_ARGS__);                   \
+  } while (0)
 
 // ---- recurrent layer pieces shared with lr_decoder.hip (implemented in lr_rnn.hip) --------------------
 size_t lr_rnn_packed_w_floats(int G, int H);

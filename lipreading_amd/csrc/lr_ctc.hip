@@ -14,6 +14,7 @@
 // independent once alpha and beta are known, so they run one wave per (sample, frame) across the
 // whole chip with lanes along the class axis (coalesced stores of the (T x C) gradient).
 #include "lr_common.h"
+#include <hip/hip_ext.h>
 
 namespace {
 
@@ -562,14 +563,14 @@ extern "C" int lr_ctc_nll(const float* log_probs, int64_t stride_b, int64_t stri
   const size_t lat = (size_t)T * C * sizeof(float);
   if (sst == 64 && max_label_len <= 31 && 32 * sizeof(int) + lat + 16 <= 60 * 1024) {
     // every state fits one wave: shuffle recursion, no per-step barrier
-    LR_LAUNCH(ctc_alpha_beta_wave_kernel, dim3(B), dim3(128), 32 * sizeof(int) + lat + 16, stream, log_probs, stride_b,
+    LR_LAUNCH_PROF(LR_PROF_CTC_ALPHA_BETA, ctc_alpha_beta_wave_kernel, dim3(B), dim3(128), 32 * sizeof(int) + lat + 16, stream, log_probs, stride_b,
               stride_t, labels, label_stride, frame_lens, label_lens, nll, ws, T, C, max_label_len);
   } else if (base + lat <= 60 * 1024) {
-    LR_LAUNCH(ctc_alpha_beta_kernel<true>, dim3(B), dim3(nthr), base + lat, stream, log_probs,
+    LR_LAUNCH_PROF(LR_PROF_CTC_ALPHA_BETA, ctc_alpha_beta_kernel<true>, dim3(B), dim3(nthr), base + lat, stream, log_probs,
               stride_b, stride_t, labels, label_stride, frame_lens, label_lens, nll, ws, T, C, sst,
               max_label_len, concurrent);
   } else {
-    LR_LAUNCH(ctc_alpha_beta_kernel<false>, dim3(B), dim3(nthr), base, stream, log_probs, stride_b,
+    LR_LAUNCH_PROF(LR_PROF_CTC_ALPHA_BETA, ctc_alpha_beta_kernel<false>, dim3(B), dim3(nthr), base, stream, log_probs, stride_b,
               stride_t, labels, label_stride, frame_lens, label_lens, nll, ws, T, C, sst,
               max_label_len, concurrent);
   }
@@ -587,7 +588,7 @@ extern "C" int lr_ctc_grad(const float* log_probs, int64_t stride_b, int64_t str
   if (workspace_bytes < lr_ctc_workspace_bytes(B, T, C, max_label_len)) return LR_ERR_WORKSPACE;
   const int sst = ctc_state_stride(max_label_len);
   const CtcWs ws = ctc_ws_carve(workspace, B, T, C, max_label_len);
-  LR_LAUNCH(ctc_grad_rows_kernel, dim3((T + 3) / 4, B), dim3(256), 0, stream, log_probs, stride_b,
+  LR_LAUNCH_PROF(LR_PROF_CTC_GRAD, ctc_grad_rows_kernel, dim3((T + 3) / 4, B), dim3(256), 0, stream, log_probs, stride_b,
             stride_t, frame_lens, label_lens, nll, grad_weight, grad, ws, T, C, sst, max_label_len);
   return lr_launch_status();
 }

@@ -54,7 +54,7 @@ def pad_frames(seqs, device):
 def make_collate_fn(device):
   """Returns a `_collate_fn(batch)` with the reference's contract (data_loader.py:117-152):
   batch = [(frames (len,68,3), caption (n,))] -> (frames f32 (B,Tmax,68,3), frame_lens i64,
-  chars i64 (B,Cmax) PAD=0, char_lens i64); frames/chars live on `device`, lens on the host."""
+  chars i64 (B,Cmax) PAD=0, char_lens i64); frames live on `device`, chars and both lens on the host."""
   def _collate_fn(batch):
     assert all(len(x) == 2 for x in batch)
     frames, captions = zip(*batch)
@@ -64,5 +64,7 @@ def make_collate_fn(device):
     tgt = torch.zeros((len(caps), int(tgt_lens.max())), dtype=torch.long)
     for i, c in enumerate(caps):
       tgt[i, :len(c)] = torch.from_numpy(c)
-    return src, src_lens, tgt.to(device, non_blocking=True), tgt_lens
+    # chars stay on the host like the lengths (the reference's collate returns host tensors and train()
+    # uploads them): the framing asserts of train_better_model.py:26-33 then need no device read
+    return src, src_lens, tgt, tgt_lens
   return _collate_fn

@@ -172,12 +172,23 @@ def iterate_batches(dataset, batch_size, collate_fn):
     yield collate_fn([dataset[i] for i in range(lo, min(lo + batch_size, len(dataset)))])
 
 
-class BatchList(list):
-  """A materialised epoch (len() = number of batches, as len(data_loader) in the reference)."""
+class BatchLoader(object):
+  """`DataLoader(dataset, batch_size, collate_fn=..., shuffle=False)` (src/scripts/train.py:209-211):
+  len() = number of batches; every iteration collates its batches afresh, so only the batch in
+  flight lives on the device (not the whole train/val/test set for the life of the run)."""
+
+  def __init__(self, dataset, batch_size, collate_fn):
+    self.dataset, self.batch_size, self.collate_fn = dataset, batch_size, collate_fn
+
+  def __len__(self):
+    return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+  def __iter__(self):
+    return iterate_batches(self.dataset, self.batch_size, self.collate_fn)
 
 
 def make_loader(dataset, batch_size, collate_fn):
-  return BatchList(iterate_batches(dataset, batch_size, collate_fn))
+  return BatchLoader(dataset, batch_size, collate_fn)
 
 
 _WORDS = ("the quick brown fox jumps over a lazy dog and then it went home to see what was going on "

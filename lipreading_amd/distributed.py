@@ -58,6 +58,9 @@ class GradSync(object):
     self._launched = [False] * len(groups)
     self.side = torch.cuda.Stream() if self.overlap else None
     self._hooks = []
+    self._direct_hook = None
+    self._held = 0
+    self._closed = False
     if self.overlap:
       for pi, p in enumerate(params):
         self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(pi)))
@@ -89,11 +92,49 @@ class GradSync(object):
 
   def _make_hook(self, pi):
     def hook(_param):
+      if self._held or self._closed:
+        return
       gi = self._owner[pi]
+      if self._launched[gi]:
+        # the bucket already holds the SUM over ranks: a gradient accumulated into it now would never
+        # be exchanged and the ranks would silently diverge
+        raise RuntimeError(
+            "GradSync: a gradient of bucket %d arrived after the bucket was all-reduced (a second "
+            "backward before sync()); run the extra backward passes under `with sync.hold():` so the "
+            "buckets go out when sync() is called, or call sync() between them" % gi)
       self._pending[gi] -= 1
       if self._pending[gi] == 0:
         self._launch(gi)
     return hook
+
+  def hold(self):
+    """Context manager: gradients that become ready inside it launch nothing; every bucket is
+    exchanged by the next sync() call instead.  For steps that run more than one backward before
+    the optimiser (the reference's decoder_loss.backward(retain_graph) followed by
+    ctc_loss.backward(), train_better_model.py:69,74)."""
+    sync = self
+
+    class _Hold(object):
+      def __enter__(self):
+        sync._held += 1
+
+      def __exit__(self, *exc):
+        sync._held -= 1
+        return False
+    return _Hold()
+
+  def close(self):
+    """Remove the parameter hooks and the entry in encoder.grad_ready_hooks (which otherwise keep
+    this object, its flat buffer and the model alive for the life of the process)."""
+    for h in self._hooks:
+      h.remove()
+    self._hooks = []
+    if self._direct_hook is not None:
+      from . import encoder as _encoder
+      if self._direct_hook in _encoder.grad_ready_hooks:
+        _encoder.grad_ready_hooks.remove(self._direct_hook)
+      self._direct_hook = None
+    self._closed = True
 
   def _launch(self, gi):
     if self._launched[gi]:

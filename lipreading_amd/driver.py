@@ -50,10 +50,24 @@ def _coerce(name, text, like):
   return text
 
 
+# Flags of the reference's config/ files that are not parameters of the live train() (train.py:134-167):
+#  - `--teacher_forcing_ratio` (config/train/attn/*, config/archive/experiments/ecd/*) predates the
+#    max_tfr/min_tfr schedule; it maps to max_tfr.
+#  - the archived trainer's set (archive/train_model.py:186-205; config/train/micro and
+#    config/train/test_train_nano — BASELINE configs[0]/[1] — are written in it): the ones with a live
+#    counterpart are renamed, the rest (SGD momentum, checkpointing, tensorboard) have no meaning on
+#    this path and are accepted with a warning.  That trainer is CTC-only, so its files switch enable_ctc on.
+RENAMED = {"teacher_forcing_ratio": "max_tfr", "dataset": "data", "batch": "batch_size", "epochs": "max_epochs",
+           "hidden_layers": "num_layers", "max_norm": "grad_norm"}
+IGNORED = {"momentum", "anneal", "annealing", "checkpoint", "tensorboard", "continue_from", "silent"}
+ARCHIVED_ONLY = {"dataset", "batch", "epochs", "hidden_layers", "max_norm"} | IGNORED
+
+
 def parse_flags(argv, defaults=DEFAULTS):
   """Positional arguments are flag files (one or several `--name=value` tokens per line, as under
   the reference's config/); later `--name=value` arguments override them.  Unknown flags are an
-  error, as in the reference's argument parser."""
+  error, as in the reference's argument parser; deprecated / archived ones (RENAMED, IGNORED) are
+  accepted with a warning."""
   tokens = []
   for a in argv:
     if a.startswith("--"):
@@ -62,11 +76,23 @@ def parse_flags(argv, defaults=DEFAULTS):
       with open(a) as f:
         tokens += [t for t in f.read().replace("\n", " ").split(" ") if t.startswith("--")]
   out = dict(defaults)
+  archived = False
   for t in tokens:
     name, _, text = t[2:].partition("=")
+    archived = archived or name in ARCHIVED_ONLY
+    if name in IGNORED:
+      print("warning: --%s has no meaning on this path; ignored" % name, file=sys.stderr)
+      continue
+    if name in RENAMED:
+      print("warning: --%s is read as --%s" % (name, RENAMED[name]), file=sys.stderr)
+      name = RENAMED[name]
     if name not in out:
       raise SystemExit("unknown flag --%s" % name)
     out[name] = _coerce(name, text, defaults[name])
+  if isinstance(out.get("rnn_type"), str):
+    out["rnn_type"] = out["rnn_type"].upper()          # the archived files write `gru`
+  if archived:
+    out["enable_ctc"] = True
   return out
 
 

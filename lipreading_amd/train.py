@@ -19,8 +19,12 @@ from .optim import FusedAdam
 
 
 def _check_framing(chars, char_lens, frame_lens, char2idx, use_ctc):
-  """train_better_model.py:26-33, on host tensors."""
-  chars, char_lens, frame_lens = chars.cpu(), char_lens.cpu(), frame_lens.cpu()
+  """train_better_model.py:26-33.  The loader hands chars / lengths over on the HOST (data.py's
+  collate, as the reference's does), so the asserts cost no device round trip; a caller that passes
+  device tensors pays one copy here.  The ascending-length requirement is ctc_loss.py:39's, so it is
+  only checked when the CTC loss will run."""
+  if chars.is_cuda or char_lens.is_cuda or frame_lens.is_cuda:
+    chars, char_lens, frame_lens = chars.cpu(), char_lens.cpu(), frame_lens.cpu()
   assert (chars[:, 0].squeeze() == char2idx[BOS]).all()
   assert (chars.gather(1, (char_lens - 1).unsqueeze(dim=1)).squeeze() == char2idx[EOS]).all()
   if use_ctc:
@@ -28,7 +32,8 @@ def _check_framing(chars, char_lens, frame_lens, char2idx, use_ctc):
   labels = chars[:, 1:]
   label_lens = char_lens - 1
   assert (labels != char2idx[PAD]).sum() == label_lens.sum()
-  assert (frame_lens[1:] - frame_lens[:-1] >= 0).all()  # ctc_loss.py:39
+  if use_ctc:
+    assert (frame_lens[1:] - frame_lens[:-1] >= 0).all()  # ctc_loss.py:39
 
 
 def ctc_step(encoder, opt, frames, frame_lens, chars, char_lens, grad_norm=None, max_len=None,
@@ -100,8 +105,8 @@ def train(encoder, decoding_step, data_loader, opt, device, char2idx,
     _check_framing(chars, char_lens, frame_lens, char2idx, use_ctc)
     max_len = int(frame_lens.max()) if not frame_lens.is_cuda else None
     label_lens_host = (char_lens - 1).cpu()
-    frames, chars = frames.to(device), chars.to(device)
-    frame_lens_d, char_lens_d = frame_lens.to(device), char_lens.to(device)
+    frames, chars = frames.to(device, non_blocking=True), chars.to(device, non_blocking=True)
+    frame_lens_d, char_lens_d = frame_lens.to(device, non_blocking=True), char_lens.to(device, non_blocking=True)
     if decoding_step is None:
       loss, _ = ctc_step(encoder, opt, frames, frame_lens_d, chars, char_lens_d, grad_norm=grad_norm,
                          max_len=max_len, grad_sync=grad_sync)
@@ -158,7 +163,7 @@ def eval(encoder, decoding_step, data_loader, device, char2idx):
   count = torch.zeros((), dtype=torch.float32, device=device)
   with torch.no_grad():
     for frames, frame_lens, chars, char_lens in data_loader:
-      _check_framing(chars, char_lens, frame_lens, char2idx, False)
+      _check_framing(chars, char_lens, frame_lens, char2idx, use_ctc)
       max_len = int(frame_lens.max()) if not frame_lens.is_cuda else None
       label_lens_host = (char_lens - 1).cpu()
       frames, chars = frames.to(device), chars.to(device)

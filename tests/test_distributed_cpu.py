@@ -49,6 +49,20 @@ def _worker(rank, world, port, out_dir):
       model(x[lo:hi]).pow(2).sum().backward()
       scale = sync(status)
     assert scale == 0.5
+    # hook logic (registered on the GPU path only): a gradient for an already-exchanged bucket is an
+    # error, unless the step runs under hold()
+    hook = sync._make_hook(0)
+    sync._launched[0] = True
+    try:
+      hook(None)
+      raise AssertionError("second backward into an exchanged bucket must raise")
+    except RuntimeError as e:
+      assert "second backward" in str(e)
+    with sync.hold():
+      hook(None)
+    sync._launched[0] = False
+    sync.close()
+    hook(None)          # closed: inert
     np.save(os.path.join(out_dir, "grad_%d.npy" % rank), flat.grad.numpy())
     np.save(os.path.join(out_dir, "data_%d.npy" % rank), flat.data.detach().numpy())
     np.save(os.path.join(out_dir, "status_%d.npy" % rank), status.numpy())
@@ -87,3 +101,39 @@ def test_flat_parameters_views_and_alignment():
   assert float(flat.grad.abs().sum()) == 0
   model(torch.ones(2, 12)).sum().backward()     # accumulates in place into the flat buffer
   assert float(flat.grad.abs().sum()) > 0
+
+
+def test_bench_launches_its_own_ranks():
+  """`python bench.py --gpus 2` (no torch.distributed.run around it) re-executes itself as 2 ranks with
+  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; LIPREADING_BENCH_PROBE=1 swaps the GPU work for a gloo
+  group that reports what it saw, so the plumbing is checked without a GPU.  Rank 0 prints the one
+  JSON line."""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = {k: v for k, v in os.environ.items()
+         if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+  env["LIPREADING_BENCH_PROBE"] = "1"
+  res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+  assert res.returncode == 0, res.stderr[-2000:]
+  lines = [l for l in res.stdout.splitlines() if l.strip()]
+  js = [l for l in lines if l.startswith("{")]   # (gloo prints a connection banner of its own)
+  assert len(js) == 1 and lines[-1] == js[0], res.stdout      # ONE JSON line, the last, from rank 0 only
+  out = json.loads(js[0])
+  assert out["probe"] and out["world"] == 2 and out["n_gpus"] == 2
+  assert out["ranks"] == [0, 1] and out["local_ranks"] == [0, 1]
+  assert out["sum_rank_plus_1"] == 3.0 and out["master"].startswith("127.0.0.1:")
+
+
+def test_bench_launcher_reports_a_dead_rank():
+  """A rank that exits non-zero takes the launch down with it (the others are terminated, not left
+  waiting in a collective): a mismatch between --gpus and WORLD_SIZE is one such exit."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0", LIPREADING_BENCH_PROBE="0")
+  res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
+                       capture_output=True, text=True, timeout=300)
+  assert res.returncode != 0 and "must agree" in res.stderr

@@ -77,10 +77,10 @@ def test_overlapped_gradient_exchange_matches_plain_step(dev, pg, pixels):
     torch.cuda.synchronize()
     results.append(flat.data.detach().cpu().numpy().copy())
     if sync is not None:
-      for h in sync._hooks:
-        h.remove()
       from lipreading_amd import encoder as _enc
-      _enc.grad_ready_hooks.remove(sync._direct_hook)
+      n_hooks = len(_enc.grad_ready_hooks)
+      sync.close()
+      assert len(_enc.grad_ready_hooks) == n_hooks - 1 and not sync._hooks
   np.testing.assert_allclose(results[1], results[0], rtol=1e-6, atol=1e-7)
 
 
@@ -127,12 +127,61 @@ def test_train_loop_with_decoder_and_gradient_exchange(dev, pg):
     torch.cuda.synchronize()
     results.append((dl, cl_, fe.data.detach().cpu().numpy().copy(), fd.data.detach().cpu().numpy().copy()))
     if syncs is not None:
-      from lipreading_amd import encoder as _enc
       for s in syncs:
-        for h in s._hooks:
-          h.remove()
-        if getattr(s, "_direct_hook", None) in _enc.grad_ready_hooks:
-          _enc.grad_ready_hooks.remove(s._direct_hook)
+        s.close()
   assert abs(results[0][0] - results[1][0]) < 1e-6 and abs(results[0][1] - results[1][1]) < 1e-6
   np.testing.assert_allclose(results[1][2], results[0][2], rtol=1e-6, atol=1e-7)
   np.testing.assert_allclose(results[1][3], results[0][3], rtol=1e-6, atol=1e-7)
+
+
+def test_second_backward_before_sync_is_loud_or_held(dev, pg):
+  """The reference runs decoder_loss.backward(retain_graph) and then ctc_loss.backward()
+  (train_better_model.py:69,74).  With overlapped buckets the second backward would add to a bucket
+  that was already all-reduced: GradSync raises instead of letting ranks diverge, and under
+  `with sync.hold():` both backward passes accumulate first and the buckets go out at sync()."""
+  from lipreading_amd.ctc import ctc_loss_with_status
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.distributed import GradSync
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.optim import FlatParameters
+  torch.manual_seed(21)
+  enc = VideoEncoder(204, 16, rnn_type='GRU', bidirectional=True, enable_ctc=True, vocab_size=64,
+                     char2idx=default_char2idx()).to(dev).train()
+  flat = FlatParameters(enc)
+  g = torch.Generator().manual_seed(22)
+  B, T = 4, 10
+  x = torch.randn(B, T, 68, 3, generator=g).to(dev)
+  lens = torch.full((B,), T, device=dev)
+  labels = torch.randint(4, 64, (B, 3), generator=g).to(dev)
+  ll = torch.full((B,), 3, device=dev)
+
+  def losses():
+    lp, hid, _ = enc(x, lens, max_len=T)
+    loss, status, _ = ctc_loss_with_status(lp, labels, lens, ll, 'mean')
+    return hid.pow(2).mean(), loss, status
+
+  flat.zero_grad()
+  a, b, _ = losses()
+  (a + b).backward()
+  want = flat.grad.clone()
+
+  sync = GradSync(flat, groups=GradSync.groups_for_encoder(enc, flat), overlap=True)
+  try:
+    flat.zero_grad()
+    a, b, status = losses()
+    with sync.hold():
+      a.backward(retain_graph=True)
+      b.backward()
+      assert not any(sync._launched)
+    assert sync(status) == 1.0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(flat.grad.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=1e-7)
+    # without hold(): loud
+    flat.zero_grad()
+    a, b, status = losses()
+    a.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+      b.backward()
+    sync(status)
+  finally:
+    sync.close()

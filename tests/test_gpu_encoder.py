@@ -300,3 +300,35 @@ def test_persistent_bf16_recurrence_tracks_the_step_kernels(dev, B, T, lens):
     assert float((a - b).norm()) / max(1e-6, float(a.norm())) < 2e-2
   # padded positions are exactly zero in both
   assert float((res["bf16"][1] * (1 - valid.cpu())).abs().max()) == 0.0
+
+
+def test_bf16_recurrence_against_the_oracle_at_the_bench_shape(dev):
+  """VideoEncoder.recurrence = 'bf16' (the pixel regime's default) compared with the ORACLE — the
+  reference's fp32 nn.GRU path — not with this repo's step kernels: landmarks (B=32,T=75), BiGRU-256,
+  ragged lengths.  Stated tolerances: CTC 'mean' loss within 1e-4 absolute (north_star), log-probs
+  within 2e-3 absolute on valid frames (bf16 recurrent operands: 2^-9 relative per product term)."""
+  from lipreading_amd.ctc import ctc_loss_with_status
+  ref, enc = make_pair("GRU", 256, 1, True, dev)
+  enc.recurrence = 'bf16'
+  g = torch.Generator().manual_seed(5)
+  B, T = 32, 75
+  lens = torch.sort(torch.randint(40, T + 1, (B,), generator=g))[0]
+  lens[-8:] = T
+  frames = torch.randn(B, T, 68, 3, generator=g)
+  for b in range(B):
+    frames[b, int(lens[b]):] = 0
+  labels = torch.randint(4, 64, (B, 30), generator=g)
+  ll = torch.full((B,), 30)
+  with torch.no_grad():
+    lp_r, hid_r, _ = ref(frames, lens)
+    lp_h, hid_h, _ = enc(frames.to(dev), lens.to(dev), max_len=T)
+    loss_r = O.ctc_loss(lp_r, labels, lens, ll, 'mean')
+    loss_h, status, _ = ctc_loss_with_status(lp_h, labels.to(dev), lens.to(dev), ll.to(dev), 'mean')
+  assert int(status) == 0
+  from lipreading_amd import _C
+  assert _C.lib().lr_rnn_persistent_supported(0, B, T, 204, 256, 2) == 1     # the one-launch path really ran
+  valid = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(-1)
+  d_lp = float(((lp_h.cpu() - lp_r) * valid).abs().max())
+  d_loss = abs(float(loss_h) - float(loss_r))
+  print("bf16 recurrence vs oracle: loss %.7f vs %.7f (|d| %.3g), max |d log-prob| %.3g" % (float(loss_h), float(loss_r), d_loss, d_lp))
+  assert d_loss <= 1e-4 and d_lp <= 2e-3

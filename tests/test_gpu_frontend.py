@@ -281,3 +281,104 @@ def test_patch_resident_layer2_matches_implicit_gemm_and_oracle(dev):
   assert rel_err(res[True][0], ref.detach().numpy()) < 2e-2
   for a, q in zip(res[True][1:], params_cpu):
     assert rel_err(a, q.grad.numpy()) < 4e-2, tuple(q.shape)
+
+
+# ---- headline regime (BASELINE configs[1]) against the ORACLE, not against this repo's other paths ----
+# Stated tolerances: |loss_hip - loss_oracle| <= 1e-3 absolute on the 'mean' CTC loss
+# (bench.PARITY_TOL_PIXELS); encoder/CTC-head gradients within 3e-2 of the oracle's norm per tensor, conv
+# gradients within 6e-2 (bf16 activations: a rounding flip moves an activation by 2^-8 relative).
+PIXEL_LOSS_TOL = 1e-3
+
+
+@pytest.mark.parametrize("B,lens", [(8, None), (8, [40, 52, 52, 60, 75, 75, 75, 75])])
+def test_pixel_regime_defaults_match_the_oracle(dev, B, lens):
+  """Same uint8 clips and the same weights through (a) PixelLipReader with its DEFAULTS (bf16 conv
+  stack, bf16 features handed over as stored, split-bf16 input projection, one-launch recurrence with
+  bf16 recurrent operands) -> HIP ctc_loss, and (b) oracle.conv_frontend(emulate_bf16=True) ->
+  OracleVideoEncoder (the reference's fp32 nn.GRU path) -> oracle.ctc_loss, at the metric's shape family
+  (T = 75, 96x96, 2 x BiGRU-256).  The loss and every gradient are compared."""
+  from lipreading_amd.ctc import ctc_loss_with_status
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.frontend import ConvFrontend3D, PixelLipReader, feature_dim
+  T, H = 75, 96
+  torch.manual_seed(31)
+  ref = O.OracleVideoEncoder(feature_dim(H, H), 256, rnn_type='GRU', num_layers=2, bidirectional=True,
+                             enable_ctc=True, vocab_size=64, char2idx=O.default_char2idx()).train()
+  enc = VideoEncoder(feature_dim(H, H), 256, rnn_type='GRU', num_layers=2, bidirectional=True, enable_ctc=True,
+                     vocab_size=64, char2idx=default_char2idx())
+  enc.load_state_dict(ref.state_dict())
+  fe = ConvFrontend3D()
+  convs = [p.detach().clone().requires_grad_(True) for p in fe.parameters_in_order()]
+  model = PixelLipReader(enc, fe).to(dev).train()
+  assert enc.recurrence == 'bf16' and enc.input_projection == 'bf16x3'
+  g = torch.Generator().manual_seed(32)
+  clips = torch.randint(0, 256, (B, T, 3, H, H), generator=g, dtype=torch.uint8)
+  lens = torch.tensor(lens) if lens is not None else torch.full((B,), T)
+  labels = torch.randint(4, 64, (B, 12), generator=g)
+  ll = torch.full((B,), 12)
+  # oracle
+  feats = O.conv_frontend(clips, convs, emulate_bf16=True)
+  lp_r, _, _ = ref(feats.reshape(B, T, -1, 1), lens)
+  loss_r = O.ctc_loss(lp_r, labels, lens, ll, 'mean')
+  loss_r.backward()
+  # HIP
+  lp_h, _, _ = model(clips.to(dev), lens.to(dev), max_len=T)
+  loss_h, status, _ = ctc_loss_with_status(lp_h, labels.to(dev), lens.to(dev), ll.to(dev), 'mean')
+  assert int(status) == 0
+  loss_h.backward()
+  from lipreading_amd import encoder as E
+  E.flush_deferred()
+  torch.cuda.synchronize()
+  d_loss = abs(float(loss_h) - float(loss_r))
+  valid = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(-1)
+  d_lp = float(((lp_h.detach().cpu() - lp_r.detach()) * valid).abs().max())
+  print("pixel parity: loss hip %.7f oracle %.7f |d| %.3g; max |d log-prob| %.3g" % (float(loss_h), float(loss_r), d_loss, d_lp))
+  assert d_loss <= PIXEL_LOSS_TOL, (float(loss_h), float(loss_r))
+  assert d_lp <= 2e-2
+  ref_grads = dict(ref.named_parameters())
+  worst = {}
+  for k, p in enc.named_parameters():
+    a, b = p.grad.cpu(), ref_grads[k].grad
+    worst[k] = float((a - b).norm()) / max(1e-8, float(b.norm()))
+    assert worst[k] <= 3e-2, (k, worst[k])
+  for i, (p, q) in enumerate(zip(fe.parameters_in_order(), convs)):
+    r = float((p.grad.cpu() - q.grad).norm()) / max(1e-8, float(q.grad.norm()))
+    worst["conv[%d]" % i] = r
+    assert r <= 6e-2, (i, r)
+  print("pixel parity: worst relative gradient differences", {k: float("%.2g" % v) for k, v in worst.items()})
+
+
+@pytest.mark.parametrize("B", [8, 32, 64])
+def test_pixel_step_at_the_sharded_batch_shapes(dev, B):
+  """BASELINE configs[3] is (B=64,T=75,3,96,96) over 8 GPUs: 8 clips per rank (strong) or 32 per rank
+  (weak, the bench's choice); a single GPU must also take the whole B=64.  One full optimisation step
+  of PixelLipReader at each of those per-rank batches: finite loss, no skipped batch, weights move."""
+  from lipreading_amd.ctc import ctc_loss_with_status
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.frontend import ConvFrontend3D, PixelLipReader, feature_dim
+  from lipreading_amd.optim import FlatParameters, FusedAdam
+  torch.manual_seed(41)
+  enc = VideoEncoder(feature_dim(96, 96), 256, rnn_type='GRU', num_layers=2, bidirectional=True, enable_ctc=True,
+                     vocab_size=64, char2idx=default_char2idx())
+  model = PixelLipReader(enc, ConvFrontend3D()).to(dev).train()
+  flat = FlatParameters(model)
+  opt = FusedAdam(flat, lr=1e-4)
+  g = torch.Generator().manual_seed(42)
+  clips = torch.randint(0, 256, (B, 75, 3, 96, 96), generator=g, dtype=torch.uint8).to(dev)
+  lens = torch.full((B,), 75, device=dev)
+  labels = torch.randint(4, 64, (B, 31), generator=g).to(dev)
+  ll = torch.full((B,), 31, device=dev)
+  before = flat.data.clone()
+  losses = []
+  for _ in range(2):
+    opt.zero_grad()
+    lp, _, _ = model(clips, lens, max_len=75)
+    loss, status, _ = ctc_loss_with_status(lp, labels, lens, ll, 'mean')
+    loss.backward()
+    opt.step(grad_norm=50, skip=status)
+    assert int(status) == 0
+    losses.append(float(loss))
+  assert np.isfinite(losses).all() and losses[1] < losses[0], losses
+  assert float((flat.data - before).abs().max()) > 0
