@@ -100,6 +100,37 @@ int lr_lmk_apply_padding(const int32_t* rects_in, const int32_t* dims, int32_t* 
 int lr_lmk_translate(const float* lmk_in, const int32_t* rects, float* lmk_out, int n,
                      int npts, lr_stream_t stream);
 
+/* PRNet crop geometry (src/models/face/prnet.py:112-119,136-140, image_info = the UNPADDED face rect
+ * as generate_dataview.py:62 passes it): old = (r-l+b-t)/2, centre of the box, size = int(old*1.6),
+ * similarity transform of the crop square onto resolution x resolution (what the reference obtains
+ * from skimage.transform.estimate_transform('similarity', ...)).
+ *   rects [n,4] int32 (left,right,top,bottom) -> tform [n,3,3] float64 row-major, sizes [n] int32 (NULL ok) */
+int lr_lmk_crop_transform(const int32_t* rects, double* tform, int32_t* sizes, int n, int resolution,
+                          lr_stream_t stream);
+
+/* Restore (prnet.py:150-156): the network's position map of the crop -> image coordinates:
+ * z /= tform[0][0]; [x y] = (tform^-1 [x y 1])[0:2].
+ *   cropped_pos [n, npix, 3] f32 (PosPrediction.predict's output, prnet.py:304-309), tform [n,3,3] f64
+ *   -> pos [n, npix, 3] f64 (np.dot's result type). */
+int lr_lmk_restore(const float* cropped_pos, const double* tform, double* pos, int n, int64_t npix,
+                   lr_stream_t stream);
+
+/* get_landmarks (prnet.py:162-170): kpt[i,k,:] = pos[i, uv[1][k], uv[0][k], :]; with `rects` non-NULL
+ * also getFace's translation by (left, top) of rects[i] (face.py:164-175).
+ *   pos [n,res,res,3] f64, uv_kpt_ind [2,K] int32, rects [n,4] int32 or NULL -> kpt [n,K,3] f64 */
+int lr_lmk_gather(const double* pos, const int32_t* uv_kpt_ind, const int32_t* rects, double* kpt, int n,
+                  int resolution, int K, lr_stream_t stream);
+
+/* The arithmetic of _gen_data (src/scripts/generate_dataview.py:58-64) around the two networks, in one
+ * launch: padded rect = _applyPadding(dims, rect, padding) (extractFace, :61); the UNPADDED rect
+ * defines the PRNet crop (:62); the K landmark points are gathered from the position map, restored
+ * to image coordinates and translated by the PADDED rect (:64).
+ *   cropped_pos [n,res,res,3] f32, rects [n,4], dims [n,2] = (img_h, img_w), uv_kpt_ind [2,K]
+ *   -> lmk_f64 [n,K,3] and/or lmk_f32 [n,K,3] (either may be NULL), rects_padded [n,4] (NULL ok) */
+int lr_lmk_landmarks(const float* cropped_pos, const int32_t* rects, const int32_t* dims, double padding,
+                     const int32_t* uv_kpt_ind, double* lmk_f64, float* lmk_f32, int32_t* rects_padded,
+                     int n, int resolution, int K, lr_stream_t stream);
+
 /* A9 (BUILD-DEFINED, no reference symbol: face.py:21 defines `_mouth = slice(48,68)` and never uses
  * it): crop the mouth region and resample it to S x S.  Per frame: bounding box of landmarks
  * [lo,hi) (x = lmk[..,0], y = lmk[..,1], image pixels) -> centre, side = max(w,h)*(1+2*margin)

@@ -5,7 +5,7 @@ error, the call raises.  Nothing in this module imports from oracle/.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 from . import _build
 
@@ -21,6 +21,10 @@ SIGNATURES = {
     "lr_collate_pad_f32": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "lr_lmk_apply_padding": (c_int, [P, P, P, c_int, c_float, P]),
     "lr_lmk_translate": (c_int, [P, P, P, c_int, c_int, P]),
+    "lr_lmk_crop_transform": (c_int, [P, P, P, c_int, c_int, P]),
+    "lr_lmk_restore": (c_int, [P, P, P, c_int, c_int64, P]),
+    "lr_lmk_gather": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "lr_lmk_landmarks": (c_int, [P, P, P, c_double, P, P, P, P, c_int, c_int, c_int, P]),
     "lr_lip_crop_u8": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     "lr_sgemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "lr_sgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, P, c_int, P, c_int, c_float,

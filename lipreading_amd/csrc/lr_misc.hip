@@ -88,6 +88,109 @@ __global__ void lmk_translate_kernel(const float* __restrict__ in, const int32_t
   }
 }
 
+// ---- PRNet crop / restore / landmark gather (src/models/face/prnet.py:112-119,136-156,162-170) --------
+// Crop geometry of one face rect (left, right, top, bottom): old = (r-l+b-t)/2, centre = (r-(r-l)/2,
+// b-(b-t)/2), size = int(old*1.6); the reference then asks skimage for the similarity transform that
+// maps the crop square's corners (c-size/2, c-size/2), (c-size/2, c+size/2), (c+size/2, c-size/2) onto
+// (0,0), (0,res-1), (res-1,0).  Those three source points ARE a similarity image of the destination
+// points (axis-aligned right isosceles triangles), so the least-squares (Umeyama) solution is the exact
+// one: scale s = (res-1)/size, no rotation, t = -s * (c - size/2).  size == 0 gives inf/nan as the
+// reference's division does.
+struct CropT { double s, tx, ty; };
+__device__ __forceinline__ CropT crop_transform_of(const int32_t* r, int res, int* size_out) {
+  const int left = r[0], right = r[1], top = r[2], bottom = r[3];
+  const double old_size = (double)(right - left + bottom - top) / 2.0;
+  const double cx = (double)right - (double)(right - left) / 2.0, cy = (double)bottom - (double)(bottom - top) / 2.0;
+  const int size = (int)(old_size * 1.6);
+  CropT t;
+  t.s = (double)(res - 1) / (double)size;
+  t.tx = -t.s * (cx - (double)size / 2.0);
+  t.ty = -t.s * (cy - (double)size / 2.0);
+  if (size_out) *size_out = size;
+  return t;
+}
+
+__global__ void lmk_crop_transform_kernel(const int32_t* __restrict__ rects, double* __restrict__ tform,
+                                          int32_t* __restrict__ sizes, int n, int res) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int size;
+  const CropT t = crop_transform_of(rects + 4 * i, res, &size);
+  double* o = tform + 9 * (int64_t)i;
+  o[0] = t.s; o[1] = 0.0; o[2] = t.tx;
+  o[3] = 0.0; o[4] = t.s; o[5] = t.ty;
+  o[6] = 0.0; o[7] = 0.0; o[8] = 1.0;
+  if (sizes) sizes[i] = size;
+}
+
+// restore (prnet.py:150-156): z /= tform[0][0]; [x y]' = (tform^-1 [x y 1]')[0:2], for a general affine
+// tform (row-major 3x3, last row 0 0 1).  float32 position map in, float64 out (np.dot's result type).
+__device__ __forceinline__ void restore_point(const double* m, double x, double y, double z, double* o) {
+  const double det = m[0] * m[4] - m[1] * m[3];
+  const double i00 = m[4] / det, i01 = -m[1] / det, i10 = -m[3] / det, i11 = m[0] / det;
+  const double i02 = -(i00 * m[2] + i01 * m[5]), i12 = -(i10 * m[2] + i11 * m[5]);
+  o[0] = i00 * x + i01 * y + i02;
+  o[1] = i10 * x + i11 * y + i12;
+  o[2] = z / m[0];
+}
+__global__ void lmk_restore_kernel(const float* __restrict__ cp, const double* __restrict__ tform,
+                                   double* __restrict__ pos, int64_t npix) {
+  const int frame = blockIdx.y;
+  const double* m = tform + 9 * (int64_t)frame;
+  const float* src = cp + (int64_t)frame * npix * 3;
+  double* dst = pos + (int64_t)frame * npix * 3;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x)
+    restore_point(m, (double)src[3 * p], (double)src[3 * p + 1], (double)src[3 * p + 2], dst + 3 * p);
+}
+
+// get_landmarks (prnet.py:162-170): kpt[k] = pos[uv[1][k]][uv[0][k]][:], optionally translated by a rect's
+// (left, top) as getFace does (face.py:164-175).  grid n frames, K threads.
+__global__ void lmk_gather_kernel(const double* __restrict__ pos, const int32_t* __restrict__ uv,
+                                  const int32_t* __restrict__ rects, double* __restrict__ kpt, int res, int K) {
+  const int frame = blockIdx.x, k = threadIdx.x;
+  if (k >= K) return;
+  const int u = uv[k], v = uv[K + k];
+  const double* p = pos + (((int64_t)frame * res + v) * res + u) * 3;
+  double* o = kpt + ((int64_t)frame * K + k) * 3;
+  o[0] = p[0] - (rects ? (double)rects[4 * frame] : 0.0);
+  o[1] = p[1] - (rects ? (double)rects[4 * frame + 2] : 0.0);
+  o[2] = p[2];
+}
+
+// generate_dataview.py:58-64 minus the two networks, fused: padded rect (extractFace, padding) ->
+// crop transform of the UNPADDED rect -> restore only the K gathered points -> translate by the
+// PADDED rect.  Reads K*12 bytes of each frame's 786 KB position map.
+__global__ void lmk_landmarks_kernel(const float* __restrict__ cp, const int32_t* __restrict__ rects,
+                                     const int32_t* __restrict__ dims, double padding,
+                                     const int32_t* __restrict__ uv, double* __restrict__ out64,
+                                     float* __restrict__ out32, int32_t* __restrict__ rects_padded, int res, int K) {
+  const int frame = blockIdx.x, k = threadIdx.x;
+  const int32_t* r = rects + 4 * frame;
+  const int img_h = dims[2 * frame], img_w = dims[2 * frame + 1];
+  const int box_h = r[3] - r[2], box_w = r[1] - r[0];
+  const int pw = (int)(padding * (double)box_w), ph = (int)(padding * (double)box_h);
+  const int left = max(0, r[0] - pw), right = min(img_w, r[1] + pw);
+  const int top = max(0, r[2] - ph), bottom = min(img_h, r[3] + ph);
+  if (k == 0 && rects_padded) {
+    rects_padded[4 * frame] = left;
+    rects_padded[4 * frame + 1] = right;
+    rects_padded[4 * frame + 2] = top;
+    rects_padded[4 * frame + 3] = bottom;
+  }
+  if (k >= K) return;
+  const CropT t = crop_transform_of(r, res, nullptr);
+  const double m[9] = {t.s, 0.0, t.tx, 0.0, t.s, t.ty, 0.0, 0.0, 1.0};
+  const int u = uv[k], v = uv[K + k];
+  const float* p = cp + (((int64_t)frame * res + v) * res + u) * 3;
+  double o[3];
+  restore_point(m, (double)p[0], (double)p[1], (double)p[2], o);
+  o[0] -= (double)left;
+  o[1] -= (double)top;
+  const int64_t base = ((int64_t)frame * K + k) * 3;
+  if (out64) { out64[base] = o[0]; out64[base + 1] = o[1]; out64[base + 2] = o[2]; }
+  if (out32) { out32[base] = (float)o[0]; out32[base + 1] = (float)o[1]; out32[base + 2] = (float)o[2]; }
+}
+
 __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
   float acc = 0.f;
   const int64_t n4 = n >> 2;
@@ -208,6 +311,39 @@ extern "C" int lr_lmk_translate(const float* lmk_in, const int32_t* rects, float
   LR_CHECK_ARG(lmk_in && rects && lmk_out && n > 0 && npts > 0);
   const int64_t total = (int64_t)n * npts * 3;
   LR_LAUNCH(lmk_translate_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, lmk_in, rects, lmk_out, total, npts * 3);
+  return lr_launch_status();
+}
+
+extern "C" int lr_lmk_crop_transform(const int32_t* rects, double* tform, int32_t* sizes, int n, int resolution,
+                                     lr_stream_t stream) {
+  LR_CHECK_ARG(rects && tform && n > 0 && resolution > 1);
+  LR_LAUNCH(lmk_crop_transform_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, rects, tform, sizes, n, resolution);
+  return lr_launch_status();
+}
+
+extern "C" int lr_lmk_restore(const float* cropped_pos, const double* tform, double* pos, int n, int64_t npix,
+                              lr_stream_t stream) {
+  LR_CHECK_ARG(cropped_pos && tform && pos && n > 0 && npix > 0);
+  int gx = (int)((npix + 255) / 256);
+  if (gx > 256) gx = 256;
+  LR_LAUNCH(lmk_restore_kernel, dim3(gx, n), dim3(256), 0, stream, cropped_pos, tform, pos, npix);
+  return lr_launch_status();
+}
+
+extern "C" int lr_lmk_gather(const double* pos, const int32_t* uv_kpt_ind, const int32_t* rects, double* kpt, int n,
+                             int resolution, int K, lr_stream_t stream) {
+  LR_CHECK_ARG(pos && uv_kpt_ind && kpt && n > 0 && resolution > 0 && K > 0 && K <= 1024);
+  LR_LAUNCH(lmk_gather_kernel, dim3(n), dim3((K + 63) / 64 * 64), 0, stream, pos, uv_kpt_ind, rects, kpt, resolution, K);
+  return lr_launch_status();
+}
+
+extern "C" int lr_lmk_landmarks(const float* cropped_pos, const int32_t* rects, const int32_t* dims, double padding,
+                                const int32_t* uv_kpt_ind, double* lmk_f64, float* lmk_f32, int32_t* rects_padded,
+                                int n, int resolution, int K, lr_stream_t stream) {
+  LR_CHECK_ARG(cropped_pos && rects && dims && uv_kpt_ind && (lmk_f64 || lmk_f32));
+  LR_CHECK_ARG(n > 0 && resolution > 1 && K > 0 && K <= 1024);
+  LR_LAUNCH(lmk_landmarks_kernel, dim3(n), dim3((K + 63) / 64 * 64), 0, stream, cropped_pos, rects, dims, padding,
+            uv_kpt_ind, lmk_f64, lmk_f32, rects_padded, resolution, K);
   return lr_launch_status();
 }
 

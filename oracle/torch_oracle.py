@@ -13,7 +13,11 @@ reference itself (tests/golden/make_golden.py):
   - enc_* / step_* fixtures: reference VideoEncoder with a stand-in for the absent, unpinned
     third-party `allennlp.nn.util` (masked_log_softmax / sort_batch_by_length) -> SHIMMED pin;
     parity at that boundary is otherwise unpinned.
-  - lmk_*: face.py needs dlib to import, so those cases are hand-computed    -> parity unpinned
+  - lmk_* fixtures: reference face.py (_applyPadding, extractFace, getFace) imported with inert
+    `dlib` / `src.models.face.prnet` stubs (neither is on the arithmetic path)   -> CLEAN pin
+  - prn_* fixtures: the reference's PRN.process / get_landmarks bodies (prnet.py:112-170) run with the
+    network replaced by a fixed position map; `skimage.transform.estimate_transform` (scikit-image
+    0.14.1, absent) stood in by umeyama_similarity below                        -> SHIMMED pin
 """
 import math
 
@@ -71,6 +75,86 @@ def get_face(lmks, rect):
   out[:, 0] -= rect[0]
   out[:, 1] -= rect[2]
   return out
+
+
+def umeyama_similarity(src, dst):
+  """`skimage.transform.estimate_transform('similarity', src, dst).params` (prnet.py:140) — the
+  reference pins scikit-image==0.14.1 (requirements.txt:31), which is NOT under /root/reference
+  and not installed here, so this is a restatement of the published algorithm that function
+  implements: S. Umeyama, "Least-squares estimation of transformation parameters between two point
+  patterns", IEEE TPAMI 13(4), 1991 (eq. 34-43) — demean, covariance A = dst_c^T src_c / n, SVD,
+  reflection guard d, R = U diag(d) V^T, scale = sum(S*d) / var(src), t = mean_dst - scale R mean_src.
+  PARITY UNPINNED at this boundary (no reference test vectors; the library is absent)."""
+  src, dst = np.asarray(src, np.float64), np.asarray(dst, np.float64)
+  num, dim = src.shape
+  src_mean, dst_mean = src.mean(axis=0), dst.mean(axis=0)
+  src_c, dst_c = src - src_mean, dst - dst_mean
+  A = dst_c.T @ src_c / num
+  d = np.ones(dim)
+  if np.linalg.det(A) < 0:
+    d[dim - 1] = -1
+  T = np.eye(dim + 1)
+  U, S, Vt = np.linalg.svd(A)
+  rank = np.linalg.matrix_rank(A)
+  if rank == 0:
+    return np.nan * T
+  if rank == dim - 1:
+    if np.linalg.det(U) * np.linalg.det(Vt) > 0:
+      T[:dim, :dim] = U @ Vt
+    else:
+      s = d[dim - 1]
+      d[dim - 1] = -1
+      T[:dim, :dim] = U @ np.diag(d) @ Vt
+      d[dim - 1] = s
+  else:
+    T[:dim, :dim] = U @ np.diag(d) @ Vt
+  scale = 1.0 / src_c.var(axis=0).sum() * (S @ d)
+  T[:dim, dim] = dst_mean - scale * (T[:dim, :dim] @ src_mean.T)
+  T[:dim, :dim] *= scale
+  return T
+
+
+def prn_crop_transform(rect, resolution=256):
+  """prnet.py:112-119,136-140 with image_info = the (unpadded) face rect (left, right, top, bottom):
+  crop square of side int(1.6 * mean box side) about the box centre -> similarity transform onto
+  the resolution x resolution network input.  Returns (tform 3x3 float64, size)."""
+  left, right, top, bottom = [int(v) for v in rect]
+  old_size = (right - left + bottom - top) / 2
+  center = np.array([right - (right - left) / 2.0, bottom - (bottom - top) / 2.0])
+  size = int(old_size * 1.6)
+  src_pts = np.array([[center[0] - size / 2, center[1] - size / 2], [center[0] - size / 2, center[1] + size / 2],
+                      [center[0] + size / 2, center[1] - size / 2]])
+  dst_pts = np.array([[0, 0], [0, resolution - 1], [resolution - 1, 0]])
+  return umeyama_similarity(src_pts, dst_pts), size
+
+
+def prn_restore(cropped_pos, tform):
+  """prnet.py:150-156: position map of the crop -> image coordinates.  z /= tform[0,0];
+  [x, y] = (tform^-1 [x, y, 1])[:2].  float64 like np.dot's result (the reference's numpy 1.15 keeps
+  z at float32 precision — array/np.float64-scalar stays float32 there; numpy >= 2 promotes: the two
+  differ by one float32 rounding of z, below what the dataview's float32 consumer can see)."""
+  res = cropped_pos.shape[0]
+  v = np.reshape(cropped_pos, [-1, 3]).T.astype(np.float64)
+  z = v[2, :].copy() / tform[0, 0]
+  v[2, :] = 1
+  out = np.dot(np.linalg.inv(tform), v)
+  out = np.vstack((out[:2, :], z))
+  return np.reshape(out.T, [res, res, 3])
+
+
+def prn_get_landmarks(pos, uv_kpt_ind):
+  """prnet.py:162-170: kpt = pos[uv_kpt_ind[1], uv_kpt_ind[0], :] (68 gathers, row index second)."""
+  return pos[uv_kpt_ind[1, :], uv_kpt_ind[0, :], :]
+
+
+def landmark_step(cropped_pos, rect, dims, uv_kpt_ind, padding=0.3):
+  """generate_dataview.py:58-64 minus the two networks: the UNPADDED dlib rect goes to the PRNet crop
+  (:62), the PADDED one (extractFace(padding=0.3), :61) is what getFace translates by (:64).
+  Returns (face landmarks (K,3) float64, padded rect)."""
+  padded = apply_padding(dims, rect, padding)
+  tform, _ = prn_crop_transform(rect, cropped_pos.shape[0])
+  kpt = prn_get_landmarks(prn_restore(cropped_pos, tform), uv_kpt_ind)
+  return get_face(kpt, padded), padded
 
 
 # ------------------------------------------------------------------------------------------

@@ -52,6 +52,11 @@ def golden_lmk():
   return load_golden("lmk_cases.npz")
 
 
+@pytest.fixture(scope="session")
+def golden_prn():
+  return load_golden("prn_cases.npz")
+
+
 def has_gpu():
   try:
     import torch

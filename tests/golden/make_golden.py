@@ -21,8 +21,11 @@ Pins (see oracle/torch_oracle.py header):
   dec_cases.npz     reference VideoEncoder + CharDecodingStep (five attention types) driven as
                     train_better_model.py:46-74 does at teacher_forcing_ratio = 1; needs the
                     allennlp stand-ins incl. masked_softmax                              SHIMMED
-  lmk_cases.npz     hand-computed from face.py:76-90,164-175 (face.py needs dlib to import)
-                    -> parity unpinned for the landmark row
+  lmk_cases.npz     reference face.py _applyPadding / extractFace / getFace, imported with inert
+                    dlib / tensorflow / skimage stubs (none on the arithmetic path)     CLEAN
+  prn_cases.npz     reference PRN.process + get_landmarks (prnet.py:112-170) composed as
+                    generate_dataview.py:58-64, network output replaced by a seeded position map;
+                    skimage's estimate_transform stood in by oracle.umeyama_similarity  SHIMMED
 """
 import os
 import sys
@@ -323,24 +326,109 @@ def gen_dec(bm, ref_ctc, char2idx):
   np.savez_compressed(os.path.join(OUT, "dec_cases.npz"), **cases)
 
 
-def gen_lmk():
-  """Hand-computed from the formulas at face.py:76-90 and :164-175 (not produced by running
-  the reference: face.py imports dlib)."""
-  cases = {
-      # dims (h,w,c), rect (l,r,t,b), padding -> padded rect
-      "dims": np.array([[480, 640, 3], [100, 100, 3], [720, 1280, 3]]),
-      "rects": np.array([[200, 300, 100, 220], [5, 95, 10, 90], [1000, 1270, 600, 715]]),
-      "padding": np.array(0.3),
-      # int(0.3*100)=30,int(0.3*120)=36 ; int(0.3*90)=27,int(0.3*80)=24 ; int(0.3*270)=81,int(0.3*115)=34
-      "padded": np.array([[170, 330, 64, 256], [0, 100, 0, 100], [919, 1280, 566, 720]]),
-      "lmk": np.array([[[210.5, 130.25, -3.0], [250.0, 200.0, 12.5]],
-                       [[50.0, 50.0, 0.0], [7.25, 11.5, 1.0]],
-                       [[1100.0, 650.0, 30.0], [1279.0, 719.0, -60.0]]], dtype=np.float64),
-      "face": np.array([[[40.5, 66.25, -3.0], [80.0, 136.0, 12.5]],
-                        [[50.0, 50.0, 0.0], [7.25, 11.5, 1.0]],
-                        [[181.0, 84.0, 30.0], [360.0, 153.0, -60.0]]], dtype=np.float64),
-  }
+def install_face_stubs():
+  """What face.py / prnet.py need at IMPORT time and this container lacks.  Inert (never on the
+  arithmetic path): dlib, tensorflow(+contrib), skimage.io, skimage.transform.warp (its result only
+  feeds the network, which the fixtures replace by a fixed position map).  NOT inert:
+  skimage.transform.estimate_transform (scikit-image 0.14.1) — stood in by the oracle's restatement of
+  the Umeyama algorithm, which makes every prn_* vector a SHIMMED pin."""
+  repo = os.path.dirname(os.path.dirname(OUT))
+  if repo not in sys.path:
+    sys.path.insert(0, repo)
+  from oracle import torch_oracle as O
+  class _Inert(types.ModuleType):
+    """Any attribute is another inert object (prnet.py names tf.nn.relu / tcl.batch_norm as default
+    arguments at import time); calling one is an error."""
+    def __getattr__(self, item):
+      if item.startswith("__"):
+        raise AttributeError(item)
+      return _Inert(self.__name__ + "." + item)
+
+    def __call__(self, *a, **k):
+      raise NotImplementedError("inert stub %s called" % self.__name__)
+  for name in ("dlib", "tensorflow", "tensorflow.contrib", "tensorflow.contrib.layers",
+               "tensorflow.contrib.framework", "skimage", "skimage.io"):
+    sys.modules.setdefault(name, _Inert(name))
+  sys.modules.setdefault("skimage.transform", types.ModuleType("skimage.transform"))
+
+  class _Tform(object):
+    def __init__(self, params):
+      self.params, self.inverse = params, None
+
+  def estimate_transform(kind, src, dst):
+    assert kind == 'similarity'
+    return _Tform(O.umeyama_similarity(src, dst))
+  sys.modules["skimage.transform"].estimate_transform = estimate_transform
+  sys.modules["skimage.transform"].warp = lambda image, inv, output_shape=None: np.zeros(tuple(output_shape) + (3,))
+
+
+def gen_lmk(face):
+  """Reference face.py:_applyPadding (:76-90), extractFace (:103-115) and getFace (:164-175) RUN
+  (inert dlib / tensorflow / skimage stubs, see install_face_stubs).  CLEAN pin."""
+  rng = np.random.RandomState(123456)
+  dims = np.array([[480, 640, 3], [100, 100, 3], [720, 1280, 3], [360, 480, 3], [1080, 1920, 3]])
+  rects = np.array([[200, 300, 100, 220], [5, 95, 10, 90], [1000, 1270, 600, 715], [0, 37, 3, 41],
+                    [700, 1211, 150, 661]])
+  padding = 0.3
+  lmk = np.stack([np.stack([rng.uniform(0, d[1], 68), rng.uniform(0, d[0], 68), rng.uniform(-60, 60, 68)], 1)
+                  for d in dims])
+  lmk = np.round(lmk * 64) / 64     # exact in float32 too: the translation is then bit-exact in either width
+  padded, faces, crops = [], [], []
+  for d, r, l in zip(dims, rects, lmk):
+    p = face._applyPadding(tuple(int(v) for v in d), tuple(int(v) for v in r), padding)
+    img = np.zeros(tuple(int(v) for v in d), dtype=np.uint8)
+    crop, p2 = face.extractFace(img, tuple(int(v) for v in r), padding=padding)
+    assert tuple(p2) == tuple(p)
+    padded.append(p)
+    crops.append(crop.shape[:2])
+    faces.append(face.getFace(l, tuple(int(v) for v in p)))
+  cases = {"dims": dims, "rects": rects, "padding": np.array(padding), "padded": np.array(padded),
+           "crop_hw": np.array(crops), "lmk": lmk, "face": np.stack(faces)}
   np.savez_compressed(os.path.join(OUT, "lmk_cases.npz"), **cases)
+
+
+def prn_position_map(seed, rect, res=256):
+  """A synthetic network output: what PosPrediction.predict returns (prnet.py:304-309: net output x
+  256*1.1, float32) — smooth-ish coordinates inside the 256 x 256 crop plus noise.  tests regenerate
+  it from the seed (RandomState is a frozen legacy generator)."""
+  rng = np.random.RandomState(seed)
+  u, v = np.meshgrid(np.arange(res, dtype=np.float64), np.arange(res, dtype=np.float64))
+  pos = np.stack([u + rng.uniform(-20, 20, (res, res)), v + rng.uniform(-20, 20, (res, res)),
+                  rng.uniform(-80, 80, (res, res))], -1)
+  return pos.astype(np.float32)
+
+
+def gen_prn(face, prnet):
+  """The reference's PRN.process (prnet.py:77-159; crop geometry :112-140, restore :150-156) and
+  get_landmarks (:162-170) bodies, composed as generate_dataview.py:58-64 does (_gen_data: unpadded
+  rect -> PRNet, padded rect -> getFace).  The PRN object is built without __init__ (no weights, no
+  TensorFlow) and its net_forward returns prn_position_map(seed).  SHIMMED pin: estimate_transform."""
+  uv = np.loadtxt(os.path.join(REF, "src/models/extern/prnet/Data/uv/uv_kpt_ind.txt")).astype(np.int32)  # 2 x 68 (data)
+  cases = {"uv_kpt_ind": uv}
+  dims = np.array([[480, 640, 3], [720, 1280, 3], [360, 480, 3], [1080, 1920, 3]])
+  rects = np.array([[200, 300, 100, 220], [1000, 1270, 600, 715], [0, 37, 3, 41], [700, 1211, 150, 661]])
+  seeds = np.array([11, 12, 13, 14])
+  tforms, kpts, faces, padded, sub = [], [], [], [], []
+  for d, r, seed in zip(dims, rects, seeds):
+    prn = prnet.PRN.__new__(prnet.PRN)
+    prn.resolution_inp = prn.resolution_op = 256
+    prn.uv_kpt_ind = uv
+    cropped = prn_position_map(int(seed), r)
+    prn.net_forward = lambda image, _c=cropped: _c
+    img = np.zeros(tuple(int(v) for v in d), dtype=np.uint8)
+    rect = tuple(int(v) for v in r)
+    _, rect_pad = face.extractFace(img, rect, padding=0.3)             # generate_dataview.py:61
+    pos, _ = prn.process(img, image_info=rect)                         # :62 via face.detect3dLandmarks
+    kpt = prn.get_landmarks(pos)
+    tform, _ = __import__("oracle.torch_oracle", fromlist=["x"]).prn_crop_transform(rect)
+    tforms.append(tform)
+    kpts.append(kpt)
+    faces.append(face.getFace(kpt, rect_pad))                          # :64
+    padded.append(rect_pad)
+    sub.append(pos[::16, ::16])
+  cases.update({"dims": dims, "rects": rects, "seeds": seeds, "tform": np.stack(tforms), "kpt": np.stack(kpts),
+                "face_lmk": np.stack(faces), "padded": np.array(padded), "pos_sub16": np.stack(sub)})
+  np.savez_compressed(os.path.join(OUT, "prn_cases.npz"), **cases)
 
 
 def main():
@@ -361,7 +449,11 @@ def main():
   gen_enc(bm, char2idx)
   gen_step(bm, ref_ctc, char2idx)
   gen_dec(bm, ref_ctc, char2idx)
-  gen_lmk()
+  install_face_stubs()
+  import src.models.face.prnet as ref_prnet                   # shimmed import (estimate_transform)
+  import src.utils.data.face as ref_face                      # clean apart from the inert stubs
+  gen_lmk(ref_face)
+  gen_prn(ref_face, ref_prnet)
   for f in sorted(os.listdir(OUT)):
     if f.endswith(".npz"):
       print("%-20s %8d bytes" % (f, os.path.getsize(os.path.join(OUT, f))))

@@ -169,7 +169,7 @@ def test_landmark_step(golden_lmk, dev):
                             float(g["padding"]))
   np.testing.assert_array_equal(padded.cpu().numpy(), g["padded"])
   face = LM.get_face(torch.tensor(g["lmk"], device=dev), padded)
-  np.testing.assert_allclose(face.cpu().numpy(), g["face"].astype(np.float32), rtol=0, atol=0)
+  np.testing.assert_array_equal(face.cpu().numpy(), g["face"].astype(np.float32))   # reference vectors, bit-exact
   # seeded, against the oracle: a 75-frame clip of 68 points
   rng = np.random.RandomState(123456)
   lm = rng.uniform(0, 200, (75, 68, 3)).astype(np.float32)
@@ -184,6 +184,48 @@ def test_landmark_step(golden_lmk, dev):
   out = LM.get_face(torch.tensor(lm, device=dev), pd)
   exp = np.stack([O.get_face(lm[i], exp_pd[i]) for i in range(75)])
   np.testing.assert_array_equal(out.cpu().numpy(), exp)
+
+
+def test_prnet_crop_restore_gather(golden_prn, dev):
+  """A7 remainder through the C ABI against the reference vectors (prn_cases: PRN.process and
+  get_landmarks bodies run on a seeded position map, composed as generate_dataview.py:58-64) and, on a
+  75-frame clip, against the oracle.  Stated tolerances: integer rect math bit-exact; transform and
+  coordinates 1e-9 absolute (float64 closed form vs LAPACK inverse + np.dot; coordinates are ~1e2..1e3)."""
+  from lipreading_amd import landmarks as LM
+  from tests.golden.make_golden import prn_position_map
+  g = golden_prn
+  uv = torch.tensor(g["uv_kpt_ind"], device=dev)
+  n = len(g["rects"])
+  cropped = np.stack([prn_position_map(int(g["seeds"][i]), g["rects"][i]) for i in range(n)])
+  rects, dims = torch.tensor(g["rects"], device=dev), torch.tensor(g["dims"], device=dev)
+  tform, sizes = LM.crop_transform(rects)
+  np.testing.assert_allclose(tform.cpu().numpy(), g["tform"], rtol=0, atol=1e-12)
+  pos = LM.restore(torch.tensor(cropped, device=dev), tform)
+  assert pos.dtype == torch.float64 and pos.shape == (n, 256, 256, 3)
+  np.testing.assert_allclose(pos.cpu().numpy()[:, ::16, ::16], g["pos_sub16"], rtol=0, atol=1e-9)
+  np.testing.assert_allclose(LM.get_landmarks(pos, uv).cpu().numpy(), g["kpt"], rtol=0, atol=1e-9)
+  padded = LM.apply_padding(dims, rects, 0.3)
+  np.testing.assert_array_equal(padded.cpu().numpy(), g["padded"])
+  np.testing.assert_allclose(LM.get_landmarks(pos, uv, padded).cpu().numpy(), g["face_lmk"], rtol=0, atol=1e-9)
+  # the fused launch: the whole of _gen_data around the two networks
+  lmk, padded2 = LM.landmark_step(torch.tensor(cropped, device=dev), rects, dims, uv, padding=0.3)
+  np.testing.assert_array_equal(padded2.cpu().numpy(), g["padded"])
+  np.testing.assert_allclose(lmk.cpu().numpy(), g["face_lmk"], rtol=0, atol=1e-9)
+  lmk32, _ = LM.landmark_step(torch.tensor(cropped, device=dev), rects, dims, uv, padding=0.3, dtype=torch.float32)
+  np.testing.assert_array_equal(lmk32.cpu().numpy(), g["face_lmk"].astype(np.float32))   # what _collate_fn makes of the row
+  # a 75-frame clip against the oracle
+  rng = np.random.RandomState(7)
+  F = 75
+  r = np.zeros((F, 4), np.int32)
+  r[:, 0], r[:, 2] = rng.randint(0, 900, F), rng.randint(0, 500, F)
+  r[:, 1], r[:, 3] = r[:, 0] + rng.randint(40, 380, F), r[:, 2] + rng.randint(40, 220, F)
+  d = np.tile(np.array([[720, 1280, 3]]), (F, 1))
+  cp = rng.uniform(-50, 300, (F, 256, 256, 3)).astype(np.float32)
+  got, gp = LM.landmark_step(torch.tensor(cp, device=dev), torch.tensor(r, device=dev), torch.tensor(d, device=dev), uv)
+  for i in range(F):
+    want, wp = O.landmark_step(cp[i], tuple(int(v) for v in r[i]), tuple(d[i]), g["uv_kpt_ind"], 0.3)
+    assert list(wp) == gp[i].tolist()
+    np.testing.assert_allclose(got[i].cpu().numpy(), want, rtol=0, atol=1e-9)
 
 
 def test_collate_matches_oracle(dev):

@@ -108,13 +108,39 @@ def test_step_oracle_matches_reference(golden_step, name):
     np.testing.assert_allclose(v.numpy(), sd1[k], rtol=1e-4, atol=1e-6, err_msg=k)
 
 
-def test_landmark_oracle_matches_hand_computed(golden_lmk):
+def test_landmark_oracle_matches_reference(golden_lmk):
+  """lmk_cases: the reference's _applyPadding / extractFace / getFace were RUN (clean pin)."""
   g = golden_lmk
   for i in range(len(g["rects"])):
     padded = O.apply_padding(tuple(g["dims"][i]), tuple(int(x) for x in g["rects"][i]),
                              float(g["padding"]))
     assert list(padded) == list(g["padded"][i])
-    np.testing.assert_allclose(O.get_face(g["lmk"][i], padded), g["face"][i])
+    assert (padded[3] - padded[2], padded[1] - padded[0]) == tuple(g["crop_hw"][i])     # extractFace's crop
+    np.testing.assert_array_equal(O.get_face(g["lmk"][i], padded), g["face"][i])
+
+
+def test_prn_oracle_matches_reference(golden_prn):
+  """prn_cases: the reference's PRN.process / get_landmarks bodies run on a seeded position map
+  (shimmed pin: estimate_transform).  Crop transform, restored map (16-strided sample), gathered
+  landmarks and the dataview row (padded-rect translation) — generate_dataview.py:58-64."""
+  from tests.golden.make_golden import prn_position_map
+  g = golden_prn
+  uv = g["uv_kpt_ind"]
+  assert uv.shape == (2, 68)
+  for i in range(len(g["rects"])):
+    rect = tuple(int(v) for v in g["rects"][i])
+    cropped = prn_position_map(int(g["seeds"][i]), rect)
+    tform, size = O.prn_crop_transform(rect)
+    np.testing.assert_allclose(tform, g["tform"][i], rtol=0, atol=1e-12)
+    # the closed form the HIP kernel uses: exact similarity of the three corner points
+    np.testing.assert_allclose(tform, [[255.0 / size, 0, tform[0, 2]], [0, 255.0 / size, tform[1, 2]], [0, 0, 1]],
+                               rtol=1e-13, atol=1e-13)
+    pos = O.prn_restore(cropped, tform)
+    np.testing.assert_allclose(pos[::16, ::16], g["pos_sub16"][i], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(O.prn_get_landmarks(pos, uv), g["kpt"][i], rtol=1e-12, atol=1e-9)
+    face, padded = O.landmark_step(cropped, rect, tuple(g["dims"][i]), uv, 0.3)
+    assert list(padded) == list(g["padded"][i])
+    np.testing.assert_allclose(face, g["face_lmk"][i], rtol=1e-12, atol=1e-9)
 
 
 def test_collate_pads_with_zeros():
