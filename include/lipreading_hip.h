@@ -40,6 +40,8 @@ typedef enum lr_status {
 typedef enum lr_rnn_mode {
   LR_RNN_GRU = 0, /* torch.nn.GRU  gate order r,z,n   (3 gates) */
   LR_RNN_LSTM = 1, /* torch.nn.LSTM gate order i,f,g,o (4 gates) */
+  LR_RNN_TANH = 2, /* torch.nn.RNN (nonlinearity='tanh'): h' = tanh(W_ih x + b_ih + W_hh h + b_hh) (1 "gate");
+                      better_model.py:9 allows rnn_type='RNN' */
   LR_RNN_CELL_MASK = 0xff,
   /* Optional flags OR-ed into `mode` of lr_rnn_layer_* / lr_rnn_*_bytes (build-defined, used by
    * the pixel regime only; the reference-faithful path passes none and stays on exact fp32 MFMA):
@@ -294,8 +296,33 @@ typedef struct lr_decoder_grads {
   int emb_padding_idx;  /* nn.Embedding(padding_idx): that row receives no gradient; -1 = none    */
 } lr_decoder_grads;
 
-/* The whole decoder loop of one batch (max_label_len = L steps), single-layer RNN of hidden size
- * Hd started from the encoder's final state (h0 [B][Hd], c0 for the LSTM).
+/* Layers 1 .. num_layers-1 of the decoder's RNN stack (better_model.py:136,147-148: the decoder takes
+ * the encoder's num_layers; nn.GRU/LSTM/RNN(char_dim, Hd, num_layers) semantics: layer k's input is
+ * layer k-1's output of the same step).  Entry k-1 holds layer k: rnn.weight_ih_l{k} [G*Hd][Hd],
+ * rnn.weight_hh_l{k} [G*Hd][Hd], rnn.bias_ih_l{k}, rnn.bias_hh_l{k} [G*Hd].  drop_mask (NULL = none):
+ * [num_layers-1][B][L][Hd] multipliers (0 or 1/(1-p)) applied to the outputs of every layer but the
+ * last — the inter-layer dropout of nn.GRU(dropout=p) in training mode, drawn by the caller.
+ * Passing NULL for the struct = a single-layer decoder (every shipped config). */
+#define LR_DEC_MAX_LAYERS 8
+typedef struct lr_decoder_upper {
+  int num_layers;
+  const float* w_ih[LR_DEC_MAX_LAYERS - 1];
+  const float* w_hh[LR_DEC_MAX_LAYERS - 1];
+  const float* b_ih[LR_DEC_MAX_LAYERS - 1];
+  const float* b_hh[LR_DEC_MAX_LAYERS - 1];
+  const float* drop_mask;
+} lr_decoder_upper;
+typedef struct lr_decoder_upper_grads {
+  float* w_ih[LR_DEC_MAX_LAYERS - 1];
+  float* w_hh[LR_DEC_MAX_LAYERS - 1];
+  float* b_ih[LR_DEC_MAX_LAYERS - 1];
+  float* b_hh[LR_DEC_MAX_LAYERS - 1];
+} lr_decoder_upper_grads;
+
+/* The whole decoder loop of one batch (max_label_len = L steps): an RNN stack (mode = LR_RNN_GRU /
+ * LR_RNN_LSTM / LR_RNN_TANH, num_layers layers) of hidden size Hd started from the encoder's final
+ * state (h0 [num_layers][B][Hd], c0 likewise for the LSTM); the attention and the output head read the
+ * top layer's state.
  *   tokens [B][L] int32    teacher inputs chars[:, i] (device)
  *   teacher_forced_host[L] HOST bytes: 1 = step i is fed tokens[:, i], 0 = fed the previous step's
  *                          multinomial sample (train_better_model.py:57-58; step 0 always uses tokens)
@@ -304,21 +331,26 @@ typedef struct lr_decoder_grads {
  *   sampled [B][L] int32   multinomial(exp(log_probs)) of every step (counter-based RNG on `seed`;
  *                          equal to torch's sampler in distribution only)
  * The caller derives the loss (nll_loss, ignore_index = PAD, train_better_model.py:62) and the
- * accuracy counts (:131-133) from log_probs / sampled.  h_n / c_n [B][Hd] (may be NULL) receive
- * the RNN state after the last step (the final_state a single reference step returns).           */
-size_t lr_decoder_reserve_bytes(int mode, int attn_type, int B, int L, int T, int Hd, int Cd, int V, int A);
-size_t lr_decoder_workspace_bytes(int mode, int attn_type, int B, int L, int T, int Hd, int Cd, int V, int A);
-int lr_decoder_forward(int mode, int attn_type, const lr_decoder_params* params_host, const int32_t* tokens,
+ * accuracy counts (:131-133) from log_probs / sampled.  h_n / c_n [num_layers][B][Hd] (may be NULL)
+ * receive the RNN state after the last step (the final_state a single reference step returns).   */
+size_t lr_decoder_reserve_bytes(int mode, int attn_type, int num_layers, int B, int L, int T, int Hd, int Cd,
+                                int V, int A);
+size_t lr_decoder_workspace_bytes(int mode, int attn_type, int num_layers, int B, int L, int T, int Hd, int Cd,
+                                  int V, int A);
+int lr_decoder_forward(int mode, int attn_type, const lr_decoder_params* params_host,
+                       const lr_decoder_upper* upper_host, const int32_t* tokens,
                        const uint8_t* teacher_forced_host, const float* enc, const int32_t* enc_lens,
                        const float* h0, const float* c0, const int32_t* step_lens, uint64_t seed,
                        float* log_probs, int32_t* sampled, float* h_n, float* c_n, void* reserve,
                        size_t reserve_bytes, int B, int L, int T, int Hd, int Cd, int V, int A,
                        lr_stream_t stream);
-/* Backward of the loop: d_log_probs [B][L][V] (+ dh_n / dc_n [B][Hd], gradient arriving through the
- * returned final state; may be NULL) -> d_enc [B][T][Hd] (overwritten), dh0 / dc0 [B][Hd] (gradient
- * into the encoder's final state) and every parameter gradient.                                    */
+/* Backward of the loop: d_log_probs [B][L][V] (+ dh_n / dc_n [num_layers][B][Hd], gradient arriving
+ * through the returned final state; may be NULL) -> d_enc [B][T][Hd] (overwritten), dh0 / dc0
+ * [num_layers][B][Hd] (gradient into the encoder's final state) and every parameter gradient
+ * (upper_grads_host may be NULL for a single layer).                                                 */
 int lr_decoder_backward(int mode, int attn_type, const lr_decoder_params* params_host,
-                        const lr_decoder_grads* grads_host, const float* enc, const int32_t* enc_lens,
+                        const lr_decoder_upper* upper_host, const lr_decoder_grads* grads_host,
+                        const lr_decoder_upper_grads* upper_grads_host, const float* enc, const int32_t* enc_lens,
                         const float* h0, const float* c0, const int32_t* step_lens, const float* log_probs,
                         const float* d_log_probs, const float* dh_n, const float* dc_n, float* d_enc,
                         float* dh0, float* dc0, const void* reserve, size_t reserve_bytes, void* workspace,

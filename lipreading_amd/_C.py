@@ -59,11 +59,11 @@ SIGNATURES = {
     "lr_proj_logsoftmax_forward": (c_int, [P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, P]),
     "lr_proj_logsoftmax_backward": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int, c_int,
                                              c_int, P]),
-    "lr_decoder_reserve_bytes": (c_size_t, [c_int] * 9),
-    "lr_decoder_workspace_bytes": (c_size_t, [c_int] * 9),
-    "lr_decoder_forward": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, c_uint64, P, P, P, P, P, c_size_t] +
+    "lr_decoder_reserve_bytes": (c_size_t, [c_int] * 10),
+    "lr_decoder_workspace_bytes": (c_size_t, [c_int] * 10),
+    "lr_decoder_forward": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, P, c_uint64, P, P, P, P, P, c_size_t] +
                            [c_int] * 7 + [P]),
-    "lr_decoder_backward": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P,
+    "lr_decoder_backward": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P,
                                      c_size_t, c_int] + [c_int] * 7 + [P]),
     "lr_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "lr_ctc_nll": (c_int, [P, c_int64, c_int64, P, c_int, P, P, P, P, c_size_t, c_int, c_int,
@@ -105,6 +105,20 @@ class DecoderGrads(ctypes.Structure):
   """lr_decoder_grads."""
   _fields_ = [(n, c_void_p) for n in ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "attn_w1", "attn_b1", "attn_w2",
                                       "attn_b2", "w_c", "b_c", "w_o", "b_o")] + [("emb_padding_idx", c_int)]
+
+
+DEC_MAX_LAYERS = 8   # LR_DEC_MAX_LAYERS
+
+
+class DecoderUpper(ctypes.Structure):
+  """lr_decoder_upper: layers 1.. of the decoder's RNN stack."""
+  _fields_ = [("num_layers", c_int)] + [(n, c_void_p * (DEC_MAX_LAYERS - 1)) for n in ("w_ih", "w_hh", "b_ih", "b_hh")] + \
+             [("drop_mask", c_void_p)]
+
+
+class DecoderUpperGrads(ctypes.Structure):
+  """lr_decoder_upper_grads."""
+  _fields_ = [(n, c_void_p * (DEC_MAX_LAYERS - 1)) for n in ("w_ih", "w_hh", "b_ih", "b_hh")]
 
 
 class LipReadingHipError(RuntimeError):

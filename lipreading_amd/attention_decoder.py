@@ -21,43 +21,63 @@ from .encoder import _RNNParams, _direct_grads, _notify
 
 _ALLOWED_ATTENTION_TYPES = {'none', 'dot', 'general', '1_layer_nn', 'concat'}   # better_model.py:11
 _ATT_CODE = {'none': 0, 'dot': 1, 'general': 2, '1_layer_nn': 3, 'concat': 4}
-_MODES = {'GRU': 0, 'LSTM': 1}
+_MODES = {'GRU': 0, 'LSTM': 1, 'RNN': 2}
 _FIELDS = ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "attn_w1", "attn_b1", "attn_w2", "attn_b2", "w_c", "b_c",
            "w_o", "b_o")
 
 
+def _upper_struct(upper, drop_mask):
+  """lr_decoder_upper for the layers above the first (upper = flat list w_ih, w_hh, b_ih, b_hh per layer)."""
+  nl = 1 + len(upper) // 4
+  if nl == 1:
+    return None, nl
+  st = _C.DecoderUpper()
+  st.num_layers = nl
+  for k in range(nl - 1):
+    for j, name in enumerate(("w_ih", "w_hh", "b_ih", "b_hh")):
+      getattr(st, name)[k] = upper[4 * k + j].data_ptr()
+  st.drop_mask = _C.ptr(drop_mask)
+  return st, nl
+
+
 class _AttnDecoderFunction(torch.autograd.Function):
   """All L decoder steps: (tokens, teacher-forcing pattern, encoder states, initial state, params)
-  -> (log_probs (B,L,V), sampled (B,L), h_n, c_n)."""
+  -> (log_probs (B,L,V), sampled (B,L), h_n, c_n).  `params` = the 13 tensors of lr_decoder_params
+  (None where the attention type has none) followed by 4 tensors per RNN layer above the first."""
 
   @staticmethod
   def forward(ctx, tokens, teacher_forced, seed, mode, attn_type, attn_hidden, enc, enc_lens, h0, c0,
-              out_mask, *params):
+              out_mask, drop_mask, *params):
     L_ = _C.lib()
     B, L = tokens.shape
     T, Hd = enc.shape[1], enc.shape[2]
-    emb, w_o = params[0], params[11]
+    params, upper = params[:13], params[13:]
+    emb = params[0]
     V, Cd = emb.shape
     A = max(int(attn_hidden), 0)
     dev = enc.device
     pstruct = _C.DecoderParams(*[_C.ptr(p) for p in params], out_mask.data_ptr())
+    ustruct, NL = _upper_struct(upper, drop_mask)
+    assert h0.shape == (NL, B, Hd)
     lp = torch.empty((B, L, V), dtype=torch.float32, device=dev)
     sampled = torch.empty((B, L), dtype=torch.int32, device=dev)
-    h_n = torch.empty((B, Hd), dtype=torch.float32, device=dev)
-    c_n = torch.empty((B, Hd), dtype=torch.float32, device=dev) if mode == 1 else None
+    h_n = torch.empty((NL, B, Hd), dtype=torch.float32, device=dev)
+    c_n = torch.empty((NL, B, Hd), dtype=torch.float32, device=dev) if mode == 1 else None
     step_lens = torch.full((B,), L, dtype=torch.int32, device=dev)
-    rbytes = L_.lr_decoder_reserve_bytes(mode, attn_type, B, L, T, Hd, Cd, V, A)
+    rbytes = L_.lr_decoder_reserve_bytes(mode, attn_type, NL, B, L, T, Hd, Cd, V, A)
     reserve = torch.empty(rbytes, dtype=torch.uint8, device=dev)
     tf = (ctypes.c_uint8 * L)(*[1 if f else 0 for f in teacher_forced])
-    _C.check(L_.lr_decoder_forward(mode, attn_type, ctypes.byref(pstruct), tokens.data_ptr(), tf,
+    _C.check(L_.lr_decoder_forward(mode, attn_type, ctypes.byref(pstruct),
+                                   ctypes.byref(ustruct) if ustruct is not None else None, tokens.data_ptr(), tf,
                                    enc.data_ptr(), enc_lens.data_ptr(), h0.data_ptr(), _C.ptr(c0),
                                    step_lens.data_ptr(), int(seed) & 0xFFFFFFFFFFFFFFFF, lp.data_ptr(),
                                    sampled.data_ptr(), h_n.data_ptr(), _C.ptr(c_n), reserve.data_ptr(), rbytes,
                                    B, L, T, Hd, Cd, V, A, _C.stream_handle()), "lr_decoder_forward")
     ctx.save_for_backward(enc, enc_lens, h0, c0 if c0 is not None else h0, out_mask, lp, reserve, step_lens,
-                          *[p for p in params if p is not None])
+                          drop_mask if drop_mask is not None else out_mask,
+                          *[p for p in params if p is not None], *upper)
     ctx.present = [p is not None for p in params]
-    ctx.cfg = (mode, attn_type, A, B, L, T, Hd, Cd, V, c0 is not None)
+    ctx.cfg = (mode, attn_type, A, B, L, T, Hd, Cd, V, c0 is not None, NL, drop_mask is not None)
     ctx.mark_non_differentiable(sampled)
     if c_n is None:
       c_n = torch.zeros((0,), device=dev)
@@ -67,30 +87,45 @@ class _AttnDecoderFunction(torch.autograd.Function):
   @staticmethod
   def backward(ctx, d_lp, _ds, dh_n, dc_n):
     L_ = _C.lib()
-    mode, attn_type, A, B, L, T, Hd, Cd, V, has_c = ctx.cfg
+    mode, attn_type, A, B, L, T, Hd, Cd, V, has_c, NL, has_drop = ctx.cfg
     saved = ctx.saved_tensors
-    enc, enc_lens, h0, c0, out_mask, lp, reserve, step_lens = saved[:8]
+    enc, enc_lens, h0, c0, out_mask, lp, reserve, step_lens, drop_mask = saved[:9]
+    if not has_drop:
+      drop_mask = None
     present = ctx.present
-    it = iter(saved[8:])
+    rest = list(saved[9:])
+    n_real = sum(present)
+    it = iter(rest[:n_real])
     params = [next(it) if pr else None for pr in present]
+    upper = rest[n_real:]
     if not has_c:
       c0 = None
     dev = enc.device
-    real = [p for p in params if p is not None]
+    real = [p for p in params if p is not None] + list(upper)
     direct = _direct_grads(real)
     grads = [(p.grad if direct else torch.empty_like(p)) if p is not None else None for p in params]
+    ugrads = [(p.grad if direct else torch.empty_like(p)) for p in upper]
     pstruct = _C.DecoderParams(*[_C.ptr(p) for p in params], out_mask.data_ptr())
+    ustruct, _ = _upper_struct(upper, drop_mask)
     pad_idx = getattr(params[0], "_lr_padding_idx", -1)
     gstruct = _C.DecoderGrads(*[_C.ptr(g) for g in grads], int(pad_idx))
+    gustruct = None
+    if NL > 1:
+      gustruct = _C.DecoderUpperGrads()
+      for k in range(NL - 1):
+        for j, name in enumerate(("w_ih", "w_hh", "b_ih", "b_hh")):
+          getattr(gustruct, name)[k] = ugrads[4 * k + j].data_ptr()
     d_lp = (d_lp if d_lp is not None else torch.zeros_like(lp)).contiguous()
     dh_n = dh_n.contiguous() if dh_n is not None else None
     dc_n = dc_n.contiguous() if (has_c and dc_n is not None and dc_n.numel()) else None
     d_enc = torch.empty_like(enc)
     dh0 = torch.empty_like(h0)
     dc0 = torch.empty_like(h0) if has_c else None
-    wbytes = L_.lr_decoder_workspace_bytes(mode, attn_type, B, L, T, Hd, Cd, V, A)
+    wbytes = L_.lr_decoder_workspace_bytes(mode, attn_type, NL, B, L, T, Hd, Cd, V, A)
     ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-    _C.check(L_.lr_decoder_backward(mode, attn_type, ctypes.byref(pstruct), ctypes.byref(gstruct),
+    _C.check(L_.lr_decoder_backward(mode, attn_type, ctypes.byref(pstruct),
+                                    ctypes.byref(ustruct) if ustruct is not None else None, ctypes.byref(gstruct),
+                                    ctypes.byref(gustruct) if gustruct is not None else None,
                                     enc.data_ptr(), enc_lens.data_ptr(), h0.data_ptr(), _C.ptr(c0),
                                     step_lens.data_ptr(), lp.data_ptr(), d_lp.data_ptr(), _C.ptr(dh_n),
                                     _C.ptr(dc_n), d_enc.data_ptr(), dh0.data_ptr(), _C.ptr(dc0),
@@ -99,10 +134,10 @@ class _AttnDecoderFunction(torch.autograd.Function):
              "lr_decoder_backward")
     if direct:
       _notify(real)
-      pgrads = (None,) * len(params)
+      pgrads = (None,) * (len(params) + len(upper))
     else:
-      pgrads = tuple(grads)
-    return (None, None, None, None, None, None, d_enc, None, dh0, dc0, None) + pgrads
+      pgrads = tuple(grads) + tuple(ugrads)
+    return (None, None, None, None, None, None, d_enc, None, dh0, dc0, None, None) + pgrads
 
 
 class CharDecodingStep(nn.Module):
@@ -115,10 +150,8 @@ class CharDecodingStep(nn.Module):
       assert attn_hidden_size > 0
     self.hidden_size = encoder.hidden_size * (2 if encoder.bidirectional else 1)
     self.rnn_type = encoder.rnn_type
-    self.num_layers = encoder.num_layers
-    if self.num_layers != 1:
-      raise NotImplementedError("the HIP decoder loop implements the single-layer decoder every shipped "
-                                "config uses (num_layers=1)")
+    self.num_layers = encoder.num_layers          # better_model.py:136
+    assert 1 <= self.num_layers <= _C.DEC_MAX_LAYERS, "the decoder stack holds up to %d layers" % _C.DEC_MAX_LAYERS
     self.rnn_dropout = rnn_dropout
     self.char_dim = char_dim
     self.vocab_size = vocab_size
@@ -157,8 +190,9 @@ class CharDecodingStep(nn.Module):
     r = self.rnn
     self.embedding.weight._lr_padding_idx = self.embedding.padding_idx
     wc, bc = (self.concat_layer.weight, self.concat_layer.bias) if at != 'none' else (None, None)
+    upper = [w for layer in range(1, self.num_layers) for w in r.layer_weights(layer, 1)]
     return [self.embedding.weight, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0, w1, b1, w2, b2,
-            wc, bc, self.output_proj.weight, self.output_proj.bias]
+            wc, bc, self.output_proj.weight, self.output_proj.bias] + upper
 
   def decode_sequence(self, tokens, previous_state, encoder_lens, encoder_hidden_states,
                       teacher_forced=None, seed=None):
@@ -170,10 +204,18 @@ class CharDecodingStep(nn.Module):
     _C.require_cuda(tokens, encoder_hidden_states)
     B, L = tokens.shape
     mode = _MODES[self.rnn_type]
+    # (num_layers, B, Hd): one initial state per layer of the stack (better_model.py:181)
     if isinstance(previous_state, tuple):
-      h0, c0 = previous_state[0][0].contiguous(), previous_state[1][0].contiguous()
+      h0, c0 = previous_state[0].contiguous(), previous_state[1].contiguous()
     else:
-      h0, c0 = previous_state[0].contiguous(), None
+      h0, c0 = previous_state.contiguous(), None
+    assert h0.dim() == 3 and h0.shape[0] == self.num_layers, "previous_state must be (num_layers, B, hidden)"
+    drop_mask = None
+    if self.training and self.rnn_dropout and self.num_layers > 1:
+      # nn.GRU/LSTM(dropout=p), training mode: outputs of every layer but the last, independently per step
+      keep = 1.0 - float(self.rnn_dropout)
+      drop_mask = torch.bernoulli(torch.full((self.num_layers - 1, B, L, self.hidden_size), keep,
+                                             device=encoder_hidden_states.device)) / keep
     enc = encoder_hidden_states.to(torch.float32).contiguous()
     if teacher_forced is None:
       teacher_forced = [True] * L
@@ -184,9 +226,9 @@ class CharDecodingStep(nn.Module):
     lp, sampled, h_n, c_n = _AttnDecoderFunction.apply(
         tokens.to(torch.int32).contiguous(), tuple(bool(t) for t in teacher_forced), int(seed), mode,
         _ATT_CODE[self.attention_type], self.attn_hidden_size, enc,
-        encoder_lens.to(device=enc.device, dtype=torch.int32).contiguous(), h0, c0, self.output_mask,
+        encoder_lens.to(device=enc.device, dtype=torch.int32).contiguous(), h0, c0, self.output_mask, drop_mask,
         *self._params())
-    final_state = (h_n.unsqueeze(0), c_n.unsqueeze(0)) if mode == 1 else h_n.unsqueeze(0)
+    final_state = (h_n, c_n) if mode == 1 else h_n
     return lp, sampled, final_state
 
   def forward(self, input_, previous_state, encoder_lens, encoder_hidden_states):

@@ -408,8 +408,10 @@ __global__ void dec_colsum_final_kernel(const float* __restrict__ partial, float
 }
 
 struct Sizes {
-  int B, L, T, Hd, Cd, V, A, G, type;
+  int B, L, T, Hd, Cd, V, A, G, type, NL;
 };
+constexpr int MAXL = LR_DEC_MAX_LAYERS;
+inline int gates_of_mode(int mode) { return mode == LR_RNN_GRU ? 3 : (mode == LR_RNN_LSTM ? 4 : 1); }
 
 size_t max_gemm_ws(const int (*dims)[3], int n) {
   size_t gb = 0;
@@ -421,8 +423,13 @@ size_t max_gemm_ws(const int (*dims)[3], int n) {
 }
 
 // ---- reserve (forward -> backward) layout, in floats; per-(sample, step) buffers are [B][L][...] ------
+// Per layer k of the decoder's RNN stack: gate buffer, extra (GRU W_hn h + b_hn / LSTM c), output
+// states hs, two packed-state parity slots, packed W_hh, folded bias.  The head and the attention read
+// the TOP layer's states: hs = hsl[NL-1].
 struct Res {
-  size_t EW, biasf, gates, extra, hs, hp, wp, ids, logits, wts, ctx, pre, aux1, aux2, ph, gemm, total;
+  size_t EW, ids, logits, wts, ctx, pre, aux1, aux2, ph, gemm, total;
+  size_t biasf[MAXL], gates[MAXL], extra[MAXL], hsl[MAXL], hp[MAXL], wp[MAXL], xm[MAXL];
+  size_t hs;
   size_t hp_slot, gemm_bytes;
 };
 Res res_layout(const Sizes& z) {
@@ -432,13 +439,18 @@ Res res_layout(const Sizes& z) {
   size_t o = 0;
   auto take = [&](size_t n) { size_t at = o; o += (n + 63) / 64 * 64; return at; };
   r.EW = take((size_t)z.V * GH);
-  r.biasf = take(GH);
-  r.gates = take(BL * GH);
-  r.extra = take(BL * z.Hd);
-  r.hs = take(BL * z.Hd);
   r.hp_slot = lr_rnn_packed_state_floats(z.B, z.Hd);
-  r.hp = take(2 * r.hp_slot);
-  r.wp = take(lr_rnn_packed_w_floats(z.G, z.Hd));
+  for (int k = 0; k < MAXL; ++k) r.biasf[k] = r.gates[k] = r.extra[k] = r.hsl[k] = r.hp[k] = r.wp[k] = r.xm[k] = 0;
+  for (int k = 0; k < z.NL; ++k) {
+    r.biasf[k] = take(GH);
+    r.gates[k] = take(BL * GH);
+    r.extra[k] = take(BL * z.Hd);
+    r.hsl[k] = take(BL * z.Hd);
+    r.hp[k] = take(2 * r.hp_slot);
+    r.wp[k] = take(lr_rnn_packed_w_floats(z.G, z.Hd));
+    r.xm[k] = take(k + 1 < z.NL ? BL * z.Hd : 0);   // dropout-masked copy of hsl[k] (input of layer k+1)
+  }
+  r.hs = r.hsl[z.NL - 1];
   r.ids = take(BL);
   r.logits = take(attn ? BL * z.T : 0);    // raw attention logits
   r.wts = take(attn ? BL * z.T : 0);       // attention weights
@@ -449,8 +461,8 @@ Res res_layout(const Sizes& z) {
   r.ph = take(z.type == ATT_CONCAT ? BL * z.A : 0);
   const int a = z.A > 0 ? z.A : 1;
   const int dims[][3] = {{z.V, (int)GH, z.Cd}, {(int)BT, z.Hd, z.Hd}, {(int)BT, a, z.Hd}, {(int)BL, z.Hd, z.Hd},
-                         {(int)BL, a, z.Hd}};
-  r.gemm_bytes = max_gemm_ws(dims, 5);
+                         {(int)BL, a, z.Hd}, {(int)BL, (int)GH, z.Hd}};
+  r.gemm_bytes = max_gemm_ws(dims, 6);
   r.gemm = take((r.gemm_bytes + 3) / 4);
   r.total = o;
   return r;
@@ -492,17 +504,31 @@ Wsp ws_layout(const Sizes& z) {
   const int dims[][3] = {{(int)BL, z.Hd, z.V}, {(int)BL, z.Hd, z.Hd}, {z.Hd, z.Hd, (int)BL}, {z.V, z.Hd, (int)BL},
                          {(int)GH, z.Hd, (int)BL}, {(int)GH, z.Cd, z.V}, {z.V, z.Cd, (int)GH},
                          {(int)BT, z.Hd, z.Hd}, {z.Hd, z.Hd, (int)BT}, {a, z.Hd, (int)BT}, {(int)BT, z.Hd, a},
-                         {a, z.Hd, (int)BL}, {(int)BL, z.Hd, a}, {z.Hd, 1, (int)BL}, {z.Hd, 1, (int)BT}};
-  w.gemm_bytes = max_gemm_ws(dims, 15);
+                         {a, z.Hd, (int)BL}, {(int)BL, z.Hd, a}, {z.Hd, 1, (int)BL}, {z.Hd, 1, (int)BT},
+                         {(int)GH, z.Hd, (int)BL}, {(int)BL, z.Hd, (int)GH}};
+  w.gemm_bytes = max_gemm_ws(dims, 17);
   w.gemm = take((w.gemm_bytes + 3) / 4);
   w.total = o;
   return w;
 }
 
-bool sizes_ok(int mode, int type, int B, int L, int T, int Hd, int Cd, int V, int A) {
-  return (mode == LR_RNN_GRU || mode == LR_RNN_LSTM) && type >= ATT_NONE && type <= ATT_CONCAT && B > 0 &&
-         B <= 65535 && L > 0 && L <= 65535 && T > 0 && Hd > 0 && Hd % 4 == 0 && Cd > 0 && V > 0 && V <= 1024 &&
-         (type != ATT_CONCAT || A > 0);
+bool sizes_ok(int mode, int type, int B, int L, int T, int Hd, int Cd, int V, int A, int NL = 1) {
+  return (mode == LR_RNN_GRU || mode == LR_RNN_LSTM || mode == LR_RNN_TANH) && type >= ATT_NONE &&
+         type <= ATT_CONCAT && B > 0 && B <= 65535 && L > 0 && L <= 65535 && T > 0 && Hd > 0 && Hd % 4 == 0 &&
+         Cd > 0 && V > 0 && V <= 1024 && (type != ATT_CONCAT || A > 0) && NL >= 1 && NL <= MAXL;
+}
+inline int layers_of(const lr_decoder_upper* up) { return up ? up->num_layers : 1; }
+// rows [i0, i1) of every sample: out = x * mask (inter-layer dropout multipliers), 4 floats per thread
+__global__ void dec_mask_rows_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                     float* __restrict__ out, int L, int Hd, int i0, int n) {
+  const int b = blockIdx.y;
+  const int64_t base = ((int64_t)b * L + i0) * Hd;
+  const int64_t total4 = (int64_t)n * Hd / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(x + base)[i];
+    const float4 m = reinterpret_cast<const float4*>(mask + base)[i];
+    reinterpret_cast<float4*>(out + base)[i] = make_float4(a.x * m.x, a.y * m.y, a.z * m.z, a.w * m.w);
+  }
 }
 
 #define LR_TRY(expr)              \
@@ -522,33 +548,36 @@ int colsum_into(const float* x, int ld, int rows, int ncol, float* scratch, floa
 
 }  // namespace
 
-extern "C" size_t lr_decoder_reserve_bytes(int mode, int attn_type, int B, int L, int T, int Hd, int Cd, int V,
-                                           int A) {
-  if (!sizes_ok(mode, attn_type, B, L, T, Hd, Cd, V, A)) return 0;
-  const Sizes z = {B, L, T, Hd, Cd, V, A, mode == LR_RNN_GRU ? 3 : 4, attn_type};
+extern "C" size_t lr_decoder_reserve_bytes(int mode, int attn_type, int num_layers, int B, int L, int T, int Hd,
+                                           int Cd, int V, int A) {
+  if (!sizes_ok(mode, attn_type, B, L, T, Hd, Cd, V, A, num_layers)) return 0;
+  const Sizes z = {B, L, T, Hd, Cd, V, A, gates_of_mode(mode), attn_type, num_layers};
   return res_layout(z).total * sizeof(float);
 }
 
-extern "C" size_t lr_decoder_workspace_bytes(int mode, int attn_type, int B, int L, int T, int Hd, int Cd, int V,
-                                             int A) {
-  if (!sizes_ok(mode, attn_type, B, L, T, Hd, Cd, V, A)) return 0;
-  const Sizes z = {B, L, T, Hd, Cd, V, A, mode == LR_RNN_GRU ? 3 : 4, attn_type};
+extern "C" size_t lr_decoder_workspace_bytes(int mode, int attn_type, int num_layers, int B, int L, int T, int Hd,
+                                             int Cd, int V, int A) {
+  if (!sizes_ok(mode, attn_type, B, L, T, Hd, Cd, V, A, num_layers)) return 0;
+  const Sizes z = {B, L, T, Hd, Cd, V, A, gates_of_mode(mode), attn_type, num_layers};
   return ws_layout(z).total * sizeof(float);
 }
 
-extern "C" int lr_decoder_forward(int mode, int attn_type, const lr_decoder_params* p, const int32_t* tokens,
+extern "C" int lr_decoder_forward(int mode, int attn_type, const lr_decoder_params* p, const lr_decoder_upper* up,
+                                  const int32_t* tokens,
                                   const uint8_t* teacher_forced_host, const float* enc, const int32_t* enc_lens,
                                   const float* h0, const float* c0, const int32_t* step_lens, uint64_t seed,
                                   float* log_probs, int32_t* sampled, float* h_n, float* c_n, void* reserve,
                                   size_t reserve_bytes, int B, int L, int T, int Hd, int Cd, int V, int A,
                                   lr_stream_t stream_) {
-  LR_CHECK_ARG(sizes_ok(mode, attn_type, B, L, T, Hd, Cd, V, A));
+  const int NL = layers_of(up);
+  LR_CHECK_ARG(sizes_ok(mode, attn_type, B, L, T, Hd, Cd, V, A, NL));
   LR_CHECK_ARG(p && tokens && teacher_forced_host && enc && enc_lens && h0 && step_lens && log_probs && sampled &&
                reserve);
   LR_CHECK_ARG(p->emb && p->w_ih && p->w_hh && p->b_ih && p->b_hh && p->w_o && p->b_o && p->out_mask);
   LR_CHECK_ARG(attn_type == ATT_NONE || (p->w_c && p->b_c));
-  LR_CHECK_ARG(mode == LR_RNN_GRU || c0);
-  const Sizes z = {B, L, T, Hd, Cd, V, A, mode == LR_RNN_GRU ? 3 : 4, attn_type};
+  LR_CHECK_ARG(mode != LR_RNN_LSTM || c0);
+  for (int k = 1; k < NL; ++k) LR_CHECK_ARG(up->w_ih[k - 1] && up->w_hh[k - 1] && up->b_ih[k - 1] && up->b_hh[k - 1]);
+  const Sizes z = {B, L, T, Hd, Cd, V, A, gates_of_mode(mode), attn_type, NL};
   const Res r = res_layout(z);
   if (reserve_bytes < r.total * sizeof(float)) return LR_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
@@ -556,9 +585,19 @@ extern "C" int lr_decoder_forward(int mode, int attn_type, const lr_decoder_para
   const int G = z.G, GH = G * Hd, BL = B * L, R = B * T;
   const bool attn = attn_type != ATT_NONE;
   float* EW = base + r.EW;
-  float* gates = base + r.gates;
-  float* hs = base + r.hs;
-  float* hp = base + r.hp;
+  float* hs = base + r.hs;          // the top layer's states
+  const size_t state = (size_t)B * Hd;   // floats per layer of h0 / c0 / h_n / c_n
+  const float* w_hh[MAXL];
+  const float* w_ihu[MAXL];
+  const float* b_ihl[MAXL];
+  const float* b_hhl[MAXL];
+  for (int k = 0; k < NL; ++k) {
+    w_hh[k] = k == 0 ? p->w_hh : up->w_hh[k - 1];
+    w_ihu[k] = k == 0 ? nullptr : up->w_ih[k - 1];
+    b_ihl[k] = k == 0 ? p->b_ih : up->b_ih[k - 1];
+    b_hhl[k] = k == 0 ? p->b_hh : up->b_hh[k - 1];
+  }
+  const float* drop = (up && NL > 1) ? up->drop_mask : nullptr;   // [NL-1][B][L][Hd] or NULL
   float* logits = base + r.logits;
   float* wts = base + r.wts;
   float* ctx = base + r.ctx;
@@ -567,14 +606,17 @@ extern "C" int lr_decoder_forward(int mode, int attn_type, const lr_decoder_para
   void* gws = base + r.gemm;
   int32_t* ids = (int32_t*)(base + r.ids);
 
-  // table of input projections: EW = emb @ W_ih^T + folded bias
-  LR_TRY(lr_rnn_fold_bias(p->b_ih, p->b_hh, base + r.biasf, G, Hd, stream));
-  LR_TRY(lr_sgemm_impl(0, 1, V, GH, Cd, 1.f, p->emb, Cd, p->w_ih, Cd, 0.f, EW, GH, base + r.biasf, 0, 0, gws,
+  // table of input projections of layer 0: EW = emb @ W_ih^T + folded bias
+  for (int k = 0; k < NL; ++k) {
+    LR_TRY(lr_rnn_fold_bias(b_ihl[k], b_hhl[k], base + r.biasf[k], G, Hd, stream));
+    LR_TRY(lr_rnn_pack_w(w_hh[k], base + r.wp[k], G, Hd, 0, stream));
+    lr_clear_error();
+    if (hipMemsetAsync(base + r.hp[k], 0, 2 * r.hp_slot * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
+    // step 0 reads parity (0+1)&1 = 1
+    LR_TRY(lr_rnn_pack_state(h0 + k * state, base + r.hp[k] + r.hp_slot, B, Hd, stream));
+  }
+  LR_TRY(lr_sgemm_impl(0, 1, V, GH, Cd, 1.f, p->emb, Cd, p->w_ih, Cd, 0.f, EW, GH, base + r.biasf[0], 0, 0, gws,
                        r.gemm_bytes, stream));
-  LR_TRY(lr_rnn_pack_w(p->w_hh, base + r.wp, G, Hd, 0, stream));
-  lr_clear_error();
-  if (hipMemsetAsync(hp, 0, 2 * r.hp_slot * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
-  LR_TRY(lr_rnn_pack_state(h0, hp + r.hp_slot, B, Hd, stream));   // step 0 reads parity (0+1)&1 = 1
 
   // step-independent halves of the attention logits
   const float* src = nullptr;     // dot: enc; general: GE = enc W_g        [B][T][Hd]
@@ -648,52 +690,78 @@ extern "C" int lr_decoder_forward(int mode, int attn_type, const lr_decoder_para
     return lr_launch_status();
   };
 
+  // A run of steps whose input tokens are known goes through the stack LAYER by layer (a layer's input
+  // projection over the run is one GEMM on the layer below's outputs, nn.GRU/LSTM(num_layers) semantics:
+  // better_model.py:147-148,181); a sampled-input step is a run of one.
   int done = 0;   // steps whose head has been computed
   for (int i = 0; i < L;) {
     int run = 1;
     if (teacher_forced_host[i] || i == 0) {
       while (i + run < L && teacher_forced_host[i + run]) ++run;
       LR_LAUNCH(dec_gather_kernel, dim3(run, B), dim3(256), 0, stream, (const float*)EW, tokens,
-                (const int32_t*)sampled, ids, gates, L, GH, V, i, 1);
+                (const int32_t*)sampled, ids, base + r.gates[0], L, GH, V, i, 1);
     } else {
       LR_TRY(flush(done, i));   // the input of step i is the sample drawn from step i-1's output
       done = i;
       LR_LAUNCH(dec_gather_kernel, dim3(1, B), dim3(256), 0, stream, (const float*)EW, tokens,
-                (const int32_t*)sampled, ids, gates, L, GH, V, i, 0);
+                (const int32_t*)sampled, ids, base + r.gates[0], L, GH, V, i, 0);
     }
     LR_TRY(lr_launch_status());
-    for (int s = i; s < i + run; ++s)
-      LR_TRY(lr_rnn_step_fwd(G, gates, base + r.extra, hs, hp, step_lens, base + r.wp, p->b_hh, h0, c0, B, L, Hd, s,
-                             stream));
+    for (int k = 0; k < NL; ++k) {
+      if (k > 0) {
+        const float* x = base + r.hsl[k - 1];
+        if (drop) {   // nn.GRU/LSTM(dropout=p): the outputs of every layer but the last are dropped out
+          int gx_ = (int)(((int64_t)run * Hd / 4 + 255) / 256);
+          if (gx_ > 64) gx_ = 64;
+          LR_LAUNCH(dec_mask_rows_kernel, dim3(gx_, B), dim3(256), 0, stream, x, drop + (size_t)(k - 1) * BL * Hd,
+                    base + r.xm[k - 1], L, Hd, i, run);
+          LR_TRY(lr_launch_status());
+          x = base + r.xm[k - 1];
+        }
+        LR_TRY(rows_gemm(GH, Hd, x, Hd, w_ihu[k], Hd, 0.f, base + r.gates[k], GH, base + r.biasf[k], i, i + run));
+      }
+      for (int s = i; s < i + run; ++s)
+        LR_TRY(lr_rnn_step_fwd(G, base + r.gates[k], base + r.extra[k], base + r.hsl[k], base + r.hp[k], step_lens,
+                               base + r.wp[k], b_hhl[k], h0 + k * state, c0 ? c0 + k * state : nullptr, B, L, Hd, s,
+                               stream));
+    }
     i += run;
   }
   LR_TRY(flush(done, L));
   // state after the last step (what the reference's step returns as final_state, better_model.py:181)
   lr_clear_error();
-  if (h_n && hipMemcpy2DAsync(h_n, (size_t)Hd * sizeof(float), hs + (size_t)(L - 1) * Hd,
-                              (size_t)L * Hd * sizeof(float), (size_t)Hd * sizeof(float), B,
-                              hipMemcpyDeviceToDevice, stream) != hipSuccess)
-    return LR_ERR_LAUNCH;
-  if (c_n && G == 4 && hipMemcpy2DAsync(c_n, (size_t)Hd * sizeof(float), base + r.extra + (size_t)(L - 1) * Hd,
-                                        (size_t)L * Hd * sizeof(float), (size_t)Hd * sizeof(float), B,
-                                        hipMemcpyDeviceToDevice, stream) != hipSuccess)
-    return LR_ERR_LAUNCH;
+  for (int k = 0; k < NL; ++k) {
+    if (h_n && hipMemcpy2DAsync(h_n + k * state, (size_t)Hd * sizeof(float), base + r.hsl[k] + (size_t)(L - 1) * Hd,
+                                (size_t)L * Hd * sizeof(float), (size_t)Hd * sizeof(float), B,
+                                hipMemcpyDeviceToDevice, stream) != hipSuccess)
+      return LR_ERR_LAUNCH;
+    if (c_n && G == 4 && hipMemcpy2DAsync(c_n + k * state, (size_t)Hd * sizeof(float),
+                                          base + r.extra[k] + (size_t)(L - 1) * Hd, (size_t)L * Hd * sizeof(float),
+                                          (size_t)Hd * sizeof(float), B, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+      return LR_ERR_LAUNCH;
+  }
   return LR_OK;
 }
 
-extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_params* p, const lr_decoder_grads* g,
+extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_params* p, const lr_decoder_upper* up,
+                                   const lr_decoder_grads* g, const lr_decoder_upper_grads* gup,
                                    const float* enc, const int32_t* enc_lens, const float* h0, const float* c0,
                                    const int32_t* step_lens, const float* log_probs, const float* d_log_probs,
                                    const float* dh_n, const float* dc_n, float* d_enc, float* dh0, float* dc0,
                                    const void* reserve, size_t reserve_bytes,
                                    void* workspace, size_t workspace_bytes, int accumulate, int B, int L, int T,
                                    int Hd, int Cd, int V, int A, lr_stream_t stream_) {
-  LR_CHECK_ARG(sizes_ok(mode, attn_type, B, L, T, Hd, Cd, V, A));
+  const int NL = layers_of(up);
+  LR_CHECK_ARG(sizes_ok(mode, attn_type, B, L, T, Hd, Cd, V, A, NL));
   LR_CHECK_ARG(p && g && enc && enc_lens && h0 && step_lens && log_probs && d_log_probs && d_enc && dh0 &&
                reserve && workspace);
   LR_CHECK_ARG(g->emb && g->w_ih && g->w_hh && g->b_ih && g->b_hh && g->w_o && g->b_o);
-  LR_CHECK_ARG(mode == LR_RNN_GRU || (c0 && dc0));
-  const Sizes z = {B, L, T, Hd, Cd, V, A, mode == LR_RNN_GRU ? 3 : 4, attn_type};
+  LR_CHECK_ARG(mode != LR_RNN_LSTM || (c0 && dc0));
+  LR_CHECK_ARG(NL == 1 || gup);
+  for (int k = 1; k < NL; ++k)
+    LR_CHECK_ARG(up->w_ih[k - 1] && up->w_hh[k - 1] && gup->w_ih[k - 1] && gup->w_hh[k - 1] && gup->b_ih[k - 1] &&
+                 gup->b_hh[k - 1]);
+  const Sizes z = {B, L, T, Hd, Cd, V, A, gates_of_mode(mode), attn_type, NL};
   const Res r = res_layout(z);
   const Wsp w = ws_layout(z);
   if (reserve_bytes < r.total * sizeof(float)) return LR_ERR_WORKSPACE;
@@ -720,9 +788,8 @@ extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_par
   float* colsum = wb + w.colsum;
   if ((size_t)L * T * sizeof(float) > 60 * 1024 && attn_type == ATT_CONCAT) return LR_ERR_UNSUPPORTED;
 
-  LR_TRY(lr_rnn_pack_w(p->w_hh, wb + w.wpT, G, Hd, 1, stream));
-  lr_clear_error();
-  if (hipMemsetAsync(wb + w.dgp, 0, 2 * w.dgp_slot * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
+  const size_t state = (size_t)B * Hd;
+  const float* drop = (up && NL > 1) ? up->drop_mask : nullptr;
 
   // ---- output head, all (sample, step) rows at once -------------------------------------------------
   LR_LAUNCH(dec_out_bwd_rows_kernel, dim3((BL + 3) / 4), dim3(256), 0, stream, d_log_probs, log_probs, dlogits, BL, V);
@@ -811,33 +878,61 @@ extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_par
     }
   }
 
-  // ---- the only sequential part: the RNN backward over the L steps --------------------------------
-  for (int s = 0; s < L; ++s)
-    LR_TRY(lr_rnn_step_bwd(G, rb + r.gates, rb + r.extra, hs, dy, dh_n, dc_n, dG, wb + w.dcar, wb + w.dgp, step_lens,
-                           wb + w.wpT, h0, c0, B, L, Hd, s, stream));
-  // gradient into the initial state (the encoder's final state)
-  LR_TRY(lr_rnn_dh0(G, wb + w.dcar, wb + w.dgp + (size_t)((L - 1) & 1) * w.dgp_slot, wb + w.wpT, dh0, dc0, B, L, Hd,
-                    stream));
-
-  // ---- weight gradients: one GEMM each over all (sample, step) rows ---------------------------------
+  // ---- the only sequential part: the RNN backward over the L steps, top layer first -----------------
   const int ldg = 4 * Hd;
-  // W_hh: h_prev of step t is hs[b][t-1]; step 0 used h0
-  if (G == 3) {
-    LR_TRY(lr_sgemm_impl(1, 0, 2 * Hd, Hd, BL, 1.f, dG, ldg, hs, Hd, beta, g->w_hh, Hd, nullptr, -1, L, gws,
-                         w.gemm_bytes, stream));
-    LR_TRY(lr_sgemm_impl(1, 0, Hd, Hd, BL, 1.f, dG + 3 * Hd, ldg, hs, Hd, beta, g->w_hh + (size_t)2 * Hd * Hd, Hd,
-                         nullptr, -1, L, gws, w.gemm_bytes, stream));
-    LR_TRY(lr_sgemm_impl(1, 0, 2 * Hd, Hd, B, 1.f, dG, L * ldg, h0, Hd, 1.f, g->w_hh, Hd, nullptr, 0, 0, nullptr, 0,
-                         stream));
-    LR_TRY(lr_sgemm_impl(1, 0, Hd, Hd, B, 1.f, dG + 3 * Hd, L * ldg, h0, Hd, 1.f, g->w_hh + (size_t)2 * Hd * Hd, Hd,
-                         nullptr, 0, 0, nullptr, 0, stream));
-  } else {
-    LR_TRY(lr_sgemm_impl(1, 0, GH, Hd, BL, 1.f, dG, ldg, hs, Hd, beta, g->w_hh, Hd, nullptr, -1, L, gws,
-                         w.gemm_bytes, stream));
-    LR_TRY(lr_sgemm_impl(1, 0, GH, Hd, B, 1.f, dG, L * ldg, h0, Hd, 1.f, g->w_hh, Hd, nullptr, 0, 0, nullptr, 0,
-                         stream));
+  for (int k = NL - 1; k >= 0; --k) {
+    const float* w_hh_k = k == 0 ? p->w_hh : up->w_hh[k - 1];
+    float* gw_hh = k == 0 ? g->w_hh : gup->w_hh[k - 1];
+    float* gb_ih = k == 0 ? g->b_ih : gup->b_ih[k - 1];
+    float* gb_hh = k == 0 ? g->b_hh : gup->b_hh[k - 1];
+    const float* hs_k = rb + r.hsl[k];
+    const float* h0_k = h0 + k * state;
+    const float* c0_k = c0 ? c0 + k * state : nullptr;
+    LR_TRY(lr_rnn_pack_w(w_hh_k, wb + w.wpT, G, Hd, 1, stream));
+    lr_clear_error();
+    if (hipMemsetAsync(wb + w.dgp, 0, 2 * w.dgp_slot * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
+    for (int s2 = 0; s2 < L; ++s2)
+      LR_TRY(lr_rnn_step_bwd(G, rb + r.gates[k], rb + r.extra[k], hs_k, dy, dh_n ? dh_n + k * state : nullptr,
+                             dc_n ? dc_n + k * state : nullptr, dG, wb + w.dcar, wb + w.dgp, step_lens, wb + w.wpT,
+                             h0_k, c0_k, B, L, Hd, s2, stream));
+    // gradient into the initial state (the encoder's final state of this layer)
+    LR_TRY(lr_rnn_dh0(G, wb + w.dcar, wb + w.dgp + (size_t)((L - 1) & 1) * w.dgp_slot, wb + w.wpT, dh0 + k * state,
+                      dc0 ? dc0 + k * state : nullptr, B, L, Hd, stream));
+    // W_hh: h_prev of step t is hs[b][t-1]; step 0 used h0
+    if (G == 3) {
+      LR_TRY(lr_sgemm_impl(1, 0, 2 * Hd, Hd, BL, 1.f, dG, ldg, hs_k, Hd, beta, gw_hh, Hd, nullptr, -1, L, gws,
+                           w.gemm_bytes, stream));
+      LR_TRY(lr_sgemm_impl(1, 0, Hd, Hd, BL, 1.f, dG + 3 * Hd, ldg, hs_k, Hd, beta, gw_hh + (size_t)2 * Hd * Hd, Hd,
+                           nullptr, -1, L, gws, w.gemm_bytes, stream));
+      LR_TRY(lr_sgemm_impl(1, 0, 2 * Hd, Hd, B, 1.f, dG, L * ldg, h0_k, Hd, 1.f, gw_hh, Hd, nullptr, 0, 0, nullptr, 0,
+                           stream));
+      LR_TRY(lr_sgemm_impl(1, 0, Hd, Hd, B, 1.f, dG + 3 * Hd, L * ldg, h0_k, Hd, 1.f, gw_hh + (size_t)2 * Hd * Hd, Hd,
+                           nullptr, 0, 0, nullptr, 0, stream));
+    } else {
+      LR_TRY(lr_sgemm_impl(1, 0, GH, Hd, BL, 1.f, dG, ldg, hs_k, Hd, beta, gw_hh, Hd, nullptr, -1, L, gws,
+                           w.gemm_bytes, stream));
+      LR_TRY(lr_sgemm_impl(1, 0, GH, Hd, B, 1.f, dG, L * ldg, h0_k, Hd, 1.f, gw_hh, Hd, nullptr, 0, 0, nullptr, 0,
+                           stream));
+    }
+    LR_TRY(lr_rnn_bias_grads(dG, colsum, gb_ih, gb_hh, BL, Hd, G, accumulate, stream));
+    if (k > 0) {
+      // input projection of an upper layer: x = (dropped-out) states of the layer below
+      const float* x = drop ? rb + r.xm[k - 1] : rb + r.hsl[k - 1];
+      LR_TRY(lr_sgemm_impl(1, 0, GH, Hd, BL, 1.f, dG, ldg, x, Hd, beta, gup->w_ih[k - 1], Hd, nullptr, 0, 0, gws,
+                           w.gemm_bytes, stream));
+      // ... and the gradient that reaches the layer below through it replaces dy
+      LR_TRY(lr_sgemm_impl(0, 0, BL, Hd, GH, 1.f, dG, ldg, up->w_ih[k - 1], Hd, 0.f, dy, Hd, nullptr, 0, 0, gws,
+                           w.gemm_bytes, stream));
+      if (drop) {
+        int gx_ = (int)(((int64_t)L * Hd / 4 + 255) / 256);
+        if (gx_ > 64) gx_ = 64;
+        LR_LAUNCH(dec_mask_rows_kernel, dim3(gx_, B), dim3(256), 0, stream, (const float*)dy,
+                  drop + (size_t)(k - 1) * BL * Hd, dy, L, Hd, 0, L);
+        LR_TRY(lr_launch_status());
+      }
+    }
   }
-  LR_TRY(lr_rnn_bias_grads(dG, colsum, g->b_ih, g->b_hh, BL, Hd, G, accumulate, stream));
+  // (the loop ends on layer 0: dG now holds layer 0's gate gradients for the embedding path below)
   // embedding / W_ih through the table: dEW[v] = sum of the dG_x rows that used token v
   LR_LAUNCH(dec_scatter_dew_kernel, dim3(V, (GH + 255) / 256), dim3(256), 0, stream, (const float*)dG, ids,
             wb + w.dEW, BL, G, Hd);

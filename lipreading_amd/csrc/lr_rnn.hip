@@ -112,7 +112,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(float* gates, flo
     len_b = lens[b];
 #pragma unroll
     for (int g = 0; g < G; ++g) gx[g] = go[g * H];
-    if (G == 3) {
+    if (G == 1) {
+      // tanh RNN: the previous state only enters through the recurrent product
+    } else if (G == 3) {
       bhn = p.b[d][2 * H + j];
       if (in_seq) prev_own = y[btp * DH + d * H + j];              // h_{t-1}
       else if (has_prev) prev_own = p.h0[((int64_t)d * B + b) * H + j];
@@ -178,11 +180,17 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(float* gates, flo
               (bl + 16 * (jl >> 2)) * 4 + (jl & 3);
   if (t >= len_b) {  // padded position: zero output, zero carried state
     *yo = 0.f;
-    *eo = 0.f;
+    if (G != 1) *eo = 0.f;
     *ho = 0.f;
     return;
   }
-  if (G == 3) {
+  if (G == 1) {
+    // nn.RNN (tanh): h' = tanh(W_ih x + b_ih + W_hh h + b_hh); the gate buffer keeps h' for backward
+    const float h = tanhf(gx[0] + s[0]);
+    go[0] = h;
+    *yo = h;
+    *ho = h;
+  } else if (G == 3) {
     const float hn = s[2] + bhn;
     const float r = lr_sigmoid(gx[0] + s[0]);
     const float z = lr_sigmoid(gx[1] + s[1]);
@@ -248,8 +256,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(
     const float* gi = gates + (bt * D + d) * (int64_t)GH + j;
 #pragma unroll
     for (int g = 0; g < G; ++g) gv[g] = gi[g * H];
-    ex = extra[(bt * D + d) * H + j];                       // GRU: W_hn h + b_hn ; LSTM: c_t
-    if (has_prev) prev = G == 3 ? y[btp * DH + d * H + j] : extra[(btp * D + d) * H + j];
+    if (G != 1) ex = extra[(bt * D + d) * H + j];           // GRU: W_hn h + b_hn ; LSTM: c_t
+    if (G == 1) {
+    } else if (has_prev) prev = G == 3 ? y[btp * DH + d * H + j] : extra[(btp * D + d) * H + j];
     else if (init_prev) {
       const float* src = G == 3 ? p.h0 : p.c0;
       if (src) prev = src[((int64_t)d * B + b) * H + j];
@@ -310,7 +319,16 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(
   }
   const bool is_last = d == 0 ? (t == len_b - 1) : (t == 0);  // where the final state was read
   if (is_last) dh += inj_h;
-  if (G == 3) {
+  if (G == 1) {
+    const float h = gv[0];
+    const float dpre = dh * (1.f - h * h);
+    dgo[0] = dpre;
+    dgo[H] = 0.f;
+    dgo[2 * H] = 0.f;
+    dgo[3 * H] = 0.f;
+    *dco = 0.f;
+    po[0] = dpre;
+  } else if (G == 3) {
     dh += car;  // dh_{t+1} * z_{t+1}
     const float r = gv[0], z = gv[1], n = gv[2], hn = ex, hp = prev;
     const float dn_pre = dh * (1.f - z) * (1.f - n * n);
@@ -356,7 +374,7 @@ __global__ void fold_bias_kernel(const float* __restrict__ b_ih, const float* __
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= G * H) return;
   float v = b_ih[i];
-  if (G == 4 || i < 2 * H) v += b_hh[i];
+  if (G != 3 || i < 2 * H) v += b_hh[i];
   out[i] = v;
 }
 
@@ -419,7 +437,12 @@ __global__ void bias_grad_final_kernel(const float* __restrict__ partial, BiasPt
   const int d = col / (4 * H), slot = (col / H) & 3, j = col % H;
   float* ih = nullptr;
   float* hh = nullptr;
-  if (G == 4) {
+  if (G == 1) {
+    if (slot == 0) {
+      ih = p.db_ih[d] + j;
+      hh = p.db_hh[d] + j;
+    }
+  } else if (G == 4) {
     ih = p.db_ih[d] + slot * H + j;
     hh = p.db_hh[d] + slot * H + j;
   } else {
@@ -482,7 +505,9 @@ __global__ __launch_bounds__(NW * 64) void rnn_dh0_kernel(const float* __restric
 #pragma unroll
   for (int w = 0; w < NW; ++w) dh += red[(w * TILE + bl) * RED_LD + jl];
   const float car = dcar[((int64_t)b * T) * H + j];   // t = 0, D = 1
-  if (G == 3) {
+  if (G == 1) {
+    dh0[(int64_t)b * H + j] = dh;
+  } else if (G == 3) {
     dh0[(int64_t)b * H + j] = dh + car;
   } else {
     dh0[(int64_t)b * H + j] = dh;
@@ -539,12 +564,13 @@ WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
 }
 
 inline int cell_of(int mode) { return mode & LR_RNN_CELL_MASK; }
+inline int gates_of(int mode) { return cell_of(mode) == LR_RNN_GRU ? 3 : (cell_of(mode) == LR_RNN_LSTM ? 4 : 1); }
 inline bool proj_x3(int mode) { return (mode & LR_RNN_PROJ_BF16X3) != 0; }
 inline bool x_exact(int mode) { return (mode & LR_RNN_INPUT_BF16_EXACT) != 0; }
 inline bool recur_bf16(int mode) { return (mode & LR_RNN_RECUR_BF16) != 0; }
 inline bool x_stored_bf16(int mode) { return (mode & LR_RNN_INPUT_STORED_BF16) != 0; }
 bool dims_ok(int mode, int B, int T, int I, int H, int D) {
-  return (cell_of(mode) == LR_RNN_GRU || cell_of(mode) == LR_RNN_LSTM) &&
+  return (cell_of(mode) == LR_RNN_GRU || cell_of(mode) == LR_RNN_LSTM || cell_of(mode) == LR_RNN_TANH) &&
          (mode & ~(LR_RNN_CELL_MASK | LR_RNN_PROJ_BF16X3 | LR_RNN_INPUT_BF16_EXACT | LR_RNN_RECUR_BF16 |
                    LR_RNN_INPUT_STORED_BF16)) == 0 &&
          // a bf16-stored input only makes sense on the split-bf16 projection, as an exact operand
@@ -561,17 +587,17 @@ size_t x3_ws_floats(int G, int B, int T, int I, int H, int D) {
 
 extern "C" int lr_rnn_persistent_supported(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D)) return 0;
-  return lr_gru256_persist_supported(cell_of(mode) == LR_RNN_GRU ? 3 : 4, B, H);
+  return lr_gru256_persist_supported(gates_of(mode), B, H);
 }
 
 extern "C" size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D)) return 0;
-  return reserve_layout(cell_of(mode) == LR_RNN_GRU ? 3 : 4, B, T, I, H, D, proj_x3(mode)).total * sizeof(float);
+  return reserve_layout(gates_of(mode), B, T, I, H, D, proj_x3(mode)).total * sizeof(float);
 }
 
 extern "C" size_t lr_rnn_workspace_bytes(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D)) return 0;
-  const int G = cell_of(mode) == LR_RNN_GRU ? 3 : 4;
+  const int G = gates_of(mode);
   return ((ws_layout(G, B, T, I, H, D).total + 63) / 64 * 64 + (proj_x3(mode) ? x3_ws_floats(G, B, T, I, H, D) : 0)) *
          sizeof(float);
 }
@@ -584,8 +610,8 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
   LR_CHECK_ARG(dims_ok(mode, B, T, I, H, D));
   LR_CHECK_ARG(x && lens && w_ih && w_hh && b_ih && b_hh && y && h_n && reserve);
   if (H % 4 != 0) return LR_ERR_UNSUPPORTED;  // float4 operand loads along K
-  const int G = cell_of(mode) == LR_RNN_GRU ? 3 : 4;
-  LR_CHECK_ARG(G == 3 || c_n);
+  const int G = gates_of(mode);
+  LR_CHECK_ARG(G != 4 || c_n);
   for (int d = 0; d < D; ++d) LR_CHECK_ARG(w_ih[d] && w_hh[d] && b_ih[d] && b_hh[d]);
   const Layout l = reserve_layout(G, B, T, I, H, D, proj_x3(mode));
   if (reserve_bytes < l.total * sizeof(float)) return LR_ERR_WORKSPACE;
@@ -653,11 +679,13 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
       // sampled launch: the events carry the dispatch's own begin/end timestamps
       lr_clear_error();
       if (G == 3) hipExtLaunchKernelGGL(rnn_fwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, hp, lens, p, B, T, H, D, s);
-      else hipExtLaunchKernelGGL(rnn_fwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, hp, lens, p, B, T, H, D, s);
+      else if (G == 4) hipExtLaunchKernelGGL(rnn_fwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, hp, lens, p, B, T, H, D, s);
+      else hipExtLaunchKernelGGL(rnn_fwd_step_kernel<1>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, hp, lens, p, B, T, H, D, s);
       continue;
     }
     if (G == 3) LR_LAUNCH(rnn_fwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, D, s);
-    else LR_LAUNCH(rnn_fwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, D, s);
+    else if (G == 4) LR_LAUNCH(rnn_fwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, D, s);
+    else LR_LAUNCH(rnn_fwd_step_kernel<1>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, D, s);
   }
   int st = lr_launch_status();
   if (st != LR_OK) return st;
@@ -688,7 +716,7 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
   const float wbeta = accumulate ? 1.f : 0.f;
   LR_CHECK_ARG(dw_ih && dw_hh && db_ih && db_hh);
   if (H % 4 != 0) return LR_ERR_UNSUPPORTED;
-  const int G = cell_of(mode) == LR_RNN_GRU ? 3 : 4;
+  const int G = gates_of(mode);
   for (int d = 0; d < D; ++d)
     LR_CHECK_ARG(w_ih[d] && w_hh[d] && dw_ih[d] && dw_hh[d] && db_ih[d] && db_hh[d]);
   (void)b_ih;
@@ -744,11 +772,13 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
       if (s == T / 2 && lr_prof_next(LR_PROF_RNN_BWD, &e0, &e1)) {
         lr_clear_error();
         if (G == 3) hipExtLaunchKernelGGL(rnn_bwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
-        else hipExtLaunchKernelGGL(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
+        else if (G == 4) hipExtLaunchKernelGGL(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
+        else hipExtLaunchKernelGGL(rnn_bwd_step_kernel<1>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
         continue;
       }
       if (G == 3) LR_LAUNCH(rnn_bwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
-      else LR_LAUNCH(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
+      else if (G == 4) LR_LAUNCH(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
+      else LR_LAUNCH(rnn_bwd_step_kernel<1>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
     }
     st = lr_launch_status();
     if (st != LR_OK) return st;
@@ -878,7 +908,8 @@ int lr_rnn_step_fwd(int G, float* gates, float* extra, float* y, float* hp, cons
   p.c0 = c0;
   const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, 1);
   if (G == 3) LR_LAUNCH(rnn_fwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, 1, step);
-  else LR_LAUNCH(rnn_fwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, 1, step);
+  else if (G == 4) LR_LAUNCH(rnn_fwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, 1, step);
+  else LR_LAUNCH(rnn_fwd_step_kernel<1>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, 1, step);
   return lr_launch_status();
 }
 int lr_rnn_step_bwd(int G, const float* gates, const float* extra, const float* y, const float* dy,
@@ -892,14 +923,16 @@ int lr_rnn_step_bwd(int G, const float* gates, const float* extra, const float* 
   p.c0 = c0;
   const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, 1);
   if (G == 3) LR_LAUNCH(rnn_bwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, 1, step);
-  else LR_LAUNCH(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, 1, step);
+  else if (G == 4) LR_LAUNCH(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, 1, step);
+  else LR_LAUNCH(rnn_bwd_step_kernel<1>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, 1, step);
   return lr_launch_status();
 }
 int lr_rnn_dh0(int G, const float* dcar, const float* dgp_slot, const float* wpT, float* dh0, float* dc0, int B,
                int T, int H, hipStream_t stream) {
   const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, 1);
   if (G == 3) LR_LAUNCH(rnn_dh0_kernel<3>, grid, dim3(NW * 64), 0, stream, dcar, dgp_slot, wpT, dh0, dc0, B, T, H);
-  else LR_LAUNCH(rnn_dh0_kernel<4>, grid, dim3(NW * 64), 0, stream, dcar, dgp_slot, wpT, dh0, dc0, B, T, H);
+  else if (G == 4) LR_LAUNCH(rnn_dh0_kernel<4>, grid, dim3(NW * 64), 0, stream, dcar, dgp_slot, wpT, dh0, dc0, B, T, H);
+  else LR_LAUNCH(rnn_dh0_kernel<1>, grid, dim3(NW * 64), 0, stream, dcar, dgp_slot, wpT, dh0, dc0, B, T, H);
   return lr_launch_status();
 }
 int lr_rnn_bias_grads(const float* dG, float* partial, float* db_ih, float* db_hh, int rows, int H, int G,

@@ -49,13 +49,12 @@ class GradSync(object):
       last = g[-1]
       hi = flat.offsets[last + 1] if last + 1 < len(params) else flat.numel
       self.bounds.append((lo, hi))
-    self._pending = [len(g) for g in groups]
     self._owner = {}
     for gi, g in enumerate(groups):
       for pi in g:
         self._owner[pi] = gi
     self._works = []
-    self._launched = [False] * len(groups)
+    self._reset_round()
     self.side = torch.cuda.Stream() if self.overlap else None
     self._hooks = []
     self._direct_hook = None
@@ -67,7 +66,7 @@ class GradSync(object):
       # gradients written in place by the HIP backward kernels bypass AccumulateGrad
       from . import encoder as _encoder
       index = {id(p): i for i, p in enumerate(params)}
-      per_param = [self._make_hook(i) for i in range(len(params))]
+      per_param = [self._make_hook(i, kind=1) for i in range(len(params))]
 
       def direct_hook(ready):
         for p in ready:
@@ -90,22 +89,40 @@ class GradSync(object):
       groups.append([index[id(encoder.output_proj.weight)], index[id(encoder.output_proj.bias)]])
     return groups
 
-  def _make_hook(self, pi):
+  def _make_hook(self, pi, kind=0):
+    """kind 0: autograd's post-accumulate hook; kind 1: announced by a HIP backward that wrote the
+    gradient in place.  A parameter whose gradient is written in place is announced by BOTH in the same
+    backward (torch >= 2.x runs the post-accumulate hook even when the Function returned None), so
+    a parameter counts as ready on the first announcement of either kind; the SAME kind arriving twice
+    for a parameter is a second backward."""
     def hook(_param):
       if self._held or self._closed:
         return
       gi = self._owner[pi]
-      if self._launched[gi]:
-        # the bucket already holds the SUM over ranks: a gradient accumulated into it now would never
-        # be exchanged and the ranks would silently diverge
-        raise RuntimeError(
-            "GradSync: a gradient of bucket %d arrived after the bucket was all-reduced (a second "
-            "backward before sync()); run the extra backward passes under `with sync.hold():` so the "
-            "buckets go out when sync() is called, or call sync() between them" % gi)
+      self._count[kind][pi] += 1
+      if self._count[kind][pi] > 1:
+        if self._launched[gi]:
+          # the bucket already holds the SUM over ranks: a gradient accumulated into it now would never
+          # be exchanged and the ranks would silently diverge
+          raise RuntimeError(
+              "GradSync: a gradient of bucket %d arrived after the bucket was all-reduced (a second "
+              "backward before sync()); run the extra backward passes under `with sync.hold():` so the "
+              "buckets go out when sync() is called, or call sync() between them" % gi)
+        return
+      if self._ready[pi]:
+        return
+      self._ready[pi] = True
       self._pending[gi] -= 1
       if self._pending[gi] == 0:
         self._launch(gi)
     return hook
+
+  def _reset_round(self):
+    n = len(self.flat.params)
+    self._pending = [len(g) for g in self.groups]
+    self._launched = [False] * len(self.groups)
+    self._ready = [False] * n
+    self._count = ([0] * n, [0] * n)
 
   def hold(self):
     """Context manager: gradients that become ready inside it launch nothing; every bucket is
@@ -168,8 +185,7 @@ class GradSync(object):
     for w in self._works:
       w.wait()
     self._works = []
-    self._pending = [len(g) for g in self.groups]
-    self._launched = [False] * len(self.groups)
+    self._reset_round()
     return 1.0 / self.world
 
   def broadcast_parameters(self, src=0):

@@ -29,8 +29,9 @@ DEFAULTS = dict(  # train.py:134-167
     num_layers=1, frame_dim=68 * 3, hidden_size=700, char_dim=300,
     rnn_type='LSTM', attention_type='1_layer_nn', attn_hidden_size=-1, bidirectional=False,
     rnn_dropout=0.0, seed=123456, cuda=False,
-    # not reference flags: where data/ and weights/ live, and a cap for smoke runs
-    root=".", max_epochs=None,
+    # not reference flags: where data/ and weights/ live, a cap for smoke runs, and the encoder+CTC-only
+    # loop (no attention decoder; error = greedy-decoded CER) that the archived trainer's flag files select
+    root=".", max_epochs=None, ctc_only=False,
 )
 
 
@@ -92,7 +93,10 @@ def parse_flags(argv, defaults=DEFAULTS):
   if isinstance(out.get("rnn_type"), str):
     out["rnn_type"] = out["rnn_type"].upper()          # the archived files write `gru`
   if archived:
+    # archive/train_model.py trains a CTC-only model (no attention decoder) and reports greedy CER/WER
     out["enable_ctc"] = True
+    out["ctc_only"] = True
+    out["bidirectional"] = True     # archive/train_model.py's LipReader is bidirectional throughout
   return out
 
 
@@ -180,14 +184,28 @@ def run(**flags):
   encoder, decoding_step = init_models(char2idx, f["num_layers"], f["frame_dim"], f["hidden_size"], f["char_dim"],
                                        f["enable_ctc"], f["rnn_type"], f["attention_type"], f["attn_hidden_size"],
                                        f["bidirectional"], f["rnn_dropout"], device)
-  flats = (FlatParameters(encoder), FlatParameters(decoding_step))
+  ctc_only = bool(f["ctc_only"])
+  if ctc_only:
+    assert f["enable_ctc"], "--ctc_only needs --enable_ctc"
+    decoding_step = None
+    flats = (FlatParameters(encoder),)
+  else:
+    flats = (FlatParameters(encoder), FlatParameters(decoding_step))
   weights_dir = weights_path(f["root"], f["data"])
   encoder_path = os.path.join(weights_dir, "best_encoder.pth")
   decoder_path = os.path.join(weights_dir, "best_decoder.pth")
 
+  def error_of(loader):
+    """The live loop's "CER" is the sampled-token mismatch rate of the attention decoder (train.py:287-288
+    via eval's correct/count); without a decoder it is the greedy-decoded CER of the CTC head
+    (decoder.py:64-73 on :182-197, as archive/train_model.py:351-357 composes them)."""
+    if ctc_only:
+      return T.greedy_cer(encoder, loader, device, char2idx)
+    _, correct, count, _ = T.eval(encoder, decoding_step, loader, device, char2idx)
+    return _cer(correct, count)
+
   print("Initial evaluation...")
-  _, correct, count, _ = T.eval(encoder, decoding_step, val_loader, device, char2idx)
-  val_cer = _cer(correct, count)
+  val_cer = error_of(val_loader)
   print("\tCER: ", val_cer)
   best_val_cer, best_idx = 1.0, -1
   lr = f["learning_rate"]
@@ -205,27 +223,27 @@ def run(**flags):
       print(f'\tAnnealing to {lr}')
       if os.path.isfile(encoder_path):
         restore(encoder, encoder_path)
-        restore(decoding_step, decoder_path)
+        if not ctc_only:
+          restore(decoding_step, decoder_path)
       best_idx = epochs
     tfr = max(f["min_tfr"], f["max_tfr"] - epochs / f["tr_epochs"])
     assert 0.0 <= tfr <= 1.0
     print(f'\tCurrent Teacher Forcing Ratio: {tfr}')
     opt = tuple(FusedAdam(fl, lr=lr) for fl in flats)   # Adam state is rebuilt every epoch (:275-276)
-    dec_loss, ctc_loss = T.train(encoder, decoding_step, train_loader, opt, device, char2idx,
+    dec_loss, ctc_loss = T.train(encoder, decoding_step, train_loader, opt[0] if ctc_only else opt, device, char2idx,
                                  teacher_forcing_ratio=tfr, grad_norm=f["grad_norm"])
     print(f'\tAVG Decoder Loss: {dec_loss}')
     print(f'\tAVG CTC Loss: {ctc_loss}')
-    _, vc, vn, _ = T.eval(encoder, decoding_step, val_loader, device, char2idx)
-    _, tc, tn, _ = T.eval(encoder, decoding_step, train_loader, device, char2idx)
-    val_cer, train_cer = _cer(vc, vn), _cer(tc, tn)
+    val_cer, train_cer = error_of(val_loader), error_of(train_loader)
     encoder.save_best_model(val_cer, encoder_path)
-    decoding_step.save_best_model(val_cer, decoder_path)
-    _, sc, sn, _ = T.eval(encoder, decoding_step, test_loader, device, char2idx)
+    if not ctc_only:
+      decoding_step.save_best_model(val_cer, decoder_path)
+    test_cer = error_of(test_loader)
     print(f'\tTrain CER: {train_cer}')
     print(f'\tVal CER: {val_cer}')
-    print(f'\tTest CER: {_cer(sc, sn)}')
+    print(f'\tTest CER: {test_cer}')
     history.append(dict(epoch=epochs, decoder_loss=dec_loss, ctc_loss=ctc_loss, train_cer=train_cer,
-                        val_cer=val_cer, test_cer=_cer(sc, sn), lr=lr, tfr=tfr))
+                        val_cer=val_cer, test_cer=test_cer, lr=lr, tfr=tfr))
     if val_cer < best_val_cer:   # :339-341
       best_val_cer, best_idx = val_cer, epochs
     epochs += 1

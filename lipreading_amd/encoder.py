@@ -21,9 +21,9 @@ from .data import BOS, PAD
 
 _ALLOWED_RNN_TYPES = {'LSTM', 'GRU', 'RNN'}          # better_model.py:9
 _ALLOWED_FRAME_PROCESSING = {'flatten'}              # better_model.py:10
-_MODES = {'GRU': 0, 'LSTM': 1}
+_MODES = {'GRU': 0, 'LSTM': 1, 'RNN': 2}
 _PROJ_BF16X3, _INPUT_BF16_EXACT, _RECUR_BF16, _INPUT_STORED_BF16 = 0x100, 0x200, 0x400, 0x800   # lr_rnn_mode flags
-_GATES = {'GRU': 3, 'LSTM': 4}
+_GATES = {'GRU': 3, 'LSTM': 4, 'RNN': 1}
 
 
 def _ptr_array(tensors):
@@ -238,9 +238,6 @@ class VideoEncoder(nn.Module):
     super(VideoEncoder, self).__init__()
     assert frame_processing in _ALLOWED_FRAME_PROCESSING
     assert rnn_type in _ALLOWED_RNN_TYPES
-    if rnn_type == 'RNN':
-      # the reference allows nn.RNN (tanh) but ships no config that uses it
-      raise NotImplementedError("rnn_type='RNN' has no HIP kernel; use 'GRU' or 'LSTM'")
     if enable_ctc:
       assert vocab_size > 0 and char2idx is not None
 

@@ -53,6 +53,16 @@ def golden_lmk():
 
 
 @pytest.fixture(scope="session")
+def golden_enc2():
+  return load_golden("enc2_cases.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_dec2():
+  return load_golden("dec2_cases.npz")
+
+
+@pytest.fixture(scope="session")
 def golden_prn():
   return load_golden("prn_cases.npz")
 

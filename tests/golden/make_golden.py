@@ -21,6 +21,8 @@ Pins (see oracle/torch_oracle.py header):
   dec_cases.npz     reference VideoEncoder + CharDecodingStep (five attention types) driven as
                     train_better_model.py:46-74 does at teacher_forcing_ratio = 1; needs the
                     allennlp stand-ins incl. masked_softmax                              SHIMMED
+  enc2_cases.npz    as enc_cases for rnn_type='RNN' (tanh)                               SHIMMED
+  dec2_cases.npz    as dec_cases for decoders with num_layers 2 / 3 and the tanh RNN     SHIMMED
   lmk_cases.npz     reference face.py _applyPadding / extractFace / getFace, imported with inert
                     dlib / tensorflow / skimage stubs (none on the arithmetic path)     CLEAN
   prn_cases.npz     reference PRN.process + get_landmarks (prnet.py:112-170) composed as
@@ -198,12 +200,16 @@ def enc_inputs(g, B, T, lens, scale):
   return frames
 
 
-def gen_enc(bm, char2idx):
+ENC_CFGS = [("gru_bi", "GRU", True, 1, 12), ("gru_uni", "GRU", False, 1, 8),
+            ("lstm_bi", "LSTM", True, 1, 12), ("lstm_uni", "LSTM", False, 1, 8),
+            ("gru_bi_l2", "GRU", True, 2, 8), ("lstm_bi_l2", "LSTM", True, 2, 8)]
+# rnn_type='RNN' (tanh; better_model.py:9 allows it) — a second file so enc_cases.npz stays byte-identical
+ENC2_CFGS = [("rnn_bi", "RNN", True, 1, 12), ("rnn_uni_l2", "RNN", False, 2, 8), ("rnn_bi_l2", "RNN", True, 2, 8)]
+
+
+def gen_enc(bm, char2idx, cfgs=ENC_CFGS, out="enc_cases.npz"):
   g = torch.Generator().manual_seed(123456)
   cases = {}
-  cfgs = [("gru_bi", "GRU", True, 1, 12), ("gru_uni", "GRU", False, 1, 8),
-          ("lstm_bi", "LSTM", True, 1, 12), ("lstm_uni", "LSTM", False, 1, 8),
-          ("gru_bi_l2", "GRU", True, 2, 8), ("lstm_bi_l2", "LSTM", True, 2, 8)]
   for name, rnn_type, bi, layers, H in cfgs:
     torch.manual_seed(123456)
     enc = bm.VideoEncoder(204, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
@@ -225,7 +231,7 @@ def gen_enc(bm, char2idx):
     for k, v in enc.state_dict().items():
       cases["%s/sd/%s" % (name, k)] = v.numpy()
     cases[name + "/cfg"] = np.array([H, layers, int(bi)])
-  np.savez_compressed(os.path.join(OUT, "enc_cases.npz"), **cases)
+  np.savez_compressed(os.path.join(OUT, out), **cases)
 
 
 def gen_step(bm, ref_ctc, char2idx):
@@ -270,19 +276,27 @@ def gen_step(bm, ref_ctc, char2idx):
   np.savez_compressed(os.path.join(OUT, "step_cases.npz"), **cases)
 
 
-def gen_dec(bm, ref_ctc, char2idx):
+DEC_CFGS = [("gru_1layernn", "GRU", True, "1_layer_nn", -1), ("lstm_dot", "LSTM", True, "dot", -1),
+            ("gru_general", "GRU", False, "general", -1), ("lstm_concat", "LSTM", False, "concat", 10),
+            ("gru_none", "GRU", True, "none", -1)]
+# decoders with num_layers > 1 (better_model.py:136,147-148) and the tanh RNN; second file, as above
+DEC2_CFGS = [("gru_l2_1layernn", "GRU", True, "1_layer_nn", -1, 2), ("lstm_l2_dot", "LSTM", False, "dot", -1, 2),
+             ("rnn_l1_general", "RNN", True, "general", -1, 1), ("rnn_l3_none", "RNN", False, "none", -1, 3),
+             ("lstm_l3_concat", "LSTM", True, "concat", 6, 3)]
+
+
+def gen_dec(bm, ref_ctc, char2idx, cfgs=DEC_CFGS, out_file="dec_cases.npz"):
   """Reference VideoEncoder -> reference CharDecodingStep, driven as train_better_model.py:46-65
   does with teacher_forcing_ratio=1 (decoder loss), plus the CTC loss; gradients of
   decoder_loss.backward(retain_graph) followed by ctc_loss.backward() (:69,:74).  SHIMMED."""
   g = torch.Generator().manual_seed(123456)
   cases = {}
-  cfgs = [("gru_1layernn", "GRU", True, "1_layer_nn", -1), ("lstm_dot", "LSTM", True, "dot", -1),
-          ("gru_general", "GRU", False, "general", -1), ("lstm_concat", "LSTM", False, "concat", 10),
-          ("gru_none", "GRU", True, "none", -1)]
-  for name, rnn_type, bi, attn, ah in cfgs:
+  for cfg in cfgs:
+    name, rnn_type, bi, attn, ah = cfg[:5]
+    layers = cfg[5] if len(cfg) > 5 else 1
     torch.manual_seed(123456)
     H = 8
-    enc = bm.VideoEncoder(204, H, rnn_type=rnn_type, num_layers=1, bidirectional=bi, enable_ctc=True,
+    enc = bm.VideoEncoder(204, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi, enable_ctc=True,
                           vocab_size=V, char2idx=char2idx)
     dec = bm.CharDecodingStep(enc, char_dim=12, vocab_size=V, char2idx=char2idx, attention_type=attn,
                               attn_hidden_size=ah)
@@ -322,8 +336,8 @@ def gen_dec(bm, ref_ctc, char2idx):
     cases[name + "/dec_loss"] = dec_loss.detach().numpy()
     cases[name + "/ctc_loss"] = ctc.detach().numpy()
     cases[name + "/dec_log_probs"] = torch.stack(outs, 1).detach().numpy()
-    cases[name + "/cfg"] = np.array([H, int(bi), 12, ah])
-  np.savez_compressed(os.path.join(OUT, "dec_cases.npz"), **cases)
+    cases[name + "/cfg"] = np.array([H, int(bi), 12, ah] + ([layers] if len(cfg) > 5 else []))
+  np.savez_compressed(os.path.join(OUT, out_file), **cases)
 
 
 def install_face_stubs():
@@ -449,6 +463,8 @@ def main():
   gen_enc(bm, char2idx)
   gen_step(bm, ref_ctc, char2idx)
   gen_dec(bm, ref_ctc, char2idx)
+  gen_enc(bm, char2idx, ENC2_CFGS, "enc2_cases.npz")
+  gen_dec(bm, ref_ctc, char2idx, DEC2_CFGS, "dec2_cases.npz")
   install_face_stubs()
   import src.models.face.prnet as ref_prnet                   # shimmed import (estimate_transform)
   import src.utils.data.face as ref_face                      # clean apart from the inert stubs

@@ -49,20 +49,23 @@ def _worker(rank, world, port, out_dir):
       model(x[lo:hi]).pow(2).sum().backward()
       scale = sync(status)
     assert scale == 0.5
-    # hook logic (registered on the GPU path only): a gradient for an already-exchanged bucket is an
-    # error, unless the step runs under hold()
-    hook = sync._make_hook(0)
-    sync._launched[0] = True
+    # hook logic (registered on the GPU path only).  Bucket 0 = params 0, 1.  An in-place gradient is
+    # announced twice in one backward (kind 1 by the HIP backward, kind 0 by autograd's hook): once ready.
+    auto0, direct0, auto1 = sync._make_hook(0, 0), sync._make_hook(0, 1), sync._make_hook(1, 0)
+    direct0(None); auto0(None)
+    assert sync._pending[0] == 1 and not sync._launched[0]
+    sync._launched[0] = True     # (as if param 1 had arrived and the bucket had gone out)
+    auto1(None)                  # first announcement of param 1: fine
     try:
-      hook(None)
+      direct0(None)              # the same kind again for param 0 = a second backward
       raise AssertionError("second backward into an exchanged bucket must raise")
     except RuntimeError as e:
       assert "second backward" in str(e)
     with sync.hold():
-      hook(None)
-    sync._launched[0] = False
+      direct0(None)
+    sync._reset_round()
     sync.close()
-    hook(None)          # closed: inert
+    direct0(None)                # closed: inert
     np.save(os.path.join(out_dir, "grad_%d.npy" % rank), flat.grad.numpy())
     np.save(os.path.join(out_dir, "data_%d.npy" % rank), flat.data.detach().numpy())
     np.save(os.path.join(out_dir, "status_%d.npy" % rank), status.numpy())

@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import torch_oracle as O
-from tests.test_oracle_golden import DEC_CASES, _flatten, build_oracle_pair
+from tests.test_oracle_golden import DEC2_CASES, DEC_CASES, _flatten, build_oracle_pair, dec_cfg
 
 pytestmark = pytest.mark.gpu
 
@@ -21,8 +21,8 @@ def hip_pair(case, rnn_type, attn, dev):
   from lipreading_amd.attention_decoder import CharDecodingStep
   from lipreading_amd.data import default_char2idx
   from lipreading_amd.encoder import VideoEncoder
-  H, bi, char_dim, ah = [int(x) for x in case["cfg"]]
-  enc = VideoEncoder(204, H, rnn_type=rnn_type, num_layers=1, bidirectional=bool(bi), enable_ctc=True,
+  H, bi, char_dim, ah, layers = dec_cfg(case)
+  enc = VideoEncoder(204, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bool(bi), enable_ctc=True,
                      vocab_size=64, char2idx=default_char2idx())
   dec = CharDecodingStep(enc, char_dim=char_dim, vocab_size=64, char2idx=default_char2idx(),
                          attention_type=attn, attn_hidden_size=ah)
@@ -40,13 +40,14 @@ def grads_close(mod, want, tol=3e-4):
     assert np.abs(got - ref).max() / scale < tol, (k, np.abs(got - ref).max(), scale)
 
 
-@pytest.mark.parametrize("name", sorted(DEC_CASES))
-def test_decoder_matches_reference_vectors(golden_dec, dev, name):
+@pytest.mark.parametrize("name", sorted(DEC_CASES) + sorted(DEC2_CASES))
+def test_decoder_matches_reference_vectors(golden_dec, golden_dec2, dev, name):
   """encoder -> decoder loop at teacher_forcing_ratio 1 + CTC, decoder_loss.backward(retain_graph)
-  then ctc_loss.backward() (train_better_model.py:46-74)."""
+  then ctc_loss.backward() (train_better_model.py:46-74).  dec2 cases: decoders with 2 / 3 layers
+  (better_model.py:136,147-148) and rnn_type='RNN'."""
   from lipreading_amd.ctc import ctc_loss
-  case = golden_dec[name]
-  enc, dec = hip_pair(case, *DEC_CASES[name], dev)
+  case = (golden_dec2 if name in DEC2_CASES else golden_dec)[name]
+  enc, dec = hip_pair(case, *{**DEC_CASES, **DEC2_CASES}[name], dev)
   lens = torch.tensor(case["lens"])
   chars = torch.tensor(case["chars"], device=dev)
   char_lens = torch.tensor(case["char_lens"])
@@ -69,12 +70,12 @@ def test_decoder_matches_reference_vectors(golden_dec, dev, name):
   assert s.shape == (4, L) and ((s >= 2) & (s < 64)).all()
 
 
-@pytest.mark.parametrize("name", ["gru_1layernn", "lstm_concat"])
-def test_single_step_api_equals_fused_loop(golden_dec, dev, name):
+@pytest.mark.parametrize("name", ["gru_1layernn", "lstm_concat", "gru_l2_1layernn", "lstm_l3_concat"])
+def test_single_step_api_equals_fused_loop(golden_dec, golden_dec2, dev, name):
   """CharDecodingStep.forward (the reference's per-step contract) chained L times gives the fused
   decode_sequence result, values and gradients."""
-  case = golden_dec[name]
-  enc, dec = hip_pair(case, *DEC_CASES[name], dev)
+  case = (golden_dec2 if name in DEC2_CASES else golden_dec)[name]
+  enc, dec = hip_pair(case, *{**DEC_CASES, **DEC2_CASES}[name], dev)
   lens = torch.tensor(case["lens"])
   chars = torch.tensor(case["chars"], device=dev)
   L = int(case["char_lens"].max()) - 1
@@ -142,6 +143,101 @@ def test_sampled_inputs_and_bench_sizes_match_oracle(dev):
     # (the score bias of '1_layer_nn' has a mathematically zero gradient - softmax is shift
     #  invariant - so both sides hold rounding noise there; the absolute floor covers it)
     assert np.abs(p.grad.cpu().numpy() - r).max() / max(1e-4, np.abs(r).max()) < 5e-4, k
+
+
+@pytest.mark.parametrize("rnn_type,layers,attn", [("LSTM", 2, "general"), ("GRU", 3, "dot"), ("RNN", 2, "1_layer_nn")])
+def test_multilayer_decoder_with_sampled_inputs_matches_oracle(dev, rnn_type, layers, attn):
+  """Decoder stacks deeper than one layer (better_model.py:136,147-148) under a MIXED teacher-forcing
+  pattern: a sampled-input step needs the top layer's output of the step before, so the stack runs
+  layer-major inside each run of known inputs.  The HIP loop's own samples are replayed through the
+  oracle (nn.GRU/LSTM/RNN(num_layers)) step by step; values and every gradient are compared."""
+  from lipreading_amd.attention_decoder import CharDecodingStep
+  from lipreading_amd.data import default_char2idx
+  Hd, Cd = 48, 20
+
+  class Enc:   # only what CharDecodingStep reads from the encoder (better_model.py:134-136)
+    hidden_size, bidirectional, num_layers = Hd // 2, True, layers
+  Enc.rnn_type = rnn_type
+  torch.manual_seed(15)
+  ref = O.OracleCharDecodingStep(Hd, rnn_type, layers, Cd, 64, O.default_char2idx(), attention_type=attn)
+  dec = CharDecodingStep(Enc(), Cd, 64, default_char2idx(), attention_type=attn)
+  dec.load_state_dict(ref.state_dict())
+  dec = dec.to(dev)
+  g = torch.Generator().manual_seed(16)
+  B, T, L = 7, 23, 9
+  enc = torch.randn(B, T, Hd, generator=g) * 0.5
+  lens = torch.sort(torch.randint(10, T + 1, (B,), generator=g))[0]
+  h0 = torch.randn(layers, B, Hd, generator=g) * 0.5
+  c0 = torch.randn(layers, B, Hd, generator=g) * 0.5
+  chars = torch.randint(4, 64, (B, L), generator=g)
+  tf = [True, True, False, True, False, False, True, True, False]
+  encd = enc.to(dev).requires_grad_(True)
+  h0d, c0d = h0.to(dev).requires_grad_(True), c0.to(dev).requires_grad_(True)
+  state_d = (h0d, c0d) if rnn_type == "LSTM" else h0d
+  lp, sampled, fin = dec.decode_sequence(chars.to(dev), state_d, lens, encd, teacher_forced=tf, seed=17)
+  s = sampled.cpu().long()
+  encr = enc.clone().requires_grad_(True)
+  h0r, c0r = h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+  state, rows = ((h0r, c0r) if rnn_type == "LSTM" else h0r), []
+  for i in range(L):
+    inp = chars[:, i] if tf[i] else s[:, i - 1]
+    o, state = ref(inp, state, lens, encr)
+    rows.append(o)
+  want = torch.stack(rows, 1)
+  np.testing.assert_allclose(lp.detach().cpu().numpy(), want.detach().numpy(), rtol=2e-4, atol=2e-5)
+  fins_d = fin if isinstance(fin, tuple) else (fin,)
+  fins_r = state if isinstance(state, tuple) else (state,)
+  for a, b in zip(fins_d, fins_r):
+    assert a.shape == (layers, B, Hd)
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=2e-4, atol=2e-5)
+  wgt = torch.randn(B, L, 64, generator=g) / 100
+  wf = torch.randn(layers, B, Hd, generator=g) / 50
+  # the returned final state takes part in the loss: its gradient enters every layer's last step
+  ((lp * wgt.to(dev)).sum() + sum((f * wf.to(dev)).sum() for f in fins_d)).backward()
+  ((want * wgt).sum() + sum((f * wf).sum() for f in fins_r)).backward()
+  pairs = [("enc", encd.grad, encr.grad), ("h0", h0d.grad, h0r.grad)]
+  if rnn_type == "LSTM":
+    pairs.append(("c0", c0d.grad, c0r.grad))
+  gr = dict(ref.named_parameters())
+  pairs += [(k, p.grad, gr[k].grad) for k, p in dec.named_parameters()]
+  for k, a, b in pairs:
+    a, b = a.cpu().numpy(), b.numpy()
+    assert np.abs(a - b).max() / max(1e-4, np.abs(b).max()) < 5e-4, k
+
+
+def test_multilayer_decoder_dropout_is_a_mask_between_layers(dev):
+  """nn.GRU(dropout=p) semantics in training mode: the outputs of every layer but the last are dropped
+  out before they feed the next layer.  The draw is RNG-dependent (parity in distribution only), so the
+  check is structural: p -> 0 reproduces the no-dropout result, eval mode ignores it, and with p > 0 the
+  training-mode result differs while gradients stay finite."""
+  from lipreading_amd.attention_decoder import CharDecodingStep
+  from lipreading_amd.data import default_char2idx
+
+  class Enc:
+    hidden_size, bidirectional, rnn_type, num_layers = 16, True, 'GRU', 2
+  torch.manual_seed(25)
+  dec = CharDecodingStep(Enc(), 12, 64, default_char2idx(), rnn_dropout=0.0, attention_type='dot').to(dev).train()
+  g = torch.Generator().manual_seed(26)
+  B, T, L = 5, 11, 6
+  enc = (torch.randn(B, T, 32, generator=g) * 0.5).to(dev)
+  lens = torch.tensor([7, 9, 11, 11, 11])
+  h0 = (torch.randn(2, B, 32, generator=g) * 0.5).to(dev)
+  chars = torch.randint(4, 64, (B, L), generator=g).to(dev)
+  base, _, _ = dec.decode_sequence(chars, h0, lens, enc, seed=1)
+  dec.rnn_dropout = 0.5
+  dec.eval()
+  ev, _, _ = dec.decode_sequence(chars, h0, lens, enc, seed=1)
+  assert torch.equal(ev, base)
+  dec.train()
+  torch.manual_seed(27)
+  dr, _, _ = dec.decode_sequence(chars, h0, lens, enc, seed=1)
+  assert float((dr - base).abs().max()) > 1e-3
+  dec.zero_grad()
+  dr.sum().backward()
+  assert all(torch.isfinite(p.grad).all() for p in dec.parameters() if p.grad is not None)
+  # only layer 0's outputs are dropped: the mask reaches layer 0's weights' gradient but a zero mask
+  # row cannot make the top layer's bias gradient vanish
+  assert float(dec.rnn.bias_hh_l1.grad.abs().sum()) > 0
 
 
 @pytest.mark.parametrize("rnn_type,attn", [("GRU", "1_layer_nn"), ("LSTM", "dot")])

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import torch_oracle as O
-from tests.test_oracle_golden import ENC_CASES, _flatten, build_oracle_encoder
+from tests.test_oracle_golden import ENC2_CASES, ENC_CASES, _flatten, build_oracle_encoder, rnn_type_of
 
 pytestmark = pytest.mark.gpu
 
@@ -120,11 +120,11 @@ def test_sgemm_epilogue_splitk_and_row_shift(dev):
 
 
 # ---- encoder forward against the reference vectors -------------------------------------------
-@pytest.mark.parametrize("name", ENC_CASES)
+@pytest.mark.parametrize("name", ENC_CASES + ENC2_CASES)
 @pytest.mark.parametrize("tag", ["eq", "mix"])
-def test_encoder_matches_reference_vectors(golden_enc, dev, name, tag):
-  case = golden_enc[name]
-  enc = hip_encoder_from(case, "GRU" if name.startswith("gru") else "LSTM", dev).eval()
+def test_encoder_matches_reference_vectors(golden_enc, golden_enc2, dev, name, tag):
+  case = (golden_enc2 if name in ENC2_CASES else golden_enc)[name]
+  enc = hip_encoder_from(case, rnn_type_of(name), dev).eval()
   io = case[tag]
   with torch.no_grad():
     lp, hid, fin = enc(torch.tensor(io["frames"], device=dev), torch.tensor(io["lens"]))
@@ -157,7 +157,8 @@ def make_pair(rnn_type, H, layers, bi, dev, seed=123456):
 
 
 CFG = [("GRU", 256, 1, True, 32, 75), ("LSTM", 768, 1, True, 32, 75), ("GRU", 700, 1, True, 9, 40),
-       ("LSTM", 64, 2, True, 20, 33), ("GRU", 48, 2, False, 17, 21), ("LSTM", 36, 1, False, 5, 12)]
+       ("LSTM", 64, 2, True, 20, 33), ("GRU", 48, 2, False, 17, 21), ("LSTM", 36, 1, False, 5, 12),
+       ("RNN", 256, 1, True, 32, 75), ("RNN", 52, 2, False, 11, 19)]
 
 
 @pytest.mark.parametrize("rnn_type,H,layers,bi,B,T", CFG)

@@ -177,3 +177,98 @@ def test_driver_trains_from_a_flag_file_on_a_synthetic_dataview(dev, tmp_path):
   # the checkpoint is a plain state_dict with the reference's key names
   sd = torch.load(enc_path, map_location="cpu")
   assert {"rnn.weight_ih_l0", "rnn.weight_hh_l0_reverse", "output_proj.weight"} <= set(sd)
+
+
+def test_small_config_loss_and_cer_parity_with_the_cpu_path(dev, tmp_path):
+  """BASELINE configs[2]: "small (23 videos), BiLSTM encoder + CTC, fp32, loss/CER parity vs CPU".
+  A 23-video synthetic dataview in the reference's on-disk format; the HIP path (train(): collate ->
+  VideoEncoder BiLSTM -> ctc_loss -> clip -> FusedAdam) and the oracle (same op sequence on stock torch
+  CPU ops + torch.optim.Adam) start from the same weights and see the same batches for two epochs.
+  Stated tolerances: per-epoch mean CTC loss 2e-3 relative (fp32 Adam trajectories drift apart slowly);
+  greedy strings — hence the CER, decoder.py:64-73 over :182-197 — IDENTICAL when both sides decode with
+  the same weights; the two separately trained models' CERs within 0.02."""
+  from lipreading_amd import dataset as DS
+  from lipreading_amd import train as T
+  from lipreading_amd.data import make_collate_fn
+  from lipreading_amd.decoder import GreedyDecoder, ctc_labels
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.optim import FlatParameters, FusedAdam
+  root = str(tmp_path)
+  DS.write_synthetic_dataview(root, "synthetic/small", n_videos=23, captions_per_video=4, seed=3)
+  tr, va, te = DS.split_dataset(root, "synthetic/small", 0.8, np.random.RandomState(123456))
+  ds = DS.FrameCaptionDataset(root, "synthetic/small", "train", tr)
+  c2i = ds.char2idx
+  loader = DS.make_loader(ds, 8, make_collate_fn(dev))
+  torch.manual_seed(123456)
+  ref = O.OracleVideoEncoder(204, 64, rnn_type='LSTM', bidirectional=True, enable_ctc=True, vocab_size=len(c2i),
+                             char2idx=c2i).train()
+  enc = VideoEncoder(204, 64, rnn_type='LSTM', bidirectional=True, enable_ctc=True, vocab_size=len(c2i), char2idx=c2i)
+  enc.load_state_dict(ref.state_dict())
+  enc = enc.to(dev)
+  opt = FusedAdam(FlatParameters(enc), lr=1e-3)
+  ropt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+  inv = {v: k for k, v in c2i.items()}
+  labels = ctc_labels(c2i)
+
+  def oracle_cer(model):
+    model.eval()
+    dist, total, strings = 0, 0, []
+    with torch.no_grad():
+      for frames, lens, chars, cl in loader:
+        lp = model(frames.cpu(), lens)[0]
+        out, _ = O.greedy_decode(lp, lens, labels)
+        for b in range(len(out)):
+          want = ''.join(inv[int(c)] for c in chars[b, 1:int(cl[b]) - 1])
+          hyp = out[b][0].replace('<EOS>', '')
+          dist += O.edit_distance(hyp.replace(' ', ''), want.replace(' ', ''))
+          total += len(want.replace(' ', ''))
+          strings.append(hyp)
+    model.train()
+    return dist / max(total, 1), strings
+
+  for epoch in range(2):
+    hip_loss = T.train(enc, None, loader, opt, dev, c2i, grad_norm=50)[1]
+    cpu_losses = []
+    for frames, lens, chars, cl in loader:
+      l = O.encoder_ctc_step(ref, ropt, frames.cpu(), lens, chars, cl, grad_norm=50)
+      cpu_losses.append(0.0 if l is None else float(l))
+    cpu_loss = float(np.mean(cpu_losses))
+    assert abs(hip_loss - cpu_loss) <= 2e-3 * abs(cpu_loss), (epoch, hip_loss, cpu_loss)
+  # same weights on both sides: identical greedy strings, identical CER
+  twin = O.OracleVideoEncoder(204, 64, rnn_type='LSTM', bidirectional=True, enable_ctc=True, vocab_size=len(c2i),
+                              char2idx=c2i)
+  twin.load_state_dict({k: v.cpu() for k, v in enc.state_dict().items()})
+  cer_twin, strings_twin = oracle_cer(twin)
+  dec = GreedyDecoder(labels, blank_index=0)
+  enc.eval()
+  strings_hip = []
+  with torch.no_grad():
+    for frames, lens, chars, cl in loader:
+      out, _ = dec.decode(enc(frames, lens.to(dev))[0], lens.to(dev))
+      strings_hip += [o[0].replace('<EOS>', '') for o in out]
+  assert strings_hip == strings_twin
+  cer_hip = T.greedy_cer(enc, loader, dev, c2i)
+  assert abs(cer_hip - cer_twin) < 1e-12, (cer_hip, cer_twin)
+  cer_cpu, _ = oracle_cer(ref)
+  assert abs(cer_hip - cer_cpu) <= 0.02, (cer_hip, cer_cpu)
+
+
+def test_driver_runs_the_archived_ctc_only_flag_files(dev, tmp_path):
+  """config/train/micro and config/train/test_train_nano (BASELINE configs[0]/[1]) are written in the
+  archived trainer's flags: they select the encoder+CTC loop with greedy CER as the error."""
+  from lipreading_amd import driver
+  from lipreading_amd.dataset import write_synthetic_dataview
+  root = str(tmp_path)
+  write_synthetic_dataview(root, "StephenColbert/micro", n_videos=6, captions_per_video=5, seed=11)
+  cfg = tmp_path / "micro"
+  cfg.write_text("--dataset=StephenColbert/micro\n--epochs=70\n--batch=5\n--train_split=0.8\n--num_workers=1\n"
+                 "--hidden_size=800\n--hidden_layers=5\n--rnn_type=gru\n--cuda\n--learning_rate=3e-4\n--momentum=0.9\n"
+                 "--max_norm=400\n--anneal=1.1\n--checkpoint\n--tensorboard\n--continue_from=0\n")
+  flags = driver.parse_flags([str(cfg), "--root=" + root, "--max_epochs=2", "--hidden_size=48", "--num_layers=2"])
+  out = driver.run(**flags)
+  h = out["history"]
+  assert len(h) == 2 and all(np.isfinite(e["ctc_loss"]) for e in h) and h[1]["ctc_loss"] < h[0]["ctc_loss"]
+  assert all(0.0 <= e["val_cer"] <= 2.0 for e in h)
+  import os
+  # best_encoder.pth appears once the greedy CER drops below 1 (better_model.py:114-122); never a decoder file
+  assert not os.path.exists(os.path.join(out["weights_dir"], "best_decoder.pth"))

@@ -168,6 +168,7 @@ def test_driver_accepts_the_deprecated_and_archived_flag_files(tmp_path):
   assert (f["data"], f["max_epochs"], f["batch_size"], f["num_layers"], f["grad_norm"]) == \
          ("StephenColbert/micro", 70, 5, 5, 400)
   assert f["rnn_type"] == "GRU" and f["enable_ctc"] is True and f["hidden_size"] == 800
+  assert f["ctc_only"] is True and f["bidirectional"] is True
   with pytest.raises(SystemExit):
     driver.parse_flags([str(micro), "--still_unknown=1"])
 

@@ -41,6 +41,11 @@ def test_ctc_quirk_is_not_the_sample_mean(golden_ctc):
 
 
 ENC_CASES = ["gru_bi", "gru_uni", "lstm_bi", "lstm_uni", "gru_bi_l2", "lstm_bi_l2"]
+ENC2_CASES = ["rnn_bi", "rnn_uni_l2", "rnn_bi_l2"]      # enc2_cases.npz: rnn_type='RNN' (tanh)
+
+
+def rnn_type_of(name):
+  return {"gru": "GRU", "lstm": "LSTM", "rnn": "RNN"}[name.split("_")[0]]
 
 
 def build_oracle_encoder(case, rnn_type):
@@ -62,11 +67,11 @@ def _flatten(d, prefix=""):
   return out
 
 
-@pytest.mark.parametrize("name", ENC_CASES)
+@pytest.mark.parametrize("name", ENC_CASES + ENC2_CASES)
 @pytest.mark.parametrize("tag", ["eq", "mix"])
-def test_encoder_oracle_matches_reference(golden_enc, name, tag):
-  case = golden_enc[name]
-  enc = build_oracle_encoder(case, "GRU" if name.startswith("gru") else "LSTM").eval()
+def test_encoder_oracle_matches_reference(golden_enc, golden_enc2, name, tag):
+  case = (golden_enc2 if name in ENC2_CASES else golden_enc)[name]
+  enc = build_oracle_encoder(case, rnn_type_of(name)).eval()
   io = case[tag]
   with torch.no_grad():
     lp, hid, fin = enc(torch.tensor(io["frames"]), torch.tensor(io["lens"]))
@@ -158,23 +163,33 @@ DEC_CASES = {"gru_1layernn": ("GRU", "1_layer_nn"), "lstm_dot": ("LSTM", "dot"),
              "lstm_concat": ("LSTM", "concat"), "gru_none": ("GRU", "none")}
 
 
+# dec2_cases.npz: decoders with num_layers 2 / 3 (better_model.py:136,147-148) and the tanh RNN
+DEC2_CASES = {"gru_l2_1layernn": ("GRU", "1_layer_nn"), "lstm_l2_dot": ("LSTM", "dot"), "rnn_l1_general": ("RNN", "general"),
+              "rnn_l3_none": ("RNN", "none"), "lstm_l3_concat": ("LSTM", "concat")}
+
+
+def dec_cfg(case):
+  cfg = [int(x) for x in case["cfg"]]
+  return cfg + [1] if len(cfg) == 4 else cfg      # H, bi, char_dim, attn_hidden, layers
+
+
 def build_oracle_pair(case, rnn_type, attn):
-  H, bi, char_dim, ah = [int(x) for x in case["cfg"]]
-  enc = O.OracleVideoEncoder(204, H, rnn_type=rnn_type, num_layers=1, bidirectional=bool(bi),
+  H, bi, char_dim, ah, layers = dec_cfg(case)
+  enc = O.OracleVideoEncoder(204, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bool(bi),
                              enable_ctc=True, vocab_size=64, char2idx=O.default_char2idx())
   enc.load_state_dict({k: torch.tensor(v) for k, v in _flatten(case["enc_sd"]).items()})
-  dec = O.OracleCharDecodingStep(H * (2 if bi else 1), rnn_type, 1, char_dim, 64, O.default_char2idx(),
+  dec = O.OracleCharDecodingStep(H * (2 if bi else 1), rnn_type, layers, char_dim, 64, O.default_char2idx(),
                                  attention_type=attn, attn_hidden_size=ah)
   dec.load_state_dict({k: torch.tensor(v) for k, v in _flatten(case["dec_sd"]).items()})
   return enc.train(), dec.train()
 
 
-@pytest.mark.parametrize("name", sorted(DEC_CASES))
-def test_decoder_oracle_matches_reference(golden_dec, name):
+@pytest.mark.parametrize("name", sorted(DEC_CASES) + sorted(DEC2_CASES))
+def test_decoder_oracle_matches_reference(golden_dec, golden_dec2, name):
   """Encoder -> attention decoder loop (tfr = 1) + CTC; decoder_loss.backward(retain_graph) then
   ctc_loss.backward(), as train_better_model.py:46-74."""
-  case = golden_dec[name]
-  enc, dec = build_oracle_pair(case, *DEC_CASES[name])
+  case = (golden_dec2 if name in DEC2_CASES else golden_dec)[name]
+  enc, dec = build_oracle_pair(case, *{**DEC_CASES, **DEC2_CASES}[name])
   lens = torch.tensor(case["lens"])
   chars, char_lens = torch.tensor(case["chars"]), torch.tensor(case["char_lens"])
   lp_enc, hid, final = enc(torch.tensor(case["frames"]), lens)
