@@ -393,76 +393,43 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
   labels, label_lens = chars[:, 1:], char_lens - 1
   if pixels:
     frames = synth_clips(B, 123456 + rank, dev)
-  n_labels = (labels != 0).sum()
+  # The step is the PRODUCT's: lipreading_amd.train.ctc_step (encoder+CTC; train_better_model.py:46-48,74,78,80)
+  # or train.decoder_step (the whole reference step with the attention decoder loop), and the hipGraph
+  # capture is the product's too (train.StepGraphs: one graph per batch shape, replayed).
+  from lipreading_amd import train as T
+  graphs = T.StepGraphs(enabled=use_graph)
+  flags = (True,) * (LABEL_LEN + 1)     # teacher_forcing_ratio 1: every step of the decoder loop is teacher forced
 
-  def fwd_bwd():
-    # train_better_model.py:46-48,67,74 — everything up to and including backward
-    opt.zero_grad()
-    log_probs, hidden, state = model(frames, frame_lens, max_len=T_FRAMES)
-    loss, status, _ = ctc_loss_with_status(log_probs, labels, frame_lens, label_lens, 'mean')
+  def step(graphs=graphs, sync=None, dec_sync=None):
     if attn:
-      # :54-65 at teacher_forcing_ratio 1; :70/:74's two backward calls as one traversal of the sum
-      dec_opt.zero_grad()
-      Ld = LABEL_LEN + 1
-      lp, _, _ = dec.decode_sequence(chars[:, :Ld], state, frame_lens, hidden, seed=1)
-      nll = F.nll_loss(lp.reshape(-1, VOCAB), labels[:, :Ld].reshape(-1), ignore_index=0, reduction='sum')
-      (nll / n_labels + loss).backward()
-    else:
-      loss.backward()
-    return loss.detach(), status
-
-  graph = None
-  graph_note = None
-  if use_graph:
-    # one hipGraph for the few hundred launches of forward+backward.  thread_local capture mode:
-    # RCCL's watchdog thread may touch the runtime while this thread captures.
-    try:
-      torch.cuda.synchronize()
-      if DIST_ON:
-        dist.barrier()
-      side = torch.cuda.Stream()
-      side.wait_stream(torch.cuda.current_stream())
-      with torch.cuda.stream(side):
-        for _ in range(2):
-          fwd_bwd()
-      torch.cuda.current_stream().wait_stream(side)
-      torch.cuda.synchronize()
-      graph = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-        g_loss, g_status = fwd_bwd()
-    except Exception as e:   # fall back to eager launches rather than lose the measurement
-      graph = None
-      graph_note = "hipGraph capture failed (%s); eager launches" % type(e).__name__
-      torch.cuda.synchronize()
-    # every rank must take the same path (a collective follows each step either way)
-    if DIST_ON:
-      ok = torch.tensor([1 if graph is not None else 0], device=dev)
-      dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-      if int(ok.item()) == 0:
-        graph = None
-    use_graph = graph is not None
-
-  def step():
-    if graph is not None:
-      graph.replay()
-      loss, status = g_loss, g_status
-    else:
-      loss, status = fwd_bwd()
-    scale = sync(status) if sync is not None else 1.0          # RCCL all-reduce of the flat grads
-    opt.step(grad_norm=50, grad_scale=scale, skip=status)      # :78 clip + :80 Adam
-    if attn:
-      dscale = dec_sync() if dec_sync is not None else 1.0
-      dec_opt.step(grad_norm=50, grad_scale=dscale, skip=status)   # :79: the decoder is clipped separately
-    return loss, status
+      _, loss, status = T.decoder_step(enc, dec, (opt, dec_opt), frames, frame_lens, chars, char_lens, flags, 1, 0,
+                                       grad_norm=50, max_len=T_FRAMES, grad_sync=(sync, dec_sync), graphs=graphs)
+      return loss, status
+    return T.ctc_step(model, opt, frames, frame_lens, chars, char_lens, grad_norm=50, max_len=T_FRAMES,
+                      grad_sync=sync, graphs=graphs)
 
   def fence():
     if DIST_ON:
       dist.barrier()
     torch.cuda.synchronize()
 
+  graph_note = None
+  step_sync = dict(sync=sync, dec_sync=dec_sync)
+  # untimed priming, before the W warm-up steps: a shape's first steps run eagerly and the next one is
+  # captured (StepGraphs), so that warm-up and the timed region see nothing but replays
+  for _ in range(graphs.warmup + 1 if use_graph else 0):
+    loss, status = step(**step_sync)
+  if use_graph:
+    ok = torch.tensor([1 if graphs.captures > 0 else 0], device=dev)
+    if DIST_ON:   # every rank must be on the same path
+      dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+      graphs.enabled, use_graph = False, False
+      graph_note = "hipGraph capture failed; eager launches"
+
   L = _C.lib()
   for _ in range(args.warmup):
-    loss, status = step()
+    loss, status = step(**step_sync)
   # the timed region — EXACTLY args.steps steps between two fences — is repeated args.repeats times
   # back to back; `value` comes from the median repeat, the fastest is reported beside it
   elapsed_all = []
@@ -470,19 +437,19 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-      loss, status = step()
+      loss, status = step(**step_sync)
     fence()
     elapsed_all.append(time.perf_counter() - t0)
 
   # roofline leg (after the timed region, same process, same tensors)
   _C.check(L.lr_profile_enable(1), "lr_profile_enable")
   n_prof = min(args.steps, 20 if not pixels else 5)
-  for _ in range(n_prof):
+  for _ in range(n_prof):    # eager launches of the same step (graph replays do not re-run the host code that records events)
     if sync is not None:
       with sync.hold():       # no bucket goes out from the hooks: this leg only samples kernel durations
-        fwd_bwd()
+        step(graphs=None)
     else:
-      fwd_bwd()
+      step(graphs=None)
   torch.cuda.synchronize()
   L.lr_profile_enable(0)
   prof = {}
@@ -693,7 +660,10 @@ def main():
         "config": {"workload": head["workload"], "regime": head["regime"], "model": args.model,
                    "recurrent_layers": head["layers"], "per_gpu_batch": args.batch,
                    "global_batch": world * args.batch, "seq_len": T_FRAMES, "parallelism": "dp%d" % world,
-                   "launch": "hipGraph replay of forward+backward" if head["use_graph"]
+                   "launch": ("hipGraph replay of the product's step (lipreading_amd.train.StepGraphs): "
+                              + ("forward+backward captured, gradient exchange and optimiser launched after the replay"
+                                 if DIST_ON else "zero_grad, forward, loss, backward, clip and Adam in one graph"))
+                             if head["use_graph"]
                              else (head.get("graph_note") or
                                    ("eager launches; gradient all-reduce overlapped with backward on a side stream"
                                     if DIST_ON else "eager"))},

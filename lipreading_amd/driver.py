@@ -31,7 +31,7 @@ DEFAULTS = dict(  # train.py:134-167
     rnn_dropout=0.0, seed=123456, cuda=False,
     # not reference flags: where data/ and weights/ live, a cap for smoke runs, and the encoder+CTC-only
     # loop (no attention decoder; error = greedy-decoded CER) that the archived trainer's flag files select
-    root=".", max_epochs=None, ctc_only=False,
+    root=".", max_epochs=None, ctc_only=False, step_graphs=True,
 )
 
 
@@ -204,6 +204,10 @@ def run(**flags):
     _, correct, count, _ = T.eval(encoder, decoding_step, loader, device, char2idx)
     return _cer(correct, count)
 
+  opt = tuple(FusedAdam(fl, lr=f["learning_rate"]) for fl in flats)
+  # the step of every batch shape (B, Tmax, Lmax) is captured once as a hipGraph and replayed
+  graphs = T.StepGraphs(enabled=bool(f["step_graphs"]))
+
   print("Initial evaluation...")
   val_cer = error_of(val_loader)
   print("\tCER: ", val_cer)
@@ -229,9 +233,10 @@ def run(**flags):
     tfr = max(f["min_tfr"], f["max_tfr"] - epochs / f["tr_epochs"])
     assert 0.0 <= tfr <= 1.0
     print(f'\tCurrent Teacher Forcing Ratio: {tfr}')
-    opt = tuple(FusedAdam(fl, lr=lr) for fl in flats)   # Adam state is rebuilt every epoch (:275-276)
+    for o in opt:
+      o.reset(lr)     # what re-creating Adam every epoch does (:275-276): moments and step count start over
     dec_loss, ctc_loss = T.train(encoder, decoding_step, train_loader, opt[0] if ctc_only else opt, device, char2idx,
-                                 teacher_forcing_ratio=tfr, grad_norm=f["grad_norm"])
+                                 teacher_forcing_ratio=tfr, grad_norm=f["grad_norm"], graphs=graphs)
     print(f'\tAVG Decoder Loss: {dec_loss}')
     print(f'\tAVG CTC Loss: {ctc_loss}')
     val_cer, train_cer = error_of(val_loader), error_of(train_loader)
@@ -247,7 +252,8 @@ def run(**flags):
     if val_cer < best_val_cer:   # :339-341
       best_val_cer, best_idx = val_cer, epochs
     epochs += 1
-  return dict(history=history, weights_dir=weights_dir, seconds=time.time() - t0, epochs=epochs)
+  return dict(history=history, weights_dir=weights_dir, seconds=time.time() - t0, epochs=epochs,
+              graph_captures=graphs.captures, graph_replays=graphs.replays)
 
 
 def main(argv=None):

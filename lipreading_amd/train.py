@@ -36,26 +36,167 @@ def _check_framing(chars, char_lens, frame_lens, char2idx, use_ctc):
     assert (frame_lens[1:] - frame_lens[:-1] >= 0).all()  # ctc_loss.py:39
 
 
+class StepGraphs(object):
+  """hipGraph capture of the optimisation step, cached per batch shape.
+
+  A step is a few hundred short launches whose shapes depend only on (B, Tmax, Lmax): the collate
+  function already pads every batch to those, so the launch sequence of a shape is recorded ONCE and
+  replayed for every later batch of that shape (inputs are copied into the graph's static buffers; the
+  loss / status tensors a replay returns are the graph's static outputs — consume them, e.g. `sum +=
+  loss`, before the next step of the same shape).  The first `warmup` steps of a shape run eagerly on a
+  side stream (allocator warm-up, as capture requires), the next one is captured, the rest replay.
+  Same kernels in the same order on the same data: results are bit-identical to eager launches.
+
+  What is captured: zero_grad -> forward -> loss(es) -> backward, plus clip + Adam when no gradient
+  exchange sits between them (a collective is never captured: with `grad_sync` the exchange and the
+  optimiser run eagerly after the replay).  Steps whose launch sequence depends on host randomness (a
+  decoder loop with sampled inputs, teacher_forcing_ratio < 1) are not graphed."""
+
+  def __init__(self, max_entries=16, warmup=2, enabled=True):
+    self.max_entries, self.warmup, self.enabled = max_entries, warmup, enabled
+    self._entries = {}     # key -> dict(static=..., count=int, graph=CUDAGraph|None, out=...)
+    self.replays = 0
+    self.captures = 0
+
+  def run(self, key, inputs, body, capturable=True):
+    """inputs: tuple of device tensors; body(*static_inputs) -> tuple of tensors.  Returns body's
+    result for these inputs (from a replay when a graph for `key` exists)."""
+    if not (self.enabled and capturable):
+      return body(*inputs)
+    e = self._entries.pop(key, None)
+    if e is None:
+      if self.max_entries <= 0:
+        return body(*inputs)
+      while len(self._entries) >= self.max_entries:   # least recently used shape goes (its pool is freed)
+        self._entries.pop(next(iter(self._entries)))
+      e = dict(static=tuple(torch.empty_like(t) for t in inputs), count=0, graph=None, out=None)
+    self._entries[key] = e                            # most recently used = last
+    for dst, src in zip(e["static"], inputs):
+      dst.copy_(src, non_blocking=True)
+    if e["graph"] is not None:
+      e["graph"].replay()
+      self.replays += 1
+      return e["out"]
+    e["count"] += 1
+    if e["count"] <= self.warmup:
+      side = torch.cuda.Stream()
+      side.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(side):
+        out = body(*e["static"])
+      torch.cuda.current_stream().wait_stream(side)
+      return out
+    try:
+      torch.cuda.synchronize()
+      graph = torch.cuda.CUDAGraph()
+      # thread_local: another thread (RCCL's watchdog) may touch the runtime while this one captures
+      with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        out = body(*e["static"])
+    except Exception as exc:       # keep training: this shape stays on eager launches
+      torch.cuda.synchronize()
+      self._entries.pop(key, None)
+      self.max_entries -= 1
+      print("note: hipGraph capture failed for step shape %r (%s: %s); eager launches" % (key, type(exc).__name__, exc))
+      return body(*inputs)
+    graph.replay()                 # capture records, it does not run
+    e["graph"], e["out"] = graph, out
+    self.captures += 1
+    return out
+
+
 def ctc_step(encoder, opt, frames, frame_lens, chars, char_lens, grad_norm=None, max_len=None,
-             grad_sync=None):
+             grad_sync=None, graphs=None):
   """One encoder+CTC optimisation step with no host synchronisation.
 
   labels = chars[:,1:], label_lens = char_lens-1 (:31-32); encoder (:46); ctc_loss 'mean' (:48);
   zero_grad + backward (:67,:74); clip (:78); opt.step (:80).  `opt` is a FusedAdam; `grad_sync`
   (optional) is called between backward and the optimiser — the data-parallel all-reduce.
   Returns (loss, status) device tensors; status == 1 marks a batch the reference skips."""
-  labels = chars[:, 1:]
-  label_lens = char_lens - 1
-  opt.zero_grad()
-  log_probs, _, _ = encoder(frames, frame_lens, max_len=max_len)
-  loss, status, _ = ctc_loss_with_status(log_probs, labels, frame_lens.to(log_probs.device),
-                                         label_lens.to(log_probs.device), 'mean')
-  loss.backward()
-  scale = 1.0
-  if grad_sync is not None:
+  whole = grad_sync is None      # nothing between backward and the optimiser: one graph for the step
+
+  def body(frames, frame_lens, chars, char_lens):
+    labels = chars[:, 1:]
+    label_lens = char_lens - 1
+    opt.zero_grad()
+    log_probs, _, _ = encoder(frames, frame_lens, max_len=max_len)
+    loss, status, _ = ctc_loss_with_status(log_probs, labels, frame_lens, label_lens, 'mean')
+    loss.backward()
+    if whole:
+      opt.step(grad_norm=grad_norm, grad_scale=1.0, skip=status)
+    return loss.detach(), status
+
+  dev = frames.device
+  inputs = (frames, frame_lens.to(dev), chars.to(dev), char_lens.to(dev))
+  if graphs is None:
+    loss, status = body(*inputs)
+  else:
+    # a graph bakes max_len in: it must be the padded length itself
+    ml = frames.shape[1] if max_len is None else int(max_len)
+    # (the learning rate is a by-value kernel argument: part of what a graph bakes in)
+    key = ("ctc", id(encoder), id(opt), opt.lr, tuple(frames.shape), str(frames.dtype), tuple(chars.shape), ml,
+           grad_norm, whole)
+    loss, status = graphs.run(key, inputs, body, capturable=(ml == frames.shape[1]))
+  if not whole:
     scale = grad_sync(status)
-  opt.step(grad_norm=grad_norm, grad_scale=scale, skip=status)
-  return loss.detach(), status
+    opt.step(grad_norm=grad_norm, grad_scale=scale, skip=status)
+  return loss, status
+
+
+def decoder_step(encoder, decoding_step, opts, frames, frame_lens, chars, char_lens, flags, seed, pad,
+                 grad_norm=None, max_len=None, grad_sync=(None, None), graphs=None):
+  """The reference's WHOLE step (train_better_model.py:46-80) for one batch, all on the device:
+  encoder (:46) -> CTC 'mean' when the encoder has it (:48) -> decoder loop over len(flags) steps with
+  the given teacher-forcing pattern (:54-63) -> NLL / non-PAD count (:65) -> one backward of the sum
+  (:69,:74) -> per-module clip + Adam (:77-80).  opts = (encoder FusedAdam, decoder FusedAdam);
+  grad_sync = (encoder GradSync | None, decoder GradSync | None).
+  Returns (decoder_loss, ctc_loss | None, status | None) device tensors."""
+  syncs = tuple(grad_sync)
+  use_ctc = encoder.enable_ctc
+  L = len(flags)
+  whole = syncs[0] is None and syncs[1] is None
+
+  def body(frames, frame_lens_d, chars, char_lens_d):
+    labels = chars[:, 1:]
+    for o in opts:
+      o.zero_grad()
+    status, total, ctc = None, 0, None
+    if use_ctc:
+      log_probs, hidden, state = encoder(frames, frame_lens_d, max_len=max_len)
+      ctc, status, _ = ctc_loss_with_status(log_probs, labels, frame_lens_d, char_lens_d - 1, 'mean')
+      total = ctc
+    else:
+      hidden, state = encoder(frames, frame_lens_d, max_len=max_len)
+    log_probs_d, _, _ = decoding_step.decode_sequence(chars[:, :L], state, frame_lens_d, hidden,
+                                                      teacher_forced=flags, seed=seed)
+    V = log_probs_d.shape[-1]
+    nll = F.nll_loss(log_probs_d.reshape(-1, V), labels[:, :L].reshape(-1), ignore_index=pad, reduction='sum')
+    decoder_loss = nll / (labels != pad).sum()
+    (decoder_loss + total).backward()
+    if whole:
+      for o in opts:
+        o.step(grad_norm=grad_norm, grad_scale=1.0, skip=status)
+    out = (decoder_loss.detach(),)
+    return out + ((ctc.detach(), status) if use_ctc else ())
+
+  dev = frames.device
+  inputs = (frames, frame_lens.to(dev), chars.to(dev), char_lens.to(dev))
+  if graphs is None:
+    out = body(*inputs)
+  else:
+    ml = frames.shape[1] if max_len is None else int(max_len)
+    key = ("dec", id(encoder), id(decoding_step), tuple((id(o), o.lr) for o in opts), tuple(frames.shape),
+           str(frames.dtype), tuple(chars.shape), ml, L, grad_norm, whole, use_ctc)
+    # only the all-teacher-forced loop has a launch sequence that does not depend on the coins; its
+    # sampled tokens are not used by train(), so replaying the captured seed changes nothing
+    out = graphs.run(key, inputs, body, capturable=(all(flags) and ml == frames.shape[1]))
+  decoder_loss = out[0]
+  ctc, status = (out[1], out[2]) if use_ctc else (None, None)
+  if not whole:
+    # per-module clip (:77-79) on the all-reduced gradients; a batch the reference skips (:49-50)
+    # updates nothing (with several ranks: only if every rank skipped, GradSync's MIN over ranks)
+    for o, sync in zip(opts, syncs):
+      scale = sync(status) if sync is not None else 1.0
+      o.step(grad_norm=grad_norm, grad_scale=scale, skip=status)
+  return decoder_loss, ctc, status
 
 
 def _decoder_losses(decoding_step, chars, labels, label_lens_host, frame_lens, hidden, state,
@@ -73,7 +214,7 @@ def _decoder_losses(decoding_step, chars, labels, label_lens_host, frame_lens, h
 
 
 def train(encoder, decoding_step, data_loader, opt, device, char2idx,
-          teacher_forcing_ratio=1, grad_norm=None, grad_sync=None):
+          teacher_forcing_ratio=1, grad_norm=None, grad_sync=None, graphs=None):
   """Assumes sequences begin with BOS and end with EOS; data_loader yields
   (frames f32, frame_lens i64, chars i64, char_lens i64) — train_better_model.py:7-86.
 
@@ -83,7 +224,9 @@ def train(encoder, decoding_step, data_loader, opt, device, char2idx,
   modules separately (:77-79) and one Adam over both is the same update as two Adams.  The
   reference runs decoder_loss.backward(retain_graph) and then ctc_loss.backward() (:70,:74): two
   traversals of the encoder graph whose gradients add; here the two losses are summed and the
-  encoder is traversed once — the same gradients up to fp32 addition order."""
+  encoder is traversed once — the same gradients up to fp32 addition order.
+
+  `graphs` (optional, a StepGraphs): replay each batch shape's step as one hipGraph."""
   use_ctc = encoder.enable_ctc
   pad = char2idx[PAD]
   if decoding_step is None:
@@ -109,34 +252,22 @@ def train(encoder, decoding_step, data_loader, opt, device, char2idx,
     frame_lens_d, char_lens_d = frame_lens.to(device, non_blocking=True), char_lens.to(device, non_blocking=True)
     if decoding_step is None:
       loss, _ = ctc_step(encoder, opt, frames, frame_lens_d, chars, char_lens_d, grad_norm=grad_norm,
-                         max_len=max_len, grad_sync=grad_sync)
+                         max_len=max_len, grad_sync=grad_sync, graphs=graphs)
       ctc_sum += loss  # a skipped batch contributes 0, as `continue` does at :49-50
       continue
-    labels = chars[:, 1:]
-    for o in opts:
-      o.zero_grad()
-    status = None
-    total = 0
-    if use_ctc:
-      log_probs, hidden, state = encoder(frames, frame_lens_d, max_len=max_len)
-      ctc, status, _ = ctc_loss_with_status(log_probs, labels, frame_lens_d, char_lens_d - 1, 'mean')
-      total = ctc
-    else:
-      hidden, state = encoder(frames, frame_lens_d, max_len=max_len)
-    nll, _, _ = _decoder_losses(decoding_step, chars, labels, label_lens_host, frame_lens_d, hidden,
-                                state, teacher_forcing_ratio, pad)
-    decoder_loss = nll / (labels != pad).sum()
-    (decoder_loss + total).backward()
-    # per-module clip (:77-79) on the all-reduced gradients; a batch the reference skips (:49-50)
-    # updates nothing (with several ranks: only if every rank skipped, GradSync's MIN over ranks)
-    for o, sync in zip(opts, syncs):
-      scale = sync(status) if sync is not None else 1.0
-      o.step(grad_norm=grad_norm, grad_scale=scale, skip=status)
+    # the teacher-forcing coins (:57) and the sampler seed (:63) come from the host generator; drawn here,
+    # outside anything that may be captured
+    L = int(label_lens_host.max())
+    flags = tuple(bool(torch.rand(1) < teacher_forcing_ratio) for _ in range(L))
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    decoder_loss, ctc, status = decoder_step(encoder, decoding_step, opts, frames, frame_lens_d, chars, char_lens_d,
+                                             flags, seed, pad, grad_norm=grad_norm, max_len=max_len, grad_sync=syncs,
+                                             graphs=graphs)
     if status is None:
-      dec_sum += decoder_loss.detach()
+      dec_sum += decoder_loss
     else:
-      dec_sum += decoder_loss.detach() * (status.reshape(()) == 0)
-      ctc_sum += ctc.detach()
+      dec_sum += decoder_loss * (status.reshape(()) == 0)
+      ctc_sum += ctc
   avg_ctc_loss = (ctc_sum / len(data_loader)).item()  # :84 divides by len(data_loader)
   avg_decoder_loss = (dec_sum / len(data_loader)).item()
   if decoding_step is not None:

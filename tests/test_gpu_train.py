@@ -272,3 +272,58 @@ def test_driver_runs_the_archived_ctc_only_flag_files(dev, tmp_path):
   import os
   # best_encoder.pth appears once the greedy CER drops below 1 (better_model.py:114-122); never a decoder file
   assert not os.path.exists(os.path.join(out["weights_dir"], "best_decoder.pth"))
+
+
+@pytest.mark.parametrize("with_decoder", [False, True])
+def test_step_graphs_replay_is_bit_identical_to_eager(dev, with_decoder):
+  """train(..., graphs=StepGraphs()): every batch shape's step (zero_grad -> forward -> loss -> backward ->
+  clip -> Adam) is captured once as a hipGraph and replayed.  Same kernels, same order, same data: the
+  weights after three epochs over three batch shapes (two of them repeated, so replays really happen)
+  are BIT-identical to eager launches, with and without the attention decoder loop."""
+  from lipreading_amd import train as T
+  from lipreading_amd.attention_decoder import CharDecodingStep
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.optim import FlatParameters, FusedAdam
+  c2i = default_char2idx()
+  g = torch.Generator().manual_seed(4)
+  batches = []
+  for B, Tm, Cm in ((6, 20, 8), (6, 20, 8), (4, 17, 7), (6, 20, 8), (4, 17, 7), (5, 12, 6)):
+    lens = torch.sort(torch.randint(Tm // 2, Tm + 1, (B,), generator=g))[0]
+    lens[-1] = Tm
+    frames = torch.randn(B, Tm, 68, 3, generator=g)
+    for b in range(B):
+      frames[b, lens[b]:] = 0
+    cl = torch.randint(4, Cm + 1, (B,), generator=g)
+    cl[0] = Cm
+    chars = torch.zeros(B, Cm, dtype=torch.long)
+    for b in range(B):
+      n = int(cl[b])
+      chars[b, 0], chars[b, n - 1] = 1, 2
+      chars[b, 1:n - 1] = torch.randint(4, 64, (n - 2,), generator=g)
+    batches.append((frames.to(dev), lens, chars, cl))
+  results = []
+  for use_graphs in (False, True):
+    torch.manual_seed(9)
+    enc = VideoEncoder(204, 16, rnn_type='GRU', num_layers=1, bidirectional=True, enable_ctc=True,
+                       vocab_size=64, char2idx=c2i).to(dev)
+    fe = FlatParameters(enc)
+    dec = fd = None
+    if with_decoder:
+      dec = CharDecodingStep(enc, 12, 64, c2i, attention_type='1_layer_nn').to(dev)
+      fd = FlatParameters(dec)
+      opt = (FusedAdam(fe, lr=1e-3), FusedAdam(fd, lr=1e-3))
+    else:
+      opt = FusedAdam(fe, lr=1e-3)
+    graphs = T.StepGraphs() if use_graphs else None
+    torch.manual_seed(10)
+    losses = [T.train(enc, dec, batches, opt, dev, c2i, teacher_forcing_ratio=1, grad_norm=5.0, graphs=graphs)
+              for _ in range(3)]
+    torch.cuda.synchronize()
+    if use_graphs:
+      assert graphs.captures == 3 and graphs.replays > 3, (graphs.captures, graphs.replays)
+    results.append((losses, fe.data.clone(), fd.data.clone() if fd is not None else None))
+  assert results[0][0] == results[1][0]                    # epoch averages: identical floats
+  assert torch.equal(results[0][1], results[1][1])
+  if with_decoder:
+    assert torch.equal(results[0][2], results[1][2])
