@@ -61,7 +61,13 @@ typedef enum lr_rnn_mode {
   /* with LR_RNN_PROJ_BF16X3 | LR_RNN_INPUT_BF16_EXACT and I % 8 == 0: x (and dx) are STORED as bf16
    * matrices [B*T][I] — the conv frontend's features as they are; x is then the hi plane of the
    * projection's operand and is never converted or packed. */
-  LR_RNN_INPUT_STORED_BF16 = 0x800
+  LR_RNN_INPUT_STORED_BF16 = 0x800,
+  /* The recurrence of a supported layer (lr_rnn_pair_supported: GRU, H = 256) as ONE launch per pass and
+   * fp32-FAITHFUL: W_hh and the carried state are split into bf16 hi + lo planes, all four cross terms
+   * accumulate in fp32 on the bf16 matrix cores (~1e-6 of the exact fp32 product, against ~1e-3 for
+   * LR_RNN_RECUR_BF16); a pair of compute units per (sample, direction) exchanges its halves of the state
+   * once per step.  What the reference-faithful regime runs by default where it is supported. */
+  LR_RNN_RECUR_SPLIT = 0x1000
 } lr_rnn_mode;
 
 typedef enum lr_ctc_reduction {
@@ -175,6 +181,11 @@ int lr_sgemm(int transA, int transB, int M, int N, int K, float alpha, const flo
  *   reserve               saved activations for the backward pass (lr_rnn_reserve_bytes)
  * Pointer arrays (w_ih ...) are HOST arrays of D device pointers. */
 int lr_rnn_persistent_supported(int mode, int B, int T, int I, int H, int D);   /* see LR_RNN_RECUR_BF16 */
+int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D);         /* see LR_RNN_RECUR_SPLIT */
+/* LR_RNN_RECUR_SPLIT's two workgroups of a pair must be resident together; their waits are bounded, and a
+ * member that gave up leaves garbage and counts here.  Returns that count since the last call (0 = all
+ * results valid) and clears it; synchronises the device (tests / bench only). */
+int lr_rnn_pair_errors(void);
 size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D);
 size_t lr_rnn_workspace_bytes(int mode, int B, int T, int I, int H, int D);
 

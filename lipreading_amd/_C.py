@@ -43,6 +43,8 @@ SIGNATURES = {
     "lr_relu_backward": (c_int, [P, P, P, c_int64, P]),
     "lr_add_rows": (c_int, [P, P, c_int, c_int, c_int, P]),
     "lr_rnn_persistent_supported": (c_int, [c_int] * 6),
+    "lr_rnn_pair_supported": (c_int, [c_int] * 6),
+    "lr_rnn_pair_errors": (c_int, []),
     "lr_rnn_reserve_bytes": (c_size_t, [c_int] * 6),
     "lr_rnn_workspace_bytes": (c_size_t, [c_int] * 6),
     "lr_rnn_layer_forward": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int,

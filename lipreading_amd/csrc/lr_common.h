@@ -131,6 +131,17 @@ int lr_gru256_persist_backward(const float* gates, const float* extra, const flo
                                void* wpack, int B, int T, int D, hipStream_t stream);
 int lr_gru256_persist_forward(float* gates, float* extra, float* y, const float* const* w_hh, const float* const* b_hh,
                               const int32_t* lens, void* wpack, int B, int T, int D, hipStream_t stream);
+// lr_rnn_pair.hip: the GRU-256 recurrence as one launch per layer pass, fp32-faithful (W_hh and the state
+// as bf16 hi + lo planes, a pair of CUs per (sample, direction), one granule exchange per step)
+int lr_gru256_pair_supported(int G, int B, int H);
+size_t lr_gru256_pair_pack_bytes(int D);
+size_t lr_gru256_pair_bwd_pack_bytes(int D);
+size_t lr_gru256_pair_xch_bytes(int B, int D, int backward);
+int lr_gru256_pair_forward(float* gates, float* extra, float* y, const float* const* w_hh, const float* const* b_hh,
+                           const int32_t* lens, void* wpack, void* xch, int B, int T, int D, hipStream_t stream);
+int lr_gru256_pair_backward(const float* gates, const float* extra, const float* y, const float* dy, const float* dh_n,
+                            float* dG, const float* const* w_hh, const int32_t* lens, void* wpack, void* xch, int B,
+                            int T, int D, hipStream_t stream);
 // lr_xgemm.hip: fp32 GEMM on the bf16 matrix cores by hi/lo operand splitting (same operand
 // conventions; a_exact / b_exact: the operand's elements are bf16 values already)
 int lr_xgemm_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,

@@ -516,8 +516,8 @@ __global__ __launch_bounds__(NW * 64) void rnn_dh0_kernel(const float* __restric
 }
 
 struct Layout {
-  size_t gates, extra, bias, wp, hp, gemm, total;  // float offsets / total floats
-  size_t wp_per_dir, hp_floats, gemm_bytes;
+  size_t gates, extra, bias, wp, hp, gemm, xch, total;  // float offsets / total floats
+  size_t wp_per_dir, hp_floats, gemm_bytes, xch_bytes;
 };
 Layout reserve_layout(int G, int B, int T, int I, int H, int D, bool x3 = false) {
   Layout l;
@@ -531,12 +531,14 @@ Layout reserve_layout(int G, int B, int T, int I, int H, int D, bool x3 = false)
   l.hp_floats = 2 * (size_t)D * nbt * nchunk * FRAG;
   l.gemm = l.hp + l.hp_floats;                               // split-K slabs of the input projection
   l.gemm_bytes = x3 ? lr_xproj_workspace_bytes(B * T, I, G * H, D) : lr_sgemm_workspace_bytes(B * T, G * H, I);
-  l.total = l.gemm + (l.gemm_bytes + 3) / 4;
+  l.xch = (l.gemm + (l.gemm_bytes + 3) / 4 + 63) / 64 * 64;   // granule exchange of the pair recurrence
+  l.xch_bytes = lr_gru256_pair_supported(G, B, H) ? lr_gru256_pair_xch_bytes(B, D, 0) : 0;
+  l.total = l.xch + (l.xch_bytes + 3) / 4;
   return l;
 }
 struct WsLayout {
-  size_t dG, dcar, wT, dgp, colsum, gemm, total;  // float offsets
-  size_t gemm_bytes, wp_per_dir, dgp_floats;
+  size_t dG, dcar, wT, dgp, colsum, gemm, xch, total;  // float offsets
+  size_t gemm_bytes, wp_per_dir, dgp_floats, xch_bytes;
 };
 WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
   WsLayout l;
@@ -559,7 +561,9 @@ WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
   g2 = lr_sgemm_workspace_bytes(B * T, I, G * H);
   if (g2 > gb) gb = g2;
   l.gemm_bytes = gb;
-  l.total = l.gemm + (gb + 3) / 4;
+  l.xch = (l.gemm + (gb + 3) / 4 + 63) / 64 * 64;
+  l.xch_bytes = lr_gru256_pair_supported(G, B, H) ? lr_gru256_pair_xch_bytes(B, D, 1) : 0;
+  l.total = l.xch + (l.xch_bytes + 3) / 4;
   return l;
 }
 
@@ -568,11 +572,13 @@ inline int gates_of(int mode) { return cell_of(mode) == LR_RNN_GRU ? 3 : (cell_o
 inline bool proj_x3(int mode) { return (mode & LR_RNN_PROJ_BF16X3) != 0; }
 inline bool x_exact(int mode) { return (mode & LR_RNN_INPUT_BF16_EXACT) != 0; }
 inline bool recur_bf16(int mode) { return (mode & LR_RNN_RECUR_BF16) != 0; }
+inline bool recur_split(int mode) { return (mode & LR_RNN_RECUR_SPLIT) != 0; }
 inline bool x_stored_bf16(int mode) { return (mode & LR_RNN_INPUT_STORED_BF16) != 0; }
 bool dims_ok(int mode, int B, int T, int I, int H, int D) {
   return (cell_of(mode) == LR_RNN_GRU || cell_of(mode) == LR_RNN_LSTM || cell_of(mode) == LR_RNN_TANH) &&
          (mode & ~(LR_RNN_CELL_MASK | LR_RNN_PROJ_BF16X3 | LR_RNN_INPUT_BF16_EXACT | LR_RNN_RECUR_BF16 |
-                   LR_RNN_INPUT_STORED_BF16)) == 0 &&
+                   LR_RNN_INPUT_STORED_BF16 | LR_RNN_RECUR_SPLIT)) == 0 &&
+         !(recur_bf16(mode) && recur_split(mode)) &&
          // a bf16-stored input only makes sense on the split-bf16 projection, as an exact operand
          (!x_stored_bf16(mode) || (proj_x3(mode) && x_exact(mode) && I % 8 == 0)) &&
          B > 0 && T > 0 && I > 0 && H > 0 && (D == 1 || D == 2);
@@ -588,6 +594,11 @@ size_t x3_ws_floats(int G, int B, int T, int I, int H, int D) {
 extern "C" int lr_rnn_persistent_supported(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D)) return 0;
   return lr_gru256_persist_supported(gates_of(mode), B, H);
+}
+
+extern "C" int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D) {
+  if (!dims_ok(mode, B, T, I, H, D)) return 0;
+  return lr_gru256_pair_supported(gates_of(mode), B, H);
 }
 
 extern "C" size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D) {
@@ -641,6 +652,20 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
                              l.gemm_bytes, stream);
       if (st != LR_OK) return st;
     }
+  }
+  if (recur_split(mode)) {
+    // one launch for all T steps, fp32-faithful (lr_rnn_pair.hip); same interface buffers as the step kernels;
+    // the step kernels' packed-W_hh area of the reserve holds the bf16 hi/lo fragments instead
+    if (!lr_gru256_pair_supported(G, B, H)) return LR_ERR_UNSUPPORTED;
+    if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_gru256_pair_pack_bytes(D)) return LR_ERR_WORKSPACE;
+    int st = lr_gru256_pair_forward(gates, extra, y, w_hh, b_hh, lens, base + l.wp, base + l.xch, B, T, D, stream);
+    if (st != LR_OK) return st;
+    const int64_t total = (int64_t)D * B * H;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    LR_LAUNCH(final_state_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)y, (const float*)extra, lens, h_n,
+              (float*)nullptr, B, T, H, D);
+    return lr_launch_status();
   }
   if (recur_bf16(mode)) {
     // one launch for all T steps (lr_rnn_persist.hip); same interface buffers as the step kernels
@@ -741,6 +766,11 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
   int st = LR_OK;
   if (!(parts & 1)) {
     // dG is already in the workspace
+  } else if (recur_split(mode)) {
+    if (!lr_gru256_pair_supported(G, B, H) || dc_n) return LR_ERR_UNSUPPORTED;
+    if ((size_t)D * wl.wp_per_dir * sizeof(float) < lr_gru256_pair_bwd_pack_bytes(D)) return LR_ERR_WORKSPACE;
+    st = lr_gru256_pair_backward(gates, extra, y, dy, dh_n, dG, w_hh, lens, wT, wbase + wl.xch, B, T, D, stream);
+    if (st != LR_OK) return st;
   } else if (recur_bf16(mode)) {
     // one launch for all T steps (lr_rnn_persist.hip); dG comes out in the step kernels' layout.  The
     // packed-W_hh^T area of the workspace holds the bf16 fragments.

@@ -22,7 +22,7 @@ from .data import BOS, PAD
 _ALLOWED_RNN_TYPES = {'LSTM', 'GRU', 'RNN'}          # better_model.py:9
 _ALLOWED_FRAME_PROCESSING = {'flatten'}              # better_model.py:10
 _MODES = {'GRU': 0, 'LSTM': 1, 'RNN': 2}
-_PROJ_BF16X3, _INPUT_BF16_EXACT, _RECUR_BF16, _INPUT_STORED_BF16 = 0x100, 0x200, 0x400, 0x800   # lr_rnn_mode flags
+_PROJ_BF16X3, _INPUT_BF16_EXACT, _RECUR_BF16, _INPUT_STORED_BF16, _RECUR_SPLIT = 0x100, 0x200, 0x400, 0x800, 0x1000   # lr_rnn_mode flags
 _GATES = {'GRU': 3, 'LSTM': 4, 'RNN': 1}
 
 
@@ -255,9 +255,14 @@ class VideoEncoder(nn.Module):
     # 'bf16x3' is set by frontend.PixelLipReader for the build-defined pixel regime
     self.input_projection = 'f32'
     self.input_is_bf16 = False
-    # 'f32': one launch per time step, exact fp32 (reference-faithful); 'bf16' (pixel regime): the
-    # whole recurrence of a supported layer (GRU, H = 256) in one launch per pass with bf16 W_hh
-    self.recurrence = 'f32'
+    # how the T-step recurrence of a layer runs (not in the reference):
+    #   'f32'    one launch per time step, exact fp32 MFMA — every shape
+    #   'split'  ONE launch per layer pass, fp32-faithful (W_hh and the state as bf16 hi + lo planes, ~1e-6
+    #            of the fp32 product; lr_rnn_pair.hip) — where supported (GRU, H = 256), else as 'f32'
+    #   'bf16'   one launch per pass with single-plane bf16 recurrent operands (~1e-3): the build-defined
+    #            pixel regime's choice (frontend.PixelLipReader sets it); where unsupported as 'f32'
+    #   'auto'   = 'split' (the default: reference-faithful numerics at the one-launch speed)
+    self.recurrence = 'auto'
     if self.enable_ctc:
       self.vocab_size = vocab_size
       self.adj_vocab_size = self.vocab_size + 1      # idx 0 is reserved for the CTC blank
@@ -309,8 +314,11 @@ class VideoEncoder(nn.Module):
         lmode |= _PROJ_BF16X3 | (_INPUT_BF16_EXACT if (layer == 0 and self.input_is_bf16) else 0)
         if layer == 0 and stored_bf16:
           lmode |= _INPUT_STORED_BF16
+      assert self.recurrence in ('auto', 'f32', 'split', 'bf16'), self.recurrence
       if self.recurrence == 'bf16' and _C.lib().lr_rnn_persistent_supported(mode, B, max_len, x.shape[2], H, D):
         lmode |= _RECUR_BF16
+      elif self.recurrence in ('auto', 'split') and _C.lib().lr_rnn_pair_supported(mode, B, max_len, x.shape[2], H, D):
+        lmode |= _RECUR_SPLIT
       y, h_n, c_n = _RNNLayerFunction.apply(x, lens, lmode, H, need_dx, *weights)
       # (D,B,H) -> (B, D*H): forward direction first, as _cat_directions (better_model.py:98-112)
       h_fin.append(h_n.permute(1, 0, 2).reshape(B, D * H))

@@ -333,3 +333,81 @@ def test_bf16_recurrence_against_the_oracle_at_the_bench_shape(dev):
   d_loss = abs(float(loss_h) - float(loss_r))
   print("bf16 recurrence vs oracle: loss %.7f vs %.7f (|d| %.3g), max |d log-prob| %.3g" % (float(loss_h), float(loss_r), d_loss, d_lp))
   assert d_loss <= 1e-4 and d_lp <= 2e-3
+
+
+@pytest.mark.parametrize("B,T,bi,lens", [(32, 75, True, None),
+                                         (40, 30, True, "ragged"),      # more pairs than one launch holds: chunked
+                                         (70, 9, False, "ragged"),      # unidirectional: 64 samples per launch + 6
+                                         (3, 1, True, None), (5, 2, True, [2, 1, 2, 1, 1])])
+def test_split_recurrence_is_fp32_faithful(dev, B, T, bi, lens):
+  """LR_RNN_RECUR_SPLIT (VideoEncoder's default where supported: GRU, H = 256): the whole recurrence of a
+  layer pass in one launch, a pair of CUs per (sample, direction), W_hh and the state as bf16 hi + lo
+  planes.  Against the exact-fp32 step kernels on the same weights (2 layers: the second layer's input is
+  the first's output), forward and backward, ragged lengths, final-state gradient injected: agreement to
+  ~1e-5 relative — two orders tighter than the single-plane bf16 kernel — and no pair ever timed out."""
+  from lipreading_amd import _C
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.encoder import VideoEncoder
+  torch.manual_seed(31)
+  enc = VideoEncoder(96, 256, rnn_type='GRU', num_layers=2, bidirectional=bi, enable_ctc=True,
+                     vocab_size=64, char2idx=default_char2idx()).to(dev)
+  g = torch.Generator().manual_seed(32)
+  x = torch.randn(B, T, 96, 1, generator=g)
+  if lens == "ragged":
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[0] = T
+  elif lens is None:
+    lens = torch.full((B,), T)
+  else:
+    lens = torch.tensor(lens)
+  wgt = torch.randn(B, T, 65, generator=g).to(dev)
+  valid = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).float().unsqueeze(-1).to(dev)
+  assert _C.lib().lr_rnn_pair_supported(0, B, T, 96, 256, 2 if bi else 1) == 1
+  _C.lib().lr_rnn_pair_errors()
+  res = {}
+  for mode in ("f32", "split"):
+    enc.recurrence = mode
+    enc.zero_grad()
+    lp, hid, fin = enc(x.to(dev), lens, max_len=T)
+    ((lp * wgt * valid).sum() + hid.pow(2).sum() + 3.0 * fin.pow(2).sum()).backward()
+    res[mode] = [lp.detach().cpu() * valid.cpu(), hid.detach().cpu(), fin.detach().cpu()] + \
+                [p.grad.cpu().clone() for p in enc.parameters()]
+  enc.recurrence = "auto"
+  assert _C.lib().lr_rnn_pair_errors() == 0
+  if T > 1:
+    assert float((res["f32"][1] - res["split"][1]).abs().max()) > 0    # the other path really ran
+  worst = 0.0
+  for a, b in zip(res["f32"], res["split"]):
+    worst = max(worst, float((a - b).norm()) / max(1e-6, float(a.norm())))
+    assert float((a - b).norm()) / max(1e-6, float(a.norm())) < 2e-5
+    assert float((a - b).abs().max()) <= 1e-4 * max(1e-6, float(a.abs().max()))
+  print("split vs f32 recurrence: worst relative norm difference %.3g" % worst)
+  assert float((res["split"][1] * (1 - valid.cpu())).abs().max()) == 0.0     # padded positions exactly zero
+
+
+def test_split_recurrence_is_the_default_and_meets_the_loss_bar(dev):
+  """VideoEncoder() with no switches at the bench shape (landmarks B=32, T=75, BiGRU-256) runs the
+  one-launch fp32-faithful recurrence; CTC 'mean' loss within 1e-4 of the ORACLE (north_star), log-probs
+  within 3e-5."""
+  from lipreading_amd import _C
+  from lipreading_amd.ctc import ctc_loss_with_status
+  ref, enc = make_pair("GRU", 256, 1, True, dev)
+  assert enc.recurrence == 'auto'
+  g = torch.Generator().manual_seed(5)
+  B, T = 32, 75
+  lens = torch.sort(torch.randint(40, T + 1, (B,), generator=g))[0]
+  lens[-8:] = T
+  frames = torch.randn(B, T, 68, 3, generator=g)
+  for b in range(B):
+    frames[b, int(lens[b]):] = 0
+  labels = torch.randint(4, 64, (B, 30), generator=g)
+  ll = torch.full((B,), 30)
+  with torch.no_grad():
+    lp_r, _, _ = ref(frames, lens)
+    lp_h, _, _ = enc(frames.to(dev), lens.to(dev), max_len=T)
+    loss_r = O.ctc_loss(lp_r, labels, lens, ll, 'mean')
+    loss_h, status, _ = ctc_loss_with_status(lp_h, labels.to(dev), lens.to(dev), ll.to(dev), 'mean')
+  assert int(status) == 0 and _C.lib().lr_rnn_pair_errors() == 0
+  valid = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(-1)
+  d_lp = float(((lp_h.cpu() - lp_r) * valid).abs().max())
+  assert abs(float(loss_h) - float(loss_r)) <= 1e-4 and d_lp <= 3e-5, (float(loss_h), float(loss_r), d_lp)
