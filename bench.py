@@ -509,23 +509,29 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
                   "frac_of_hbm_peak": round(ctc_bytes / (ctc_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
                   "note": "one workgroup per sample: %d workgroups on 256 CUs — latency-bound, ~1%% of the step" % B}
   by_kernel = {k: round(v[0], 3) for k, v in prof.items()}
-  rec = "f32"       # which recurrence ran: 'f32' step kernels | 'split' pair kernel | 'bf16' one-CU kernel
+  # which recurrence ran, per direction of time: 'f32' one launch per step | 'split' one launch per layer pass on
+  # CU pairs / clusters, bf16 hi+lo planes | 'bf16' one launch per pass, single plane.  (LSTM-768: the forward pass
+  # has the cluster kernel, its backward still walks the step kernels.)
+  rec, rec_bwd = "f32", "f32"
   if not tfm:
     mode_id = {"GRU": 0, "LSTM": 1, "RNN": 2}[rnn_type]
     want = getattr(enc, "recurrence", "f32")
     if want == "bf16" and L.lr_rnn_persistent_supported(mode_id, B, T_FRAMES, frame_dim, H, D):
-      rec = "bf16"
-    elif want in ("auto", "split") and L.lr_rnn_pair_supported(mode_id, B, T_FRAMES, frame_dim, H, D):
-      rec = "split"
-  res["recurrence"] = rec
-  pass_names = {"bf16": ("gru256_fwd_persist_kernel (layer pass)", "gru256_bwd_persist_kernel (layer pass)"),
-                "split": ("gru256_fwd_pair_kernel (layer pass)", "gru256_bwd_pair_kernel (layer pass)")}
-  if rec in pass_names:
-    # the recurrence slots carry ONE launch per layer pass (all 75 steps), not a step
-    for old_k, new_k in zip(("rnn_fwd_step_kernel", "rnn_bwd_step_kernel"), pass_names[rec]):
-      if old_k in by_kernel:
-        by_kernel[new_k] = by_kernel.pop(old_k)
-    res["pair_errors"] = int(L.lr_rnn_pair_errors()) if rec == "split" else 0
+      rec = rec_bwd = "bf16"
+    elif want in ("auto", "split"):
+      kind = L.lr_rnn_pair_supported(mode_id, B, T_FRAMES, frame_dim, H, D)
+      rec = "split" if kind else "f32"
+      rec_bwd = "split" if kind == 1 else "f32"
+  res["recurrence"] = rec if rec == rec_bwd else "%s forward / %s backward" % (rec, rec_bwd)
+  pass_kernel = {("bf16", "GRU"): "gru256_%s_persist_kernel", ("split", "GRU"): "gru256_%s_pair_kernel",
+                 ("split", "LSTM"): "lstm768_%s_cluster_kernel"}
+  pass_names = {}
+  for slot, which, r in (("rnn_fwd_step_kernel", "fwd", rec), ("rnn_bwd_step_kernel", "bwd", rec_bwd)):
+    if (r, rnn_type) in pass_kernel and slot in by_kernel:
+      # this slot carries ONE launch per layer pass (all 75 steps), not a step
+      pass_names[slot] = pass_kernel[(r, rnn_type)] % which + " (layer pass)"
+      by_kernel[pass_names[slot]] = by_kernel.pop(slot)
+  res["pair_errors"] = int(L.lr_rnn_pair_errors()) if "split" in (rec, rec_bwd) else 0
   roofline = None
   if pixels:
     flops = conv_flops(B)
@@ -554,26 +560,34 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
     bytes_per_launch = D * G * H * H * 4          # W_hh streamed once per step, both directions
     flops_per_launch = 2.0 * B * D * G * H * H    # (B x H)·(H x G*H) per direction
     cand = {k: v for k, v in prof.items() if k.startswith("rnn_")}
-    if cand and rec in pass_names:
+    # per-STEP time of each direction (a pass kernel's launch covers T steps)
+    per_step = {k: (v[0] / T_FRAMES if k in pass_names else v[0]) for k, v in cand.items()}
+    if cand and max(per_step, key=per_step.get) in pass_names:
       # one launch per layer pass: per-step time = pass / T.  W_hh never leaves the CUs (registers + LDS of
-      # a pair, bf16 hi/lo planes), so the only per-step HBM traffic is the gate pre-activations in and the
-      # gates / state out; `achieved` still prices the step against the bytes a per-step launch re-streams
+      # a pair / cluster, bf16 hi/lo planes), so the only per-step HBM traffic is the gate pre-activations in
+      # and the gates / state out; `achieved` still prices the step against the bytes a per-step launch re-streams
       # (SURVEY section 8d's accounting: D*G*H^2*4 per step), so the figure is comparable across rounds.
-      dom = max(cand, key=lambda k: cand[k][0])
+      dom = max(per_step, key=per_step.get)
       us_pass = cand[dom][0]
-      us = us_pass / T_FRAMES
+      us = per_step[dom]
       ach = bytes_per_launch / (us * 1e-6) / 1e9
       io_bytes = B * D * H * 4 * (G + G + 2)     # read G gate pre-activations, write G gates + y + extra per (b, d, unit)
-      roofline = {"bound": "hbm", "kernel": pass_names[rec][0 if dom == "rnn_fwd_step_kernel" else 1],
+      r_dom = rec if dom == "rnn_fwd_step_kernel" else rec_bwd
+      cus = {"GRU": 2, "LSTM": 24}[rnn_type] if r_dom == "split" else 1
+      roofline = {"bound": "hbm", "kernel": pass_names[dom],
                   "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                   "traffic": io_bytes * T_FRAMES, "traffic_source": "computed: the pass's global loads and stores (W_hh stays "
                   "on-chip; no PMC pass for this kernel yet)",
                   "avg_launch_us": round(us_pass, 1), "us_per_step": round(us, 3), "steps_per_launch": T_FRAMES,
+                  "us_per_step_by_direction": {("forward" if k == "rnn_fwd_step_kernel" else "backward"): round(v, 3)
+                                               for k, v in per_step.items()},
                   "algorithmic_bytes_per_step": bytes_per_launch,
-                  "w_hh_residency": "registers + LDS of %d compute units per (sample, direction), bf16 %s; re-streamed bytes per step: 0"
-                                    % ((2, "hi + lo planes (fp32-faithful)") if rec == "split" else (1, "single plane")),
-                  "launches_per_step": 2 * layers, "avg_launch_us_by_kernel": by_kernel,
-                  "mfma_bf16_tflops": round((4 if rec == "split" else 1) * flops_per_launch / (us * 1e-6) / 1e12, 2)}
+                  "w_hh_residency": "registers + LDS of %d compute units per %s, bf16 %s; re-streamed bytes per step: 0"
+                                    % (cus, "(sample, direction)" if cus <= 2 else "(direction, 8 samples)",
+                                       "hi + lo planes (fp32-faithful)" if r_dom == "split" else "single plane"),
+                  "launches_per_step": sum(layers if k in pass_names else layers * T_FRAMES for k in cand),
+                  "avg_launch_us_by_kernel": by_kernel,
+                  "mfma_bf16_tflops": round((4 if r_dom == "split" else 1) * flops_per_launch / (us * 1e-6) / 1e12, 2)}
     elif cand:
       dom = max(cand, key=lambda k: cand[k][0])
       us = cand[dom][0]
@@ -623,8 +637,8 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
                        "clip_grad_norm 50 -> Adam 1e-4"
                        % (B, layers, rnn_type, H,
                           {"f32": "recurrence: one fp32-MFMA launch per time step",
-                           "split": "recurrence: one launch per layer pass, W_hh and state as bf16 hi+lo planes on a pair "
-                                    "of CUs, fp32 accumulation — fp32-faithful",
+                           "split": "recurrence: one launch per layer pass, W_hh and state as bf16 hi+lo planes held by a "
+                                    "pair (GRU-256) / cluster of 24 (LSTM-768, forward) CUs, fp32 accumulation — fp32-faithful",
                            "bf16": "recurrence: one launch per layer pass, bf16 operands"}[rec], D * H))
   return res
 

@@ -142,6 +142,14 @@ int lr_gru256_pair_forward(float* gates, float* extra, float* y, const float* co
 int lr_gru256_pair_backward(const float* gates, const float* extra, const float* y, const float* dy, const float* dh_n,
                             float* dG, const float* const* w_hh, const int32_t* lens, void* wpack, void* xch, int B,
                             int T, int D, hipStream_t stream);
+// lr_rnn_cluster.hip: the LSTM-768 recurrence as one launch per layer pass, fp32-faithful (W_hh sliced over a
+// cluster of 24 CUs per (direction, 8 samples), bf16 hi + lo planes, granule all-gather per step)
+int lr_cluster_errors();
+int lr_lstm768_cluster_supported(int G, int B, int H);
+size_t lr_lstm768_cluster_pack_bytes(int D);
+size_t lr_lstm768_cluster_xch_bytes(int B, int D);
+int lr_lstm768_cluster_forward(float* gates, float* extra, float* y, const float* const* w_hh, const int32_t* lens,
+                               void* wpack, void* xch, int B, int T, int D, hipStream_t stream);
 // lr_xgemm.hip: fp32 GEMM on the bf16 matrix cores by hi/lo operand splitting (same operand
 // conventions; a_exact / b_exact: the operand's elements are bf16 values already)
 int lr_xgemm_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,

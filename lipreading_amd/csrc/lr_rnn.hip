@@ -532,7 +532,8 @@ Layout reserve_layout(int G, int B, int T, int I, int H, int D, bool x3 = false)
   l.gemm = l.hp + l.hp_floats;                               // split-K slabs of the input projection
   l.gemm_bytes = x3 ? lr_xproj_workspace_bytes(B * T, I, G * H, D) : lr_sgemm_workspace_bytes(B * T, G * H, I);
   l.xch = (l.gemm + (l.gemm_bytes + 3) / 4 + 63) / 64 * 64;   // granule exchange of the pair recurrence
-  l.xch_bytes = lr_gru256_pair_supported(G, B, H) ? lr_gru256_pair_xch_bytes(B, D, 0) : 0;
+  l.xch_bytes = lr_gru256_pair_supported(G, B, H) ? lr_gru256_pair_xch_bytes(B, D, 0)
+                : (lr_lstm768_cluster_supported(G, B, H) ? lr_lstm768_cluster_xch_bytes(B, D) : 0);
   l.total = l.xch + (l.xch_bytes + 3) / 4;
   return l;
 }
@@ -598,7 +599,10 @@ extern "C" int lr_rnn_persistent_supported(int mode, int B, int T, int I, int H,
 
 extern "C" int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D)) return 0;
-  return lr_gru256_pair_supported(gates_of(mode), B, H);
+  // 1: GRU-256 (CU pairs, forward and backward); 2: LSTM-768 (24-CU clusters; forward — the backward pass
+  // of that shape still walks the step kernels)
+  if (lr_gru256_pair_supported(gates_of(mode), B, H)) return 1;
+  return lr_lstm768_cluster_supported(gates_of(mode), B, H) ? 2 : 0;
 }
 
 extern "C" size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D) {
@@ -656,15 +660,22 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
   if (recur_split(mode)) {
     // one launch for all T steps, fp32-faithful (lr_rnn_pair.hip); same interface buffers as the step kernels;
     // the step kernels' packed-W_hh area of the reserve holds the bf16 hi/lo fragments instead
-    if (!lr_gru256_pair_supported(G, B, H)) return LR_ERR_UNSUPPORTED;
-    if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_gru256_pair_pack_bytes(D)) return LR_ERR_WORKSPACE;
-    int st = lr_gru256_pair_forward(gates, extra, y, w_hh, b_hh, lens, base + l.wp, base + l.xch, B, T, D, stream);
+    int st;
+    if (lr_gru256_pair_supported(G, B, H)) {
+      if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_gru256_pair_pack_bytes(D)) return LR_ERR_WORKSPACE;
+      st = lr_gru256_pair_forward(gates, extra, y, w_hh, b_hh, lens, base + l.wp, base + l.xch, B, T, D, stream);
+    } else if (lr_lstm768_cluster_supported(G, B, H)) {
+      if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_lstm768_cluster_pack_bytes(D)) return LR_ERR_WORKSPACE;
+      st = lr_lstm768_cluster_forward(gates, extra, y, w_hh, lens, base + l.wp, base + l.xch, B, T, D, stream);
+    } else {
+      return LR_ERR_UNSUPPORTED;
+    }
     if (st != LR_OK) return st;
     const int64_t total = (int64_t)D * B * H;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 1024) blocks = 1024;
     LR_LAUNCH(final_state_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)y, (const float*)extra, lens, h_n,
-              (float*)nullptr, B, T, H, D);
+              G == 4 ? c_n : (float*)nullptr, B, T, H, D);
     return lr_launch_status();
   }
   if (recur_bf16(mode)) {
@@ -766,8 +777,8 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
   int st = LR_OK;
   if (!(parts & 1)) {
     // dG is already in the workspace
-  } else if (recur_split(mode)) {
-    if (!lr_gru256_pair_supported(G, B, H) || dc_n) return LR_ERR_UNSUPPORTED;
+  } else if (recur_split(mode) && lr_gru256_pair_supported(G, B, H)) {
+    if (dc_n) return LR_ERR_UNSUPPORTED;
     if ((size_t)D * wl.wp_per_dir * sizeof(float) < lr_gru256_pair_bwd_pack_bytes(D)) return LR_ERR_WORKSPACE;
     st = lr_gru256_pair_backward(gates, extra, y, dy, dh_n, dG, w_hh, lens, wT, wbase + wl.xch, B, T, D, stream);
     if (st != LR_OK) return st;

@@ -548,7 +548,8 @@ extern "C" int lr_rnn_pair_errors() {
   lr_clear_error();
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_pair_err), sizeof(int)) != hipSuccess) return -1;
   if (v && hipMemcpyToSymbol(HIP_SYMBOL(g_pair_err), &zero, sizeof(int)) != hipSuccess) return -1;
-  return v;
+  const int c = lr_cluster_errors();    // the LSTM-768 cluster kernels (lr_rnn_cluster.hip)
+  return c < 0 ? -1 : v + c;
 }
 
 int lr_gru256_pair_forward(float* gates, float* extra, float* y, const float* const* w_hh, const float* const* b_hh,

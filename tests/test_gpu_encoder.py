@@ -411,3 +411,48 @@ def test_split_recurrence_is_the_default_and_meets_the_loss_bar(dev):
   valid = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(-1)
   d_lp = float(((lp_h.cpu() - lp_r) * valid).abs().max())
   assert abs(float(loss_h) - float(loss_r)) <= 1e-4 and d_lp <= 3e-5, (float(loss_h), float(loss_r), d_lp)
+
+
+@pytest.mark.parametrize("B,T,bi,lens", [(32, 75, True, None), (37, 20, True, "ragged"), (13, 6, False, "ragged"),
+                                         (2, 1, True, None)])
+def test_lstm768_cluster_recurrence_is_fp32_faithful(dev, B, T, bi, lens):
+  """LR_RNN_RECUR_SPLIT on LSTM-768 (the ecd/* config shape; VideoEncoder's default there): the forward
+  recurrence of a layer pass in ONE launch — W_hh as bf16 hi + lo planes sliced over 24 CUs per (direction,
+  8 samples), one granule all-gather of the state per step.  Against the exact-fp32 step kernels on the same
+  weights, forward AND the backward that consumes the forward's saved gates / cell states, ragged lengths,
+  partial sample groups (B % 8 != 0), more groups than one launch holds."""
+  from lipreading_amd import _C
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.encoder import VideoEncoder
+  torch.manual_seed(41)
+  enc = VideoEncoder(64, 768, rnn_type='LSTM', num_layers=1, bidirectional=bi, enable_ctc=True,
+                     vocab_size=64, char2idx=default_char2idx()).to(dev)
+  g = torch.Generator().manual_seed(42)
+  x = torch.randn(B, T, 64, 1, generator=g)
+  if lens == "ragged":
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[0] = T
+  else:
+    lens = torch.full((B,), T)
+  wgt = torch.randn(B, T, 65, generator=g).to(dev)
+  valid = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).float().unsqueeze(-1).to(dev)
+  assert _C.lib().lr_rnn_pair_supported(1, B, T, 64, 768, 2 if bi else 1) == 2
+  _C.lib().lr_rnn_pair_errors()
+  res = {}
+  for mode in ("f32", "split"):
+    enc.recurrence = mode
+    enc.zero_grad()
+    lp, hid, fin = enc(x.to(dev), lens, max_len=T)
+    ((lp * wgt * valid).sum() + hid.pow(2).sum() + 3.0 * fin[0].pow(2).sum() + 2.0 * fin[1].pow(2).sum()).backward()
+    res[mode] = [lp.detach().cpu() * valid.cpu(), hid.detach().cpu(), fin[0].detach().cpu(), fin[1].detach().cpu()] + \
+                [p.grad.cpu().clone() for p in enc.parameters()]
+  enc.recurrence = "auto"
+  assert _C.lib().lr_rnn_pair_errors() == 0
+  if T > 1:
+    assert float((res["f32"][1] - res["split"][1]).abs().max()) > 0
+  worst = 0.0
+  for a, b in zip(res["f32"], res["split"]):
+    worst = max(worst, float((a - b).norm()) / max(1e-6, float(a.norm())))
+    assert float((a - b).norm()) / max(1e-6, float(a.norm())) < 2e-5
+  print("lstm768 cluster vs f32 recurrence: worst relative norm difference %.3g" % worst)
+  assert float((res["split"][1] * (1 - valid.cpu())).abs().max()) == 0.0
