@@ -384,7 +384,47 @@ __global__ void ctc_reduce_kernel(const float* __restrict__ nll,
     s_ll[i] = label_lens[i];
     s_w[i] = 0.f;
   }
+  __shared__ int s_plain;
+  if (threadIdx.x == 0) s_plain = 1;
   __syncthreads();
+  // The common batch — every label fits, one frame length, no infinite loss — is ONE run of the reference's
+  // loop (ctc_loss.py:64-105): its terms are formed by all threads and only the ordered sum is serial
+  // (the general scan below costs 14 us at B = 32 on the critical path between the CTC passes; this 3).
+  for (int i = threadIdx.x; i < B; i += blockDim.x)
+    if (s_ll[i] > kMaxLabelLen || s_fl[i] != s_fl[0] || isinf(s_nll[i])) s_plain = 0;
+  __syncthreads();
+  if (s_plain) {
+    const float fb = (float)B;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+      const float l = (float)(s_ll[i] < 1 ? 1 : s_ll[i]);
+      if (reduction == LR_CTC_MEAN) {
+        s_w[i] = fb / (fb * l);      // mb / (m * l) with mb = m = B, as the general path forms it
+        s_nll[i] = s_nll[i] / l;
+      } else {
+        s_w[i] = 1.f;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float run = 0.f;
+      for (int k = 0; k < B; ++k) run += s_nll[k];
+      float total = run, inv = 1.f;
+      if (reduction == LR_CTC_MEAN) total = run / fb * fb;
+      const bool none = total == 0.f;   // ctc_loss.py:110-112
+      float loss = total;
+      if (!none && reduction == LR_CTC_MEAN) {
+        inv = 1.f / fb;
+        loss = total / fb;
+      }
+      out_loss[0] = none ? 0.f : loss;
+      out_status[0] = none ? 1 : 0;
+      s_nll[0] = none ? 0.f : inv;
+    }
+    __syncthreads();
+    const float inv = s_nll[0];
+    for (int i = threadIdx.x; i < B; i += blockDim.x) grad_weight[i] = s_w[i] * inv;
+    return;
+  }
   if (threadIdx.x == 0) {
     // kept list = indices with label_len <= 256; walk it through an index array stored in
     // place of s_fl's upper half is not possible at B = max, so re-scan with a cursor.

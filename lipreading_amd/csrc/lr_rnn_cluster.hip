@@ -25,6 +25,15 @@
 // only).  Two parity slots: a member overwrites slot s & 1 at step s + 2 only after it consumed every
 // other member's step-(s + 1) data, each of which was published after its author read slot s & 1.
 // 8 clusters x 24 members = 192 workgroups per launch, one per CU; waits are bounded (lr_rnn_pair_errors).
+//
+// STATUS (round 2, MI355X, B = 32, T = 75): the FORWARD kernel is built and fp32-faithful (1e-6 of the step
+// kernels); it runs 5.6-6.0 us per step against the step kernel's 8.75 (BiLSTM-768 step 2.30 -> 2.07 ms).  Where
+// the time goes (measured by switching pieces off): 4.0 us per step remain with neither the tag wait nor the 92
+// partner MFMAs — the all-gather itself: 24 readers x 47 KB x 8 clusters = 9 MB of 8-byte granule reads per step
+// that miss L2 (agent-scope `sc1` stores drop the line: every read goes to the fabric) — + 1.15 us waiting for
+// tags + 0.8 us of MFMAs.  Not the VideoEncoder default (opt-in: recurrence = 'split'); the backward (row-split,
+// see above) is not built — that pass walks the step kernels.  Next: plain stores + sc1 loads when a cluster's
+// members verify (HW_REG_XCC_ID) that they share an XCD, so the gather is served from that XCD's L2.
 #include "lr_common.h"
 #include <hip/hip_ext.h>
 
@@ -190,17 +199,7 @@ __global__ __launch_bounds__(256, 1) void lstm768_fwd_cluster_kernel(
     bf16_t* hnxt = hS + ((s + 1) & 1) * 16 * CLD;
     float sum[CG] = {0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
-      // ask for the other 23 members' h_{s-1} (tag s, slot (s-1) & 1) now
       const u64* xp = xbase + ((s - 1) & 1) * xslot;
-      // (two batches of polls: 23 granules in flight at once would cost 46 registers)
-      constexpr int QH = 12;
-      u64 first[QH];
-#pragma unroll
-      for (int q = 1; q <= QH; ++q) {
-        int j = c + q;
-        if (j >= CC) j -= CC;
-        first[q - 1] = peek(xp + j * xmember);
-      }
       f32x4 acc0[2], acc1[2];     // hi / lo weight plane
       // ---- own member's k step (local q = 0): its operands are already in LDS ------------------------------------
       {
@@ -208,32 +207,47 @@ __global__ __launch_bounds__(256, 1) void lstm768_fwd_cluster_kernel(
         LR_CMFMA2_FIRST(acc0, a, Wa[0][0], Wa[1][0]);
         LR_CMFMA2_FIRST(acc1, a, Wa[0][1], Wa[1][1]);
       }
+      // the other 23 members' h_{s-1} (tag s, slot (s-1) & 1): asked for once the own k step is under way —
+      // a poll issued right behind the publish finds nothing yet and only costs a round
+      u64 g[CC - 1];
+#pragma unroll
+      for (int q = 1; q < CC; ++q) {
+        int j = c + q;
+        if (j >= CC) j -= CC;
+        g[q - 1] = peek(xp + j * xmember);
+      }
       // ---- the rest of the state -> LDS rows rs (hi) / rs + 8 (lo), local position 32 q + ru ------------------
-      auto land = [&](int q, int j, u64 seen) {
-        const float hv = await(xp + j * xmember, seen, s, &bad);
-        bf16_t hi, lo;
-        split_bf16(hv, hi, lo);
-        hcur[rs * CLD + 32 * q + ru] = hi;
-        hcur[(rs + 8) * CLD + 32 * q + ru] = lo;
-      };
-      u64 second[CC - 1 - QH];
+      // rounds of polls: every granule that is still missing is asked for again IN PARALLEL (a serial
+      // re-poll per granule costs a memory round trip each: 7 us per step instead of ~3)
+      unsigned pend = (1u << (CC - 1)) - 1;
+      for (int round = 0; pend && !bad; ++round) {
 #pragma unroll
-      for (int q = QH + 1; q < CC; ++q) {
-        int j = c + q;
-        if (j >= CC) j -= CC;
-        second[q - QH - 1] = peek(xp + j * xmember);
-      }
+        for (int q = 1; q < CC; ++q) {
+          if ((pend >> (q - 1)) & 1u) {
+            const u64 v = g[q - 1];
+            if ((int)(v >> 32) == s) {
+              bf16_t hi, lo;
+              split_bf16(__builtin_bit_cast(float, (unsigned)(v & 0xffffffffu)), hi, lo);
+              hcur[rs * CLD + 32 * q + ru] = hi;
+              hcur[(rs + 8) * CLD + 32 * q + ru] = lo;
+              pend &= ~(1u << (q - 1));
+            }
+          }
+        }
+        if (!pend) break;
+        if (round > SPIN_LIMIT) {
+          bad = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
 #pragma unroll
-      for (int q = 1; q <= QH; ++q) {
-        int j = c + q;
-        if (j >= CC) j -= CC;
-        land(q, j, first[q - 1]);
-      }
-#pragma unroll
-      for (int q = QH + 1; q < CC; ++q) {
-        int j = c + q;
-        if (j >= CC) j -= CC;
-        land(q, j, second[q - QH - 1]);
+        for (int q = 1; q < CC; ++q) {
+          if ((pend >> (q - 1)) & 1u) {
+            int j = c + q;
+            if (j >= CC) j -= CC;
+            g[q - 1] = peek(xp + j * xmember);
+          }
+        }
       }
       lr_lds_barrier();
       bf16x8 a_next = *reinterpret_cast<const bf16x8*>(hcur + col * CLD + 32 + kg * 8);

@@ -416,7 +416,7 @@ def test_split_recurrence_is_the_default_and_meets_the_loss_bar(dev):
 @pytest.mark.parametrize("B,T,bi,lens", [(32, 75, True, None), (37, 20, True, "ragged"), (13, 6, False, "ragged"),
                                          (2, 1, True, None)])
 def test_lstm768_cluster_recurrence_is_fp32_faithful(dev, B, T, bi, lens):
-  """LR_RNN_RECUR_SPLIT on LSTM-768 (the ecd/* config shape; VideoEncoder's default there): the forward
+  """LR_RNN_RECUR_SPLIT on LSTM-768 (the ecd/* config shape; opt-in there: recurrence = 'split'): the forward
   recurrence of a layer pass in ONE launch — W_hh as bf16 hi + lo planes sliced over 24 CUs per (direction,
   8 samples), one granule all-gather of the state per step.  Against the exact-fp32 step kernels on the same
   weights, forward AND the backward that consumes the forward's saved gates / cell states, ragged lengths,
