@@ -121,7 +121,16 @@ int lr_sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, cons
 int lr_sgemm_batched_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                           int64_t sA, const float* B, int ldb, int64_t sB, float beta, float* C, int ldc,
                           int64_t sC, const float* bias, int batch, hipStream_t stream);
+int lr_sgemm_batched_bias_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                               int64_t sA, const float* B, int ldb, int64_t sB, float beta, float* C, int ldc,
+                               int64_t sC, const float* bias, int64_t sBias, int batch, hipStream_t stream);
 extern "C" size_t lr_sgemm_workspace_bytes(int M, int N, int K);
+// up to 8 products C_i = A_i^T B_i (+ beta C_i) in one launch + one fixed-order combine (lr_gemm.hip)
+size_t lr_sgemm_grouped_workspace_bytes(int n, const int* M, const int* N, const int* K);
+int lr_sgemm_grouped_tn_impl(int n, const int* M, const int* N, const int* K, const float* const* A, const int* lda,
+                             const float* const* B, const int* ldb, float* const* C, const int* ldc, float beta,
+                             const int* row_shift, const int* period, void* workspace, size_t workspace_bytes,
+                             hipStream_t stream);
 // lr_rnn_persist.hip: the GRU-256 recurrence as one launch per layer pass (bf16 recurrent operands)
 int lr_gru256_persist_supported(int G, int B, int H);
 size_t lr_gru256_persist_pack_bytes(int D);

@@ -39,15 +39,17 @@ struct GemmArgs {
   int64_t sA, sB, sC;     // element strides between the problems of a batch (outer index)
   int batch_inner;        // problems per outer index (blockIdx.z = outer * batch_inner + inner)
   int64_t sA2, sB2, sC2;  // element strides of the inner index
+  int64_t sBias;          // element stride of `bias` between the problems of a batch (outer index)
 };
 
 template <int BM, int BN, bool TA, bool TB>
-__global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void sgemm_tile(GemmArgs g, const int bx, const int by, const int bz) {
   if (g.batch > 1) {   // batched: one problem per blockIdx.z, the whole K range
-    const int zo = blockIdx.z / g.batch_inner, zi = blockIdx.z - zo * g.batch_inner;
+    const int zo = bz / g.batch_inner, zi = bz - zo * g.batch_inner;
     g.A += (int64_t)zo * g.sA + (int64_t)zi * g.sA2;
     g.B += (int64_t)zo * g.sB + (int64_t)zi * g.sB2;
     g.C += (int64_t)zo * g.sC + (int64_t)zi * g.sC2;
+    if (g.bias) g.bias += (int64_t)zo * g.sBias;
   }
   constexpr int WM = BM / 64;  // 32x32 tiles per wave along M
   constexpr int WN = BN / 64;
@@ -63,9 +65,9 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM;
-  const int n0 = blockIdx.x * BN;
-  const int kbeg = g.batch > 1 ? 0 : blockIdx.z * g.k_chunk;
+  const int m0 = by * BM;
+  const int n0 = bx * BN;
+  const int kbeg = g.batch > 1 ? 0 : bz * g.k_chunk;
   const int kend = min(g.K, kbeg + g.k_chunk);
 
   // per-thread staging registers: BM*BK/1024 float4 of A, BN*BK/1024 float4 of B
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
         if (row >= g.M) continue;
         const float v = acc[i][j][r];
         if (g.slabs) {
-          g.slabs[((int64_t)blockIdx.z * g.M + row) * g.N + col] = v;
+          g.slabs[((int64_t)bz * g.M + row) * g.N + col] = v;
         } else {
           float out = g.alpha * v;
           if (g.bias) out += g.bias[col];
@@ -218,6 +220,68 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
         }
       }
     }
+}
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
+  sgemm_tile<BM, BN, TA, TB>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ---- grouped launch: several independent C_i = op(A_i) op(B_i) problems of ONE operand orientation in one
+// grid (the weight gradients of a recurrent layer: 4-6 small-M*N, long-K products that each fill a sixth
+// of the chip on their own).  Every problem is split along K into slabs; one grouped combine follows.
+constexpr int kMaxGroup = 8;
+struct GroupItem {
+  const float* A;
+  const float* B;
+  float* C;
+  float* slabs;
+  int M, N, K, lda, ldb, ldc;
+  float beta;
+  int row_shift, period;
+  int tiles_n, tiles, splits, k_chunk, block_begin;
+};
+struct GroupArgs {
+  GroupItem it[kMaxGroup];
+  int n;
+};
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void sgemm_grouped_kernel(GroupArgs ga) {
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < kMaxGroup; ++k)
+    if (k < ga.n && (int)blockIdx.x >= ga.it[k].block_begin) i = k;
+  const GroupItem& it = ga.it[i];
+  const int local = blockIdx.x - it.block_begin;
+  const int split = local / it.tiles, tile = local - split * it.tiles;
+  GemmArgs g;
+  g.A = it.A; g.B = it.B; g.C = it.C; g.bias = nullptr;
+  g.M = it.M; g.N = it.N; g.K = it.K;
+  g.lda = it.lda; g.ldb = it.ldb; g.ldc = it.ldc;
+  g.alpha = 1.f; g.beta = it.beta;
+  g.row_shift = it.row_shift; g.period = it.period;
+  g.k_chunk = it.k_chunk;
+  g.slabs = it.slabs;
+  g.vecA = (reinterpret_cast<uintptr_t>(it.A) & 15) == 0 && (it.lda & 3) == 0;
+  g.vecB = (reinterpret_cast<uintptr_t>(it.B) & 15) == 0 && (it.ldb & 3) == 0;
+  g.batch = 1; g.sA = g.sB = g.sC = 0;
+  g.batch_inner = 1; g.sA2 = g.sB2 = g.sC2 = 0; g.sBias = 0;
+  sgemm_tile<BM, BN, TA, TB>(g, tile % it.tiles_n, tile / it.tiles_n, split);
+}
+
+// grid (ceil(max M*N / 256), items): C_i = sum over the item's slabs in fixed order (+ beta * C_i)
+__global__ void grouped_reduce_kernel(GroupArgs ga) {
+  const GroupItem& it = ga.it[blockIdx.y];
+  if (!it.slabs) return;   // a problem that was not split wrote C itself
+  const int64_t total = (int64_t)it.M * it.N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < it.splits; ++z) s += it.slabs[(int64_t)z * total + i];
+    const int row = (int)(i / it.N), col = (int)(i - (int64_t)row * it.N);
+    float* c = it.C + (int64_t)row * it.ldc + col;
+    *c = it.beta != 0.f ? s + it.beta * *c : s;
+  }
 }
 
 // Deterministic split-K combine: fixed summation order over the slabs, then alpha/beta/bias.
@@ -299,7 +363,7 @@ int lr_sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, cons
   g.alpha = alpha; g.beta = beta;
   g.row_shift = row_shift; g.period = period;
   g.batch = 1; g.sA = g.sB = g.sC = 0;
-  g.batch_inner = 1; g.sA2 = g.sB2 = g.sC2 = 0;
+  g.batch_inner = 1; g.sA2 = g.sB2 = g.sC2 = 0; g.sBias = 0;
   g.vecA = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0;
   g.vecB = (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0;
   const GemmPlan p = plan_gemm(M, N, K, workspace ? workspace_bytes : 0);
@@ -322,12 +386,90 @@ int lr_sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, cons
   return st;
 }
 
+// Grouped products with A transposed (the weight-gradient orientation: C_i [M_i x N_i] = A_i^T B_i, A_i stored
+// [K][M], B_i stored [K][N] with the optional row remap of lr_sgemm): one GEMM launch + one combine for all of
+// them.  workspace: lr_sgemm_grouped_workspace_bytes of the same problem list.
+namespace {
+int plan_group(int n, const int* M, const int* N, const int* K, int* splits, int* k_chunk) {
+  long tiles = 0;
+  for (int i = 0; i < n; ++i) tiles += (long)((M[i] + 63) / 64) * ((N[i] + 63) / 64);
+  long want = tiles > 0 ? (768 + tiles - 1) / tiles : 1;   // ~3 workgroups per CU over the whole group
+  for (int i = 0; i < n; ++i) {
+    long sp = want, max_split = K[i] / (2 * BK);
+    if (sp > max_split) sp = max_split;
+    if (sp > 32) sp = 32;
+    if (sp < 1) sp = 1;
+    int chunk = (int)((K[i] + sp - 1) / sp);
+    chunk = (chunk + BK - 1) / BK * BK;
+    if (chunk < BK) chunk = BK;
+    k_chunk[i] = chunk;
+    splits[i] = (K[i] + chunk - 1) / chunk;
+    if (splits[i] < 1) splits[i] = 1;
+  }
+  return 0;
+}
+}  // namespace
+
+size_t lr_sgemm_grouped_workspace_bytes(int n, const int* M, const int* N, const int* K) {
+  if (n <= 0 || n > kMaxGroup) return 0;
+  int splits[kMaxGroup], chunk[kMaxGroup];
+  plan_group(n, M, N, K, splits, chunk);
+  size_t floats = 0;
+  for (int i = 0; i < n; ++i)
+    if (splits[i] > 1) floats += ((size_t)splits[i] * M[i] * N[i] + 63) / 64 * 64;
+  return (floats + 64) * sizeof(float);
+}
+
+int lr_sgemm_grouped_tn_impl(int n, const int* M, const int* N, const int* K, const float* const* A, const int* lda,
+                             const float* const* B, const int* ldb, float* const* C, const int* ldc, float beta,
+                             const int* row_shift, const int* period, void* workspace, size_t workspace_bytes,
+                             hipStream_t stream) {
+  LR_CHECK_ARG(n > 0 && n <= kMaxGroup && M && N && K && A && lda && B && ldb && C && ldc && workspace);
+  if (workspace_bytes < lr_sgemm_grouped_workspace_bytes(n, M, N, K)) return LR_ERR_WORKSPACE;
+  int splits[kMaxGroup], chunk[kMaxGroup];
+  plan_group(n, M, N, K, splits, chunk);
+  GroupArgs ga;
+  ga.n = n;
+  int blocks = 0;
+  int64_t biggest = 0;
+  float* slab = (float*)workspace;
+  for (int i = 0; i < n; ++i) {
+    LR_CHECK_ARG(A[i] && B[i] && C[i] && M[i] > 0 && N[i] > 0 && K[i] > 0 && ldc[i] >= N[i]);
+    GroupItem& it = ga.it[i];
+    it.A = A[i]; it.B = B[i]; it.C = C[i]; it.slabs = splits[i] > 1 ? slab : nullptr;
+    it.M = M[i]; it.N = N[i]; it.K = K[i]; it.lda = lda[i]; it.ldb = ldb[i]; it.ldc = ldc[i];
+    it.beta = beta;
+    it.row_shift = row_shift ? row_shift[i] : 0;
+    it.period = period ? period[i] : 0;
+    it.tiles_n = (N[i] + 63) / 64;
+    it.tiles = it.tiles_n * ((M[i] + 63) / 64);
+    it.splits = splits[i];
+    it.k_chunk = chunk[i];
+    it.block_begin = blocks;
+    blocks += it.tiles * it.splits;
+    if (splits[i] > 1) {
+      slab += ((size_t)splits[i] * M[i] * N[i] + 63) / 64 * 64;
+      if ((int64_t)M[i] * N[i] > biggest) biggest = (int64_t)M[i] * N[i];
+    }
+  }
+  for (int i = n; i < kMaxGroup; ++i) ga.it[i] = ga.it[0];
+  lr_clear_error();
+  hipLaunchKernelGGL((sgemm_grouped_kernel<64, 64, true, false>), dim3(blocks), dim3(256), 0, stream, ga);
+  int st = lr_launch_status();
+  if (st != LR_OK) return st;
+  if (biggest == 0) return LR_OK;   // nothing was split
+  int rb = (int)((biggest + 255) / 256);
+  if (rb > 512) rb = 512;
+  LR_LAUNCH(grouped_reduce_kernel, dim3(rb, n), dim3(256), 0, stream, ga);
+  return lr_launch_status();
+}
+
 // batch_outer x batch_inner independent products C_z = alpha * op(A_z) op(B_z) + beta * C_z + bias, problem
 // z = (o, i) at element offsets o * s?_outer + i * s?_inner (0 = shared operand); 64x64 tiles, no split-K.
 int lr_sgemm_batched2_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                            int64_t sA, int64_t sA2, const float* B, int ldb, int64_t sB, int64_t sB2, float beta,
                            float* C, int ldc, int64_t sC, int64_t sC2, const float* bias, int batch_outer,
-                           int batch_inner, hipStream_t stream) {
+                           int batch_inner, hipStream_t stream, int64_t sBias) {
   LR_CHECK_ARG(A && B && C);
   LR_CHECK_ARG(M > 0 && N > 0 && K >= 0 && lda > 0 && ldb > 0 && ldc >= N && batch_outer > 0 && batch_inner > 0 &&
                (int64_t)batch_outer * batch_inner <= 65535);
@@ -339,7 +481,7 @@ int lr_sgemm_batched2_impl(int transA, int transB, int M, int N, int K, float al
   g.row_shift = 0; g.period = 0;
   const int batch = batch_outer * batch_inner;
   g.batch = batch > 1 ? batch : 1; g.sA = sA; g.sB = sB; g.sC = sC;
-  g.batch_inner = batch_inner; g.sA2 = sA2; g.sB2 = sB2; g.sC2 = sC2;
+  g.batch_inner = batch_inner; g.sA2 = sA2; g.sB2 = sB2; g.sC2 = sC2; g.sBias = sBias;
   g.vecA = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0 && (sA & 3) == 0 && (sA2 & 3) == 0;
   g.vecB = (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0 && (sB & 3) == 0 && (sB2 & 3) == 0;
   g.k_chunk = (K + BK - 1) / BK * BK;
@@ -354,7 +496,15 @@ int lr_sgemm_batched_impl(int transA, int transB, int M, int N, int K, float alp
                           int64_t sA, const float* B, int ldb, int64_t sB, float beta, float* C, int ldc,
                           int64_t sC, const float* bias, int batch, hipStream_t stream) {
   return lr_sgemm_batched2_impl(transA, transB, M, N, K, alpha, A, lda, sA, 0, B, ldb, sB, 0, beta, C, ldc, sC, 0,
-                                bias, batch, 1, stream);
+                                bias, batch, 1, stream, 0);
+}
+
+// the same with a per-problem bias (bias + z * sBias): the two directions of a recurrent layer's input projection
+int lr_sgemm_batched_bias_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                               int64_t sA, const float* B, int ldb, int64_t sB, float beta, float* C, int ldc,
+                               int64_t sC, const float* bias, int64_t sBias, int batch, hipStream_t stream) {
+  return lr_sgemm_batched2_impl(transA, transB, M, N, K, alpha, A, lda, sA, 0, B, ldb, sB, 0, beta, C, ldc, sC, 0,
+                                bias, batch, 1, stream, sBias);
 }
 
 extern "C" int lr_sgemm_batched(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
@@ -363,7 +513,7 @@ extern "C" int lr_sgemm_batched(int transA, int transB, int M, int N, int K, flo
                                 int batch_outer, int batch_inner, lr_stream_t stream) {
   return lr_sgemm_batched2_impl(transA, transB, M, N, K, alpha, A, lda, sA_outer, sA_inner, B, ldb, sB_outer,
                                 sB_inner, beta, C, ldc, sC_outer, sC_inner, nullptr, batch_outer, batch_inner,
-                                (hipStream_t)stream);
+                                (hipStream_t)stream, 0);
 }
 
 extern "C" size_t lr_sgemm_workspace_bytes(int M, int N, int K) {

@@ -561,6 +561,20 @@ WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
   if (g2 > gb) gb = g2;
   g2 = lr_sgemm_workspace_bytes(B * T, I, G * H);
   if (g2 > gb) gb = g2;
+  {   // the layer's weight gradients as ONE grouped launch (rnn_layer_backward_impl)
+    int Ms[8], Ns[8], Ks[8], n = 0;
+    for (int d = 0; d < D; ++d) {
+      Ms[n] = G * H; Ns[n] = I; Ks[n] = B * T; ++n;
+      if (G == 3) {
+        Ms[n] = 2 * H; Ns[n] = H; Ks[n] = B * T; ++n;
+        Ms[n] = H; Ns[n] = H; Ks[n] = B * T; ++n;
+      } else {
+        Ms[n] = G * H; Ns[n] = H; Ks[n] = B * T; ++n;
+      }
+    }
+    g2 = lr_sgemm_grouped_workspace_bytes(n, Ms, Ns, Ks);
+    if (g2 > gb) gb = g2;
+  }
   l.gemm_bytes = gb;
   l.xch = (l.gemm + (gb + 3) / 4 + 63) / 64 * 64;
   l.xch_bytes = lr_gru256_pair_supported(G, B, H) ? lr_gru256_pair_xch_bytes(B, D, 1) : 0;
@@ -647,6 +661,12 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
     // gates[b,t,:,:] = x[b,t,:] @ [W_ih[0]; W_ih[1]]^T + folded bias: both directions in one product
     int st = lr_xproj_forward(x, B * T, I, w_ih, GH, D, bias, gates, x_exact(mode) ? 1 : 0, x_stored_bf16(mode) ? 1 : 0,
                               l.gemm_bytes ? (void*)(base + l.gemm) : nullptr, l.gemm_bytes, stream);
+    if (st != LR_OK) return st;
+  } else if (D == 2 && (((w_ih[1] - w_ih[0]) & 3) == 0)) {
+    // gates[b,t,d,:] = x[b,t,:] @ W_ih[d]^T + folded bias: both directions as one batched launch (x shared,
+    // W_ih[d] / bias[d] / the direction's column block of `gates` a fixed stride apart)
+    int st = lr_sgemm_batched_bias_impl(0, 1, B * T, GH, I, 1.f, x, I, 0, w_ih[0], I, (int64_t)(w_ih[1] - w_ih[0]), 0.f,
+                                        gates, D * GH, GH, bias, GH, D, stream);
     if (st != LR_OK) return st;
   } else {
     for (int d = 0; d < D; ++d) {
@@ -845,29 +865,39 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
     st = lr_xproj_dwhh(dG, ldg, y, D * H, R, T, H, G, D, dw_hh, wbeta, xws, xws_bytes, stream);
     if (st != LR_OK) return st;
   }
+  if (!x3) {
+    // every weight gradient of the layer in ONE grouped launch + one combine (lr_gemm.hip): each of these
+    // small-M*N, K = B*T products fills a sixth of the chip on its own.
+    //   dW_ih[d] (G*H x I) = dGx^T (slots 0..G-1 are contiguous rows) @ x
+    //   dW_hh[d] = dGh^T @ h_prev, h_prev[b,t] = y[b,t-1] (forward dir) / y[b,t+1] (reverse dir); the GRU's
+    //   n-gate rows take slot 3 (d/d(W_hn h + b_hn)) instead of slot 2
+    int Ms[8], Ns[8], Ks[8], ldas[8], ldbs[8], ldcs[8], shifts[8], periods[8], n = 0;
+    const float* As[8];
+    const float* Bs[8];
+    float* Cs[8];
+    auto add = [&](int M, int N, const float* A, const float* Bm, int ldb, float* C, int shift, int period) {
+      Ms[n] = M; Ns[n] = N; Ks[n] = R; As[n] = A; ldas[n] = ldg; Bs[n] = Bm; ldbs[n] = ldb; Cs[n] = C; ldcs[n] = N;
+      shifts[n] = shift; periods[n] = period;
+      ++n;
+    };
+    for (int d = 0; d < D; ++d) {
+      const float* dGd = dG + (size_t)d * 4 * H;
+      const float* yd = y + (size_t)d * H;
+      const int shift = d == 0 ? -1 : 1;
+      add(GH, I, dGd, x, I, dw_ih[d], 0, 0);
+      if (G == 3) {
+        add(2 * H, H, dGd, yd, D * H, dw_hh[d], shift, T);
+        add(H, H, dGd + 3 * H, yd, D * H, dw_hh[d] + (size_t)2 * H * H, shift, T);
+      } else {
+        add(GH, H, dGd, yd, D * H, dw_hh[d], shift, T);
+      }
+    }
+    st = lr_sgemm_grouped_tn_impl(n, Ms, Ns, Ks, As, ldas, Bs, ldbs, Cs, ldcs, wbeta, shifts, periods, gws,
+                                  wl.gemm_bytes, stream);
+    if (st != LR_OK) return st;
+  }
   for (int d = 0; d < D && !x3; ++d) {
     const float* dGd = dG + (size_t)d * 4 * H;
-    // dW_ih[d] (G*H x I) = dGx^T (slots 0..G-1 are contiguous rows) @ x
-    if (!x3) {
-      st = lr_sgemm_impl(1, 0, GH, I, R, 1.f, dGd, ldg, x, I, wbeta, dw_ih[d], I, nullptr, 0, 0, gws,
-                         wl.gemm_bytes, stream);
-      if (st != LR_OK) return st;
-    }
-    // dW_hh[d] = dGh^T @ h_prev, h_prev[b,t] = y[b,t-1] (forward dir) / y[b,t+1] (reverse dir)
-    const float* yd = y + (size_t)d * H;
-    const int shift = d == 0 ? -1 : 1;
-    if (G == 3) {
-      st = lr_sgemm_impl(1, 0, 2 * H, H, R, 1.f, dGd, ldg, yd, D * H, wbeta, dw_hh[d], H, nullptr,
-                         shift, T, gws, wl.gemm_bytes, stream);
-      if (st != LR_OK) return st;
-      st = lr_sgemm_impl(1, 0, H, H, R, 1.f, dGd + 3 * H, ldg, yd, D * H, wbeta,
-                         dw_hh[d] + (size_t)2 * H * H, H, nullptr, shift, T, gws, wl.gemm_bytes,
-                         stream);
-    } else {
-      st = lr_sgemm_impl(1, 0, GH, H, R, 1.f, dGd, ldg, yd, D * H, wbeta, dw_hh[d], H, nullptr, shift,
-                         T, gws, wl.gemm_bytes, stream);
-    }
-    if (st != LR_OK) return st;
     if (dx && !x3) {
       st = lr_sgemm_impl(0, 0, R, I, GH, 1.f, dGd, ldg, w_ih[d], I, d == 0 ? 0.f : 1.f, dx, I,
                          nullptr, 0, 0, gws, wl.gemm_bytes, stream);

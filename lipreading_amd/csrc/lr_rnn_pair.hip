@@ -460,14 +460,30 @@ __global__ __launch_bounds__(256, 1) void gru256_bwd_pair_kernel(
         }                                                                                           \
       }
       LR_PAIR_KSTEPS(0, 12)           // the member's own gate gradients
-      if (!gate_lane) {               // the partner's: LDS positions BOWN + g*128 + ul, rows hi / lo
+      if (!gate_lane && !bad) {       // the partner's: LDS positions BOWN + g*128 + ul, rows hi / lo
+        // rounds of polls: whatever is still missing is asked for again IN PARALLEL (a serial re-poll per
+        // granule would cost a memory round trip each)
+        unsigned pend = 7u;
+        for (int round = 0; pend; ++round) {
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          const float v = await(xp + g * HALF, first[g], s, &bad);
-          bf16_t hi, lo;
-          split_bf16(v, hi, lo);
-          gcur[BOWN + g * HALF + ul] = hi;
-          gcur[BGLD + BOWN + g * HALF + ul] = lo;
+          for (int g = 0; g < 3; ++g) {
+            if (((pend >> g) & 1u) && (int)(first[g] >> 32) == s) {
+              bf16_t hi, lo;
+              split_bf16(__builtin_bit_cast(float, (unsigned)(first[g] & 0xffffffffu)), hi, lo);
+              gcur[BOWN + g * HALF + ul] = hi;
+              gcur[BGLD + BOWN + g * HALF + ul] = lo;
+              pend &= ~(1u << g);
+            }
+          }
+          if (!pend) break;
+          if (round > SPIN_LIMIT) {
+            bad = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+          for (int g = 0; g < 3; ++g)
+            if ((pend >> g) & 1u) first[g] = peek(xp + g * HALF);
         }
       }
       lr_lds_barrier();
