@@ -507,6 +507,22 @@ Wsp ws_layout(const Sizes& z) {
                          {a, z.Hd, (int)BL}, {(int)BL, z.Hd, a}, {z.Hd, 1, (int)BL}, {z.Hd, 1, (int)BT},
                          {(int)GH, z.Hd, (int)BL}, {(int)BL, z.Hd, (int)GH}};
   w.gemm_bytes = max_gemm_ws(dims, 17);
+  {   // grouped weight-gradient launches of lr_decoder_backward: a layer's W_hh (+ W_ih) products, and the head's
+    const int bl = (int)BL, gh = (int)GH;
+    int M1[3], N1[3], K1[3], n1 = 0;
+    if (z.G == 3) {
+      M1[n1] = 2 * z.Hd; N1[n1] = z.Hd; K1[n1] = bl; ++n1;
+      M1[n1] = z.Hd; N1[n1] = z.Hd; K1[n1] = bl; ++n1;
+    } else {
+      M1[n1] = gh; N1[n1] = z.Hd; K1[n1] = bl; ++n1;
+    }
+    M1[n1] = gh; N1[n1] = z.Hd; K1[n1] = bl; ++n1;     // an upper layer's W_ih
+    const size_t g1 = lr_sgemm_grouped_workspace_bytes(n1, M1, N1, K1);
+    int Mh[4] = {gh, z.V, z.Hd, z.Hd}, Nh[4] = {z.Cd, z.Hd, z.Hd, z.Hd}, Kh[4] = {z.V, bl, bl, bl};
+    const size_t g2 = lr_sgemm_grouped_workspace_bytes(4, Mh, Nh, Kh);
+    if (g1 > w.gemm_bytes) w.gemm_bytes = g1;
+    if (g2 > w.gemm_bytes) w.gemm_bytes = g2;
+  }
   w.gemm = take((w.gemm_bytes + 3) / 4);
   w.total = o;
   return w;
@@ -898,28 +914,39 @@ extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_par
     // gradient into the initial state (the encoder's final state of this layer)
     LR_TRY(lr_rnn_dh0(G, wb + w.dcar, wb + w.dgp + (size_t)((L - 1) & 1) * w.dgp_slot, wb + w.wpT, dh0 + k * state,
                       dc0 ? dc0 + k * state : nullptr, B, L, Hd, stream));
-    // W_hh: h_prev of step t is hs[b][t-1]; step 0 used h0
+    // W_hh (h_prev of step t is hs[b][t-1]; step 0 used h0) and, for an upper layer, W_ih (x = the (dropped-out)
+    // states of the layer below): ONE grouped launch + one combine (lr_gemm.hip)
+    {
+      int Ms[3], Ns[3], Ks[3], ldas[3], ldbs[3], ldcs[3], shifts[3], periods[3], n = 0;
+      const float* As[3];
+      const float* Bs[3];
+      float* Cs[3];
+      auto add = [&](int M, const float* A, const float* Bm, float* C, int shift, int period) {
+        Ms[n] = M; Ns[n] = Hd; Ks[n] = BL; As[n] = A; ldas[n] = ldg; Bs[n] = Bm; ldbs[n] = Hd; Cs[n] = C; ldcs[n] = Hd;
+        shifts[n] = shift; periods[n] = period;
+        ++n;
+      };
+      if (G == 3) {
+        add(2 * Hd, dG, hs_k, gw_hh, -1, L);
+        add(Hd, dG + 3 * Hd, hs_k, gw_hh + (size_t)2 * Hd * Hd, -1, L);
+      } else {
+        add(GH, dG, hs_k, gw_hh, -1, L);
+      }
+      if (k > 0) add(GH, dG, drop ? rb + r.xm[k - 1] : rb + r.hsl[k - 1], gup->w_ih[k - 1], 0, 0);
+      LR_TRY(lr_sgemm_grouped_tn_impl(n, Ms, Ns, Ks, As, ldas, Bs, ldbs, Cs, ldcs, beta, shifts, periods, gws,
+                                      w.gemm_bytes, stream));
+    }
     if (G == 3) {
-      LR_TRY(lr_sgemm_impl(1, 0, 2 * Hd, Hd, BL, 1.f, dG, ldg, hs_k, Hd, beta, gw_hh, Hd, nullptr, -1, L, gws,
-                           w.gemm_bytes, stream));
-      LR_TRY(lr_sgemm_impl(1, 0, Hd, Hd, BL, 1.f, dG + 3 * Hd, ldg, hs_k, Hd, beta, gw_hh + (size_t)2 * Hd * Hd, Hd,
-                           nullptr, -1, L, gws, w.gemm_bytes, stream));
       LR_TRY(lr_sgemm_impl(1, 0, 2 * Hd, Hd, B, 1.f, dG, L * ldg, h0_k, Hd, 1.f, gw_hh, Hd, nullptr, 0, 0, nullptr, 0,
                            stream));
       LR_TRY(lr_sgemm_impl(1, 0, Hd, Hd, B, 1.f, dG + 3 * Hd, L * ldg, h0_k, Hd, 1.f, gw_hh + (size_t)2 * Hd * Hd, Hd,
                            nullptr, 0, 0, nullptr, 0, stream));
     } else {
-      LR_TRY(lr_sgemm_impl(1, 0, GH, Hd, BL, 1.f, dG, ldg, hs_k, Hd, beta, gw_hh, Hd, nullptr, -1, L, gws,
-                           w.gemm_bytes, stream));
       LR_TRY(lr_sgemm_impl(1, 0, GH, Hd, B, 1.f, dG, L * ldg, h0_k, Hd, 1.f, gw_hh, Hd, nullptr, 0, 0, nullptr, 0,
                            stream));
     }
     LR_TRY(lr_rnn_bias_grads(dG, colsum, gb_ih, gb_hh, BL, Hd, G, accumulate, stream));
     if (k > 0) {
-      // input projection of an upper layer: x = (dropped-out) states of the layer below
-      const float* x = drop ? rb + r.xm[k - 1] : rb + r.hsl[k - 1];
-      LR_TRY(lr_sgemm_impl(1, 0, GH, Hd, BL, 1.f, dG, ldg, x, Hd, beta, gup->w_ih[k - 1], Hd, nullptr, 0, 0, gws,
-                           w.gemm_bytes, stream));
       // ... and the gradient that reaches the layer below through it replaces dy
       LR_TRY(lr_sgemm_impl(0, 0, BL, Hd, GH, 1.f, dG, ldg, up->w_ih[k - 1], Hd, 0.f, dy, Hd, nullptr, 0, 0, gws,
                            w.gemm_bytes, stream));
@@ -942,22 +969,21 @@ extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_par
     LR_LAUNCH(zero_row_kernel, dim3(1), dim3(256), 0, stream, wb + w.dEW + (size_t)g->emb_padding_idx * GH, GH);
     LR_TRY(lr_launch_status());
   }
-  LR_TRY(lr_sgemm_impl(1, 0, GH, Cd, V, 1.f, wb + w.dEW, GH, p->emb, Cd, beta, g->w_ih, Cd, nullptr, 0, 0, gws,
-                       w.gemm_bytes, stream));
   LR_TRY(lr_sgemm_impl(0, 0, V, Cd, GH, 1.f, wb + w.dEW, GH, p->w_ih, Cd, beta, g->emb, Cd, nullptr, 0, 0, gws,
                        w.gemm_bytes, stream));
-
-  // output projection and concat layer
-  LR_TRY(lr_sgemm_impl(1, 0, V, Hd, BL, 1.f, dlogits, V, nh, Hd, beta, g->w_o, Hd, nullptr, 0, 0, gws, w.gemm_bytes,
-                       stream));
-  LR_TRY(colsum_into(dlogits, V, BL, V, colsum, g->b_o, accumulate, stream));
-  if (attn) {
-    LR_CHECK_ARG(g->w_c && g->b_c);
-    LR_TRY(lr_sgemm_impl(1, 0, Hd, Hd, BL, 1.f, dpre, Hd, ctx, Hd, beta, g->w_c, 2 * Hd, nullptr, 0, 0, gws,
-                         w.gemm_bytes, stream));
-    LR_TRY(lr_sgemm_impl(1, 0, Hd, Hd, BL, 1.f, dpre, Hd, hs, Hd, beta, g->w_c + Hd, 2 * Hd, nullptr, 0, 0, gws,
-                         w.gemm_bytes, stream));
-    LR_TRY(colsum_into(dpre, Hd, BL, Hd, colsum, g->b_c, accumulate, stream));
+  // layer 0's W_ih (through the table), the output projection and the two halves of the concat layer: one
+  // grouped launch + one combine
+  {
+    if (attn) LR_CHECK_ARG(g->w_c && g->b_c);
+    int Ms[4] = {GH, V, Hd, Hd}, Ns[4] = {Cd, Hd, Hd, Hd}, Ks[4] = {V, BL, BL, BL};
+    int ldas[4] = {GH, V, Hd, Hd}, ldbs[4] = {Cd, Hd, Hd, Hd}, ldcs[4] = {Cd, Hd, 2 * Hd, 2 * Hd};
+    const float* As[4] = {wb + w.dEW, dlogits, dpre, dpre};
+    const float* Bs[4] = {p->emb, nh, ctx, hs};
+    float* Cs[4] = {g->w_ih, g->w_o, attn ? g->w_c : nullptr, attn ? g->w_c + Hd : nullptr};
+    LR_TRY(lr_sgemm_grouped_tn_impl(attn ? 4 : 2, Ms, Ns, Ks, As, ldas, Bs, ldbs, Cs, ldcs, beta, nullptr, nullptr, gws,
+                                    w.gemm_bytes, stream));
   }
+  LR_TRY(colsum_into(dlogits, V, BL, V, colsum, g->b_o, accumulate, stream));
+  if (attn) LR_TRY(colsum_into(dpre, Hd, BL, Hd, colsum, g->b_c, accumulate, stream));
   return LR_OK;
 }
