@@ -575,11 +575,19 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
       ach = bytes_per_launch / (us * 1e-6) / 1e9
       io_bytes = B * D * H * 4 * (G + G + 2)     # read G gate pre-activations, write G gates + y + extra per (b, d, unit)
       r_dom = rec if dom == "rnn_fwd_step_kernel" else rec_bwd
+      pass_traffic, pass_traffic_src = io_bytes * T_FRAMES, "computed: the pass's global loads and stores (W_hh stays on-chip)"
+      try:   # per-launch HBM bytes of this kernel from the newest committed PMC passes, when it has been profiled
+        pmc, pmc_path = pmc_traffic()
+        if B == 32 and layers == 1:
+          pass_traffic = pmc[args.model][pass_names[dom].split(" ")[0]]["traffic_bytes"]
+          pass_traffic_src = ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 fetch correction; "
+                              "one launch = %d steps)" % (pmc_path, T_FRAMES))
+      except Exception:
+        pass
       cus = {"GRU": 2, "LSTM": 24}[rnn_type] if r_dom == "split" else 1
       roofline = {"bound": "hbm", "kernel": pass_names[dom],
                   "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                  "traffic": io_bytes * T_FRAMES, "traffic_source": "computed: the pass's global loads and stores (W_hh stays "
-                  "on-chip; no PMC pass for this kernel yet)",
+                  "traffic": pass_traffic, "traffic_source": pass_traffic_src,
                   "avg_launch_us": round(us_pass, 1), "us_per_step": round(us, 3), "steps_per_launch": T_FRAMES,
                   "us_per_step_by_direction": {("forward" if k == "rnn_fwd_step_kernel" else "backward"): round(v, 3)
                                                for k, v in per_step.items()},

@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""profiles/<round>_*_pmc_{FETCH,WRITE}_SIZE.txt (tools/rocpd_pmc.py output of separate rocprofv3 --pmc passes)
+-> profiles/<round>_pmc_traffic.json, the per-launch HBM/fabric bytes bench.py quotes as `roofline.traffic`.
+
+  python tools/make_pmc_traffic.py r02 [dir = profiles]
+
+traffic_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 for wide coalesced streams (gfx950: FETCH_SIZE reports half
+of a 16-B/lane stream, MI355X_MICROARCH.md); the conv kernels gather 64-byte segments, for which the counter is
+NOT halved, so theirs is (FETCH_SIZE + WRITE_SIZE) * 1024 with the doubled figure kept as traffic_bytes_upper."""
+import json
+import os
+import sys
+
+PIXELS = {  # bench.py's conv names -> a substring of the kernel symbol
+    "conv1_fwd": "conv1_fwd_patch_kernel", "conv2_fwd": "conv_patch_kernel<1, 2, true>",
+    "conv3_fwd": "conv_patch16_kernel<2, 3, true>", "conv2_dgrad": "conv_patch_kernel<2, 1, false>",
+    "conv3_dgrad": "conv_patch16_kernel<3, 2, false>", "conv1_wgrad": "conv1_wgrad_patch_kernel",
+    "conv2_wgrad": "conv_wgrad_tr_kernel<32", "conv3_wgrad": "conv_wgrad_tr_kernel<64"}
+RECURRENT = {"rnn_fwd_step_kernel": "rnn_fwd_step_kernel", "rnn_bwd_step_kernel": "rnn_bwd_step_kernel",
+             "gru256_fwd_pair_kernel": "gru256_fwd_pair_kernel", "gru256_bwd_pair_kernel": "gru256_bwd_pair_kernel",
+             "lstm768_fwd_cluster_kernel": "lstm768_fwd_cluster_kernel",
+             "gru256_fwd_persist_kernel": "gru256_fwd_persist_kernel", "gru256_bwd_persist_kernel": "gru256_bwd_persist_kernel"}
+
+
+def read(path):
+  rows = []
+  if not os.path.exists(path):
+    return rows
+  for line in open(path):
+    if line.startswith("#") or line.startswith("kernel "):
+      continue
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+      i = line.find(" " + counter + " ")
+      if i > 0:
+        vals = line[i + len(counter) + 2:].split()
+        rows.append((line[:i].strip(), counter, int(vals[0]), float(vals[1])))
+  return rows
+
+
+def lookup(rows, sub):
+  for name, _, calls, avg in rows:
+    if sub in name:
+      return avg, calls, name
+  return None
+
+
+def main(tag, d="profiles"):
+  out = {"_note": "HBM/fabric bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (bench.py "
+                  "--no-graph, a few steps), averaged over the launches; see tools/make_pmc_traffic.py for the formula.",
+         "source_files": []}
+  for model, table, doubled in (("gru256", RECURRENT, True), ("lstm768", RECURRENT, True), ("pixels", PIXELS, False)):
+    f = read(os.path.join(d, "%s_%s_pmc_FETCH_SIZE.txt" % (tag, model)))
+    w = read(os.path.join(d, "%s_%s_pmc_WRITE_SIZE.txt" % (tag, model)))
+    if not f or not w:
+      continue
+    out["source_files"] += ["%s/%s_%s_pmc_%s.txt" % (d, tag, model, c) for c in ("FETCH_SIZE", "WRITE_SIZE")]
+    sec = {}
+    for key, sub in table.items():
+      a, b = lookup(f, sub), lookup(w, sub)
+      if a is None or b is None:
+        continue
+      rec = {"kernel": a[2], "calls": a[1], "FETCH_SIZE_KiB_avg": round(a[0], 1), "WRITE_SIZE_KiB_avg": round(b[0], 1)}
+      if doubled:
+        rec["traffic_bytes"] = int((2 * a[0] + b[0]) * 1024)
+      else:
+        rec["traffic_bytes"] = int((a[0] + b[0]) * 1024)
+        rec["traffic_bytes_upper"] = int((2 * a[0] + b[0]) * 1024)
+      sec[key] = rec
+    out[model] = sec
+  path = os.path.join(d, "%s_pmc_traffic.json" % tag)
+  with open(path, "w") as fh:
+    json.dump(out, fh, indent=1)
+  print(path, {k: sorted(v) for k, v in out.items() if isinstance(v, dict)})
+
+
+if __name__ == "__main__":
+  main(*sys.argv[1:])

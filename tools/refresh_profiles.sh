@@ -1,41 +1,53 @@
 #!/usr/bin/env bash
-# Regenerates the round's measurement artefacts on a GPU box (run from the repo root, e.g. through
-#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh r01'
-# ); writes under gpurun_out/, copy what should be judged into profiles/.
-#   <round>_bench_default.json            the line `python bench.py` prints
-#   <round>_pixels_kernel_stats.txt       rocprofv3 --kernel-trace --stats, summarised per kernel
-#   <round>_pixels_pmc_{FETCH,WRITE}_SIZE.txt   HBM/fabric bytes per launch (separate --pmc passes)
+# Regenerates a round's measurement artefacts on a GPU box (run from the repo root, e.g. through
+#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r02'
+# ); writes under gpurun_out/, copy what should be judged into profiles/ (then run
+# `python tools/make_pmc_traffic.py r02` to rebuild the traffic JSON bench.py reads).
+#   <round>_bench_default.json / _bench_gru256.json / _bench_lstm768.json / _bench_forcedist.json   bench lines
+#   <round>_{pixels,gru256,lstm768,landmarks_attn}_kernel_stats.txt   rocprofv3 --kernel-trace --stats per kernel
+#   <round>_{pixels,gru256,lstm768}_pmc_{FETCH,WRITE}_SIZE.txt       HBM/fabric bytes per launch (separate --pmc passes)
 #   <round>_pixels_pmc_SQ_pass{1,2}.txt   matrix-pipe / LDS counters of the conv, recurrence and xgemm kernels
 # PMC passes never share a run with trace domains other than the kernel trace rocprofv3 adds itself.
 set -u
 R=$PWD
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 
 python bench.py 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_default.json"
+python bench.py --regime landmarks --model gru256 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_gru256.json"
+python bench.py --regime landmarks --model lstm768 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_lstm768.json"
+LIPREADING_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_forcedist.json"
 
-(cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o px -- \
-   python "$R/bench.py" --regime pixels --no-graph --steps 15 --warmup 2 --no-cpu-baseline > /dev/null 2>&1)
-python tools/rocpd_summary.py "$(find "$OUT/kt" -name '*.db' | head -1)" > "$OUT/${TAG}_pixels_kernel_stats.txt"
-rm -rf "$OUT/kt"
+kt() {   # name, bench args...
+  local name=$1; shift
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/kt_$name" -o kt -- \
+     python "$R/bench.py" "$@" --no-graph --steps 15 --warmup 2 --repeats 1 --no-cpu-baseline > /dev/null 2>&1)
+  python tools/rocpd_summary.py "$(find "$OUT/kt_$name" -name '*.db' | head -1)" 60 > "$OUT/${TAG}_${name}_kernel_stats.txt"
+  rm -rf "$OUT/kt_$name"
+}
+kt pixels --regime pixels
+kt gru256 --regime landmarks --model gru256
+kt lstm768 --regime landmarks --model lstm768
+kt landmarks_attn --regime landmarks_attn
 
+pmc() {   # name, counter list, filters..., -- bench args
+  local name=$1 counters=$2 suffix=$3; shift 3
+  local filters=()
+  while [ "$1" != "--" ]; do filters+=("$1"); shift; done
+  shift
+  (cd /tmp && rocprofv3 --pmc $counters -d "$OUT/pmc_$name" -o pm -- \
+     python "$R/bench.py" "$@" --no-graph --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline > /dev/null 2>&1)
+  python tools/rocpd_pmc.py "$(find "$OUT/pmc_$name" -name '*.db' | head -1)" "${filters[@]}" > "$OUT/${TAG}_${suffix}.txt"
+  rm -rf "$OUT/pmc_$name"
+}
 for c in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && rocprofv3 --pmc $c -d "$OUT/pmc_$c" -o px -- \
-     python "$R/bench.py" --regime pixels --no-graph --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1)
-  python tools/rocpd_pmc.py "$(find "$OUT/pmc_$c" -name '*.db' | head -1)" > "$OUT/${TAG}_pixels_pmc_$c.txt"
-  rm -rf "$OUT/pmc_$c"
+  pmc px_$c $c pixels_pmc_$c -- --regime pixels
+  pmc gru_$c $c gru256_pmc_$c -- --regime landmarks --model gru256
+  pmc lstm_$c $c lstm768_pmc_$c -- --regime landmarks --model lstm768
 done
-
-i=0
-for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" \
-         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA"; do
-  i=$((i + 1))
-  (cd /tmp && rocprofv3 --pmc $c -d "$OUT/pmc_sq$i" -o px -- \
-     python "$R/bench.py" --regime pixels --no-graph --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1)
-  python tools/rocpd_pmc.py "$(find "$OUT/pmc_sq$i" -name '*.db' | head -1)" conv_ conv1_ gru256 xgemm \
-     > "$OUT/${TAG}_pixels_pmc_SQ_pass$i.txt"
-  rm -rf "$OUT/pmc_sq$i"
-done
+pmc sq1 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" pixels_pmc_SQ_pass1 conv_ conv1_ gru256 xgemm -- --regime pixels
+pmc sq2 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA" pixels_pmc_SQ_pass2 conv_ conv1_ gru256 xgemm -- --regime pixels
+pmc sq3 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" gru256_pmc_SQ_pass1 gru256 sgemm -- --regime landmarks --model gru256
 ls -la "$OUT" | grep "${TAG}_"
