@@ -622,7 +622,8 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
   if tfm:
     res["workload"] = ("regime X-transformer (BASELINE configs[4]; frontend AND encoder build-defined, no reference "
                        "symbol): uint8 clips (B=%d,T=75,3,96,96) -> STCNN x3 (bf16 MFMA) -> Linear(3456,256) + "
-                       "sinusoidal positions -> 4 x TransformerEncoderLayer(256, 4 heads, ff 1024, post-LN, fp32) -> "
+                       "sinusoidal positions -> 4 x TransformerEncoderLayer(256, 4 heads, ff 1024, post-LN; self-attention "
+                       "fused on the bf16 matrix cores, projections split-bf16) -> "
                        "Linear(256,65) -> masked log-softmax -> CTC 'mean' (L=30+EOS) -> backward -> clip 50 -> "
                        "Adam 1e-4" % B)
   elif pixels:
@@ -697,7 +698,8 @@ def main():
     os.environ.setdefault("MASTER_PORT", "29617")
     dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
-  order = {"both": ["pixels", "landmarks"], "all": ["pixels", "landmarks", "landmarks_attn"]}.get(args.regime, [args.regime])
+  order = {"both": ["pixels", "landmarks"],
+           "all": ["pixels", "landmarks", "landmarks_attn", "pixels_tfm"]}.get(args.regime, [args.regime])
   results = [run_regime(args, r, world, rank, dev) for r in order]
   # the reference-faithful regime once more on the OTHER recurrences (GRU-256 only): the per-step fp32 launches
   # (every shape's fallback) and the single-plane bf16 one-launch kernel (the pixel regime's choice)

@@ -394,6 +394,17 @@ int lr_attn_softmax_forward(float* scores, const int32_t* key_lens, float scale,
                             lr_stream_t stream);
 int lr_attn_softmax_backward(const float* probs, float* dprobs, float scale, int B, int Hh, int T,
                              lr_stream_t stream);
+/* Fused self-attention core on the bf16 matrix cores (lr_attention.hip): per (sample, head)
+ * out = softmax_keys(scale * Q K^T, keys >= key_lens[b] masked) V, with Q / K / V read in place from the fused
+ * projection qkv [B][T][3*nhead*dh] (head h at columns h*dh of each third), out [B][T][nhead*dh]; backward:
+ * dout -> dqkv (same layout as qkv; every element written).  One workgroup per (sample, head), T <= 96, dh in
+ * {32, 64} (lr_attn_fused_supported); the T x T probabilities never leave the chip (the backward recomputes
+ * them).  bf16 operands, fp32 accumulation and softmax. */
+int lr_attn_fused_supported(int T, int dh);
+int lr_attn_fused_forward(const float* qkv, const int32_t* key_lens, float* out, float scale, int B, int T,
+                          int nhead, int dh, lr_stream_t stream);
+int lr_attn_fused_backward(const float* qkv, const int32_t* key_lens, const float* dout, float* dqkv, float scale,
+                           int B, int T, int nhead, int dh, lr_stream_t stream);
 int lr_relu_forward(const float* x, float* y, int64_t n, lr_stream_t stream);
 int lr_relu_backward(const float* y, const float* dy, float* dx, int64_t n, lr_stream_t stream);
 /* x[b][t][:] += pe[t][:]  (positional encoding) */

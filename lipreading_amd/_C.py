@@ -39,6 +39,9 @@ SIGNATURES = {
     "lr_layernorm_backward": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int, c_int, P]),
     "lr_attn_softmax_forward": (c_int, [P, P, c_float, c_int, c_int, c_int, P]),
     "lr_attn_softmax_backward": (c_int, [P, P, c_float, c_int, c_int, c_int, P]),
+    "lr_attn_fused_supported": (c_int, [c_int, c_int]),
+    "lr_attn_fused_forward": (c_int, [P, P, P, c_float, c_int, c_int, c_int, c_int, P]),
+    "lr_attn_fused_backward": (c_int, [P, P, P, P, c_float, c_int, c_int, c_int, c_int, P]),
     "lr_relu_forward": (c_int, [P, P, c_int64, P]),
     "lr_relu_backward": (c_int, [P, P, P, c_int64, P]),
     "lr_add_rows": (c_int, [P, P, c_int, c_int, c_int, P]),

@@ -117,7 +117,7 @@ class _AttentionFunction(torch.autograd.Function):
   positions >= key_lens[b] are masked."""
 
   @staticmethod
-  def forward(ctx, qkv, key_lens, nhead):
+  def forward(ctx, qkv, key_lens, nhead, fused=False):
     L = _C.lib()
     st = _C.stream_handle()
     B, T, D3 = qkv.shape
@@ -125,6 +125,15 @@ class _AttentionFunction(torch.autograd.Function):
     dh = D // nhead
     qkv = qkv.contiguous()
     dev = qkv.device
+    if fused:
+      # one launch per (sample, head) problem set on the bf16 matrix cores; nothing T x T is written
+      scale = 1.0 / math.sqrt(dh)
+      out = torch.empty((B, T, D), dtype=torch.float32, device=dev)
+      _C.check(L.lr_attn_fused_forward(qkv.data_ptr(), key_lens.data_ptr(), out.data_ptr(), scale, B, T, nhead, dh, st),
+               "lr_attn_fused_forward")
+      ctx.save_for_backward(qkv, key_lens)
+      ctx.cfg = (nhead, scale, True)
+      return out
     probs = torch.empty((B, nhead, T, T), dtype=torch.float32, device=dev)
     q, k, v = qkv.data_ptr(), qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D
     # scores[b,h] = Q[b,h] K[b,h]^T, read in place from the fused projection (row pitch 3D)
@@ -137,20 +146,27 @@ class _AttentionFunction(torch.autograd.Function):
     _C.check(L.lr_sgemm_batched(0, 0, T, dh, T, 1.0, probs.data_ptr(), T, nhead * T * T, T * T, v, D3, T * D3, dh,
                                 0.0, out.data_ptr(), D, T * D, dh, B, nhead, st), "lr_sgemm_batched(PV)")
     ctx.save_for_backward(qkv, probs)
-    ctx.cfg = (nhead, scale)
+    ctx.cfg = (nhead, scale, False)
     return out
 
   @staticmethod
   def backward(ctx, dout):
-    qkv, probs = ctx.saved_tensors
-    nhead, scale = ctx.cfg
+    nhead, scale, fused = ctx.cfg
     L = _C.lib()
     st = _C.stream_handle()
+    dout = dout.contiguous()
+    if fused:
+      qkv, key_lens = ctx.saved_tensors
+      B, T, D3 = qkv.shape
+      dqkv = torch.empty_like(qkv)
+      _C.check(L.lr_attn_fused_backward(qkv.data_ptr(), key_lens.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), scale,
+                                        B, T, nhead, D3 // 3 // nhead, st), "lr_attn_fused_backward")
+      return dqkv, None, None, None
+    qkv, probs = ctx.saved_tensors
     B, T, D3 = qkv.shape
     D = D3 // 3
     dh = D // nhead
     dev = qkv.device
-    dout = dout.contiguous()
     dqkv = torch.empty_like(qkv)
     q, k, v = qkv.data_ptr(), qkv.data_ptr() + 4 * D, qkv.data_ptr() + 8 * D
     dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + 4 * D, dqkv.data_ptr() + 8 * D
@@ -168,7 +184,7 @@ class _AttentionFunction(torch.autograd.Function):
                                 dh, B, nhead, st), "lr_sgemm_batched(dQ)")
     _C.check(L.lr_sgemm_batched(1, 0, T, dh, T, 1.0, dP.data_ptr(), T, PS, PI, q, D3, T * D3, dh, 0.0, dk, D3, T * D3,
                                 dh, B, nhead, st), "lr_sgemm_batched(dK)")
-    return dqkv, None, None
+    return dqkv, None, None, None
 
 
 class _ReluFunction(torch.autograd.Function):
@@ -225,6 +241,10 @@ class TransformerVideoEncoder(nn.Module):
     # 'f32': exact fp32 MFMA linears; 'bf16x3' (set by frontend.PixelLipReader): hi/lo split bf16 MFMA
     self.input_projection = 'f32'
     self.input_is_bf16 = False
+    # self-attention core: 'bf16' = fused QK^T -> masked softmax -> PV on the bf16 matrix cores, one launch per
+    # (sample, head) set (lr_attention.hip; T <= 96, head dim 32 / 64), else — and with 'f32' — batched fp32 MFMA
+    # GEMMs + a softmax kernel (exact fp32, the path the torch oracle is compared with at 2e-4)
+    self.attention = 'bf16'
     self.input_proj = nn.Linear(frame_dim, d_model)
     layer = nn.TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout=0.0, activation='relu',
                                        batch_first=True, norm_first=False)
@@ -258,7 +278,8 @@ class TransformerVideoEncoder(nn.Module):
     for layer in self.layers:
       at = layer.self_attn
       qkv = _LinearFunction.apply(h, at.in_proj_weight, at.in_proj_bias, x3)
-      a = _AttentionFunction.apply(qkv, lens, self.nhead)
+      fused = self.attention == 'bf16' and bool(_C.lib().lr_attn_fused_supported(max_len, self.d_model // self.nhead))
+      a = _AttentionFunction.apply(qkv, lens, self.nhead, fused)
       o = _LinearFunction.apply(a, at.out_proj.weight, at.out_proj.bias, x3)
       h = _LayerNormFunction.apply(o, h, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
       f = _ReluFunction.apply(_LinearFunction.apply(h, layer.linear1.weight, layer.linear1.bias, x3))

@@ -15,7 +15,7 @@ def dev():
   return torch.device("cuda:0")
 
 
-def make_pair(dev, frame_dim=204, d_model=64, nhead=4, layers=2, ff=128, seed=0):
+def make_pair(dev, frame_dim=204, d_model=64, nhead=4, layers=2, ff=128, seed=0, attention='f32'):
   from lipreading_amd.data import default_char2idx
   from lipreading_amd.transformer import TransformerVideoEncoder
   torch.manual_seed(seed)
@@ -25,6 +25,7 @@ def make_pair(dev, frame_dim=204, d_model=64, nhead=4, layers=2, ff=128, seed=0)
   sd = {k: v for k, v in ref.state_dict().items() if not k.startswith("encoder.")}
   res = enc.load_state_dict(sd)
   assert not res.missing_keys and not res.unexpected_keys   # torch's own parameter names
+  enc.attention = attention
   return ref.train(), enc.to(dev).train()
 
 
@@ -91,3 +92,67 @@ def test_transformer_ctc_training_step_runs_and_learns(dev):
     opt.step(grad_norm=50, skip=status)
     losses.append(float(loss.detach()))
   assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0], losses
+
+
+def run_attention(dev, B, T, nhead, dh, lens, seed):
+  """fused kernels vs an fp64 torch evaluation of the same formulas on the same fp32 inputs"""
+  from lipreading_amd.transformer import _AttentionFunction
+  g = torch.Generator().manual_seed(seed)
+  D = nhead * dh
+  qkv = torch.randn(B, T, 3 * D, generator=g)
+  dout = torch.randn(B, T, D, generator=g)
+  lens_t = torch.tensor(lens, dtype=torch.int32)
+  x = qkv.to(dev).requires_grad_(True)
+  out = _AttentionFunction.apply(x, lens_t.to(dev), nhead, True)
+  out.backward(dout.to(dev))
+  r = qkv.double().requires_grad_(True)
+  q, k, v = [t.reshape(B, T, nhead, dh).transpose(1, 2) for t in r.split(D, dim=-1)]
+  s = q @ k.transpose(-1, -2) / dh ** 0.5
+  mask = torch.arange(T).view(1, 1, 1, T) >= lens_t.view(B, 1, 1, 1)
+  p = torch.softmax(s.masked_fill(mask, float("-inf")), dim=-1)
+  want = (p @ v).transpose(1, 2).reshape(B, T, D)
+  want.backward(dout.double())
+  return out.detach().cpu().double(), want.detach(), x.grad.cpu().double(), r.grad
+
+
+@pytest.mark.parametrize("B,T,nhead,dh,lens", [(32, 75, 4, 64, None), (3, 96, 2, 64, [96, 50, 1]), (5, 33, 4, 32, [33, 20, 7, 33, 2]),
+                                               (2, 1, 4, 64, [1, 1])])
+def test_fused_bf16_attention_matches_the_formula(dev, B, T, nhead, dh, lens):
+  """lr_attn_fused_forward/backward (QK^T -> key-masked softmax -> PV and the backward, one launch each, bf16
+  MFMA with fp32 accumulation, probabilities recomputed in the backward) against an fp64 evaluation.  Stated
+  tolerance: 2e-2 of the largest entry, 1e-2 in relative norm — bf16 operand rounding (2^-9 per element)."""
+  if lens is None:
+    lens = [int(v) for v in torch.randint(20, T + 1, (B,), generator=torch.Generator().manual_seed(9))]
+    lens[0] = T
+  out, want, dx, dwant = run_attention(dev, B, T, nhead, dh, lens, seed=T + dh)
+  for a, b in ((out, want), (dx, dwant)):
+    assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max())
+    assert float((a - b).norm()) <= 1e-2 * float(b.norm())
+
+
+@pytest.mark.parametrize("attention", ["f32", "bf16"])
+def test_transformer_at_the_bench_shape(dev, attention):
+  """BASELINE configs[4] at the bench's sizes (d_model 256, 4 heads, 4 layers, ff 1024, T = 75, ragged lengths)
+  against torch.nn.TransformerEncoder on the CPU: the fp32 attention path at the exact-fp32 tolerance, the fused
+  bf16 MFMA attention (the default) at its stated bf16 tolerance (norm-wise: a rounding flip inside a ReLU or a
+  LayerNorm of a later layer moves single entries)."""
+  ref, enc = make_pair(dev, frame_dim=96, d_model=256, nhead=4, layers=4, ff=1024, seed=11, attention=attention)
+  g = torch.Generator().manual_seed(12)
+  B, T = 6, 75
+  lens = torch.tensor([75, 75, 60, 41, 33, 75])
+  x = torch.randn(B, T, 96, 1, generator=g)
+  wgt = torch.randn(B, T, 65, generator=g)
+  valid = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).float().unsqueeze(-1)
+  lp_r, h_r = ref(x, lens)
+  ((lp_r * wgt * valid).sum() + (h_r * valid).pow(2).sum()).backward()
+  lp, h, _ = enc(x.to(dev), lens, max_len=T)
+  vd = valid.to(dev)
+  ((lp * wgt.to(dev) * vd).sum() + (h * vd).pow(2).sum()).backward()
+  m = valid.bool().squeeze(-1)
+  tol = 3e-3 if attention == "f32" else 3e-2      # (fp32 path: 1.3e-3 measured on a 4-layer gradient, accumulation order)
+  for a, b in ((lp.detach().cpu()[m], lp_r.detach()[m]), (h.detach().cpu()[m], h_r.detach()[m])):
+    assert float((a - b).norm()) <= tol * float(b.norm()), attention
+  want = dict(ref.named_parameters())
+  for k, p in enc.named_parameters():
+    r = (want[k] if k in want else want["encoder." + k]).grad
+    assert float((p.grad.cpu() - r).norm()) <= tol * max(1e-6, float(r.norm())), (attention, k)

@@ -4,7 +4,7 @@
 # ); writes under gpurun_out/, copy what should be judged into profiles/ (then run
 # `python tools/make_pmc_traffic.py r02` to rebuild the traffic JSON bench.py reads).
 #   <round>_bench_default.json / _bench_gru256.json / _bench_lstm768.json / _bench_forcedist.json   bench lines
-#   <round>_{pixels,gru256,lstm768,landmarks_attn}_kernel_stats.txt   rocprofv3 --kernel-trace --stats per kernel
+#   <round>_{pixels,gru256,lstm768,landmarks_attn,pixels_tfm}_kernel_stats.txt   rocprofv3 --kernel-trace --stats per kernel
 #   <round>_{pixels,gru256,lstm768}_pmc_{FETCH,WRITE}_SIZE.txt       HBM/fabric bytes per launch (separate --pmc passes)
 #   <round>_pixels_pmc_SQ_pass{1,2}.txt   matrix-pipe / LDS counters of the conv, recurrence and xgemm kernels
 # PMC passes never share a run with trace domains other than the kernel trace rocprofv3 adds itself.
@@ -31,6 +31,7 @@ kt pixels --regime pixels
 kt gru256 --regime landmarks --model gru256
 kt lstm768 --regime landmarks --model lstm768
 kt landmarks_attn --regime landmarks_attn
+kt pixels_tfm --regime pixels_tfm
 
 pmc() {   # name, counter list, filters..., -- bench args
   local name=$1 counters=$2 suffix=$3; shift 3
