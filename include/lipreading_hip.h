@@ -368,6 +368,16 @@ int lr_decoder_backward(int mode, int attn_type, const lr_decoder_params* params
                         size_t workspace_bytes, int accumulate, int B, int L, int T, int Hd, int Cd, int V,
                         int A, lr_stream_t stream);
 
+/* The decoder loss of the train loop (train_better_model.py:62,65): over the R = B*L (sample, step) rows,
+ * -sum_r log_probs[r][label_r] for label_r != ignore_index (F.nll_loss(ignore_index=PAD, reduction='sum') summed
+ * over the steps) divided by the number of such rows ((labels != PAD).sum()).  labels: int64, row (b, i) at
+ * labels[b * label_stride + i] (a view of chars[:, 1:]).  out2[0] = loss, out2[1] = count (kept for the backward).
+ * Backward: d_log_probs [R][V] (every element written) from the upstream scalar gradient on the device. */
+int lr_nll_mean_forward(const float* log_probs, const int64_t* labels, int64_t label_stride, int L, int ignore_index,
+                        float* out2, int R, int V, lr_stream_t stream);
+int lr_nll_mean_backward(const int64_t* labels, int64_t label_stride, int L, int ignore_index, const float* fwd_out2,
+                         const float* grad_out, float* d_log_probs, int R, int V, lr_stream_t stream);
+
 /* ---- A10 (build-defined): transformer encoder blocks — no reference symbol ------ *
  * torch.nn.TransformerEncoderLayer(norm_first=False, activation=relu, dropout=0) arithmetic; the
  * host composition is lipreading_amd/transformer.py.  Contractions use lr_sgemm / lr_sgemm_batched. */

@@ -70,6 +70,8 @@ SIGNATURES = {
                            [c_int] * 7 + [P]),
     "lr_decoder_backward": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P,
                                      c_size_t, c_int] + [c_int] * 7 + [P]),
+    "lr_nll_mean_forward": (c_int, [P, P, c_int64, c_int, c_int, P, c_int, c_int, P]),
+    "lr_nll_mean_backward": (c_int, [P, c_int64, c_int, c_int, P, P, P, c_int, c_int, P]),
     "lr_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "lr_ctc_nll": (c_int, [P, c_int64, c_int64, P, c_int, P, P, P, P, c_size_t, c_int, c_int,
                             c_int, c_int, P]),

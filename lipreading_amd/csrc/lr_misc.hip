@@ -347,6 +347,79 @@ extern "C" int lr_lmk_landmarks(const float* cropped_pos, const int32_t* rects, 
   return lr_launch_status();
 }
 
+// ---- decoder loss (train_better_model.py:62,65): sum over (sample, step) rows of nll_loss(ignore_index = PAD,
+// reduction = 'sum') divided by the number of non-PAD labels, and its gradient -----------------------------------
+namespace {
+// one workgroup, fixed summation order: out[0] = -sum_r lp[r][label_r] / count, out[1] = count (rows whose label != ignore)
+__global__ __launch_bounds__(1024) void nll_mean_fwd_kernel(const float* __restrict__ lp, const int64_t* __restrict__ labels,
+                                                           int64_t label_stride, int L, int ignore, float* __restrict__ out,
+                                                           int R, int V) {
+  __shared__ float s_sum[1024];
+  __shared__ int s_cnt[1024];
+  float acc = 0.f;
+  int cnt = 0;
+  for (int r = threadIdx.x; r < R; r += 1024) {
+    const int64_t lab = labels[(int64_t)(r / L) * label_stride + (r % L)];
+    if (lab != ignore && lab >= 0 && lab < V) {
+      acc -= lp[(int64_t)r * V + lab];
+      ++cnt;
+    }
+  }
+  s_sum[threadIdx.x] = acc;
+  s_cnt[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      s_sum[threadIdx.x] += s_sum[threadIdx.x + o];
+      s_cnt[threadIdx.x] += s_cnt[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = s_sum[0] / (float)s_cnt[0];
+    out[1] = (float)s_cnt[0];
+  }
+}
+// d_lp[r][v] = (v == label_r != ignore) ? -g / count : 0, 4 columns per thread
+__global__ void nll_mean_bwd_kernel(const int64_t* __restrict__ labels, int64_t label_stride, int L, int ignore,
+                                    const float* __restrict__ fwd_out, const float* __restrict__ g,
+                                    float* __restrict__ d_lp, int R, int V) {
+  const int vq = V >> 2;
+  const float w = -g[0] / fwd_out[1];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)R * vq; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / vq), v = 4 * (int)(i - (int64_t)r * vq);
+    const int64_t lab = labels[(int64_t)(r / L) * label_stride + (r % L)];
+    const bool on = lab != ignore;
+    float4 o;
+    o.x = on && lab == v ? w : 0.f;
+    o.y = on && lab == v + 1 ? w : 0.f;
+    o.z = on && lab == v + 2 ? w : 0.f;
+    o.w = on && lab == v + 3 ? w : 0.f;
+    reinterpret_cast<float4*>(d_lp)[i] = o;
+  }
+}
+}  // namespace
+
+extern "C" int lr_nll_mean_forward(const float* log_probs, const int64_t* labels, int64_t label_stride, int L,
+                                   int ignore_index, float* out2, int R, int V, lr_stream_t stream) {
+  LR_CHECK_ARG(log_probs && labels && out2 && R > 0 && V > 0 && L > 0 && R % L == 0);
+  LR_LAUNCH(nll_mean_fwd_kernel, dim3(1), dim3(1024), 0, stream, log_probs, labels, label_stride, L, ignore_index, out2,
+            R, V);
+  return lr_launch_status();
+}
+
+extern "C" int lr_nll_mean_backward(const int64_t* labels, int64_t label_stride, int L, int ignore_index,
+                                    const float* fwd_out2, const float* grad_out, float* d_log_probs, int R, int V,
+                                    lr_stream_t stream) {
+  LR_CHECK_ARG(labels && fwd_out2 && grad_out && d_log_probs && R > 0 && V > 0 && L > 0 && R % L == 0);
+  if (V % 4 != 0) return LR_ERR_UNSUPPORTED;
+  int blocks = (int)(((int64_t)R * (V / 4) + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  LR_LAUNCH(nll_mean_bwd_kernel, dim3(blocks), dim3(256), 0, stream, labels, label_stride, L, ignore_index, fwd_out2,
+            grad_out, d_log_probs, R, V);
+  return lr_launch_status();
+}
+
 extern "C" int lr_sumsq(const float* x, int64_t n, float* out, lr_stream_t stream) {
   LR_CHECK_ARG(x && out && n >= 0);
   if (n == 0) return LR_OK;

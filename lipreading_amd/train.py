@@ -13,6 +13,7 @@ path BASELINE.json's north_star names; with a `CharDecodingStep` the attention d
 import torch
 import torch.nn.functional as F
 
+from . import _C
 from .ctc import ctc_loss_with_status
 from .data import BOS, EOS, PAD
 from .optim import FusedAdam
@@ -34,6 +35,44 @@ def _check_framing(chars, char_lens, frame_lens, char2idx, use_ctc):
   assert (labels != char2idx[PAD]).sum() == label_lens.sum()
   if use_ctc:
     assert (frame_lens[1:] - frame_lens[:-1] >= 0).all()  # ctc_loss.py:39
+
+
+class _NLLMeanFunction(torch.autograd.Function):
+  """train_better_model.py:62,65 in two launches: sum over the decoder steps of nll_loss(ignore_index=PAD,
+  reduction='sum') divided by (labels != PAD).sum().  log_probs (B, L, V); labels = a view of chars[:, 1:]
+  whose first L columns are the steps' labels (int64, any row stride)."""
+
+  @staticmethod
+  def forward(ctx, log_probs, labels, pad):
+    B, L, V = log_probs.shape
+    lp = log_probs.contiguous()
+    assert labels.dtype == torch.int64 and labels.stride(1) == 1 and labels.shape[0] == B and labels.shape[1] >= L
+    out2 = torch.empty(2, dtype=torch.float32, device=lp.device)
+    _C.check(_C.lib().lr_nll_mean_forward(lp.data_ptr(), labels.data_ptr(), labels.stride(0), L, int(pad),
+                                          out2.data_ptr(), B * L, V, _C.stream_handle()), "lr_nll_mean_forward")
+    ctx.save_for_backward(labels, out2)
+    ctx.cfg = (B, L, V, int(pad))
+    return out2[0]
+
+  @staticmethod
+  def backward(ctx, g):
+    labels, out2 = ctx.saved_tensors
+    B, L, V, pad = ctx.cfg
+    g = g.reshape(1).to(torch.float32).contiguous()
+    d_lp = torch.empty((B, L, V), dtype=torch.float32, device=out2.device)
+    _C.check(_C.lib().lr_nll_mean_backward(labels.data_ptr(), labels.stride(0), L, pad, out2.data_ptr(), g.data_ptr(),
+                                           d_lp.data_ptr(), B * L, V, _C.stream_handle()), "lr_nll_mean_backward")
+    return d_lp, None, None
+
+
+def decoder_nll(log_probs, labels, pad):
+  """decoder_loss of train_better_model.py:62-65 from the (B, L, V) log-probs of the loop."""
+  if log_probs.shape[-1] % 4 == 0:
+    return _NLLMeanFunction.apply(log_probs, labels, pad)
+  V = log_probs.shape[-1]
+  L = log_probs.shape[1]
+  nll = F.nll_loss(log_probs.reshape(-1, V), labels[:, :L].reshape(-1), ignore_index=pad, reduction='sum')
+  return nll / (labels != pad).sum()
 
 
 class StepGraphs(object):
@@ -167,9 +206,7 @@ def decoder_step(encoder, decoding_step, opts, frames, frame_lens, chars, char_l
       hidden, state = encoder(frames, frame_lens_d, max_len=max_len)
     log_probs_d, _, _ = decoding_step.decode_sequence(chars[:, :L], state, frame_lens_d, hidden,
                                                       teacher_forced=flags, seed=seed)
-    V = log_probs_d.shape[-1]
-    nll = F.nll_loss(log_probs_d.reshape(-1, V), labels[:, :L].reshape(-1), ignore_index=pad, reduction='sum')
-    decoder_loss = nll / (labels != pad).sum()
+    decoder_loss = decoder_nll(log_probs_d, labels, pad)
     (decoder_loss + total).backward()
     if whole:
       for o in opts:

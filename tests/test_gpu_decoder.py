@@ -311,3 +311,25 @@ def test_train_and_eval_with_decoder_follow_reference_loop(dev, rnn_type, attn):
   d, correct, cnt, c = T.eval(enc, dec, batches, dev, c2i)
   assert cnt == count and 0 <= correct <= count
   assert abs(d - nll / count) < 2e-4 and abs(c - csum / 3) < 2e-3
+
+
+def test_fused_decoder_nll_equals_the_reference_formula(dev):
+  """train.decoder_nll (lr_nll_mean_forward/backward: two launches) = sum over steps of F.nll_loss(ignore_index=PAD,
+  reduction='sum') / (labels != PAD).sum() (train_better_model.py:62,65), value and gradient; labels are the strided
+  view chars[:, 1:] the loop slices."""
+  from lipreading_amd.train import decoder_nll
+  g = torch.Generator().manual_seed(3)
+  B, L, V = 7, 9, 64
+  chars = torch.randint(4, V, (B, L + 1), generator=g)
+  for b, n in enumerate([9, 3, 5, 9, 1, 7, 2]):
+    chars[b, 1 + n:] = 0                       # PAD after each sample's labels
+  lp = torch.log_softmax(torch.randn(B, L, V, generator=g), -1)
+  labels = chars[:, 1:]
+  a = lp.clone().requires_grad_(True)
+  want = F.nll_loss(a.reshape(-1, V), labels.reshape(-1), ignore_index=0, reduction='sum') / (labels != 0).sum()
+  (want * 1.7).backward()
+  x = lp.to(dev).requires_grad_(True)
+  got = decoder_nll(x, chars.to(dev)[:, 1:], 0)
+  (got * 1.7).backward()
+  assert abs(float(got) - float(want)) <= 1e-6 * abs(float(want))
+  np.testing.assert_allclose(x.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-6, atol=0)
