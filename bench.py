@@ -49,7 +49,8 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3      # fp32-input MFMA
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA
 PARITY_TOL_LANDMARKS = 1e-4       # north_star: CTC loss within 1e-4 of the CPU reference (fp32, absolute)
-PARITY_TOL_PIXELS = 1e-3          # bf16 conv stack + bf16 recurrent operands vs the fp32 reference tail
+PARITY_TOL_PIXELS = 1e-4          # north_star's bar at (B=32,T=75,96x96); measured 3.1e-5 (bf16 conv stack and recurrent operands
+                                  # vs the oracle's bf16-storage conv + fp32 reference tail)
 # lr_profile_read slots (include/lipreading_hip.h)
 SLOTS = {0: "rnn_fwd_step_kernel", 1: "rnn_bwd_step_kernel", 2: "conv1_fwd", 3: "conv2_fwd",
          4: "conv3_fwd", 5: "conv2_dgrad", 6: "conv3_dgrad", 7: "conv1_wgrad",
