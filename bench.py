@@ -428,6 +428,26 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
       graphs.enabled, use_graph = False, False
       graph_note = "hipGraph capture failed; eager launches"
 
+  # GPU-bound steps (the pixel regimes: ~100 long kernels, two streams) gain nothing from a graph and may lose
+  # a little (the captured side-stream branches overlap less well than eager launches do): time both forms on
+  # a few untimed steps and keep the faster one.  Launch-bound steps (landmarks) always replay.
+  launch_choice = None
+  if use_graph and pixels and not DIST_ON:
+    def probe(g):
+      fence()
+      t0 = time.perf_counter()
+      for _ in range(6):
+        step(graphs=g, **{k: v for k, v in step_sync.items()})
+      fence()
+      return (time.perf_counter() - t0) / 6
+    probe(None)
+    t_replay, t_eager = probe(graphs), probe(None)
+    launch_choice = {"replay_ms": round(t_replay * 1e3, 4), "eager_ms": round(t_eager * 1e3, 4)}
+    if t_eager < 0.995 * t_replay:
+      step_sync["graphs"] = None
+      use_graph = False
+      graph_note = ("eager launches (auto: %.3f ms/step against %.3f for the hipGraph replay of the same step)"
+                    % (t_eager * 1e3, t_replay * 1e3))
   L = _C.lib()
   for _ in range(args.warmup):
     loss, status = step(**step_sync)
@@ -486,7 +506,8 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
     flat.grad.zero_()
   res = {"regime": regime, "elapsed": elapsed, "loss": float(loss.item()), "skipped": int(status.item()),
          "layers": layers, "use_graph": use_graph, "graph_note": graph_note,
-         "rccl_ranks": dist.get_world_size() if DIST_ON else 1, "all_reduce_buckets": bucket_us}
+         "rccl_ranks": dist.get_world_size() if DIST_ON else 1, "all_reduce_buckets": bucket_us,
+         "launch_choice": launch_choice}
   if sync is not None:
     sync.close()
   if dec_sync is not None:
@@ -511,8 +532,7 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
                   "note": "one workgroup per sample: %d workgroups on 256 CUs — latency-bound, ~1%% of the step" % B}
   by_kernel = {k: round(v[0], 3) for k, v in prof.items()}
   # which recurrence ran, per direction of time: 'f32' one launch per step | 'split' one launch per layer pass on
-  # CU pairs / clusters, bf16 hi+lo planes | 'bf16' one launch per pass, single plane.  (LSTM-768: the forward pass
-  # has the cluster kernel, its backward still walks the step kernels.)
+  # CU pairs (GRU-256) / 24-CU clusters (LSTM-768), bf16 hi+lo planes | 'bf16' one launch per pass, single plane.
   rec, rec_bwd = "f32", "f32"
   if not tfm:
     mode_id = {"GRU": 0, "LSTM": 1, "RNN": 2}[rnn_type]
@@ -521,10 +541,7 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
       rec = rec_bwd = "bf16"
     elif want in ("auto", "split"):
       kind = L.lr_rnn_pair_supported(mode_id, B, T_FRAMES, frame_dim, H, D)
-      if kind == 2 and want == "auto":
-        kind = 0        # forward-only kernels (LSTM-768) are opt-in
-      rec = "split" if kind else "f32"
-      rec_bwd = "split" if kind == 1 else "f32"
+      rec = rec_bwd = "split" if kind else "f32"
   res["recurrence"] = rec if rec == rec_bwd else "%s forward / %s backward" % (rec, rec_bwd)
   pass_kernel = {("bf16", "GRU"): "gru256_%s_persist_kernel", ("split", "GRU"): "gru256_%s_pair_kernel",
                  ("split", "LSTM"): "lstm768_%s_cluster_kernel"}
@@ -650,7 +667,7 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
                        % (B, layers, rnn_type, H,
                           {"f32": "recurrence: one fp32-MFMA launch per time step",
                            "split": "recurrence: one launch per layer pass, W_hh and state as bf16 hi+lo planes held by a "
-                                    "pair (GRU-256) / cluster of 24 (LSTM-768, forward) CUs, fp32 accumulation — fp32-faithful",
+                                    "pair (GRU-256) / cluster of 24 (LSTM-768) CUs, fp32 accumulation — fp32-faithful",
                            "bf16": "recurrence: one launch per layer pass, bf16 operands"}[rec], D * H))
   return res
 
@@ -702,14 +719,14 @@ def main():
   order = {"both": ["pixels", "landmarks"],
            "all": ["pixels", "landmarks", "landmarks_attn", "pixels_tfm"]}.get(args.regime, [args.regime])
   results = [run_regime(args, r, world, rank, dev) for r in order]
-  # the reference-faithful regime once more on the OTHER recurrences (GRU-256 only): the per-step fp32 launches
-  # (every shape's fallback) and the single-plane bf16 one-launch kernel (the pixel regime's choice)
+  # the reference-faithful regime once more on the OTHER recurrences: the per-step fp32 launches (every shape's
+  # fallback) and, GRU-256 only, the single-plane bf16 one-launch kernel (the pixel regime's choice)
   options = {}
   if "landmarks" in order and args.regime == "all" and MODELS[args.model][0] == "GRU" and MODELS[args.model][1] == 256:
     for name in ("f32", "bf16"):
       options[name] = run_regime(args, "landmarks", world, rank, dev, recurrence=name)
   elif "landmarks" in order and args.regime in ("all", "landmarks") and args.model == "lstm768":
-    options["split"] = run_regime(args, "landmarks", world, rank, dev, recurrence="split")
+    options["f32"] = run_regime(args, "landmarks", world, rank, dev, recurrence="f32")
   if rank == 0:
     head = results[0]
     out = {
@@ -726,6 +743,7 @@ def main():
         "config": {"workload": head["workload"], "regime": head["regime"], "model": args.model,
                    "recurrent_layers": head["layers"], "per_gpu_batch": args.batch,
                    "global_batch": world * args.batch, "seq_len": T_FRAMES, "parallelism": "dp%d" % world,
+                   "launch_probe": head.get("launch_choice"),
                    "launch": ("hipGraph replay of the product's step (lipreading_amd.train.StepGraphs): "
                               + ("forward+backward captured, gradient exchange and optimiser launched after the replay"
                                  if DIST_ON else "zero_grad, forward, loss, backward, clip and Adam in one graph"))
@@ -751,9 +769,7 @@ def main():
       lm = out["regimes"]["landmarks"] if "landmarks" in out.get("regimes", {}) else (out if head["regime"] == "landmarks" else None)
       if lm is not None:
         base_loss = results[order.index("landmarks")]["loss"]
-        notes = {"split": "VideoEncoder.recurrence = 'split' on LSTM-768: the FORWARD recurrence as one launch per layer pass "
-                          "(W_hh bf16 hi+lo planes over 24-CU clusters, granule all-gather per step), backward on the step kernels",
-                 "f32": "VideoEncoder.recurrence = 'f32': one exact-fp32 MFMA launch per time step (the fallback of every shape)",
+        notes = {"f32": "VideoEncoder.recurrence = 'f32': one exact-fp32 MFMA launch per time step (the fallback of every shape)",
                  "bf16": "VideoEncoder.recurrence = 'bf16': one launch per layer pass, single-plane bf16 recurrent operands "
                          "(not reference-faithful; the build-defined pixel regime's choice)"}
         lm["other_recurrences"] = {

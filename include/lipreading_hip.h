@@ -62,11 +62,13 @@ typedef enum lr_rnn_mode {
    * matrices [B*T][I] — the conv frontend's features as they are; x is then the hi plane of the
    * projection's operand and is never converted or packed. */
   LR_RNN_INPUT_STORED_BF16 = 0x800,
-  /* The recurrence of a supported layer (lr_rnn_pair_supported: GRU, H = 256) as ONE launch per pass and
-   * fp32-FAITHFUL: W_hh and the carried state are split into bf16 hi + lo planes, all four cross terms
-   * accumulate in fp32 on the bf16 matrix cores (~1e-6 of the exact fp32 product, against ~1e-3 for
-   * LR_RNN_RECUR_BF16); a pair of compute units per (sample, direction) exchanges its halves of the state
-   * once per step.  What the reference-faithful regime runs by default where it is supported. */
+  /* The recurrence of a supported layer (lr_rnn_pair_supported: 1 = GRU, H = 256; 2 = LSTM, H = 768) as ONE
+   * launch per pass and fp32-FAITHFUL: W_hh and the carried state are split into bf16 hi + lo planes, all four
+   * cross terms accumulate in fp32 on the bf16 matrix cores (~1e-6 of the exact fp32 product, against ~1e-3
+   * for LR_RNN_RECUR_BF16).  W_hh stays in the registers + LDS of a pair of compute units per (sample,
+   * direction) (GRU-256) or of a cluster of 24 per (direction, 8 samples) (LSTM-768), which exchange their
+   * slices of the state (forward) / their partial state gradients (backward) once per step.  What the
+   * reference-faithful regime runs by default where it is supported. */
   LR_RNN_RECUR_SPLIT = 0x1000
 } lr_rnn_mode;
 
@@ -182,7 +184,7 @@ int lr_sgemm(int transA, int transB, int M, int N, int K, float alpha, const flo
  * Pointer arrays (w_ih ...) are HOST arrays of D device pointers. */
 int lr_rnn_persistent_supported(int mode, int B, int T, int I, int H, int D);   /* see LR_RNN_RECUR_BF16 */
 int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D);         /* see LR_RNN_RECUR_SPLIT */
-/* LR_RNN_RECUR_SPLIT's two workgroups of a pair must be resident together; their waits are bounded, and a
+/* LR_RNN_RECUR_SPLIT's workgroups of a pair / cluster must be resident together; their waits are bounded, and a
  * member that gave up leaves garbage and counts here.  Returns that count since the last call (0 = all
  * results valid) and clears it; synchronises the device (tests / bench only). */
 int lr_rnn_pair_errors(void);

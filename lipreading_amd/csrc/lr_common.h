@@ -156,9 +156,13 @@ int lr_gru256_pair_backward(const float* gates, const float* extra, const float*
 int lr_cluster_errors();
 int lr_lstm768_cluster_supported(int G, int B, int H);
 size_t lr_lstm768_cluster_pack_bytes(int D);
-size_t lr_lstm768_cluster_xch_bytes(int B, int D);
+size_t lr_lstm768_cluster_xch_bytes(int B, int D, int backward);
+size_t lr_lstm768_cluster_bwd_pack_bytes(int D);
 int lr_lstm768_cluster_forward(float* gates, float* extra, float* y, const float* const* w_hh, const int32_t* lens,
                                void* wpack, void* xch, int B, int T, int D, hipStream_t stream);
+int lr_lstm768_cluster_backward(const float* gates, const float* extra, const float* dy, const float* dh_n,
+                                const float* dc_n, float* dG, const float* const* w_hh, const int32_t* lens, void* wpack,
+                                void* xch, int B, int T, int D, hipStream_t stream);
 // lr_xgemm.hip: fp32 GEMM on the bf16 matrix cores by hi/lo operand splitting (same operand
 // conventions; a_exact / b_exact: the operand's elements are bf16 values already)
 int lr_xgemm_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,

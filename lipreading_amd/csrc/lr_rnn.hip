@@ -533,7 +533,7 @@ Layout reserve_layout(int G, int B, int T, int I, int H, int D, bool x3 = false)
   l.gemm_bytes = x3 ? lr_xproj_workspace_bytes(B * T, I, G * H, D) : lr_sgemm_workspace_bytes(B * T, G * H, I);
   l.xch = (l.gemm + (l.gemm_bytes + 3) / 4 + 63) / 64 * 64;   // granule exchange of the pair recurrence
   l.xch_bytes = lr_gru256_pair_supported(G, B, H) ? lr_gru256_pair_xch_bytes(B, D, 0)
-                : (lr_lstm768_cluster_supported(G, B, H) ? lr_lstm768_cluster_xch_bytes(B, D) : 0);
+                : (lr_lstm768_cluster_supported(G, B, H) ? lr_lstm768_cluster_xch_bytes(B, D, 0) : 0);
   l.total = l.xch + (l.xch_bytes + 3) / 4;
   return l;
 }
@@ -577,7 +577,8 @@ WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
   }
   l.gemm_bytes = gb;
   l.xch = (l.gemm + (gb + 3) / 4 + 63) / 64 * 64;
-  l.xch_bytes = lr_gru256_pair_supported(G, B, H) ? lr_gru256_pair_xch_bytes(B, D, 1) : 0;
+  l.xch_bytes = lr_gru256_pair_supported(G, B, H) ? lr_gru256_pair_xch_bytes(B, D, 1)
+                : (lr_lstm768_cluster_supported(G, B, H) ? lr_lstm768_cluster_xch_bytes(B, D, 1) : 0);
   l.total = l.xch + (l.xch_bytes + 3) / 4;
   return l;
 }
@@ -613,8 +614,7 @@ extern "C" int lr_rnn_persistent_supported(int mode, int B, int T, int I, int H,
 
 extern "C" int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D)) return 0;
-  // 1: GRU-256 (CU pairs, forward and backward); 2: LSTM-768 (24-CU clusters; forward — the backward pass
-  // of that shape still walks the step kernels)
+  // 1: GRU-256 (CU pairs); 2: LSTM-768 (24-CU clusters); both passes of either shape
   if (lr_gru256_pair_supported(gates_of(mode), B, H)) return 1;
   return lr_lstm768_cluster_supported(gates_of(mode), B, H) ? 2 : 0;
 }
@@ -801,6 +801,10 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
     if (dc_n) return LR_ERR_UNSUPPORTED;
     if ((size_t)D * wl.wp_per_dir * sizeof(float) < lr_gru256_pair_bwd_pack_bytes(D)) return LR_ERR_WORKSPACE;
     st = lr_gru256_pair_backward(gates, extra, y, dy, dh_n, dG, w_hh, lens, wT, wbase + wl.xch, B, T, D, stream);
+    if (st != LR_OK) return st;
+  } else if (recur_split(mode) && lr_lstm768_cluster_supported(G, B, H)) {
+    if ((size_t)D * wl.wp_per_dir * sizeof(float) < lr_lstm768_cluster_bwd_pack_bytes(D)) return LR_ERR_WORKSPACE;
+    st = lr_lstm768_cluster_backward(gates, extra, dy, dh_n, dc_n, dG, w_hh, lens, wT, wbase + wl.xch, B, T, D, stream);
     if (st != LR_OK) return st;
   } else if (recur_bf16(mode)) {
     // one launch for all T steps (lr_rnn_persist.hip); dG comes out in the step kernels' layout.  The

@@ -26,14 +26,15 @@
 // other member's step-(s + 1) data, each of which was published after its author read slot s & 1.
 // 8 clusters x 24 members = 192 workgroups per launch, one per CU; waits are bounded (lr_rnn_pair_errors).
 //
-// STATUS (round 2, MI355X, B = 32, T = 75): the FORWARD kernel is built and fp32-faithful (1e-6 of the step
-// kernels); it runs 5.6-6.0 us per step against the step kernel's 8.75 (BiLSTM-768 step 2.30 -> 2.07 ms).  Where
-// the time goes (measured by switching pieces off): 4.0 us per step remain with neither the tag wait nor the 92
-// partner MFMAs — the all-gather itself: 24 readers x 47 KB x 8 clusters = 9 MB of 8-byte granule reads per step
-// that miss L2 (agent-scope `sc1` stores drop the line: every read goes to the fabric) — + 1.15 us waiting for
-// tags + 0.8 us of MFMAs.  Not the VideoEncoder default (opt-in: recurrence = 'split'); the backward (row-split,
-// see above) is not built — that pass walks the step kernels.  Next: plain stores + sc1 loads when a cluster's
-// members verify (HW_REG_XCC_ID) that they share an XCD, so the gather is served from that XCD's L2.
+// XCD-local exchange: every member publishes its XCC id (HW_REG_XCC_ID) once; when all 24 members of a cluster
+// share an XCD (the dispatcher's placement of blocks k, k + 8, ...), granules are stored at workgroup scope
+// (`sc0`: they stay in that XCD's L2, where the other members' agent-scope loads find them) instead of
+// agent-scope `sc1` stores that drop the line and send every reader to the fabric.
+//
+// MEASURED (round 2, MI355X, B = 32, T = 75, BiLSTM-768): forward 344 us per layer pass (4.6 us per step; step
+// kernels 9.4 us per step), backward 414 us (5.5 us per step; step kernels 10.7) — the training step 2.19 ->
+// 1.59 ms, both passes 1e-6 of the step kernels.  Where a step's time goes (forward, pieces switched off):
+// ~3 us is the exchange itself (8-byte granule reads), ~1.1 us waiting for tags, 0.8 us of MFMAs.
 #include "lr_common.h"
 #include <hip/hip_ext.h>
 
@@ -73,6 +74,20 @@ __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
 __device__ __forceinline__ void publish(u64* p, float v, int tag) {
   __hip_atomic_store(p, ((u64)(unsigned)tag << 32) | (u64)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
+}
+// the same granule with a store that stops at the writer's XCD L2 and stays there (a write-through `sc1` store
+// drops the line, so every reader then goes to the fabric).  Only other CUs of the SAME XCD are guaranteed to see
+// it there — used when a cluster verified at run time that all its members share one XCD.  (Workgroup scope is
+// the ISA's `sc0`: through the CU's write-through L1 into L2.  NOT a `volatile` store: the compiler makes that a
+// system-scope store followed by s_waitcnt vmcnt(0) — 24 serialised round trips per step in the backward kernel.)
+__device__ __forceinline__ void publish_local(u64* p, float v, int tag) {
+  __hip_atomic_store(p, ((u64)(unsigned)tag << 32) | (u64)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int xcc_id() {
+  int x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return x & 0xf;
 }
 __device__ __forceinline__ u64 peek(const u64* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -190,7 +205,30 @@ __global__ __launch_bounds__(256, 1) void lstm768_fwd_cluster_kernel(
   const u64* xbase = xch + cluster * xcluster + tid;
   const int rs = tid >> 5, ru = tid & 31;           // what this thread gathers: sample row, unit of the source member
   int bad = 0;
+  // ---- do all 24 members of this cluster sit on one XCD?  (observed: block b runs on XCD b % 8 — never
+  // guaranteed.)  Every member publishes its XCC id (agent scope, tag 1) and reads all 24; the verdict is the
+  // same on every member because it is computed from the same 24 words.
+  __shared__ int s_local;
+  {
+    u64* xid = xch + 2 * xslot + (int64_t)cluster * CC;     // after the two parity slots
+    if (tid == 0) {
+      s_local = 1;
+      publish(xid + c, __builtin_bit_cast(float, xcc_id()), 1);
+    }
+    __syncthreads();
+    if (tid < CC) {
+      u64 g = peek(xid + tid);
+      int n = 0;
+      while ((int)(g >> 32) != 1 && n++ < SPIN_LIMIT) {
+        __builtin_amdgcn_s_sleep(2);
+        g = peek(xid + tid);
+      }
+      if ((int)(g >> 32) != 1) bad = 1;
+      if ((int)(g & 0xf) != xcc_id() || bad) s_local = 0;
+    }
+  }
   __syncthreads();
+  const bool local = s_local != 0;
 
   auto step = [&](int s, Gx& gx) {
     const int t = time_of(s);
@@ -295,7 +333,8 @@ __global__ __launch_bounds__(256, 1) void lstm768_fwd_cluster_kernel(
     const float cn = live ? fg * creg + ig * gg : 0.f;
     const float h = live ? og * tanhf(cn) : 0.f;
     creg = cn;
-    publish(xmine + (s & 1) * xslot, h, s + 1);     // first: 23 members are waiting for it
+    if (local) publish_local(xmine + (s & 1) * xslot, h, s + 1);   // first: 23 members are waiting for it
+    else publish(xmine + (s & 1) * xslot, h, s + 1);
     bf16_t hi, lo;
     split_bf16(h, hi, lo);
     hnxt[sl * CLD + ul] = hi;                       // local k position of the own member: q = 0
@@ -321,6 +360,322 @@ __global__ __launch_bounds__(256, 1) void lstm768_fwd_cluster_kernel(
   if (bad) atomicAdd(&g_cluster_err, 1);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// backward recurrence (row-split, see the file header)
+// ---------------------------------------------------------------------------------------------
+// Per step a member contracts its OWN dG (4 gates x 32 units x 8 samples, bf16 hi/lo in rows 0-7 / 8-15 of the A
+// operand, K = 128 = one k step per gate) against its 128 rows of W_hh for ALL 768 output units (48 column tiles:
+// wave w owns units 192w .. 192w+191), folds the hi/lo rows, and publishes the partial dh of every unit to the
+// member that owns it; each thread then gathers the 23 remote partials of its own (sample, unit) — fixed
+// summation order — adds its own and runs the LSTM cell backward (rnn_bwd_step_kernel<4>'s arithmetic).
+constexpr int BT12 = 12;            // column tiles per wave
+constexpr int BFW = 8;              // fragments per tile: f = 2 * gate + plane
+constexpr int BFW_A = 5;            // f < 5 in AGPRs (12 x 5 = 60 fragments)
+constexpr int BFW_REG = 6;          // f == 5 in VGPRs (12 fragments); f = 6, 7 in LDS (24 per wave)
+constexpr int BKLD = CG * CU_ + 8;  // bf16 per row of the dG operand buffer (128 own kappa)
+constexpr size_t CBWD_LDS = (size_t)2 * 16 * BKLD * 2 + (size_t)4 * BT12 * (BFW - BFW_REG) * 1024 + (size_t)NS * CU_ * 4;
+
+// out[((((d*CC + c)*4 + wave)*BT12 + tile)*BFW + f)*64 + lane] = plane f & 1 of W_hh[kappa + e][j], e = 0..7,
+// kappa = (f >> 1) * 768 + 32 c + 8 kg, j = 192 wave + 16 tile + col
+__global__ void lstm768_pack_whh_rows_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
+                                             bf16x8* __restrict__ out, int D) {
+  const int64_t total = (int64_t)D * CC * 4 * BT12 * BFW * 64;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63), f = (int)((i >> 6) % BFW), tile = (int)((i / (64 * BFW)) % BT12);
+    const int wave = (int)((i / (64 * BFW * BT12)) & 3), c = (int)((i / (64 * BFW * BT12 * 4)) % CC);
+    const int d = (int)(i / ((int64_t)64 * BFW * BT12 * 4 * CC));
+    const int col = lane & 15, kg = lane >> 4, gate = f >> 1, plane = f & 1;
+    const int j = 192 * wave + 16 * tile + col;
+    const float* src = (d ? w1 : w0) + ((int64_t)gate * CH + CU_ * c + 8 * kg) * CH + j;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bf16_t hi, lo;
+      split_bf16(src[(int64_t)e * CH], hi, lo);
+      v[e] = __builtin_bit_cast(__bf16, plane ? lo : hi);
+    }
+    out[i] = v;
+  }
+}
+
+#define LR_CMFMA12(acc, a, WC, w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11)                                  \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %12, %13, %0\n\t"                                                   \
+               "v_mfma_f32_16x16x32_bf16 %1, %12, %14, %1\n\t"                                                   \
+               "v_mfma_f32_16x16x32_bf16 %2, %12, %15, %2\n\t"                                                   \
+               "v_mfma_f32_16x16x32_bf16 %3, %12, %16, %3\n\t"                                                   \
+               "v_mfma_f32_16x16x32_bf16 %4, %12, %17, %4\n\t"                                                   \
+               "v_mfma_f32_16x16x32_bf16 %5, %12, %18, %5\n\t"                                                   \
+               "v_mfma_f32_16x16x32_bf16 %6, %12, %19, %6\n\t"                                                   \
+               "v_mfma_f32_16x16x32_bf16 %7, %12, %20, %7\n\t"                                                   \
+               "v_mfma_f32_16x16x32_bf16 %8, %12, %21, %8\n\t"                                                   \
+               "v_mfma_f32_16x16x32_bf16 %9, %12, %22, %9\n\t"                                                   \
+               "v_mfma_f32_16x16x32_bf16 %10, %12, %23, %10\n\t"                                                 \
+               "v_mfma_f32_16x16x32_bf16 %11, %12, %24, %11"                                                      \
+               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), \
+                 "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11])                           \
+               : "v"(a), WC(w0), WC(w1), WC(w2), WC(w3), WC(w4), WC(w5), WC(w6), WC(w7), WC(w8), WC(w9), WC(w10),  \
+                 WC(w11))
+#define LR_CMFMA12_FIRST(acc, a, W)                                                                               \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %12, %13, 0\n\t"                                                    \
+               "v_mfma_f32_16x16x32_bf16 %1, %12, %14, 0\n\t"                                                    \
+               "v_mfma_f32_16x16x32_bf16 %2, %12, %15, 0\n\t"                                                    \
+               "v_mfma_f32_16x16x32_bf16 %3, %12, %16, 0\n\t"                                                    \
+               "v_mfma_f32_16x16x32_bf16 %4, %12, %17, 0\n\t"                                                    \
+               "v_mfma_f32_16x16x32_bf16 %5, %12, %18, 0\n\t"                                                    \
+               "v_mfma_f32_16x16x32_bf16 %6, %12, %19, 0\n\t"                                                    \
+               "v_mfma_f32_16x16x32_bf16 %7, %12, %20, 0\n\t"                                                    \
+               "v_mfma_f32_16x16x32_bf16 %8, %12, %21, 0\n\t"                                                    \
+               "v_mfma_f32_16x16x32_bf16 %9, %12, %22, 0\n\t"                                                    \
+               "v_mfma_f32_16x16x32_bf16 %10, %12, %23, 0\n\t"                                                   \
+               "v_mfma_f32_16x16x32_bf16 %11, %12, %24, 0"                                                        \
+               : "=&v"(acc[0]), "=&v"(acc[1]), "=&v"(acc[2]), "=&v"(acc[3]), "=&v"(acc[4]), "=&v"(acc[5]),         \
+                 "=&v"(acc[6]), "=&v"(acc[7]), "=&v"(acc[8]), "=&v"(acc[9]), "=&v"(acc[10]), "=&v"(acc[11])       \
+               : "v"(a), "a"(W[0][0]), "a"(W[1][0]), "a"(W[2][0]), "a"(W[3][0]), "a"(W[4][0]), "a"(W[5][0]),       \
+                 "a"(W[6][0]), "a"(W[7][0]), "a"(W[8][0]), "a"(W[9][0]), "a"(W[10][0]), "a"(W[11][0]))
+
+__global__ __launch_bounds__(256, 1) void lstm768_bwd_cluster_kernel(
+    const float* __restrict__ gates, const float* __restrict__ extra, const float* __restrict__ dy,
+    const float* __restrict__ dh_n, const float* __restrict__ dc_n, float* __restrict__ dG,
+    const bf16x8* __restrict__ wpk, const int32_t* __restrict__ lens, u64* __restrict__ xch, int g0, int nclusters, int B,
+    int T, int D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* gS = reinterpret_cast<bf16_t*>(smem);                                                    // [2][16][BKLD]
+  bf16x8* Wl = reinterpret_cast<bf16x8*>(smem + (size_t)2 * 16 * BKLD * 2);                        // [4][BT12][2][64]
+  float* own = reinterpret_cast<float*>(smem + (size_t)2 * 16 * BKLD * 2 + (size_t)4 * BT12 * (BFW - BFW_REG) * 1024);   // [NS][CU_]
+  const int cluster = blockIdx.x & 7, c = blockIdx.x >> 3;
+  if (cluster >= nclusters) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = cluster % D, group = g0 + cluster / D;
+  const int col = lane & 15, kg = lane >> 4;
+  const int DH = D * CH;
+
+  bf16x8 Wa[BT12][BFW_A], Wv[BT12];
+  const bf16x8* wsrc = wpk + ((int64_t)((d * CC + c) * 4 + wave) * BT12 * BFW) * 64 + lane;
+#pragma unroll
+  for (int tl = 0; tl < BT12; ++tl) {
+#pragma unroll
+    for (int f = 0; f < BFW; ++f) {
+      const bf16x8 w = wsrc[(tl * BFW + f) * 64];
+      if (f < BFW_A) Wa[tl][f] = w;
+      else if (f < BFW_REG) Wv[tl] = w;
+      else Wl[((wave * BT12 + tl) * (BFW - BFW_REG) + (f - BFW_REG)) * 64 + lane] = w;
+    }
+  }
+  for (int i = tid; i < 2 * 16 * BKLD; i += 256) gS[i] = 0;
+
+  // ---- one (sample, unit) per thread: sample = tid >> 5, unit = tid & 31 of this member ----------------------
+  const int sl = tid >> 5, ul = tid & 31;
+  const int unit = CU_ * c + ul;
+  const int b = group * NS + sl;
+  const bool alive = b < B;
+  const int len = alive ? lens[b] : 0;
+  const float inj_h = (alive && dh_n) ? dh_n[((int64_t)d * B + b) * CH + unit] : 0.f;
+  const float inj_c = (alive && dc_n) ? dc_n[((int64_t)d * B + b) * CH + unit] : 0.f;
+  float car = 0.f;   // dc_{t'} * f_{t'} of the step processed before
+  struct In { float dy, g[4], c, cp; };
+  In inA, inB;       // operands of even / odd steps, fetched TWO steps ahead
+  auto time_of = [&](int s) {
+    const int sc = s < T ? s : T - 1;
+    return d == 0 ? T - 1 - sc : sc;
+  };
+  auto fetch = [&](In& in, int t) {
+    in.dy = in.c = in.cp = 0.f;
+    in.g[0] = in.g[1] = in.g[2] = in.g[3] = 0.f;
+    if (!alive) return;
+    const int tp = d == 0 ? t - 1 : t + 1;
+    const int64_t bt = (int64_t)b * T + t;
+    in.dy = dy[bt * DH + d * CH + unit];
+    const float* gi = gates + (bt * D + d) * (int64_t)(CG * CH) + unit;
+#pragma unroll
+    for (int g = 0; g < CG; ++g) in.g[g] = gi[g * CH];
+    in.c = extra[(bt * D + d) * CH + unit];
+    if (tp >= 0 && tp < T) in.cp = extra[(((int64_t)b * T + tp) * D + d) * CH + unit];
+  };
+  fetch(inA, time_of(0));
+  fetch(inB, time_of(1));
+  // exchange: [slot][cluster][dst member][src member][sample][unit 32]
+  const int64_t xsrc = NS * CU_, xdst = (int64_t)CC * xsrc, xcluster = (int64_t)CC * xdst, xslot = (int64_t)nclusters * xcluster;
+  u64* xout = xch + cluster * xcluster + c * xsrc;                 // + dst * xdst + sample * 32 + unit
+  const u64* xin = xch + cluster * xcluster + c * xdst + tid;      // + src * xsrc   (tid = sample * 32 + unit)
+  int bad = 0;
+  __shared__ int s_local;
+  {
+    u64* xid = xch + 2 * xslot + (int64_t)cluster * CC;
+    if (tid == 0) {
+      s_local = 1;
+      publish(xid + c, __builtin_bit_cast(float, xcc_id()), 1);
+    }
+    __syncthreads();
+    if (tid < CC) {
+      u64 g = peek(xid + tid);
+      int n = 0;
+      while ((int)(g >> 32) != 1 && n++ < SPIN_LIMIT) {
+        __builtin_amdgcn_s_sleep(2);
+        g = peek(xid + tid);
+      }
+      if ((int)(g >> 32) != 1) bad = 1;
+      if ((int)(g & 0xf) != xcc_id() || bad) s_local = 0;
+    }
+  }
+  __syncthreads();
+  const bool local = s_local != 0;
+
+  auto step = [&](int s, In& in) {
+    const int t = time_of(s);
+    const int tnext = time_of(s + 2);
+    bf16_t* gcur = gS + (s & 1) * 16 * BKLD;        // dG of the step processed before: rows 0-7 hi, 8-15 lo
+    bf16_t* gnxt = gS + ((s + 1) & 1) * 16 * BKLD;
+    float prod = 0.f;
+    if (s > 0) {
+      // ---- partial dh of all 768 units from this member's own dG ---------------------------------------
+      f32x4 acc[BT12];
+      bf16x8 a_next = *reinterpret_cast<const bf16x8*>(gcur + col * BKLD + kg * 8);
+#pragma unroll
+      for (int ks = 0; ks < CG; ++ks) {
+        const bf16x8 a = a_next;
+        if (ks + 1 < CG) a_next = *reinterpret_cast<const bf16x8*>(gcur + col * BKLD + (ks + 1) * 32 + kg * 8);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          const int f = 2 * ks + pl;
+          if (f == 0) {
+            LR_CMFMA12_FIRST(acc, a, Wa);
+          } else if (f < BFW_A) {
+            LR_CMFMA12(acc, a, "a", Wa[0][f], Wa[1][f], Wa[2][f], Wa[3][f], Wa[4][f], Wa[5][f], Wa[6][f], Wa[7][f], Wa[8][f],
+                       Wa[9][f], Wa[10][f], Wa[11][f]);
+          } else if (f < BFW_REG) {
+            LR_CMFMA12(acc, a, "v", Wv[0], Wv[1], Wv[2], Wv[3], Wv[4], Wv[5], Wv[6], Wv[7], Wv[8], Wv[9], Wv[10], Wv[11]);
+          } else {   // LDS-resident fragments, six tiles at a time (twelve at once cost 48 registers)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              bf16x8 wl[6];
+#pragma unroll
+              for (int i = 0; i < 6; ++i)
+                wl[i] = Wl[((wave * BT12 + 6 * half + i) * (BFW - BFW_REG) + (f - BFW_REG)) * 64 + lane];
+              asm volatile("v_mfma_f32_16x16x32_bf16 %0, %6, %7, %0\n\t"
+                           "v_mfma_f32_16x16x32_bf16 %1, %6, %8, %1\n\t"
+                           "v_mfma_f32_16x16x32_bf16 %2, %6, %9, %2\n\t"
+                           "v_mfma_f32_16x16x32_bf16 %3, %6, %10, %3\n\t"
+                           "v_mfma_f32_16x16x32_bf16 %4, %6, %11, %4\n\t"
+                           "v_mfma_f32_16x16x32_bf16 %5, %6, %12, %5"
+                           : "+v"(acc[6 * half]), "+v"(acc[6 * half + 1]), "+v"(acc[6 * half + 2]), "+v"(acc[6 * half + 3]),
+                             "+v"(acc[6 * half + 4]), "+v"(acc[6 * half + 5])
+                           : "v"(a), "v"(wl[0]), "v"(wl[1]), "v"(wl[2]), "v"(wl[3]), "v"(wl[4]), "v"(wl[5]));
+            }
+          }
+        }
+      }
+      asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+      // rows 4 kg + r: rows 0-7 (kg 0, 1) came from the hi plane of dG, rows 8-15 (kg 2, 3) from the lo plane of the
+      // same samples: fold across lanes +-32.  Afterwards both halves hold sample 4 (kg & 1) + r of unit 192 wave +
+      // 16 tile + col; the lower half publishes r = 0, 1, the upper half r = 2, 3.
+      // (the slot offset goes through an opaque register: otherwise the compiler hoists the 24 + 23 per-lane
+      // addresses of BOTH parity slots out of the step loop and keeps ~190 registers of addresses alive)
+      int64_t slot_off = ((s - 1) & 1) * xslot;
+      asm volatile("" : "+s"(slot_off));
+      u64* xo = xout + slot_off;
+#pragma unroll
+      for (int tl = 0; tl < BT12; ++tl) {
+        const int j = 192 * wave + 16 * tl + col, dstm = j >> 5, ju = j & 31;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[tl][r] += __shfl_xor(acc[tl][r], 32, 64);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int r = 2 * (kg >> 1) + rr, smp = 4 * (kg & 1) + r;
+          const float v = (kg >> 1) ? (rr ? acc[tl][3] : acc[tl][2]) : (rr ? acc[tl][1] : acc[tl][0]);
+          if (dstm == c) {
+            own[smp * CU_ + ju] = v;
+          } else {
+            u64* p = xo + dstm * xdst + smp * CU_ + ju;
+            if (local) publish_local(p, v, s);
+            else publish(p, v, s);
+          }
+        }
+      }
+      // ---- gather the 23 remote partials of this thread's (sample, unit): tag s, slot (s-1) & 1 ---------
+      const u64* xp = xin + slot_off;
+      u64 g[CC - 1];
+#pragma unroll
+      for (int q = 1; q < CC; ++q) {
+        int jm = c + q;
+        if (jm >= CC) jm -= CC;
+        g[q - 1] = peek(xp + jm * xsrc);
+      }
+      lr_lds_barrier();     // `own` complete
+      unsigned pend = (1u << (CC - 1)) - 1;
+      for (int round = 0; pend && !bad; ++round) {
+#pragma unroll
+        for (int q = 1; q < CC; ++q)
+          if (((pend >> (q - 1)) & 1u) && (int)(g[q - 1] >> 32) == s) pend &= ~(1u << (q - 1));
+        if (!pend) break;
+        if (round > SPIN_LIMIT) {
+          bad = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+        for (int q = 1; q < CC; ++q) {
+          if ((pend >> (q - 1)) & 1u) {
+            int jm = c + q;
+            if (jm >= CC) jm -= CC;
+            g[q - 1] = peek(xp + jm * xsrc);
+          }
+        }
+      }
+      prod = own[sl * CU_ + ul];
+      if (!bad) {   // every g[] now holds its granule: sum in FIXED order (rotated by the member index)
+#pragma unroll
+        for (int q = 1; q < CC; ++q) prod += __builtin_bit_cast(float, (unsigned)(g[q - 1] & 0xffffffffu));
+      }
+    }
+    // ---- LSTM cell backward of step t (rnn_bwd_step_kernel<4>) --------------------------------------------------
+    const float ig = in.g[0], fg = in.g[1], gg = in.g[2], og = in.g[3], ct = in.c, cp = in.cp;
+    float dh = in.dy + prod;
+    const bool is_last = d == 0 ? (t == len - 1) : (t == 0);
+    if (is_last) dh += inj_h;
+    float dc = car;
+    if (is_last) dc += inj_c;
+    fetch(in, tnext);
+    float di = 0.f, df = 0.f, dg_ = 0.f, do_ = 0.f;
+    car = 0.f;
+    if (alive && t < len) {
+      const float tc = tanhf(ct);
+      dc += dh * og * (1.f - tc * tc);
+      di = dc * gg * ig * (1.f - ig);
+      df = dc * cp * fg * (1.f - fg);
+      dg_ = dc * ig * (1.f - gg * gg);
+      do_ = dh * tc * og * (1.f - og);
+      car = dc * fg;
+    }
+    bf16_t hi, lo;
+    split_bf16(di, hi, lo);
+    gnxt[sl * BKLD + ul] = hi;
+    gnxt[(sl + 8) * BKLD + ul] = lo;
+    split_bf16(df, hi, lo);
+    gnxt[sl * BKLD + CU_ + ul] = hi;
+    gnxt[(sl + 8) * BKLD + CU_ + ul] = lo;
+    split_bf16(dg_, hi, lo);
+    gnxt[sl * BKLD + 2 * CU_ + ul] = hi;
+    gnxt[(sl + 8) * BKLD + 2 * CU_ + ul] = lo;
+    split_bf16(do_, hi, lo);
+    gnxt[sl * BKLD + 3 * CU_ + ul] = hi;
+    gnxt[(sl + 8) * BKLD + 3 * CU_ + ul] = lo;
+    if (alive) {
+      float* dgo = dG + (((int64_t)b * T + t) * D + d) * (int64_t)(4 * CH) + unit;
+      dgo[0] = di;
+      dgo[CH] = df;
+      dgo[2 * CH] = dg_;
+      dgo[3 * CH] = do_;
+    }
+    lr_lds_barrier();   // gnxt complete; `own` free again
+  };
+  for (int s = 0; s < T; s += 2) {
+    step(s, inA);
+    if (s + 1 < T) step(s + 1, inB);
+  }
+  if (bad) atomicAdd(&g_cluster_err, 1);
+}
+
 }  // namespace
 
 // read-and-clear of the error word (lr_rnn_pair_errors adds it to the pair kernels' count)
@@ -334,11 +689,13 @@ int lr_cluster_errors() {
 
 int lr_lstm768_cluster_supported(int G, int B, int H) { return G == 4 && H == CH && B >= 1 ? 1 : 0; }
 size_t lr_lstm768_cluster_pack_bytes(int D) { return (size_t)D * CC * 4 * 2 * CF * 64 * sizeof(bf16x8); }
-size_t lr_lstm768_cluster_xch_bytes(int B, int D) {
+size_t lr_lstm768_cluster_xch_bytes(int B, int D, int backward) {
   int clusters = (B + NS - 1) / NS * D;
   if (clusters > MAX_CLUSTERS) clusters = MAX_CLUSTERS;
-  return (size_t)2 * clusters * CC * NS * CU_ * sizeof(u64);
+  const size_t per = backward ? (size_t)CC * CC * NS * CU_ : (size_t)CC * NS * CU_;
+  return ((size_t)2 * clusters * per + (size_t)clusters * CC) * sizeof(u64);
 }
+size_t lr_lstm768_cluster_bwd_pack_bytes(int D) { return (size_t)D * CC * 4 * BT12 * BFW * 64 * sizeof(bf16x8); }
 
 int lr_lstm768_cluster_forward(float* gates, float* extra, float* y, const float* const* w_hh, const int32_t* lens,
                                void* wpack, void* xch, int B, int T, int D, hipStream_t stream) {
@@ -356,7 +713,7 @@ int lr_lstm768_cluster_forward(float* gates, float* extra, float* y, const float
   const int groups = (B + NS - 1) / NS, gchunk = MAX_CLUSTERS / D;   // sample groups per launch
   for (int g0 = 0; g0 < groups; g0 += gchunk) {
     const int ng = groups - g0 < gchunk ? groups - g0 : gchunk, nclusters = ng * D;
-    if (hipMemsetAsync(xch, 0, (size_t)2 * nclusters * CC * NS * CU_ * sizeof(u64), stream) != hipSuccess)
+    if (hipMemsetAsync(xch, 0, ((size_t)2 * nclusters * CC * NS * CU_ + (size_t)nclusters * CC) * sizeof(u64), stream) != hipSuccess)
       return LR_ERR_LAUNCH;
     const dim3 grid(8 * CC);
     hipEvent_t e0, e1;
@@ -365,6 +722,40 @@ int lr_lstm768_cluster_forward(float* gates, float* extra, float* y, const float
                             (const bf16x8*)wpack, lens, (u64*)xch, g0, nclusters, B, T, D);
     else
       hipLaunchKernelGGL(lstm768_fwd_cluster_kernel, grid, dim3(256), CFWD_LDS, stream, gates, extra, y,
+                         (const bf16x8*)wpack, lens, (u64*)xch, g0, nclusters, B, T, D);
+    st = lr_launch_status();
+    if (st != LR_OK) return st;
+  }
+  return LR_OK;
+}
+
+int lr_lstm768_cluster_backward(const float* gates, const float* extra, const float* dy, const float* dh_n,
+                                const float* dc_n, float* dG, const float* const* w_hh, const int32_t* lens, void* wpack,
+                                void* xch, int B, int T, int D, hipStream_t stream) {
+  static bool attr_set = false;
+  lr_clear_error();
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)lstm768_bwd_cluster_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)CBWD_LDS) != hipSuccess)
+      return LR_ERR_LAUNCH;
+    attr_set = true;
+  }
+  LR_LAUNCH(lstm768_pack_whh_rows_kernel, dim3(1024), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D);
+  int st = lr_launch_status();
+  if (st != LR_OK) return st;
+  const int groups = (B + NS - 1) / NS, gchunk = MAX_CLUSTERS / D;
+  for (int g0 = 0; g0 < groups; g0 += gchunk) {
+    const int ng = groups - g0 < gchunk ? groups - g0 : gchunk, nclusters = ng * D;
+    if (hipMemsetAsync(xch, 0, ((size_t)2 * nclusters * CC * CC * NS * CU_ + (size_t)nclusters * CC) * sizeof(u64),
+                       stream) != hipSuccess)
+      return LR_ERR_LAUNCH;
+    const dim3 grid(8 * CC);
+    hipEvent_t e0, e1;
+    if (g0 == 0 && lr_prof_next(LR_PROF_RNN_BWD, &e0, &e1))
+      hipExtLaunchKernelGGL(lstm768_bwd_cluster_kernel, grid, dim3(256), CBWD_LDS, stream, e0, e1, 0, gates, extra, dy, dh_n,
+                            dc_n, dG, (const bf16x8*)wpack, lens, (u64*)xch, g0, nclusters, B, T, D);
+    else
+      hipLaunchKernelGGL(lstm768_bwd_cluster_kernel, grid, dim3(256), CBWD_LDS, stream, gates, extra, dy, dh_n, dc_n, dG,
                          (const bf16x8*)wpack, lens, (u64*)xch, g0, nclusters, B, T, D);
     st = lr_launch_status();
     if (st != LR_OK) return st;

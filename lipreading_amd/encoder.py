@@ -258,12 +258,12 @@ class VideoEncoder(nn.Module):
     # how the T-step recurrence of a layer runs (not in the reference):
     #   'f32'    one launch per time step, exact fp32 MFMA — every shape
     #   'split'  ONE launch per layer pass, fp32-faithful (W_hh and the state as bf16 hi + lo planes, ~1e-6
-    #            of the fp32 product) — GRU, H = 256: both passes (lr_rnn_pair.hip); LSTM, H = 768: the forward
-    #            pass (lr_rnn_cluster.hip); every other shape as 'f32'
+    #            of the fp32 product) — GRU, H = 256: a pair of CUs per (sample, direction) (lr_rnn_pair.hip);
+    #            LSTM, H = 768: a cluster of 24 CUs per (direction, 8 samples) (lr_rnn_cluster.hip); every other
+    #            shape as 'f32'
     #   'bf16'   one launch per pass with single-plane bf16 recurrent operands (~1e-3): the build-defined
     #            pixel regime's choice (frontend.PixelLipReader sets it); where unsupported as 'f32'
-    #   'auto'   (default) 'split' where BOTH passes have the kernel (GRU, H = 256), else 'f32': reference-faithful
-    #            numerics at the one-launch speed
+    #   'auto'   (default) same as 'split': reference-faithful numerics at the one-launch speed
     self.recurrence = 'auto'
     if self.enable_ctc:
       self.vocab_size = vocab_size
@@ -320,11 +320,8 @@ class VideoEncoder(nn.Module):
       if self.recurrence == 'bf16' and _C.lib().lr_rnn_persistent_supported(mode, B, max_len, x.shape[2], H, D):
         lmode |= _RECUR_BF16
       else:
-        # lr_rnn_pair_supported: 1 = both passes have a one-launch kernel (GRU-256, CU pairs): the default;
-        # 2 = forward only (LSTM-768, 24-CU clusters; a 10 % gain): on request
-        kind = _C.lib().lr_rnn_pair_supported(mode, B, max_len, x.shape[2], H, D) \
-            if self.recurrence in ('auto', 'split') else 0
-        if kind == 1 or (kind == 2 and self.recurrence == 'split'):
+        # lr_rnn_pair_supported: 1 = GRU-256 (CU pairs), 2 = LSTM-768 (24-CU clusters); 0 = step kernels
+        if self.recurrence in ('auto', 'split') and _C.lib().lr_rnn_pair_supported(mode, B, max_len, x.shape[2], H, D):
           lmode |= _RECUR_SPLIT
       y, h_n, c_n = _RNNLayerFunction.apply(x, lens, lmode, H, need_dx, *weights)
       # (D,B,H) -> (B, D*H): forward direction first, as _cat_directions (better_model.py:98-112)

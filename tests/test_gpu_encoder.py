@@ -413,19 +413,20 @@ def test_split_recurrence_is_the_default_and_meets_the_loss_bar(dev):
   assert abs(float(loss_h) - float(loss_r)) <= 1e-4 and d_lp <= 3e-5, (float(loss_h), float(loss_r), d_lp)
 
 
-@pytest.mark.parametrize("B,T,bi,lens", [(32, 75, True, None), (37, 20, True, "ragged"), (13, 6, False, "ragged"),
-                                         (2, 1, True, None)])
-def test_lstm768_cluster_recurrence_is_fp32_faithful(dev, B, T, bi, lens):
-  """LR_RNN_RECUR_SPLIT on LSTM-768 (the ecd/* config shape; opt-in there: recurrence = 'split'): the forward
-  recurrence of a layer pass in ONE launch — W_hh as bf16 hi + lo planes sliced over 24 CUs per (direction,
-  8 samples), one granule all-gather of the state per step.  Against the exact-fp32 step kernels on the same
-  weights, forward AND the backward that consumes the forward's saved gates / cell states, ragged lengths,
-  partial sample groups (B % 8 != 0), more groups than one launch holds."""
+@pytest.mark.parametrize("B,T,bi,lens,layers", [(32, 75, True, None, 1), (37, 20, True, "ragged", 1),
+                                                (13, 6, False, "ragged", 1), (2, 1, True, None, 1),
+                                                (12, 9, True, "ragged", 2), (70, 5, False, "ragged", 1)])
+def test_lstm768_cluster_recurrence_is_fp32_faithful(dev, B, T, bi, lens, layers):
+  """LR_RNN_RECUR_SPLIT on LSTM-768 (the ecd/* config shape): the recurrence of a layer pass in ONE launch —
+  W_hh as bf16 hi + lo planes sliced over 24 CUs per (direction, 8 samples); forward: one granule all-gather
+  of the state per step; backward: row-split partial dh, one granule reduce-scatter per step.  Against the
+  exact-fp32 step kernels on the same weights, forward and backward, final (h, c) gradients injected, ragged
+  lengths, partial sample groups (B % 8 != 0), more groups than one launch holds, two stacked layers."""
   from lipreading_amd import _C
   from lipreading_amd.data import default_char2idx
   from lipreading_amd.encoder import VideoEncoder
   torch.manual_seed(41)
-  enc = VideoEncoder(64, 768, rnn_type='LSTM', num_layers=1, bidirectional=bi, enable_ctc=True,
+  enc = VideoEncoder(64, 768, rnn_type='LSTM', num_layers=layers, bidirectional=bi, enable_ctc=True,
                      vocab_size=64, char2idx=default_char2idx()).to(dev)
   g = torch.Generator().manual_seed(42)
   x = torch.randn(B, T, 64, 1, generator=g)
