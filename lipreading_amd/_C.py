@@ -133,7 +133,8 @@ class LipReadingHipError(RuntimeError):
 
 
 def lib_path():
-  return _build.LIB_PATH
+  # LIPREADING_HIP_LIB: another build of the same C ABI (A/B timing of kernel variants: tools/build_variant.sh)
+  return os.environ.get("LIPREADING_HIP_LIB") or _build.LIB_PATH
 
 
 def lib():

@@ -953,9 +953,10 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_ts_kernel(ConvGeom g, const 
 // Same idea as conv_patch_kernel, shaped for 12x12 frames: a wave owns a whole frame as nine
 // 4x4-position row tiles of v_mfma_f32_16x16x32_bf16 (16 rows x 32 k: one MFMA consumes a whole
 // 32-channel group of a tap), a workgroup 4 consecutive frames; the 6 x 14 x 14-position patch of
-// one 32-channel group sits in LDS with rows padded to 16 positions and 16-byte chunks stored at
-// c ^ ((p >> 3) & 3) — with that the four 16-lane groups of ds_read_b128 each hit 16 different
-// bank slots for any tap shift (found by exhaustive search over row paddings and swizzles).  Inputs
+// one 32-channel group sits in LDS as rows of 14 positions x 64 B + 16 B of padding (P3_RS = 912 B: consecutive
+// rows are 9 sixteen-byte bank slots apart mod 16, so the 4 x 4 pixel block a 16-lane group of ds_read_b128
+// reads covers all 16 slots once for any tap shift); every fragment address of the kernel is then ONE lane
+// base + an immediate offset (< 64 KB), no per-read swizzle arithmetic.  Inputs
 // with 64 / 96 channels take 2 / 3 passes.  B fragments (16 output channels x 32 k) come from
 // global in the 16-column fragment-major packing.
 // A workgroup covers P3_TT = 2 consecutive frames with TWO waves per frame (each takes half of the
@@ -963,9 +964,9 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_ts_kernel(ConvGeom g, const 
 // workgroups share a CU: 8 waves per CU overlap each other's load phases and epilogues, and 1200
 // half-size tiles fill 256 CUs in 2.5 tile-times where 600 four-frame tiles took 3 (2.34 rounds).
 constexpr int P3_TT = 2, P3_NSPL = 4 / P3_TT, P3_H = 12, P3_W = 12, P3_PH = P3_H + 2, P3_PW = 16, P3_SLOTS = P3_TT + 2;
-constexpr int P3_POS = P3_SLOTS * P3_PH * P3_PW;   // 896 positions (2 padding columns per row)
-constexpr int P3_LDS = P3_POS * 64;                // 57,344 bytes
+constexpr int P3_RS = (P3_W + 2) * 64 + 16;        // bytes per patch row
 constexpr int P3_ROWS = P3_SLOTS * P3_PH;          // 56 patch rows: one per wave and pass, 14 passes
+constexpr int P3_LDS = P3_ROWS * P3_RS;            // 51,072 bytes
 static_assert(P3_ROWS % 28 == 0, "patch rows are loaded in batches of 7 passes x 4 waves");
 
 template <int CG, int NT16, bool POOL>
@@ -979,7 +980,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __re
   constexpr int C = 32 * CG, N = 16 * NTT, TAPS = 27;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fw = wave % P3_TT, nh = wave / P3_TT;   // frame of the tile, slice of the output channels
-  const int f0 = (int)blockIdx.x * P3_TT;
+  // XCD-aware tile order (as conv_patch_kernel): XCD b % 8 takes a contiguous run of frame tiles, whose temporal
+  // halo frames it then finds in its own L2
+  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3, rem_xcd = gridDim.x & 7;
+  const int f0 = (xcd * per_xcd + (xcd < rem_xcd ? xcd : rem_xcd) + (int)(blockIdx.x >> 3)) * P3_TT;
   const int rl = lane & 15, kg = lane >> 4;
   const int f = f0 + fw;
   const bool fvalid = f < F;
@@ -996,7 +1000,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __re
   // (h = 2(kg>>1) + {0,1}, w = 2(kg&1) + {0,1}) in scan order and the pooled epilogue is lane-local.
   // The 16 lanes ds_read_b128 serves together still cover the 4 x 4 block once, and same-column
   // lanes land on 4 different chunks for any tap shift.
-  const int base_p = (fw * P3_PH + ((rl >> 1) & 1) + 2 * (rl >> 3)) * P3_PW + (rl & 1) + 2 * ((rl >> 2) & 1);
+  const int base_b = (fw * P3_PH + ((rl >> 1) & 1) + 2 * (rl >> 3)) * P3_RS + ((rl & 1) + 2 * ((rl >> 2) & 1)) * 64 + kg * 16;
   for (int cg = 0; cg < CG; ++cg) {
     if (cg > 0) __syncthreads();
     // patch load: a wave covers one 16-position patch row (64 sixteen-byte units) per pass, so the
@@ -1017,10 +1021,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __re
           if (tvalid && ff >= 0 && ff < F && hh >= 0 && hh < P3_H)
             v[i] = *reinterpret_cast<const uint4*>(xt + ((int64_t)ff * P3_H + hh) * (P3_W * C));
         }
+        if (pw < P3_W + 2) {   // 14 positions per row (lanes of positions 14, 15 idle)
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-          const int pp = (4 * (part * 7 + i) + wave) * P3_PW + pw;
-          *reinterpret_cast<uint4*>(patch + pp * 64 + ((c ^ ((pp >> 3) & 3)) << 4)) = v[i];
+          for (int i = 0; i < 7; ++i)
+            *reinterpret_cast<uint4*>(patch + (4 * (part * 7 + i) + wave) * P3_RS + pw * 64 + c * 16) = v[i];
         }
       }
     }
@@ -1043,11 +1047,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __re
               bnext[j] = *reinterpret_cast<const bf16x8*>(wf + ((int64_t)(tap + 1) * NTT + j) * 512);
           }
           if (valid) {
-            const int to = (dt * P3_PH + dh) * P3_PW + dw;
+            const int to = (dt * P3_PH + dh) * P3_RS + dw * 64;
 #pragma unroll
             for (int mb = 0; mb < 9; ++mb) {
-              const int p = base_p + (4 * (mb / 3)) * P3_PW + 4 * (mb % 3) + to;
-              const bf16x8 a = *reinterpret_cast<const bf16x8*>(patch + p * 64 + ((kg ^ ((p >> 3) & 3)) << 4));
+              const bf16x8 a = *reinterpret_cast<const bf16x8*>(patch + base_b + (to + (4 * (mb / 3)) * P3_RS + 4 * (mb % 3) * 64));
 #pragma unroll
               for (int j = 0; j < NT16; ++j)
                 acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[j], acc[mb][j], 0, 0, 0);
@@ -1397,14 +1400,20 @@ __global__ void conv3d_pack_weights_kernel(const float* __restrict__ W, bf16_t* 
 // of 32 channels with the accumulators kept.
 //   Wave w owns output frame f0 + w: 6 MFMA row tiles of 8 rows x 4 columns x NT column tiles ->
 //   6*NT accumulators; taps reaching across a clip boundary are skipped (wave-uniform).
-//   LDS layout: position p = (slot*12 + row)*28 + col holds 4 chunks of 16 bytes, chunk c stored at
-//   c ^ ((p >> 2) & 3).  With 28 positions per row the 16 lanes that ds_read_b128 serves together
-//   (4 columns x 4 of the 8 rows, rows distinct mod 4) then hit 16 different 16-byte bank slots.
+//   LDS layout: patch row (slot*12 + row) starts at byte (slot*12 + row) * P2_RS, P2_RS = 28*64 + 16; position
+//   col of it holds its 32 channels as 4 chunks of 16 bytes in order.  The 16 bytes of padding per row shift
+//   consecutive rows by one 16-byte bank slot, so the 16 lanes that ds_read_b128 serves together (4 columns x 4
+//   rows of the 8 x 4 pixel block) hit 16 different slots — and, unlike an XOR swizzle, the address of a tap is
+//   lane base + a constant: the 60 fragment reads of a row of five taps share ONE address register and differ in
+//   the instruction's immediate offset only (the swizzle cost ~2 VALU operations per read, issue slots the one
+//   wave per SIMD needs for its MFMAs).
+// (Measured and dropped, round 2: half-WIDTH tiles — 4 frames x 8 rows x 12 columns, 73 KB patch, 3 x NT
+// accumulators, TWO workgroups per CU so that one's MFMAs cover the other's patch fill and epilogue — are bit-
+// identical but 7 % (forward) / 19 % (data gradient) SLOWER: a weight fragment then feeds 3 MFMAs instead of 6
+// and the doubled fragment traffic from L1/L2 costs more than the overlap returns.)
 constexpr int P2_TT = 4, P2_TH = 8, P2_W = 24, P2_PW = P2_W + 4, P2_PH = P2_TH + 4, P2_SLOTS = P2_TT + 2;
-constexpr int P2_POS = P2_SLOTS * P2_PH * P2_PW;   // 2016 positions
-constexpr int P2_LDS = P2_POS * 64;                // 129,024 bytes
-constexpr int P2_UNITS = P2_POS * 4;               // 16-byte units
-constexpr int P2_UPT = (P2_UNITS + 255) / 256;     // units per thread: 32 (31.5)
+constexpr int P2_RS = P2_PW * 64 + 16;             // bytes per patch row: 28 positions x 64 B + 16 B of padding
+constexpr int P2_LDS = P2_SLOTS * P2_PH * P2_RS;   // 130,176 bytes
 constexpr int P2_BDIST = 2;                        // taps between a B fragment's load and its use
 
 template <int CG, int NT, bool POOL>
@@ -1417,7 +1426,12 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
   constexpr int C = 32 * CG, N = 32 * NT, TAPS = 75;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int htiles = H / P2_TH;
-  const int f0 = (int)(blockIdx.x / htiles) * P2_TT, h0 = (int)(blockIdx.x % htiles) * P2_TH;
+  // XCD-aware tile order: block b runs on XCD b % 8 (each XCD has its own L2), so XCD x takes a CONTIGUOUS run of
+  // tiles (h-tiles of a frame tile, then the next frame tile): the tiles resident together on an XCD are
+  // neighbours in time and height and find each other's halo rows in that XCD's L2 instead of re-fetching them.
+  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3, rem_xcd = gridDim.x & 7;
+  const int tile = xcd * per_xcd + (xcd < rem_xcd ? xcd : rem_xcd) + (int)(blockIdx.x >> 3);
+  const int f0 = (tile / htiles) * P2_TT, h0 = (tile % htiles) * P2_TH;
   const int lr = lane & 31, kg = lane >> 5;
   const int f = f0 + wave;
   const bool fvalid = f < F;
@@ -1443,7 +1457,7 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
   // slots of a 256-byte bank line: same-w lanes of a group sit on rows {0,1,6,7} or {2,3,4,5},
   // 3*row mod 4 all different.
   const int a_h = ((lr >> 1) & 1) + 2 * (lr >> 3), a_w = (lr & 1) + 2 * ((lr >> 2) & 1);
-  const int base_p = (wave * P2_PH + a_h) * P2_PW + a_w;
+  const int base_b = (wave * P2_PH + a_h) * P2_RS + a_w * 64 + kg * 16;   // byte offset of this lane's pixel, k chunk kg
   for (int cg = 0; cg < CG; ++cg) {
     if (cg > 0) __syncthreads();   // every wave is done with the previous channel group's patch
     // ---- load the patch -------------------------------------------------------------------------
@@ -1472,8 +1486,7 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
 #pragma unroll
           for (int i = 0; i < 18; ++i) {
             const int k = half * 18 + i;
-            const int pp = (2 * k + rp) * P2_PW + pw;
-            *reinterpret_cast<uint4*>(patch + pp * 64 + ((c ^ ((pp >> 2) & 3)) << 4)) = v[i];
+            *reinterpret_cast<uint4*>(patch + (2 * k + rp) * P2_RS + pw * 64 + c * 16) = v[i];
           }
         }
       }
@@ -1498,44 +1511,42 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
           for (int j = 0; j < NT; ++j)
             bb[kc][j] = *reinterpret_cast<const bf16x8*>(wfb + ((int64_t)ii * 2 * NT + kc * NT + j) * 512);
       };
-      auto load_a = [&](bf16x8 (&aa)[6], int x, int grp) {   // x = base position + tap offset
-        const int X = x >> 2;
-#pragma unroll
-        for (int w3 = 0; w3 < 3; ++w3) {
-          const int wb = 3 * grp + w3;
-          const int sw = (X + wb) & 3;
-#pragma unroll
-          for (int kc = 0; kc < 2; ++kc)
-            aa[w3 * 2 + kc] =
-                *reinterpret_cast<const bf16x8*>(patch + (x + 4 * wb) * 64 + (((kc * 2 + kg) ^ sw) << 4));
-        }
-      };
-      auto run = [&](const bf16x8 (&aa)[6], const bf16x8 (&bb)[2][NT], int grp) {
+      auto load_a = [&](bf16x8 (&aa)[6], int xb, int imm, int grp) {   // xb = lane base + row offset (bytes), imm = 64 dw
 #pragma unroll
         for (int w3 = 0; w3 < 3; ++w3)
 #pragma unroll
           for (int kc = 0; kc < 2; ++kc)
+            aa[w3 * 2 + kc] = *reinterpret_cast<const bf16x8*>(patch + xb + (imm + (3 * grp + w3) * 256 + kc * 32));
+      };
+      // k chunk outermost: consecutive MFMAs never share an accumulator (with NT = 1 the w3-outer order issued
+      // the two k chunks of a tile back to back, each waiting for the other's result)
+      auto run = [&](const bf16x8 (&aa)[6], const bf16x8 (&bb)[2][NT], int grp) {
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+          for (int w3 = 0; w3 < 3; ++w3)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
               acc[3 * grp + w3][j] =
                   __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[w3 * 2 + kc], bb[kc][j], acc[3 * grp + w3][j], 0, 0, 0);
       };
-      auto row_off = [&](int r) {   // patch offset of row r's first tap: r = dt*5 + dh
+      auto row_off = [&](int r) {   // byte offset of row r's first tap: r = dt*5 + dh
         const int rr = row0 + (r < nrow ? r : nrow - 1);
-        return ((rr / 5) * P2_PH + rr % 5) * P2_PW;
+        return ((rr / 5) * P2_PH + rr % 5) * P2_RS;
       };
 #pragma unroll
       for (int d = 0; d < P2_BDIST; ++d) load_b(bq[d], d);
-      load_a(a0, base_p + row_off(0), 0);
+      load_a(a0, base_b + row_off(0), 0, 0);
 #pragma unroll 1
       for (int r = 0; r < nrow; ++r) {
-        const int x0 = base_p + row_off(r), xn = base_p + row_off(r + 1);
+        const int x0 = base_b + row_off(r), xn = base_b + row_off(r + 1);
 #pragma unroll
         for (int dw = 0; dw < 5; ++dw) {
           load_b(bq[(dw + P2_BDIST) % 5], 5 * r + dw + P2_BDIST);
-          load_a(a1, x0 + dw, 1);
+          load_a(a1, x0, 64 * dw, 1);
           run(a0, bq[dw], 0);
-          load_a(a0, dw < 4 ? x0 + dw + 1 : xn, 0);
+          if (dw < 4) load_a(a0, x0, 64 * (dw + 1), 0);
+          else load_a(a0, xn, 0, 0);
           run(a1, bq[dw], 1);
         }
         // The machine scheduler would sink every load next to its use (lowest register pressure);

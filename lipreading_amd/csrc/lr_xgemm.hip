@@ -253,15 +253,27 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
             bh[j] = *reinterpret_cast<const bf16x8*>(&Bh[o]);
             if (!BX) bl[j] = *reinterpret_cast<const bf16x8*>(&Bl[o]);
           }
+          // small terms first, so they are not absorbed by a large partial sum; term by term over the four
+          // accumulators, so that consecutive MFMAs never wait for each other's result
+          if (!BX) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
+          if (!AX) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          }
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              // small terms first, so they are not absorbed by a large partial sum
-              if (!BX) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-              if (!AX) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-            }
         }
       }
     }
@@ -295,31 +307,81 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
     }
 }
 
-// deterministic split-K combine (fixed order over the slabs), then alpha / beta / bias
-__global__ void xsplitk_reduce_kernel(const float* __restrict__ slabs, int splits, float* __restrict__ C,
-                                      float* __restrict__ C1, int split_row, int ldc,
-                                      const float* __restrict__ bias, int M, int N, float alpha, float beta,
-                                      float* __restrict__ Cb, int64_t slab_bstride, int c_bf16) {
+// deterministic split-K combine (fixed order over the slabs), then alpha / beta / bias.  Four consecutive
+// elements per thread (16-byte loads of every slab in flight together) when N % 4 == 0; this pass is pure HBM
+// streaming of (splits + 1) * M * N floats.
+__global__ __launch_bounds__(256) void xsplitk_reduce_kernel(const float* __restrict__ slabs, int splits,
+                                                             float* __restrict__ C, float* __restrict__ C1,
+                                                             int split_row, int ldc, const float* __restrict__ bias,
+                                                             int M, int N, float alpha, float beta,
+                                                             float* __restrict__ Cb, int64_t slab_bstride, int c_bf16) {
   const int64_t total = (int64_t)M * N;
   if (blockIdx.y) {   // batch 1
     slabs += slab_bstride;
     C = Cb;
     C1 = Cb;
   }
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += slabs[(int64_t)z * total + i];
+  auto finish = [&](int64_t i, float s) {
     const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
     float out = alpha * s;
     if (bias) out += bias[col];
     if (c_bf16) {
       const __bf16 hb = (__bf16)out;
       reinterpret_cast<bf16_t*>(C)[(int64_t)row * ldc + col] = __builtin_bit_cast(bf16_t, hb);
-      continue;
+      return;
     }
     float* c = (row < split_row ? C + (int64_t)row * ldc : C1 + (int64_t)(row - split_row) * ldc) + col;
     if (beta != 0.f) out += beta * *c;
     *c = out;
+  };
+  if ((N & 3) == 0) {
+    const int64_t quads = total >> 2;
+    const bool vec_out = !c_bf16 && (ldc & 3) == 0 &&
+                         ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(C1) |
+                           (bias ? reinterpret_cast<uintptr_t>(bias) : 0)) & 15) == 0;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)gridDim.x * blockDim.x) {
+      const float4* src = reinterpret_cast<const float4*>(slabs) + q;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      int z = 0;
+      for (; z + 4 <= splits; z += 4) {   // four slabs' loads in flight; summed in slab order
+        const float4 v0 = src[(int64_t)z * quads], v1 = src[(int64_t)(z + 1) * quads];
+        const float4 v2 = src[(int64_t)(z + 2) * quads], v3 = src[(int64_t)(z + 3) * quads];
+        s.x = (((s.x + v0.x) + v1.x) + v2.x) + v3.x;
+        s.y = (((s.y + v0.y) + v1.y) + v2.y) + v3.y;
+        s.z = (((s.z + v0.z) + v1.z) + v2.z) + v3.z;
+        s.w = (((s.w + v0.w) + v1.w) + v2.w) + v3.w;
+      }
+      for (; z < splits; ++z) {
+        const float4 v = src[(int64_t)z * quads];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      const int64_t i = q << 2;
+      if (vec_out) {   // plain fp32 output with 16-byte aligned rows: one store (and one read for beta) per quad
+        const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
+        float4* c = reinterpret_cast<float4*>((row < split_row ? C + (int64_t)row * ldc : C1 + (int64_t)(row - split_row) * ldc) + col);
+        float4 o = make_float4(alpha * s.x, alpha * s.y, alpha * s.z, alpha * s.w);
+        if (bias) {
+          const float4 b = *reinterpret_cast<const float4*>(bias + col);
+          o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+        }
+        if (beta != 0.f) {
+          const float4 p = *c;
+          o.x += beta * p.x; o.y += beta * p.y; o.z += beta * p.z; o.w += beta * p.w;
+        }
+        *c = o;
+        continue;
+      }
+      finish(i, s.x);
+      finish(i + 1, s.y);
+      finish(i + 2, s.z);
+      finish(i + 3, s.w);
+    }
+    return;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slabs[(int64_t)z * total + i];
+    finish(i, s);
   }
 }
 
@@ -331,8 +393,11 @@ size_t plane_floats(int rows, int K, bool exact) {
 }
 
 // Split K so that the workgroups fill the 512 resident slots (2 per CU) in as few rounds as possible:
-// cost(s) = rounds(s) * (K / s + fixed per-workgroup overhead), >= 4 stages per split.  Large tile
-// grids are never split (the fp32 slabs would cost more than the tail they remove).
+// cost(s) = rounds(s) * (K / s + fixed per-workgroup overhead) + the slabs: every split writes a 128 x 128
+// fp32 tile that the combine pass reads back (2 x 64 KB of HBM traffic per tile and split ~ 2.2 k-units, the
+// unit being what one k element of a tile round costs) — without that term a 324-tile, K = 2400 product (the
+// first layer's dW_ih) was split three ways and its combine pass (101 us) cost more than the product.
+// >= 4 stages per split.
 int want_splits(int M, int N, int K) {
   const long tiles = (long)((M + XBM - 1) / XBM) * ((N + XBN - 1) / XBN);
   if (tiles >= 384) return 1;
@@ -341,7 +406,7 @@ int want_splits(int M, int N, int K) {
   long best = 1, best_cost = -1;
   for (long sp = 1; sp <= max_split; ++sp) {
     const long rounds = (tiles * sp + 511) / 512;
-    const long cost = rounds * (K / sp + 96);
+    const long cost = rounds * (K / sp + 96) + (sp > 1 ? (sp * tiles * 22) / 10 : 0);
     if (best_cost < 0 || cost < best_cost) { best = sp; best_cost = cost; }
   }
   return (int)best;
@@ -417,8 +482,9 @@ int contract(const bf16_t* Ahp, const bf16_t* Alp, const bf16_t* Bhp, const bf16
   int st = lr_launch_status();
   if (st != LR_OK || splits == 1) return st;
   const int64_t total = (int64_t)M * N;
-  int blocks = (int)((total + 255) / 256);
+  int blocks = (int)(((N & 3) == 0 ? total / 4 : total) + 255) / 256;
   if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
   LR_LAUNCH(xsplitk_reduce_kernel, dim3(blocks, nbatch), dim3(256), 0, stream, (const float*)g.slabs, splits, C, g.C1,
             g.split_row, ldc, bias, M, N, alpha, beta, g.Cb, g.slab_bstride, c_bf16);
   return lr_launch_status();
