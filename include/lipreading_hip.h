@@ -472,6 +472,15 @@ int lr_ctc_reduce(const float* nll, const int32_t* frame_lens, const int32_t* la
                   int reduction, float* out_loss, int32_t* out_status, float* grad_weight, int B,
                   lr_stream_t stream);
 
+/* The train loop's label plumbing in ONE launch (train_better_model.py:31-32 labels = chars[:, 1:], label_lens =
+ * char_lens - 1; ctc_loss.py:42,80 int32 integers, labels moved up by one so that index 0 is the blank):
+ *   labels_p1[b][l]  = (int32) chars[b * chars_stride + 1 + l] + 1     l < L (= chars' width - 1)
+ *   frame_lens32[b]  = (int32) frame_lens[b];   label_lens32[b] = (int32) char_lens[b] - 1
+ * (as torch ops these are five elementwise launches at the head of every step). */
+int lr_ctc_prepare_i64(const int64_t* chars, int64_t chars_stride, const int64_t* frame_lens, const int64_t* char_lens,
+                       int32_t* labels_p1, int32_t* frame_lens32, int32_t* label_lens32, int B, int L,
+                       lr_stream_t stream);
+
 /* ---- A6: CTC greedy decode — src/models/lipreader/decoder.py:165-197 -------------------- */
 
 /* argmax over classes (first maximum, as torch.max), then per sample for t < sizes[b]:
@@ -507,6 +516,11 @@ int lr_clip_to_ndhwc_bf16(const void* clips, int is_u8, void* out, int64_t frame
  *              is passed on to lr_conv3d_forward in `flags`. */
 int lr_conv3d_pack_weights(const float* W, void* out, int Cout, int Cin_real, int Cin_pad, int KT,
                            int KH, int KW, int dgrad, lr_stream_t stream);
+/* n <= 8 operands in ONE launch (HOST arrays of n entries each, meaning as above): a training step packs the
+ * forward operand of every layer and the data-gradient operand of the upper layers together. */
+int lr_conv3d_pack_weights_multi(int n, const float* const* W, void* const* out, const int* Cout, const int* Cin_real,
+                                 const int* Cin_pad, const int* KT, const int* KH, const int* KW, const int* dgrad,
+                                 lr_stream_t stream);
 
 /* Y[b,t,ho,wo,n] = act( sum_{kt,kh,kw,c} X[b,t+kt-pt,ho*s+kh-ph,wo*s+kw-pw,c] * Wp[n][(kt,kh,kw)][c]
  *                       + bias[n] ),  zero padding, temporal stride 1 and KT = 2*pt+1, spatial stride s.

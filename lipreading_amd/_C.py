@@ -70,6 +70,7 @@ SIGNATURES = {
                            [c_int] * 7 + [P]),
     "lr_decoder_backward": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P,
                                      c_size_t, c_int] + [c_int] * 7 + [P]),
+    "lr_ctc_prepare_i64": (c_int, [P, c_int64, P, P, P, P, P, c_int, c_int, P]),
     "lr_nll_mean_forward": (c_int, [P, P, c_int64, c_int, c_int, P, c_int, c_int, P]),
     "lr_nll_mean_backward": (c_int, [P, c_int64, c_int, c_int, P, P, P, c_int, c_int, P]),
     "lr_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -82,6 +83,7 @@ SIGNATURES = {
                                       c_int, P]),
     "lr_clip_to_ndhwc_bf16": (c_int, [P, c_int, P, c_int64, c_int, c_int, P]),
     "lr_conv3d_pack_weights": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "lr_conv3d_pack_weights_multi": (c_int, [c_int] + [P] * 9 + [P]),
     "lr_conv3d_forward": (c_int, [P, P, P, P] + [c_int] * 14 + [P]),
     "lr_conv3d_patch_supported": (c_int, [c_int] * 11),
     "lr_conv3d_pool_fusion_supported": (c_int, [c_int] * 11),

@@ -1192,6 +1192,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(const bf16_t* __r
     }
   }
   uint4 pre[UPT];
+  unsigned pre_ok = 0;   // bit i: unit i of the tile in flight is real data (else it is stored as zeros)
+  // BRANCH-FREE on purpose: with `if (ok) v = load` hipcc branches around every one of the 19 loads (~20
+  // instructions and two exec-mask round trips apiece, in basic blocks of their own that nothing overlaps with
+  // the MFMAs: a quarter of a tile's time).  Every unit is loaded — from the tile origin when it is padding — and
+  // padding is replaced by zeros on the way into LDS.
   auto issue = [&](int tile) {   // global -> registers: every 16-byte unit of a tile
     const int f0 = (tile / htiles) * TT, h0 = (tile % htiles) * TH;
     unsigned okx = 0, okz = 0;   // per frame slot: X frame (shifted by kt - 1, same clip) / dZ frame exists
@@ -1203,22 +1208,29 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(const bf16_t* __r
     }
     const bf16_t* xb = X + ((int64_t)f0 * H + h0) * W * CIN;
     const bf16_t* zb = dZ + ((int64_t)f0 * H + h0) * W * COUT;
+    pre_ok = 0;
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
       const int m = umeta[i], sf = m & 3;
-      const bool isx = (m & 4) != 0;
+      // units tid + 256 i below XUNITS are X, the others dZ: a compile-time fact for all but one i
+      const bool isx = 256 * i + 255 < XUNITS ? true : (256 * i >= XUNITS ? false : (m & 4) != 0);
       const unsigned hh = (unsigned)(h0 + ((m >> 8) & 0xff) - 16);
       const bool ok = (m & 8) && (((isx ? okx : okz) >> sf) & 1u) && (!isx || hh < (unsigned)H);
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) v = *reinterpret_cast<const uint4*>((isx ? xb : zb) + urel[i]);
-      pre[i] = v;
+      pre_ok |= (ok ? 1u : 0u) << i;
+      pre[i] = *reinterpret_cast<const uint4*>((isx ? xb : zb) + (ok ? urel[i] : 0));
     }
   };
   auto deposit = [&](int buf) {   // registers -> LDS buffer (planes of [position][32 channels])
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
       const int u = tid + 256 * i;
-      if (u < UNITS) *reinterpret_cast<uint4*>(lds + buf * BUF + u * 16) = pre[i];
+      const bool ok = (pre_ok >> i) & 1u;
+      uint4 v = pre[i];
+      v.x = ok ? v.x : 0u;
+      v.y = ok ? v.y : 0u;
+      v.z = ok ? v.z : 0u;
+      v.w = ok ? v.w : 0u;
+      if (u < UNITS) *reinterpret_cast<uint4*>(lds + buf * BUF + u * 16) = v;
     }
   };
 
@@ -1352,9 +1364,9 @@ __global__ __launch_bounds__(1024) void conv_wgrad_slab_reduce_kernel(const floa
 // frag != 0 the same elements are written fragment-major for conv_patch_kernel,
 //   Wf[cg][tap][kc][nt][lane = kg*32 + n%32][j] = Wp[nt*32 + n%32][tap][cg*32 + kc*16 + kg*8 + j],
 // i.e. every MFMA B fragment (32 output channels x 16 k) is 1 KB contiguous, 16 bytes per lane.
-__global__ void conv3d_pack_weights_kernel(const float* __restrict__ W, bf16_t* __restrict__ out, int Cout,
-                                           int Cin_real, int Cin_pad, int KT, int KH, int KW,
-                                           int dgrad, int frag) {
+__device__ __forceinline__ void conv3d_pack_weights_body(const float* __restrict__ W, bf16_t* __restrict__ out,
+                                                         int Cout, int Cin_real, int Cin_pad, int KT, int KH, int KW,
+                                                         int dgrad, int frag) {
   const int taps = KT * KH * KW;
   const int Nout = dgrad ? Cin_real : Cout, Kch = dgrad ? Cout : Cin_pad;
   const int64_t total = (int64_t)Nout * taps * Kch;
@@ -1384,6 +1396,25 @@ __global__ void conv3d_pack_weights_kernel(const float* __restrict__ W, bf16_t* 
     }
     out[dst] = f2bf(v);
   }
+}
+__global__ void conv3d_pack_weights_kernel(const float* __restrict__ W, bf16_t* __restrict__ out, int Cout,
+                                           int Cin_real, int Cin_pad, int KT, int KH, int KW,
+                                           int dgrad, int frag) {
+  conv3d_pack_weights_body(W, out, Cout, Cin_real, Cin_pad, KT, KH, KW, dgrad, frag);
+}
+// several operands in one launch (blockIdx.y = item): a training step packs the forward operand of every layer
+// and the data-gradient operand of the upper layers — five ~4 us launches otherwise
+constexpr int kPackMax = 8;
+struct PackItems {
+  const float* W[kPackMax];
+  bf16_t* out[kPackMax];
+  int cout[kPackMax], cin_real[kPackMax], cin_pad[kPackMax], kt[kPackMax], kh[kPackMax], kw[kPackMax];
+  int flip[kPackMax], frag[kPackMax];
+};
+__global__ void conv3d_pack_weights_multi_kernel(PackItems p) {
+  const int z = blockIdx.y;
+  conv3d_pack_weights_body(p.W[z], p.out[z], p.cout[z], p.cin_real[z], p.cin_pad[z], p.kt[z], p.kh[z], p.kw[z],
+                           p.flip[z], p.frag[z]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1884,6 +1915,32 @@ extern "C" int lr_conv3d_pack_weights(const float* W, void* out, int Cout, int C
                              : (int64_t)Cout * KT * KH * KW * Cin_pad;
   LR_LAUNCH(conv3d_pack_weights_kernel, dim3(grid1d(total)), dim3(256), 0, stream, W, (bf16_t*)out,
             Cout, Cin_real, Cin_pad, KT, KH, KW, flip, frag);
+  return lr_launch_status();
+}
+
+extern "C" int lr_conv3d_pack_weights_multi(int n, const float* const* W, void* const* out, const int* Cout,
+                                            const int* Cin_real, const int* Cin_pad, const int* KT, const int* KH,
+                                            const int* KW, const int* dgrad, lr_stream_t stream) {
+  LR_CHECK_ARG(n >= 1 && n <= kPackMax && W && out && Cout && Cin_real && Cin_pad && KT && KH && KW && dgrad);
+  PackItems p;
+  int64_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    LR_CHECK_ARG(W[i] && out[i] && Cout[i] > 0 && Cin_real[i] > 0 && Cin_pad[i] >= Cin_real[i]);
+    const int flip = dgrad[i] & 1, frag = (dgrad[i] & 2) ? 1 : ((dgrad[i] & 4) ? 2 : 0);
+    if (frag && ((flip ? Cin_real[i] : Cout[i]) % 32 != 0 || (flip ? Cout[i] : Cin_pad[i]) % 32 != 0))
+      return LR_ERR_UNSUPPORTED;
+    p.W[i] = W[i]; p.out[i] = (bf16_t*)out[i];
+    p.cout[i] = Cout[i]; p.cin_real[i] = Cin_real[i]; p.cin_pad[i] = Cin_pad[i];
+    p.kt[i] = KT[i]; p.kh[i] = KH[i]; p.kw[i] = KW[i]; p.flip[i] = flip; p.frag[i] = frag;
+    const int64_t total = flip ? (int64_t)Cin_real[i] * KT[i] * KH[i] * KW[i] * Cout[i]
+                               : (int64_t)Cout[i] * KT[i] * KH[i] * KW[i] * Cin_pad[i];
+    if (total > most) most = total;
+  }
+  for (int i = n; i < kPackMax; ++i) {
+    p.W[i] = nullptr; p.out[i] = nullptr;
+    p.cout[i] = p.cin_real[i] = p.cin_pad[i] = p.kt[i] = p.kh[i] = p.kw[i] = p.flip[i] = p.frag[i] = 0;
+  }
+  LR_LAUNCH(conv3d_pack_weights_multi_kernel, dim3(grid1d(most), n), dim3(256), 0, stream, p);
   return lr_launch_status();
 }
 

@@ -420,6 +420,33 @@ extern "C" int lr_nll_mean_backward(const int64_t* labels, int64_t label_stride,
   return lr_launch_status();
 }
 
+// labels = chars[:, 1:] + 1 as int32, frame_lens / (char_lens - 1) as int32 (include/lipreading_hip.h)
+__global__ void ctc_prepare_i64_kernel(const int64_t* __restrict__ chars, int64_t chars_stride,
+                                       const int64_t* __restrict__ frame_lens, const int64_t* __restrict__ char_lens,
+                                       int32_t* __restrict__ labels_p1, int32_t* __restrict__ frame_lens32,
+                                       int32_t* __restrict__ label_lens32, int B, int L) {
+  const int total = B * L;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int b = i / L, l = i - b * L;
+    labels_p1[i] = (int32_t)chars[(int64_t)b * chars_stride + 1 + l] + 1;
+  }
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+    frame_lens32[b] = (int32_t)frame_lens[b];
+    label_lens32[b] = (int32_t)char_lens[b] - 1;
+  }
+}
+
+extern "C" int lr_ctc_prepare_i64(const int64_t* chars, int64_t chars_stride, const int64_t* frame_lens,
+                                  const int64_t* char_lens, int32_t* labels_p1, int32_t* frame_lens32,
+                                  int32_t* label_lens32, int B, int L, lr_stream_t stream) {
+  LR_CHECK_ARG(chars && frame_lens && char_lens && labels_p1 && frame_lens32 && label_lens32 && B > 0 && L > 0);
+  int blocks = (B * L + 255) / 256;
+  if (blocks > 256) blocks = 256;
+  LR_LAUNCH(ctc_prepare_i64_kernel, dim3(blocks), dim3(256), 0, stream, chars, chars_stride, frame_lens, char_lens,
+            labels_p1, frame_lens32, label_lens32, B, L);
+  return lr_launch_status();
+}
+
 extern "C" int lr_sumsq(const float* x, int64_t n, float* out, lr_stream_t stream) {
   LR_CHECK_ARG(x && out && n >= 0);
   if (n == 0) return LR_OK;

@@ -377,6 +377,18 @@ __global__ void fold_bias_kernel(const float* __restrict__ b_ih, const float* __
   if (G != 3 || i < 2 * H) v += b_hh[i];
   out[i] = v;
 }
+// both directions of a layer in one launch (blockIdx.y = direction; out[d] = out + d * G * H)
+__global__ void fold_bias2_kernel(const float* __restrict__ b_ih0, const float* __restrict__ b_hh0,
+                                  const float* __restrict__ b_ih1, const float* __restrict__ b_hh1,
+                                  float* __restrict__ out, int G, int H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, d = blockIdx.y;
+  if (i >= G * H) return;
+  const float* b_ih = d ? b_ih1 : b_ih0;
+  const float* b_hh = d ? b_hh1 : b_hh0;
+  float v = b_ih[i];
+  if (G != 3 || i < 2 * H) v += b_hh[i];
+  out[(size_t)d * G * H + i] = v;
+}
 
 // W_hh [G*H][H] -> fragment-major operand for the FORWARD product (rows = hidden units, K = h):
 //   out[((jt*G + g)*nchunk + c)*256 + l*4 + q] = W_hh[g*H + jt*16 + (l&15)][c*16 + 4*(l>>4) + q]
@@ -637,10 +649,10 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
                                     float* h_n, float* c_n, void* reserve, size_t reserve_bytes,
                                     int B, int T, int I, int H, int D, lr_stream_t stream_) {
   LR_CHECK_ARG(dims_ok(mode, B, T, I, H, D));
-  LR_CHECK_ARG(x && lens && w_ih && w_hh && b_ih && b_hh && y && h_n && reserve);
+  LR_CHECK_ARG(x && lens && w_ih && w_hh && b_ih && b_hh && y && reserve);
   if (H % 4 != 0) return LR_ERR_UNSUPPORTED;  // float4 operand loads along K
   const int G = gates_of(mode);
-  LR_CHECK_ARG(G != 4 || c_n);
+  LR_CHECK_ARG(G != 4 || c_n || !h_n);   // h_n == NULL: the caller does not want the final states (one launch less)
   for (int d = 0; d < D; ++d) LR_CHECK_ARG(w_ih[d] && w_hh[d] && b_ih[d] && b_hh[d]);
   const Layout l = reserve_layout(G, B, T, I, H, D, proj_x3(mode));
   if (reserve_bytes < l.total * sizeof(float)) return LR_ERR_WORKSPACE;
@@ -651,9 +663,9 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
   float* bias = base + l.bias;
   const int GH = G * H;
 
-  for (int d = 0; d < D; ++d) {
-    LR_LAUNCH(fold_bias_kernel, dim3((GH + 255) / 256), dim3(256), 0, stream, b_ih[d], b_hh[d],
-              bias + (size_t)d * GH, G, H);
+  {
+    LR_LAUNCH(fold_bias2_kernel, dim3((GH + 255) / 256, D), dim3(256), 0, stream, b_ih[0], b_hh[0], b_ih[D - 1],
+              b_hh[D - 1], bias, G, H);
     int st = lr_launch_status();
     if (st != LR_OK) return st;
   }
@@ -691,6 +703,7 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
       return LR_ERR_UNSUPPORTED;
     }
     if (st != LR_OK) return st;
+    if (!h_n) return LR_OK;
     const int64_t total = (int64_t)D * B * H;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 1024) blocks = 1024;
@@ -705,6 +718,7 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
     if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_gru256_persist_pack_bytes(D)) return LR_ERR_WORKSPACE;
     int st = lr_gru256_persist_forward(gates, extra, y, w_hh, b_hh, lens, base + l.wp, B, T, D, stream);
     if (st != LR_OK) return st;
+    if (!h_n) return LR_OK;
     const int64_t total = (int64_t)D * B * H;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 1024) blocks = 1024;
@@ -745,6 +759,7 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
   }
   int st = lr_launch_status();
   if (st != LR_OK) return st;
+  if (!h_n) return LR_OK;
   const int64_t total = (int64_t)D * B * H;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 1024) blocks = 1024;

@@ -185,22 +185,48 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
     g.C1 = g.Cb;
   }
 
-  // a plane tile is 128 rows x 32 k = 512 16-byte units: two per thread (row = e / 4, unit = e % 4)
-  auto fetch = [&](const bf16_t* p, int row, int row_lim, int k) -> uint4 {
-    if (row >= row_lim || k >= kend) return make_uint4(0u, 0u, 0u, 0u);   // planes are zero-padded to ldp
-    return *reinterpret_cast<const uint4*>(p + (int64_t)row * g.ldp + k);
-  };
+  // a plane tile is 128 rows x 32 k = 512 16-byte units: two per thread (row = e / 4, unit = e % 4).  Rows past
+  // the matrix edge are CLAMPED, not zeroed (their products land in accumulator rows / columns that are never
+  // stored, and the planes hold finite numbers); only the K tail needs zeros, and only in a split's last stage,
+  // so the loads of every other stage are unconditional (a per-load predicate makes hipcc branch around each load).
   constexpr int NPL = 2 + (AX ? 0 : 1) + (BX ? 0 : 1);
+  // (element offsets of the thread's two units inside a plane — a plane stays below 2^31 elements —, added to the
+  // uniform plane pointer + k0: scalar base + 32-bit lane offset addressing, no 64-bit address registers)
+  unsigned offa[2], offb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + i * 256, row = e >> 2, ku = 8 * (e & 3);
+    offa[i] = (unsigned)min(m0 + row, g.M - 1) * (unsigned)g.ldp + ku;
+    offb[i] = (unsigned)min(n0 + row, g.N - 1) * (unsigned)g.ldp + ku;
+  }
   uint4 rr[XDEPTH][NPL][2];
   auto load = [&](int slot, int k0) {
+    const bf16_t* const pl_ptr[4] = {g.Ah + k0, AX ? nullptr : g.Al + k0, g.Bh + k0, BX ? nullptr : g.Bl + k0};
+    if (k0 + XBK <= kend) {   // workgroup-uniform
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = tid + i * 256, row = e >> 2, k = k0 + 8 * (e & 3);
-      int pl = 0;
-      rr[slot][pl++][i] = fetch(g.Ah, m0 + row, g.M, k);
-      if (!AX) rr[slot][pl++][i] = fetch(g.Al, m0 + row, g.M, k);
-      rr[slot][pl++][i] = fetch(g.Bh, n0 + row, g.N, k);
-      if (!BX) rr[slot][pl++][i] = fetch(g.Bl, n0 + row, g.N, k);
+      for (int i = 0; i < 2; ++i) {
+        int pl = 0;
+        rr[slot][pl++][i] = *reinterpret_cast<const uint4*>(pl_ptr[0] + offa[i]);
+        if (!AX) rr[slot][pl++][i] = *reinterpret_cast<const uint4*>(pl_ptr[1] + offa[i]);
+        rr[slot][pl++][i] = *reinterpret_cast<const uint4*>(pl_ptr[2] + offb[i]);
+        if (!BX) rr[slot][pl++][i] = *reinterpret_cast<const uint4*>(pl_ptr[3] + offb[i]);
+      }
+    } else {                  // the K tail: units at or past kend are zero (planes are zero-padded to ldp only)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool ok = k0 + 8 * ((tid + i * 256) & 3) < kend;
+        const int back = ok ? 0 : k0 - kbeg;   // a unit past the end reads the split's first stage instead
+        int pl = 0;
+        auto get = [&](const bf16_t* p, unsigned off) {
+          uint4 v = *reinterpret_cast<const uint4*>(p + off - back);
+          v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+          return v;
+        };
+        rr[slot][pl++][i] = get(pl_ptr[0], offa[i]);
+        if (!AX) rr[slot][pl++][i] = get(pl_ptr[1], offa[i]);
+        rr[slot][pl++][i] = get(pl_ptr[2], offb[i]);
+        if (!BX) rr[slot][pl++][i] = get(pl_ptr[3], offb[i]);
+      }
     }
   };
   auto store = [&](int slot) {
@@ -224,6 +250,9 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int lr = lane & 31, lk = lane >> 5;
+  const int fa = (wm * 64 + lr) * XLD + lk * 8, fb = (wn * 64 + lr) * XLD + lk * 8;   // fragment offsets (elements)
+  constexpr int NFRAG = 2 * NPL;                   // fragment reads per k16 step
+  constexpr int NMMA = 4 * (1 + (AX ? 0 : 1) + (BX ? 0 : 1));
 #pragma unroll
   for (int sl = 0; sl < XDEPTH; ++sl)
     if (kbeg + sl * XBK < kend) load(sl, kbeg + sl * XBK);
@@ -238,43 +267,51 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
         store(sl);
         lr_lds_barrier();
         if (k0 + XDEPTH * XBK < kend) load(sl, k0 + XDEPTH * XBK);
+        // both k16 steps' fragments are read up front (left alone, hipcc puts every read next to its first use
+        // and each group of MFMAs waits out an LDS round trip), then the MFMAs run term by term over the four
+        // accumulators: small terms first, so they are not absorbed by a large partial sum, and consecutive
+        // MFMAs never wait for each other's result
+        bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
 #pragma unroll
-        for (int kk = 0; kk < XBK; kk += 16) {
-          bf16x8 ah[2], al[2], bh[2], bl[2];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            const int o = (wm * 64 + i * 32 + lr) * XLD + kk + lk * 8;
-            ah[i] = *reinterpret_cast<const bf16x8*>(&Ah[o]);
-            if (!AX) al[i] = *reinterpret_cast<const bf16x8*>(&Al[o]);
+            ah[ks][i] = *reinterpret_cast<const bf16x8*>(&Ah[fa + i * 32 * XLD + ks * 16]);
+            if (!AX) al[ks][i] = *reinterpret_cast<const bf16x8*>(&Al[fa + i * 32 * XLD + ks * 16]);
+            bh[ks][i] = *reinterpret_cast<const bf16x8*>(&Bh[fb + i * 32 * XLD + ks * 16]);
+            if (!BX) bl[ks][i] = *reinterpret_cast<const bf16x8*>(&Bl[fb + i * 32 * XLD + ks * 16]);
           }
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int o = (wn * 64 + j * 32 + lr) * XLD + kk + lk * 8;
-            bh[j] = *reinterpret_cast<const bf16x8*>(&Bh[o]);
-            if (!BX) bl[j] = *reinterpret_cast<const bf16x8*>(&Bl[o]);
-          }
-          // small terms first, so they are not absorbed by a large partial sum; term by term over the four
-          // accumulators, so that consecutive MFMAs never wait for each other's result
+        for (int ks = 0; ks < 2; ++ks) {
           if (!BX) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
               for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
           }
           if (!AX) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
               for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
           }
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
         }
+        // pinned order: the first step's reads, then one of the second step's reads behind each of the first
+        // MFMAs, then the remaining MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, NFRAG, 0);
+#pragma unroll
+        for (int q = 0; q < NFRAG; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NMMA - NFRAG, 0);
       }
     }
   }

@@ -20,6 +20,7 @@ class _CTCLossFunction(torch.autograd.Function):
   @staticmethod
   def forward(ctx, log_probs, labels_p1, frame_lens, label_lens, reduction, max_label_len):
     L = _C.lib()
+    ctx.set_materialize_grads(False)   # status / nll get no gradient: no zero tensors (a fill launch each) for them
     B, T, C = log_probs.shape
     dev = log_probs.device
     ws_bytes = L.lr_ctc_workspace_bytes(B, T, C, max_label_len)
@@ -43,6 +44,8 @@ class _CTCLossFunction(torch.autograd.Function):
 
   @staticmethod
   def backward(ctx, grad_out, _gs, _gn):
+    if grad_out is None:
+      return None, None, None, None, None, None
     log_probs, labels_p1, frame_lens, label_lens, nll, gw, ws = ctx.saved_tensors
     L = _C.lib()
     B, T, C = log_probs.shape
@@ -84,6 +87,38 @@ def ctc_loss_with_status(encoder_outputs, labels, frame_lens, label_lens, reduct
   ll = label_lens.to(torch.int32).contiguous()
   max_label_len = max(1, min(int(labels_p1.shape[1]), 256))
   return _CTCLossFunction.apply(lp, labels_p1, fl, ll, _REDUCTIONS[reduction], max_label_len)
+
+
+def prepare_ctc_inputs(chars, frame_lens, char_lens):
+  """The train loop's label plumbing (train_better_model.py:31-32 + ctc_loss.py:42,80) in one launch:
+  chars (B, Lc) int64 with BOS in column 0, frame_lens / char_lens (B,) int64, all on the device ->
+  (labels_p1 (B, Lc-1) int32 = chars[:, 1:] + 1, frame_lens int32, label_lens int32 = char_lens - 1)."""
+  _C.require_cuda(chars, frame_lens, char_lens)
+  assert chars.dim() == 2 and chars.shape[1] >= 2 and chars.dtype == torch.int64 and chars.stride(1) == 1
+  assert frame_lens.dtype == torch.int64 and char_lens.dtype == torch.int64
+  B, Lc = chars.shape
+  dev = chars.device
+  labels_p1 = torch.empty((B, Lc - 1), dtype=torch.int32, device=dev)
+  fl = torch.empty(B, dtype=torch.int32, device=dev)
+  ll = torch.empty(B, dtype=torch.int32, device=dev)
+  _C.check(_C.lib().lr_ctc_prepare_i64(chars.data_ptr(), chars.stride(0), frame_lens.contiguous().data_ptr(),
+                                       char_lens.contiguous().data_ptr(), labels_p1.data_ptr(), fl.data_ptr(),
+                                       ll.data_ptr(), B, Lc - 1, _C.stream_handle()), "lr_ctc_prepare_i64")
+  return labels_p1, fl, ll
+
+
+def ctc_loss_prepared(encoder_outputs, labels_p1, frame_lens32, label_lens32, reduction):
+  """ctc_loss_with_status on the outputs of prepare_ctc_inputs (no conversions, no host synchronisation)."""
+  _C.require_cuda(encoder_outputs, labels_p1, frame_lens32, label_lens32)
+  if reduction not in _REDUCTIONS:
+    raise ValueError("reduction must be 'mean' or 'sum', got %r" % (reduction,))
+  lp = encoder_outputs if encoder_outputs.dtype == torch.float32 else encoder_outputs.float()
+  if lp.stride(2) != 1:
+    lp = lp.contiguous()
+  assert labels_p1.dtype == torch.int32 and labels_p1.is_contiguous() and labels_p1.shape[0] == lp.shape[0]
+  assert frame_lens32.dtype == torch.int32 and label_lens32.dtype == torch.int32
+  max_label_len = max(1, min(int(labels_p1.shape[1]), 256))
+  return _CTCLossFunction.apply(lp, labels_p1, frame_lens32, label_lens32, _REDUCTIONS[reduction], max_label_len)
 
 
 def ctc_loss(encoder_outputs, labels, frame_lens, label_lens, reduction, device=None):

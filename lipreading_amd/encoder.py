@@ -81,28 +81,33 @@ class _RNNLayerFunction(torch.autograd.Function):
   """One (bi)directional layer: lr_rnn_layer_forward / lr_rnn_layer_backward."""
 
   @staticmethod
-  def forward(ctx, x, lens, mode, H, need_dx, *weights):
+  def forward(ctx, x, lens, mode, H, need_dx, need_state, *weights):
     L = _C.lib()
     B, T, I = x.shape
     D = len(weights) // 4
     dev = x.device
     w_ih, w_hh = list(weights[0::4]), list(weights[1::4])
     b_ih, b_hh = list(weights[2::4]), list(weights[3::4])
+    # unused outputs come back to backward() as None, not as zero tensors (a fill launch each)
+    ctx.set_materialize_grads(False)
     y = torch.empty((B, T, D * H), dtype=torch.float32, device=dev)
-    h_n = torch.empty((D, B, H), dtype=torch.float32, device=dev)
-    c_n = torch.empty((D, B, H), dtype=torch.float32, device=dev) if (mode & 0xff) == 1 else None
+    # need_state False: the final states are not extracted (h_n == NULL; the CTC-only step never reads them)
+    h_n = torch.empty((D, B, H) if need_state else (0,), dtype=torch.float32, device=dev)
+    c_n = torch.empty((D, B, H), dtype=torch.float32, device=dev) if ((mode & 0xff) == 1 and need_state) else None
     rbytes = L.lr_rnn_reserve_bytes(mode, B, T, I, H, D)
     reserve = torch.empty(rbytes, dtype=torch.uint8, device=dev)
     _C.check(L.lr_rnn_layer_forward(mode, x.data_ptr(), lens.data_ptr(), _ptr_array(w_ih),
                                     _ptr_array(w_hh), _ptr_array(b_ih), _ptr_array(b_hh),
-                                    y.data_ptr(), h_n.data_ptr(), _C.ptr(c_n), reserve.data_ptr(),
+                                    y.data_ptr(), h_n.data_ptr() if need_state else None, _C.ptr(c_n), reserve.data_ptr(),
                                     rbytes, B, T, I, H, D, _C.stream_handle()),
              "lr_rnn_layer_forward")
     ctx.save_for_backward(x, lens, y, reserve, *weights)
     ctx.cfg = (mode, H, D, need_dx)
     if c_n is None:
-      c_n = torch.zeros((0,), device=dev)
+      c_n = torch.empty((0,), device=dev)
       ctx.mark_non_differentiable(c_n)
+    if not need_state:
+      ctx.mark_non_differentiable(h_n)
     return y, h_n, c_n
 
   @staticmethod
@@ -141,7 +146,7 @@ class _RNNLayerFunction(torch.autograd.Function):
         # THIS stream, i.e. starts as soon as these gradients exist, not when the streams are joined
         _notify(weights)
       _deferred.append((x, lens, y, dy, reserve, ws, grads, weights))
-      return (dx, None, None, None, None) + (None,) * len(weights)
+      return (dx, None, None, None, None, None) + (None,) * len(weights)
     _C.check(L.lr_rnn_layer_backward(
         mode, x.data_ptr(), lens.data_ptr(), _ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(b_ih),
         _ptr_array(b_hh), y.data_ptr(), dy.data_ptr(), _C.ptr(dh_n), _C.ptr(dc_n), _C.ptr(dx),
@@ -151,8 +156,8 @@ class _RNNLayerFunction(torch.autograd.Function):
     flush_deferred()   # the layer above's weight-gradient half overlapped this layer's recurrence
     if direct:
       _notify(weights)
-      return (dx, None, None, None, None) + (None,) * len(weights)
-    return (dx, None, None, None, None) + tuple(grads)
+      return (dx, None, None, None, None, None) + (None,) * len(weights)
+    return (dx, None, None, None, None, None) + tuple(grads)
 
 
 class _ProjLogSoftmaxFunction(torch.autograd.Function):
@@ -281,7 +286,7 @@ class VideoEncoder(nn.Module):
     if self.enable_ctc:
       self.output_proj = nn.Linear(self.num_dirs * self.hidden_size, self.adj_vocab_size)
 
-  def forward(self, frames, frame_lens, max_len=None):
+  def forward(self, frames, frame_lens, max_len=None, need_final_state=True):
     """frames (B, seq_len, num_lmks, lmk_dim) f32, frame_lens (B,) -> as better_model.py:53-96:
     (log_probs (B,Tmax,V+1), hidden (B,Tmax,D*H), final_state) if enable_ctc else
     (hidden, final_state); final_state is (h, c) for the LSTM, each (layers, B, D*H).
@@ -323,18 +328,21 @@ class VideoEncoder(nn.Module):
         # lr_rnn_pair_supported: 1 = GRU-256 (CU pairs), 2 = LSTM-768 (24-CU clusters); 0 = step kernels
         if self.recurrence in ('auto', 'split') and _C.lib().lr_rnn_pair_supported(mode, B, max_len, x.shape[2], H, D):
           lmode |= _RECUR_SPLIT
-      y, h_n, c_n = _RNNLayerFunction.apply(x, lens, lmode, H, need_dx, *weights)
-      # (D,B,H) -> (B, D*H): forward direction first, as _cat_directions (better_model.py:98-112)
-      h_fin.append(h_n.permute(1, 0, 2).reshape(B, D * H))
-      if mode == 1:
-        c_fin.append(c_n.permute(1, 0, 2).reshape(B, D * H))
+      y, h_n, c_n = _RNNLayerFunction.apply(x, lens, lmode, H, need_dx, need_final_state, *weights)
+      if need_final_state:
+        # (D,B,H) -> (B, D*H): forward direction first, as _cat_directions (better_model.py:98-112)
+        h_fin.append(h_n.permute(1, 0, 2).reshape(B, D * H))
+        if mode == 1:
+          c_fin.append(c_n.permute(1, 0, 2).reshape(B, D * H))
       x = y
       if self.rnn_dropout and self.training and layer + 1 < self.num_layers:
         x = F.dropout(x, p=self.rnn_dropout, training=True)   # nn.GRU/LSTM inter-layer dropout
     hidden_states = y
-    final_state = torch.stack(h_fin, 0)
-    if mode == 1:
-      final_state = (final_state, torch.stack(c_fin, 0))
+    final_state = None
+    if need_final_state:
+      final_state = torch.stack(h_fin, 0)
+      if mode == 1:
+        final_state = (final_state, torch.stack(c_fin, 0))
 
     if self.enable_ctc:
       output_log_probs = _ProjLogSoftmaxFunction.apply(hidden_states, self.output_proj.weight,

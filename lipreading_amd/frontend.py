@@ -17,6 +17,8 @@ channels-last activations, implicit-GEMM convolution on v_mfma_f32_32x32x16_bf16
 accumulation, fused bias+ReLU.  There is NO reference parity for this stage; the oracle is torch
 conv3d/max_pool3d on the CPU (oracle/torch_oracle.py conv_frontend).
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -42,6 +44,15 @@ def _pad4(c):
 
 def feature_dim(H, W):
   return 96 * (H // 16) * (W // 16)
+
+
+def _pack_weights(L, packs, st):
+  """packs: (weight fp32, out bf16, cout, cin, cin_pad, kt, kh, kw, dgrad flags) — one launch for all of them."""
+  n = len(packs)
+  ptrs = (ctypes.c_void_p * n)(*[p[0].data_ptr() for p in packs])
+  outs = (ctypes.c_void_p * n)(*[p[1].data_ptr() for p in packs])
+  cols = [(ctypes.c_int * n)(*[p[k] for p in packs]) for k in range(2, 9)]
+  _C.check(L.lr_conv3d_pack_weights_multi(n, ptrs, outs, *cols, st), "lr_conv3d_pack_weights_multi")
 
 
 class _ConvFrontendFunction(torch.autograd.Function):
@@ -70,15 +81,31 @@ class _ConvFrontendFunction(torch.autograd.Function):
       _C.check(L.lr_clip_to_ndhwc_bf16(src.data_ptr(), 1 if is_u8 else 0, x.data_ptr(), frames, H, W, st),
                "lr_clip_to_ndhwc_bf16")
     saved = [x]
+    # every bf16 weight operand of the step in ONE launch: the forward operand of each layer (fragment-major where
+    # the layer has a patch-resident kernel) and, when a backward will follow, the flipped / channel-transposed
+    # operand of the upper layers' data gradients (kept for the backward)
+    packs, fwd_ops, dgrad_ops = [], [], {}
+    h, w = H, W
+    for li, (cin, cout, (kt, kh, kw), stride, (pt, ph, pw)) in enumerate(LAYERS):
+      cin_p = _pad4(cin)
+      frag = L.lr_conv3d_patch_supported(h, w, cin_p, cout, kt, kh, kw, stride, pt, ph, pw) if _PATCH_KERNELS else 0
+      wp = torch.empty((cout, kt * kh * kw, cin_p), dtype=bf, device=dev)
+      packs.append((params[2 * li], wp, cout, cin, cin_p, kt, kh, kw, frag))
+      fwd_ops.append((wp, frag))
+      ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
+      if li > 0 and any(ctx.needs_input_grad[2:]):
+        fragd = L.lr_conv3d_patch_supported(ho, wo, cout, cin, kt, kh, kw, 1, pt, ph, pw) if _PATCH_KERNELS else 0
+        wd = torch.empty((cin, kt * kh * kw, cout), dtype=bf, device=dev)
+        packs.append((params[2 * li], wd, cout, cin, cin_p, kt, kh, kw, 1 | fragd))
+        dgrad_ops[li] = (wd, fragd)
+      h, w = ho // 2, wo // 2
+    _pack_weights(L, packs, st)
+    ctx.dgrad_ops = dgrad_ops
     h, w = H, W
     for li, (cin, cout, (kt, kh, kw), stride, (pt, ph, pw)) in enumerate(LAYERS):
       weight, bias = params[2 * li], params[2 * li + 1]
       cin_p = _pad4(cin)
-      wp = torch.empty((cout, kt * kh * kw, cin_p), dtype=bf, device=dev)
-      # layers with a patch-resident kernel take their weights in its fragment-major order
-      frag = L.lr_conv3d_patch_supported(h, w, cin_p, cout, kt, kh, kw, stride, pt, ph, pw) if _PATCH_KERNELS else 0
-      _C.check(L.lr_conv3d_pack_weights(weight.data_ptr(), wp.data_ptr(), cout, cin, cin_p, kt, kh, kw, frag,
-                                        st), "lr_conv3d_pack_weights")
+      wp, frag = fwd_ops[li]
       ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
       pooled = torch.empty((frames, ho // 2, wo // 2, cout), dtype=bf, device=dev)
       fuse = _PATCH_KERNELS and (frag or cin_p == 4) and L.lr_conv3d_pool_fusion_supported(
@@ -168,10 +195,13 @@ class _ConvFrontendFunction(torch.autograd.Function):
       if li > 0:
         # data gradient of a stride-1 "same" convolution = the forward kernel on dZ with the
         # flipped, channel-transposed weights
-        wd = torch.empty((cin, kt * kh * kw, cout), dtype=bf, device=dev)
-        frag = L.lr_conv3d_patch_supported(ho, wo, cout, cin, kt, kh, kw, 1, pt, ph, pw) if _PATCH_KERNELS else 0
-        _C.check(L.lr_conv3d_pack_weights(params[2 * li].data_ptr(), wd.data_ptr(), cout, cin, cin_p, kt,
-                                          kh, kw, 1 | frag, st), "lr_conv3d_pack_weights")
+        if li in ctx.dgrad_ops:   # packed with the forward operands (same weights: nothing updates them in between)
+          wd, frag = ctx.dgrad_ops[li]
+        else:
+          wd = torch.empty((cin, kt * kh * kw, cout), dtype=bf, device=dev)
+          frag = L.lr_conv3d_patch_supported(ho, wo, cout, cin, kt, kh, kw, 1, pt, ph, pw) if _PATCH_KERNELS else 0
+          _C.check(L.lr_conv3d_pack_weights(params[2 * li].data_ptr(), wd.data_ptr(), cout, cin, cin_p, kt,
+                                            kh, kw, 1 | frag, st), "lr_conv3d_pack_weights")
         dP = torch.empty((frames, h, w, cin), dtype=bf, device=dev)
         _C.check(L.lr_conv3d_forward(dZ.data_ptr(), wd.data_ptr(), None, dP.data_ptr(), B, T, ho, wo, cout,
                                      cin, kt, kh, kw, 1, pt, ph, pw, frag, st), "lr_conv3d_forward(dgrad)")
@@ -221,7 +251,7 @@ class PixelLipReader(nn.Module):
     # weight-gradient GEMMs of upper recurrent layers overlap the recurrence of the layer below
     from . import encoder as _enc
     _enc.overlap_weight_grads = True
-  def forward(self, clips, frame_lens, max_len=None):
+  def forward(self, clips, frame_lens, max_len=None, need_final_state=True):
     feats = self.frontend(clips, out_bf16=True)
     B, T, F = feats.shape
-    return self.encoder(feats.reshape(B, T, F, 1), frame_lens, max_len=max_len)
+    return self.encoder(feats.reshape(B, T, F, 1), frame_lens, max_len=max_len, need_final_state=need_final_state)

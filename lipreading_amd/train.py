@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _C
-from .ctc import ctc_loss_with_status
+from .ctc import ctc_loss_prepared, ctc_loss_with_status, prepare_ctc_inputs
 from .data import BOS, EOS, PAD
 from .optim import FusedAdam
 
@@ -153,11 +153,20 @@ def ctc_step(encoder, opt, frames, frame_lens, chars, char_lens, grad_norm=None,
   whole = grad_sync is None      # nothing between backward and the optimiser: one graph for the step
 
   def body(frames, frame_lens, chars, char_lens):
-    labels = chars[:, 1:]
-    label_lens = char_lens - 1
+    # labels = chars[:, 1:] + 1, label_lens = char_lens - 1 and the int32 lengths in one launch; the encoder takes
+    # the int32 frame lengths as they are
+    fused_prep = (chars.dtype == torch.int64 and frame_lens.dtype == torch.int64 and char_lens.dtype == torch.int64
+                  and chars.dim() == 2 and chars.stride(1) == 1)
+    if fused_prep:
+      labels_p1, frame_lens32, label_lens32 = prepare_ctc_inputs(chars, frame_lens, char_lens)
     opt.zero_grad()
-    log_probs, _, _ = encoder(frames, frame_lens, max_len=max_len)
-    loss, status, _ = ctc_loss_with_status(log_probs, labels, frame_lens, label_lens, 'mean')
+    # (the CTC-only step never reads the encoder's final states: they are not extracted)
+    log_probs, _, _ = encoder(frames, frame_lens32 if fused_prep else frame_lens, max_len=max_len,
+                              need_final_state=False)
+    if fused_prep:
+      loss, status, _ = ctc_loss_prepared(log_probs, labels_p1, frame_lens32, label_lens32, 'mean')
+    else:
+      loss, status, _ = ctc_loss_with_status(log_probs, chars[:, 1:], frame_lens, char_lens - 1, 'mean')
     loss.backward()
     if whole:
       opt.step(grad_norm=grad_norm, grad_scale=1.0, skip=status)

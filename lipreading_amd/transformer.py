@@ -260,9 +260,10 @@ class TransformerVideoEncoder(nn.Module):
       self.register_buffer("output_mask", mask, persistent=False)
       self.output_proj = nn.Linear(d_model, self.adj_vocab_size)
 
-  def forward(self, frames, frame_lens, max_len=None):
+  def forward(self, frames, frame_lens, max_len=None, need_final_state=True):
     """frames (B, T, ...) f32, frame_lens (B,) -> (log_probs (B,Tmax,V+1), hidden (B,Tmax,d_model), None)
-    [(hidden, None) without the CTC head] — VideoEncoder's contract; there is no recurrent final state."""
+    [(hidden, None) without the CTC head] — VideoEncoder's contract; there is no recurrent final state
+    (`need_final_state` is accepted for that contract and has nothing to switch off)."""
     _C.require_cuda(frames)
     frames = frames.reshape(frames.shape[0], frames.shape[1], -1)
     B, T, I = frames.shape

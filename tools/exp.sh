@@ -1,9 +1,10 @@
 #!/bin/bash
-# scratch experiment: A/B of two library builds on the pixel regime, alternating
-for round in 1 2 3; do
-for v in e135c3 cur; do
-LIPREADING_HIP_LIB=$(pwd)/lipreading_amd/_lib/alt/$v.so timeout 600 python bench.py --regime pixels --no-cpu-baseline --repeats 3 2>/dev/null | tail -1 | python -c "
+# scratch experiment: full GPU suite after the small-launch diet, then pixel + landmark benches
+mkdir -p gpurun_out
+timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/exp_pytest.log 2>&1
+echo "pytest exit $?"; grep -E "passed|failed|Error" gpurun_out/exp_pytest.log | tail -5
+for rg in pixels landmarks; do
+timeout 600 python bench.py --regime $rg --no-cpu-baseline --repeats 3 2>/dev/null | tail -1 | python -c "
 import sys, json
-j = json.loads(sys.stdin.read()); print('$v', j['value'], j['ms_per_step'], j['timing']['ms_per_step_min'])"
-done
+j = json.loads(sys.stdin.read()); print('$rg', j['value'], j['ms_per_step'], j['timing']['ms_per_step_min'])"
 done
