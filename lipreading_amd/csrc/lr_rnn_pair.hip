@@ -69,6 +69,36 @@ __device__ __forceinline__ void publish(u64* p, float v, int tag) {
 __device__ __forceinline__ u64 peek(const u64* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The same granule with a store that stops at the writer's XCD L2 and stays there (the agent-scope `sc1` store
+// writes through and drops the line, so the partner's poll goes to the fabric).  Only the other CUs of the SAME
+// XCD are guaranteed to see it there: used when the two members verified at run time (HW_REG_XCC_ID) that they
+// share an XCD — the usual placement of blocks i and i + 8.  (As lr_rnn_cluster.hip.)
+__device__ __forceinline__ void publish_local(u64* p, float v, int tag) {
+  __hip_atomic_store(p, granule(v, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int xcc_id() {
+  int x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return x & 0xf;
+}
+// one-time handshake of a pair: each member publishes its XCC id (tag 1) at xid[member] and reads the partner's;
+// true when both run on the same XCD.  A partner that never answers leaves `false` (the per-step waits raise the
+// error word).
+__device__ __forceinline__ bool pair_shares_xcd(u64* xid, int m, int tid) {
+  __shared__ int s_local;
+  if (tid == 0) {
+    publish(xid + m, __builtin_bit_cast(float, xcc_id()), 1);
+    u64 g = peek(xid + (1 - m));
+    int n = 0;
+    while ((int)(g >> 32) != 1 && n++ < SPIN_LIMIT) {
+      __builtin_amdgcn_s_sleep(2);
+      g = peek(xid + (1 - m));
+    }
+    s_local = ((int)(g >> 32) == 1 && (int)(g & 0xf) == xcc_id()) ? 1 : 0;
+  }
+  __syncthreads();
+  return s_local != 0;
+}
 // wait until the granule carries `tag`; returns its value (0 and *err set after SPIN_LIMIT polls)
 __device__ __forceinline__ float await(const u64* p, u64 first, int tag, int* err) {
   u64 g = first;
@@ -203,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void gru256_fwd_pair_kernel(float* __restri
   const u64* xtheirs = xch + ((int64_t)pair * 2 + (1 - m)) * HALF + ul;
   const int64_t xslot = (int64_t)npairs * 2 * HALF;
   int bad = 0;
-  __syncthreads();
+  const bool local = pair_shares_xcd(xch + 2 * xslot + (int64_t)pair * 2, m, tid);   // (a barrier inside)
 
   auto step = [&](int s, Gx& gx) {
     const int t = time_of(s);
@@ -283,7 +313,8 @@ __global__ __launch_bounds__(256, 1) void gru256_fwd_pair_kernel(float* __restri
       fetch_gx(gx, tnext);
       const float h = live ? (1.f - z) * n + z * hreg : 0.f;
       hreg = h;
-      publish(xmine + (s & 1) * xslot, h, s + 1);      // first: the partner is waiting for it
+      if (local) publish_local(xmine + (s & 1) * xslot, h, s + 1);      // first: the partner is waiting for it
+      else publish(xmine + (s & 1) * xslot, h, s + 1);
       bf16_t hi, lo;
       split_bf16(h, hi, lo);
       hnxt[ul] = hi;
@@ -418,7 +449,7 @@ __global__ __launch_bounds__(256, 1) void gru256_bwd_pair_kernel(
   const u64* xtheirs = xch + ((int64_t)pair * 2 + (1 - m)) * BOWN + ul;
   const int64_t xslot = (int64_t)npairs * 2 * BOWN;
   int bad = 0;
-  __syncthreads();
+  const bool local = pair_shares_xcd(xch + 2 * xslot + (int64_t)pair * 2, m, tid);   // (a barrier inside)
 
   auto step = [&](int s, In& in) {
     const int t = time_of(s);
@@ -514,9 +545,15 @@ __global__ __launch_bounds__(256, 1) void gru256_bwd_pair_kernel(
         car = dh * z;
       }
       u64* xo = xmine + (s & 1) * xslot;
-      publish(xo, dr_pre, s + 1);
-      publish(xo + HALF, dz_pre, s + 1);
-      publish(xo + 2 * HALF, dnr, s + 1);
+      if (local) {
+        publish_local(xo, dr_pre, s + 1);
+        publish_local(xo + HALF, dz_pre, s + 1);
+        publish_local(xo + 2 * HALF, dnr, s + 1);
+      } else {
+        publish(xo, dr_pre, s + 1);
+        publish(xo + HALF, dz_pre, s + 1);
+        publish(xo + 2 * HALF, dnr, s + 1);
+      }
       bf16_t hi, lo;
       split_bf16(dr_pre, hi, lo);
       gnxt[ul] = hi;
@@ -554,7 +591,7 @@ size_t lr_gru256_pair_bwd_pack_bytes(int D) { return (size_t)D * 2 * 4 * BNT * B
 size_t lr_gru256_pair_xch_bytes(int B, int D, int backward) {
   int pairs = B * D;
   if (pairs > MAX_PAIRS) pairs = MAX_PAIRS / D * D;
-  return (size_t)2 * pairs * 2 * (backward ? BOWN : HALF) * sizeof(u64);
+  return ((size_t)2 * pairs * 2 * (backward ? BOWN : HALF) + (size_t)pairs * 2) * sizeof(u64);   // two slots + the XCC ids
 }
 
 // number of times a member gave up waiting for its partner since the last call (0 = every result is valid);
@@ -584,7 +621,8 @@ int lr_gru256_pair_forward(float* gates, float* extra, float* y, const float* co
   const int chunk = MAX_PAIRS / D;   // samples per launch
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int nb = B - b0 < chunk ? B - b0 : chunk, npairs = nb * D;
-    if (hipMemsetAsync(xch, 0, (size_t)2 * npairs * 2 * HALF * sizeof(u64), stream) != hipSuccess) return LR_ERR_LAUNCH;
+    if (hipMemsetAsync(xch, 0, ((size_t)2 * npairs * 2 * HALF + (size_t)npairs * 2) * sizeof(u64), stream) != hipSuccess)
+      return LR_ERR_LAUNCH;
     const dim3 grid(16 * ((npairs + 7) / 8));
     hipEvent_t e0, e1;
     if (b0 == 0 && lr_prof_next(LR_PROF_RNN_FWD, &e0, &e1))
@@ -616,7 +654,8 @@ int lr_gru256_pair_backward(const float* gates, const float* extra, const float*
   const int chunk = MAX_PAIRS / D;
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int nb = B - b0 < chunk ? B - b0 : chunk, npairs = nb * D;
-    if (hipMemsetAsync(xch, 0, (size_t)2 * npairs * 2 * BOWN * sizeof(u64), stream) != hipSuccess) return LR_ERR_LAUNCH;
+    if (hipMemsetAsync(xch, 0, ((size_t)2 * npairs * 2 * BOWN + (size_t)npairs * 2) * sizeof(u64), stream) != hipSuccess)
+      return LR_ERR_LAUNCH;
     const dim3 grid(16 * ((npairs + 7) / 8));
     hipEvent_t e0, e1;
     if (b0 == 0 && lr_prof_next(LR_PROF_RNN_BWD, &e0, &e1))

@@ -97,6 +97,14 @@ class StepGraphs(object):
     self.replays = 0
     self.captures = 0
 
+  def staging_buffers(self):
+    """The static input tensors of the most recently used shape (None before its first step): a loader can write
+    the next batch of that shape straight into them (same stream) and hand THEM to the step, which then skips
+    its device-to-device staging copy of every input."""
+    if not self._entries:
+      return None
+    return next(reversed(self._entries.values()))["static"]
+
   def run(self, key, inputs, body, capturable=True):
     """inputs: tuple of device tensors; body(*static_inputs) -> tuple of tensors.  Returns body's
     result for these inputs (from a replay when a graph for `key` exists)."""
@@ -111,7 +119,10 @@ class StepGraphs(object):
       e = dict(static=tuple(torch.empty_like(t) for t in inputs), count=0, graph=None, out=None)
     self._entries[key] = e                            # most recently used = last
     for dst, src in zip(e["static"], inputs):
-      dst.copy_(src, non_blocking=True)
+      # a caller that stages its batches straight into the graph's buffers (staging_buffers) passes them back:
+      # nothing to copy
+      if dst.data_ptr() != src.data_ptr():
+        dst.copy_(src, non_blocking=True)
     if e["graph"] is not None:
       e["graph"].replay()
       self.replays += 1
