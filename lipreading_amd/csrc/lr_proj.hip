@@ -80,6 +80,65 @@ __global__ void log_softmax_bwd_rows_kernel(const float* __restrict__ g, const f
   }
 }
 
+// The whole forward head in ONE launch (K % 16 == 0): log_probs[r,:] = log_softmax(hidden[r,:] W^T + bias +
+// log(mask + 1e-45)).  The product is tiny (2400 x 65 x 512 at the bench shape) and the unfused chain — folded-bias
+// kernel, split-K GEMM, combine pass, row log-softmax — is four launches of ~5-10 us each, which is what it costs.
+// A workgroup owns 16 rows; wave w owns classes [16w, 16w + 16) (ceil(C / 16) waves, C <= 256) and runs the exact-
+// fp32 v_mfma_f32_16x16x4_f32 over all of K: a lane's float4 of hidden[row][k0 + 4q ..] / W[class][k0 + 4q ..]
+// (q = lane / 16) feeds four MFMAs, which contract k in the order k0 + 4q + j — the same permutation on both
+// operands.  The 16 x C logits meet in LDS, where sixteen lanes per row reduce max and sum.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(1024) void proj_logsoftmax_fused_kernel(const float* __restrict__ hidden,
+                                                                     const float* __restrict__ W,
+                                                                     const float* __restrict__ bias,
+                                                                     const float* __restrict__ mask,
+                                                                     float* __restrict__ log_probs, int R, int K,
+                                                                     int C) {
+  __shared__ float logits[16][kMaxClasses + 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int row = lane & 15, q = lane >> 4;
+  const int r0 = blockIdx.x * 16;
+  const int rr = min(r0 + row, R - 1);               // rows past the end compute a copy of the last row (never stored)
+  const int cls = min(16 * wave + row, C - 1);       // classes past C likewise
+  const float4* ap = reinterpret_cast<const float4*>(hidden + (int64_t)rr * K) + q;
+  const float4* bp = reinterpret_cast<const float4*>(W + (int64_t)cls * K) + q;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int steps = K / 16;
+  float4 a = ap[0], b = bp[0];
+  for (int s = 0; s < steps; ++s) {
+    const float4 an = s + 1 < steps ? ap[(s + 1) * 4] : a, bn = s + 1 < steps ? bp[(s + 1) * 4] : b;
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    a = an;
+    b = bn;
+  }
+  // D layout: lane holds rows 4q .. 4q + 3 of column (class) 16 wave + (lane & 15)
+  {
+    const int c = 16 * wave + row;
+    const float add = c < C ? bias[c] + logf(mask[c] + 1e-45f) : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) logits[4 * q + i][c] = acc[i] + add;
+  }
+  __syncthreads();
+  // sixteen lanes per row, four rows per wave and pass
+  for (int rl = wave * 4 + q; rl < 16; rl += nw * 4) {
+    const int r = r0 + rl;
+    float m = LR_NEG_INF;
+    for (int c = row; c < C; c += 16) m = fmaxf(m, logits[rl][c]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float sum = 0.f;
+    for (int c = row; c < C; c += 16) sum += expf(logits[rl][c] - m);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float lse = m + logf(sum);
+    if (r < R)
+      for (int c = row; c < C; c += 16) log_probs[(int64_t)r * C + c] = logits[rl][c] - lse;
+  }
+}
+
 // out[c] = fixed-order sum of the LR_COLSUM_SPLITS partial column sums (lr_colsum_partial).
 __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int C,
                                     int accumulate) {
@@ -116,6 +175,12 @@ extern "C" int lr_proj_logsoftmax_forward(const float* hidden, const float* W, c
   if (C > kMaxClasses) return LR_ERR_UNSUPPORTED;
   if (workspace_bytes < lr_proj_workspace_bytes(R, K, C)) return LR_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
+  if (K % 16 == 0 && ((reinterpret_cast<uintptr_t>(hidden) | reinterpret_cast<uintptr_t>(W)) & 15) == 0) {
+    const int nw = (C + 15) / 16;
+    LR_LAUNCH(proj_logsoftmax_fused_kernel, dim3((R + 15) / 16), dim3(64 * nw), 0, stream, hidden, W, bias, mask,
+              log_probs, R, K, C);
+    return lr_launch_status();
+  }
   float* mb = (float*)workspace;  // [C] bias + log(mask + 1e-45)
   char* gws = (char*)workspace + proj_head_bytes(C);
   const size_t gws_bytes = workspace_bytes - proj_head_bytes(C);

@@ -127,8 +127,10 @@ __device__ __forceinline__ void pair_of(int block, int& pair, int& member) {
 // kernel consumes them: out[((((d*2 + m)*4 + wave)*FNT + tl)*FF + f)*64 + lane] (8 bf16 = plane f & 1 of
 // W_hh[gate*256 + unit][k .. k+7], gate = tl >> 1, unit = 128m + 32 wave + 16 (tl & 1) + col, k = the
 // member-local k step f >> 1 (own half first) + 8 kg; lane = kg*16 + col).
+// (also clears the first launch's exchange buffer, `nzero` granules: one launch less than a memset node beside it)
 __global__ void gru256_pair_pack_whh_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
-                                            bf16x8* __restrict__ out, int D) {
+                                            bf16x8* __restrict__ out, int D, u64* __restrict__ xch, int nzero) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += gridDim.x * blockDim.x) xch[i] = 0;
   const int total = D * 2 * 4 * FNT * FF * 64;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int lane = i & 63, f = (i >> 6) % FF, tl = (i / (64 * FF)) % FNT, wave = (i / (64 * FF * FNT)) & 3;
@@ -357,7 +359,8 @@ constexpr size_t BWD_LDS = (size_t)2 * 2 * BGLD * 2 + 16 + (size_t)HALF * 4;
 // out[((((d*2 + m)*4 + wave)*BNT + nt)*BF + f)*64 + lane]: plane f & 1 of W_hh[kappa + e][j], j = 128m + 32 wave +
 // 16 nt + col, kappa = local k step f >> 1 -> (gate = (ks % 12) / 4, unit k = 128 (own ? m : 1-m) + 32 (ks % 4) + 8 kg)
 __global__ void gru256_pair_pack_whh_t_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
-                                              bf16x8* __restrict__ out, int D) {
+                                              bf16x8* __restrict__ out, int D, u64* __restrict__ xch, int nzero) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += gridDim.x * blockDim.x) xch[i] = 0;
   const int total = D * 2 * 4 * BNT * BF * 64;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int lane = i & 63, f = (i >> 6) % BF, nt = (i / (64 * BF)) & 1, wave = (i / (64 * BF * 2)) & 3;
@@ -615,13 +618,18 @@ int lr_gru256_pair_forward(float* gates, float* extra, float* y, const float* co
       return LR_ERR_LAUNCH;
     attr_set = true;
   }
-  LR_LAUNCH(gru256_pair_pack_whh_kernel, dim3(192), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D);
+  const int chunk = MAX_PAIRS / D;   // samples per launch
+  {
+    const int np0 = (B < chunk ? B : chunk) * D;   // the pack kernel clears the first launch's exchange buffer
+    LR_LAUNCH(gru256_pair_pack_whh_kernel, dim3(192), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D,
+              (u64*)xch, 2 * np0 * 2 * HALF + np0 * 2);
+  }
   int st = lr_launch_status();
   if (st != LR_OK) return st;
-  const int chunk = MAX_PAIRS / D;   // samples per launch
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int nb = B - b0 < chunk ? B - b0 : chunk, npairs = nb * D;
-    if (hipMemsetAsync(xch, 0, ((size_t)2 * npairs * 2 * HALF + (size_t)npairs * 2) * sizeof(u64), stream) != hipSuccess)
+    if (b0 > 0 &&
+        hipMemsetAsync(xch, 0, ((size_t)2 * npairs * 2 * HALF + (size_t)npairs * 2) * sizeof(u64), stream) != hipSuccess)
       return LR_ERR_LAUNCH;
     const dim3 grid(16 * ((npairs + 7) / 8));
     hipEvent_t e0, e1;
@@ -648,13 +656,18 @@ int lr_gru256_pair_backward(const float* gates, const float* extra, const float*
       return LR_ERR_LAUNCH;
     attr_set = true;
   }
-  LR_LAUNCH(gru256_pair_pack_whh_t_kernel, dim3(192), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D);
+  const int chunk = MAX_PAIRS / D;
+  {
+    const int np0 = (B < chunk ? B : chunk) * D;
+    LR_LAUNCH(gru256_pair_pack_whh_t_kernel, dim3(192), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D,
+              (u64*)xch, 2 * np0 * 2 * BOWN + np0 * 2);
+  }
   int st = lr_launch_status();
   if (st != LR_OK) return st;
-  const int chunk = MAX_PAIRS / D;
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int nb = B - b0 < chunk ? B - b0 : chunk, npairs = nb * D;
-    if (hipMemsetAsync(xch, 0, ((size_t)2 * npairs * 2 * BOWN + (size_t)npairs * 2) * sizeof(u64), stream) != hipSuccess)
+    if (b0 > 0 &&
+        hipMemsetAsync(xch, 0, ((size_t)2 * npairs * 2 * BOWN + (size_t)npairs * 2) * sizeof(u64), stream) != hipSuccess)
       return LR_ERR_LAUNCH;
     const dim3 grid(16 * ((npairs + 7) / 8));
     hipEvent_t e0, e1;

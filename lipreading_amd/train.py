@@ -75,6 +75,19 @@ def decoder_nll(log_probs, labels, pad):
   return nll / (labels != pad).sum()
 
 
+_ONES = {}
+
+
+def _one(device):
+  """A cached scalar 1 on `device`: the root gradient of loss.backward() (autograd otherwise fills a fresh
+  ones_like tensor every step — one more launch)."""
+  key = (device.type, device.index)
+  t = _ONES.get(key)
+  if t is None:
+    t = _ONES[key] = torch.ones((), dtype=torch.float32, device=device)
+  return t
+
+
 class StepGraphs(object):
   """hipGraph capture of the optimisation step, cached per batch shape.
 
@@ -178,7 +191,7 @@ def ctc_step(encoder, opt, frames, frame_lens, chars, char_lens, grad_norm=None,
       loss, status, _ = ctc_loss_prepared(log_probs, labels_p1, frame_lens32, label_lens32, 'mean')
     else:
       loss, status, _ = ctc_loss_with_status(log_probs, chars[:, 1:], frame_lens, char_lens - 1, 'mean')
-    loss.backward()
+    loss.backward(_one(loss.device))
     if whole:
       opt.step(grad_norm=grad_norm, grad_scale=1.0, skip=status)
     return loss.detach(), status
@@ -227,7 +240,7 @@ def decoder_step(encoder, decoding_step, opts, frames, frame_lens, chars, char_l
     log_probs_d, _, _ = decoding_step.decode_sequence(chars[:, :L], state, frame_lens_d, hidden,
                                                       teacher_forced=flags, seed=seed)
     decoder_loss = decoder_nll(log_probs_d, labels, pad)
-    (decoder_loss + total).backward()
+    (decoder_loss + total).backward(_one(decoder_loss.device))
     if whole:
       for o in opts:
         o.step(grad_norm=grad_norm, grad_scale=1.0, skip=status)
