@@ -102,18 +102,45 @@ __global__ __launch_bounds__(1024) void proj_logsoftmax_fused_kernel(const float
   const int cls = min(16 * wave + row, C - 1);       // classes past C likewise
   const float4* ap = reinterpret_cast<const float4*>(hidden + (int64_t)rr * K) + q;
   const float4* bp = reinterpret_cast<const float4*>(W + (int64_t)cls * K) + q;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // two accumulators (even / odd float4 of a group: dependent MFMAs are 4 issues apart), groups of four float4
+  // per operand with the NEXT group's eight loads in flight behind the current group's sixteen MFMAs (a single
+  // load ahead left every step waiting out an L2 round trip: 50 us at K = 1536)
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const int steps = K / 16;
-  float4 a = ap[0], b = bp[0];
-  for (int s = 0; s < steps; ++s) {
-    const float4 an = s + 1 < steps ? ap[(s + 1) * 4] : a, bn = s + 1 < steps ? bp[(s + 1) * 4] : b;
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
-    a = an;
-    b = bn;
+  constexpr int GR = 4;
+  float4 a[GR], b[GR], an[GR], bn[GR];
+#pragma unroll
+  for (int i = 0; i < GR; ++i) {
+    const int s = i < steps ? i : steps - 1;
+    a[i] = ap[s * 4];
+    b[i] = bp[s * 4];
   }
+  for (int s0 = 0; s0 < steps; s0 += GR) {
+#pragma unroll
+    for (int i = 0; i < GR; ++i) {
+      const int s = s0 + GR + i < steps ? s0 + GR + i : steps - 1;
+      an[i] = ap[s * 4];
+      bn[i] = bp[s * 4];
+    }
+#pragma unroll
+    for (int i = 0; i < GR; ++i) {
+      if (s0 + i < steps) {   // workgroup-uniform
+        f32x4& acc = (i & 1) ? acc1 : acc0;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[i].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[i].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[i].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[i].w, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < GR; ++i) {
+      a[i] = an[i];
+      b[i] = bn[i];
+    }
+  }
+  f32x4 acc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = acc0[i] + acc1[i];
   // D layout: lane holds rows 4q .. 4q + 3 of column (class) 16 wave + (lane & 15)
   {
     const int c = 16 * wave + row;

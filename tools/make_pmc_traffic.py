@@ -19,6 +19,7 @@ PIXELS = {  # bench.py's conv names -> a substring of the kernel symbol
 RECURRENT = {"rnn_fwd_step_kernel": "rnn_fwd_step_kernel", "rnn_bwd_step_kernel": "rnn_bwd_step_kernel",
              "gru256_fwd_pair_kernel": "gru256_fwd_pair_kernel", "gru256_bwd_pair_kernel": "gru256_bwd_pair_kernel",
              "lstm768_fwd_cluster_kernel": "lstm768_fwd_cluster_kernel",
+             "lstm768_bwd_cluster_kernel": "lstm768_bwd_cluster_kernel",
              "gru256_fwd_persist_kernel": "gru256_fwd_persist_kernel", "gru256_bwd_persist_kernel": "gru256_bwd_persist_kernel"}
 
 

@@ -7,6 +7,7 @@
 #   <round>_{pixels,gru256,lstm768,landmarks_attn,pixels_tfm}_kernel_stats.txt   rocprofv3 --kernel-trace --stats per kernel
 #   <round>_{pixels,gru256,lstm768}_pmc_{FETCH,WRITE}_SIZE.txt       HBM/fabric bytes per launch (separate --pmc passes)
 #   <round>_pixels_pmc_SQ_pass{1,2}.txt   matrix-pipe / LDS counters of the conv, recurrence and xgemm kernels
+#   <round>_{pixels,gru256}_step_timeline.txt   every dispatch of one replayed step with start offset and queue
 # PMC passes never share a run with trace domains other than the kernel trace rocprofv3 adds itself.
 set -u
 R=$PWD
@@ -32,6 +33,16 @@ kt gru256 --regime landmarks --model gru256
 kt lstm768 --regime landmarks --model lstm768
 kt landmarks_attn --regime landmarks_attn
 kt pixels_tfm --regime pixels_tfm
+
+tl() {   # name, anchor kernel, bench args...: one graph-replay step of the timed region as a timeline
+  local name=$1 anchor=$2; shift 2
+  (cd /tmp && rocprofv3 --kernel-trace -d "$OUT/tl_$name" -o kt -- \
+     python "$R/bench.py" "$@" --steps 8 --warmup 2 --repeats 1 --no-cpu-baseline > /dev/null 2>&1)
+  python tools/rocpd_timeline.py "$(find "$OUT/tl_$name" -name '*.db' | head -1)" "$anchor" 8 > "$OUT/${TAG}_${name}_step_timeline.txt"
+  rm -rf "$OUT/tl_$name"
+}
+tl pixels conv1_fwd --regime pixels
+tl gru256 ctc_prepare --regime landmarks --model gru256
 
 pmc() {   # name, counter list, filters..., -- bench args
   local name=$1 counters=$2 suffix=$3; shift 3
