@@ -390,10 +390,22 @@ int lr_sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, cons
 // [K][M], B_i stored [K][N] with the optional row remap of lr_sgemm): one GEMM launch + one combine for all of
 // them.  workspace: lr_sgemm_grouped_workspace_bytes of the same problem list.
 namespace {
+// tile edge of a group: 128 when the group is large enough to fill the chip with 128 x 128 tiles (the LSTM-768
+// layer: 1536 tiles of 64 x 64 — a 128-tile moves half the operand bytes per flop through LDS), else 64
+int group_tile(int n, const int* M, const int* N) {
+  long t128 = 0;
+  for (int i = 0; i < n; ++i) {
+    if (M[i] % 128 != 0 || N[i] < 128) return 64;
+    t128 += (long)(M[i] / 128) * ((N[i] + 127) / 128);
+  }
+  return t128 >= 256 ? 128 : 64;
+}
 int plan_group(int n, const int* M, const int* N, const int* K, int* splits, int* k_chunk) {
+  const int T = group_tile(n, M, N);
   long tiles = 0;
-  for (int i = 0; i < n; ++i) tiles += (long)((M[i] + 63) / 64) * ((N[i] + 63) / 64);
-  long want = tiles > 0 ? (768 + tiles - 1) / tiles : 1;   // ~3 workgroups per CU over the whole group
+  for (int i = 0; i < n; ++i) tiles += (long)((M[i] + T - 1) / T) * ((N[i] + T - 1) / T);
+  const long slots = T == 128 ? 512 : 768;                 // ~2 (128-tiles) / ~3 (64-tiles) workgroups per CU
+  long want = tiles > 0 ? (slots + tiles - 1) / tiles : 1;
   for (int i = 0; i < n; ++i) {
     long sp = want, max_split = K[i] / (2 * BK);
     if (sp > max_split) sp = max_split;
@@ -430,6 +442,7 @@ int lr_sgemm_grouped_tn_impl(int n, const int* M, const int* N, const int* K, co
   plan_group(n, M, N, K, splits, chunk);
   GroupArgs ga;
   ga.n = n;
+  const int T = group_tile(n, M, N);
   int blocks = 0;
   int64_t biggest = 0;
   float* slab = (float*)workspace;
@@ -441,8 +454,8 @@ int lr_sgemm_grouped_tn_impl(int n, const int* M, const int* N, const int* K, co
     it.beta = beta;
     it.row_shift = row_shift ? row_shift[i] : 0;
     it.period = period ? period[i] : 0;
-    it.tiles_n = (N[i] + 63) / 64;
-    it.tiles = it.tiles_n * ((M[i] + 63) / 64);
+    it.tiles_n = (N[i] + T - 1) / T;
+    it.tiles = it.tiles_n * ((M[i] + T - 1) / T);
     it.splits = splits[i];
     it.k_chunk = chunk[i];
     it.block_begin = blocks;
@@ -454,7 +467,8 @@ int lr_sgemm_grouped_tn_impl(int n, const int* M, const int* N, const int* K, co
   }
   for (int i = n; i < kMaxGroup; ++i) ga.it[i] = ga.it[0];
   lr_clear_error();
-  hipLaunchKernelGGL((sgemm_grouped_kernel<64, 64, true, false>), dim3(blocks), dim3(256), 0, stream, ga);
+  if (T == 128) hipLaunchKernelGGL((sgemm_grouped_kernel<128, 128, true, false>), dim3(blocks), dim3(256), 0, stream, ga);
+  else hipLaunchKernelGGL((sgemm_grouped_kernel<64, 64, true, false>), dim3(blocks), dim3(256), 0, stream, ga);
   int st = lr_launch_status();
   if (st != LR_OK) return st;
   if (biggest == 0) return LR_OK;   // nothing was split
@@ -487,8 +501,15 @@ int lr_sgemm_batched2_impl(int transA, int transB, int M, int N, int K, float al
   g.k_chunk = (K + BK - 1) / BK * BK;
   if (g.k_chunk < BK) g.k_chunk = BK;
   g.slabs = nullptr;
-  dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
-  launch_tile<64, 64>(transA, transB, g, grid, stream);
+  // 128 x 128 tiles when they alone fill the chip (the LSTM-768 input projection: 2 x 19 x 24 of them), else 64 x 64
+  const long big = (long)((N + 127) / 128) * ((M + 127) / 128) * (batch > 1 ? batch : 1);
+  if (big >= 512) {
+    dim3 grid((N + 127) / 128, (M + 127) / 128, batch);
+    launch_tile<128, 128>(transA, transB, g, grid, stream);
+  } else {
+    dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
+    launch_tile<64, 64>(transA, transB, g, grid, stream);
+  }
   return lr_launch_status();
 }
 
