@@ -239,3 +239,29 @@ def test_collate_matches_oracle(dev):
   np.testing.assert_array_equal(f.cpu().numpy(), rf.numpy())
   np.testing.assert_array_equal(c.cpu().numpy(), rc.numpy())
   assert fl.tolist() == rfl.tolist() and cl.tolist() == rcl.tolist()
+
+
+def test_ctc_prepare_equals_the_reference_label_plumbing(dev):
+  """lr_ctc_prepare_i64 (one launch) against the reference's own expressions: labels = chars[:, 1:] and
+  label_lens = char_lens - 1 (train_better_model.py:31-32), then int32 integers with labels moved up by one
+  (ctc_loss.py:42,80) — bit-exact, on a non-contiguous `chars` view too; and the loss through the prepared
+  inputs equals the loss through the converting path."""
+  from lipreading_amd.ctc import ctc_loss_prepared, ctc_loss_with_status, prepare_ctc_inputs
+  g = torch.Generator().manual_seed(12)
+  B, Lc, T, C = 7, 9, 20, 65
+  wide = torch.randint(0, 64, (B, Lc + 3), generator=g)
+  chars = wide[:, :Lc].to(dev)                      # row stride Lc + 3: a view, as collate may hand over
+  frame_lens = torch.sort(torch.randint(12, T + 1, (B,), generator=g))[0].to(dev)
+  char_lens = torch.randint(3, Lc + 1, (B,), generator=g).to(dev)
+  lab, fl, ll = prepare_ctc_inputs(chars, frame_lens, char_lens)
+  assert lab.dtype == fl.dtype == ll.dtype == torch.int32
+  assert torch.equal(lab.cpu(), (chars[:, 1:].cpu() + 1).to(torch.int32))
+  assert torch.equal(fl.cpu(), frame_lens.cpu().to(torch.int32))
+  assert torch.equal(ll.cpu(), (char_lens.cpu() - 1).to(torch.int32))
+  lp = torch.log_softmax(torch.randn(B, T, C, generator=g), dim=-1).to(dev).requires_grad_(True)
+  a, sa, _ = ctc_loss_prepared(lp, lab, fl, ll, 'mean')
+  b, sb, _ = ctc_loss_with_status(lp, chars[:, 1:], frame_lens, char_lens - 1, 'mean')
+  assert int(sa) == int(sb) and float(a.detach()) == float(b.detach())
+  ga, = torch.autograd.grad(a, lp)
+  gb, = torch.autograd.grad(b, lp)
+  assert torch.equal(ga, gb)

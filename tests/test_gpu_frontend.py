@@ -382,3 +382,37 @@ def test_pixel_step_at_the_sharded_batch_shapes(dev, B):
     losses.append(float(loss))
   assert np.isfinite(losses).all() and losses[1] < losses[0], losses
   assert float((flat.data - before).abs().max()) > 0
+
+
+def test_packing_every_weight_operand_in_one_launch_equals_packing_them_one_by_one(dev):
+  """lr_conv3d_pack_weights_multi (what the frontend's forward launches once per step: the forward operand of
+  each layer and the data-gradient operands of layers 2, 3) against lr_conv3d_pack_weights item by item:
+  bit-identical bf16 operands, fragment-major orders included."""
+  import ctypes
+  from lipreading_amd import _C
+  from lipreading_amd.frontend import LAYERS, _pack_weights, _pad4
+  L = _C.lib()
+  st = _C.stream_handle()
+  g = torch.Generator().manual_seed(21)
+  packs, singles = [], []
+  h = w = 96
+  for li, (cin, cout, (kt, kh, kw), stride, (pt, ph, pw)) in enumerate(LAYERS):
+    cin_p = _pad4(cin)
+    weight = torch.randn(cout, cin, kt, kh, kw, generator=g).to(dev)
+    ho, wo = (h + 2 * ph - kh) // stride + 1, (w + 2 * pw - kw) // stride + 1
+    flags = [L.lr_conv3d_patch_supported(h, w, cin_p, cout, kt, kh, kw, stride, pt, ph, pw)]
+    if li > 0:
+      flags.append(1 | L.lr_conv3d_patch_supported(ho, wo, cout, cin, kt, kh, kw, 1, pt, ph, pw))
+    for f in flags:
+      shape = (cin, kt * kh * kw, cout) if f & 1 else (cout, kt * kh * kw, cin_p)
+      a = torch.zeros(shape, dtype=torch.bfloat16, device=dev)
+      b = torch.zeros(shape, dtype=torch.bfloat16, device=dev)
+      packs.append((weight, a, cout, cin, cin_p, kt, kh, kw, f))
+      _C.check(L.lr_conv3d_pack_weights(weight.data_ptr(), b.data_ptr(), cout, cin, cin_p, kt, kh, kw, f, st), "single")
+      singles.append(b)
+    h, w = ho // 2, wo // 2
+  assert len(packs) == 5
+  _pack_weights(L, packs, st)
+  torch.cuda.synchronize()
+  for p, b in zip(packs, singles):
+    assert torch.equal(p[1].view(torch.int16), b.view(torch.int16))

@@ -327,3 +327,56 @@ def test_step_graphs_replay_is_bit_identical_to_eager(dev, with_decoder):
   assert torch.equal(results[0][1], results[1][1])
   if with_decoder:
     assert torch.equal(results[0][2], results[1][2])
+
+
+def test_ctc_step_without_final_states_and_with_staged_inputs_is_the_same_step(dev):
+  """ctc_step asks the encoder for no final states (need_final_state=False: h_n == NULL in the C ABI) and a
+  caller may stage its batches straight into the graph's input buffers (StepGraphs.staging_buffers): the
+  encoder returns bit-identical log-probs and hidden states without the final states, and the weights after
+  four steps on staged inputs equal those of four steps whose inputs were copied into the graph's buffers."""
+  from lipreading_amd import train as T
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.optim import FlatParameters, FusedAdam
+  c2i = default_char2idx()
+  g = torch.Generator().manual_seed(14)
+  B, Tm, Cm = 6, 18, 8
+  lens = torch.sort(torch.randint(Tm // 2, Tm + 1, (B,), generator=g))[0]
+  lens[-1] = Tm
+  frames = torch.randn(B, Tm, 68, 3, generator=g).to(dev)
+  cl = torch.full((B,), Cm, dtype=torch.long)
+  chars = torch.randint(4, 64, (B, Cm), generator=g)
+  chars[:, 0], chars[:, -1] = 1, 2
+  lens_d, chars_d, cl_d = lens.to(dev), chars.to(dev), cl.to(dev)
+
+  def fresh():
+    torch.manual_seed(3)
+    enc = VideoEncoder(204, 16, rnn_type='LSTM', num_layers=2, bidirectional=True, enable_ctc=True,
+                       vocab_size=64, char2idx=c2i).to(dev)
+    flat = FlatParameters(enc)
+    return enc, flat, FusedAdam(flat, lr=1e-3)
+
+  enc, flat, opt = fresh()
+  with torch.no_grad():
+    lp1, hid1, fin1 = enc(frames, lens_d, max_len=Tm)
+    lp0, hid0, fin0 = enc(frames, lens_d, max_len=Tm, need_final_state=False)
+  assert fin0 is None and fin1 is not None and torch.equal(lp0, lp1) and torch.equal(hid0, hid1)
+  graphs = T.StepGraphs()
+  for _ in range(4):
+    T.ctc_step(enc, opt, frames, lens_d, chars_d, cl_d, grad_norm=5.0, max_len=Tm, graphs=graphs)
+  ref = flat.data.clone()
+
+  enc, flat, opt = fresh()
+  graphs = T.StepGraphs()
+  assert graphs.staging_buffers() is None
+  ins = (frames, lens_d, chars_d, cl_d)
+  for i in range(4):
+    T.ctc_step(enc, opt, *ins, grad_norm=5.0, max_len=Tm, graphs=graphs)
+    if i == 0:   # from now on the batch lives in the graph's own input buffers
+      st = graphs.staging_buffers()
+      for dst, src in zip(st, ins):
+        dst.copy_(src)
+      ins = st
+  torch.cuda.synchronize()
+  assert graphs.captures == 1 and graphs.replays >= 1
+  assert torch.equal(flat.data, ref)
