@@ -18,6 +18,7 @@ accumulation, fused bias+ReLU.  There is NO reference parity for this stage; the
 conv3d/max_pool3d on the CPU (oracle/torch_oracle.py conv_frontend).
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -44,6 +45,20 @@ def _pad4(c):
 
 def feature_dim(H, W):
   return 96 * (H // 16) * (W // 16)
+
+
+# layers 2 and 3: weight gradient on a side stream beside the data gradient (LIPREADING_CONV_WGRAD_SIDE=0 keeps
+# everything on one stream): the two kernels of a layer leave each other's tails and load phases less idle
+# (pixel step 2.77 -> 2.71 ms)
+_WGRAD_SIDE_STREAM = os.environ.get("LIPREADING_CONV_WGRAD_SIDE", "1") == "1"
+_conv_side = None
+
+
+def _conv_side_stream(device):
+  global _conv_side
+  if _conv_side is None or _conv_side.device != device:
+    _conv_side = torch.cuda.Stream(device=device)
+  return _conv_side
 
 
 def _pack_weights(L, packs, st):
@@ -162,6 +177,7 @@ class _ConvFrontendFunction(torch.autograd.Function):
     for (_, _, (kt, kh, kw), stride, (pt, ph, pw)) in LAYERS:
       h, w = sizes[-1]
       sizes.append((((h + 2 * ph - kh) // stride + 1) // 2, ((w + 2 * pw - kw) // stride + 1) // 2))
+    side_keep = []
     for li in (2, 1, 0):
       cin, cout, (kt, kh, kw), stride, (pt, ph, pw) = LAYERS[li]
       cin_p = _pad4(cin)
@@ -188,10 +204,23 @@ class _ConvFrontendFunction(torch.autograd.Function):
         _C.check(L.lr_unpool_relu_mask_bf16(act.data_ptr(), dP.data_ptr(), dZ.data_ptr(),
                                             grads[2 * li + 1].data_ptr(), 1 if direct else 0, ws.data_ptr(), wbytes,
                                             frames, ho, wo, cout, st), "lr_unpool_relu_mask_bf16")
-      _C.check(L.lr_conv3d_wgrad(x_in.data_ptr(), dZ.data_ptr(), grads[2 * li].data_ptr(),
-                                 None, ws.data_ptr(), wbytes, 1 if direct else 0,
-                                 B, T, h, w, cin_p, cin, cout, kt, kh, kw, stride, pt, ph, pw, st),
-               "lr_conv3d_wgrad")
+      if _WGRAD_SIDE_STREAM and direct and li > 0:
+        # the weight gradient and the data gradient of a layer both read dZ and feed nothing to each other: the
+        # weight gradient goes to a side stream (joined at the end of this backward), the data gradient — which
+        # the layer below waits for — stays on this one
+        side = _conv_side_stream(dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+          _C.check(L.lr_conv3d_wgrad(x_in.data_ptr(), dZ.data_ptr(), grads[2 * li].data_ptr(),
+                                     None, ws.data_ptr(), wbytes, 1,
+                                     B, T, h, w, cin_p, cin, cout, kt, kh, kw, stride, pt, ph, pw, _C.stream_handle()),
+                   "lr_conv3d_wgrad")
+        side_keep.append((x_in, dZ, ws))
+      else:
+        _C.check(L.lr_conv3d_wgrad(x_in.data_ptr(), dZ.data_ptr(), grads[2 * li].data_ptr(),
+                                   None, ws.data_ptr(), wbytes, 1 if direct else 0,
+                                   B, T, h, w, cin_p, cin, cout, kt, kh, kw, stride, pt, ph, pw, st),
+                 "lr_conv3d_wgrad")
       if li > 0:
         # data gradient of a stride-1 "same" convolution = the forward kernel on dZ with the
         # flipped, channel-transposed weights
@@ -205,6 +234,9 @@ class _ConvFrontendFunction(torch.autograd.Function):
         dP = torch.empty((frames, h, w, cin), dtype=bf, device=dev)
         _C.check(L.lr_conv3d_forward(dZ.data_ptr(), wd.data_ptr(), None, dP.data_ptr(), B, T, ho, wo, cout,
                                      cin, kt, kh, kw, 1, pt, ph, pw, frag, st), "lr_conv3d_forward(dgrad)")
+    if side_keep:
+      torch.cuda.current_stream().wait_stream(_conv_side_stream(dev))
+      del side_keep[:]
     # the first recurrent layer's weight-gradient GEMMs ran on the side stream beside these kernels
     _enc.flush_deferred()
     if direct:
