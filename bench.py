@@ -469,7 +469,12 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
     fence()
     elapsed_all.append(time.perf_counter() - t0)
 
-  # roofline leg (after the timed region, same process, same tensors)
+  # roofline leg (after the timed region, same process, same tensors).  Per-kernel durations are taken with the conv
+  # backward on ONE stream: in the timed step a layer's weight gradient runs on a side stream beside its data
+  # gradient (frontend._WGRAD_SIDE_STREAM) — the two then share the chip and each one's duration says nothing about
+  # the kernel itself.
+  from lipreading_amd import frontend as _FE
+  _side_saved, _FE._WGRAD_SIDE_STREAM = _FE._WGRAD_SIDE_STREAM, False
   _C.check(L.lr_profile_enable(1), "lr_profile_enable")
   n_prof = min(args.steps, 20 if not pixels else 5)
   for _ in range(n_prof):    # eager launches of the same step (graph replays do not re-run the host code that records events)
@@ -480,6 +485,7 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
       step(graphs=None)
   torch.cuda.synchronize()
   L.lr_profile_enable(0)
+  _FE._WGRAD_SIDE_STREAM = _side_saved
   prof = {}
   for which, name in SLOTS.items():
     ms, n = ctypes.c_float(0), ctypes.c_int(0)
@@ -581,6 +587,9 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
                   "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                   "traffic_source": traffic_src,
                   "avg_launch_us": round(us, 1), "algorithmic_flops_per_launch": flops[dom],
+                  "note": "kernel durations of this block: eager steps with the conv backward on one stream (stand-alone "
+                          "kernels); the timed step runs each layer's weight gradient on a side stream beside its data "
+                          "gradient" if (_side_saved and not tfm) else None,
                   "avg_launch_us_by_kernel": by_kernel,
                   "tflops_by_kernel": {k: round(flops[k] / (v[0] * 1e-6) / 1e12, 1) for k, v in cand.items()}}
   else:

@@ -47,10 +47,13 @@ def feature_dim(H, W):
   return 96 * (H // 16) * (W // 16)
 
 
-# layers 2 and 3: weight gradient on a side stream beside the data gradient (LIPREADING_CONV_WGRAD_SIDE=0 keeps
-# everything on one stream): the two kernels of a layer leave each other's tails and load phases less idle
-# (pixel step 2.77 -> 2.71 ms)
-_WGRAD_SIDE_STREAM = os.environ.get("LIPREADING_CONV_WGRAD_SIDE", "1") == "1"
+# layers 2 and 3: weight gradient on a side stream beside the data gradient.  Measured (B=32, T=75): with the
+# recurrent encoder, whose first layer's weight-gradient GEMMs already run beside the conv backward on the encoder's
+# side stream, a third queue fills the gaps (pixel step 2.77 -> 2.71 ms); with the transformer encoder — two queues
+# only, the weight gradient and the data gradient of a layer simply sharing the chip — it costs 3 % (5.37 -> 5.54
+# ms).  So: on exactly when the encoder has deferred work in flight; LIPREADING_CONV_WGRAD_SIDE=0 / 1 forces it.
+_WGRAD_SIDE_ENV = os.environ.get("LIPREADING_CONV_WGRAD_SIDE", "auto")
+_WGRAD_SIDE_STREAM = _WGRAD_SIDE_ENV != "0"
 _conv_side = None
 
 
@@ -204,7 +207,7 @@ class _ConvFrontendFunction(torch.autograd.Function):
         _C.check(L.lr_unpool_relu_mask_bf16(act.data_ptr(), dP.data_ptr(), dZ.data_ptr(),
                                             grads[2 * li + 1].data_ptr(), 1 if direct else 0, ws.data_ptr(), wbytes,
                                             frames, ho, wo, cout, st), "lr_unpool_relu_mask_bf16")
-      if _WGRAD_SIDE_STREAM and direct and li > 0:
+      if _WGRAD_SIDE_STREAM and direct and li > 0 and (_WGRAD_SIDE_ENV == "1" or _enc._deferred):
         # the weight gradient and the data gradient of a layer both read dZ and feed nothing to each other: the
         # weight gradient goes to a side stream (joined at the end of this backward), the data gradient — which
         # the layer below waits for — stays on this one
