@@ -17,8 +17,10 @@
 //
 // The price is one exchange per step: a member needs the other member's 128 new state values (forward;
 // 384 gate gradients backward).  They travel as 8-byte {value, tag = step + 1} granules written with
-// ONE agent-scope store each and polled with agent-scope loads (MI355X_MICROARCH.md "handoff-1to1":
-// ~1 us idle, data-tagged granules need no fence); both members sit on the same XCD (blocks i and i + 8).
+// ONE store each and polled with agent-scope loads (MI355X_MICROARCH.md "handoff-1to1": ~1 us idle,
+// data-tagged granules need no fence); both members sit on the same XCD (blocks i and i + 8), verify it
+// (HW_REG_XCC_ID) and then store at workgroup scope, so the granule stays in that XCD's L2 (an agent-scope
+// store writes through and drops the line: forward 1.93 -> 1.74 us per step, backward 2.27 -> 2.11).
 // The k loop runs the member's OWN half first (its operands are local), so about a third of the
 // exchange latency hides behind MFMAs.  Two parity slots suffice: a producer overwrites slot s & 1 at
 // step s + 2 only after it consumed the partner's step-(s + 1) data, which the partner published
