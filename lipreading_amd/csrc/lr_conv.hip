@@ -1002,10 +1002,11 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_ts_kernel(ConvGeom g, const 
 // Same idea as conv_patch_kernel, shaped for 12x12 frames: a wave owns a whole frame as nine
 // 4x4-position row tiles of v_mfma_f32_16x16x32_bf16 (16 rows x 32 k: one MFMA consumes a whole
 // 32-channel group of a tap), a workgroup 4 consecutive frames; the 6 x 14 x 14-position patch of
-// one 32-channel group sits in LDS as rows of 14 positions x 64 B + 16 B of padding (P3_RS = 912 B: consecutive
-// rows are 9 sixteen-byte bank slots apart mod 16, so the 4 x 4 pixel block a 16-lane group of ds_read_b128
-// reads covers all 16 slots once for any tap shift); every fragment address of the kernel is then ONE lane
-// base + an immediate offset (< 64 KB), no per-read swizzle arithmetic.  Inputs
+// one 32-channel group sits in LDS as rows of 16 positions x 64 B (P3_RS = 1024 B, four bank lines; 14 used), chunk
+// c of a position stored at c ^ (2 * (row & 1)): with ds_read_b128's fixed lane groups (see conv_patch_kernel) the
+// 16 lanes of a group then hit 16 different 16-byte slots for every tap shift (exhaustive check), and a fragment
+// address is one of TWO lane bases (even / odd tap row; they differ in bit 5) + an immediate offset (< 64 KB) —
+// no per-read swizzle arithmetic.  Inputs
 // with 64 / 96 channels take 2 / 3 passes.  B fragments (16 output channels x 32 k) come from
 // global in the 16-column fragment-major packing.
 // A workgroup covers P3_TT = 2 consecutive frames with TWO waves per frame (each takes half of the
@@ -1013,9 +1014,9 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_ts_kernel(ConvGeom g, const 
 // workgroups share a CU: 8 waves per CU overlap each other's load phases and epilogues, and 1200
 // half-size tiles fill 256 CUs in 2.5 tile-times where 600 four-frame tiles took 3 (2.34 rounds).
 constexpr int P3_TT = 2, P3_NSPL = 4 / P3_TT, P3_H = 12, P3_W = 12, P3_PH = P3_H + 2, P3_PW = 16, P3_SLOTS = P3_TT + 2;
-constexpr int P3_RS = (P3_W + 2) * 64 + 16;        // bytes per patch row
+constexpr int P3_RS = P3_PW * 64;                  // bytes per patch row (16 positions, 14 used)
 constexpr int P3_ROWS = P3_SLOTS * P3_PH;          // 56 patch rows: one per wave and pass, 14 passes
-constexpr int P3_LDS = P3_ROWS * P3_RS;            // 51,072 bytes
+constexpr int P3_LDS = P3_ROWS * P3_RS;            // 57,344 bytes
 static_assert(P3_ROWS % 28 == 0, "patch rows are loaded in batches of 7 passes x 4 waves");
 
 template <int CG, int NT16, bool POOL>
@@ -1049,7 +1050,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __re
   // (h = 2(kg>>1) + {0,1}, w = 2(kg&1) + {0,1}) in scan order and the pooled epilogue is lane-local.
   // The 16 lanes ds_read_b128 serves together still cover the 4 x 4 block once, and same-column
   // lanes land on 4 different chunks for any tap shift.
-  const int base_b = (fw * P3_PH + ((rl >> 1) & 1) + 2 * (rl >> 3)) * P3_RS + ((rl & 1) + 2 * ((rl >> 2) & 1)) * 64 + kg * 16;
+  // lane base for EVEN tap rows dh (the patch row is slot*14 + pixel row + 4 (mb/3) + dh: its parity is that of
+  // pixel row + dh); odd tap rows use base_b ^ 32
+  const int prow = ((rl >> 1) & 1) + 2 * (rl >> 3);
+  const int base_b = (fw * P3_PH + prow) * P3_RS + ((rl & 1) + 2 * ((rl >> 2) & 1)) * 64 + ((kg ^ (2 * (prow & 1))) << 4);
   for (int cg = 0; cg < CG; ++cg) {
     if (cg > 0) __syncthreads();
     // patch load: a wave covers one 16-position patch row (64 sixteen-byte units) per pass, so the
@@ -1070,10 +1074,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __re
           if (tvalid && ff >= 0 && ff < F && hh >= 0 && hh < P3_H)
             v[i] = *reinterpret_cast<const uint4*>(xt + ((int64_t)ff * P3_H + hh) * (P3_W * C));
         }
-        if (pw < P3_W + 2) {   // 14 positions per row (lanes of positions 14, 15 idle)
 #pragma unroll
-          for (int i = 0; i < 7; ++i)
-            *reinterpret_cast<uint4*>(patch + (4 * (part * 7 + i) + wave) * P3_RS + pw * 64 + c * 16) = v[i];
+        for (int i = 0; i < 7; ++i) {
+          const int R = 4 * (part * 7 + i) + wave, ph = R % P3_PH;     // P3_PH is even: row parity = ph & 1
+          *reinterpret_cast<uint4*>(patch + R * P3_RS + pw * 64 + ((c ^ (2 * (ph & 1))) << 4)) = v[i];
         }
       }
     }
@@ -1097,9 +1101,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __re
           }
           if (valid) {
             const int to = (dt * P3_PH + dh) * P3_RS + dw * 64;
+            const int bb = base_b ^ ((dh & 1) << 5);
 #pragma unroll
             for (int mb = 0; mb < 9; ++mb) {
-              const bf16x8 a = *reinterpret_cast<const bf16x8*>(patch + base_b + (to + (4 * (mb / 3)) * P3_RS + 4 * (mb % 3) * 64));
+              const bf16x8 a = *reinterpret_cast<const bf16x8*>(patch + bb + (to + (4 * (mb / 3)) * P3_RS + 4 * (mb % 3) * 64));
 #pragma unroll
               for (int j = 0; j < NT16; ++j)
                 acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[j], acc[mb][j], 0, 0, 0);
@@ -1476,20 +1481,23 @@ __global__ void conv3d_pack_weights_multi_kernel(PackItems p) {
 // of 32 channels with the accumulators kept.
 //   Wave w owns output frame f0 + w: 6 MFMA row tiles of 8 rows x 4 columns x NT column tiles ->
 //   6*NT accumulators; taps reaching across a clip boundary are skipped (wave-uniform).
-//   LDS layout: patch row (slot*12 + row) starts at byte (slot*12 + row) * P2_RS, P2_RS = 28*64 + 16; position
-//   col of it holds its 32 channels as 4 chunks of 16 bytes in order.  The 16 bytes of padding per row shift
-//   consecutive rows by one 16-byte bank slot, so the 16 lanes that ds_read_b128 serves together (4 columns x 4
-//   rows of the 8 x 4 pixel block) hit 16 different slots — and, unlike an XOR swizzle, the address of a tap is
-//   lane base + a constant: the 60 fragment reads of a row of five taps share ONE address register and differ in
-//   the instruction's immediate offset only (the swizzle cost ~2 VALU operations per read, issue slots the one
-//   wave per SIMD needs for its MFMAs).
+//   LDS layout: patch row (slot*12 + row) starts at byte (slot*12 + row) * P2_RS, P2_RS = 28 * 64 (a multiple of the
+//   256-byte bank line); position col of it holds its 32 channels as 4 chunks of 16 bytes, chunk c stored at
+//   c ^ (row & 3).  ds_read_b128 serves a wave in four FIXED lane groups ({0-3, 12-15, 20-27}, {4-11, 16-19,
+//   28-31} and the same + 32): with the 8 x 4 pixel block below each group reads two columns of four rows whose
+//   indices are distinct mod 4, twice, so the row-only swizzle puts its 16 lanes on 16 different 16-byte slots
+//   for every tap shift (checked exhaustively).  Unlike round 1's swizzle on the position index, the column
+//   part of a tap shift is a plain byte offset: the reads of a row of five taps share TWO address registers (one
+//   per k chunk; they differ in bit 5) and the instruction's immediate does the rest.  (A padded row stride
+//   without swizzle — tried first — is 2-way conflicted for these lane groups whatever the padding:
+//   SQ_LDS_BANK_CONFLICT went from 0 to 83 % of the LDS cycles.)
 // (Measured and dropped, round 2: half-WIDTH tiles — 4 frames x 8 rows x 12 columns, 73 KB patch, 3 x NT
 // accumulators, TWO workgroups per CU so that one's MFMAs cover the other's patch fill and epilogue — are bit-
 // identical but 7 % (forward) / 19 % (data gradient) SLOWER: a weight fragment then feeds 3 MFMAs instead of 6
 // and the doubled fragment traffic from L1/L2 costs more than the overlap returns.)
 constexpr int P2_TT = 4, P2_TH = 8, P2_W = 24, P2_PW = P2_W + 4, P2_PH = P2_TH + 4, P2_SLOTS = P2_TT + 2;
-constexpr int P2_RS = P2_PW * 64 + 16;             // bytes per patch row: 28 positions x 64 B + 16 B of padding
-constexpr int P2_LDS = P2_SLOTS * P2_PH * P2_RS;   // 130,176 bytes
+constexpr int P2_RS = P2_PW * 64;                  // bytes per patch row: 28 positions x 64 B = 7 bank lines
+constexpr int P2_LDS = P2_SLOTS * P2_PH * P2_RS;   // 129,024 bytes
 constexpr int P2_BDIST = 2;                        // taps between a B fragment's load and its use
 
 template <int CG, int NT, bool POOL>
@@ -1533,7 +1541,7 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
   // slots of a 256-byte bank line: same-w lanes of a group sit on rows {0,1,6,7} or {2,3,4,5},
   // 3*row mod 4 all different.
   const int a_h = ((lr >> 1) & 1) + 2 * (lr >> 3), a_w = (lr & 1) + 2 * ((lr >> 2) & 1);
-  const int base_b = (wave * P2_PH + a_h) * P2_RS + a_w * 64 + kg * 16;   // byte offset of this lane's pixel, k chunk kg
+  const int base_b = (wave * P2_PH + a_h) * P2_RS + a_w * 64;   // byte offset of this lane's pixel (chunk bits added per tap row)
   for (int cg = 0; cg < CG; ++cg) {
     if (cg > 0) __syncthreads();   // every wave is done with the previous channel group's patch
     // ---- load the patch -------------------------------------------------------------------------
@@ -1562,7 +1570,7 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
 #pragma unroll
           for (int i = 0; i < 18; ++i) {
             const int k = half * 18 + i;
-            *reinterpret_cast<uint4*>(patch + (2 * k + rp) * P2_RS + pw * 64 + c * 16) = v[i];
+            *reinterpret_cast<uint4*>(patch + (2 * k + rp) * P2_RS + pw * 64 + ((c ^ ((2 * k + rp) & 3)) << 4)) = v[i];
           }
         }
       }
@@ -1587,12 +1595,14 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
           for (int j = 0; j < NT; ++j)
             bb[kc][j] = *reinterpret_cast<const bf16x8*>(wfb + ((int64_t)ii * 2 * NT + kc * NT + j) * 512);
       };
-      auto load_a = [&](bf16x8 (&aa)[6], int xb, int imm, int grp) {   // xb = lane base + row offset (bytes), imm = 64 dw
+      // xb = lane base + row offset + swizzled chunk of k chunk 0 (bytes; k chunk 1 is xb ^ 32), imm = 64 dw
+      auto load_a = [&](bf16x8 (&aa)[6], int xb, int imm, int grp) {
+        const int xb1 = xb ^ 32;
 #pragma unroll
         for (int w3 = 0; w3 < 3; ++w3)
 #pragma unroll
           for (int kc = 0; kc < 2; ++kc)
-            aa[w3 * 2 + kc] = *reinterpret_cast<const bf16x8*>(patch + xb + (imm + (3 * grp + w3) * 256 + kc * 32));
+            aa[w3 * 2 + kc] = *reinterpret_cast<const bf16x8*>(patch + (kc ? xb1 : xb) + (imm + (3 * grp + w3) * 256));
       };
       // k chunk outermost: consecutive MFMAs never share an accumulator (with NT = 1 the w3-outer order issued
       // the two k chunks of a tile back to back, each waiting for the other's result)
@@ -1606,9 +1616,12 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
               acc[3 * grp + w3][j] =
                   __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[w3 * 2 + kc], bb[kc][j], acc[3 * grp + w3][j], 0, 0, 0);
       };
-      auto row_off = [&](int r) {   // byte offset of row r's first tap: r = dt*5 + dh
+      // byte offset of tap row r (r = dt*5 + dh) + this lane's chunk of k chunk 0 in that patch row: the patch row
+      // is slot*12 + a_h + dh, so its swizzle key is (a_h + dh) & 3
+      auto row_off = [&](int r) {
         const int rr = row0 + (r < nrow ? r : nrow - 1);
-        return ((rr / 5) * P2_PH + rr % 5) * P2_RS;
+        const int dh = rr % 5;
+        return ((rr / 5) * P2_PH + dh) * P2_RS + ((kg ^ ((a_h + dh) & 3)) << 4);
       };
 #pragma unroll
       for (int d = 0; d < P2_BDIST; ++d) load_b(bq[d], d);
