@@ -59,7 +59,7 @@ constexpr int MAX_CLUSTERS = 8;    // per launch: 192 workgroups
 
 constexpr int CF = 2 * CKS;        // 48 fragments per column tile: f = 2 * local k step + plane
 constexpr int CF_A = 30;           // f < 30 in AGPRs (2 tiles x 30 = 60 fragments)
-constexpr int CF_REG = 38;         // f < 38 in registers (2 x 8 = 16 fragments in VGPRs); 38..47 in LDS (80 KB)
+constexpr int CF_REG = 44;         // f < 44 in registers (2 x 14 = 28 fragments in VGPRs); 44..47 in LDS (32 KB)
 constexpr size_t CFWD_LDS = (size_t)2 * 16 * CLD * 2 + (size_t)4 * 2 * (CF - CF_REG) * 1024 + (size_t)4 * 2 * 256 * 4;
 
 __device__ __forceinline__ bf16_t f2bf(float f) {
@@ -237,7 +237,11 @@ __global__ __launch_bounds__(256, 1) void lstm768_fwd_cluster_kernel(
     bf16_t* hnxt = hS + ((s + 1) & 1) * 16 * CLD;
     float sum[CG] = {0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
-      const u64* xp = xbase + ((s - 1) & 1) * xslot;
+      // (opaque slot offset: otherwise the 23 per-lane gather addresses of BOTH parity slots are hoisted out of the
+      // step loop and held in registers — the registers CF_REG wants for weight fragments)
+      int64_t slot_off = ((s - 1) & 1) * xslot;
+      asm volatile("" : "+s"(slot_off));
+      const u64* xp = xbase + slot_off;
       f32x4 acc0[2], acc1[2];     // hi / lo weight plane
       // ---- own member's k step (local q = 0): its operands are already in LDS ------------------------------------
       {
