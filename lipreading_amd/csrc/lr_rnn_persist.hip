@@ -39,7 +39,7 @@ typedef unsigned short bf16_t;
 constexpr int PH = 256;            // hidden size this kernel is built for
 constexpr int PKS = PH / 32;       // k steps of 32 (forward: k = previous state)
 constexpr int PKS_A = 5;           // k steps whose weight fragments live in AGPRs (12 x 5 x 4 = 240 of the 256)
-constexpr int PKS_REG = 7;         // k steps held in registers at all (AGPR + VGPR); the rest sit in LDS
+constexpr int PKS_REG = 8;         // k steps held in registers (AGPR + VGPR); any rest would sit in LDS (none: all 96 fragments fit)
 constexpr int PNT = 12;            // 16-unit column tiles per wave: 3 gates x 4
 constexpr int PHLD = PH + 8;       // bf16 per LDS row of the state (528 B: conflict-free b128 rows)
 constexpr int PBH = 1;             // samples per workgroup (rows >= PBH of the 16-row MFMA operand are zero)
