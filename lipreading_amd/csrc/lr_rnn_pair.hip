@@ -47,7 +47,7 @@ constexpr int FNT = 6;             // column tiles per wave: 3 gates x 2 (wave w
 constexpr int FKS = PH / 32;       // 8 k steps of 32; LOCAL k order: the member's own 128 units first
 constexpr int FF = 2 * FKS;        // fragments per tile: f = 2 * kstep + plane (0 = W_hi, 1 = W_lo)
 constexpr int FF_A = 10;           // f < 10 in AGPRs (6 x 10 = 60 fragments = 240 registers)
-constexpr int FF_REG = 14;         // f < 14 in registers (6 x 4 = 24 fragments in VGPRs); f = 14, 15 in LDS
+constexpr int FF_REG = 16;         // f < 16 in registers (6 x 6 = 36 fragments in VGPRs): all of them, none in LDS
 constexpr size_t FWD_LDS = (size_t)2 * 16 * PHLD * 2 + (size_t)4 * FNT * (FF - FF_REG) * 1024 + (size_t)3 * HALF * 4;
 
 __device__ __forceinline__ bf16_t f2bf(float f) {
