@@ -1002,11 +1002,12 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_ts_kernel(ConvGeom g, const 
 // Same idea as conv_patch_kernel, shaped for 12x12 frames: a wave owns a whole frame as nine
 // 4x4-position row tiles of v_mfma_f32_16x16x32_bf16 (16 rows x 32 k: one MFMA consumes a whole
 // 32-channel group of a tap), a workgroup 4 consecutive frames; the 6 x 14 x 14-position patch of
-// one 32-channel group sits in LDS as rows of 16 positions x 64 B (P3_RS = 1024 B, four bank lines; 14 used), chunk
-// c of a position stored at c ^ (2 * (row & 1)): with ds_read_b128's fixed lane groups (see conv_patch_kernel) the
-// 16 lanes of a group then hit 16 different 16-byte slots for every tap shift (exhaustive check), and a fragment
-// address is one of TWO lane bases (even / odd tap row; they differ in bit 5) + an immediate offset (< 64 KB) —
-// no per-read swizzle arithmetic.  Inputs
+// one 32-channel group sits in LDS as rows of 14 positions x 64 B + 16 B of padding (P3_RS = 912 B); every
+// fragment address of the kernel is then ONE lane base + an immediate offset (< 64 KB), no per-read swizzle
+// arithmetic.  With ds_read_b128's fixed lane groups ({0-3, 12-15, 20-27}, ...) this layout is 2-way bank
+// conflicted (no row padding avoids that); the conflict-free row swizzle c ^ (2 (row & 1)) on 1024-byte rows
+// was measured too and is SLOWER here (forward 85 -> 95 us: the LDS pipe is not what bounds this kernel, the
+// second address register and the larger patch are paid for nothing), so the padded rows stay.  Inputs
 // with 64 / 96 channels take 2 / 3 passes.  B fragments (16 output channels x 32 k) come from
 // global in the 16-column fragment-major packing.
 // A workgroup covers P3_TT = 2 consecutive frames with TWO waves per frame (each takes half of the
@@ -1014,9 +1015,9 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_ts_kernel(ConvGeom g, const 
 // workgroups share a CU: 8 waves per CU overlap each other's load phases and epilogues, and 1200
 // half-size tiles fill 256 CUs in 2.5 tile-times where 600 four-frame tiles took 3 (2.34 rounds).
 constexpr int P3_TT = 2, P3_NSPL = 4 / P3_TT, P3_H = 12, P3_W = 12, P3_PH = P3_H + 2, P3_PW = 16, P3_SLOTS = P3_TT + 2;
-constexpr int P3_RS = P3_PW * 64;                  // bytes per patch row (16 positions, 14 used)
+constexpr int P3_RS = (P3_W + 2) * 64 + 16;        // bytes per patch row
 constexpr int P3_ROWS = P3_SLOTS * P3_PH;          // 56 patch rows: one per wave and pass, 14 passes
-constexpr int P3_LDS = P3_ROWS * P3_RS;            // 57,344 bytes
+constexpr int P3_LDS = P3_ROWS * P3_RS;            // 51,072 bytes
 static_assert(P3_ROWS % 28 == 0, "patch rows are loaded in batches of 7 passes x 4 waves");
 
 template <int CG, int NT16, bool POOL>
@@ -1050,10 +1051,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __re
   // (h = 2(kg>>1) + {0,1}, w = 2(kg&1) + {0,1}) in scan order and the pooled epilogue is lane-local.
   // The 16 lanes ds_read_b128 serves together still cover the 4 x 4 block once, and same-column
   // lanes land on 4 different chunks for any tap shift.
-  // lane base for EVEN tap rows dh (the patch row is slot*14 + pixel row + 4 (mb/3) + dh: its parity is that of
-  // pixel row + dh); odd tap rows use base_b ^ 32
-  const int prow = ((rl >> 1) & 1) + 2 * (rl >> 3);
-  const int base_b = (fw * P3_PH + prow) * P3_RS + ((rl & 1) + 2 * ((rl >> 2) & 1)) * 64 + ((kg ^ (2 * (prow & 1))) << 4);
+  const int base_b = (fw * P3_PH + ((rl >> 1) & 1) + 2 * (rl >> 3)) * P3_RS + ((rl & 1) + 2 * ((rl >> 2) & 1)) * 64 + kg * 16;
   for (int cg = 0; cg < CG; ++cg) {
     if (cg > 0) __syncthreads();
     // patch load: a wave covers one 16-position patch row (64 sixteen-byte units) per pass, so the
@@ -1074,10 +1072,10 @@ __global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __re
           if (tvalid && ff >= 0 && ff < F && hh >= 0 && hh < P3_H)
             v[i] = *reinterpret_cast<const uint4*>(xt + ((int64_t)ff * P3_H + hh) * (P3_W * C));
         }
+        if (pw < P3_W + 2) {   // 14 positions per row (lanes of positions 14, 15 idle)
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-          const int R = 4 * (part * 7 + i) + wave, ph = R % P3_PH;     // P3_PH is even: row parity = ph & 1
-          *reinterpret_cast<uint4*>(patch + R * P3_RS + pw * 64 + ((c ^ (2 * (ph & 1))) << 4)) = v[i];
+          for (int i = 0; i < 7; ++i)
+            *reinterpret_cast<uint4*>(patch + (4 * (part * 7 + i) + wave) * P3_RS + pw * 64 + c * 16) = v[i];
         }
       }
     }
@@ -1101,10 +1099,9 @@ __global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __re
           }
           if (valid) {
             const int to = (dt * P3_PH + dh) * P3_RS + dw * 64;
-            const int bb = base_b ^ ((dh & 1) << 5);
 #pragma unroll
             for (int mb = 0; mb < 9; ++mb) {
-              const bf16x8 a = *reinterpret_cast<const bf16x8*>(patch + bb + (to + (4 * (mb / 3)) * P3_RS + 4 * (mb % 3) * 64));
+              const bf16x8 a = *reinterpret_cast<const bf16x8*>(patch + base_b + (to + (4 * (mb / 3)) * P3_RS + 4 * (mb % 3) * 64));
 #pragma unroll
               for (int j = 0; j < NT16; ++j)
                 acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[j], acc[mb][j], 0, 0, 0);
