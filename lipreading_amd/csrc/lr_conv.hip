@@ -1497,24 +1497,28 @@ constexpr int P2_RS = P2_PW * 64;                  // bytes per patch row: 28 po
 constexpr int P2_LDS = P2_SLOTS * P2_PH * P2_RS;   // 129,024 bytes
 constexpr int P2_BDIST = 2;                        // taps between a B fragment's load and its use
 
-template <int CG, int NT, bool POOL>
-__global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __restrict__ X,
-                                                            const bf16_t* __restrict__ Wf,
-                                                            const float* __restrict__ bias,
-                                                            bf16_t* __restrict__ Y, unsigned char* __restrict__ code,
-                                                            int F, int T, int H, int relu) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char patch[];
+constexpr int kChipCUs = 256;                      // one workgroup of this kernel per CU
+
+// One tile.  SPLIT = false: the 4-frame tile described above, wave w = frame f0 + w with all 6 x NT accumulators.
+// SPLIT = true (the launch's LAST tiles, see conv_patch_kernel): a tile of FT = 1 (NT = 2) or 2 (NT = 1) frames
+// whose accumulator tiles are dealt to the four waves — three row tiles x one column tile each — so that it takes
+// 1/4 (1/2) of a whole tile's time; same patch layout, same per-accumulator MFMA order (results are bit-identical).
+template <int CG, int NT, bool POOL, bool SPLIT>
+__device__ __forceinline__ void conv_patch_tile(unsigned char* __restrict__ patch, const bf16_t* __restrict__ X,
+                                                const bf16_t* __restrict__ Wf, const float* __restrict__ bias,
+                                                bf16_t* __restrict__ Y, unsigned char* __restrict__ code, int F, int T,
+                                                int H, int relu, int f0, int h0) {
   constexpr int C = 32 * CG, N = 32 * NT, TAPS = 75;
+  constexpr int FT = SPLIT ? (NT == 2 ? 1 : 2) : P2_TT;   // frames of this tile
+  constexpr int MTW = SPLIT ? 3 : 6, NTW = SPLIT ? 1 : NT;   // accumulator tiles of one wave: MTW x NTW
+  constexpr int NPASS = (FT + 2) * (P2_PH / 2);           // patch fill passes (two patch rows each)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int htiles = H / P2_TH;
-  // XCD-aware tile order: block b runs on XCD b % 8 (each XCD has its own L2), so XCD x takes a CONTIGUOUS run of
-  // tiles (h-tiles of a frame tile, then the next frame tile): the tiles resident together on an XCD are
-  // neighbours in time and height and find each other's halo rows in that XCD's L2 instead of re-fetching them.
-  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3, rem_xcd = gridDim.x & 7;
-  const int tile = xcd * per_xcd + (xcd < rem_xcd ? xcd : rem_xcd) + (int)(blockIdx.x >> 3);
-  const int f0 = (tile / htiles) * P2_TT, h0 = (tile % htiles) * P2_TH;
   const int lr = lane & 31, kg = lane >> 5;
-  const int f = f0 + wave;
+  // frame of the tile, first row tile (in threes) and column tile this wave computes
+  const int fi = !SPLIT ? wave : (NT == 2 ? 0 : wave >> 1);
+  const int g0 = !SPLIT ? 0 : (NT == 2 ? wave >> 1 : wave & 1);
+  const int j0 = !SPLIT ? 0 : (NT == 2 ? wave & 1 : 0);
+  const int f = f0 + fi;
   const bool fvalid = f < F;
   const int t = f % T;
   // temporal taps reaching across the clip boundary are skipped: this wave runs tap rows
@@ -1523,11 +1527,11 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
   const int row0 = 5 * dt_lo;
   const int nrow = fvalid ? 5 * (dt_hi - dt_lo + 1) : 0;
 
-  f32x16 acc[6][NT];
+  f32x16 acc[MTW][NTW];
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < MTW; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -1538,13 +1542,14 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
   // slots of a 256-byte bank line: same-w lanes of a group sit on rows {0,1,6,7} or {2,3,4,5},
   // 3*row mod 4 all different.
   const int a_h = ((lr >> 1) & 1) + 2 * (lr >> 3), a_w = (lr & 1) + 2 * ((lr >> 2) & 1);
-  const int base_b = (wave * P2_PH + a_h) * P2_RS + a_w * 64;   // byte offset of this lane's pixel (chunk bits added per tap row)
+  // byte offset of this lane's pixel in its first row tile (chunk bits added per tap row)
+  const int base_b = (fi * P2_PH + a_h) * P2_RS + a_w * 64 + g0 * (3 * 256);
   for (int cg = 0; cg < CG; ++cg) {
     if (cg > 0) __syncthreads();   // every wave is done with the previous channel group's patch
     // ---- load the patch -------------------------------------------------------------------------
     // 224 threads cover two patch rows (28 positions x 4 sixteen-byte chunks each) per pass, 36
     // passes: slot and row of a pass are compile-time, so a unit costs a handful of VALU operations
-    // (decoding a flat unit index cost ~60 and a third of the kernel's VALU work).  Two batches of 18
+    // (decoding a flat unit index cost ~60 and a third of the kernel's VALU work).  Batches of 18
     // loads, each issued completely before its first store.
     {
       const int rp = tid >= 112 ? 1 : 0, un = tid - 112 * rp;   // row of the pair, unit in the row
@@ -1552,22 +1557,25 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
       const bool tvalid = tid < 224 && pw >= 2 && pw < P2_W + 2;
       const bf16_t* xt = X + ((int64_t)(pw - 2)) * C + cg * 32 + c * 8;
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+      for (int half = 0; half < (NPASS + 17) / 18; ++half) {
         uint4 v[18];
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
           const int k = half * 18 + i;            // pass: patch rows 2k, 2k+1
-          const int s = k / 6, ph = 2 * (k % 6) + rp;
-          const int ff = f0 - 1 + s, hh = h0 - 2 + ph;
-          v[i] = make_uint4(0u, 0u, 0u, 0u);
-          if (tvalid && ff >= 0 && ff < F && hh >= 0 && hh < H)
-            v[i] = *reinterpret_cast<const uint4*>(xt + ((int64_t)ff * H + hh) * (P2_W * C));
+          if (k < NPASS) {
+            const int s = k / 6, ph = 2 * (k % 6) + rp;
+            const int ff = f0 - 1 + s, hh = h0 - 2 + ph;
+            v[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (tvalid && ff >= 0 && ff < F && hh >= 0 && hh < H)
+              v[i] = *reinterpret_cast<const uint4*>(xt + ((int64_t)ff * H + hh) * (P2_W * C));
+          }
         }
         if (tid < 224) {
 #pragma unroll
           for (int i = 0; i < 18; ++i) {
             const int k = half * 18 + i;
-            *reinterpret_cast<uint4*>(patch + (2 * k + rp) * P2_RS + pw * 64 + ((c ^ ((2 * k + rp) & 3)) << 4)) = v[i];
+            if (k < NPASS)
+              *reinterpret_cast<uint4*>(patch + (2 * k + rp) * P2_RS + pw * 64 + ((c ^ ((2 * k + rp) & 3)) << 4)) = v[i];
           }
         }
       }
@@ -1580,16 +1588,16 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
     // 0-2 / 3-5: one half's reads fly during the other half's 6*NT MFMAs), B fragments sit in a ring
     // of five taps and are loaded P2_BDIST taps ahead of their use.
     if (nrow > 0) {
-      const bf16_t* wfb = Wf + ((int64_t)cg * TAPS + 5 * row0) * (2 * NT) * 512 + lane * 8;
+      const bf16_t* wfb = Wf + ((int64_t)cg * TAPS + 5 * row0) * (2 * NT) * 512 + j0 * 512 + lane * 8;
       const int last = 5 * nrow - 1;
-      bf16x8 bq[5][2][NT];
+      bf16x8 bq[5][2][NTW];
       bf16x8 a0[6], a1[6];
-      auto load_b = [&](bf16x8 (&bb)[2][NT], int i) {
+      auto load_b = [&](bf16x8 (&bb)[2][NTW], int i) {
         const int ii = i < last ? i : last;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
+          for (int j = 0; j < NTW; ++j)
             bb[kc][j] = *reinterpret_cast<const bf16x8*>(wfb + ((int64_t)ii * 2 * NT + kc * NT + j) * 512);
       };
       // xb = lane base + row offset + swizzled chunk of k chunk 0 (bytes; k chunk 1 is xb ^ 32), imm = 64 dw
@@ -1603,13 +1611,13 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
       };
       // k chunk outermost: consecutive MFMAs never share an accumulator (with NT = 1 the w3-outer order issued
       // the two k chunks of a tile back to back, each waiting for the other's result)
-      auto run = [&](const bf16x8 (&aa)[6], const bf16x8 (&bb)[2][NT], int grp) {
+      auto run = [&](const bf16x8 (&aa)[6], const bf16x8 (&bb)[2][NTW], int grp) {
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
           for (int w3 = 0; w3 < 3; ++w3)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+            for (int j = 0; j < NTW; ++j)
               acc[3 * grp + w3][j] =
                   __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[w3 * 2 + kc], bb[kc][j], acc[3 * grp + w3][j], 0, 0, 0);
       };
@@ -1623,27 +1631,59 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
 #pragma unroll
       for (int d = 0; d < P2_BDIST; ++d) load_b(bq[d], d);
       load_a(a0, base_b + row_off(0), 0, 0);
+      if constexpr (!SPLIT) {
 #pragma unroll 1
-      for (int r = 0; r < nrow; ++r) {
-        const int x0 = base_b + row_off(r), xn = base_b + row_off(r + 1);
+        for (int r = 0; r < nrow; ++r) {
+          const int x0 = base_b + row_off(r), xn = base_b + row_off(r + 1);
 #pragma unroll
-        for (int dw = 0; dw < 5; ++dw) {
-          load_b(bq[(dw + P2_BDIST) % 5], 5 * r + dw + P2_BDIST);
-          load_a(a1, x0, 64 * dw, 1);
-          run(a0, bq[dw], 0);
-          if (dw < 4) load_a(a0, x0, 64 * (dw + 1), 0);
-          else load_a(a0, xn, 0, 0);
-          run(a1, bq[dw], 1);
+          for (int dw = 0; dw < 5; ++dw) {
+            load_b(bq[(dw + P2_BDIST) % 5], 5 * r + dw + P2_BDIST);
+            load_a(a1, x0, 64 * dw, 1);
+            run(a0, bq[dw], 0);
+            if (dw < 4) load_a(a0, x0, 64 * (dw + 1), 0);
+            else load_a(a0, xn, 0, 0);
+            run(a1, bq[dw], 1);
+          }
+          // The machine scheduler would sink every load next to its use (lowest register pressure);
+          // pin the interleave instead: per half tap, [B loads] then 6 x {1 LDS read, NT MFMAs}.
+#pragma unroll
+          for (int st = 0; st < 10; ++st) {
+            if ((st & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 2 * NT, 0);   // VMEM reads
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // DS read
+              __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);   // MFMA
+            }
+          }
         }
-        // The machine scheduler would sink every load next to its use (lowest register pressure);
-        // pin the interleave instead: per half tap, [B loads] then 6 x {1 LDS read, NT MFMAs}.
+      } else {
+        // three row tiles per wave: the whole tap's A fragments are double-buffered, tap by tap (five taps per
+        // row: the buffers swap roles once per row, a register copy)
+#pragma unroll 1
+        for (int r = 0; r < nrow; ++r) {
+          const int x0 = base_b + row_off(r), xn = base_b + row_off(r + 1);
 #pragma unroll
-        for (int st = 0; st < 10; ++st) {
-          if ((st & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 2 * NT, 0);   // VMEM reads
+          for (int dw = 0; dw < 5; ++dw) {
+            load_b(bq[(dw + P2_BDIST) % 5], 5 * r + dw + P2_BDIST);
+            if (dw & 1) {
+              load_a(a0, x0, 64 * (dw + 1), 0);
+              run(a1, bq[dw], 0);
+            } else {
+              if (dw < 4) load_a(a1, x0, 64 * (dw + 1), 0);
+              else load_a(a1, xn, 0, 0);
+              run(a0, bq[dw], 0);
+            }
+          }
 #pragma unroll
-          for (int g = 0; g < 6; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // DS read
-            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);   // MFMA
+          for (int i = 0; i < 6; ++i) a0[i] = a1[i];
+#pragma unroll
+          for (int st = 0; st < 5; ++st) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // VMEM reads
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // DS read
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
+            }
           }
         }
       }
@@ -1657,17 +1697,17 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
     if (!fvalid) return;
     const int Hp = H >> 1;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = j * 32 + lr;
+    for (int j = 0; j < NTW; ++j) {
+      const int n = (j0 + j) * 32 + lr;
       const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-      for (int wb = 0; wb < 6; ++wb)
+      for (int wb = 0; wb < MTW; ++wb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           bf16_t best;
           int arg;
           relu_pool4(acc[wb][j][4 * g], acc[wb][j][4 * g + 1], acc[wb][j][4 * g + 2], acc[wb][j][4 * g + 3], bv, best, arg);
-          const int64_t o = ((((int64_t)f * Hp + (h0 >> 1) + g) * (P2_W / 2)) + 2 * wb + kg) * N + n;
+          const int64_t o = ((((int64_t)f * Hp + (h0 >> 1) + g) * (P2_W / 2)) + 2 * (3 * g0 + wb) + kg) * N + n;
           Y[o] = best;
           code[o] = (unsigned char)arg;
         }
@@ -1676,18 +1716,46 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
   }
   if (!fvalid) return;
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = j * 32 + lr;
+  for (int j = 0; j < NTW; ++j) {
+    const int n = (j0 + j) * 32 + lr;
     const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-    for (int wb = 0; wb < 6; ++wb)
+    for (int wb = 0; wb < MTW; ++wb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int hh = h0 + ((r >> 1) & 1) + 2 * (r >> 2), ww = 4 * wb + (r & 1) + 2 * kg;
+        const int hh = h0 + ((r >> 1) & 1) + 2 * (r >> 2), ww = 4 * (3 * g0 + wb) + (r & 1) + 2 * kg;
         float v = acc[wb][j][r] + bv;
         if (relu) v = fmaxf(v, 0.f);
         Y[(((int64_t)f * H + hh) * P2_W + ww) * N + n] = f2bf(v);
       }
+  }
+}
+
+// Blocks 0 .. nfull-1 run whole tiles; the blocks after them run the remaining tiles split by frame
+// (P2_TT / FT blocks per tile).  The host splits the tiles left over after the last FULL round of one workgroup per
+// CU when they are few (1800 tiles on 256 CUs: 7 rounds + 8 tiles, which used to cost an eighth round).
+template <int CG, int NT, bool POOL>
+__global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __restrict__ X,
+                                                            const bf16_t* __restrict__ Wf,
+                                                            const float* __restrict__ bias,
+                                                            bf16_t* __restrict__ Y, unsigned char* __restrict__ code,
+                                                            int F, int T, int H, int relu, int nfull) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char patch[];
+  const int htiles = H / P2_TH;
+  if ((int)blockIdx.x < nfull) {
+    // XCD-aware tile order: block b runs on XCD b % 8 (each XCD has its own L2), so XCD x takes a CONTIGUOUS run of
+    // tiles (h-tiles of a frame tile, then the next frame tile): the tiles resident together on an XCD are
+    // neighbours in time and height and find each other's halo rows in that XCD's L2 instead of re-fetching them.
+    const int xcd = blockIdx.x & 7, per_xcd = nfull >> 3, rem_xcd = nfull & 7;
+    const int tile = xcd * per_xcd + (xcd < rem_xcd ? xcd : rem_xcd) + (int)(blockIdx.x >> 3);
+    conv_patch_tile<CG, NT, POOL, false>(patch, X, Wf, bias, Y, code, F, T, H, relu, (tile / htiles) * P2_TT,
+                                         (tile % htiles) * P2_TH);
+  } else {
+    constexpr int FT = NT == 2 ? 1 : 2, PER = P2_TT / FT;
+    const int sb = (int)blockIdx.x - nfull;
+    const int tile = nfull + sb / PER;
+    conv_patch_tile<CG, NT, POOL, true>(patch, X, Wf, bias, Y, code, F, T, H, relu,
+                                        (tile / htiles) * P2_TT + (sb % PER) * FT, (tile % htiles) * P2_TH);
   }
 }
 
@@ -2068,9 +2136,15 @@ static int conv_forward_impl(const void* X, const void* Wp, const float* bias, v
     // fragment-major weights: the patch-resident kernel (no other kernel reads that packing)
     if (lr_conv3d_patch_supported(Hin, Win, Cin, Cout, KT, KH, KW, stride, pt, ph, pw) != 2) return LR_ERR_UNSUPPORTED;
     const int F = B * T;
-    const dim3 pgrid((unsigned)(((F + P2_TT - 1) / P2_TT) * (Hin / P2_TH)));
-    hipEvent_t e0, e1;
     const bool fwd = Cin == 32;
+    // tiles left over after the last full round of one workgroup per CU, when they are few, run split by frame
+    // (4 blocks per tile forward, 2 for the data gradient) so that they do not cost a round of their own
+    const int ntiles = ((F + P2_TT - 1) / P2_TT) * (Hin / P2_TH);
+    const int left = ntiles % kChipCUs;
+    const int nsplit = ntiles > kChipCUs && left > 0 && left <= kChipCUs / 4 ? left : 0;
+    const int nfull = ntiles - nsplit;
+    const dim3 pgrid((unsigned)(nfull + nsplit * (fwd ? 4 : 2)));
+    hipEvent_t e0, e1;
     const bool sample = lr_prof_next(fwd ? LR_PROF_CONV2_FWD : LR_PROF_CONV2_DGRAD, &e0, &e1);
     static bool attr_set[3] = {false, false, false};
     lr_clear_error();
@@ -2083,9 +2157,10 @@ static int conv_forward_impl(const void* X, const void* Wp, const float* bias, v
       attr_set[IDX] = true;                                                                                   \
     }                                                                                                         \
     if (sample) hipExtLaunchKernelGGL((conv_patch_kernel<__VA_ARGS__>), pgrid, dim3(256), P2_LDS,              \
-                                      (hipStream_t)stream, e0, e1, 0, x, w, bias, y, code, F, T, Hin, relu);  \
+                                      (hipStream_t)stream, e0, e1, 0, x, w, bias, y, code, F, T, Hin, relu,   \
+                                      nfull);                                                                 \
     else hipLaunchKernelGGL((conv_patch_kernel<__VA_ARGS__>), pgrid, dim3(256), P2_LDS, (hipStream_t)stream,   \
-                            x, w, bias, y, code, F, T, Hin, relu);                                            \
+                            x, w, bias, y, code, F, T, Hin, relu, nfull);                                     \
   } while (0)
     if (fwd && code) LR_PATCH(2, 1, 2, true);
     else if (fwd) LR_PATCH(0, 1, 2, false);

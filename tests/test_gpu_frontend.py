@@ -283,6 +283,55 @@ def test_patch_resident_layer2_matches_implicit_gemm_and_oracle(dev):
     assert rel_err(a, q.grad.numpy()) < 4e-2, tuple(q.shape)
 
 
+def test_layer2_tail_tiles_split_by_frame_are_the_same_numbers(dev):
+  """The patch-resident layer-2 kernels run the few tiles left over after the last full round of one workgroup per
+  CU split by frame (four waves share a frame's accumulator tiles).  7 clips x 49 frames = 343 frames = 258 tiles:
+  tiles 256 and 257 (frames 340-342 + one frame past the end, rows 8-23) take that path.  Every output frame depends
+  on its own clip only and each accumulator sums its taps in the same order wherever it is computed, so the 7-clip
+  launch must reproduce, bit for bit, a 6-clip launch (222 tiles: no split) and a launch of the last clip alone."""
+  from lipreading_amd import _C
+  L = _C.lib()
+  st = _C.stream_handle()
+  bf = torch.bfloat16
+  B, T, h, w, cin, cout = 7, 49, 24, 24, 32, 64
+  kt, kh, kw, pt, ph, pw = 3, 5, 5, 1, 2, 2
+  g = torch.Generator().manual_seed(17)
+  x = (torch.randn(B * T, h, w, cin, generator=g) * 0.5).clamp_min(0).to(bf).to(dev)
+  dz = (torch.randn(B * T, h, w, cout, generator=g) * 0.1).to(bf).to(dev)
+  weight = (torch.randn(cout, cin, kt, kh, kw, generator=g) * 0.02).to(dev)
+  bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+  frag = L.lr_conv3d_patch_supported(h, w, cin, cout, kt, kh, kw, 1, pt, ph, pw)
+  fragd = L.lr_conv3d_patch_supported(h, w, cout, cin, kt, kh, kw, 1, pt, ph, pw)
+  assert frag == 2 and fragd == 2
+  wp = torch.empty((cout, kt * kh * kw, cin), dtype=bf, device=dev)
+  wd = torch.empty((cin, kt * kh * kw, cout), dtype=bf, device=dev)
+  _C.check(L.lr_conv3d_pack_weights(weight.data_ptr(), wp.data_ptr(), cout, cin, cin, kt, kh, kw, frag, st))
+  _C.check(L.lr_conv3d_pack_weights(weight.data_ptr(), wd.data_ptr(), cout, cin, cin, kt, kh, kw, 1 | fragd, st))
+
+  def run(first, nclips):
+    xs, zs = x[first * T:(first + nclips) * T].contiguous(), dz[first * T:(first + nclips) * T].contiguous()
+    F = nclips * T
+    pooled = torch.empty((F, h // 2, w // 2, cout), dtype=bf, device=dev)
+    code = torch.empty(pooled.shape, dtype=torch.uint8, device=dev)
+    full = torch.empty((F, h, w, cout), dtype=bf, device=dev)
+    dx = torch.empty((F, h, w, cin), dtype=bf, device=dev)
+    _C.check(L.lr_conv3d_forward_pooled(xs.data_ptr(), wp.data_ptr(), bias.data_ptr(), pooled.data_ptr(), code.data_ptr(),
+                                        nclips, T, h, w, cin, cout, kt, kh, kw, 1, pt, ph, pw, 1 | frag, st))
+    _C.check(L.lr_conv3d_forward(xs.data_ptr(), wp.data_ptr(), bias.data_ptr(), full.data_ptr(), nclips, T, h, w, cin,
+                                 cout, kt, kh, kw, 1, pt, ph, pw, 1 | frag, st))
+    _C.check(L.lr_conv3d_forward(zs.data_ptr(), wd.data_ptr(), None, dx.data_ptr(), nclips, T, h, w, cout, cin, kt, kh,
+                                 kw, 1, pt, ph, pw, fragd, st))
+    torch.cuda.synchronize()
+    return [t.view(torch.uint8 if t.dtype == torch.uint8 else torch.int16).cpu() for t in (pooled, code, full, dx)]
+
+  whole = run(0, 7)
+  head, tail = run(0, 6), run(6, 1)
+  for name, a, b, c in zip(("pooled", "code", "full", "dgrad"), whole, head, tail):
+    assert torch.equal(a[:6 * T], b), name
+    assert torch.equal(a[6 * T:], c), name
+  assert int(whole[2][6 * T:].ne(0).sum()) > 0 and int(whole[3][6 * T:].ne(0).sum()) > 0
+
+
 # ---- headline regime (BASELINE configs[1]) against the ORACLE, not against this repo's other paths ----
 # Stated tolerances (DESIGN.md section 7): |loss_hip - loss_oracle| <= 1e-3 absolute on the 'mean' CTC loss
 # (bench.PARITY_TOL_PIXELS); encoder/CTC-head gradients within 3e-2 of the oracle's norm per tensor, conv

@@ -3,6 +3,8 @@
 #   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r02'
 # ); writes under gpurun_out/, copy what should be judged into profiles/ (then run
 # `python tools/make_pmc_traffic.py r02` to rebuild the traffic JSON bench.py reads).
+# A second argument "pixels" regenerates only what a change to the conv kernels moves: the default bench line and the
+# pixel regimes' kernel statistics, traffic, timeline and counters, most important first.
 #   <round>_bench_default.json / _bench_gru256.json / _bench_lstm768.json / _bench_forcedist.json   bench lines
 #   <round>_{pixels,gru256,lstm768,landmarks_attn,pixels_tfm}_kernel_stats.txt   rocprofv3 --kernel-trace --stats per kernel
 #   <round>_{pixels,gru256,lstm768}_pmc_{FETCH,WRITE}_SIZE.txt       HBM/fabric bytes per launch (separate --pmc passes)
@@ -12,14 +14,10 @@
 set -u
 R=$PWD
 TAG=${1:-r02}
+ONLY=${2:-all}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-
-python bench.py 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_default.json"
-python bench.py --regime landmarks --model gru256 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_gru256.json"
-python bench.py --regime landmarks --model lstm768 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_lstm768.json"
-LIPREADING_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_forcedist.json"
 
 kt() {   # name, bench args...
   local name=$1; shift
@@ -30,12 +28,6 @@ kt() {   # name, bench args...
   python tools/rocpd_summary.py "$(find "$OUT/kt_$name" -name '*.db' | head -1)" 60 > "$OUT/${TAG}_${name}_kernel_stats.txt"
   rm -rf "$OUT/kt_$name"
 }
-kt pixels --regime pixels
-kt gru256 --regime landmarks --model gru256
-kt lstm768 --regime landmarks --model lstm768
-kt landmarks_attn --regime landmarks_attn
-kt pixels_tfm --regime pixels_tfm
-
 tl() {   # name, anchor kernel, bench args...: one graph-replay step of the timed region as a timeline
   local name=$1 anchor=$2; shift 2
   (cd /tmp && rocprofv3 --kernel-trace -d "$OUT/tl_$name" -o kt -- \
@@ -43,9 +35,6 @@ tl() {   # name, anchor kernel, bench args...: one graph-replay step of the time
   python tools/rocpd_timeline.py "$(find "$OUT/tl_$name" -name '*.db' | head -1)" "$anchor" 8 > "$OUT/${TAG}_${name}_step_timeline.txt"
   rm -rf "$OUT/tl_$name"
 }
-tl pixels conv1_fwd --regime pixels
-tl gru256 ctc_prepare --regime landmarks --model gru256
-
 pmc() {   # name, counter list, filters..., -- bench args
   local name=$1 counters=$2 suffix=$3; shift 3
   local filters=()
@@ -56,12 +45,26 @@ pmc() {   # name, counter list, filters..., -- bench args
   python tools/rocpd_pmc.py "$(find "$OUT/pmc_$name" -name '*.db' | head -1)" "${filters[@]}" > "$OUT/${TAG}_${suffix}.txt"
   rm -rf "$OUT/pmc_$name"
 }
-for c in FETCH_SIZE WRITE_SIZE; do
-  pmc px_$c $c pixels_pmc_$c -- --regime pixels
-  pmc gru_$c $c gru256_pmc_$c -- --regime landmarks --model gru256
-  pmc lstm_$c $c lstm768_pmc_$c -- --regime landmarks --model lstm768
-done
+
+python bench.py 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_default.json"
+kt pixels --regime pixels
+for c in FETCH_SIZE WRITE_SIZE; do pmc px_$c $c pixels_pmc_$c -- --regime pixels; done
+tl pixels conv1_fwd --regime pixels
+kt pixels_tfm --regime pixels_tfm
+LIPREADING_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_forcedist.json"
 pmc sq1 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" pixels_pmc_SQ_pass1 conv_ conv1_ gru256 xgemm -- --regime pixels
 pmc sq2 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA" pixels_pmc_SQ_pass2 conv_ conv1_ gru256 xgemm -- --regime pixels
-pmc sq3 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" gru256_pmc_SQ_pass1 gru256 sgemm -- --regime landmarks --model gru256
+if [ "$ONLY" != "pixels" ]; then
+  python bench.py --regime landmarks --model gru256 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_gru256.json"
+  python bench.py --regime landmarks --model lstm768 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_lstm768.json"
+  kt gru256 --regime landmarks --model gru256
+  kt lstm768 --regime landmarks --model lstm768
+  kt landmarks_attn --regime landmarks_attn
+  tl gru256 ctc_prepare --regime landmarks --model gru256
+  for c in FETCH_SIZE WRITE_SIZE; do
+    pmc gru_$c $c gru256_pmc_$c -- --regime landmarks --model gru256
+    pmc lstm_$c $c lstm768_pmc_$c -- --regime landmarks --model lstm768
+  done
+  pmc sq3 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" gru256_pmc_SQ_pass1 gru256 sgemm -- --regime landmarks --model gru256
+fi
 ls -la "$OUT" | grep "${TAG}_"
