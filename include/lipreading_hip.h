@@ -62,13 +62,17 @@ typedef enum lr_rnn_mode {
    * matrices [B*T][I] — the conv frontend's features as they are; x is then the hi plane of the
    * projection's operand and is never converted or packed. */
   LR_RNN_INPUT_STORED_BF16 = 0x800,
-  /* The recurrence of a supported layer (lr_rnn_pair_supported: 1 = GRU, H = 256; 2 = LSTM, H = 768) as ONE
+  /* The recurrence of a supported layer (lr_rnn_pair_supported: 1 = GRU, H = 256; 2 = GRU or LSTM with
+   * ceil(H / 32) in {8, 16, 22, 24, 25}: H = 256, 512, 700, 768, 800 and the sizes that round up to them — the
+   * reference's config/defaults.txt:19-21, config/train/attn/attention_type:16-19, config/train/micro:6-8) as ONE
    * launch per pass and fp32-FAITHFUL: W_hh and the carried state are split into bf16 hi + lo planes, all four
    * cross terms accumulate in fp32 on the bf16 matrix cores (~1e-6 of the exact fp32 product, against ~1e-3
    * for LR_RNN_RECUR_BF16).  W_hh stays in the registers + LDS of a pair of compute units per (sample,
-   * direction) (GRU-256) or of a cluster of 24 per (direction, 8 samples) (LSTM-768), which exchange their
+   * direction) (GRU-256) or of a cluster of ceil(H / 32) per (direction, 8 samples), which exchange their
    * slices of the state (forward) / their partial state gradients (backward) once per step.  What the
-   * reference-faithful regime runs by default where it is supported. */
+   * reference-faithful regime runs by default where it is supported; the decoder loop (lr_decoder_forward /
+   * _backward) takes the same cluster kernels, started from the encoder's final state, when every step is
+   * teacher forced. */
   LR_RNN_RECUR_SPLIT = 0x1000
 } lr_rnn_mode;
 
@@ -184,10 +188,33 @@ int lr_sgemm(int transA, int transB, int M, int N, int K, float alpha, const flo
  * Pointer arrays (w_ih ...) are HOST arrays of D device pointers. */
 int lr_rnn_persistent_supported(int mode, int B, int T, int I, int H, int D);   /* see LR_RNN_RECUR_BF16 */
 int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D);         /* see LR_RNN_RECUR_SPLIT */
-/* LR_RNN_RECUR_SPLIT's workgroups of a pair / cluster must be resident together; their waits are bounded, and a
- * member that gave up leaves garbage and counts here.  Returns that count since the last call (0 = all
- * results valid) and clears it; synchronises the device (tests / bench only). */
+/* LR_RNN_RECUR_SPLIT's workgroups of a pair / cluster must be resident together (lr_rnn_pair_supported checks the
+ * device's compute-unit count); their waits are bounded, and a member that gave up leaves garbage and raises the
+ * device-side FAULT WORD.  The reference's contract for a batch it cannot use is assert / `None` => skip
+ * (src/train/train_better_model.py:46-50); here, with no host round trip:
+ *   fault words  int32[2] on the device, {pending, total}.  A recurrence that timed out ORs 1 into `pending`;
+ *                lr_ctc_reduce then reports the batch as skipped (loss 0, status 2, zero gradient weights) and
+ *                lr_adam_step leaves parameters, moments and step count untouched, exactly as for skip != 0;
+ *                lr_step_begin (the top of the next step) moves `pending` into `total`.
+ * lr_fault_words_ptr   device pointer to the two words (allocated on the first call — never call it first under
+ *                      stream capture), NULL if that failed.
+ * lr_rnn_pair_errors   pending + total since the last call, and clears both; synchronises the device (once per
+ *                      epoch in train(), tests, bench).
+ * lr_step_begin        zeroes the flat gradient buffer grad[0..n) (16-byte aligned; what opt.zero_grad() does,
+ *                      train_better_model.py:67) and rolls the fault words; one launch.
+ * lr_rnn_debug_drop_member   TEST HOOK: member `m` (>= 0) of every pair / cluster returns at once, so its partners
+ *                      time out (a few tenths of a second) and raise the fault; -1 (default) = off.
+ * lr_fault_export / lr_fault_import   data parallel (lipreading_amd/distributed.py): out2 = {status[0] (0 when
+ *                      status is NULL), -(pending != 0)} for ONE MIN all-reduce over the ranks; import writes
+ *                      in2[0] back to status[0] (skip the batch only if every rank skipped it) and raises the local
+ *                      fault when in2[1] < 0 (ANY rank timed out: its garbage gradient is in the sum, so every rank
+ *                      skips the update and the ranks stay identical). */
 int lr_rnn_pair_errors(void);
+int lr_fault_export(const int32_t* status, int32_t* out2, lr_stream_t stream);
+int lr_fault_import(const int32_t* in2, int32_t* status, lr_stream_t stream);
+void* lr_fault_words_ptr(void);
+int lr_step_begin(float* grad, int64_t n, lr_stream_t stream);
+void lr_rnn_debug_drop_member(int member);
 size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D);
 size_t lr_rnn_workspace_bytes(int mode, int B, int T, int I, int H, int D);
 
@@ -602,8 +629,9 @@ int lr_sumsq(const float* x, int64_t n, float* out, lr_stream_t stream);
  *   grad_scale multiplies the gradient first (1/world_size after an all-reduce sum);
  *   max_norm > 0 applies clip_grad_norm_ (train_better_model.py:78) with the total norm taken
  *   from sumsq[0] (lr_sumsq over the same gradient buffer): coef = min(1, max_norm/(norm+1e-6)).
- *   step_count  [1] int32 DEVICE counter, incremented here (bias correction uses the new value),
- *               so a captured hipGraph replays correct corrections;
+ *   step_count  [2] int32 DEVICE counters: [0] updates taken, incremented here (bias correction uses the new
+ *               value), so a captured hipGraph replays correct corrections; [1] steps skipped (skip != 0 or a
+ *               pending recurrence fault), so the caller can report them without a per-step host read;
  *   skip        [1] int32 DEVICE flag or NULL: non-zero = the reference skipped this batch
  *               (`continue`, train_better_model.py:49-50): nothing is updated, step_count stays;
  *   scratch     [4] floats of device scratch. */

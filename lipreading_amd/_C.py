@@ -48,6 +48,11 @@ SIGNATURES = {
     "lr_rnn_persistent_supported": (c_int, [c_int] * 6),
     "lr_rnn_pair_supported": (c_int, [c_int] * 6),
     "lr_rnn_pair_errors": (c_int, []),
+    "lr_fault_words_ptr": (c_void_p, []),
+    "lr_fault_export": (c_int, [P, P, P]),
+    "lr_fault_import": (c_int, [P, P, P]),
+    "lr_step_begin": (c_int, [P, c_int64, P]),
+    "lr_rnn_debug_drop_member": (None, [c_int]),
     "lr_rnn_reserve_bytes": (c_size_t, [c_int] * 6),
     "lr_rnn_workspace_bytes": (c_size_t, [c_int] * 6),
     "lr_rnn_layer_forward": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int,
@@ -159,6 +164,8 @@ def lib():
       fn.restype = restype
       fn.argtypes = argtypes
     _lib = handle
+    if torch.cuda.is_available():
+      handle.lr_fault_words_ptr()   # allocate the device-side fault words now, outside any stream capture
   return _lib
 
 

@@ -98,6 +98,12 @@ bool lr_prof_next(int slot, hipEvent_t* start, hipEvent_t* stop);
       hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)(stream), __VA_ARGS__);                   \
   } while (0)
 
+// ---- device-side fault words {pending, total} of the one-launch recurrences (lr_misc.hip; see
+// include/lipreading_hip.h lr_fault_words_ptr).  NULL only when the allocation failed.
+int32_t* lr_fault_words();
+int lr_device_cus();                // compute units of the current device, 0 without one
+int lr_debug_drop_member_value();   // test hook (lr_rnn_debug_drop_member): that member of every cluster / pair exits at once
+
 // ---- recurrent layer pieces shared with lr_decoder.hip (implemented in lr_rnn.hip) --------------------
 size_t lr_rnn_packed_w_floats(int G, int H);
 size_t lr_rnn_packed_state_floats(int B, int H);
@@ -151,18 +157,20 @@ int lr_gru256_pair_forward(float* gates, float* extra, float* y, const float* co
 int lr_gru256_pair_backward(const float* gates, const float* extra, const float* y, const float* dy, const float* dh_n,
                             float* dG, const float* const* w_hh, const int32_t* lens, void* wpack, void* xch, int B,
                             int T, int D, hipStream_t stream);
-// lr_rnn_cluster.hip: the LSTM-768 recurrence as one launch per layer pass, fp32-faithful (W_hh sliced over a
-// cluster of 24 CUs per (direction, 8 samples), bf16 hi + lo planes, granule all-gather per step)
-int lr_cluster_errors();
-int lr_lstm768_cluster_supported(int G, int B, int H);
-size_t lr_lstm768_cluster_pack_bytes(int D);
-size_t lr_lstm768_cluster_xch_bytes(int B, int D, int backward);
-size_t lr_lstm768_cluster_bwd_pack_bytes(int D);
-int lr_lstm768_cluster_forward(float* gates, float* extra, float* y, const float* const* w_hh, const int32_t* lens,
-                               void* wpack, void* xch, int B, int T, int D, hipStream_t stream);
-int lr_lstm768_cluster_backward(const float* gates, const float* extra, const float* dy, const float* dh_n,
-                                const float* dc_n, float* dG, const float* const* w_hh, const int32_t* lens, void* wpack,
-                                void* xch, int B, int T, int D, hipStream_t stream);
+// lr_rnn_cluster.hip: the GRU / LSTM recurrence as one launch per layer pass, fp32-faithful (W_hh sliced over a
+// cluster of ceil(H / 32) CUs per (direction, 8 samples), bf16 hi + lo planes, self-tagged 4-byte exchange words);
+// G = 3 (GRU) or 4 (LSTM); h0 / c0 (may be NULL) = the state before the first step, [D][B][H]; dh0 / dc0 (may be
+// NULL) receive the gradient into it
+int lr_rnn_cluster_supported(int G, int B, int H);
+size_t lr_rnn_cluster_pack_bytes(int G, int H, int D, int backward);
+size_t lr_rnn_cluster_xch_bytes(int B, int H, int D, int backward);
+int lr_rnn_cluster_forward(int G, float* gates, float* extra, float* y, const float* const* w_hh, const float* const* b_hh,
+                           const float* h0, const float* c0, const int32_t* lens, void* wpack, void* xch, int B, int T,
+                           int D, int H, hipStream_t stream);
+int lr_rnn_cluster_backward(int G, const float* gates, const float* extra, const float* y, const float* dy,
+                            const float* dh_n, const float* dc_n, float* dG, float* dh0, float* dc0, const float* h0,
+                            const float* c0, const float* const* w_hh, const int32_t* lens, void* wpack, void* xch, int B,
+                            int T, int D, int H, hipStream_t stream);
 // lr_xgemm.hip: fp32 GEMM on the bf16 matrix cores by hi/lo operand splitting (same operand
 // conventions; a_exact / b_exact: the operand's elements are bf16 values already)
 int lr_xgemm_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,

@@ -371,7 +371,18 @@ __global__ void ctc_reduce_kernel(const float* __restrict__ nll,
                                   const int32_t* __restrict__ frame_lens,
                                   const int32_t* __restrict__ label_lens, int reduction,
                                   float* __restrict__ out_loss, int32_t* __restrict__ out_status,
-                                  float* __restrict__ grad_weight, int B) {
+                                  float* __restrict__ grad_weight, int B, const int32_t* __restrict__ fault) {
+  // fault[0] != 0: a one-launch recurrence that produced these log-probs gave up waiting for a partner workgroup
+  // (lr_common.h lr_fault_words): the numbers are garbage, so the batch is reported like one the reference
+  // skips (loss 0, status 2, zero gradient) — train_better_model.py:49-50.
+  if (fault && fault[0] != 0) {
+    if (threadIdx.x == 0) {
+      out_loss[0] = 0.f;
+      out_status[0] = 2;
+    }
+    for (int i = threadIdx.x; i < B; i += blockDim.x) grad_weight[i] = 0.f;
+    return;
+  }
   __shared__ float s_nll[kReduceMaxB];
   __shared__ int s_fl[kReduceMaxB];
   __shared__ int s_ll[kReduceMaxB];
@@ -640,7 +651,8 @@ extern "C" int lr_ctc_reduce(const float* nll, const int32_t* frame_lens,
   LR_CHECK_ARG(B > 0 && (reduction == LR_CTC_SUM || reduction == LR_CTC_MEAN));
   if (B > kReduceMaxB) return LR_ERR_UNSUPPORTED;
   LR_LAUNCH(ctc_reduce_kernel, dim3(1), dim3(256), 0, stream, nll,
-                     frame_lens, label_lens, reduction, out_loss, out_status, grad_weight, B);
+                     frame_lens, label_lens, reduction, out_loss, out_status, grad_weight, B,
+                     (const int32_t*)lr_fault_words());
   return lr_launch_status();
 }
 

@@ -431,7 +431,17 @@ struct Res {
   size_t biasf[MAXL], gates[MAXL], extra[MAXL], hsl[MAXL], hp[MAXL], wp[MAXL], xm[MAXL];
   size_t hs;
   size_t hp_slot, gemm_bytes;
+  size_t xch, xch_bytes;   // exchange words of the one-launch recurrence (lr_rnn_cluster.hip), when it covers (G, B, Hd)
 };
+// the packed recurrent weights of a layer: the step kernels' fragment order, or the cluster recurrence's
+size_t packed_w_floats(const Sizes& z, int backward) {
+  size_t n = lr_rnn_packed_w_floats(z.G, z.Hd);
+  if (z.G != 1 && lr_rnn_cluster_supported(z.G, z.B, z.Hd)) {
+    const size_t c = (lr_rnn_cluster_pack_bytes(z.G, z.Hd, 1, backward) + 3) / 4;
+    if (c > n) n = c;
+  }
+  return n;
+}
 Res res_layout(const Sizes& z) {
   Res r;
   const size_t GH = (size_t)z.G * z.Hd, BL = (size_t)z.B * z.L, BT = (size_t)z.B * z.T;
@@ -447,7 +457,7 @@ Res res_layout(const Sizes& z) {
     r.extra[k] = take(BL * z.Hd);
     r.hsl[k] = take(BL * z.Hd);
     r.hp[k] = take(2 * r.hp_slot);
-    r.wp[k] = take(lr_rnn_packed_w_floats(z.G, z.Hd));
+    r.wp[k] = take(packed_w_floats(z, 0));
     r.xm[k] = take(k + 1 < z.NL ? BL * z.Hd : 0);   // dropout-masked copy of hsl[k] (input of layer k+1)
   }
   r.hs = r.hsl[z.NL - 1];
@@ -464,6 +474,8 @@ Res res_layout(const Sizes& z) {
                          {(int)BL, a, z.Hd}, {(int)BL, (int)GH, z.Hd}};
   r.gemm_bytes = max_gemm_ws(dims, 6);
   r.gemm = take((r.gemm_bytes + 3) / 4);
+  r.xch_bytes = (z.G != 1 && lr_rnn_cluster_supported(z.G, z.B, z.Hd)) ? lr_rnn_cluster_xch_bytes(z.B, z.Hd, 1, 0) : 0;
+  r.xch = take((r.xch_bytes + 3) / 4);
   r.total = o;
   return r;
 }
@@ -472,6 +484,7 @@ struct Wsp {
   size_t wpT, dG, dcar, dgp, dy, dlogits, dpre, dctx, dlg, dsum, dEW, dsrc, dcterm, dPE, dph, dw2p, colsum, gemm,
       total;
   size_t dgp_slot, gemm_bytes;
+  size_t xch, xch_bytes;
 };
 Wsp ws_layout(const Sizes& z) {
   Wsp w;
@@ -479,7 +492,9 @@ Wsp ws_layout(const Sizes& z) {
   const bool attn = z.type != ATT_NONE;
   size_t o = 0;
   auto take = [&](size_t n) { size_t at = o; o += (n + 63) / 64 * 64; return at; };
-  w.wpT = take(lr_rnn_packed_w_floats(z.G, z.Hd));
+  w.wpT = take(packed_w_floats(z, 1));
+  w.xch_bytes = (z.G != 1 && lr_rnn_cluster_supported(z.G, z.B, z.Hd)) ? lr_rnn_cluster_xch_bytes(z.B, z.Hd, 1, 1) : 0;
+  w.xch = take((w.xch_bytes + 3) / 4);
   w.dG = take(BL * 4 * z.Hd);
   w.dcar = take(BL * z.Hd);
   w.dgp_slot = (size_t)((z.B + 15) / 16) * z.G * ((z.Hd + 15) / 16) * 256;
@@ -622,9 +637,14 @@ extern "C" int lr_decoder_forward(int mode, int attn_type, const lr_decoder_para
   void* gws = base + r.gemm;
   int32_t* ids = (int32_t*)(base + r.ids);
 
+  // every input token known up front (teacher forcing on all steps) and a shape the cluster recurrence covers:
+  // each layer's L steps go out as one launch
+  bool one_launch = r.xch_bytes != 0;
+  for (int i = 1; i < L; ++i) one_launch = one_launch && teacher_forced_host[i];
   // table of input projections of layer 0: EW = emb @ W_ih^T + folded bias
   for (int k = 0; k < NL; ++k) {
     LR_TRY(lr_rnn_fold_bias(b_ihl[k], b_hhl[k], base + r.biasf[k], G, Hd, stream));
+    if (one_launch) continue;   // the cluster recurrence packs W_hh itself and reads h0 / c0 directly
     LR_TRY(lr_rnn_pack_w(w_hh[k], base + r.wp[k], G, Hd, 0, stream));
     lr_clear_error();
     if (hipMemsetAsync(base + r.hp[k], 0, 2 * r.hp_slot * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
@@ -735,6 +755,16 @@ extern "C" int lr_decoder_forward(int mode, int attn_type, const lr_decoder_para
           x = base + r.xm[k - 1];
         }
         LR_TRY(rows_gemm(GH, Hd, x, Hd, w_ihu[k], Hd, 0.f, base + r.gates[k], GH, base + r.biasf[k], i, i + run));
+      }
+      if (one_launch) {
+        // the whole loop is one run (teacher_forcing_ratio = 1: the shipped configs and eval): the layer's L steps as
+        // ONE launch, fp32-faithful (lr_rnn_cluster.hip), started from the encoder's final state
+        const float* whh1[1] = {w_hh[k]};
+        const float* bhh1[1] = {b_hhl[k]};
+        LR_TRY(lr_rnn_cluster_forward(G, base + r.gates[k], base + r.extra[k], base + r.hsl[k], whh1, bhh1,
+                                      h0 + k * state, c0 ? c0 + k * state : nullptr, step_lens, base + r.wp[k],
+                                      base + r.xch, B, L, 1, Hd, stream));
+        continue;
       }
       for (int s = i; s < i + run; ++s)
         LR_TRY(lr_rnn_step_fwd(G, base + r.gates[k], base + r.extra[k], base + r.hsl[k], base + r.hp[k], step_lens,
@@ -904,16 +934,25 @@ extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_par
     const float* hs_k = rb + r.hsl[k];
     const float* h0_k = h0 + k * state;
     const float* c0_k = c0 ? c0 + k * state : nullptr;
-    LR_TRY(lr_rnn_pack_w(w_hh_k, wb + w.wpT, G, Hd, 1, stream));
-    lr_clear_error();
-    if (hipMemsetAsync(wb + w.dgp, 0, 2 * w.dgp_slot * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
-    for (int s2 = 0; s2 < L; ++s2)
-      LR_TRY(lr_rnn_step_bwd(G, rb + r.gates[k], rb + r.extra[k], hs_k, dy, dh_n ? dh_n + k * state : nullptr,
-                             dc_n ? dc_n + k * state : nullptr, dG, wb + w.dcar, wb + w.dgp, step_lens, wb + w.wpT,
-                             h0_k, c0_k, B, L, Hd, s2, stream));
-    // gradient into the initial state (the encoder's final state of this layer)
-    LR_TRY(lr_rnn_dh0(G, wb + w.dcar, wb + w.dgp + (size_t)((L - 1) & 1) * w.dgp_slot, wb + w.wpT, dh0 + k * state,
-                      dc0 ? dc0 + k * state : nullptr, B, L, Hd, stream));
+    if (w.xch_bytes) {
+      // the L reverse steps AND the gradient into the initial state as one launch (lr_rnn_cluster.hip)
+      const float* whh1[1] = {w_hh_k};
+      LR_TRY(lr_rnn_cluster_backward(G, rb + r.gates[k], rb + r.extra[k], hs_k, dy, dh_n ? dh_n + k * state : nullptr,
+                                     dc_n ? dc_n + k * state : nullptr, dG, dh0 + k * state,
+                                     dc0 ? dc0 + k * state : nullptr, h0_k, c0_k, whh1, step_lens, wb + w.wpT, wb + w.xch,
+                                     B, L, 1, Hd, stream));
+    } else {
+      LR_TRY(lr_rnn_pack_w(w_hh_k, wb + w.wpT, G, Hd, 1, stream));
+      lr_clear_error();
+      if (hipMemsetAsync(wb + w.dgp, 0, 2 * w.dgp_slot * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
+      for (int s2 = 0; s2 < L; ++s2)
+        LR_TRY(lr_rnn_step_bwd(G, rb + r.gates[k], rb + r.extra[k], hs_k, dy, dh_n ? dh_n + k * state : nullptr,
+                               dc_n ? dc_n + k * state : nullptr, dG, wb + w.dcar, wb + w.dgp, step_lens, wb + w.wpT,
+                               h0_k, c0_k, B, L, Hd, s2, stream));
+      // gradient into the initial state (the encoder's final state of this layer)
+      LR_TRY(lr_rnn_dh0(G, wb + w.dcar, wb + w.dgp + (size_t)((L - 1) & 1) * w.dgp_slot, wb + w.wpT, dh0 + k * state,
+                        dc0 ? dc0 + k * state : nullptr, B, L, Hd, stream));
+    }
     // W_hh (h_prev of step t is hs[b][t-1]; step 0 used h0) and, for an upper layer, W_ih (x = the (dropped-out)
     // states of the layer below): ONE grouped launch + one combine (lr_gemm.hip)
     {

@@ -221,13 +221,17 @@ __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __re
 //   st[3] = gradient scale (grad_scale x clip coefficient)
 __global__ void adam_prepare_kernel(int32_t* __restrict__ step_count,
                                     const int32_t* __restrict__ skip,
+                                    const int32_t* __restrict__ fault,
                                     const float* __restrict__ sumsq, float max_norm,
                                     float grad_scale, float lr, float beta1, float beta2,
                                     float* __restrict__ st) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const bool active = !(skip && skip[0] != 0);
+  // fault[0] != 0: a one-launch recurrence of THIS step gave up waiting for a partner workgroup (its outputs
+  // and gradients are garbage): the step is skipped like a batch the reference skips (train_better_model.py:49-50)
+  const bool active = !(skip && skip[0] != 0) && !(fault && fault[0] != 0);
   int t = step_count[0];
   if (active) step_count[0] = ++t;
+  else step_count[1] += 1;      // steps skipped (a batch the reference `continue`s past, or a recurrence fault)
   if (t < 1) t = 1;
   const float bc1 = 1.f - powf(beta1, (float)t);
   const float bc2 = 1.f - powf(beta2, (float)t);
@@ -447,6 +451,115 @@ extern "C" int lr_ctc_prepare_i64(const int64_t* chars, int64_t chars_stride, co
   return lr_launch_status();
 }
 
+// ---- device-side fault words (see include/lipreading_hip.h: lr_fault_words) ---------------------------------
+// One int32[2] per device, {pending, total}.  The one-launch recurrences OR 1 into `pending` when a member gives
+// up waiting; lr_ctc_reduce and lr_adam_step read `pending` (skip the batch / the update); lr_step_begin moves
+// `pending` into `total` at the top of the next step.  Allocated on first use (never under stream capture: the
+// product runs its first steps eagerly, and _C.lib() calls lr_fault_words() when it loads the library).
+namespace {
+constexpr int kMaxDevices = 64;
+int32_t* g_fault_words[kMaxDevices];
+int g_drop_member = -1;
+__global__ void step_begin_kernel(float4* __restrict__ g, int64_t n4, float* __restrict__ tail, int ntail,
+                                  int32_t* __restrict__ fault) {
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i0 == 0 && fault) {
+    fault[1] += fault[0];
+    fault[0] = 0;
+  }
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t i = i0; i < n4; i += (int64_t)gridDim.x * blockDim.x) g[i] = z;
+  if (i0 < ntail) tail[i0] = 0.f;
+}
+__global__ void fault_export_kernel(const int32_t* __restrict__ status, const int32_t* __restrict__ fault,
+                                    int32_t* __restrict__ out2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  out2[0] = status ? status[0] : 0;
+  out2[1] = (fault && fault[0] != 0) ? -1 : 0;
+}
+__global__ void fault_import_kernel(const int32_t* __restrict__ in2, int32_t* __restrict__ status,
+                                    int32_t* __restrict__ fault) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (status) status[0] = in2[0];
+  if (fault && in2[1] < 0) fault[0] |= 1;
+}
+}  // namespace
+
+int32_t* lr_fault_words() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  if (!g_fault_words[dev]) {
+    int32_t* p = nullptr;
+    if (hipMalloc((void**)&p, 4 * sizeof(int32_t)) != hipSuccess) {
+      lr_clear_error();
+      return nullptr;
+    }
+    if (hipMemset(p, 0, 4 * sizeof(int32_t)) != hipSuccess) {
+      lr_clear_error();
+      (void)hipFree(p);
+      return nullptr;
+    }
+    g_fault_words[dev] = p;
+  }
+  return g_fault_words[dev];
+}
+int lr_debug_drop_member_value() { return g_drop_member; }
+// compute units of the current device (0 without a device): the one-launch recurrences need their partner
+// workgroups resident together, one per CU
+int lr_device_cus() {
+  static int cus[kMaxDevices];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    lr_clear_error();
+    return 0;
+  }
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+      lr_clear_error();
+      return 0;
+    }
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
+extern "C" void* lr_fault_words_ptr(void) { return lr_fault_words(); }
+extern "C" void lr_rnn_debug_drop_member(int member) { g_drop_member = member; }
+
+extern "C" int lr_rnn_pair_errors(void) {
+  int32_t* w = lr_fault_words();
+  if (!w) return -1;
+  int32_t v[2] = {0, 0}, zero[2] = {0, 0};
+  lr_clear_error();
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(v, w, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if ((v[0] || v[1]) && hipMemcpy(w, zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) return -1;
+  return v[0] + v[1];
+}
+
+// data parallel: {status, -(pending != 0)} for ONE MIN all-reduce — the batch is skipped when every rank skipped it
+// (status), the update is skipped everywhere when ANY rank's recurrence timed out (its garbage gradient is in the sum)
+extern "C" int lr_fault_export(const int32_t* status, int32_t* out2, lr_stream_t stream) {
+  LR_CHECK_ARG(out2);
+  LR_LAUNCH(fault_export_kernel, dim3(1), dim3(64), 0, stream, status, (const int32_t*)lr_fault_words(), out2);
+  return lr_launch_status();
+}
+extern "C" int lr_fault_import(const int32_t* in2, int32_t* status, lr_stream_t stream) {
+  LR_CHECK_ARG(in2);
+  LR_LAUNCH(fault_import_kernel, dim3(1), dim3(64), 0, stream, in2, status, lr_fault_words());
+  return lr_launch_status();
+}
+
+extern "C" int lr_step_begin(float* grad, int64_t n, lr_stream_t stream) {
+  LR_CHECK_ARG(n >= 0 && (grad || n == 0));
+  LR_CHECK_ARG((reinterpret_cast<uintptr_t>(grad) & 15) == 0);
+  const int64_t n4 = n / 4;
+  LR_LAUNCH(step_begin_kernel, dim3(grid_for(n4 > 0 ? n4 : 1, 256)), dim3(256), 0, stream, (float4*)grad, n4,
+            grad + n4 * 4, (int)(n - n4 * 4), lr_fault_words());
+  return lr_launch_status();
+}
+
 extern "C" int lr_sumsq(const float* x, int64_t n, float* out, lr_stream_t stream) {
   LR_CHECK_ARG(x && out && n >= 0);
   if (n == 0) return LR_OK;
@@ -462,8 +575,8 @@ extern "C" int lr_adam_step(float* param, const float* grad, float* exp_avg, flo
                             float lr, float beta1, float beta2, float eps, int32_t* step_count,
                             const int32_t* skip, float* scratch, lr_stream_t stream) {
   LR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_count && scratch && n >= 0);
-  LR_LAUNCH(adam_prepare_kernel, dim3(1), dim3(64), 0, stream, step_count, skip, sumsq, max_norm,
-            grad_scale, lr, beta1, beta2, scratch);
+  LR_LAUNCH(adam_prepare_kernel, dim3(1), dim3(64), 0, stream, step_count, skip, (const int32_t*)lr_fault_words(),
+            sumsq, max_norm, grad_scale, lr, beta1, beta2, scratch);
   int st = lr_launch_status();
   if (st != LR_OK || n == 0) return st;
   LR_LAUNCH(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, param, grad, exp_avg,

@@ -539,13 +539,17 @@ Layout reserve_layout(int G, int B, int T, int I, int H, int D, bool x3 = false)
   l.bias = l.extra + (size_t)B * T * D * H;
   l.wp = (l.bias + (size_t)D * G * H + 63) / 64 * 64;       // 256-byte aligned
   l.wp_per_dir = nchunk * G * nchunk * FRAG;
+  if (lr_rnn_cluster_supported(G, B, H)) {   // the cluster recurrence's fragment order pads H and the GRU's gate tiles
+    const size_t cf = (lr_rnn_cluster_pack_bytes(G, H, 1, 0) / sizeof(float) + 63) / 64 * 64;
+    if (cf > l.wp_per_dir) l.wp_per_dir = cf;
+  }
   l.hp = l.wp + (size_t)D * l.wp_per_dir;
   l.hp_floats = 2 * (size_t)D * nbt * nchunk * FRAG;
   l.gemm = l.hp + l.hp_floats;                               // split-K slabs of the input projection
   l.gemm_bytes = x3 ? lr_xproj_workspace_bytes(B * T, I, G * H, D) : lr_sgemm_workspace_bytes(B * T, G * H, I);
   l.xch = (l.gemm + (l.gemm_bytes + 3) / 4 + 63) / 64 * 64;   // granule exchange of the pair recurrence
   l.xch_bytes = lr_gru256_pair_supported(G, B, H) ? lr_gru256_pair_xch_bytes(B, D, 0)
-                : (lr_lstm768_cluster_supported(G, B, H) ? lr_lstm768_cluster_xch_bytes(B, D, 0) : 0);
+                : (lr_rnn_cluster_supported(G, B, H) ? lr_rnn_cluster_xch_bytes(B, H, D, 0) : 0);
   l.total = l.xch + (l.xch_bytes + 3) / 4;
   return l;
 }
@@ -560,6 +564,10 @@ WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
   l.dcar = l.dG + (size_t)B * T * D * 4 * H;
   l.wT = (l.dcar + (size_t)B * T * D * H + 63) / 64 * 64;   // packed W_hh^T, 256-byte aligned
   l.wp_per_dir = nchunk * G * nchunk * FRAG;
+  if (lr_rnn_cluster_supported(G, B, H)) {
+    const size_t cf = (lr_rnn_cluster_pack_bytes(G, H, 1, 1) / sizeof(float) + 63) / 64 * 64;
+    if (cf > l.wp_per_dir) l.wp_per_dir = cf;
+  }
   l.dgp = l.wT + (size_t)D * l.wp_per_dir;                  // packed dG_h, two parities
   l.dgp_floats = 2 * (size_t)D * nbt * G * nchunk * FRAG;
   l.colsum = l.dgp + l.dgp_floats;
@@ -590,7 +598,7 @@ WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
   l.gemm_bytes = gb;
   l.xch = (l.gemm + (gb + 3) / 4 + 63) / 64 * 64;
   l.xch_bytes = lr_gru256_pair_supported(G, B, H) ? lr_gru256_pair_xch_bytes(B, D, 1)
-                : (lr_lstm768_cluster_supported(G, B, H) ? lr_lstm768_cluster_xch_bytes(B, D, 1) : 0);
+                : (lr_rnn_cluster_supported(G, B, H) ? lr_rnn_cluster_xch_bytes(B, H, D, 1) : 0);
   l.total = l.xch + (l.xch_bytes + 3) / 4;
   return l;
 }
@@ -626,9 +634,10 @@ extern "C" int lr_rnn_persistent_supported(int mode, int B, int T, int I, int H,
 
 extern "C" int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D)) return 0;
-  // 1: GRU-256 (CU pairs); 2: LSTM-768 (24-CU clusters); both passes of either shape
+  // 1: GRU-256 (CU pairs); 2: clusters of ceil(H / 32) CUs (lr_rnn_cluster.hip: GRU / LSTM, H up to 800 in the
+  // instantiated sizes); both passes of either kind
   if (lr_gru256_pair_supported(gates_of(mode), B, H)) return 1;
-  return lr_lstm768_cluster_supported(gates_of(mode), B, H) ? 2 : 0;
+  return lr_rnn_cluster_supported(gates_of(mode), B, H) ? 2 : 0;
 }
 
 extern "C" size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D) {
@@ -696,9 +705,10 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
     if (lr_gru256_pair_supported(G, B, H)) {
       if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_gru256_pair_pack_bytes(D)) return LR_ERR_WORKSPACE;
       st = lr_gru256_pair_forward(gates, extra, y, w_hh, b_hh, lens, base + l.wp, base + l.xch, B, T, D, stream);
-    } else if (lr_lstm768_cluster_supported(G, B, H)) {
-      if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_lstm768_cluster_pack_bytes(D)) return LR_ERR_WORKSPACE;
-      st = lr_lstm768_cluster_forward(gates, extra, y, w_hh, lens, base + l.wp, base + l.xch, B, T, D, stream);
+    } else if (lr_rnn_cluster_supported(G, B, H)) {
+      if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_rnn_cluster_pack_bytes(G, H, D, 0)) return LR_ERR_WORKSPACE;
+      st = lr_rnn_cluster_forward(G, gates, extra, y, w_hh, b_hh, nullptr, nullptr, lens, base + l.wp, base + l.xch, B, T,
+                                  D, H, stream);
     } else {
       return LR_ERR_UNSUPPORTED;
     }
@@ -817,9 +827,10 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
     if ((size_t)D * wl.wp_per_dir * sizeof(float) < lr_gru256_pair_bwd_pack_bytes(D)) return LR_ERR_WORKSPACE;
     st = lr_gru256_pair_backward(gates, extra, y, dy, dh_n, dG, w_hh, lens, wT, wbase + wl.xch, B, T, D, stream);
     if (st != LR_OK) return st;
-  } else if (recur_split(mode) && lr_lstm768_cluster_supported(G, B, H)) {
-    if ((size_t)D * wl.wp_per_dir * sizeof(float) < lr_lstm768_cluster_bwd_pack_bytes(D)) return LR_ERR_WORKSPACE;
-    st = lr_lstm768_cluster_backward(gates, extra, dy, dh_n, dc_n, dG, w_hh, lens, wT, wbase + wl.xch, B, T, D, stream);
+  } else if (recur_split(mode) && lr_rnn_cluster_supported(G, B, H)) {
+    if ((size_t)D * wl.wp_per_dir * sizeof(float) < lr_rnn_cluster_pack_bytes(G, H, D, 1)) return LR_ERR_WORKSPACE;
+    st = lr_rnn_cluster_backward(G, gates, extra, y, dy, dh_n, dc_n, dG, nullptr, nullptr, nullptr, nullptr, w_hh, lens,
+                                 wT, wbase + wl.xch, B, T, D, H, stream);
     if (st != LR_OK) return st;
   } else if (recur_bf16(mode)) {
     // one launch for all T steps (lr_rnn_persist.hip); dG comes out in the step kernels' layout.  The

@@ -40,7 +40,6 @@ constexpr int PH = 256;            // hidden size
 constexpr int HALF = 128;          // hidden units per pair member
 constexpr int PHLD = PH + 8;       // bf16 per LDS row of the state
 constexpr int SPIN_LIMIT = 1 << 18;   // polls before a member gives up on its partner (~0.1 s), once per launch
-__device__ int g_pair_err;            // number of members that gave up since lr_rnn_pair_errors() last read it
 
 // ---- forward geometry --------------------------------------------------------------------------------
 constexpr int FNT = 6;             // column tiles per wave: 3 gates x 2 (wave w owns units 32w .. 32w+31 of the member)
@@ -181,6 +180,7 @@ __global__ __launch_bounds__(256, 1) void gru256_fwd_pair_kernel(float* __restri
                                                                  const float* __restrict__ bhh0,
                                                                  const float* __restrict__ bhh1,
                                                                  const int32_t* __restrict__ lens, u64* __restrict__ xch,
+                                                                 int32_t* __restrict__ fault, int drop,
                                                                  int b0, int npairs, int B, int T, int D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* hS = reinterpret_cast<bf16_t*>(smem);                                                  // [2][16][PHLD]
@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256, 1) void gru256_fwd_pair_kernel(float* __restri
   int pair, m;
   pair_of(blockIdx.x, pair, m);
   if (pair >= npairs) return;      // both members of a pair beyond the range leave together
+  if (m == drop) return;           // test hook (lr_rnn_debug_drop_member): the partner must time out and report
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = b0 + pair / D, d = pair % D;
   const float* bhh = d ? bhh1 : bhh0;
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void gru256_fwd_pair_kernel(float* __restri
     step(s, gxA);
     if (s + 1 < T) step(s + 1, gxB);
   }
-  if (bad) atomicAdd(&g_pair_err, 1);
+  if (bad && fault) atomicOr(fault, 1);   // device-side: this step is skipped (lr_common.h lr_fault_words)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -396,14 +397,15 @@ __global__ void gru256_pair_pack_whh_t_kernel(const float* __restrict__ w0, cons
 __global__ __launch_bounds__(256, 1) void gru256_bwd_pair_kernel(
     const float* __restrict__ gates, const float* __restrict__ extra, const float* __restrict__ y,
     const float* __restrict__ dy, const float* __restrict__ dh_n, float* __restrict__ dG,
-    const bf16x8* __restrict__ wpk, const int32_t* __restrict__ lens, u64* __restrict__ xch, int b0, int npairs, int B,
-    int T, int D) {
+    const bf16x8* __restrict__ wpk, const int32_t* __restrict__ lens, u64* __restrict__ xch, int32_t* __restrict__ fault,
+    int drop, int b0, int npairs, int B, int T, int D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* gS = reinterpret_cast<bf16_t*>(smem);                                        // [2 parity][2 rows][BGLD]
   float* S = reinterpret_cast<float*>(smem + (size_t)2 * 2 * BGLD * 2 + 16);           // [HALF]
   int pair, m;
   pair_of(blockIdx.x, pair, m);
   if (pair >= npairs) return;
+  if (m == drop) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = b0 + pair / D, d = pair % D;
   const int col = lane & 15, kg = lane >> 4;
@@ -581,14 +583,16 @@ __global__ __launch_bounds__(256, 1) void gru256_bwd_pair_kernel(
     step(s, inA);
     if (s + 1 < T) step(s + 1, inB);
   }
-  if (bad) atomicAdd(&g_pair_err, 1);
+  if (bad && fault) atomicOr(fault, 1);   // device-side: this step is skipped (lr_common.h lr_fault_words)
 }
 
 constexpr int MAX_PAIRS = 64;   // per launch: 128 workgroups, one per CU, on a 256-CU chip (both members
                                 // of every pair must be resident at once)
 }  // namespace
 
-int lr_gru256_pair_supported(int G, int B, int H) { return G == 3 && H == PH && B >= 1 ? 1 : 0; }
+// (the two members of a pair are blocks i and i + 8 of a group of 16 consecutive blocks: they are resident together
+// on any device with at least 16 compute units)
+int lr_gru256_pair_supported(int G, int B, int H) { return G == 3 && H == PH && B >= 1 && lr_device_cus() >= 16 ? 1 : 0; }
 
 size_t lr_gru256_pair_pack_bytes(int D) { return (size_t)D * 2 * 4 * FNT * FF * 64 * sizeof(bf16x8); }
 size_t lr_gru256_pair_bwd_pack_bytes(int D) { return (size_t)D * 2 * 4 * BNT * BF * 64 * sizeof(bf16x8); }
@@ -597,17 +601,6 @@ size_t lr_gru256_pair_xch_bytes(int B, int D, int backward) {
   int pairs = B * D;
   if (pairs > MAX_PAIRS) pairs = MAX_PAIRS / D * D;
   return ((size_t)2 * pairs * 2 * (backward ? BOWN : HALF) + (size_t)pairs * 2) * sizeof(u64);   // two slots + the XCC ids
-}
-
-// number of times a member gave up waiting for its partner since the last call (0 = every result is valid);
-// synchronises the device.  Only tests and the bench's check read it.
-extern "C" int lr_rnn_pair_errors() {
-  int v = 0, zero = 0;
-  lr_clear_error();
-  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_pair_err), sizeof(int)) != hipSuccess) return -1;
-  if (v && hipMemcpyToSymbol(HIP_SYMBOL(g_pair_err), &zero, sizeof(int)) != hipSuccess) return -1;
-  const int c = lr_cluster_errors();    // the LSTM-768 cluster kernels (lr_rnn_cluster.hip)
-  return c < 0 ? -1 : v + c;
 }
 
 int lr_gru256_pair_forward(float* gates, float* extra, float* y, const float* const* w_hh, const float* const* b_hh,
@@ -637,10 +630,12 @@ int lr_gru256_pair_forward(float* gates, float* extra, float* y, const float* co
     hipEvent_t e0, e1;
     if (b0 == 0 && lr_prof_next(LR_PROF_RNN_FWD, &e0, &e1))
       hipExtLaunchKernelGGL(gru256_fwd_pair_kernel, grid, dim3(256), FWD_LDS, stream, e0, e1, 0, gates, extra, y,
-                            (const bf16x8*)wpack, b_hh[0], b_hh[D - 1], lens, (u64*)xch, b0, npairs, B, T, D);
+                            (const bf16x8*)wpack, b_hh[0], b_hh[D - 1], lens, (u64*)xch, lr_fault_words(),
+                            lr_debug_drop_member_value(), b0, npairs, B, T, D);
     else
       hipLaunchKernelGGL(gru256_fwd_pair_kernel, grid, dim3(256), FWD_LDS, stream, gates, extra, y,
-                         (const bf16x8*)wpack, b_hh[0], b_hh[D - 1], lens, (u64*)xch, b0, npairs, B, T, D);
+                         (const bf16x8*)wpack, b_hh[0], b_hh[D - 1], lens, (u64*)xch, lr_fault_words(),
+                            lr_debug_drop_member_value(), b0, npairs, B, T, D);
     st = lr_launch_status();
     if (st != LR_OK) return st;
   }
@@ -675,10 +670,12 @@ int lr_gru256_pair_backward(const float* gates, const float* extra, const float*
     hipEvent_t e0, e1;
     if (b0 == 0 && lr_prof_next(LR_PROF_RNN_BWD, &e0, &e1))
       hipExtLaunchKernelGGL(gru256_bwd_pair_kernel, grid, dim3(256), BWD_LDS, stream, e0, e1, 0, gates, extra, y, dy,
-                            dh_n, dG, (const bf16x8*)wpack, lens, (u64*)xch, b0, npairs, B, T, D);
+                            dh_n, dG, (const bf16x8*)wpack, lens, (u64*)xch, lr_fault_words(), lr_debug_drop_member_value(), b0,
+                            npairs, B, T, D);
     else
       hipLaunchKernelGGL(gru256_bwd_pair_kernel, grid, dim3(256), BWD_LDS, stream, gates, extra, y, dy, dh_n, dG,
-                         (const bf16x8*)wpack, lens, (u64*)xch, b0, npairs, B, T, D);
+                         (const bf16x8*)wpack, lens, (u64*)xch, lr_fault_words(), lr_debug_drop_member_value(), b0, npairs,
+                         B, T, D);
     st = lr_launch_status();
     if (st != LR_OK) return st;
   }

@@ -60,6 +60,8 @@ class GradSync(object):
     self._direct_hook = None
     self._held = 0
     self._closed = False
+    # {status, -(fault pending)} of the step: one MIN all-reduce carries both (see __call__)
+    self._pair = torch.zeros(2, dtype=torch.int32, device=flat.grad.device) if self.cuda else None
     if self.overlap:
       for pi, p in enumerate(params):
         self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(pi)))
@@ -173,18 +175,28 @@ class GradSync(object):
     skipped contributed zero gradients."""
     for gi in range(len(self.groups)):
       self._launch(gi)   # anything backward did not reach (or no-overlap mode)
-    if status is not None:
+    word = status
+    if self.cuda:
+      # On the GPU the exchanged word is {status, -(fault pending)}: a rank whose one-launch recurrence timed out
+      # (include/lipreading_hip.h, fault words) has put garbage into the gradient sum, so EVERY rank must skip the
+      # update (MIN of -1/0), while a batch is skipped as such only if every rank skipped it (MIN of status).
+      from . import _C
+      word = self._pair
+      _C.check(_C.lib().lr_fault_export(_C.ptr(status), word.data_ptr(), _C.stream_handle()), "lr_fault_export")
+    if word is not None:
       if self.overlap:
         self.side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.side):
-          dist.all_reduce(status, op=dist.ReduceOp.MIN, group=self.pg)
+          dist.all_reduce(word, op=dist.ReduceOp.MIN, group=self.pg)
       else:
-        self._works.append(dist.all_reduce(status, op=dist.ReduceOp.MIN, group=self.pg, async_op=True))
+        self._works.append(dist.all_reduce(word, op=dist.ReduceOp.MIN, group=self.pg, async_op=True))
     if self.overlap:
       torch.cuda.current_stream().wait_stream(self.side)
     for w in self._works:
       w.wait()
     self._works = []
+    if self.cuda:
+      _C.check(_C.lib().lr_fault_import(word.data_ptr(), _C.ptr(status), _C.stream_handle()), "lr_fault_import")
     self._reset_round()
     return 1.0 / self.world
 

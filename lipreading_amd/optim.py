@@ -46,7 +46,13 @@ class FlatParameters(object):
         p.grad = view
 
   def zero_grad(self):
-    self.grad.zero_()
+    """opt.zero_grad() (train_better_model.py:67) AND the top of a step for the device-side fault words: one launch
+    (lr_step_begin) clears the flat gradient buffer and moves a time-out raised by a one-launch recurrence of the
+    PREVIOUS step from `pending` to `total` (include/lipreading_hip.h)."""
+    if self.grad.is_cuda:
+      _C.check(_C.lib().lr_step_begin(self.grad.data_ptr(), self.numel, _C.stream_handle()), "lr_step_begin")
+    else:
+      self.grad.zero_()   # storage-only use (gloo tests on CPU)
     self.attach_grads()
 
 
@@ -59,7 +65,7 @@ class FusedAdam(object):
     dev = flat.data.device
     self.exp_avg = torch.zeros_like(flat.data)
     self.exp_avg_sq = torch.zeros_like(flat.data)
-    self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
+    self.step_count = torch.zeros(2, dtype=torch.int32, device=dev)   # [updates taken, steps skipped]
     self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
     self._scratch = torch.zeros(4, dtype=torch.float32, device=dev)
 
@@ -78,7 +84,9 @@ class FusedAdam(object):
   def step(self, grad_norm=None, grad_scale=1.0, skip=None):
     """grad_norm: max norm for clip_grad_norm_ (None = no clipping); grad_scale: multiplies the
     gradient first (1/world after an all-reduce sum); skip: int32[1] device flag — non-zero
-    leaves parameters, moments and step count untouched (the reference's `continue`)."""
+    leaves parameters, moments and step count untouched (the reference's `continue`).  The
+    kernel also reads the device-side fault word: a step whose one-launch recurrence timed out
+    (garbage gradients) updates nothing either."""
     from .encoder import flush_deferred
     flush_deferred()   # weight-gradient work still on the side stream (encoder.overlap_weight_grads)
     L = _C.lib()
@@ -95,6 +103,11 @@ class FusedAdam(object):
                             self.lr, self.betas[0], self.betas[1], self.eps,
                             self.step_count.data_ptr(), _C.ptr(skip), self._scratch.data_ptr(), st),
              "lr_adam_step")
+
+  def skipped_steps(self):
+    """Steps that updated nothing since the last reset() (a batch the reference `continue`s past, or a step whose
+    one-launch recurrence timed out); one host read."""
+    return int(self.step_count[1].item())
 
   def total_norm(self):
     """sqrt of the last sum of squares (valid after a step with grad_norm)."""

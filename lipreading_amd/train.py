@@ -19,7 +19,7 @@ from .data import BOS, EOS, PAD
 from .optim import FusedAdam
 
 
-def _check_framing(chars, char_lens, frame_lens, char2idx, use_ctc):
+def _check_framing(chars, char_lens, frame_lens, char2idx, use_ctc, in_eval=False):
   """train_better_model.py:26-33.  The loader hands chars / lengths over on the HOST (data.py's
   collate, as the reference's does), so the asserts cost no device round trip; a caller that passes
   device tensors pays one copy here.  The ascending-length requirement is ctc_loss.py:39's, so it is
@@ -28,7 +28,9 @@ def _check_framing(chars, char_lens, frame_lens, char2idx, use_ctc):
     chars, char_lens, frame_lens = chars.cpu(), char_lens.cpu(), frame_lens.cpu()
   assert (chars[:, 0].squeeze() == char2idx[BOS]).all()
   assert (chars.gather(1, (char_lens - 1).unsqueeze(dim=1)).squeeze() == char2idx[EOS]).all()
-  if use_ctc:
+  if use_ctc and not in_eval:
+    # (the reference's eval does not assert this, train_better_model.py:100-106: a caption longer than its clip makes
+    # ctc_loss skip the sample there, and does so here)
     assert (frame_lens >= char_lens).all()  # otherwise ctc loss will produce inf
   labels = chars[:, 1:]
   label_lens = char_lens - 1
@@ -75,6 +77,27 @@ def decoder_nll(log_probs, labels, pad):
   return nll / (labels != pad).sum()
 
 
+class _Held(object):
+  """`with _Held(syncs):` = every GradSync in `syncs` on hold(): gradients that become ready inside launch no
+  collective (a collective is never captured into a hipGraph, and a replay fires no hooks at all); the buckets
+  go out when the sync is called after the step."""
+
+  def __init__(self, syncs):
+    self._cms = [s.hold() for s in syncs if s is not None and hasattr(s, "hold")]
+
+  def __enter__(self):
+    for cm in self._cms:
+      cm.__enter__()
+
+  def __exit__(self, *exc):
+    for cm in reversed(self._cms):
+      cm.__exit__(*exc)
+    return False
+
+
+# what the last train() epoch skipped: {"batches", "skipped", "recurrence_faults"} (None before the first epoch)
+last_epoch_stats = None
+
 _ONES = {}
 
 
@@ -107,6 +130,7 @@ class StepGraphs(object):
   def __init__(self, max_entries=16, warmup=2, enabled=True):
     self.max_entries, self.warmup, self.enabled = max_entries, warmup, enabled
     self._entries = {}     # key -> dict(static=..., count=int, graph=CUDAGraph|None, out=...)
+    self._failed = set()   # shapes whose capture failed once: eager launches from then on, no retry
     self.replays = 0
     self.captures = 0
 
@@ -121,7 +145,7 @@ class StepGraphs(object):
   def run(self, key, inputs, body, capturable=True):
     """inputs: tuple of device tensors; body(*static_inputs) -> tuple of tensors.  Returns body's
     result for these inputs (from a replay when a graph for `key` exists)."""
-    if not (self.enabled and capturable):
+    if not (self.enabled and capturable) or key in self._failed:
       return body(*inputs)
     e = self._entries.pop(key, None)
     if e is None:
@@ -157,7 +181,7 @@ class StepGraphs(object):
     except Exception as exc:       # keep training: this shape stays on eager launches
       torch.cuda.synchronize()
       self._entries.pop(key, None)
-      self.max_entries -= 1
+      self._failed.add(key)
       print("note: hipGraph capture failed for step shape %r (%s: %s); eager launches" % (key, type(exc).__name__, exc))
       return body(*inputs)
     graph.replay()                 # capture records, it does not run
@@ -206,7 +230,8 @@ def ctc_step(encoder, opt, frames, frame_lens, chars, char_lens, grad_norm=None,
     # (the learning rate is a by-value kernel argument: part of what a graph bakes in)
     key = ("ctc", id(encoder), id(opt), opt.lr, tuple(frames.shape), str(frames.dtype), tuple(chars.shape), ml,
            grad_norm, whole)
-    loss, status = graphs.run(key, inputs, body, capturable=(ml == frames.shape[1]))
+    with _Held((grad_sync,)):   # (an overlapping GradSync must not exchange from inside a capture)
+      loss, status = graphs.run(key, inputs, body, capturable=(ml == frames.shape[1]))
   if not whole:
     scale = grad_sync(status)
     opt.step(grad_norm=grad_norm, grad_scale=scale, skip=status)
@@ -257,7 +282,8 @@ def decoder_step(encoder, decoding_step, opts, frames, frame_lens, chars, char_l
            str(frames.dtype), tuple(chars.shape), ml, L, grad_norm, whole, use_ctc)
     # only the all-teacher-forced loop has a launch sequence that does not depend on the coins; its
     # sampled tokens are not used by train(), so replaying the captured seed changes nothing
-    out = graphs.run(key, inputs, body, capturable=(all(flags) and ml == frames.shape[1]))
+    with _Held(syncs):
+      out = graphs.run(key, inputs, body, capturable=(all(flags) and ml == frames.shape[1]))
   decoder_loss = out[0]
   ctc, status = (out[1], out[2]) if use_ctc else (None, None)
   if not whole:
@@ -299,6 +325,7 @@ def train(encoder, decoding_step, data_loader, opt, device, char2idx,
   `graphs` (optional, a StepGraphs): replay each batch shape's step as one hipGraph."""
   use_ctc = encoder.enable_ctc
   pad = char2idx[PAD]
+  device = torch.device(device)
   if decoding_step is None:
     assert use_ctc, "without a decoding step the encoder must have enable_ctc=True"
     assert isinstance(opt, FusedAdam), "opt must be lipreading_amd.optim.FusedAdam"
@@ -314,6 +341,7 @@ def train(encoder, decoding_step, data_loader, opt, device, char2idx,
   encoder.train()
   ctc_sum = torch.zeros((), dtype=torch.float32, device=device)
   dec_sum = torch.zeros((), dtype=torch.float32, device=device)
+  skipped_before = opts[0].skipped_steps() if device.type == "cuda" else 0
   for frames, frame_lens, chars, char_lens in data_loader:
     _check_framing(chars, char_lens, frame_lens, char2idx, use_ctc)
     max_len = int(frame_lens.max()) if not frame_lens.is_cuda else None
@@ -340,6 +368,16 @@ def train(encoder, decoding_step, data_loader, opt, device, char2idx,
       ctc_sum += ctc
   avg_ctc_loss = (ctc_sum / len(data_loader)).item()  # :84 divides by len(data_loader)
   avg_decoder_loss = (dec_sum / len(data_loader)).item()
+  # batches that updated nothing this epoch — the reference's `continue` (:49-50) and, here, steps whose one-launch
+  # recurrence timed out (the device-side fault word made CTC / Adam skip them) — read once per epoch
+  global last_epoch_stats
+  if device.type == "cuda":
+    faults = int(_C.lib().lr_rnn_pair_errors())
+    last_epoch_stats = {"batches": len(data_loader), "skipped": opts[0].skipped_steps() - skipped_before,
+                        "recurrence_faults": faults}
+    if last_epoch_stats["skipped"] or faults:
+      print("\tSkipped batches: %(skipped)d of %(batches)d (recurrence time-outs: %(recurrence_faults)d)"
+            % last_epoch_stats)
   if decoding_step is not None:
     print(f'\tTraining decoder_loss: {avg_decoder_loss}')
   if use_ctc:
@@ -364,7 +402,7 @@ def eval(encoder, decoding_step, data_loader, device, char2idx):
   count = torch.zeros((), dtype=torch.float32, device=device)
   with torch.no_grad():
     for frames, frame_lens, chars, char_lens in data_loader:
-      _check_framing(chars, char_lens, frame_lens, char2idx, use_ctc)
+      _check_framing(chars, char_lens, frame_lens, char2idx, use_ctc, in_eval=True)
       max_len = int(frame_lens.max()) if not frame_lens.is_cuda else None
       label_lens_host = (char_lens - 1).cpu()
       frames, chars = frames.to(device), chars.to(device)

@@ -40,12 +40,13 @@ def test_fused_adam_matches_torch_adam(dev, max_norm):
     opt.step(grad_norm=max_norm)
   for a, b in zip(mod.parameters(), ref.parameters()):
     np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=2e-5, atol=2e-6)
-  assert int(opt.step_count.item()) == 5
+  assert int(opt.step_count[0].item()) == 5
   # skip flag: nothing moves, the step counter stays (train_better_model.py:49-50 `continue`)
   before = flat.data.clone()
   skip = torch.ones(1, dtype=torch.int32, device=dev)
   opt.step(grad_norm=max_norm, skip=skip)
-  assert torch.equal(before, flat.data) and int(opt.step_count.item()) == 5
+  assert torch.equal(before, flat.data) and int(opt.step_count[0].item()) == 5
+  assert opt.skipped_steps() == 1   # ... and the skip is counted on the device (train() reports it per epoch)
   # grad_scale = 1/world: same as averaging the gradient first
   opt2 = FusedAdam(flat, lr=1e-2)
   flat.grad.mul_(4.0)
