@@ -204,6 +204,9 @@ int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D);         
  *                      train_better_model.py:67) and rolls the fault words; one launch.
  * lr_rnn_debug_drop_member   TEST HOOK: member `m` (>= 0) of every pair / cluster returns at once, so its partners
  *                      time out (a few tenths of a second) and raise the fault; -1 (default) = off.
+ * lr_rnn_debug_disable_cluster   TEST HOOK: non-zero makes lr_rnn_pair_supported answer 0 for the cluster shapes
+ *                      (and the decoder loop take its step kernels), so the two paths can be compared on one
+ *                      model.  Size queries depend on it: set it BEFORE the forward whose backward it should cover.
  * lr_fault_export / lr_fault_import   data parallel (lipreading_amd/distributed.py): out2 = {status[0] (0 when
  *                      status is NULL), -(pending != 0)} for ONE MIN all-reduce over the ranks; import writes
  *                      in2[0] back to status[0] (skip the batch only if every rank skipped it) and raises the local
@@ -215,6 +218,7 @@ int lr_fault_import(const int32_t* in2, int32_t* status, lr_stream_t stream);
 void* lr_fault_words_ptr(void);
 int lr_step_begin(float* grad, int64_t n, lr_stream_t stream);
 void lr_rnn_debug_drop_member(int member);
+void lr_rnn_debug_disable_cluster(int off);
 size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D);
 size_t lr_rnn_workspace_bytes(int mode, int B, int T, int I, int H, int D);
 

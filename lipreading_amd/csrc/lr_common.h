@@ -102,7 +102,8 @@ bool lr_prof_next(int slot, hipEvent_t* start, hipEvent_t* stop);
 // include/lipreading_hip.h lr_fault_words_ptr).  NULL only when the allocation failed.
 int32_t* lr_fault_words();
 int lr_device_cus();                // compute units of the current device, 0 without one
-int lr_debug_drop_member_value();   // test hook (lr_rnn_debug_drop_member): that member of every cluster / pair exits at once
+int lr_debug_drop_member_value();
+int lr_debug_cluster_disabled();    // test hook (lr_rnn_debug_disable_cluster): lr_rnn_cluster_supported answers 0   // test hook (lr_rnn_debug_drop_member): that member of every cluster / pair exits at once
 
 // ---- recurrent layer pieces shared with lr_decoder.hip (implemented in lr_rnn.hip) --------------------
 size_t lr_rnn_packed_w_floats(int G, int H);

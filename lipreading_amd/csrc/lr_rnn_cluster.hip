@@ -853,7 +853,7 @@ int bwd_launch(const float* gates, const float* extra, const float* y, const flo
 }  // namespace
 
 int lr_rnn_cluster_supported(int G, int B, int H) {
-  if (B < 1 || H < 1) return 0;
+  if (B < 1 || H < 1 || lr_debug_cluster_disabled()) return 0;
   const int cc = (H + UPM - 1) / UPM;
   bool shape = false;
 #define X(g, c) shape = shape || (G == g && cc == c);

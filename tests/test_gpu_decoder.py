@@ -333,3 +333,57 @@ def test_fused_decoder_nll_equals_the_reference_formula(dev):
   (got * 1.7).backward()
   assert abs(float(got) - float(want)) <= 1e-6 * abs(float(want))
   np.testing.assert_allclose(x.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("rnn_type,Hd,layers,attn", [("GRU", 512, 1, "1_layer_nn"), ("LSTM", 512, 2, "general"),
+                                                     ("GRU", 256, 2, "none"), ("LSTM", 704, 1, "dot")])
+def test_decoder_loop_on_the_cluster_recurrence_equals_the_step_kernels(dev, rnn_type, Hd, layers, attn):
+  """With every step teacher forced (the shipped configs and eval) the decoder's RNN — unidirectional, started from
+  the encoder's final state (better_model.py:134-148,181) — runs each layer's L steps as ONE launch of the cluster
+  recurrence (lr_rnn_cluster.hip), and its backward returns the gradient into that initial state from the same
+  launch.  Against the per-step kernels on the same weights and inputs (test hook lr_rnn_debug_disable_cluster):
+  log-probs, final states and every gradient incl. d(h0), d(c0), d(enc)."""
+  from lipreading_amd import _C
+  from lipreading_amd.attention_decoder import CharDecodingStep
+  from lipreading_amd.data import default_char2idx
+  L_ = _C.lib()
+
+  class Enc:   # only what CharDecodingStep reads from the encoder (better_model.py:134-136)
+    hidden_size, bidirectional, num_layers = Hd // 2, True, layers
+  Enc.rnn_type = rnn_type
+  torch.manual_seed(21)
+  dec = CharDecodingStep(Enc(), 300, 64, default_char2idx(), attention_type=attn).to(dev)
+  g = torch.Generator().manual_seed(22)
+  B, T, L = 32, 75, 31
+  enc = (torch.randn(B, T, Hd, generator=g) * 0.5).to(dev)
+  lens = torch.sort(torch.randint(40, T + 1, (B,), generator=g))[0]
+  h0 = (torch.randn(layers, B, Hd, generator=g) * 0.5).to(dev)
+  c0 = (torch.randn(layers, B, Hd, generator=g) * 0.5).to(dev)
+  chars = torch.randint(4, 64, (B, L), generator=g).to(dev)
+  wgt = (torch.randn(B, L, 64, generator=g) / 100).to(dev)
+  wf = (torch.randn(layers, B, Hd, generator=g) / 50).to(dev)
+  mode = {"GRU": 0, "LSTM": 1}[rnn_type]
+  assert L_.lr_rnn_pair_supported(mode, B, L, Hd, Hd, 1) == 2
+  L_.lr_rnn_pair_errors()
+  out = {}
+  try:
+    for name, off in (("cluster", 0), ("steps", 1)):
+      L_.lr_rnn_debug_disable_cluster(off)
+      dec.zero_grad()
+      e, h, c = enc.clone().requires_grad_(True), h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+      lp, _, fin = dec.decode_sequence(chars, (h, c) if rnn_type == "LSTM" else h, lens, e, seed=5)
+      fins = fin if isinstance(fin, tuple) else (fin,)
+      ((lp * wgt).sum() + sum((f * wf).sum() for f in fins)).backward()
+      out[name] = [lp.detach().cpu()] + [f.detach().cpu() for f in fins] + [e.grad.cpu(), h.grad.cpu()] + \
+                  ([c.grad.cpu()] if rnn_type == "LSTM" else []) + [p.grad.cpu().clone() for p in dec.parameters()]
+  finally:
+    L_.lr_rnn_debug_disable_cluster(0)
+  assert L_.lr_rnn_pair_errors() == 0
+  assert float((out["cluster"][0] - out["steps"][0]).abs().max()) > 0     # the other path really ran
+  worst = 0.0
+  for a, b in zip(out["steps"], out["cluster"]):
+    # (floor: the score bias of '1_layer_nn' has a mathematically zero gradient — rounding noise on both sides)
+    rel = float((a - b).norm()) / max(1e-4, float(a.norm()))
+    worst = max(worst, rel)
+    assert rel < 3e-5, rel
+  print("decoder %s-%d x%d: cluster vs step kernels, worst relative norm difference %.3g" % (rnn_type, Hd, layers, worst))

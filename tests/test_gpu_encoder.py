@@ -156,7 +156,10 @@ def make_pair(rnn_type, H, layers, bi, dev, seed=123456):
   return ref, enc.to(dev)
 
 
+# (the reference's own shapes — LSTM-700: config/defaults.txt:19-21; LSTM-512: config/train/attn/attention_type:16-19;
+#  GRU-800: config/train/micro:6-8 — run the one-launch cluster recurrence on the DEFAULT path, like GRU-256 / LSTM-768)
 CFG = [("GRU", 256, 1, True, 32, 75), ("LSTM", 768, 1, True, 32, 75), ("GRU", 700, 1, True, 9, 40),
+       ("LSTM", 700, 1, True, 32, 75), ("LSTM", 512, 1, True, 32, 75), ("GRU", 800, 2, True, 32, 75),
        ("LSTM", 64, 2, True, 20, 33), ("GRU", 48, 2, False, 17, 21), ("LSTM", 36, 1, False, 5, 12),
        ("RNN", 256, 1, True, 32, 75), ("RNN", 52, 2, False, 11, 19)]
 
@@ -182,10 +185,16 @@ def test_encoder_forward_backward_matches_oracle(dev, rnn_type, H, layers, bi, B
       l = l + (f * 0.01).sum()
     return l
 
+  from lipreading_amd import _C
+  if rnn_type != "RNN" and H in (256, 512, 700, 768, 800):
+    # the default path IS the one-launch recurrence for these
+    assert _C.lib().lr_rnn_pair_supported({"GRU": 0, "LSTM": 1}[rnn_type], B, T, 204, H, 2 if bi else 1) in (1, 2)
+  _C.lib().lr_rnn_pair_errors()
   out_r = ref(frames, lens)
   loss_of(out_r).backward()
   out_g = enc(frames.to(dev), lens)
   loss_of(out_g).backward()
+  assert _C.lib().lr_rnn_pair_errors() == 0
   tol = 3e-5 if H <= 256 else 1e-4
   np.testing.assert_allclose(out_g[0].detach().cpu().numpy(), out_r[0].detach().numpy(), rtol=1e-4, atol=tol)
   np.testing.assert_allclose(out_g[1].detach().cpu().numpy(), out_r[1].detach().numpy(), rtol=1e-4, atol=tol)
@@ -413,20 +422,30 @@ def test_split_recurrence_is_the_default_and_meets_the_loss_bar(dev):
   assert abs(float(loss_h) - float(loss_r)) <= 1e-4 and d_lp <= 3e-5, (float(loss_h), float(loss_r), d_lp)
 
 
-@pytest.mark.parametrize("B,T,bi,lens,layers", [(32, 75, True, None, 1), (37, 20, True, "ragged", 1),
-                                                (13, 6, False, "ragged", 1), (2, 1, True, None, 1),
-                                                (12, 9, True, "ragged", 2), (70, 5, False, "ragged", 1)])
-def test_lstm768_cluster_recurrence_is_fp32_faithful(dev, B, T, bi, lens, layers):
-  """LR_RNN_RECUR_SPLIT on LSTM-768 (the ecd/* config shape): the recurrence of a layer pass in ONE launch —
-  W_hh as bf16 hi + lo planes sliced over 24 CUs per (direction, 8 samples); forward: one granule all-gather
-  of the state per step; backward: row-split partial dh, one granule reduce-scatter per step.  Against the
-  exact-fp32 step kernels on the same weights, forward and backward, final (h, c) gradients injected, ragged
-  lengths, partial sample groups (B % 8 != 0), more groups than one launch holds, two stacked layers."""
+CLUSTER_CASES = [("LSTM", 768, 32, 75, True, None, 1), ("LSTM", 768, 37, 20, True, "ragged", 1),
+                 ("LSTM", 768, 13, 6, False, "ragged", 1), ("LSTM", 768, 2, 1, True, None, 1),
+                 ("LSTM", 768, 12, 9, True, "ragged", 2), ("LSTM", 768, 70, 5, False, "ragged", 1),
+                 ("LSTM", 700, 32, 75, True, "ragged", 1), ("LSTM", 700, 11, 8, False, "ragged", 2),
+                 ("LSTM", 512, 32, 75, True, None, 1), ("LSTM", 500, 9, 7, True, "ragged", 1),
+                 ("GRU", 800, 32, 75, True, "ragged", 1), ("GRU", 800, 19, 10, False, "ragged", 2),
+                 ("GRU", 512, 32, 31, False, None, 1), ("GRU", 780, 5, 4, True, "ragged", 1),
+                 ("LSTM", 256, 20, 12, True, "ragged", 1), ("GRU", 704, 70, 5, True, "ragged", 1)]
+
+
+@pytest.mark.parametrize("rnn_type,H,B,T,bi,lens,layers", CLUSTER_CASES)
+def test_cluster_recurrence_is_fp32_faithful(dev, rnn_type, H, B, T, bi, lens, layers):
+  """LR_RNN_RECUR_SPLIT on the cluster shapes (lr_rnn_cluster.hip: GRU / LSTM, ceil(H / 32) CUs per (direction, 8
+  samples); the reference's LSTM-700 / LSTM-512 / GRU-800 / LSTM-768 and sizes that pad up to them): the recurrence
+  of a layer pass in ONE launch — W_hh as bf16 hi + lo planes sliced over the cluster; forward: one all-gather of
+  the state per step; backward: row-split partial dh, one reduce-scatter per step; self-tagged 4-byte exchange
+  words.  Against the exact-fp32 step kernels on the same weights, forward and backward, final-state gradients
+  injected, ragged lengths, partial sample groups (B % 8 != 0), hidden sizes that are not a multiple of 32, more
+  groups than one launch holds, two stacked layers."""
   from lipreading_amd import _C
   from lipreading_amd.data import default_char2idx
   from lipreading_amd.encoder import VideoEncoder
   torch.manual_seed(41)
-  enc = VideoEncoder(64, 768, rnn_type='LSTM', num_layers=layers, bidirectional=bi, enable_ctc=True,
+  enc = VideoEncoder(64, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi, enable_ctc=True,
                      vocab_size=64, char2idx=default_char2idx()).to(dev)
   g = torch.Generator().manual_seed(42)
   x = torch.randn(B, T, 64, 1, generator=g)
@@ -437,15 +456,16 @@ def test_lstm768_cluster_recurrence_is_fp32_faithful(dev, B, T, bi, lens, layers
     lens = torch.full((B,), T)
   wgt = torch.randn(B, T, 65, generator=g).to(dev)
   valid = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).float().unsqueeze(-1).to(dev)
-  assert _C.lib().lr_rnn_pair_supported(1, B, T, 64, 768, 2 if bi else 1) == 2
+  assert _C.lib().lr_rnn_pair_supported({"GRU": 0, "LSTM": 1}[rnn_type], B, T, 64, H, 2 if bi else 1) == 2
   _C.lib().lr_rnn_pair_errors()
   res = {}
   for mode in ("f32", "split"):
     enc.recurrence = mode
     enc.zero_grad()
     lp, hid, fin = enc(x.to(dev), lens, max_len=T)
-    ((lp * wgt * valid).sum() + hid.pow(2).sum() + 3.0 * fin[0].pow(2).sum() + 2.0 * fin[1].pow(2).sum()).backward()
-    res[mode] = [lp.detach().cpu() * valid.cpu(), hid.detach().cpu(), fin[0].detach().cpu(), fin[1].detach().cpu()] + \
+    fins = fin if isinstance(fin, tuple) else (fin,)
+    ((lp * wgt * valid).sum() + hid.pow(2).sum() + sum((3.0 - i) * f.pow(2).sum() for i, f in enumerate(fins))).backward()
+    res[mode] = [lp.detach().cpu() * valid.cpu(), hid.detach().cpu()] + [f.detach().cpu() for f in fins] + \
                 [p.grad.cpu().clone() for p in enc.parameters()]
   enc.recurrence = "auto"
   assert _C.lib().lr_rnn_pair_errors() == 0
@@ -455,5 +475,58 @@ def test_lstm768_cluster_recurrence_is_fp32_faithful(dev, B, T, bi, lens, layers
   for a, b in zip(res["f32"], res["split"]):
     worst = max(worst, float((a - b).norm()) / max(1e-6, float(a.norm())))
     assert float((a - b).norm()) / max(1e-6, float(a.norm())) < 2e-5
-  print("lstm768 cluster vs f32 recurrence: worst relative norm difference %.3g" % worst)
+  print("%s-%d cluster vs f32 recurrence: worst relative norm difference %.3g" % (rnn_type, H, worst))
   assert float((res["split"][1] * (1 - valid.cpu())).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rnn_type,H", [("GRU", 256), ("LSTM", 512)])
+def test_a_recurrence_time_out_skips_the_step_and_is_reported(dev, rnn_type, H, capsys):
+  """A member of a pair / cluster that never shows up (here: the test hook makes member 1 return at once) leaves
+  its partners waiting; their waits are bounded, what they produce is garbage, and the reference's contract for a
+  batch it cannot use is assert / None => skip (src/train/train_better_model.py:46-50).  Here the fault travels on
+  the device: lr_ctc_reduce reports status != 0 with loss 0, lr_adam_step leaves the weights alone, train() counts
+  the batch as skipped and reports the time-outs — no host round trip inside the step."""
+  from lipreading_amd import _C, train as T_
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.optim import FlatParameters, FusedAdam
+  L = _C.lib()
+  torch.manual_seed(3)
+  c2i = default_char2idx()
+  enc = VideoEncoder(204, H, rnn_type=rnn_type, bidirectional=True, enable_ctc=True, vocab_size=64, char2idx=c2i).to(dev)
+  opt = FusedAdam(FlatParameters(enc), lr=1e-3)
+  g = torch.Generator().manual_seed(4)
+  B, Tn = 8, 12
+  frames = torch.randn(B, Tn, 68, 3, generator=g)
+  lens = torch.full((B,), Tn)
+  chars = torch.zeros(B, 7, dtype=torch.long)
+  chars[:, 0], chars[:, 1:6], chars[:, 6] = c2i['<BOS>'], torch.randint(4, 64, (B, 5), generator=g), c2i['<EOS>']
+  char_lens = torch.full((B,), 7)
+  batch = [(frames, lens, chars, char_lens)]
+  L.lr_rnn_pair_errors()
+  # a healthy step first
+  before = opt.flat.data.clone()
+  loss, status = T_.ctc_step(enc, opt, frames.to(dev), lens.to(dev), chars.to(dev), char_lens.to(dev), grad_norm=50)
+  assert int(status) == 0 and float(loss) > 0 and not torch.equal(before, opt.flat.data)
+  assert L.lr_rnn_pair_errors() == 0
+  try:
+    L.lr_rnn_debug_drop_member(1)
+    before = opt.flat.data.clone()
+    steps_before = int(opt.step_count[0])
+    loss, status = T_.ctc_step(enc, opt, frames.to(dev), lens.to(dev), chars.to(dev), char_lens.to(dev), grad_norm=50)
+    torch.cuda.synchronize()
+    assert int(status) != 0 and float(loss) == 0.0           # reported like a batch the reference skips
+    assert torch.equal(before, opt.flat.data)                # nothing was updated
+    assert int(opt.step_count[0]) == steps_before and opt.skipped_steps() >= 1
+    # the product loop: the epoch runs through, counts the batch and names the cause
+    T_.train(enc, None, batch, opt, dev, c2i, grad_norm=50)
+    assert T_.last_epoch_stats["skipped"] == 1 and T_.last_epoch_stats["recurrence_faults"] >= 1
+    assert "recurrence time-outs" in capsys.readouterr().out
+  finally:
+    L.lr_rnn_debug_drop_member(-1)
+  # and the next healthy step is a normal step again (the fault word was rolled by lr_step_begin)
+  L.lr_rnn_pair_errors()
+  before = opt.flat.data.clone()
+  loss, status = T_.ctc_step(enc, opt, frames.to(dev), lens.to(dev), chars.to(dev), char_lens.to(dev), grad_norm=50)
+  assert int(status) == 0 and float(loss) > 0 and not torch.equal(before, opt.flat.data)
+  assert torch.isfinite(opt.flat.data).all() and L.lr_rnn_pair_errors() == 0
