@@ -2,7 +2,7 @@
 """Benchmark of the video->characters hot path on MI355X.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--regime pixels|landmarks|landmarks_attn|all]
-                  [--model gru256|lstm768] [--batch B]
+                  [--model gru256|lstm768|lstm700|lstm512|gru800] [--batch B]
 
 One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
 (frontend ->) VideoEncoder forward -> CTC 'mean' loss -> backward -> clip_grad_norm_(50) ->
@@ -43,6 +43,10 @@ MODELS = {
     # name: (rnn_type, hidden, bidirectional)
     "gru256": ("GRU", 256, True),     # LipNet-style BiGRU-256 (BASELINE configs[1] encoder)
     "lstm768": ("LSTM", 768, True),   # config/archive/experiments/ecd/* shape (configs[2])
+    # the hidden sizes of the reference's live config files (one-launch cluster recurrence, lr_rnn_cluster.hip)
+    "lstm700": ("LSTM", 700, True),   # config/defaults.txt:19-21 (hidden_size 700, LSTM)
+    "lstm512": ("LSTM", 512, True),   # config/train/attn/attention_type:16-19 (BiLSTM-512 + CTC)
+    "gru800": ("GRU", 800, True),     # config/train/micro:6-8 (GRU-800; the archived trainer stacks 5 layers: --layers 5)
 }
 T_FRAMES, N_LMK, LMK_DIM, VOCAB, LABEL_LEN, IMG = 75, 68, 3, 64, 30, 96
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -327,6 +331,10 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
   from lipreading_amd.optim import FlatParameters, FusedAdam
 
   rnn_type, H, bi = MODELS[args.model]
+  if os.environ.get("LIPREADING_RNN_DEBUG"):
+    # experiment switch (include/lipreading_hip.h lr_rnn_debug_disable_cluster): 1 = no cluster recurrence,
+    # 2 = no pair recurrence (GRU-256 then takes the 8-member cluster kernels)
+    _C.lib().lr_rnn_debug_disable_cluster(int(os.environ["LIPREADING_RNN_DEBUG"]))
   tfm = regime == "pixels_tfm"     # BASELINE configs[4]: conv features -> transformer encoder -> CTC (build-defined)
   pixels = regime == "pixels" or tfm
   attn = regime == "landmarks_attn"
@@ -547,6 +555,8 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
   # which recurrence ran, per direction of time: 'f32' one launch per step | 'split' one launch per layer pass on
   # CU pairs (GRU-256) / 24-CU clusters (LSTM-768), bf16 hi+lo planes | 'bf16' one launch per pass, single plane.
   rec, rec_bwd = "f32", "f32"
+  kind = 0                       # 1: CU pairs (GRU-256), 2: clusters of ceil(H / 32) CUs (lr_rnn_cluster.hip)
+  members = (H + 31) // 32
   if not tfm:
     mode_id = {"GRU": 0, "LSTM": 1, "RNN": 2}[rnn_type]
     want = getattr(enc, "recurrence", "f32")
@@ -556,13 +566,16 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
       kind = L.lr_rnn_pair_supported(mode_id, B, T_FRAMES, frame_dim, H, D)
       rec = rec_bwd = "split" if kind else "f32"
   res["recurrence"] = rec if rec == rec_bwd else "%s forward / %s backward" % (rec, rec_bwd)
-  pass_kernel = {("bf16", "GRU"): "gru256_%s_persist_kernel", ("split", "GRU"): "gru256_%s_pair_kernel",
-                 ("split", "LSTM"): "lstm768_%s_cluster_kernel"}
+  pass_kernel = None
+  if rec == "bf16":
+    pass_kernel = "gru256_%s_persist_kernel"
+  elif rec == "split":
+    pass_kernel = "gru256_%s_pair_kernel" if kind == 1 else "rnnc_%%s_kernel<%d,%d>" % (G, members)
   pass_names = {}
-  for slot, which, r in (("rnn_fwd_step_kernel", "fwd", rec), ("rnn_bwd_step_kernel", "bwd", rec_bwd)):
-    if (r, rnn_type) in pass_kernel and slot in by_kernel:
+  for slot, which in (("rnn_fwd_step_kernel", "fwd"), ("rnn_bwd_step_kernel", "bwd")):
+    if pass_kernel and slot in by_kernel:
       # this slot carries ONE launch per layer pass (all 75 steps), not a step
-      pass_names[slot] = pass_kernel[(r, rnn_type)] % which + " (layer pass)"
+      pass_names[slot] = pass_kernel % which + " (layer pass)"
       by_kernel[pass_names[slot]] = by_kernel.pop(slot)
   res["pair_errors"] = int(L.lr_rnn_pair_errors()) if "split" in (rec, rec_bwd) else 0
   roofline = None
@@ -618,7 +631,7 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
                               "one launch = %d steps)" % (pmc_path, T_FRAMES))
       except Exception:
         pass
-      cus = {"GRU": 2, "LSTM": 24}[rnn_type] if r_dom == "split" else 1
+      cus = (2 if kind == 1 else members) if r_dom == "split" else 1
       roofline = {"bound": "hbm", "kernel": pass_names[dom],
                   "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                   "traffic": pass_traffic, "traffic_source": pass_traffic_src,
@@ -683,7 +696,9 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
                        % (B, layers, rnn_type, H,
                           {"f32": "recurrence: one fp32-MFMA launch per time step",
                            "split": "recurrence: one launch per layer pass, W_hh and state as bf16 hi+lo planes held by a "
-                                    "pair (GRU-256) / cluster of 24 (LSTM-768) CUs, fp32 accumulation — fp32-faithful",
+                                    "%s, fp32 accumulation — fp32-faithful"
+                                    % ("pair of CUs per (sample, direction)" if kind == 1 else
+                                       "cluster of %d CUs per (direction, 8 samples)" % members),
                            "bf16": "recurrence: one launch per layer pass, bf16 operands"}[rec], D * H))
   return res
 
@@ -741,7 +756,7 @@ def main():
   if "landmarks" in order and args.regime == "all" and MODELS[args.model][0] == "GRU" and MODELS[args.model][1] == 256:
     for name in ("f32", "bf16"):
       options[name] = run_regime(args, "landmarks", world, rank, dev, recurrence=name)
-  elif "landmarks" in order and args.regime in ("all", "landmarks") and args.model == "lstm768":
+  elif "landmarks" in order and args.regime in ("all", "landmarks"):
     options["f32"] = run_regime(args, "landmarks", world, rank, dev, recurrence="f32")
   if rank == 0:
     head = results[0]

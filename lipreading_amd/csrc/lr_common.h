@@ -103,7 +103,8 @@ bool lr_prof_next(int slot, hipEvent_t* start, hipEvent_t* stop);
 int32_t* lr_fault_words();
 int lr_device_cus();                // compute units of the current device, 0 without one
 int lr_debug_drop_member_value();
-int lr_debug_cluster_disabled();    // test hook (lr_rnn_debug_disable_cluster): lr_rnn_cluster_supported answers 0   // test hook (lr_rnn_debug_drop_member): that member of every cluster / pair exits at once
+int lr_debug_cluster_disabled();    // test hook (lr_rnn_debug_disable_cluster, bit 0): lr_rnn_cluster_supported answers 0
+int lr_debug_pair_disabled();       // (bit 1): lr_gru256_pair_supported answers 0   // test hook (lr_rnn_debug_drop_member): that member of every cluster / pair exits at once
 
 // ---- recurrent layer pieces shared with lr_decoder.hip (implemented in lr_rnn.hip) --------------------
 size_t lr_rnn_packed_w_floats(int G, int H);

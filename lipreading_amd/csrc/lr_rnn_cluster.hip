@@ -83,15 +83,17 @@ struct Cfg {
   static constexpr int CF_L = CF - CF_REG;
   static constexpr size_t FWD_LDS = (size_t)2 * 16 * CLD * 2 + (size_t)4 * 2 * CF_L * 1024 + (size_t)4 * 2 * 256 * 4;
   // backward: K = the member's own dG, KB blocks of 32 (LSTM i, f, g, o; GRU dr, dz, d(W_hn h)); the HP output
-  // units are 2 CC column tiles, NT per wave; BFW fragments per tile: f = 2 * k block + plane
+  // units are 2 CC column tiles; wave w owns the two tiles of every destination member w, w + 4, ... (NT = 2 NL
+  // tiles: a wave's four accumulator values per lane and destination are ONE 16-byte store, and the wave's 64 lanes
+  // write that destination's whole 1 KB block); BFW fragments per tile: f = 2 * k block + plane
   static constexpr int KB = G;
-  static constexpr int NT = (2 * CC + 3) / 4;
+  static constexpr int NT = 2 * NL;
   static constexpr int BFW = 2 * KB;
   static constexpr int BFW_A = imin(BFW, 60 / NT);
   static constexpr int BFW_REG = imin(BFW, BFW_A + imax(1, 14 / NT));
   static constexpr int BFW_L = BFW - BFW_REG;
   static constexpr int BKLD = KB * UPM + 8;
-  static constexpr size_t BWD_LDS = (size_t)2 * 16 * BKLD * 2 + (size_t)4 * NT * BFW_L * 1024 + (size_t)NS * UPM * 4;
+  static constexpr size_t BWD_LDS = (size_t)2 * 16 * BKLD * 2 + (size_t)4 * NT * BFW_L * 1024 + (size_t)5 * XMEMBER * 4;
   static constexpr size_t FWD_PACK = (size_t)CC * 4 * 2 * CF * 64 * sizeof(bf16x8);     // per direction
   static constexpr size_t BWD_PACK = (size_t)CC * 4 * NT * BFW * 64 * sizeof(bf16x8);
 };
@@ -204,7 +206,8 @@ __global__ void rnnc_pack_fwd_kernel(const float* __restrict__ w0, const float* 
 
 // backward: out[((((d*CC + c)*4 + wave)*NT + tile)*BFW + f)*64 + lane] = plane f & 1 of W_hh[kappa + e][j], e = 0..7,
 // kappa = (f >> 1) * H + 32 c + 8 kg (k block f >> 1 = the gate whose recurrent pre-activation gradient multiplies
-// these rows), j = 16 (wave NT + tile) + col; zero where 32 c + 8 kg + e >= H or j >= H.
+// these rows), j = 32 (wave + 4 (tile >> 1)) + 16 (tile & 1) + col (the units of destination member wave + 4 (tile >> 1));
+// zero where 32 c + 8 kg + e >= H or j >= H.
 template <int G, int CC>
 __global__ void rnnc_pack_bwd_kernel(const float* __restrict__ w0, const float* __restrict__ w1, bf16x8* __restrict__ out,
                                      int D, int H) {
@@ -215,7 +218,7 @@ __global__ void rnnc_pack_bwd_kernel(const float* __restrict__ w0, const float* 
     const int wave = (int)((i / (64 * BFW * NT)) & 3), c = (int)((i / (64 * BFW * NT * 4)) % CC);
     const int d = (int)(i / ((int64_t)64 * BFW * NT * 4 * CC));
     const int col = lane & 15, kg = lane >> 4, kb = f >> 1, plane = f & 1;
-    const int j = 16 * (wave * NT + tile) + col;
+    const int j = UPM * (wave + 4 * (tile >> 1)) + 16 * (tile & 1) + col;
     const int u0 = UPM * c + 8 * kg;
     const float* src = (d ? w1 : w0) + ((int64_t)kb * H + u0) * H + j;
     bf16x8 v;
@@ -499,10 +502,14 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
 // backward recurrence (row-split, see the file header)
 // ---------------------------------------------------------------------------------------------------------------
 // Per step a member contracts its OWN dG (KB blocks x 32 units x 8 samples, bf16 hi/lo in rows 0-7 / 8-15 of the A
-// operand, one k step per block) against its rows of W_hh for ALL HP output units (2 CC column tiles, NT per wave),
-// folds the hi/lo rows, and publishes the partial dh of every unit to the member that owns it; each thread then
-// gathers the CC - 1 remote partials of its own (sample, unit) — fixed summation order — adds its own and runs the
-// cell backward (rnn_bwd_step_kernel's arithmetic).  Exchange layout: [slot][cluster][dst member][src member][sample][unit].
+// operand, one k step per block) against its rows of W_hh for ALL HP output units (2 CC column tiles; wave w owns
+// those of the destination members w, w + 4, ...), folds the hi/lo rows, and publishes the partial dh of a
+// destination's 8 x 32 (sample, unit) values as ONE store instruction: a lane's four values (two tiles x two rows)
+// are 16 contiguous bytes of the 1 KB block [slot][cluster][dst member][src member][lane][tile half][row].  The
+// gather mirrors the forward's: thread (wave ww, lane l) takes the 16 bytes of lane l from the blocks of source
+// members ww, ww + 4, ... and adds them up (fixed order); the four waves' sums and the member's own partial meet in
+// LDS, where each thread picks up the five values of its own (sample, unit) and runs the cell backward
+// (rnn_bwd_step_kernel's arithmetic).
 template <int G, int CC>
 __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
     const float* __restrict__ gates, const float* __restrict__ extra, const float* __restrict__ y,
@@ -511,11 +518,12 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
     const bf16x8* __restrict__ wpk, const int32_t* __restrict__ lens, u32* __restrict__ xch, int32_t* __restrict__ fault,
     int drop, int g0, int nclusters, int B, int T, int D, int H) {
   using C = Cfg<G, CC>;
-  constexpr int KB = C::KB, NT = C::NT, BFW = C::BFW, BFW_A = C::BFW_A, BFW_REG = C::BFW_REG, BFW_L = C::BFW_L, BKLD = C::BKLD;
+  constexpr int KB = C::KB, NT = C::NT, NL = C::NL, BFW = C::BFW, BFW_A = C::BFW_A, BFW_REG = C::BFW_REG, BFW_L = C::BFW_L,
+                BKLD = C::BKLD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* gS = reinterpret_cast<bf16_t*>(smem);                                                    // [2][16][BKLD]
   bf16x8* Wl = reinterpret_cast<bf16x8*>(smem + (size_t)2 * 16 * BKLD * 2);                        // [4][NT][BFW_L][64]
-  float* own = reinterpret_cast<float*>(smem + (size_t)2 * 16 * BKLD * 2 + (size_t)4 * NT * BFW_L * 1024);   // [NS][UPM]
+  float* red = reinterpret_cast<float*>(smem + (size_t)2 * 16 * BKLD * 2 + (size_t)4 * NT * BFW_L * 1024);   // [5][XMEMBER]: the four waves' sums of remote partials, then this member's own
   __shared__ int s_local;
   const int cluster = blockIdx.x & 7, c = blockIdx.x >> 3;
   if (cluster >= nclusters) return;
@@ -577,8 +585,16 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
   fetch(inA, time_of(0));
   fetch(inB, time_of(1));
   const int xdst = CC * XMEMBER, xcluster = CC * xdst, xslot = nclusters * xcluster;   // words (32-bit: scalar multiplies)
-  u32* xout = xch + cluster * xcluster + c * XMEMBER;                 // + dst * xdst + sample * 32 + unit
-  const u32* xin = xch + cluster * xcluster + c * xdst + tid;         // + src * XMEMBER   (tid = sample * 32 + unit)
+  u32* xout = xch + cluster * xcluster + c * XMEMBER + 4 * lane;      // + dst * xdst
+  const u32* xin = xch + cluster * xcluster + c * xdst + 4 * lane;    // + src * XMEMBER
+  // where this thread's (sample sl, unit ul) sits in a block: lane kg * 16 + col, word 2 * tile half + row
+  const int rpos = ((((sl >> 1) & 1) * 2 + (sl >> 2)) * 16 + (ul & 15)) * 4 + (ul >> 4) * 2 + (sl & 1);
+  unsigned pend0 = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int j = 4 * i + wave;
+    if (j < CC && j != c) pend0 |= 1u << i;
+  }
   int bad = 0;
   xcd_handshake<CC>(xch + 2 * xslot + cluster * CC, c, tid, &s_local, bad);   // (also: gS cleared)
   const bool local = s_local != 0;
@@ -620,42 +636,57 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
     }
     LR_MFMA_DRAIN();
     // rows 4 kg + r: rows 0-7 (kg 0, 1) came from the hi plane of dG, rows 8-15 (kg 2, 3) from the lo plane of the
-    // same samples: fold across lanes +-32.  Afterwards both halves hold sample 4 (kg & 1) + r of unit 16 (wave NT +
-    // tile) + col; the lower half publishes r = 0, 1, the upper half r = 2, 3.
+    // same samples: fold across lanes +-32.  Afterwards both halves hold sample 4 (kg & 1) + r of the tile's unit
+    // col; the lower half keeps r = 0, 1, the upper half r = 2, 3: sample 4 (kg & 1) + 2 (kg >> 1) + row.
     int slot_off = __builtin_amdgcn_readfirstlane(((s - 1) & 1) * xslot);
     asm volatile("" : "+s"(slot_off));
     u32* xo = xout + slot_off;
     const u32 tg = tag_of(s - 1);
 #pragma unroll
-    for (int tl = 0; tl < NT; ++tl) {
-      const int tile = wave * NT + tl, dstm = tile >> 1, ju = 16 * (tile & 1) + col;
+    for (int m = 0; m < NL; ++m) {
+      const int dstm = wave + 4 * m;
+      float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[tl][r] += __shfl_xor(acc[tl][r], 32, 64);
+      for (int th = 0; th < 2; ++th) {
+        f32x4& a = acc[2 * m + th];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] += __shfl_xor(a[r], 32, 64);
+        v[2 * th] = (kg >> 1) ? a[2] : a[0];
+        v[2 * th + 1] = (kg >> 1) ? a[3] : a[1];
+      }
       if (dstm < CC) {
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          const int r = 2 * (kg >> 1) + rr, smp = 4 * (kg & 1) + r;
-          const float v = (kg >> 1) ? (rr ? acc[tl][3] : acc[tl][2]) : (rr ? acc[tl][1] : acc[tl][0]);
-          if (dstm == c) own[smp * UPM + ju] = v;
-          else publish(xo + dstm * xdst + smp * UPM + ju, xword(v, tg), local);
+        if (dstm == c) {
+          *reinterpret_cast<float4*>(red + 4 * XMEMBER + 4 * lane) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          const u32x4 w = {xword(v[0], tg), xword(v[1], tg), xword(v[2], tg), xword(v[3], tg)};
+          // one 16-byte store per lane: the wave writes the destination's whole 1 KB block.  Each WORD is valid on
+          // its own, so it does not matter whether the 16 bytes land together.
+          u32* p = xo + dstm * xdst;
+          if (local) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(w) : "memory");   // workgroup scope
+          else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");   // agent scope
         }
       }
     }
-    // ---- gather the CC - 1 remote partials of this thread's (sample, unit) -----------------------------------
+    // ---- gather: the 16 bytes of this lane from the blocks of source members wave, wave + 4, ... ------------------
     const u32* xp = xin + slot_off;
-    u32 g[CC - 1];
+    u32x4 g[NL];
 #pragma unroll
-    for (int q = 1; q < CC; ++q) {
-      int jm = c + q;
-      if (jm >= CC) jm -= CC;
-      g[q - 1] = peek(xp + jm * XMEMBER);
+    for (int i = 0; i < NL; ++i) {
+      g[i] = (u32x4){0u, 0u, 0u, 0u};
+      if ((pend0 >> i) & 1u) g[i] = peek4(xp + (4 * i + wave) * XMEMBER);
     }
-    lr_lds_barrier();     // `own` complete
-    unsigned pend = (1u << (CC - 1)) - 1;
+    unsigned pend = pend0;
     for (int round = 0; pend && !bad; ++round) {
+      LR_VM_DRAIN();
 #pragma unroll
-      for (int q = 1; q < CC; ++q)
-        if (((pend >> (q - 1)) & 1u) && (g[q - 1] & 3u) == tg) pend &= ~(1u << (q - 1));
+      for (int i = 0; i < NL; ++i) LR_TOUCH(g[i]);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        if ((pend >> i) & 1u) {
+          const u32x4 v = g[i];
+          if ((((v[0] ^ tg) | (v[1] ^ tg) | (v[2] ^ tg) | (v[3] ^ tg)) & 3u) == 0u) pend &= ~(1u << i);
+        }
+      }
       if (!pend) break;
       if (round > SPIN_LIMIT) {
         bad = 1;
@@ -663,19 +694,28 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
       }
       __builtin_amdgcn_s_sleep(2);
 #pragma unroll
-      for (int q = 1; q < CC; ++q) {
-        if ((pend >> (q - 1)) & 1u) {
-          int jm = c + q;
-          if (jm >= CC) jm -= CC;
-          g[q - 1] = peek(xp + jm * XMEMBER);
+      for (int i = 0; i < NL; ++i)
+        if ((pend >> i) & 1u) g[i] = peek4(xp + (4 * i + wave) * XMEMBER);
+    }
+    {   // this wave's sum over its source members, in FIXED order; absent sweeps hold zeros
+      float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+      if (!bad) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          if ((pend0 >> i) & 1u) {
+            p0 += xval(g[i][0]);
+            p1 += xval(g[i][1]);
+            p2 += xval(g[i][2]);
+            p3 += xval(g[i][3]);
+          }
         }
       }
+      *reinterpret_cast<float4*>(red + wave * XMEMBER + 4 * lane) = make_float4(p0, p1, p2, p3);
     }
-    float prod = own[sl * UPM + ul];
-    if (!bad) {   // every g[] now holds its word: sum in FIXED order (rotated by the member index)
+    lr_lds_barrier();     // `red` complete
+    float prod = red[4 * XMEMBER + rpos];
 #pragma unroll
-      for (int q = 1; q < CC; ++q) prod += xval(g[q - 1]);
-    }
+    for (int w = 0; w < 4; ++w) prod += red[w * XMEMBER + rpos];
     return prod;
   };
 
@@ -749,7 +789,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
 #pragma unroll
       for (int k = 0; k < 4; ++k) dgo[(int64_t)k * H] = dgv[k];
     }
-    lr_lds_barrier();   // gnxt complete; `own` free again
+    lr_lds_barrier();   // gnxt complete; `red` free again
   };
   const int nsteps = dh0 ? T + 1 : T;   // with dh0: one more product + reduce-scatter after the last step
   for (int s = 0; s < nsteps; s += 2) {
@@ -848,7 +888,8 @@ int bwd_launch(const float* gates, const float* extra, const float* y, const flo
 //   CC = 22  H in (672, 704]   LSTM-700 (config/defaults.txt)
 //   CC = 24  H in (736, 768]   LSTM-768 (config/archive/experiments/ecd)
 //   CC = 25  H in (768, 800]   GRU-800 (config/train/micro)
-#define LR_CLUSTER_SHAPES(X) X(3, 8) X(4, 8) X(3, 16) X(4, 16) X(3, 22) X(4, 22) X(3, 24) X(4, 24) X(3, 25) X(4, 25)
+// (LSTM with 25 members — no reference config — would need 168 KB of LDS for its backward fragments: step kernels)
+#define LR_CLUSTER_SHAPES(X) X(3, 8) X(4, 8) X(3, 16) X(4, 16) X(3, 22) X(4, 22) X(3, 24) X(4, 24) X(3, 25)
 
 }  // namespace
 

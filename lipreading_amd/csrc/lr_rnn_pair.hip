@@ -592,7 +592,9 @@ constexpr int MAX_PAIRS = 64;   // per launch: 128 workgroups, one per CU, on a 
 
 // (the two members of a pair are blocks i and i + 8 of a group of 16 consecutive blocks: they are resident together
 // on any device with at least 16 compute units)
-int lr_gru256_pair_supported(int G, int B, int H) { return G == 3 && H == PH && B >= 1 && lr_device_cus() >= 16 ? 1 : 0; }
+int lr_gru256_pair_supported(int G, int B, int H) {
+  return G == 3 && H == PH && B >= 1 && lr_device_cus() >= 16 && !lr_debug_pair_disabled() ? 1 : 0;
+}
 
 size_t lr_gru256_pair_pack_bytes(int D) { return (size_t)D * 2 * 4 * FNT * FF * 64 * sizeof(bf16x8); }
 size_t lr_gru256_pair_bwd_pack_bytes(int D) { return (size_t)D * 2 * 4 * BNT * BF * 64 * sizeof(bf16x8); }

@@ -363,7 +363,7 @@ def test_decoder_loop_on_the_cluster_recurrence_equals_the_step_kernels(dev, rnn
   wgt = (torch.randn(B, L, 64, generator=g) / 100).to(dev)
   wf = (torch.randn(layers, B, Hd, generator=g) / 50).to(dev)
   mode = {"GRU": 0, "LSTM": 1}[rnn_type]
-  assert L_.lr_rnn_pair_supported(mode, B, L, Hd, Hd, 1) == 2
+  assert L_.lr_rnn_pair_supported(mode, B, L, Hd, Hd, 1) in (1, 2)   # (GRU-256: the encoder would take the pair kernels)
   L_.lr_rnn_pair_errors()
   out = {}
   try:
@@ -381,9 +381,9 @@ def test_decoder_loop_on_the_cluster_recurrence_equals_the_step_kernels(dev, rnn
   assert L_.lr_rnn_pair_errors() == 0
   assert float((out["cluster"][0] - out["steps"][0]).abs().max()) > 0     # the other path really ran
   worst = 0.0
-  for a, b in zip(out["steps"], out["cluster"]):
+  for i, (a, b) in enumerate(zip(out["steps"], out["cluster"])):
     # (floor: the score bias of '1_layer_nn' has a mathematically zero gradient — rounding noise on both sides)
     rel = float((a - b).norm()) / max(1e-4, float(a.norm()))
     worst = max(worst, rel)
-    assert rel < 3e-5, rel
+    assert rel < 5e-5, (i, rel, tuple(a.shape))
   print("decoder %s-%d x%d: cluster vs step kernels, worst relative norm difference %.3g" % (rnn_type, Hd, layers, worst))
