@@ -206,7 +206,8 @@ int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D);         
  *                      time out (a few tenths of a second) and raise the fault; -1 (default) = off.
  * lr_rnn_debug_disable_cluster   TEST HOOK: bit 0 makes lr_rnn_pair_supported answer 0 for the cluster shapes
  *                      (and the decoder loop take its step kernels), bit 1 switches the GRU-256 pair kernels off
- *                      (GRU-256 then takes the 8-member cluster kernels), so the paths can be compared on one
+ *                      (GRU-256 then takes the 8-member cluster kernels), bit 2 keeps the weight gradients of
+ *                      LR_RNN_RECUR_SPLIT layers on the fp32 grouped GEMM, so the paths can be compared on one
  *                      model.  Size queries depend on it: set it BEFORE the forward whose backward it should cover.
  * lr_fault_export / lr_fault_import   data parallel (lipreading_amd/distributed.py): out2 = {status[0] (0 when
  *                      status is NULL), -(pending != 0)} for ONE MIN all-reduce over the ranks; import writes

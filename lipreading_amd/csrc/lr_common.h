@@ -104,7 +104,8 @@ int32_t* lr_fault_words();
 int lr_device_cus();                // compute units of the current device, 0 without one
 int lr_debug_drop_member_value();
 int lr_debug_cluster_disabled();    // test hook (lr_rnn_debug_disable_cluster, bit 0): lr_rnn_cluster_supported answers 0
-int lr_debug_pair_disabled();       // (bit 1): lr_gru256_pair_supported answers 0   // test hook (lr_rnn_debug_drop_member): that member of every cluster / pair exits at once
+int lr_debug_pair_disabled();       // (bit 1): lr_gru256_pair_supported answers 0
+int lr_debug_wgrad_f32();           // (bit 2): LR_RNN_RECUR_SPLIT layers keep their weight gradients on the fp32 grouped GEMM   // test hook (lr_rnn_debug_drop_member): that member of every cluster / pair exits at once
 
 // ---- recurrent layer pieces shared with lr_decoder.hip (implemented in lr_rnn.hip) --------------------
 size_t lr_rnn_packed_w_floats(int G, int H);
@@ -182,7 +183,7 @@ extern "C" size_t lr_xgemm_workspace_bytes(int transA, int transB, int M, int N,
 // the three products of a recurrent layer's input projection with all D directions in one
 // contraction each (gates / dG hold the directions side by side in a row; dstride = floats between
 // the directions' blocks of a dG row)
-size_t lr_xproj_workspace_bytes(int R, int I, int GH, int D);
+size_t lr_xproj_workspace_bytes(int R, int I, int GH, int D, int H);
 int lr_xproj_forward(const float* x, int R, int I, const float* const* w_ih, int GH, int D, const float* bias,
                      float* gates, int x_exact, int x_bf16, void* workspace, size_t workspace_bytes,
                      hipStream_t stream);

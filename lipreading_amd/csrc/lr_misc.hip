@@ -460,7 +460,7 @@ namespace {
 constexpr int kMaxDevices = 64;
 int32_t* g_fault_words[kMaxDevices];
 int g_drop_member = -1;
-int g_cluster_off = 0;   // bit 0: no cluster recurrence; bit 1: no pair recurrence (GRU-256 then takes the cluster kernels)
+int g_cluster_off = 0;   // bit 0: no cluster recurrence; bit 1: no pair recurrence; bit 2: weight gradients on the fp32 grouped GEMM
 __global__ void step_begin_kernel(float4* __restrict__ g, int64_t n4, float* __restrict__ tail, int ntail,
                                   int32_t* __restrict__ fault) {
   const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -530,6 +530,7 @@ extern "C" void lr_rnn_debug_drop_member(int member) { g_drop_member = member; }
 extern "C" void lr_rnn_debug_disable_cluster(int off) { g_cluster_off = off; }
 int lr_debug_cluster_disabled() { return g_cluster_off & 1; }
 int lr_debug_pair_disabled() { return (g_cluster_off >> 1) & 1; }
+int lr_debug_wgrad_f32() { return (g_cluster_off >> 2) & 1; }
 
 extern "C" int lr_rnn_pair_errors(void) {
   int32_t* w = lr_fault_words();

@@ -546,10 +546,10 @@ Layout reserve_layout(int G, int B, int T, int I, int H, int D, bool x3 = false)
   l.hp = l.wp + (size_t)D * l.wp_per_dir;
   l.hp_floats = 2 * (size_t)D * nbt * nchunk * FRAG;
   l.gemm = l.hp + l.hp_floats;                               // split-K slabs of the input projection
-  l.gemm_bytes = x3 ? lr_xproj_workspace_bytes(B * T, I, G * H, D) : lr_sgemm_workspace_bytes(B * T, G * H, I);
+  l.gemm_bytes = x3 ? lr_xproj_workspace_bytes(B * T, I, G * H, D, H) : lr_sgemm_workspace_bytes(B * T, G * H, I);
   l.xch = (l.gemm + (l.gemm_bytes + 3) / 4 + 63) / 64 * 64;   // granule exchange of the pair recurrence
-  l.xch_bytes = lr_gru256_pair_supported(G, B, H) ? lr_gru256_pair_xch_bytes(B, D, 0)
-                : (lr_rnn_cluster_supported(G, B, H) ? lr_rnn_cluster_xch_bytes(B, H, D, 0) : 0);
+  l.xch_bytes = lr_rnn_cluster_supported(G, B, H) ? lr_rnn_cluster_xch_bytes(B, H, D, 0)
+                : (lr_gru256_pair_supported(G, B, H) ? lr_gru256_pair_xch_bytes(B, D, 0) : 0);
   l.total = l.xch + (l.xch_bytes + 3) / 4;
   return l;
 }
@@ -597,8 +597,8 @@ WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
   }
   l.gemm_bytes = gb;
   l.xch = (l.gemm + (gb + 3) / 4 + 63) / 64 * 64;
-  l.xch_bytes = lr_gru256_pair_supported(G, B, H) ? lr_gru256_pair_xch_bytes(B, D, 1)
-                : (lr_rnn_cluster_supported(G, B, H) ? lr_rnn_cluster_xch_bytes(B, H, D, 1) : 0);
+  l.xch_bytes = lr_rnn_cluster_supported(G, B, H) ? lr_rnn_cluster_xch_bytes(B, H, D, 1)
+                : (lr_gru256_pair_supported(G, B, H) ? lr_gru256_pair_xch_bytes(B, D, 1) : 0);
   l.total = l.xch + (l.xch_bytes + 3) / 4;
   return l;
 }
@@ -622,7 +622,15 @@ bool dims_ok(int mode, int B, int T, int I, int H, int D) {
 // extra workspace floats of the bf16x3 input projection's backward (operand planes + split-K slabs
 // of the larger of its products, all directions in one contraction)
 size_t x3_ws_floats(int G, int B, int T, int I, int H, int D) {
-  return (lr_xproj_workspace_bytes(B * T, I, G * H, D) / sizeof(float) + 63) / 64 * 64;
+  return (lr_xproj_workspace_bytes(B * T, I, G * H, D, H) / sizeof(float) + 63) / 64 * 64;
+}
+// The weight gradients of a layer whose recurrence runs fp32-FAITHFUL on the bf16 matrix cores (LR_RNN_RECUR_SPLIT)
+// take the same route: dW_ih and dW_hh as split-bf16 products (bf16 hi + lo operand planes, three cross terms, fp32
+// accumulation: ~1e-5 of the fp32 product, lr_xgemm.hip) instead of the fp32-MFMA grouped GEMM — at LSTM-768 that
+// GEMM was 325 us of a 1.22 ms step at 56 % of the fp32 matrix peak.  Small layers stay on the grouped fp32 GEMM
+// (one launch + one combine beats two packs + two contractions + two combines).
+bool wgrad_split(int mode, int G, int H) {
+  return recur_split(mode) && !proj_x3(mode) && G * H >= 768 && !lr_debug_wgrad_f32();
 }
 
 }  // namespace
@@ -634,10 +642,11 @@ extern "C" int lr_rnn_persistent_supported(int mode, int B, int T, int I, int H,
 
 extern "C" int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D)) return 0;
-  // 1: GRU-256 (CU pairs); 2: clusters of ceil(H / 32) CUs (lr_rnn_cluster.hip: GRU / LSTM, H up to 800 in the
-  // instantiated sizes); both passes of either kind
-  if (lr_gru256_pair_supported(gates_of(mode), B, H)) return 1;
-  return lr_rnn_cluster_supported(gates_of(mode), B, H) ? 2 : 0;
+  // 2: clusters of ceil(H / 32) CUs (lr_rnn_cluster.hip: GRU / LSTM, H up to 800 in the instantiated sizes — GRU-256
+  // included: the 8-member cluster measured 118 + 131 us per layer pass against the pair kernels' 125 + 160);
+  // 1: GRU-256 on CU pairs (lr_rnn_pair.hip), where a device is too small for a cluster launch; both passes of either
+  if (lr_rnn_cluster_supported(gates_of(mode), B, H)) return 2;
+  return lr_gru256_pair_supported(gates_of(mode), B, H) ? 1 : 0;
 }
 
 extern "C" size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D) {
@@ -648,7 +657,8 @@ extern "C" size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int
 extern "C" size_t lr_rnn_workspace_bytes(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D)) return 0;
   const int G = gates_of(mode);
-  return ((ws_layout(G, B, T, I, H, D).total + 63) / 64 * 64 + (proj_x3(mode) ? x3_ws_floats(G, B, T, I, H, D) : 0)) *
+  return ((ws_layout(G, B, T, I, H, D).total + 63) / 64 * 64 +
+          ((proj_x3(mode) || wgrad_split(mode, G, H)) ? x3_ws_floats(G, B, T, I, H, D) : 0)) *
          sizeof(float);
 }
 
@@ -702,13 +712,13 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
     // one launch for all T steps, fp32-faithful (lr_rnn_pair.hip); same interface buffers as the step kernels;
     // the step kernels' packed-W_hh area of the reserve holds the bf16 hi/lo fragments instead
     int st;
-    if (lr_gru256_pair_supported(G, B, H)) {
-      if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_gru256_pair_pack_bytes(D)) return LR_ERR_WORKSPACE;
-      st = lr_gru256_pair_forward(gates, extra, y, w_hh, b_hh, lens, base + l.wp, base + l.xch, B, T, D, stream);
-    } else if (lr_rnn_cluster_supported(G, B, H)) {
+    if (lr_rnn_cluster_supported(G, B, H)) {
       if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_rnn_cluster_pack_bytes(G, H, D, 0)) return LR_ERR_WORKSPACE;
       st = lr_rnn_cluster_forward(G, gates, extra, y, w_hh, b_hh, nullptr, nullptr, lens, base + l.wp, base + l.xch, B, T,
                                   D, H, stream);
+    } else if (lr_gru256_pair_supported(G, B, H)) {
+      if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_gru256_pair_pack_bytes(D)) return LR_ERR_WORKSPACE;
+      st = lr_gru256_pair_forward(gates, extra, y, w_hh, b_hh, lens, base + l.wp, base + l.xch, B, T, D, stream);
     } else {
       return LR_ERR_UNSUPPORTED;
     }
@@ -806,8 +816,10 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
   if (reserve_bytes < rl.total * sizeof(float)) return LR_ERR_WORKSPACE;
   const WsLayout wl = ws_layout(G, B, T, I, H, D);
   const bool x3 = proj_x3(mode);
+  const bool wx = wgrad_split(mode, G, H);   // weight gradients as split-bf16 products (see wgrad_split)
   const size_t xws_off = (wl.total + 63) / 64 * 64;   // floats; keeps the bf16 planes 16-byte aligned
-  if (workspace_bytes < (x3 ? xws_off + x3_ws_floats(G, B, T, I, H, D) : wl.total) * sizeof(float)) return LR_ERR_WORKSPACE;
+  if (workspace_bytes < ((x3 || wx) ? xws_off + x3_ws_floats(G, B, T, I, H, D) : wl.total) * sizeof(float))
+    return LR_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   const float* rbase = (const float*)reserve;
   const float* gates = rbase + rl.gates;
@@ -822,15 +834,15 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
   int st = LR_OK;
   if (!(parts & 1)) {
     // dG is already in the workspace
-  } else if (recur_split(mode) && lr_gru256_pair_supported(G, B, H)) {
-    if (dc_n) return LR_ERR_UNSUPPORTED;
-    if ((size_t)D * wl.wp_per_dir * sizeof(float) < lr_gru256_pair_bwd_pack_bytes(D)) return LR_ERR_WORKSPACE;
-    st = lr_gru256_pair_backward(gates, extra, y, dy, dh_n, dG, w_hh, lens, wT, wbase + wl.xch, B, T, D, stream);
-    if (st != LR_OK) return st;
   } else if (recur_split(mode) && lr_rnn_cluster_supported(G, B, H)) {
     if ((size_t)D * wl.wp_per_dir * sizeof(float) < lr_rnn_cluster_pack_bytes(G, H, D, 1)) return LR_ERR_WORKSPACE;
     st = lr_rnn_cluster_backward(G, gates, extra, y, dy, dh_n, dc_n, dG, nullptr, nullptr, nullptr, nullptr, w_hh, lens,
                                  wT, wbase + wl.xch, B, T, D, H, stream);
+    if (st != LR_OK) return st;
+  } else if (recur_split(mode) && lr_gru256_pair_supported(G, B, H)) {
+    if (dc_n) return LR_ERR_UNSUPPORTED;
+    if ((size_t)D * wl.wp_per_dir * sizeof(float) < lr_gru256_pair_bwd_pack_bytes(D)) return LR_ERR_WORKSPACE;
+    st = lr_gru256_pair_backward(gates, extra, y, dy, dh_n, dG, w_hh, lens, wT, wbase + wl.xch, B, T, D, stream);
     if (st != LR_OK) return st;
   } else if (recur_bf16(mode)) {
     // one launch for all T steps (lr_rnn_persist.hip); dG comes out in the step kernels' layout.  The
@@ -878,7 +890,7 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
   const int R = B * T;
   const int ldg = D * 4 * H;
   void* xws = wbase + xws_off;   // bf16x3 input projection: operand planes + split-K slabs
-  const size_t xws_bytes = x3 ? x3_ws_floats(G, B, T, I, H, D) * sizeof(float) : 0;
+  const size_t xws_bytes = (x3 || wx) ? x3_ws_floats(G, B, T, I, H, D) * sizeof(float) : 0;
   if (x3) {
     // input projection: all directions in one contraction per product (lr_xgemm.hip)
     if ((parts & 1) && dx) {
@@ -895,7 +907,14 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
     st = lr_xproj_dwhh(dG, ldg, y, D * H, R, T, H, G, D, dw_hh, wbeta, xws, xws_bytes, stream);
     if (st != LR_OK) return st;
   }
-  if (!x3) {
+  if (wx) {
+    // fp32-faithful on the bf16 matrix cores, like the recurrence that produced dG (lr_xgemm.hip)
+    st = lr_xproj_dw(dG, ldg, 4 * H, x, R, I, GH, D, dw_ih, wbeta, 0, 0, xws, xws_bytes, stream);
+    if (st != LR_OK) return st;
+    st = lr_xproj_dwhh(dG, ldg, y, D * H, R, T, H, G, D, dw_hh, wbeta, xws, xws_bytes, stream);
+    if (st != LR_OK) return st;
+  }
+  if (!x3 && !wx) {
     // every weight gradient of the layer in ONE grouped launch + one combine (lr_gemm.hip): each of these
     // small-M*N, K = B*T products fills a sixth of the chip on its own.
     //   dW_ih[d] (G*H x I) = dGx^T (slots 0..G-1 are contiguous rows) @ x

@@ -587,15 +587,16 @@ int lr_xgemm_impl(int transA, int transB, int M, int N, int K, float alpha, cons
 // (lr_rnn.hip, LR_RNN_PROJ_BF16X3).  R = B*T rows, I input features, GH gate rows per direction, D
 // directions; gates / dG keep the directions side by side in a row (leading dimensions ldgates, ldg).
 // Every product packs all of its operand blocks in one launch (PackList).
-size_t lr_xproj_workspace_bytes(int R, int I, int GH, int D) {
-  if (R <= 0 || I <= 0 || GH <= 0 || D <= 0) return 0;
+size_t lr_xproj_workspace_bytes(int R, int I, int GH, int D, int H) {
+  if (R <= 0 || I <= 0 || GH <= 0 || D <= 0 || H <= 0) return 0;
   size_t a = lr_xgemm_workspace_bytes(0, 1, R, D * GH, I);
   size_t b = lr_xgemm_workspace_bytes(1, 0, D * GH, I, R);
   if (b > a) a = b;
   b = lr_xgemm_workspace_bytes(0, 0, R, I, D * GH);
   if (b > a) a = b;
-  // recurrent weight gradient: D batched products GH x H' over K = R, H' <= GH
-  b = (size_t)D * (plane_floats(GH, R, false) + plane_floats(GH, R, false) + pad64((size_t)16 * GH * GH)) * sizeof(float);
+  // recurrent weight gradient: D batched products GH x H over K = R (lr_xproj_dwhh) and their split-K slabs
+  b = ((size_t)D * (plane_floats(GH, R, false) + plane_floats(H, R, false)) +
+       pad64((size_t)want_splits(GH, H * D, R) * GH * H * D)) * sizeof(float);
   if (b > a) a = b;
   return a;
 }

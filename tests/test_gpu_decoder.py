@@ -374,7 +374,8 @@ def test_decoder_loop_on_the_cluster_recurrence_equals_the_step_kernels(dev, rnn
       lp, _, fin = dec.decode_sequence(chars, (h, c) if rnn_type == "LSTM" else h, lens, e, seed=5)
       fins = fin if isinstance(fin, tuple) else (fin,)
       ((lp * wgt).sum() + sum((f * wf).sum() for f in fins)).backward()
-      out[name] = [lp.detach().cpu()] + [f.detach().cpu() for f in fins] + [e.grad.cpu(), h.grad.cpu()] + \
+      egrad = e.grad if e.grad is not None else torch.zeros_like(e)    # (attention 'none' never reads the encoder states)
+      out[name] = [lp.detach().cpu()] + [f.detach().cpu() for f in fins] + [egrad.cpu(), h.grad.cpu()] + \
                   ([c.grad.cpu()] if rnn_type == "LSTM" else []) + [p.grad.cpu().clone() for p in dec.parameters()]
   finally:
     L_.lr_rnn_debug_disable_cluster(0)

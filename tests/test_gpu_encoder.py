@@ -348,10 +348,13 @@ def test_bf16_recurrence_against_the_oracle_at_the_bench_shape(dev):
                                          (40, 30, True, "ragged"),      # more pairs than one launch holds: chunked
                                          (70, 9, False, "ragged"),      # unidirectional: 64 samples per launch + 6
                                          (3, 1, True, None), (5, 2, True, [2, 1, 2, 1, 1])])
-def test_split_recurrence_is_fp32_faithful(dev, B, T, bi, lens):
-  """LR_RNN_RECUR_SPLIT (VideoEncoder's default where supported: GRU, H = 256): the whole recurrence of a
-  layer pass in one launch, a pair of CUs per (sample, direction), W_hh and the state as bf16 hi + lo
-  planes.  Against the exact-fp32 step kernels on the same weights (2 layers: the second layer's input is
+@pytest.mark.parametrize("kernels", ["pair", "cluster"])
+def test_split_recurrence_is_fp32_faithful(dev, B, T, bi, lens, kernels):
+  """LR_RNN_RECUR_SPLIT (VideoEncoder's default where supported) on GRU, H = 256: the whole recurrence of a
+  layer pass in one launch, W_hh and the state as bf16 hi + lo planes — on the 8-member cluster kernels
+  (lr_rnn_cluster.hip, the default since round 3: 118 + 131 us per pass) and on the CU-pair kernels
+  (lr_rnn_pair.hip: 125 + 160 us; what a device too small for a cluster launch runs — selected here by switching
+  the cluster kernels off).  Against the exact-fp32 step kernels on the same weights (2 layers: the second layer's input is
   the first's output), forward and backward, ragged lengths, final-state gradient injected: agreement to
   ~1e-5 relative — two orders tighter than the single-plane bf16 kernel — and no pair ever timed out."""
   from lipreading_amd import _C
@@ -371,16 +374,20 @@ def test_split_recurrence_is_fp32_faithful(dev, B, T, bi, lens):
     lens = torch.tensor(lens)
   wgt = torch.randn(B, T, 65, generator=g).to(dev)
   valid = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).float().unsqueeze(-1).to(dev)
-  assert _C.lib().lr_rnn_pair_supported(0, B, T, 96, 256, 2 if bi else 1) == 1
-  _C.lib().lr_rnn_pair_errors()
-  res = {}
-  for mode in ("f32", "split"):
-    enc.recurrence = mode
-    enc.zero_grad()
-    lp, hid, fin = enc(x.to(dev), lens, max_len=T)
-    ((lp * wgt * valid).sum() + hid.pow(2).sum() + 3.0 * fin.pow(2).sum()).backward()
-    res[mode] = [lp.detach().cpu() * valid.cpu(), hid.detach().cpu(), fin.detach().cpu()] + \
-                [p.grad.cpu().clone() for p in enc.parameters()]
+  _C.lib().lr_rnn_debug_disable_cluster(1 if kernels == "pair" else 0)
+  try:
+    assert _C.lib().lr_rnn_pair_supported(0, B, T, 96, 256, 2 if bi else 1) == (1 if kernels == "pair" else 2)
+    _C.lib().lr_rnn_pair_errors()
+    res = {}
+    for mode in ("f32", "split"):
+      enc.recurrence = mode
+      enc.zero_grad()
+      lp, hid, fin = enc(x.to(dev), lens, max_len=T)
+      ((lp * wgt * valid).sum() + hid.pow(2).sum() + 3.0 * fin.pow(2).sum()).backward()
+      res[mode] = [lp.detach().cpu() * valid.cpu(), hid.detach().cpu(), fin.detach().cpu()] + \
+                  [p.grad.cpu().clone() for p in enc.parameters()]
+  finally:
+    _C.lib().lr_rnn_debug_disable_cluster(0)
   enc.recurrence = "auto"
   assert _C.lib().lr_rnn_pair_errors() == 0
   if T > 1:
@@ -479,8 +486,8 @@ def test_cluster_recurrence_is_fp32_faithful(dev, rnn_type, H, B, T, bi, lens, l
   assert float((res["split"][1] * (1 - valid.cpu())).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("rnn_type,H", [("GRU", 256), ("LSTM", 512)])
-def test_a_recurrence_time_out_skips_the_step_and_is_reported(dev, rnn_type, H, capsys):
+@pytest.mark.parametrize("rnn_type,H,pair", [("GRU", 256, False), ("GRU", 256, True), ("LSTM", 512, False)])
+def test_a_recurrence_time_out_skips_the_step_and_is_reported(dev, rnn_type, H, pair, capsys):
   """A member of a pair / cluster that never shows up (here: the test hook makes member 1 return at once) leaves
   its partners waiting; their waits are bounded, what they produce is garbage, and the reference's contract for a
   batch it cannot use is assert / None => skip (src/train/train_better_model.py:46-50).  Here the fault travels on
@@ -504,6 +511,7 @@ def test_a_recurrence_time_out_skips_the_step_and_is_reported(dev, rnn_type, H, 
   char_lens = torch.full((B,), 7)
   batch = [(frames, lens, chars, char_lens)]
   L.lr_rnn_pair_errors()
+  L.lr_rnn_debug_disable_cluster(1 if pair else 0)      # pair: the CU-pair kernels instead of the cluster kernels
   # a healthy step first
   before = opt.flat.data.clone()
   loss, status = T_.ctc_step(enc, opt, frames.to(dev), lens.to(dev), chars.to(dev), char_lens.to(dev), grad_norm=50)
@@ -525,8 +533,11 @@ def test_a_recurrence_time_out_skips_the_step_and_is_reported(dev, rnn_type, H, 
   finally:
     L.lr_rnn_debug_drop_member(-1)
   # and the next healthy step is a normal step again (the fault word was rolled by lr_step_begin)
-  L.lr_rnn_pair_errors()
-  before = opt.flat.data.clone()
-  loss, status = T_.ctc_step(enc, opt, frames.to(dev), lens.to(dev), chars.to(dev), char_lens.to(dev), grad_norm=50)
-  assert int(status) == 0 and float(loss) > 0 and not torch.equal(before, opt.flat.data)
-  assert torch.isfinite(opt.flat.data).all() and L.lr_rnn_pair_errors() == 0
+  try:
+    L.lr_rnn_pair_errors()
+    before = opt.flat.data.clone()
+    loss, status = T_.ctc_step(enc, opt, frames.to(dev), lens.to(dev), chars.to(dev), char_lens.to(dev), grad_norm=50)
+    assert int(status) == 0 and float(loss) > 0 and not torch.equal(before, opt.flat.data)
+    assert torch.isfinite(opt.flat.data).all() and L.lr_rnn_pair_errors() == 0
+  finally:
+    L.lr_rnn_debug_disable_cluster(0)
