@@ -201,7 +201,8 @@ int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D);         
  * lr_rnn_pair_errors   pending + total since the last call, and clears both; synchronises the device (once per
  *                      epoch in train(), tests, bench).
  * lr_step_begin        zeroes the flat gradient buffer grad[0..n) (16-byte aligned; what opt.zero_grad() does,
- *                      train_better_model.py:67) and rolls the fault words; one launch.
+ *                      train_better_model.py:67) and rolls the fault words; also_zero (may be NULL): one more float
+ *                      to clear (the accumulator lr_sumsq adds into); one launch.
  * lr_rnn_debug_drop_member   TEST HOOK: member `m` (>= 0) of every pair / cluster returns at once, so its partners
  *                      time out (a few tenths of a second) and raise the fault; -1 (default) = off.
  * lr_rnn_debug_disable_cluster   TEST HOOK: bit 0 makes lr_rnn_pair_supported answer 0 for the cluster shapes
@@ -218,7 +219,7 @@ int lr_rnn_pair_errors(void);
 int lr_fault_export(const int32_t* status, int32_t* out2, lr_stream_t stream);
 int lr_fault_import(const int32_t* in2, int32_t* status, lr_stream_t stream);
 void* lr_fault_words_ptr(void);
-int lr_step_begin(float* grad, int64_t n, lr_stream_t stream);
+int lr_step_begin(float* grad, int64_t n, float* also_zero, lr_stream_t stream);
 void lr_rnn_debug_drop_member(int member);
 void lr_rnn_debug_disable_cluster(int off);
 size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D);

@@ -51,7 +51,7 @@ SIGNATURES = {
     "lr_fault_words_ptr": (c_void_p, []),
     "lr_fault_export": (c_int, [P, P, P]),
     "lr_fault_import": (c_int, [P, P, P]),
-    "lr_step_begin": (c_int, [P, c_int64, P]),
+    "lr_step_begin": (c_int, [P, c_int64, P, P]),
     "lr_rnn_debug_drop_member": (None, [c_int]),
     "lr_rnn_debug_disable_cluster": (None, [c_int]),
     "lr_rnn_reserve_bytes": (c_size_t, [c_int] * 6),

@@ -462,12 +462,13 @@ int32_t* g_fault_words[kMaxDevices];
 int g_drop_member = -1;
 int g_cluster_off = 0;   // bit 0: no cluster recurrence; bit 1: no pair recurrence; bit 2: weight gradients on the fp32 grouped GEMM
 __global__ void step_begin_kernel(float4* __restrict__ g, int64_t n4, float* __restrict__ tail, int ntail,
-                                  int32_t* __restrict__ fault) {
+                                  int32_t* __restrict__ fault, float* __restrict__ also_zero) {
   const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i0 == 0 && fault) {
     fault[1] += fault[0];
     fault[0] = 0;
   }
+  if (i0 == 0 && also_zero) also_zero[0] = 0.f;
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int64_t i = i0; i < n4; i += (int64_t)gridDim.x * blockDim.x) g[i] = z;
   if (i0 < ntail) tail[i0] = 0.f;
@@ -556,12 +557,12 @@ extern "C" int lr_fault_import(const int32_t* in2, int32_t* status, lr_stream_t 
   return lr_launch_status();
 }
 
-extern "C" int lr_step_begin(float* grad, int64_t n, lr_stream_t stream) {
+extern "C" int lr_step_begin(float* grad, int64_t n, float* also_zero, lr_stream_t stream) {
   LR_CHECK_ARG(n >= 0 && (grad || n == 0));
   LR_CHECK_ARG((reinterpret_cast<uintptr_t>(grad) & 15) == 0);
   const int64_t n4 = n / 4;
   LR_LAUNCH(step_begin_kernel, dim3(grid_for(n4 > 0 ? n4 : 1, 256)), dim3(256), 0, stream, (float4*)grad, n4,
-            grad + n4 * 4, (int)(n - n4 * 4), lr_fault_words());
+            grad + n4 * 4, (int)(n - n4 * 4), lr_fault_words(), also_zero);
   return lr_launch_status();
 }
 

@@ -16,6 +16,15 @@ ascending lengths, `ctc_loss.py:39`), a caption plus BOS/EOS is shorter than its
 
 `write_synthetic_dataview` produces dataviews in exactly this layout so the nano/micro/small
 configurations can run without the YouTube corpus (which is not shipped, `.gitignore:4`).
+
+Pixel regime (BUILD-DEFINED, BASELINE configs[1]/[4]: "3Dconv + ..."; the reference's dataview keeps only the
+landmarks).  What `generate_dataview.py:58-76` has in hand per frame is the video frame AND its landmarks; a dataview
+written with `frames=True` keeps both:
+  <root>/data/datasets/<name>/<vid>/face_frames_seq.npy  object array of (len_i, 3, H, W) uint8 frames, aligned with
+                                                         face_lmk_seq row by row (landmarks in those frames' pixels)
+`FrameCaptionDataset(pixels=True)` then yields ((frames u8, landmarks), caption ids) under the SAME filter / sort /
+vocabulary as the landmark dataset (its cache is <split>/face_frames.pkl beside the reference's three pickles), and
+`data.make_pixel_collate_fn` turns a batch into mouth-crop clips (B, Tmax, 3, 96, 96) on the device (lr_lip_crop_u8).
 """
 import glob
 import json
@@ -55,6 +64,15 @@ def split_dataset(root, dataset_name, train_split=0.8, rand=None):
   val_test_size = len(vid_ids) - train_idx
   val_idx = train_idx + val_test_size // 2
   return vid_ids[:train_idx], vid_ids[train_idx:val_idx], vid_ids[val_idx:]
+
+
+def keep_and_order(frames, captions, start_ends, fps=29.97, threshold=0.8):
+  """The indices filter_occlusions keeps, in sort_by_seqlen's order: for data that must stay aligned with the
+  landmark sequences (the pixel frames of a `frames=True` dataview)."""
+  kept = [i for i, (f, c, (start, end)) in enumerate(zip(frames, captions, start_ends))
+          if (end - start) * fps * threshold <= len(f) and len(c) + 2 < len(f)]
+  order = np.argsort([frames[i].shape[0] for i in kept])
+  return [kept[i] for i in order]
 
 
 def filter_occlusions(frames, captions, start_ends, fps=29.97, threshold=0.8):
@@ -112,7 +130,7 @@ class FrameCaptionDataset(object):
 
   def __init__(self, root, dataset_name, split_name, vid_ids, labels='labels.json', start_end='s_e',
                threshold=0.8, fps=29.97, cap='cap', frame_type='face_lmk_seq',
-               sentence_dataset=False, in_ext='.npy', out_ext='.pkl', refresh=False):
+               sentence_dataset=False, in_ext='.npy', out_ext='.pkl', refresh=False, pixels=False):
     assert all(os.path.isdir(x) for x in vid_ids)
     assert frame_type in ('face_lmk_seq', 'face_vtx_seq')
     if sentence_dataset:
@@ -131,6 +149,18 @@ class FrameCaptionDataset(object):
     self.frames, self.captions = frames, captions
     self.num_elements = len(captions)
     self.frame_type = frame_type
+    self.pixels = None
+    if pixels:   # build-defined: the u8 frames of a `frames=True` dataview, same filter and order as the landmarks
+      ppath = os.path.join(pickle_dir, 'face_frames' + out_ext)
+      if refresh or not os.path.isfile(ppath):
+        self.pixels = self.construct_pixels(vid_ids, ppath, start_end=start_end, cap=cap, frame_type=frame_type,
+                                            in_ext=in_ext, fps=fps, threshold=threshold)
+      else:
+        with open(ppath, 'rb') as f:
+          self.pixels = pickle.load(f)
+      assert len(self.pixels) == len(self.frames)
+      assert all(p.shape[0] == f.shape[0] and p.dtype == np.uint8 and p.ndim == 4 and p.shape[1] == 3
+                 for p, f in zip(self.pixels, self.frames))
 
   def __len__(self):
     return self.num_elements
@@ -138,7 +168,27 @@ class FrameCaptionDataset(object):
   def __getitem__(self, index):
     frames = self.frames[index]
     assert len(frames.shape) == 3
+    if self.pixels is not None:
+      return (self.pixels[index], frames), parse_caption(self.char2idx, self.captions[index])
     return frames, parse_caption(self.char2idx, self.captions[index])
+
+  @staticmethod
+  def construct_pixels(vid_ids, out_path, start_end='s_e', cap='cap', frame_type='face_lmk_seq',
+                       pixel_type='face_frames_seq', in_ext='.npy', fps=29.97, threshold=0.8):
+    def load(base):
+      rows = []
+      for vid in vid_ids:
+        path = os.path.join(vid, base + in_ext)
+        assert os.path.isfile(path), "%s (a dataview written with frames=True has it)" % path
+        rows.extend(list(np.load(path, allow_pickle=True)))
+      return rows
+    lmks, captions, start_ends, pix = load(frame_type), load(cap), load(start_end), load(pixel_type)
+    assert len(pix) == len(lmks) == len(captions) == len(start_ends)
+    order = keep_and_order(lmks, captions, start_ends, fps=fps, threshold=threshold)
+    out = [np.ascontiguousarray(pix[i]) for i in order]
+    with open(out_path, 'wb') as f:
+      pickle.dump(out, f)
+    return out
 
   @staticmethod
   def construct_dataset(root, dataset_name, pickle_dir, vid_ids, labels='labels.json',
@@ -196,11 +246,19 @@ _WORDS = ("the quick brown fox jumps over a lazy dog and then it went home to se
 
 
 def write_synthetic_dataview(root, dataset_name, n_videos, captions_per_video=8, seed=123456,
-                             fps=29.97, min_seconds=1.0, max_seconds=3.0):
+                             fps=29.97, min_seconds=1.0, max_seconds=3.0, frames=False, frame_hw=96):
   """Synthetic dataviews in the reference's on-disk format.  Landmarks are smooth random walks in
   a ~200-pixel face box (x, y in pixels, z relative depth), i.e. the unnormalised magnitudes the
-  reference feeds its encoder."""
+  reference feeds its encoder.
+
+  frames=True (build-defined pixel regime): every caption also gets `face_frames_seq` — (len, 3, frame_hw,
+  frame_hw) uint8 frames (a fixed random texture per caption whose brightness follows the mouth opening, plus
+  noise) — and the landmarks live in those frames' pixel coordinates, the mouth points (48..67) clustered in the
+  lower middle so that the lip crop has something to frame."""
   rng = np.random.RandomState(seed)
+  if frames:
+    return _write_synthetic_pixel_dataview(root, dataset_name, n_videos, captions_per_video, rng, fps, min_seconds,
+                                           max_seconds, int(frame_hw))
   for v in range(n_videos):
     vid_dir = datasets_path(root, dataset_name, "vid%04d" % v)
     os.makedirs(vid_dir, exist_ok=True)
@@ -224,4 +282,41 @@ def write_synthetic_dataview(root, dataset_name, n_videos, captions_per_video=8,
       for i, r in enumerate(rows):
         arr[i] = r
       np.save(os.path.join(vid_dir, base + ".npy"), arr, allow_pickle=True)
+  return datasets_path(root, dataset_name)
+
+
+def _write_synthetic_pixel_dataview(root, dataset_name, n_videos, captions_per_video, rng, fps, min_seconds,
+                                    max_seconds, hw):
+  for v in range(n_videos):
+    vid_dir = datasets_path(root, dataset_name, "vid%04d" % v)
+    os.makedirs(vid_dir, exist_ok=True)
+    s_e, lmks, caps, pix = [], [], [], []
+    t = 0.0
+    for _ in range(captions_per_video):
+      dur = rng.uniform(min_seconds, max_seconds)
+      n = int(round(dur * fps))
+      base = np.stack([rng.uniform(0.2, 0.8, 68) * hw, rng.uniform(0.2, 0.8, 68) * hw, rng.uniform(-30, 30, 68)], 1)
+      # mouth points: a cluster in the lower middle of the frame, opening and closing over time
+      cx, cy = rng.uniform(0.4, 0.6) * hw, rng.uniform(0.6, 0.75) * hw
+      ang = np.linspace(0, 2 * np.pi, 20, endpoint=False)
+      openness = 0.5 + 0.5 * np.sin(np.linspace(0, rng.uniform(2, 6) * np.pi, n))
+      seq = np.repeat(base[None], n, axis=0) + np.cumsum(rng.randn(n, 68, 3) * 0.1, axis=0)
+      seq[:, 48:68, 0] = cx + 0.12 * hw * np.cos(ang)[None]
+      seq[:, 48:68, 1] = cy + (0.03 + 0.06 * openness[:, None]) * hw * np.sin(ang)[None]
+      tex = rng.randint(0, 256, (3, hw, hw)).astype(np.float32)
+      fr = tex[None] * (0.6 + 0.4 * openness[:, None, None, None]) + rng.randn(n, 3, hw, hw).astype(np.float32) * 4
+      words = []
+      while len(' '.join(words)) < max(3, n // 3):
+        words.append(_WORDS[rng.randint(len(_WORDS))])
+      cap = ' '.join(words)[:max(3, n - 3)]
+      s_e.append((t, t + dur))
+      lmks.append(seq.astype(np.float64))
+      caps.append(cap)
+      pix.append(np.clip(fr, 0, 255).astype(np.uint8))
+      t += dur
+    for base_name, rows in (("s_e", s_e), ("face_lmk_seq", lmks), ("cap", caps), ("face_frames_seq", pix)):
+      arr = np.empty(len(rows), dtype=object)
+      for i, r in enumerate(rows):
+        arr[i] = r
+      np.save(os.path.join(vid_dir, base_name + ".npy"), arr, allow_pickle=True)
   return datasets_path(root, dataset_name)

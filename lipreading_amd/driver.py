@@ -32,6 +32,12 @@ DEFAULTS = dict(  # train.py:134-167
     # not reference flags: where data/ and weights/ live, a cap for smoke runs, and the encoder+CTC-only
     # loop (no attention decoder; error = greedy-decoded CER) that the archived trainer's flag files select
     root=".", max_epochs=None, ctc_only=False, step_graphs=True,
+    # build-defined pixel regime (BASELINE configs[1] "3Dconv+BiGRU+CTC", configs[4] "transformer encoder over
+    # per-frame conv features"): --frontend=conv3d reads a dataview written with frames (u8 frames + landmarks),
+    # crops the mouth on the device (lr_lip_crop_u8) and puts the STCNN frontend in front of the sequence encoder;
+    # --encoder=transformer swaps the recurrent encoder for the transformer (hidden_size = d_model, num_layers
+    # layers, --nhead heads).  Either one selects the encoder+CTC loop with greedy CER (no attention decoder).
+    frontend="none", encoder="rnn", nhead=4, crop_size=96,
 )
 
 
@@ -78,6 +84,7 @@ def parse_flags(argv, defaults=DEFAULTS):
         tokens += [t for t in f.read().replace("\n", " ").split(" ") if t.startswith("--")]
   out = dict(defaults)
   archived = False
+  explicit = set()
   for t in tokens:
     name, _, text = t[2:].partition("=")
     archived = archived or name in ARCHIVED_ONLY
@@ -90,13 +97,25 @@ def parse_flags(argv, defaults=DEFAULTS):
     if name not in out:
       raise SystemExit("unknown flag --%s" % name)
     out[name] = _coerce(name, text, defaults[name])
+    explicit.add(name)
   if isinstance(out.get("rnn_type"), str):
     out["rnn_type"] = out["rnn_type"].upper()          # the archived files write `gru`
   if archived:
-    # archive/train_model.py trains a CTC-only model (no attention decoder) and reports greedy CER/WER
-    out["enable_ctc"] = True
-    out["ctc_only"] = True
-    out["bidirectional"] = True     # archive/train_model.py's LipReader is bidirectional throughout
+    # archive/train_model.py trains a CTC-only model (no attention decoder) and reports greedy CER/WER; its
+    # LipReader is bidirectional throughout.  These are that trainer's DEFAULTS: a flag the command line or the
+    # file sets itself (e.g. --bidirectional=False) wins.
+    for name, value in (("enable_ctc", True), ("ctc_only", True), ("bidirectional", True)):
+      if name not in explicit:
+        out[name] = value
+  if out.get("frontend") not in ("none", "conv3d"):
+    raise SystemExit("--frontend must be none or conv3d")
+  if out.get("encoder") not in ("rnn", "transformer"):
+    raise SystemExit("--encoder must be rnn or transformer")
+  if out["frontend"] != "none" or out["encoder"] != "rnn":
+    # the build-defined regimes are encoder + CTC (BASELINE configs[1], [4]); no attention decoder behind them
+    for name in ("enable_ctc", "ctc_only"):
+      if name not in explicit:
+        out[name] = True
   return out
 
 
@@ -112,6 +131,28 @@ def init_models(char2idx, num_layers, frame_dim, hidden_size, char_dim, enable_c
                                    rnn_dropout=rnn_dropout, attention_type=attention_type,
                                    attn_hidden_size=attn_hidden_size, device=device).to(device)
   return encoder, decoding_step
+
+
+def init_pixel_model(char2idx, f, device):
+  """BUILD-DEFINED (no reference symbol): [conv3d frontend ->] recurrent or transformer encoder -> CTC head.
+  The sequence encoder keeps the reference's constructor arguments where it has them."""
+  from .encoder import VideoEncoder
+  pixels = f["frontend"] == "conv3d"
+  frame_dim = f["frame_dim"]
+  if pixels:
+    from .frontend import ConvFrontend3D, PixelLipReader, feature_dim
+    frame_dim = feature_dim(f["crop_size"], f["crop_size"])
+  if f["encoder"] == "transformer":
+    from .transformer import TransformerVideoEncoder
+    enc = TransformerVideoEncoder(frame_dim, d_model=f["hidden_size"], nhead=f["nhead"], num_layers=f["num_layers"],
+                                  dim_feedforward=4 * f["hidden_size"], enable_ctc=True, vocab_size=len(char2idx),
+                                  char2idx=char2idx)
+  else:
+    enc = VideoEncoder(frame_dim, f["hidden_size"], rnn_type=f["rnn_type"], num_layers=f["num_layers"],
+                       bidirectional=f["bidirectional"], rnn_dropout=f["rnn_dropout"], enable_ctc=True,
+                       vocab_size=len(char2idx), char2idx=char2idx, device=device)
+  model = PixelLipReader(enc, ConvFrontend3D()) if pixels else enc
+  return model.to(device)
 
 
 def restore(net, save_file, verbose=True):
@@ -165,6 +206,9 @@ def run(**flags):
   from .optim import FlatParameters, FusedAdam
   f = dict(DEFAULTS)
   f.update(flags)
+  if f["frontend"] != "none" or f["encoder"] != "rnn":
+    # the build-defined regimes are encoder + CTC with greedy CER (parse_flags sets the same for flag files)
+    f["enable_ctc"], f["ctc_only"] = flags.get("enable_ctc", True), flags.get("ctc_only", True)
   torch.manual_seed(f["seed"])
   rand = np.random.RandomState(seed=f["seed"])
   assert torch.cuda.is_available(), "the driver runs the HIP path: an MI355X is required (no CPU fallback)"
@@ -173,18 +217,28 @@ def run(**flags):
     print("note: --cuda=False is ignored: this build has no CPU execution path")
   print("Initializing dataset '{}'".format(f["data"]))
   splits = split_dataset(f["root"], f["data"], f["train_split"], rand=rand)
+  pixels = f["frontend"] == "conv3d"
   sets = [FrameCaptionDataset(f["root"], f["data"], name, ids, labels=f["labels"],
                               threshold=f["occlussion_threshold"], sentence_dataset=f["sentence_dataset"],
-                              refresh=f["refresh"])
+                              refresh=f["refresh"], pixels=pixels)
           for name, ids in zip(("train", "val", "test"), splits)]
   char2idx = sets[0].char2idx
-  collate = make_collate_fn(device)   # padded on the GPU (lr_collate_pad_f32); lengths stay on the host
+  if pixels:
+    # u8 frames + landmarks -> mouth crops (B, Tmax, 3, S, S) on the GPU (lr_lip_crop_u8)
+    from .data import make_pixel_collate_fn
+    collate = make_pixel_collate_fn(device, size=f["crop_size"])
+  else:
+    collate = make_collate_fn(device)   # padded on the GPU (lr_collate_pad_f32); lengths stay on the host
   train_loader, val_loader, test_loader = (make_loader(d, f["batch_size"], collate) for d in sets)
   print("Initializing model")
-  encoder, decoding_step = init_models(char2idx, f["num_layers"], f["frame_dim"], f["hidden_size"], f["char_dim"],
-                                       f["enable_ctc"], f["rnn_type"], f["attention_type"], f["attn_hidden_size"],
-                                       f["bidirectional"], f["rnn_dropout"], device)
   ctc_only = bool(f["ctc_only"])
+  if pixels or f["encoder"] == "transformer":
+    assert ctc_only and f["enable_ctc"], "--frontend=conv3d / --encoder=transformer run the encoder+CTC loop"
+    encoder, decoding_step = init_pixel_model(char2idx, f, device), None
+  else:
+    encoder, decoding_step = init_models(char2idx, f["num_layers"], f["frame_dim"], f["hidden_size"], f["char_dim"],
+                                         f["enable_ctc"], f["rnn_type"], f["attention_type"], f["attn_hidden_size"],
+                                         f["bidirectional"], f["rnn_dropout"], device)
   if ctc_only:
     assert f["enable_ctc"], "--ctc_only needs --enable_ctc"
     decoding_step = None
@@ -253,7 +307,8 @@ def run(**flags):
       best_val_cer, best_idx = val_cer, epochs
     epochs += 1
   return dict(history=history, weights_dir=weights_dir, seconds=time.time() - t0, epochs=epochs,
-              graph_captures=graphs.captures, graph_replays=graphs.replays)
+              graph_captures=graphs.captures, graph_replays=graphs.replays, encoder=encoder,
+              decoding_step=decoding_step, char2idx=char2idx, loaders=(train_loader, val_loader, test_loader))
 
 
 def main(argv=None):

@@ -283,10 +283,25 @@ class PixelLipReader(nn.Module):
     # BASELINE configs[1] names this regime "bf16".  Other shapes keep the fp32 step kernels;
     # `encoder.recurrence = 'f32'` switches it off.
     encoder.recurrence = 'bf16'
+    if hasattr(encoder, "attention"):
+      encoder.attention = 'bf16'     # transformer encoder: fused attention on the bf16 matrix cores
+    self.best_error = 1
     # weight-gradient GEMMs of upper recurrent layers overlap the recurrence of the layer below
     from . import encoder as _enc
     _enc.overlap_weight_grads = True
+
   def forward(self, clips, frame_lens, max_len=None, need_final_state=True):
     feats = self.frontend(clips, out_bf16=True)
     B, T, F = feats.shape
     return self.encoder(feats.reshape(B, T, F, 1), frame_lens, max_len=max_len, need_final_state=need_final_state)
+
+  def save_best_model(self, error, file_path):
+    """VideoEncoder.save_best_model's contract (better_model.py:114-122) for the whole pixel model: the
+    state_dict holds `frontend.conv{1,2,3}.*` and `encoder.*`."""
+    if error < self.best_error:
+      self.best_error = error
+      folder = os.path.dirname(file_path)
+      if folder and not os.path.exists(folder):
+        os.makedirs(folder)
+      torch.save(self.state_dict(), file_path)
+      print("\tSaving best error '{}' to '{}'".format(self.best_error, file_path))

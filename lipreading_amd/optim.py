@@ -45,14 +45,18 @@ class FlatParameters(object):
       if p.grad is None or p.grad.data_ptr() != view.data_ptr():
         p.grad = view
 
-  def zero_grad(self):
+  def zero_grad(self, also_zero=None):
     """opt.zero_grad() (train_better_model.py:67) AND the top of a step for the device-side fault words: one launch
     (lr_step_begin) clears the flat gradient buffer and moves a time-out raised by a one-launch recurrence of the
-    PREVIOUS step from `pending` to `total` (include/lipreading_hip.h)."""
+    PREVIOUS step from `pending` to `total` (include/lipreading_hip.h).  also_zero: a float32[1] device tensor to
+    clear in the same launch (FusedAdam's sum-of-squares accumulator)."""
     if self.grad.is_cuda:
-      _C.check(_C.lib().lr_step_begin(self.grad.data_ptr(), self.numel, _C.stream_handle()), "lr_step_begin")
+      _C.check(_C.lib().lr_step_begin(self.grad.data_ptr(), self.numel, _C.ptr(also_zero), _C.stream_handle()),
+               "lr_step_begin")
     else:
       self.grad.zero_()   # storage-only use (gloo tests on CPU)
+      if also_zero is not None:
+        also_zero.zero_()
     self.attach_grads()
 
 
@@ -70,7 +74,9 @@ class FusedAdam(object):
     self._scratch = torch.zeros(4, dtype=torch.float32, device=dev)
 
   def zero_grad(self):
-    self.flat.zero_grad()
+    # (the clip's accumulator is cleared by the same launch: one fill launch less per step)
+    self.flat.zero_grad(also_zero=self._sumsq)
+    self._sumsq_clean = True
 
   def reset(self, lr=None):
     """What re-creating torch.optim.Adam each epoch does (train.py:280): moments and step
@@ -94,7 +100,9 @@ class FusedAdam(object):
     st = _C.stream_handle()
     sumsq = None
     if grad_norm is not None:
-      self._sumsq.zero_()
+      if not getattr(self, "_sumsq_clean", False):
+        self._sumsq.zero_()     # (a caller that cleared the gradients some other way than self.zero_grad())
+      self._sumsq_clean = False
       _C.check(L.lr_sumsq(f.grad.data_ptr(), f.numel, self._sumsq.data_ptr(), st), "lr_sumsq")
       sumsq = self._sumsq
     _C.check(L.lr_adam_step(f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),

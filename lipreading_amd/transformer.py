@@ -241,10 +241,11 @@ class TransformerVideoEncoder(nn.Module):
     # 'f32': exact fp32 MFMA linears; 'bf16x3' (set by frontend.PixelLipReader): hi/lo split bf16 MFMA
     self.input_projection = 'f32'
     self.input_is_bf16 = False
-    # self-attention core: 'bf16' = fused QK^T -> masked softmax -> PV on the bf16 matrix cores, one launch per
-    # (sample, head) set (lr_attention.hip; T <= 96, head dim 32 / 64), else — and with 'f32' — batched fp32 MFMA
-    # GEMMs + a softmax kernel (exact fp32, the path the torch oracle is compared with at 2e-4)
-    self.attention = 'bf16'
+    # self-attention core: 'f32' (default) = batched fp32 MFMA GEMMs + a softmax kernel (exact fp32, the path the
+    # torch oracle is compared with at 2e-4); 'bf16' (set by frontend.PixelLipReader, like the bf16 input
+    # projection) = fused QK^T -> masked softmax -> PV on the bf16 matrix cores, one launch per (sample, head) set
+    # (lr_attention.hip; T <= 96, head dim 32 / 64)
+    self.attention = 'f32'
     self.input_proj = nn.Linear(frame_dim, d_model)
     layer = nn.TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout=0.0, activation='relu',
                                        batch_first=True, norm_first=False)

@@ -52,6 +52,56 @@ def test_dataset_invariants_and_pickle_cache(root):
     np.testing.assert_array_equal(ds[i][1], ds2[i][1])
 
 
+def test_pixel_dataview_keeps_frames_aligned_with_landmarks(tmp_path):
+  """frames=True (build-defined pixel regime): every caption also carries its uint8 frames; the dataset applies
+  the SAME occlusion filter, sort and vocabulary to them as to the landmarks, caches them beside the reference's
+  three pickles, and leaves those three readable as before."""
+  root = str(tmp_path)
+  DS.write_synthetic_dataview(root, "synthetic/px", n_videos=4, captions_per_video=3, frames=True, frame_hw=48,
+                              min_seconds=0.6, max_seconds=1.2)
+  d = DS.datasets_path(root, "synthetic/px")
+  vid = sorted(os.listdir(d))[0]
+  fr = np.load(os.path.join(d, vid, "face_frames_seq.npy"), allow_pickle=True)
+  lm = np.load(os.path.join(d, vid, "face_lmk_seq.npy"), allow_pickle=True)
+  assert fr[0].dtype == np.uint8 and fr[0].shape[1:] == (3, 48, 48) and fr[0].shape[0] == lm[0].shape[0]
+  assert (lm[0][..., :2] >= 0).all() and (lm[0][..., :2] < 48).all()         # landmarks in the frames' pixels
+  ids = DS.gen_vid_ids(root, "synthetic/px", np.random.RandomState(0))
+  px = DS.FrameCaptionDataset(root, "synthetic/px", "train", ids, pixels=True)
+  plain = DS.FrameCaptionDataset(root, "synthetic/px", "train", ids)         # the landmark view of the same cache
+  assert len(px) == len(plain) > 0
+  lens = []
+  for i in range(len(px)):
+    (frames, lmk), cap = px[i]
+    np.testing.assert_array_equal(lmk, plain[i][0])
+    np.testing.assert_array_equal(cap, plain[i][1])
+    assert frames.shape[0] == lmk.shape[0] and frames.shape[1:] == (3, 48, 48)
+    lens.append(frames.shape[0])
+  assert lens == sorted(lens)
+  pdir = DS.pickles_path(root, "synthetic/px", "non-sentence", "train")
+  assert sorted(os.listdir(pdir)) == ["captions.pkl", "char2idx.pkl", "face_frames.pkl", "frames.pkl"]
+  again = DS.FrameCaptionDataset(root, "synthetic/px", "train", ids, pixels=True)    # from the cache
+  np.testing.assert_array_equal(again[0][0][0], px[0][0][0])
+  # a landmark-only dataview has no frames to offer: loud, not silent
+  DS.write_synthetic_dataview(root, "synthetic/lm", n_videos=2, captions_per_video=2)
+  with pytest.raises(AssertionError, match="frames=True"):
+    DS.FrameCaptionDataset(root, "synthetic/lm", "train", DS.gen_vid_ids(root, "synthetic/lm"), pixels=True)
+
+
+def test_driver_flags_of_the_pixel_regime_and_archived_defaults(tmp_path):
+  from lipreading_amd import driver
+  f = driver.parse_flags(["--frontend=conv3d", "--encoder=transformer", "--hidden_size=64"])
+  assert f["frontend"] == "conv3d" and f["encoder"] == "transformer" and f["ctc_only"] and f["enable_ctc"]
+  with pytest.raises(SystemExit):
+    driver.parse_flags(["--frontend=resnet"])
+  # the archived trainer's defaults (CTC-only, bidirectional) apply only where the file / command line is silent
+  cfg = tmp_path / "micro"
+  cfg.write_text("--dataset=x\n--batch=5\n--hidden_size=800\n--hidden_layers=5\n--rnn_type=gru\n")
+  f = driver.parse_flags([str(cfg)])
+  assert f["ctc_only"] and f["bidirectional"] and f["num_layers"] == 5 and f["rnn_type"] == "GRU"
+  f = driver.parse_flags([str(cfg), "--bidirectional=False"])
+  assert f["ctc_only"] and f["bidirectional"] is False
+
+
 def test_filter_occlusions_and_unknown_characters():
   f = [np.zeros((30, 68, 3)), np.zeros((10, 68, 3)), np.zeros((30, 68, 3))]
   c = ["short", "this caption is far too long", "ok cap"]

@@ -18,9 +18,13 @@ PIXELS = {  # bench.py's conv names -> a substring of the kernel symbol
     "conv2_wgrad": "conv_wgrad_tr_kernel<32", "conv3_wgrad": "conv_wgrad_tr_kernel<64"}
 RECURRENT = {"rnn_fwd_step_kernel": "rnn_fwd_step_kernel", "rnn_bwd_step_kernel": "rnn_bwd_step_kernel",
              "gru256_fwd_pair_kernel": "gru256_fwd_pair_kernel", "gru256_bwd_pair_kernel": "gru256_bwd_pair_kernel",
-             "lstm768_fwd_cluster_kernel": "lstm768_fwd_cluster_kernel",
-             "lstm768_bwd_cluster_kernel": "lstm768_bwd_cluster_kernel",
-             "gru256_fwd_persist_kernel": "gru256_fwd_persist_kernel", "gru256_bwd_persist_kernel": "gru256_bwd_persist_kernel"}
+             "gru256_fwd_persist_kernel": "gru256_fwd_persist_kernel", "gru256_bwd_persist_kernel": "gru256_bwd_persist_kernel",
+             "sgemm_grouped_kernel": "sgemm_grouped_kernel", "xgemm_kernel": "xgemm_kernel"}
+# the cluster recurrence's instantiations (lr_rnn_cluster.hip): bench.py's name "rnnc_fwd_kernel<G,CC>"
+for _g, _cc in ((3, 8), (4, 8), (3, 16), (4, 16), (3, 22), (4, 22), (3, 24), (4, 24), (3, 25)):
+  for _w in ("fwd", "bwd"):
+    RECURRENT["rnnc_%s_kernel<%d,%d>" % (_w, _g, _cc)] = "rnnc_%s_kernel<%d, %d>" % (_w, _g, _cc)
+MODELS = ("gru256", "lstm768", "lstm700", "lstm512", "gru800")
 
 
 def read(path):
@@ -30,7 +34,7 @@ def read(path):
   for line in open(path):
     if line.startswith("#") or line.startswith("kernel "):
       continue
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES"):
       i = line.find(" " + counter + " ")
       if i > 0:
         vals = line[i + len(counter) + 2:].split()
@@ -38,9 +42,9 @@ def read(path):
   return rows
 
 
-def lookup(rows, sub):
-  for name, _, calls, avg in rows:
-    if sub in name:
+def lookup(rows, sub, counter=None):
+  for name, c, calls, avg in rows:
+    if sub in name and (counter is None or c == counter):
       return avg, calls, name
   return None
 
@@ -49,9 +53,10 @@ def main(tag, d="profiles"):
   out = {"_note": "HBM/fabric bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (bench.py "
                   "--no-graph, a few steps), averaged over the launches; see tools/make_pmc_traffic.py for the formula.",
          "source_files": []}
-  for model, table, doubled in (("gru256", RECURRENT, True), ("lstm768", RECURRENT, True), ("pixels", PIXELS, False)):
+  for model, table, doubled in [(m, RECURRENT, True) for m in MODELS] + [("pixels", PIXELS, False)]:
     f = read(os.path.join(d, "%s_%s_pmc_FETCH_SIZE.txt" % (tag, model)))
     w = read(os.path.join(d, "%s_%s_pmc_WRITE_SIZE.txt" % (tag, model)))
+    sq = read(os.path.join(d, "%s_%s_pmc_SQ_pass1.txt" % (tag, model)))
     if not f or not w:
       continue
     out["source_files"] += ["%s/%s_%s_pmc_%s.txt" % (d, tag, model, c) for c in ("FETCH_SIZE", "WRITE_SIZE")]
@@ -66,6 +71,13 @@ def main(tag, d="profiles"):
       else:
         rec["traffic_bytes"] = int((a[0] + b[0]) * 1024)
         rec["traffic_bytes_upper"] = int((2 * a[0] + b[0]) * 1024)
+      busy, wave = lookup(sq, sub, "SQ_VALU_MFMA_BUSY_CYCLES"), lookup(sq, sub, "SQ_WAVE_CYCLES")
+      wait = lookup(sq, sub, "SQ_WAIT_ANY")
+      if busy and wave and wave[0] > 0:
+        # matrix-pipe busy fraction: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_WAVE_CYCLES) (one wave per SIMD kernels)
+        rec["mfma_busy"] = round(busy[0] / (4.0 * wave[0]), 4)
+        if wait:
+          rec["wait_any_frac"] = round(wait[0] / wave[0], 4)
       sec[key] = rec
     out[model] = sec
   path = os.path.join(d, "%s_pmc_traffic.json" % tag)
