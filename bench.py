@@ -279,18 +279,26 @@ def parity_block(regime, model_name, layers, B, dev, train_steps=50):
       note = ("same uint8 clips and weights; oracle = F.conv3d/max_pool3d with bf16 rounding at this repo's "
               "storage points -> reference VideoEncoder (fp32) -> reference ctc_loss; HIP = PixelLipReader "
               "defaults (%s recurrence, %s input projection)" % (enc.recurrence, enc.input_projection))
-      # the same lattice from the fp32-faithful recurrence, and the un-shaped oracle (fp32 conv, no bf16 anywhere)
-      default_rec = enc.recurrence
-      enc.recurrence = "split"
-      lp_split, _, _ = model(clips_d, lens_d, max_len=T_FRAMES)
-      enc.recurrence = default_rec
-      lp_ref32 = oracle_lp(False)
-      l_split, _ = hip_loss(lp_split)
+      # the same lattice from the other recurrences / projections of the HIP path, and the un-shaped oracle (fp32
+      # conv, no bf16 anywhere)
+      default_rec, default_proj = enc.recurrence, enc.input_projection
       l_ref = float(O.ctc_loss(lp_ref, labels, frame_lens, label_lens, 'mean'))
+      s_ref0 = GreedyStrings.oracle(lp_ref, frame_lens)
+
+      def variant(rec, proj):
+        enc.recurrence, enc.input_projection = rec, proj
+        lp_v, _, _ = model(clips_d, lens_d, max_len=T_FRAMES)
+        enc.recurrence, enc.input_projection = default_rec, default_proj
+        l_v, _ = hip_loss(lp_v)
+        return dict(_frame_flips(lp_v, lp_ref, frame_lens), loss_hip=round(l_v, 7), abs_diff=float("%.3g" % abs(l_v - l_ref)),
+                    greedy_strings_equal=GreedyStrings.hip(lp_v, lens_d) == s_ref0)
+
+      extra["other_paths_vs_the_same_oracle"] = {
+          "recurrence 'bf16' (single-plane operands; round 2's default)": variant("bf16", default_proj),
+          "recurrence 'split' (fp32-faithful)": variant("split", default_proj),
+          "recurrence 'split' + input projection 'bf16x1' (ONE bf16 product: W_ih rounded to bf16)": variant("split", "bf16x1")}
+      lp_ref32 = oracle_lp(False)
       l_ref32 = float(O.ctc_loss(lp_ref32, labels, frame_lens, label_lens, 'mean'))
-      extra["recurrence_split"] = dict(_frame_flips(lp_split, lp_ref, frame_lens), loss_hip=round(l_split, 7),
-                                       abs_diff=float("%.3g" % abs(l_split - l_ref)),
-                                       greedy_strings_equal=GreedyStrings.hip(lp_split, lens_d) == GreedyStrings.oracle(lp_ref, frame_lens))
       extra["loss_oracle_fp32conv"] = round(l_ref32, 7)
       extra["abs_diff_vs_fp32conv_oracle"] = float("%.3g" % abs(hip_loss(lp_hip)[0] - l_ref32))
       extra["vs_fp32conv_oracle"] = _frame_flips(lp_hip, lp_ref32, frame_lens)
@@ -451,6 +459,9 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
   # bf16 recurrent operands in a landmark regime too (not reference-faithful: reported as such)
   if os.environ.get("LIPREADING_RECURRENCE") and hasattr(enc, "recurrence"):
     enc.recurrence = os.environ["LIPREADING_RECURRENCE"]
+  if os.environ.get("LIPREADING_INPUT_PROJECTION") and pixels:
+    # experiment: 'bf16x1' = one bf16 product per GEMM of the recurrent layers' projections (LR_RNN_PROJ_BF16X1)
+    enc.input_projection = os.environ["LIPREADING_INPUT_PROJECTION"]
   if recurrence is not None and hasattr(enc, "recurrence"):
     enc.recurrence = recurrence
   model = model.to(dev).train()

@@ -73,7 +73,12 @@ typedef enum lr_rnn_mode {
    * reference-faithful regime runs by default where it is supported; the decoder loop (lr_decoder_forward /
    * _backward) takes the same cluster kernels, started from the encoder's final state, when every step is
    * teacher forced. */
-  LR_RNN_RECUR_SPLIT = 0x1000
+  LR_RNN_RECUR_SPLIT = 0x1000,
+  /* with LR_RNN_PROJ_BF16X3: keep only the bf16 hi plane of EVERY operand of the input projection, its two
+   * gradients and dW_hh — one product each instead of two or three (weights and gate gradients rounded to bf16
+   * once per step, ~2^-9 relative).  An experiment of the build-defined pixel regime (encoder.input_projection =
+   * 'bf16x1'); measured against the oracle in bench.py's parity block, not a default. */
+  LR_RNN_PROJ_BF16X1 = 0x2000
 } lr_rnn_mode;
 
 typedef enum lr_ctc_reduction {

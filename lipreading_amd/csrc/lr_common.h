@@ -184,13 +184,15 @@ extern "C" size_t lr_xgemm_workspace_bytes(int transA, int transB, int M, int N,
 // contraction each (gates / dG hold the directions side by side in a row; dstride = floats between
 // the directions' blocks of a dG row)
 size_t lr_xproj_workspace_bytes(int R, int I, int GH, int D, int H);
+// (one_product: every operand as its bf16 hi plane only, LR_RNN_PROJ_BF16X1)
 int lr_xproj_forward(const float* x, int R, int I, const float* const* w_ih, int GH, int D, const float* bias,
                      float* gates, int x_exact, int x_bf16, void* workspace, size_t workspace_bytes,
-                     hipStream_t stream);
+                     hipStream_t stream, int one_product = 0);
 int lr_xproj_dw(const float* dG, int ldg, int dstride, const float* x, int R, int I, int GH, int D,
                 float* const* dw_ih, float beta, int x_exact, int x_bf16, void* workspace, size_t workspace_bytes,
-                hipStream_t stream);
+                hipStream_t stream, int one_product = 0);
 int lr_xproj_dx(const float* dG, int ldg, int dstride, const float* const* w_ih, int R, int I, int GH, int D,
                 float* dx, int hi_only, int dx_bf16, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int lr_xproj_dwhh(const float* dG, int ldg, const float* y, int ldy, int R, int T, int H, int G, int D,
-                  float* const* dw_hh, float beta, void* workspace, size_t workspace_bytes, hipStream_t stream);
+                  float* const* dw_hh, float beta, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                  int one_product = 0);

@@ -610,11 +610,12 @@ inline bool x_exact(int mode) { return (mode & LR_RNN_INPUT_BF16_EXACT) != 0; }
 inline bool recur_bf16(int mode) { return (mode & LR_RNN_RECUR_BF16) != 0; }
 inline bool recur_split(int mode) { return (mode & LR_RNN_RECUR_SPLIT) != 0; }
 inline bool x_stored_bf16(int mode) { return (mode & LR_RNN_INPUT_STORED_BF16) != 0; }
+inline bool proj_x1(int mode) { return (mode & LR_RNN_PROJ_BF16X1) != 0; }
 bool dims_ok(int mode, int B, int T, int I, int H, int D) {
   return (cell_of(mode) == LR_RNN_GRU || cell_of(mode) == LR_RNN_LSTM || cell_of(mode) == LR_RNN_TANH) &&
          (mode & ~(LR_RNN_CELL_MASK | LR_RNN_PROJ_BF16X3 | LR_RNN_INPUT_BF16_EXACT | LR_RNN_RECUR_BF16 |
-                   LR_RNN_INPUT_STORED_BF16 | LR_RNN_RECUR_SPLIT)) == 0 &&
-         !(recur_bf16(mode) && recur_split(mode)) &&
+                   LR_RNN_INPUT_STORED_BF16 | LR_RNN_RECUR_SPLIT | LR_RNN_PROJ_BF16X1)) == 0 &&
+         !(recur_bf16(mode) && recur_split(mode)) && (!proj_x1(mode) || proj_x3(mode)) &&
          // a bf16-stored input only makes sense on the split-bf16 projection, as an exact operand
          (!x_stored_bf16(mode) || (proj_x3(mode) && x_exact(mode) && I % 8 == 0)) &&
          B > 0 && T > 0 && I > 0 && H > 0 && (D == 1 || D == 2);
@@ -630,7 +631,8 @@ size_t x3_ws_floats(int G, int B, int T, int I, int H, int D) {
 // GEMM was 325 us of a 1.22 ms step at 56 % of the fp32 matrix peak.  Small layers stay on the grouped fp32 GEMM
 // (one launch + one combine beats two packs + two contractions + two combines).
 bool wgrad_split(int mode, int G, int H) {
-  return recur_split(mode) && !proj_x3(mode) && G * H >= 768 && !lr_debug_wgrad_f32();
+  // (measured, B = 32, T = 75: LSTM-768 1.218 -> 1.155 ms per step; GRU-256 0.479 -> 0.484: too small to pay)
+  return recur_split(mode) && !proj_x3(mode) && G * H >= 1536 && !lr_debug_wgrad_f32();
 }
 
 }  // namespace
@@ -691,7 +693,7 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
   if (proj_x3(mode)) {
     // gates[b,t,:,:] = x[b,t,:] @ [W_ih[0]; W_ih[1]]^T + folded bias: both directions in one product
     int st = lr_xproj_forward(x, B * T, I, w_ih, GH, D, bias, gates, x_exact(mode) ? 1 : 0, x_stored_bf16(mode) ? 1 : 0,
-                              l.gemm_bytes ? (void*)(base + l.gemm) : nullptr, l.gemm_bytes, stream);
+                              l.gemm_bytes ? (void*)(base + l.gemm) : nullptr, l.gemm_bytes, stream, proj_x1(mode) ? 1 : 0);
     if (st != LR_OK) return st;
   } else if (D == 2 && (((w_ih[1] - w_ih[0]) & 3) == 0)) {
     // gates[b,t,d,:] = x[b,t,:] @ W_ih[d]^T + folded bias: both directions as one batched launch (x shared,
@@ -895,16 +897,16 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
     // input projection: all directions in one contraction per product (lr_xgemm.hip)
     if ((parts & 1) && dx) {
       // a bf16 input's gradient goes to a bf16 consumer (the conv frontend's backward): hi terms only
-      st = lr_xproj_dx(dG, ldg, 4 * H, w_ih, R, I, GH, D, dx, x_exact(mode) ? 1 : 0, x_stored_bf16(mode) ? 1 : 0, xws,
-                       xws_bytes, stream);
+      st = lr_xproj_dx(dG, ldg, 4 * H, w_ih, R, I, GH, D, dx, (x_exact(mode) || proj_x1(mode)) ? 1 : 0,
+                       x_stored_bf16(mode) ? 1 : 0, xws, xws_bytes, stream);
       if (st != LR_OK) return st;
     }
     if (!(parts & 2)) return LR_OK;
     st = lr_xproj_dw(dG, ldg, 4 * H, x, R, I, GH, D, dw_ih, wbeta, x_exact(mode) ? 1 : 0, x_stored_bf16(mode) ? 1 : 0,
-                     xws, xws_bytes, stream);
+                     xws, xws_bytes, stream, proj_x1(mode) ? 1 : 0);
     if (st != LR_OK) return st;
     // recurrent weight gradient on the same split-bf16 path (one contraction per direction)
-    st = lr_xproj_dwhh(dG, ldg, y, D * H, R, T, H, G, D, dw_hh, wbeta, xws, xws_bytes, stream);
+    st = lr_xproj_dwhh(dG, ldg, y, D * H, R, T, H, G, D, dw_hh, wbeta, xws, xws_bytes, stream, proj_x1(mode) ? 1 : 0);
     if (st != LR_OK) return st;
   }
   if (wx) {

@@ -362,11 +362,13 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
         asm volatile("" : "+s"(slot_off));
         const u32* xp = xbase + slot_off;
         const u32 tg = tag_of(s - 1);
+        // (a thread that has given up issues nothing: peek4's loads are invisible to the compiler, and the loop
+        // below — the only place that drains them — does not run for it)
         u32x4 g[NL];
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
           g[i] = (u32x4){0u, 0u, 0u, 0u};
-          if ((pend0 >> i) & 1u) g[i] = peek4(xp + (4 * i + wave) * XMEMBER);
+          if (((pend0 >> i) & 1u) && !bad) g[i] = peek4(xp + (4 * i + wave) * XMEMBER);
         }
         unsigned pend = pend0;
         for (int round = 0; pend && !bad; ++round) {
@@ -673,7 +675,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       g[i] = (u32x4){0u, 0u, 0u, 0u};
-      if ((pend0 >> i) & 1u) g[i] = peek4(xp + (4 * i + wave) * XMEMBER);
+      if (((pend0 >> i) & 1u) && !bad) g[i] = peek4(xp + (4 * i + wave) * XMEMBER);   // (see the forward kernel)
     }
     unsigned pend = pend0;
     for (int round = 0; pend && !bad; ++round) {

@@ -604,19 +604,20 @@ size_t lr_xproj_workspace_bytes(int R, int I, int GH, int D, int H) {
 // gates[R][D*GH] = x[R][I] . [W_ih[0]; W_ih[1]]^T + bias[D*GH]
 // x_bf16: x is stored as a bf16 matrix [R][I] (the conv frontend's features): with I % 8 == 0 it IS
 // the hi plane of the A operand and is not packed at all.
+// one_product (LR_RNN_PROJ_BF16X1): every operand as its bf16 hi plane only — ONE product instead of two or three
 int lr_xproj_forward(const float* x, int R, int I, const float* const* w_ih, int GH, int D, const float* bias,
                      float* gates, int x_exact, int x_bf16, void* workspace, size_t workspace_bytes,
-                     hipStream_t stream) {
+                     hipStream_t stream, int one_product) {
   const int N = D * GH, ldp = ldp_of(I);
   if (1 + D > XPACK_MAX || (x_bf16 && !x_exact)) return LR_ERR_UNSUPPORTED;
   Planes pl;
-  if (!carve(workspace, workspace_bytes, R, N, I, x_exact != 0, false, &pl)) return LR_ERR_WORKSPACE;
+  if (!carve(workspace, workspace_bytes, R, N, I, x_exact != 0 || one_product, one_product != 0, &pl)) return LR_ERR_WORKSPACE;
   PackList pk;
   const bool direct = x_bf16 && ldp == I;
   if (direct) pl.Ah = (bf16_t*)x;
   else pk.add(x, I, R, I, 0, pl.Ah, pl.Al, ldp, ldp, 0, 1, x_bf16);
   for (int d = 0; d < D; ++d)
-    pk.add(w_ih[d], I, GH, I, 0, pl.Bh + (size_t)d * GH * ldp, pl.Bl + (size_t)d * GH * ldp, ldp, ldp);
+    pk.add(w_ih[d], I, GH, I, 0, pl.Bh + (size_t)d * GH * ldp, pl.Bl ? pl.Bl + (size_t)d * GH * ldp : nullptr, ldp, ldp);
   int st = pk.launch(stream);
   if (st != LR_OK) return st;
   return contract(pl.Ah, pl.Al, pl.Bh, pl.Bl, R, N, I, 1.f, 0.f, gates, nullptr, R, N, bias, pl.slabs, pl.slab_floats,
@@ -626,14 +627,15 @@ int lr_xproj_forward(const float* x, int R, int I, const float* const* w_ih, int
 // dW_ih[d][GH][I] (beta) = dG[:, d, :GH]^T . x   — rows d*GH.. of one (D*GH) x I product over K = R
 int lr_xproj_dw(const float* dG, int ldg, int dstride, const float* x, int R, int I, int GH, int D,
                 float* const* dw_ih, float beta, int x_exact, int x_bf16, void* workspace, size_t workspace_bytes,
-                hipStream_t stream) {
+                hipStream_t stream, int one_product) {
   const int M = D * GH, ldp = ldp_of(R);
   if (1 + D > XPACK_MAX) return LR_ERR_UNSUPPORTED;
   Planes pl;
-  if (!carve(workspace, workspace_bytes, M, I, R, false, x_exact != 0, &pl)) return LR_ERR_WORKSPACE;
+  if (!carve(workspace, workspace_bytes, M, I, R, one_product != 0, x_exact != 0 || one_product, &pl)) return LR_ERR_WORKSPACE;
   PackList pk;
   for (int d = 0; d < D; ++d)
-    pk.add(dG + (size_t)d * dstride, ldg, R, GH, 1, pl.Ah + (size_t)d * GH * ldp, pl.Al + (size_t)d * GH * ldp, ldp, ldp);
+    pk.add(dG + (size_t)d * dstride, ldg, R, GH, 1, pl.Ah + (size_t)d * GH * ldp,
+           pl.Al ? pl.Al + (size_t)d * GH * ldp : nullptr, ldp, ldp);
   pk.add(x, I, R, I, 1, pl.Bh, pl.Bl, ldp, ldp, 0, 1, x_bf16);
   int st = pk.launch(stream);
   if (st != LR_OK) return st;
@@ -665,7 +667,8 @@ int lr_xproj_dx(const float* dG, int ldg, int dstride, const float* const* w_ih,
 // (0, 1, 3) for the GRU (dr, dz, d(W_hn h + b_hn)) and (0..3) for the LSTM.  The directions are two
 // batches of one launch (operands packed together, one contraction, one split-K combine).
 int lr_xproj_dwhh(const float* dG, int ldg, const float* y, int ldy, int R, int T, int H, int G, int D,
-                  float* const* dw_hh, float beta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                  float* const* dw_hh, float beta, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                  int one_product) {
   const int GH = G * H, ldp = ldp_of(R);
   if (D > 2 || 3 * D > XPACK_MAX) return LR_ERR_UNSUPPORTED;
   const size_t fa = plane_floats(GH, R, false), fb = plane_floats(H, R, false);
@@ -680,12 +683,12 @@ int lr_xproj_dwhh(const float* dG, int ldg, const float* y, int ldy, int R, int 
   for (int d = 0; d < D; ++d) {
     const float* g = dG + (size_t)d * 4 * H;
     bf16_t* Ah = A0 + (size_t)d * fa * 2;           // fa floats = 2 fa bf16 per batch
-    bf16_t* Al = Ah + (size_t)GH * ldp;
+    bf16_t* Al = one_product ? nullptr : Ah + (size_t)GH * ldp;
     bf16_t* Bh = B0 + (size_t)d * fb * 2;
-    bf16_t* Bl = Bh + (size_t)H * ldp;
+    bf16_t* Bl = one_product ? nullptr : Bh + (size_t)H * ldp;
     if (G == 3) {
       pk.add(g, ldg, R, 2 * H, 1, Ah, Al, ldp, ldp);
-      pk.add(g + 3 * H, ldg, R, H, 1, Ah + (size_t)2 * H * ldp, Al + (size_t)2 * H * ldp, ldp, ldp);
+      pk.add(g + 3 * H, ldg, R, H, 1, Ah + (size_t)2 * H * ldp, Al ? Al + (size_t)2 * H * ldp : nullptr, ldp, ldp);
     } else {
       pk.add(g, ldg, R, GH, 1, Ah, Al, ldp, ldp);
     }
@@ -693,8 +696,9 @@ int lr_xproj_dwhh(const float* dG, int ldg, const float* y, int ldy, int R, int 
   }
   int st = pk.launch(stream);
   if (st != LR_OK) return st;
-  return contract(A0, A0 + (size_t)GH * ldp, B0, B0 + (size_t)H * ldp, GH, H, R, 1.f, beta, dw_hh[0], nullptr, GH, H,
-                  nullptr, slabs, slab_floats, stream, D, (int64_t)fa * 2, (int64_t)fb * 2, D > 1 ? dw_hh[1] : nullptr);
+  return contract(A0, one_product ? nullptr : A0 + (size_t)GH * ldp, B0, one_product ? nullptr : B0 + (size_t)H * ldp, GH, H,
+                  R, 1.f, beta, dw_hh[0], nullptr, GH, H, nullptr, slabs, slab_floats, stream, D, (int64_t)fa * 2,
+                  (int64_t)fb * 2, D > 1 ? dw_hh[1] : nullptr);
 }
 
 extern "C" int lr_xgemm(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,

@@ -23,6 +23,7 @@ _ALLOWED_RNN_TYPES = {'LSTM', 'GRU', 'RNN'}          # better_model.py:9
 _ALLOWED_FRAME_PROCESSING = {'flatten'}              # better_model.py:10
 _MODES = {'GRU': 0, 'LSTM': 1, 'RNN': 2}
 _PROJ_BF16X3, _INPUT_BF16_EXACT, _RECUR_BF16, _INPUT_STORED_BF16, _RECUR_SPLIT = 0x100, 0x200, 0x400, 0x800, 0x1000   # lr_rnn_mode flags
+_PROJ_BF16X1 = 0x2000
 _GATES = {'GRU': 3, 'LSTM': 4, 'RNN': 1}
 
 
@@ -303,7 +304,7 @@ class VideoEncoder(nn.Module):
       max_len = int(frame_lens.max())          # host read iff frame_lens lives on the device
     assert 1 <= max_len <= T
     # the pixel regime hands the frontend's bf16 features over as they are (LR_RNN_INPUT_STORED_BF16)
-    stored_bf16 = (frames.dtype == torch.bfloat16 and self.input_projection == 'bf16x3' and self.input_is_bf16
+    stored_bf16 = (frames.dtype == torch.bfloat16 and self.input_projection in ('bf16x3', 'bf16x1') and self.input_is_bf16
                    and I % 8 == 0)
     x = frames[:, :max_len].contiguous() if stored_bf16 else frames[:, :max_len].to(torch.float32).contiguous()
     lens = frame_lens.to(device=x.device, dtype=torch.int32).contiguous()
@@ -314,11 +315,13 @@ class VideoEncoder(nn.Module):
       weights = self.rnn.layer_weights(layer, D)
       need_dx = layer > 0 or x.requires_grad
       lmode = mode
-      if self.input_projection == 'bf16x3':
+      if self.input_projection in ('bf16x3', 'bf16x1'):
         # build-defined (pixel regime): input projection on the bf16 matrix cores with hi/lo split
         # operands (include/lipreading_hip.h LR_RNN_PROJ_BF16X3); layer 0's input is bf16-exact
         # when it comes from the bf16 conv frontend
         lmode |= _PROJ_BF16X3 | (_INPUT_BF16_EXACT if (layer == 0 and self.input_is_bf16) else 0)
+        if self.input_projection == 'bf16x1':   # experiment: one bf16 product per GEMM (LR_RNN_PROJ_BF16X1)
+          lmode |= _PROJ_BF16X1
         if layer == 0 and stored_bf16:
           lmode |= _INPUT_STORED_BF16
       assert self.recurrence in ('auto', 'f32', 'split', 'bf16'), self.recurrence

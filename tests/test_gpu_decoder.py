@@ -376,7 +376,8 @@ def test_decoder_loop_on_the_cluster_recurrence_equals_the_step_kernels(dev, rnn
       ((lp * wgt).sum() + sum((f * wf).sum() for f in fins)).backward()
       egrad = e.grad if e.grad is not None else torch.zeros_like(e)    # (attention 'none' never reads the encoder states)
       out[name] = [lp.detach().cpu()] + [f.detach().cpu() for f in fins] + [egrad.cpu(), h.grad.cpu()] + \
-                  ([c.grad.cpu()] if rnn_type == "LSTM" else []) + [p.grad.cpu().clone() for p in dec.parameters()]
+                  ([c.grad.cpu()] if rnn_type == "LSTM" else []) + \
+                  [(p.grad if p.grad is not None else torch.zeros_like(p)).cpu().clone() for p in dec.parameters()]
   finally:
     L_.lr_rnn_debug_disable_cluster(0)
   assert L_.lr_rnn_pair_errors() == 0

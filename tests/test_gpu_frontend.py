@@ -197,7 +197,7 @@ def test_pixel_regime_fast_paths_track_the_plain_ones(dev):
   enc = VideoEncoder(feature_dim(H, H), 256, rnn_type='GRU', num_layers=2, bidirectional=True, enable_ctc=True,
                      vocab_size=64, char2idx=default_char2idx())
   model = PixelLipReader(enc, ConvFrontend3D()).to(dev).train()
-  assert enc.recurrence == 'bf16' and enc.input_projection == 'bf16x3'
+  assert enc.recurrence == 'split' and enc.input_projection == 'bf16x3'
   g = torch.Generator().manual_seed(8)
   B, T = 3, 11
   clips = torch.randint(0, 256, (B, T, 3, H, H), generator=g, dtype=torch.uint8).to(dev)
@@ -216,7 +216,7 @@ def test_pixel_regime_fast_paths_track_the_plain_ones(dev):
         assert feats.dtype == torch.float32
         lp, hid, _ = enc(feats.reshape(B, T, -1, 1), lens, max_len=T)
       finally:
-        enc.recurrence, enc.input_projection, enc.input_is_bf16 = 'bf16', 'bf16x3', True
+        enc.recurrence, enc.input_projection, enc.input_is_bf16 = 'split', 'bf16x3', True
     loss, status, _ = ctc_loss_with_status(lp, labels, lens, ll, 'mean')
     assert int(status) == 0
     loss.backward()
@@ -333,17 +333,19 @@ def test_layer2_tail_tiles_split_by_frame_are_the_same_numbers(dev):
 
 
 # ---- headline regime (BASELINE configs[1]) against the ORACLE, not against this repo's other paths ----
-# Stated tolerances: |loss_hip - loss_oracle| <= 1e-3 absolute on the 'mean' CTC loss
-# (bench.PARITY_TOL_PIXELS); encoder/CTC-head gradients within 3e-2 of the oracle's norm per tensor, conv
-# gradients within 6e-2 (bf16 activations: a rounding flip moves an activation by 2^-8 relative).
-PIXEL_LOSS_TOL = 1e-3
+# Stated tolerances, ~3x what was measured: |loss_hip - loss_oracle| <= 1e-4 absolute on the
+# 'mean' CTC loss — north_star's bar, the same as bench.PARITY_TOL_PIXELS at B = 32 (round 2: 1e-3 here, with the
+# single-plane bf16 recurrence measuring 5-7e-5; the fp32-faithful recurrence is the default now); log-probs 1e-3;
+# encoder/CTC-head gradients within 3e-3 of the oracle's norm per tensor (measured 6-8e-4), conv gradients within
+# 1e-2 (measured 2-2.5e-3: bf16 activations, a rounding flip moves an activation by 2^-8 relative).
+PIXEL_LOSS_TOL = 1e-4
 
 
 @pytest.mark.parametrize("B,lens", [(8, None), (8, [40, 52, 52, 60, 75, 75, 75, 75])])
 def test_pixel_regime_defaults_match_the_oracle(dev, B, lens):
   """Same uint8 clips and the same weights through (a) PixelLipReader with its DEFAULTS (bf16 conv
-  stack, bf16 features handed over as stored, split-bf16 input projection, one-launch recurrence with
-  bf16 recurrent operands) -> HIP ctc_loss, and (b) oracle.conv_frontend(emulate_bf16=True) ->
+  stack, bf16 features handed over as stored, split-bf16 input projection, one-launch fp32-faithful
+  recurrence) -> HIP ctc_loss, and (b) oracle.conv_frontend(emulate_bf16=True) ->
   OracleVideoEncoder (the reference's fp32 nn.GRU path) -> oracle.ctc_loss, at the metric's shape family
   (T = 75, 96x96, 2 x BiGRU-256).  The loss and every gradient are compared."""
   from lipreading_amd.ctc import ctc_loss_with_status
@@ -360,7 +362,7 @@ def test_pixel_regime_defaults_match_the_oracle(dev, B, lens):
   fe = ConvFrontend3D()
   convs = [p.detach().clone().requires_grad_(True) for p in fe.parameters_in_order()]
   model = PixelLipReader(enc, fe).to(dev).train()
-  assert enc.recurrence == 'bf16' and enc.input_projection == 'bf16x3'
+  assert enc.recurrence == 'split' and enc.input_projection == 'bf16x3'
   g = torch.Generator().manual_seed(32)
   clips = torch.randint(0, 256, (B, T, 3, H, H), generator=g, dtype=torch.uint8)
   lens = torch.tensor(lens) if lens is not None else torch.full((B,), T)
@@ -384,17 +386,17 @@ def test_pixel_regime_defaults_match_the_oracle(dev, B, lens):
   d_lp = float(((lp_h.detach().cpu() - lp_r.detach()) * valid).abs().max())
   print("pixel parity: loss hip %.7f oracle %.7f |d| %.3g; max |d log-prob| %.3g" % (float(loss_h), float(loss_r), d_loss, d_lp))
   assert d_loss <= PIXEL_LOSS_TOL, (float(loss_h), float(loss_r))
-  assert d_lp <= 2e-2
+  assert d_lp <= 1e-3
   ref_grads = dict(ref.named_parameters())
   worst = {}
   for k, p in enc.named_parameters():
     a, b = p.grad.cpu(), ref_grads[k].grad
     worst[k] = float((a - b).norm()) / max(1e-8, float(b.norm()))
-    assert worst[k] <= 3e-2, (k, worst[k])
+    assert worst[k] <= 3e-3, (k, worst[k])
   for i, (p, q) in enumerate(zip(fe.parameters_in_order(), convs)):
     r = float((p.grad.cpu() - q.grad).norm()) / max(1e-8, float(q.grad.norm()))
     worst["conv[%d]" % i] = r
-    assert r <= 6e-2, (i, r)
+    assert r <= 1e-2, (i, r)
   print("pixel parity: worst relative gradient differences", {k: float("%.2g" % v) for k, v in worst.items()})
 
 
