@@ -434,6 +434,11 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
     # experiment switch (include/lipreading_hip.h lr_rnn_debug_disable_cluster): 1 = no cluster recurrence,
     # 2 = no pair recurrence (GRU-256 then takes the 8-member cluster kernels)
     _C.lib().lr_rnn_debug_disable_cluster(int(os.environ["LIPREADING_RNN_DEBUG"]))
+  if os.environ.get("LIPREADING_RNN_TUNE"):
+    # experiment: "fwd_delay,fwd_sleep,bwd_delay,bwd_sleep" (lr_rnn_debug_tune)
+    t_ = [int(v) for v in os.environ["LIPREADING_RNN_TUNE"].split(",")]
+    _C.lib().lr_rnn_debug_tune(0, t_[0], t_[1])
+    _C.lib().lr_rnn_debug_tune(1, t_[2], t_[3])
   tfm = regime == "pixels_tfm"     # BASELINE configs[4]: conv features -> transformer encoder -> CTC (build-defined)
   pixels = regime == "pixels" or tfm
   attn = regime == "landmarks_attn"
@@ -459,6 +464,10 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
   # bf16 recurrent operands in a landmark regime too (not reference-faithful: reported as such)
   if os.environ.get("LIPREADING_RECURRENCE") and hasattr(enc, "recurrence"):
     enc.recurrence = os.environ["LIPREADING_RECURRENCE"]
+  if os.environ.get("LIPREADING_OVERLAP_WGRAD") and pixels:
+    # experiment: 0 = the recurrent layers' weight-gradient GEMMs stay on the main stream
+    from lipreading_amd import encoder as _enc_mod
+    _enc_mod.overlap_weight_grads = os.environ["LIPREADING_OVERLAP_WGRAD"] != "0"
   if os.environ.get("LIPREADING_INPUT_PROJECTION") and pixels:
     # experiment: 'bf16x1' = one bf16 product per GEMM of the recurrent layers' projections (LR_RNN_PROJ_BF16X1)
     enc.input_projection = os.environ["LIPREADING_INPUT_PROJECTION"]

@@ -54,6 +54,7 @@ SIGNATURES = {
     "lr_step_begin": (c_int, [P, c_int64, P, P]),
     "lr_rnn_debug_drop_member": (None, [c_int]),
     "lr_rnn_debug_disable_cluster": (None, [c_int]),
+    "lr_rnn_debug_tune": (None, [c_int, c_int, c_int]),
     "lr_rnn_reserve_bytes": (c_size_t, [c_int] * 6),
     "lr_rnn_workspace_bytes": (c_size_t, [c_int] * 6),
     "lr_rnn_layer_forward": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int,

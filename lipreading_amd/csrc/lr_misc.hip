@@ -532,6 +532,13 @@ extern "C" void lr_rnn_debug_disable_cluster(int off) { g_cluster_off = off; }
 int lr_debug_cluster_disabled() { return g_cluster_off & 1; }
 int lr_debug_pair_disabled() { return (g_cluster_off >> 1) & 1; }
 int lr_debug_wgrad_f32() { return (g_cluster_off >> 2) & 1; }
+// tuning knobs of the cluster recurrence's exchange (lr_rnn_debug_tune): [0] forward, [1] backward; bits 0-7 = 64-clock
+// sleeps before the first poll, bits 8-15 = sleeps between poll rounds
+namespace { int g_tune[2] = {1 << 8, 1 << 8}; }   // (swept on the MI355X: one sleep between rounds, no first-poll delay)
+int lr_debug_tune_value(int which) { return g_tune[which & 1]; }
+extern "C" void lr_rnn_debug_tune(int which, int first_poll_delay, int round_sleep) {
+  g_tune[which & 1] = (first_poll_delay & 0xff) | ((round_sleep & 0xff) << 8);
+}
 
 extern "C" int lr_rnn_pair_errors(void) {
   int32_t* w = lr_fault_words();

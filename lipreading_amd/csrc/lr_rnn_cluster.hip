@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
     float* __restrict__ gates, float* __restrict__ extra, float* __restrict__ y, const bf16x8* __restrict__ wpk,
     const float* __restrict__ bhh0, const float* __restrict__ bhh1, const float* __restrict__ h0,
     const float* __restrict__ c0, const int32_t* __restrict__ lens, u32* __restrict__ xch, int32_t* __restrict__ fault,
-    int drop, int g0, int nclusters, int B, int T, int D, int H) {
+    int drop, int tune, int g0, int nclusters, int B, int T, int D, int H) {
   using C = Cfg<G, CC>;
   constexpr int CLD = C::CLD, CF = C::CF, CF_A = C::CF_A, CF_REG = C::CF_REG, CF_L = C::CF_L, NL = C::NL, HP = C::HP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -364,6 +364,13 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
         const u32 tg = tag_of(s - 1);
         // (a thread that has given up issues nothing: peek4's loads are invisible to the compiler, and the loop
         // below — the only place that drains them — does not run for it)
+        // (tuning knobs, lr_rnn_debug_tune: sleeps before the first poll / between rounds.  Swept on the MI355X: a
+        // first-poll delay only costs — the first poll is usually answered —, one sleep between rounds is best by 1-3 %.
+        // Also measured and dropped: issuing the step's HBM traffic (next step's pre-activation loads, y / extra /
+        // gates stores) right AFTER the gather instead of before the publish, so that the polls would not queue
+        // behind it in the in-order return path — GRU-256 got 11 % slower: that traffic hides in the exchange wait
+        // where it is, and its address arithmetic then sits between the gather and the product.)
+        for (int w = 0; w < (tune & 0xff); ++w) __builtin_amdgcn_s_sleep(1);
         u32x4 g[NL];
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
             bad = 1;
             break;
           }
-          __builtin_amdgcn_s_sleep(2);
+          for (int w = 0; w < ((tune >> 8) & 0xff); ++w) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
           for (int i = 0; i < NL; ++i)
             if ((pend >> i) & 1u) g[i] = peek4(xp + (4 * i + wave) * XMEMBER);
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ dh_n, const float* __restrict__ dc_n, float* __restrict__ dG,
     float* __restrict__ dh0, float* __restrict__ dc0, const float* __restrict__ h0, const float* __restrict__ c0,
     const bf16x8* __restrict__ wpk, const int32_t* __restrict__ lens, u32* __restrict__ xch, int32_t* __restrict__ fault,
-    int drop, int g0, int nclusters, int B, int T, int D, int H) {
+    int drop, int tune, int g0, int nclusters, int B, int T, int D, int H) {
   using C = Cfg<G, CC>;
   constexpr int KB = C::KB, NT = C::NT, NL = C::NL, BFW = C::BFW, BFW_A = C::BFW_A, BFW_REG = C::BFW_REG, BFW_L = C::BFW_L,
                 BKLD = C::BKLD;
@@ -671,6 +678,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
     }
     // ---- gather: the 16 bytes of this lane from the blocks of source members wave, wave + 4, ... ------------------
     const u32* xp = xin + slot_off;
+    for (int w = 0; w < (tune & 0xff); ++w) __builtin_amdgcn_s_sleep(1);
     u32x4 g[NL];
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
@@ -694,7 +702,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
         bad = 1;
         break;
       }
-      __builtin_amdgcn_s_sleep(2);
+      for (int w = 0; w < ((tune >> 8) & 0xff); ++w) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
       for (int i = 0; i < NL; ++i)
         if ((pend >> i) & 1u) g[i] = peek4(xp + (4 * i + wave) * XMEMBER);
@@ -827,6 +835,7 @@ int fwd_launch(float* gates, float* extra, float* y, const float* const* w_hh, c
   if (st != LR_OK) return st;
   int32_t* fault = lr_fault_words();
   const int drop = lr_debug_drop_member_value();
+  const int tune = lr_debug_tune_value(0);
   const int groups = (B + NS - 1) / NS, gchunk = MAX_CLUSTERS / D;   // sample groups per launch
   for (int g0 = 0; g0 < groups; g0 += gchunk) {
     const int ng = groups - g0 < gchunk ? groups - g0 : gchunk, nclusters = ng * D;
@@ -835,12 +844,12 @@ int fwd_launch(float* gates, float* extra, float* y, const float* const* w_hh, c
     hipEvent_t e0, e1;
     if (g0 == 0 && lr_prof_next(LR_PROF_RNN_FWD, &e0, &e1))
       hipExtLaunchKernelGGL((rnnc_fwd_kernel<G, CC>), grid, dim3(256), C::FWD_LDS, stream, e0, e1, 0, gates, extra, y,
-                            (const bf16x8*)wpack, b_hh[0], b_hh[D - 1], h0, c0, lens, (u32*)xch, fault, drop, g0, nclusters,
-                            B, T, D, H);
+                            (const bf16x8*)wpack, b_hh[0], b_hh[D - 1], h0, c0, lens, (u32*)xch, fault, drop, tune, g0,
+                            nclusters, B, T, D, H);
     else
       hipLaunchKernelGGL((rnnc_fwd_kernel<G, CC>), grid, dim3(256), C::FWD_LDS, stream, gates, extra, y,
-                         (const bf16x8*)wpack, b_hh[0], b_hh[D - 1], h0, c0, lens, (u32*)xch, fault, drop, g0, nclusters, B,
-                         T, D, H);
+                         (const bf16x8*)wpack, b_hh[0], b_hh[D - 1], h0, c0, lens, (u32*)xch, fault, drop, tune, g0, nclusters,
+                         B, T, D, H);
     st = lr_launch_status();
     if (st != LR_OK) return st;
   }
@@ -865,6 +874,7 @@ int bwd_launch(const float* gates, const float* extra, const float* y, const flo
   if (st != LR_OK) return st;
   int32_t* fault = lr_fault_words();
   const int drop = lr_debug_drop_member_value();
+  const int tune = lr_debug_tune_value(1);
   const int groups = (B + NS - 1) / NS, gchunk = MAX_CLUSTERS / D;
   for (int g0 = 0; g0 < groups; g0 += gchunk) {
     const int ng = groups - g0 < gchunk ? groups - g0 : gchunk, nclusters = ng * D;
@@ -873,11 +883,12 @@ int bwd_launch(const float* gates, const float* extra, const float* y, const flo
     hipEvent_t e0, e1;
     if (g0 == 0 && lr_prof_next(LR_PROF_RNN_BWD, &e0, &e1))
       hipExtLaunchKernelGGL((rnnc_bwd_kernel<G, CC>), grid, dim3(256), C::BWD_LDS, stream, e0, e1, 0, gates, extra, y, dy,
-                            dh_n, dc_n, dG, dh0, dc0, h0, c0, (const bf16x8*)wpack, lens, (u32*)xch, fault, drop, g0,
+                            dh_n, dc_n, dG, dh0, dc0, h0, c0, (const bf16x8*)wpack, lens, (u32*)xch, fault, drop, tune, g0,
                             nclusters, B, T, D, H);
     else
       hipLaunchKernelGGL((rnnc_bwd_kernel<G, CC>), grid, dim3(256), C::BWD_LDS, stream, gates, extra, y, dy, dh_n, dc_n, dG,
-                         dh0, dc0, h0, c0, (const bf16x8*)wpack, lens, (u32*)xch, fault, drop, g0, nclusters, B, T, D, H);
+                         dh0, dc0, h0, c0, (const bf16x8*)wpack, lens, (u32*)xch, fault, drop, tune, g0, nclusters, B, T, D,
+                         H);
     st = lr_launch_status();
     if (st != LR_OK) return st;
   }

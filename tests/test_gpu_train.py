@@ -419,8 +419,13 @@ def test_pixel_pipeline_end_to_end_on_a_six_video_dataview(dev, tmp_path, encode
   assert len(h) == 2 and all(np.isfinite(e["ctc_loss"]) for e in h) and h[1]["ctc_loss"] < h[0]["ctc_loss"]
   assert all(0.0 <= e[k] <= 2.0 for e in h for k in ("train_cer", "val_cer", "test_cer"))
   model, c2i, (train_loader, _, _) = out["encoder"], out["char2idx"], out["loaders"]
-  sd = torch.load(os.path.join(out["weights_dir"], "best_encoder.pth"), map_location="cpu")
-  assert "frontend.conv1.weight" in sd and any(k.startswith("encoder.") for k in sd)
+  # (best_encoder.pth is written when the validation CER drops below 1 — two epochs need not get there; the
+  # checkpoint contract is checked directly)
+  ckpt = os.path.join(out["weights_dir"], "probe_encoder.pth")
+  model.best_error = 1
+  model.save_best_model(0.5, ckpt)
+  sd = torch.load(ckpt, map_location="cpu")
+  assert "frontend.conv1.weight" in sd and any(k.startswith("encoder.") for k in sd) and model.best_error == 0.5
   # ---- the oracle twin on the same weights and the same raw samples -------------------------------------------
   labels = ctc_labels(c2i)
   convs = [p.detach().cpu().clone() for p in model.frontend.parameters_in_order()]
