@@ -168,9 +168,13 @@ int lr_gru256_pair_backward(const float* gates, const float* extra, const float*
 int lr_rnn_cluster_supported(int G, int B, int H);
 size_t lr_rnn_cluster_pack_bytes(int G, int H, int D, int backward);
 size_t lr_rnn_cluster_xch_bytes(int B, int H, int D, int backward);
+// prologue_done: lr_rnn_cluster_prologue already ran for this pass (W_hh packed into wpack, the first launch's
+// exchange words cleared) — one launch that also folds the layer's biases into bias_out [D][G*H] for the input projection
 int lr_rnn_cluster_forward(int G, float* gates, float* extra, float* y, const float* const* w_hh, const float* const* b_hh,
                            const float* h0, const float* c0, const int32_t* lens, void* wpack, void* xch, int B, int T,
-                           int D, int H, hipStream_t stream);
+                           int D, int H, hipStream_t stream, int prologue_done = 0);
+int lr_rnn_cluster_prologue(int G, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
+                            float* bias_out, void* wpack, void* xch, int B, int D, int H, hipStream_t stream);
 int lr_rnn_cluster_backward(int G, const float* gates, const float* extra, const float* y, const float* dy,
                             const float* dh_n, const float* dc_n, float* dG, float* dh0, float* dc0, const float* h0,
                             const float* c0, const float* const* w_hh, const int32_t* lens, void* wpack, void* xch, int B,

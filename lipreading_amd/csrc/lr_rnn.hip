@@ -684,7 +684,14 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
   float* bias = base + l.bias;
   const int GH = G * H;
 
-  {
+  // the cluster recurrence's prologue does three launches' work in one: biases folded, W_hh packed into its fragment
+  // order, exchange words cleared (none of it depends on the input projection below)
+  const bool cluster = recur_split(mode) && lr_rnn_cluster_supported(G, B, H);
+  if (cluster) {
+    if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_rnn_cluster_pack_bytes(G, H, D, 0)) return LR_ERR_WORKSPACE;
+    int st = lr_rnn_cluster_prologue(G, w_hh, b_ih, b_hh, bias, base + l.wp, base + l.xch, B, D, H, stream);
+    if (st != LR_OK) return st;
+  } else {
     LR_LAUNCH(fold_bias2_kernel, dim3((GH + 255) / 256, D), dim3(256), 0, stream, b_ih[0], b_hh[0], b_ih[D - 1],
               b_hh[D - 1], bias, G, H);
     int st = lr_launch_status();
@@ -717,7 +724,7 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
     if (lr_rnn_cluster_supported(G, B, H)) {
       if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_rnn_cluster_pack_bytes(G, H, D, 0)) return LR_ERR_WORKSPACE;
       st = lr_rnn_cluster_forward(G, gates, extra, y, w_hh, b_hh, nullptr, nullptr, lens, base + l.wp, base + l.xch, B, T,
-                                  D, H, stream);
+                                  D, H, stream, 1);
     } else if (lr_gru256_pair_supported(G, B, H)) {
       if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_gru256_pair_pack_bytes(D)) return LR_ERR_WORKSPACE;
       st = lr_gru256_pair_forward(gates, extra, y, w_hh, b_hh, lens, base + l.wp, base + l.xch, B, T, D, stream);

@@ -180,10 +180,26 @@ __device__ __forceinline__ void xcd_handshake(u32* xid, int c, int tid, int* s_l
 // out[((((d*CC + c)*4 + wave)*2 + t)*CF + f)*64 + lane] = plane f & 1 of W_hh[gate*H + unit][k .. k+7],
 // gate = 2t + (col >> 3), unit = 32c + 8 wave + (col & 7), k = 32 ((c + (f >> 1)) % CC) + 8 kg (LOCAL k order: the
 // own member's k step first); zero where gate >= G, unit >= H or k >= H.
+// The same launch clears the first launch's exchange words and (FoldPtrs given) folds the layer's biases for the
+// input projection (lr_rnn.hip fold_bias2_kernel's arithmetic: b_ih + b_hh, except the GRU's n gate, whose b_hn sits
+// inside r * (W_hn h + b_hn)) — one launch where there were three (a dependent launch costs ~1.5-5 us here).
+struct FoldPtrs {
+  const float* b_ih[2];
+  const float* b_hh[2];
+  float* out;      // [D][G*H], or nullptr: nothing to fold
+};
 template <int G, int CC>
 __global__ void rnnc_pack_fwd_kernel(const float* __restrict__ w0, const float* __restrict__ w1, bf16x8* __restrict__ out,
-                                     int D, int H) {
+                                     int D, int H, u32* __restrict__ xch, int nzero, FoldPtrs fold) {
   constexpr int CF = Cfg<G, CC>::CF;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += gridDim.x * blockDim.x) xch[i] = 0u;
+  if (fold.out)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < D * G * H; i += gridDim.x * blockDim.x) {
+      const int d = i / (G * H), j = i - d * (G * H);
+      float v = fold.b_ih[d][j];
+      if (G != 3 || j < 2 * H) v += fold.b_hh[d][j];
+      fold.out[i] = v;
+    }
   const int64_t total = (int64_t)D * CC * 4 * 2 * CF * 64;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int lane = (int)(i & 63), f = (int)((i >> 6) % CF), t = (int)((i / (64 * CF)) & 1);
@@ -210,8 +226,9 @@ __global__ void rnnc_pack_fwd_kernel(const float* __restrict__ w0, const float* 
 // zero where 32 c + 8 kg + e >= H or j >= H.
 template <int G, int CC>
 __global__ void rnnc_pack_bwd_kernel(const float* __restrict__ w0, const float* __restrict__ w1, bf16x8* __restrict__ out,
-                                     int D, int H) {
+                                     int D, int H, u32* __restrict__ xch, int nzero) {
   constexpr int NT = Cfg<G, CC>::NT, BFW = Cfg<G, CC>::BFW;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += gridDim.x * blockDim.x) xch[i] = 0u;
   const int64_t total = (int64_t)D * CC * 4 * NT * BFW * 64;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int lane = (int)(i & 63), f = (int)((i >> 6) % BFW), tile = (int)((i / (64 * BFW)) % NT);
@@ -817,10 +834,32 @@ size_t xch_words(int CC, int nclusters, int backward) {
   return (size_t)2 * nclusters * per + (size_t)nclusters * CC;
 }
 
+// words of the first launch's exchange area
+inline int first_xch_words(int CC, int B, int D, int backward) {
+  const int groups = (B + NS - 1) / NS, gchunk = MAX_CLUSTERS / D;
+  return (int)xch_words(CC, (groups < gchunk ? groups : gchunk) * D, backward);
+}
+
+// the layer's prologue: W_hh -> fragments, exchange words of the first launch cleared, biases folded (b_ih may be
+// NULL: nothing to fold)
+template <int G, int CC>
+int fwd_prologue(const float* const* w_hh, const float* const* b_ih, const float* const* b_hh, float* bias_out, void* wpack,
+                 void* xch, int B, int D, int H, hipStream_t stream) {
+  FoldPtrs fold;
+  for (int d = 0; d < 2; ++d) {
+    fold.b_ih[d] = b_ih ? b_ih[d < D ? d : 0] : nullptr;
+    fold.b_hh[d] = b_hh ? b_hh[d < D ? d : 0] : nullptr;
+  }
+  fold.out = b_ih ? bias_out : nullptr;
+  LR_LAUNCH((rnnc_pack_fwd_kernel<G, CC>), dim3(1024), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D, H,
+            (u32*)xch, first_xch_words(CC, B, D, 0), fold);
+  return lr_launch_status();
+}
+
 template <int G, int CC>
 int fwd_launch(float* gates, float* extra, float* y, const float* const* w_hh, const float* const* b_hh, const float* h0,
                const float* c0, const int32_t* lens, void* wpack, void* xch, int B, int T, int D, int H,
-               hipStream_t stream) {
+               hipStream_t stream, int prologue_done) {
   using C = Cfg<G, CC>;
   static bool attr_set = false;
   lr_clear_error();
@@ -830,16 +869,19 @@ int fwd_launch(float* gates, float* extra, float* y, const float* const* w_hh, c
       return LR_ERR_LAUNCH;
     attr_set = true;
   }
-  LR_LAUNCH((rnnc_pack_fwd_kernel<G, CC>), dim3(1024), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D, H);
-  int st = lr_launch_status();
-  if (st != LR_OK) return st;
+  int st = LR_OK;
+  if (!prologue_done) {
+    st = fwd_prologue<G, CC>(w_hh, nullptr, nullptr, nullptr, wpack, xch, B, D, H, stream);
+    if (st != LR_OK) return st;
+  }
   int32_t* fault = lr_fault_words();
   const int drop = lr_debug_drop_member_value();
   const int tune = lr_debug_tune_value(0);
   const int groups = (B + NS - 1) / NS, gchunk = MAX_CLUSTERS / D;   // sample groups per launch
   for (int g0 = 0; g0 < groups; g0 += gchunk) {
     const int ng = groups - g0 < gchunk ? groups - g0 : gchunk, nclusters = ng * D;
-    if (hipMemsetAsync(xch, 0, xch_words(CC, nclusters, 0) * sizeof(u32), stream) != hipSuccess) return LR_ERR_LAUNCH;
+    // (the first launch's words were cleared by the prologue)
+    if (g0 > 0 && hipMemsetAsync(xch, 0, xch_words(CC, nclusters, 0) * sizeof(u32), stream) != hipSuccess) return LR_ERR_LAUNCH;
     const dim3 grid(8 * CC);
     hipEvent_t e0, e1;
     if (g0 == 0 && lr_prof_next(LR_PROF_RNN_FWD, &e0, &e1))
@@ -869,7 +911,8 @@ int bwd_launch(const float* gates, const float* extra, const float* y, const flo
       return LR_ERR_LAUNCH;
     attr_set = true;
   }
-  LR_LAUNCH((rnnc_pack_bwd_kernel<G, CC>), dim3(1024), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D, H);
+  LR_LAUNCH((rnnc_pack_bwd_kernel<G, CC>), dim3(1024), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D, H,
+            (u32*)xch, first_xch_words(CC, B, D, 1));
   int st = lr_launch_status();
   if (st != LR_OK) return st;
   int32_t* fault = lr_fault_words();
@@ -878,7 +921,7 @@ int bwd_launch(const float* gates, const float* extra, const float* y, const flo
   const int groups = (B + NS - 1) / NS, gchunk = MAX_CLUSTERS / D;
   for (int g0 = 0; g0 < groups; g0 += gchunk) {
     const int ng = groups - g0 < gchunk ? groups - g0 : gchunk, nclusters = ng * D;
-    if (hipMemsetAsync(xch, 0, xch_words(CC, nclusters, 1) * sizeof(u32), stream) != hipSuccess) return LR_ERR_LAUNCH;
+    if (g0 > 0 && hipMemsetAsync(xch, 0, xch_words(CC, nclusters, 1) * sizeof(u32), stream) != hipSuccess) return LR_ERR_LAUNCH;
     const dim3 grid(8 * CC);
     hipEvent_t e0, e1;
     if (g0 == 0 && lr_prof_next(LR_PROF_RNN_BWD, &e0, &e1))
@@ -934,10 +977,22 @@ size_t lr_rnn_cluster_xch_bytes(int B, int H, int D, int backward) {
 
 int lr_rnn_cluster_forward(int G, float* gates, float* extra, float* y, const float* const* w_hh, const float* const* b_hh,
                            const float* h0, const float* c0, const int32_t* lens, void* wpack, void* xch, int B, int T,
-                           int D, int H, hipStream_t stream) {
+                           int D, int H, hipStream_t stream, int prologue_done) {
   const int cc = (H + UPM - 1) / UPM;
+#define X(g, c)          \
+  if (G == g && cc == c) \
+    return fwd_launch<g, c>(gates, extra, y, w_hh, b_hh, h0, c0, lens, wpack, xch, B, T, D, H, stream, prologue_done);
+  LR_CLUSTER_SHAPES(X)
+#undef X
+  return LR_ERR_UNSUPPORTED;
+}
+
+int lr_rnn_cluster_prologue(int G, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
+                            float* bias_out, void* wpack, void* xch, int B, int D, int H, hipStream_t stream) {
+  const int cc = (H + UPM - 1) / UPM;
+  lr_clear_error();
 #define X(g, c) \
-  if (G == g && cc == c) return fwd_launch<g, c>(gates, extra, y, w_hh, b_hh, h0, c0, lens, wpack, xch, B, T, D, H, stream);
+  if (G == g && cc == c) return fwd_prologue<g, c>(w_hh, b_ih, b_hh, bias_out, wpack, xch, B, D, H, stream);
   LR_CLUSTER_SHAPES(X)
 #undef X
   return LR_ERR_UNSUPPORTED;
