@@ -25,6 +25,13 @@
 // in flight per workgroup (register ring) behind LDS-only barriers; K is split over workgroups
 // until ~2 are resident per CU, partial sums reduced in fixed order (deterministic); tiles are
 // ordered so that the ~64 resident on one XCD share operand panels in its L2.
+//
+// Where it stands (round 3, tools/bench_xgemm.py, contraction alone): 0.5-0.75 PF/s on the steps' shapes (K >= 1536),
+// i.e. 20-30 % of the bf16 peak.  Measured and dropped: two LDS stage buffers with ONE barrier per stage instead of
+// store / barrier / read / barrier on one buffer — no change (+-3 % on every shape), so the barriers are not what
+// bounds it.  What does: a 128 x 128 tile pulls 3-4 plane tiles (24-32 KB) through the CU's vector L1 per stage of
+// 512-768 MFMA clocks, ~47 B/clk with two workgroups per CU — the L1's rate.  The next step is a 256 x 256 tile
+// (8 waves, 23 B/clk), not a deeper pipeline.
 #include "lr_common.h"
 
 namespace {
