@@ -23,7 +23,9 @@ RECURRENT = {"rnn_fwd_step_kernel": "rnn_fwd_step_kernel", "rnn_bwd_step_kernel"
 # the cluster recurrence's instantiations (lr_rnn_cluster.hip): bench.py's name "rnnc_fwd_kernel<G,CC>"
 for _g, _cc in ((3, 8), (4, 8), (3, 16), (4, 16), (3, 22), (4, 22), (3, 24), (4, 24), (3, 25)):
   for _w in ("fwd", "bwd"):
-    RECURRENT["rnnc_%s_kernel<%d,%d>" % (_w, _g, _cc)] = "rnnc_%s_kernel<%d, %d>" % (_w, _g, _cc)
+    # (the profiler leaves some of these names mangled: both spellings)
+    RECURRENT["rnnc_%s_kernel<%d,%d>" % (_w, _g, _cc)] = ("rnnc_%s_kernel<%d, %d>" % (_w, _g, _cc),
+                                                          "rnnc_%s_kernelILi%dELi%dE" % (_w, _g, _cc))
 MODELS = ("gru256", "lstm768", "lstm700", "lstm512", "gru800")
 
 
@@ -43,8 +45,9 @@ def read(path):
 
 
 def lookup(rows, sub, counter=None):
+  subs = sub if isinstance(sub, tuple) else (sub,)
   for name, c, calls, avg in rows:
-    if sub in name and (counter is None or c == counter):
+    if any(x in name for x in subs) and (counter is None or c == counter):
       return avg, calls, name
   return None
 

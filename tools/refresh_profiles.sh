@@ -5,15 +5,16 @@
 # `python tools/make_pmc_traffic.py r02` to rebuild the traffic JSON bench.py reads).
 # A second argument "pixels" regenerates only what a change to the conv kernels moves: the default bench line and the
 # pixel regimes' kernel statistics, traffic, timeline and counters, most important first.
-#   <round>_bench_default.json / _bench_gru256.json / _bench_lstm768.json / _bench_forcedist.json   bench lines
-#   <round>_{pixels,gru256,lstm768,landmarks_attn,pixels_tfm}_kernel_stats.txt   rocprofv3 --kernel-trace --stats per kernel
-#   <round>_{pixels,gru256,lstm768}_pmc_{FETCH,WRITE}_SIZE.txt       HBM/fabric bytes per launch (separate --pmc passes)
-#   <round>_pixels_pmc_SQ_pass{1,2}.txt   matrix-pipe / LDS counters of the conv, recurrence and xgemm kernels
+#   <round>_bench_default.json / _bench_{gru256,lstm768,lstm700,lstm512,gru800}.json / _bench_forcedist.json   bench lines
+#   <round>_{pixels,gru256,lstm768,lstm700,landmarks_attn,pixels_tfm}_kernel_stats.txt   rocprofv3 --kernel-trace --stats per kernel
+#   <round>_{pixels,gru256,lstm768,lstm700}_pmc_{FETCH,WRITE}_SIZE.txt   HBM/fabric bytes per launch (separate --pmc passes)
+#   <round>_{pixels,gru256,lstm768}_pmc_SQ_pass1.txt, <round>_pixels_pmc_SQ_pass2.txt   matrix-pipe / LDS counters of the
+#                                                                       conv, recurrence and GEMM kernels
 #   <round>_{pixels,gru256}_step_timeline.txt   every dispatch of one replayed step with start offset and queue
 # PMC passes never share a run with trace domains other than the kernel trace rocprofv3 adds itself.
 set -u
 R=$PWD
-TAG=${1:-r02}
+TAG=${1:-r03}
 ONLY=${2:-all}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
@@ -52,19 +53,24 @@ for c in FETCH_SIZE WRITE_SIZE; do pmc px_$c $c pixels_pmc_$c -- --regime pixels
 tl pixels conv1_fwd --regime pixels
 kt pixels_tfm --regime pixels_tfm
 LIPREADING_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_forcedist.json"
-pmc sq1 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" pixels_pmc_SQ_pass1 conv_ conv1_ gru256 xgemm -- --regime pixels
-pmc sq2 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA" pixels_pmc_SQ_pass2 conv_ conv1_ gru256 xgemm -- --regime pixels
+pmc sq1 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" pixels_pmc_SQ_pass1 conv_ conv1_ rnnc_ xgemm -- --regime pixels
+pmc sq2 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA" pixels_pmc_SQ_pass2 conv_ conv1_ rnnc_ xgemm -- --regime pixels
 if [ "$ONLY" != "pixels" ]; then
-  python bench.py --regime landmarks --model gru256 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_gru256.json"
-  python bench.py --regime landmarks --model lstm768 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_lstm768.json"
+  for m in gru256 lstm768 lstm700 lstm512 gru800; do
+    python bench.py --regime landmarks --model $m 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_$m.json"
+  done
   kt gru256 --regime landmarks --model gru256
   kt lstm768 --regime landmarks --model lstm768
+  kt lstm700 --regime landmarks --model lstm700
   kt landmarks_attn --regime landmarks_attn
   tl gru256 ctc_prepare --regime landmarks --model gru256
+  tl lstm768 ctc_prepare --regime landmarks --model lstm768
   for c in FETCH_SIZE WRITE_SIZE; do
     pmc gru_$c $c gru256_pmc_$c -- --regime landmarks --model gru256
     pmc lstm_$c $c lstm768_pmc_$c -- --regime landmarks --model lstm768
+    pmc lstm7_$c $c lstm700_pmc_$c -- --regime landmarks --model lstm700
   done
-  pmc sq3 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" gru256_pmc_SQ_pass1 gru256 sgemm -- --regime landmarks --model gru256
+  pmc sq3 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" gru256_pmc_SQ_pass1 rnnc_ sgemm xgemm -- --regime landmarks --model gru256
+  pmc sq4 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" lstm768_pmc_SQ_pass1 rnnc_ sgemm xgemm -- --regime landmarks --model lstm768
 fi
 ls -la "$OUT" | grep "${TAG}_"
