@@ -116,6 +116,19 @@ __device__ __forceinline__ void split_bf16_pair(float a, float b, u32& hi, u32& 
   lo = __builtin_bit_cast(u32, l);
 }
 
+// ---- gate non-linearities --------------------------------------------------------------------------------------
+// The cell runs ONCE per thread and step, on the critical path of the step chain, and its transcendental functions
+// were a sixth of a GRU-256 step: expf / tanhf of the device library cost ~10 / ~30+ instructions (range
+// reduction, fix-ups, an IEEE division).  Here: v_exp_f32 and v_rcp_f32 (1 ulp each) — sigmoid to ~3e-7 relative,
+// tanh to ~2e-7 ABSOLUTE (1 - 2 / (1 + e^2x): exact saturation at both ends, cancellation only where |tanh| is
+// small), an order of magnitude inside the 2^-18 of the hi + lo operand split these kernels already work with.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
 // ---- exchange words ------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 tag_of(int step) { return 1u + (u32)((step >> 1) % 3); }
 __device__ __forceinline__ u32 xword(float v, u32 tag) {
@@ -361,7 +374,8 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
 #pragma unroll
     for (int g = 0; g < G; ++g) sum[g] = 0.f;
     if (s > 0 || has_h0) {
-      f32x4 acc0[2], acc1[2];     // hi / lo weight plane
+      f32x4 acc0[2], acc1[2];     // hi / lo weight plane: four accumulation chains per wave (eight — even / odd k
+                                  // steps apart — measured 4 % slower: the chains are not what the product waits for)
       // ---- own member's k step (local q = 0): its operands are already in LDS --------------------------------------
       {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(hcur + col * CLD + kg * 8);
@@ -474,21 +488,21 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
     float go[G];
     if (G == 3) {
       const float hn = sum[2] + bhn;
-      const float r = lr_sigmoid(gx.v[0] + sum[0]);
-      const float z = lr_sigmoid(gx.v[1] + sum[1]);
-      const float n = tanhf(gx.v[2] + r * hn);
+      const float r = fast_sigmoid(gx.v[0] + sum[0]);
+      const float z = fast_sigmoid(gx.v[1] + sum[1]);
+      const float n = fast_tanh(gx.v[2] + r * hn);
       h = live ? (1.f - z) * n + z * sreg : 0.f;
       go[0] = r;
       go[1] = z;
       go[2] = n;
       ex = live ? hn : 0.f;
     } else {
-      const float ig = lr_sigmoid(gx.v[0] + sum[0]);
-      const float fg = lr_sigmoid(gx.v[1] + sum[1]);
-      const float gg = tanhf(gx.v[2] + sum[2]);
-      const float og = lr_sigmoid(gx.v[G - 1] + sum[G - 1]);
+      const float ig = fast_sigmoid(gx.v[0] + sum[0]);
+      const float fg = fast_sigmoid(gx.v[1] + sum[1]);
+      const float gg = fast_tanh(gx.v[2] + sum[2]);
+      const float og = fast_sigmoid(gx.v[G - 1] + sum[G - 1]);
       const float cn = live ? fg * sreg + ig * gg : 0.f;
-      h = live ? og * tanhf(cn) : 0.f;
+      h = live ? og * fast_tanh(cn) : 0.f;
       go[0] = ig;
       go[1] = fg;
       go[2] = gg;
@@ -786,7 +800,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
       float di = 0.f, df = 0.f, dg_ = 0.f, do_ = 0.f;
       car = 0.f;
       if (live) {
-        const float tc = tanhf(ct);
+        const float tc = fast_tanh(ct);
         dc += dh * og * (1.f - tc * tc);
         di = dc * gg * ig * (1.f - ig);
         df = dc * cp * fg * (1.f - fg);
