@@ -198,6 +198,11 @@ int lr_xproj_dw(const float* dG, int ldg, int dstride, const float* x, int R, in
                 hipStream_t stream, int one_product = 0);
 int lr_xproj_dx(const float* dG, int ldg, int dstride, const float* const* w_ih, int R, int I, int GH, int D,
                 float* dx, int hi_only, int dx_bf16, void* workspace, size_t workspace_bytes, hipStream_t stream);
+// dW_ih and dW_hh from ONE pack of dG (layers whose recurrent side reads dG slots 0..G-1: LSTM, tanh RNN)
+size_t lr_xproj_dw_both_workspace_bytes(int R, int I, int GH, int H, int D);
+int lr_xproj_dw_both(const float* dG, int ldg, int dstride, const float* x, const float* y, int ldy, int R, int T, int I,
+                     int H, int GH, int D, float* const* dw_ih, float* const* dw_hh, float beta, void* workspace,
+                     size_t workspace_bytes, hipStream_t stream);
 int lr_xproj_dwhh(const float* dG, int ldg, const float* y, int ldy, int R, int T, int H, int G, int D,
                   float* const* dw_hh, float beta, void* workspace, size_t workspace_bytes, hipStream_t stream,
                   int one_product = 0);

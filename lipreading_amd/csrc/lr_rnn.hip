@@ -623,7 +623,10 @@ bool dims_ok(int mode, int B, int T, int I, int H, int D) {
 // extra workspace floats of the bf16x3 input projection's backward (operand planes + split-K slabs
 // of the larger of its products, all directions in one contraction)
 size_t x3_ws_floats(int G, int B, int T, int I, int H, int D) {
-  return (lr_xproj_workspace_bytes(B * T, I, G * H, D, H) / sizeof(float) + 63) / 64 * 64;
+  size_t b = lr_xproj_workspace_bytes(B * T, I, G * H, D, H);
+  const size_t b2 = lr_xproj_dw_both_workspace_bytes(B * T, I, G * H, H, D);
+  if (b2 > b) b = b2;
+  return (b / sizeof(float) + 63) / 64 * 64;
 }
 // The weight gradients of a layer whose recurrence runs fp32-FAITHFUL on the bf16 matrix cores (LR_RNN_RECUR_SPLIT)
 // take the same route: dW_ih and dW_hh as split-bf16 products (bf16 hi + lo operand planes, three cross terms, fp32
@@ -916,8 +919,13 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
     st = lr_xproj_dwhh(dG, ldg, y, D * H, R, T, H, G, D, dw_hh, wbeta, xws, xws_bytes, stream, proj_x1(mode) ? 1 : 0);
     if (st != LR_OK) return st;
   }
-  if (wx) {
-    // fp32-faithful on the bf16 matrix cores, like the recurrence that produced dG (lr_xgemm.hip)
+  if (wx && G != 3) {
+    // fp32-faithful on the bf16 matrix cores, like the recurrence that produced dG (lr_xgemm.hip); both products
+    // read the same dG slots: ONE pack of dG
+    st = lr_xproj_dw_both(dG, ldg, 4 * H, x, y, D * H, R, T, I, H, GH, D, dw_ih, dw_hh, wbeta, xws, xws_bytes, stream);
+    if (st != LR_OK) return st;
+  } else if (wx) {
+    // (GRU: the recurrent side reads slot 3 where the input side reads slot 2)
     st = lr_xproj_dw(dG, ldg, 4 * H, x, R, I, GH, D, dw_ih, wbeta, 0, 0, xws, xws_bytes, stream);
     if (st != LR_OK) return st;
     st = lr_xproj_dwhh(dG, ldg, y, D * H, R, T, H, G, D, dw_hh, wbeta, xws, xws_bytes, stream);

@@ -708,6 +708,50 @@ int lr_xproj_dwhh(const float* dG, int ldg, const float* y, int ldy, int R, int 
                   (int64_t)fb * 2, D > 1 ? dw_hh[1] : nullptr);
 }
 
+// dW_ih AND dW_hh of a layer whose recurrent side reads the same dG slots as its input side (LSTM: i, f, g, o; the
+// tanh RNN) from ONE pack of dG: the transposed hi / lo planes of dG [D*GH][R] are the A operand of both products
+// (lr_xproj_dw + lr_xproj_dwhh pack them twice: 37 us each at BiLSTM-768).  One pack launch (dG blocks, x, the
+// time-shifted y blocks), two contractions.
+size_t lr_xproj_dw_both_workspace_bytes(int R, int I, int GH, int H, int D) {
+  if (R <= 0 || I <= 0 || GH <= 0 || H <= 0 || D <= 0) return 0;
+  size_t slab = (size_t)want_splits(D * GH, I, R) * D * GH * I;
+  const size_t s2 = (size_t)want_splits(GH, H * D, R) * GH * H * D;
+  if (s2 > slab) slab = s2;
+  return (plane_floats(D * GH, R, false) + plane_floats(I, R, false) + (size_t)D * plane_floats(H, R, false) + pad64(slab)) *
+         sizeof(float);
+}
+int lr_xproj_dw_both(const float* dG, int ldg, int dstride, const float* x, const float* y, int ldy, int R, int T, int I,
+                     int H, int GH, int D, float* const* dw_ih, float* const* dw_hh, float beta, void* workspace,
+                     size_t workspace_bytes, hipStream_t stream) {
+  const int M = D * GH, ldp = ldp_of(R);
+  if (D > 2 || 2 * D + 1 > XPACK_MAX) return LR_ERR_UNSUPPORTED;
+  const size_t fa = plane_floats(M, R, false), fx = plane_floats(I, R, false), fy = plane_floats(H, R, false);
+  const size_t avail = workspace_bytes / sizeof(float);
+  if (avail < fa + fx + D * fy) return LR_ERR_WORKSPACE;
+  float* ws = (float*)workspace;
+  bf16_t* Ah = (bf16_t*)ws;
+  bf16_t* Al = Ah + (size_t)M * ldp;
+  bf16_t* Xh = (bf16_t*)(ws + fa);
+  bf16_t* Xl = Xh + (size_t)I * ldp;
+  bf16_t* Y0 = (bf16_t*)(ws + fa + fx);
+  float* slabs = ws + fa + fx + D * fy;
+  const size_t slab_floats = avail - fa - fx - D * fy;
+  PackList pk;
+  for (int d = 0; d < D; ++d) {
+    pk.add(dG + (size_t)d * dstride, ldg, R, GH, 1, Ah + (size_t)d * GH * ldp, Al + (size_t)d * GH * ldp, ldp, ldp);
+    bf16_t* Yh = Y0 + (size_t)d * fy * 2;
+    pk.add(y + (size_t)d * H, ldy, R, H, 1, Yh, Yh + (size_t)H * ldp, ldp, ldp, d == 0 ? -1 : 1, T);
+  }
+  pk.add(x, I, R, I, 1, Xh, Xl, ldp, ldp);
+  int st = pk.launch(stream);
+  if (st != LR_OK) return st;
+  st = contract(Ah, Al, Xh, Xl, M, I, R, 1.f, beta, dw_ih[0], D > 1 ? dw_ih[1] : nullptr, GH, I, nullptr, slabs, slab_floats,
+                stream);
+  if (st != LR_OK) return st;
+  return contract(Ah, Al, Y0, Y0 + (size_t)H * ldp, GH, H, R, 1.f, beta, dw_hh[0], nullptr, GH, H, nullptr, slabs, slab_floats,
+                  stream, D, (int64_t)GH * ldp, (int64_t)fy * 2, D > 1 ? dw_hh[1] : nullptr);
+}
+
 extern "C" int lr_xgemm(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                         const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
                         int a_exact, int b_exact, void* workspace, size_t workspace_bytes, lr_stream_t stream) {
