@@ -40,6 +40,21 @@ def _upper_struct(upper, drop_mask):
   return st, nl
 
 
+_STEP_LENS = {}
+
+
+def _step_lens(B, L, dev):
+  """The (B,) int32 vector of L the C ABI takes as `step_lens`: constant per (B, L, device), so it is built once (a
+  fill launch per step otherwise).  Never written by a kernel."""
+  key = (B, L, dev.type, dev.index)
+  t = _STEP_LENS.get(key)
+  if t is None:
+    if len(_STEP_LENS) > 64:
+      _STEP_LENS.clear()
+    t = _STEP_LENS[key] = torch.full((B,), L, dtype=torch.int32, device=dev)
+  return t
+
+
 class _AttnDecoderFunction(torch.autograd.Function):
   """All L decoder steps: (tokens, teacher-forcing pattern, encoder states, initial state, params)
   -> (log_probs (B,L,V), sampled (B,L), h_n, c_n).  `params` = the 13 tensors of lr_decoder_params
@@ -63,7 +78,7 @@ class _AttnDecoderFunction(torch.autograd.Function):
     sampled = torch.empty((B, L), dtype=torch.int32, device=dev)
     h_n = torch.empty((NL, B, Hd), dtype=torch.float32, device=dev)
     c_n = torch.empty((NL, B, Hd), dtype=torch.float32, device=dev) if mode == 1 else None
-    step_lens = torch.full((B,), L, dtype=torch.int32, device=dev)
+    step_lens = _step_lens(B, L, dev)
     rbytes = L_.lr_decoder_reserve_bytes(mode, attn_type, NL, B, L, T, Hd, Cd, V, A)
     reserve = torch.empty(rbytes, dtype=torch.uint8, device=dev)
     tf = (ctypes.c_uint8 * L)(*[1 if f else 0 for f in teacher_forced])
