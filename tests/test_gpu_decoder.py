@@ -335,9 +335,10 @@ def test_fused_decoder_nll_equals_the_reference_formula(dev):
   np.testing.assert_allclose(x.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-6, atol=0)
 
 
-@pytest.mark.parametrize("rnn_type,Hd,layers,attn", [("GRU", 512, 1, "1_layer_nn"), ("LSTM", 512, 2, "general"),
-                                                     ("GRU", 256, 2, "none"), ("LSTM", 704, 1, "dot")])
-def test_decoder_loop_on_the_cluster_recurrence_equals_the_step_kernels(dev, rnn_type, Hd, layers, attn):
+@pytest.mark.parametrize("rnn_type,Hd,layers,attn,B,L", [("GRU", 512, 1, "1_layer_nn", 32, 31), ("LSTM", 512, 2, "general", 32, 31),
+                                                         ("GRU", 256, 2, "none", 32, 31), ("LSTM", 704, 1, "dot", 32, 31),
+                                                         ("LSTM", 256, 1, "concat", 5, 3), ("GRU", 500, 1, "dot", 13, 1)])
+def test_decoder_loop_on_the_cluster_recurrence_equals_the_step_kernels(dev, rnn_type, Hd, layers, attn, B, L):
   """With every step teacher forced (the shipped configs and eval) the decoder's RNN — unidirectional, started from
   the encoder's final state (better_model.py:134-148,181) — runs each layer's L steps as ONE launch of the cluster
   recurrence (lr_rnn_cluster.hip), and its backward returns the gradient into that initial state from the same
@@ -352,11 +353,12 @@ def test_decoder_loop_on_the_cluster_recurrence_equals_the_step_kernels(dev, rnn
     hidden_size, bidirectional, num_layers = Hd // 2, True, layers
   Enc.rnn_type = rnn_type
   torch.manual_seed(21)
-  dec = CharDecodingStep(Enc(), 300, 64, default_char2idx(), attention_type=attn).to(dev)
+  dec = CharDecodingStep(Enc(), 300, 64, default_char2idx(), attention_type=attn,
+                         attn_hidden_size=(64 if attn == "concat" else -1)).to(dev)
   g = torch.Generator().manual_seed(22)
-  B, T, L = 32, 75, 31
+  T = 75 if B == 32 else 9     # (ragged sample groups, a single step: B % 8 != 0, L = 1)
   enc = (torch.randn(B, T, Hd, generator=g) * 0.5).to(dev)
-  lens = torch.sort(torch.randint(40, T + 1, (B,), generator=g))[0]
+  lens = torch.sort(torch.randint(max(1, T // 2), T + 1, (B,), generator=g))[0]
   h0 = (torch.randn(layers, B, Hd, generator=g) * 0.5).to(dev)
   c0 = (torch.randn(layers, B, Hd, generator=g) * 0.5).to(dev)
   chars = torch.randint(4, 64, (B, L), generator=g).to(dev)
@@ -381,7 +383,8 @@ def test_decoder_loop_on_the_cluster_recurrence_equals_the_step_kernels(dev, rnn
   finally:
     L_.lr_rnn_debug_disable_cluster(0)
   assert L_.lr_rnn_pair_errors() == 0
-  assert float((out["cluster"][0] - out["steps"][0]).abs().max()) > 0     # the other path really ran
+  if L > 1:
+    assert float((out["cluster"][0] - out["steps"][0]).abs().max()) > 0     # the other path really ran
   worst = 0.0
   for i, (a, b) in enumerate(zip(out["steps"], out["cluster"])):
     # (floor: the score bias of '1_layer_nn' has a mathematically zero gradient — rounding noise on both sides)
