@@ -301,8 +301,12 @@ def run(**flags):
     print(f'\tTrain CER: {train_cer}')
     print(f'\tVal CER: {val_cer}')
     print(f'\tTest CER: {test_cer}')
+    stats = T.last_epoch_stats or {}
     history.append(dict(epoch=epochs, decoder_loss=dec_loss, ctc_loss=ctc_loss, train_cer=train_cer,
-                        val_cer=val_cer, test_cer=test_cer, lr=lr, tfr=tfr))
+                        val_cer=val_cer, test_cer=test_cer, lr=lr, tfr=tfr,
+                        # batches that updated nothing (the reference's `continue`, train_better_model.py:49-50) and how
+                        # many of them because a one-launch recurrence timed out
+                        skipped_batches=stats.get("skipped", 0), recurrence_faults=stats.get("recurrence_faults", 0)))
     if val_cer < best_val_cer:   # :339-341
       best_val_cer, best_idx = val_cer, epochs
     epochs += 1
