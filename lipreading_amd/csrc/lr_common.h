@@ -98,6 +98,12 @@ bool lr_prof_next(int slot, hipEvent_t* start, hipEvent_t* stop);
       hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)(stream), __VA_ARGS__);                   \
   } while (0)
 
+// ---- conv frontend, weight gradient of the stride-1 layers, second form (lr_conv_wgrad.hip) ----------
+constexpr int LR_CONV_TR2_SLOTS = 85;   // slots per temporal tap: 3 x 85 = 255 workgroups, one slab each
+int lr_conv_wgrad_tr2_supported(int layer, int F, int H);   // 160 KB of LDS hold the two tile buffers + the tile table
+int lr_conv_wgrad_tr2(int layer, const void* X, const void* dZ, float* slabs, int F, int T, int H,
+                      bool sample, hipEvent_t e0, hipEvent_t e1, hipStream_t stream);
+
 // ---- device-side fault words {pending, total} of the one-launch recurrences (lr_misc.hip; see
 // include/lipreading_hip.h lr_fault_words_ptr).  NULL only when the allocation failed.
 int32_t* lr_fault_words();

@@ -21,6 +21,7 @@
 #include "lr_common.h"
 #include <hip/hip_ext.h>
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -2012,7 +2013,7 @@ static int wgrad_splits(int Cout, int Ktot) {
   return s;
 }
 constexpr int kColsumSplits = 256;
-constexpr int kTsWgsPerKt = 85;   // 3 temporal offsets x 85 = 255 resident workgroups
+constexpr int kTsWgsPerKt = LR_CONV_TR2_SLOTS;   // 3 temporal offsets x 85 = 255 resident workgroups
 
 }  // namespace
 
@@ -2349,7 +2350,14 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
       const bf16_t* dz = (const bf16_t*)dZ;
       float* slabs = (float*)workspace;
       const int F = B * T;
-      static bool attr_set[3] = {false, false, false};
+      static bool attr_set[9] = {false, false, false, false, false, false, false, false, false};
+      static int variant = -1;   // TEMPORARY A/B knob: 0 first form, else second form (lr_conv_wgrad.hip)
+      if (variant < 0) {
+        const char* e = getenv("LIPREADING_CONV_WGRAD_TR");
+        variant = e ? atoi(e) : 2;
+      }
+      const bool second = variant != 0 && lr_conv_wgrad_tr2_supported(l2 ? 2 : 3, F, Hin);
+      const int nslots = second ? LR_CONV_TR2_SLOTS : kTrSlots;
       lr_clear_error();
 #define LR_WGTR(IDX, LDSB, ...)                                                                              \
   do {                                                                                                      \
@@ -2366,7 +2374,10 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
   } while (0)
       // 6-row tiles where the height allows (18 k16 steps per tile instead of 12 amortise the per-tile
       // load / deposit / barrier better; 142 KB of the 160 KB of LDS for the two buffers)
-      if (l2 && Hin % 6 == 0) LR_WGTR(2, 2 * (2 * 10 * 28 * 64 + 2 * 2 * 6 * 24 * 64), 32, 2, 5, 5, 24, 2, 6);
+      if (second) {
+        const int st2 = lr_conv_wgrad_tr2(l2 ? 2 : 3, x, dz, slabs, F, T, Hin, sample, e0, e1, (hipStream_t)stream);
+        if (st2 != LR_OK) return st2;
+      } else if (l2 && Hin % 6 == 0) LR_WGTR(2, 2 * (2 * 10 * 28 * 64 + 2 * 2 * 6 * 24 * 64), 32, 2, 5, 5, 24, 2, 6);
       else if (l2) LR_WGTR(0, 2 * (2 * 8 * 28 * 64 + 2 * 2 * 4 * 24 * 64), 32, 2, 5, 5, 24, 2, 4);
       else LR_WGTR(1, 2 * (2 * 2 * 8 * 14 * 64 + 3 * 2 * 6 * 12 * 64), 64, 3, 3, 3, 12, 2, 6);
 #undef LR_WGTR
@@ -2375,12 +2386,12 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
       {
         const int64_t se = (int64_t)Cout * Cin_pad * KT * KH * KW;
         LR_LAUNCH(conv_wgrad_slab_reduce_kernel, dim3((unsigned)((se + 63) / 64)), dim3(64, 4), 0, stream,
-                  (const float*)slabs, kTrSlots, se, dW, 1, Cout, Cin_pad, Cin_pad, KT * KH * KW, KH * KW, 0,
+                  (const float*)slabs, nslots, se, dW, 1, Cout, Cin_pad, Cin_pad, KT * KH * KW, KH * KW, 0,
                   accumulate);
       }
       st = lr_launch_status();
       if (st != LR_OK || !dbias) return st;
-      float* cpart2 = slabs + (size_t)3 * kTrSlots * KH * KW * Cout * Cin_pad;
+      float* cpart2 = slabs + (size_t)3 * kTsWgsPerKt * KH * KW * Cout * Cin_pad;
       LR_LAUNCH(colsum_bf16_partial_kernel, dim3(kColsumSplits), dim3(256), 0, stream, dz, g.M, Cout, cpart2,
                 kColsumSplits);
       LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(1024), 0, stream, (const float*)cpart2, kColsumSplits, dbias,
