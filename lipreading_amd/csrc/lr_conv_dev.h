@@ -1,0 +1,46 @@
+// Device-side helpers shared by the conv frontend's translation units (lr_conv.hip, lr_conv_patch.hip).
+// Build-defined subsystem: the reference has no conv frontend (regime X).
+#pragma once
+#include "lr_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;  // storage type
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 h = (__bf16)f;  // round to nearest even (v_cvt_pk_bf16_f32 on gfx950)
+  return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ float bf2f(bf16_t v) {
+  return __builtin_bit_cast(float, (unsigned)v << 16);
+}
+
+// ReLU -> 2x2 max-pool of one window in the forward epilogues: the bf16 value that is stored and the position
+// (row-major scan) of its FIRST maximum, torch's rule, decided on the values that would have been stored.  The
+// epilogues are VALU-bound (the layer-2 forward spends 6.6 k cycles of a tile's 81 k here, 48 windows per lane:
+// s_memtime, round 3), so this is written to be few instructions: the four a + bias are converted two per
+// instruction; ReLU is a packed signed-integer max with 0 on the bf16 BIT PATTERNS (a negative float — and -0 — is a
+// negative int16; the non-negative ones order as integers the way they order as numbers); the window's maximum and
+// its first position come out of ONE unsigned maximum over the keys (pattern << 16 | 3 - position): equal patterns
+// leave the decision to the low bits, the smaller position wins.  17 VALU instead of 30 (round 2: float ReLU,
+// sign-bit masks, a compare-and-select chain); results identical bit for bit.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void relu_pool4(float a0, float a1, float a2, float a3, float bias, bf16_t& best, int& arg) {
+  const f32x2_t lo = {a0 + bias, a1 + bias}, hi = {a2 + bias, a3 + bias};
+  const s16x2_t zero = {0, 0};
+  const s16x2_t q01 = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, __builtin_convertvector(lo, bf16x2_t)), zero);
+  const s16x2_t q23 = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, __builtin_convertvector(hi, bf16x2_t)), zero);
+  const unsigned p01 = __builtin_bit_cast(unsigned, q01), p23 = __builtin_bit_cast(unsigned, q23);
+  const unsigned k0 = (p01 << 16) | 3u, k1 = (p01 & 0xffff0000u) | 2u, k2 = (p23 << 16) | 1u, k3 = p23 & 0xffff0000u;
+  const unsigned k01 = k0 > k1 ? k0 : k1, k23 = k2 > k3 ? k2 : k3;
+  const unsigned k = k01 > k23 ? k01 : k23;
+  best = (bf16_t)(k >> 16);
+  arg = (int)(~k & 3u);
+}
+
+}  // namespace

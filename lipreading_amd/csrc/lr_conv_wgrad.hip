@@ -43,12 +43,6 @@ __device__ __forceinline__ bf16x8 lds_tr_pair(const unsigned char* lds, int a0, 
 //     behind the MFMA loop; the tile loop is ONE basic block (the round after a workgroup's last tile moves zeros),
 //     and a tile's scalars (frame, row band, time in the clip) advance by constants instead of being divided out.
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-#ifdef LR_TR2_STAMPS
-__device__ unsigned long long g_tr2_stamps[16];
-#define TR2_STAMP(k) do { if (it == 3) stamps[k] = __builtin_readcyclecounter(); } while (0)
-#else
-#define TR2_STAMP(k) do { } while (0)
-#endif
 constexpr int kTr2Slots = LR_CONV_TR2_SLOTS;
 
 // LDS image of one tile: the X patch planes, then the dZ planes, each rounded up to whole rounds of 256 sixteen-byte
@@ -244,12 +238,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr2_kernel(const bf16_t* __
 #pragma unroll
   for (int i = 0; i < UPT; ++i) *reinterpret_cast<u32x4_t*>(lds + tid * 16 + i * 4096) = pre[i];
   __syncthreads();
-#ifdef LR_TR2_STAMPS
-  unsigned long long stamps[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
   for (int it = 0; it < mine; ++it) {
     const int cur = it & 1;
-    TR2_STAMP(0);
     unsigned char* dep = lds + (cur ^ 1) * BUF + tid * 16;   // where this thread's units of the next tile go
     int xb[UPW], zb[MT];
 #pragma unroll
@@ -263,7 +253,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr2_kernel(const bf16_t* __
     // LSTR-th MFMA of the first half of the tile and its LDS stores behind every SSTR-th of the second half.  SPREAD
     // OUT: the four waves run in step, so a load in one gap is 4 KB through the CU's 64 B/clk vector memory path — 64
     // cycles, two MFMAs' worth — and with one load (one store) behind EVERY MFMA of two steps those steps ran at 64-82
-    // (56) cycles per MFMA instead of 34 (s_memtime stamps, round 3).  (sched_group_barrier
+    // (56) cycles per MFMA instead of 34 (s_memtime stamps, round 3: a layer-2 tile = 390 cycles from the barrier
+    // to the first MFMA's group + 234 MFMAs at 34.5-36 + the barrier, 9.0 k cycles; the first form 12.2 k).
+    // Measured and dropped: reading step 0 of the NEXT tile behind the MFMAs of the last step (barrier moved in
+    // front of that step, with a counted lgkmcnt so that it waits for the stores only) hides those 390 cycles and
+    // changed nothing (layer 2 340.6 vs 339.9 us, layer 3 105.6 vs 105.6 on one box, tools/bench_conv_wgrad.py): at
+    // 1.24 PFLOP/s on random operands the kernel runs against the chip's power budget, where a saved cycle comes back
+    // as clock (MI355X_MICROARCH.md, DVFS give-back; the guide's best 8192^3 bf16 GEMMs reach 1.16-1.22 PFLOP/s).  (sched_group_barrier
     // pins, which the first form uses, lost the MFMAs of the store steps to the end of the tile; and the stores have
     // to be WRITTEN among the reads in any case: the compiler cannot know that the two LDS buffers do not alias and
     // keeps every read that precedes a store in the source in front of it.)
@@ -304,24 +300,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr2_kernel(const bf16_t* __
         if (st == SETUP && m == 5) entry_bases();
         if (st == SETUP && m >= 6 && m < 13) entry_bad(m - 6);
         __builtin_amdgcn_sched_barrier(0);   // nothing moves across: the line runs as written
-#ifdef LR_TR2_STAMPS
-        if (st == 0 && m == 0) TR2_STAMP(1);
-        if (st == 1 && m == NM - 1) TR2_STAMP(2);
-        if (gap == LG0 + LSTR * UPT) TR2_STAMP(3);
-        if (gap == MID - 1) TR2_STAMP(4);
-        if (st == STEPS - 2 && m == NM - 1) TR2_STAMP(5);
-        if (st == STEPS - 1 && m == NM - 1) TR2_STAMP(6);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
       }
     }
     __syncthreads();   // buffer `cur` is free again; the next tile is in place
-    TR2_STAMP(7);
   }
-#ifdef LR_TR2_STAMPS
-  if (blockIdx.x == 8 && tid == 0 && CIN == 32)
-    for (int k = 0; k < 8; ++k) g_tr2_stamps[k] = stamps[k];
-#endif
   // partial result of this workgroup: slabs[slot*3 + kt][tap][n][c]
   const int lr = lane & 31, lk = lane >> 5;
   float* out = slabs + (int64_t)(slot * 3 + kt) * (KH * KW) * COUT * CIN;
@@ -390,8 +372,3 @@ int lr_conv_wgrad_tr2(int layer, const void* X, const void* dZ, float* slabs, in
   return lr_launch_status();
 }
 
-#ifdef LR_TR2_STAMPS
-extern "C" int lr_debug_tr2_stamps(unsigned long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tr2_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
-}
-#endif
