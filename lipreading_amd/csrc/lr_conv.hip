@@ -347,477 +347,6 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(ConvGeom g, const bf1
 }
 
 // ---------------------------------------------------------------------------------------------
-// first layer (4-channel padded RGB input, spatial stride 2): patch-resident kernels
-// ---------------------------------------------------------------------------------------------
-// With Cin = 4 an im2col row is 75 separate 8-byte gathers and neighbouring rows overlap almost
-// completely, so the generic implicit GEMM is gather-bound (82 TF/s forward, 36 TF/s weight
-// gradient).  Here a workgroup owns a 16x16 tile of output pixels of one frame and loads the
-// input patch it needs ONCE into LDS: 3 frames x 35 x 35 pixels x 4 channels (29 kB).  Every
-// operand of the forward product and of the weight gradient is then an LDS read at
-// (pixel offset + tap offset): no im2col staging, no barrier inside the K loop.
-// Two ds_read_b64_tr_b16 (gfx950 LDS transpose read) -> one MFMA operand.  16 lanes read a
-// [4 k][16 columns] block, 8 bytes each (lane s: row s>>2, columns 4(s&3)..4(s&3)+3), and lane L gets
-// column L of the 4 rows; a0 / a1 address the lane's 8 bytes of k 0..3 / 4..7.
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 lds_tr_pair(const unsigned char* lds, int a0, int a1) {
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a0));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a1));
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);
-}
-
-constexpr int C1_T = 16;                       // output tile edge
-constexpr int C1_P = 2 * C1_T + 3;             // patch edge (stride 2, 5x5 taps): 35
-constexpr int C1_PIX = C1_T * C1_T;            // 256 output pixels = 8 MFMA row tiles
-constexpr int C1_K = 304;                      // 75 taps x 4 channels = 300, padded to 19 k steps of 16
-constexpr int C1_WLD = C1_K + 8;               // weight row in LDS (624 B: conflict-free b128 reads)
-constexpr int C1_PATCH = 3 * C1_P * C1_P * 4;  // bf16 elements of the patch
-
-constexpr int C1_FPIX = C1_P * C1_P;          // pixels of one patch frame (1225)
-constexpr int kC1WgradWgs = 512;              // persistent workgroups of the first layer's weight gradient
-
-// The patch is a RING of three frames: a workgroup walks the tiles (t = 0, 1, 2, ...) of one spatial
-// window of one clip in order, so tile t only has to bring frame t+1 — frames t-1 and t are already
-// in LDS (FETCH_SIZE with a fresh 3-frame patch per tile: 3.4x the input; with the ring ~1.25x).
-// Frame ti of the clip lives in slot (ti + 1) % 3, i.e. temporal tap kt of tile t in slot (t + kt) % 3.
-// tap = (kt*5 + kh)*5 + kw  ->  element offset inside the patch [3 slots][35][35][4]
-__device__ __forceinline__ int c1_tap_off(int tap, int t) {
-  if (tap >= 75) return -1;
-  const int kw = tap % 5, kh = (tap / 5) % 5, kt = tap / 25;
-  return ((((t + kt) % 3) * C1_P + kh) * C1_P + kw) * 4;
-}
-
-// Frame kt (0..2) of tile (f = b*T + t, rows 2*y0-2.., cols 2*x0-2..): 1225 8-byte pixels, 5 per
-// thread.  Split into "issue every global load" and "write to LDS" so that the NEXT tile's new frame
-// (kt = 2) flies while the current tile's MFMAs run; only 5 staging registers stay live across the
-// MFMA loop (15 for a whole patch cost a wave of occupancy).
-constexpr int C1_NPU = (C1_FPIX + 255) / 256;   // 5
-// U8: X is the raw clip, uint8 planar [frame][3][Hin][Win] — the three bytes of a pixel are loaded as
-// they are (rp.x, rp.y, rb) and turned into the bf16 pixel (value / 255, 4th channel 0) when they are
-// written to LDS, exactly as lr_clip_to_ndhwc_bf16 would have: no bf16 copy of the clip exists.
-// Branch-free: every pixel is loaded — from the nearest pixel inside the frame (of frame f itself when the
-// temporal tap leaves the clip) where the patch hangs over the edge — and bit 31 of rb[i] says whether it is real;
-// c1_frame_store writes zeros for the others.  (`if (inside) load` made hipcc branch around each of the 15 byte
-// loads of a tile: ~40 exec-mask branches per tile in kernels that are bound by their scalar / vector issue.)
-// (BRANCHFREE false: the predicated loads, zeros for the rest — the weight-gradient kernel, whose loads sit in
-// front of a long MFMA phase, measured 4 % slower with the branch-free form, the forward 6 % faster.)
-template <bool U8, bool BRANCHFREE = true>
-__device__ __forceinline__ void c1_frame_issue(const bf16_t* __restrict__ X, uint2 (&rp)[C1_NPU],
-                                               unsigned (&rb)[C1_NPU], int f, int T, int Hin, int Win, int y0,
-                                               int x0, int tid, int kt) {
-  const int ti = f % T + kt - 1;
-  const bool frame_ok = ti >= 0 && ti < T;
-  if (!BRANCHFREE) {
-#pragma unroll
-    for (int i = 0; i < C1_NPU; ++i) {
-      const int e = tid + i * 256;
-      const int px = e % C1_P, py = e / C1_P;
-      const int yi = 2 * y0 - 2 + py, xi = 2 * x0 - 2 + px;
-      rp[i] = make_uint2(0u, 0u);
-      rb[i] = 0x80000000u;
-      if (frame_ok && e < C1_FPIX && yi >= 0 && yi < Hin && xi >= 0 && xi < Win) {
-        if (U8) {
-          const int64_t plane = (int64_t)Hin * Win;
-          const unsigned char* src = reinterpret_cast<const unsigned char*>(X) + (int64_t)(f + kt - 1) * 3 * plane +
-                                     (int64_t)yi * Win + xi;
-          rp[i].x = src[0];
-          rp[i].y = src[plane];
-          rb[i] = 0x80000000u | src[2 * plane];
-        } else {
-          rp[i] = *reinterpret_cast<const uint2*>(X + ((((int64_t)(f + kt - 1)) * Hin + yi) * Win + xi) * 4);
-        }
-      }
-    }
-    return;
-  }
-  const int64_t fr = frame_ok ? f + kt - 1 : f;
-#pragma unroll
-  for (int i = 0; i < C1_NPU; ++i) {
-    const int e = tid + i * 256;
-    const int ee = e < C1_FPIX ? e : 0;
-    const int px = ee % C1_P, py = ee / C1_P;
-    const int yi = 2 * y0 - 2 + py, xi = 2 * x0 - 2 + px;
-    const bool ok = frame_ok && e < C1_FPIX && yi >= 0 && yi < Hin && xi >= 0 && xi < Win;
-    const int yc = min(max(yi, 0), Hin - 1), xc = min(max(xi, 0), Win - 1);
-    if (U8) {
-      const int64_t plane = (int64_t)Hin * Win;
-      const unsigned char* src = reinterpret_cast<const unsigned char*>(X) + fr * 3 * plane + (int64_t)yc * Win + xc;
-      rp[i].x = src[0];
-      rp[i].y = src[plane];
-      rb[i] = (unsigned)src[2 * plane] | (ok ? 0x80000000u : 0u);
-    } else {
-      rp[i] = *reinterpret_cast<const uint2*>(X + ((fr * Hin + yc) * Win + xc) * 4);
-      rb[i] = ok ? 0x80000000u : 0u;
-    }
-  }
-}
-template <bool U8>
-__device__ __forceinline__ void c1_frame_store(bf16_t* Ps, const uint2 (&rp)[C1_NPU], const unsigned (&rb)[C1_NPU],
-                                               int tid, int t, int kt) {
-  bf16_t* slot = Ps + ((t + kt) % 3) * C1_FPIX * 4;
-#pragma unroll
-  for (int i = 0; i < C1_NPU; ++i) {
-    const int e = tid + i * 256;
-    if (e >= C1_FPIX) continue;
-    const bool ok = (rb[i] >> 31) != 0;
-    uint2 v = rp[i];
-    if (U8) {
-      v.x = (unsigned)f2bf((float)rp[i].x * (1.f / 255.f)) | ((unsigned)f2bf((float)rp[i].y * (1.f / 255.f)) << 16);
-      v.y = (unsigned)f2bf((float)(rb[i] & 0xffu) * (1.f / 255.f));
-    }
-    v.x = ok ? v.x : 0u;
-    v.y = ok ? v.y : 0u;
-    *reinterpret_cast<uint2*>(&slot[e * 4]) = v;
-  }
-}
-// first tile of a walk: frames t-1 and t are fetched synchronously (once per ~28 tiles)
-template <bool U8>
-__device__ __forceinline__ void c1_walk_start(const bf16_t* __restrict__ X, bf16_t* Ps, int f, int T, int Hin,
-                                              int Win, int y0, int x0, int tid) {
-#pragma unroll 1
-  for (int kt = 0; kt < 2; ++kt) {
-    uint2 r[C1_NPU];
-    unsigned r3[C1_NPU];
-    c1_frame_issue<U8>(X, r, r3, f, T, Hin, Win, y0, x0, tid, kt);
-    c1_frame_store<U8>(Ps, r, r3, tid, f % T, kt);
-  }
-}
-
-// Walk order of the persistent first-layer kernels: tile q = seq*T + t with seq = (clip, ty, tx);
-// workgroup w owns the contiguous range [w*N/G, (w+1)*N/G).
-struct C1Tile { int f, t, y0, x0; };
-__device__ __forceinline__ C1Tile c1_tile(int64_t q64, int T, int tiles_x, int tiles_y) {
-  C1Tile r;
-  const unsigned q = (unsigned)q64;   // tile counts stay far below 2^31: 32-bit divisions
-  const unsigned seq = q / (unsigned)T;
-  r.t = (int)(q - seq * (unsigned)T);
-  const int tx = (int)(seq % (unsigned)tiles_x), ty = (int)((seq / (unsigned)tiles_x) % (unsigned)tiles_y);
-  r.f = (int)(seq / (unsigned)(tiles_x * tiles_y)) * T + r.t;
-  r.y0 = ty * C1_T;
-  r.x0 = tx * C1_T;
-  return r;
-}
-
-// Persistent workgroups: the 32 x 300 weights are staged once, then tiles are streamed.
-// POOL: the epilogue applies ReLU -> MaxPool((1,2,2)) in registers (a lane holds all four pixels of
-// its windows) and writes the pooled activation + the 2-bit position of the window's first maximum
-// (row-major scan, torch's rule) instead of the full-resolution activation.
-template <bool POOL, bool U8>
-__global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __restrict__ X,
-                                                              const bf16_t* __restrict__ Wp,  // [32][300]
-                                                              const float* __restrict__ bias,
-                                                              bf16_t* __restrict__ Y, unsigned char* __restrict__ code,
-                                                              int frames, int T,
-                                                              int Hin, int Win, int Ho, int Wo, int relu) {
-  __shared__ __attribute__((aligned(16))) bf16_t Ps[C1_PATCH + 8];
-  __shared__ __attribute__((aligned(16))) bf16_t Ws[32 * C1_WLD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lr = lane & 31, lk = lane >> 5;
-  const int tiles_x = (Wo + C1_T - 1) / C1_T, tiles_y = (Ho + C1_T - 1) / C1_T;
-  const int64_t ntiles = (int64_t)frames * tiles_x * tiles_y;
-  // weights: row n = 300 bf16 = 75 x 8 bytes; pad columns 300..311 with zeros
-  for (int e = tid; e < 32 * (C1_WLD / 4); e += 256) {
-    const int n = e / (C1_WLD / 4), u = e - n * (C1_WLD / 4);
-    uint2 v = make_uint2(0u, 0u);
-    if (u < 75) v = *reinterpret_cast<const uint2*>(Wp + n * 300 + u * 4);
-    *reinterpret_cast<uint2*>(&Ws[n * C1_WLD + u * 4]) = v;
-  }
-  if (tid < 8) Ps[C1_PATCH + tid] = 0;   // landing zone for the padded taps (k >= 300)
-
-  // wave w: row tiles 2w, 2w+1; row tile m covers pixels (y = 2m + (lr>>4), x = lr & 15)
-  int pixoff[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int yl = 2 * (2 * wave + i) + (lr >> 4), xl = lr & 15;
-    pixoff[i] = ((2 * yl) * C1_P + 2 * xl) * 4;
-  }
-  const float bv = bias ? bias[lr] : 0.f;
-  uint2 rp[C1_NPU];             // frame t+1 of the tile about to be computed
-  unsigned rb[C1_NPU];
-  const int64_t q_end = ntiles * (blockIdx.x + 1) / gridDim.x;
-  const int64_t q_begin = ntiles * blockIdx.x / gridDim.x;
-  int64_t q = q_begin;
-  if (q < q_end) {
-    const C1Tile c = c1_tile(q, T, tiles_x, tiles_y);
-    c1_frame_issue<U8>(X, rp, rb, c.f, T, Hin, Win, c.y0, c.x0, tid, 2);
-  }
-  for (; q < q_end; ++q) {
-    const C1Tile c = c1_tile(q, T, tiles_x, tiles_y);
-    const int f = c.f, y0 = c.y0, x0 = c.x0;
-    __syncthreads();            // previous tile's fragments are no longer being read
-    if (q == q_begin || c.t == 0) c1_walk_start<U8>(X, Ps, f, T, Hin, Win, y0, x0, tid);
-    c1_frame_store<U8>(Ps, rp, rb, tid, c.t, 2);
-    __syncthreads();
-    if (q + 1 < q_end) {        // next tile's new frame flies while this tile's MFMAs run
-      const C1Tile n = c1_tile(q + 1, T, tiles_x, tiles_y);
-      c1_frame_issue<U8>(X, rp, rb, n.f, T, Hin, Win, n.y0, n.x0, tid, 2);
-    }
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    // 19 k steps of 16 (4 taps x 4 channels), fully unrolled: a step's taps are compile-time for
-    // each half of the wave (lk), so a fragment address is one select + one add (no table lookup
-    // in front of every read), and the fragments of step ks+1 are read during the MFMAs of step ks.
-    const int so0 = ((c.t + 0) % 3) * C1_FPIX * 4, so1 = ((c.t + 1) % 3) * C1_FPIX * 4,
-              so2 = ((c.t + 2) % 3) * C1_FPIX * 4;   // ring slot of temporal tap kt (elements)
-    auto tap_elem = [&](int tap) {   // compile-time tap -> element offset in the patch (uniform)
-      const int kw = tap % 5, kh = (tap / 5) % 5, kt = tap / 25;
-      return (kt == 0 ? so0 : kt == 1 ? so1 : so2) + (kh * C1_P + kw) * 4;
-    };
-    uint2 alo[2][2], ahi[2][2];
-    bf16x8 bw[2];
-    auto load_k = [&](int ks, uint2 (&lo)[2], uint2 (&hi)[2], bf16x8& b) {
-      // lk = 0: taps 4ks, 4ks+1;  lk = 1: taps 4ks+2, 4ks+3 (tap 75 = zero padding)
-      const int e0 = lk ? tap_elem(4 * ks + 2) : tap_elem(4 * ks);
-      const bool pad1 = 4 * ks + 3 >= 75;
-      const int e1 = lk ? (pad1 ? 0 : tap_elem(pad1 ? 0 : 4 * ks + 3)) : tap_elem(4 * ks + 1);
-      b = *reinterpret_cast<const bf16x8*>(&Ws[lr * C1_WLD + ks * 16 + lk * 8]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        lo[i] = *reinterpret_cast<const uint2*>(&Ps[pixoff[i] + e0]);
-        hi[i] = *reinterpret_cast<const uint2*>(&Ps[(pad1 && lk) ? C1_PATCH : pixoff[i] + e1]);
-      }
-    };
-    constexpr int KS = C1_K / 16;
-    load_k(0, alo[0], ahi[0], bw[0]);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) load_k(ks + 1, alo[(ks + 1) & 1], ahi[(ks + 1) & 1], bw[(ks + 1) & 1]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const uint4 av = make_uint4(alo[ks & 1][i].x, alo[ks & 1][i].y, ahi[ks & 1][i].x, ahi[ks & 1][i].y);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bw[ks & 1], acc[i], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-#pragma unroll
-    for (int ks = 0; ks + 1 < KS; ++ks) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-    if (POOL) {
-      // row tile = 2 output rows x 16 columns: registers r and r + 8 are vertical neighbours,
-      // r and r + 1 (r even) horizontal ones
-      const int Hp = Ho >> 1, Wp2 = Wo >> 1;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int pp = 0; pp < 2; ++pp) {
-            const int r0 = 4 * a + 2 * pp;
-            const int yp = (y0 >> 1) + 2 * wave + i, xp = (x0 >> 1) + pp + 4 * a + 2 * lk;
-            if (yp >= Hp || xp >= Wp2) continue;
-            bf16_t best;
-            int arg;
-            relu_pool4(acc[i][r0], acc[i][r0 + 1], acc[i][r0 + 8], acc[i][r0 + 9], bv, best, arg);
-            const int64_t o = (((int64_t)f * Hp + yp) * Wp2 + xp) * 32 + lr;
-            Y[o] = best;
-            code[o] = (unsigned char)arg;
-          }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int prow = (r & 3) + 8 * (r >> 2) + 4 * lk;         // pixel index inside the row tile
-          const int y = y0 + 2 * (2 * wave + i) + (prow >> 4), x = x0 + (prow & 15);
-          if (y >= Ho || x >= Wo) continue;
-          float v = acc[i][r] + bv;
-          if (relu) v = fmaxf(v, 0.f);
-          Y[(((int64_t)f * Ho + y) * Wo + x) * 32 + lr] = f2bf(v);
-        }
-    }
-  }
-}
-
-// weight gradient of the first layer: slab[wg][n][k] = sum over the workgroup's tiles of
-// dZ[pix][n] * patch(pix, k).  Wave w owns column tiles w, w+4, w+8 of the 10 (320 columns).
-// POOLED: the layer's forward fused ReLU + MaxPool (lr_conv3d_forward_pooled), and instead of a
-// materialised dZ the kernel takes the pooled gradient dP, the pooled activation and the window
-// codes and rebuilds its dZ tile on the way into LDS (a window's gradient goes to position `code` if
-// the pooled activation is > 0) — the 354 MB dZ of this layer is never written or read.  The bias
-// gradient (column sums of dZ) falls out of the same pass: bias_part[wg][32].
-template <bool POOLED, bool U8>
-__global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __restrict__ X,
-                                                                const bf16_t* __restrict__ dZ,
-                                                                const bf16_t* __restrict__ pooled,
-                                                                const unsigned char* __restrict__ code,
-                                                                float* __restrict__ slabs,
-                                                                float* __restrict__ bias_part, int frames,
-                                                                int T, int Hin, int Win, int Ho, int Wo) {
-  // Both operands are read with LDS transpose reads: the contraction runs over PIXELS, the slow axis
-  // of the channels-last dZ tile and of the patch.  dZ tile: [pixel][32 channels], 64 B per pixel (4
-  // pixels = 256 contiguous bytes per read).  im2col column (tap, c): a lane's 8 bytes are the 4
-  // channels of one tap at one pixel, so the 16 source lanes of a read cover 4 pixels x 4 taps.
-  constexpr int ZLD = 32;
-  __shared__ __attribute__((aligned(16))) bf16_t Ps[C1_PATCH + 8];
-  __shared__ __attribute__((aligned(16))) bf16_t Zs[C1_PIX * ZLD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lr = lane & 31, lk = lane >> 5;
-  const int sl = lane & 15, colhalf = (lane >> 4) & 1;
-  const int tiles_x = (Wo + C1_T - 1) / C1_T, tiles_y = (Ho + C1_T - 1) / C1_T;
-  const int64_t ntiles = (int64_t)frames * tiles_x * tiles_y;
-  // column tile jt = wave + 4j covers taps 8jt..8jt+7; this lane sources tap 8jt + 4 colhalf + (sl & 3)
-  f32x16 acc[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  if (tid < 8) Ps[C1_PATCH + tid] = 0;
-
-  uint2 rp[C1_NPU];
-  unsigned rb[C1_NPU];
-  uint4 rz[POOLED ? 2 : 4];   // POOLED: pooled gradient and activation of this thread's window
-  uint2 rc = make_uint2(0u, 0u);
-  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int wpy = tid >> 5, wpx = (tid >> 2) & 7, wcg = tid & 3;   // POOLED: window (py, px) of the 8 x 8, 8 channels
-  auto issue = [&](const C1Tile& c) {
-    const int f = c.f, y0 = c.y0, x0 = c.x0;
-    c1_frame_issue<U8, false>(X, rp, rb, f, T, Hin, Win, y0, x0, tid, 2);
-    if (POOLED) {
-      const int Hp = Ho >> 1, Wp = Wo >> 1;
-      const int yp = (y0 >> 1) + wpy, xp = (x0 >> 1) + wpx;
-      rz[0] = rz[1] = make_uint4(0u, 0u, 0u, 0u);
-      rc = make_uint2(0u, 0u);
-      if (yp < Hp && xp < Wp) {
-        const int64_t pi = (((int64_t)f * Hp + yp) * Wp + xp) * 32 + wcg * 8;
-        rz[0] = *reinterpret_cast<const uint4*>(dZ + pi);       // dP
-        rz[1] = *reinterpret_cast<const uint4*>(pooled + pi);
-        rc = *reinterpret_cast<const uint2*>(code + pi);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {   // dZ tile: 256 pixels x 32 channels in 16-byte units
-        const int e = tid + i * 256;
-        const int pix = e >> 2, u = e & 3;
-        const int y = y0 + (pix >> 4), x = x0 + (pix & 15);
-        rz[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (y < Ho && x < Wo) rz[i] = *reinterpret_cast<const uint4*>(dZ + (((int64_t)f * Ho + y) * Wo + x) * 32 + u * 8);
-      }
-    }
-  };
-  const unsigned char* PsB = reinterpret_cast<const unsigned char*>(Ps);
-  const unsigned char* ZsB = reinterpret_cast<const unsigned char*>(Zs);
-  const int64_t q_end = ntiles * (blockIdx.x + 1) / gridDim.x;
-  const int64_t q_begin = ntiles * blockIdx.x / gridDim.x;
-  int64_t q = q_begin;
-  if (q < q_end) issue(c1_tile(q, T, tiles_x, tiles_y));
-  for (; q < q_end; ++q) {
-    const C1Tile c = c1_tile(q, T, tiles_x, tiles_y);
-    __syncthreads();
-    if (q == q_begin || c.t == 0) c1_walk_start<U8>(X, Ps, c.f, T, Hin, Win, c.y0, c.x0, tid);
-    c1_frame_store<U8>(Ps, rp, rb, tid, c.t, 2);
-    if (POOLED) {
-      // rebuild the window's four dZ units (8 channels each): gradient at position `code`, if the
-      // pooled activation is positive
-      const unsigned gw[4] = {rz[0].x, rz[0].y, rz[0].z, rz[0].w}, pw_[4] = {rz[1].x, rz[1].y, rz[1].z, rz[1].w};
-      unsigned o[4][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int wd = e >> 1, sh = (e & 1) * 16;
-        const float act = bf2f((bf16_t)((pw_[wd] >> sh) & 0xffffu));
-        const int arg = (int)(((e < 4 ? rc.x : rc.y) >> (8 * (e & 3))) & 3u);
-        const unsigned g = act > 0.f ? ((gw[wd] >> sh) & 0xffffu) : 0u;
-        bsum[e] += bf2f((bf16_t)g);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j == arg) o[j][wd] |= g << sh;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int pix = (2 * wpy + (j >> 1)) * 16 + 2 * wpx + (j & 1);
-        *reinterpret_cast<uint4*>(&Zs[pix * ZLD + wcg * 8]) = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int e = tid + i * 256;
-        *reinterpret_cast<uint4*>(&Zs[(e >> 2) * ZLD + (e & 3) * 8]) = rz[i];
-      }
-    }
-    // byte offset of this lane's tap per column tile, and a mask that drops the pixel offset for the
-    // padded columns (taps >= 75, and the third tile of waves 2 and 3, which run it on zeros rather
-    // than branch: they would wait at the tile barrier anyway) so those read the zero zone
-    int tbase[3], tmask[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int tap = (wave + 4 * j) * 8 + 4 * colhalf + (sl & 3);
-      const int o = (wave + 4 * j) < 10 ? c1_tap_off(tap, c.t) : -1;
-      tbase[j] = o >= 0 ? o * 2 : C1_PATCH * 2;
-      tmask[j] = o >= 0 ? -1 : 0;
-    }
-    __syncthreads();
-    if (q + 1 < q_end) issue(c1_tile(q + 1, T, tiles_x, tiles_y));
-    // 16 k steps (16 pixels each), fully unrolled; the transpose reads of step ks+1 fly during the
-    // MFMAs of step ks (fragments double buffered by parity, interleave pinned below)
-    bf16x8 fa[2], fb[2][3];
-    auto load_k = [&](int ks, bf16x8& a, bf16x8 (&b)[3]) {
-      // this lane's source pixel of the two 4-pixel groups: k = lk*8 + {0..3 | 4..7}
-      int za[2], pa[2];
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int pix = ks * 16 + lk * 8 + hh * 4 + (sl >> 2);
-        za[hh] = pix * 64 + colhalf * 32 + (sl & 3) * 8;
-        pa[hh] = ((2 * (pix >> 4)) * C1_P + 2 * (pix & 15)) * 8;
-      }
-      a = lds_tr_pair(ZsB, za[0], za[1]);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) b[j] = lds_tr_pair(PsB, (pa[0] & tmask[j]) + tbase[j], (pa[1] & tmask[j]) + tbase[j]);
-    };
-    constexpr int KS = C1_PIX / 16;
-    load_k(0, fa[0], fb[0]);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) load_k(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1], fb[ks & 1][j], acc[j], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-    for (int ks = 0; ks + 1 < KS; ++ks) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-  }
-  float* out = slabs + (int64_t)blockIdx.x * 32 * 320;
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    if (wave + 4 * j < 10) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        out[((r & 3) + 8 * (r >> 2) + 4 * lk) * 320 + (wave + 4 * j) * 32 + lr] = acc[j][r];
-    }
-  }
-  if (POOLED && bias_part) {   // column sums of this workgroup's dZ tiles, fixed order
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(Zs);   // 256 x 8 floats
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bsum[e];
-    __syncthreads();
-    if (tid < 32) {
-      const int gq = tid >> 3, e = tid & 7;
-      float sacc = 0.f;
-      for (int w = 0; w < 64; ++w) sacc += red[(w * 4 + gq) * 8 + e];
-      bias_part[(int64_t)blockIdx.x * 32 + tid] = sacc;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // tap-stationary weight gradient for stride-1 "same" layers with Cin in {32,64} (layers 2 and 3)
 // ---------------------------------------------------------------------------------------------
 // dW[n][tap][c] = sum_pixels dZ[pix][n] * X[pix + tap][c].  Instead of building im2col rows (each
@@ -1814,26 +1343,11 @@ static int conv_forward_impl(const void* X, const void* Wp, const float* bias, v
   }
   if (code && Cin != 4) return LR_ERR_UNSUPPORTED;   // the second layer's fused pooling lives in the patch kernel
   if (Cin == 4 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 && ph == 2 && pw == 2) {
-    // first layer: patch-resident kernel (one 16x16 output tile of one frame per workgroup)
+    // first layer: patch-resident kernel (one 16x16 output tile of one frame per workgroup), lr_conv1.hip
     hipEvent_t e0, e1;
     const bool sample = relu && lr_prof_next(LR_PROF_CONV1_FWD, &e0, &e1);
-    int tiles = B * T * ((g.Ho + C1_T - 1) / C1_T) * ((g.Wo + C1_T - 1) / C1_T);
-    if (tiles > 768) tiles = 768;   // persistent: 3 workgroups per CU, each streams its share of tiles
-    lr_clear_error();
-#define LR_C1(POOLV, U8V)                                                                                         \
-  do {                                                                                                           \
-    if (sample) hipExtLaunchKernelGGL((conv1_fwd_patch_kernel<POOLV, U8V>), dim3(tiles), dim3(256), 0,            \
-                                      (hipStream_t)stream, e0, e1, 0, x, w, bias, y, code, B * T, T, Hin, Win,    \
-                                      g.Ho, g.Wo, relu);                                                         \
-    else hipLaunchKernelGGL((conv1_fwd_patch_kernel<POOLV, U8V>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, \
-                            x, w, bias, y, code, B * T, T, Hin, Win, g.Ho, g.Wo, relu);                          \
-  } while (0)
-    if (code && u8) LR_C1(true, true);
-    else if (code) LR_C1(true, false);
-    else if (u8) LR_C1(false, true);
-    else LR_C1(false, false);
-#undef LR_C1
-    return lr_launch_status();
+    return lr_conv1_forward(code != nullptr, u8, x, w, bias, y, code, B * T, T, Hin, Win, g.Ho, g.Wo, relu, sample, e0,
+                            e1, (hipStream_t)stream);
   }
   // instrumentation slot: forward layers by input channels, data gradients by (Cin, relu == 0)
   int slot = -1;
@@ -1886,8 +1400,8 @@ extern "C" size_t lr_conv3d_wgrad_workspace_bytes(int Cout, int Cin_pad, int KT,
   size_t slab = (size_t)wgrad_splits(Cout, Ktot) * Cout * Ktot;
   const size_t ts = (size_t)KT * kTsWgsPerKt * KH * KW * Cout * Cin_pad;   // tap-stationary path
   if (ts > slab) slab = ts;
-  if (slab < (size_t)kC1WgradWgs * 32 * 320) slab = (size_t)kC1WgradWgs * 32 * 320;   // first-layer patch kernel
-  const size_t colparts = kColsumSplits > kC1WgradWgs ? kColsumSplits : kC1WgradWgs;
+  if (slab < (size_t)LR_CONV1_WGRAD_WGS * 32 * 320) slab = (size_t)LR_CONV1_WGRAD_WGS * 32 * 320;   // first-layer patch kernel
+  const size_t colparts = kColsumSplits > LR_CONV1_WGRAD_WGS ? kColsumSplits : LR_CONV1_WGRAD_WGS;
   return (slab + colparts * Cout) * sizeof(float);
 }
 
@@ -1911,30 +1425,18 @@ extern "C" int lr_conv3d_wgrad_pooled(const void* X, const void* pooled, const v
   const size_t need = lr_conv3d_wgrad_workspace_bytes(Cout, Cin_pad, KT, KH, KW);
   if (workspace_bytes < need) return LR_ERR_WORKSPACE;
   float* slabs = (float*)workspace;
-  float* bpart = (float*)((char*)workspace + need) - (size_t)kC1WgradWgs * Cout;
+  float* bpart = (float*)((char*)workspace + need) - (size_t)LR_CONV1_WGRAD_WGS * Cout;
   hipEvent_t e0, e1;
   const bool sample = lr_prof_next(LR_PROF_CONV1_WGRAD, &e0, &e1);
-  const int nwg = kC1WgradWgs;
-  lr_clear_error();
-#define LR_C1W(U8V)                                                                                              \
-  do {                                                                                                           \
-    if (sample) hipExtLaunchKernelGGL((conv1_wgrad_patch_kernel<true, U8V>), dim3(nwg), dim3(256), 0,             \
-                                      (hipStream_t)stream, e0, e1, 0, (const bf16_t*)X, (const bf16_t*)dP,        \
-                                      (const bf16_t*)pooled, (const unsigned char*)code, slabs,                   \
-                                      dbias ? bpart : (float*)nullptr, B * T, T, Hin, Win, g.Ho, g.Wo);           \
-    else hipLaunchKernelGGL((conv1_wgrad_patch_kernel<true, U8V>), dim3(nwg), dim3(256), 0, (hipStream_t)stream,  \
-                            (const bf16_t*)X, (const bf16_t*)dP, (const bf16_t*)pooled,                           \
-                            (const unsigned char*)code, slabs, dbias ? bpart : (float*)nullptr, B * T, T, Hin,    \
-                            Win, g.Ho, g.Wo);                                                                     \
-  } while (0)
-  if (u8) LR_C1W(true);
-  else LR_C1W(false);
-#undef LR_C1W
-  int st = lr_launch_status();
-  if (st != LR_OK) return st;
+  const int nwg = LR_CONV1_WGRAD_WGS;
+  {
+    const int st1 = lr_conv1_wgrad(true, u8, X, dP, pooled, code, slabs, dbias ? bpart : (float*)nullptr, B * T, T, Hin, Win,
+                                   g.Ho, g.Wo, sample, e0, e1, (hipStream_t)stream);
+    if (st1 != LR_OK) return st1;
+  }
   LR_LAUNCH(conv_wgrad_slab_reduce_kernel, dim3(32 * 320 / 64), dim3(64, 16), 0, stream, (const float*)slabs, nwg,
             (int64_t)32 * 320, dW, 0, 32, 4, 3, 75, 25, 320, accumulate);
-  st = lr_launch_status();
+  int st = lr_launch_status();
   if (st != LR_OK || !dbias) return st;
   LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(1024), 0, stream, (const float*)bpart, nwg, dbias, Cout,
             accumulate);
@@ -1961,15 +1463,9 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
                                    &e0, &e1);
   if (Cin_pad == 4 && Cin_real == 3 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 &&
       ph == 2 && pw == 2) {
-    const int nwg = kC1WgradWgs;   // persistent workgroups (2 per CU: 194 registers), partial sums reduced in fixed order
-    lr_clear_error();
-    if (sample) hipExtLaunchKernelGGL((conv1_wgrad_patch_kernel<false, false>), dim3(nwg), dim3(256), 0, (hipStream_t)stream,
-                                      e0, e1, 0, x, dz, (const bf16_t*)nullptr, (const unsigned char*)nullptr, slabs,
-                                      (float*)nullptr, B * T, T, Hin, Win, g.Ho, g.Wo);
-    else hipLaunchKernelGGL((conv1_wgrad_patch_kernel<false, false>), dim3(nwg), dim3(256), 0, (hipStream_t)stream, x, dz,
-                            (const bf16_t*)nullptr, (const unsigned char*)nullptr, slabs, (float*)nullptr, B * T, T,
-                            Hin, Win, g.Ho, g.Wo);
-    int st = lr_launch_status();
+    const int nwg = LR_CONV1_WGRAD_WGS;   // persistent workgroups, partial sums reduced in fixed order
+    int st = lr_conv1_wgrad(false, false, x, dz, nullptr, nullptr, slabs, nullptr, B * T, T, Hin, Win, g.Ho, g.Wo, sample,
+                            e0, e1, (hipStream_t)stream);
     if (st != LR_OK) return st;
     LR_LAUNCH(conv_wgrad_slab_reduce_kernel, dim3(32 * 320 / 64), dim3(64, 16), 0, stream, (const float*)slabs, nwg,
               (int64_t)32 * 320, dW, 0, 32, 4, 3, 75, 25, 320, accumulate);

@@ -43,4 +43,18 @@ __device__ __forceinline__ void relu_pool4(float a0, float a1, float a2, float a
   arg = (int)(~k & 3u);
 }
 
+// Two ds_read_b64_tr_b16 (gfx950 LDS transpose read) -> one MFMA operand.  16 lanes read a
+// [4 k][16 columns] block, 8 bytes each (lane s: row s>>2, columns 4(s&3)..4(s&3)+3), and lane L gets
+// column L of the 4 rows; a0 / a1 address the lane's 8 bytes of k 0..3 / 4..7.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_tr_pair(const unsigned char* lds, int a0, int a1) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + a1));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+
 }  // namespace
