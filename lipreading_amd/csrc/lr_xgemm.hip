@@ -30,8 +30,13 @@
 // i.e. 20-30 % of the bf16 peak.  Measured and dropped: two LDS stage buffers with ONE barrier per stage instead of
 // store / barrier / read / barrier on one buffer — no change (+-3 % on every shape), so the barriers are not what
 // bounds it.  What does: a 128 x 128 tile pulls 3-4 plane tiles (24-32 KB) through the CU's vector L1 per stage of
-// 512-768 MFMA clocks, ~47 B/clk with two workgroups per CU — the L1's rate.  The next step is a 256 x 256 tile
-// (8 waves, 23 B/clk), not a deeper pipeline.
+// 512-768 MFMA clocks, ~47 B/clk with two workgroups per CU — the L1's rate.
+// Measured and dropped as well (round 3): a 256 x 256 tile on 8 waves (wave tile 128 x 64: 6-9 fragment reads for 8-16
+// MFMAs, two LDS buffers with one barrier per stage, loads two stages ahead) for the products with at most three
+// planes.  Bit-compatible results, and SLOWER on the steps' shapes: 173 us instead of 122 for the first layer's dW_ih
+// (1536 x 3456 x 2400), 93 instead of 79 for its data gradient — these outputs are 84-135 tiles of 256 x 256, so the
+// chip is only filled by splitting K three ways, and the slabs' write + combine pass costs more than the larger tile
+// saves; a tile this size wants outputs of >= 256 tiles (4096 x 4096).
 #include "lr_common.h"
 
 namespace {
