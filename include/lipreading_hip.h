@@ -497,6 +497,15 @@ int lr_ctc_grad(const float* log_probs, int64_t stride_b, int64_t stride_t, cons
                 size_t workspace_bytes, int B, int T, int C, int max_label_len,
                 lr_stream_t stream);
 
+/* lr_ctc_grad with every grad_weight[b] multiplied by the DEVICE scalar grad_scale[0] (NULL = 1): the incoming
+ * gradient of the reduced loss in an autograd backward (_CTCLossFunction.backward), without an elementwise launch
+ * to fold it into the weights first. */
+int lr_ctc_grad_scaled(const float* log_probs, int64_t stride_b, int64_t stride_t, const int32_t* labels,
+                       int label_stride, const int32_t* frame_lens, const int32_t* label_lens,
+                       const float* nll, const float* grad_weight, const float* grad_scale, float* grad,
+                       void* workspace, size_t workspace_bytes, int B, int T, int C, int max_label_len,
+                       lr_stream_t stream);
+
 /* The reference's batch reduction (ctc_loss.py:46-114) evaluated on the device from the
  * per-sample nll, so no host round trip is needed to apply it:
  *   - samples with label_lens > 256 are dropped (:46);

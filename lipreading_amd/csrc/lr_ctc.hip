@@ -306,6 +306,7 @@ __global__ void ctc_grad_rows_kernel(const float* __restrict__ lp, int64_t strid
                                      const int32_t* __restrict__ label_lens,
                                      const float* __restrict__ nll,
                                      const float* __restrict__ grad_weight,
+                                     const float* __restrict__ grad_scale,
                                      float* __restrict__ grad, CtcWs ws, int T, int C, int sst,
                                      int max_label_len) {
   const int b = blockIdx.y;
@@ -315,7 +316,7 @@ __global__ void ctc_grad_rows_kernel(const float* __restrict__ lp, int64_t strid
   const int L = label_lens[b];
   int Tb = frame_lens[b];
   if (Tb > T) Tb = T;
-  const float w = grad_weight ? grad_weight[b] : 1.f;
+  const float w = (grad_weight ? grad_weight[b] : 1.f) * (grad_scale ? grad_scale[0] : 1.f);
   const float nll_b = nll[b];
   float* grow = grad + (int64_t)b * stride_b + (int64_t)t * stride_t;
   const bool dead = (L > max_label_len) || L < 0 || Tb <= 0 || w == 0.f || isinf(nll_b) ||
@@ -628,11 +629,11 @@ extern "C" int lr_ctc_nll(const float* log_probs, int64_t stride_b, int64_t stri
   return lr_launch_status();
 }
 
-extern "C" int lr_ctc_grad(const float* log_probs, int64_t stride_b, int64_t stride_t,
-                           const int32_t* labels, int label_stride, const int32_t* frame_lens,
-                           const int32_t* label_lens, const float* nll, const float* grad_weight,
-                           float* grad, void* workspace, size_t workspace_bytes, int B, int T,
-                           int C, int max_label_len, lr_stream_t stream) {
+extern "C" int lr_ctc_grad_scaled(const float* log_probs, int64_t stride_b, int64_t stride_t,
+                                  const int32_t* labels, int label_stride, const int32_t* frame_lens,
+                                  const int32_t* label_lens, const float* nll, const float* grad_weight,
+                                  const float* grad_scale, float* grad, void* workspace, size_t workspace_bytes,
+                                  int B, int T, int C, int max_label_len, lr_stream_t stream) {
   LR_CHECK_ARG(log_probs && labels && frame_lens && label_lens && nll && grad && workspace);
   LR_CHECK_ARG(B > 0 && T > 0 && C > 0 && max_label_len >= 0 && label_stride >= 0);
   if (max_label_len > kMaxLabelLen) max_label_len = kMaxLabelLen;
@@ -640,8 +641,17 @@ extern "C" int lr_ctc_grad(const float* log_probs, int64_t stride_b, int64_t str
   const int sst = ctc_state_stride(max_label_len);
   const CtcWs ws = ctc_ws_carve(workspace, B, T, C, max_label_len);
   LR_LAUNCH_PROF(LR_PROF_CTC_GRAD, ctc_grad_rows_kernel, dim3((T + 3) / 4, B), dim3(256), 0, stream, log_probs, stride_b,
-            stride_t, frame_lens, label_lens, nll, grad_weight, grad, ws, T, C, sst, max_label_len);
+            stride_t, frame_lens, label_lens, nll, grad_weight, grad_scale, grad, ws, T, C, sst, max_label_len);
   return lr_launch_status();
+}
+
+extern "C" int lr_ctc_grad(const float* log_probs, int64_t stride_b, int64_t stride_t,
+                           const int32_t* labels, int label_stride, const int32_t* frame_lens,
+                           const int32_t* label_lens, const float* nll, const float* grad_weight,
+                           float* grad, void* workspace, size_t workspace_bytes, int B, int T,
+                           int C, int max_label_len, lr_stream_t stream) {
+  return lr_ctc_grad_scaled(log_probs, stride_b, stride_t, labels, label_stride, frame_lens, label_lens, nll,
+                            grad_weight, nullptr, grad, workspace, workspace_bytes, B, T, C, max_label_len, stream);
 }
 
 extern "C" int lr_ctc_reduce(const float* nll, const int32_t* frame_lens,

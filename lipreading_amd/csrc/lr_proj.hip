@@ -178,6 +178,136 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __
 
 }  // namespace
 
+// sum_{z<n} p[z*stride] with 8 loads in flight; the 8 partial sums are combined in a fixed order (deterministic)
+__device__ __forceinline__ float strided_sum8(const float* __restrict__ p, int n, int64_t stride) {
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int z = 0;
+  for (; z + 8 <= n; z += 8) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] += p[(int64_t)(z + i) * stride];
+  }
+  for (; z < n; ++z) a[z & 7] += p[(int64_t)z * stride];
+  return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
+// The whole backward head in TWO launches (C <= 128): the unfused chain — row kernel, two split-K GEMMs, their
+// combine pass, two column-sum stages — is six launches of 5-10 us each for 0.3 GFLOP, a tenth of the landmark
+// regime's step.  (1) A workgroup owns 16 rows: it forms their dlogits (kept in LDS in both orientations, written
+// out), multiplies them with W into its dhidden rows, and reduces its rows' outer products with `hidden` into a
+// private dW slab and a dbias row — plain fp32 FMAs, a thread per k column (256 columns per workgroup: the grid's
+// second dimension), dlogits broadcast out of LDS 16 bytes at a time.  (2) The slabs are summed in workgroup order (deterministic) into dW / dbias.
+constexpr int kPbRows = 16, kPbThreads = 256, kPbMaxC = 128;   // grid (row blocks, K / 256): a thread owns ONE k column
+__global__ __launch_bounds__(kPbThreads) void proj_bwd_fused_kernel(const float* __restrict__ g,
+                                                                    const float* __restrict__ lp,
+                                                                    const float* __restrict__ hidden,
+                                                                    const float* __restrict__ W,
+                                                                    float* __restrict__ dlogits,
+                                                                    float* __restrict__ dhidden,
+                                                                    float* __restrict__ slabs, int R, int K, int C) {
+  __shared__ __attribute__((aligned(16))) float dl_rc[kPbRows][kPbMaxC];   // [row][class]
+  __shared__ __attribute__((aligned(16))) float dl_cr[kPbMaxC][kPbRows];   // [class][row]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * kPbRows;
+  const int Cp = (C + 7) & ~7;   // classes in LDS / slab rows: zeros past C
+  // dlogits[r,c] = g[r,c] - exp(lp[r,c]) * sum_c g[r,c]: a wave per row, two rows per wave
+  for (int rr = wave; rr < kPbRows; rr += kPbThreads / 64) {
+    const int r = row0 + rr;
+    float gv[kPbMaxC / 64], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kPbMaxC / 64; ++i) {
+      const int c = lane + i * 64;
+      gv[i] = (r < R && c < C) ? g[(int64_t)r * C + c] : 0.f;
+      s += gv[i];
+    }
+    s = lr_wave_sum(s);
+#pragma unroll
+    for (int i = 0; i < kPbMaxC / 64; ++i) {
+      const int c = lane + i * 64;
+      if (c >= Cp) continue;
+      float d = 0.f;
+      if (r < R && c < C) {
+        d = gv[i] - expf(lp[(int64_t)r * C + c]) * s;
+        if (blockIdx.y == 0) dlogits[(int64_t)r * C + c] = d;
+      }
+      dl_rc[rr][c] = d;
+      dl_cr[c][rr] = d;
+    }
+  }
+  __syncthreads();
+  const int nrow = min(kPbRows, R - row0);
+  float* slab = slabs + (int64_t)blockIdx.x * ((int64_t)Cp * K + Cp);
+  const int k = blockIdx.y * kPbThreads + tid;
+  if (k < K) {
+    if (dhidden) {   // dhidden[r,k] = sum_c dlogits[r,c] W[c,k]
+      float acc[kPbRows];
+#pragma unroll
+      for (int r = 0; r < kPbRows; ++r) acc[r] = 0.f;
+      // eight W loads in flight (one dependent load per class was 500 cycles of latency per class: 25 us)
+      for (int c0 = 0; c0 < C; c0 += 8) {
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = c0 + j < C ? W[(int64_t)(c0 + j) * K + k] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+          for (int q = 0; q < kPbRows / 4; ++q) {
+            const float4 d = *reinterpret_cast<const float4*>(&dl_cr[c0 + j][4 * q]);
+            acc[4 * q] += d.x * w[j]; acc[4 * q + 1] += d.y * w[j]; acc[4 * q + 2] += d.z * w[j]; acc[4 * q + 3] += d.w * w[j];
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kPbRows; ++r)
+        if (r < nrow) dhidden[(int64_t)(row0 + r) * K + k] = acc[r];
+    }
+    // slab[c,k] = sum_r dlogits[r,c] hidden[r,k], eight classes at a time (the slab has C rounded up to 8 rows, so
+    // that no store needs a predicate)
+    float h[kPbRows];
+#pragma unroll
+    for (int r = 0; r < kPbRows; ++r) h[r] = r < nrow ? hidden[(int64_t)(row0 + r) * K + k] : 0.f;
+#pragma unroll 1
+    for (int c0 = 0; c0 < C; c0 += 8) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < kPbRows; ++r) {
+        const float4 d0 = *reinterpret_cast<const float4*>(&dl_rc[r][c0]);
+        const float4 d1 = *reinterpret_cast<const float4*>(&dl_rc[r][c0 + 4]);
+        acc[0] += d0.x * h[r]; acc[1] += d0.y * h[r]; acc[2] += d0.z * h[r]; acc[3] += d0.w * h[r];
+        acc[4] += d1.x * h[r]; acc[5] += d1.y * h[r]; acc[6] += d1.z * h[r]; acc[7] += d1.w * h[r];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) slab[(int64_t)(c0 + j) * K + k] = acc[j];
+    }
+  }
+  if (blockIdx.y == 0 && tid < C) {   // the rows' column sums (dbias)
+    float sacc = 0.f;
+    for (int r = 0; r < kPbRows; ++r) sacc += dl_rc[r][tid];
+    slab[(int64_t)Cp * K + tid] = sacc;
+  }
+}
+
+// out[i] (+)= sum over the workgroups' slabs; i < C*K: dW, then C elements of dbias.  blockDim = (64, 4): thread
+// row y sums slabs y, y + 4, ... (8 loads in flight), the four partial sums meet in LDS in a fixed order.
+__global__ void proj_bwd_reduce_kernel(const float* __restrict__ slabs, int nslab, int64_t n_dw, int C,
+                                       float* __restrict__ dW, float* __restrict__ dbias, int accumulate) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x, y = threadIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const int Cp = (C + 7) & ~7;
+  const int64_t K = n_dw / C, per = (int64_t)Cp * K + Cp;   // a slab: [Cp][K] + [Cp]
+  float s = 0.f;
+  if (i < n_dw + C) {
+    const int mine = (nslab - y + 3) / 4;
+    s = strided_sum8(slabs + (int64_t)y * per + (i < n_dw ? i : (int64_t)Cp * K + (i - n_dw)), mine, 4 * per);
+  }
+  part[y][lane] = s;
+  __syncthreads();
+  if (y != 0 || i >= n_dw + C) return;
+  const float tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+  float* out = i < n_dw ? dW + i : dbias + (i - n_dw);
+  *out = accumulate ? *out + tot : tot;
+}
+
 // workspace head: [C] folded bias (forward) or [LR_COLSUM_SPLITS][C] partial sums (backward)
 static size_t proj_head_bytes(int C) {
   return lr_align_up((size_t)LR_COLSUM_SPLITS * C * sizeof(float), 256);
@@ -190,6 +320,9 @@ extern "C" size_t lr_proj_workspace_bytes(int R, int K, int C) {
   size_t c = lr_sgemm_workspace_bytes(R, C, K);  // forward
   size_t m = a > b ? a : b;
   if (c > m) m = c;
+  const size_t Cp = ((size_t)C + 7) / 8 * 8;
+  const size_t fused = C <= kPbMaxC ? (size_t)((R + kPbRows - 1) / kPbRows) * (Cp * K + Cp) * sizeof(float) : 0;
+  if (fused > m) m = fused;   // the fused backward's per-workgroup slabs
   return m + proj_head_bytes(C);
 }
 
@@ -233,6 +366,18 @@ extern "C" int lr_proj_logsoftmax_backward(const float* g, const float* log_prob
   hipStream_t stream = (hipStream_t)stream_;
   char* gws = (char*)workspace + proj_head_bytes(C);
   const size_t gws_bytes = workspace_bytes - proj_head_bytes(C);
+  if (C <= kPbMaxC) {
+    const int nblk = (R + kPbRows - 1) / kPbRows;
+    float* slabs = (float*)gws;
+    LR_LAUNCH(proj_bwd_fused_kernel, dim3(nblk, (K + kPbThreads - 1) / kPbThreads), dim3(kPbThreads), 0, stream, g, log_probs, hidden, W, dlogits, dhidden,
+              slabs, R, K, C);
+    int st0 = lr_launch_status();
+    if (st0 != LR_OK) return st0;
+    const int64_t n_dw = (int64_t)C * K;
+    LR_LAUNCH(proj_bwd_reduce_kernel, dim3((unsigned)((n_dw + C + 63) / 64)), dim3(64, 4), 0, stream,
+              (const float*)slabs, nblk, n_dw, C, dW, dbias, accumulate);
+    return lr_launch_status();
+  }
   LR_LAUNCH(log_softmax_bwd_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, g, log_probs,
             dlogits, R, C);
   int st = lr_launch_status();

@@ -51,15 +51,19 @@ class _CTCLossFunction(torch.autograd.Function):
     B, T, C = log_probs.shape
     st = _C.stream_handle()
     ml = ctx.max_label_len
-    w = gw * grad_out.reshape(()).to(torch.float32)
+    # the incoming gradient of the reduced loss multiplies every sample's weight INSIDE the kernel (a device scalar:
+    # `gw * grad_out` here was an elementwise launch of its own, ~5 us of a 470 us step)
+    go = grad_out.reshape(1)
+    if go.dtype != torch.float32:
+      go = go.float()
     grad = torch.empty((B, T, C), dtype=torch.float32, device=log_probs.device)
     # grad is addressed with the same (stride_b, stride_t) as log_probs, so give the kernel a
     # contiguous view of the lattice when the input is a transposed view
     lp = log_probs if log_probs.is_contiguous() else log_probs.contiguous()
-    _C.check(L.lr_ctc_grad(lp.data_ptr(), lp.stride(0), lp.stride(1), labels_p1.data_ptr(),
-                           labels_p1.stride(0), frame_lens.data_ptr(), label_lens.data_ptr(),
-                           nll.data_ptr(), w.data_ptr(), grad.data_ptr(), ws.data_ptr(),
-                           ws.numel(), B, T, C, ml, st), "lr_ctc_grad")
+    _C.check(L.lr_ctc_grad_scaled(lp.data_ptr(), lp.stride(0), lp.stride(1), labels_p1.data_ptr(),
+                                  labels_p1.stride(0), frame_lens.data_ptr(), label_lens.data_ptr(),
+                                  nll.data_ptr(), gw.data_ptr(), go.data_ptr(), grad.data_ptr(), ws.data_ptr(),
+                                  ws.numel(), B, T, C, ml, st), "lr_ctc_grad_scaled")
     return grad, None, None, None, None, None
 
 
