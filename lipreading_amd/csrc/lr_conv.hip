@@ -646,214 +646,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __re
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// weight gradient with LDS transpose reads (stride-1 layers):  dW[n][kt][kh][kw][c] =
-//     sum_pos dZ[pos][n] * X[pos + tap][c]
-// ---------------------------------------------------------------------------------------------
-// The contraction runs over POSITIONS, the slow axis of both channels-last operands, while an MFMA
-// operand wants 8 consecutive k per lane.  gfx950's ds_read_b64_tr_b16 does that transpose on the
-// way out of LDS: 16 lanes read a [4 positions][16 channels] block (8 bytes each: lane s -> position
-// s>>2, channels 4(s&3)..) and lane L receives channel L of the 4 positions.  Two such reads give
-// the 8 k values of a lane, for A (dZ: rows = output channels) and B (X at a tap offset: columns =
-// input channels) alike, so both stay in their natural channels-last order in LDS, as planes of
-// [position][32 channels] (64 B per position: the 4 positions x 64 B of a read are 256 contiguous
-// bytes — every bank once — whatever the tap shift).
-//   Workgroup = (temporal tap kt, slot): it keeps dW[:, kt, :, :, :] (MT x KH*KW*CIN/32 MFMA tiles,
-//   split over 4 waves by tap) in registers while it walks its share of (2-frame x TH-row) tiles;
-//   the X patch is loaded already shifted by kt - 1 frames (zero across clip boundaries).  The next
-//   tile's 16-byte units are issued into registers before the current tile's MFMAs and stored to the
-//   other LDS buffer after them.  The three kt siblings of a slot sit on one XCD (block b runs on
-//   XCD b % 8) and walk the same tiles, so dZ comes out of HBM once.  Slabs and the fixed-order
-//   reduction are those of the tap-stationary kernel above.
-constexpr int kTrSlots = 80;   // slots per temporal tap: 3 x 80 = 240 workgroups = 30 per XCD
-
-template <int CIN, int MT, int KH, int KW, int W, int TT, int TH>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_tr_kernel(const bf16_t* __restrict__ X,
-                                                               const bf16_t* __restrict__ dZ,
-                                                               float* __restrict__ slabs, int F, int T, int H) {
-  constexpr int CH = CIN / 32, PH = TH + KH - 1, PW = W + KW - 1;
-  constexpr int XPOS = TT * PH * PW, ZPOS = TT * TH * W;
-  constexpr int XBYTES = CH * XPOS * 64, ZBYTES = MT * ZPOS * 64, BUF = XBYTES + ZBYTES;
-  constexpr int XUNITS = XBYTES / 16, UNITS = BUF / 16, UPT = (UNITS + 255) / 256;
-  constexpr int W4 = W / 4, GPS = TH * W4;   // position groups (4 columns) per row band of one frame
-  constexpr int STEPS = TT * GPS / 4;        // k16 steps per tile
-  constexpr int NU = KH * KW * CH, UPW = (NU + 3) / 4, COUT = MT * 32;
-  static_assert(W % 4 == 0 && (TT * GPS) % 4 == 0, "tile must be a whole number of k16 steps");
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // block b -> XCD b % 8; the kt siblings of a slot are blocks 8(3i + kt) + x
-  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
-  const int kt = kq % 3, slot = (kq / 3) * 8 + xcd;
-  const int htiles = H / TH;
-  const int ntile = ((F + TT - 1) / TT) * htiles;
-
-  f32x16 acc[UPW][MT];
-#pragma unroll
-  for (int j = 0; j < UPW; ++j)
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-
-  // this wave's n-units (tap, 32-channel plane): LDS offset of the tap shift.  Every wave runs UPW
-  // units; where NU is not a multiple of 4 the waves that would idle at the tile barrier anyway
-  // repeat the last unit instead (result not stored), which keeps the step loop free of branches.
-  int uoff[UPW];
-#pragma unroll
-  for (int j = 0; j < UPW; ++j) {
-    const int u = wave + 4 * j < NU ? wave + 4 * j : NU - 1;
-    const int tap = u / CH, plane = u - tap * CH;
-    uoff[j] = plane * XPOS * 64 + ((tap / KW) * PW + tap % KW) * 64;
-  }
-  const int sl = lane & 15, kg = lane >> 5;
-  const int laneoff = ((lane >> 4) & 1) * 32 + (sl & 3) * 8 + (sl >> 2) * 64;
-
-  // A thread moves the same 16-byte units of every tile: decode them once.  urel = element offset
-  // from the tile origin (frame f0, row h0), umeta = frame slot | X-or-dZ | statically valid | row offset.
-  int urel[UPT], umeta[UPT];
-#pragma unroll
-  for (int i = 0; i < UPT; ++i) {
-    const int u = tid + 256 * i;
-    urel[i] = 0;
-    umeta[i] = 0;
-    if (u < XUNITS) {
-      const int plane = u / (XPOS * 4), rem = u - plane * (XPOS * 4);
-      const int pos = rem >> 2, c8 = rem & 3;
-      const int sf = pos / (PH * PW), r2 = pos - sf * (PH * PW);
-      const int ph = r2 / PW, pw = r2 - ph * PW;
-      const int dh = ph - (KH - 1) / 2, w = pw - (KW - 1) / 2;
-      urel[i] = (((sf + kt - 1) * H + dh) * W + w) * CIN + plane * 32 + c8 * 8;
-      umeta[i] = sf | 4 | ((w >= 0 && w < W) ? 8 : 0) | ((dh + 16) << 8);
-    } else if (u < UNITS) {
-      const int uz = u - XUNITS;
-      const int mt = uz / (ZPOS * 4), rem = uz - mt * (ZPOS * 4);
-      const int pos = rem >> 2, c8 = rem & 3;
-      const int sf = pos / (TH * W), r2 = pos - sf * (TH * W);
-      const int h = r2 / W, w = r2 - h * W;
-      urel[i] = ((sf * H + h) * W + w) * COUT + mt * 32 + c8 * 8;
-      umeta[i] = sf | 8 | ((h + 16) << 8);
-    }
-  }
-  uint4 pre[UPT];
-  unsigned pre_ok = 0;   // bit i: unit i of the tile in flight is real data (else it is stored as zeros)
-  // BRANCH-FREE on purpose: with `if (ok) v = load` hipcc branches around every one of the 19 loads (~20
-  // instructions and two exec-mask round trips apiece, in basic blocks of their own that nothing overlaps with
-  // the MFMAs: a quarter of a tile's time).  Every unit is loaded — from the tile origin when it is padding — and
-  // padding is replaced by zeros on the way into LDS.
-  auto issue = [&](int tile) {   // global -> registers: every 16-byte unit of a tile
-    const int f0 = (tile / htiles) * TT, h0 = (tile % htiles) * TH;
-    unsigned okx = 0, okz = 0;   // per frame slot: X frame (shifted by kt - 1, same clip) / dZ frame exists
-#pragma unroll
-    for (int sf = 0; sf < TT; ++sf) {
-      const int f = f0 + sf, tt = f % T + kt - 1;
-      if (f < F) okz |= 1u << sf;
-      if (f < F && tt >= 0 && tt < T) okx |= 1u << sf;
-    }
-    const bf16_t* xb = X + ((int64_t)f0 * H + h0) * W * CIN;
-    const bf16_t* zb = dZ + ((int64_t)f0 * H + h0) * W * COUT;
-    pre_ok = 0;
-#pragma unroll
-    for (int i = 0; i < UPT; ++i) {
-      const int m = umeta[i], sf = m & 3;
-      // units tid + 256 i below XUNITS are X, the others dZ: a compile-time fact for all but one i
-      const bool isx = 256 * i + 255 < XUNITS ? true : (256 * i >= XUNITS ? false : (m & 4) != 0);
-      const unsigned hh = (unsigned)(h0 + ((m >> 8) & 0xff) - 16);
-      const bool ok = (m & 8) && (((isx ? okx : okz) >> sf) & 1u) && (!isx || hh < (unsigned)H);
-      pre_ok |= (ok ? 1u : 0u) << i;
-      pre[i] = *reinterpret_cast<const uint4*>((isx ? xb : zb) + (ok ? urel[i] : 0));
-    }
-  };
-  auto deposit = [&](int buf) {   // registers -> LDS buffer (planes of [position][32 channels])
-#pragma unroll
-    for (int i = 0; i < UPT; ++i) {
-      const int u = tid + 256 * i;
-      const bool ok = (pre_ok >> i) & 1u;
-      uint4 v = pre[i];
-      v.x = ok ? v.x : 0u;
-      v.y = ok ? v.y : 0u;
-      v.z = ok ? v.z : 0u;
-      v.w = ok ? v.w : 0u;
-      if (u < UNITS) *reinterpret_cast<uint4*>(lds + buf * BUF + u * 16) = v;
-    }
-  };
-
-  int tile = slot;
-  if (tile < ntile) {
-    issue(tile);
-    deposit(0);
-  }
-  __syncthreads();
-  for (int it = 0; tile < ntile; tile += kTrSlots, ++it) {
-    const int cur = it & 1;
-    const bool has_next = tile + kTrSlots < ntile;
-    if (has_next) issue(tile + kTrSlots);
-    const unsigned char* base = lds + cur * BUF;
-    // One wave per SIMD: the fragment reads of step st+1 must be in flight during the MFMAs of step
-    // st, or every MFMA pair waits out an LDS round trip (SQ_WAIT_ANY was 40% of the wave cycles with
-    // the reads where the compiler puts them, next to their use).  Fully unrolled, fragments double
-    // buffered by step parity, and the interleave pinned with sched_group_barrier: one transpose
-    // read between consecutive MFMAs.
-    constexpr int NM = UPW * MT, ND = 2 * (MT + UPW);   // MFMAs / LDS reads per step
-    static_assert(ND >= NM, "the pinned interleave assumes at least one read per MFMA");
-    bf16x8 fa[2][MT], fb[2][UPW];
-    auto load_step = [&](int st, bf16x8 (&aa)[MT], bf16x8 (&bb)[UPW]) {
-      // the lane's two position groups of this k16 step: g = 4 st + 2 kg + {0, 1}
-      int za[2], xa[2];
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int g = 4 * st + 2 * kg + hh;
-        const int sf = g / GPS, r = g - sf * GPS;
-        const int h = r / W4, w0 = 4 * (r - h * W4);
-        za[hh] = XBYTES + ((sf * TH + h) * W + w0) * 64 + laneoff;
-        xa[hh] = ((sf * PH + h) * PW + w0) * 64 + laneoff;
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i) aa[i] = lds_tr_pair(base, za[0] + i * ZPOS * 64, za[1] + i * ZPOS * 64);
-#pragma unroll
-      for (int j = 0; j < UPW; ++j) bb[j] = lds_tr_pair(base, xa[0] + uoff[j], xa[1] + uoff[j]);
-    };
-    load_step(0, fa[0], fb[0]);
-#pragma unroll
-    for (int st = 0; st < STEPS; ++st) {
-      if (st + 1 < STEPS) load_step(st + 1, fa[(st + 1) & 1], fb[(st + 1) & 1]);
-#pragma unroll
-      for (int j = 0; j < UPW; ++j)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st & 1][i], fb[st & 1][j], acc[j][i], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);          // step 0's fragments
-#pragma unroll
-    for (int st = 0; st + 1 < STEPS; ++st) {
-      __builtin_amdgcn_sched_group_barrier(0x100, ND - NM, 0);
-#pragma unroll
-      for (int m = 0; m < NM; ++m) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA of step st
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // a read of step st + 1
-      }
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);          // last step
-    if (has_next) deposit(cur ^ 1);
-    __syncthreads();   // buffer `cur` is free again; the next tile is in place
-  }
-  // partial result of this workgroup: slabs[slot*3 + kt][tap][n][c]
-  const int lr = lane & 31, lk = lane >> 5;
-  float* out = slabs + (int64_t)(slot * 3 + kt) * (KH * KW) * COUT * CIN;
-#pragma unroll
-  for (int j = 0; j < UPW; ++j) {
-    const int u = wave + 4 * j;
-    if (u < NU) {
-      const int tap = u / CH, plane = u - tap * CH;
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-          out[((int64_t)tap * COUT + n) * CIN + plane * 32 + lr] = acc[j][i][r];
-        }
-    }
-  }
-}
+// (The weight gradient of the stride-1 layers at the frontend's sizes — LDS transpose reads, persistent workgroups —
+// is lr_conv_wgrad.hip; the slab reduction below serves it as well.)
 
 // Reduction of the per-workgroup weight-gradient slabs into dW (fp32, torch layout [n][c][kt][kh][kw]).
 // Lanes run over CONSECUTIVE slab elements, so every slab read is a coalesced 256-byte wave load
@@ -1482,45 +1276,15 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
     const bool l2 = Cin_pad == 32 && Cout == 64 && KH == 5 && KW == 5 && Win == 24 && Hin % 4 == 0;
     const bool l3 = Cin_pad == 64 && Cout == 96 && KH == 3 && KW == 3 && Win == 12 && Hin % 6 == 0;
     if (stride == 1 && KT == 3 && pt == 1 && 2 * ph + 1 == KH && 2 * pw + 1 == KW && Cin_real == Cin_pad &&
-        (l2 || l3)) {
+        (l2 || l3) && lr_conv_wgrad_tr2_supported(l2 ? 2 : 3, B * T, Hin)) {
       hipEvent_t e0, e1;
       const bool sample = lr_prof_next(l2 ? LR_PROF_CONV2_WGRAD : LR_PROF_CONV3_WGRAD, &e0, &e1);
       const bf16_t* x = (const bf16_t*)X;
       const bf16_t* dz = (const bf16_t*)dZ;
       float* slabs = (float*)workspace;
       const int F = B * T;
-      static bool attr_set[9] = {false, false, false, false, false, false, false, false, false};
-      static int variant = -1;   // TEMPORARY A/B knob: 0 first form, else second form (lr_conv_wgrad.hip)
-      if (variant < 0) {
-        const char* e = getenv("LIPREADING_CONV_WGRAD_TR");
-        variant = e ? atoi(e) : 2;
-      }
-      const bool second = variant != 0 && lr_conv_wgrad_tr2_supported(l2 ? 2 : 3, F, Hin);
-      const int nslots = second ? LR_CONV_TR2_SLOTS : kTrSlots;
-      lr_clear_error();
-#define LR_WGTR(IDX, LDSB, ...)                                                                              \
-  do {                                                                                                      \
-    if (!attr_set[IDX]) {                                                                                   \
-      if (hipFuncSetAttribute((const void*)conv_wgrad_tr_kernel<__VA_ARGS__>,                                \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)              \
-        return LR_ERR_LAUNCH;                                                                               \
-      attr_set[IDX] = true;                                                                                 \
-    }                                                                                                       \
-    if (sample) hipExtLaunchKernelGGL((conv_wgrad_tr_kernel<__VA_ARGS__>), dim3(3 * kTrSlots), dim3(256), LDSB, \
-                                      (hipStream_t)stream, e0, e1, 0, x, dz, slabs, F, T, Hin);             \
-    else hipLaunchKernelGGL((conv_wgrad_tr_kernel<__VA_ARGS__>), dim3(3 * kTrSlots), dim3(256), LDSB,        \
-                            (hipStream_t)stream, x, dz, slabs, F, T, Hin);                                  \
-  } while (0)
-      // 6-row tiles where the height allows (18 k16 steps per tile instead of 12 amortise the per-tile
-      // load / deposit / barrier better; 142 KB of the 160 KB of LDS for the two buffers)
-      if (second) {
-        const int st2 = lr_conv_wgrad_tr2(l2 ? 2 : 3, x, dz, slabs, F, T, Hin, sample, e0, e1, (hipStream_t)stream);
-        if (st2 != LR_OK) return st2;
-      } else if (l2 && Hin % 6 == 0) LR_WGTR(2, 2 * (2 * 10 * 28 * 64 + 2 * 2 * 6 * 24 * 64), 32, 2, 5, 5, 24, 2, 6);
-      else if (l2) LR_WGTR(0, 2 * (2 * 8 * 28 * 64 + 2 * 2 * 4 * 24 * 64), 32, 2, 5, 5, 24, 2, 4);
-      else LR_WGTR(1, 2 * (2 * 2 * 8 * 14 * 64 + 3 * 2 * 6 * 12 * 64), 64, 3, 3, 3, 12, 2, 6);
-#undef LR_WGTR
-      int st = lr_launch_status();
+      const int nslots = LR_CONV_TR2_SLOTS;
+      int st = lr_conv_wgrad_tr2(l2 ? 2 : 3, x, dz, slabs, F, T, Hin, sample, e0, e1, (hipStream_t)stream);
       if (st != LR_OK) return st;
       {
         const int64_t se = (int64_t)Cout * Cin_pad * KT * KH * KW;

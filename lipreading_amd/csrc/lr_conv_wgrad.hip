@@ -21,7 +21,15 @@ __device__ __forceinline__ bf16x8 lds_tr_pair(const unsigned char* lds, int a0, 
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// Second form of lr_conv.hip's conv_wgrad_tr_kernel (same operands, same LDS image, same slabs), rebuilt around what the first one
+// Weight gradient of the frontend's stride-1 layers:  dW[n][kt][kh][kw][c] = sum_pos dZ[pos][n] * X[pos + tap][c].
+// The contraction runs over POSITIONS, the slow axis of both channels-last operands, while an MFMA operand wants 8
+// consecutive k per lane: gfx950's ds_read_b64_tr_b16 does that transpose on the way out of LDS (16 lanes read a
+// [4 positions][16 channels] block, 8 bytes each, and lane L receives channel L of the 4 positions; two reads = one
+// operand), so dZ and X stay channels-last in LDS, as planes of [position][32 channels].  A workgroup = (temporal tap
+// kt, slot) keeps dW[:, kt] — all (tap, 32-channel plane) units x row tiles — in accumulators while it walks its share
+// of (2-frame x TH-row) tiles; the X patch is loaded already shifted by kt - 1 frames.  Partial results go to slabs,
+// reduced in fixed order (conv_wgrad_slab_reduce_kernel, lr_conv.hip).
+// This is the kernel's SECOND form (round 3; the first, rounds 1-2, is in the history), rebuilt around what the first
 // spent outside its MFMAs — 34 % of a tile's 12.2 k cycles at layer 2 (r03_pixels_pmc_SQ_pass1: MFMA busy 0.63):
 //   * 85 slots per temporal tap instead of 80: 255 workgroups (the first used 240 of the 256 CUs).  Blocks 0..239
 //     keep the three kt siblings of a slot on one XCD; the last 15 blocks are slots 80..84, siblings side by side.
@@ -330,26 +338,32 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr2_kernel(const bf16_t* __
 
 }  // namespace
 
-// The tile table has to fit behind the two LDS buffers: (tiles of a workgroup + 1) x 32 bytes.
-static int tr2_table_bytes(int F, int H) {
-  const int ntile = ((F + 1) / 2) * (H / 6);
+// The tile table has to fit behind the two LDS buffers: (tiles of a workgroup + 1) x 32 bytes.  Layer 2 takes 6-row
+// tiles where the height allows, 4-row tiles otherwise.
+static int tr2_tile_rows(int layer, int H) { return H % 6 == 0 ? 6 : (layer == 2 && H % 4 == 0 ? 4 : 0); }
+static int tr2_table_bytes(int F, int H, int th) {
+  const int ntile = ((F + 1) / 2) * (H / th);
   return ((ntile + kTr2Slots - 1) / kTr2Slots + 1) * 32;
 }
 int lr_conv_wgrad_tr2_supported(int layer, int F, int H) {
-  if ((layer != 2 && layer != 3) || H <= 0 || H % 6 != 0 || F <= 0) return 0;
-  const int room = layer == 2 ? Tr2<32, 2, 5, 5, 24, 2, 6>::TAB_BYTES : Tr2<64, 3, 3, 3, 12, 2, 6>::TAB_BYTES;
-  return tr2_table_bytes(F, H) <= room;
+  if ((layer != 2 && layer != 3) || H <= 0 || F <= 0) return 0;
+  const int th = tr2_tile_rows(layer, H);
+  if (!th) return 0;
+  const int room = layer == 3 ? Tr2<64, 3, 3, 3, 12, 2, 6>::TAB_BYTES
+                              : (th == 6 ? Tr2<32, 2, 5, 5, 24, 2, 6>::TAB_BYTES : Tr2<32, 2, 5, 5, 24, 2, 4>::TAB_BYTES);
+  return tr2_table_bytes(F, H, th) <= room;
 }
 
-// layer: 2 (24 wide, 32 -> 64 channels, 3x5x5) or 3 (12 wide, 64 -> 96, 3x3x3); H % 6 == 0.  slabs: 3 x
-// LR_CONV_TR2_SLOTS partial results, the layout of the first form.
+// layer: 2 (24 wide, 32 -> 64 channels, 3x5x5; H % 6 == 0 or H % 4 == 0) or 3 (12 wide, 64 -> 96, 3x3x3; H % 6 == 0).
+// slabs: 3 x LR_CONV_TR2_SLOTS partial results [slot * 3 + kt][tap][n][c].
 int lr_conv_wgrad_tr2(int layer, const void* X, const void* dZ, float* slabs, int F, int T, int H,
                       bool sample, hipEvent_t e0, hipEvent_t e1, hipStream_t stream) {
-  static bool attr_set[2] = {false, false};
+  static bool attr_set[3] = {false, false, false};
   const bf16_t* x = (const bf16_t*)X;
   const bf16_t* dz = (const bf16_t*)dZ;
   if (!lr_conv_wgrad_tr2_supported(layer, F, H) || T <= 0) return LR_ERR_UNSUPPORTED;
-  const int tabb = tr2_table_bytes(F, H);
+  const int th = tr2_tile_rows(layer, H);
+  const int tabb = tr2_table_bytes(F, H, th);
   lr_clear_error();
 #define LR_WGTR2(IDX, ...)                                                                                   \
   do {                                                                                                      \
@@ -366,9 +380,9 @@ int lr_conv_wgrad_tr2(int layer, const void* X, const void* dZ, float* slabs, in
     else hipLaunchKernelGGL((conv_wgrad_tr2_kernel<__VA_ARGS__>), dim3(3 * kTr2Slots), dim3(256), LDSB,      \
                             stream, x, dz, slabs, F, T, H);                                                 \
   } while (0)
-  if (layer == 2) LR_WGTR2(0, 32, 2, 5, 5, 24, 2, 6);
+  if (layer == 2 && th == 6) LR_WGTR2(0, 32, 2, 5, 5, 24, 2, 6);
+  else if (layer == 2) LR_WGTR2(2, 32, 2, 5, 5, 24, 2, 4);
   else LR_WGTR2(1, 64, 3, 3, 3, 12, 2, 6);
 #undef LR_WGTR2
   return lr_launch_status();
 }
-

@@ -332,23 +332,25 @@ def test_layer2_tail_tiles_split_by_frame_are_the_same_numbers(dev):
   assert int(whole[2][6 * T:].ne(0).sum()) > 0 and int(whole[3][6 * T:].ne(0).sum()) > 0
 
 
-@pytest.mark.parametrize("layer,B,T", [(2, 2, 45), (2, 3, 7), (2, 1, 1), (3, 2, 45), (3, 5, 9), (3, 1, 2)])
-def test_stride1_weight_gradient_against_torch(dev, layer, B, T):
+@pytest.mark.parametrize("layer,B,T,H", [(2, 2, 45, 24), (2, 3, 7, 24), (2, 1, 1, 24), (2, 2, 9, 16), (3, 2, 45, 12),
+                                         (3, 5, 9, 12), (3, 1, 2, 12)])
+def test_stride1_weight_gradient_against_torch(dev, layer, B, T, H):
   """lr_conv3d_wgrad on the geometries of layers 2 and 3 (the persistent LDS-transpose-read kernel of
   lr_conv_wgrad.hip: 255 workgroups, units split by row tile, padding through out-of-range buffer loads, the
   next tile loaded and stored among the current tile's MFMAs) against torch's fp32 conv3d weight gradient of the
   same bf16 operands.  B*T = 90 frames gives a workgroup up to three tiles (the table, both LDS buffers and the
   tile of zeros after the last one are all exercised); 21, 45 and 2 frames leave workgroups without any tile and
   put clip boundaries and the end of the batch inside a 2-frame tile; T = 1, 2: every temporal tap but the
-  middle one(s) leaves the clip.  Accumulation is fp32 in another order: 2e-5 of the largest gradient."""
+  middle one(s) leaves the clip; a 16-row layer-2 input takes the 4-row tiles.  Accumulation is fp32 in another
+  order: 2e-5 of the largest gradient."""
   from lipreading_amd import _C
   L = _C.lib()
   st = _C.stream_handle()
   cin, cout, k, hw = (32, 64, (3, 5, 5), 24) if layer == 2 else (64, 96, (3, 3, 3), 12)
   pads = (1, k[1] // 2, k[2] // 2)
   g = torch.Generator().manual_seed(100 * layer + T)
-  x = (torch.randn(B, T, hw, hw, cin, generator=g)).clamp_min(0).bfloat16()
-  dz = (torch.randn(B, T, hw, hw, cout, generator=g) * 0.1).bfloat16()
+  x = (torch.randn(B, T, H, hw, cin, generator=g)).clamp_min(0).bfloat16()
+  dz = (torch.randn(B, T, H, hw, cout, generator=g) * 0.1).bfloat16()
   w = torch.zeros(cout, cin, *k, requires_grad=True)
   out = torch.nn.functional.conv3d(x.float().permute(0, 4, 1, 2, 3), w, None, stride=1, padding=pads)
   out.backward(dz.float().permute(0, 4, 1, 2, 3))
@@ -360,9 +362,9 @@ def test_stride1_weight_gradient_against_torch(dev, layer, B, T):
     dw = torch.full((cout, cin) + k, 0.5 if accumulate else float("nan"), device=dev)
     db = torch.full((cout,), 0.25 if accumulate else float("nan"), device=dev)
     _C.check(L.lr_conv3d_wgrad(xd.data_ptr(), dzd.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), wbytes,
-                               accumulate, B, T, hw, hw, cin, cin, cout, *k, 1, *pads, st))
+                               accumulate, B, T, H, hw, cin, cin, cout, *k, 1, *pads, st))
     got_w, got_b = dw.cpu().numpy() - 0.5 * accumulate, db.cpu().numpy() - 0.25 * accumulate
-    assert np.abs(got_w - ref_w).max() <= 2e-5 * np.abs(ref_w).max() + 1e-6 * accumulate, (layer, B, T, accumulate)
+    assert np.abs(got_w - ref_w).max() <= 2e-5 * np.abs(ref_w).max() + 1e-6 * accumulate, (layer, B, T, H, accumulate)
     assert np.abs(got_b - ref_b).max() <= 1e-4 * max(1.0, np.abs(ref_b).max())
 
 
