@@ -125,40 +125,81 @@ constexpr int XPACK_MAX = 8;
 struct XPackArgs {
   XPackBlock b[XPACK_MAX];
 };
+// 64 x 64 tiles, 16 bytes per lane on both sides where the block's addresses allow: a lane loads four consecutive
+// input columns (float4, or four bf16) and stores EIGHT consecutive plane elements (one uint4 per plane) that it
+// collects from the LDS tile — down a tile column when the block is transposed; tile rows of 65 floats make both
+// directions conflict-free.  (Round 2's form — 32 x 32 tiles, one element per lane, 2-byte stores — moved ~0.8 TB/s:
+// the eight pack launches of a pixel step were 150 us, 60 of them on the critical path.)
 __global__ __launch_bounds__(256) void xpack_multi_kernel(XPackArgs a) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[64][65];
   const XPackBlock& k = a.b[blockIdx.z];
   const int orows = k.transpose ? k.cols : k.rows;
-  const int or0 = blockIdx.y * 32, oc0 = blockIdx.x * 32;
+  const int or0 = blockIdx.y * 64, oc0 = blockIdx.x * 64;
   if (or0 >= orows || oc0 >= k.owidth) return;   // workgroup-uniform
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int t = threadIdx.x;
   const int ir0 = k.transpose ? oc0 : or0, ic0 = k.transpose ? or0 : oc0;
+  const bool in_vec = (k.ld_in & 3) == 0 && (reinterpret_cast<uintptr_t>(k.in) & (k.in_bf16 ? 7 : 15)) == 0;
+  const bool out_vec = (k.ldp & 7) == 0 && (k.owidth & 7) == 0 && (reinterpret_cast<uintptr_t>(k.hi) & 15) == 0 &&
+                       (!k.lo || (reinterpret_cast<uintptr_t>(k.lo) & 15) == 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = ir0 + ty + 8 * i, c = ic0 + tx;
-    bool ok = r < k.rows && c < k.cols;
+    const int rl = (t >> 4) + 16 * i, cl = 4 * (t & 15);
+    const int r = ir0 + rl, c = ic0 + cl;
+    bool ok = r < k.rows;
     if (ok && k.shift != 0) {
       const int tt = r % k.period + k.shift;
       ok = tt >= 0 && tt < k.period;
     }
-    float v = 0.f;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (ok) {
       const int64_t idx = (int64_t)(r + k.shift) * k.ld_in + c;
-      v = k.in_bf16 ? __builtin_bit_cast(float, (unsigned)reinterpret_cast<const bf16_t*>(k.in)[idx] << 16) : k.in[idx];
+      if (in_vec && c + 3 < k.cols) {
+        if (k.in_bf16) {
+          const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(k.in) + idx);
+          v[0] = __builtin_bit_cast(float, u.x << 16); v[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+          v[2] = __builtin_bit_cast(float, u.y << 16); v[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+        } else {
+          const float4 f = *reinterpret_cast<const float4*>(k.in + idx);
+          v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j < k.cols)
+            v[j] = k.in_bf16 ? __builtin_bit_cast(float, (unsigned)reinterpret_cast<const bf16_t*>(k.in)[idx + j] << 16)
+                             : k.in[idx + j];
+      }
     }
-    tile[ty + 8 * i][tx] = v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[rl][cl + j] = v[j];
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int orow = or0 + ty + 8 * i, ocol = oc0 + tx;
+  for (int i = 0; i < 2; ++i) {
+    const int orl = (t >> 3) + 32 * i, ocl = 8 * (t & 7);
+    const int orow = or0 + orl, ocol = oc0 + ocl;
     if (orow >= orows || ocol >= k.owidth) continue;
-    const float v = k.transpose ? tile[tx][ty + 8 * i] : tile[ty + 8 * i][tx];
-    const __bf16 h = (__bf16)v;
-    k.hi[(int64_t)orow * k.ldp + ocol] = __builtin_bit_cast(bf16_t, h);
-    if (k.lo) {
-      const __bf16 l = (__bf16)(v - (float)h);
-      k.lo[(int64_t)orow * k.ldp + ocol] = __builtin_bit_cast(bf16_t, l);
+    unsigned hw[4], lw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v0 = k.transpose ? tile[ocl + 2 * j][orl] : tile[orl][ocl + 2 * j];
+      const float v1 = k.transpose ? tile[ocl + 2 * j + 1][orl] : tile[orl][ocl + 2 * j + 1];
+      const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+      hw[j] = (unsigned)__builtin_bit_cast(bf16_t, h0) | ((unsigned)__builtin_bit_cast(bf16_t, h1) << 16);
+      const __bf16 l0 = (__bf16)(v0 - (float)h0), l1 = (__bf16)(v1 - (float)h1);
+      lw[j] = (unsigned)__builtin_bit_cast(bf16_t, l0) | ((unsigned)__builtin_bit_cast(bf16_t, l1) << 16);
+    }
+    const int64_t o = (int64_t)orow * k.ldp + ocol;
+    if (out_vec) {
+      *reinterpret_cast<uint4*>(k.hi + o) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+      if (k.lo) *reinterpret_cast<uint4*>(k.lo + o) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (ocol + j >= k.owidth) continue;
+        k.hi[o + j] = (bf16_t)(hw[j >> 1] >> (16 * (j & 1)));
+        if (k.lo) k.lo[o + j] = (bf16_t)(lw[j >> 1] >> (16 * (j & 1)));
+      }
     }
   }
 }
@@ -482,8 +523,8 @@ struct PackList {
     k.ld_in = ld_in; k.rows = rows; k.cols = cols; k.transpose = transpose; k.ldp = ldp; k.owidth = owidth;
     k.shift = shift; k.period = period; k.in_bf16 = in_bf16;
     const int orows = transpose ? cols : rows;
-    if ((owidth + 31) / 32 > gx) gx = (owidth + 31) / 32;
-    if ((orows + 31) / 32 > gy) gy = (orows + 31) / 32;
+    if ((owidth + 63) / 64 > gx) gx = (owidth + 63) / 64;
+    if ((orows + 63) / 64 > gy) gy = (orows + 63) / 64;
   }
   int launch(hipStream_t stream) {
     LR_LAUNCH(xpack_multi_kernel, dim3(gx, gy, n), dim3(256), 0, stream, a);
