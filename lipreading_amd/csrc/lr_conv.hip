@@ -18,6 +18,11 @@
 // slow axis of both operands; tiles are staged pixel-major in LDS and the MFMA fragments are read
 // down the columns (ds_read_u16).  K is split over workgroups into fp32 slabs that a second kernel
 // reduces in fixed order (deterministic) into the torch-layout gradient.
+//
+// This file: the generic implicit-GEMM kernels, layer 3's patch-resident kernel, the elementwise stages, weight
+// packing, the slab reduction and the C ABI's dispatch.  The kernels the metric's geometry actually runs have
+// translation units of their own: lr_conv1.hip (layer 1), lr_conv_patch.hip (layer 2 forward / data gradient),
+// lr_conv_wgrad.hip (weight gradient of layers 2 and 3); lr_conv_dev.h holds what they share.
 #include "lr_common.h"
 #include "lr_conv_dev.h"
 #include <hip/hip_ext.h>

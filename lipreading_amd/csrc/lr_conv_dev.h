@@ -1,4 +1,4 @@
-// Device-side helpers shared by the conv frontend's translation units (lr_conv.hip, lr_conv_patch.hip).
+// Device-side helpers shared by the conv frontend's translation units (lr_conv.hip, lr_conv1.hip, lr_conv_patch.hip).
 // Build-defined subsystem: the reference has no conv frontend (regime X).
 #pragma once
 #include "lr_common.h"

@@ -1,5 +1,5 @@
 // gfx950 HIP kernels of the build-defined conv frontend: the stride-1 layers' weight gradient, second form
-// (lr_conv.hip holds the first form, the slab reduction and the host dispatch; see the comment below).
+// (lr_conv.hip holds the slab reduction and the host dispatch).
 // No reference file: the reference has no conv frontend (regime X).
 #include "lr_common.h"
 #include <hip/hip_ext.h>
@@ -10,7 +10,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short bf16_t;  // storage type
 
-// Two ds_read_b64_tr_b16 (gfx950 LDS transpose read) -> one MFMA operand (see lr_conv.hip).
+// Two ds_read_b64_tr_b16 (gfx950 LDS transpose read) -> one MFMA operand (see lr_conv_dev.h).
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 lds_tr_pair(const unsigned char* lds, int a0, int a1) {
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;

@@ -12,7 +12,7 @@ LipNet-style (three spatio-temporal convolutions, each followed by ReLU and a (1
     features[b, t] = pooled3[b, t].reshape(6*6*96)   (h, w, c order; 3456 per frame at 96x96)
 
 Parameters are held as nn.Conv3d modules (state_dict keys conv{1,2,3}.{weight,bias}, torch layout
-and initialisation) but never called: the arithmetic is the HIP path of lr_conv.hip — bf16
+and initialisation) but never called: the arithmetic is the HIP path of lr_conv*.hip — bf16
 channels-last activations, implicit-GEMM convolution on v_mfma_f32_32x32x16_bf16 with fp32
 accumulation, fused bias+ReLU.  There is NO reference parity for this stage; the oracle is torch
 conv3d/max_pool3d on the CPU (oracle/torch_oracle.py conv_frontend).

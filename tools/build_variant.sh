@@ -1,12 +1,13 @@
 #!/bin/bash
-# Build a variant library for A/B timing: tools/build_variant.sh <tag> <path/to/lr_conv.hip>
+# Build a variant library for A/B timing: tools/build_variant.sh <tag> <path/to/variant of a csrc/*.hip> [name of the
+# translation unit it replaces, default: the variant's own file name]
 # -> lipreading_amd/_lib/alt/<tag>.so (the other objects come from the current in-tree build).
 set -e
-TAG=$1; SRC=$2
+TAG=$1; SRC=$2; UNIT=${3:-$(basename $SRC .hip)}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OBJ=/tmp/variant_$TAG.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -I$ROOT/lipreading_amd/csrc -c $SRC -o $OBJ
-OTHERS=$(ls $ROOT/lipreading_amd/_lib/obj/*.o | grep -v lr_conv.o)
+OTHERS=$(ls $ROOT/lipreading_amd/_lib/obj/*.o | grep -v "/$UNIT.o")
 mkdir -p $ROOT/lipreading_amd/_lib/alt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/lipreading_amd/_lib/alt/$TAG.so $OBJ $OTHERS
 echo built $ROOT/lipreading_amd/_lib/alt/$TAG.so
