@@ -120,6 +120,40 @@ def test_sgemm_epilogue_splitk_and_row_shift(dev):
 
 
 # ---- encoder forward against the reference vectors -------------------------------------------
+@pytest.mark.parametrize("R,K,C", [(2400, 512, 65), (37, 200, 29), (100, 520, 128), (16, 256, 1), (33, 64, 130)])
+def test_output_head_backward_against_torch(dev, R, K, C):
+  """lr_proj_logsoftmax_backward (C <= 128: the fused rows kernel + slab reduction of lr_proj.hip, two launches; wider
+  heads: the GEMM chain) against autograd of log_softmax(hidden W^T + b): ragged row blocks (R not a multiple of 16),
+  K that is not a multiple of the 256 columns a workgroup owns, C at and past the fused path's limit, a single class,
+  dhidden = NULL, and accumulate = 1 on top of existing dW / dbias."""
+  from lipreading_amd import _C
+  L = _C.lib()
+  st = _C.stream_handle()
+  g = torch.Generator().manual_seed(R + K + C)
+  hidden = torch.randn(R, K, generator=g, requires_grad=True)
+  W = (torch.randn(C, K, generator=g) / K ** 0.5).requires_grad_(True)
+  b = torch.randn(C, generator=g).requires_grad_(True)
+  gout = torch.randn(R, C, generator=g)
+  lp = torch.log_softmax(hidden @ W.t() + b, dim=1)
+  lp.backward(gout)
+  hd, Wd, lpd, gd = hidden.detach().to(dev), W.detach().to(dev), lp.detach().to(dev), gout.to(dev)
+  wsb = L.lr_proj_workspace_bytes(R, K, C)
+  ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+  for accumulate, want_dh in ((0, True), (1, False)):
+    dlogits = torch.empty(R, C, device=dev)
+    dh = torch.full((R, K), float("nan"), device=dev) if want_dh else None
+    dW = torch.full((C, K), 0.5 if accumulate else float("nan"), device=dev)
+    db = torch.full((C,), 0.25 if accumulate else float("nan"), device=dev)
+    _C.check(L.lr_proj_logsoftmax_backward(gd.data_ptr(), lpd.data_ptr(), hd.data_ptr(), Wd.data_ptr(), dlogits.data_ptr(),
+                                           dh.data_ptr() if want_dh else None, dW.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                           wsb, accumulate, R, K, C, st), "lr_proj_logsoftmax_backward")
+    scale = float(W.grad.abs().max())
+    assert float((dW.cpu() - 0.5 * accumulate - W.grad).abs().max()) <= 2e-5 * max(1.0, scale)
+    assert float((db.cpu() - 0.25 * accumulate - b.grad).abs().max()) <= 2e-5 * max(1.0, float(b.grad.abs().max()))
+    if want_dh:
+      assert float((dh.cpu() - hidden.grad).abs().max()) <= 2e-5 * max(1.0, float(hidden.grad.abs().max()))
+
+
 @pytest.mark.parametrize("name", ENC_CASES + ENC2_CASES)
 @pytest.mark.parametrize("tag", ["eq", "mix"])
 def test_encoder_matches_reference_vectors(golden_enc, golden_enc2, dev, name, tag):
