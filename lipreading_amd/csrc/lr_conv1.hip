@@ -348,7 +348,9 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
   // pixels = 256 contiguous bytes per read).  im2col column (tap, c): a lane's 8 bytes are the 4
   // channels of one tap at one pixel, so the 16 source lanes of a read cover 4 pixels x 4 taps.
   constexpr int ZLD = 32;
-  __shared__ __attribute__((aligned(16))) bf16_t Ps[C1_PATCH + 8];
+  // the patch, then a zone of zeros the padded columns read: wide enough for the largest immediate of a k step
+  constexpr int ZERO_ELEMS = (15 * 2 * C1_P * 8 + 64 + 8 + 15) / 16 * 8;
+  __shared__ __attribute__((aligned(16))) bf16_t Ps[C1_PATCH + ZERO_ELEMS];
   __shared__ __attribute__((aligned(16))) bf16_t Zs[C1_PIX * ZLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lk = lane >> 5;
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  if (tid < 8) Ps[C1_PATCH + tid] = 0;
+  for (int e = tid; e < ZERO_ELEMS; e += 256) Ps[C1_PATCH + e] = 0;
 
   uint2 rp[C1_NPU];
   unsigned rb[C1_NPU];
@@ -438,31 +440,27 @@ __global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __
     // byte offset of this lane's tap per column tile, and a mask that drops the pixel offset for the
     // padded columns (taps >= 75, and the third tile of waves 2 and 3, which run it on zeros rather
     // than branch: they would wait at the tile barrier anyway) so those read the zero zone
-    int tbase[3], tmask[3];
+    // A fragment address = lane base + an immediate: a k step is one tile row of 16 pixels (ks * 2 patch rows, ks *
+    // 1 KB of the dZ tile) and a lane's two 4-pixel groups are 4 pixels apart, so only the base depends on the lane
+    // (round 2 recomputed pixel and tap offsets per read: 212 vector instructions around the 48 MFMAs of a tile).
+    int pbase[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int tap = (wave + 4 * j) * 8 + 4 * colhalf + (sl & 3);
       const int o = (wave + 4 * j) < 10 ? c1_tap_off(tap, c.t) : -1;
-      tbase[j] = o >= 0 ? o * 2 : C1_PATCH * 2;
-      tmask[j] = o >= 0 ? -1 : 0;
+      pbase[j] = o >= 0 ? o * 2 + (lk * 8 + (sl >> 2)) * 16 : C1_PATCH * 2;
     }
     __syncthreads();
     if (q + 1 < q_end) issue(n);
     // 16 k steps (16 pixels each), fully unrolled; the transpose reads of step ks+1 fly during the
     // MFMAs of step ks (fragments double buffered by parity, interleave pinned below)
+    const int zbase = (lk * 8 + (sl >> 2)) * 64 + colhalf * 32 + (sl & 3) * 8;
     bf16x8 fa[2], fb[2][3];
     auto load_k = [&](int ks, bf16x8& a, bf16x8 (&b)[3]) {
-      // this lane's source pixel of the two 4-pixel groups: k = lk*8 + {0..3 | 4..7}
-      int za[2], pa[2];
+      // this lane's source pixels of the two 4-pixel groups: k = lk*8 + {0..3 | 4..7} of tile row ks
+      a = lds_tr_pair(ZsB, zbase + ks * 1024, zbase + ks * 1024 + 256);
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int pix = ks * 16 + lk * 8 + hh * 4 + (sl >> 2);
-        za[hh] = pix * 64 + colhalf * 32 + (sl & 3) * 8;
-        pa[hh] = ((2 * (pix >> 4)) * C1_P + 2 * (pix & 15)) * 8;
-      }
-      a = lds_tr_pair(ZsB, za[0], za[1]);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) b[j] = lds_tr_pair(PsB, (pa[0] & tmask[j]) + tbase[j], (pa[1] & tmask[j]) + tbase[j]);
+      for (int j = 0; j < 3; ++j) b[j] = lds_tr_pair(PsB, pbase[j] + ks * (2 * C1_P * 8), pbase[j] + ks * (2 * C1_P * 8) + 64);
     };
     constexpr int KS = C1_PIX / 16;
     load_k(0, fa[0], fb[0]);
