@@ -227,7 +227,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
     // (Measured and dropped, round 3: a K order in which the two lane halves of a step are a CONSTANT distance apart
     // — kw and kw + 2, kh and kh + 2 — so that a fragment address is a per-tile lane base plus an immediate: 95 vector
     // adds per tile fewer (of ~470) and one ds_read2_b64 per operand, bit-identical results, and 150-166 us instead of
-    // 134; likewise with the interleave written out behind scheduling fences and fragments read two steps ahead.)
+    // 134; likewise with the interleave written out behind scheduling fences and fragments read two steps ahead, and
+    // with the pins recounted for the merged reads: 144 us on a box where this form runs 134 — the LDS, not the
+    // vector ALU, is what the reordered reads load.)
     // 19 k steps of 16 (4 taps x 4 channels), fully unrolled: a step's taps are compile-time for
     // each half of the wave (lk), so a fragment address is one select + one add (no table lookup
     // in front of every read), and the fragments of step ks+1 are read during the MFMAs of step ks.
