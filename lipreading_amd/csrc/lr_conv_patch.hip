@@ -357,6 +357,8 @@ __device__ __forceinline__ void conv_patch_tile(unsigned char* __restrict__ patc
 // Blocks 0 .. nfull-1 run whole tiles; the blocks after them run the remaining tiles split by frame
 // (P2_TT / FT blocks per tile).  The host splits the tiles left over after the last FULL round of one workgroup per
 // CU when they are few (1800 tiles on 256 CUs: 7 rounds + 8 tiles, which used to cost an eighth round).
+// (256 PERSISTENT workgroups looping over their seven tiles instead of a workgroup per tile: the same within 1 %,
+// round 3 — the dispatcher's relaunch of a 150 KB-LDS workgroup is not what the rounds lose.)
 template <int CG, int NT, bool POOL>
 __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __restrict__ X,
                                                             const bf16_t* __restrict__ Wf,
