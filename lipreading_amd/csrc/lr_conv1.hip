@@ -29,6 +29,10 @@ constexpr int C1_FPIX = C1_P * C1_P;          // pixels of one patch frame (1225
 // window of one clip in order, so tile t only has to bring frame t+1 — frames t-1 and t are already
 // in LDS (FETCH_SIZE with a fresh 3-frame patch per tile: 3.4x the input; with the ring ~1.25x).
 // Frame ti of the clip lives in slot (ti + 1) % 3, i.e. temporal tap kt of tile t in slot (t + kt) % 3.
+// (Round 2's counters show two-way LDS bank conflicts in both kernels, 37 % / 44 % of their LDS cycles: an operand read
+// takes two output rows x 16 columns, i.e. every second pixel of input rows two apart, and both rows land on the same
+// half of the banks.  Shifting every second PAIR of patch rows by one pixel — 36-pixel rows — removes them and
+// changes neither kernel's time, round 3: they are not what the kernels wait for.)
 // tap = (kt*5 + kh)*5 + kw  ->  element offset inside the patch [3 slots][35][35][4]
 __device__ __forceinline__ int c1_tap_off(int tap, int t) {
   if (tap >= 75) return -1;
