@@ -192,11 +192,25 @@ __device__ __forceinline__ float strided_sum8(const float* __restrict__ p, int n
 
 // The whole backward head in TWO launches (C <= 128): the unfused chain — row kernel, two split-K GEMMs, their
 // combine pass, two column-sum stages — is six launches of 5-10 us each for 0.3 GFLOP, a tenth of the landmark
-// regime's step.  (1) A workgroup owns 16 rows: it forms their dlogits (kept in LDS in both orientations, written
-// out), multiplies them with W into its dhidden rows, and reduces its rows' outer products with `hidden` into a
-// private dW slab and a dbias row — plain fp32 FMAs, a thread per k column (256 columns per workgroup: the grid's
-// second dimension), dlogits broadcast out of LDS 16 bytes at a time.  (2) The slabs are summed in workgroup order (deterministic) into dW / dbias.
-constexpr int kPbRows = 16, kPbThreads = 256, kPbMaxC = 128;   // grid (row blocks, K / 256): a thread owns ONE k column
+// regime's step.  (1) A workgroup owns 16 rows x 64 k columns (the grid's second dimension): it forms the rows'
+// dlogits in LDS (written out by the first column block), multiplies them with W into its dhidden tile, and contracts
+// them with its `hidden` tile over the 16 rows into a private dW slab (+ a dbias row) — both on the exact-fp32
+// v_mfma_f32_16x16x4_f32, like the forward head: a wave owns one 16-column tile; dhidden = 17 k steps over the
+// classes (eight k steps' W loads in flight), the slab = 4 k steps over the rows per class tile.  The hidden tile is
+// loaded before the dlogits phase so that its latency runs under it.  (2) The slabs are summed in workgroup order
+// (deterministic) into dW / dbias.
+// Measured at R = 2400, K = 512, C = 65 (fused + reduce): scalar FMAs with dlogits broadcast out of LDS, 16 x 256
+// tiles: 22.7 + 7.1 us; MFMAs, 16 x 256: 19.4 + 7.5; 16 x 128: 17.7 + 7.4; 16 x 64 (this): 17.2 + 7.4; more rows per
+// workgroup write fewer slabs (150 slabs of C x K floats = 20 MB) but run longer serial chains on fewer workgroups:
+// 32 x 256: 24.2 + 5.1, 64 x 256: 38.2 + 4.6, 32 x 64: 20.4 + 5.1, 64 x 64: 27.7 + 4.6.  LR_PB_RT / LR_PB_CT: the
+// row tiles per workgroup / column tiles per wave of those variants.
+#ifndef LR_PB_RT
+#define LR_PB_RT 1
+#endif
+#ifndef LR_PB_CT
+#define LR_PB_CT 1
+#endif
+constexpr int kPbRT = LR_PB_RT, kPbRows = 16 * kPbRT, kPbCT = LR_PB_CT, kPbCols = 64 * kPbCT, kPbThreads = 256, kPbMaxC = 128, kPbLd = kPbMaxC + 4;
 __global__ __launch_bounds__(kPbThreads) void proj_bwd_fused_kernel(const float* __restrict__ g,
                                                                     const float* __restrict__ lp,
                                                                     const float* __restrict__ hidden,
@@ -204,12 +218,29 @@ __global__ __launch_bounds__(kPbThreads) void proj_bwd_fused_kernel(const float*
                                                                     float* __restrict__ dlogits,
                                                                     float* __restrict__ dhidden,
                                                                     float* __restrict__ slabs, int R, int K, int C) {
-  __shared__ __attribute__((aligned(16))) float dl_rc[kPbRows][kPbMaxC];   // [row][class]
-  __shared__ __attribute__((aligned(16))) float dl_cr[kPbMaxC][kPbRows];   // [class][row]
+  __shared__ __attribute__((aligned(16))) float dl[kPbRows][kPbLd];   // [row][class], zeros past C up to kPbMaxC (and past R)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * kPbRows;
-  const int Cp = (C + 7) & ~7;   // classes in LDS / slab rows: zeros past C
-  // dlogits[r,c] = g[r,c] - exp(lp[r,c]) * sum_c g[r,c]: a wave per row, two rows per wave
+  const int Cp = (C + 7) & ~7;        // slab rows
+  const int C16 = (C + 15) & ~15;     // classes in LDS: whole MFMA row tiles
+  const int nrow = min(kPbRows, R - row0);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int colb = blockIdx.y * kPbCols;     // first k column of the workgroup
+  // this wave's four column tiles: columns colb + 16 (wave + 4 q) + l15.  The hidden tile does not depend on dlogits:
+  // it is loaded FIRST, so that the loads' latency runs under the dlogits phase.
+  int col[kPbCT];
+#pragma unroll
+  for (int q = 0; q < kPbCT; ++q) col[q] = colb + 16 * (wave + 4 * q) + l15;
+  float hb[kPbCT][4 * kPbRT];   // [column tile][k step over the rows]
+#pragma unroll
+  for (int q = 0; q < kPbCT; ++q)
+#pragma unroll
+    for (int ks = 0; ks < 4 * kPbRT; ++ks) {
+      const int r = 4 * ks + l4;
+      hb[q][ks] = (r < nrow && col[q] < K) ? hidden[(int64_t)(row0 + r) * K + col[q]] : 0.f;
+    }
+  // dlogits[r,c] = g[r,c] - exp(lp[r,c]) * sum_c g[r,c]: a wave per row, 16 rows per wave (four at a time)
+#pragma unroll 4
   for (int rr = wave; rr < kPbRows; rr += kPbThreads / 64) {
     const int r = row0 + rr;
     float gv[kPbMaxC / 64], s = 0.f;
@@ -223,65 +254,70 @@ __global__ __launch_bounds__(kPbThreads) void proj_bwd_fused_kernel(const float*
 #pragma unroll
     for (int i = 0; i < kPbMaxC / 64; ++i) {
       const int c = lane + i * 64;
-      if (c >= Cp) continue;
       float d = 0.f;
       if (r < R && c < C) {
         d = gv[i] - expf(lp[(int64_t)r * C + c]) * s;
         if (blockIdx.y == 0) dlogits[(int64_t)r * C + c] = d;
       }
-      dl_rc[rr][c] = d;
-      dl_cr[c][rr] = d;
+      dl[rr][c] = d;
     }
   }
   __syncthreads();
-  const int nrow = min(kPbRows, R - row0);
   float* slab = slabs + (int64_t)blockIdx.x * ((int64_t)Cp * K + Cp);
-  const int k = blockIdx.y * kPbThreads + tid;
-  if (k < K) {
-    if (dhidden) {   // dhidden[r,k] = sum_c dlogits[r,c] W[c,k]
-      float acc[kPbRows];
+  if (dhidden) {   // dhidden[r,k] = sum_c dlogits[r,c] W[c,k]: A = dl (row 16 rt + l15, class c0 + l4), B = W (class c0 + l4, column)
+    f32x4 acc[kPbRT][kPbCT];
 #pragma unroll
-      for (int r = 0; r < kPbRows; ++r) acc[r] = 0.f;
-      // eight W loads in flight (one dependent load per class was 500 cycles of latency per class: 25 us)
-      for (int c0 = 0; c0 < C; c0 += 8) {
-        float w[8];
+    for (int rt = 0; rt < kPbRT; ++rt)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = c0 + j < C ? W[(int64_t)(c0 + j) * K + k] : 0.f;
+      for (int q = 0; q < kPbCT; ++q) acc[rt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8 / kPbCT;   // k steps whose loads are in flight together (8 loads a lane)
+    for (int c0 = 0; c0 < C; c0 += 4 * U) {
+      float bw[U][kPbCT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + 4 * u + l4;
 #pragma unroll
-          for (int q = 0; q < kPbRows / 4; ++q) {
-            const float4 d = *reinterpret_cast<const float4*>(&dl_cr[c0 + j][4 * q]);
-            acc[4 * q] += d.x * w[j]; acc[4 * q + 1] += d.y * w[j]; acc[4 * q + 2] += d.z * w[j]; acc[4 * q + 3] += d.w * w[j];
-          }
+        for (int q = 0; q < kPbCT; ++q) bw[u][q] = (c < C && col[q] < K) ? W[(int64_t)c * K + col[q]] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int rt = 0; rt < kPbRT; ++rt) {
+          const float a = dl[16 * rt + l15][c0 + 4 * u + l4];
+#pragma unroll
+          for (int q = 0; q < kPbCT; ++q) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[u][q], acc[rt][q], 0, 0, 0);
         }
-      }
-#pragma unroll
-      for (int r = 0; r < kPbRows; ++r)
-        if (r < nrow) dhidden[(int64_t)(row0 + r) * K + k] = acc[r];
     }
-    // slab[c,k] = sum_r dlogits[r,c] hidden[r,k], eight classes at a time (the slab has C rounded up to 8 rows, so
-    // that no store needs a predicate)
-    float h[kPbRows];
 #pragma unroll
-    for (int r = 0; r < kPbRows; ++r) h[r] = r < nrow ? hidden[(int64_t)(row0 + r) * K + k] : 0.f;
-#pragma unroll 1
-    for (int c0 = 0; c0 < C; c0 += 8) {
-      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < kPbRT; ++rt)
 #pragma unroll
-      for (int r = 0; r < kPbRows; ++r) {
-        const float4 d0 = *reinterpret_cast<const float4*>(&dl_rc[r][c0]);
-        const float4 d1 = *reinterpret_cast<const float4*>(&dl_rc[r][c0 + 4]);
-        acc[0] += d0.x * h[r]; acc[1] += d0.y * h[r]; acc[2] += d0.z * h[r]; acc[3] += d0.w * h[r];
-        acc[4] += d1.x * h[r]; acc[5] += d1.y * h[r]; acc[6] += d1.z * h[r]; acc[7] += d1.w * h[r];
+      for (int q = 0; q < kPbCT; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // D: column l15, rows 16 rt + 4 l4 + i
+          const int r = 16 * rt + 4 * l4 + i;
+          if (r < nrow && col[q] < K) dhidden[(int64_t)(row0 + r) * K + col[q]] = acc[rt][q][i];
+        }
+  }
+  // slab[c,k] = sum_r dlogits[r,c] hidden[r,k]: A = dl^T (class mt*16 + l15, row 4 ks + l4), B = hidden (row 4 ks + l4, column)
+  for (int mt = 0; mt < C16 / 16; ++mt) {
+    float af[4 * kPbRT];
+#pragma unroll
+    for (int ks = 0; ks < 4 * kPbRT; ++ks) af[ks] = dl[4 * ks + l4][mt * 16 + l15];
+#pragma unroll
+    for (int q = 0; q < kPbCT; ++q) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4 * kPbRT; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks], hb[q][ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {   // D: column l15, classes mt*16 + 4 l4 + i
+        const int c = mt * 16 + 4 * l4 + i;
+        if (c < Cp && col[q] < K) slab[(int64_t)c * K + col[q]] = acc[i];
       }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) slab[(int64_t)(c0 + j) * K + k] = acc[j];
     }
   }
-  if (blockIdx.y == 0 && tid < C) {   // the rows' column sums (dbias)
+  if (blockIdx.y == 0 && tid < Cp) {   // the rows' column sums (dbias)
     float sacc = 0.f;
-    for (int r = 0; r < kPbRows; ++r) sacc += dl_rc[r][tid];
+    for (int r = 0; r < kPbRows; ++r) sacc += dl[r][tid];
     slab[(int64_t)Cp * K + tid] = sacc;
   }
 }
@@ -369,7 +405,7 @@ extern "C" int lr_proj_logsoftmax_backward(const float* g, const float* log_prob
   if (C <= kPbMaxC) {
     const int nblk = (R + kPbRows - 1) / kPbRows;
     float* slabs = (float*)gws;
-    LR_LAUNCH(proj_bwd_fused_kernel, dim3(nblk, (K + kPbThreads - 1) / kPbThreads), dim3(kPbThreads), 0, stream, g, log_probs, hidden, W, dlogits, dhidden,
+    LR_LAUNCH(proj_bwd_fused_kernel, dim3(nblk, (K + kPbCols - 1) / kPbCols), dim3(kPbThreads), 0, stream, g, log_probs, hidden, W, dlogits, dhidden,
               slabs, R, K, C);
     int st0 = lr_launch_status();
     if (st0 != LR_OK) return st0;
