@@ -19,8 +19,6 @@ namespace {
 constexpr int C1_T = 16;                       // output tile edge
 constexpr int C1_P = 2 * C1_T + 3;             // patch edge (stride 2, 5x5 taps): 35
 constexpr int C1_PIX = C1_T * C1_T;            // 256 output pixels = 8 MFMA row tiles
-constexpr int C1_K = 304;                      // 75 taps x 4 channels = 300, padded to 19 k steps of 16
-constexpr int C1_WLD = C1_K + 8;               // weight row in LDS (624 B: conflict-free b128 reads)
 constexpr int C1_PATCH = 3 * C1_P * C1_P * 4;  // bf16 elements of the patch
 
 constexpr int C1_FPIX = C1_P * C1_P;          // pixels of one patch frame (1225)
@@ -175,110 +173,241 @@ __device__ __forceinline__ C1Tile c1_next(const C1Tile& c, int T, int tiles_x, i
   return n;
 }
 
-// Persistent workgroups: the 32 x 300 weights are staged once, then tiles are streamed.
+// ---------------------------------------------------------------------------------------------
+// forward: a patch of THREE channels per pixel
+// ---------------------------------------------------------------------------------------------
+// The fourth channel is padding (always zero: the raw clip has three planes, lr_clip_to_ndhwc_bf16 writes a zero,
+// lr_conv3d_pack_weights zero weights), and with it in the patch a quarter of the forward's MFMAs and LDS reads are
+// spent on zeros — in a kernel that is bound by what it reads out of LDS (19 k steps x (1 KB of weights + 2 KB of
+// pixels) per wave and tile = 228 KB per tile and workgroup, 1.8 k cycles of the LDS against 1.2 k of the MFMAs).
+// The forward therefore keeps its own patch with 6 bytes per pixel: the 5 taps x 3 channels of one (kt, kh) row of
+// the filter are 15 CONTIGUOUS bf16 behind pixel (2y + kh, 2x), one k step of 16 with one zero weight — 15 k steps
+// instead of 19 (30 MFMAs per wave and tile instead of 38, 180 KB out of LDS instead of 228), and a fragment address
+// is a per-kernel lane base + the tile's slot offset + an immediate (round 2 / 3: a select and an add per read).
+// Rows are 36 pixels (216 bytes): the 36th is only ever multiplied by the zero weight.  Pixels go in as PAIRS (the
+// patch's x origin is even): one 16-bit load per plane and pair from the raw clip, three dwords per pair into LDS.
+// (The weight gradient contracts over pixels with LDS transpose reads of 8-byte units and keeps the 4-channel patch.)
+#ifndef LR_C1_FWD_WGS
+#define LR_C1_FWD_WGS 1024
+#endif
+constexpr int F1_RW = C1_P + 1;                  // pixels per patch row
+constexpr int F1_RB = F1_RW * 6;                 // bytes per patch row (216)
+constexpr int F1_SLOT = C1_P * F1_RB;            // bytes per ring slot (one frame): 7560
+constexpr int F1_PATCH = 3 * F1_SLOT;            // 22,680 bytes
+constexpr int F1_PPR = F1_RW / 2;                // pixel pairs per row (18)
+constexpr int F1_PAIRS = C1_P * F1_PPR;          // pixel pairs per frame (630)
+constexpr int F1_NPU = (F1_PAIRS + 255) / 256;   // pairs per thread (3)
+constexpr int F1_KS = 15;                        // k steps: (kt, kh) rows of the filter
+constexpr int F1_WLD = F1_KS * 16 + 8;           // weight row in LDS (496 B: conflict-free b128 reads)
+
+struct F1Pix { int py[F1_NPU], px[F1_NPU]; };    // row and (even) column of the thread's pairs inside the patch frame
+__device__ __forceinline__ F1Pix f1_pix(int tid) {
+  F1Pix r;
+#pragma unroll
+  for (int i = 0; i < F1_NPU; ++i) {
+    // past the frame's last pair a thread repeats its own previous pair (same load, same LDS write): a branch around
+    // the LDS write would leave the pair's loads "pending" on the path that skips it, and hipcc then waits for ALL
+    // outstanding memory operations (vmcnt) at the next instruction that redefines one of those registers — here in
+    // front of the next tile's loads (the previous tile's stores) and in front of the MFMA loop (the loads just issued)
+    const int e0 = tid + i * 256, e = e0 < F1_PAIRS ? e0 : e0 - 256;
+    r.py[i] = e / F1_PPR;
+    r.px[i] = 2 * (e % F1_PPR);
+  }
+  return r;
+}
+// One frame of the patch in flight: raw words per pair (U8: the pair's two bytes of each plane; else the two 4-channel
+// bf16 pixels) and two validity bits per pair in `ok` (bit 2i: left pixel, bit 2i + 1: right pixel).  Branch-free as in
+// c1_frame_issue: a pixel outside the frame / the clip loads pixel (0, 0) and is written as zeros.
+// EVENW: Win is even, so a pair (its left column is even) is inside or outside the frame as a whole and is ONE aligned
+// load per plane (U8) or ONE 16-byte load; odd widths load the two pixels on their own.
+template <bool U8> struct F1Stage { unsigned w[F1_NPU][U8 ? 3 : 4]; unsigned ok; };
+template <bool U8, bool EVENW>
+__device__ __forceinline__ void f1_frame_issue(const bf16_t* __restrict__ X, const F1Pix& pm, F1Stage<U8>& s, int f, int t,
+                                               int T, int Hin, int Win, int y0, int x0, int kt) {
+  const int ti = t + kt - 1;
+  const bool frame_ok = ti >= 0 && ti < T;
+  const int64_t fr = frame_ok ? f + kt - 1 : f;
+  const int yb = 2 * y0 - 2, xb = 2 * x0 - 2;
+  const int64_t plane = (int64_t)Hin * Win;
+  const unsigned char* p0 = reinterpret_cast<const unsigned char*>(X) + fr * 3 * plane;
+  const unsigned char *p1 = p0 + plane, *p2 = p1 + plane;
+  const bf16_t* pf = X + fr * plane * 4;
+  s.ok = 0u;
+#pragma unroll
+  for (int i = 0; i < F1_NPU; ++i) {
+    const int yi = pm.py[i] + yb, xi = pm.px[i] + xb;
+    const bool row_ok = frame_ok && (unsigned)yi < (unsigned)Hin;
+    const bool ok0 = row_ok && (unsigned)xi < (unsigned)Win;
+    const bool ok1 = EVENW ? ok0 : (row_ok && (unsigned)(xi + 1) < (unsigned)Win);
+    const int off0 = ok0 ? yi * Win + xi : 0;
+    s.ok |= (ok0 ? 1u : 0u) << (2 * i) | (ok1 ? 2u : 0u) << (2 * i);
+    if (EVENW) {
+      if (U8) {
+        s.w[i][0] = *reinterpret_cast<const unsigned short*>(p0 + off0);
+        s.w[i][1] = *reinterpret_cast<const unsigned short*>(p1 + off0);
+        s.w[i][2] = *reinterpret_cast<const unsigned short*>(p2 + off0);
+      } else {
+        const uint4 v = *reinterpret_cast<const uint4*>(pf + (int64_t)off0 * 4);
+        s.w[i][0] = v.x, s.w[i][1] = v.y, s.w[i][2] = v.z, s.w[i][3] = v.w;
+      }
+    } else {
+      const int off1 = ok1 ? yi * Win + xi + 1 : 0;
+      if (U8) {
+        s.w[i][0] = (unsigned)p0[off0] | ((unsigned)p0[off1] << 8);
+        s.w[i][1] = (unsigned)p1[off0] | ((unsigned)p1[off1] << 8);
+        s.w[i][2] = (unsigned)p2[off0] | ((unsigned)p2[off1] << 8);
+      } else {
+        const uint2 a = *reinterpret_cast<const uint2*>(pf + (int64_t)off0 * 4);
+        const uint2 b = *reinterpret_cast<const uint2*>(pf + (int64_t)off1 * 4);
+        s.w[i][0] = a.x, s.w[i][1] = a.y, s.w[i][2] = b.x, s.w[i][3] = b.y;
+      }
+    }
+  }
+}
+// bf16 of a byte of the clip, exactly as lr_clip_to_ndhwc_bf16 makes it
+__device__ __forceinline__ unsigned f1_u8_bf(unsigned byte) { return (unsigned)f2bf((float)byte * (1.f / 255.f)); }
+template <bool U8>
+__device__ __forceinline__ void f1_frame_store(unsigned char* PsB, const F1Pix& pm, const F1Stage<U8>& s, int tid, int t,
+                                               int kt) {
+  unsigned char* slot = PsB + ((t + kt) % 3) * F1_SLOT;
+#pragma unroll
+  for (int i = 0; i < F1_NPU; ++i) {
+    unsigned d0, d1, d2;   // {c0 c1} {c2 | c0'} {c1' c2'} of the pair's left and right (') pixel
+    if (U8) {
+      const unsigned a = s.w[i][0], b = s.w[i][1], c = s.w[i][2];
+      d0 = f1_u8_bf(a & 0xffu) | (f1_u8_bf(b & 0xffu) << 16);
+      d1 = f1_u8_bf(c & 0xffu) | (f1_u8_bf((a >> 8) & 0xffu) << 16);
+      d2 = f1_u8_bf((b >> 8) & 0xffu) | (f1_u8_bf((c >> 8) & 0xffu) << 16);
+    } else {
+      d0 = s.w[i][0];
+      d1 = (s.w[i][1] & 0xffffu) | (s.w[i][2] << 16);
+      d2 = (s.w[i][2] >> 16) | (s.w[i][3] << 16);
+    }
+    const bool ok0 = (s.ok >> (2 * i)) & 1u, ok1 = (s.ok >> (2 * i + 1)) & 1u;
+    d0 = ok0 ? d0 : 0u;
+    d1 = (ok0 ? d1 & 0xffffu : 0u) | (ok1 ? d1 & 0xffff0000u : 0u);
+    d2 = ok1 ? d2 : 0u;
+    unsigned* dst = reinterpret_cast<unsigned*>(slot + pm.py[i] * F1_RB + pm.px[i] * 6);
+    dst[0] = d0;
+    dst[1] = d1;
+    dst[2] = d2;
+  }
+}
+// first tile of a walk: frames t-1 and t are fetched synchronously (once per ~28 tiles)
+template <bool U8, bool EVENW>
+__device__ __forceinline__ void f1_walk_start(const bf16_t* __restrict__ X, const F1Pix& pm, unsigned char* PsB, int f,
+                                              int t, int T, int Hin, int Win, int y0, int x0, int tid) {
+#pragma unroll 1
+  for (int kt = 0; kt < 2; ++kt) {
+    F1Stage<U8> s;
+    f1_frame_issue<U8, EVENW>(X, pm, s, f, t, T, Hin, Win, y0, x0, kt);
+    f1_frame_store<U8>(PsB, pm, s, tid, t, kt);
+  }
+}
+
+// Persistent workgroups: the 32 x 225 weights are staged once, then tiles are streamed.
 // POOL: the epilogue applies ReLU -> MaxPool((1,2,2)) in registers (a lane holds all four pixels of
 // its windows) and writes the pooled activation + the 2-bit position of the window's first maximum
 // (row-major scan, torch's rule) instead of the full-resolution activation.
-template <bool POOL, bool U8>
+template <bool POOL, bool U8, bool EVENW>
 __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __restrict__ X,
-                                                              const bf16_t* __restrict__ Wp,  // [32][300]
+                                                              const bf16_t* __restrict__ Wp,  // [32][75 taps][4]
                                                               const float* __restrict__ bias,
                                                               bf16_t* __restrict__ Y, unsigned char* __restrict__ code,
                                                               int frames, int T,
                                                               int Hin, int Win, int Ho, int Wo, int relu) {
-  __shared__ __attribute__((aligned(16))) bf16_t Ps[C1_PATCH + 8];
-  __shared__ __attribute__((aligned(16))) bf16_t Ws[32 * C1_WLD];
+  __shared__ __attribute__((aligned(16))) unsigned char PsB[F1_PATCH + 8];
+  __shared__ __attribute__((aligned(16))) bf16_t Ws[32 * F1_WLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lk = lane >> 5;
   const int tiles_x = (Wo + C1_T - 1) / C1_T, tiles_y = (Ho + C1_T - 1) / C1_T;
   const int64_t ntiles = (int64_t)frames * tiles_x * tiles_y;
-  // weights: row n = 300 bf16 = 75 x 8 bytes; pad columns 300..311 with zeros
-  for (int e = tid; e < 32 * (C1_WLD / 4); e += 256) {
-    const int n = e / (C1_WLD / 4), u = e - n * (C1_WLD / 4);
-    uint2 v = make_uint2(0u, 0u);
-    if (u < 75) v = *reinterpret_cast<const uint2*>(Wp + n * 300 + u * 4);
-    *reinterpret_cast<uint2*>(&Ws[n * C1_WLD + u * 4]) = v;
+  // weights: row n, k step s = kt*5 + kh, element j = kw*3 + c (j = 15 and the row's tail: zeros)
+  for (int e = tid; e < 32 * F1_WLD; e += 256) {
+    const int n = e / F1_WLD, u = e - n * F1_WLD;
+    const int st = u >> 4, j = u & 15;
+    Ws[e] = (st < F1_KS && j < 15) ? Wp[n * 300 + (st * 5 + j / 3) * 4 + j % 3] : (bf16_t)0;
   }
-  if (tid < 8) Ps[C1_PATCH + tid] = 0;   // landing zone for the padded taps (k >= 300)
 
-  // wave w: row tiles 2w, 2w+1; row tile m covers pixels (y = 2m + (lr>>4), x = lr & 15)
-  int pixoff[2];
+  // wave w: row tiles 2w, 2w+1; row tile m covers pixels (y = 2m + (lr>>4), x = lr & 15); a lane's fragment of a
+  // (kt, kh) step = 16 bytes at its pixel's (2y + kh, 2x) + 16 lk
+  int pixbase[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int yl = 2 * (2 * wave + i) + (lr >> 4), xl = lr & 15;
-    pixoff[i] = ((2 * yl) * C1_P + 2 * xl) * 4;
+    pixbase[i] = (2 * yl) * F1_RB + (2 * xl) * 6 + lk * 16;
   }
   const float bv = bias ? bias[lr] : 0.f;
-  const C1Pix pm = c1_pix(tid);
+  const F1Pix pm = f1_pix(tid);
   const bool exact = Ho % C1_T == 0 && Wo % C1_T == 0;   // no tile hangs over the output's edge
-  uint2 rp[C1_NPU];             // frame t+1 of the tile about to be computed
-  unsigned rb[C1_NPU];
+  F1Stage<U8> stg;              // the new frame (temporal tap 2) of the NEXT tile, in flight during a tile's MFMAs
   const int64_t q_end = ntiles * (blockIdx.x + 1) / gridDim.x;
   const int64_t q_begin = ntiles * blockIdx.x / gridDim.x;
-  int64_t q = q_begin;
-  C1Tile c = c1_tile(q < q_end ? q : 0, T, tiles_x, tiles_y);
-  if (q < q_end) c1_frame_issue<U8>(X, pm, rp, rb, c.f, c.t, T, Hin, Win, c.y0, c.x0, 2);
-  for (; q < q_end; ++q) {
+  if (q_begin >= q_end) return;
+  C1Tile c = c1_tile(q_begin, T, tiles_x, tiles_y);
+  // the first tile's patch, synchronously
+  f1_walk_start<U8, EVENW>(X, pm, PsB, c.f, c.t, T, Hin, Win, c.y0, c.x0, tid);
+  f1_frame_issue<U8, EVENW>(X, pm, stg, c.f, c.t, T, Hin, Win, c.y0, c.x0, 2);
+  f1_frame_store<U8>(PsB, pm, stg, tid, c.t, 2);
+  __syncthreads();
+  // A tile: issue the next tile's frame -> MFMAs -> barrier -> that frame into the ring slot the MFMAs no longer read
+  // -> barrier -> epilogue.  The frame's loads are consumed BEFORE this tile's output stores are issued: vmcnt counts
+  // loads and stores in one queue, and with the stores in front of the wait (round 2 / 3 had the LDS write at the top
+  // of the next tile) every tile waited for its predecessor's stores to be acknowledged.
+  for (int64_t q = q_begin; q < q_end; ++q) {
     const int f = c.f, y0 = c.y0, x0 = c.x0;
     const C1Tile n = c1_next(c, T, tiles_x, tiles_y);
-    __syncthreads();            // previous tile's fragments are no longer being read
-    if (q == q_begin || c.t == 0) c1_walk_start<U8>(X, pm, Ps, f, c.t, T, Hin, Win, y0, x0, tid);
-    c1_frame_store<U8>(Ps, rp, rb, tid, c.t, 2);
-    __syncthreads();
-    // next tile's new frame flies while this tile's MFMAs run
-    if (q + 1 < q_end) c1_frame_issue<U8>(X, pm, rp, rb, n.f, n.t, T, Hin, Win, n.y0, n.x0, 2);
+    const bool more = q + 1 < q_end;
+    if (more) f1_frame_issue<U8, EVENW>(X, pm, stg, n.f, n.t, T, Hin, Win, n.y0, n.x0, 2);
     f32x16 acc[2];
-    // (Measured and dropped, round 3: a K order in which the two lane halves of a step are a CONSTANT distance apart
-    // — kw and kw + 2, kh and kh + 2 — so that a fragment address is a per-tile lane base plus an immediate: 95 vector
-    // adds per tile fewer (of ~470) and one ds_read2_b64 per operand, bit-identical results, and 150-166 us instead of
-    // 134; likewise with the interleave written out behind scheduling fences and fragments read two steps ahead, and
-    // with the pins recounted for the merged reads: 144 us on a box where this form runs 134 — the LDS, not the
-    // vector ALU, is what the reordered reads load.)
-    // 19 k steps of 16 (4 taps x 4 channels), fully unrolled: a step's taps are compile-time for
-    // each half of the wave (lk), so a fragment address is one select + one add (no table lookup
-    // in front of every read), and the fragments of step ks+1 are read during the MFMAs of step ks.
-    const int so0 = ((c.t + 0) % 3) * C1_FPIX * 4, so1 = ((c.t + 1) % 3) * C1_FPIX * 4,
-              so2 = ((c.t + 2) % 3) * C1_FPIX * 4;   // ring slot of temporal tap kt (elements)
-    auto tap_elem = [&](int tap) {   // compile-time tap -> element offset in the patch (uniform)
-      const int kw = tap % 5, kh = (tap / 5) % 5, kt = tap / 25;
-      return (kt == 0 ? so0 : kt == 1 ? so1 : so2) + (kh * C1_P + kw) * 4;
-    };
-    uint2 alo[2][2], ahi[2][2];
+    // (Measured and dropped with the 4-channel patch, round 3: a K order in which the two lane halves of a step are a
+    // CONSTANT distance apart so that a fragment address is a lane base plus an immediate — bit-identical results and
+    // 150-166 us instead of 134; with the interleave written out behind scheduling fences: 144.  The 3-channel patch
+    // gets the immediates for free: a step is one contiguous row.)
+    // 15 k steps of 16 (one (kt, kh) row: 5 taps x 3 channels + a zero), fully unrolled; the fragments of step
+    // ks+1 are read during the MFMAs of step ks.
+    int abase[3][2];   // ring slot of temporal tap kt + the lane's pixel
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) abase[kt][i] = pixbase[i] + ((c.t + kt) % 3) * F1_SLOT;
+    uint4 af[2][2];
     bf16x8 bw[2];
-    auto load_k = [&](int ks, uint2 (&lo)[2], uint2 (&hi)[2], bf16x8& b) {
-      // lk = 0: taps 4ks, 4ks+1;  lk = 1: taps 4ks+2, 4ks+3 (tap 75 = zero padding)
-      const int e0 = lk ? tap_elem(4 * ks + 2) : tap_elem(4 * ks);
-      const bool pad1 = 4 * ks + 3 >= 75;
-      const int e1 = lk ? (pad1 ? 0 : tap_elem(pad1 ? 0 : 4 * ks + 3)) : tap_elem(4 * ks + 1);
-      b = *reinterpret_cast<const bf16x8*>(&Ws[lr * C1_WLD + ks * 16 + lk * 8]);
+    auto load_k = [&](int ks, uint4 (&a)[2], bf16x8& b) {
+      const int kt = ks / 5, kh = ks % 5;
+      b = *reinterpret_cast<const bf16x8*>(&Ws[lr * F1_WLD + ks * 16 + lk * 8]);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        lo[i] = *reinterpret_cast<const uint2*>(&Ps[pixoff[i] + e0]);
-        hi[i] = *reinterpret_cast<const uint2*>(&Ps[(pad1 && lk) ? C1_PATCH : pixoff[i] + e1]);
+        const unsigned* p = reinterpret_cast<const unsigned*>(PsB + abase[kt][i] + kh * F1_RB);
+        a[i] = make_uint4(p[0], p[1], p[2], p[3]);
       }
     };
-    constexpr int KS = C1_K / 16;
-    load_k(0, alo[0], ahi[0], bw[0]);
+    load_k(0, af[0], bw[0]);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) load_k(ks + 1, alo[(ks + 1) & 1], ahi[(ks + 1) & 1], bw[(ks + 1) & 1]);
+    for (int ks = 0; ks < F1_KS; ++ks) {
+      if (ks + 1 < F1_KS) load_k(ks + 1, af[(ks + 1) & 1], bw[(ks + 1) & 1]);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const uint4 av = make_uint4(alo[ks & 1][i].x, alo[ks & 1][i].y, ahi[ks & 1][i].x, ahi[ks & 1][i].y);
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bw[ks & 1], ks == 0 ? zero : acc[i],
-                                                         0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ks & 1][i]), bw[ks & 1],
+                                                         ks == 0 ? zero : acc[i], 0, 0, 0);
       }
     }
     __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
 #pragma unroll
-    for (int ks = 0; ks + 1 < KS; ++ks) {
+    for (int ks = 0; ks + 1 < F1_KS; ++ks) {
       __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    __syncthreads();            // this tile's fragments are no longer being read
+    if (more) {
+      if (n.t == 0) f1_walk_start<U8, EVENW>(X, pm, PsB, n.f, n.t, T, Hin, Win, n.y0, n.x0, tid);   // a new walk: whole patch
+      f1_frame_store<U8>(PsB, pm, stg, tid, n.t, 2);
+    }
+    __syncthreads();
     if (POOL) {
       // row tile = 2 output rows x 16 columns: registers r and r + 8 are vertical neighbours,
       // r and r + 1 (r even) horizontal ones
@@ -524,20 +653,26 @@ int lr_conv1_forward(bool pool, bool u8, const void* X, const void* Wp, const fl
   const bf16_t* w = (const bf16_t*)Wp;
   bf16_t* y = (bf16_t*)Y;
   int tiles = frames * ((Ho + C1_T - 1) / C1_T) * ((Wo + C1_T - 1) / C1_T);
-  if (tiles > 768) tiles = 768;   // persistent: 3 workgroups per CU, each streams its share of tiles
+  if (tiles > LR_C1_FWD_WGS) tiles = LR_C1_FWD_WGS;   // persistent: 4 workgroups per CU, each streams its share of tiles
   lr_clear_error();
+#define LR_C1B(POOLV, U8V, EV)                                                                                    \
+  do {                                                                                                           \
+    if (sample) hipExtLaunchKernelGGL((conv1_fwd_patch_kernel<POOLV, U8V, EV>), dim3(tiles), dim3(256), 0, stream, \
+                                      e0, e1, 0, x, w, bias, y, code, frames, T, Hin, Win, Ho, Wo, relu);         \
+    else hipLaunchKernelGGL((conv1_fwd_patch_kernel<POOLV, U8V, EV>), dim3(tiles), dim3(256), 0, stream, x, w,    \
+                            bias, y, code, frames, T, Hin, Win, Ho, Wo, relu);                                   \
+  } while (0)
 #define LR_C1(POOLV, U8V)                                                                                         \
   do {                                                                                                           \
-    if (sample) hipExtLaunchKernelGGL((conv1_fwd_patch_kernel<POOLV, U8V>), dim3(tiles), dim3(256), 0, stream, e0, \
-                                      e1, 0, x, w, bias, y, code, frames, T, Hin, Win, Ho, Wo, relu);             \
-    else hipLaunchKernelGGL((conv1_fwd_patch_kernel<POOLV, U8V>), dim3(tiles), dim3(256), 0, stream, x, w, bias,  \
-                            y, code, frames, T, Hin, Win, Ho, Wo, relu);                                         \
+    if (Win % 2 == 0) LR_C1B(POOLV, U8V, true);                                                                  \
+    else LR_C1B(POOLV, U8V, false);                                                                              \
   } while (0)
   if (pool && u8) LR_C1(true, true);
   else if (pool) LR_C1(true, false);
   else if (u8) LR_C1(false, true);
   else LR_C1(false, false);
 #undef LR_C1
+#undef LR_C1B
   return lr_launch_status();
 }
 
