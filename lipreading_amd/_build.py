@@ -24,6 +24,14 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "lipreading_hip.h")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                "-Wall", "-Wno-unused-function"]
+# per translation unit (tools/build_variant.sh repeats them).  lr_conv1: MFMA results in VGPRs — the first layer's
+# kernels have registers to spare and are bound by their vector instructions; the accumulators' way through AGPRs
+# costs the forward 32 v_accvgpr_read per tile.
+UNIT_FLAGS = {"lr_conv1": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
+def _flags(src):
+  return HIPCC_FLAGS + UNIT_FLAGS.get(os.path.splitext(os.path.basename(src))[0], [])
 
 
 def _hipcc():
@@ -52,7 +60,7 @@ def _digest(paths, extra=""):
 
 
 def _fingerprint():
-  return _digest(sources() + _shared_inputs(), " ".join(HIPCC_FLAGS))
+  return _digest(sources() + _shared_inputs(), " ".join(HIPCC_FLAGS) + repr(sorted(UNIT_FLAGS.items())))
 
 
 def is_current():
@@ -67,12 +75,12 @@ def _compile_one(src, verbose):
   name = os.path.splitext(os.path.basename(src))[0]
   obj = os.path.join(OBJ_DIR, name + ".o")
   stamp = obj + ".stamp"
-  want = _digest([src] + _shared_inputs(), " ".join(HIPCC_FLAGS))
+  want = _digest([src] + _shared_inputs(), " ".join(_flags(src)))
   if os.path.exists(obj) and os.path.exists(stamp):
     with open(stamp) as f:
       if f.read().strip() == want:
         return obj
-  cmd = [_hipcc()] + HIPCC_FLAGS + ["-c", src, "-o", obj]
+  cmd = [_hipcc()] + _flags(src) + ["-c", src, "-o", obj]
   if verbose:
     print(" ".join(cmd), flush=True)
   res = subprocess.run(cmd, capture_output=True, text=True)

@@ -184,24 +184,31 @@ __device__ __forceinline__ C1Tile c1_next(const C1Tile& c, int T, int tiles_x, i
 // the filter are 15 CONTIGUOUS bf16 behind pixel (2y + kh, 2x), one k step of 16 with one zero weight — 15 k steps
 // instead of 19 (30 MFMAs per wave and tile instead of 38, 180 KB out of LDS instead of 228), and a fragment address
 // is a per-kernel lane base + the tile's slot offset + an immediate (round 2 / 3: a select and an add per read).
-// Rows are 36 pixels (216 bytes): the 36th is only ever multiplied by the zero weight.  Pixels go in as PAIRS (the
+// Rows are 36 pixels: the 36th is only ever multiplied by the zero weight.  Pixels go in as PAIRS (the
 // patch's x origin is even): one 16-bit load per plane and pair from the raw clip, three dwords per pair into LDS.
 // (The weight gradient contracts over pixels with LDS transpose reads of 8-byte units and keeps the 4-channel patch.)
 #ifndef LR_C1_FWD_WGS
 #define LR_C1_FWD_WGS 1024
 #endif
 constexpr int F1_RW = C1_P + 1;                  // pixels per patch row
-constexpr int F1_RB = F1_RW * 6;                 // bytes per patch row (216)
-constexpr int F1_SLOT = C1_P * F1_RB;            // bytes per ring slot (one frame): 7560
-constexpr int F1_PATCH = 3 * F1_SLOT;            // 22,680 bytes
+// bytes per patch row: 36 pixels = 216, padded to 224.  A fragment read is two ds_read2_b32 (4-byte alignment is all a
+// 6-byte pixel gives), i.e. dword accesses banked (address / 4) mod 32 over lanes 0-31 = two output rows x 16 columns:
+// the columns are 3 dwords apart (conflict-free on their own), and the two rows land on disjoint banks only when two
+// patch rows are 16 dwords (mod 32) apart: row stride = 32 (mod 64) bytes.  (216: SQ_LDS_BANK_CONFLICT = 43 % of the
+// kernel's LDS cycles and the LDS array busy for two thirds of its duration, profiles/r03_pixels_pmc_SQ_pass2/3.)
+constexpr int F1_RB = 224;
+static_assert(F1_RB >= F1_RW * 6 && F1_RB % 64 == 32 && (4 * F1_RB + 12) / 4 <= 255, "row stride: banks and ds_read2_b32 offsets");
+constexpr int F1_SLOT = C1_P * F1_RB;            // bytes per ring slot (one frame): 7840
+constexpr int F1_PATCH = 3 * F1_SLOT;            // 23,520 bytes
 constexpr int F1_PPR = F1_RW / 2;                // pixel pairs per row (18)
 constexpr int F1_PAIRS = C1_P * F1_PPR;          // pixel pairs per frame (630)
 constexpr int F1_NPU = (F1_PAIRS + 255) / 256;   // pairs per thread (3)
 constexpr int F1_KS = 15;                        // k steps: (kt, kh) rows of the filter
 constexpr int F1_WLD = F1_KS * 16 + 8;           // weight row in LDS (496 B: conflict-free b128 reads)
 
-struct F1Pix { int py[F1_NPU], px[F1_NPU]; };    // row and (even) column of the thread's pairs inside the patch frame
-__device__ __forceinline__ F1Pix f1_pix(int tid) {
+// row and (even) column of the thread's pairs inside the patch frame, and py * Win + px
+struct F1Pix { int py[F1_NPU], px[F1_NPU], lin[F1_NPU]; };
+__device__ __forceinline__ F1Pix f1_pix(int tid, int Win) {
   F1Pix r;
 #pragma unroll
   for (int i = 0; i < F1_NPU; ++i) {
@@ -212,18 +219,30 @@ __device__ __forceinline__ F1Pix f1_pix(int tid) {
     const int e0 = tid + i * 256, e = e0 < F1_PAIRS ? e0 : e0 - 256;
     r.py[i] = e / F1_PPR;
     r.px[i] = 2 * (e % F1_PPR);
+    r.lin[i] = r.py[i] * Win + r.px[i];
   }
   return r;
 }
 // One frame of the patch in flight: raw words per pair (U8: the pair's two bytes of each plane; else the two 4-channel
-// bf16 pixels) and two validity bits per pair in `ok` (bit 2i: left pixel, bit 2i + 1: right pixel).  Branch-free as in
-// c1_frame_issue: a pixel outside the frame / the clip loads pixel (0, 0) and is written as zeros.
+// bf16 pixels) and, in the MASKED forms, two validity bits per pair in `ok` (bit 2i: left pixel, bit 2i + 1: right
+// pixel): a pixel outside the frame / the clip loads pixel (0, 0) and is written as zeros (branch-free as in
+// c1_frame_issue).
 // EVENW: Win is even, so a pair (its left column is even) is inside or outside the frame as a whole and is ONE aligned
 // load per plane (U8) or ONE 16-byte load; odd widths load the two pixels on their own.
-template <bool U8> struct F1Stage { unsigned w[F1_NPU][U8 ? 3 : 4]; unsigned ok; };
+// U8 && EVENW (the product's path) needs no mask at all: the three planes are read through buffer descriptors of
+// exactly one plane each (none of it when the frame lies outside the clip), so rows above / below the frame are out
+// of the descriptor's range and come back as zeros — which bf16(0 / 255) is; columns left / right of the frame get an
+// out-of-range offset.  A pair then costs 4 vector instructions to address (offset = the thread's py * Win + px, a
+// kernel constant, + the tile's scalar; column test; select) instead of ~14 (two coordinates, four compares, a 64-bit
+// multiply-add, three 64-bit adds, the mask bits), and nothing to mask when it is written.
+template <bool U8, bool EVENW> struct F1Stage {
+  static constexpr bool MASKED = !(U8 && EVENW);
+  unsigned w[F1_NPU][U8 ? 3 : 4];
+  unsigned ok;
+};
 template <bool U8, bool EVENW>
-__device__ __forceinline__ void f1_frame_issue(const bf16_t* __restrict__ X, const F1Pix& pm, F1Stage<U8>& s, int f, int t,
-                                               int T, int Hin, int Win, int y0, int x0, int kt) {
+__device__ __forceinline__ void f1_frame_issue(const bf16_t* __restrict__ X, const F1Pix& pm, F1Stage<U8, EVENW>& s, int f,
+                                               int t, int T, int Hin, int Win, int y0, int x0, int kt) {
   const int ti = t + kt - 1;
   const bool frame_ok = ti >= 0 && ti < T;
   const int64_t fr = frame_ok ? f + kt - 1 : f;
@@ -233,60 +252,80 @@ __device__ __forceinline__ void f1_frame_issue(const bf16_t* __restrict__ X, con
   const unsigned char *p1 = p0 + plane, *p2 = p1 + plane;
   const bf16_t* pf = X + fr * plane * 4;
   s.ok = 0u;
+  if constexpr (U8 && EVENW) {
+    const int records = frame_ok ? (int)plane : 0;
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p0), (short)0, records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p1), (short)0, records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p2), (short)0, records, 0x00020000);
+    const int sb = yb * Win + xb;
 #pragma unroll
-  for (int i = 0; i < F1_NPU; ++i) {
-    const int yi = pm.py[i] + yb, xi = pm.px[i] + xb;
-    const bool row_ok = frame_ok && (unsigned)yi < (unsigned)Hin;
-    const bool ok0 = row_ok && (unsigned)xi < (unsigned)Win;
-    const bool ok1 = EVENW ? ok0 : (row_ok && (unsigned)(xi + 1) < (unsigned)Win);
-    const int off0 = ok0 ? yi * Win + xi : 0;
-    s.ok |= (ok0 ? 1u : 0u) << (2 * i) | (ok1 ? 2u : 0u) << (2 * i);
-    if (EVENW) {
-      if (U8) {
-        s.w[i][0] = *reinterpret_cast<const unsigned short*>(p0 + off0);
-        s.w[i][1] = *reinterpret_cast<const unsigned short*>(p1 + off0);
-        s.w[i][2] = *reinterpret_cast<const unsigned short*>(p2 + off0);
-      } else {
+    for (int i = 0; i < F1_NPU; ++i) {
+      const bool col_ok = (unsigned)(pm.px[i] + xb) < (unsigned)Win;
+      const int off = col_ok ? pm.lin[i] + sb : (int)0x80000000;
+      s.w[i][0] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r0, off, 0, 0);
+      s.w[i][1] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r1, off, 0, 0);
+      s.w[i][2] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r2, off, 0, 0);
+    }
+    return;
+  } else {
+#pragma unroll
+    for (int i = 0; i < F1_NPU; ++i) {
+      const int yi = pm.py[i] + yb, xi = pm.px[i] + xb;
+      const bool row_ok = frame_ok && (unsigned)yi < (unsigned)Hin;
+      const bool ok0 = row_ok && (unsigned)xi < (unsigned)Win;
+      const bool ok1 = EVENW ? ok0 : (row_ok && (unsigned)(xi + 1) < (unsigned)Win);
+      const int off0 = ok0 ? yi * Win + xi : 0;
+      s.ok |= (ok0 ? 1u : 0u) << (2 * i) | (ok1 ? 2u : 0u) << (2 * i);
+      if constexpr (EVENW) {   // bf16 pixels (U8 && EVENW returned above)
         const uint4 v = *reinterpret_cast<const uint4*>(pf + (int64_t)off0 * 4);
         s.w[i][0] = v.x, s.w[i][1] = v.y, s.w[i][2] = v.z, s.w[i][3] = v.w;
-      }
-    } else {
-      const int off1 = ok1 ? yi * Win + xi + 1 : 0;
-      if (U8) {
-        s.w[i][0] = (unsigned)p0[off0] | ((unsigned)p0[off1] << 8);
-        s.w[i][1] = (unsigned)p1[off0] | ((unsigned)p1[off1] << 8);
-        s.w[i][2] = (unsigned)p2[off0] | ((unsigned)p2[off1] << 8);
       } else {
-        const uint2 a = *reinterpret_cast<const uint2*>(pf + (int64_t)off0 * 4);
-        const uint2 b = *reinterpret_cast<const uint2*>(pf + (int64_t)off1 * 4);
-        s.w[i][0] = a.x, s.w[i][1] = a.y, s.w[i][2] = b.x, s.w[i][3] = b.y;
+        const int off1 = ok1 ? yi * Win + xi + 1 : 0;
+        if constexpr (U8) {
+          s.w[i][0] = (unsigned)p0[off0] | ((unsigned)p0[off1] << 8);
+          s.w[i][1] = (unsigned)p1[off0] | ((unsigned)p1[off1] << 8);
+          s.w[i][2] = (unsigned)p2[off0] | ((unsigned)p2[off1] << 8);
+        } else {
+          const uint2 a = *reinterpret_cast<const uint2*>(pf + (int64_t)off0 * 4);
+          const uint2 b = *reinterpret_cast<const uint2*>(pf + (int64_t)off1 * 4);
+          s.w[i][0] = a.x, s.w[i][1] = a.y, s.w[i][2] = b.x, s.w[i][3] = b.y;
+        }
       }
     }
   }
 }
-// bf16 of a byte of the clip, exactly as lr_clip_to_ndhwc_bf16 makes it
-__device__ __forceinline__ unsigned f1_u8_bf(unsigned byte) { return (unsigned)f2bf((float)byte * (1.f / 255.f)); }
-template <bool U8>
-__device__ __forceinline__ void f1_frame_store(unsigned char* PsB, const F1Pix& pm, const F1Stage<U8>& s, int tid, int t,
-                                               int kt) {
+// bf16 of two bytes of the clip, exactly as lr_clip_to_ndhwc_bf16 makes them (byte / 255 in fp32, round to nearest
+// even), as ONE packed multiply and ONE packed conversion: {lo: byte `bl` of wl, hi: byte `bh` of wh}.  (Written value
+// by value hipcc spends cvt + mul + cvt + shift + or on each: 28 vector instructions per pair of pixels against 15.)
+template <int bl, int bh>
+__device__ __forceinline__ unsigned f1_bf_pair(unsigned wl, unsigned wh) {
+  const f32x2_t v = f32x2_t{(float)((wl >> (8 * bl)) & 0xffu), (float)((wh >> (8 * bh)) & 0xffu)} * (1.f / 255.f);
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+template <bool U8, bool EVENW>
+__device__ __forceinline__ void f1_frame_store(unsigned char* PsB, const F1Pix& pm, const F1Stage<U8, EVENW>& s, int tid,
+                                               int t, int kt) {
   unsigned char* slot = PsB + ((t + kt) % 3) * F1_SLOT;
 #pragma unroll
   for (int i = 0; i < F1_NPU; ++i) {
     unsigned d0, d1, d2;   // {c0 c1} {c2 | c0'} {c1' c2'} of the pair's left and right (') pixel
-    if (U8) {
-      const unsigned a = s.w[i][0], b = s.w[i][1], c = s.w[i][2];
-      d0 = f1_u8_bf(a & 0xffu) | (f1_u8_bf(b & 0xffu) << 16);
-      d1 = f1_u8_bf(c & 0xffu) | (f1_u8_bf((a >> 8) & 0xffu) << 16);
-      d2 = f1_u8_bf((b >> 8) & 0xffu) | (f1_u8_bf((c >> 8) & 0xffu) << 16);
+    if constexpr (U8) {
+      // planes 0 and 1 in one word (bytes: a a' b b') so that every byte is a v_cvt_f32_ubyteN away
+      const unsigned ab = s.w[i][0] | (s.w[i][1] << 16), c = s.w[i][2];
+      d0 = f1_bf_pair<0, 2>(ab, ab);
+      d1 = f1_bf_pair<0, 1>(c, ab);
+      d2 = f1_bf_pair<3, 1>(ab, c);
     } else {
       d0 = s.w[i][0];
       d1 = (s.w[i][1] & 0xffffu) | (s.w[i][2] << 16);
       d2 = (s.w[i][2] >> 16) | (s.w[i][3] << 16);
     }
-    const bool ok0 = (s.ok >> (2 * i)) & 1u, ok1 = (s.ok >> (2 * i + 1)) & 1u;
-    d0 = ok0 ? d0 : 0u;
-    d1 = (ok0 ? d1 & 0xffffu : 0u) | (ok1 ? d1 & 0xffff0000u : 0u);
-    d2 = ok1 ? d2 : 0u;
+    if (F1Stage<U8, EVENW>::MASKED) {
+      const bool ok0 = (s.ok >> (2 * i)) & 1u, ok1 = (s.ok >> (2 * i + 1)) & 1u;
+      d0 = ok0 ? d0 : 0u;
+      d1 = (ok0 ? d1 & 0xffffu : 0u) | (ok1 ? d1 & 0xffff0000u : 0u);
+      d2 = ok1 ? d2 : 0u;
+    }
     unsigned* dst = reinterpret_cast<unsigned*>(slot + pm.py[i] * F1_RB + pm.px[i] * 6);
     dst[0] = d0;
     dst[1] = d1;
@@ -299,9 +338,9 @@ __device__ __forceinline__ void f1_walk_start(const bf16_t* __restrict__ X, cons
                                               int t, int T, int Hin, int Win, int y0, int x0, int tid) {
 #pragma unroll 1
   for (int kt = 0; kt < 2; ++kt) {
-    F1Stage<U8> s;
+    F1Stage<U8, EVENW> s;
     f1_frame_issue<U8, EVENW>(X, pm, s, f, t, T, Hin, Win, y0, x0, kt);
-    f1_frame_store<U8>(PsB, pm, s, tid, t, kt);
+    f1_frame_store<U8, EVENW>(PsB, pm, s, tid, t, kt);
   }
 }
 
@@ -338,9 +377,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
     pixbase[i] = (2 * yl) * F1_RB + (2 * xl) * 6 + lk * 16;
   }
   const float bv = bias ? bias[lr] : 0.f;
-  const F1Pix pm = f1_pix(tid);
+  const F1Pix pm = f1_pix(tid, Win);
   const bool exact = Ho % C1_T == 0 && Wo % C1_T == 0;   // no tile hangs over the output's edge
-  F1Stage<U8> stg;              // the new frame (temporal tap 2) of the NEXT tile, in flight during a tile's MFMAs
+  F1Stage<U8, EVENW> stg;              // the new frame (temporal tap 2) of the NEXT tile, in flight during a tile's MFMAs
   const int64_t q_end = ntiles * (blockIdx.x + 1) / gridDim.x;
   const int64_t q_begin = ntiles * blockIdx.x / gridDim.x;
   if (q_begin >= q_end) return;
@@ -348,7 +387,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
   // the first tile's patch, synchronously
   f1_walk_start<U8, EVENW>(X, pm, PsB, c.f, c.t, T, Hin, Win, c.y0, c.x0, tid);
   f1_frame_issue<U8, EVENW>(X, pm, stg, c.f, c.t, T, Hin, Win, c.y0, c.x0, 2);
-  f1_frame_store<U8>(PsB, pm, stg, tid, c.t, 2);
+  f1_frame_store<U8, EVENW>(PsB, pm, stg, tid, c.t, 2);
   __syncthreads();
   // A tile: issue the next tile's frame -> MFMAs -> barrier -> that frame into the ring slot the MFMAs no longer read
   // -> barrier -> epilogue.  The frame's loads are consumed BEFORE this tile's output stores are issued: vmcnt counts
@@ -370,7 +409,12 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) abase[kt][i] = pixbase[i] + ((c.t + kt) % 3) * F1_SLOT;
+      for (int i = 0; i < 2; ++i) {
+        abase[kt][i] = pixbase[i] + ((c.t + kt) % 3) * F1_SLOT;
+        // six registers of their own: left to itself hipcc keeps ONE base and re-derives the other five in front of
+        // every read (45 vector adds per tile), because a ds_read2_b32 offset only reaches 1020 bytes
+        asm volatile("" : "+v"(abase[kt][i]));
+      }
     uint4 af[2][2];
     bf16x8 bw[2];
     auto load_k = [&](int ks, uint4 (&a)[2], bf16x8& b) {
@@ -405,7 +449,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
     __syncthreads();            // this tile's fragments are no longer being read
     if (more) {
       if (n.t == 0) f1_walk_start<U8, EVENW>(X, pm, PsB, n.f, n.t, T, Hin, Win, n.y0, n.x0, tid);   // a new walk: whole patch
-      f1_frame_store<U8>(PsB, pm, stg, tid, n.t, 2);
+      f1_frame_store<U8, EVENW>(PsB, pm, stg, tid, n.t, 2);
     }
     __syncthreads();
     if (POOL) {

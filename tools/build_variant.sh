@@ -6,7 +6,9 @@ set -e
 TAG=$1; SRC=$2; UNIT=${3:-$(basename $SRC .hip)}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OBJ=/tmp/variant_$TAG.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -I$ROOT/lipreading_amd/csrc -I$ROOT/include -c $SRC -o $OBJ
+EXTRA=""   # the unit's flags of lipreading_amd/_build.py (UNIT_FLAGS)
+if [ "$UNIT" = lr_conv1 ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form"; fi
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $EXTRA -I$ROOT/lipreading_amd/csrc -I$ROOT/include -c $SRC -o $OBJ
 OTHERS=$(ls $ROOT/lipreading_amd/_lib/obj/*.o | grep -v "/$UNIT.o")
 mkdir -p $ROOT/lipreading_amd/_lib/alt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/lipreading_amd/_lib/alt/$TAG.so $OBJ $OTHERS

@@ -10,6 +10,7 @@
 #   <round>_{pixels,gru256,lstm768,lstm700}_pmc_{FETCH,WRITE}_SIZE.txt   HBM/fabric bytes per launch (separate --pmc passes)
 #   <round>_{pixels,gru256,lstm768}_pmc_SQ_pass1.txt, <round>_pixels_pmc_SQ_pass2.txt   matrix-pipe / LDS counters of the
 #                                                                       conv, recurrence and GEMM kernels
+#   <round>_pixels_pmc_SQ_pass3.txt   the conv kernels' wave cycles by state (parked / issue-stalled / issuing per pipe)
 #   <round>_{pixels,gru256}_step_timeline.txt   every dispatch of one replayed step with start offset and queue
 # PMC passes never share a run with trace domains other than the kernel trace rocprofv3 adds itself.
 set -u
@@ -55,6 +56,8 @@ kt pixels_tfm --regime pixels_tfm
 LIPREADING_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_forcedist.json"
 pmc sq1 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" pixels_pmc_SQ_pass1 conv_ conv1_ rnnc_ xgemm -- --regime pixels
 pmc sq2 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA" pixels_pmc_SQ_pass2 conv_ conv1_ rnnc_ xgemm -- --regime pixels
+# where the conv kernels' wave cycles go: parked (s_waitcnt / barrier), issue-stalled, or issuing — and in which pipe
+pmc sq2b "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SALU" pixels_pmc_SQ_pass3 conv_ conv1_ -- --regime pixels
 if [ "$ONLY" != "pixels" ]; then
   for m in gru256 lstm768 lstm700 lstm512 gru800; do
     python bench.py --regime landmarks --model $m 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_$m.json"
