@@ -581,7 +581,10 @@ int lr_conv3d_pack_weights_multi(int n, const float* const* W, void* const* out,
  *   flags & 2 / flags & 4: Wp is fragment-major (lr_conv3d_pack_weights dgrad & 2 / & 4);
  *   flags & 8 (first STCNN layer only, LR_ERR_UNSUPPORTED elsewhere): X is the raw clip, uint8
  *   [B][T][3][Hin][Win], scaled by 1/255 on the way into LDS exactly as lr_clip_to_ndhwc_bf16
- *   would have — no bf16 copy of the clip is made.                                               */
+ *   would have — no bf16 copy of the clip is made.
+ *   The first STCNN layer's geometry (Cin = 4, Cout = 32, taps 3x5x5, stride 2, padding 1,2,2) is a 3-channel
+ *   layer padded to four: its kernel contracts channels 0..2 only — X[...,3] and Wp[...][3] are padding (zero, as
+ *   lr_clip_to_ndhwc_bf16 and lr_conv3d_pack_weights with Cin_real = 3 write them) and are not read.  */
 int lr_conv3d_forward(const void* X, const void* Wp, const float* bias, void* Y, int B, int T, int Hin,
                       int Win, int Cin, int Cout, int KT, int KH, int KW, int stride, int pt, int ph,
                       int pw, int flags, lr_stream_t stream);

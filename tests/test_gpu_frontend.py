@@ -61,6 +61,43 @@ def test_single_conv_layer_and_dgrad_against_torch(dev):
       assert rel_err(got.numpy(), xr.grad.numpy()) < 1.5e-2, (cin, cout)
 
 
+@pytest.mark.parametrize("H,W", [(19, 21), (20, 22), (37, 33)])
+@pytest.mark.parametrize("dtype", ["u8", "bf16"])
+def test_first_layer_forward_at_odd_and_ragged_sizes_against_torch(dev, dtype, H, W):
+  """The first layer's patch kernel at frame sizes the frontend never produces: odd widths (pixel pairs that straddle the
+  frame's edge: the kernel's per-pixel loads instead of pair loads), heights and widths whose 16 x 16 output tiles hang
+  over the edge, several tiles per frame (37 x 33 -> 19 x 17 outputs), from the raw uint8 clip (flags & 8) and from the
+  4-channel bf16 copy, without the pooling epilogue; against F.conv3d on the same bf16 values."""
+  from lipreading_amd import _C
+  L = _C.lib()
+  st = _C.stream_handle()
+  g = torch.Generator().manual_seed(H * 100 + W)
+  B, T, cin, cin_p, cout, kt, kh, kw = 1, 4, 3, 4, 32, 3, 5, 5
+  clips = torch.randint(0, 256, (B * T, 3, H, W), generator=g, dtype=torch.uint8)
+  w = torch.randn(cout, cin, kt, kh, kw, generator=g) / (cin * kt * kh * kw) ** 0.5
+  b = torch.randn(cout, generator=g)
+  xb = (clips.float() * (1.0 / 255.0)).bfloat16()                       # [F][3][H][W], what the kernel makes of a byte
+  ref = torch.nn.functional.conv3d(xb.float().reshape(B, T, 3, H, W).permute(0, 2, 1, 3, 4), w.bfloat16().float(), b,
+                                   stride=(1, 2, 2), padding=(1, 2, 2))
+  ho, wo = ref.shape[-2], ref.shape[-1]
+  wp = torch.empty((cout, kt * kh * kw, cin_p), dtype=torch.bfloat16, device=dev)
+  _C.check(L.lr_conv3d_pack_weights(w.to(dev).data_ptr(), wp.data_ptr(), cout, cin, cin_p, kt, kh, kw, 0, st))
+  y = torch.full((B * T, ho, wo, cout), float("nan"), dtype=torch.bfloat16, device=dev)
+  if dtype == "u8":
+    x = clips.to(dev)
+    flags = 8
+  else:
+    x = torch.zeros((B * T, H, W, cin_p), dtype=torch.bfloat16)
+    x[..., :3] = xb.permute(0, 2, 3, 1)
+    x = x.to(dev)
+    flags = 0
+  _C.check(L.lr_conv3d_forward(x.data_ptr(), wp.data_ptr(), b.to(dev).data_ptr(), y.data_ptr(), B, T, H, W, cin_p, cout,
+                               kt, kh, kw, 2, 1, 2, 2, flags, st))
+  got = y.float().cpu().reshape(B, T, ho, wo, cout).permute(0, 4, 1, 2, 3)
+  assert torch.isfinite(got).all()
+  assert rel_err(got.numpy(), ref.numpy()) < 1e-2, (dtype, H, W)
+
+
 @pytest.mark.parametrize("dtype", ["u8", "f32"])
 def test_frontend_forward_backward_matches_oracle(dev, dtype):
   from lipreading_amd.frontend import ConvFrontend3D, feature_dim

@@ -3,8 +3,10 @@
 # error or warning).   usage: tools/hip_resources.sh lipreading_amd/csrc/lr_rnn_cluster.hip [name filter]
 set -u
 SRC=$1; FILT=${2:-.}
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function \
-  -Rpass-analysis=kernel-resource-usage -c "$SRC" -o /tmp/hip_resources.o 2>&1 | python3 -c '
+EXTRA=""   # the unit's flags of lipreading_amd/_build.py (UNIT_FLAGS)
+if [ "$(basename $SRC .hip)" = lr_conv1 ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form"; fi
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $EXTRA \
+  -I$(dirname $0)/../include -Rpass-analysis=kernel-resource-usage -c "$SRC" -o /tmp/hip_resources.o 2>&1 | python3 -c '
 import re, sys
 name = None; row = {}
 for line in sys.stdin:
