@@ -553,6 +553,20 @@ __global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __re
   // The 16 lanes ds_read_b128 serves together still cover the 4 x 4 block once, and same-column
   // lanes land on 4 different chunks for any tap shift.
   const int base_b = (fw * P3_PH + ((rl >> 1) & 1) + 2 * (rl >> 3)) * P3_RS + ((rl & 1) + 2 * ((rl >> 2) & 1)) * 64 + kg * 16;
+  // B fragments: a ring of THREE taps' fragments, indexed by dw (compile-time), running through the channel passes as
+  // one sequence g = cg * 27 + tap: the fragments of g + 3 are loaded into the registers of g right after g's MFMAs.
+  // (Round 2 / 3 loaded tap + 1 during tap and copied next -> current at the end of the tap: the copy READS the
+  // registers the load is filling, so the wave waited for the load inside the tap it was issued in — 288 (data
+  // gradient) / 432 (forward) MFMA cycles of cover for an L2 round trip, and a cold start after every patch fill:
+  // SQ_WAIT_ANY = 51 % / 37 % of the kernels' wave cycles, profiles/r03_pixels_pmc_SQ_pass3.txt.)  The first three
+  // taps are in flight before the first patch fill, a pass's last row loads the next pass's first taps.
+  const bf16_t* wfl = Wf + (int64_t)nh * NT16 * 512 + lane * 8;   // + (g * NTT + j) * 512
+  bf16x8 br[3][NT16];
+#pragma unroll
+  for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+    for (int j = 0; j < NT16; ++j) br[dw][j] = *reinterpret_cast<const bf16x8*>(wfl + (dw * NTT + j) * 512);
+  int g = 0;
   for (int cg = 0; cg < CG; ++cg) {
     if (cg > 0) __syncthreads();
     // patch load: a wave covers one 16-position patch row (64 sixteen-byte units) per pass, so the
@@ -581,23 +595,13 @@ __global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __re
       }
     }
     __syncthreads();
-    const bf16_t* wf = Wf + ((int64_t)cg * TAPS * NTT + nh * NT16) * 512 + lane * 8;
-    bf16x8 bcur[NT16], bnext[NT16];
-#pragma unroll
-    for (int j = 0; j < NT16; ++j) bcur[j] = *reinterpret_cast<const bf16x8*>(wf + j * 512);
-    int tap = 0;
 #pragma unroll 1
     for (int dt = 0; dt < 3; ++dt) {
       const bool valid = fvalid && t + dt - 1 >= 0 && t + dt - 1 < T;   // wave-uniform
 #pragma unroll 1
       for (int dh = 0; dh < 3; ++dh) {   // (unrolled further, the 243 fragment addresses get hoisted and spilled)
 #pragma unroll
-        for (int dw = 0; dw < 3; ++dw, ++tap) {
-          if (tap + 1 < TAPS) {
-#pragma unroll
-            for (int j = 0; j < NT16; ++j)
-              bnext[j] = *reinterpret_cast<const bf16x8*>(wf + ((int64_t)(tap + 1) * NTT + j) * 512);
-          }
+        for (int dw = 0; dw < 3; ++dw, ++g) {
           if (valid) {
             const int to = (dt * P3_PH + dh) * P3_RS + dw * 64;
 #pragma unroll
@@ -605,11 +609,13 @@ __global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __re
               const bf16x8 a = *reinterpret_cast<const bf16x8*>(patch + base_b + (to + (4 * (mb / 3)) * P3_RS + 4 * (mb % 3) * 64));
 #pragma unroll
               for (int j = 0; j < NT16; ++j)
-                acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur[j], acc[mb][j], 0, 0, 0);
+                acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, br[dw][j], acc[mb][j], 0, 0, 0);
             }
           }
+          const int gn = g + 3 < CG * TAPS ? g + 3 : CG * TAPS - 1;   // (the last three reload the last tap: no branch)
 #pragma unroll
-          for (int j = 0; j < NT16; ++j) bcur[j] = bnext[j];
+          for (int j = 0; j < NT16; ++j)
+            br[dw][j] = *reinterpret_cast<const bf16x8*>(wfl + ((int64_t)gn * NTT + j) * 512);
         }
       }
     }
