@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_ts_kernel(ConvGeom g, const 
 // output channels: NT16 sixteen-column tiles per wave), so its patch is 4 slots = 57 KB and two
 // workgroups share a CU: 8 waves per CU overlap each other's load phases and epilogues, and 1200
 // half-size tiles fill 256 CUs in 2.5 tile-times where 600 four-frame tiles took 3 (2.34 rounds).
-constexpr int P3_TT = 2, P3_NSPL = 4 / P3_TT, P3_H = 12, P3_W = 12, P3_PH = P3_H + 2, P3_PW = 16, P3_SLOTS = P3_TT + 2;
+constexpr int P3_TT = 2, P3_NSPL = 4 / P3_TT, P3_H = 12, P3_W = 12, P3_PH = P3_H + 2, P3_SLOTS = P3_TT + 2;
 constexpr int P3_RS = (P3_W + 2) * 64 + 16;        // bytes per patch row
 constexpr int P3_ROWS = P3_SLOTS * P3_PH;          // 56 patch rows: one per wave and pass, 14 passes
 constexpr int P3_LDS = P3_ROWS * P3_RS;            // 51,072 bytes
@@ -1149,7 +1149,7 @@ static int conv_forward_impl(const void* X, const void* Wp, const float* bias, v
   if (code && Cin != 4) return LR_ERR_UNSUPPORTED;   // the second layer's fused pooling lives in the patch kernel
   if (Cin == 4 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 && ph == 2 && pw == 2) {
     // first layer: patch-resident kernel (one 16x16 output tile of one frame per workgroup), lr_conv1.hip
-    hipEvent_t e0, e1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool sample = relu && lr_prof_next(LR_PROF_CONV1_FWD, &e0, &e1);
     return lr_conv1_forward(code != nullptr, u8, x, w, bias, y, code, B * T, T, Hin, Win, g.Ho, g.Wo, relu, sample, e0,
                             e1, (hipStream_t)stream);
