@@ -13,9 +13,11 @@ namespace {
 // With Cin = 4 an im2col row is 75 separate 8-byte gathers and neighbouring rows overlap almost
 // completely, so the generic implicit GEMM is gather-bound (82 TF/s forward, 36 TF/s weight
 // gradient).  Here a workgroup owns a 16x16 tile of output pixels of one frame and loads the
-// input patch it needs ONCE into LDS: 3 frames x 35 x 35 pixels x 4 channels (29 kB).  Every
-// operand of the forward product and of the weight gradient is then an LDS read at
-// (pixel offset + tap offset): no im2col staging, no barrier inside the K loop.
+// input patch it needs ONCE into LDS: 3 frames x 35 x 35 pixels.  Every operand of the forward
+// product and of the weight gradient is then an LDS read at (pixel offset + tap offset): no im2col
+// staging, no barrier inside the K loop.
+// This first part — the 4-channel patch (8 bytes per pixel, 29 kB), c1_* — serves the WEIGHT GRADIENT
+// (and the tile walk both kernels share); the forward keeps a 3-channel patch of its own, f1_* below.
 constexpr int C1_T = 16;                       // output tile edge
 constexpr int C1_P = 2 * C1_T + 3;             // patch edge (stride 2, 5x5 taps): 35
 constexpr int C1_PIX = C1_T * C1_T;            // 256 output pixels = 8 MFMA row tiles
@@ -29,8 +31,9 @@ constexpr int C1_FPIX = C1_P * C1_P;          // pixels of one patch frame (1225
 // Frame ti of the clip lives in slot (ti + 1) % 3, i.e. temporal tap kt of tile t in slot (t + kt) % 3.
 // (Round 2's counters show two-way LDS bank conflicts in both kernels, 37 % / 44 % of their LDS cycles: an operand read
 // takes two output rows x 16 columns, i.e. every second pixel of input rows two apart, and both rows land on the same
-// half of the banks.  Shifting every second PAIR of patch rows by one pixel — 36-pixel rows — removes them and
-// changes neither kernel's time, round 3: they are not what the kernels wait for.)
+// half of the banks.  Shifting every second PAIR of patch rows by one pixel — 36-pixel rows — removed them and
+// changed neither kernel's time early in round 3, with this 4-channel patch in both.  The rebuilt forward is another
+// matter: there the LDS array WAS the bound and the conflict-free row stride gave 16 %, see F1_RB.)
 // tap = (kt*5 + kh)*5 + kw  ->  element offset inside the patch [3 slots][35][35][4]
 __device__ __forceinline__ int c1_tap_off(int tap, int t) {
   if (tap >= 75) return -1;
