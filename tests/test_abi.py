@@ -61,3 +61,18 @@ def test_product_package_never_imports_the_oracle():
         src = open(os.path.join(dirpath, f)).read()
         assert not re.search(r"^\s*(from|import)\s+oracle\b|import_module\(.oracle|oracle/_ref|lr_oracle",
                              src, flags=re.M), "%s reaches into oracle/" % f
+
+
+def test_per_unit_compile_flags_name_existing_units_and_reach_the_tools():
+  """_build.UNIT_FLAGS (flags of single translation units) must name sources that exist — a typo would silently build
+  the unit without them — and the two shell tools that compile a unit on their own (variant libraries for A/B timing,
+  the register-usage report) must repeat them, or they would time / report another kernel than the library holds."""
+  units = {os.path.splitext(os.path.basename(p))[0] for p in _build.sources()}
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  for unit, flags in _build.UNIT_FLAGS.items():
+    assert unit in units, unit
+    assert flags and all(isinstance(f, str) for f in flags)
+    for tool in ("tools/build_variant.sh", "tools/hip_resources.sh"):
+      with open(os.path.join(root, tool)) as f:
+        text = f.read()
+      assert unit in text and " ".join(flags) in text, (tool, unit)
