@@ -38,6 +38,7 @@
 // chip is only filled by splitting K three ways, and the slabs' write + combine pass costs more than the larger tile
 // saves; a tile this size wants outputs of >= 256 tiles (4096 x 4096).
 #include "lr_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -45,8 +46,21 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short bf16_t;
 
-constexpr int XBM = 128, XBN = 128, XBK = 32, XLD = XBK + 8;
-constexpr int XDEPTH = 3;     // stages of global loads in flight
+// LR_XBK = 64: a build-time variant for A/B timing (tools/build_variant.sh with VARIANT_DEFS=-DLR_XBK=64; untimed, off):
+// 64-k stages — half the barriers and fragment-read restarts per MFMA — with ONE stage of loads in flight (the next
+// stage's loads are issued right after this stage's LDS write and land under its 32-48 MFMAs per wave; two register
+// sets of 64-k stages do not fit two workgroups per CU: 232 + 64 registers).  Rows of 64 + 8 elements (144 bytes) are
+// as conflict-free for the fragment reads' lane groups as the 80-byte rows of the 32-k stage.  The default build's
+// code is unchanged instruction for instruction.
+#ifndef LR_XBK
+#define LR_XBK 32
+#endif
+static_assert(LR_XBK == 32 || LR_XBK == 64, "stage depth");
+constexpr int XBM = 128, XBN = 128, XBK = LR_XBK, XLD = XBK + 8;
+constexpr int XDEPTH = XBK == 32 ? 3 : 1;     // stages of global loads in flight
+constexpr int XUPR = XBK / 8;                 // 16-byte units per plane-tile row
+constexpr int XUSH = XBK == 32 ? 2 : 3;       // log2 of it
+constexpr int XNU = XBM * XUPR / 256;         // units per thread and plane tile
 constexpr int XGROUP_M = 4;   // m-panels per group of the tile order
 
 struct XArgs {
@@ -238,26 +252,26 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
     g.C1 = g.Cb;
   }
 
-  // a plane tile is 128 rows x 32 k = 512 16-byte units: two per thread (row = e / 4, unit = e % 4).  Rows past
+  // a plane tile is 128 rows x 32 k = 512 16-byte units: two per thread (row = e / 4, unit = e % 4; 64-k stages: four).  Rows past
   // the matrix edge are CLAMPED, not zeroed (their products land in accumulator rows / columns that are never
   // stored, and the planes hold finite numbers); only the K tail needs zeros, and only in a split's last stage,
   // so the loads of every other stage are unconditional (a per-load predicate makes hipcc branch around each load).
   constexpr int NPL = 2 + (AX ? 0 : 1) + (BX ? 0 : 1);
   // (element offsets of the thread's two units inside a plane — a plane stays below 2^31 elements —, added to the
   // uniform plane pointer + k0: scalar base + 32-bit lane offset addressing, no 64-bit address registers)
-  unsigned offa[2], offb[2];
+  unsigned offa[XNU], offb[XNU];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int e = tid + i * 256, row = e >> 2, ku = 8 * (e & 3);
+  for (int i = 0; i < XNU; ++i) {
+    const int e = tid + i * 256, row = e >> XUSH, ku = 8 * (e & (XUPR - 1));
     offa[i] = (unsigned)min(m0 + row, g.M - 1) * (unsigned)g.ldp + ku;
     offb[i] = (unsigned)min(n0 + row, g.N - 1) * (unsigned)g.ldp + ku;
   }
-  uint4 rr[XDEPTH][NPL][2];
+  uint4 rr[XDEPTH][NPL][XNU];
   auto load = [&](int slot, int k0) {
     const bf16_t* const pl_ptr[4] = {g.Ah + k0, AX ? nullptr : g.Al + k0, g.Bh + k0, BX ? nullptr : g.Bl + k0};
     if (k0 + XBK <= kend) {   // workgroup-uniform
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < XNU; ++i) {
         int pl = 0;
         rr[slot][pl++][i] = *reinterpret_cast<const uint4*>(pl_ptr[0] + offa[i]);
         if (!AX) rr[slot][pl++][i] = *reinterpret_cast<const uint4*>(pl_ptr[1] + offa[i]);
@@ -266,8 +280,8 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
       }
     } else {                  // the K tail: units at or past kend are zero (planes are zero-padded to ldp only)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const bool ok = k0 + 8 * ((tid + i * 256) & 3) < kend;
+      for (int i = 0; i < XNU; ++i) {
+        const bool ok = k0 + 8 * ((tid + i * 256) & (XUPR - 1)) < kend;
         const int back = ok ? 0 : k0 - kbeg;   // a unit past the end reads the split's first stage instead
         int pl = 0;
         auto get = [&](const bf16_t* p, unsigned off) {
@@ -284,8 +298,8 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
   };
   auto store = [&](int slot) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = tid + i * 256, o = (e >> 2) * XLD + 8 * (e & 3);
+    for (int i = 0; i < XNU; ++i) {
+      const int e = tid + i * 256, o = (e >> XUSH) * XLD + 8 * (e & (XUPR - 1));
       int pl = 0;
       *reinterpret_cast<uint4*>(&Ah[o]) = rr[slot][pl++][i];
       if (!AX) *reinterpret_cast<uint4*>(&Al[o]) = rr[slot][pl++][i];
@@ -324,47 +338,52 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
         // and each group of MFMAs waits out an LDS round trip), then the MFMAs run term by term over the four
         // accumulators: small terms first, so they are not absorbed by a large partial sum, and consecutive
         // MFMAs never wait for each other's result
-        bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            ah[ks][i] = *reinterpret_cast<const bf16x8*>(&Ah[fa + i * 32 * XLD + ks * 16]);
-            if (!AX) al[ks][i] = *reinterpret_cast<const bf16x8*>(&Al[fa + i * 32 * XLD + ks * 16]);
-            bh[ks][i] = *reinterpret_cast<const bf16x8*>(&Bh[fb + i * 32 * XLD + ks * 16]);
-            if (!BX) bl[ks][i] = *reinterpret_cast<const bf16x8*>(&Bl[fb + i * 32 * XLD + ks * 16]);
-          }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          if (!BX) {
-#pragma unroll
+        auto half = [&](auto HF) {   // 32 k at a time (one pass at the default stage depth)
+          constexpr int hf = decltype(HF)::value;
+          bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+  #pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+  #pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              ah[ks][i] = *reinterpret_cast<const bf16x8*>(&Ah[fa + i * 32 * XLD + hf * 32 + ks * 16]);
+              if (!AX) al[ks][i] = *reinterpret_cast<const bf16x8*>(&Al[fa + i * 32 * XLD + hf * 32 + ks * 16]);
+              bh[ks][i] = *reinterpret_cast<const bf16x8*>(&Bh[fb + i * 32 * XLD + hf * 32 + ks * 16]);
+              if (!BX) bl[ks][i] = *reinterpret_cast<const bf16x8*>(&Bl[fb + i * 32 * XLD + hf * 32 + ks * 16]);
+            }
+  #pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            if (!BX) {
+  #pragma unroll
+              for (int i = 0; i < 2; ++i)
+  #pragma unroll
+                for (int j = 0; j < 2; ++j)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+            }
+            if (!AX) {
+  #pragma unroll
+              for (int i = 0; i < 2; ++i)
+  #pragma unroll
+                for (int j = 0; j < 2; ++j)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+            }
+  #pragma unroll
             for (int i = 0; i < 2; ++i)
-#pragma unroll
+  #pragma unroll
               for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
           }
-          if (!AX) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+          // pinned order: the first step's reads, then one of the second step's reads behind each of the first
+          // MFMAs, then the remaining MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x100, NFRAG, 0);
+  #pragma unroll
+          for (int q = 0; q < NFRAG; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
-        }
-        // pinned order: the first step's reads, then one of the second step's reads behind each of the first
-        // MFMAs, then the remaining MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x100, NFRAG, 0);
-#pragma unroll
-        for (int q = 0; q < NFRAG; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NMMA - NFRAG, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * NMMA - NFRAG, 0);
+        };
+        half(std::integral_constant<int, 0>{});
+        if constexpr (XBK == 64) half(std::integral_constant<int, 1>{});
       }
     }
   }
