@@ -48,6 +48,9 @@
 // MEASURED: see DESIGN.md section 4 (round 2, 8-byte granules, LSTM-768 only: forward 4.6 us, backward 5.5 us per
 // step against 9.4 / 10.7 for the step kernels).
 #include "lr_common.h"
+#ifndef LR_RNNC_PREWAIT
+#define LR_RNNC_PREWAIT 0
+#endif
 #include <hip/hip_ext.h>
 
 namespace {
@@ -531,6 +534,16 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
     }
     lr_lds_barrier();   // hnxt's own k step complete; hcur free for the next gather
   };
+  // LR_RNNC_PREWAIT = 1 (build-time variant for A/B timing; untimed, off): one full vmcnt wait in front of the step loop.
+  // The loads before the loop that the loop's body uses (bhn, sreg: issued under `if (alive)`) are never provably
+  // complete for hipcc's wait-count pass, so the FIRST use in every iteration — `sum[2] + bhn` in the even step's cell
+  // — gets a vmcnt(0), and that sits right BEHIND the even step's prefetch of the pre-activations of step s + 2 (hipcc
+  // hoists those loads above the cell): every second step waits out a fresh HBM / MALL load before it publishes its
+  // state, i.e. before the other members of the cluster can go on (the ISA of <3,8> and <4,24>: vmcnt(3|4), the
+  // prefetch, vmcnt(0); with the wait below both are gone and the prefetch's latency runs under the exchange).
+#if LR_RNNC_PREWAIT
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), lgkmcnt / expcnt untouched
+#endif
   for (int s = 0; s < T; s += 2) {
     step(s, gxA);
     if (s + 1 < T) step(s + 1, gxB);
