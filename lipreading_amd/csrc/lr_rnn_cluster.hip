@@ -51,6 +51,9 @@
 #ifndef LR_RNNC_PREWAIT
 #define LR_RNNC_PREWAIT 0
 #endif
+#ifndef LR_RNNC_UNCOND_FETCH
+#define LR_RNNC_UNCOND_FETCH 0
+#endif
 #include <hip/hip_ext.h>
 
 namespace {
@@ -342,9 +345,22 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
     const int sc = s < T ? s : T - 1;
     return d == 0 ? sc : T - 1 - sc;
   };
+  // LR_RNNC_UNCOND_FETCH = 1 (build-time variant, with LR_RNNC_PREWAIT; untimed, off): threads without a (sample, unit) fetch
+  // element (0, 0) instead of nothing.  A load under `if (alive)` merges with the old value at the join: hipcc keeps
+  // the new values in registers of their own, copies them home at the END of the two-step loop body — a read of the
+  // load's destination, hence a vmcnt(0) there for a prefetch issued a hundred instructions earlier — and cannot count
+  // loads that may or may not have been issued; unconditional, the ISA's only waits around the prefetch are the
+  // counted ones of its consumer two steps later.
+#if LR_RNNC_UNCOND_FETCH
+  const int bq = alive ? b : 0, uq = alive ? unit : 0;
+#endif
   auto fetch_gx = [&](Gx& gx, int t) {
+#if LR_RNNC_UNCOND_FETCH
+    const float* gp = gates + (((int64_t)bq * T + t) * D + d) * (int64_t)(G * H) + uq;
+#else
     if (!alive) return;
     const float* gp = gates + (((int64_t)b * T + t) * D + d) * (int64_t)(G * H) + unit;
+#endif
 #pragma unroll
     for (int g = 0; g < G; ++g) gx.v[g] = gp[(int64_t)g * H];
   };
