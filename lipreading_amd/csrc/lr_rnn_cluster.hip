@@ -625,12 +625,37 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
   const float inj_h = (alive && dh_n) ? dh_n[((int64_t)d * B + b) * H + unit] : 0.f;
   const float inj_c = (G == 4 && alive && dc_n) ? dc_n[((int64_t)d * B + b) * H + unit] : 0.f;
   float car = 0.f;   // GRU: dh_{t'} * z_{t'}; LSTM: dc_{t'} * f_{t'} of the step processed before
+#if LR_RNNC_UNCOND_FETCH
+  struct In { float dy, g[G], ex, prev, pmask; };   // prev counts when pmask = 1 (0: no state before the first step)
+  const int bq = alive ? b : 0, uq = alive ? unit : 0;
+#else
   struct In { float dy, g[G], ex, prev; };
+#endif
   In inA, inB;       // operands of even / odd steps, fetched TWO steps ahead
   auto time_of = [&](int s) {
     const int sc = s < T ? s : T - 1;
     return d == 0 ? T - 1 - sc : sc;
   };
+#if LR_RNNC_UNCOND_FETCH
+  // (the forward's variant, see there: every thread loads, from element (0, 0) when it has no (sample, unit) — what it
+  // makes of the values is multiplied by `live` anyway —, and the previous state comes from ONE address chosen by
+  // wave-uniform conditions; where there is none, an in-clip address is loaded and pmask = 0 drops it at its use)
+  auto fetch = [&](In& in, int t) {
+    const int tp = d == 0 ? t - 1 : t + 1;
+    const bool inside = tp >= 0 && tp < T;
+    const int64_t bt = (int64_t)bq * T + t, btp = (int64_t)bq * T + (inside ? tp : t);
+    in.dy = dy[bt * DH + d * H + uq];
+    const float* gi = gates + (bt * D + d) * (int64_t)(G * H) + uq;
+#pragma unroll
+    for (int g = 0; g < G; ++g) in.g[g] = gi[(int64_t)g * H];
+    in.ex = extra[(bt * D + d) * H + uq];
+    const float* src = G == 3 ? h0 : c0;     // the state before the first step (decoder loop), else zero
+    const float* pin = G == 3 ? y + btp * DH + d * H + uq : extra + (btp * D + d) * H + uq;
+    const float* pp = (inside || !src) ? pin : src + ((int64_t)d * B + bq) * H + uq;
+    in.prev = *pp;
+    in.pmask = (inside || src) ? 1.f : 0.f;
+  };
+#else
   auto fetch = [&](In& in, int t) {
     in.dy = in.ex = in.prev = 0.f;
 #pragma unroll
@@ -651,6 +676,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
       if (src) in.prev = src[((int64_t)d * B + b) * H + unit];
     }
   };
+#endif
   fetch(inA, time_of(0));
   fetch(inB, time_of(1));
   const int xdst = CC * XMEMBER, xcluster = CC * xdst, xslot = nclusters * xcluster;   // words (32-bit: scalar multiplies)
@@ -809,7 +835,11 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
     if (G == 3) {
       // rnn_bwd_step_kernel<3>
       dh += car;   // dh_{t+1} * z_{t+1}
+#if LR_RNNC_UNCOND_FETCH
+      const float r = in.g[0], z = in.g[1], n = in.g[2], hn = in.ex, hp = in.prev * in.pmask;
+#else
       const float r = in.g[0], z = in.g[1], n = in.g[2], hn = in.ex, hp = in.prev;
+#endif
       const float dn_pre = live ? dh * (1.f - z) * (1.f - n * n) : 0.f;
       const float dr_pre = dn_pre * hn * r * (1.f - r);
       const float dz_pre = live ? dh * (hp - n) * z * (1.f - z) : 0.f;
@@ -823,7 +853,11 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
       kv[2] = dn_pre * r;    // recurrent path of the n gate: d/d(W_hn h + b_hn)
     } else {
       // rnn_bwd_step_kernel<4>
+#if LR_RNNC_UNCOND_FETCH
+      const float ig = in.g[0], fg = in.g[1], gg = in.g[2], og = in.g[G - 1], ct = in.ex, cp = in.prev * in.pmask;
+#else
       const float ig = in.g[0], fg = in.g[1], gg = in.g[2], og = in.g[G - 1], ct = in.ex, cp = in.prev;
+#endif
       float dc = car;
       if (is_last) dc += inj_c;
       float di = 0.f, df = 0.f, dg_ = 0.f, do_ = 0.f;
