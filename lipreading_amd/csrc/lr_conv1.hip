@@ -722,9 +722,11 @@ int lr_conv1_forward(bool pool, bool u8, const void* X, const void* Wp, const fl
     else hipLaunchKernelGGL((conv1_fwd_patch_kernel<POOLV, U8V, EV>), dim3(tiles), dim3(256), 0, stream, x, w,    \
                             bias, y, code, frames, T, Hin, Win, Ho, Wo, relu);                                   \
   } while (0)
+  // pair loads: an even width AND a base the pair's load is aligned at (2 bytes of a plane, 16 bytes of two bf16 pixels)
+  const bool pairs = Win % 2 == 0 && (reinterpret_cast<uintptr_t>(X) & (u8 ? 1u : 15u)) == 0;
 #define LR_C1(POOLV, U8V)                                                                                         \
   do {                                                                                                           \
-    if (Win % 2 == 0) LR_C1B(POOLV, U8V, true);                                                                  \
+    if (pairs) LR_C1B(POOLV, U8V, true);                                                                         \
     else LR_C1B(POOLV, U8V, false);                                                                              \
   } while (0)
   if (pool && u8) LR_C1(true, true);
