@@ -14,6 +14,7 @@ VARIANT_DEFS="-DLR_P2_PROLOGUE_ORDER=1" bash tools/build_variant.sh p2order $C/l
 VARIANT_DEFS="-DLR_P3_MIN_WGS=3" bash tools/build_variant.sh p3wg3 $C/lr_conv.hip
 VARIANT_DEFS="-DLR_C1_WREG=1" bash tools/build_variant.sh wreg $C/lr_conv1.hip
 VARIANT_DEFS="-DLR_XBK=64" bash tools/build_variant.sh xbk64 $C/lr_xgemm.hip
+VARIANT_DEFS="-DLR_CTC_PIN_LOADS=1" bash tools/build_variant.sh ctcpin $C/lr_ctc.hip
 # layer 3 before its fragment ring (the form that was timed in round 3)
 if git rev-parse --verify -q 709ee36 > /dev/null; then
   mkdir -p /tmp/lr_noring && git show 709ee36:$C/lr_conv.hip > /tmp/lr_noring/lr_conv.hip
