@@ -521,13 +521,11 @@ constexpr int P3_ROWS = P3_SLOTS * P3_PH;          // 56 patch rows: one per wav
 constexpr int P3_LDS = P3_ROWS * P3_RS;            // 51,072 bytes
 static_assert(P3_ROWS % 28 == 0, "patch rows are loaded in batches of 7 passes x 4 waves");
 
-// (LR_P3_MIN_WGS = 3, a build-time variant for A/B timing: three workgroups per CU again after the fragment ring took the
-// forward's registers from 161 to 185, at the price of 17 spilled registers in its patch fill; untimed)
-#ifndef LR_P3_MIN_WGS
-#define LR_P3_MIN_WGS 2
-#endif
+// (Measured and dropped, round 4: three workgroups per CU again after the fragment ring took the forward's registers
+// from 161 to 185 — 17 spilled registers in its patch fill, forward 86.9 -> 95.0 us.  The ring itself against the
+// form before it, same visit: forward 84.7 -> 86.9 us, data gradient 99.2 -> 91.6: kept.)
 template <int CG, int NT16, bool POOL>
-__global__ __launch_bounds__(256, LR_P3_MIN_WGS) void conv_patch16_kernel(const bf16_t* __restrict__ X,
+__global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __restrict__ X,
                                                               const bf16_t* __restrict__ Wf,
                                                               const float* __restrict__ bias,
                                                               bf16_t* __restrict__ Y, unsigned char* __restrict__ code,

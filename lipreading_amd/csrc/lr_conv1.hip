@@ -190,15 +190,9 @@ __device__ __forceinline__ C1Tile c1_next(const C1Tile& c, int T, int tiles_x, i
 // Rows are 36 pixels: the 36th is only ever multiplied by the zero weight.  Pixels go in as PAIRS (the
 // patch's x origin is even): one 16-bit load per plane and pair from the raw clip, three dwords per pair into LDS.
 // (The weight gradient contracts over pixels with LDS transpose reads of 8-byte units and keeps the 4-channel patch.)
-// Build-time variants for A/B timing (tools/build_variant.sh with -D...): LR_C1_WREG = 1 keeps the
-// forward's weight fragments in registers (60 VGPRs: one LDS read in five less, three waves per SIMD instead of four);
-// untimed, off.
-#ifndef LR_C1_WREG
-#define LR_C1_WREG 0
-#endif
-#ifndef LR_C1_FWD_WGS
-#define LR_C1_FWD_WGS (LR_C1_WREG ? 768 : 1024)
-#endif
+// The forward keeps its weight fragments in REGISTERS (60 VGPRs: one LDS read in five less, three waves per SIMD instead
+// of four).  MEASURED (round 4, same box): 112.4 -> 107.5 us against reading them from LDS at every k step.
+constexpr int LR_C1_FWD_WGS = 768;
 constexpr int F1_RW = C1_P + 1;                  // pixels per patch row
 // bytes per patch row: 36 pixels = 216, padded to 224.  A fragment read is two ds_read2_b32 (4-byte alignment is all a
 // 6-byte pixel gives), i.e. dword accesses banked (address / 4) mod 32 over lanes 0-31 = two output rows x 16 columns:
@@ -387,12 +381,10 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
   }
   const float bv = bias ? bias[lr] : 0.f;
   const F1Pix pm = f1_pix(tid, Win);
-  bf16x8 wreg[LR_C1_WREG ? F1_KS : 1];
-  if constexpr (LR_C1_WREG != 0) {
-    __syncthreads();
+  bf16x8 wreg[F1_KS];
+  __syncthreads();
 #pragma unroll
-    for (int ks = 0; ks < F1_KS; ++ks) wreg[ks] = *reinterpret_cast<const bf16x8*>(&Ws[lr * F1_WLD + ks * 16 + lk * 8]);
-  }
+  for (int ks = 0; ks < F1_KS; ++ks) wreg[ks] = *reinterpret_cast<const bf16x8*>(&Ws[lr * F1_WLD + ks * 16 + lk * 8]);
   const bool exact = Ho % C1_T == 0 && Wo % C1_T == 0;   // no tile hangs over the output's edge
   F1Stage<U8, EVENW> stg;              // the new frame (temporal tap 2) of the NEXT tile, in flight during a tile's MFMAs
   const int64_t q_end = ntiles * (blockIdx.x + 1) / gridDim.x;
@@ -434,8 +426,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
     bf16x8 bw[2];
     auto load_k = [&](int ks, uint4 (&a)[2], bf16x8& b) {
       const int kt = ks / 5, kh = ks % 5;
-      if constexpr (LR_C1_WREG != 0) b = wreg[ks];
-      else b = *reinterpret_cast<const bf16x8*>(&Ws[lr * F1_WLD + ks * 16 + lk * 8]);
+      b = wreg[ks];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const unsigned* p = reinterpret_cast<const unsigned*>(PsB + abase[kt][i] + kh * F1_RB);

@@ -39,9 +39,6 @@ constexpr int P2_TT = 4, P2_TH = 8, P2_W = 24, P2_PW = P2_W + 4, P2_PH = P2_TH +
 constexpr int P2_RS = P2_PW * 64;                  // bytes per patch row: 28 positions x 64 B = 7 bank lines
 constexpr int P2_LDS = P2_SLOTS * P2_PH * P2_RS;   // 129,024 bytes
 constexpr int P2_STAGE = 6144;                     // per-wave output staging area behind the patch (epilogue)
-#ifndef LR_P2_PROLOGUE_ORDER
-#define LR_P2_PROLOGUE_ORDER 0
-#endif
 constexpr int P2_BDIST = 2;                        // taps between a B fragment's load and its use
 
 constexpr int kChipCUs = 256;                      // one workgroup of this kernel per CU
@@ -180,14 +177,12 @@ __device__ __forceinline__ void conv_patch_tile(unsigned char* __restrict__ patc
 #pragma unroll
       for (int d = 0; d < P2_BDIST; ++d) {
         load_b(bq[d], d);
-        // LR_P2_PROLOGUE_ORDER = 1 (build-time variant for A/B timing; untimed, off): keep the prologue's fragment
-        // loads in PROGRAM order.  Left alone hipcc issues them youngest tap first, so on the loop's entry path the
-        // first tap's first fragment is the LAST load in the queue — and the wait in front of the row's first MFMA,
-        // merged over both paths into the loop header, becomes vmcnt(1) on EVERY row: it then also waits for the
-        // fragments of the row's second tap, the last of which was issued ~200 MFMA cycles earlier (the taps of a
-        // row after the second have their proper vmcnt(6..8)).  Candidate for the 36 -> 33 cycles per MFMA the
-        // stamps show in these loops.
-        if constexpr (LR_P2_PROLOGUE_ORDER != 0) __builtin_amdgcn_sched_barrier(0);
+        // Keep the prologue's fragment loads in PROGRAM order.  Left alone hipcc issues them youngest tap first, so on
+        // the loop's entry path the first tap's first fragment is the LAST load in the queue — and the wait in front of
+        // the row's first MFMA, merged over both paths into the loop header, becomes vmcnt(1) on EVERY row: it then also
+        // waits for the fragments of the row's second tap (the taps of a row after the second have their proper
+        // vmcnt(6..8)).  MEASURED (round 4, same box): data gradient 345.4 -> 334.7 us, forward unchanged (316.7 / 316.6).
+        __builtin_amdgcn_sched_barrier(0);
       }
       load_a(a0, base_b + row_off(0), 0, 0);
       if constexpr (!SPLIT) {

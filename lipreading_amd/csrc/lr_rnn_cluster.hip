@@ -48,12 +48,6 @@
 // MEASURED: see DESIGN.md section 4 (round 2, 8-byte granules, LSTM-768 only: forward 4.6 us, backward 5.5 us per
 // step against 9.4 / 10.7 for the step kernels).
 #include "lr_common.h"
-#ifndef LR_RNNC_PREWAIT
-#define LR_RNNC_PREWAIT 0
-#endif
-#ifndef LR_RNNC_UNCOND_FETCH
-#define LR_RNNC_UNCOND_FETCH 0
-#endif
 #include <hip/hip_ext.h>
 
 namespace {
@@ -345,22 +339,12 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
     const int sc = s < T ? s : T - 1;
     return d == 0 ? sc : T - 1 - sc;
   };
-  // LR_RNNC_UNCOND_FETCH = 1 (build-time variant, with LR_RNNC_PREWAIT; untimed, off): threads without a (sample, unit) fetch
-  // element (0, 0) instead of nothing.  A load under `if (alive)` merges with the old value at the join: hipcc keeps
-  // the new values in registers of their own, copies them home at the END of the two-step loop body — a read of the
-  // load's destination, hence a vmcnt(0) there for a prefetch issued a hundred instructions earlier — and cannot count
-  // loads that may or may not have been issued; unconditional, the ISA's only waits around the prefetch are the
-  // counted ones of its consumer two steps later.
-#if LR_RNNC_UNCOND_FETCH
-  const int bq = alive ? b : 0, uq = alive ? unit : 0;
-#endif
+  // (Measured and dropped, round 4: threads without a (sample, unit) fetching element (0, 0) instead of nothing, so that
+  // the prefetch has counted waits only — <3,8> forward 111.0 -> 108.6 us, <4,24> 199.7 -> 202.1, backward 153.6 -> 153.9
+  // / 277.1 -> 279.3: inside the pool's noise, and it costs a mask operand in the backward cell.)
   auto fetch_gx = [&](Gx& gx, int t) {
-#if LR_RNNC_UNCOND_FETCH
-    const float* gp = gates + (((int64_t)bq * T + t) * D + d) * (int64_t)(G * H) + uq;
-#else
     if (!alive) return;
     const float* gp = gates + (((int64_t)b * T + t) * D + d) * (int64_t)(G * H) + unit;
-#endif
 #pragma unroll
     for (int g = 0; g < G; ++g) gx.v[g] = gp[(int64_t)g * H];
   };
@@ -550,16 +534,14 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
     }
     lr_lds_barrier();   // hnxt's own k step complete; hcur free for the next gather
   };
-  // LR_RNNC_PREWAIT = 1 (build-time variant for A/B timing; untimed, off): one full vmcnt wait in front of the step loop.
-  // The loads before the loop that the loop's body uses (bhn, sreg: issued under `if (alive)`) are never provably
-  // complete for hipcc's wait-count pass, so the FIRST use in every iteration — `sum[2] + bhn` in the even step's cell
-  // — gets a vmcnt(0), and that sits right BEHIND the even step's prefetch of the pre-activations of step s + 2 (hipcc
-  // hoists those loads above the cell): every second step waits out a fresh HBM / MALL load before it publishes its
-  // state, i.e. before the other members of the cluster can go on (the ISA of <3,8> and <4,24>: vmcnt(3|4), the
-  // prefetch, vmcnt(0); with the wait below both are gone and the prefetch's latency runs under the exchange).
-#if LR_RNNC_PREWAIT
+  // One full vmcnt wait in front of the step loop.  The loads before the loop that the loop's body uses (bhn, sreg:
+  // issued under `if (alive)`) are never provably complete for hipcc's wait-count pass, so the FIRST use in every
+  // iteration — `sum[2] + bhn` in the even step's cell — got a vmcnt(0), right BEHIND the even step's prefetch of the
+  // pre-activations of step s + 2 (hipcc hoists those loads above the cell): every second step waited out a fresh HBM /
+  // MALL load before it published its state, i.e. before the other members of the cluster could go on.  With the wait
+  // here the prefetch's latency runs under the exchange.  MEASURED (round 4, same box, layer pass): <3,8> 119.8 -> 111.0
+  // us in the pixel step, 114.1 -> 104.6 in regime R; <4,24> 207.3 -> 199.7.
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), lgkmcnt / expcnt untouched
-#endif
   for (int s = 0; s < T; s += 2) {
     step(s, gxA);
     if (s + 1 < T) step(s + 1, gxB);
@@ -625,37 +607,12 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
   const float inj_h = (alive && dh_n) ? dh_n[((int64_t)d * B + b) * H + unit] : 0.f;
   const float inj_c = (G == 4 && alive && dc_n) ? dc_n[((int64_t)d * B + b) * H + unit] : 0.f;
   float car = 0.f;   // GRU: dh_{t'} * z_{t'}; LSTM: dc_{t'} * f_{t'} of the step processed before
-#if LR_RNNC_UNCOND_FETCH
-  struct In { float dy, g[G], ex, prev, pmask; };   // prev counts when pmask = 1 (0: no state before the first step)
-  const int bq = alive ? b : 0, uq = alive ? unit : 0;
-#else
   struct In { float dy, g[G], ex, prev; };
-#endif
   In inA, inB;       // operands of even / odd steps, fetched TWO steps ahead
   auto time_of = [&](int s) {
     const int sc = s < T ? s : T - 1;
     return d == 0 ? T - 1 - sc : sc;
   };
-#if LR_RNNC_UNCOND_FETCH
-  // (the forward's variant, see there: every thread loads, from element (0, 0) when it has no (sample, unit) — what it
-  // makes of the values is multiplied by `live` anyway —, and the previous state comes from ONE address chosen by
-  // wave-uniform conditions; where there is none, an in-clip address is loaded and pmask = 0 drops it at its use)
-  auto fetch = [&](In& in, int t) {
-    const int tp = d == 0 ? t - 1 : t + 1;
-    const bool inside = tp >= 0 && tp < T;
-    const int64_t bt = (int64_t)bq * T + t, btp = (int64_t)bq * T + (inside ? tp : t);
-    in.dy = dy[bt * DH + d * H + uq];
-    const float* gi = gates + (bt * D + d) * (int64_t)(G * H) + uq;
-#pragma unroll
-    for (int g = 0; g < G; ++g) in.g[g] = gi[(int64_t)g * H];
-    in.ex = extra[(bt * D + d) * H + uq];
-    const float* src = G == 3 ? h0 : c0;     // the state before the first step (decoder loop), else zero
-    const float* pin = G == 3 ? y + btp * DH + d * H + uq : extra + (btp * D + d) * H + uq;
-    const float* pp = (inside || !src) ? pin : src + ((int64_t)d * B + bq) * H + uq;
-    in.prev = *pp;
-    in.pmask = (inside || src) ? 1.f : 0.f;
-  };
-#else
   auto fetch = [&](In& in, int t) {
     in.dy = in.ex = in.prev = 0.f;
 #pragma unroll
@@ -676,7 +633,6 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
       if (src) in.prev = src[((int64_t)d * B + b) * H + unit];
     }
   };
-#endif
   fetch(inA, time_of(0));
   fetch(inB, time_of(1));
   const int xdst = CC * XMEMBER, xcluster = CC * xdst, xslot = nclusters * xcluster;   // words (32-bit: scalar multiplies)
@@ -835,11 +791,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
     if (G == 3) {
       // rnn_bwd_step_kernel<3>
       dh += car;   // dh_{t+1} * z_{t+1}
-#if LR_RNNC_UNCOND_FETCH
-      const float r = in.g[0], z = in.g[1], n = in.g[2], hn = in.ex, hp = in.prev * in.pmask;
-#else
       const float r = in.g[0], z = in.g[1], n = in.g[2], hn = in.ex, hp = in.prev;
-#endif
       const float dn_pre = live ? dh * (1.f - z) * (1.f - n * n) : 0.f;
       const float dr_pre = dn_pre * hn * r * (1.f - r);
       const float dz_pre = live ? dh * (hp - n) * z * (1.f - z) : 0.f;
@@ -853,11 +805,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
       kv[2] = dn_pre * r;    // recurrent path of the n gate: d/d(W_hn h + b_hn)
     } else {
       // rnn_bwd_step_kernel<4>
-#if LR_RNNC_UNCOND_FETCH
-      const float ig = in.g[0], fg = in.g[1], gg = in.g[2], og = in.g[G - 1], ct = in.ex, cp = in.prev * in.pmask;
-#else
       const float ig = in.g[0], fg = in.g[1], gg = in.g[2], og = in.g[G - 1], ct = in.ex, cp = in.prev;
-#endif
       float dc = car;
       if (is_last) dc += inj_c;
       float di = 0.f, df = 0.f, dg_ = 0.f, do_ = 0.f;

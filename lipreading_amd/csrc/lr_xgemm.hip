@@ -19,10 +19,10 @@
 // K-contiguous ([rows][K]; operands that are row-contiguous in memory are transposed on the way,
 // 32x32 tiles through LDS).  Splitting inside the contraction instead costs ~8 VALU lane-ops per
 // element per tile that uses it — measured 2x the MFMA time at 128x128 tiles.  (2) contract: 256
-// threads = 2x2 waves, workgroup tile 128x128, wave tile 64x64 (2x2 MFMA tiles), BK = 32 per LDS
-// stage; plane tiles are staged as bf16 [row][32 + 8] (80-byte rows: the 16-byte fragment reads of
-// 16 consecutive rows cover all 64 banks exactly once); three stages of 16-byte global loads stay
-// in flight per workgroup (register ring) behind LDS-only barriers; K is split over workgroups
+// threads = 2x2 waves, workgroup tile 128x128, wave tile 64x64 (2x2 MFMA tiles), BK = 64 per LDS
+// stage; plane tiles are staged as bf16 [row][64 + 8] (144-byte rows: conflict-free for the fragment
+// reads' lane groups); one stage of 16-byte global loads is in flight per workgroup (issued right behind
+// the previous stage's LDS write) behind LDS-only barriers; K is split over workgroups
 // until ~2 are resident per CU, partial sums reduced in fixed order (deterministic); tiles are
 // ordered so that the ~64 resident on one XCD share operand panels in its L2.
 //
@@ -46,20 +46,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short bf16_t;
 
-// LR_XBK = 64: a build-time variant for A/B timing (tools/build_variant.sh with VARIANT_DEFS=-DLR_XBK=64; untimed, off):
-// 64-k stages — half the barriers and fragment-read restarts per MFMA — with ONE stage of loads in flight (the next
-// stage's loads are issued right after this stage's LDS write and land under its 32-48 MFMAs per wave; two register
-// sets of 64-k stages do not fit two workgroups per CU: 232 + 64 registers).  Rows of 64 + 8 elements (144 bytes) are
-// as conflict-free for the fragment reads' lane groups as the 80-byte rows of the 32-k stage.  The default build's
-// code is unchanged instruction for instruction.
-#ifndef LR_XBK
-#define LR_XBK 32
-#endif
-static_assert(LR_XBK == 32 || LR_XBK == 64, "stage depth");
-constexpr int XBM = 128, XBN = 128, XBK = LR_XBK, XLD = XBK + 8;
-constexpr int XDEPTH = XBK == 32 ? 3 : 1;     // stages of global loads in flight
+// 64-k stages — half the barriers and fragment-read restarts per MFMA of a 32-k stage — with ONE stage of loads in
+// flight: the next stage's loads are issued right after this stage's LDS write and land under its 32-48 MFMAs per wave
+// (two register sets of 64-k stages do not fit two workgroups per CU: 232 + 64 registers).  Rows of 64 + 8 elements (144
+// bytes) are as conflict-free for the fragment reads' lane groups as the 80-byte rows of a 32-k stage.
+// MEASURED (round 4, same box) against rounds 1-3's 32-k stages behind a three-slot register ring (whose first slot's LDS
+// write drained the two younger stages as well — hipcc's wait counts for loads issued and consumed under conditions):
+// pixel step 2.59 -> 2.55 ms; K = 3456 projection 102.9 -> 99.3 us, its dx 79.3 -> 73.5, the other shapes within 1 %.
+constexpr int XBM = 128, XBN = 128, XBK = 64, XLD = XBK + 8;
+constexpr int XDEPTH = 1;                     // stages of global loads in flight
 constexpr int XUPR = XBK / 8;                 // 16-byte units per plane-tile row
-constexpr int XUSH = XBK == 32 ? 2 : 3;       // log2 of it
+constexpr int XUSH = 3;                       // log2 of it
 constexpr int XNU = XBM * XUPR / 256;         // units per thread and plane tile
 constexpr int XGROUP_M = 4;   // m-panels per group of the tile order
 
@@ -252,7 +249,7 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
     g.C1 = g.Cb;
   }
 
-  // a plane tile is 128 rows x 32 k = 512 16-byte units: two per thread (row = e / 4, unit = e % 4; 64-k stages: four).  Rows past
+  // a plane tile is 128 rows x 64 k = 1024 16-byte units: four per thread (row = e / 8, unit = e % 8).  Rows past
   // the matrix edge are CLAMPED, not zeroed (their products land in accumulator rows / columns that are never
   // stored, and the planes hold finite numbers); only the K tail needs zeros, and only in a split's last stage,
   // so the loads of every other stage are unconditional (a per-load predicate makes hipcc branch around each load).
@@ -325,11 +322,11 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
     if (kbeg + sl * XBK < kend) load(sl, kbeg + sl * XBK);
   for (int kb = kbeg; kb < kend; kb += XDEPTH * XBK) {
 #pragma unroll
-    for (int sl = 0; sl < XDEPTH; ++sl) {   // fully unrolled: the ring slots are static registers
+    for (int sl = 0; sl < XDEPTH; ++sl) {   // fully unrolled: the stage registers are static
       const int k0 = kb + sl * XBK;
       if (k0 < kend) {                     // workgroup-uniform
-        // LDS-only barriers: __syncthreads() would also drain vmcnt, i.e. wait for the two younger
-        // stages still in flight, and put the whole memory latency back on every stage
+        // LDS-only barriers: __syncthreads() would also drain vmcnt (harmless with one stage in flight, whose
+        // loads were consumed by store() just above, but it is the same instruction count)
         lr_lds_barrier();
         store(sl);
         lr_lds_barrier();
@@ -338,7 +335,7 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
         // and each group of MFMAs waits out an LDS round trip), then the MFMAs run term by term over the four
         // accumulators: small terms first, so they are not absorbed by a large partial sum, and consecutive
         // MFMAs never wait for each other's result
-        auto half = [&](auto HF) {   // 32 k at a time (one pass at the default stage depth)
+        auto half = [&](auto HF) {   // 32 k at a time
           constexpr int hf = decltype(HF)::value;
           bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
   #pragma unroll
@@ -383,7 +380,7 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 2 * NMMA - NFRAG, 0);
         };
         half(std::integral_constant<int, 0>{});
-        if constexpr (XBK == 64) half(std::integral_constant<int, 1>{});
+        half(std::integral_constant<int, 1>{});
       }
     }
   }
