@@ -590,14 +590,24 @@ int lr_conv3d_forward(const void* X, const void* Wp, const float* bias, void* Y,
                       int pw, int flags, lr_stream_t stream);
 /* Forward with the ReLU -> MaxPool3d((1,2,2)) that follows it fused into the epilogue, for layers
  * with lr_conv3d_pool_fusion_supported() == 1: P bf16 [B][T][Ho/2][Wo/2][Cout] receives the pooled
- * activation and code (uint8, same shape) the position 0..3 (row-major in the 2x2 window) of each
- * window's first maximum; the full-resolution activation is never written.  Backward of the pair:
- * lr_unpool_code_bf16. */
+ * activation and code (uint8, same shape) each window's CODE: the position 0..3 (row-major in the 2x2
+ * window) of its first maximum, or 4 when the pooled activation is 0 (ReLU blocks the window's gradient);
+ * the full-resolution activation is never written.  Backward of the pair: lr_unpool_code_bf16 (materialises
+ * dZ), or — never writing dZ — lr_conv3d_dgrad_pooled / lr_conv3d_wgrad_pooled. */
 int lr_conv3d_pool_fusion_supported(int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW, int stride,
                                     int pt, int ph, int pw);
 int lr_conv3d_forward_pooled(const void* X, const void* Wp, const float* bias, void* P, void* code, int B,
                              int T, int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW, int stride,
                              int pt, int ph, int pw, int flags, lr_stream_t stream);
+/* Data gradient of a stride-1 "same" layer whose forward fused ReLU + MaxPool, taken straight from the pooled
+ * gradient dP bf16 [B][T][Ho/2][Wo/2][Cout] and the window codes (uint8, same shape): dX bf16 [B][T][Ho][Wo][Cin]
+ * = conv(un-pool(dP, code), flipped / channel-transposed weights).  The kernel rebuilds its dZ patch on the way
+ * into LDS; dZ itself (Ho x Wo, 75 % zeros) is never written.  Wd: lr_conv3d_pack_weights with the dgrad flag and
+ * the fragment bit `_supported` returns (0: not supported — use lr_unpool_code_bf16 + lr_conv3d_forward).
+ * Build-defined like the rest of the frontend (no reference symbol). */
+int lr_conv3d_dgrad_pooled_supported(int Ho, int Wo, int Cout, int Cin, int KT, int KH, int KW, int pt, int ph, int pw);
+int lr_conv3d_dgrad_pooled(const void* dP, const void* code, const void* Wd, void* dX, int B, int T, int Ho, int Wo,
+                           int Cout, int Cin, int KT, int KH, int KW, int pt, int ph, int pw, lr_stream_t stream);
 /* Non-zero when the layer (as lr_conv3d_forward sees it: Cin = contraction channels, Cout = output
  * channels) has a patch-resident kernel — the input patch of an output tile is loaded into LDS
  * once and all taps run out of LDS, instead of re-gathering it per tap.  The value is the weight

@@ -97,6 +97,8 @@ SIGNATURES = {
     "lr_conv3d_patch_supported": (c_int, [c_int] * 11),
     "lr_conv3d_pool_fusion_supported": (c_int, [c_int] * 11),
     "lr_conv3d_forward_pooled": (c_int, [P, P, P, P, P] + [c_int] * 14 + [P]),
+    "lr_conv3d_dgrad_pooled_supported": (c_int, [c_int] * 10),
+    "lr_conv3d_dgrad_pooled": (c_int, [P, P, P, P] + [c_int] * 12 + [P]),
     "lr_unpool_code_bf16": (c_int, [P, P, P, P, P, c_int, P, c_size_t, c_int64, c_int, c_int, c_int, P]),
     "lr_conv3d_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),
     "lr_conv3d_wgrad": (c_int, [P, P, P, P, P, c_size_t] + [c_int] * 15 + [P]),

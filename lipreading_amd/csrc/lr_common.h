@@ -108,8 +108,8 @@ int lr_conv1_wgrad(bool pooled, bool u8, const void* X, const void* dZ, const vo
                    hipEvent_t e0, hipEvent_t e1, hipStream_t stream);
 
 // ---- conv frontend, patch-resident forward / data gradient of the 24-wide (3,5,5) layer (lr_conv_patch.hip) ----
-int lr_conv_patch24(bool fwd, const void* X, const void* Wf, const float* bias, void* Y, unsigned char* code, int F,
-                    int T, int Hin, int relu, bool sample, hipEvent_t e0, hipEvent_t e1, hipStream_t stream);
+int lr_conv_patch24(bool fwd, bool unpool, const void* X, const void* Wf, const float* bias, void* Y, unsigned char* code,
+                    int F, int T, int Hin, int relu, bool sample, hipEvent_t e0, hipEvent_t e1, hipStream_t stream);
 
 // ---- conv frontend, weight gradient of the stride-1 layers, second form (lr_conv_wgrad.hip) ----------
 constexpr int LR_CONV_TR2_SLOTS = 85;   // slots per temporal tap: 3 x 85 = 255 workgroups, one slab each

@@ -524,7 +524,10 @@ static_assert(P3_ROWS % 28 == 0, "patch rows are loaded in batches of 7 passes x
 // (Measured and dropped, round 4: three workgroups per CU again after the fragment ring took the forward's registers
 // from 161 to 185 — 17 spilled registers in its patch fill, forward 86.9 -> 95.0 us.  The ring itself against the
 // form before it, same visit: forward 84.7 -> 86.9 us, data gradient 99.2 -> 91.6: kept.)
-template <int CG, int NT16, bool POOL>
+// UNPOOL (data gradient of a layer whose forward fused ReLU + MaxPool): X is the POOLED gradient dP [F][6][6][C] and
+// `code` the windows' codes; the fill rebuilds the dZ patch on the way into LDS (unpool8; see conv_patch_tile in
+// lr_conv_patch.hip): no un-pooling kernel in front of this one, no dZ in memory.
+template <int CG, int NT16, bool POOL, bool UNPOOL>
 __global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __restrict__ X,
                                                               const bf16_t* __restrict__ Wf,
                                                               const float* __restrict__ bias,
@@ -570,11 +573,52 @@ __global__ __launch_bounds__(256, 2) void conv_patch16_kernel(const bf16_t* __re
 #pragma unroll
     for (int j = 0; j < NT16; ++j) br[dw][j] = *reinterpret_cast<const bf16x8*>(wfl + (dw * NTT + j) * 512);
   int g = 0;
+  if constexpr (UNPOOL) {
+    // halo rows (0 and 13 of every slot) and halo columns (positions 0 and 13) are zeros for every channel group
+    for (int u = tid; u < P3_ROWS * (P3_W + 2) * 4; u += 256) {
+      const int R = u / ((P3_W + 2) * 4), q = u - R * ((P3_W + 2) * 4), pos = q >> 2, ph = R % P3_PH;
+      if (ph == 0 || ph == P3_PH - 1 || pos == 0 || pos == P3_W + 1)
+        *reinterpret_cast<uint4*>(patch + R * P3_RS + pos * 64 + (q & 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
   for (int cg = 0; cg < CG; ++cg) {
     if (cg > 0) __syncthreads();
     // patch load: a wave covers one 16-position patch row (64 sixteen-byte units) per pass, so the
     // row / slot decode is wave-uniform scalar work; batches of 7 passes, each fully in flight
-    {
+    if constexpr (UNPOOL) {
+      // pooled units of the patch: 4 slots x 6 x 6 windows x 4 chunks of 8 channels = 576, dealt flat over the threads;
+      // a window's four units go to patch rows 2 hp + 1, 2 hp + 2, positions 2 wp + 1, 2 wp + 2 (the halo rows and
+      // columns were zeroed once)
+      constexpr int UNITS = P3_SLOTS * 36 * 4, UI = (UNITS + 255) / 256;
+      uint4 dv[UI];
+      uint2 cv[UI];
+#pragma unroll
+      for (int i = 0; i < UI; ++i) {
+        const int u = tid + 256 * i, s = u / 144, r = u - 144 * s;
+        const int ff = f0 - 1 + s;
+        dv[i] = make_uint4(0u, 0u, 0u, 0u);
+        cv[i] = make_uint2(0u, 0u);
+        if (u < UNITS && ff >= 0 && ff < F) {
+          const int64_t pi = ((int64_t)ff * 36 + (r >> 2)) * C + cg * 32 + (r & 3) * 8;
+          dv[i] = *reinterpret_cast<const uint4*>(X + pi);
+          cv[i] = *reinterpret_cast<const uint2*>(code + pi);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < UI; ++i) {
+        const int u = tid + 256 * i, s = u / 144, r = u - 144 * s;
+        if (u < UNITS) {
+          uint4 o[4];
+          unpool8(dv[i], cv[i], o);
+          const int win = r >> 2, hp = win / 6, wp = win - 6 * hp;
+          unsigned char* dst = patch + (s * P3_PH + 2 * hp + 1) * P3_RS + (2 * wp + 1) * 64 + (r & 3) * 16;
+          *reinterpret_cast<uint4*>(dst) = o[0];
+          *reinterpret_cast<uint4*>(dst + 64) = o[1];
+          *reinterpret_cast<uint4*>(dst + P3_RS) = o[2];
+          *reinterpret_cast<uint4*>(dst + P3_RS + 64) = o[3];
+        }
+      }
+    } else {
       const int pw = (tid & 63) >> 2, c = tid & 3;
       const bool tvalid = pw >= 1 && pw <= P3_W;
       const bf16_t* xt = X + ((int64_t)(pw - 1)) * C + cg * 32 + c * 8;
@@ -1096,11 +1140,14 @@ extern "C" int lr_conv3d_pool_fusion_supported(int Hin, int Win, int Cin, int Co
 
 // code == nullptr: Y = full-resolution activation; else Y = ReLU -> MaxPool((1,2,2)) of it and code =
 // position of each window's first maximum (layers with lr_conv3d_pool_fusion_supported only)
+// ucode != nullptr (data gradients through the patch-resident kernels only): X is the POOLED gradient
+// [B][T][Hin/2][Win/2][Cin] and ucode the windows' codes; the kernel un-pools on the way into LDS.
 static int conv_forward_impl(const void* X, const void* Wp, const float* bias, void* Y, unsigned char* code, int B,
                              int T, int Hin, int Win, int Cin, int Cout, int KT, int KH, int KW, int stride, int pt,
-                             int ph, int pw, int flags, lr_stream_t stream) {
+                             int ph, int pw, int flags, lr_stream_t stream, const unsigned char* ucode = nullptr) {
   LR_CHECK_ARG(X && Wp && Y);
   const int relu = flags & 1;
+  if (ucode && (code || relu || bias || !(flags & 6))) return LR_ERR_UNSUPPORTED;
   const bool u8 = (flags & 8) != 0;   // X is the raw uint8 planar clip: first-layer patch kernel only
   if (u8 && !(Cin == 4 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 && ph == 2 && pw == 2))
     return LR_ERR_UNSUPPORTED;
@@ -1120,7 +1167,7 @@ static int conv_forward_impl(const void* X, const void* Wp, const float* bias, v
     hipEvent_t e0, e1;
     const bool fwd = Cin == 64;
     const bool sample = lr_prof_next(fwd ? LR_PROF_CONV3_FWD : LR_PROF_CONV3_DGRAD, &e0, &e1);
-    static bool attr16[3] = {false, false, false};
+    static bool attr16[4] = {false, false, false, false};
     lr_clear_error();
 #define LR_PATCH16(IDX, ...)                                                                                    \
   do {                                                                                                         \
@@ -1135,9 +1182,12 @@ static int conv_forward_impl(const void* X, const void* Wp, const float* bias, v
     else hipLaunchKernelGGL((conv_patch16_kernel<__VA_ARGS__>), pgrid, dim3(256), P3_LDS, (hipStream_t)stream,  \
                             x, w, bias, y, code, F, T, relu);                                                  \
   } while (0)
-    if (fwd && code) LR_PATCH16(2, 2, 6 / P3_NSPL, true);
-    else if (fwd) LR_PATCH16(0, 2, 6 / P3_NSPL, false);
-    else LR_PATCH16(1, 3, 4 / P3_NSPL, false);
+    if (ucode && fwd) return LR_ERR_UNSUPPORTED;
+    if (ucode) code = const_cast<unsigned char*>(ucode);
+    if (fwd && code) LR_PATCH16(2, 2, 6 / P3_NSPL, true, false);
+    else if (fwd) LR_PATCH16(0, 2, 6 / P3_NSPL, false, false);
+    else if (ucode) LR_PATCH16(3, 3, 4 / P3_NSPL, false, true);
+    else LR_PATCH16(1, 3, 4 / P3_NSPL, false, false);
 #undef LR_PATCH16
     return lr_launch_status();
   }
@@ -1147,7 +1197,9 @@ static int conv_forward_impl(const void* X, const void* Wp, const float* bias, v
     hipEvent_t e0, e1;
     const bool fwd = Cin == 32;
     const bool sample = lr_prof_next(fwd ? LR_PROF_CONV2_FWD : LR_PROF_CONV2_DGRAD, &e0, &e1);
-    return lr_conv_patch24(fwd, x, w, bias, y, code, B * T, T, Hin, relu, sample, e0, e1, (hipStream_t)stream);
+    if (ucode && fwd) return LR_ERR_UNSUPPORTED;
+    return lr_conv_patch24(fwd, ucode != nullptr, x, w, bias, y, ucode ? const_cast<unsigned char*>(ucode) : code, B * T, T,
+                           Hin, relu, sample, e0, e1, (hipStream_t)stream);
   }
   if (code && Cin != 4) return LR_ERR_UNSUPPORTED;   // the second layer's fused pooling lives in the patch kernel
   if (Cin == 4 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 && ph == 2 && pw == 2) {
@@ -1192,6 +1244,24 @@ extern "C" int lr_conv3d_forward(const void* X, const void* Wp, const float* bia
                                  int stride, int pt, int ph, int pw, int flags, lr_stream_t stream) {
   return conv_forward_impl(X, Wp, bias, Y, nullptr, B, T, Hin, Win, Cin, Cout, KT, KH, KW, stride, pt, ph, pw, flags,
                            stream);
+}
+
+extern "C" int lr_conv3d_dgrad_pooled_supported(int Ho, int Wo, int Cout, int Cin, int KT, int KH, int KW, int pt, int ph,
+                                                int pw) {
+  // the data gradient of a stride-1 "same" convolution is the forward kernel on dZ (Cout channels) with the flipped,
+  // channel-transposed weights: supported where that product has a patch-resident kernel
+  if (Ho <= 0 || Wo <= 0 || (Ho & 1) || (Wo & 1)) return 0;
+  return lr_conv3d_patch_supported(Ho, Wo, Cout, Cin, KT, KH, KW, 1, pt, ph, pw);
+}
+
+extern "C" int lr_conv3d_dgrad_pooled(const void* dP, const void* code, const void* Wd, void* dX, int B, int T, int Ho,
+                                      int Wo, int Cout, int Cin, int KT, int KH, int KW, int pt, int ph, int pw,
+                                      lr_stream_t stream) {
+  LR_CHECK_ARG(dP && code && Wd && dX);
+  const int frag = lr_conv3d_dgrad_pooled_supported(Ho, Wo, Cout, Cin, KT, KH, KW, pt, ph, pw);
+  if (!frag) return LR_ERR_UNSUPPORTED;
+  return conv_forward_impl(dP, Wd, nullptr, dX, nullptr, B, T, Ho, Wo, Cout, Cin, KT, KH, KW, 1, pt, ph, pw, frag, stream,
+                           (const unsigned char*)code);
 }
 
 extern "C" int lr_conv3d_forward_pooled(const void* X, const void* Wp, const float* bias, void* P, void* code,

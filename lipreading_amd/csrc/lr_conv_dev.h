@@ -18,8 +18,10 @@ __device__ __forceinline__ float bf2f(bf16_t v) {
   return __builtin_bit_cast(float, (unsigned)v << 16);
 }
 
-// ReLU -> 2x2 max-pool of one window in the forward epilogues: the bf16 value that is stored and the position
-// (row-major scan) of its FIRST maximum, torch's rule, decided on the values that would have been stored.  The
+// ReLU -> 2x2 max-pool of one window in the forward epilogues: the bf16 value that is stored and the window's CODE:
+// the position (row-major scan) of its FIRST maximum, torch's rule, decided on the values that would have been stored
+// — or 4 when that maximum is 0, i.e. when ReLU blocks the window's gradient (no position matches 4: the backward
+// kernels that un-pool on the way into LDS, unpool8 below, then need neither the pooled activation nor a compare).  The
 // epilogues are VALU-bound (the layer-2 forward spends 6.6 k cycles of a tile's 81 k here, 48 windows per lane:
 // s_memtime, round 3), so this is written to be few instructions: the four a + bias are converted two per
 // instruction; ReLU is a packed signed-integer max with 0 on the bf16 BIT PATTERNS (a negative float — and -0 — is a
@@ -40,7 +42,24 @@ __device__ __forceinline__ void relu_pool4(float a0, float a1, float a2, float a
   const unsigned k01 = k0 > k1 ? k0 : k1, k23 = k2 > k3 ? k2 : k3;
   const unsigned k = k01 > k23 ? k01 : k23;
   best = (bf16_t)(k >> 16);
-  arg = (int)(~k & 3u);
+  arg = k < 0x10000u ? 4 : (int)(~k & 3u);
+}
+
+// The backward of ReLU -> MaxPool((1,2,2)) for 8 channels of one window, in registers: d = the window's pooled
+// gradient (8 bf16), cc = its 8 codes (relu_pool4: 0..3 = position of the maximum, 4 = blocked by ReLU); o[j] = the
+// gradient of position j (row-major in the window): d where the code is j, zero elsewhere.  Byte arithmetic on four
+// codes at a time: x = codes ^ jjjj is zero exactly in the matching bytes, and with every byte of x <= 7 the
+// byte-wise 8 - x (no borrows) has bit 3 set exactly there; (m << 5) - (m >> 3) spreads each such bit into 0xff of
+// its byte; v_perm_b32 doubles the bytes into 16-bit lane masks.  20 VALU per position.
+__device__ __forceinline__ void unpool8(const uint4 d, const uint2 cc, uint4 (&o)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned x0 = cc.x ^ (0x01010101u * (unsigned)j), x1 = cc.y ^ (0x01010101u * (unsigned)j);
+    const unsigned m0 = (0x08080808u - x0) & 0x08080808u, m1 = (0x08080808u - x1) & 0x08080808u;
+    const unsigned b0 = (m0 << 5) - (m0 >> 3), b1 = (m1 << 5) - (m1 >> 3);
+    o[j] = make_uint4(d.x & __builtin_amdgcn_perm(b0, b0, 0x01010000u), d.y & __builtin_amdgcn_perm(b0, b0, 0x03030202u),
+                      d.z & __builtin_amdgcn_perm(b1, b1, 0x01010000u), d.w & __builtin_amdgcn_perm(b1, b1, 0x03030202u));
+  }
 }
 
 // Two ds_read_b64_tr_b16 (gfx950 LDS transpose read) -> one MFMA operand.  16 lanes read a

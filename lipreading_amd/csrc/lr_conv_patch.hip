@@ -47,7 +47,12 @@ constexpr int kChipCUs = 256;                      // one workgroup of this kern
 // SPLIT = true (the launch's LAST tiles, see conv_patch_kernel): a tile of FT = 1 (NT = 2) or 2 (NT = 1) frames
 // whose accumulator tiles are dealt to the four waves — three row tiles x one column tile each — so that it takes
 // 1/4 (1/2) of a whole tile's time; same patch layout, same per-accumulator MFMA order (results are bit-identical).
-template <int CG, int NT, bool POOL, bool SPLIT>
+// UNPOOL (data gradient of a layer whose forward fused ReLU + MaxPool): X is the POOLED gradient dP [F][H/2][12][C]
+// and `code` the windows' codes (relu_pool4); the fill rebuilds the full-resolution dZ patch on the way into LDS —
+// a thread loads 16 bytes of dP and 8 codes and stores the window's four 16-byte units (unpool8) — so dZ is never
+// written to or read from memory (round 3: a 114 us HBM-bound un-pooling kernel in front of this one, 177 MB written
+// and read back, 75 % of it zeros), and the fill loads 3/8 of the bytes with 14 load instructions per thread, not 36.
+template <int CG, int NT, bool POOL, bool SPLIT, bool UNPOOL>
 __device__ __forceinline__ void conv_patch_tile(unsigned char* __restrict__ patch, const bf16_t* __restrict__ X,
                                                 const bf16_t* __restrict__ Wf, const float* __restrict__ bias,
                                                 bf16_t* __restrict__ Y, unsigned char* __restrict__ code, int F, int T,
@@ -88,6 +93,14 @@ __device__ __forceinline__ void conv_patch_tile(unsigned char* __restrict__ patc
   const int a_h = ((lr >> 1) & 1) + 2 * (lr >> 3), a_w = (lr & 1) + 2 * ((lr >> 2) & 1);
   // byte offset of this lane's pixel in its first row tile (chunk bits added per tap row)
   const int base_b = (fi * P2_PH + a_h) * P2_RS + a_w * 64 + g0 * (3 * 256);
+  if constexpr (UNPOOL) {
+    // the halo columns of every patch row are zeros for every channel group: written once (the fill below only
+    // touches positions 2 .. 25)
+    for (int u = tid; u < (FT + 2) * P2_PH * 16; u += 256) {
+      const int q = (u >> 2) & 3;
+      *reinterpret_cast<uint4*>(patch + (u >> 4) * P2_RS + (q < 2 ? q : P2_W + q) * 64 + (u & 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
   for (int cg = 0; cg < CG; ++cg) {
     if (cg > 0) __syncthreads();   // every wave is done with the previous channel group's patch
     // ---- load the patch -------------------------------------------------------------------------
@@ -97,7 +110,50 @@ __device__ __forceinline__ void conv_patch_tile(unsigned char* __restrict__ patc
     // loads, each issued completely before its first store.
     // (One batch of 36 — every load of a fill in flight before the first store — measured the same forward and 1 %
     // slower in the data gradient, round 3: the fill runs at the rate of the CU's outstanding misses either way.)
-    {
+    if constexpr (UNPOOL) {
+      // pooled units of the patch: (FT + 2) slots x 6 pooled rows x 12 pooled columns x 4 chunks of 8 channels, dealt
+      // flat over the 256 threads (unit u = tid + 256 i: row = u / 48 counts slots and pooled rows together, so the
+      // two patch rows of a window are 2 row, 2 row + 1); the halo columns (positions 0, 1, 26, 27) were zeroed once
+      constexpr int UROWS = (FT + 2) * (P2_PH / 2), UNITS = UROWS * 48, UI = (UNITS + 255) / 256;
+      const int Hp = H >> 1, hp0 = (h0 >> 1) - 1;
+      uint4 dv[UI];
+      uint2 cv[UI];
+      int row = tid / 48, rem = tid - 48 * row;
+      int orow[UI], orem[UI];
+#pragma unroll
+      for (int i = 0; i < UI; ++i) {
+        orow[i] = row;
+        orem[i] = rem;
+        const int s = (row * 43) >> 8, pr = row - 6 * s;   // slot, pooled row of the slot (row < 48)
+        const int ff = f0 - 1 + s, hp = hp0 + pr;
+        dv[i] = make_uint4(0u, 0u, 0u, 0u);
+        cv[i] = make_uint2(0u, 0u);
+        if (row < UROWS && ff >= 0 && ff < F && hp >= 0 && hp < Hp) {
+          const int64_t pi = (((int64_t)ff * Hp + hp) * (P2_W / 2) + (rem >> 2)) * C + cg * 32 + (rem & 3) * 8;
+          dv[i] = *reinterpret_cast<const uint4*>(X + pi);
+          cv[i] = *reinterpret_cast<const uint2*>(code + pi);
+        }
+        rem += 256 % 48;
+        row += 256 / 48;
+        if (rem >= 48) {
+          rem -= 48;
+          row += 1;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < UI; ++i) {
+        if (orow[i] < UROWS) {
+          uint4 o[4];
+          unpool8(dv[i], cv[i], o);
+          const int c = orem[i] & 3, sw = (c ^ (2 * (orow[i] & 1))) << 4;   // swizzle key of patch row 2 row (+ 1: ^ 16)
+          unsigned char* dst = patch + (2 * orow[i]) * P2_RS + (2 * (orem[i] >> 2) + 2) * 64;
+          *reinterpret_cast<uint4*>(dst + sw) = o[0];
+          *reinterpret_cast<uint4*>(dst + 64 + sw) = o[1];
+          *reinterpret_cast<uint4*>(dst + P2_RS + (sw ^ 16)) = o[2];
+          *reinterpret_cast<uint4*>(dst + P2_RS + 64 + (sw ^ 16)) = o[3];
+        }
+      }
+    } else {
       const int rp = tid >= 112 ? 1 : 0, un = tid - 112 * rp;   // row of the pair, unit in the row
       const int pw = un >> 2, c = un & 3;
       const bool tvalid = tid < 224 && pw >= 2 && pw < P2_W + 2;
@@ -367,7 +423,7 @@ __device__ __forceinline__ void conv_patch_tile(unsigned char* __restrict__ patc
 // CU when they are few (1800 tiles on 256 CUs: 7 rounds + 8 tiles, which used to cost an eighth round).
 // (256 PERSISTENT workgroups looping over their seven tiles instead of a workgroup per tile: the same within 1 %,
 // round 3 — the dispatcher's relaunch of a 150 KB-LDS workgroup is not what the rounds lose.)
-template <int CG, int NT, bool POOL>
+template <int CG, int NT, bool POOL, bool UNPOOL>
 __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __restrict__ X,
                                                             const bf16_t* __restrict__ Wf,
                                                             const float* __restrict__ bias,
@@ -381,23 +437,24 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
     // neighbours in time and height and find each other's halo rows in that XCD's L2 instead of re-fetching them.
     const int xcd = blockIdx.x & 7, per_xcd = nfull >> 3, rem_xcd = nfull & 7;
     const int tile = xcd * per_xcd + (xcd < rem_xcd ? xcd : rem_xcd) + (int)(blockIdx.x >> 3);
-    conv_patch_tile<CG, NT, POOL, false>(patch, X, Wf, bias, Y, code, F, T, H, relu, (tile / htiles) * P2_TT,
+    conv_patch_tile<CG, NT, POOL, false, UNPOOL>(patch, X, Wf, bias, Y, code, F, T, H, relu, (tile / htiles) * P2_TT,
                                          (tile % htiles) * P2_TH);
   } else {
     constexpr int FT = NT == 2 ? 1 : 2, PER = P2_TT / FT;
     const int sb = (int)blockIdx.x - nfull;
     const int tile = nfull + sb / PER;
-    conv_patch_tile<CG, NT, POOL, true>(patch, X, Wf, bias, Y, code, F, T, H, relu,
+    conv_patch_tile<CG, NT, POOL, true, UNPOOL>(patch, X, Wf, bias, Y, code, F, T, H, relu,
                                         (tile / htiles) * P2_TT + (sb % PER) * FT, (tile % htiles) * P2_TH);
   }
 }
 
 }  // namespace
 
-// fwd: 32 -> 64 channels (code != nullptr: fused ReLU + 2x2 max-pool epilogue); else the data gradient, 64 -> 32.
+// fwd: 32 -> 64 channels (code != nullptr: fused ReLU + 2x2 max-pool epilogue); else the data gradient, 64 -> 32
+// (unpool: X is the pooled gradient [F][Hin/2][12][64] and code the windows' codes, see conv_patch_tile).
 // Wf: fragment-major weights (lr_conv3d_pack_weights, frag = 2).  H % 8 == 0, width 24.
-int lr_conv_patch24(bool fwd, const void* X, const void* Wf, const float* bias, void* Y, unsigned char* code, int F,
-                    int T, int Hin, int relu, bool sample, hipEvent_t e0, hipEvent_t e1, hipStream_t stream) {
+int lr_conv_patch24(bool fwd, bool unpool, const void* X, const void* Wf, const float* bias, void* Y, unsigned char* code,
+                    int F, int T, int Hin, int relu, bool sample, hipEvent_t e0, hipEvent_t e1, hipStream_t stream) {
   const bf16_t* x = (const bf16_t*)X;
   const bf16_t* w = (const bf16_t*)Wf;
   bf16_t* y = (bf16_t*)Y;
@@ -408,7 +465,7 @@ int lr_conv_patch24(bool fwd, const void* X, const void* Wf, const float* bias, 
   const int nsplit = ntiles > kChipCUs && left > 0 && left <= kChipCUs / 4 ? left : 0;
   const int nfull = ntiles - nsplit;
   const dim3 pgrid((unsigned)(nfull + nsplit * (fwd ? 4 : 2)));
-  static bool attr_set[3] = {false, false, false};
+  static bool attr_set[4] = {false, false, false, false};
   lr_clear_error();
 #define LR_PATCH(IDX, ...)                                                                                     \
   do {                                                                                                        \
@@ -423,9 +480,11 @@ int lr_conv_patch24(bool fwd, const void* X, const void* Wf, const float* bias, 
     else hipLaunchKernelGGL((conv_patch_kernel<__VA_ARGS__>), pgrid, dim3(256), P2_LDS + 4 * P2_STAGE, stream, x, w, bias, y, \
                             code, F, T, Hin, relu, nfull);                                                    \
   } while (0)
-  if (fwd && code) LR_PATCH(2, 1, 2, true);
-  else if (fwd) LR_PATCH(0, 1, 2, false);
-  else LR_PATCH(1, 2, 1, false);
+  if (unpool && (fwd || !code)) return LR_ERR_UNSUPPORTED;
+  if (fwd && code) LR_PATCH(2, 1, 2, true, false);
+  else if (fwd) LR_PATCH(0, 1, 2, false, false);
+  else if (unpool) LR_PATCH(3, 2, 1, false, true);
+  else LR_PATCH(1, 2, 1, false, false);
 #undef LR_PATCH
   return lr_launch_status();
 }

@@ -37,6 +37,9 @@ _PATCH_KERNELS = True
 # ... and this one to compare the first layer's fused paths (raw uint8 clip into the kernels, weight
 # gradient that un-pools on the fly) with the staged ones (bf16 clip copy, materialised dZ)
 _FUSE_FIRST_LAYER = True
+# ... and this one to compare the data gradients that un-pool on the fly (lr_conv3d_dgrad_pooled: layers 2 and 3 take
+# the pooled gradient and the window codes) with the staged form (lr_unpool_code_bf16, then lr_conv3d_forward on dZ)
+_FUSE_UNPOOL = True
 
 
 def _pad4(c):
@@ -197,9 +200,61 @@ class _ConvFrontendFunction(torch.autograd.Function):
                                           1 if direct else 0, B, T, h, w, cin_p, cin, cout, kt, kh, kw, stride, pt,
                                           ph, pw, 1 if x_in.dtype == torch.uint8 else 0, st), "lr_conv3d_wgrad_pooled")
         continue
+      coded = act.dtype == torch.uint8   # the forward fused the pooling: act holds the window codes
+      # data gradient of a stride-1 "same" convolution = the forward kernel on dZ with the flipped,
+      # channel-transposed weights (packed with the forward operands: nothing updates the weights in between)
+      wd = frag = None
+      if li > 0:
+        if li in ctx.dgrad_ops:
+          wd, frag = ctx.dgrad_ops[li]
+        else:
+          wd = torch.empty((cin, kt * kh * kw, cout), dtype=bf, device=dev)
+          frag = L.lr_conv3d_patch_supported(ho, wo, cout, cin, kt, kh, kw, 1, pt, ph, pw) if _PATCH_KERNELS else 0
+          _C.check(L.lr_conv3d_pack_weights(params[2 * li].data_ptr(), wd.data_ptr(), cout, cin, cin_p, kt,
+                                            kh, kw, 1 | frag, st), "lr_conv3d_pack_weights")
+      # ... taken STRAIGHT from the pooled gradient and the window codes where the layer has the kernel: the layer
+      # below only waits for this, and the un-pooled dZ (75 % zeros) then exists for the weight gradient alone
+      dP_in = dP
+      fused_dgrad = bool(li > 0 and coded and _FUSE_UNPOOL and frag and frag == L.lr_conv3d_dgrad_pooled_supported(
+          ho, wo, cout, cin, kt, kh, kw, pt, ph, pw))
+      if fused_dgrad:
+        dP = torch.empty((frames, h, w, cin), dtype=bf, device=dev)
+        _C.check(L.lr_conv3d_dgrad_pooled(dP_in.data_ptr(), act.data_ptr(), wd.data_ptr(), dP.data_ptr(), B, T, ho, wo,
+                                          cout, cin, kt, kh, kw, pt, ph, pw, st), "lr_conv3d_dgrad_pooled")
+
+      def weight_half(accumulate, stream):
+        # un-pool (the bias gradient — the sum of the routed gradients — falls out of that pass), then dW
+        dZ = torch.empty((frames, ho, wo, cout), dtype=bf, device=dev)
+        if coded:
+          _C.check(L.lr_unpool_code_bf16(pooled.data_ptr(), act.data_ptr(), dP_in.data_ptr(), dZ.data_ptr(),
+                                         grads[2 * li + 1].data_ptr(), accumulate, ws.data_ptr(), wbytes,
+                                         frames, ho, wo, cout, stream), "lr_unpool_code_bf16")
+        else:
+          _C.check(L.lr_unpool_relu_mask_bf16(act.data_ptr(), dP_in.data_ptr(), dZ.data_ptr(),
+                                              grads[2 * li + 1].data_ptr(), accumulate, ws.data_ptr(), wbytes,
+                                              frames, ho, wo, cout, stream), "lr_unpool_relu_mask_bf16")
+        _C.check(L.lr_conv3d_wgrad(x_in.data_ptr(), dZ.data_ptr(), grads[2 * li].data_ptr(),
+                                   None, ws.data_ptr(), wbytes, accumulate,
+                                   B, T, h, w, cin_p, cin, cout, kt, kh, kw, stride, pt, ph, pw, stream),
+                 "lr_conv3d_wgrad")
+        return dZ
+
+      on_side = _WGRAD_SIDE_STREAM and direct and li > 0 and (_WGRAD_SIDE_ENV == "1" or _enc._deferred)
+      if on_side and fused_dgrad:
+        # the whole weight half (un-pooling included) runs on a side stream beside the data gradient, joined at the
+        # end of this backward
+        side = _conv_side_stream(dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+          dZ = weight_half(1, _C.stream_handle())
+        side_keep.append((x_in, dZ, ws, dP_in))
+        continue
+      if fused_dgrad:
+        weight_half(1 if direct else 0, st)
+        continue
       dZ = torch.empty((frames, ho, wo, cout), dtype=bf, device=dev)
       # the bias gradient (sum of the routed gradients) falls out of the un-pooling pass
-      if act.dtype == torch.uint8:   # the forward fused the pooling: act holds the window codes
+      if coded:
         _C.check(L.lr_unpool_code_bf16(pooled.data_ptr(), act.data_ptr(), dP.data_ptr(), dZ.data_ptr(),
                                        grads[2 * li + 1].data_ptr(), 1 if direct else 0, ws.data_ptr(), wbytes,
                                        frames, ho, wo, cout, st), "lr_unpool_code_bf16")
@@ -207,7 +262,7 @@ class _ConvFrontendFunction(torch.autograd.Function):
         _C.check(L.lr_unpool_relu_mask_bf16(act.data_ptr(), dP.data_ptr(), dZ.data_ptr(),
                                             grads[2 * li + 1].data_ptr(), 1 if direct else 0, ws.data_ptr(), wbytes,
                                             frames, ho, wo, cout, st), "lr_unpool_relu_mask_bf16")
-      if _WGRAD_SIDE_STREAM and direct and li > 0 and (_WGRAD_SIDE_ENV == "1" or _enc._deferred):
+      if on_side:
         # the weight gradient and the data gradient of a layer both read dZ and feed nothing to each other: the
         # weight gradient goes to a side stream (joined at the end of this backward), the data gradient — which
         # the layer below waits for — stays on this one
@@ -225,15 +280,6 @@ class _ConvFrontendFunction(torch.autograd.Function):
                                    B, T, h, w, cin_p, cin, cout, kt, kh, kw, stride, pt, ph, pw, st),
                  "lr_conv3d_wgrad")
       if li > 0:
-        # data gradient of a stride-1 "same" convolution = the forward kernel on dZ with the
-        # flipped, channel-transposed weights
-        if li in ctx.dgrad_ops:   # packed with the forward operands (same weights: nothing updates them in between)
-          wd, frag = ctx.dgrad_ops[li]
-        else:
-          wd = torch.empty((cin, kt * kh * kw, cout), dtype=bf, device=dev)
-          frag = L.lr_conv3d_patch_supported(ho, wo, cout, cin, kt, kh, kw, 1, pt, ph, pw) if _PATCH_KERNELS else 0
-          _C.check(L.lr_conv3d_pack_weights(params[2 * li].data_ptr(), wd.data_ptr(), cout, cin, cin_p, kt,
-                                            kh, kw, 1 | frag, st), "lr_conv3d_pack_weights")
         dP = torch.empty((frames, h, w, cin), dtype=bf, device=dev)
         _C.check(L.lr_conv3d_forward(dZ.data_ptr(), wd.data_ptr(), None, dP.data_ptr(), B, T, ho, wo, cout,
                                      cin, kt, kh, kw, 1, pt, ph, pw, frag, st), "lr_conv3d_forward(dgrad)")

@@ -150,6 +150,47 @@ def test_pixel_lipreader_trains_end_to_end(dev):
   assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], losses
 
 
+@pytest.mark.parametrize("B,T,H", [(2, 9, 96), (1, 5, 96), (3, 7, 64), (2, 75, 96)])
+def test_data_gradients_that_unpool_on_the_fly_equal_the_staged_ones(dev, B, T, H):
+  """Layers 2 and 3: lr_conv3d_dgrad_pooled takes the pooled gradient and the window codes and rebuilds its dZ patch
+  on the way into LDS; staged reference: lr_unpool_code_bf16 materialises dZ and lr_conv3d_forward (the same
+  patch-resident kernel) reads it.  The same bf16 values reach the same MFMAs in the same order: every gradient is
+  bit-identical, with and without the conv side stream."""
+  from lipreading_amd import frontend as FE
+  torch.manual_seed(19)
+  fe = FE.ConvFrontend3D().to(dev)
+  g = torch.Generator().manual_seed(20)
+  clips = torch.randint(0, 256, (B, T, 3, H, H), generator=g, dtype=torch.uint8).to(dev)
+  wgt = torch.randn(B, T, FE.feature_dim(H, H), generator=g).to(dev)
+  res = {}
+  for fused in (True, False):
+    FE._FUSE_UNPOOL = fused
+    try:
+      fe.zero_grad()
+      out = fe(clips)
+      (out * wgt).sum().backward()
+      torch.cuda.synchronize()
+      res[fused] = [out.detach().clone()] + [p.grad.detach().clone() for p in fe.parameters_in_order()]
+    finally:
+      FE._FUSE_UNPOOL = True
+  for a, b in zip(res[True], res[False]):
+    assert torch.equal(a, b)
+  # the codes: 0..3 = position of the window's first maximum, 4 = pooled activation 0 (ReLU blocks the gradient)
+  from lipreading_amd import _C
+  L = _C.lib()
+  x = torch.randn(B * T, 24, 24, 32, generator=g).to(dev).bfloat16()
+  w = (torch.randn(64, 32, 3, 5, 5, generator=g) * 0.05).to(dev)
+  bias = torch.randn(64, generator=g).to(dev) - 1.0
+  wp = torch.empty((64, 75, 32), dtype=torch.bfloat16, device=dev)
+  frag = L.lr_conv3d_patch_supported(24, 24, 32, 64, 3, 5, 5, 1, 1, 2, 2)
+  _C.check(L.lr_conv3d_pack_weights(w.data_ptr(), wp.data_ptr(), 64, 32, 32, 3, 5, 5, frag, _C.stream_handle()), "pack")
+  pooled = torch.empty((B * T, 12, 12, 64), dtype=torch.bfloat16, device=dev)
+  code = torch.empty(pooled.shape, dtype=torch.uint8, device=dev)
+  _C.check(L.lr_conv3d_forward_pooled(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), pooled.data_ptr(), code.data_ptr(), B, T,
+                                      24, 24, 32, 64, 3, 5, 5, 1, 1, 2, 2, 1 | frag, _C.stream_handle()), "fwd")
+  assert int(code.max()) == 4 and bool(((code == 4) == (pooled.float() == 0)).all())
+
+
 def test_first_layer_fused_paths_equal_the_staged_ones(dev):
   """The first layer's kernels read the raw uint8 clip and its weight gradient rebuilds dZ from the
   pooled tensors on the fly (lr_conv3d_forward_pooled flags & 8, lr_conv3d_wgrad_pooled).  Staged
