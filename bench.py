@@ -593,7 +593,11 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
   # gradient (frontend._WGRAD_SIDE_STREAM) — the two then share the chip and each one's duration says nothing about
   # the kernel itself.
   from lipreading_amd import frontend as _FE
+  from lipreading_amd import encoder as _ENC
   _side_saved, _FE._WGRAD_SIDE_STREAM = _FE._WGRAD_SIDE_STREAM, False
+  # ... and the recurrent layers' weight-gradient GEMMs too (encoder.overlap_weight_grads puts them on a side stream,
+  # where they ran beside layer 3's backward: round 3's conv3_wgrad read 84 us on one visit and 199 on the next)
+  _ovl_saved, _ENC.overlap_weight_grads = _ENC.overlap_weight_grads, False
   _C.check(L.lr_profile_enable(1), "lr_profile_enable")
   n_prof = min(args.steps, 20 if not pixels else 5)
   for _ in range(n_prof):    # eager launches of the same step (graph replays do not re-run the host code that records events)
@@ -605,6 +609,7 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
   torch.cuda.synchronize()
   L.lr_profile_enable(0)
   _FE._WGRAD_SIDE_STREAM = _side_saved
+  _ENC.overlap_weight_grads = _ovl_saved
   prof = {}
   for which, name in SLOTS.items():
     ms, n = ctypes.c_float(0), ctypes.c_int(0)

@@ -114,7 +114,7 @@ int lr_conv_patch24(bool fwd, bool unpool, const void* X, const void* Wf, const 
 // ---- conv frontend, weight gradient of the stride-1 layers, second form (lr_conv_wgrad.hip) ----------
 constexpr int LR_CONV_TR2_SLOTS = 85;   // slots per temporal tap: 3 x 85 = 255 workgroups, one slab each
 int lr_conv_wgrad_tr2_supported(int layer, int F, int H);   // 160 KB of LDS hold the two tile buffers + the tile table
-int lr_conv_wgrad_tr2(int layer, const void* X, const void* dZ, float* slabs, int F, int T, int H,
+int lr_conv_wgrad_tr2(int layer, const void* X, const void* dZ, const void* code, float* slabs, int F, int T, int H,
                       bool sample, hipEvent_t e0, hipEvent_t e1, hipStream_t stream);
 
 // ---- device-side fault words {pending, total} of the one-launch recurrences (lr_misc.hip; see

@@ -989,8 +989,11 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restr
 // column sums of a bf16 [M][C] matrix (C % 8 == 0), two-stage (deterministic).  Stage 1: every
 // thread owns 8 channels (one 16-byte load per row) and strides over the rows of its workgroup's
 // slice; the workgroup combines its row lanes through LDS and writes partial[blockIdx.x][C].
+// code != nullptr: x is a POOLED gradient and code the windows' codes (relu_pool4): elements whose code is 4 (blocked
+// by ReLU) are left out — the column sums of the un-pooled dZ, i.e. the bias gradient, without dZ.
 __global__ void colsum_bf16_partial_kernel(const bf16_t* __restrict__ x, int64_t M, int C,
-                                           float* __restrict__ partial, int splits) {
+                                           float* __restrict__ partial, int splits,
+                                           const unsigned char* __restrict__ code) {
   __shared__ float red[256][9];
   const int tpr = C >> 3;                    // threads per row
   const int rl = threadIdx.x / tpr, cg = threadIdx.x - rl * tpr;
@@ -1000,7 +1003,17 @@ __global__ void colsum_bf16_partial_kernel(const bf16_t* __restrict__ x, int64_t
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (rl < rows_per_iter) {
     for (int64_t r = r0 + rl; r < r1; r += rows_per_iter) {
-      const uint4 v = *reinterpret_cast<const uint4*>(x + r * C + cg * 8);
+      uint4 v = *reinterpret_cast<const uint4*>(x + r * C + cg * 8);
+      if (code) {
+        const uint2 cc = *reinterpret_cast<const uint2*>(code + r * C + cg * 8);
+        // bit 2 of a code byte = blocked: spread it into a byte mask, double the bytes into 16-bit lanes
+        const unsigned k0 = (cc.x >> 2) & 0x01010101u, k1 = (cc.y >> 2) & 0x01010101u;
+        const unsigned b0 = (k0 << 8) - k0, b1 = (k1 << 8) - k1;
+        v.x &= ~__builtin_amdgcn_perm(b0, b0, 0x01010000u);
+        v.y &= ~__builtin_amdgcn_perm(b0, b0, 0x03030202u);
+        v.z &= ~__builtin_amdgcn_perm(b1, b1, 0x01010000u);
+        v.w &= ~__builtin_amdgcn_perm(b1, b1, 0x03030202u);
+      }
       acc[0] += bf2f((bf16_t)(v.x & 0xffffu)); acc[1] += bf2f((bf16_t)(v.x >> 16));
       acc[2] += bf2f((bf16_t)(v.y & 0xffffu)); acc[3] += bf2f((bf16_t)(v.y >> 16));
       acc[4] += bf2f((bf16_t)(v.z & 0xffffu)); acc[5] += bf2f((bf16_t)(v.z >> 16));
@@ -1283,25 +1296,77 @@ extern "C" size_t lr_conv3d_wgrad_workspace_bytes(int Cout, int Cin_pad, int KT,
   return (slab + colparts * Cout) * sizeof(float);
 }
 
+// The stride-1 layers' weight gradient with LDS transpose reads (lr_conv_wgrad.hip): which layer (2 / 3) the geometry
+// is, 0 if neither; and the run: kernel, slab reduction, bias gradient.  code != nullptr: dZ is the POOLED gradient
+// [F][Ho/2][Wo/2][Cout] and code the windows' codes — the kernel un-pools on the way into LDS and the bias gradient is
+// the column sum of dP over the windows ReLU did not block.
+static int wgrad_tr2_layer(int F, int Hin, int Win, int Cin_pad, int Cin_real, int Cout, int KT, int KH, int KW, int stride,
+                           int pt, int ph, int pw) {
+  const bool l2 = Cin_pad == 32 && Cout == 64 && KH == 5 && KW == 5 && Win == 24 && Hin % 4 == 0;
+  const bool l3 = Cin_pad == 64 && Cout == 96 && KH == 3 && KW == 3 && Win == 12 && Hin % 6 == 0;
+  if (stride == 1 && KT == 3 && pt == 1 && 2 * ph + 1 == KH && 2 * pw + 1 == KW && Cin_real == Cin_pad && (l2 || l3) &&
+      lr_conv_wgrad_tr2_supported(l2 ? 2 : 3, F, Hin))
+    return l2 ? 2 : 3;
+  return 0;
+}
+static int wgrad_tr2_run(const void* X, const void* dZ, const void* code, float* dW, float* dbias, void* workspace,
+                         int accumulate, int F, int T, int Hin, int Win, int Cin_pad, int Cout, int KT, int KH, int KW,
+                         bool sample, hipEvent_t e0, hipEvent_t e1, hipStream_t stream) {
+  const int layer = Cin_pad == 32 ? 2 : 3;
+  float* slabs = (float*)workspace;
+  const int nslots = LR_CONV_TR2_SLOTS;
+  int st = lr_conv_wgrad_tr2(layer, X, dZ, code, slabs, F, T, Hin, sample, e0, e1, stream);
+  if (st != LR_OK) return st;
+  {
+    const int64_t se = (int64_t)Cout * Cin_pad * KT * KH * KW;
+    LR_LAUNCH(conv_wgrad_slab_reduce_kernel, dim3((unsigned)((se + 63) / 64)), dim3(64, 4), 0, stream,
+              (const float*)slabs, nslots, se, dW, 1, Cout, Cin_pad, Cin_pad, KT * KH * KW, KH * KW, 0,
+              accumulate);
+  }
+  st = lr_launch_status();
+  if (st != LR_OK || !dbias) return st;
+  float* cpart2 = slabs + (size_t)3 * kTsWgsPerKt * KH * KW * Cout * Cin_pad;
+  // rows of dZ (stride-1 "same" layers: output extent = input extent), or of the pooled gradient
+  const int64_t rows = code ? (int64_t)F * (Hin / 2) * (Win / 2) : (int64_t)F * Hin * Win;
+  LR_LAUNCH(colsum_bf16_partial_kernel, dim3(kColsumSplits), dim3(256), 0, stream, (const bf16_t*)dZ, rows, Cout, cpart2,
+            kColsumSplits, (const unsigned char*)code);
+  LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(1024), 0, stream, (const float*)cpart2, kColsumSplits, dbias,
+            Cout, accumulate);
+  return lr_launch_status();
+}
+
 extern "C" int lr_conv3d_wgrad_pooled_supported(int Hin, int Win, int Cin_pad, int Cin_real, int Cout, int KT,
                                                int KH, int KW, int stride, int pt, int ph, int pw) {
   const int Ho = (Hin + 2 * ph - KH) / (stride > 0 ? stride : 1) + 1, Wo = (Win + 2 * pw - KW) / (stride > 0 ? stride : 1) + 1;
-  return Cin_pad == 4 && Cin_real == 3 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 &&
-         ph == 2 && pw == 2 && Ho % 2 == 0 && Wo % 2 == 0;
+  if (Cin_pad == 4 && Cin_real == 3 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 &&
+      ph == 2 && pw == 2 && Ho % 2 == 0 && Wo % 2 == 0)
+    return 1;
+  // 2: the stride-1 layers' transpose-read kernel un-pools on the fly (any frame count that fits its tile table: the
+  // caller asks again through lr_conv3d_wgrad_pooled, which answers LR_ERR_UNSUPPORTED when B * T does not)
+  return wgrad_tr2_layer(1, Hin, Win, Cin_pad, Cin_real, Cout, KT, KH, KW, stride, pt, ph, pw) && Hin % 2 == 0 ? 2 : 0;
 }
 
 extern "C" int lr_conv3d_wgrad_pooled(const void* X, const void* pooled, const void* code, const void* dP, float* dW,
                                       float* dbias, void* workspace, size_t workspace_bytes, int accumulate, int B,
                                       int T, int Hin, int Win, int Cin_pad, int Cin_real, int Cout, int KT, int KH,
                                       int KW, int stride, int pt, int ph, int pw, int flags, lr_stream_t stream) {
-  LR_CHECK_ARG(X && pooled && code && dP && dW && workspace);
+  LR_CHECK_ARG(X && code && dP && dW && workspace);
   const bool u8 = (flags & 1) != 0;   // X is the raw uint8 planar clip
-  if (!lr_conv3d_wgrad_pooled_supported(Hin, Win, Cin_pad, Cin_real, Cout, KT, KH, KW, stride, pt, ph, pw))
-    return LR_ERR_UNSUPPORTED;
+  const int kind = lr_conv3d_wgrad_pooled_supported(Hin, Win, Cin_pad, Cin_real, Cout, KT, KH, KW, stride, pt, ph, pw);
+  if (!kind) return LR_ERR_UNSUPPORTED;
   ConvGeom g;
   if (!fill_geom(&g, B, T, Hin, Win, Cin_pad, Cout, KT, KH, KW, stride, pt, ph, pw)) return LR_ERR_UNSUPPORTED;
   const size_t need = lr_conv3d_wgrad_workspace_bytes(Cout, Cin_pad, KT, KH, KW);
   if (workspace_bytes < need) return LR_ERR_WORKSPACE;
+  if (kind == 2) {   // layers 2 / 3 (the codes carry the ReLU mask: `pooled` is not read)
+    if (u8 || !wgrad_tr2_layer(B * T, Hin, Win, Cin_pad, Cin_real, Cout, KT, KH, KW, stride, pt, ph, pw))
+      return LR_ERR_UNSUPPORTED;
+    hipEvent_t e0, e1;
+    const bool sample = lr_prof_next(Cin_pad == 32 ? LR_PROF_CONV2_WGRAD : LR_PROF_CONV3_WGRAD, &e0, &e1);
+    return wgrad_tr2_run(X, dP, code, dW, dbias, workspace, accumulate, B * T, T, Hin, Win, Cin_pad, Cout, KT, KH, KW,
+                         sample, e0, e1, (hipStream_t)stream);
+  }
+  LR_CHECK_ARG(pooled);
   float* slabs = (float*)workspace;
   float* bpart = (float*)((char*)workspace + need) - (size_t)LR_CONV1_WGRAD_WGS * Cout;
   hipEvent_t e0, e1;
@@ -1350,42 +1415,15 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
     st = lr_launch_status();
     if (st != LR_OK || !dbias) return st;
     LR_LAUNCH(colsum_bf16_partial_kernel, dim3(kColsumSplits), dim3(256), 0, stream, dz, g.M, Cout, cpart,
-              kColsumSplits);
+              kColsumSplits, (const unsigned char*)nullptr);
     LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(1024), 0, stream, (const float*)cpart, kColsumSplits, dbias,
               Cout, accumulate);
     return lr_launch_status();
   }
   // stride-1 layers of the frontend: LDS-transpose-read kernel (dZ and X stay channels-last in LDS)
-  {
-    const bool l2 = Cin_pad == 32 && Cout == 64 && KH == 5 && KW == 5 && Win == 24 && Hin % 4 == 0;
-    const bool l3 = Cin_pad == 64 && Cout == 96 && KH == 3 && KW == 3 && Win == 12 && Hin % 6 == 0;
-    if (stride == 1 && KT == 3 && pt == 1 && 2 * ph + 1 == KH && 2 * pw + 1 == KW && Cin_real == Cin_pad &&
-        (l2 || l3) && lr_conv_wgrad_tr2_supported(l2 ? 2 : 3, B * T, Hin)) {
-      hipEvent_t e0, e1;
-      const bool sample = lr_prof_next(l2 ? LR_PROF_CONV2_WGRAD : LR_PROF_CONV3_WGRAD, &e0, &e1);
-      const bf16_t* x = (const bf16_t*)X;
-      const bf16_t* dz = (const bf16_t*)dZ;
-      float* slabs = (float*)workspace;
-      const int F = B * T;
-      const int nslots = LR_CONV_TR2_SLOTS;
-      int st = lr_conv_wgrad_tr2(l2 ? 2 : 3, x, dz, slabs, F, T, Hin, sample, e0, e1, (hipStream_t)stream);
-      if (st != LR_OK) return st;
-      {
-        const int64_t se = (int64_t)Cout * Cin_pad * KT * KH * KW;
-        LR_LAUNCH(conv_wgrad_slab_reduce_kernel, dim3((unsigned)((se + 63) / 64)), dim3(64, 4), 0, stream,
-                  (const float*)slabs, nslots, se, dW, 1, Cout, Cin_pad, Cin_pad, KT * KH * KW, KH * KW, 0,
-                  accumulate);
-      }
-      st = lr_launch_status();
-      if (st != LR_OK || !dbias) return st;
-      float* cpart2 = slabs + (size_t)3 * kTsWgsPerKt * KH * KW * Cout * Cin_pad;
-      LR_LAUNCH(colsum_bf16_partial_kernel, dim3(kColsumSplits), dim3(256), 0, stream, dz, g.M, Cout, cpart2,
-                kColsumSplits);
-      LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(1024), 0, stream, (const float*)cpart2, kColsumSplits, dbias,
-                Cout, accumulate);
-      return lr_launch_status();
-    }
-  }
+  if (wgrad_tr2_layer(B * T, Hin, Win, Cin_pad, Cin_real, Cout, KT, KH, KW, stride, pt, ph, pw))
+    return wgrad_tr2_run(X, dZ, nullptr, dW, dbias, workspace, accumulate, B * T, T, Hin, Win, Cin_pad, Cout, KT, KH, KW,
+                         sample, e0, e1, (hipStream_t)stream);
   const bool ts_path = stride == 1 && (Cin_pad == 32 || Cin_pad == 64) && Cin_real == Cin_pad &&
                        2 * ph + 1 == KH && 2 * pw + 1 == KW && KH * KW * (Cin_pad / 32) <= 28;
   if (ts_path) {
@@ -1433,7 +1471,7 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
         st = lr_launch_status();
         if (st != LR_OK || !dbias) return st;
         LR_LAUNCH(colsum_bf16_partial_kernel, dim3(kColsumSplits), dim3(256), 0, stream, dz, g.M, Cout, cpart,
-                  kColsumSplits);
+                  kColsumSplits, (const unsigned char*)nullptr);
         LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(1024), 0, stream, (const float*)cpart, kColsumSplits,
                   dbias, Cout, accumulate);
         return lr_launch_status();
@@ -1473,7 +1511,7 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
   st = lr_launch_status();
   if (st != LR_OK || !dbias) return st;
   LR_LAUNCH(colsum_bf16_partial_kernel, dim3(kColsumSplits), dim3(256), 0, stream, dz, g.M, Cout, cpart,
-            kColsumSplits);
+            kColsumSplits, (const unsigned char*)nullptr);
   LR_LAUNCH(colsum_final_acc_kernel, dim3(1), dim3(1024), 0, stream, (const float*)cpart, kColsumSplits,
             dbias, Cout, accumulate);
   return lr_launch_status();

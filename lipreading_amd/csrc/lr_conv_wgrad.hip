@@ -64,16 +64,33 @@ struct Tr2 {
   static constexpr int XI = (XUNITS + 255) / 256, ZI = (ZUNITS + 255) / 256, UPT = XI + ZI;
   static constexpr int XREG = XI * 4096, ZREG = ZI * 4096, BUF = XREG + ZREG;
   static constexpr int LDS_BYTES = 2 * BUF, TAB_BYTES = 160 * 1024 - LDS_BYTES;   // tile table behind the buffers
+  // UNPOOL: the dZ planes are rebuilt from POOLED units (one window x 8 channels: 16 bytes of dP + 8 codes -> the
+  // window's four dZ units)
+  static constexpr int PPOS = TT * (TH / 2) * (W / 2), PZU = MT * PPOS * 4, PZ = (PZU + 255) / 256;
 };
 
-template <int CIN, int MT, int KH, int KW, int W, int TT, int TH>
+// UNPOOL (the layer's forward fused ReLU + MaxPool): dZ is the POOLED gradient dP [F][H/2][W/2][COUT] and `code` the
+// windows' codes (relu_pool4, lr_conv_dev.h); the dZ planes of a tile are rebuilt on the way into LDS — a thread loads
+// 16 bytes of dP and 8 codes per pooled unit and stores the window's four units (unpool8's arithmetic, cut into slices
+// of <= 8 VALU instructions that ride in the MFMA gaps like the stores do) — so the full-resolution dZ is never written
+// to or read from memory.
+template <int CIN, int MT, int KH, int KW, int W, int TT, int TH, bool UNPOOL>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_tr2_kernel(const bf16_t* __restrict__ X,
                                                                 const bf16_t* __restrict__ dZ,
+                                                                const unsigned char* __restrict__ code,
                                                                 float* __restrict__ slabs, int F, int T, int H) {
   static_assert(TT == 2, "lanes 0-31 / 32-63 of a fragment read take frame 0 / 1 of the tile");
+  static_assert(!UNPOOL || (TH % 2 == 0 && W % 2 == 0), "whole pooling windows per tile");
   typedef Tr2<CIN, MT, KH, KW, W, TT, TH> G;
   constexpr int CH = G::CH, PH = G::PH, PW = G::PW, XPOS = G::XPOS, ZPOS = G::ZPOS;
-  constexpr int XUNITS = G::XUNITS, ZUNITS = G::ZUNITS, XI = G::XI, UPT = G::UPT, XREG = G::XREG, BUF = G::BUF;
+  constexpr int XUNITS = G::XUNITS, ZUNITS = G::ZUNITS, XI = G::XI, XREG = G::XREG, BUF = G::BUF;
+  constexpr int PZ = G::PZ, PZU = G::PZU, PPOS = G::PPOS;
+  // loads of a tile: the X units, then (UNPOOL) PZ 16-byte loads of dP and PZ 8-byte loads of codes, else the dZ units;
+  // store-phase events: the X units' stores, then (UNPOOL) three slices per (pooled unit, window position) — the
+  // third one stores —, else the dZ units' stores
+  constexpr int UPT = UNPOOL ? XI + 2 * PZ : G::UPT;
+  constexpr int NEV = UNPOOL ? XI + 12 * PZ : G::UPT;
+  constexpr int NPRE = UNPOOL ? XI + PZ : G::UPT;
   constexpr int W4 = W / 4, GPS = TH * W4;   // position groups (4 columns) of one frame's rows
   constexpr int STEPS = GPS / 2;             // k16 steps per tile: 2 groups x 2 frames each
   constexpr int NU = KH * KW * CH, COUT = MT * 32;
@@ -85,10 +102,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr2_kernel(const bf16_t* __
   // MFMA "gaps" g = st * NM + m of a tile: the next tile's table entry in step 1, its UPT loads one every LSTR gaps
   // from LG0, its UPT LDS stores one every SSTR gaps from MID (see the loop)
   constexpr int GAPS = STEPS * NM, SETUP = 1, LG0 = 2 * NM, MID = (LG0 + GAPS) / 2;
-  constexpr int LSTR = (MID - LG0) / UPT, SSTR = (GAPS - 4 - MID) / UPT;
+  constexpr int LSTR = (MID - LG0) / UPT, SSTR = (GAPS - 4 - MID) / NEV;
   static_assert(W % 4 == 0 && GPS % 2 == 0, "tile must be a whole number of k16 steps");
   static_assert(LEFT * CHUNKS <= 4, "one chunk of a left-over unit per wave");
-  static_assert(ND >= NM && NM >= 13 && UPT <= 31 && LSTR >= 1 && SSTR >= 1, "placement of the next tile's loads / stores");
+  static_assert(ND >= NM && NM >= 13 && NPRE <= 31 && LSTR >= 1 && SSTR >= 1, "placement of the next tile's loads / stores");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int kt, slot;
@@ -141,10 +158,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr2_kernel(const bf16_t* __
   // rounds of dZ).  voff = byte offset from the tile's resource base; bit i of a mask: unit i is never data /
   // a row above the tile / a row below it / an X (dZ) unit of frame slot sf.
   const int negx = ((H + (KH - 1) / 2) * W + (KW - 1) / 2) * CIN;   // elements the X resource starts before the tile
-  unsigned voff[UPT];
+  unsigned voff[NPRE];
+  int zdst[UNPOOL ? PZ : 1];   // UNPOOL: byte offset (inside a buffer) of the window's first dZ unit
   unsigned m_nok = 0, m_top = 0, m_bot = 0, m_xf0 = 0, m_xf1 = 0, m_zf0 = 0, m_zf1 = 0;
 #pragma unroll
-  for (int i = 0; i < UPT; ++i) {
+  for (int i = 0; i < NPRE; ++i) {
     voff[i] = 0;
     if (i < XI) {
       const int u = tid + 256 * i;
@@ -160,6 +178,22 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr2_kernel(const bf16_t* __
         if (dh >= TH) m_bot |= 1u << i;
         m_xf0 |= sf == 0 ? 1u << i : 0u;
         m_xf1 |= sf == 1 ? 1u << i : 0u;
+      } else {
+        m_nok |= 1u << i;
+      }
+    } else if constexpr (UNPOOL) {
+      const int up = tid + 256 * (i - XI);
+      zdst[i - XI] = XREG;
+      if (up < PZU) {
+        const int mt = up / (PPOS * 4), rem = up - mt * (PPOS * 4);
+        const int ppos = rem >> 2, c8 = rem & 3;
+        const int sf = ppos / ((TH / 2) * (W / 2)), r2 = ppos - sf * ((TH / 2) * (W / 2));
+        const int hp = r2 / (W / 2), wp = r2 - hp * (W / 2);
+        // element offset in dP (and byte offset in the codes) from the tile's pooled origin; x2 = bytes in dP
+        voff[i] = (unsigned)((((sf * (H >> 1) + hp) * (W / 2) + wp) * COUT + mt * 32 + c8 * 8) * 2);
+        zdst[i - XI] = XREG + ((mt * ZPOS + sf * (TH * W) + 2 * hp * W + 2 * wp) * 4 + c8) * 16;
+        m_zf0 |= sf == 0 ? 1u << i : 0u;
+        m_zf1 |= sf == 1 ? 1u << i : 0u;
       } else {
         m_nok |= 1u << i;
       }
@@ -191,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr2_kernel(const bf16_t* __
   for (int e = tid; e <= mine; e += 256) {
     const int tile = slot + e * kTr2Slots;
     unsigned fl = 0x7f;
-    uint64_t xa = (uint64_t)X, za = (uint64_t)dZ;
+    uint64_t xa = (uint64_t)X, za = (uint64_t)dZ, ca = (uint64_t)code;
     if (e < mine) {
       const int ft = tile / htiles, hb = tile - ft * htiles;
       const int f0 = ft * TT;
@@ -205,24 +239,38 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr2_kernel(const bf16_t* __
       const int64_t org = ((int64_t)f0 * H + hb * TH) * W;
       xa = (uint64_t)(X + (org * CIN - negx));
       za = (uint64_t)(dZ + org * COUT);
+      if constexpr (UNPOOL) {
+        const int64_t porg = ((int64_t)f0 * (H >> 1) + hb * (TH / 2)) * (W / 2) * COUT;
+        za = (uint64_t)(dZ + porg);
+        ca = (uint64_t)(code + porg);
+      }
     }
     *reinterpret_cast<u32x4_t*>(tab + e * 32) = u32x4_t{(unsigned)xa, (unsigned)(xa >> 32), (unsigned)za, (unsigned)(za >> 32)};
     *reinterpret_cast<unsigned*>(tab + e * 32 + 16) = fl;
+    if constexpr (UNPOOL) *reinterpret_cast<uint2*>(tab + e * 32 + 24) = make_uint2((unsigned)ca, (unsigned)(ca >> 32));
   }
   __syncthreads();
-  u32x4_t pre[UPT];
+  u32x4_t pre[NPRE];
+  uint2 prc[UNPOOL ? PZ : 1];   // UNPOOL: the codes of the pooled units
   u32x4_t ent;                // the table entry of the tile whose units are being loaded (the same in every lane)
+  uint2 entc = make_uint2(0u, 0u);
   unsigned efl = 0, bad = 0;
   const bf16_t *xp = X, *zp = dZ;
+  const unsigned char* cp = code;
   auto entry_read = [&](int e) {
     ent = *reinterpret_cast<const u32x4_t*>(tab + e * 32);
     efl = *reinterpret_cast<const unsigned*>(tab + e * 32 + 16);
+    if constexpr (UNPOOL) entc = *reinterpret_cast<const uint2*>(tab + e * 32 + 24);
   };
   auto entry_bases = [&]() {
     const unsigned x0 = __builtin_amdgcn_readfirstlane(ent.x), x1 = __builtin_amdgcn_readfirstlane(ent.y);
     const unsigned z0 = __builtin_amdgcn_readfirstlane(ent.z), z1 = __builtin_amdgcn_readfirstlane(ent.w);
     xp = (const bf16_t*)(((uint64_t)x1 << 32) | x0);
     zp = (const bf16_t*)(((uint64_t)z1 << 32) | z0);
+    if constexpr (UNPOOL) {
+      const unsigned c0 = __builtin_amdgcn_readfirstlane(entc.x), c1 = __builtin_amdgcn_readfirstlane(entc.y);
+      cp = (const unsigned char*)(((uint64_t)c1 << 32) | c0);
+    }
   };
   // term k of the padding mask: a per-lane unit mask, taken when bit k of the flags is set
   auto entry_bad = [&](int k) {
@@ -230,11 +278,49 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr2_kernel(const bf16_t* __
     const unsigned on = (unsigned)__builtin_amdgcn_sbfe((int)efl, k, 1);   // 0 or ~0
     bad = (k == 0 ? m_nok : bad) | (m & on);
   };
-  auto issue_unit = [&](int i) {   // global -> registers: one 16-byte unit, zeros when it is padding
+  auto issue_unit = [&](int i) {   // global -> registers: one 16-byte unit (8 codes), zeros when it is padding
+    if constexpr (UNPOOL) {
+      if (i >= NPRE) {   // the codes of pooled unit i - NPRE: a byte per element, so half the dP offset
+        const int p = i - NPRE;
+        const __amdgpu_buffer_rsrc_t r =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(cp), (short)0, 0x7fffffff, 0x00020000);
+        const unsigned o = (voff[XI + p] >> 1) | (((bad >> (XI + p)) & 1u) << 31);
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)o, 0, 0);
+        prc[p] = make_uint2(v[0], v[1]);
+        return;
+      }
+    }
     const __amdgpu_buffer_rsrc_t r =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(i < XI ? xp : zp), (short)0, 0x7fffffff, 0x00020000);
     const unsigned o = voff[i] | (((bad >> i) & 1u) << 31);
     pre[i] = __builtin_amdgcn_raw_buffer_load_b128(r, (int)o, 0, 0);
+  };
+  // store-phase event e of the tile whose units are in pre / prc, into the buffer at `dep0` (a thread's X units sit at
+  // tid * 16 + i * 4096): e < XI the X unit e; UNPOOL then (pooled unit p, window position j, slice): 0 = the bytes
+  // that match position j, 1 = their byte masks, 2 = mask, select and store (unpool8's arithmetic, lr_conv_dev.h);
+  // else the dZ unit e
+  unsigned ua = 0, ub = 0;
+  auto store_event = [&](unsigned char* buf, int e) {
+    if (e < XI || !UNPOOL) {
+      *reinterpret_cast<u32x4_t*>(buf + tid * 16 + e * 4096) = pre[e];
+      return;
+    }
+    const int q = e - XI, p = q / 12, j = (q % 12) / 3, slice = q % 3;
+    if (slice == 0) {
+      ua = (0x08080808u - (prc[p].x ^ (0x01010101u * (unsigned)j))) & 0x08080808u;
+      ub = (0x08080808u - (prc[p].y ^ (0x01010101u * (unsigned)j))) & 0x08080808u;
+    } else if (slice == 1) {
+      ua = (ua << 5) - (ua >> 3);
+      ub = (ub << 5) - (ub >> 3);
+    } else {
+      const u32x4_t d = pre[XI + p];
+      const u32x4_t o = {d.x & __builtin_amdgcn_perm(ua, ua, 0x01010000u), d.y & __builtin_amdgcn_perm(ua, ua, 0x03030202u),
+                         d.z & __builtin_amdgcn_perm(ub, ub, 0x01010000u), d.w & __builtin_amdgcn_perm(ub, ub, 0x03030202u)};
+      // (the last round's units past the end are no units: nothing to store — unlike the whole-round regions of the
+      // X patch, the dZ planes have no padding for them to land in)
+      if (p < PZ - 1 || tid < PZU - 256 * (PZ - 1))
+        *reinterpret_cast<u32x4_t*>(buf + zdst[p] + (j >> 1) * (W * 64) + (j & 1) * 64) = o;
+    }
   };
 
   entry_read(0);
@@ -244,11 +330,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr2_kernel(const bf16_t* __
 #pragma unroll
   for (int i = 0; i < UPT; ++i) issue_unit(i);
 #pragma unroll
-  for (int i = 0; i < UPT; ++i) *reinterpret_cast<u32x4_t*>(lds + tid * 16 + i * 4096) = pre[i];
+  for (int e = 0; e < NEV; ++e) store_event(lds, e);
   __syncthreads();
   for (int it = 0; it < mine; ++it) {
     const int cur = it & 1;
-    unsigned char* dep = lds + (cur ^ 1) * BUF + tid * 16;   // where this thread's units of the next tile go
+    unsigned char* dep = lds + (cur ^ 1) * BUF;   // where the next tile goes
     int xb[UPW], zb[MT];
 #pragma unroll
     for (int j = 0; j < UPW; ++j) xb[j] = xbase[j] + cur * BUF;
@@ -300,10 +386,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_tr2_kernel(const bf16_t* __
         if (st + 1 < STEPS) read_one(st + 1, ND - NM + m);
         const int gap = st * NM + m;
         if (gap >= LG0 && (gap - LG0) % LSTR == 0 && (gap - LG0) / LSTR < UPT) issue_unit((gap - LG0) / LSTR);
-        if (gap >= MID && (gap - MID) % SSTR == 0 && (gap - MID) / SSTR < UPT) {
-          const int i2 = (gap - MID) / SSTR;
-          *reinterpret_cast<u32x4_t*>(dep + i2 * 4096) = pre[i2];
-        }
+        if (gap >= MID && (gap - MID) % SSTR == 0 && (gap - MID) / SSTR < NEV) store_event(dep, (gap - MID) / SSTR);
         if (st == SETUP && m == 0) entry_read(it + 1);
         if (st == SETUP && m == 5) entry_bases();
         if (st == SETUP && m >= 6 && m < 13) entry_bad(m - 6);
@@ -356,33 +439,42 @@ int lr_conv_wgrad_tr2_supported(int layer, int F, int H) {
 
 // layer: 2 (24 wide, 32 -> 64 channels, 3x5x5; H % 6 == 0 or H % 4 == 0) or 3 (12 wide, 64 -> 96, 3x3x3; H % 6 == 0).
 // slabs: 3 x LR_CONV_TR2_SLOTS partial results [slot * 3 + kt][tap][n][c].
-int lr_conv_wgrad_tr2(int layer, const void* X, const void* dZ, float* slabs, int F, int T, int H,
+// code != nullptr: dZ is the POOLED gradient [F][H/2][W/2][Cout] and code the windows' codes (the kernel un-pools).
+int lr_conv_wgrad_tr2(int layer, const void* X, const void* dZ, const void* code, float* slabs, int F, int T, int H,
                       bool sample, hipEvent_t e0, hipEvent_t e1, hipStream_t stream) {
-  static bool attr_set[3] = {false, false, false};
+  static bool attr_set[6] = {false, false, false, false, false, false};
   const bf16_t* x = (const bf16_t*)X;
   const bf16_t* dz = (const bf16_t*)dZ;
+  const unsigned char* cd = (const unsigned char*)code;
   if (!lr_conv_wgrad_tr2_supported(layer, F, H) || T <= 0) return LR_ERR_UNSUPPORTED;
   const int th = tr2_tile_rows(layer, H);
   const int tabb = tr2_table_bytes(F, H, th);
   lr_clear_error();
-#define LR_WGTR2(IDX, ...)                                                                                   \
+#define LR_WGTR2(IDX, UNP, ...)                                                                                 \
   do {                                                                                                      \
     constexpr int LDSMAX = 160 * 1024;                                                                      \
     const int LDSB = Tr2<__VA_ARGS__>::LDS_BYTES + tabb;                                                    \
     if (!attr_set[IDX]) {                                                                                   \
-      if (hipFuncSetAttribute((const void*)conv_wgrad_tr2_kernel<__VA_ARGS__>,                               \
+      if (hipFuncSetAttribute((const void*)conv_wgrad_tr2_kernel<__VA_ARGS__, UNP>,                          \
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSMAX) != hipSuccess)            \
         return LR_ERR_LAUNCH;                                                                               \
       attr_set[IDX] = true;                                                                                 \
     }                                                                                                       \
-    if (sample) hipExtLaunchKernelGGL((conv_wgrad_tr2_kernel<__VA_ARGS__>), dim3(3 * kTr2Slots), dim3(256),  \
-                                      LDSB, stream, e0, e1, 0, x, dz, slabs, F, T, H);                      \
-    else hipLaunchKernelGGL((conv_wgrad_tr2_kernel<__VA_ARGS__>), dim3(3 * kTr2Slots), dim3(256), LDSB,      \
-                            stream, x, dz, slabs, F, T, H);                                                 \
+    if (sample) hipExtLaunchKernelGGL((conv_wgrad_tr2_kernel<__VA_ARGS__, UNP>), dim3(3 * kTr2Slots), dim3(256), \
+                                      LDSB, stream, e0, e1, 0, x, dz, cd, slabs, F, T, H);                  \
+    else hipLaunchKernelGGL((conv_wgrad_tr2_kernel<__VA_ARGS__, UNP>), dim3(3 * kTr2Slots), dim3(256), LDSB, \
+                            stream, x, dz, cd, slabs, F, T, H);                                             \
   } while (0)
-  if (layer == 2 && th == 6) LR_WGTR2(0, 32, 2, 5, 5, 24, 2, 6);
-  else if (layer == 2) LR_WGTR2(2, 32, 2, 5, 5, 24, 2, 4);
-  else LR_WGTR2(1, 64, 3, 3, 3, 12, 2, 6);
+#define LR_WGTR2_KERNEL(IDX, ...)                                         \
+  do {                                                                   \
+    if (cd) LR_WGTR2(2 * (IDX) + 1, true, __VA_ARGS__);                   \
+    else LR_WGTR2(2 * (IDX), false, __VA_ARGS__);                         \
+  } while (0)
+  if (cd && (H & 1)) return LR_ERR_UNSUPPORTED;
+  if (layer == 2 && th == 6) LR_WGTR2_KERNEL(0, 32, 2, 5, 5, 24, 2, 6);
+  else if (layer == 2) LR_WGTR2_KERNEL(2, 32, 2, 5, 5, 24, 2, 4);
+  else LR_WGTR2_KERNEL(1, 64, 3, 3, 3, 12, 2, 6);
+#undef LR_WGTR2_KERNEL
 #undef LR_WGTR2
   return lr_launch_status();
 }

@@ -39,7 +39,9 @@ _PATCH_KERNELS = True
 _FUSE_FIRST_LAYER = True
 # ... and this one to compare the data gradients that un-pool on the fly (lr_conv3d_dgrad_pooled: layers 2 and 3 take
 # the pooled gradient and the window codes) with the staged form (lr_unpool_code_bf16, then lr_conv3d_forward on dZ)
-_FUSE_UNPOOL = True
+# (LIPREADING_FUSE_UNPOOL: experiment switch for A/B timing — 0 = staged, 1 = only the data gradients un-pool on the fly)
+_FUSE_UNPOOL = os.environ.get("LIPREADING_FUSE_UNPOOL", "2") != "0"
+_FUSE_UNPOOL_WGRAD = os.environ.get("LIPREADING_FUSE_UNPOOL", "2") == "2"
 
 
 def _pad4(c):
@@ -223,7 +225,17 @@ class _ConvFrontendFunction(torch.autograd.Function):
                                           cout, cin, kt, kh, kw, pt, ph, pw, st), "lr_conv3d_dgrad_pooled")
 
       def weight_half(accumulate, stream):
-        # un-pool (the bias gradient — the sum of the routed gradients — falls out of that pass), then dW
+        # dW and the bias gradient straight from the pooled gradient and the codes where the layer has the kernel
+        # (no dZ at all then) ...
+        if coded and _FUSE_UNPOOL_WGRAD and L.lr_conv3d_wgrad_pooled_supported(h, w, cin_p, cin, cout, kt, kh, kw, stride,
+                                                                              pt, ph, pw) == 2:
+          rc = L.lr_conv3d_wgrad_pooled(x_in.data_ptr(), pooled.data_ptr(), act.data_ptr(), dP_in.data_ptr(),
+                                        grads[2 * li].data_ptr(), grads[2 * li + 1].data_ptr(), ws.data_ptr(), wbytes,
+                                        accumulate, B, T, h, w, cin_p, cin, cout, kt, kh, kw, stride, pt, ph, pw, 0, stream)
+          if rc != -4:   # LR_ERR_UNSUPPORTED: a frame count whose tile table does not fit the kernel's LDS
+            _C.check(rc, "lr_conv3d_wgrad_pooled")
+            return None
+        # ... else un-pool (the bias gradient — the sum of the routed gradients — falls out of that pass), then dW
         dZ = torch.empty((frames, ho, wo, cout), dtype=bf, device=dev)
         if coded:
           _C.check(L.lr_unpool_code_bf16(pooled.data_ptr(), act.data_ptr(), dP_in.data_ptr(), dZ.data_ptr(),

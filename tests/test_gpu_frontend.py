@@ -153,9 +153,9 @@ def test_pixel_lipreader_trains_end_to_end(dev):
 @pytest.mark.parametrize("B,T,H", [(2, 9, 96), (1, 5, 96), (3, 7, 64), (2, 75, 96)])
 def test_data_gradients_that_unpool_on_the_fly_equal_the_staged_ones(dev, B, T, H):
   """Layers 2 and 3: lr_conv3d_dgrad_pooled takes the pooled gradient and the window codes and rebuilds its dZ patch
-  on the way into LDS; staged reference: lr_unpool_code_bf16 materialises dZ and lr_conv3d_forward (the same
-  patch-resident kernel) reads it.  The same bf16 values reach the same MFMAs in the same order: every gradient is
-  bit-identical, with and without the conv side stream."""
+  on the way into LDS, and so does their weight gradient (lr_conv3d_wgrad_pooled); staged reference:
+  lr_unpool_code_bf16 materialises dZ and lr_conv3d_forward / lr_conv3d_wgrad (the same kernels) read it.  The same
+  bf16 values reach the same MFMAs in the same order: every gradient is bit-identical."""
   from lipreading_amd import frontend as FE
   torch.manual_seed(19)
   fe = FE.ConvFrontend3D().to(dev)
@@ -163,8 +163,8 @@ def test_data_gradients_that_unpool_on_the_fly_equal_the_staged_ones(dev, B, T, 
   clips = torch.randint(0, 256, (B, T, 3, H, H), generator=g, dtype=torch.uint8).to(dev)
   wgt = torch.randn(B, T, FE.feature_dim(H, H), generator=g).to(dev)
   res = {}
-  for fused in (True, False):
-    FE._FUSE_UNPOOL = fused
+  for fused in (2, 1, 0):   # data and weight gradients un-pool on the fly | data gradients only | staged
+    FE._FUSE_UNPOOL, FE._FUSE_UNPOOL_WGRAD = fused > 0, fused > 1
     try:
       fe.zero_grad()
       out = fe(clips)
@@ -172,9 +172,16 @@ def test_data_gradients_that_unpool_on_the_fly_equal_the_staged_ones(dev, B, T, 
       torch.cuda.synchronize()
       res[fused] = [out.detach().clone()] + [p.grad.detach().clone() for p in fe.parameters_in_order()]
     finally:
-      FE._FUSE_UNPOOL = True
-  for a, b in zip(res[True], res[False]):
+      FE._FUSE_UNPOOL = FE._FUSE_UNPOOL_WGRAD = True
+  for a, b in zip(res[1], res[0]):
     assert torch.equal(a, b)
+  # the weight gradients that un-pool on the fly (lr_conv3d_wgrad_pooled, layers 2 and 3): the same products in the
+  # same order — bit-identical; their bias gradients are the same sums in another order
+  for i, (a, b) in enumerate(zip(res[2], res[0])):
+    if i in (4, 6):   # conv2.bias, conv3.bias
+      assert float((a - b).abs().max()) <= 2e-5 * max(1e-6, float(b.abs().max())), i
+    else:
+      assert torch.equal(a, b), i
   # the codes: 0..3 = position of the window's first maximum, 4 = pooled activation 0 (ReLU blocks the gradient)
   from lipreading_amd import _C
   L = _C.lib()
