@@ -963,14 +963,24 @@ int bwd_launch(const float* gates, const float* extra, const float* y, const flo
   return LR_OK;
 }
 
-// the instantiated (gates, members) pairs: members = ceil(H / 32)
-//   CC =  8  H in (224, 256]   GRU / LSTM-256 with an initial state (decoder behind a 128-unit bidirectional encoder)
-//   CC = 16  H in (480, 512]   LSTM-512 (config/train/attn/attention_type), the decoder GRU/LSTM-512
-//   CC = 22  H in (672, 704]   LSTM-700 (config/defaults.txt)
-//   CC = 24  H in (736, 768]   LSTM-768 (config/archive/experiments/ecd)
-//   CC = 25  H in (768, 800]   GRU-800 (config/train/micro)
-// (LSTM with 25 members — no reference config — would need 168 KB of LDS for its backward fragments: step kernels)
-#define LR_CLUSTER_SHAPES(X) X(3, 8) X(4, 8) X(3, 16) X(4, 16) X(3, 22) X(4, 22) X(3, 24) X(4, 24) X(3, 25)
+// the instantiated (gates, members) pairs: members = ceil(H / 32) — EVERY hidden size the kernels' storage holds:
+//   GRU   1 .. 27 members  H <= 864   (GRU-800: config/train/micro; the decoder GRU-512 behind a BiGRU-256)
+//   LSTM  1 .. 24 members  H <= 768   (LSTM-700: config/defaults.txt; LSTM-512: config/train/attn/attention_type;
+//                                      LSTM-768: config/archive/experiments/ecd)
+// What stops there is the member's slice of W_hh (G x 32 rows x HP columns x hi + lo planes), which must stay in the
+// registers and LDS of ONE compute unit: 28 GRU members would take 164 KB of LDS for the forward fragments, 25 LSTM
+// members 186 KB for the backward ones (the backward keeps 60 fragments per wave in AGPRs, 14 in VGPRs — 198 of 256
+// VGPRs at 24 members —, the rest in LDS).  Larger layers (LSTM-800, the 1024 / 1400 / 1536-unit decoders behind
+// BiLSTM-512 / 700 / 768 encoders, better_model.py:134-148) would need 16-unit members on clusters that span XCDs:
+// they run the step kernels (lr_rnn.hip), and lipreading_amd.encoder says so once.
+#define LR_CLUSTER_CC_COMMON(X, g) \
+  X(g, 1) X(g, 2) X(g, 3) X(g, 4) X(g, 5) X(g, 6) X(g, 7) X(g, 8) X(g, 9) X(g, 10) X(g, 11) X(g, 12) X(g, 13) X(g, 14) \
+  X(g, 15) X(g, 16) X(g, 17) X(g, 18) X(g, 19) X(g, 20) X(g, 21) X(g, 22) X(g, 23) X(g, 24)
+#define LR_CLUSTER_SHAPES(X) LR_CLUSTER_CC_COMMON(X, 3) X(3, 25) X(3, 26) X(3, 27) LR_CLUSTER_CC_COMMON(X, 4)
+#define X(g, c)                                                                                                      \
+  static_assert(Cfg<g, c>::FWD_LDS <= 160 * 1024 && Cfg<g, c>::BWD_LDS <= 160 * 1024, "a member's fragments fit one CU");
+LR_CLUSTER_SHAPES(X)
+#undef X
 
 }  // namespace
 

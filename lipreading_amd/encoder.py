@@ -78,6 +78,20 @@ def flush_deferred():
   del _deferred[:]   # the tensors the side stream was using may be released now
 
 
+# (rnn_type, H) pairs whose fall-back to the per-step kernels has been announced (one warning each)
+_fallback_noted = set()
+
+
+def _note_step_kernel_fallback(rnn_type, H):
+  if (rnn_type, H) in _fallback_noted:
+    return
+  _fallback_noted.add((rnn_type, H))
+  import warnings
+  warnings.warn("lipreading_amd: no one-launch recurrence for %s-%d (a member's slice of W_hh must fit one compute unit: "
+                "GRU up to 864 hidden units, LSTM up to 768, and the device needs 8 * ceil(H / 32) compute units); this "
+                "layer runs one launch per time step (3-5x slower per pass)" % (rnn_type, H), stacklevel=3)
+
+
 class _RNNLayerFunction(torch.autograd.Function):
   """One (bi)directional layer: lr_rnn_layer_forward / lr_rnn_layer_backward."""
 
@@ -264,9 +278,8 @@ class VideoEncoder(nn.Module):
     # how the T-step recurrence of a layer runs (not in the reference):
     #   'f32'    one launch per time step, exact fp32 MFMA — every shape
     #   'split'  ONE launch per layer pass, fp32-faithful (W_hh and the state as bf16 hi + lo planes, ~1e-6
-    #            of the fp32 product) — GRU, H = 256: a pair of CUs per (sample, direction) (lr_rnn_pair.hip);
-    #            LSTM, H = 768: a cluster of 24 CUs per (direction, 8 samples) (lr_rnn_cluster.hip); every other
-    #            shape as 'f32'
+    #            of the fp32 product): a cluster of ceil(H / 32) CUs per (direction, 8 samples) (lr_rnn_cluster.hip) —
+    #            GRU with H <= 864, LSTM with H <= 768; larger layers as 'f32' (announced once)
     #   'bf16'   one launch per pass with single-plane bf16 recurrent operands (~1e-3): the build-defined
     #            pixel regime's choice (frontend.PixelLipReader sets it); where unsupported as 'f32'
     #   'auto'   (default) same as 'split': reference-faithful numerics at the one-launch speed
@@ -328,9 +341,13 @@ class VideoEncoder(nn.Module):
       if self.recurrence == 'bf16' and _C.lib().lr_rnn_persistent_supported(mode, B, max_len, x.shape[2], H, D):
         lmode |= _RECUR_BF16
       else:
-        # lr_rnn_pair_supported: 1 = GRU-256 (CU pairs), 2 = LSTM-768 (24-CU clusters); 0 = step kernels
-        if self.recurrence in ('auto', 'split') and _C.lib().lr_rnn_pair_supported(mode, B, max_len, x.shape[2], H, D):
-          lmode |= _RECUR_SPLIT
+        # lr_rnn_pair_supported: 2 = clusters of ceil(H / 32) CUs (GRU H <= 864, LSTM H <= 768), 1 = GRU-256 on CU
+        # pairs (a device too small for a cluster launch); 0 = step kernels
+        if self.recurrence in ('auto', 'split'):
+          if _C.lib().lr_rnn_pair_supported(mode, B, max_len, x.shape[2], H, D):
+            lmode |= _RECUR_SPLIT
+          elif mode != 2:
+            _note_step_kernel_fallback(self.rnn_type, H)
       y, h_n, c_n = _RNNLayerFunction.apply(x, lens, lmode, H, need_dx, need_final_state, *weights)
       if need_final_state:
         # (D,B,H) -> (B, D*H): forward direction first, as _cat_directions (better_model.py:98-112)
