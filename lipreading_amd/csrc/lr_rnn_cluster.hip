@@ -161,7 +161,14 @@ __device__ __forceinline__ int xcc_id() {
 #define LR_MFMA_A0(acc, a, w) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(w))
 #define LR_MFMA_A(acc, a, w) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w))
 #define LR_MFMA_V(acc, a, w) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(w))
+// The asm MFMAs are opaque to the compiler's hazard recogniser: let the last ones retire before any VALU instruction
+// reads an accumulator — and TIE every accumulator to a statement behind the wait (LR_ACC_READY), or the reads are free
+// to move in front of it: they are plain register arithmetic, which a volatile asm with a "memory" clobber does not
+// order.  (Round 4 found <3,2>'s ISA adding acc0 + acc1 of two registers BETWEEN the last two MFMAs: the 2-member
+// clusters were off by 1e-4 — the lo-plane product of the last k step — in half of the samples; every other
+// instantiation happened to be scheduled the other way round.)
 #define LR_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 3" ::: "memory")
+#define LR_ACC_READY(acc) asm volatile("" : "+v"(acc))
 
 // do all members of this cluster sit on one XCD?  Every member publishes its XCC id (agent scope) and reads all
 // CC; the verdict is the same on every member because it is computed from the same CC words.  Returns through
@@ -472,6 +479,10 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
         }
       }
       LR_MFMA_DRAIN();
+      LR_ACC_READY(acc0[0]);
+      LR_ACC_READY(acc0[1]);
+      LR_ACC_READY(acc1[0]);
+      LR_ACC_READY(acc1[1]);
       // tile (wave, t): S[row 4 kg + r][col] ; rows 0-7 = state hi of samples 0-7, rows 8-15 = state lo
       float* Sw = S + wave * 2 * 256;
 #pragma unroll
@@ -686,6 +697,8 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
       }
     }
     LR_MFMA_DRAIN();
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) LR_ACC_READY(acc[tl]);
     // rows 4 kg + r: rows 0-7 (kg 0, 1) came from the hi plane of dG, rows 8-15 (kg 2, 3) from the lo plane of the
     // same samples: fold across lanes +-32.  Afterwards both halves hold sample 4 (kg & 1) + r of the tile's unit
     // col; the lower half keeps r = 0, 1, the upper half r = 2, 3: sample 4 (kg & 1) + 2 (kg >> 1) + row.

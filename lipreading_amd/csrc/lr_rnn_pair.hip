@@ -296,6 +296,10 @@ __global__ __launch_bounds__(256, 1) void gru256_fwd_pair_kernel(float* __restri
       // the asm MFMAs are opaque to the compiler's hazard recogniser: let the last ones retire before any
       // VALU instruction reads an accumulator
       asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+      // (... and tie the accumulators to a statement behind the wait: their reads are plain register arithmetic,
+      // which nothing else keeps behind it — see LR_ACC_READY in lr_rnn_cluster.hip)
+#pragma unroll
+      for (int tl = 0; tl < FNT; ++tl) asm volatile("" : "+v"(acc[tl]));
       // rows 0 (state hi) + 1 (state lo) of the tile = the full product; they sit in lanes kg == 0, regs 0, 1
       if (kg == 0) {
 #pragma unroll
@@ -528,6 +532,11 @@ __global__ __launch_bounds__(256, 1) void gru256_bwd_pair_kernel(
       LR_PAIR_KSTEPS(12, BKS)
 #undef LR_PAIR_KSTEPS
       asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#pragma unroll
+      for (int nt = 0; nt < BNT; ++nt) {   // (reads stay behind the wait: see the forward kernel)
+        asm volatile("" : "+v"(acc0[nt]));
+        asm volatile("" : "+v"(acc1[nt]));
+      }
       if (kg == 0) {   // rows 0 + 1: lanes 0..15, registers 0 and 1
 #pragma unroll
         for (int nt = 0; nt < BNT; ++nt)

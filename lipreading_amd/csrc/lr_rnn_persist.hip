@@ -212,6 +212,10 @@ __global__ __launch_bounds__(256, 1) void gru256_fwd_persist_kernel(float* __res
     // the asm MFMAs are opaque to the compiler's hazard recogniser: let the last ones retire before
     // any VALU instruction reads an accumulator
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+    // (... and tie the accumulators to a statement behind the wait: their reads are plain register arithmetic,
+    // which nothing else keeps behind it — see LR_ACC_READY in lr_rnn_cluster.hip)
+#pragma unroll
+    for (int tl = 0; tl < PNT; ++tl) asm volatile("" : "+v"(acc[tl]));
     // rows 4 kg + i of the result tile: the group's samples are rows 0..PBH-1, i.e. lanes with kg == 0
     if (kg == 0) {
 #pragma unroll
@@ -398,6 +402,11 @@ __global__ __launch_bounds__(256, 1) void gru256_bwd_persist_kernel(
       }
     }
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {   // (reads stay behind the wait: see the forward kernel)
+      asm volatile("" : "+v"(acc0[nt]));
+      asm volatile("" : "+v"(acc1[nt]));
+    }
     if (kg == 0) {   // row 0 = the sample: lanes 0..15, register 0
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) S[64 * wave + 16 * nt + col] = acc0[nt][0] + acc1[nt][0];

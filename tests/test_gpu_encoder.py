@@ -474,8 +474,8 @@ CLUSTER_CASES = [("LSTM", 768, 32, 75, True, None, 1), ("LSTM", 768, 37, 20, Tru
                  # round 4: every member count the kernels' storage holds (1 .. 27 GRU, 1 .. 24 LSTM), not a list of sizes
                  ("LSTM", 128, 32, 75, True, "ragged", 1), ("LSTM", 384, 32, 40, True, None, 1),
                  ("LSTM", 600, 32, 75, True, "ragged", 1), ("LSTM", 640, 9, 7, False, "ragged", 2),
-                 ("LSTM", 32, 17, 9, True, "ragged", 1), ("LSTM", 10, 3, 5, True, "ragged", 2),
-                 ("GRU", 40, 11, 6, True, "ragged", 1), ("GRU", 96, 32, 20, False, None, 1),
+                 ("LSTM", 32, 17, 9, True, "ragged", 1), ("LSTM", 12, 3, 5, True, "ragged", 2),
+                 ("GRU", 40, 11, 6, True, "ragged", 1), ("GRU", 96, 32, 20, False, None, 1), ("GRU", 64, 32, 75, True, None, 2),
                  ("GRU", 864, 32, 30, True, "ragged", 1), ("GRU", 832, 10, 6, False, "ragged", 1),
                  ("GRU", 160, 8, 75, True, None, 1), ("LSTM", 200, 5, 11, True, "ragged", 1)]
 
@@ -487,11 +487,11 @@ def test_one_launch_recurrence_covers_every_hidden_size_its_storage_holds(dev):
   from lipreading_amd import _C, encoder as E
   from lipreading_amd.data import default_char2idx
   L = _C.lib()
-  for H in (1, 7, 32, 33, 128, 384, 600, 640, 700, 768):
+  for H in (4, 8, 32, 36, 128, 384, 600, 640, 700, 768):
     assert L.lr_rnn_pair_supported(1, 32, 75, 204, H, 2) == 2, H
-  for H in (1, 128, 256, 512, 800, 833, 864):
+  for H in (4, 128, 256, 512, 800, 836, 864):
     assert L.lr_rnn_pair_supported(0, 32, 75, 204, H, 2) == 2, H
-  for mode, H in ((1, 769), (1, 800), (1, 1024), (1, 1400), (1, 1536), (0, 865), (0, 1024)):
+  for mode, H in ((1, 772), (1, 800), (1, 1024), (1, 1400), (1, 1536), (0, 868), (0, 1024), (1, 30)):
     assert L.lr_rnn_pair_supported(mode, 32, 75, 204, H, 1) == 0, (mode, H)
   enc = E.VideoEncoder(16, 800, rnn_type='LSTM', bidirectional=False, enable_ctc=True, vocab_size=64,
                        char2idx=default_char2idx()).to(dev)
