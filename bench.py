@@ -47,6 +47,7 @@ MODELS = {
     "lstm700": ("LSTM", 700, True),   # config/defaults.txt:19-21 (hidden_size 700, LSTM)
     "lstm512": ("LSTM", 512, True),   # config/train/attn/attention_type:16-19 (BiLSTM-512 + CTC)
     "gru800": ("GRU", 800, True),     # config/train/micro:6-8 (GRU-800; the archived trainer stacks 5 layers: --layers 5)
+    "lstm700uni": ("LSTM", 700, False),   # config/defaults.txt:19-26 as shipped: LSTM-700, bidirectional=False (decoder LSTM-700)
 }
 T_FRAMES, N_LMK, LMK_DIM, VOCAB, LABEL_LEN, IMG = 75, 68, 3, 64, 30, 96
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -116,7 +117,8 @@ def conv_flops(B):
   return out
 
 
-def cpu_baseline(regime, model, layers, B, budget_s=20.0, warmup=3, min_steps=10):
+def cpu_baseline(regime, model, layers, B, budget_s=20.0, warmup=3, min_steps=10, char_dim=300, attention='1_layer_nn',
+                 use_ctc=True):
   """The oracle's step on this host's cores: `warmup` untimed steps, then >= `min_steps` timed ones
   (BASELINE.md section 3), each timed on its own; median and min reported.  The sample is bounded:
   when a full-batch step would blow the budget (the pixel regime's conv frontend on the CPU), the
@@ -129,6 +131,7 @@ def cpu_baseline(regime, model, layers, B, budget_s=20.0, warmup=3, min_steps=10
   tfm = regime == "pixels_tfm"
   pixels = regime == "pixels" or tfm
   B_cpu = min(B, 4) if pixels else B     # ~1 s per step either way on a 100+-thread host
+  full_steps = 3                         # timed steps at the GPU line's batch when the sample's batch is smaller
   frame_dim = 96 * (IMG // 16) ** 2 if pixels else N_LMK * LMK_DIM
   if tfm:
     tenc = O.OracleTransformerEncoder(frame_dim, 256, 4, 4, 1024, VOCAB, O.default_char2idx()).train()
@@ -136,7 +139,7 @@ def cpu_baseline(regime, model, layers, B, budget_s=20.0, warmup=3, min_steps=10
     enc.parameters = tenc.parameters
   else:
     enc = O.OracleVideoEncoder(frame_dim, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
-                               enable_ctc=True, vocab_size=VOCAB, char2idx=O.default_char2idx()).train()
+                               enable_ctc=use_ctc, vocab_size=VOCAB, char2idx=O.default_char2idx()).train()
   params = list(enc.parameters())
   convs = []
   if pixels:
@@ -147,8 +150,8 @@ def cpu_baseline(regime, model, layers, B, budget_s=20.0, warmup=3, min_steps=10
   attn = regime == "landmarks_attn"
   dec = None
   if attn:
-    dec = O.OracleCharDecodingStep(H * (2 if bi else 1), rnn_type, 1, 300, VOCAB, O.default_char2idx(),
-                                   attention_type='1_layer_nn').train()
+    dec = O.OracleCharDecodingStep(H * (2 if bi else 1), rnn_type, 1, char_dim, VOCAB, O.default_char2idx(),
+                                   attention_type=attention).train()
   opt = torch.optim.Adam(params + (list(dec.parameters()) if attn else []), lr=1e-4)
   data = {}
 
@@ -163,13 +166,18 @@ def cpu_baseline(regime, model, layers, B, budget_s=20.0, warmup=3, min_steps=10
     if pixels:
       feats = O.conv_frontend(clips, convs, emulate_bf16=False)
       x = feats.reshape(n, T_FRAMES, -1, 1)
-    lp, hid, st = enc(x, frame_lens)
-    loss = O.ctc_loss(lp, chars[:, 1:], frame_lens, char_lens - 1, 'mean')
+    if use_ctc:
+      lp, hid, st = enc(x, frame_lens)
+      loss = O.ctc_loss(lp, chars[:, 1:], frame_lens, char_lens - 1, 'mean')
+    else:   # (enable_ctc=False, config/defaults.txt:12: the encoder returns (hidden, final_state), train_better_model.py:52)
+      hid, st = enc(x, frame_lens)
+      loss = None
     opt.zero_grad()
     if attn:   # train_better_model.py:56-74, both backward calls as the reference makes them
       dl, _ = O.decoder_loop(dec, chars, char_lens, hid, frame_lens, st)
-      dl.backward(retain_graph=True)
-    loss.backward()
+      dl.backward(retain_graph=loss is not None)
+    if loss is not None:
+      loss.backward()
     torch.nn.utils.clip_grad_norm_(params, 50)
     if attn:
       torch.nn.utils.clip_grad_norm_(dec.parameters(), 50)
@@ -187,13 +195,17 @@ def cpu_baseline(regime, model, layers, B, budget_s=20.0, warmup=3, min_steps=10
   per = B_cpu * T_FRAMES
   full = None
   if B_cpu != B:
-    # the bounded sample runs at a smaller batch than the GPU line: ONE step at the GPU line's batch beside it, so the
-    # two figures also exist at the same batch (a single timed step after one untimed one: seconds each)
+    # the bounded sample runs at a smaller batch than the GPU line: `full_steps` steps at the GPU line's batch beside it,
+    # so the two figures also exist at the same batch (one untimed step, then the timed ones: seconds each; median)
     step(B)
-    t0 = time.perf_counter()
-    step(B)
-    dt = time.perf_counter() - t0
-    full = {"batch": B, "steps": 1, "ms_per_step": round(dt * 1e3, 1), "value": round(B * T_FRAMES / dt, 1), "unit": "frames/s"}
+    dts = []
+    for _ in range(full_steps):
+      t0 = time.perf_counter()
+      step(B)
+      dts.append(time.perf_counter() - t0)
+    dt = statistics.median(dts)
+    full = {"batch": B, "steps": full_steps, "ms_per_step": round(dt * 1e3, 1), "ms_per_step_min": round(min(dts) * 1e3, 1),
+            "value": round(B * T_FRAMES / dt, 1), "unit": "frames/s"}
   return {"value": round(per / med, 1), "unit": "frames/s", "value_best": round(per / best, 1), "full_batch_step": full,
           "ms_per_step_median": round(med * 1e3, 2), "ms_per_step_min": round(best * 1e3, 2),
           "steps": len(times), "warmup": warmup,
@@ -345,6 +357,57 @@ def parity_block(regime, model_name, layers, B, dev, train_steps=50):
   return out
 
 
+def parity_block_attn(model_name, B, dev, char_dim, attention, use_ctc):
+  """The reference's WHOLE forward (train_better_model.py:46-65) on identical inputs and weights: encoder (+ CTC 'mean'
+  when the encoder has it) and the teacher-forced CharDecodingStep loop with its NLL / non-PAD count — HIP path against
+  the oracle (stock torch CPU ops in the reference's order).  Tolerance 1e-4 absolute on both losses (fp32)."""
+  import torch
+  from oracle import torch_oracle as O   # the checker
+  from lipreading_amd import train as T
+  from lipreading_amd.attention_decoder import CharDecodingStep
+  from lipreading_amd.ctc import ctc_loss_with_status
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.encoder import VideoEncoder
+  rnn_type, H, bi = MODELS[model_name]
+  D = 2 if bi else 1
+  torch.manual_seed(123456)
+  ref = O.OracleVideoEncoder(N_LMK * LMK_DIM, H, rnn_type=rnn_type, num_layers=1, bidirectional=bi, enable_ctc=use_ctc,
+                             vocab_size=VOCAB, char2idx=O.default_char2idx()).eval()
+  rdec = O.OracleCharDecodingStep(D * H, rnn_type, 1, char_dim, VOCAB, O.default_char2idx(), attention_type=attention).eval()
+  enc = VideoEncoder(N_LMK * LMK_DIM, H, rnn_type=rnn_type, num_layers=1, bidirectional=bi, enable_ctc=use_ctc,
+                     vocab_size=VOCAB, char2idx=default_char2idx())
+  dec = CharDecodingStep(enc, char_dim=char_dim, vocab_size=VOCAB, char2idx=default_char2idx(), attention_type=attention)
+  enc.load_state_dict(ref.state_dict())
+  dec.load_state_dict(rdec.state_dict())
+  enc, dec = enc.to(dev).eval(), dec.to(dev).eval()
+  frames, frame_lens, chars, char_lens = synth_batch(B, 123456)
+  labels, label_lens = chars[:, 1:], char_lens - 1
+  L = int(label_lens.max())
+  out = {"regime": "landmarks_attn", "batch": B, "tol": PARITY_TOL_LANDMARKS,
+         "what": "same landmarks, captions and weights; oracle = reference VideoEncoder%s + CharDecodingStep loop (teacher "
+                 "forced) + NLL / non-PAD count on stock torch CPU ops (fp32)" % (" + ctc_loss" if use_ctc else "")}
+  with torch.no_grad():
+    if use_ctc:
+      lp_r, hid_r, st_r = ref(frames, frame_lens)
+      lp_h, hid_h, st_h = enc(frames.to(dev), frame_lens.to(dev), max_len=T_FRAMES)
+      l_r = float(O.ctc_loss(lp_r, labels, frame_lens, label_lens, 'mean'))
+      l_h, status, _ = ctc_loss_with_status(lp_h, labels.to(dev), frame_lens.to(dev), label_lens.to(dev), 'mean')
+      out.update(ctc_loss_hip=round(float(l_h), 7), ctc_loss_oracle=round(l_r, 7), ctc_abs_diff=float("%.3g" % abs(float(l_h) - l_r)),
+                 greedy_strings_equal=GreedyStrings.hip(lp_h, frame_lens.to(dev)) == GreedyStrings.oracle(lp_r, frame_lens))
+    else:
+      hid_r, st_r = ref(frames, frame_lens)
+      hid_h, st_h = enc(frames.to(dev), frame_lens.to(dev), max_len=T_FRAMES)
+    dl_r, dlp_r = O.decoder_loop(rdec, chars, char_lens, hid_r, frame_lens, st_r)
+    dlp_h, _, _ = dec.decode_sequence(chars[:, :L].to(dev), st_h, frame_lens.to(dev), hid_h, teacher_forced=(True,) * L)
+    dl_h = float(T.decoder_nll(dlp_h, labels.to(dev), 0))
+  dd = abs(dl_h - float(dl_r))
+  out.update(decoder_loss_hip=round(dl_h, 7), decoder_loss_oracle=round(float(dl_r), 7), decoder_abs_diff=float("%.3g" % dd),
+             max_abs_decoder_log_prob_diff=float("%.3g" % float((dlp_h.cpu() - dlp_r).abs().max())),
+             abs_diff=float("%.3g" % max(dd, out.get("ctc_abs_diff", 0.0))))
+  out["ok"] = bool(out["abs_diff"] <= PARITY_TOL_LANDMARKS)
+  return out
+
+
 class GreedyStrings(object):
   @staticmethod
   def hip(lp, lens):
@@ -457,8 +520,9 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
     enc = TransformerVideoEncoder(frame_dim, d_model=256, nhead=4, num_layers=4, dim_feedforward=1024,
                                   enable_ctc=True, vocab_size=VOCAB, char2idx=default_char2idx())
   else:
+    # (the attention regime follows the reference's config file: --no-ctc = enable_ctc False, config/defaults.txt:12)
     enc = VideoEncoder(frame_dim, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
-                       enable_ctc=True, vocab_size=VOCAB, char2idx=default_char2idx())
+                       enable_ctc=not (attn and args.no_ctc), vocab_size=VOCAB, char2idx=default_char2idx())
   model = PixelLipReader(enc, ConvFrontend3D()) if pixels else enc
   # experiment switch: 'f32' = step kernels in the pixel regime; 'bf16' = the one-launch recurrence with
   # bf16 recurrent operands in a landmark regime too (not reference-faithful: reported as such)
@@ -481,8 +545,8 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
   if attn:
     import torch.nn.functional as F
     from lipreading_amd.attention_decoder import CharDecodingStep
-    dec = CharDecodingStep(enc, char_dim=300, vocab_size=VOCAB, char2idx=default_char2idx(),
-                           attention_type='1_layer_nn').to(dev).train()
+    dec = CharDecodingStep(enc, char_dim=args.char_dim, vocab_size=VOCAB, char2idx=default_char2idx(),
+                           attention_type=args.attention).to(dev).train()
     dec_flat = FlatParameters(dec)
     dec_opt = FusedAdam(dec_flat, lr=1e-4)
   use_graph = not args.no_graph
@@ -522,8 +586,10 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
 
   def step(graphs=graphs, sync=None, dec_sync=None):
     if attn:
-      _, loss, status = T.decoder_step(enc, dec, (opt, dec_opt), frames, frame_lens, chars, char_lens, flags, 1, 0,
-                                       grad_norm=50, max_len=T_FRAMES, grad_sync=(sync, dec_sync), graphs=graphs)
+      dloss, loss, status = T.decoder_step(enc, dec, (opt, dec_opt), frames, frame_lens, chars, char_lens, flags, 1, 0,
+                                           grad_norm=50, max_len=T_FRAMES, grad_sync=(sync, dec_sync), graphs=graphs)
+      if loss is None:   # enable_ctc False: the decoder loss is the step's loss, nothing can be skipped
+        return dloss, _zero_status
       return loss, status
     return T.ctc_step(model, opt, frames, frame_lens, chars, char_lens, grad_norm=50, max_len=T_FRAMES,
                       grad_sync=sync, graphs=graphs)
@@ -533,6 +599,7 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
       dist.barrier()
     torch.cuda.synchronize()
 
+  _zero_status = torch.zeros(1, dtype=torch.int32, device=dev)
   graph_note = None
   step_sync = dict(sync=sync, dec_sync=dec_sync)
   # untimed priming, before the W warm-up steps: a shape's first steps run eagerly and the next one is
@@ -812,10 +879,15 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
                            if rec == "split" else "input projection bf16x3, fp32 recurrence"), D * H))
   elif attn:
     res["workload"] = ("regime R+decoder (the reference's whole train step): landmarks (B=%d,T=75,68,3) f32 -> "
-                       "1-layer Bi%s-%d -> Linear(%d,65) + CTC 'mean' (L=30+EOS) AND CharDecodingStep x31 "
-                       "(%s-%d, char_dim 300, 1_layer_nn attention over the 75 encoder states, teacher forced, "
+                       "1-layer %s%s-%d%s AND CharDecodingStep x31 "
+                       "(%s-%d, char_dim %d, %s attention over the 75 encoder states, teacher forced, "
                        "multinomial sample per step) + NLL -> backward -> per-module clip_grad_norm 50 -> Adam 1e-4"
-                       % (B, rnn_type, H, D * H, rnn_type, D * H))
+                       % (B, "Bi" if bi else "", rnn_type, H,
+                          " -> Linear(%d,65) + CTC 'mean' (L=30+EOS)" % (D * H) if enc.enable_ctc else " (enable_ctc False)",
+                          rnn_type, D * H, args.char_dim, args.attention))
+    dec_kind = L.lr_rnn_pair_supported({"GRU": 0, "LSTM": 1, "RNN": 2}[rnn_type], B, LABEL_LEN + 1, args.char_dim + D * H, D * H, 1)
+    res["decoder_recurrence"] = ("one launch per loop pass (cluster of %d CUs per 8 samples)" % ((D * H + 31) // 32) if dec_kind == 2
+                                 else "one launch per decoder step (no one-launch kernels for %s-%d)" % (rnn_type, D * H))
   else:
     res["workload"] = ("regime R (reference-faithful): landmarks (B=%d,T=75,68,3) f32 -> %d-layer Bi%s-%d (%s) -> "
                        "Linear(%d,65) -> masked log-softmax -> CTC 'mean' (L=30+EOS) -> backward -> "
@@ -846,6 +918,10 @@ def main():
                   help="launch every kernel eagerly instead of replaying a captured hipGraph")
   ap.add_argument("--repeats", type=int, default=5,
                   help="how many times the timed region of exactly --steps steps is repeated (median reported)")
+  ap.add_argument("--char-dim", type=int, default=300, help="landmarks_attn: the decoder's character embedding size "
+                  "(config/defaults.txt: 300; config/train/attn/attention_type: 256)")
+  ap.add_argument("--attention", default="1_layer_nn", help="landmarks_attn: attention_type of CharDecodingStep")
+  ap.add_argument("--no-ctc", action="store_true", help="landmarks_attn: enable_ctc False (config/defaults.txt)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-budget", type=float, default=12.0,
                   help="seconds of timed CPU-oracle steps per regime (never fewer than 10 steps)")
@@ -916,6 +992,8 @@ def main():
         "pair_errors": sum(r.get("pair_errors", 0) for r in results),
         "roofline": head["roofline"], "ctc": head.get("ctc"),
     }
+    if head.get("decoder_recurrence"):
+      out["config"]["decoder_recurrence"] = head["decoder_recurrence"]
     if len(results) > 1:
       out["regimes"] = {r["regime"]: {"value": r["value"], "unit": "frames/s", "ms_per_step": r["ms_per_step"],
                                       "ms_per_step_min": r["ms_per_step_min"],
@@ -940,11 +1018,15 @@ def main():
       for rg in ("pixels", "landmarks"):
         if rg in by_regime:
           par[rg] = parity_block(rg, args.model, by_regime[rg]["layers"], args.batch, dev)
+      if "landmarks_attn" in by_regime:
+        par["landmarks_attn"] = parity_block_attn(args.model, args.batch, dev, args.char_dim, args.attention, not args.no_ctc)
       out["parity"] = par.get(head["regime"])
       for rg, blk in par.items():
         if rg != head["regime"] and "regimes" in out and rg in out["regimes"]:
           out["regimes"][rg]["parity"] = blk
-      out["cpu_baseline"] = cpu_baseline(head["regime"], args.model, head["layers"], args.batch, args.cpu_budget)
+      out["cpu_baseline"] = cpu_baseline(head["regime"], args.model, head["layers"], args.batch, args.cpu_budget,
+                                         char_dim=args.char_dim, attention=args.attention,
+                                         use_ctc=not (head["regime"] == "landmarks_attn" and args.no_ctc))
       if "regimes" in out and "landmarks" in out["regimes"] and head["regime"] != "landmarks":
         out["regimes"]["landmarks"]["cpu_baseline"] = cpu_baseline(
             "landmarks", args.model, by_regime["landmarks"]["layers"], args.batch, args.cpu_budget)
