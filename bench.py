@@ -563,10 +563,12 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
     # of backward.  graph: forward+backward replay as one hipGraph and the exchange follows it
     # (hooks do not fire on replay, and no collective is ever captured).
     groups = None   # one bucket
-    if not tfm:
+    if pixels and not tfm:
+      # [conv], [encoder]: the encoder's bucket goes out behind the last recurrence of the step and rides under the
+      # conv backward (distributed.GradSync.groups_for_pixel_model)
+      groups = GradSync.groups_for_pixel_model(model, flat)
+    elif not tfm:
       groups = GradSync.groups_for_encoder(enc, flat)
-      if pixels:   # conv parameters come first in the flat buffer: one more bucket
-        groups = [list(range(min(min(g) for g in groups)))] + groups
     sync = GradSync(flat, groups=groups, overlap=not use_graph)
     sync.broadcast_parameters(0)
     if attn:

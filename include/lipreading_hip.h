@@ -220,6 +220,19 @@ int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D);         
  *                      in2[0] back to status[0] (skip the batch only if every rank skipped it) and raises the local
  *                      fault when in2[1] < 0 (ANY rank timed out: its garbage gradient is in the sum, so every rank
  *                      skips the update and the ranks stay identical). */
+/* lr_rnn_one_launch_enable   PRODUCT switch: 0 = every recurrence (encoder layers and the decoder loop) takes the
+ *                      per-step kernels from the next forward on, 1 (default) = the one-launch kernels where supported.
+ *                      lipreading_amd.train switches it off — once, with a warning — after three consecutive steps
+ *                      whose one-launch recurrence timed out (e.g. a device whose compute units are held by another
+ *                      process): a slow run instead of one that skips every batch (the reference's contract is skip a
+ *                      bad batch and keep training, src/train/train_better_model.py:49-50).  Size queries depend on it:
+ *                      switch between steps.
+ * lr_debug_busy        TEST HOOK: `workgroups` workgroups that each hold lds_bytes of LDS (up to a whole CU's 160 KB)
+ *                      and spin for `microseconds` — a stand-in for a foreign kernel (an RCCL ring kernel on another
+ *                      stream) that occupies compute units across the launch of a cluster recurrence. */
+void lr_rnn_one_launch_enable(int on);
+int lr_rnn_one_launch_enabled(void);
+int lr_debug_busy(int workgroups, int lds_bytes, int microseconds, lr_stream_t stream);
 int lr_rnn_pair_errors(void);
 int lr_fault_export(const int32_t* status, int32_t* out2, lr_stream_t stream);
 int lr_fault_import(const int32_t* in2, int32_t* status, lr_stream_t stream);

@@ -55,6 +55,9 @@ SIGNATURES = {
     "lr_rnn_debug_drop_member": (None, [c_int]),
     "lr_rnn_debug_disable_cluster": (None, [c_int]),
     "lr_rnn_debug_tune": (None, [c_int, c_int, c_int]),
+    "lr_rnn_one_launch_enable": (None, [c_int]),
+    "lr_rnn_one_launch_enabled": (c_int, []),
+    "lr_debug_busy": (c_int, [c_int, c_int, c_int, P]),
     "lr_rnn_reserve_bytes": (c_size_t, [c_int] * 6),
     "lr_rnn_workspace_bytes": (c_size_t, [c_int] * 6),
     "lr_rnn_layer_forward": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, c_int,

@@ -529,8 +529,39 @@ int lr_device_cus() {
 extern "C" void* lr_fault_words_ptr(void) { return lr_fault_words(); }
 extern "C" void lr_rnn_debug_drop_member(int member) { g_drop_member = member; }
 extern "C" void lr_rnn_debug_disable_cluster(int off) { g_cluster_off = off; }
-int lr_debug_cluster_disabled() { return g_cluster_off & 1; }
-int lr_debug_pair_disabled() { return (g_cluster_off >> 1) & 1; }
+// lr_rnn_one_launch_enable(0): the product's switch (lipreading_amd.train after repeated recurrence time-outs) — no
+// pair / cluster recurrence, encoder layers and decoder loop alike, until it is switched on again
+namespace { int g_one_launch_off = 0; }
+extern "C" void lr_rnn_one_launch_enable(int on) { g_one_launch_off = on ? 0 : 1; }
+extern "C" int lr_rnn_one_launch_enabled(void) { return g_one_launch_off ? 0 : 1; }
+int lr_debug_cluster_disabled() { return (g_cluster_off & 1) | g_one_launch_off; }
+int lr_debug_pair_disabled() { return ((g_cluster_off >> 1) & 1) | g_one_launch_off; }
+
+// TEST HOOK (lr_debug_busy): `workgroups` workgroups that each take a whole compute unit's LDS (lds_bytes) and spin for
+// `microseconds` of wall clock — a stand-in for a foreign kernel (an RCCL ring kernel on another stream) that holds CUs
+// while a cluster recurrence, whose members must all be resident, is launched.
+namespace {
+__global__ __launch_bounds__(256) void busy_kernel(long long ticks, int* sink) {
+  extern __shared__ int hog[];
+  const long long t0 = wall_clock64();
+  int v = 0;
+  while (wall_clock64() - t0 < ticks) {
+    hog[threadIdx.x] = v++;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  if (sink && v == -1) sink[0] = hog[0];
+}
+}  // namespace
+extern "C" int lr_debug_busy(int workgroups, int lds_bytes, int microseconds, lr_stream_t stream) {
+  LR_CHECK_ARG(workgroups > 0 && lds_bytes >= 1024 && lds_bytes <= 160 * 1024 && microseconds >= 0);
+  lr_clear_error();
+  if (hipFuncSetAttribute((const void*)busy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    return LR_ERR_LAUNCH;
+  // wall_clock64 ticks at 100 MHz on gfx9
+  hipLaunchKernelGGL(busy_kernel, dim3(workgroups), dim3(256), (size_t)lds_bytes, (hipStream_t)stream,
+                     (long long)microseconds * 100, (int*)nullptr);
+  return lr_launch_status();
+}
 int lr_debug_wgrad_f32() { return (g_cluster_off >> 2) & 1; }
 // tuning knobs of the cluster recurrence's exchange (lr_rnn_debug_tune): [0] forward, [1] backward; bits 0-7 = 64-clock
 // sleeps before the first poll, bits 8-15 = sleeps between poll rounds

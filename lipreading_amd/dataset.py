@@ -125,6 +125,13 @@ def load_pickles(pickle_dir, out_ext='.pkl'):
   return tuple(out)
 
 
+def _lmk_fingerprint(lmks):
+  """(frames, crc32 of the landmark bytes) of one sample: what ties a row of the pixel cache to its landmarks."""
+  import zlib
+  a = np.ascontiguousarray(np.asarray(lmks, dtype=np.float32))
+  return (int(a.shape[0]), int(zlib.crc32(a.tobytes())))
+
+
 class FrameCaptionDataset(object):
   """data_loader.py:154-257.  `__getitem__` returns (frames (len,68,3) float, caption ids)."""
 
@@ -152,12 +159,21 @@ class FrameCaptionDataset(object):
     self.pixels = None
     if pixels:   # build-defined: the u8 frames of a `frames=True` dataview, same filter and order as the landmarks
       ppath = os.path.join(pickle_dir, 'face_frames' + out_ext)
-      if refresh or not os.path.isfile(ppath):
-        self.pixels = self.construct_pixels(vid_ids, ppath, start_end=start_end, cap=cap, frame_type=frame_type,
-                                            in_ext=in_ext, fps=fps, threshold=threshold)
-      else:
+      cached = None
+      if not refresh and os.path.isfile(ppath):
         with open(ppath, 'rb') as f:
-          self.pixels = pickle.load(f)
+          cached = pickle.load(f)
+      # The landmark / caption pickles may come from an earlier run (other vid_ids, seed or train_split) while this
+      # cache is rebuilt from the CURRENT vid_ids: equal-length clips would then pair pixels with another sample's
+      # landmarks and caption without an error.  Every row carries the fingerprint of the landmarks it was cut with.
+      want = [_lmk_fingerprint(f) for f in self.frames]
+      if not (isinstance(cached, dict) and cached.get("lmk_fingerprint") == want):
+        cached = self.construct_pixels(vid_ids, ppath, start_end=start_end, cap=cap, frame_type=frame_type,
+                                       in_ext=in_ext, fps=fps, threshold=threshold)
+      assert cached["lmk_fingerprint"] == want, \
+          ("the pixel frames under %s do not belong to the cached landmarks in %s (built from other videos or another "
+           "split): pass refresh=True" % (os.path.dirname(vid_ids[0]), pickle_dir))
+      self.pixels = cached["pixels"]
       assert len(self.pixels) == len(self.frames)
       assert all(p.shape[0] == f.shape[0] and p.dtype == np.uint8 and p.ndim == 4 and p.shape[1] == 3
                  for p, f in zip(self.pixels, self.frames))
@@ -185,7 +201,8 @@ class FrameCaptionDataset(object):
     lmks, captions, start_ends, pix = load(frame_type), load(cap), load(start_end), load(pixel_type)
     assert len(pix) == len(lmks) == len(captions) == len(start_ends)
     order = keep_and_order(lmks, captions, start_ends, fps=fps, threshold=threshold)
-    out = [np.ascontiguousarray(pix[i]) for i in order]
+    out = {"pixels": [np.ascontiguousarray(pix[i]) for i in order],
+           "lmk_fingerprint": [_lmk_fingerprint(lmks[i]) for i in order]}
     with open(out_path, 'wb') as f:
       pickle.dump(out, f)
     return out

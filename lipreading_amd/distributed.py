@@ -92,6 +92,21 @@ class GradSync(object):
       groups.append([index[id(encoder.output_proj.weight)], index[id(encoder.output_proj.bias)]])
     return groups
 
+  @staticmethod
+  def groups_for_pixel_model(model, flat):
+    """[the conv frontend's parameters], [every parameter of the encoder]: TWO buckets.  The encoder's bucket is
+    complete when the first recurrent layer's weight gradients are — they are the last of the encoder's and run on
+    its side stream beside the conv backward — so its all-reduce (21+ MB, the step's large one) goes out when no
+    cluster recurrence is left in the step: an RCCL ring kernel never holds compute units while a one-launch
+    recurrence, whose workgroups must all be resident together, is being placed, and it still has the whole conv
+    backward (1.1 ms at the bench shape) to hide under.  (A bucket per recurrent layer, as groups_for_encoder cuts
+    them, puts the upper layers' all-reduces right beside the lower layers' recurrence launches.)"""
+    index = {id(p): i for i, p in enumerate(flat.params)}
+    conv = [index[id(p)] for p in model.frontend.parameters()]
+    enc = [index[id(p)] for p in model.encoder.parameters()]
+    assert sorted(conv + enc) == list(range(len(flat.params))) and max(conv) < min(enc)
+    return [conv, enc]
+
   def _make_hook(self, pi, kind=0):
     """kind 0: autograd's post-accumulate hook; kind 1: announced by a HIP backward that wrote the
     gradient in place.  A parameter whose gradient is written in place is announced by BOTH in the same

@@ -134,6 +134,12 @@ class StepGraphs(object):
     self.replays = 0
     self.captures = 0
 
+  def reset(self):
+    """Drop every captured graph (their launch sequences are stale: e.g. after the recurrence fell back to the step
+    kernels); shapes are captured again on their next steps."""
+    self._entries.clear()
+    self._failed.clear()
+
   def staging_buffers(self):
     """The static input tensors of the most recently used shape (None before its first step): a loader can write
     the next batch of that shape straight into them (same stream) and hand THEM to the step, which then skips
@@ -188,6 +194,65 @@ class StepGraphs(object):
     e["graph"], e["out"] = graph, out
     self.captures += 1
     return out
+
+
+class RecurrenceWatch(object):
+  """Keeps a run alive when the one-launch recurrences cannot run on this device.
+
+  A pair / cluster recurrence needs all of its workgroups resident together (one per compute unit); when they are not
+  — compute units held by another process or by a long foreign kernel — its members time out, the device-side fault
+  word makes the step a skipped one (include/lipreading_hip.h), and the NEXT step would do the same, a few tenths
+  of a second each: a run that skips every batch.  The reference's contract is skip a bad batch and keep training
+  (src/train/train_better_model.py:49-50), so after `limit` consecutive faulted steps this switches every recurrence
+  to the per-step kernels for the rest of the process (lr_rnn_one_launch_enable(0)), says so once, and drops the
+  captured hipGraphs (`graphs`), whose launch sequences are stale.
+
+  No host round trip in the step: after a step, the step's fault flag is exported on the stream and copied to pinned
+  memory asynchronously; the copy is looked at when it has landed (a later step), never waited for."""
+
+  def __init__(self, device, limit=3):
+    self.limit, self.run, self.tripped = int(limit), 0, False
+    self._dev = torch.zeros(2, dtype=torch.int32, device=device)
+    self._host = torch.zeros(2, dtype=torch.int32).pin_memory()
+    self._event = None
+
+  def after_step(self, graphs=None):
+    """Call once per optimisation step, after it was enqueued.  Returns True when the fall-back was just taken."""
+    if self.tripped or not _C.lib().lr_rnn_one_launch_enabled():
+      return False
+    if self._event is not None:
+      if not self._event.query():
+        return False            # the previous flag has not landed yet: this step goes unobserved
+      self.run = self.run + 1 if int(self._host[1]) < 0 else 0
+      self._event = None
+      if self.run >= self.limit:
+        self.tripped = True
+        torch.cuda.synchronize()
+        _C.lib().lr_rnn_one_launch_enable(0)
+        if graphs is not None:
+          graphs.reset()
+        import warnings
+        warnings.warn("lipreading_amd: the one-launch recurrence timed out in %d consecutive steps (its workgroups were "
+                      "not resident together: are this GPU's compute units shared?); every recurrence runs on the "
+                      "per-step kernels from here on (slower, same results)" % self.run)
+        return True
+    _C.check(_C.lib().lr_fault_export(None, self._dev.data_ptr(), _C.stream_handle()), "lr_fault_export")
+    self._host.copy_(self._dev, non_blocking=True)
+    self._event = torch.cuda.Event()
+    self._event.record()
+    return False
+
+
+def _roll_faults(device):
+  """Outside a training step (eval, greedy decoding) nothing rolls the fault words: do it here, so that a time-out of
+  an earlier batch does not mark every later one (lr_step_begin with an empty gradient buffer)."""
+  _C.check(_C.lib().lr_step_begin(None, 0, None, _C.stream_handle()), "lr_step_begin")
+
+
+def _fault_keep(flag2):
+  """1 if no one-launch recurrence has timed out since the last roll, else 0 — a device scalar, no host read."""
+  _C.check(_C.lib().lr_fault_export(None, flag2.data_ptr(), _C.stream_handle()), "lr_fault_export")
+  return (flag2[1] == 0)
 
 
 def ctc_step(encoder, opt, frames, frame_lens, chars, char_lens, grad_norm=None, max_len=None,
@@ -351,6 +416,8 @@ def train(encoder, decoding_step, data_loader, opt, device, char2idx,
   ctc_sum = torch.zeros((), dtype=torch.float32, device=device)
   dec_sum = torch.zeros((), dtype=torch.float32, device=device)
   skipped_before = opts[0].skipped_steps() if device.type == "cuda" else 0
+  watch = RecurrenceWatch(device) if device.type == "cuda" else None
+  flag2 = torch.zeros(2, dtype=torch.int32, device=device) if device.type == "cuda" else None
   for frames, frame_lens, chars, char_lens in data_loader:
     _check_framing(chars, char_lens, frame_lens, char2idx, use_ctc)
     max_len = int(frame_lens.max()) if not frame_lens.is_cuda else None
@@ -361,6 +428,8 @@ def train(encoder, decoding_step, data_loader, opt, device, char2idx,
       loss, _ = ctc_step(encoder, opt, frames, frame_lens_d, chars, char_lens_d, grad_norm=grad_norm,
                          max_len=max_len, grad_sync=grad_sync, graphs=graphs)
       ctc_sum += loss  # a skipped batch contributes 0, as `continue` does at :49-50
+      if watch is not None:
+        watch.after_step(graphs)
       continue
     # the teacher-forcing coins (:57) and the sampler seed (:63) come from the host generator; drawn here,
     # outside anything that may be captured
@@ -370,11 +439,17 @@ def train(encoder, decoding_step, data_loader, opt, device, char2idx,
     decoder_loss, ctc, status = decoder_step(encoder, decoding_step, opts, frames, frame_lens_d, chars, char_lens_d,
                                              flags, seed, pad, grad_norm=grad_norm, max_len=max_len, grad_sync=syncs,
                                              graphs=graphs)
+    # a recurrence time-out anywhere in the step (the decoder loop's included, which runs AFTER the CTC status was
+    # written) leaves garbage in decoder_loss: the fault word masks it, with or without a CTC status
+    keep = _fault_keep(flag2) if flag2 is not None else 1
     if status is None:
-      dec_sum += decoder_loss
+      dec_sum += torch.where(keep, decoder_loss, torch.zeros_like(decoder_loss)) if flag2 is not None else decoder_loss
     else:
-      dec_sum += decoder_loss * (status.reshape(()) == 0)
+      ok = (status.reshape(()) == 0) & keep if flag2 is not None else (status.reshape(()) == 0)
+      dec_sum += torch.where(ok, decoder_loss, torch.zeros_like(decoder_loss))
       ctc_sum += ctc
+    if watch is not None:
+      watch.after_step(graphs)
   avg_ctc_loss = (ctc_sum / len(data_loader)).item()  # :84 divides by len(data_loader)
   avg_decoder_loss = (dec_sum / len(data_loader)).item()
   # batches that updated nothing this epoch — the reference's `continue` (:49-50) and, here, steps whose one-launch
@@ -409,9 +484,14 @@ def eval(encoder, decoding_step, data_loader, device, char2idx):
   dec_sum = torch.zeros((), dtype=torch.float32, device=device)
   correct = torch.zeros((), dtype=torch.int64, device=device)
   count = torch.zeros((), dtype=torch.float32, device=device)
+  on_gpu = torch.device(device).type == "cuda"
+  flag2 = torch.zeros(2, dtype=torch.int32, device=device) if on_gpu else None
+  faulted = torch.zeros((), dtype=torch.int32, device=device)
   with torch.no_grad():
     for frames, frame_lens, chars, char_lens in data_loader:
       _check_framing(chars, char_lens, frame_lens, char2idx, use_ctc, in_eval=True)
+      if on_gpu:
+        _roll_faults(device)   # a time-out in an earlier batch must not mark this one
       max_len = int(frame_lens.max()) if not frame_lens.is_cuda else None
       label_lens_host = (char_lens - 1).cpu()
       frames, chars = frames.to(device), chars.to(device)
@@ -427,13 +507,26 @@ def eval(encoder, decoding_step, data_loader, device, char2idx):
       else:
         hidden, state = encoder(frames, frame_lens_d, max_len=max_len)
       if decoding_step is None:
+        if on_gpu:
+          faulted += (~_fault_keep(flag2)).int()
         continue
       nll, sampled, L = _decoder_losses(decoding_step, chars, labels, label_lens_host, frame_lens_d,
                                         hidden, state, 2.0, pad)
       mask = labels[:, :L] != pad
-      dec_sum += nll * keep
+      if on_gpu:
+        # (a one-launch recurrence that timed out — the encoder's or the decoder loop's — left garbage: the batch counts
+        # like one the reference `continue`s past, and is reported below)
+        fk = _fault_keep(flag2)
+        faulted += (~fk).int()
+        keep = keep * fk
+      dec_sum += torch.where(keep.bool(), nll, torch.zeros_like(nll)) if torch.is_tensor(keep) else nll
       correct += ((sampled.long() == labels[:, :L]) & mask).sum() * keep
       count += mask.sum().float() * keep
+  if on_gpu:
+    _roll_faults(device)
+    nf = int(faulted.item())
+    if nf:
+      print("\tEvaluation batches dropped after a recurrence time-out: %d of %d" % (nf, len(data_loader)))
   ctc_avg = (ctc_sum / len(data_loader)).item()
   if decoding_step is None:
     return 0.0, 0, 0, ctc_avg
@@ -451,11 +544,24 @@ def greedy_cer(encoder, data_loader, device, char2idx):
   inv = {v: k for k, v in char2idx.items()}
   encoder.eval()
   dist, total = 0, 0
+  on_gpu = torch.device(device).type == "cuda"
   with torch.no_grad():
     for frames, frame_lens, chars, char_lens in data_loader:
       max_len = int(frame_lens.max()) if not frame_lens.is_cuda else None
       log_probs, _, _ = encoder(frames.to(device), frame_lens.to(device), max_len=max_len)
       strings, _ = dec.decode(log_probs, frame_lens.to(device))
+      if on_gpu and _C.lib().lr_rnn_pair_errors() != 0:
+        # (decode() has just synchronised: reading the fault words costs nothing more.)  The one-launch recurrence
+        # timed out: these strings are garbage, and val_cer drives save_best_model and the annealing — decode this
+        # batch again on the per-step kernels instead of scoring it
+        inner = getattr(encoder, "encoder", encoder)   # (PixelLipReader wraps the VideoEncoder)
+        if hasattr(inner, "recurrence"):
+          saved, inner.recurrence = inner.recurrence, 'f32'
+          try:
+            log_probs, _, _ = encoder(frames.to(device), frame_lens.to(device), max_len=max_len)
+            strings, _ = dec.decode(log_probs, frame_lens.to(device))
+          finally:
+            inner.recurrence = saved
       for b in range(len(strings)):
         ref = ''.join(inv[int(c)] for c in chars[b, 1:int(char_lens[b]) - 1])  # strip BOS/EOS
         hyp = strings[b][0].replace(EOS, '')

@@ -607,3 +607,45 @@ def test_a_recurrence_time_out_skips_the_step_and_is_reported(dev, rnn_type, H, 
     assert torch.isfinite(opt.flat.data).all() and L.lr_rnn_pair_errors() == 0
   finally:
     L.lr_rnn_debug_disable_cluster(0)
+
+
+def test_cluster_recurrence_survives_a_foreign_kernel_that_holds_compute_units(dev):
+  """What a data-parallel run does to the one-launch recurrence: while the gradient all-reduce of one bucket runs (an
+  RCCL ring kernel on a side stream, holding compute units of its own), the next layer's cluster kernels — 8 x 24 = 192
+  workgroups that must ALL be resident, one per compute unit — are launched.  A 1-rank all-reduce is a memcpy and gloo
+  runs on the host, so the stand-in is lr_debug_busy: 96 workgroups that each hold a whole CU's LDS for 3 ms, on a
+  side stream, across the launches of rnnc_fwd_kernel<4,24> and rnnc_bwd_kernel<4,24>.  192 + 96 > 256: members have
+  to wait for compute units; their waits are bounded at a few tenths of a second, the foreign kernel is not: no
+  time-out, and the same numbers as the undisturbed run."""
+  from lipreading_amd import _C
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.encoder import VideoEncoder
+  L = _C.lib()
+  torch.manual_seed(51)
+  enc = VideoEncoder(64, 768, rnn_type='LSTM', bidirectional=True, enable_ctc=True, vocab_size=64,
+                     char2idx=default_char2idx()).to(dev)
+  g = torch.Generator().manual_seed(52)
+  B, T = 32, 30
+  x = torch.randn(B, T, 64, 1, generator=g).to(dev)
+  lens = torch.full((B,), T)
+  wgt = torch.randn(B, T, 65, generator=g).to(dev)
+  assert L.lr_rnn_pair_supported(1, B, T, 64, 768, 2) == 2
+  L.lr_rnn_pair_errors()
+  side = torch.cuda.Stream()
+  res = {}
+  for busy in (False, True, True):
+    enc.zero_grad()
+    torch.cuda.synchronize()
+    if busy:
+      with torch.cuda.stream(side):
+        _C.check(L.lr_debug_busy(96, 160 * 1024, 3000, _C.stream_handle()), "lr_debug_busy")
+    lp, hid, _ = enc(x, lens, max_len=T)
+    if busy:   # ... and again across the backward launch
+      with torch.cuda.stream(side):
+        _C.check(L.lr_debug_busy(96, 160 * 1024, 3000, _C.stream_handle()), "lr_debug_busy")
+    ((lp * wgt).sum() + hid.pow(2).sum()).backward()
+    torch.cuda.synchronize()
+    res[busy] = [lp.detach().clone(), hid.detach().clone()] + [p.grad.clone() for p in enc.parameters()]
+  assert L.lr_rnn_pair_errors() == 0
+  for a, b in zip(res[False], res[True]):
+    assert torch.equal(a, b)

@@ -471,3 +471,69 @@ def test_pixel_pipeline_end_to_end_on_a_six_video_dataview(dev, tmp_path, encode
   # within a rounding of a tie — stated tolerance: CER within 0.02, at least 3 of 4 strings identical
   assert abs(cer_h - cer_o) <= 0.02 and same >= 0.75 * total
   assert abs(T.greedy_cer(model, train_loader, dev, c2i) - cer_h) < 1e-12
+
+
+def test_repeated_recurrence_time_outs_fall_back_to_the_step_kernels(dev, capsys):
+  """A device on which the one-launch recurrence cannot run (here: the test hook makes member 1 of every cluster leave
+  at once, so its partners time out in EVERY step) must not turn into a run that skips every batch: the reference's
+  contract is skip a bad batch and keep training (src/train/train_better_model.py:49-50).  train() watches the
+  device-side fault flag without a host round trip (RecurrenceWatch) and after three consecutive faulted steps
+  switches every recurrence to the per-step kernels, warns once, drops the captured graphs — the rest of the epoch
+  trains.  eval() and greedy_cer() do not score a batch whose recurrence timed out."""
+  import warnings
+  from lipreading_amd import _C, train as T_
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.optim import FlatParameters, FusedAdam
+  L = _C.lib()
+  torch.manual_seed(5)
+  c2i = default_char2idx()
+  enc = VideoEncoder(204, 128, rnn_type='LSTM', bidirectional=True, enable_ctc=True, vocab_size=64, char2idx=c2i).to(dev)
+  opt = FusedAdam(FlatParameters(enc), lr=1e-3)
+  g = torch.Generator().manual_seed(6)
+  B, Tn = 8, 12
+  batches = []
+  for _ in range(8):
+    frames = torch.randn(B, Tn, 68, 3, generator=g)
+    chars = torch.zeros(B, 7, dtype=torch.long)
+    chars[:, 0], chars[:, 1:6], chars[:, 6] = c2i['<BOS>'], torch.randint(4, 64, (B, 5), generator=g), c2i['<EOS>']
+    batches.append((frames, torch.full((B,), Tn), chars, torch.full((B,), 7)))
+  assert L.lr_rnn_pair_supported(1, B, Tn, 204, 128, 2) == 2 and L.lr_rnn_one_launch_enabled() == 1
+  L.lr_rnn_pair_errors()
+  graphs = T_.StepGraphs(warmup=1)
+  try:
+    L.lr_rnn_debug_drop_member(1)
+    # evaluation first: every batch's recurrence times out -> nothing is scored, and it is said
+    ctc_avg = T_.eval(enc, None, batches[:2], dev, c2i)[3]
+    assert ctc_avg == 0.0 and "dropped after a recurrence time-out: 2 of 2" in capsys.readouterr().out
+    before = opt.flat.data.clone()
+    with warnings.catch_warnings(record=True) as w:
+      warnings.simplefilter("always")
+      T_.train(enc, None, batches, opt, dev, c2i, grad_norm=50, graphs=graphs)
+    notes = [str(m.message) for m in w if "per-step kernels from here on" in str(m.message)]
+    assert len(notes) == 1, [str(m.message) for m in w]
+    assert L.lr_rnn_one_launch_enabled() == 0
+    st = T_.last_epoch_stats
+    # the first steps were lost (three faulted ones are needed to decide, a fourth or fifth may be under way when
+    # the flag lands), the rest trained
+    assert 3 <= st["skipped"] <= 6 and st["batches"] == 8, st
+    assert not torch.equal(before, opt.flat.data) and torch.isfinite(opt.flat.data).all()
+    # with the hook still dropping members nothing uses them any more: a whole healthy epoch, CER is computed
+    T_.train(enc, None, batches, opt, dev, c2i, grad_norm=50, graphs=graphs)
+    assert T_.last_epoch_stats["skipped"] == 0
+    assert 0.0 <= T_.greedy_cer(enc, batches[:2], dev, c2i)
+  finally:
+    L.lr_rnn_debug_drop_member(-1)
+    L.lr_rnn_one_launch_enable(1)
+    L.lr_rnn_pair_errors()
+  # greedy_cer on the one-launch kernels again, one batch's recurrence timing out: that batch is decoded a second
+  # time on the step kernels, and the CER equals the undisturbed one
+  enc.eval()
+  want = T_.greedy_cer(enc, batches[:3], dev, c2i)
+  try:
+    L.lr_rnn_debug_drop_member(1)
+    got = T_.greedy_cer(enc, batches[:3], dev, c2i)
+  finally:
+    L.lr_rnn_debug_drop_member(-1)
+    L.lr_rnn_pair_errors()
+  assert got == want

@@ -74,9 +74,8 @@ def main():
           p.add_(0.25)
     flat = FlatParameters(model)
     opt = FusedAdam(flat, lr=1e-3)
-    groups = GradSync.groups_for_encoder(enc, flat)
-    if kind == "pixels":
-      groups = [list(range(min(min(g) for g in groups)))] + groups
+    # pixels: [conv], [encoder] — the encoder's bucket goes out behind the step's last recurrence
+    groups = GradSync.groups_for_pixel_model(model, flat) if kind == "pixels" else GradSync.groups_for_encoder(enc, flat)
     sync = GradSync(flat, groups=groups, overlap=True)
     sync.broadcast_parameters(0)
     lo, hi = shard_batch(B_FULL, rank, world)
