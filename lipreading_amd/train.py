@@ -208,38 +208,54 @@ class RecurrenceWatch(object):
   captured hipGraphs (`graphs`), whose launch sequences are stale.
 
   No host round trip in the step: after a step, the step's fault flag is exported on the stream and copied to pinned
-  memory asynchronously; the copy is looked at when it has landed (a later step), never waited for."""
+  memory asynchronously; the copy is looked at once it has landed, a step or two later.  Only when the host has run
+  more than `lag` steps ahead of an unobserved flag does it wait for it (the device still has those steps queued, so
+  nothing idles: this bounds the host's run-ahead, as a healthy loop's own `.item()` reads would)."""
 
-  def __init__(self, device, limit=3):
-    self.limit, self.run, self.tripped = int(limit), 0, False
-    self._dev = torch.zeros(2, dtype=torch.int32, device=device)
-    self._host = torch.zeros(2, dtype=torch.int32).pin_memory()
-    self._event = None
+  def __init__(self, device, limit=3, lag=2):
+    self.limit, self.run, self.tripped, self.lag = int(limit), 0, False, int(lag)
+    n = self.lag + 2
+    self._dev = torch.zeros(n, 2, dtype=torch.int32, device=device)
+    self._host = torch.zeros(n, 2, dtype=torch.int32).pin_memory()
+    self._pending = []          # (slot, event) of the steps not yet observed, oldest first
+    self._step = 0
+
+  def _observe(self, graphs):
+    slot, _ = self._pending.pop(0)
+    self.run = self.run + 1 if int(self._host[slot, 1]) < 0 else 0
+    if self.run < self.limit:
+      return False
+    self.tripped = True
+    del self._pending[:]
+    torch.cuda.synchronize()
+    _C.lib().lr_rnn_one_launch_enable(0)
+    if graphs is not None:
+      graphs.reset()
+    import warnings
+    warnings.warn("lipreading_amd: the one-launch recurrence timed out in %d consecutive steps (its workgroups were "
+                  "not resident together: are this GPU's compute units shared?); every recurrence runs on the "
+                  "per-step kernels from here on (slower, same results)" % self.run)
+    return True
 
   def after_step(self, graphs=None):
     """Call once per optimisation step, after it was enqueued.  Returns True when the fall-back was just taken."""
     if self.tripped or not _C.lib().lr_rnn_one_launch_enabled():
       return False
-    if self._event is not None:
-      if not self._event.query():
-        return False            # the previous flag has not landed yet: this step goes unobserved
-      self.run = self.run + 1 if int(self._host[1]) < 0 else 0
-      self._event = None
-      if self.run >= self.limit:
-        self.tripped = True
-        torch.cuda.synchronize()
-        _C.lib().lr_rnn_one_launch_enable(0)
-        if graphs is not None:
-          graphs.reset()
-        import warnings
-        warnings.warn("lipreading_amd: the one-launch recurrence timed out in %d consecutive steps (its workgroups were "
-                      "not resident together: are this GPU's compute units shared?); every recurrence runs on the "
-                      "per-step kernels from here on (slower, same results)" % self.run)
+    while self._pending:
+      _, ev = self._pending[0]
+      if not ev.query():
+        if len(self._pending) <= self.lag:
+          break                 # not landed yet, and the host is not far ahead: look again after the next step
+        ev.synchronize()
+      if self._observe(graphs):
         return True
-    _C.check(_C.lib().lr_fault_export(None, self._dev.data_ptr(), _C.stream_handle()), "lr_fault_export")
-    self._host.copy_(self._dev, non_blocking=True)
-    self._event = torch.cuda.Event()
-    self._event.record()
+    slot = self._step % self._dev.shape[0]
+    self._step += 1
+    _C.check(_C.lib().lr_fault_export(None, self._dev[slot].data_ptr(), _C.stream_handle()), "lr_fault_export")
+    self._host[slot].copy_(self._dev[slot], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    self._pending.append((slot, ev))
     return False
 
 
