@@ -433,6 +433,10 @@ int lr_decoder_backward(int mode, int attn_type, const lr_decoder_params* params
  * Backward: d_log_probs [R][V] (every element written) from the upstream scalar gradient on the device. */
 int lr_nll_mean_forward(const float* log_probs, const int64_t* labels, int64_t label_stride, int L, int ignore_index,
                         float* out2, int R, int V, lr_stream_t stream);
+/* ... the same with out3 = {loss, count, the un-divided sum}: eval keeps sum and count apart
+ * (train_better_model.py:127,138: nll sums added over the batches, divided by the total count at the end). */
+int lr_nll_forward3(const float* log_probs, const int64_t* labels, int64_t label_stride, int L, int ignore_index,
+                    float* out3, int R, int V, lr_stream_t stream);
 int lr_nll_mean_backward(const int64_t* labels, int64_t label_stride, int L, int ignore_index, const float* fwd_out2,
                          const float* grad_out, float* d_log_probs, int R, int V, lr_stream_t stream);
 
@@ -671,6 +675,16 @@ int lr_unpool_code_bf16(const void* pooled, const void* code, const void* dP, vo
                         int C, lr_stream_t stream);
 int lr_bf16_to_f32(const void* in, float* out, int64_t n, lr_stream_t stream);
 int lr_f32_to_bf16(const float* in, void* out, int64_t n, lr_stream_t stream);
+
+/* Inter-layer dropout of nn.GRU / nn.LSTM(dropout = p) in training mode (better_model.py:47-49 hands rnn_dropout to
+ * torch; every shipped config sets 0): mask[i] = 0 with probability p, else 1 / (1 - p) (Philox4x32-10, key = seed,
+ * counter = i / 4: the same mask for a (seed, n) whatever the launch geometry), y = x * mask.  Backward: dx = dy * mask
+ * (lr_mul_f32).  lr_cat_directions: (D, B, H) -> (B, D*H), forward direction first (better_model.py:98-112
+ * _cat_directions), for one or two tensors (h, c) in one launch; inverse != 0: the way back (its gradient). */
+int lr_dropout_forward(const float* x, float* y, float* mask, int64_t n, float p, uint64_t seed, lr_stream_t stream);
+int lr_mul_f32(const float* a, const float* b, float* out, int64_t n, lr_stream_t stream);
+int lr_cat_directions(const float* in0, float* out0, const float* in1, float* out1, int B, int H, int D, int inverse,
+                      lr_stream_t stream);
 
 /* ---- A5 tail: optimiser side of the reference step — train_better_model.py:78-80 -------- */
 

@@ -82,6 +82,7 @@ SIGNATURES = {
                                      c_size_t, c_int] + [c_int] * 7 + [P]),
     "lr_ctc_prepare_i64": (c_int, [P, c_int64, P, P, P, P, P, c_int, c_int, P]),
     "lr_nll_mean_forward": (c_int, [P, P, c_int64, c_int, c_int, P, c_int, c_int, P]),
+    "lr_nll_forward3": (c_int, [P, P, c_int64, c_int, c_int, P, c_int, c_int, P]),
     "lr_nll_mean_backward": (c_int, [P, c_int64, c_int, c_int, P, P, P, c_int, c_int, P]),
     "lr_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "lr_ctc_nll": (c_int, [P, c_int64, c_int64, P, c_int, P, P, P, P, c_size_t, c_int, c_int,
@@ -112,6 +113,9 @@ SIGNATURES = {
     "lr_unpool_relu_mask_bf16": (c_int, [P, P, P, P, c_int, P, c_size_t, c_int64, c_int, c_int, c_int, P]),
     "lr_bf16_to_f32": (c_int, [P, P, c_int64, P]),
     "lr_f32_to_bf16": (c_int, [P, P, c_int64, P]),
+    "lr_dropout_forward": (c_int, [P, P, P, c_int64, c_float, ctypes.c_uint64, P]),
+    "lr_mul_f32": (c_int, [P, P, P, c_int64, P]),
+    "lr_cat_directions": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "lr_sumsq": (c_int, [P, c_int64, P, P]),
     "lr_adam_step": (c_int, [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_float,
                               c_float, P, P, P, P]),

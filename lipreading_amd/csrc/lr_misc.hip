@@ -357,7 +357,7 @@ namespace {
 // one workgroup, fixed summation order: out[0] = -sum_r lp[r][label_r] / count, out[1] = count (rows whose label != ignore)
 __global__ __launch_bounds__(1024) void nll_mean_fwd_kernel(const float* __restrict__ lp, const int64_t* __restrict__ labels,
                                                            int64_t label_stride, int L, int ignore, float* __restrict__ out,
-                                                           int R, int V) {
+                                                           int R, int V, int out3) {
   __shared__ float s_sum[1024];
   __shared__ int s_cnt[1024];
   float acc = 0.f;
@@ -382,6 +382,18 @@ __global__ __launch_bounds__(1024) void nll_mean_fwd_kernel(const float* __restr
   if (threadIdx.x == 0) {
     out[0] = s_sum[0] / (float)s_cnt[0];
     out[1] = (float)s_cnt[0];
+    if (out3) out[2] = s_sum[0];
+  }
+}
+// the same gradient for any V (one element per thread): V % 4 != 0
+__global__ void nll_mean_bwd_scalar_kernel(const int64_t* __restrict__ labels, int64_t label_stride, int L, int ignore,
+                                           const float* __restrict__ fwd_out, const float* __restrict__ g,
+                                           float* __restrict__ d_lp, int R, int V) {
+  const float w = -g[0] / fwd_out[1];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)R * V; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / V), v = (int)(i - (int64_t)r * V);
+    const int64_t lab = labels[(int64_t)(r / L) * label_stride + (r % L)];
+    d_lp[i] = (lab != ignore && lab == v) ? w : 0.f;
   }
 }
 // d_lp[r][v] = (v == label_r != ignore) ? -g / count : 0, 4 columns per thread
@@ -408,7 +420,15 @@ extern "C" int lr_nll_mean_forward(const float* log_probs, const int64_t* labels
                                    int ignore_index, float* out2, int R, int V, lr_stream_t stream) {
   LR_CHECK_ARG(log_probs && labels && out2 && R > 0 && V > 0 && L > 0 && R % L == 0);
   LR_LAUNCH(nll_mean_fwd_kernel, dim3(1), dim3(1024), 0, stream, log_probs, labels, label_stride, L, ignore_index, out2,
-            R, V);
+            R, V, 0);
+  return lr_launch_status();
+}
+
+extern "C" int lr_nll_forward3(const float* log_probs, const int64_t* labels, int64_t label_stride, int L, int ignore_index,
+                               float* out3, int R, int V, lr_stream_t stream) {
+  LR_CHECK_ARG(log_probs && labels && out3 && R > 0 && V > 0 && L > 0 && R % L == 0);
+  LR_LAUNCH(nll_mean_fwd_kernel, dim3(1), dim3(1024), 0, stream, log_probs, labels, label_stride, L, ignore_index, out3,
+            R, V, 1);
   return lr_launch_status();
 }
 
@@ -416,11 +436,101 @@ extern "C" int lr_nll_mean_backward(const int64_t* labels, int64_t label_stride,
                                     const float* fwd_out2, const float* grad_out, float* d_log_probs, int R, int V,
                                     lr_stream_t stream) {
   LR_CHECK_ARG(labels && fwd_out2 && grad_out && d_log_probs && R > 0 && V > 0 && L > 0 && R % L == 0);
-  if (V % 4 != 0) return LR_ERR_UNSUPPORTED;
+  if (V % 4 != 0 || (reinterpret_cast<uintptr_t>(d_log_probs) & 15) != 0) {
+    int blocks = (int)(((int64_t)R * V + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    LR_LAUNCH(nll_mean_bwd_scalar_kernel, dim3(blocks), dim3(256), 0, stream, labels, label_stride, L, ignore_index,
+              fwd_out2, grad_out, d_log_probs, R, V);
+    return lr_launch_status();
+  }
   int blocks = (int)(((int64_t)R * (V / 4) + 255) / 256);
   if (blocks > 1024) blocks = 1024;
   LR_LAUNCH(nll_mean_bwd_kernel, dim3(blocks), dim3(256), 0, stream, labels, label_stride, L, ignore_index, fwd_out2,
             grad_out, d_log_probs, R, V);
+  return lr_launch_status();
+}
+
+// ---- inter-layer dropout of nn.GRU / nn.LSTM(dropout = p) in training mode (better_model.py:47-49 passes rnn_dropout
+// through; every shipped config sets 0) ------------------------------------------------------------------------
+// mask[i] = 0 with probability p, 1 / (1 - p) otherwise — Philox4x32-10 keyed by (seed), counter = the element's group of
+// four, so the mask of a (seed, n) is the same whatever the launch geometry; y = x * mask.  The backward is the same
+// multiply (lr_mul_f32).  torch draws its mask from its own generator stream: like the decoder loop's samples
+// (better_model.py:63), the mask is a random variable, not a value to match — it is tested as a mask.
+namespace {
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mask, int64_t n,
+                                   float p, unsigned long long seed) {
+  const float scale = 1.f / (1.f - p);
+  const int64_t groups = (n + 3) >> 2;
+  for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < groups; gi += (int64_t)gridDim.x * blockDim.x) {
+    unsigned r[4];
+    philox4x32_10((unsigned)gi, (unsigned)(gi >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = 4 * gi + e;
+      if (i < n) {
+        // uniform in [0, 1) from the top 24 bits: keep with probability 1 - p
+        const float u = (float)(r[e] >> 8) * (1.f / 16777216.f);
+        const float m = u < p ? 0.f : scale;
+        mask[i] = m;
+        y[i] = x[i] * m;
+      }
+    }
+  }
+}
+__global__ void mul_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = a[i] * b[i];
+}
+// (D, B, H) -> (B, D * H), forward direction first (better_model.py:98-112 _cat_directions), or back; nt tensors at once
+struct CatPtrs {
+  const float* in[2];
+  float* out[2];
+};
+__global__ void cat_directions_kernel(CatPtrs p, int nt, int B, int H, int D, int inverse) {
+  const int64_t total = (int64_t)nt * D * B * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i / ((int64_t)D * B * H));
+    const int64_t r = i - (int64_t)k * D * B * H;
+    const int j = (int)(r % H), b = (int)((r / H) % B), d = (int)(r / ((int64_t)H * B));
+    const int64_t dbh = ((int64_t)d * B + b) * H + j, bdh = ((int64_t)b * D + d) * H + j;
+    if (inverse) p.out[k][dbh] = p.in[k][bdh];
+    else p.out[k][bdh] = p.in[k][dbh];
+  }
+}
+}  // namespace
+
+extern "C" int lr_dropout_forward(const float* x, float* y, float* mask, int64_t n, float p, uint64_t seed,
+                                  lr_stream_t stream) {
+  LR_CHECK_ARG(x && y && mask && n > 0 && p >= 0.f && p < 1.f);
+  LR_LAUNCH(dropout_fwd_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, stream, x, y, mask, n, p,
+            (unsigned long long)seed);
+  return lr_launch_status();
+}
+extern "C" int lr_mul_f32(const float* a, const float* b, float* out, int64_t n, lr_stream_t stream) {
+  LR_CHECK_ARG(a && b && out && n > 0);
+  LR_LAUNCH(mul_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, a, b, out, n);
+  return lr_launch_status();
+}
+extern "C" int lr_cat_directions(const float* in0, float* out0, const float* in1, float* out1, int B, int H, int D,
+                                 int inverse, lr_stream_t stream) {
+  LR_CHECK_ARG(in0 && out0 && B > 0 && H > 0 && (D == 1 || D == 2) && ((in1 == nullptr) == (out1 == nullptr)));
+  CatPtrs p;
+  p.in[0] = in0; p.out[0] = out0; p.in[1] = in1; p.out[1] = out1;
+  const int nt = in1 ? 2 : 1;
+  LR_LAUNCH(cat_directions_kernel, dim3(grid_for((int64_t)nt * D * B * H, 256)), dim3(256), 0, stream, p, nt, B, H, D, inverse);
   return lr_launch_status();
 }
 

@@ -14,7 +14,6 @@ import os
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _C
 from .data import BOS, PAD
@@ -173,6 +172,65 @@ class _RNNLayerFunction(torch.autograd.Function):
       _notify(weights)
       return (dx, None, None, None, None, None) + (None,) * len(weights)
     return (dx, None, None, None, None, None) + tuple(grads)
+
+
+class _DropoutFunction(torch.autograd.Function):
+  """nn.GRU / nn.LSTM(dropout=p) between stacked layers, training mode: lr_dropout_forward (Philox mask, seed drawn from
+  torch's host generator) and the same multiply on the way back."""
+
+  @staticmethod
+  def forward(ctx, x, p, seed):
+    x = x.contiguous()
+    y, mask = torch.empty_like(x), torch.empty_like(x)
+    _C.check(_C.lib().lr_dropout_forward(x.data_ptr(), y.data_ptr(), mask.data_ptr(), x.numel(), float(p), int(seed),
+                                         _C.stream_handle()), "lr_dropout_forward")
+    ctx.save_for_backward(mask)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    mask, = ctx.saved_tensors
+    dy = dy.contiguous()
+    dx = torch.empty_like(dy)
+    _C.check(_C.lib().lr_mul_f32(dy.data_ptr(), mask.data_ptr(), dx.data_ptr(), dy.numel(), _C.stream_handle()), "lr_mul_f32")
+    return dx, None, None
+
+
+class _CatDirectionsFunction(torch.autograd.Function):
+  """(D,B,H) -> (B, D*H), forward direction first (better_model.py:98-112 _cat_directions), for h (and c) of a layer in
+  ONE launch each way (torch: permute + reshape copies per tensor, and their gradients' copies back)."""
+
+  @staticmethod
+  def forward(ctx, h, c):
+    D, B, H = h.shape
+    h = h.contiguous()
+    out_h = torch.empty((B, D * H), dtype=h.dtype, device=h.device)
+    out_c = None
+    if c is not None:
+      c = c.contiguous()
+      out_c = torch.empty_like(out_h)
+    _C.check(_C.lib().lr_cat_directions(h.data_ptr(), out_h.data_ptr(), _C.ptr(c), _C.ptr(out_c), B, H, D, 0,
+                                        _C.stream_handle()), "lr_cat_directions")
+    ctx.dims = (D, B, H, c is not None)
+    ctx.set_materialize_grads(False)
+    if c is None:
+      return out_h
+    return out_h, out_c
+
+  @staticmethod
+  def backward(ctx, gh, gc=None):
+    D, B, H, has_c = ctx.dims
+    if gh is None and gc is None:
+      return None, None
+    ref = gh if gh is not None else gc
+    gh = gh.contiguous() if gh is not None else torch.zeros_like(ref)
+    if has_c:
+      gc = gc.contiguous() if gc is not None else torch.zeros_like(ref)
+    dh = torch.empty((D, B, H), dtype=ref.dtype, device=ref.device)
+    dc = torch.empty_like(dh) if has_c else None
+    _C.check(_C.lib().lr_cat_directions(gh.data_ptr(), dh.data_ptr(), _C.ptr(gc) if has_c else None, _C.ptr(dc), B, H, D, 1,
+                                        _C.stream_handle()), "lr_cat_directions")
+    return dh, dc
 
 
 class _ProjLogSoftmaxFunction(torch.autograd.Function):
@@ -350,19 +408,24 @@ class VideoEncoder(nn.Module):
             _note_step_kernel_fallback(self.rnn_type, H)
       y, h_n, c_n = _RNNLayerFunction.apply(x, lens, lmode, H, need_dx, need_final_state, *weights)
       if need_final_state:
-        # (D,B,H) -> (B, D*H): forward direction first, as _cat_directions (better_model.py:98-112)
-        h_fin.append(h_n.permute(1, 0, 2).reshape(B, D * H))
+        # (D,B,H) -> (B, D*H): forward direction first, as _cat_directions (better_model.py:98-112); h and c in one launch
         if mode == 1:
-          c_fin.append(c_n.permute(1, 0, 2).reshape(B, D * H))
+          hf, cf = _CatDirectionsFunction.apply(h_n, c_n)
+          c_fin.append(cf)
+        else:
+          hf = _CatDirectionsFunction.apply(h_n, None)
+        h_fin.append(hf)
       x = y
       if self.rnn_dropout and self.training and layer + 1 < self.num_layers:
-        x = F.dropout(x, p=self.rnn_dropout, training=True)   # nn.GRU/LSTM inter-layer dropout
+        # nn.GRU/LSTM inter-layer dropout; the seed comes from torch's host generator (no device work)
+        x = _DropoutFunction.apply(x, float(self.rnn_dropout), int(torch.randint(0, 2 ** 62, (1,)).item()))
     hidden_states = y
     final_state = None
     if need_final_state:
-      final_state = torch.stack(h_fin, 0)
+      # (layers, B, D*H): one layer (every shipped config) is a view, more are stacked
+      final_state = h_fin[0].unsqueeze(0) if len(h_fin) == 1 else torch.stack(h_fin, 0)
       if mode == 1:
-        final_state = (final_state, torch.stack(c_fin, 0))
+        final_state = (final_state, c_fin[0].unsqueeze(0) if len(c_fin) == 1 else torch.stack(c_fin, 0))
 
     if self.enable_ctc:
       output_log_probs = _ProjLogSoftmaxFunction.apply(hidden_states, self.output_proj.weight,

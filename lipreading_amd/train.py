@@ -11,7 +11,6 @@ path BASELINE.json's north_star names; with a `CharDecodingStep` the attention d
 (:56-65) runs as one fused enqueue per batch (lipreading_amd/attention_decoder.py).
 """
 import torch
-import torch.nn.functional as F
 
 from . import _C
 from .ctc import ctc_loss_prepared, ctc_loss_with_status, prepare_ctc_inputs
@@ -68,13 +67,20 @@ class _NLLMeanFunction(torch.autograd.Function):
 
 
 def decoder_nll(log_probs, labels, pad):
-  """decoder_loss of train_better_model.py:62-65 from the (B, L, V) log-probs of the loop."""
-  if log_probs.shape[-1] % 4 == 0:
-    return _NLLMeanFunction.apply(log_probs, labels, pad)
-  V = log_probs.shape[-1]
-  L = log_probs.shape[1]
-  nll = F.nll_loss(log_probs.reshape(-1, V), labels[:, :L].reshape(-1), ignore_index=pad, reduction='sum')
-  return nll / (labels != pad).sum()
+  """decoder_loss of train_better_model.py:62-65 from the (B, L, V) log-probs of the loop (any V)."""
+  return _NLLMeanFunction.apply(log_probs, labels, pad)
+
+
+def decoder_nll_sum(log_probs, labels, pad):
+  """(sum of -log_probs[label] over the non-PAD steps, their count): eval adds the sums over the batches and divides
+  once (train_better_model.py:127,138).  No gradient."""
+  B, L, V = log_probs.shape
+  lp = log_probs.contiguous()
+  assert labels.dtype == torch.int64 and labels.stride(1) == 1 and labels.shape[0] == B and labels.shape[1] >= L
+  out3 = torch.empty(3, dtype=torch.float32, device=lp.device)
+  _C.check(_C.lib().lr_nll_forward3(lp.data_ptr(), labels.data_ptr(), labels.stride(0), L, int(pad), out3.data_ptr(),
+                                    B * L, V, _C.stream_handle()), "lr_nll_forward3")
+  return out3[2], out3[1]
 
 
 class _Held(object):
@@ -394,8 +400,7 @@ def _decoder_losses(decoding_step, chars, labels, label_lens_host, frame_lens, h
   flags = [bool(torch.rand(1) < teacher_forcing_ratio) for _ in range(L)]
   log_probs, sampled, _ = decoding_step.decode_sequence(chars[:, :L], state, frame_lens, hidden,
                                                         teacher_forced=flags)
-  V = log_probs.shape[-1]
-  nll = F.nll_loss(log_probs.reshape(-1, V), labels[:, :L].reshape(-1), ignore_index=pad, reduction='sum')
+  nll, _ = decoder_nll_sum(log_probs, labels, pad)
   return nll, sampled, L
 
 

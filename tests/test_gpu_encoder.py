@@ -649,3 +649,69 @@ def test_cluster_recurrence_survives_a_foreign_kernel_that_holds_compute_units(d
   assert L.lr_rnn_pair_errors() == 0
   for a, b in zip(res[False], res[True]):
     assert torch.equal(a, b)
+
+
+def test_inter_layer_dropout_is_a_philox_mask(dev):
+  """rnn_dropout > 0 (better_model.py:47-49 hands it to nn.GRU / nn.LSTM): between stacked layers, training mode only —
+  lr_dropout_forward.  torch's mask comes from torch's generator stream, so the mask is tested AS A MASK: values in
+  {0, 1 / (1 - p)}, the dropped fraction, determinism in the seed, independence of the launch geometry, the backward
+  the same multiply; eval mode and the last layer untouched."""
+  import torch.nn.functional as F
+  from lipreading_amd import _C, encoder as E
+  from lipreading_amd.data import default_char2idx
+  L = _C.lib()
+  n, p = 1000003, 0.3
+  x = torch.randn(n, device=dev)
+  y, m = torch.empty_like(x), torch.empty_like(x)
+  _C.check(L.lr_dropout_forward(x.data_ptr(), y.data_ptr(), m.data_ptr(), n, p, 12345, _C.stream_handle()), "dropout")
+  keep = 1.0 / (1.0 - p)
+  assert bool(((m == 0) | ((m - keep).abs() < 1e-6)).all()) and torch.equal(y, x * m)
+  frac = float((m == 0).float().mean())
+  assert abs(frac - p) < 4 * (p * (1 - p) / n) ** 0.5 + 1e-4, frac
+  m2 = torch.empty_like(x)
+  _C.check(L.lr_dropout_forward(x.data_ptr(), y.data_ptr(), m2.data_ptr(), n, p, 12345, _C.stream_handle()), "dropout")
+  assert torch.equal(m, m2)
+  _C.check(L.lr_dropout_forward(x.data_ptr(), y.data_ptr(), m2.data_ptr(), n, p, 12346, _C.stream_handle()), "dropout")
+  assert not torch.equal(m, m2) and abs(float(((m == 0) & (m2 == 0)).float().mean()) - p * p) < 0.005   # independent draws
+  # a prefix of the same seed is the same mask (counter = element index / 4, not the launch)
+  _C.check(L.lr_dropout_forward(x.data_ptr(), y.data_ptr(), m2.data_ptr(), 4099, p, 12345, _C.stream_handle()), "dropout")
+  assert torch.equal(m[:4099], m2[:4099])
+  # in the encoder: training mode changes the second layer's input, eval mode does not; gradients flow through the mask
+  torch.manual_seed(7)
+  enc = E.VideoEncoder(64, 32, rnn_type='GRU', num_layers=2, bidirectional=True, rnn_dropout=0.5, enable_ctc=True,
+                       vocab_size=64, char2idx=default_char2idx()).to(dev)
+  xx = torch.randn(4, 9, 64, 1, device=dev)
+  lens = torch.full((4,), 9)
+  enc.eval()
+  a = enc(xx, lens, max_len=9)[1]
+  b = enc(xx, lens, max_len=9)[1]
+  assert torch.equal(a, b)
+  enc.train()
+  c = enc(xx, lens, max_len=9)[1]
+  d = enc(xx, lens, max_len=9)[1]
+  assert not torch.equal(c, d) and not torch.equal(a, c)
+  c.pow(2).sum().backward()
+  assert all(p_.grad is not None and torch.isfinite(p_.grad).all() and float(p_.grad.abs().max()) > 0 for p_ in enc.parameters())
+  # _DropoutFunction's backward is the mask multiply
+  z = torch.randn(5, 7, device=dev, requires_grad=True)
+  out = E._DropoutFunction.apply(z, 0.25, 99)
+  out.backward(torch.ones_like(out))
+  assert bool(((z.grad == 0) | ((z.grad - 1 / 0.75).abs() < 1e-6)).all()) and torch.equal(z.grad == 0, out.detach() == 0)
+
+
+def test_final_states_in_one_launch_equal_the_permuted_copies(dev):
+  """_cat_directions (better_model.py:98-112): (D,B,H) -> (B, D*H) for h and c of a layer in one launch each way."""
+  from lipreading_amd import encoder as E
+  g = torch.Generator().manual_seed(3)
+  for D, B, H in ((2, 5, 12), (1, 3, 8), (2, 32, 700)):
+    h = torch.randn(D, B, H, generator=g).to(dev).requires_grad_()
+    c = torch.randn(D, B, H, generator=g).to(dev).requires_grad_()
+    oh, oc = E._CatDirectionsFunction.apply(h, c)
+    assert torch.equal(oh, h.detach().permute(1, 0, 2).reshape(B, D * H)) and torch.equal(oc, c.detach().permute(1, 0, 2).reshape(B, D * H))
+    wh, wc = torch.randn(B, D * H, generator=g).to(dev), torch.randn(B, D * H, generator=g).to(dev)
+    ((oh * wh).sum() + (oc * wc).sum()).backward()
+    assert torch.equal(h.grad, wh.reshape(B, D, H).permute(1, 0, 2)) and torch.equal(c.grad, wc.reshape(B, D, H).permute(1, 0, 2))
+    h2 = h.detach().clone().requires_grad_()
+    o2 = E._CatDirectionsFunction.apply(h2, None)
+    (o2 * wh).sum().backward()
+    assert torch.equal(o2, oh) and torch.equal(h2.grad, h.grad)

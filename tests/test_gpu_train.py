@@ -537,3 +537,27 @@ def test_repeated_recurrence_time_outs_fall_back_to_the_step_kernels(dev, capsys
     L.lr_rnn_debug_drop_member(-1)
     L.lr_rnn_pair_errors()
   assert got == want
+
+
+@pytest.mark.parametrize("V", [64, 61, 30, 7])
+def test_decoder_nll_for_any_vocabulary_size(dev, V):
+  """train_better_model.py:62-65 / :127,138: the decoder loss and its gradient for vocabularies that are not a multiple
+  of four as well (round 3 fell back to F.nll_loss there), and eval's (sum, count) pair."""
+  import torch.nn.functional as F
+  from lipreading_amd import train as T
+  g = torch.Generator().manual_seed(V)
+  B, L = 5, 9
+  lp = torch.log_softmax(torch.randn(B, L, V, generator=g), -1).to(dev).requires_grad_()
+  chars = torch.randint(1, V, (B, L + 2), generator=g)
+  chars[1, 5:] = 0
+  chars[3, 2:] = 0
+  chars = chars.to(dev)
+  labels = chars[:, 1:]
+  loss = T.decoder_nll(lp, labels, 0)
+  loss.backward()
+  lp_r = lp.detach().clone().requires_grad_()
+  want = F.nll_loss(lp_r.reshape(-1, V), labels[:, :L].reshape(-1), ignore_index=0, reduction='sum') / (labels[:, :L] != 0).sum()
+  want.backward()
+  assert abs(float(loss) - float(want)) < 1e-5 and float((lp.grad - lp_r.grad).abs().max()) < 1e-7
+  s, n = T.decoder_nll_sum(lp.detach(), labels, 0)
+  assert abs(float(s) - float(want) * float(n)) < 1e-4 and int(n) == int((labels[:, :L] != 0).sum())
