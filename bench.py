@@ -99,7 +99,14 @@ def pmc_traffic():
   if not cands:
     return None, None
   with open(cands[-1]) as f:
-    return json.load(f), os.path.relpath(cands[-1], ROOT)
+    pmc = json.load(f)
+  # the passes are figures of the kernels they ran: quoted only when this build is of the same sources and flags
+  # (lipreading_amd/_build.py's fingerprint, written beside the passes on the GPU box); anything else is stale
+  from lipreading_amd import _build
+  if pmc.get("source_fingerprint") != _build._fingerprint():
+    raise LookupError("%s was taken with other kernel sources (fingerprint %s..., this build %s...)"
+                      % (os.path.relpath(cands[-1], ROOT), str(pmc.get("source_fingerprint"))[:12], _build._fingerprint()[:12]))
+  return pmc, os.path.relpath(cands[-1], ROOT)
 
 
 def conv_flops(B):
@@ -779,7 +786,10 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
           traffic = pmc["pixels"][dom]["traffic_bytes"]
           mfma_busy = pmc["pixels"][dom].get("mfma_busy")
           traffic_src = ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
-                         "64-byte gathers: fetch not doubled, see its note)" % pmc_path)
+                         "64-byte gathers: fetch not doubled, see its note; source fingerprint %s = this build's)"
+                         % (pmc_path, pmc["source_fingerprint"][:12]))
+      except LookupError as e:
+        traffic_src = "none: %s" % e
       except Exception:
         pass
       roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,

@@ -12,16 +12,16 @@ import os
 import sys
 
 PIXELS = {  # bench.py's conv names -> a substring of the kernel symbol
-    "conv1_fwd": "conv1_fwd_patch_kernel", "conv2_fwd": "conv_patch_kernel<1, 2, true>",
-    "conv3_fwd": "conv_patch16_kernel<2, 3, true>", "conv2_dgrad": "conv_patch_kernel<2, 1, false>",
-    "conv3_dgrad": "conv_patch16_kernel<3, 2, false>", "conv1_wgrad": "conv1_wgrad_patch_kernel",
+    "conv1_fwd": "conv1_fwd_patch_kernel", "conv2_fwd": "conv_patch_kernel<1, 2, true",
+    "conv3_fwd": "conv_patch16_kernel<2, 3, true", "conv2_dgrad": "conv_patch_kernel<2, 1, false",
+    "conv3_dgrad": "conv_patch16_kernel<3, 2, false", "conv1_wgrad": "conv1_wgrad_patch_kernel",
     "conv2_wgrad": "conv_wgrad_tr2_kernel<32", "conv3_wgrad": "conv_wgrad_tr2_kernel<64"}
 RECURRENT = {"rnn_fwd_step_kernel": "rnn_fwd_step_kernel", "rnn_bwd_step_kernel": "rnn_bwd_step_kernel",
              "gru256_fwd_pair_kernel": "gru256_fwd_pair_kernel", "gru256_bwd_pair_kernel": "gru256_bwd_pair_kernel",
              "gru256_fwd_persist_kernel": "gru256_fwd_persist_kernel", "gru256_bwd_persist_kernel": "gru256_bwd_persist_kernel",
              "sgemm_grouped_kernel": "sgemm_grouped_kernel", "xgemm_kernel": "xgemm_kernel"}
 # the cluster recurrence's instantiations (lr_rnn_cluster.hip): bench.py's name "rnnc_fwd_kernel<G,CC>"
-for _g, _cc in ((3, 8), (4, 8), (3, 16), (4, 16), (3, 22), (4, 22), (3, 24), (4, 24), (3, 25)):
+for _g, _cc in [(3, c) for c in range(1, 28)] + [(4, c) for c in range(1, 25)]:
   for _w in ("fwd", "bwd"):
     # (the profiler leaves some of these names mangled: both spellings)
     RECURRENT["rnnc_%s_kernel<%d,%d>" % (_w, _g, _cc)] = ("rnnc_%s_kernel<%d, %d>" % (_w, _g, _cc),
@@ -56,6 +56,16 @@ def main(tag, d="profiles"):
   out = {"_note": "HBM/fabric bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (bench.py "
                   "--no-graph, a few steps), averaged over the launches; see tools/make_pmc_traffic.py for the formula.",
          "source_files": []}
+  # which kernels the passes ran: the fingerprint of every csrc/*.hip, header and compiler flag (lipreading_amd/_build.py),
+  # written on the GPU box beside the passes (tools/refresh_profiles.sh).  bench.py quotes these figures only on a
+  # build with the same fingerprint.
+  fp = os.path.join(d, "%s_source_fingerprint.txt" % tag)
+  out["source_fingerprint"] = open(fp).read().strip() if os.path.exists(fp) else None
+  try:
+    import subprocess
+    out["git_head_when_assembled"] = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+  except Exception:
+    out["git_head_when_assembled"] = None
   for model, table, doubled in [(m, RECURRENT, True) for m in MODELS] + [("pixels", PIXELS, False)]:
     f = read(os.path.join(d, "%s_%s_pmc_FETCH_SIZE.txt" % (tag, model)))
     w = read(os.path.join(d, "%s_%s_pmc_WRITE_SIZE.txt" % (tag, model)))

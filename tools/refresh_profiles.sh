@@ -48,6 +48,8 @@ pmc() {   # name, counter list, filters..., -- bench args
   rm -rf "$OUT/pmc_$name"
 }
 
+# which kernels these artefacts are of (bench.py quotes the PMC figures only on a build with the same fingerprint)
+python -c "from lipreading_amd import _build; print(_build._fingerprint())" > "$OUT/${TAG}_source_fingerprint.txt"
 python bench.py 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_default.json"
 kt pixels --regime pixels
 for c in FETCH_SIZE WRITE_SIZE; do pmc px_$c $c pixels_pmc_$c -- --regime pixels; done
