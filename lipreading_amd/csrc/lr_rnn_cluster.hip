@@ -169,6 +169,13 @@ __device__ __forceinline__ int xcc_id() {
 // instantiation happened to be scheduled the other way round.)
 #define LR_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 3" ::: "memory")
 #define LR_ACC_READY(acc) asm volatile("" : "+v"(acc))
+// lanes 0-31: x + (x of lane + 32); lanes 32-63: y + (y of lane - 32).  (Inline asm: this ROCm's
+// __builtin_amdgcn_permlane32_swap folds its two results into one register.  s_nop: the wait states a lane-crossing
+// VALU read wants behind a VALU write of its operands, which the hazard recogniser cannot place around an asm.)
+__device__ __forceinline__ float fold32(float x, float y) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+  return x + y;
+}
 
 // do all members of this cluster sit on one XCD?  Every member publishes its XCC id (agent scope) and reads all
 // CC; the verdict is the same on every member because it is computed from the same CC words.  Returns through
@@ -712,11 +719,13 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
       float v[4];
 #pragma unroll
       for (int th = 0; th < 2; ++th) {
-        f32x4& a = acc[2 * m + th];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] += __shfl_xor(a[r], 32, 64);
-        v[2 * th] = (kg >> 1) ? a[2] : a[0];
-        v[2 * th + 1] = (kg >> 1) ? a[3] : a[1];
+        // v_permlane32_swap (gfx950) trades the upper half of one register for the lower half of another: with a[0] and
+        // a[2] that leaves {a0.lo, a2.lo} and {a0.hi, a2.hi}, whose sum IS the fold — lanes 0-31 hold a[0] + the a[0] of
+        // lane + 32, lanes 32-63 a[2] + the a[2] of lane - 32 — in two VALU instructions per kept value (rounds 2-3: four
+        // ds_bpermute + four adds + two selects per tile through the LDS pipe, half of them for values nobody keeps)
+        const f32x4 a = acc[2 * m + th];
+        v[2 * th] = fold32(a[0], a[2]);
+        v[2 * th + 1] = fold32(a[1], a[3]);
       }
       if (dstm < CC) {
         if (dstm == c) {
