@@ -647,7 +647,7 @@ extern "C" int lr_rnn_persistent_supported(int mode, int B, int T, int I, int H,
 
 extern "C" int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D) || H % 4 != 0) return 0;   // (H % 4: lr_rnn_layer_forward's own requirement)
-  // 2: clusters of ceil(H / 32) CUs (lr_rnn_cluster.hip: every GRU with H <= 864, every LSTM with H <= 768 — GRU-256
+  // 2: clusters of ceil(H / 32) CUs — ceil(H / 16) past 864 (GRU) / 768 (LSTM) units — (lr_rnn_cluster.hip: H <= 1152; GRU-256
   // included: the 8-member cluster measured 118 + 131 us per layer pass against the pair kernels' 125 + 160);
   // 1: GRU-256 on CU pairs (lr_rnn_pair.hip), where a device is too small for a cluster launch; both passes of either
   if (lr_rnn_cluster_supported(gates_of(mode), B, H)) return 2;

@@ -60,41 +60,54 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;
 typedef unsigned u32;
 
-constexpr int UPM = 32;            // hidden units per member
 constexpr int NS = 8;              // samples per cluster (rows 0-7 hi, 8-15 lo of the A operand)
 constexpr int SPIN_LIMIT = 1 << 18;
-constexpr int MAX_CLUSTERS = 8;    // per launch: one cluster per XCD
-constexpr int XMEMBER = NS * UPM;  // exchange words a member publishes per step (forward) / per destination (backward)
 
 constexpr int imin(int a, int b) { return a < b ? a : b; }
 constexpr int imax(int a, int b) { return a > b ? a : b; }
 
-template <int G, int CC>
+// U = hidden units per member: 32 (a cluster of ceil(H / 32) CUs, at most one XCD's worth: the sizes up to 864 / 768),
+// or 16 (round 4: twice the members, half the slice of W_hh each — LSTM-800 and the 1024-unit decoder behind a
+// BiLSTM-512 encoder, config/train/attn/attention_type:16-19 with better_model.py:134-148; a cluster then spans two
+// XCDs and exchanges at agent scope).  Everything below is written in these terms:
+//   UW    units a wave owns (8 | 4); its gate columns are NTILE MFMA column tiles of GPT gates x UW units
+//   KS    k steps of 32 state columns (CC | CC / 2: with 16-unit members a k step is a PAIR of members)
+//   XB    exchange words a member publishes per step (forward) / per destination and step (backward): NS x U
+//   TPB   16-byte gather items per XB block: a thread's item g = sweep * 256 + tid belongs to member g / TPB
+template <int G, int CC, int U>
 struct Cfg {
   static_assert(G == 3 || G == 4, "GRU or LSTM");
-  static constexpr int HP = UPM * CC;              // padded hidden size
+  static_assert(U == 32 || (U == 16 && CC % 2 == 0), "16-unit members come in pairs (one k step of 32)");
+  static constexpr int UW = U / 4, NTILE = U / 16, GPT = 16 / UW;
+  static constexpr int HP = U * CC;                // padded hidden size
+  static constexpr int KS = HP / 32;
   static constexpr int CLD = HP + 8;               // bf16 per LDS row of the state
-  static constexpr int NL = (CC + 3) / 4;          // 16-byte gather loads per thread and step (4 members per sweep)
-  // forward: wave w owns units 8w .. 8w+7 as two column tiles (t = 0: gates 0, 1; t = 1: gates 2, 3);
-  // CF fragments per tile: f = 2 * local k step + plane
-  static constexpr int CF = 2 * CC;
-  static constexpr int CF_A = imin(CF, 30);        // f < CF_A in AGPRs (2 tiles x 30 = 60 fragments)
-  static constexpr int CF_REG = imin(CF, 44);      // f < CF_REG in registers; the rest in LDS
+  static constexpr int XB = NS * U, TPB = XB / 4;
+  static constexpr int NL = (CC * TPB + 255) / 256;   // 16-byte gather loads per thread and step
+  static constexpr int MAXCL = CC <= 32 ? 8 : (CC <= 64 ? 4 : 2);   // clusters per launch (block b -> cluster b % MAXCL)
+  // forward: CF fragments per tile: f = 2 * local k step + plane
+  static constexpr int CF = 2 * KS;
+  static constexpr int CF_A = imin(CF, 60 / NTILE);             // f < CF_A in AGPRs (60 fragments per wave)
+  static constexpr int CF_REG = imin(CF, CF_A + 28 / NTILE);    // f < CF_REG in registers; the rest in LDS
   static constexpr int CF_L = CF - CF_REG;
-  static constexpr size_t FWD_LDS = (size_t)2 * 16 * CLD * 2 + (size_t)4 * 2 * CF_L * 1024 + (size_t)4 * 2 * 256 * 4;
-  // backward: K = the member's own dG, KB blocks of 32 (LSTM i, f, g, o; GRU dr, dz, d(W_hn h)); the HP output
-  // units are 2 CC column tiles; wave w owns the two tiles of every destination member w, w + 4, ... (NT = 2 NL
-  // tiles: a wave's four accumulator values per lane and destination are ONE 16-byte store, and the wave's 64 lanes
-  // write that destination's whole 1 KB block); BFW fragments per tile: f = 2 * k block + plane
-  static constexpr int KB = G;
-  static constexpr int NT = 2 * NL;
+  static constexpr size_t FWD_LDS = (size_t)2 * 16 * CLD * 2 + (size_t)4 * NTILE * CF_L * 1024 + (size_t)4 * NTILE * 256 * 4;
+  // backward: K = the member's own dG in KB k steps of 32 (U = 32: one per gate — LSTM i, f, g, o; GRU dr, dz,
+  // d(W_hn h); U = 16: two gates x 16 units per k step); the HP output units are column tiles of 16; wave w owns the
+  // TPD tiles of every destination member w, w + 4, ... (a wave's 2 TPD accumulator values per lane and destination
+  // are ONE store, and the wave's 64 lanes write that destination's whole XB block); BFW fragments per tile: f = 2 *
+  // k step + plane
+  static constexpr int KB = U == 32 ? G : 2;
+  static constexpr int TPD = U / 16, ND = (CC + 3) / 4;
+  static constexpr int NT = ND * TPD;
+  static constexpr int VPL = 2 * TPD;              // values per lane and destination
   static constexpr int BFW = 2 * KB;
   static constexpr int BFW_A = imin(BFW, 60 / NT);
   static constexpr int BFW_REG = imin(BFW, BFW_A + imax(1, 14 / NT));
   static constexpr int BFW_L = BFW - BFW_REG;
-  static constexpr int BKLD = KB * UPM + 8;
-  static constexpr size_t BWD_LDS = (size_t)2 * 16 * BKLD * 2 + (size_t)4 * NT * BFW_L * 1024 + (size_t)5 * XMEMBER * 4;
-  static constexpr size_t FWD_PACK = (size_t)CC * 4 * 2 * CF * 64 * sizeof(bf16x8);     // per direction
+  static constexpr int BKLD = KB * 32 + 8;
+  static constexpr int NRED = 256 / TPB;           // partial sums of the gather: one per (wave, block of the sweep)
+  static constexpr size_t BWD_LDS = (size_t)2 * 16 * BKLD * 2 + (size_t)4 * NT * BFW_L * 1024 + (size_t)(NRED + 1) * XB * 4;
+  static constexpr size_t FWD_PACK = (size_t)CC * 4 * NTILE * CF * 64 * sizeof(bf16x8);     // per direction
   static constexpr size_t BWD_PACK = (size_t)CC * 4 * NT * BFW * 64 * sizeof(bf16x8);
 };
 
@@ -204,9 +217,9 @@ __device__ __forceinline__ void xcd_handshake(u32* xid, int c, int tid, int* s_l
 // weight packing
 // ---------------------------------------------------------------------------------------------------------------
 // W_hh [G*H][H] fp32 of each direction -> bf16 hi/lo MFMA B fragments of the forward product:
-// out[((((d*CC + c)*4 + wave)*2 + t)*CF + f)*64 + lane] = plane f & 1 of W_hh[gate*H + unit][k .. k+7],
-// gate = 2t + (col >> 3), unit = 32c + 8 wave + (col & 7), k = 32 ((c + (f >> 1)) % CC) + 8 kg (LOCAL k order: the
-// own member's k step first); zero where gate >= G, unit >= H or k >= H.
+// out[((((d*CC + c)*4 + wave)*NTILE + t)*CF + f)*64 + lane] = plane f & 1 of W_hh[gate*H + unit][k .. k+7],
+// gate = GPT t + col / UW, unit = U c + UW wave + col % UW, k = 32 ((own k step + (f >> 1)) % KS) + 8 kg (LOCAL k order:
+// the own member's k step — c, or c / 2 with 16-unit members — first); zero where gate >= G, unit >= H or k >= H.
 // The same launch clears the first launch's exchange words and (FoldPtrs given) folds the layer's biases for the
 // input projection (lr_rnn.hip fold_bias2_kernel's arithmetic: b_ih + b_hh, except the GRU's n gate, whose b_hn sits
 // inside r * (W_hn h + b_hn)) — one launch where there were three (a dependent launch costs ~1.5-5 us here).
@@ -215,10 +228,11 @@ struct FoldPtrs {
   const float* b_hh[2];
   float* out;      // [D][G*H], or nullptr: nothing to fold
 };
-template <int G, int CC>
+template <int G, int CC, int U>
 __global__ void rnnc_pack_fwd_kernel(const float* __restrict__ w0, const float* __restrict__ w1, bf16x8* __restrict__ out,
                                      int D, int H, u32* __restrict__ xch, int nzero, FoldPtrs fold) {
-  constexpr int CF = Cfg<G, CC>::CF;
+  using C = Cfg<G, CC, U>;
+  constexpr int CF = C::CF, NTILE = C::NTILE, UW = C::UW, GPT = C::GPT, KS = C::KS;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += gridDim.x * blockDim.x) xch[i] = 0u;
   if (fold.out)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < D * G * H; i += gridDim.x * blockDim.x) {
@@ -227,13 +241,14 @@ __global__ void rnnc_pack_fwd_kernel(const float* __restrict__ w0, const float* 
       if (G != 3 || j < 2 * H) v += fold.b_hh[d][j];
       fold.out[i] = v;
     }
-  const int64_t total = (int64_t)D * CC * 4 * 2 * CF * 64;
+  const int64_t total = (int64_t)D * CC * 4 * NTILE * CF * 64;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int lane = (int)(i & 63), f = (int)((i >> 6) % CF), t = (int)((i / (64 * CF)) & 1);
-    const int wave = (int)((i / (64 * CF * 2)) & 3), c = (int)((i / (64 * CF * 8)) % CC), d = (int)(i / ((int64_t)64 * CF * 8 * CC));
+    const int lane = (int)(i & 63), f = (int)((i >> 6) % CF), t = (int)((i / (64 * CF)) % NTILE);
+    const int wave = (int)((i / (64 * CF * NTILE)) & 3), c = (int)((i / (64 * CF * NTILE * 4)) % CC);
+    const int d = (int)(i / ((int64_t)64 * CF * NTILE * 4 * CC));
     const int col = lane & 15, kg = lane >> 4, q = f >> 1, plane = f & 1;
-    const int gate = 2 * t + (col >> 3), unit = UPM * c + 8 * wave + (col & 7);
-    const int k = 32 * ((c + q) % CC) + 8 * kg;
+    const int gate = GPT * t + col / UW, unit = U * c + UW * wave + col % UW;
+    const int k = 32 * (((U == 32 ? c : c >> 1) + q) % KS) + 8 * kg;
     const float* row = (d ? w1 : w0) + ((int64_t)gate * H + unit) * H + k;
     const bool rok = gate < G && unit < H;
     bf16x8 v;
@@ -247,14 +262,15 @@ __global__ void rnnc_pack_fwd_kernel(const float* __restrict__ w0, const float* 
   }
 }
 
-// backward: out[((((d*CC + c)*4 + wave)*NT + tile)*BFW + f)*64 + lane] = plane f & 1 of W_hh[kappa + e][j], e = 0..7,
-// kappa = (f >> 1) * H + 32 c + 8 kg (k block f >> 1 = the gate whose recurrent pre-activation gradient multiplies
-// these rows), j = 32 (wave + 4 (tile >> 1)) + 16 (tile & 1) + col (the units of destination member wave + 4 (tile >> 1));
-// zero where 32 c + 8 kg + e >= H or j >= H.
-template <int G, int CC>
+// backward: out[((((d*CC + c)*4 + wave)*NT + tile)*BFW + f)*64 + lane] = plane f & 1 of W_hh[gate * H + unit + e][j],
+// e = 0..7: entry 8 kg + e of k step f >> 1 of the member's own dG — U = 32: gate = the k step, unit = 32 c + 8 kg;
+// U = 16: gate = 2 (k step) + (kg >> 1), unit = 16 c + 8 (kg & 1) — and j = U (wave + 4 (tile / TPD)) + 16 (tile % TPD) + col
+// (the units of destination member wave + 4 (tile / TPD)); zero where gate >= G, unit + e >= H or j >= H.
+template <int G, int CC, int U>
 __global__ void rnnc_pack_bwd_kernel(const float* __restrict__ w0, const float* __restrict__ w1, bf16x8* __restrict__ out,
                                      int D, int H, u32* __restrict__ xch, int nzero) {
-  constexpr int NT = Cfg<G, CC>::NT, BFW = Cfg<G, CC>::BFW;
+  using C = Cfg<G, CC, U>;
+  constexpr int NT = C::NT, BFW = C::BFW, TPD = C::TPD;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += gridDim.x * blockDim.x) xch[i] = 0u;
   const int64_t total = (int64_t)D * CC * 4 * NT * BFW * 64;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -262,14 +278,15 @@ __global__ void rnnc_pack_bwd_kernel(const float* __restrict__ w0, const float* 
     const int wave = (int)((i / (64 * BFW * NT)) & 3), c = (int)((i / (64 * BFW * NT * 4)) % CC);
     const int d = (int)(i / ((int64_t)64 * BFW * NT * 4 * CC));
     const int col = lane & 15, kg = lane >> 4, kb = f >> 1, plane = f & 1;
-    const int j = UPM * (wave + 4 * (tile >> 1)) + 16 * (tile & 1) + col;
-    const int u0 = UPM * c + 8 * kg;
-    const float* src = (d ? w1 : w0) + ((int64_t)kb * H + u0) * H + j;
+    const int j = U * (wave + 4 * (tile / TPD)) + 16 * (tile % TPD) + col;
+    const int gate = U == 32 ? kb : 2 * kb + (kg >> 1);
+    const int u0 = U == 32 ? U * c + 8 * kg : U * c + 8 * (kg & 1);
+    const float* src = (d ? w1 : w0) + ((int64_t)gate * H + u0) * H + j;
     bf16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       bf16_t hi, lo;
-      split_bf16(j < H && u0 + e < H ? src[(int64_t)e * H] : 0.f, hi, lo);
+      split_bf16(gate < G && j < H && u0 + e < H ? src[(int64_t)e * H] : 0.f, hi, lo);
       v[e] = __builtin_bit_cast(__bf16, plane ? lo : hi);
     }
     out[i] = v;
@@ -279,42 +296,45 @@ __global__ void rnnc_pack_bwd_kernel(const float* __restrict__ w0, const float* 
 // ---------------------------------------------------------------------------------------------------------------
 // forward recurrence
 // ---------------------------------------------------------------------------------------------------------------
-// grid: 8 * CC workgroups x 256 threads; block b -> cluster b & 7 (= its XCD), member b >> 3.
-// cluster k -> (sample group g0 + k / D, direction k % D).  Gate phase: lane = sample * 8 + unit of the wave: every
-// lane is busy and consumes its own wave's results (wave-local LDS exchange, no workgroup barrier).
-// Exchange layout: [slot][cluster][member][wave][sample][unit of the wave] words — a wave publishes 64 consecutive
+// grid: MAXCL * CC workgroups x 256 threads; block b -> cluster b % MAXCL (U = 32: MAXCL = 8, the cluster = one XCD;
+// U = 16: 4 or 2, a cluster spans XCDs k, k + MAXCL, ...), member b / MAXCL.
+// cluster k -> (sample group g0 + k / D, direction k % D).  Gate phase: lane = sample * UW + unit of the wave: it
+// consumes its own wave's results (wave-local LDS exchange, no workgroup barrier); with 4-unit waves lanes 32-63 idle.
+// Exchange layout: [slot][cluster][member][wave][sample][unit of the wave] words — a wave publishes NS * UW consecutive
 // words with one store instruction; a reading thread takes four consecutive units of one (member, wave, sample).
-template <int G, int CC>
+template <int G, int CC, int U>
 __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
     float* __restrict__ gates, float* __restrict__ extra, float* __restrict__ y, const bf16x8* __restrict__ wpk,
     const float* __restrict__ bhh0, const float* __restrict__ bhh1, const float* __restrict__ h0,
     const float* __restrict__ c0, const int32_t* __restrict__ lens, u32* __restrict__ xch, int32_t* __restrict__ fault,
     int drop, int tune, int g0, int nclusters, int B, int T, int D, int H) {
-  using C = Cfg<G, CC>;
+  using C = Cfg<G, CC, U>;
   constexpr int CLD = C::CLD, CF = C::CF, CF_A = C::CF_A, CF_REG = C::CF_REG, CF_L = C::CF_L, NL = C::NL, HP = C::HP;
+  constexpr int NTILE = C::NTILE, UW = C::UW, GPT = C::GPT, KS = C::KS, XB = C::XB, TPB = C::TPB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* hS = reinterpret_cast<bf16_t*>(smem);                                                    // [2][16][CLD]
-  bf16x8* Wl = reinterpret_cast<bf16x8*>(smem + (size_t)2 * 16 * CLD * 2);                         // [4][2][CF_L][64]
-  float* S = reinterpret_cast<float*>(smem + (size_t)2 * 16 * CLD * 2 + (size_t)4 * 2 * CF_L * 1024);   // [4][2][16][16]
+  bf16x8* Wl = reinterpret_cast<bf16x8*>(smem + (size_t)2 * 16 * CLD * 2);                         // [4][NTILE][CF_L][64]
+  float* S = reinterpret_cast<float*>(smem + (size_t)2 * 16 * CLD * 2 + (size_t)4 * NTILE * CF_L * 1024);   // [4][NTILE][16][16]
   __shared__ int s_local;
-  const int cluster = blockIdx.x & 7, c = blockIdx.x >> 3;
+  const int cluster = blockIdx.x % C::MAXCL, c = blockIdx.x / C::MAXCL;
+  const int ks_own = U == 32 ? c : c >> 1;   // the k step this member's units sit in
   if (cluster >= nclusters) return;     // whole clusters leave together
   if (c == drop) return;                // test hook (lr_rnn_debug_drop_member): the others must time out and report
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = cluster % D, group = g0 + cluster / D;
   const int col = lane & 15, kg = lane >> 4;
 
-  // ---- weights: 4 CC fragments per wave ----------------------------------------------------------------------
-  bf16x8 Wa[2][CF_A], Wv[2][imax(1, CF_REG - CF_A)];
-  const bf16x8* wsrc = wpk + ((int64_t)((d * CC + c) * 4 + wave) * 2 * CF) * 64 + lane;
+  // ---- weights: NTILE * CF fragments per wave ------------------------------------------------------------------
+  bf16x8 Wa[NTILE][CF_A], Wv[NTILE][imax(1, CF_REG - CF_A)];
+  const bf16x8* wsrc = wpk + ((int64_t)((d * CC + c) * 4 + wave) * NTILE * CF) * 64 + lane;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < NTILE; ++t) {
 #pragma unroll
     for (int f = 0; f < CF; ++f) {
       const bf16x8 w = wsrc[(t * CF + f) * 64];
       if (f < CF_A) Wa[t][f] = w;
       else if (f < CF_REG) Wv[t][f - CF_A] = w;
-      else Wl[((wave * 2 + t) * CF_L + (f - CF_REG)) * 64 + lane] = w;
+      else Wl[((wave * NTILE + t) * CF_L + (f - CF_REG)) * 64 + lane] = w;
     }
   }
   // ---- the state before step 0 (zero, or h0): hS[0], hi in rows 0-7, lo in rows 8-15, LOCAL k order ------------
@@ -323,8 +343,8 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
     const int r = i / CLD, pos = i - r * CLD;
     float v = 0.f;
     if (h0 && pos < HP) {
-      int j = c + (pos >> 5);
-      if (j >= CC) j -= CC;
+      int j = ks_own + (pos >> 5);
+      if (j >= KS) j -= KS;
       const int k = 32 * j + (pos & 31), bb = group * NS + r;
       if (k < H && bb < B) v = h0[((int64_t)d * B + bb) * H + k];
     }
@@ -335,11 +355,13 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
   }
 
   // ---- gate-phase role: one (sample, unit) per thread ----------------------------------------------------------
-  const int sl = lane >> 3, u8 = lane & 7;          // sample within the group, unit within the wave
-  const int ul = 8 * wave + u8;                     // member-local unit
-  const int unit = UPM * c + ul;
+  const bool active = lane < NS * UW;               // (4-unit waves: the upper half of the wave has no (sample, unit))
+  const int sl = (lane / UW) & 7, u8 = lane % UW;   // sample within the group, unit within the wave
+  const int ul = UW * wave + u8;                    // member-local unit
+  const int unit = U * c + ul;
+  const int own_pos = ((U * c) & 31) + ul;          // its column in the own k step (local k step 0)
   const int b = group * NS + sl;
-  const bool alive = b < B && unit < H;
+  const bool alive = active && b < B && unit < H;
   const int len = alive ? lens[b] : 0;
   const float bhn = (G == 3 && alive) ? (d ? bhh1 : bhh0)[2 * H + unit] : 0.f;
   float sreg = 0.f;                                 // carried fp32 state of this (sample, unit): GRU h, LSTM c
@@ -366,15 +388,18 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
   for (int g = 0; g < G; ++g) gxA.v[g] = gxB.v[g] = 0.f;
   fetch_gx(gxA, time_of(0));
   fetch_gx(gxB, time_of(1));
-  const int xcluster = CC * XMEMBER, xslot = nclusters * xcluster;   // words (32-bit: scalar multiplies)
-  u32* xmine = xch + cluster * xcluster + c * XMEMBER + tid;            // word wave*64 + sample*8 + unit of the wave
-  const u32* xbase = xch + cluster * xcluster + 4 * lane;               // + member * XMEMBER
-  // what this thread gathers in sweep i: member 4 i + wave; sample rsmp, local units rpos .. rpos + 3
-  const int rsmp = (lane >> 1) & 7, rpos = 8 * (lane >> 4) + 4 * (lane & 1);
+  const int xcluster = CC * XB, xslot = nclusters * xcluster;       // words (32-bit: scalar multiplies)
+  u32* xmine = xch + cluster * xcluster + c * XB + wave * (NS * UW) + lane;   // word (wave, sample, unit of the wave)
+  // what this thread gathers in sweep i: item g = 256 i + tid of the cluster's CC * TPB 16-byte items, i.e. member
+  // g / TPB (32-unit members: 4 i + wave; 16-unit members: 8 i + 2 wave + (lane >> 5)), its words 4 w .. 4 w + 3 with
+  // w = g % TPB: wave w / (2 NS) ... of the source, sample rsmp, member-local units rpos .. rpos + 3
+  const int gw = tid % TPB, gj0 = tid / TPB;                            // item inside a block; member of sweep 0
+  const u32* xbase = xch + cluster * xcluster + gj0 * XB + 4 * gw;      // + sweep * (256 / TPB) * XB
+  const int rsmp = ((4 * gw) % (NS * UW)) / UW, rpos = UW * ((4 * gw) / (NS * UW)) + (4 * gw) % UW;
   unsigned pend0 = 0;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
-    const int j = 4 * i + wave;
+    const int j = (256 / TPB) * i + gj0;
     if (j < CC && j != c) pend0 |= 1u << i;
   }
   int bad = 0;
@@ -391,10 +416,11 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
 #pragma unroll
     for (int g = 0; g < G; ++g) sum[g] = 0.f;
     if (s > 0 || has_h0) {
-      f32x4 acc0[2], acc1[2];     // hi / lo weight plane: four accumulation chains per wave (eight — even / odd k
+      f32x4 acc0[NTILE], acc1[NTILE];   // hi / lo weight plane: four accumulation chains per wave (eight — even / odd k
                                   // steps apart — measured 4 % slower: the chains are not what the product waits for)
-      // ---- own member's k step (local q = 0): its operands are already in LDS --------------------------------------
-      {
+      // ---- own member's k step (local q = 0): its operands are already in LDS (32-unit members; with 16-unit
+      // members half of that k step is the partner's and arrives with the gather) ------------------------------------
+      if constexpr (U == 32) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(hcur + col * CLD + kg * 8);
         LR_MFMA_A0(acc0[0], a, Wa[0][0]);
         LR_MFMA_A0(acc0[1], a, Wa[1][0]);
@@ -423,7 +449,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
           g[i] = (u32x4){0u, 0u, 0u, 0u};
-          if (((pend0 >> i) & 1u) && !bad) g[i] = peek4(xp + (4 * i + wave) * XMEMBER);
+          if (((pend0 >> i) & 1u) && !bad) g[i] = peek4(xp + i * (256 / TPB) * XB);
         }
         unsigned pend = pend0;
         for (int round = 0; pend && !bad; ++round) {
@@ -435,13 +461,16 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
             if ((pend >> i) & 1u) {
               const u32x4 v = g[i];
               if ((((v[0] ^ tg) | (v[1] ^ tg) | (v[2] ^ tg) | (v[3] ^ tg)) & 3u) == 0u) {
-                int q = 4 * i + wave - c;
-                if (q < 0) q += CC;
+                // where member j's units sit in the LOCAL k order: k step (U j) / 32 relative to the own one
+                const int j = (256 / TPB) * i + gj0;
+                int q = ((U * j) >> 5) - ks_own;
+                if (q < 0) q += KS;
+                const int pos = 32 * q + ((U * j) & 31) + rpos;
                 u32 hi0, lo0, hi1, lo1;
                 split_bf16_pair(xval(v[0]), xval(v[1]), hi0, lo0);
                 split_bf16_pair(xval(v[2]), xval(v[3]), hi1, lo1);
-                *reinterpret_cast<uint2*>(hcur + rsmp * CLD + 32 * q + rpos) = make_uint2(hi0, hi1);
-                *reinterpret_cast<uint2*>(hcur + (rsmp + 8) * CLD + 32 * q + rpos) = make_uint2(lo0, lo1);
+                *reinterpret_cast<uint2*>(hcur + rsmp * CLD + pos) = make_uint2(hi0, hi1);
+                *reinterpret_cast<uint2*>(hcur + (rsmp + 8) * CLD + pos) = make_uint2(lo0, lo1);
                 pend &= ~(1u << i);
               }
             }
@@ -454,52 +483,62 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
           for (int w = 0; w < ((tune >> 8) & 0xff); ++w) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
           for (int i = 0; i < NL; ++i)
-            if ((pend >> i) & 1u) g[i] = peek4(xp + (4 * i + wave) * XMEMBER);
+            if ((pend >> i) & 1u) g[i] = peek4(xp + i * (256 / TPB) * XB);
         }
         lr_lds_barrier();
       }
-      bf16x8 a_next = *reinterpret_cast<const bf16x8*>(hcur + col * CLD + 32 + kg * 8);
+      constexpr int Q0 = U == 32 ? 1 : 0;    // first k step behind the gather
+      bf16x8 a_next = *reinterpret_cast<const bf16x8*>(hcur + col * CLD + 32 * Q0 + kg * 8);
 #pragma unroll
-      for (int q = 1; q < CC; ++q) {
+      for (int q = Q0; q < KS; ++q) {
         const bf16x8 a = a_next;
-        if (q + 1 < CC) a_next = *reinterpret_cast<const bf16x8*>(hcur + col * CLD + (q + 1) * 32 + kg * 8);
+        if (q + 1 < KS) a_next = *reinterpret_cast<const bf16x8*>(hcur + col * CLD + (q + 1) * 32 + kg * 8);
         const int f0 = 2 * q, f1 = 2 * q + 1;
-        if (f1 < CF_A) {
-          LR_MFMA_A(acc0[0], a, Wa[0][f0]);
-          LR_MFMA_A(acc0[1], a, Wa[1][f0]);
-          LR_MFMA_A(acc1[0], a, Wa[0][f1]);
-          LR_MFMA_A(acc1[1], a, Wa[1][f1]);
+        if (U == 16 && q == 0) {   // (16-unit members: nothing was accumulated in front of the gather)
+#pragma unroll
+          for (int t = 0; t < NTILE; ++t) {
+            LR_MFMA_A0(acc0[t], a, Wa[t][0]);
+            LR_MFMA_A0(acc1[t], a, Wa[t][1]);
+          }
+        } else if (f1 < CF_A) {
+#pragma unroll
+          for (int t = 0; t < NTILE; ++t) LR_MFMA_A(acc0[t], a, Wa[t][f0]);
+#pragma unroll
+          for (int t = 0; t < NTILE; ++t) LR_MFMA_A(acc1[t], a, Wa[t][f1]);
         } else if (f1 < CF_REG) {
-          LR_MFMA_V(acc0[0], a, Wv[0][f0 - CF_A]);
-          LR_MFMA_V(acc0[1], a, Wv[1][f0 - CF_A]);
-          LR_MFMA_V(acc1[0], a, Wv[0][f1 - CF_A]);
-          LR_MFMA_V(acc1[1], a, Wv[1][f1 - CF_A]);
+#pragma unroll
+          for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc0[t], a, Wv[t][f0 - CF_A]);
+#pragma unroll
+          for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc1[t], a, Wv[t][f1 - CF_A]);
         } else {
-          const bf16x8 w00 = Wl[((wave * 2 + 0) * CF_L + (f0 - CF_REG)) * 64 + lane];
-          const bf16x8 w10 = Wl[((wave * 2 + 1) * CF_L + (f0 - CF_REG)) * 64 + lane];
-          const bf16x8 w01 = Wl[((wave * 2 + 0) * CF_L + (f1 - CF_REG)) * 64 + lane];
-          const bf16x8 w11 = Wl[((wave * 2 + 1) * CF_L + (f1 - CF_REG)) * 64 + lane];
-          LR_MFMA_V(acc0[0], a, w00);
-          LR_MFMA_V(acc0[1], a, w10);
-          LR_MFMA_V(acc1[0], a, w01);
-          LR_MFMA_V(acc1[1], a, w11);
+          bf16x8 w0[NTILE], w1[NTILE];
+#pragma unroll
+          for (int t = 0; t < NTILE; ++t) {
+            w0[t] = Wl[((wave * NTILE + t) * CF_L + (f0 - CF_REG)) * 64 + lane];
+            w1[t] = Wl[((wave * NTILE + t) * CF_L + (f1 - CF_REG)) * 64 + lane];
+          }
+#pragma unroll
+          for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc0[t], a, w0[t]);
+#pragma unroll
+          for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc1[t], a, w1[t]);
         }
       }
       LR_MFMA_DRAIN();
-      LR_ACC_READY(acc0[0]);
-      LR_ACC_READY(acc0[1]);
-      LR_ACC_READY(acc1[0]);
-      LR_ACC_READY(acc1[1]);
-      // tile (wave, t): S[row 4 kg + r][col] ; rows 0-7 = state hi of samples 0-7, rows 8-15 = state lo
-      float* Sw = S + wave * 2 * 256;
 #pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2)
+      for (int t = 0; t < NTILE; ++t) {
+        LR_ACC_READY(acc0[t]);
+        LR_ACC_READY(acc1[t]);
+      }
+      // tile (wave, t): S[row 4 kg + r][col] ; rows 0-7 = state hi of samples 0-7, rows 8-15 = state lo
+      float* Sw = S + wave * NTILE * 256;
+#pragma unroll
+      for (int t2 = 0; t2 < NTILE; ++t2)
 #pragma unroll
         for (int r = 0; r < 4; ++r) Sw[t2 * 256 + (4 * kg + r) * 16 + col] = acc0[t2][r] + acc1[t2][r];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local exchange
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        const float* Sg = Sw + (g >> 1) * 256 + (g & 1) * 8 + u8;
+        const float* Sg = Sw + (g / GPT) * 256 + (g % GPT) * UW + u8;
         sum[g] = Sg[sl * 16] + Sg[(sl + 8) * 16];
       }
     }
@@ -533,13 +572,15 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
     }
     fetch_gx(gx, tnext);
     const u32 w = xword(h, tag_of(s));
-    publish(xmine + (s & 1) * xslot, w, local);      // first: the other members are waiting for it
+    if (active) publish(xmine + (s & 1) * xslot, w, local);      // first: the other members are waiting for it
     h = xval(w);                                     // the state everyone uses, this member included
     if (G == 3) sreg = h;
     bf16_t hi, lo;
     split_bf16(h, hi, lo);
-    hnxt[sl * CLD + ul] = hi;                        // local k position of the own member: q = 0
-    hnxt[(sl + 8) * CLD + ul] = lo;
+    if (active) {
+      hnxt[sl * CLD + own_pos] = hi;                 // local k position of the own member: q = 0
+      hnxt[(sl + 8) * CLD + own_pos] = lo;
+    }
     if (alive) {
       const int64_t bt = (int64_t)b * T + t;
       y[bt * ((int64_t)D * H) + d * H + unit] = h;
@@ -579,22 +620,23 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
 // members ww, ww + 4, ... and adds them up (fixed order); the four waves' sums and the member's own partial meet in
 // LDS, where each thread picks up the five values of its own (sample, unit) and runs the cell backward
 // (rnn_bwd_step_kernel's arithmetic).
-template <int G, int CC>
+template <int G, int CC, int U>
 __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
     const float* __restrict__ gates, const float* __restrict__ extra, const float* __restrict__ y,
     const float* __restrict__ dy, const float* __restrict__ dh_n, const float* __restrict__ dc_n, float* __restrict__ dG,
     float* __restrict__ dh0, float* __restrict__ dc0, const float* __restrict__ h0, const float* __restrict__ c0,
     const bf16x8* __restrict__ wpk, const int32_t* __restrict__ lens, u32* __restrict__ xch, int32_t* __restrict__ fault,
     int drop, int tune, int g0, int nclusters, int B, int T, int D, int H) {
-  using C = Cfg<G, CC>;
+  using C = Cfg<G, CC, U>;
   constexpr int KB = C::KB, NT = C::NT, NL = C::NL, BFW = C::BFW, BFW_A = C::BFW_A, BFW_REG = C::BFW_REG, BFW_L = C::BFW_L,
                 BKLD = C::BKLD;
+  constexpr int XB = C::XB, TPB = C::TPB, TPD = C::TPD, ND = C::ND, VPL = C::VPL, NRED = C::NRED;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* gS = reinterpret_cast<bf16_t*>(smem);                                                    // [2][16][BKLD]
   bf16x8* Wl = reinterpret_cast<bf16x8*>(smem + (size_t)2 * 16 * BKLD * 2);                        // [4][NT][BFW_L][64]
-  float* red = reinterpret_cast<float*>(smem + (size_t)2 * 16 * BKLD * 2 + (size_t)4 * NT * BFW_L * 1024);   // [5][XMEMBER]: the four waves' sums of remote partials, then this member's own
+  float* red = reinterpret_cast<float*>(smem + (size_t)2 * 16 * BKLD * 2 + (size_t)4 * NT * BFW_L * 1024);   // [NRED + 1][XB]: the sums of remote partials per (wave, block of the sweep), then this member's own
   __shared__ int s_local;
-  const int cluster = blockIdx.x & 7, c = blockIdx.x >> 3;
+  const int cluster = blockIdx.x % C::MAXCL, c = blockIdx.x / C::MAXCL;
   if (cluster >= nclusters) return;
   if (c == drop) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -616,11 +658,13 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
   }
   for (int i = tid; i < 2 * 16 * BKLD; i += 256) gS[i] = 0;
 
-  // ---- one (sample, unit) per thread: sample = tid >> 5, unit = tid & 31 of this member ------------------------
-  const int sl = tid >> 5, ul = tid & 31;
-  const int unit = UPM * c + ul;
+  // ---- one (sample, unit) per thread: sample = tid / U, unit = tid % U of this member (16-unit members: threads
+  // 128-255 have none) ---------------------------------------------------------------------------------------------
+  const bool active = tid < NS * U;
+  const int sl = (tid / U) & 7, ul = tid % U;
+  const int unit = U * c + ul;
   const int b = group * NS + sl;
-  const bool alive = b < B && unit < H;
+  const bool alive = active && b < B && unit < H;
   const int len = alive ? lens[b] : 0;
   const float inj_h = (alive && dh_n) ? dh_n[((int64_t)d * B + b) * H + unit] : 0.f;
   const float inj_c = (G == 4 && alive && dc_n) ? dc_n[((int64_t)d * B + b) * H + unit] : 0.f;
@@ -653,15 +697,17 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
   };
   fetch(inA, time_of(0));
   fetch(inB, time_of(1));
-  const int xdst = CC * XMEMBER, xcluster = CC * xdst, xslot = nclusters * xcluster;   // words (32-bit: scalar multiplies)
-  u32* xout = xch + cluster * xcluster + c * XMEMBER + 4 * lane;      // + dst * xdst
-  const u32* xin = xch + cluster * xcluster + c * xdst + 4 * lane;    // + src * XMEMBER
-  // where this thread's (sample sl, unit ul) sits in a block: lane kg * 16 + col, word 2 * tile half + row
-  const int rpos = ((((sl >> 1) & 1) * 2 + (sl >> 2)) * 16 + (ul & 15)) * 4 + (ul >> 4) * 2 + (sl & 1);
+  const int xdst = CC * XB, xcluster = CC * xdst, xslot = nclusters * xcluster;   // words (32-bit: scalar multiplies)
+  u32* xout = xch + cluster * xcluster + c * XB + VPL * lane;         // + dst * xdst
+  // gather item g = 256 i + tid of the CC * TPB 16-byte items addressed to this member: source member g / TPB
+  const int gw = tid % TPB, gj0 = tid / TPB;
+  const u32* xin = xch + cluster * xcluster + c * xdst + gj0 * XB + 4 * gw;    // + sweep * (256 / TPB) * XB
+  // where this thread's (sample sl, unit ul) sits in a block: lane kg * 16 + col, word 2 * (tile of the destination) + row
+  const int rpos = ((((sl >> 1) & 1) * 2 + (sl >> 2)) * 16 + (ul & 15)) * VPL + (ul >> 4) * 2 + (sl & 1);
   unsigned pend0 = 0;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
-    const int j = 4 * i + wave;
+    const int j = (256 / TPB) * i + gj0;
     if (j < CC && j != c) pend0 |= 1u << i;
   }
   int bad = 0;
@@ -714,29 +760,37 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
     u32* xo = xout + slot_off;
     const u32 tg = tag_of(s - 1);
 #pragma unroll
-    for (int m = 0; m < NL; ++m) {
+    for (int m = 0; m < ND; ++m) {
       const int dstm = wave + 4 * m;
-      float v[4];
+      float v[VPL];
 #pragma unroll
-      for (int th = 0; th < 2; ++th) {
+      for (int th = 0; th < TPD; ++th) {
         // v_permlane32_swap (gfx950) trades the upper half of one register for the lower half of another: with a[0] and
         // a[2] that leaves {a0.lo, a2.lo} and {a0.hi, a2.hi}, whose sum IS the fold — lanes 0-31 hold a[0] + the a[0] of
         // lane + 32, lanes 32-63 a[2] + the a[2] of lane - 32 — in two VALU instructions per kept value (rounds 2-3: four
         // ds_bpermute + four adds + two selects per tile through the LDS pipe, half of them for values nobody keeps)
-        const f32x4 a = acc[2 * m + th];
+        const f32x4 a = acc[TPD * m + th];
         v[2 * th] = fold32(a[0], a[2]);
         v[2 * th + 1] = fold32(a[1], a[3]);
       }
       if (dstm < CC) {
         if (dstm == c) {
-          *reinterpret_cast<float4*>(red + 4 * XMEMBER + 4 * lane) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+          for (int e = 0; e < VPL; ++e) red[NRED * XB + VPL * lane + e] = v[e];
         } else {
-          const u32x4 w = {xword(v[0], tg), xword(v[1], tg), xword(v[2], tg), xword(v[3], tg)};
-          // one 16-byte store per lane: the wave writes the destination's whole 1 KB block.  Each WORD is valid on
-          // its own, so it does not matter whether the 16 bytes land together.
+          // one store per lane: the wave writes the destination's whole block.  Each WORD is valid on its own, so it
+          // does not matter whether the bytes land together.
           u32* p = xo + dstm * xdst;
-          if (local) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(w) : "memory");   // workgroup scope
-          else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");   // agent scope
+          if constexpr (VPL == 4) {
+            const u32x4 w = {xword(v[0], tg), xword(v[1], tg), xword(v[2], tg), xword(v[3], tg)};
+            if (local) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(w) : "memory");   // workgroup scope
+            else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");   // agent scope
+          } else {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 w = {xword(v[0], tg), xword(v[1], tg)};
+            if (local) asm volatile("global_store_dwordx2 %0, %1, off sc0" ::"v"(p), "v"(w) : "memory");
+            else asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+          }
         }
       }
     }
@@ -747,7 +801,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       g[i] = (u32x4){0u, 0u, 0u, 0u};
-      if (((pend0 >> i) & 1u) && !bad) g[i] = peek4(xp + (4 * i + wave) * XMEMBER);   // (see the forward kernel)
+      if (((pend0 >> i) & 1u) && !bad) g[i] = peek4(xp + i * (256 / TPB) * XB);   // (see the forward kernel)
     }
     unsigned pend = pend0;
     for (int round = 0; pend && !bad; ++round) {
@@ -769,9 +823,9 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
       for (int w = 0; w < ((tune >> 8) & 0xff); ++w) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
       for (int i = 0; i < NL; ++i)
-        if ((pend >> i) & 1u) g[i] = peek4(xp + (4 * i + wave) * XMEMBER);
+        if ((pend >> i) & 1u) g[i] = peek4(xp + i * (256 / TPB) * XB);
     }
-    {   // this wave's sum over its source members, in FIXED order; absent sweeps hold zeros
+    {   // this thread's sum over the source members of its sweeps, in FIXED order; absent sweeps hold zeros
       float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
       if (!bad) {
 #pragma unroll
@@ -784,12 +838,12 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
           }
         }
       }
-      *reinterpret_cast<float4*>(red + wave * XMEMBER + 4 * lane) = make_float4(p0, p1, p2, p3);
+      *reinterpret_cast<float4*>(red + gj0 * XB + 4 * gw) = make_float4(p0, p1, p2, p3);
     }
     lr_lds_barrier();     // `red` complete
-    float prod = red[4 * XMEMBER + rpos];
+    float prod = red[NRED * XB + rpos];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) prod += red[w * XMEMBER + rpos];
+    for (int w = 0; w < NRED; ++w) prod += red[w * XB + rpos];
     return prod;
   };
 
@@ -809,7 +863,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
     const bool is_last = d == 0 ? (t == len - 1) : (t == 0);   // where the final state was read
     if (is_last) dh += inj_h;
     const bool live = alive && t < len;
-    float kv[KB], dgv[4];
+    float kv[G], dgv[4];
     if (G == 3) {
       // rnn_bwd_step_kernel<3>
       dh += car;   // dh_{t+1} * z_{t+1}
@@ -848,15 +902,17 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
       kv[0] = di;
       kv[1] = df;
       kv[2] = dg_;
-      kv[KB - 1] = do_;
+      kv[G - 1] = do_;
     }
     fetch(in, tnext);
+    if (active) {
 #pragma unroll
-    for (int k = 0; k < KB; ++k) {
-      bf16_t hi, lo;
-      split_bf16(kv[k], hi, lo);
-      gnxt[sl * BKLD + k * UPM + ul] = hi;
-      gnxt[(sl + 8) * BKLD + k * UPM + ul] = lo;
+      for (int k = 0; k < G; ++k) {   // gate k's entry of this (sample, unit): k step (k U) / 32 of the member's dG
+        bf16_t hi, lo;
+        split_bf16(kv[k], hi, lo);
+        gnxt[sl * BKLD + k * U + ul] = hi;
+        gnxt[(sl + 8) * BKLD + k * U + ul] = lo;
+      }
     }
     if (alive) {
       float* dgo = dG + (((int64_t)b * T + t) * D + d) * (int64_t)(4 * H) + unit;
@@ -876,20 +932,21 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-size_t xch_words(int CC, int nclusters, int backward) {
-  const size_t per = backward ? (size_t)CC * CC * XMEMBER : (size_t)CC * XMEMBER;
+size_t xch_words(int CC, int U, int nclusters, int backward) {
+  const size_t xb = (size_t)NS * U;
+  const size_t per = backward ? (size_t)CC * CC * xb : (size_t)CC * xb;
   return (size_t)2 * nclusters * per + (size_t)nclusters * CC;
 }
 
 // words of the first launch's exchange area
-inline int first_xch_words(int CC, int B, int D, int backward) {
-  const int groups = (B + NS - 1) / NS, gchunk = MAX_CLUSTERS / D;
-  return (int)xch_words(CC, (groups < gchunk ? groups : gchunk) * D, backward);
+inline int first_xch_words(int CC, int U, int maxcl, int B, int D, int backward) {
+  const int groups = (B + NS - 1) / NS, gchunk = maxcl / D;
+  return (int)xch_words(CC, U, (groups < gchunk ? groups : gchunk) * D, backward);
 }
 
 // the layer's prologue: W_hh -> fragments, exchange words of the first launch cleared, biases folded (b_ih may be
 // NULL: nothing to fold)
-template <int G, int CC>
+template <int G, int CC, int U>
 int fwd_prologue(const float* const* w_hh, const float* const* b_ih, const float* const* b_hh, float* bias_out, void* wpack,
                  void* xch, int B, int D, int H, hipStream_t stream) {
   FoldPtrs fold;
@@ -898,45 +955,45 @@ int fwd_prologue(const float* const* w_hh, const float* const* b_ih, const float
     fold.b_hh[d] = b_hh ? b_hh[d < D ? d : 0] : nullptr;
   }
   fold.out = b_ih ? bias_out : nullptr;
-  LR_LAUNCH((rnnc_pack_fwd_kernel<G, CC>), dim3(1024), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D, H,
-            (u32*)xch, first_xch_words(CC, B, D, 0), fold);
+  LR_LAUNCH((rnnc_pack_fwd_kernel<G, CC, U>), dim3(1024), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D, H,
+            (u32*)xch, first_xch_words(CC, U, Cfg<G, CC, U>::MAXCL, B, D, 0), fold);
   return lr_launch_status();
 }
 
-template <int G, int CC>
+template <int G, int CC, int U>
 int fwd_launch(float* gates, float* extra, float* y, const float* const* w_hh, const float* const* b_hh, const float* h0,
                const float* c0, const int32_t* lens, void* wpack, void* xch, int B, int T, int D, int H,
                hipStream_t stream, int prologue_done) {
-  using C = Cfg<G, CC>;
+  using C = Cfg<G, CC, U>;
   static bool attr_set = false;
   lr_clear_error();
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)rnnc_fwd_kernel<G, CC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)rnnc_fwd_kernel<G, CC, U>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)C::FWD_LDS) != hipSuccess)
       return LR_ERR_LAUNCH;
     attr_set = true;
   }
   int st = LR_OK;
   if (!prologue_done) {
-    st = fwd_prologue<G, CC>(w_hh, nullptr, nullptr, nullptr, wpack, xch, B, D, H, stream);
+    st = fwd_prologue<G, CC, U>(w_hh, nullptr, nullptr, nullptr, wpack, xch, B, D, H, stream);
     if (st != LR_OK) return st;
   }
   int32_t* fault = lr_fault_words();
   const int drop = lr_debug_drop_member_value();
   const int tune = lr_debug_tune_value(0);
-  const int groups = (B + NS - 1) / NS, gchunk = MAX_CLUSTERS / D;   // sample groups per launch
+  const int groups = (B + NS - 1) / NS, gchunk = C::MAXCL / D;   // sample groups per launch
   for (int g0 = 0; g0 < groups; g0 += gchunk) {
     const int ng = groups - g0 < gchunk ? groups - g0 : gchunk, nclusters = ng * D;
     // (the first launch's words were cleared by the prologue)
-    if (g0 > 0 && hipMemsetAsync(xch, 0, xch_words(CC, nclusters, 0) * sizeof(u32), stream) != hipSuccess) return LR_ERR_LAUNCH;
-    const dim3 grid(8 * CC);
+    if (g0 > 0 && hipMemsetAsync(xch, 0, xch_words(CC, U, nclusters, 0) * sizeof(u32), stream) != hipSuccess) return LR_ERR_LAUNCH;
+    const dim3 grid(C::MAXCL * CC);
     hipEvent_t e0, e1;
     if (g0 == 0 && lr_prof_next(LR_PROF_RNN_FWD, &e0, &e1))
-      hipExtLaunchKernelGGL((rnnc_fwd_kernel<G, CC>), grid, dim3(256), C::FWD_LDS, stream, e0, e1, 0, gates, extra, y,
+      hipExtLaunchKernelGGL((rnnc_fwd_kernel<G, CC, U>), grid, dim3(256), C::FWD_LDS, stream, e0, e1, 0, gates, extra, y,
                             (const bf16x8*)wpack, b_hh[0], b_hh[D - 1], h0, c0, lens, (u32*)xch, fault, drop, tune, g0,
                             nclusters, B, T, D, H);
     else
-      hipLaunchKernelGGL((rnnc_fwd_kernel<G, CC>), grid, dim3(256), C::FWD_LDS, stream, gates, extra, y,
+      hipLaunchKernelGGL((rnnc_fwd_kernel<G, CC, U>), grid, dim3(256), C::FWD_LDS, stream, gates, extra, y,
                          (const bf16x8*)wpack, b_hh[0], b_hh[D - 1], h0, c0, lens, (u32*)xch, fault, drop, tune, g0, nclusters,
                          B, T, D, H);
     st = lr_launch_status();
@@ -945,38 +1002,38 @@ int fwd_launch(float* gates, float* extra, float* y, const float* const* w_hh, c
   return LR_OK;
 }
 
-template <int G, int CC>
+template <int G, int CC, int U>
 int bwd_launch(const float* gates, const float* extra, const float* y, const float* dy, const float* dh_n, const float* dc_n,
                float* dG, float* dh0, float* dc0, const float* h0, const float* c0, const float* const* w_hh,
                const int32_t* lens, void* wpack, void* xch, int B, int T, int D, int H, hipStream_t stream) {
-  using C = Cfg<G, CC>;
+  using C = Cfg<G, CC, U>;
   static bool attr_set = false;
   lr_clear_error();
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)rnnc_bwd_kernel<G, CC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)rnnc_bwd_kernel<G, CC, U>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)C::BWD_LDS) != hipSuccess)
       return LR_ERR_LAUNCH;
     attr_set = true;
   }
-  LR_LAUNCH((rnnc_pack_bwd_kernel<G, CC>), dim3(1024), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D, H,
-            (u32*)xch, first_xch_words(CC, B, D, 1));
+  LR_LAUNCH((rnnc_pack_bwd_kernel<G, CC, U>), dim3(1024), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D, H,
+            (u32*)xch, first_xch_words(CC, U, C::MAXCL, B, D, 1));
   int st = lr_launch_status();
   if (st != LR_OK) return st;
   int32_t* fault = lr_fault_words();
   const int drop = lr_debug_drop_member_value();
   const int tune = lr_debug_tune_value(1);
-  const int groups = (B + NS - 1) / NS, gchunk = MAX_CLUSTERS / D;
+  const int groups = (B + NS - 1) / NS, gchunk = C::MAXCL / D;
   for (int g0 = 0; g0 < groups; g0 += gchunk) {
     const int ng = groups - g0 < gchunk ? groups - g0 : gchunk, nclusters = ng * D;
-    if (g0 > 0 && hipMemsetAsync(xch, 0, xch_words(CC, nclusters, 1) * sizeof(u32), stream) != hipSuccess) return LR_ERR_LAUNCH;
-    const dim3 grid(8 * CC);
+    if (g0 > 0 && hipMemsetAsync(xch, 0, xch_words(CC, U, nclusters, 1) * sizeof(u32), stream) != hipSuccess) return LR_ERR_LAUNCH;
+    const dim3 grid(C::MAXCL * CC);
     hipEvent_t e0, e1;
     if (g0 == 0 && lr_prof_next(LR_PROF_RNN_BWD, &e0, &e1))
-      hipExtLaunchKernelGGL((rnnc_bwd_kernel<G, CC>), grid, dim3(256), C::BWD_LDS, stream, e0, e1, 0, gates, extra, y, dy,
+      hipExtLaunchKernelGGL((rnnc_bwd_kernel<G, CC, U>), grid, dim3(256), C::BWD_LDS, stream, e0, e1, 0, gates, extra, y, dy,
                             dh_n, dc_n, dG, dh0, dc0, h0, c0, (const bf16x8*)wpack, lens, (u32*)xch, fault, drop, tune, g0,
                             nclusters, B, T, D, H);
     else
-      hipLaunchKernelGGL((rnnc_bwd_kernel<G, CC>), grid, dim3(256), C::BWD_LDS, stream, gates, extra, y, dy, dh_n, dc_n, dG,
+      hipLaunchKernelGGL((rnnc_bwd_kernel<G, CC, U>), grid, dim3(256), C::BWD_LDS, stream, gates, extra, y, dy, dh_n, dc_n, dG,
                          dh0, dc0, h0, c0, (const bf16x8*)wpack, lens, (u32*)xch, fault, drop, tune, g0, nclusters, B, T, D,
                          H);
     st = lr_launch_status();
@@ -985,60 +1042,102 @@ int bwd_launch(const float* gates, const float* extra, const float* y, const flo
   return LR_OK;
 }
 
-// the instantiated (gates, members) pairs: members = ceil(H / 32) — EVERY hidden size the kernels' storage holds:
-//   GRU   1 .. 27 members  H <= 864   (GRU-800: config/train/micro; the decoder GRU-512 behind a BiGRU-256)
-//   LSTM  1 .. 24 members  H <= 768   (LSTM-700: config/defaults.txt; LSTM-512: config/train/attn/attention_type;
-//                                      LSTM-768: config/archive/experiments/ecd)
-// What stops there is the member's slice of W_hh (G x 32 rows x HP columns x hi + lo planes), which must stay in the
-// registers and LDS of ONE compute unit: 28 GRU members would take 164 KB of LDS for the forward fragments, 25 LSTM
-// members 186 KB for the backward ones (the backward keeps 60 fragments per wave in AGPRs, 14 in VGPRs — 198 of 256
-// VGPRs at 24 members —, the rest in LDS).  Larger layers (LSTM-800, the 1024 / 1400 / 1536-unit decoders behind
-// BiLSTM-512 / 700 / 768 encoders, better_model.py:134-148) would need 16-unit members on clusters that span XCDs:
-// they run the step kernels (lr_rnn.hip), and lipreading_amd.encoder says so once.
+// the instantiated (gates, members, units per member) triples — EVERY hidden size the kernels' storage holds:
+//   32-unit members (a cluster = ceil(H / 32) CUs of one XCD)
+//     GRU   1 .. 27 members  H <= 864   (GRU-800: config/train/micro; the decoder GRU-512 behind a BiGRU-256)
+//     LSTM  1 .. 24 members  H <= 768   (LSTM-700: config/defaults.txt; LSTM-512: config/train/attn/attention_type;
+//                                        LSTM-768: config/archive/experiments/ecd)
+//   What stops there is the member's slice of W_hh (G x 32 rows x HP columns x hi + lo planes), which must stay in the
+//   registers and LDS of ONE compute unit: 28 GRU members would take 164 KB of LDS for the forward fragments, 25 LSTM
+//   members 186 KB for the backward ones (the backward keeps 60 fragments per wave in AGPRs, 14 in VGPRs — 198 of 256
+//   VGPRs at 24 members —, the rest in LDS).
+//   16-unit members (round 4; an even number of them, 50 .. 72: a cluster spans two or more XCDs, agent-scope exchange)
+//     LSTM  768 < H <= 1152  (LSTM-800; LSTM-1024 = the decoder of config/train/attn/attention_type's BiLSTM-512,
+//                             better_model.py:134-148: with the reference's batch of 4 ONE cluster of 64 CUs)
+//     GRU   864 < H <= 1152
+//   Larger layers (the 1400 / 1536-unit decoders behind BiLSTM-700 / 768 encoders) exceed a CU's storage with 16-unit
+//   members too (the backward's accumulators and VGPR-resident fragments): they run the step kernels (lr_rnn.hip), and
+//   lipreading_amd.encoder / attention_decoder say so once.
 #define LR_CLUSTER_CC_COMMON(X, g) \
-  X(g, 1) X(g, 2) X(g, 3) X(g, 4) X(g, 5) X(g, 6) X(g, 7) X(g, 8) X(g, 9) X(g, 10) X(g, 11) X(g, 12) X(g, 13) X(g, 14) \
-  X(g, 15) X(g, 16) X(g, 17) X(g, 18) X(g, 19) X(g, 20) X(g, 21) X(g, 22) X(g, 23) X(g, 24)
-#define LR_CLUSTER_SHAPES(X) LR_CLUSTER_CC_COMMON(X, 3) X(3, 25) X(3, 26) X(3, 27) LR_CLUSTER_CC_COMMON(X, 4)
-#define X(g, c)                                                                                                      \
-  static_assert(Cfg<g, c>::FWD_LDS <= 160 * 1024 && Cfg<g, c>::BWD_LDS <= 160 * 1024, "a member's fragments fit one CU");
+  X(g, 1, 32) X(g, 2, 32) X(g, 3, 32) X(g, 4, 32) X(g, 5, 32) X(g, 6, 32) X(g, 7, 32) X(g, 8, 32) X(g, 9, 32) X(g, 10, 32) \
+  X(g, 11, 32) X(g, 12, 32) X(g, 13, 32) X(g, 14, 32) X(g, 15, 32) X(g, 16, 32) X(g, 17, 32) X(g, 18, 32) X(g, 19, 32)     \
+  X(g, 20, 32) X(g, 21, 32) X(g, 22, 32) X(g, 23, 32) X(g, 24, 32)
+#define LR_CLUSTER_CC16_COMMON(X, g) \
+  X(g, 56, 16) X(g, 58, 16) X(g, 60, 16) X(g, 62, 16) X(g, 64, 16) X(g, 66, 16) X(g, 68, 16) X(g, 70, 16) X(g, 72, 16)
+#define LR_CLUSTER_SHAPES(X)                                                                                     \
+  LR_CLUSTER_CC_COMMON(X, 3) X(3, 25, 32) X(3, 26, 32) X(3, 27, 32) LR_CLUSTER_CC_COMMON(X, 4)                    \
+  LR_CLUSTER_CC16_COMMON(X, 3) X(4, 50, 16) X(4, 52, 16) X(4, 54, 16) LR_CLUSTER_CC16_COMMON(X, 4)
+#define X(g, c, u)                                                                                               \
+  static_assert(Cfg<g, c, u>::FWD_LDS <= 160 * 1024 && Cfg<g, c, u>::BWD_LDS <= 160 * 1024, "a member's fragments fit one CU");
 LR_CLUSTER_SHAPES(X)
 #undef X
+
+// (members, units per member) of a hidden size; false: no cluster recurrence
+bool resolve_shape(int G, int H, int* cc, int* u) {
+  const int c32 = (H + 31) / 32;
+  if (c32 <= (G == 3 ? 27 : 24)) {
+    *cc = c32;
+    *u = 32;
+    return true;
+  }
+  int c16 = (H + 15) / 16;
+  c16 += c16 & 1;
+  if (c16 >= (G == 3 ? 56 : 50) && c16 <= 72) {
+    *cc = c16;
+    *u = 16;
+    return true;
+  }
+  return false;
+}
 
 }  // namespace
 
 int lr_rnn_cluster_supported(int G, int B, int H) {
-  if (B < 1 || H < 1 || lr_debug_cluster_disabled()) return 0;
-  const int cc = (H + UPM - 1) / UPM;
-  bool shape = false;
-#define X(g, c) shape = shape || (G == g && cc == c);
-  LR_CLUSTER_SHAPES(X)
-#undef X
-  // all 8 * CC workgroups of a launch must be resident together, one per compute unit
-  return shape && lr_device_cus() >= 8 * cc ? 1 : 0;
+  if (B < 1 || H < 1 || (G != 3 && G != 4) || lr_debug_cluster_disabled()) return 0;
+  int cc, u;
+  if (!resolve_shape(G, H, &cc, &u)) return 0;
+  // all MAXCL * CC workgroups of a launch must be resident together, one per compute unit
+  const int maxcl = cc <= 32 ? 8 : (cc <= 64 ? 4 : 2);
+  return lr_device_cus() >= maxcl * cc ? 1 : 0;
 }
 
 size_t lr_rnn_cluster_pack_bytes(int G, int H, int D, int backward) {
-  const int cc = (H + UPM - 1) / UPM;
-#define X(g, c) if (G == g && cc == c) return (size_t)D * (backward ? Cfg<g, c>::BWD_PACK : Cfg<g, c>::FWD_PACK);
+  int cc, u;
+  if (!resolve_shape(G, H, &cc, &u)) return 0;
+#define X(g, c, uu) \
+  if (G == g && cc == c && u == uu) return (size_t)D * (backward ? Cfg<g, c, uu>::BWD_PACK : Cfg<g, c, uu>::FWD_PACK);
   LR_CLUSTER_SHAPES(X)
 #undef X
   return 0;
 }
 
 size_t lr_rnn_cluster_xch_bytes(int B, int H, int D, int backward) {
-  const int cc = (H + UPM - 1) / UPM;
+  int cc, u;
+  // (the exchange area does not depend on the gate count: resolve as the LSTM, whose 32-unit range is the smaller)
+  if (!resolve_shape(4, H, &cc, &u) && !resolve_shape(3, H, &cc, &u)) return 0;
+  const int maxcl = cc <= 32 ? 8 : (cc <= 64 ? 4 : 2);
   int clusters = (B + NS - 1) / NS * D;
-  if (clusters > MAX_CLUSTERS) clusters = MAX_CLUSTERS;
-  return xch_words(cc, clusters, backward) * sizeof(u32);
+  if (clusters > maxcl) clusters = maxcl;
+  size_t w = xch_words(cc, u, clusters, backward);
+  int cc3, u3;
+  if (resolve_shape(3, H, &cc3, &u3) && (cc3 != cc || u3 != u)) {   // a GRU of this size takes the other form: the larger
+    const int m3 = cc3 <= 32 ? 8 : (cc3 <= 64 ? 4 : 2);
+    int cl3 = (B + NS - 1) / NS * D;
+    if (cl3 > m3) cl3 = m3;
+    const size_t w3 = xch_words(cc3, u3, cl3, backward);
+    if (w3 > w) w = w3;
+  }
+  return w * sizeof(u32);
 }
 
 int lr_rnn_cluster_forward(int G, float* gates, float* extra, float* y, const float* const* w_hh, const float* const* b_hh,
                            const float* h0, const float* c0, const int32_t* lens, void* wpack, void* xch, int B, int T,
                            int D, int H, hipStream_t stream, int prologue_done) {
-  const int cc = (H + UPM - 1) / UPM;
-#define X(g, c)          \
-  if (G == g && cc == c) \
-    return fwd_launch<g, c>(gates, extra, y, w_hh, b_hh, h0, c0, lens, wpack, xch, B, T, D, H, stream, prologue_done);
+  int cc, u;
+  if (!resolve_shape(G, H, &cc, &u)) return LR_ERR_UNSUPPORTED;
+#define X(g, c, uu)                 \
+  if (G == g && cc == c && u == uu) \
+    return fwd_launch<g, c, uu>(gates, extra, y, w_hh, b_hh, h0, c0, lens, wpack, xch, B, T, D, H, stream, prologue_done);
   LR_CLUSTER_SHAPES(X)
 #undef X
   return LR_ERR_UNSUPPORTED;
@@ -1046,10 +1145,11 @@ int lr_rnn_cluster_forward(int G, float* gates, float* extra, float* y, const fl
 
 int lr_rnn_cluster_prologue(int G, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
                             float* bias_out, void* wpack, void* xch, int B, int D, int H, hipStream_t stream) {
-  const int cc = (H + UPM - 1) / UPM;
+  int cc, u;
   lr_clear_error();
-#define X(g, c) \
-  if (G == g && cc == c) return fwd_prologue<g, c>(w_hh, b_ih, b_hh, bias_out, wpack, xch, B, D, H, stream);
+  if (!resolve_shape(G, H, &cc, &u)) return LR_ERR_UNSUPPORTED;
+#define X(g, c, uu) \
+  if (G == g && cc == c && u == uu) return fwd_prologue<g, c, uu>(w_hh, b_ih, b_hh, bias_out, wpack, xch, B, D, H, stream);
   LR_CLUSTER_SHAPES(X)
 #undef X
   return LR_ERR_UNSUPPORTED;
@@ -1059,11 +1159,12 @@ int lr_rnn_cluster_backward(int G, const float* gates, const float* extra, const
                             const float* dh_n, const float* dc_n, float* dG, float* dh0, float* dc0, const float* h0,
                             const float* c0, const float* const* w_hh, const int32_t* lens, void* wpack, void* xch, int B,
                             int T, int D, int H, hipStream_t stream) {
-  const int cc = (H + UPM - 1) / UPM;
-#define X(g, c)                                                                                                       \
-  if (G == g && cc == c)                                                                                              \
-    return bwd_launch<g, c>(gates, extra, y, dy, dh_n, dc_n, dG, dh0, dc0, h0, c0, w_hh, lens, wpack, xch, B, T, D, H, \
-                            stream);
+  int cc, u;
+  if (!resolve_shape(G, H, &cc, &u)) return LR_ERR_UNSUPPORTED;
+#define X(g, c, uu)                                                                                                      \
+  if (G == g && cc == c && u == uu)                                                                                      \
+    return bwd_launch<g, c, uu>(gates, extra, y, dy, dh_n, dc_n, dG, dh0, dc0, h0, c0, w_hh, lens, wpack, xch, B, T, D, H, \
+                                stream);
   LR_CLUSTER_SHAPES(X)
 #undef X
   return LR_ERR_UNSUPPORTED;

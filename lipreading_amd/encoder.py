@@ -87,8 +87,8 @@ def _note_step_kernel_fallback(rnn_type, H):
   _fallback_noted.add((rnn_type, H))
   import warnings
   warnings.warn("lipreading_amd: no one-launch recurrence for %s-%d (a member's slice of W_hh must fit one compute unit: "
-                "GRU up to 864 hidden units, LSTM up to 768, and the device needs 8 * ceil(H / 32) compute units); this "
-                "layer runs one launch per time step (3-5x slower per pass)" % (rnn_type, H), stacklevel=3)
+                "hidden sizes up to 1152, multiples of 4, on a device with enough compute units for a launch's clusters); "
+                "this layer runs one launch per time step (2-5x slower per pass)" % (rnn_type, H), stacklevel=3)
 
 
 class _RNNLayerFunction(torch.autograd.Function):
@@ -337,7 +337,7 @@ class VideoEncoder(nn.Module):
     #   'f32'    one launch per time step, exact fp32 MFMA — every shape
     #   'split'  ONE launch per layer pass, fp32-faithful (W_hh and the state as bf16 hi + lo planes, ~1e-6
     #            of the fp32 product): a cluster of ceil(H / 32) CUs per (direction, 8 samples) (lr_rnn_cluster.hip) —
-    #            GRU with H <= 864, LSTM with H <= 768; larger layers as 'f32' (announced once)
+    #            H <= 1152 (16-unit members on larger clusters past 864 / 768); larger layers as 'f32' (announced once)
     #   'bf16'   one launch per pass with single-plane bf16 recurrent operands (~1e-3): the build-defined
     #            pixel regime's choice (frontend.PixelLipReader sets it); where unsupported as 'f32'
     #   'auto'   (default) same as 'split': reference-faithful numerics at the one-launch speed
@@ -399,8 +399,8 @@ class VideoEncoder(nn.Module):
       if self.recurrence == 'bf16' and _C.lib().lr_rnn_persistent_supported(mode, B, max_len, x.shape[2], H, D):
         lmode |= _RECUR_BF16
       else:
-        # lr_rnn_pair_supported: 2 = clusters of ceil(H / 32) CUs (GRU H <= 864, LSTM H <= 768), 1 = GRU-256 on CU
-        # pairs (a device too small for a cluster launch); 0 = step kernels
+        # lr_rnn_pair_supported: 2 = clusters of ceil(H / 32) (or, past 864 / 768 units, ceil(H / 16)) CUs, H <= 1152;
+        # 1 = GRU-256 on CU pairs (a device too small for a cluster launch); 0 = step kernels
         if self.recurrence in ('auto', 'split'):
           if _C.lib().lr_rnn_pair_supported(mode, B, max_len, x.shape[2], H, D):
             lmode |= _RECUR_SPLIT

@@ -477,12 +477,19 @@ CLUSTER_CASES = [("LSTM", 768, 32, 75, True, None, 1), ("LSTM", 768, 37, 20, Tru
                  ("LSTM", 32, 17, 9, True, "ragged", 1), ("LSTM", 12, 3, 5, True, "ragged", 2),
                  ("GRU", 40, 11, 6, True, "ragged", 1), ("GRU", 96, 32, 20, False, None, 1), ("GRU", 64, 32, 75, True, None, 2),
                  ("GRU", 864, 32, 30, True, "ragged", 1), ("GRU", 832, 10, 6, False, "ragged", 1),
-                 ("GRU", 160, 8, 75, True, None, 1), ("LSTM", 200, 5, 11, True, "ragged", 1)]
+                 ("GRU", 160, 8, 75, True, None, 1), ("LSTM", 200, 5, 11, True, "ragged", 1),
+                 # 16-unit members on clusters of 50 .. 72 CUs that span XCDs (768 / 864 < H <= 1152)
+                 ("LSTM", 1024, 32, 31, False, None, 1), ("LSTM", 1024, 4, 31, False, "ragged", 1),
+                 ("LSTM", 800, 32, 40, True, "ragged", 1), ("LSTM", 800, 11, 9, False, "ragged", 2),
+                 ("GRU", 1024, 13, 12, False, "ragged", 1), ("GRU", 896, 32, 20, True, None, 1),
+                 ("LSTM", 1152, 9, 6, False, "ragged", 1), ("LSTM", 788, 20, 7, True, "ragged", 1),
+                 ("GRU", 1100, 40, 5, False, "ragged", 1)]
 
 
 def test_one_launch_recurrence_covers_every_hidden_size_its_storage_holds(dev):
-  """lr_rnn_pair_supported: GRU up to 27 members (H <= 864), LSTM up to 24 (H <= 768) — any H, not an enumerated list
-  (round 3 instantiated five sizes); beyond that the step kernels run and VideoEncoder says so ONCE."""
+  """lr_rnn_pair_supported: any H up to 1152 (multiples of 4), not an enumerated list (round 3 instantiated five sizes):
+  32-unit members up to 27 (GRU) / 24 (LSTM) of them, 16-unit members beyond; past 1152 the step kernels run and
+  VideoEncoder says so ONCE."""
   import warnings
   from lipreading_amd import _C, encoder as E
   from lipreading_amd.data import default_char2idx
@@ -491,9 +498,11 @@ def test_one_launch_recurrence_covers_every_hidden_size_its_storage_holds(dev):
     assert L.lr_rnn_pair_supported(1, 32, 75, 204, H, 2) == 2, H
   for H in (4, 128, 256, 512, 800, 836, 864):
     assert L.lr_rnn_pair_supported(0, 32, 75, 204, H, 2) == 2, H
-  for mode, H in ((1, 772), (1, 800), (1, 1024), (1, 1400), (1, 1536), (0, 868), (0, 1024), (1, 30)):
+  for H in (772, 800, 1024, 1100, 1152):
+    assert L.lr_rnn_pair_supported(1, 32, 75, 204, H, 1) == 2 and L.lr_rnn_pair_supported(0, 32, 75, 204, max(H, 868), 1) == 2, H
+  for mode, H in ((1, 1156), (1, 1400), (1, 1536), (0, 1156), (0, 2048), (1, 30)):
     assert L.lr_rnn_pair_supported(mode, 32, 75, 204, H, 1) == 0, (mode, H)
-  enc = E.VideoEncoder(16, 800, rnn_type='LSTM', bidirectional=False, enable_ctc=True, vocab_size=64,
+  enc = E.VideoEncoder(16, 1400, rnn_type='LSTM', bidirectional=False, enable_ctc=True, vocab_size=64,
                        char2idx=default_char2idx()).to(dev)
   x = torch.randn(2, 3, 16, 1, device=dev)
   E._fallback_noted.clear()
@@ -502,7 +511,7 @@ def test_one_launch_recurrence_covers_every_hidden_size_its_storage_holds(dev):
     enc(x, torch.tensor([3, 3]), max_len=3)
     enc(x, torch.tensor([3, 3]), max_len=3)
   notes = [str(m.message) for m in w if "one-launch recurrence" in str(m.message)]
-  assert len(notes) == 1 and "LSTM-800" in notes[0], notes
+  assert len(notes) == 1 and "LSTM-1400" in notes[0], notes
 
 
 @pytest.mark.parametrize("rnn_type,H,B,T,bi,lens,layers", CLUSTER_CASES)
