@@ -898,7 +898,8 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
                           " -> Linear(%d,65) + CTC 'mean' (L=30+EOS)" % (D * H) if enc.enable_ctc else " (enable_ctc False)",
                           rnn_type, D * H, args.char_dim, args.attention))
     dec_kind = L.lr_rnn_pair_supported({"GRU": 0, "LSTM": 1, "RNN": 2}[rnn_type], B, LABEL_LEN + 1, args.char_dim + D * H, D * H, 1)
-    res["decoder_recurrence"] = ("one launch per loop pass (cluster of %d CUs per 8 samples)" % ((D * H + 31) // 32) if dec_kind == 2
+    dec_members = (D * H + 31) // 32 if D * H <= (864 if rnn_type == "GRU" else 768) else (D * H + 15) // 16 // 2 * 2 + ((D * H + 15) // 16 % 2) * 2
+    res["decoder_recurrence"] = ("one launch per loop pass (cluster of %d CUs per 8 samples)" % dec_members if dec_kind == 2
                                  else "one launch per decoder step (no one-launch kernels for %s-%d)" % (rnn_type, D * H))
   else:
     res["workload"] = ("regime R (reference-faithful): landmarks (B=%d,T=75,68,3) f32 -> %d-layer Bi%s-%d (%s) -> "
