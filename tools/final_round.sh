@@ -1,8 +1,8 @@
 #!/usr/bin/env bash
 # One GPU-box visit at the end of a round: smoke(), the whole -m gpu suite, then the round's artefacts
-# (tools/refresh_profiles.sh).   usage: gpurun --timeout 3000 -- 'bash tools/final_round.sh r03'
+# (tools/refresh_profiles.sh).   usage: gpurun --timeout 3000 -- 'bash tools/final_round.sh r04'
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out
 mkdir -p $OUT
 timeout 300 python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' > $OUT/${TAG}_smoke.log 2>&1

@@ -15,7 +15,7 @@
 # PMC passes never share a run with trace domains other than the kernel trace rocprofv3 adds itself.
 set -u
 R=$PWD
-TAG=${1:-r03}
+TAG=${1:-r04}
 ONLY=${2:-all}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
