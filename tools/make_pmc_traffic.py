@@ -24,8 +24,9 @@ RECURRENT = {"rnn_fwd_step_kernel": "rnn_fwd_step_kernel", "rnn_bwd_step_kernel"
 for _g, _cc in [(3, c) for c in range(1, 28)] + [(4, c) for c in range(1, 25)]:
   for _w in ("fwd", "bwd"):
     # (the profiler leaves some of these names mangled: both spellings)
-    RECURRENT["rnnc_%s_kernel<%d,%d>" % (_w, _g, _cc)] = ("rnnc_%s_kernel<%d, %d>" % (_w, _g, _cc),
-                                                          "rnnc_%s_kernelILi%dELi%dE" % (_w, _g, _cc))
+    # (32-unit members; third template argument = units per member)
+    RECURRENT["rnnc_%s_kernel<%d,%d>" % (_w, _g, _cc)] = ("rnnc_%s_kernel<%d, %d, 32>" % (_w, _g, _cc),
+                                                          "rnnc_%s_kernelILi%dELi%dELi32E" % (_w, _g, _cc))
 MODELS = ("gru256", "lstm768", "lstm700", "lstm512", "gru800")
 
 
