@@ -23,9 +23,10 @@ export TMPDIR=/tmp
 
 kt() {   # name, bench args...
   local name=$1; shift
-  # (per-kernel statistics with the conv backward on one stream, as bench.py's roofline leg: the default step runs a
-  # layer's weight gradient beside its data gradient, and two kernels sharing the chip have no durations of their own)
-  (cd /tmp && LIPREADING_CONV_WGRAD_SIDE=0 rocprofv3 --kernel-trace --stats -d "$OUT/kt_$name" -o kt -- \
+  # (per-kernel statistics with EVERY side stream off, as bench.py's roofline leg: the default step runs a layer's weight
+  # gradient beside its data gradient and the recurrent layers' weight-gradient GEMMs beside the conv backward, and two
+  # kernels sharing the chip have no durations of their own)
+  (cd /tmp && LIPREADING_CONV_WGRAD_SIDE=0 LIPREADING_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --stats -d "$OUT/kt_$name" -o kt -- \
      python "$R/bench.py" "$@" --no-graph --steps 15 --warmup 2 --repeats 1 --no-cpu-baseline > /dev/null 2>&1)
   python tools/rocpd_summary.py "$(find "$OUT/kt_$name" -name '*.db' | head -1)" 60 > "$OUT/${TAG}_${name}_kernel_stats.txt"
   rm -rf "$OUT/kt_$name"
@@ -42,7 +43,7 @@ pmc() {   # name, counter list, filters..., -- bench args
   local filters=()
   while [ "$1" != "--" ]; do filters+=("$1"); shift; done
   shift
-  (cd /tmp && LIPREADING_CONV_WGRAD_SIDE=0 rocprofv3 --pmc $counters -d "$OUT/pmc_$name" -o pm -- \
+  (cd /tmp && LIPREADING_CONV_WGRAD_SIDE=0 LIPREADING_OVERLAP_WGRAD=0 rocprofv3 --pmc $counters -d "$OUT/pmc_$name" -o pm -- \
      python "$R/bench.py" "$@" --no-graph --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline > /dev/null 2>&1)
   python tools/rocpd_pmc.py "$(find "$OUT/pmc_$name" -name '*.db' | head -1)" "${filters[@]}" > "$OUT/${TAG}_${suffix}.txt"
   rm -rf "$OUT/pmc_$name"
