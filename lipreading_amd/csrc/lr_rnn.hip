@@ -71,6 +71,10 @@ constexpr int FRAG = 256;  // floats per 16x16 operand fragment
 // product up front (NW waves x UF chunks x (1+G) loads in flight), the 256 epilogue threads
 // issue their gate / length / previous-state loads before the product starts, and only then do
 // the MFMAs, the LDS combine and the stores run.
+// (Measured and dropped, round 4: TWO 16-row batch tiles per workgroup for batches above 16 rows, so that every W_hh
+// fragment a wave loads feeds both tiles and W_hh is streamed once per 32 rows — BiGRU-256 on these kernels 0.89 -> 1.11
+// ms per step, BiLSTM-768 2.03 -> 2.63: what bounds a launch is each workgroup's one memory round trip, not the total
+// bytes, and half the workgroups are half the loads in flight.)
 constexpr int NW = 8;        // waves per workgroup (512 threads): K is split NW ways
 constexpr int UF_FWD = 6;    // chunks (16 k each) a wave keeps in flight, forward
 constexpr int UF_BWD_GRU = 12;   // backward has one accumulator and 2 loads per fragment:
