@@ -74,9 +74,17 @@ class FusedAdam(object):
     self._scratch = torch.zeros(4, dtype=torch.float32, device=dev)
 
   def zero_grad(self):
+    """opt.zero_grad() — and THE TOP OF A STEP for the device-side fault words: the same launch rolls a recurrence
+    time-out of the PREVIOUS step from `pending` to `total` (include/lipreading_hip.h).  Call it BEFORE the forward pass
+    (train.ctc_step / decoder_step do; `step_begin` is the same call under the name that says so): a loop that runs
+    forward -> zero_grad -> backward -> step would clear a time-out raised by its own forward pass before lr_adam_step
+    reads it, and update the weights from garbage gradients.  Gradient accumulation over micro-batches: one
+    zero_grad() in front of the first micro-batch's forward, none in between."""
     # (the clip's accumulator is cleared by the same launch: one fill launch less per step)
     self.flat.zero_grad(also_zero=self._sumsq)
     self._sumsq_clean = True
+
+  step_begin = zero_grad
 
   def reset(self, lr=None):
     """What re-creating torch.optim.Adam each epoch does (train.py:280): moments and step
