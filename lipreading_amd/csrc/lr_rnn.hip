@@ -71,10 +71,6 @@ constexpr int FRAG = 256;  // floats per 16x16 operand fragment
 // product up front (NW waves x UF chunks x (1+G) loads in flight), the 256 epilogue threads
 // issue their gate / length / previous-state loads before the product starts, and only then do
 // the MFMAs, the LDS combine and the stores run.
-// (Measured and dropped, round 4: TWO 16-row batch tiles per workgroup for batches above 16 rows, so that every W_hh
-// fragment a wave loads feeds both tiles and W_hh is streamed once per 32 rows — BiGRU-256 on these kernels 0.89 -> 1.11
-// ms per step, BiLSTM-768 2.03 -> 2.63: what bounds a launch is each workgroup's one memory round trip, not the total
-// bytes, and half the workgroups are half the loads in flight.)
 constexpr int NW = 8;        // waves per workgroup (512 threads): K is split NW ways
 constexpr int UF_FWD = 6;    // chunks (16 k each) a wave keeps in flight, forward
 constexpr int UF_BWD_GRU = 12;   // backward has one accumulator and 2 loads per fragment:
@@ -86,34 +82,27 @@ constexpr int UF_BWD_LSTM = 12;  // (24 in flight measured slower: 11.5 vs 10.6 
   accv = __builtin_amdgcn_mfma_f32_16x16x4f32((av).z, (wv).z, accv, 0, 0, 0); \
   accv = __builtin_amdgcn_mfma_f32_16x16x4f32((av).w, (wv).w, accv, 0, 0, 0)
 
-// NB = batch tiles (16 rows each) per workgroup: with NB = 2 (batches above 16 rows) a wave multiplies every W_hh
-// fragment it loads with BOTH tiles' state fragments — W_hh, the operand that bounds these kernels, is streamed once per
-// 32 batch rows instead of once per 16 (round 4: B = 32 re-read all of W_hh twice per step) —, and all 512 threads
-// run the epilogue (threads 256-511: the second tile).  Dynamic LDS: [NB][NW][G][TILE][RED_LD] floats.
-template <int G, int NB>
+template <int G>
 __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(float* gates, float* extra, float* y,
                                                               float* hp,
                                                               const int32_t* __restrict__ lens,
                                                               StepPtrs p, int B, int T, int H, int D,
                                                               int step) {
-  extern __shared__ float red[];
+  __shared__ float red[NW * G * TILE * RED_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nbt = (B + TILE - 1) / TILE;          // 16-row batch tiles of the call (the packed state's tiling)
-  const int bt0 = blockIdx.y * NB;                // first of this workgroup's
-  const int half = tid >> 8;                      // which of its tiles this thread's epilogue row is in
   const int d = blockIdx.z;
   const int t = d == 0 ? step : T - 1 - step;
   const int tp = d == 0 ? t - 1 : t + 1;
   const bool in_seq = tp >= 0 && tp < T;
   const bool has_prev = in_seq || (p.h0 != nullptr && step == 0);
-  const int j0 = blockIdx.x * TILE, b0 = (bt0 + half) * TILE;
+  const int j0 = blockIdx.x * TILE, b0 = blockIdx.y * TILE;
   const int DH = D * H;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // ---- epilogue operands first (threads 0..256 NB - 1 own one (batch row, hidden unit) each) -------
+  // ---- epilogue operands first (threads 0..255 own one (batch row, hidden unit) each) -------
   const int bl = (tid >> 4) & 15, jl = tid & 15;
   const int b = b0 + bl, j = j0 + jl;
-  const bool epi = half < NB && b < B && j < H;
+  const bool epi = tid < 256 && b < B && j < H;
   const int64_t bt = (int64_t)b * T + t, btp = (int64_t)b * T + tp;
   float gx[G];
   float prev_own = 0.f, bhn = 0.f;
@@ -137,25 +126,22 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(float* gates, flo
 
   // ---- recurrent product: acc[g] (16 batch x 16 units) += h_prev (16 x K) . W_g^T (K x 16) ---
   if (has_prev) {
-    f32x4 acc[NB][G];
+    f32x4 acc[G];
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
-#pragma unroll
-      for (int g = 0; g < G; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < G; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int rowi = lane & 15, kq = lane >> 4;
     const int nchunk = (H + 15) >> 4;
+    const int nbt = gridDim.y;
     // previous step's packed state: parity (step-1)&1
-    const float* hsrc = hp + ((((int64_t)((step + 1) & 1) * D + d) * nbt + bt0) * nchunk) * FRAG + lane * 4;
+    const float* hsrc = hp + ((((int64_t)((step + 1) & 1) * D + d) * nbt + blockIdx.y) * nchunk) * FRAG + lane * 4;
     const float* wsrc = p.w[d] + ((int64_t)blockIdx.x * G * nchunk) * FRAG + lane * 4;
     for (int c0 = wave; c0 < nchunk; c0 += NW * UF_FWD) {
-      float4 a[NB][UF_FWD], w[UF_FWD][G];
+      float4 a[UF_FWD], w[UF_FWD][G];
 #pragma unroll
       for (int u = 0; u < UF_FWD; ++u) {
         const int c = c0 + u * NW;
         const bool ok = c < nchunk;
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-          a[i][u] = ok && bt0 + i < nbt ? ld4(hsrc + ((int64_t)i * nchunk + c) * FRAG) : zero4;
+        a[u] = ok ? ld4(hsrc + (int64_t)c * FRAG) : zero4;
 #pragma unroll
         for (int g = 0; g < G; ++g) w[u][g] = ok ? ld4(wsrc + ((int64_t)g * nchunk + c) * FRAG) : zero4;
       }
@@ -163,20 +149,16 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(float* gates, flo
       for (int u = 0; u < UF_FWD; ++u) {
         if (c0 + u * NW < nchunk) {
 #pragma unroll
-          for (int i = 0; i < NB; ++i)
-#pragma unroll
-            for (int g = 0; g < G; ++g) { LR_MFMA4(acc[i][g], a[i][u], w[u][g]); }
+          for (int g = 0; g < G; ++g) { LR_MFMA4(acc[g], a[u], w[u][g]); }
         }
       }
     }
     // C/D layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + r
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
+    for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          red[(((i * NW + wave) * G + g) * TILE + kq * 4 + r) * RED_LD + rowi] = acc[i][g][r];
+      for (int r = 0; r < 4; ++r)
+        red[((wave * G + g) * TILE + kq * 4 + r) * RED_LD + rowi] = acc[g][r];
   }
   __syncthreads();
   if (!epi) return;
@@ -187,14 +169,14 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(float* gates, flo
     s[g] = 0.f;
     if (has_prev) {
 #pragma unroll
-      for (int w = 0; w < NW; ++w) s[g] += red[(((half * NW + w) * G + g) * TILE + bl) * RED_LD + jl];
+      for (int w = 0; w < NW; ++w) s[g] += red[((w * G + g) * TILE + bl) * RED_LD + jl];
     }
   }
   float* yo = y + bt * DH + d * H + j;
   float* eo = extra + (bt * D + d) * H + j;
   // this step's packed state for the next launch: fragment (batch tile, chunk = unit tile),
   // lane = row + 16*(k/4), element k%4
-  float* ho = hp + ((((int64_t)(step & 1) * D + d) * nbt + bt0 + half) * ((H + 15) >> 4) + blockIdx.x) * FRAG +
+  float* ho = hp + ((((int64_t)(step & 1) * D + d) * gridDim.y + blockIdx.y) * ((H + 15) >> 4) + blockIdx.x) * FRAG +
               (bl + 16 * (jl >> 2)) * 4 + (jl & 3);
   if (t >= len_b) {  // padded position: zero output, zero carried state
     *yo = 0.f;
@@ -240,15 +222,14 @@ __global__ __launch_bounds__(NW * 64) void rnn_fwd_step_kernel(float* gates, flo
 // dG has four slots per (b,t,d): GRU [dr_pre, dz_pre, dn_pre, dhn_lin], LSTM [di,df,dg,do]_pre.
 // The recurrent product uses slots (0,1,3) for the GRU (d/d(W_hh h + b_hh)) and (0,1,2,3) for
 // the LSTM; dW_ih / dx use slots (0,1,2) / (0,1,2,3).
-template <int G, int NB>   // NB: batch tiles per workgroup, as in the forward kernel
+template <int G>
 __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(
     const float* __restrict__ gates, const float* __restrict__ extra, const float* __restrict__ y,
     const float* __restrict__ dy, const float* __restrict__ dh_n, const float* __restrict__ dc_n,
     float* dG, float* dcar, float* dgp, const int32_t* __restrict__ lens, StepPtrs p, int B, int T,
     int H, int D, int step) {
-  __shared__ float red[NB * NW * TILE * RED_LD];
+  __shared__ float red[NW * TILE * RED_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nbt = (B + TILE - 1) / TILE, bt0 = blockIdx.y * NB, half = tid >> 8;
   const int d = blockIdx.z;
   const int t = d == 0 ? T - 1 - step : step;   // reverse of the forward order
   const int tn = d == 0 ? t + 1 : t - 1;        // step processed just before this one
@@ -256,14 +237,14 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(
   const bool has_next = tn >= 0 && tn < T;
   const bool has_prev = tp >= 0 && tp < T;
   const bool init_prev = !has_prev && p.h0 != nullptr;   // step 0 of a layer with an initial state
-  const int j0 = blockIdx.x * TILE, b0 = (bt0 + half) * TILE;
+  const int j0 = blockIdx.x * TILE, b0 = blockIdx.y * TILE;
   const int DH = D * H, GH = G * H;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // ---- epilogue operands first ----------------------------------------------------------------
   const int bl = (tid >> 4) & 15, jl = tid & 15;
   const int b = b0 + bl, j = j0 + jl;
-  const bool epi = half < NB && b < B && j < H;
+  const bool epi = tid < 256 && b < B && j < H;
   const int64_t bt = (int64_t)b * T + t, btn = (int64_t)b * T + tn, btp = (int64_t)b * T + tp;
   int len_b = 0;
   float dh = 0.f, car = 0.f, inj_h = 0.f, inj_c = 0.f, gv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -289,36 +270,28 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(
   // ---- recurrent product: dh[b][j] += sum_{g,k} dG_h[b][tn][g][k] * W_hh[g*H+k][j] -------------
   constexpr int UF_BWD = G == 4 ? UF_BWD_LSTM : UF_BWD_GRU;
   if (has_next) {
-    f32x4 acc[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int rowi = lane & 15, kq = lane >> 4;
     const int nchunk = (H + 15) >> 4;
     const int total = G * nchunk;   // K = (gate, k) in fragments of 16
-    const float* asrc = dgp + ((((int64_t)((step + 1) & 1) * D + d) * nbt + bt0) * total) * FRAG + lane * 4;
+    const float* asrc = dgp + ((((int64_t)((step + 1) & 1) * D + d) * gridDim.y + blockIdx.y) * total) * FRAG + lane * 4;
     const float* wsrc = p.w[d] + ((int64_t)blockIdx.x * total) * FRAG + lane * 4;
     for (int f0 = wave; f0 < total; f0 += NW * UF_BWD) {
-      float4 a[NB][UF_BWD], w[UF_BWD];
+      float4 a[UF_BWD], w[UF_BWD];
 #pragma unroll
       for (int u = 0; u < UF_BWD; ++u) {
         const int f = f0 + u * NW;
         const bool ok = f < total;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) a[i][u] = ok && bt0 + i < nbt ? ld4(asrc + ((int64_t)i * total + f) * FRAG) : zero4;
+        a[u] = ok ? ld4(asrc + (int64_t)f * FRAG) : zero4;
         w[u] = ok ? ld4(wsrc + (int64_t)f * FRAG) : zero4;
       }
 #pragma unroll
       for (int u = 0; u < UF_BWD; ++u) {
-        if (f0 + u * NW < total) {
-#pragma unroll
-          for (int i = 0; i < NB; ++i) { LR_MFMA4(acc[i], a[i][u], w[u]); }
-        }
+        if (f0 + u * NW < total) { LR_MFMA4(acc, a[u], w[u]); }
       }
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[((i * NW + wave) * TILE + kq * 4 + r) * RED_LD + rowi] = acc[i][r];
+    for (int r = 0; r < 4; ++r) red[(wave * TILE + kq * 4 + r) * RED_LD + rowi] = acc[r];
   }
   __syncthreads();
   if (!epi) return;
@@ -327,7 +300,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(
   float* dco = dcar + (bt * D + d) * H + j;
   // packed copy of d/d(W_hh h + b_hh) for the next launch's product: fragment f = g*nchunk + chunk
   const int nchunk_e = (H + 15) >> 4;
-  float* po = dgp + ((((int64_t)(step & 1) * D + d) * nbt + bt0 + half) * (G * nchunk_e) + blockIdx.x) * FRAG +
+  float* po = dgp + ((((int64_t)(step & 1) * D + d) * gridDim.y + blockIdx.y) * (G * nchunk_e) + blockIdx.x) * FRAG +
               (bl + 16 * (jl >> 2)) * 4 + (jl & 3);
   const int64_t pstride = (int64_t)nchunk_e * FRAG;  // gate g -> + g * pstride
   if (t >= len_b) {  // padded position: contributes nothing, carries nothing
@@ -342,7 +315,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_bwd_step_kernel(
   }
   if (has_next) {
 #pragma unroll
-    for (int w = 0; w < NW; ++w) dh += red[((half * NW + w) * TILE + bl) * RED_LD + jl];
+    for (int w = 0; w < NW; ++w) dh += red[(w * TILE + bl) * RED_LD + jl];
   }
   const bool is_last = d == 0 ? (t == len_b - 1) : (t == 0);  // where the final state was read
   if (is_last) dh += inj_h;
@@ -552,72 +525,6 @@ __global__ __launch_bounds__(NW * 64) void rnn_dh0_kernel(const float* __restric
     dh0[(int64_t)b * H + j] = dh;
     if (dc0) dc0[(int64_t)b * H + j] = car;
   }
-}
-
-// ---- step-kernel launches: G in {1, 3, 4} x NB in {1, 2} batch tiles per workgroup (NB = 2 above 16 batch rows) ----
-inline int step_nb(int B) { return B > TILE ? 2 : 1; }
-inline dim3 step_grid(int B, int H, int D) {
-  const int nb = step_nb(B);
-  return dim3((H + TILE - 1) / TILE, ((B + TILE - 1) / TILE + nb - 1) / nb, D);
-}
-template <int G, int NB>
-int launch_fwd_step(dim3 grid, hipStream_t stream, bool sample, hipEvent_t e0, hipEvent_t e1, float* gates, float* extra,
-                    float* y, float* hp, const int32_t* lens, const StepPtrs& p, int B, int T, int H, int D, int s) {
-  constexpr size_t lds = (size_t)NB * NW * G * TILE * RED_LD * sizeof(float);
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute((const void*)rnn_fwd_step_kernel<G, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
-      return LR_ERR_LAUNCH;
-    attr_set = true;
-  }
-  if (sample)
-    hipExtLaunchKernelGGL((rnn_fwd_step_kernel<G, NB>), grid, dim3(NW * 64), lds, stream, e0, e1, 0, gates, extra, y, hp, lens,
-                          p, B, T, H, D, s);
-  else
-    hipLaunchKernelGGL((rnn_fwd_step_kernel<G, NB>), grid, dim3(NW * 64), lds, stream, gates, extra, y, hp, lens, p, B, T, H, D,
-                       s);
-  return LR_OK;
-}
-inline int fwd_step(int G, dim3 grid, hipStream_t stream, bool sample, hipEvent_t e0, hipEvent_t e1, float* gates,
-                    float* extra, float* y, float* hp, const int32_t* lens, const StepPtrs& p, int B, int T, int H, int D,
-                    int s) {
-#define LR_FS(g, nb) return launch_fwd_step<g, nb>(grid, stream, sample, e0, e1, gates, extra, y, hp, lens, p, B, T, H, D, s)
-  if (step_nb(B) == 2) {
-    if (G == 3) LR_FS(3, 2);
-    if (G == 4) LR_FS(4, 2);
-    LR_FS(1, 2);
-  }
-  if (G == 3) LR_FS(3, 1);
-  if (G == 4) LR_FS(4, 1);
-  LR_FS(1, 1);
-#undef LR_FS
-}
-template <int G, int NB>
-void launch_bwd_step(dim3 grid, hipStream_t stream, bool sample, hipEvent_t e0, hipEvent_t e1, const float* gates,
-                     const float* extra, const float* y, const float* dy, const float* dh_n, const float* dc_n, float* dG,
-                     float* dcar, float* dgp, const int32_t* lens, const StepPtrs& p, int B, int T, int H, int D, int s) {
-  if (sample)
-    hipExtLaunchKernelGGL((rnn_bwd_step_kernel<G, NB>), grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n,
-                          dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
-  else
-    hipLaunchKernelGGL((rnn_bwd_step_kernel<G, NB>), grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar,
-                       dgp, lens, p, B, T, H, D, s);
-}
-inline void bwd_step(int G, dim3 grid, hipStream_t stream, bool sample, hipEvent_t e0, hipEvent_t e1, const float* gates,
-                     const float* extra, const float* y, const float* dy, const float* dh_n, const float* dc_n, float* dG,
-                     float* dcar, float* dgp, const int32_t* lens, const StepPtrs& p, int B, int T, int H, int D, int s) {
-#define LR_BS(g, nb) \
-  return launch_bwd_step<g, nb>(grid, stream, sample, e0, e1, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s)
-  if (step_nb(B) == 2) {
-    if (G == 3) LR_BS(3, 2);
-    if (G == 4) LR_BS(4, 2);
-    LR_BS(1, 2);
-  }
-  if (G == 3) LR_BS(3, 1);
-  if (G == 4) LR_BS(4, 1);
-  LR_BS(1, 1);
-#undef LR_BS
 }
 
 struct Layout {
@@ -867,12 +774,20 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
   if (D == 1) { p.w[1] = p.w[0]; p.b[1] = p.b[0]; }
   lr_clear_error();
   if (hipMemsetAsync(hp, 0, l.hp_floats * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
-  const dim3 grid = step_grid(B, H, D);
+  const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, D);
   for (int s = 0; s < T; ++s) {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    // (a sampled launch: the events carry the dispatch's own begin/end timestamps)
-    const bool sample = s == T / 2 && lr_prof_next(LR_PROF_RNN_FWD, &e0, &e1);
-    if (fwd_step(G, grid, stream, sample, e0, e1, gates, extra, y, hp, lens, p, B, T, H, D, s) != LR_OK) return LR_ERR_LAUNCH;
+    hipEvent_t e0, e1;
+    if (s == T / 2 && lr_prof_next(LR_PROF_RNN_FWD, &e0, &e1)) {
+      // sampled launch: the events carry the dispatch's own begin/end timestamps
+      lr_clear_error();
+      if (G == 3) hipExtLaunchKernelGGL(rnn_fwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, hp, lens, p, B, T, H, D, s);
+      else if (G == 4) hipExtLaunchKernelGGL(rnn_fwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, hp, lens, p, B, T, H, D, s);
+      else hipExtLaunchKernelGGL(rnn_fwd_step_kernel<1>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, hp, lens, p, B, T, H, D, s);
+      continue;
+    }
+    if (G == 3) LR_LAUNCH(rnn_fwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, D, s);
+    else if (G == 4) LR_LAUNCH(rnn_fwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, D, s);
+    else LR_LAUNCH(rnn_fwd_step_kernel<1>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, D, s);
   }
   int st = lr_launch_status();
   if (st != LR_OK) return st;
@@ -966,11 +881,19 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
     if (st != LR_OK) return st;
     if (hipMemsetAsync(dgp, 0, wl.dgp_floats * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
 
-    const dim3 grid = step_grid(B, H, D);
+    const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, D);
     for (int s = 0; s < T; ++s) {
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      const bool sample = s == T / 2 && lr_prof_next(LR_PROF_RNN_BWD, &e0, &e1);
-      bwd_step(G, grid, stream, sample, e0, e1, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
+      hipEvent_t e0, e1;
+      if (s == T / 2 && lr_prof_next(LR_PROF_RNN_BWD, &e0, &e1)) {
+        lr_clear_error();
+        if (G == 3) hipExtLaunchKernelGGL(rnn_bwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
+        else if (G == 4) hipExtLaunchKernelGGL(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
+        else hipExtLaunchKernelGGL(rnn_bwd_step_kernel<1>, grid, dim3(NW * 64), 0, stream, e0, e1, 0, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
+        continue;
+      }
+      if (G == 3) LR_LAUNCH(rnn_bwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
+      else if (G == 4) LR_LAUNCH(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
+      else LR_LAUNCH(rnn_bwd_step_kernel<1>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, D, s);
     }
     st = lr_launch_status();
     if (st != LR_OK) return st;
@@ -1120,9 +1043,10 @@ int lr_rnn_step_fwd(int G, float* gates, float* extra, float* y, float* hp, cons
   p.b[0] = p.b[1] = b_hh;
   p.h0 = h0;
   p.c0 = c0;
-  lr_clear_error();
-  if (fwd_step(G, step_grid(B, H, 1), stream, false, nullptr, nullptr, gates, extra, y, hp, lens, p, B, T, H, 1, step) != LR_OK)
-    return LR_ERR_LAUNCH;
+  const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, 1);
+  if (G == 3) LR_LAUNCH(rnn_fwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, 1, step);
+  else if (G == 4) LR_LAUNCH(rnn_fwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, 1, step);
+  else LR_LAUNCH(rnn_fwd_step_kernel<1>, grid, dim3(NW * 64), 0, stream, gates, extra, y, hp, lens, p, B, T, H, 1, step);
   return lr_launch_status();
 }
 int lr_rnn_step_bwd(int G, const float* gates, const float* extra, const float* y, const float* dy,
@@ -1134,9 +1058,10 @@ int lr_rnn_step_bwd(int G, const float* gates, const float* extra, const float* 
   p.b[0] = p.b[1] = nullptr;
   p.h0 = h0;
   p.c0 = c0;
-  lr_clear_error();
-  bwd_step(G, step_grid(B, H, 1), stream, false, nullptr, nullptr, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T,
-           H, 1, step);
+  const dim3 grid((H + TILE - 1) / TILE, (B + TILE - 1) / TILE, 1);
+  if (G == 3) LR_LAUNCH(rnn_bwd_step_kernel<3>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, 1, step);
+  else if (G == 4) LR_LAUNCH(rnn_bwd_step_kernel<4>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, 1, step);
+  else LR_LAUNCH(rnn_bwd_step_kernel<1>, grid, dim3(NW * 64), 0, stream, gates, extra, y, dy, dh_n, dc_n, dG, dcar, dgp, lens, p, B, T, H, 1, step);
   return lr_launch_status();
 }
 int lr_rnn_dh0(int G, const float* dcar, const float* dgp_slot, const float* wpT, float* dh0, float* dc0, int B,
