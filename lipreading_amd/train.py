@@ -361,7 +361,13 @@ def decoder_step(encoder, decoding_step, opts, frames, frame_lens, chars, char_l
     log_probs_d, _, _ = decoding_step.decode_sequence(chars[:, :L], state, frame_lens32 if fused_prep else frame_lens_d, hidden,
                                                       teacher_forced=flags, seed=seed)
     decoder_loss = decoder_nll(log_probs_d, labels, pad)
-    (decoder_loss + total).backward(_one(decoder_loss.device))
+    # one traversal from BOTH roots (the reference's two backward calls, train_better_model.py:70,74, add up to this);
+    # no `decoder_loss + ctc` tensor: that sum was an elementwise launch of its own
+    one = _one(decoder_loss.device)
+    if use_ctc:
+      torch.autograd.backward([decoder_loss, total], [one, one])
+    else:
+      decoder_loss.backward(one)
     if whole:
       for o in opts:
         o.step(grad_norm=grad_norm, grad_scale=1.0, skip=status)
