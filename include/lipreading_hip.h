@@ -238,6 +238,11 @@ int lr_fault_export(const int32_t* status, int32_t* out2, lr_stream_t stream);
 int lr_fault_import(const int32_t* in2, int32_t* status, lr_stream_t stream);
 void* lr_fault_words_ptr(void);
 int lr_step_begin(float* grad, int64_t n, float* also_zero, lr_stream_t stream);
+/* lr_step_begin and lr_ctc_prepare_i64 (below) in ONE launch: the two first launches of a training step
+ * (train_better_model.py:31-32 and :67) depend on nothing and not on each other. */
+int lr_step_begin_ctc(float* grad, int64_t n, float* also_zero, const int64_t* chars, int64_t chars_stride,
+                      const int64_t* frame_lens, const int64_t* char_lens, int32_t* labels_p1, int32_t* frame_lens32,
+                      int32_t* label_lens32, int B, int L, lr_stream_t stream);
 void lr_rnn_debug_drop_member(int member);
 void lr_rnn_debug_disable_cluster(int off);
 /* TUNING HOOK of the cluster recurrence's exchange polling: which = 0 forward / 1 backward kernels;
@@ -707,6 +712,13 @@ int lr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
                  const float* sumsq, float max_norm, float grad_scale, float lr, float beta1,
                  float beta2, float eps, int32_t* step_count, const int32_t* skip, float* scratch,
                  lr_stream_t stream);
+/* lr_sumsq + lr_adam_step with max_norm > 0 in TWO launches instead of three: the sum-of-squares kernel's last workgroup
+ * (a ticket in scratch8[4], which it puts back to 0) derives the step's coefficients.  sumsq [1]: cleared by the caller
+ * (lr_step_begin's also_zero), receives the sum of squares; scratch8: EIGHT floats of device scratch, zero before the
+ * first call; everything else as lr_adam_step. */
+int lr_clip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* sumsq,
+                      float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
+                      int32_t* step_count, const int32_t* skip, float* scratch8, lr_stream_t stream);
 
 #ifdef __cplusplus
 }

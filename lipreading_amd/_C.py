@@ -52,6 +52,7 @@ SIGNATURES = {
     "lr_fault_export": (c_int, [P, P, P]),
     "lr_fault_import": (c_int, [P, P, P]),
     "lr_step_begin": (c_int, [P, c_int64, P, P]),
+    "lr_step_begin_ctc": (c_int, [P, c_int64, P, P, c_int64, P, P, P, P, P, c_int, c_int, P]),
     "lr_rnn_debug_drop_member": (None, [c_int]),
     "lr_rnn_debug_disable_cluster": (None, [c_int]),
     "lr_rnn_debug_tune": (None, [c_int, c_int, c_int]),
@@ -119,6 +120,8 @@ SIGNATURES = {
     "lr_sumsq": (c_int, [P, c_int64, P, P]),
     "lr_adam_step": (c_int, [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_float,
                               c_float, P, P, P, P]),
+    "lr_clip_adam_step": (c_int, [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_float,
+                                   c_float, P, P, P, P]),
 }
 
 

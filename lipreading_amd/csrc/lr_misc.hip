@@ -219,13 +219,10 @@ __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __re
 // whole optimiser step replayable from a hipGraph (host-computed corrections would be frozen).
 //   st[0] = active (0/1), st[1] = lr / (1 - beta1^t), st[2] = 1 / sqrt(1 - beta2^t),
 //   st[3] = gradient scale (grad_scale x clip coefficient)
-__global__ void adam_prepare_kernel(int32_t* __restrict__ step_count,
-                                    const int32_t* __restrict__ skip,
-                                    const int32_t* __restrict__ fault,
-                                    const float* __restrict__ sumsq, float max_norm,
-                                    float grad_scale, float lr, float beta1, float beta2,
-                                    float* __restrict__ st) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void adam_prepare_body(int32_t* __restrict__ step_count, const int32_t* __restrict__ skip,
+                                                  const int32_t* __restrict__ fault, bool has_sumsq, float sumsq_value,
+                                                  float max_norm, float grad_scale, float lr, float beta1, float beta2,
+                                                  float* __restrict__ st) {
   // fault[0] != 0: a one-launch recurrence of THIS step gave up waiting for a partner workgroup (its outputs
   // and gradients are garbage): the step is skipped like a batch the reference skips (train_better_model.py:49-50)
   const bool active = !(skip && skip[0] != 0) && !(fault && fault[0] != 0);
@@ -236,9 +233,9 @@ __global__ void adam_prepare_kernel(int32_t* __restrict__ step_count,
   const float bc1 = 1.f - powf(beta1, (float)t);
   const float bc2 = 1.f - powf(beta2, (float)t);
   float scale = grad_scale;
-  if (max_norm > 0.f && sumsq) {
+  if (max_norm > 0.f && has_sumsq) {
     // clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
-    const float norm = sqrtf(sumsq[0]) * fabsf(grad_scale);
+    const float norm = sqrtf(sumsq_value) * fabsf(grad_scale);
     const float coef = max_norm / (norm + 1e-6f);
     if (coef < 1.f) scale *= coef;
   }
@@ -246,6 +243,46 @@ __global__ void adam_prepare_kernel(int32_t* __restrict__ step_count,
   st[1] = lr / bc1;
   st[2] = 1.f / sqrtf(bc2);
   st[3] = scale;
+}
+__global__ void adam_prepare_kernel(int32_t* __restrict__ step_count, const int32_t* __restrict__ skip,
+                                    const int32_t* __restrict__ fault, const float* __restrict__ sumsq, float max_norm,
+                                    float grad_scale, float lr, float beta1, float beta2, float* __restrict__ st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  adam_prepare_body(step_count, skip, fault, sumsq != nullptr, sumsq ? sumsq[0] : 0.f, max_norm, grad_scale, lr, beta1, beta2,
+                    st);
+}
+// sumsq_kernel AND adam_prepare_kernel in one launch (lr_clip_adam_step): every workgroup adds its partial sum of squares
+// to out[0] and takes a ticket (st[4], an unsigned that the last workgroup puts back to 0); the one that draws the last
+// ticket — every other partial sum is in out[0] by then — derives the step's coefficients.
+__global__ void sumsq_prepare_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out,
+                                     int32_t* __restrict__ step_count, const int32_t* __restrict__ skip,
+                                     const int32_t* __restrict__ fault, float max_norm, float grad_scale, float lr,
+                                     float beta1, float beta2, float* __restrict__ st) {
+  float acc = 0.f;
+  const int64_t n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) acc += x[i] * x[i];
+  acc = lr_wave_sum(acc);
+  __shared__ float part[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  float s = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += part[w];
+  atomicAdd(out, s);
+  __threadfence();
+  unsigned* ticket = reinterpret_cast<unsigned*>(st + 4);
+  if (atomicAdd(ticket, 1u) != gridDim.x - 1) return;
+  *ticket = 0u;
+  __threadfence();
+  const float total = atomicAdd(out, 0.f);   // (an atomic read: served where the other workgroups' adds were)
+  adam_prepare_body(step_count, skip, fault, true, total, max_norm, grad_scale, lr, beta1, beta2, st);
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -583,6 +620,37 @@ __global__ void step_begin_kernel(float4* __restrict__ g, int64_t n4, float* __r
   for (int64_t i = i0; i < n4; i += (int64_t)gridDim.x * blockDim.x) g[i] = z;
   if (i0 < ntail) tail[i0] = 0.f;
 }
+// lr_step_begin + lr_ctc_prepare_i64 in one launch (lr_step_begin_ctc): the step's first two launches depend on nothing
+// and on each other not at all; the last workgroups of the grid do the label plumbing
+__global__ void step_begin_ctc_kernel(float4* __restrict__ g, int64_t n4, float* __restrict__ tail, int ntail,
+                                      int32_t* __restrict__ fault, float* __restrict__ also_zero, int zero_blocks,
+                                      const int64_t* __restrict__ chars, int64_t chars_stride,
+                                      const int64_t* __restrict__ frame_lens, const int64_t* __restrict__ char_lens,
+                                      int32_t* __restrict__ labels_p1, int32_t* __restrict__ frame_lens32,
+                                      int32_t* __restrict__ label_lens32, int B, int L) {
+  if ((int)blockIdx.x >= zero_blocks) {
+    const int pb = blockIdx.x - zero_blocks, np = gridDim.x - zero_blocks;
+    const int total = B * L;
+    for (int i = pb * blockDim.x + threadIdx.x; i < total; i += np * blockDim.x) {
+      const int b = i / L, l = i - b * L;
+      labels_p1[i] = (int32_t)chars[(int64_t)b * chars_stride + 1 + l] + 1;
+    }
+    for (int b = pb * blockDim.x + threadIdx.x; b < B; b += np * blockDim.x) {
+      frame_lens32[b] = (int32_t)frame_lens[b];
+      label_lens32[b] = (int32_t)char_lens[b] - 1;
+    }
+    return;
+  }
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i0 == 0 && fault) {
+    fault[1] += fault[0];
+    fault[0] = 0;
+  }
+  if (i0 == 0 && also_zero) also_zero[0] = 0.f;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t i = i0; i < n4; i += (int64_t)zero_blocks * blockDim.x) g[i] = z;
+  if (i0 < ntail) tail[i0] = 0.f;
+}
 __global__ void fault_export_kernel(const int32_t* __restrict__ status, const int32_t* __restrict__ fault,
                                     int32_t* __restrict__ out2) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -714,6 +782,22 @@ extern "C" int lr_step_begin(float* grad, int64_t n, float* also_zero, lr_stream
   return lr_launch_status();
 }
 
+extern "C" int lr_step_begin_ctc(float* grad, int64_t n, float* also_zero, const int64_t* chars, int64_t chars_stride,
+                                 const int64_t* frame_lens, const int64_t* char_lens, int32_t* labels_p1,
+                                 int32_t* frame_lens32, int32_t* label_lens32, int B, int L, lr_stream_t stream) {
+  LR_CHECK_ARG(n >= 0 && (grad || n == 0));
+  LR_CHECK_ARG((reinterpret_cast<uintptr_t>(grad) & 15) == 0);
+  LR_CHECK_ARG(chars && frame_lens && char_lens && labels_p1 && frame_lens32 && label_lens32 && B > 0 && L > 0);
+  const int64_t n4 = n / 4;
+  const int zero_blocks = grid_for(n4 > 0 ? n4 : 1, 256);
+  int prep_blocks = (B * L + 255) / 256;
+  if (prep_blocks > 16) prep_blocks = 16;
+  LR_LAUNCH(step_begin_ctc_kernel, dim3(zero_blocks + prep_blocks), dim3(256), 0, stream, (float4*)grad, n4, grad + n4 * 4,
+            (int)(n - n4 * 4), lr_fault_words(), also_zero, zero_blocks, chars, chars_stride, frame_lens, char_lens, labels_p1,
+            frame_lens32, label_lens32, B, L);
+  return lr_launch_status();
+}
+
 extern "C" int lr_sumsq(const float* x, int64_t n, float* out, lr_stream_t stream) {
   LR_CHECK_ARG(x && out && n >= 0);
   if (n == 0) return LR_OK;
@@ -735,6 +819,22 @@ extern "C" int lr_adam_step(float* param, const float* grad, float* exp_avg, flo
   if (st != LR_OK || n == 0) return st;
   LR_LAUNCH(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, param, grad, exp_avg,
             exp_avg_sq, n, (const float*)scratch, beta1, beta2, eps);
+  return lr_launch_status();
+}
+
+extern "C" int lr_clip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                 float* sumsq, float max_norm, float grad_scale, float lr, float beta1, float beta2,
+                                 float eps, int32_t* step_count, const int32_t* skip, float* scratch8, lr_stream_t stream) {
+  LR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_count && scratch8 && sumsq && n > 0 && max_norm > 0.f);
+  LR_CHECK_ARG((reinterpret_cast<uintptr_t>(grad) & 15) == 0);
+  int g = grid_for((n + 3) / 4, 256);
+  if (g > 256) g = 256;  // one atomic per workgroup
+  LR_LAUNCH(sumsq_prepare_kernel, dim3(g), dim3(256), 0, stream, grad, n, sumsq, step_count, skip,
+            (const int32_t*)lr_fault_words(), max_norm, grad_scale, lr, beta1, beta2, scratch8);
+  int st = lr_launch_status();
+  if (st != LR_OK) return st;
+  LR_LAUNCH(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, n,
+            (const float*)scratch8, beta1, beta2, eps);
   return lr_launch_status();
 }
 

@@ -45,11 +45,26 @@ class FlatParameters(object):
       if p.grad is None or p.grad.data_ptr() != view.data_ptr():
         p.grad = view
 
-  def zero_grad(self, also_zero=None):
+  def zero_grad(self, also_zero=None, ctc_inputs=None):
     """opt.zero_grad() (train_better_model.py:67) AND the top of a step for the device-side fault words: one launch
     (lr_step_begin) clears the flat gradient buffer and moves a time-out raised by a one-launch recurrence of the
     PREVIOUS step from `pending` to `total` (include/lipreading_hip.h).  also_zero: a float32[1] device tensor to
-    clear in the same launch (FusedAdam's sum-of-squares accumulator)."""
+    clear in the same launch (FusedAdam's sum-of-squares accumulator).  ctc_inputs = (chars, frame_lens, char_lens)
+    int64 on the device: the step's label plumbing (ctc.prepare_ctc_inputs) rides in the same launch; returns its
+    (labels_p1, frame_lens32, label_lens32)."""
+    if self.grad.is_cuda and ctc_inputs is not None:
+      import torch as _t
+      chars, frame_lens, char_lens = ctc_inputs
+      B, Lc = chars.shape
+      labels_p1 = _t.empty((B, Lc - 1), dtype=_t.int32, device=chars.device)
+      fl = _t.empty(B, dtype=_t.int32, device=chars.device)
+      ll = _t.empty(B, dtype=_t.int32, device=chars.device)
+      _C.check(_C.lib().lr_step_begin_ctc(self.grad.data_ptr(), self.numel, _C.ptr(also_zero), chars.data_ptr(),
+                                          chars.stride(0), frame_lens.contiguous().data_ptr(),
+                                          char_lens.contiguous().data_ptr(), labels_p1.data_ptr(), fl.data_ptr(),
+                                          ll.data_ptr(), B, Lc - 1, _C.stream_handle()), "lr_step_begin_ctc")
+      self.attach_grads()
+      return labels_p1, fl, ll
     if self.grad.is_cuda:
       _C.check(_C.lib().lr_step_begin(self.grad.data_ptr(), self.numel, _C.ptr(also_zero), _C.stream_handle()),
                "lr_step_begin")
@@ -71,7 +86,7 @@ class FusedAdam(object):
     self.exp_avg_sq = torch.zeros_like(flat.data)
     self.step_count = torch.zeros(2, dtype=torch.int32, device=dev)   # [updates taken, steps skipped]
     self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
-    self._scratch = torch.zeros(4, dtype=torch.float32, device=dev)
+    self._scratch = torch.zeros(8, dtype=torch.float32, device=dev)   # [0..3] the step's coefficients, [4] a ticket
 
   def zero_grad(self):
     """opt.zero_grad() — and THE TOP OF A STEP for the device-side fault words: the same launch rolls a recurrence
@@ -85,6 +100,13 @@ class FusedAdam(object):
     self._sumsq_clean = True
 
   step_begin = zero_grad
+
+  def zero_grad_and_prepare_ctc(self, chars, frame_lens, char_lens):
+    """zero_grad() with the step's CTC label plumbing (ctc.prepare_ctc_inputs) in the same launch; returns
+    (labels_p1, frame_lens32, label_lens32)."""
+    out = self.flat.zero_grad(also_zero=self._sumsq, ctc_inputs=(chars, frame_lens, char_lens))
+    self._sumsq_clean = True
+    return out
 
   def reset(self, lr=None):
     """What re-creating torch.optim.Adam each epoch does (train.py:280): moments and step
@@ -106,16 +128,19 @@ class FusedAdam(object):
     L = _C.lib()
     f = self.flat
     st = _C.stream_handle()
-    sumsq = None
-    if grad_norm is not None:
+    if grad_norm is not None and float(grad_norm) > 0:
       if not getattr(self, "_sumsq_clean", False):
         self._sumsq.zero_()     # (a caller that cleared the gradients some other way than self.zero_grad())
       self._sumsq_clean = False
-      _C.check(L.lr_sumsq(f.grad.data_ptr(), f.numel, self._sumsq.data_ptr(), st), "lr_sumsq")
-      sumsq = self._sumsq
+      # sum of squares -> clip coefficient -> Adam in two launches (the first one's last workgroup derives the coefficients)
+      _C.check(L.lr_clip_adam_step(f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                   self.exp_avg_sq.data_ptr(), f.numel, self._sumsq.data_ptr(), float(grad_norm),
+                                   float(grad_scale), self.lr, self.betas[0], self.betas[1], self.eps,
+                                   self.step_count.data_ptr(), _C.ptr(skip), self._scratch.data_ptr(), st),
+               "lr_clip_adam_step")
+      return
     _C.check(L.lr_adam_step(f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),
-                            self.exp_avg_sq.data_ptr(), f.numel, _C.ptr(sumsq),
-                            float(grad_norm) if grad_norm is not None else 0.0, float(grad_scale),
+                            self.exp_avg_sq.data_ptr(), f.numel, None, 0.0, float(grad_scale),
                             self.lr, self.betas[0], self.betas[1], self.eps,
                             self.step_count.data_ptr(), _C.ptr(skip), self._scratch.data_ptr(), st),
              "lr_adam_step")

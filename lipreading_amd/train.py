@@ -292,9 +292,10 @@ def ctc_step(encoder, opt, frames, frame_lens, chars, char_lens, grad_norm=None,
     # the int32 frame lengths as they are
     fused_prep = (chars.dtype == torch.int64 and frame_lens.dtype == torch.int64 and char_lens.dtype == torch.int64
                   and chars.dim() == 2 and chars.stride(1) == 1)
-    if fused_prep:
-      labels_p1, frame_lens32, label_lens32 = prepare_ctc_inputs(chars, frame_lens, char_lens)
-    opt.zero_grad()
+    if fused_prep:   # ... and in the SAME launch as zero_grad (lr_step_begin_ctc)
+      labels_p1, frame_lens32, label_lens32 = opt.zero_grad_and_prepare_ctc(chars, frame_lens, char_lens)
+    else:
+      opt.zero_grad()
     # (the CTC-only step never reads the encoder's final states: they are not extracted)
     log_probs, _, _ = encoder(frames, frame_lens32 if fused_prep else frame_lens, max_len=max_len,
                               need_final_state=False)
@@ -340,15 +341,15 @@ def decoder_step(encoder, decoding_step, opts, frames, frame_lens, chars, char_l
 
   def body(frames, frame_lens_d, chars, char_lens_d):
     labels = chars[:, 1:]
-    for o in opts:
-      o.zero_grad()
     status, total, ctc = None, 0, None
     # labels + 1, label_lens = char_lens - 1 and the int32 lengths in one launch (as ctc_step does) instead of four
-    # ATen conversions
+    # ATen conversions — the launch that clears the encoder's gradients
     fused_prep = (use_ctc and chars.dtype == torch.int64 and frame_lens_d.dtype == torch.int64
                   and char_lens_d.dtype == torch.int64 and chars.dim() == 2 and chars.stride(1) == 1)
     if fused_prep:
-      labels_p1, frame_lens32, label_lens32 = prepare_ctc_inputs(chars, frame_lens_d, char_lens_d)
+      labels_p1, frame_lens32, label_lens32 = opts[0].zero_grad_and_prepare_ctc(chars, frame_lens_d, char_lens_d)
+    for o in (opts[1:] if fused_prep else opts):
+      o.zero_grad()
     if use_ctc:
       log_probs, hidden, state = encoder(frames, frame_lens32 if fused_prep else frame_lens_d, max_len=max_len)
       if fused_prep:
