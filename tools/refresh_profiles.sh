@@ -69,8 +69,8 @@ if [ "$ONLY" != "pixels" ]; then
   kt lstm768 --regime landmarks --model lstm768
   kt lstm700 --regime landmarks --model lstm700
   kt landmarks_attn --regime landmarks_attn
-  tl gru256 ctc_prepare --regime landmarks --model gru256
-  tl lstm768 ctc_prepare --regime landmarks --model lstm768
+  tl gru256 step_begin --regime landmarks --model gru256
+  tl lstm768 step_begin --regime landmarks --model lstm768
   for c in FETCH_SIZE WRITE_SIZE; do
     pmc gru_$c $c gru256_pmc_$c -- --regime landmarks --model gru256
     pmc lstm_$c $c lstm768_pmc_$c -- --regime landmarks --model lstm768
