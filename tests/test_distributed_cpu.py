@@ -140,3 +140,28 @@ def test_bench_launcher_reports_a_dead_rank():
   res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
                        capture_output=True, text=True, timeout=300)
   assert res.returncode != 0 and "must agree" in res.stderr
+
+
+def test_gradient_buckets_of_the_pixel_model_are_conv_then_encoder():
+  """GradSync.groups_for_pixel_model: [the conv frontend's parameters], [every parameter of the encoder] — two
+  contiguous stretches of the flat buffer that tile it, so the encoder's all-reduce is ONE collective that goes out
+  behind the step's last recurrence (it rides under the conv backward), and groups_for_encoder's per-layer buckets
+  still tile the encoder for the landmark regimes."""
+  import torch
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.distributed import GradSync
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.frontend import ConvFrontend3D, PixelLipReader, feature_dim
+  from lipreading_amd.optim import FlatParameters
+  enc = VideoEncoder(feature_dim(96, 96), 16, rnn_type='GRU', num_layers=2, bidirectional=True, enable_ctc=True,
+                     vocab_size=64, char2idx=default_char2idx())
+  model = PixelLipReader(enc, ConvFrontend3D())
+  flat = FlatParameters(model)
+  conv, rest = GradSync.groups_for_pixel_model(model, flat)
+  assert conv == list(range(6)) and rest == list(range(6, len(flat.params)))
+  assert [tuple(flat.params[i].shape) for i in conv[:2]] == [(32, 3, 3, 5, 5), (32,)]
+  per_layer = GradSync.groups_for_encoder(enc, flat)
+  assert sorted(i for g in per_layer for i in g) == rest
+  # contiguous in the flat buffer: bounds of consecutive groups meet
+  offs = flat.offsets + [flat.numel]
+  assert offs[conv[-1] + 1] == offs[rest[0]]
