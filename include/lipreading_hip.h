@@ -646,16 +646,14 @@ int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* dbias, void
                     lr_stream_t stream);
 
 /* The same weight (and bias) gradient for a layer whose forward fused ReLU + MaxPool
- * (lr_conv3d_forward_pooled), taken straight from the pooled gradient dP, the pooled activation and
- * the window codes: the un-pooled dZ is rebuilt tile by tile inside the kernel and never touches
- * memory.  Build-defined like the rest of the frontend (the reference has no conv
+ * (lr_conv3d_forward_pooled), taken straight from the pooled gradient dP and the window codes: the
+ * un-pooled dZ is rebuilt tile by tile inside the kernel and never touches memory.  Build-defined like the rest of the frontend (the reference has no conv
  * stage; its only trace is the commented-out stack at src/models/lipreader/model.py:122,153-156).
- * `_supported` is non-zero for the layers that have this kernel: 1 = the first STCNN layer (reads `pooled` for the
- * ReLU mask; flags bit 0: X is the raw clip, uint8 [B][T][3][Hin][Win], scaled by 1/255 on the way into LDS as
- * lr_clip_to_ndhwc_bf16 would, not bf16 NDHWC); 2 = the stride-1 layers 2 and 3 (the codes carry the ReLU mask —
- * code 4 — so `pooled` is not read and may be NULL; dbias = column sums of dP over the windows ReLU did not block;
- * LR_ERR_UNSUPPORTED for a frame count whose tile table does not fit the kernel's LDS: use lr_unpool_code_bf16 +
- * lr_conv3d_wgrad then).  Workspace as for lr_conv3d_wgrad. */
+ * `_supported` is non-zero for the layers that have this kernel: 1 = the first STCNN layer (flags bit 0: X is the raw
+ * clip, uint8 [B][T][3][Hin][Win], scaled by 1/255 on the way into LDS as lr_clip_to_ndhwc_bf16 would, not bf16 NDHWC);
+ * 2 = the stride-1 layers 2 and 3 (LR_ERR_UNSUPPORTED for a frame count whose tile table does not fit the kernel's LDS:
+ * use lr_unpool_code_bf16 + lr_conv3d_wgrad then).  The codes carry the ReLU mask — code 4 — so `pooled` is not read
+ * and may be NULL; dbias = column sums of dP over the windows ReLU did not block.  Workspace as for lr_conv3d_wgrad. */
 int lr_conv3d_wgrad_pooled_supported(int Hin, int Win, int Cin_pad, int Cin_real, int Cout, int KT, int KH,
                                      int KW, int stride, int pt, int ph, int pw);
 int lr_conv3d_wgrad_pooled(const void* X, const void* pooled, const void* code, const void* dP, float* dW,

@@ -99,13 +99,13 @@ bool lr_prof_next(int slot, hipEvent_t* start, hipEvent_t* stop);
   } while (0)
 
 // ---- conv frontend, first layer: patch-resident forward and weight gradient (lr_conv1.hip) -----------------
-constexpr int LR_CONV1_WGRAD_WGS = 512;   // persistent workgroups of the first layer's weight gradient, one slab each
+constexpr int LR_CONV1_WGRAD_WGS = 256;   // persistent workgroups of the first layer's weight gradient (one per CU), one slab each
 int lr_conv1_forward(bool pool, bool u8, const void* X, const void* Wp, const float* bias, void* Y, unsigned char* code,
                      int frames, int T, int Hin, int Win, int Ho, int Wo, int relu, bool sample, hipEvent_t e0,
                      hipEvent_t e1, hipStream_t stream);
-int lr_conv1_wgrad(bool pooled, bool u8, const void* X, const void* dZ, const void* pooled_act, const void* code,
-                   float* slabs, float* bias_part, int frames, int T, int Hin, int Win, int Ho, int Wo, bool sample,
-                   hipEvent_t e0, hipEvent_t e1, hipStream_t stream);
+int lr_conv1_wgrad(bool pooled, bool u8, const void* X, const void* dZ, const void* code, float* slabs, float* bias_part,
+                   int frames, int T, int Hin, int Win, int Ho, int Wo, bool sample, hipEvent_t e0, hipEvent_t e1,
+                   hipStream_t stream);
 
 // ---- conv frontend, patch-resident forward / data gradient of the 24-wide (3,5,5) layer (lr_conv_patch.hip) ----
 int lr_conv_patch24(bool fwd, bool unpool, const void* X, const void* Wf, const float* bias, void* Y, unsigned char* code,

@@ -1366,14 +1366,14 @@ extern "C" int lr_conv3d_wgrad_pooled(const void* X, const void* pooled, const v
     return wgrad_tr2_run(X, dP, code, dW, dbias, workspace, accumulate, B * T, T, Hin, Win, Cin_pad, Cout, KT, KH, KW,
                          sample, e0, e1, (hipStream_t)stream);
   }
-  LR_CHECK_ARG(pooled);
+  (void)pooled;   // the codes carry the ReLU mask (code 4) for the first layer as well
   float* slabs = (float*)workspace;
   float* bpart = (float*)((char*)workspace + need) - (size_t)LR_CONV1_WGRAD_WGS * Cout;
   hipEvent_t e0, e1;
   const bool sample = lr_prof_next(LR_PROF_CONV1_WGRAD, &e0, &e1);
   const int nwg = LR_CONV1_WGRAD_WGS;
   {
-    const int st1 = lr_conv1_wgrad(true, u8, X, dP, pooled, code, slabs, dbias ? bpart : (float*)nullptr, B * T, T, Hin, Win,
+    const int st1 = lr_conv1_wgrad(true, u8, X, dP, code, slabs, dbias ? bpart : (float*)nullptr, B * T, T, Hin, Win,
                                    g.Ho, g.Wo, sample, e0, e1, (hipStream_t)stream);
     if (st1 != LR_OK) return st1;
   }
@@ -1407,7 +1407,7 @@ extern "C" int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* 
   if (Cin_pad == 4 && Cin_real == 3 && Cout == 32 && KT == 3 && KH == 5 && KW == 5 && stride == 2 && pt == 1 &&
       ph == 2 && pw == 2) {
     const int nwg = LR_CONV1_WGRAD_WGS;   // persistent workgroups, partial sums reduced in fixed order
-    int st = lr_conv1_wgrad(false, false, x, dz, nullptr, nullptr, slabs, nullptr, B * T, T, Hin, Win, g.Ho, g.Wo, sample,
+    int st = lr_conv1_wgrad(false, false, x, dz, nullptr, slabs, nullptr, B * T, T, Hin, Win, g.Ho, g.Wo, sample,
                             e0, e1, (hipStream_t)stream);
     if (st != LR_OK) return st;
     LR_LAUNCH(conv_wgrad_slab_reduce_kernel, dim3(32 * 320 / 64), dim3(64, 16), 0, stream, (const float*)slabs, nwg,

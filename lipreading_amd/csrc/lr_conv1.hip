@@ -4,6 +4,7 @@
 #include "lr_common.h"
 #include "lr_conv_dev.h"
 #include <hip/hip_ext.h>
+#include <type_traits>
 
 namespace {
 
@@ -16,30 +17,28 @@ namespace {
 // input patch it needs ONCE into LDS: 3 frames x 35 x 35 pixels.  Every operand of the forward
 // product and of the weight gradient is then an LDS read at (pixel offset + tap offset): no im2col
 // staging, no barrier inside the K loop.
-// This first part — the 4-channel patch (8 bytes per pixel, 29 kB), c1_* — serves the WEIGHT GRADIENT
-// (and the tile walk both kernels share); the forward keeps a 3-channel patch of its own, f1_* below.
+// This first part — the 4-channel patch (8 bytes per pixel), c1_* — serves the WEIGHT GRADIENT (and the tile walk both
+// kernels share); the forward keeps a 3-channel patch of its own, f1_* below.
 constexpr int C1_T = 16;                       // output tile edge
 constexpr int C1_P = 2 * C1_T + 3;             // patch edge (stride 2, 5x5 taps): 35
 constexpr int C1_PIX = C1_T * C1_T;            // 256 output pixels = 8 MFMA row tiles
-constexpr int C1_PATCH = 3 * C1_P * C1_P * 4;  // bf16 elements of the patch
-
-constexpr int C1_FPIX = C1_P * C1_P;          // pixels of one patch frame (1225)
-
-// The patch is a RING of three frames: a workgroup walks the tiles (t = 0, 1, 2, ...) of one spatial
-// window of one clip in order, so tile t only has to bring frame t+1 — frames t-1 and t are already
-// in LDS (FETCH_SIZE with a fresh 3-frame patch per tile: 3.4x the input; with the ring ~1.25x).
-// Frame ti of the clip lives in slot (ti + 1) % 3, i.e. temporal tap kt of tile t in slot (t + kt) % 3.
-// (Round 2's counters show two-way LDS bank conflicts in both kernels, 37 % / 44 % of their LDS cycles: an operand read
-// takes two output rows x 16 columns, i.e. every second pixel of input rows two apart, and both rows land on the same
-// half of the banks.  Shifting every second PAIR of patch rows by one pixel — 36-pixel rows — removed them and
-// changed neither kernel's time early in round 3, with this 4-channel patch in both.  The rebuilt forward is another
-// matter: there the LDS array WAS the bound and the conflict-free row stride gave 16 %, see F1_RB.)
-// tap = (kt*5 + kh)*5 + kw  ->  element offset inside the patch [3 slots][35][35][4]
-__device__ __forceinline__ int c1_tap_off(int tap, int t) {
-  if (tap >= 75) return -1;
-  const int kw = tap % 5, kh = (tap / 5) % 5, kt = tap / 25;
-  return ((((t + kt) % 3) * C1_P + kh) * C1_P + kw) * 4;
-}
+constexpr int C1_FPIX = C1_P * C1_P;           // pixels of one patch frame (1225)
+// The weight gradient's patch is a RING of frames: a workgroup walks the tiles (t = 0, 1, 2, ...) of one spatial
+// window of one clip in order, so tile t only has to bring frame t+1 — frames t-1 and t are already in LDS
+// (FETCH_SIZE with a fresh 3-frame patch per tile: 3.4x the input; with the ring ~1.25x).  Four slots: frame ti of
+// the clip lives in slot (ti + 1) & 3, i.e. temporal tap kt of tile t in slot (t + kt) & 3, and the fourth slot takes
+// frame t+2 while tile t is being contracted.
+// LDS layout of a slot: 44-pixel rows (352 B), 1568 pixels (12,544 B) per slot.  A transpose read of the patch takes,
+// per 32-lane group, 4 pixels x 8 consecutive taps, i.e. up to three patch rows: with the rows packed (280 B) two of
+// them share banks — two-way conflicts on most reads, 44 % of the kernel's LDS cycles in round 3
+// (SQ_LDS_BANK_CONFLICT) — with 352-byte rows the three rows sit 24 banks apart (modelled over every tap group and
+// ring rotation: 2.11 -> 1.02 cycles per lane group; measured: 11 % of the LDS cycles are conflicts now, the dZ
+// tile's stores included).  Patch column p (input x = 2 x0 - 2 + p) sits at pixel column p + C1_XOFF of its row: the
+// dword fill below stores from two pixels further left.
+constexpr int C1_RING = 4;
+constexpr int C1_RS = 44;                      // pixels between patch rows in LDS
+constexpr int C1_FS = 1568;                    // pixels between the ring's frame slots
+constexpr int C1_XOFF = 2;
 
 // Frame kt (0..2) of tile (f = b*T + t, rows 2*y0-2.., cols 2*x0-2..): 1225 8-byte pixels, 5 per
 // thread.  Split into "issue every global load" and "write to LDS" so that the NEXT tile's new frame
@@ -113,9 +112,9 @@ __device__ __forceinline__ void c1_frame_issue(const bf16_t* __restrict__ X, con
   }
 }
 template <bool U8>
-__device__ __forceinline__ void c1_frame_store(bf16_t* Ps, const uint2 (&rp)[C1_NPU], const unsigned (&rb)[C1_NPU],
-                                               int tid, int t, int kt) {
-  bf16_t* slot = Ps + ((t + kt) % 3) * C1_FPIX * 4;
+__device__ __forceinline__ void c1_frame_store(bf16_t* Ps, const C1Pix& pm, const uint2 (&rp)[C1_NPU],
+                                               const unsigned (&rb)[C1_NPU], int tid, int t, int kt) {
+  bf16_t* slot = Ps + (((t + kt) & (C1_RING - 1)) * C1_FS + C1_XOFF) * 4;
 #pragma unroll
   for (int i = 0; i < C1_NPU; ++i) {
     const int e = tid + i * 256;
@@ -128,7 +127,7 @@ __device__ __forceinline__ void c1_frame_store(bf16_t* Ps, const uint2 (&rp)[C1_
     }
     v.x = ok ? v.x : 0u;
     v.y = ok ? v.y : 0u;
-    *reinterpret_cast<uint2*>(&slot[e * 4]) = v;
+    *reinterpret_cast<uint2*>(&slot[(pm.py[i] * C1_RS + pm.px[i]) * 4]) = v;
   }
 }
 // first tile of a walk: frames t-1 and t are fetched synchronously (once per ~28 tiles)
@@ -140,7 +139,7 @@ __device__ __forceinline__ void c1_walk_start(const bf16_t* __restrict__ X, cons
     uint2 r[C1_NPU];
     unsigned r3[C1_NPU];
     c1_frame_issue<U8>(X, pm, r, r3, f, t, T, Hin, Win, y0, x0, kt);
-    c1_frame_store<U8>(Ps, r, r3, tid, t, kt);
+    c1_frame_store<U8>(Ps, pm, r, r3, tid, t, kt);
   }
 }
 
@@ -514,183 +513,373 @@ __global__ __launch_bounds__(256) void conv1_fwd_patch_kernel(const bf16_t* __re
   }
 }
 
-// weight gradient of the first layer: slab[wg][n][k] = sum over the workgroup's tiles of
-// dZ[pix][n] * patch(pix, k).  Wave w owns column tiles w, w+4, w+8 of the 10 (320 columns).
-// POOLED: the layer's forward fused ReLU + MaxPool (lr_conv3d_forward_pooled), and instead of a
-// materialised dZ the kernel takes the pooled gradient dP, the pooled activation and the window
-// codes and rebuilds its dZ tile on the way into LDS (a window's gradient goes to position `code` if
-// the pooled activation is > 0) — the 354 MB dZ of this layer is never written or read.  The bias
-// gradient (column sums of dZ) falls out of the same pass: bias_part[wg][32].
-template <bool POOLED, bool U8>
-__global__ __launch_bounds__(256) void conv1_wgrad_patch_kernel(const bf16_t* __restrict__ X,
+// ---------------------------------------------------------------------------------------------
+// weight gradient: slab[wg][n][k] = sum over the workgroup's tiles of dZ[pix][n] * patch(pix, k)
+// ---------------------------------------------------------------------------------------------
+// POOLED: the layer's forward fused ReLU + MaxPool (lr_conv3d_forward_pooled), and instead of a materialised dZ the
+// kernel takes the pooled gradient dP and the window codes and rebuilds its dZ tile on the way into LDS (a window's
+// gradient goes to position `code`; code 4 — ReLU blocked the window — to none): the 354 MB dZ of this layer is never
+// written or read, and neither is the pooled activation (round 3 read it for the ReLU mask the codes carry: 88 MB).
+// The bias gradient (column sums of dZ) falls out of the same pass: bias_part[wg][32].
+// Both operands are read with LDS transpose reads: the contraction runs over PIXELS, the slow axis of the channels-
+// last dZ tile and of the patch.  dZ tile: [pixel][32 channels], 64 B per pixel (4 pixels = 256 contiguous bytes per
+// read).  im2col column (tap, c): a lane's 8 bytes are the 4 channels of one tap at one pixel, so the 16 source
+// lanes of a read cover 4 pixels x 4 taps.
+//
+// Three ROLES in one 768-thread workgroup per CU, a wave of each on every SIMD:
+//   waves 0..3  (contract) run the MFMAs of tile q out of one dZ buffer and three slots of the patch ring, while
+//   waves 4..7  (frame)    bring tile q + 1's new frame of the ring from the raw clip and
+//   waves 8..11 (dZ)       un-pool tile q + 1's gradient into the other dZ buffer;
+// ONE barrier per tile hands tile q + 1 over and tile q - 1's buffers back.  (Rounds 2-4 alternated a fill phase —
+// ~300 vector instructions per wave — and a contraction phase — 48 MFMAs — in every wave, two barriers per tile,
+// two 256-thread workgroups per CU: 144 us, matrix pipes busy 45 % of the time, a third workgroup per CU slower.
+// With the roles the fill's vector instructions issue beside the contraction's MFMAs: 114 us in the step.  What is
+// left: the matrix pipe's 1.28 k cycles per tile and the fills' ~1.1 k cycles of vector issue per SIMD add up rather
+// than overlap — period 2.45 k cycles, SQ counters of the round — so the kernel is bound by the vector instructions
+// of the fills; measured and dropped on that road: un-pooling by scatter (zero the window, eight 2-byte stores at
+// the position the code names: a quarter fewer vector instructions, 5x the LDS bank conflicts, 133 us), static
+// wave priorities either way (no change / slower), loads four tiles ahead with masks at the store (fills alone 15 %
+// faster, kernel 4 % slower).)
+//   LDS: a ring of FOUR frame slots (tile t reads frames t-1, t, t+1; the frame role writes frame t+2) + TWO dZ tiles
+//        = 4 x 12,544 + 2 x 16,384 = 82,944 bytes.
+//   A walk start (a new spatial window: all three frames are new) cannot be staged under the previous tile — it
+//   would overwrite slots that tile reads — so the roles take one extra barrier there (once per 75 tiles).
+// The contraction splits K as well as N: wave w takes pixel rows 8 (w >> 1) .. + 7 of the tile (8 k steps) and column
+// tiles 5 (w & 1) .. + 4 — 40 MFMAs on every wave (with 3 / 3 / 2 / 2 column tiles per wave: 48 on two waves) and
+// 192 instead of 224 transpose-read pairs per tile; the two k halves are added once, through LDS, when the workgroup
+// has walked all its tiles.  Columns of taps 75..79 (the im2col matrix has 80 tap columns for 75 taps) are never
+// read back: their lanes read tap 74's pixels — a broadcast — where round 3 kept a zone of zeros for them, and
+// column tiles 10, 11 are not computed at all.
+// The raw clip in DWORDS.  A patch row starts at x = 2 x0 - 2 = 2 mod 4 (x0 is a multiple of 16), so the ten aligned
+// dwords from x = 2 x0 - 4 cover it (40 pixels for 35; the 44-pixel LDS rows hold them: columns 0, 1 and 37..39 are
+// never read).  A frame is 35 x 10 = 350 units of (3 planes x 4 pixels): three dword loads, v_cvt_f32_ubyte0..3
+// straight out of them, two 16-byte LDS stores — against 4 x 3 byte loads, per-pixel address arithmetic and four
+// 8-byte stores for the same pixels (fill role alone, loads only: 72 us with byte loads).  Needs Win % 4 == 0 and a
+// 4-byte aligned clip (the host picks the byte path otherwise).
+constexpr int C1W_UD = 10, C1W_UNITS = C1_P * C1W_UD, C1W_NU = (C1W_UNITS + 255) / 256;   // 350 units, 2 per thread
+// Units outside the image, the clip or the frame's 350 load nothing and convert their zeros to zeros: no validity mask
+// reaches the store.  (The loads therefore sit in a branch, and hipcc, which cannot count loads issued in a branch,
+// waits for every load in flight at the first use of a staging register: the fill roles run one tile ahead of their
+// loads.  Unconditional loads, four tiles ahead, with a mask applied at the store — measured — run the fills alone
+// 15 % faster and the kernel 4 % slower.)
+struct C1Units { unsigned a[C1W_NU], b[C1W_NU], c[C1W_NU]; };
+__device__ __forceinline__ void c1w_units_issue(const bf16_t* __restrict__ X, C1Units& r, int tid, int f, int t, int T,
+                                                int Hin, int Win, int y0, int x0, int kt) {
+  const int ti = t + kt - 1;
+  const bool frame_ok = ti >= 0 && ti < T;
+  const int64_t fr = frame_ok ? f + kt - 1 : f;
+  const int yb = 2 * y0 - 2, xd = 2 * x0 - 4;
+  const int64_t plane = (int64_t)Hin * Win;
+  const unsigned char* p0 = reinterpret_cast<const unsigned char*>(X) + fr * 3 * plane;
+#pragma unroll
+  for (int i = 0; i < C1W_NU; ++i) {
+    const int u = tid + 256 * i, ur = u / C1W_UD, ud = u - ur * C1W_UD;
+    const int y = yb + ur, x = xd + 4 * ud;
+    r.a[i] = r.b[i] = r.c[i] = 0u;
+    if (frame_ok && u < C1W_UNITS && (unsigned)y < (unsigned)Hin && (unsigned)x < (unsigned)Win) {
+      const unsigned char* p = p0 + y * Win + x;
+      r.a[i] = *reinterpret_cast<const unsigned*>(p);
+      r.b[i] = *reinterpret_cast<const unsigned*>(p + plane);
+      r.c[i] = *reinterpret_cast<const unsigned*>(p + 2 * plane);
+    }
+  }
+}
+__device__ __forceinline__ uint2 c1w_pixel(float r, float g, float b) {   // value / 255 as lr_clip_to_ndhwc_bf16 has it
+  return make_uint2((unsigned)f2bf(r * (1.f / 255.f)) | ((unsigned)f2bf(g * (1.f / 255.f)) << 16),
+                    (unsigned)f2bf(b * (1.f / 255.f)));
+}
+__device__ __forceinline__ void c1w_units_store(bf16_t* Ps, const C1Units& r, int tid, int t, int kt) {
+  unsigned char* slot = reinterpret_cast<unsigned char*>(Ps) + ((t + kt) & (C1_RING - 1)) * (C1_FS * 8);
+#pragma unroll
+  for (int i = 0; i < C1W_NU; ++i) {
+    const int u = tid + 256 * i, ur = u / C1W_UD, ud = u - ur * C1W_UD;
+    if (u < C1W_UNITS) {
+      const unsigned a = r.a[i], b = r.b[i], c = r.c[i];
+      const uint2 p0 = c1w_pixel((float)(a & 0xffu), (float)(b & 0xffu), (float)(c & 0xffu));
+      const uint2 p1 = c1w_pixel((float)((a >> 8) & 0xffu), (float)((b >> 8) & 0xffu), (float)((c >> 8) & 0xffu));
+      const uint2 p2 = c1w_pixel((float)((a >> 16) & 0xffu), (float)((b >> 16) & 0xffu), (float)((c >> 16) & 0xffu));
+      const uint2 p3 = c1w_pixel((float)(a >> 24), (float)(b >> 24), (float)(c >> 24));
+      uint4* dst = reinterpret_cast<uint4*>(slot + (ur * C1_RS + 4 * ud) * 8);
+      dst[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
+      dst[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
+    }
+  }
+}
+constexpr int C1W_ZT = C1_PIX * 32;                                   // bf16 elements of one dZ tile
+constexpr int C1W_LDS = (C1_RING * C1_FS * 4 + 2 * C1W_ZT) * 2;      // bytes: 82,944
+template <bool POOLED, int UM>   // UM: X is 0 = bf16 NDHWC (4 channels), 1 = the raw uint8 clip read in bytes, 2 = in dwords
+__global__ __launch_bounds__(768) void conv1_wgrad_roles_kernel(const bf16_t* __restrict__ X,
                                                                 const bf16_t* __restrict__ dZ,
-                                                                const bf16_t* __restrict__ pooled,
                                                                 const unsigned char* __restrict__ code,
                                                                 float* __restrict__ slabs,
-                                                                float* __restrict__ bias_part, int frames,
-                                                                int T, int Hin, int Win, int Ho, int Wo) {
-  // Both operands are read with LDS transpose reads: the contraction runs over PIXELS, the slow axis
-  // of the channels-last dZ tile and of the patch.  dZ tile: [pixel][32 channels], 64 B per pixel (4
-  // pixels = 256 contiguous bytes per read).  im2col column (tap, c): a lane's 8 bytes are the 4
-  // channels of one tap at one pixel, so the 16 source lanes of a read cover 4 pixels x 4 taps.
+                                                                float* __restrict__ bias_part, int frames, int T,
+                                                                int Hin, int Win, int Ho, int Wo) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char c1w_lds[];
+  bf16_t* Ps = reinterpret_cast<bf16_t*>(c1w_lds);
+  bf16_t* Zs = Ps + C1_RING * C1_FS * 4;
   constexpr int ZLD = 32;
-  // the patch, then a zone of zeros the padded columns read: wide enough for the largest immediate of a k step
-  constexpr int ZERO_ELEMS = (15 * 2 * C1_P * 8 + 64 + 8 + 15) / 16 * 8;
-  __shared__ __attribute__((aligned(16))) bf16_t Ps[C1_PATCH + ZERO_ELEMS];
-  __shared__ __attribute__((aligned(16))) bf16_t Zs[C1_PIX * ZLD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lr = lane & 31, lk = lane >> 5;
-  const int sl = lane & 15, colhalf = (lane >> 4) & 1;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int tiles_x = (Wo + C1_T - 1) / C1_T, tiles_y = (Ho + C1_T - 1) / C1_T;
   const int64_t ntiles = (int64_t)frames * tiles_x * tiles_y;
-  // column tile jt = wave + 4j covers taps 8jt..8jt+7; this lane sources tap 8jt + 4 colhalf + (sl & 3)
-  f32x16 acc[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  for (int e = tid; e < ZERO_ELEMS; e += 256) Ps[C1_PATCH + e] = 0;
-
-  uint2 rp[C1_NPU];
-  unsigned rb[C1_NPU];
-  uint4 rz[POOLED ? 2 : 4];   // POOLED: pooled gradient and activation of this thread's window
-  uint2 rc = make_uint2(0u, 0u);
-  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int wpy = tid >> 5, wpx = (tid >> 2) & 7, wcg = tid & 3;   // POOLED: window (py, px) of the 8 x 8, 8 channels
-  const C1Pix pm = c1_pix(tid);
-  auto issue = [&](const C1Tile& c) {
-    const int f = c.f, y0 = c.y0, x0 = c.x0;
-    c1_frame_issue<U8, false>(X, pm, rp, rb, f, c.t, T, Hin, Win, y0, x0, 2);
-    if (POOLED) {
-      const int Hp = Ho >> 1, Wp = Wo >> 1;
-      const int yp = (y0 >> 1) + wpy, xp = (x0 >> 1) + wpx;
-      rz[0] = rz[1] = make_uint4(0u, 0u, 0u, 0u);
-      rc = make_uint2(0u, 0u);
-      if (yp < Hp && xp < Wp) {
-        const int64_t pi = (((int64_t)f * Hp + yp) * Wp + xp) * 32 + wcg * 8;
-        rz[0] = *reinterpret_cast<const uint4*>(dZ + pi);       // dP
-        rz[1] = *reinterpret_cast<const uint4*>(pooled + pi);
-        rc = *reinterpret_cast<const uint2*>(code + pi);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {   // dZ tile: 256 pixels x 32 channels in 16-byte units
-        const int e = tid + i * 256;
-        const int pix = e >> 2, u = e & 3;
-        const int y = y0 + (pix >> 4), x = x0 + (pix & 15);
-        rz[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (y < Ho && x < Wo) rz[i] = *reinterpret_cast<const uint4*>(dZ + (((int64_t)f * Ho + y) * Wo + x) * 32 + u * 8);
-      }
-    }
-  };
-  const unsigned char* PsB = reinterpret_cast<const unsigned char*>(Ps);
-  const unsigned char* ZsB = reinterpret_cast<const unsigned char*>(Zs);
   const int64_t q_end = ntiles * (blockIdx.x + 1) / gridDim.x;
   const int64_t q_begin = ntiles * blockIdx.x / gridDim.x;
-  int64_t q = q_begin;
-  C1Tile c = c1_tile(q < q_end ? q : 0, T, tiles_x, tiles_y);
-  if (q < q_end) issue(c);
-  for (; q < q_end; ++q) {
-    const C1Tile n = c1_next(c, T, tiles_x, tiles_y);
-    __syncthreads();
-    if (q == q_begin || c.t == 0) c1_walk_start<U8>(X, pm, Ps, c.f, c.t, T, Hin, Win, c.y0, c.x0, tid);
-    c1_frame_store<U8>(Ps, rp, rb, tid, c.t, 2);
-    if (POOLED) {
-      // rebuild the window's four dZ units (8 channels each): gradient at position `code`, if the
-      // pooled activation is positive
-      const unsigned gw[4] = {rz[0].x, rz[0].y, rz[0].z, rz[0].w}, pw_[4] = {rz[1].x, rz[1].y, rz[1].z, rz[1].w};
-      unsigned o[4][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+  float* out = slabs + (int64_t)blockIdx.x * 32 * 320;
+  float* red = reinterpret_cast<float*>(c1w_lds);   // end of the walk: 2 x 5 x 16 x 64 partial sums, then 256 x 8 bias sums
+  constexpr int RED_ACC = 2 * 5 * 16 * 64;
+
+  if (wave < 4) {
+    // ---------------- contract ----------------
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 31, lk = lane >> 5;
+    const int sl = lane & 15, colhalf = (lane >> 4) & 1;
+    const int khalf = wave >> 1, ct0 = (wave & 1) * 5;
+    f32x16 acc[5];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int wd = e >> 1, sh = (e & 1) * 16;
-        const float act = bf2f((bf16_t)((pw_[wd] >> sh) & 0xffffu));
-        const int arg = (int)(((e < 4 ? rc.x : rc.y) >> (8 * (e & 3))) & 3u);
-        const unsigned g = act > 0.f ? ((gw[wd] >> sh) & 0xffffu) : 0u;
-        bsum[e] += bf2f((bf16_t)g);
+    for (int j = 0; j < 5; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j == arg) o[j][wd] |= g << sh;
-      }
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const unsigned char* PsB = reinterpret_cast<const unsigned char*>(Ps);
+    const unsigned char* ZsB = reinterpret_cast<const unsigned char*>(Zs);
+    // this lane's taps (columns of taps 75..79 are never read back: their lanes read tap 74's pixels, a broadcast)
+    int tap_kt[5], tap_in[5];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int pix = (2 * wpy + (j >> 1)) * 16 + 2 * wpx + (j & 1);
-        *reinterpret_cast<uint4*>(&Zs[pix * ZLD + wcg * 8]) = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int e = tid + i * 256;
-        *reinterpret_cast<uint4*>(&Zs[(e >> 2) * ZLD + (e & 3) * 8]) = rz[i];
-      }
+    for (int j = 0; j < 5; ++j) {
+      int tap = (ct0 + j) * 8 + 4 * colhalf + (sl & 3);
+      tap = tap < 75 ? tap : 74;
+      tap_kt[j] = tap / 25;
+      tap_in[j] = ((((tap / 5) % 5) * C1_RS + tap % 5 + C1_XOFF) * 4) * 2 + (lk * 8 + (sl >> 2)) * 16 +
+                  khalf * 8 * (2 * C1_RS * 8);
     }
-    // byte offset of this lane's tap per column tile, and a mask that drops the pixel offset for the
-    // padded columns (taps >= 75, and the third tile of waves 2 and 3, which run it on zeros rather
-    // than branch: they would wait at the tile barrier anyway) so those read the zero zone
-    // A fragment address = lane base + an immediate: a k step is one tile row of 16 pixels (ks * 2 patch rows, ks *
-    // 1 KB of the dZ tile) and a lane's two 4-pixel groups are 4 pixels apart, so only the base depends on the lane
-    // (round 2 recomputed pixel and tap offsets per read: 212 vector instructions around the 48 MFMAs of a tile).
-    int pbase[3];
+    const int zlane = (lk * 8 + (sl >> 2)) * 64 + colhalf * 32 + (sl & 3) * 8 + khalf * 8 * 1024;
+    // Software-pipelined across tiles: the barrier that hands tile q + 1 over sits between the READS of tile q's last
+    // k step and its MFMAs, and the first reads of tile q + 1 are issued right behind it — those MFMAs cover their
+    // latency (at the top of the tile loop the twelve reads of a tile's first k step were exposed: the contraction
+    // alone took 1.85 k cycles per tile for 1.28 k of MFMAs).
+    int64_t q = q_begin;
+    C1Tile c = c1_tile(q < q_end ? q : 0, T, tiles_x, tiles_y);
+    int pbase[5], zbase = 0;
+    bf16x8 fa[2], fb[2][5];
+    auto bases = [&](const C1Tile& tl, int64_t qq) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int tap = (wave + 4 * j) * 8 + 4 * colhalf + (sl & 3);
-      const int o = (wave + 4 * j) < 10 ? c1_tap_off(tap, c.t) : -1;
-      pbase[j] = o >= 0 ? o * 2 + (lk * 8 + (sl >> 2)) * 16 : C1_PATCH * 2;
-    }
-    __syncthreads();
-    if (q + 1 < q_end) issue(n);
-    // 16 k steps (16 pixels each), fully unrolled; the transpose reads of step ks+1 fly during the
-    // MFMAs of step ks (fragments double buffered by parity, interleave pinned below)
-    const int zbase = (lk * 8 + (sl >> 2)) * 64 + colhalf * 32 + (sl & 3) * 8;
-    bf16x8 fa[2], fb[2][3];
-    auto load_k = [&](int ks, bf16x8& a, bf16x8 (&b)[3]) {
-      // this lane's source pixels of the two 4-pixel groups: k = lk*8 + {0..3 | 4..7} of tile row ks
+      for (int j = 0; j < 5; ++j) pbase[j] = ((tl.t + tap_kt[j]) & 3) * (C1_FS * 8) + tap_in[j];
+      zbase = zlane + (int)(qq & 1) * (C1W_ZT * 2);
+    };
+    auto load_k = [&](int ks, bf16x8& a, bf16x8 (&b)[5]) {
       a = lds_tr_pair(ZsB, zbase + ks * 1024, zbase + ks * 1024 + 256);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) b[j] = lds_tr_pair(PsB, pbase[j] + ks * (2 * C1_P * 8), pbase[j] + ks * (2 * C1_P * 8) + 64);
+      for (int j = 0; j < 5; ++j)
+        b[j] = lds_tr_pair(PsB, pbase[j] + ks * (2 * C1_RS * 8), pbase[j] + ks * (2 * C1_RS * 8) + 64);
     };
-    constexpr int KS = C1_PIX / 16;
-    load_k(0, fa[0], fb[0]);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) load_k(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1], fb[ks & 1][j], acc[j], 0, 0, 0);
+    if (q < q_end) {
+      bases(c, q);
+      __syncthreads();   // the first tile is staged
+      load_k(0, fa[0], fb[0]);
     }
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    auto steps_0_to_6 = [&]() {
 #pragma unroll
-    for (int ks = 0; ks + 1 < KS; ++ks) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      for (int ks = 0; ks < 7; ++ks) {
+        load_k(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1], fb[ks & 1][j], acc[j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 7; ++ks) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+    };
+    auto step_7 = [&]() {
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1][j], acc[j], 0, 0, 0);
+    };
+    // (the last tile is peeled off: with "is there a next tile" as a branch inside the loop, the paths merge in front of
+    // step 7's MFMAs and hipcc makes them wait for the NEW tile's reads)
+    for (; q + 1 < q_end; ++q) {
+      const C1Tile n = c1_next(c, T, tiles_x, tiles_y);
+      steps_0_to_6();
+      bases(n, q + 1);
+      if (n.t == 0) __syncthreads();   // walk start: the frame role waits for this tile's reads
+      __syncthreads();                 // tile q + 1 is staged (and this tile's reads are done)
+      load_k(0, fa[0], fb[0]);
+      step_7();
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+      c = n;
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-    c = n;
-  }
-  float* out = slabs + (int64_t)blockIdx.x * 32 * 320;
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    if (wave + 4 * j < 10) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        out[((r & 3) + 8 * (r >> 2) + 4 * lk) * 320 + (wave + 4 * j) * 32 + lr] = acc[j][r];
+    if (q < q_end) {
+      steps_0_to_6();
+      step_7();
     }
-  }
-  if (POOLED && bias_part) {   // column sums of this workgroup's dZ tiles, fixed order
+    __syncthreads();   // every read of the walk is done: LDS becomes the reduction buffer
+    if (khalf == 1) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(((wave & 1) * 5 + j) * 16 + r) * 64 + lane] = acc[j][r];
+    }
     __syncthreads();
-    float* red = reinterpret_cast<float*>(Zs);   // 256 x 8 floats
+    if (khalf == 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bsum[e];
-    __syncthreads();
-    if (tid < 32) {
-      const int gq = tid >> 3, e = tid & 7;
-      float sacc = 0.f;
-      for (int w = 0; w < 64; ++w) sacc += red[(w * 4 + gq) * 8 + e];
-      bias_part[(int64_t)blockIdx.x * 32 + tid] = sacc;
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          out[((r & 3) + 8 * (r >> 2) + 4 * lk) * 320 + (ct0 + j) * 32 + lr] =
+              acc[j][r] + red[(((wave & 1) * 5 + j) * 16 + r) * 64 + lane];
     }
+    return;
+  }
+
+  // ---------------- fill ----------------
+  // Two fill roles: waves 4..7 bring the patch ring's new frame, waves 8..11 the dZ tile (each alone would take longer
+  // than the contraction: 95 us for both in one role with the contraction switched off, against its 78).  Two sets of
+  // staging registers, the tile loop unrolled by two: a tile's loads are issued when the tile before it has been staged.
+  constexpr bool U8 = UM != 0;
+  const bool frame_role = wave < 8;
+  const int tid = threadIdx.x - (frame_role ? 256 : 512);
+  int64_t q = q_begin;
+  C1Tile c0 = c1_tile(q < q_end ? q : 0, T, tiles_x, tiles_y);
+  C1Tile c1 = c1_next(c0, T, tiles_x, tiles_y);
+  // the tile loop both fill roles run: stage(S, tile, q) writes tile q out of the staging registers S into LDS,
+  // issue(S, tile) loads a tile into them
+  auto walk = [&](auto& S0, auto& S1, auto&& issue, auto&& stage) {
+    if (q < q_end) issue(S0, c0);
+    if (q + 1 < q_end) issue(S1, c1);
+    for (; q < q_end; q += 2) {
+      const C1Tile c2 = c1_next(c1, T, tiles_x, tiles_y);
+      stage(S0, c0, q);
+      if (q + 2 < q_end) issue(S0, c2);
+      __syncthreads();   // tile q is staged (and the contraction is done with tile q - 1)
+      if (q + 1 < q_end) {
+        const C1Tile c3 = c1_next(c2, T, tiles_x, tiles_y);
+        stage(S1, c1, q + 1);
+        if (q + 3 < q_end) issue(S1, c3);
+        __syncthreads();
+        c0 = c2;
+        c1 = c3;
+      }
+    }
+    __syncthreads();
+  };
+  if (frame_role) {
+    struct Frame {
+      uint2 rp[UM == 2 ? 1 : C1_NPU];
+      unsigned rb[UM == 2 ? 1 : C1_NPU];
+      C1Units un;
+    };
+    const C1Pix pm = c1_pix(tid);
+    Frame S0, S1;
+    walk(S0, S1,
+         [&](Frame& S, const C1Tile& c) {
+           if constexpr (UM == 2) c1w_units_issue(X, S.un, tid, c.f, c.t, T, Hin, Win, c.y0, c.x0, 2);
+           else c1_frame_issue<U8, false>(X, pm, S.rp, S.rb, c.f, c.t, T, Hin, Win, c.y0, c.x0, 2);
+         },
+         [&](const Frame& S, const C1Tile& c, int64_t qq) {
+           if (qq == q_begin || c.t == 0) {
+             if (qq != q_begin) __syncthreads();   // the previous tile still reads the slots a walk start rewrites
+             if constexpr (UM == 2) {
+#pragma unroll 1
+               for (int kt = 0; kt < 2; ++kt) {
+                 C1Units w;
+                 c1w_units_issue(X, w, tid, c.f, c.t, T, Hin, Win, c.y0, c.x0, kt);
+                 c1w_units_store(Ps, w, tid, c.t, kt);
+               }
+             } else {
+               c1_walk_start<U8>(X, pm, Ps, c.f, c.t, T, Hin, Win, c.y0, c.x0, tid);
+             }
+           }
+           if constexpr (UM == 2) c1w_units_store(Ps, S.un, tid, c.t, 2);
+           else c1_frame_store<U8>(Ps, pm, S.rp, S.rb, tid, c.t, 2);
+         });
+    __syncthreads();
+    return;
+  }
+  struct Grad {
+    uint4 rz[POOLED ? 1 : 4];   // POOLED: the pooled gradient of this thread's window (8 channels)
+    uint2 rc;
+  };
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int wpy = tid >> 5, wpx = (tid >> 2) & 7, wcg = tid & 3;   // POOLED: window (py, px) of the 8 x 8, 8 channels
+  Grad G0, G1;
+  walk(G0, G1,
+       [&](Grad& S, const C1Tile& c) {
+         const int f = c.f, y0 = c.y0, x0 = c.x0;
+         if (POOLED) {
+           const int Hp = Ho >> 1, Wp = Wo >> 1;
+           const int yp = (y0 >> 1) + wpy, xp = (x0 >> 1) + wpx;
+           S.rz[0] = make_uint4(0u, 0u, 0u, 0u);
+           S.rc = make_uint2(0u, 0u);
+           if (yp < Hp && xp < Wp) {
+             const int64_t pi = (((int64_t)f * Hp + yp) * Wp + xp) * 32 + wcg * 8;
+             S.rz[0] = *reinterpret_cast<const uint4*>(dZ + pi);       // dP
+             S.rc = *reinterpret_cast<const uint2*>(code + pi);
+           }
+         } else {
+#pragma unroll
+           for (int i = 0; i < 4; ++i) {   // dZ tile: 256 pixels x 32 channels in 16-byte units
+             const int e = tid + i * 256;
+             const int pix = e >> 2, u = e & 3;
+             const int y = y0 + (pix >> 4), x = x0 + (pix & 15);
+             S.rz[i] = make_uint4(0u, 0u, 0u, 0u);
+             if (y < Ho && x < Wo)
+               S.rz[i] = *reinterpret_cast<const uint4*>(dZ + (((int64_t)f * Ho + y) * Wo + x) * 32 + u * 8);
+           }
+         }
+       },
+       [&](const Grad& S, const C1Tile& c, int64_t qq) {
+         if (qq != q_begin && c.t == 0) __syncthreads();   // (the frame role's walk start)
+         bf16_t* Zq = Zs + (int)(qq & 1) * C1W_ZT;
+         if (POOLED) {
+           // rebuild the window's four dZ units (8 channels each): the gradient goes to position `code` (code 4 —
+           // ReLU blocked the window — to none); at most one unit holds it, so their OR is what the bias gradient sums
+           uint4 o[4];
+           unpool8(S.rz[0], S.rc, o);
+           const unsigned gw[4] = {o[0].x | o[1].x | o[2].x | o[3].x, o[0].y | o[1].y | o[2].y | o[3].y,
+                                   o[0].z | o[1].z | o[2].z | o[3].z, o[0].w | o[1].w | o[2].w | o[3].w};
+#pragma unroll
+           for (int wd = 0; wd < 4; ++wd) {
+             bsum[2 * wd] += __uint_as_float(gw[wd] << 16);
+             bsum[2 * wd + 1] += __uint_as_float(gw[wd] & 0xffff0000u);
+           }
+           // store s writes position s of the even windows and s ^ 1 of the odd ones: the two windows of an 8-lane
+           // store group then land on different halves of the 32 banks (pixels 2 apart are 128 bytes apart: the same
+           // banks)
+           const bool oddw = (wpx & 1) != 0;
+#pragma unroll
+           for (int sidx = 0; sidx < 4; ++sidx) {
+             const uint4 a = o[sidx], b = o[sidx ^ 1];
+             const uint4 v = make_uint4(oddw ? b.x : a.x, oddw ? b.y : a.y, oddw ? b.z : a.z, oddw ? b.w : a.w);
+             const int j = sidx ^ (wpx & 1);
+             const int pix = (2 * wpy + (j >> 1)) * 16 + 2 * wpx + (j & 1);
+             *reinterpret_cast<uint4*>(&Zq[pix * ZLD + wcg * 8]) = v;
+           }
+         } else {
+#pragma unroll
+           for (int i = 0; i < 4; ++i) {
+             const int e = tid + i * 256;
+             *reinterpret_cast<uint4*>(&Zq[(e >> 2) * ZLD + (e & 3) * 8]) = S.rz[i];
+           }
+         }
+       });
+  if (POOLED && bias_part) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[RED_ACC + tid * 8 + e] = bsum[e];
+  }
+  __syncthreads();
+  if (POOLED && bias_part && tid < 32) {   // column sums of this workgroup's dZ tiles, fixed order
+    const int gq = tid >> 3, e = tid & 7;
+    float sacc = 0.f;
+    for (int w = 0; w < 64; ++w) sacc += red[RED_ACC + (w * 4 + gq) * 8 + e];
+    bias_part[(int64_t)blockIdx.x * 32 + tid] = sacc;
   }
 }
 
@@ -729,25 +918,35 @@ int lr_conv1_forward(bool pool, bool u8, const void* X, const void* Wp, const fl
   return lr_launch_status();
 }
 
-// pooled: dZ is the POOLED gradient and (pooled_act, code) rebuild the full-resolution one on the fly; bias_part (may
+// pooled: dZ is the POOLED gradient and the window codes rebuild the full-resolution one on the fly; bias_part (may
 // be null) receives LR_CONV1_WGRAD_WGS x 32 column sums.  slabs: LR_CONV1_WGRAD_WGS x 32 x 320 partial results.
-int lr_conv1_wgrad(bool pooled, bool u8, const void* X, const void* dZ, const void* pooled_act, const void* code,
-                   float* slabs, float* bias_part, int frames, int T, int Hin, int Win, int Ho, int Wo, bool sample,
-                   hipEvent_t e0, hipEvent_t e1, hipStream_t stream) {
+int lr_conv1_wgrad(bool pooled, bool u8, const void* X, const void* dZ, const void* code, float* slabs, float* bias_part,
+                   int frames, int T, int Hin, int Win, int Ho, int Wo, bool sample, hipEvent_t e0, hipEvent_t e1,
+                   hipStream_t stream) {
   const int nwg = LR_CONV1_WGRAD_WGS;
   lr_clear_error();
-#define LR_C1W(PV, U8V)                                                                                           \
+  static bool attr[4] = {false, false, false, false};
+#define LR_C1W(IDX, PV, UMV)                                                                                      \
   do {                                                                                                           \
-    if (sample) hipExtLaunchKernelGGL((conv1_wgrad_patch_kernel<PV, U8V>), dim3(nwg), dim3(256), 0, stream, e0,   \
-                                      e1, 0, (const bf16_t*)X, (const bf16_t*)dZ, (const bf16_t*)pooled_act,      \
-                                      (const unsigned char*)code, slabs, bias_part, frames, T, Hin, Win, Ho, Wo); \
-    else hipLaunchKernelGGL((conv1_wgrad_patch_kernel<PV, U8V>), dim3(nwg), dim3(256), 0, stream,                 \
-                            (const bf16_t*)X, (const bf16_t*)dZ, (const bf16_t*)pooled_act,                       \
-                            (const unsigned char*)code, slabs, bias_part, frames, T, Hin, Win, Ho, Wo);           \
+    if (!attr[IDX]) {                                                                                            \
+      if (hipFuncSetAttribute((const void*)conv1_wgrad_roles_kernel<PV, UMV>,                                     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, C1W_LDS) != hipSuccess)                \
+        return LR_ERR_LAUNCH;                                                                                    \
+      attr[IDX] = true;                                                                                          \
+    }                                                                                                            \
+    if (sample) hipExtLaunchKernelGGL((conv1_wgrad_roles_kernel<PV, UMV>), dim3(nwg), dim3(768), C1W_LDS, stream, \
+                                      e0, e1, 0, (const bf16_t*)X, (const bf16_t*)dZ, (const unsigned char*)code, \
+                                      slabs, bias_part, frames, T, Hin, Win, Ho, Wo);                            \
+    else hipLaunchKernelGGL((conv1_wgrad_roles_kernel<PV, UMV>), dim3(nwg), dim3(768), C1W_LDS, stream,           \
+                            (const bf16_t*)X, (const bf16_t*)dZ, (const unsigned char*)code, slabs, bias_part,   \
+                            frames, T, Hin, Win, Ho, Wo);                                                        \
   } while (0)
-  if (pooled && u8) LR_C1W(true, true);
-  else if (pooled) LR_C1W(true, false);
-  else if (!u8) LR_C1W(false, false);
+  // the raw clip in dwords: rows of whole dwords at an aligned base (tiles start at multiples of 16 output columns)
+  const bool dwords = Win % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 3u) == 0;
+  if (pooled && u8 && dwords) LR_C1W(0, true, 2);
+  else if (pooled && u8) LR_C1W(1, true, 1);
+  else if (pooled) LR_C1W(2, true, 0);
+  else if (!u8) LR_C1W(3, false, 0);
   else return LR_ERR_UNSUPPORTED;
 #undef LR_C1W
   return lr_launch_status();

@@ -198,18 +198,22 @@ def test_data_gradients_that_unpool_on_the_fly_equal_the_staged_ones(dev, B, T, 
   assert int(code.max()) == 4 and bool(((code == 4) == (pooled.float() == 0)).all())
 
 
-def test_first_layer_fused_paths_equal_the_staged_ones(dev):
-  """The first layer's kernels read the raw uint8 clip and its weight gradient rebuilds dZ from the
-  pooled tensors on the fly (lr_conv3d_forward_pooled flags & 8, lr_conv3d_wgrad_pooled).  Staged
-  reference: lr_clip_to_ndhwc_bf16 copy, lr_unpool_code_bf16 + lr_conv3d_wgrad on the materialised
-  dZ.  Same arithmetic on the same bf16 values: features and conv1.weight.grad are bit-identical,
-  the bias gradient is the same sum in another order."""
+@pytest.mark.parametrize("B,T,H,shift", [(2, 9, 96, 0), (2, 80, 96, 0), (3, 7, 64, 0), (2, 9, 96, 1), (1, 40, 96, 2)])
+def test_first_layer_fused_paths_equal_the_staged_ones(dev, B, T, H, shift):
+  """The first layer's kernels read the raw uint8 clip and its weight gradient rebuilds dZ from the pooled gradient and
+  the window codes on the fly (lr_conv3d_forward_pooled flags & 8, lr_conv3d_wgrad_pooled).  Staged reference:
+  lr_clip_to_ndhwc_bf16 copy, lr_unpool_code_bf16 + lr_conv3d_wgrad on the materialised dZ.  Same arithmetic on the
+  same bf16 values: features and conv1.weight.grad are bit-identical, the bias gradient is the same sum in another
+  order.  (2, 80, 96): 1440 tiles, five or six per workgroup of the weight gradient, walk starts (t = 0) in the middle
+  of a workgroup's range and a clip boundary; shift: the clip starts 1 / 2 bytes off a dword boundary, where the
+  weight gradient reads it in bytes instead of dwords and the forward in bytes instead of pairs."""
   from lipreading_amd import frontend as FE
   torch.manual_seed(9)
   fe = FE.ConvFrontend3D().to(dev)
   g = torch.Generator().manual_seed(10)
-  B, T, H = 2, 9, 96
-  clips = torch.randint(0, 256, (B, T, 3, H, H), generator=g, dtype=torch.uint8).to(dev)
+  raw = torch.randint(0, 256, (B * T * 3 * H * H + 4,), generator=g, dtype=torch.uint8).to(dev)
+  clips = raw[shift:shift + B * T * 3 * H * H].view(B, T, 3, H, H)
+  assert clips.data_ptr() % 4 == shift
   wgt = torch.randn(B, T, FE.feature_dim(H, H), generator=g).to(dev)
   res = {}
   for fused in (True, False):
