@@ -14,7 +14,7 @@ import sys
 PIXELS = {  # bench.py's conv names -> a substring of the kernel symbol
     "conv1_fwd": "conv1_fwd_patch_kernel", "conv2_fwd": "conv_patch_kernel<1, 2, true",
     "conv3_fwd": "conv_patch16_kernel<2, 3, true", "conv2_dgrad": "conv_patch_kernel<2, 1, false",
-    "conv3_dgrad": "conv_patch16_kernel<3, 2, false", "conv1_wgrad": "conv1_wgrad_patch_kernel",
+    "conv3_dgrad": "conv_patch16_kernel<3, 2, false", "conv1_wgrad": "conv1_wgrad_roles_kernel",
     "conv2_wgrad": "conv_wgrad_tr2_kernel<32", "conv3_wgrad": "conv_wgrad_tr2_kernel<64"}
 RECURRENT = {"rnn_fwd_step_kernel": "rnn_fwd_step_kernel", "rnn_bwd_step_kernel": "rnn_bwd_step_kernel",
              "gru256_fwd_pair_kernel": "gru256_fwd_pair_kernel", "gru256_bwd_pair_kernel": "gru256_bwd_pair_kernel",
