@@ -59,6 +59,9 @@ def feature_dim(H, W):
 # ms).  So: on exactly when the encoder has deferred work in flight; LIPREADING_CONV_WGRAD_SIDE=0 / 1 forces it.
 _WGRAD_SIDE_ENV = os.environ.get("LIPREADING_CONV_WGRAD_SIDE", "auto")
 _WGRAD_SIDE_STREAM = _WGRAD_SIDE_ENV != "0"
+# the side stream's weight half of a layer starts when the layer's pooled gradient exists (1) — beside the layer's OWN
+# data gradient — or (0, rounds 2-4) when that data gradient has finished, i.e. beside the layer BELOW's
+_WGRAD_EARLY = os.environ.get("LIPREADING_CONV_WGRAD_EARLY", "1") != "0"
 _conv_side = None
 
 
@@ -219,7 +222,13 @@ class _ConvFrontendFunction(torch.autograd.Function):
       dP_in = dP
       fused_dgrad = bool(li > 0 and coded and _FUSE_UNPOOL and frag and frag == L.lr_conv3d_dgrad_pooled_supported(
           ho, wo, cout, cin, kt, kh, kw, pt, ph, pw))
+      on_side = _WGRAD_SIDE_STREAM and direct and li > 0 and (_WGRAD_SIDE_ENV == "1" or _enc._deferred)
+      ready = None
       if fused_dgrad:
+        if on_side and _WGRAD_EARLY:
+          # everything the weight half reads (dP_in, the codes, the layer's input) and its workspace exist HERE
+          ready = torch.cuda.Event()
+          ready.record(torch.cuda.current_stream())
         dP = torch.empty((frames, h, w, cin), dtype=bf, device=dev)
         _C.check(L.lr_conv3d_dgrad_pooled(dP_in.data_ptr(), act.data_ptr(), wd.data_ptr(), dP.data_ptr(), B, T, ho, wo,
                                           cout, cin, kt, kh, kw, pt, ph, pw, st), "lr_conv3d_dgrad_pooled")
@@ -251,12 +260,14 @@ class _ConvFrontendFunction(torch.autograd.Function):
                  "lr_conv3d_wgrad")
         return dZ
 
-      on_side = _WGRAD_SIDE_STREAM and direct and li > 0 and (_WGRAD_SIDE_ENV == "1" or _enc._deferred)
       if on_side and fused_dgrad:
         # the whole weight half (un-pooling included) runs on a side stream beside the data gradient, joined at the
         # end of this backward
         side = _conv_side_stream(dev)
-        side.wait_stream(torch.cuda.current_stream())
+        if ready is not None:
+          side.wait_event(ready)
+        else:
+          side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
           dZ = weight_half(1, _C.stream_handle())
         side_keep.append((x_in, dZ, ws, dP_in))
