@@ -252,8 +252,8 @@ def parity_block(regime, model_name, layers, B, dev, train_steps=50):
   shape.  Landmarks regime: every stage is pinned to the reference, tolerance 1e-4 absolute (fp32).
   Pixels regime: the conv stage is build-defined; the oracle is F.conv3d with this repo's bf16 storage
   points emulated, then the reference's encoder and CTC — tolerance stated in DESIGN.md section 7; the loss of
-  the plain fp32 F.conv3d oracle (no bf16 anywhere) is reported beside it, both recurrences of the HIP path are
-  compared ('bf16' single plane = the default of this regime, 'split' = fp32-faithful), and the comparison is
+  the plain fp32 F.conv3d oracle (no bf16 anywhere) is reported beside it, the one-product input projection
+  ('bf16x1') is compared with the default, and the comparison is
   repeated on the weights after `train_steps` optimisation steps of the HIP path (peaked log-probs: a random
   initialisation's lattice is nearly flat, so its argmaxes sit within a rounding of a tie)."""
   import torch
@@ -313,7 +313,6 @@ def parity_block(regime, model_name, layers, B, dev, train_steps=50):
                     greedy_strings_equal=GreedyStrings.hip(lp_v, lens_d) == s_ref0)
 
       extra["other_paths_vs_the_same_oracle"] = {
-          "recurrence 'bf16' (single-plane operands; round 2's default)": variant("bf16", default_proj),
           "recurrence 'split' (fp32-faithful)": variant("split", default_proj),
           "recurrence 'split' + input projection 'bf16x1' (ONE bf16 product: W_ih rounded to bf16)": variant("split", "bf16x1")}
       lp_ref32 = oracle_lp(False)
@@ -531,8 +530,7 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
     enc = VideoEncoder(frame_dim, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
                        enable_ctc=not (attn and args.no_ctc), vocab_size=VOCAB, char2idx=default_char2idx())
   model = PixelLipReader(enc, ConvFrontend3D()) if pixels else enc
-  # experiment switch: 'f32' = step kernels in the pixel regime; 'bf16' = the one-launch recurrence with
-  # bf16 recurrent operands in a landmark regime too (not reference-faithful: reported as such)
+  # experiment switch: 'f32' = step kernels instead of the one-launch cluster recurrence
   if os.environ.get("LIPREADING_RECURRENCE") and hasattr(enc, "recurrence"):
     enc.recurrence = os.environ["LIPREADING_RECURRENCE"]
   if os.environ.get("LIPREADING_OVERLAP_WGRAD") and pixels:
@@ -744,25 +742,21 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
                   "frac_of_hbm_peak": round(ctc_bytes / (ctc_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
                   "note": "one workgroup per sample: %d workgroups on 256 CUs — latency-bound, ~1%% of the step" % B}
   by_kernel = {k: round(v[0], 3) for k, v in prof.items()}
-  # which recurrence ran, per direction of time: 'f32' one launch per step | 'split' one launch per layer pass on
-  # CU pairs (GRU-256) / 24-CU clusters (LSTM-768), bf16 hi+lo planes | 'bf16' one launch per pass, single plane.
+  # which recurrence ran: 'f32' one launch per step | 'split' one launch per layer pass on clusters of ceil(H / 32)
+  # (past 864 / 768 units: ceil(H / 16)) CUs, bf16 hi + lo planes (lr_rnn_cluster.hip)
   rec, rec_bwd = "f32", "f32"
-  kind = 0                       # 1: CU pairs (GRU-256), 2: clusters of ceil(H / 32) CUs (lr_rnn_cluster.hip)
+  kind = 0
   members = (H + 31) // 32
   if not tfm:
     mode_id = {"GRU": 0, "LSTM": 1, "RNN": 2}[rnn_type]
     want = getattr(enc, "recurrence", "f32")
-    if want == "bf16" and L.lr_rnn_persistent_supported(mode_id, B, T_FRAMES, frame_dim, H, D):
-      rec = rec_bwd = "bf16"
-    elif want in ("auto", "split"):
+    if want in ("auto", "split"):
       kind = L.lr_rnn_pair_supported(mode_id, B, T_FRAMES, frame_dim, H, D)
       rec = rec_bwd = "split" if kind else "f32"
   res["recurrence"] = rec if rec == rec_bwd else "%s forward / %s backward" % (rec, rec_bwd)
   pass_kernel = None
-  if rec == "bf16":
-    pass_kernel = "gru256_%s_persist_kernel"
-  elif rec == "split":
-    pass_kernel = "gru256_%s_pair_kernel" if kind == 1 else "rnnc_%%s_kernel<%d,%d>" % (G, members)
+  if rec == "split":
+    pass_kernel = "rnnc_%%s_kernel<%d,%d>" % (G, members)
   pass_names = {}
   for slot, which in (("rnn_fwd_step_kernel", "fwd"), ("rnn_bwd_step_kernel", "bwd")):
     if pass_kernel and slot in by_kernel:
@@ -833,7 +827,7 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
                               "one launch = %d steps)" % (pmc_path, T_FRAMES))
       except Exception:
         pass
-      cus = (2 if kind == 1 else members) if r_dom == "split" else 1
+      cus = members if r_dom == "split" else 1
       roofline = {"bound": "hbm", "kernel": pass_names[dom],
                   "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                   "traffic": pass_traffic, "traffic_source": pass_traffic_src,
@@ -885,10 +879,8 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
                        "accumulate) -> %d-layer Bi%s-%d (%s) -> Linear(%d,65) -> masked log-softmax -> CTC "
                        "'mean' (L=30+EOS) -> backward -> clip_grad_norm 50 -> Adam 1e-4"
                        % (B, layers, rnn_type, H,
-                          "input projection bf16x3; recurrence in one launch per pass, bf16 operands, fp32 "
-                          "accumulation and state" if rec == "bf16" else
-                          ("input projection bf16x3; recurrence in one launch per pass, bf16 hi+lo planes (fp32-faithful)"
-                           if rec == "split" else "input projection bf16x3, fp32 recurrence"), D * H))
+                          "input projection bf16x3; recurrence in one launch per pass, bf16 hi+lo planes (fp32-faithful)"
+                          if rec == "split" else "input projection bf16x3, fp32 recurrence", D * H))
   elif attn:
     res["workload"] = ("regime R+decoder (the reference's whole train step): landmarks (B=%d,T=75,68,3) f32 -> "
                        "1-layer %s%s-%d%s AND CharDecodingStep x31 "
@@ -908,10 +900,8 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
                        % (B, layers, rnn_type, H,
                           {"f32": "recurrence: one fp32-MFMA launch per time step",
                            "split": "recurrence: one launch per layer pass, W_hh and state as bf16 hi+lo planes held by a "
-                                    "%s, fp32 accumulation — fp32-faithful"
-                                    % ("pair of CUs per (sample, direction)" if kind == 1 else
-                                       "cluster of %d CUs per (direction, 8 samples)" % members),
-                           "bf16": "recurrence: one launch per layer pass, bf16 operands"}[rec], D * H))
+                                    "cluster of %d CUs per (direction, 8 samples), fp32 accumulation — fp32-faithful"
+                                    % members}[rec], D * H))
   return res
 
 
@@ -966,13 +956,9 @@ def main():
   order = {"both": ["pixels", "landmarks"],
            "all": ["pixels", "landmarks", "landmarks_attn", "pixels_tfm"]}.get(args.regime, [args.regime])
   results = [run_regime(args, r, world, rank, dev) for r in order]
-  # the reference-faithful regime once more on the OTHER recurrences: the per-step fp32 launches (every shape's
-  # fallback) and, GRU-256 only, the single-plane bf16 one-launch kernel (the pixel regime's choice)
+  # the reference-faithful regime once more on the OTHER recurrence: the per-step fp32 launches (every shape's fallback)
   options = {}
-  if "landmarks" in order and args.regime == "all" and MODELS[args.model][0] == "GRU" and MODELS[args.model][1] == 256:
-    for name in ("f32", "bf16"):
-      options[name] = run_regime(args, "landmarks", world, rank, dev, recurrence=name)
-  elif "landmarks" in order and args.regime in ("all", "landmarks"):
+  if "landmarks" in order and args.regime in ("all", "landmarks"):
     options["f32"] = run_regime(args, "landmarks", world, rank, dev, recurrence="f32")
   if rank == 0:
     head = results[0]
@@ -982,9 +968,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": ("bf16 (conv frontend, recurrent and input-projection operands; fp32 accumulation, state, CTC)"
-                  if head.get("recurrence") == "bf16" else "bf16 (conv frontend, fp32 accumulate) + f32 (encoder, CTC)")
-                 if head["regime"] == "pixels" else
+        "dtype": "bf16 (conv frontend, fp32 accumulate) + f32 (encoder, CTC)" if head["regime"] == "pixels" else
                  ("bf16 (conv frontend, fp32 accumulate) + f32 (transformer encoder, CTC)" if head["regime"] == "pixels_tfm" else "f32"),
         "data": "synthetic",
         "config": {"workload": head["workload"], "regime": head["regime"], "per_gpu_batch": args.batch,
@@ -1017,9 +1001,7 @@ def main():
       lm = out["regimes"]["landmarks"] if "landmarks" in out.get("regimes", {}) else (out if head["regime"] == "landmarks" else None)
       if lm is not None:
         base_loss = results[order.index("landmarks")]["loss"]
-        notes = {"f32": "VideoEncoder.recurrence = 'f32': one exact-fp32 MFMA launch per time step (the fallback of every shape)",
-                 "bf16": "VideoEncoder.recurrence = 'bf16': one launch per layer pass, single-plane bf16 recurrent operands "
-                         "(not reference-faithful; the build-defined pixel regime's choice)"}
+        notes = {"f32": "VideoEncoder.recurrence = 'f32': one exact-fp32 MFMA launch per time step (the fallback of every shape)"}
         lm["other_recurrences"] = {
             name: {"note": notes[name], "value": o["value"], "unit": "frames/s", "ms_per_step": o["ms_per_step"],
                    "final_loss": round(o["loss"], 6), "final_loss_delta_vs_default": round(o["loss"] - base_loss, 7)}

@@ -52,24 +52,19 @@ typedef enum lr_rnn_mode {
    * of x is already a bf16 value, so x needs no lo term, and dx goes to a bf16 consumer (the
    * frontend's backward), so dx is contracted from the hi terms only. */
   LR_RNN_INPUT_BF16_EXACT = 0x200,
-  /* Run the recurrence of a GRU layer with H = 256 as ONE launch per pass (forward and backward):
-   * W_hh rounded to bf16 lives in the registers + LDS of one compute unit per (sample, direction),
-   * the recurrent product runs on the bf16 matrix cores with fp32 accumulation, gate math and
-   * carried state (lr_rnn_persist.hip).  Build-defined (pixel regime, BASELINE configs[1] "bf16");
-   * other shapes return LR_ERR_UNSUPPORTED — query lr_rnn_persistent_supported first. */
-  LR_RNN_RECUR_BF16 = 0x400,
+  /* (0x400: rounds 1-4's single-plane bf16 recurrence, LR_RNN_RECUR_BF16 — removed in round 5: no shipped
+   * configuration ran it once the fp32-faithful one-launch kernels below covered every size) */
   /* with LR_RNN_PROJ_BF16X3 | LR_RNN_INPUT_BF16_EXACT and I % 8 == 0: x (and dx) are STORED as bf16
    * matrices [B*T][I] — the conv frontend's features as they are; x is then the hi plane of the
    * projection's operand and is never converted or packed. */
   LR_RNN_INPUT_STORED_BF16 = 0x800,
-  /* The recurrence of a supported layer (lr_rnn_pair_supported: 1 = GRU, H = 256; 2 = GRU or LSTM with
-   * ceil(H / 32) in {8, 16, 22, 24, 25}: H = 256, 512, 700, 768, 800 and the sizes that round up to them — the
-   * reference's config/defaults.txt:19-21, config/train/attn/attention_type:16-19, config/train/micro:6-8) as ONE
-   * launch per pass and fp32-FAITHFUL: W_hh and the carried state are split into bf16 hi + lo planes, all four
-   * cross terms accumulate in fp32 on the bf16 matrix cores (~1e-6 of the exact fp32 product, against ~1e-3
-   * for LR_RNN_RECUR_BF16).  W_hh stays in the registers + LDS of a pair of compute units per (sample,
-   * direction) (GRU-256) or of a cluster of ceil(H / 32) per (direction, 8 samples), which exchange their
-   * slices of the state (forward) / their partial state gradients (backward) once per step.  What the
+  /* The recurrence of a supported layer (lr_rnn_pair_supported != 0: GRU or LSTM, H % 4 == 0, H up to the largest
+   * cluster — the reference's config/defaults.txt:19-21, config/train/attn/attention_type:16-19, config/train/micro:6-8
+   * and the decoders behind them, better_model.py:134-148) as ONE launch per pass and fp32-FAITHFUL: W_hh and the
+   * carried state are split into bf16 hi + lo planes, all four cross terms accumulate in fp32 on the bf16 matrix cores
+   * (~1e-6 of the exact fp32 product).  W_hh stays in the registers + LDS of a cluster of ceil(H / 32) (past 864 /
+   * 768 units: ceil(H / 16)) compute units per (direction, 8 samples), which exchange their slices of the state
+   * (forward) / their partial state gradients (backward) once per step (lr_rnn_cluster.hip).  What the
    * reference-faithful regime runs by default where it is supported; the decoder loop (lr_decoder_forward /
    * _backward) takes the same cluster kernels, started from the encoder's final state, when every step is
    * teacher forced. */
@@ -191,8 +186,11 @@ int lr_sgemm(int transA, int transB, int M, int N, int K, float alpha, const flo
  *   h_n    [D,B,H]        final hidden state; c_n [D,B,H] (LSTM; may be NULL for GRU)
  *   reserve               saved activations for the backward pass (lr_rnn_reserve_bytes)
  * Pointer arrays (w_ih ...) are HOST arrays of D device pointers. */
-int lr_rnn_persistent_supported(int mode, int B, int T, int I, int H, int D);   /* see LR_RNN_RECUR_BF16 */
-int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D);         /* see LR_RNN_RECUR_SPLIT */
+int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D);         /* see LR_RNN_RECUR_SPLIT: 2 or 0 */
+/* ... and why not: 0 = the layer has a one-launch recurrence on this device now; 1 = no kernel for the shape; 2 =
+ * switched off by lr_rnn_one_launch_enable(0); 3 = switched off by the test hook lr_rnn_debug_disable_cluster; 4 = the
+ * device has too few compute units for a launch's clusters.  (What a caller says when it falls back.) */
+int lr_rnn_one_launch_status(int mode, int B, int T, int I, int H, int D);
 /* LR_RNN_RECUR_SPLIT's workgroups of a pair / cluster must be resident together (lr_rnn_pair_supported checks the
  * device's compute-unit count); their waits are bounded, and a member that gave up leaves garbage and raises the
  * device-side FAULT WORD.  The reference's contract for a batch it cannot use is assert / `None` => skip
@@ -211,8 +209,7 @@ int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D);         
  * lr_rnn_debug_drop_member   TEST HOOK: member `m` (>= 0) of every pair / cluster returns at once, so its partners
  *                      time out (a few tenths of a second) and raise the fault; -1 (default) = off.
  * lr_rnn_debug_disable_cluster   TEST HOOK: bit 0 makes lr_rnn_pair_supported answer 0 for the cluster shapes
- *                      (and the decoder loop take its step kernels), bit 1 switches the GRU-256 pair kernels off
- *                      (GRU-256 then takes the 8-member cluster kernels), bit 2 keeps the weight gradients of
+ *                      (and the decoder loop take its step kernels), bit 2 keeps the weight gradients of
  *                      LR_RNN_RECUR_SPLIT layers on the fp32 grouped GEMM, so the paths can be compared on one
  *                      model.  Size queries depend on it: set it BEFORE the forward whose backward it should cover.
  * lr_fault_export / lr_fault_import   data parallel (lipreading_amd/distributed.py): out2 = {status[0] (0 when
@@ -447,7 +444,7 @@ int lr_nll_mean_backward(const int64_t* labels, int64_t label_stride, int L, int
 
 /* ---- A10 (build-defined): transformer encoder blocks — no reference symbol ------ *
  * torch.nn.TransformerEncoderLayer(norm_first=False, activation=relu, dropout=0) arithmetic; the
- * host composition is lipreading_amd/transformer.py.  Contractions use lr_sgemm / lr_sgemm_batched. */
+ * host composition is lipreading_amd/transformer.py -> lr_tfm_* below; the pieces are entry points of their own. */
 
 /* batch_outer x batch_inner independent fp32 products C_z = alpha op(A_z) op(B_z) + beta C_z, problem
  * z = (o, i) at element offsets o*s?_outer + i*s?_inner from the base pointers (0: shared operand).
@@ -482,10 +479,67 @@ int lr_attn_fused_forward(const float* qkv, const int32_t* key_lens, float* out,
                           int nhead, int dh, lr_stream_t stream);
 int lr_attn_fused_backward(const float* qkv, const int32_t* key_lens, const float* dout, float* dqkv, float scale,
                            int B, int T, int nhead, int dh, lr_stream_t stream);
-int lr_relu_forward(const float* x, float* y, int64_t n, lr_stream_t stream);
-int lr_relu_backward(const float* y, const float* dy, float* dx, int64_t n, lr_stream_t stream);
-/* x[b][t][:] += pe[t][:]  (positional encoding) */
-int lr_add_rows(float* x, const float* pe, int B, int T, int D, lr_stream_t stream);
+/* Products straight from the tensors as they lie in memory (lr_fgemm.hip; BUILD-DEFINED, no reference symbol):
+ *   C[M][N] = epilogue(sum_k op(A)[m][k] op(B)[k][n]),  form NT: A [M][K], B [N][K];  NN: A [M][K], B [K][N];
+ *   TN: A [K][M], B [K][N].  prec LR_FGEMM_X3: fp32 operands split into bf16 hi + lo on the way into LDS, three
+ *   products on the bf16 matrix cores (~1e-5 relative); LR_FGEMM_F32: exact fp32 matrix-core products.  a_bf16 (NT
+ *   only) / b_bf16 (TN only): that operand is stored as bf16.  Epilogue per job: out = alpha * acc + bias[n] +
+ *   addend[(m % add_period) * ldadd + n]; LR_FGEMM_RELU; mask (out = mask[m * ldmask + n] > 0 ? out : 0); + beta * C;
+ *   LR_FGEMM_C_BF16: C is a bf16 matrix (beta must be 0).  colsum (TN only, splits <= 1): colsum[m] = beta *
+ *   colsum[m] + sum_k A[k][m] — the bias gradient of a weight-gradient product.  splits > 1: K is cut into that many
+ *   ranges whose partial sums go through `slabs` ([splits][M][N] floats) and one combine launch (lr_fgemm_splits
+ *   suggests a count).  Up to 20 jobs of one form share a launch.  Only enqueues. */
+#define LR_FGEMM_X3 0
+#define LR_FGEMM_F32 1
+#define LR_FGEMM_NT 0
+#define LR_FGEMM_NN 1
+#define LR_FGEMM_TN 2
+#define LR_FGEMM_RELU 1
+#define LR_FGEMM_C_BF16 2
+typedef struct {
+  const void* A;
+  const void* B;
+  void* C;
+  const float* bias;
+  const float* addend;
+  const float* mask;
+  float* colsum;
+  float* slabs;
+  int32_t M, N, K, lda, ldb, ldc, ldadd, add_period, ldmask, flags, splits;
+  float alpha, beta;
+} lr_fgemm_job;
+int lr_fgemm(int prec, int form, int a_bf16, int b_bf16, const lr_fgemm_job* jobs, int njobs, lr_stream_t stream);
+int lr_fgemm_splits(int M, int N, int K);
+
+/* The whole encoder stack of lipreading_amd/transformer.py as three enqueues (lr_transformer.hip):
+ *   h0 = x W_p^T + b_p + pe[t];  per layer (post-LN, ReLU feed-forward, dropout 0 — torch.nn.TransformerEncoderLayer):
+ *   qkv = h W_qkv^T + b;  a = attention(qkv, key_lens);  h1 = LN1(a W_o^T + b_o + h);
+ *   h2 = LN2(relu(h1 W_1^T + b_1) W_2^T + b_2 + h1).
+ * mode: LR_TFM_X3 (projections as split-bf16 products, else exact fp32) | LR_TFM_X_BF16 (x is stored as bf16) |
+ *   LR_TFM_DX_BF16 (dx is written as bf16) | LR_TFM_ATTN_FUSED (lr_attn_fused_*; else fp32 batched products + softmax).
+ * weights: 2 + 12 * nlayers device pointers in torch's registration order: input_proj.weight [Dm][I], .bias, then per
+ *   layer in_proj_weight [3Dm][Dm], in_proj_bias, out_proj.weight [Dm][Dm], .bias, linear1.weight [F][Dm], .bias,
+ *   linear2.weight [Dm][F], .bias, norm1.weight, .bias, norm2.weight, .bias.  pe: [>= T][Dm].
+ * forward: x [B*T][I] -> h_out [B*T][Dm]; `reserve` (lr_tfm_reserve_bytes) keeps what the backward reads.
+ * backward_data: dh_out -> dx (NULL: not wanted) and every layer's pre-activation gradients, kept in `workspace`
+ *   (lr_tfm_workspace_bytes); backward_weights (any stream that waits for backward_data) turns them into the 2 + 12 *
+ *   nlayers gradients: every weight gradient of the stack with its bias gradient in ONE launch (two when x is bf16),
+ *   the LayerNorm parameter gradients in one more; accumulate != 0 adds to `grads`. */
+#define LR_TFM_X3 1
+#define LR_TFM_X_BF16 2
+#define LR_TFM_DX_BF16 4
+#define LR_TFM_ATTN_FUSED 8
+size_t lr_tfm_reserve_bytes(int mode, int B, int T, int I, int Dm, int nhead, int F, int nlayers);
+size_t lr_tfm_workspace_bytes(int mode, int B, int T, int I, int Dm, int nhead, int F, int nlayers);
+int lr_tfm_forward(int mode, const void* x, const int32_t* key_lens, const float* const* weights, const float* pe,
+                   float* h_out, void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes, int B, int T,
+                   int I, int Dm, int nhead, int F, int nlayers, float eps, lr_stream_t stream);
+int lr_tfm_backward_data(int mode, const int32_t* key_lens, const float* const* weights, const float* dh_out, void* dx,
+                         void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes, int B, int T, int I,
+                         int Dm, int nhead, int F, int nlayers, lr_stream_t stream);
+int lr_tfm_backward_weights(int mode, const void* x, float* const* grads, int accumulate, void* reserve,
+                            size_t reserve_bytes, void* workspace, size_t workspace_bytes, int B, int T, int I, int Dm,
+                            int nhead, int F, int nlayers, lr_stream_t stream);
 
 /* ---- A4: CTC loss — src/train/ctc_loss.py:28-114 ---------------------------------------- */
 
@@ -681,7 +735,8 @@ int lr_f32_to_bf16(const float* in, void* out, int64_t n, lr_stream_t stream);
 
 /* Inter-layer dropout of nn.GRU / nn.LSTM(dropout = p) in training mode (better_model.py:47-49 hands rnn_dropout to
  * torch; every shipped config sets 0): mask[i] = 0 with probability p, else 1 / (1 - p) (Philox4x32-10, key = seed,
- * counter = i / 4: the same mask for a (seed, n) whatever the launch geometry), y = x * mask.  Backward: dx = dy * mask
+ * counter = i / 4: the same mask for a (seed, n) whatever the launch geometry), y = x * mask (x == y == NULL: only
+ * the mask is written — the decoder loop applies it inside its own kernels).  Backward: dx = dy * mask
  * (lr_mul_f32).  lr_cat_directions: (D, B, H) -> (B, D*H), forward direction first (better_model.py:98-112
  * _cat_directions), for one or two tensors (h, c) in one launch; inverse != 0: the way back (its gradient). */
 int lr_dropout_forward(const float* x, float* y, float* mask, int64_t n, float p, uint64_t seed, lr_stream_t stream);

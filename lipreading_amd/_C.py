@@ -13,6 +13,9 @@ _lib = None
 
 P = c_void_p  # every device pointer crosses the boundary as void*
 
+# lr_status (include/lipreading_hip.h)
+LR_OK, LR_ERR_INVALID_ARG, LR_ERR_WORKSPACE, LR_ERR_LAUNCH, LR_ERR_UNSUPPORTED, LR_ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
+
 # name -> (restype, argtypes); mirrors include/lipreading_hip.h declaration by declaration.
 SIGNATURES = {
     "lr_version": (c_int, []),
@@ -42,11 +45,15 @@ SIGNATURES = {
     "lr_attn_fused_supported": (c_int, [c_int, c_int]),
     "lr_attn_fused_forward": (c_int, [P, P, P, c_float, c_int, c_int, c_int, c_int, P]),
     "lr_attn_fused_backward": (c_int, [P, P, P, P, c_float, c_int, c_int, c_int, c_int, P]),
-    "lr_relu_forward": (c_int, [P, P, c_int64, P]),
-    "lr_relu_backward": (c_int, [P, P, P, c_int64, P]),
-    "lr_add_rows": (c_int, [P, P, c_int, c_int, c_int, P]),
-    "lr_rnn_persistent_supported": (c_int, [c_int] * 6),
+    "lr_fgemm": (c_int, [c_int, c_int, c_int, c_int, P, c_int, P]),
+    "lr_fgemm_splits": (c_int, [c_int, c_int, c_int]),
+    "lr_tfm_reserve_bytes": (c_size_t, [c_int] * 8),
+    "lr_tfm_workspace_bytes": (c_size_t, [c_int] * 8),
+    "lr_tfm_forward": (c_int, [c_int, P, P, P, P, P, P, c_size_t, P, c_size_t] + [c_int] * 7 + [c_float, P]),
+    "lr_tfm_backward_data": (c_int, [c_int, P, P, P, P, P, c_size_t, P, c_size_t] + [c_int] * 7 + [P]),
+    "lr_tfm_backward_weights": (c_int, [c_int, P, P, c_int, P, c_size_t, P, c_size_t] + [c_int] * 7 + [P]),
     "lr_rnn_pair_supported": (c_int, [c_int] * 6),
+    "lr_rnn_one_launch_status": (c_int, [c_int] * 6),
     "lr_rnn_pair_errors": (c_int, []),
     "lr_fault_words_ptr": (c_void_p, []),
     "lr_fault_export": (c_int, [P, P, P]),
@@ -135,6 +142,13 @@ class DecoderGrads(ctypes.Structure):
   """lr_decoder_grads."""
   _fields_ = [(n, c_void_p) for n in ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "attn_w1", "attn_b1", "attn_w2",
                                       "attn_b2", "w_c", "b_c", "w_o", "b_o")] + [("emb_padding_idx", c_int)]
+
+
+class FgemmJob(ctypes.Structure):
+  """lr_fgemm_job (include/lipreading_hip.h)."""
+  _fields_ = [(n, c_void_p) for n in ("A", "B", "C", "bias", "addend", "mask", "colsum", "slabs")] + \
+             [(n, ctypes.c_int32) for n in ("M", "N", "K", "lda", "ldb", "ldc", "ldadd", "add_period", "ldmask", "flags",
+                                            "splits")] + [("alpha", c_float), ("beta", c_float)]
 
 
 DEC_MAX_LAYERS = 8   # LR_DEC_MAX_LAYERS

@@ -231,17 +231,17 @@ class CharDecodingStep(nn.Module):
       # (0 with probability p, else 1 / (1 - p): lr_dropout_forward's Philox mask, seeded from torch's host generator)
       drop_mask = torch.empty((self.num_layers - 1, B, L, self.hidden_size), dtype=torch.float32,
                               device=encoder_hidden_states.device)
-      scratch = torch.empty_like(drop_mask)
-      _C.check(_C.lib().lr_dropout_forward(scratch.data_ptr(), scratch.data_ptr(), drop_mask.data_ptr(), drop_mask.numel(),
+      _C.check(_C.lib().lr_dropout_forward(None, None, drop_mask.data_ptr(), drop_mask.numel(),
                                            float(self.rnn_dropout), int(torch.randint(0, 2 ** 62, (1,)).item()),
                                            _C.stream_handle()), "lr_dropout_forward")
     enc = encoder_hidden_states.to(torch.float32).contiguous()
     if teacher_forced is None:
       teacher_forced = [True] * L
-    if L > 1 and mode != 2 and all(teacher_forced) and not _C.lib().lr_rnn_pair_supported(mode, B, L, self.hidden_size,
-                                                                                        self.hidden_size, 1):
-      from .encoder import _note_step_kernel_fallback
-      _note_step_kernel_fallback(self.rnn_type, self.hidden_size)   # (one warning per shape)
+    if L > 1 and mode != 2 and all(teacher_forced):
+      why = _C.lib().lr_rnn_one_launch_status(mode, B, L, self.hidden_size, self.hidden_size, 1)
+      if why != 0:
+        from .encoder import _note_step_kernel_fallback
+        _note_step_kernel_fallback(self.rnn_type, self.hidden_size, why)   # (one warning per shape and reason)
     if seed is None:
       # drawn from torch's (host) generator, so --seed / torch.manual_seed control the multinomial
       # draws of the loop as they do in the reference (train_better_model.py:63); no device sync

@@ -123,7 +123,6 @@ int32_t* lr_fault_words();
 int lr_device_cus();                // compute units of the current device, 0 without one
 int lr_debug_drop_member_value();
 int lr_debug_cluster_disabled();    // test hook (lr_rnn_debug_disable_cluster, bit 0): lr_rnn_cluster_supported answers 0
-int lr_debug_pair_disabled();       // (bit 1): lr_gru256_pair_supported answers 0
 int lr_debug_tune_value(int which);  // lr_rnn_debug_tune: exchange polling knobs of the cluster recurrence (0 forward, 1 backward)
 int lr_debug_wgrad_f32();           // (bit 2): LR_RNN_RECUR_SPLIT layers keep their weight gradients on the fp32 grouped GEMM   // test hook (lr_rnn_debug_drop_member): that member of every cluster / pair exits at once
 
@@ -160,31 +159,16 @@ int lr_sgemm_grouped_tn_impl(int n, const int* M, const int* N, const int* K, co
                              const float* const* B, const int* ldb, float* const* C, const int* ldc, float beta,
                              const int* row_shift, const int* period, void* workspace, size_t workspace_bytes,
                              hipStream_t stream);
-// lr_rnn_persist.hip: the GRU-256 recurrence as one launch per layer pass (bf16 recurrent operands)
-int lr_gru256_persist_supported(int G, int B, int H);
-size_t lr_gru256_persist_pack_bytes(int D);
-size_t lr_gru256_persist_bwd_pack_bytes(int D);
-int lr_gru256_persist_backward(const float* gates, const float* extra, const float* y, const float* dy,
-                               const float* dh_n, float* dG, const float* const* w_hh, const int32_t* lens,
-                               void* wpack, int B, int T, int D, hipStream_t stream);
-int lr_gru256_persist_forward(float* gates, float* extra, float* y, const float* const* w_hh, const float* const* b_hh,
-                              const int32_t* lens, void* wpack, int B, int T, int D, hipStream_t stream);
-// lr_rnn_pair.hip: the GRU-256 recurrence as one launch per layer pass, fp32-faithful (W_hh and the state
-// as bf16 hi + lo planes, a pair of CUs per (sample, direction), one granule exchange per step)
-int lr_gru256_pair_supported(int G, int B, int H);
-size_t lr_gru256_pair_pack_bytes(int D);
-size_t lr_gru256_pair_bwd_pack_bytes(int D);
-size_t lr_gru256_pair_xch_bytes(int B, int D, int backward);
-int lr_gru256_pair_forward(float* gates, float* extra, float* y, const float* const* w_hh, const float* const* b_hh,
-                           const int32_t* lens, void* wpack, void* xch, int B, int T, int D, hipStream_t stream);
-int lr_gru256_pair_backward(const float* gates, const float* extra, const float* y, const float* dy, const float* dh_n,
-                            float* dG, const float* const* w_hh, const int32_t* lens, void* wpack, void* xch, int B,
-                            int T, int D, hipStream_t stream);
+// lr_fgemm.hip: products straight from the tensors as they lie in memory (include/lipreading_hip.h lr_fgemm)
+int lr_fgemm_launch(int prec, int form, int a_bf16, int b_bf16, const lr_fgemm_job* jobs, int njobs, hipStream_t stream);
+int lr_fgemm_want_splits(int M, int N, int K);
+size_t lr_fgemm_slab_floats(int M, int N, int splits);
 // lr_rnn_cluster.hip: the GRU / LSTM recurrence as one launch per layer pass, fp32-faithful (W_hh sliced over a
 // cluster of ceil(H / 32) CUs per (direction, 8 samples), bf16 hi + lo planes, self-tagged 4-byte exchange words);
 // G = 3 (GRU) or 4 (LSTM); h0 / c0 (may be NULL) = the state before the first step, [D][B][H]; dh0 / dc0 (may be
 // NULL) receive the gradient into it
 int lr_rnn_cluster_supported(int G, int B, int H);
+int lr_rnn_cluster_cus(int G, int H);   // compute units one launch needs resident together; 0: no kernel for the shape
 size_t lr_rnn_cluster_pack_bytes(int G, int H, int D, int backward);
 size_t lr_rnn_cluster_xch_bytes(int B, int H, int D, int backward);
 // prologue_done: lr_rnn_cluster_prologue already ran for this pass (W_hh packed into wpack, the first launch's

@@ -507,7 +507,7 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-__global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mask, int64_t n,
+__global__ void dropout_fwd_kernel(const float* x, float* y, float* __restrict__ mask, int64_t n,
                                    float p, unsigned long long seed) {
   const float scale = 1.f / (1.f - p);
   const int64_t groups = (n + 3) >> 2;
@@ -522,7 +522,7 @@ __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restric
         const float u = (float)(r[e] >> 8) * (1.f / 16777216.f);
         const float m = u < p ? 0.f : scale;
         mask[i] = m;
-        y[i] = x[i] * m;
+        if (y) y[i] = x[i] * m;      // x == y == NULL: the mask alone
       }
     }
   }
@@ -551,7 +551,7 @@ __global__ void cat_directions_kernel(CatPtrs p, int nt, int B, int H, int D, in
 
 extern "C" int lr_dropout_forward(const float* x, float* y, float* mask, int64_t n, float p, uint64_t seed,
                                   lr_stream_t stream) {
-  LR_CHECK_ARG(x && y && mask && n > 0 && p >= 0.f && p < 1.f);
+  LR_CHECK_ARG(mask && ((x && y) || (!x && !y)) && n > 0 && p >= 0.f && p < 1.f);
   LR_LAUNCH(dropout_fwd_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, stream, x, y, mask, n, p,
             (unsigned long long)seed);
   return lr_launch_status();
@@ -607,7 +607,7 @@ namespace {
 constexpr int kMaxDevices = 64;
 int32_t* g_fault_words[kMaxDevices];
 int g_drop_member = -1;
-int g_cluster_off = 0;   // bit 0: no cluster recurrence; bit 1: no pair recurrence; bit 2: weight gradients on the fp32 grouped GEMM
+int g_cluster_off = 0;   // bit 0: no cluster recurrence; bit 2: weight gradients on the fp32 grouped GEMM
 __global__ void step_begin_kernel(float4* __restrict__ g, int64_t n4, float* __restrict__ tail, int ntail,
                                   int32_t* __restrict__ fault, float* __restrict__ also_zero) {
   const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -713,7 +713,6 @@ namespace { int g_one_launch_off = 0; }
 extern "C" void lr_rnn_one_launch_enable(int on) { g_one_launch_off = on ? 0 : 1; }
 extern "C" int lr_rnn_one_launch_enabled(void) { return g_one_launch_off ? 0 : 1; }
 int lr_debug_cluster_disabled() { return (g_cluster_off & 1) | g_one_launch_off; }
-int lr_debug_pair_disabled() { return ((g_cluster_off >> 1) & 1) | g_one_launch_off; }
 
 // TEST HOOK (lr_debug_busy): `workgroups` workgroups that each take a whole compute unit's LDS (lds_bytes) and spin for
 // `microseconds` of wall clock — a stand-in for a foreign kernel (an RCCL ring kernel on another stream) that holds CUs

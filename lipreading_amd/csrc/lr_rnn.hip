@@ -547,9 +547,8 @@ Layout reserve_layout(int G, int B, int T, int I, int H, int D, bool x3 = false)
   l.hp_floats = 2 * (size_t)D * nbt * nchunk * FRAG;
   l.gemm = l.hp + l.hp_floats;                               // split-K slabs of the input projection
   l.gemm_bytes = x3 ? lr_xproj_workspace_bytes(B * T, I, G * H, D, H) : lr_sgemm_workspace_bytes(B * T, G * H, I);
-  l.xch = (l.gemm + (l.gemm_bytes + 3) / 4 + 63) / 64 * 64;   // granule exchange of the pair recurrence
-  l.xch_bytes = lr_rnn_cluster_supported(G, B, H) ? lr_rnn_cluster_xch_bytes(B, H, D, 0)
-                : (lr_gru256_pair_supported(G, B, H) ? lr_gru256_pair_xch_bytes(B, D, 0) : 0);
+  l.xch = (l.gemm + (l.gemm_bytes + 3) / 4 + 63) / 64 * 64;   // exchange words of the cluster recurrence
+  l.xch_bytes = lr_rnn_cluster_supported(G, B, H) ? lr_rnn_cluster_xch_bytes(B, H, D, 0) : 0;
   l.total = l.xch + (l.xch_bytes + 3) / 4;
   return l;
 }
@@ -597,8 +596,7 @@ WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
   }
   l.gemm_bytes = gb;
   l.xch = (l.gemm + (gb + 3) / 4 + 63) / 64 * 64;
-  l.xch_bytes = lr_rnn_cluster_supported(G, B, H) ? lr_rnn_cluster_xch_bytes(B, H, D, 1)
-                : (lr_gru256_pair_supported(G, B, H) ? lr_gru256_pair_xch_bytes(B, D, 1) : 0);
+  l.xch_bytes = lr_rnn_cluster_supported(G, B, H) ? lr_rnn_cluster_xch_bytes(B, H, D, 1) : 0;
   l.total = l.xch + (l.xch_bytes + 3) / 4;
   return l;
 }
@@ -607,15 +605,14 @@ inline int cell_of(int mode) { return mode & LR_RNN_CELL_MASK; }
 inline int gates_of(int mode) { return cell_of(mode) == LR_RNN_GRU ? 3 : (cell_of(mode) == LR_RNN_LSTM ? 4 : 1); }
 inline bool proj_x3(int mode) { return (mode & LR_RNN_PROJ_BF16X3) != 0; }
 inline bool x_exact(int mode) { return (mode & LR_RNN_INPUT_BF16_EXACT) != 0; }
-inline bool recur_bf16(int mode) { return (mode & LR_RNN_RECUR_BF16) != 0; }
 inline bool recur_split(int mode) { return (mode & LR_RNN_RECUR_SPLIT) != 0; }
 inline bool x_stored_bf16(int mode) { return (mode & LR_RNN_INPUT_STORED_BF16) != 0; }
 inline bool proj_x1(int mode) { return (mode & LR_RNN_PROJ_BF16X1) != 0; }
 bool dims_ok(int mode, int B, int T, int I, int H, int D) {
   return (cell_of(mode) == LR_RNN_GRU || cell_of(mode) == LR_RNN_LSTM || cell_of(mode) == LR_RNN_TANH) &&
-         (mode & ~(LR_RNN_CELL_MASK | LR_RNN_PROJ_BF16X3 | LR_RNN_INPUT_BF16_EXACT | LR_RNN_RECUR_BF16 |
-                   LR_RNN_INPUT_STORED_BF16 | LR_RNN_RECUR_SPLIT | LR_RNN_PROJ_BF16X1)) == 0 &&
-         !(recur_bf16(mode) && recur_split(mode)) && (!proj_x1(mode) || proj_x3(mode)) &&
+         (mode & ~(LR_RNN_CELL_MASK | LR_RNN_PROJ_BF16X3 | LR_RNN_INPUT_BF16_EXACT | LR_RNN_INPUT_STORED_BF16 |
+                   LR_RNN_RECUR_SPLIT | LR_RNN_PROJ_BF16X1)) == 0 &&
+         (!proj_x1(mode) || proj_x3(mode)) &&
          // a bf16-stored input only makes sense on the split-bf16 projection, as an exact operand
          (!x_stored_bf16(mode) || (proj_x3(mode) && x_exact(mode) && I % 8 == 0)) &&
          B > 0 && T > 0 && I > 0 && H > 0 && (D == 1 || D == 2);
@@ -640,18 +637,21 @@ bool wgrad_split(int mode, int G, int H) {
 
 }  // namespace
 
-extern "C" int lr_rnn_persistent_supported(int mode, int B, int T, int I, int H, int D) {
-  if (!dims_ok(mode, B, T, I, H, D)) return 0;
-  return lr_gru256_persist_supported(gates_of(mode), B, H);
+extern "C" int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D) {
+  return lr_rnn_one_launch_status(mode, B, T, I, H, D) == 0 ? 2 : 0;
 }
 
-extern "C" int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D) {
-  if (!dims_ok(mode, B, T, I, H, D) || H % 4 != 0) return 0;   // (H % 4: lr_rnn_layer_forward's own requirement)
-  // 2: clusters of ceil(H / 32) CUs — ceil(H / 16) past 864 (GRU) / 768 (LSTM) units — (lr_rnn_cluster.hip: H <= 1152; GRU-256
-  // included: the 8-member cluster measured 118 + 131 us per layer pass against the pair kernels' 125 + 160);
-  // 1: GRU-256 on CU pairs (lr_rnn_pair.hip), where a device is too small for a cluster launch; both passes of either
-  if (lr_rnn_cluster_supported(gates_of(mode), B, H)) return 2;
-  return lr_gru256_pair_supported(gates_of(mode), B, H) ? 1 : 0;
+// why (not): 0 = the layer has a one-launch recurrence on this device now; 1 = no kernel for the shape (H % 4 != 0, H
+// past the largest cluster, a tanh RNN); 2 = switched off by lr_rnn_one_launch_enable(0) (lipreading_amd.train after
+// repeated time-outs); 3 = switched off by the test hook lr_rnn_debug_disable_cluster; 4 = the device has too few
+// compute units for a launch's clusters
+extern "C" int lr_rnn_one_launch_status(int mode, int B, int T, int I, int H, int D) {
+  if (!dims_ok(mode, B, T, I, H, D) || H % 4 != 0) return 1;   // (H % 4: lr_rnn_layer_forward's own requirement)
+  const int need = lr_rnn_cluster_cus(gates_of(mode), H);
+  if (need == 0) return 1;
+  if (!lr_rnn_one_launch_enabled()) return 2;
+  if (lr_debug_cluster_disabled()) return 3;
+  return lr_device_cus() >= need ? 0 : 4;
 }
 
 extern "C" size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D) {
@@ -721,16 +721,13 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
     }
   }
   if (recur_split(mode)) {
-    // one launch for all T steps, fp32-faithful (lr_rnn_pair.hip); same interface buffers as the step kernels;
+    // one launch for all T steps, fp32-faithful (lr_rnn_cluster.hip); same interface buffers as the step kernels;
     // the step kernels' packed-W_hh area of the reserve holds the bf16 hi/lo fragments instead
     int st;
     if (lr_rnn_cluster_supported(G, B, H)) {
       if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_rnn_cluster_pack_bytes(G, H, D, 0)) return LR_ERR_WORKSPACE;
       st = lr_rnn_cluster_forward(G, gates, extra, y, w_hh, b_hh, nullptr, nullptr, lens, base + l.wp, base + l.xch, B, T,
                                   D, H, stream, 1);
-    } else if (lr_gru256_pair_supported(G, B, H)) {
-      if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_gru256_pair_pack_bytes(D)) return LR_ERR_WORKSPACE;
-      st = lr_gru256_pair_forward(gates, extra, y, w_hh, b_hh, lens, base + l.wp, base + l.xch, B, T, D, stream);
     } else {
       return LR_ERR_UNSUPPORTED;
     }
@@ -741,21 +738,6 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
     if (blocks > 1024) blocks = 1024;
     LR_LAUNCH(final_state_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)y, (const float*)extra, lens, h_n,
               G == 4 ? c_n : (float*)nullptr, B, T, H, D);
-    return lr_launch_status();
-  }
-  if (recur_bf16(mode)) {
-    // one launch for all T steps (lr_rnn_persist.hip); same interface buffers as the step kernels
-    if (!lr_gru256_persist_supported(G, B, H)) return LR_ERR_UNSUPPORTED;
-    // the step kernels' packed-W_hh area of the reserve holds the bf16 fragments instead
-    if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_gru256_persist_pack_bytes(D)) return LR_ERR_WORKSPACE;
-    int st = lr_gru256_persist_forward(gates, extra, y, w_hh, b_hh, lens, base + l.wp, B, T, D, stream);
-    if (st != LR_OK) return st;
-    if (!h_n) return LR_OK;
-    const int64_t total = (int64_t)D * B * H;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 1024) blocks = 1024;
-    LR_LAUNCH(final_state_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)y, (const float*)extra, lens, h_n,
-              (float*)nullptr, B, T, H, D);
     return lr_launch_status();
   }
   StepPtrs p;
@@ -850,18 +832,6 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
     if ((size_t)D * wl.wp_per_dir * sizeof(float) < lr_rnn_cluster_pack_bytes(G, H, D, 1)) return LR_ERR_WORKSPACE;
     st = lr_rnn_cluster_backward(G, gates, extra, y, dy, dh_n, dc_n, dG, nullptr, nullptr, nullptr, nullptr, w_hh, lens,
                                  wT, wbase + wl.xch, B, T, D, H, stream);
-    if (st != LR_OK) return st;
-  } else if (recur_split(mode) && lr_gru256_pair_supported(G, B, H)) {
-    if (dc_n) return LR_ERR_UNSUPPORTED;
-    if ((size_t)D * wl.wp_per_dir * sizeof(float) < lr_gru256_pair_bwd_pack_bytes(D)) return LR_ERR_WORKSPACE;
-    st = lr_gru256_pair_backward(gates, extra, y, dy, dh_n, dG, w_hh, lens, wT, wbase + wl.xch, B, T, D, stream);
-    if (st != LR_OK) return st;
-  } else if (recur_bf16(mode)) {
-    // one launch for all T steps (lr_rnn_persist.hip); dG comes out in the step kernels' layout.  The
-    // packed-W_hh^T area of the workspace holds the bf16 fragments.
-    if (!lr_gru256_persist_supported(G, B, H) || dc_n) return LR_ERR_UNSUPPORTED;
-    if ((size_t)D * wl.wp_per_dir * sizeof(float) < lr_gru256_persist_bwd_pack_bytes(D)) return LR_ERR_WORKSPACE;
-    st = lr_gru256_persist_backward(gates, extra, y, dy, dh_n, dG, w_hh, lens, wT, B, T, D, stream);
     if (st != LR_OK) return st;
   } else {
     StepPtrs p;

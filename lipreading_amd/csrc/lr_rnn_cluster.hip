@@ -1092,13 +1092,17 @@ bool resolve_shape(int G, int H, int* cc, int* u) {
 
 }  // namespace
 
-int lr_rnn_cluster_supported(int G, int B, int H) {
-  if (B < 1 || H < 1 || (G != 3 && G != 4) || lr_debug_cluster_disabled()) return 0;
+// all MAXCL * CC workgroups of a launch must be resident together, one per compute unit
+int lr_rnn_cluster_cus(int G, int H) {
   int cc, u;
-  if (!resolve_shape(G, H, &cc, &u)) return 0;
-  // all MAXCL * CC workgroups of a launch must be resident together, one per compute unit
-  const int maxcl = cc <= 32 ? 8 : (cc <= 64 ? 4 : 2);
-  return lr_device_cus() >= maxcl * cc ? 1 : 0;
+  if (H < 1 || (G != 3 && G != 4) || !resolve_shape(G, H, &cc, &u)) return 0;
+  return (cc <= 32 ? 8 : (cc <= 64 ? 4 : 2)) * cc;
+}
+
+int lr_rnn_cluster_supported(int G, int B, int H) {
+  if (B < 1 || lr_debug_cluster_disabled()) return 0;
+  const int need = lr_rnn_cluster_cus(G, H);
+  return need > 0 && lr_device_cus() >= need ? 1 : 0;
 }
 
 size_t lr_rnn_cluster_pack_bytes(int G, int H, int D, int backward) {

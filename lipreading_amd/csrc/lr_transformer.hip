@@ -4,11 +4,13 @@
 // configs[4] names one ("transformer encoder over per-frame conv features (self-attn MFMA path) + CTC").
 // The specification is this repo's (lipreading_amd/transformer.py): post-LayerNorm encoder layers
 // with ReLU feed-forward, exactly torch.nn.TransformerEncoderLayer(norm_first=False, dropout=0),
-// which is also the CPU oracle.  The contractions (QKV / output / feed-forward projections,
-// QK^T and PV per (sample, head)) run on the fp32 matrix cores through lr_sgemm / lr_sgemm_batched;
-// this file holds what is left: LayerNorm (+ residual), the key-masked softmax of the attention
-// scores, ReLU and the positional-encoding add, forward and backward.  All are one pass over
-// rows of a few hundred floats: HBM-bound, one wave per row, lanes along the row.
+// which is also the CPU oracle.  This file holds the row-wise kernels — LayerNorm, the key-masked softmax of
+// the unfused attention — and, since round 5, the STACK itself (lr_tfm_forward / backward_data / backward_weights):
+// the whole encoder as three enqueues from C++, every projection a lr_fgemm.hip product that takes its operands as
+// they lie in memory and carries bias / residual / positional table / ReLU / ReLU mask in its epilogue, every weight
+// gradient of every layer (with its bias gradient) in ONE launch, LayerNorm parameter gradients in one more.
+// Round 4 composed the same arithmetic per operation from Python: 375 launches per step at the bench shape, 58 of
+// them ATen adds; this is 29 forward + 30 backward launches.
 #include "lr_common.h"
 
 namespace {
@@ -82,16 +84,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     partial[(int64_t)blockIdx.x * 2 * D + c] = red[c] + red[2 * D + c] + red[4 * D + c] + red[6 * D + c];
 }
 
-// out[c] (+)= fixed-order sum over blocks of partial[block][c]
-__global__ void partial_sum_kernel(const float* __restrict__ partial, int blocks, int ld, int n,
-                                   float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
-  float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += partial[(int64_t)b * ld + c];
-  out[c] = accumulate ? out[c] + s : s;
-}
-
 // In-place softmax over the keys of scores [B][Hh][T(query)][T(key)] * scale, keys >= key_lens[b]
 // masked out (probability exactly 0, as an additive -inf mask gives).  One wave per query row.
 __global__ __launch_bounds__(256) void attn_softmax_fwd_kernel(float* __restrict__ scores,
@@ -125,25 +117,30 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const float* __re
   for (int k = lane; k < T; k += 64) d[k] = scale * p[k] * (d[k] - s);
 }
 
-__global__ void relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    y[i] = fmaxf(x[i], 0.f);
-}
-__global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx,
-                                int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    dx[i] = y[i] > 0.f ? dy[i] : 0.f;
-}
-// x[b][t][:] += pe[t][:]
-__global__ void add_rows_kernel(float* __restrict__ x, const float* __restrict__ pe, int64_t n, int64_t period) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    x[i] += pe[i % period];
-}
-
-inline int grid_for(int64_t n) {
-  int64_t g = (n + 255) / 256;
-  if (g > 2048) g = 2048;
-  return g < 1 ? 1 : (int)g;
+// LayerNorm parameter gradients of up to LN_MAX_JOBS LayerNorms in one launch: out[job][c] (+)= fixed-order sum over the
+// kLnBlocks partial rows of partial[job][block][c], c in [0, 2 D) (dgamma | dbeta side by side in a partial row).
+// grid (ceil(2 D / 64), jobs), 256 threads = 4 block groups x 64 columns.
+constexpr int LN_MAX_JOBS = 32;
+struct LnJobs {
+  const float* partial[LN_MAX_JOBS];
+  float* dgamma[LN_MAX_JOBS];
+  float* dbeta[LN_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const LnJobs jobs, int D, int accumulate) {
+  __shared__ float red[4][64];
+  const int job = blockIdx.y, cg = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cg;
+  const float* p = jobs.partial[job];
+  float s = 0.f;
+  if (c < 2 * D)
+    for (int b = rg; b < kLnBlocks; b += 4) s += p[(int64_t)b * 2 * D + c];
+  red[rg][cg] = s;
+  __syncthreads();
+  if (rg == 0 && c < 2 * D) {
+    s = ((red[0][cg] + red[1][cg]) + red[2][cg]) + red[3][cg];
+    float* out = c < D ? jobs.dgamma[job] + c : jobs.dbeta[job] + (c - D);
+    *out = accumulate ? *out + s : s;
+  }
 }
 
 }  // namespace
@@ -172,10 +169,11 @@ extern "C" int lr_layernorm_backward(const float* x, const float* residual, cons
             R, D);
   int st = lr_launch_status();
   if (st != LR_OK) return st;
-  LR_LAUNCH(partial_sum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, (const float*)partial, kLnBlocks, 2 * D, D,
-            dgamma, accumulate);
-  LR_LAUNCH(partial_sum_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, (const float*)(partial + D), kLnBlocks,
-            2 * D, D, dbeta, accumulate);
+  LnJobs jobs;
+  jobs.partial[0] = partial;
+  jobs.dgamma[0] = dgamma;
+  jobs.dbeta[0] = dbeta;
+  LR_LAUNCH(ln_param_reduce_kernel, dim3((2 * D + 63) / 64, 1), dim3(256), 0, stream, jobs, D, accumulate);
   return lr_launch_status();
 }
 
@@ -195,21 +193,302 @@ extern "C" int lr_attn_softmax_backward(const float* probs, float* dprobs, float
   return lr_launch_status();
 }
 
-extern "C" int lr_relu_forward(const float* x, float* y, int64_t n, lr_stream_t stream) {
-  LR_CHECK_ARG(x && y && n > 0);
-  LR_LAUNCH(relu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, n);
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The encoder stack (include/lipreading_hip.h lr_tfm_*).  Row count R = B * T; every tensor [R][width] fp32, contiguous.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+inline size_t al64(size_t n) { return (n + 63) / 64 * 64; }
+
+// what the forward keeps for the backward (float offsets into `reserve`)
+struct TfmReserve {
+  size_t h0, layer0, per_layer, total;
+  size_t qkv, a, s1, st1, h1, f1, s2, st2, h2, probs;   // inside a layer's block
+};
+TfmReserve tfm_reserve(int mode, int B, int T, int Dm, int nh, int F, int nl) {
+  TfmReserve r;
+  const size_t R = (size_t)B * T;
+  r.h0 = 0;
+  r.layer0 = al64(R * Dm);
+  size_t p = 0;
+  r.qkv = p; p += al64(R * 3 * Dm);
+  r.a = p; p += al64(R * Dm);
+  r.s1 = p; p += al64(R * Dm);
+  r.st1 = p; p += al64(2 * R);
+  r.h1 = p; p += al64(R * Dm);
+  r.f1 = p; p += al64(R * F);
+  r.s2 = p; p += al64(R * Dm);
+  r.st2 = p; p += al64(2 * R);
+  r.h2 = p; p += al64(R * Dm);
+  r.probs = p; p += (mode & LR_TFM_ATTN_FUSED) ? 0 : al64((size_t)B * nh * T * T);
+  r.per_layer = p;
+  r.total = r.layer0 + (size_t)nl * p;
+  return r;
+}
+
+// the backward's buffers: a layer's pre-activation gradients live until backward_weights has contracted them
+struct TfmWs {
+  size_t layer0, per_layer, ds2, df1, ds1, dqkv, lnp1, lnp2;   // per layer
+  size_t dh1, da, dhA, dhB, dP, slabs, slab_floats, total;
+};
+TfmWs tfm_ws(int mode, int B, int T, int I, int Dm, int nh, int F, int nl) {
+  TfmWs w;
+  const size_t R = (size_t)B * T, lnp = (size_t)kLnBlocks * 2 * Dm;
+  size_t p = 0;
+  w.ds2 = p; p += al64(R * Dm);
+  w.df1 = p; p += al64(R * F);
+  w.ds1 = p; p += al64(R * Dm);
+  w.dqkv = p; p += al64(R * 3 * Dm);
+  w.lnp1 = p; p += al64(lnp);
+  w.lnp2 = p; p += al64(lnp);
+  w.per_layer = p;
+  w.layer0 = 0;
+  size_t o = (size_t)nl * p;
+  w.dh1 = o; o += al64(R * Dm);
+  w.da = o; o += al64(R * Dm);
+  w.dhA = o; o += al64(R * Dm);
+  w.dhB = o; o += al64(R * Dm);
+  w.dP = o; o += (mode & LR_TFM_ATTN_FUSED) ? 0 : al64((size_t)B * nh * T * T);
+  w.slabs = o;
+  w.slab_floats = al64(lr_fgemm_slab_floats((int)R, Dm, lr_fgemm_want_splits((int)R, Dm, I)));
+  o += w.slab_floats;
+  w.total = o;
+  return w;
+}
+
+bool tfm_dims_ok(int mode, int B, int T, int I, int Dm, int nh, int F, int nl) {
+  return B > 0 && T > 0 && I > 0 && Dm > 0 && nh > 0 && F > 0 && nl > 0 && Dm % nh == 0 && Dm % 4 == 0 && F % 4 == 0 &&
+         (Dm / nh) % 4 == 0 && 2 * nl <= LN_MAX_JOBS && (size_t)4 * 2 * Dm * sizeof(float) <= 60 * 1024 &&
+         (mode & ~(LR_TFM_X3 | LR_TFM_X_BF16 | LR_TFM_DX_BF16 | LR_TFM_ATTN_FUSED)) == 0 &&
+         (!(mode & LR_TFM_ATTN_FUSED) || lr_attn_fused_supported(T, Dm / nh));
+}
+
+lr_fgemm_job job(const void* A, int lda, const void* Bm, int ldb, void* C, int ldc, int M, int N, int K) {
+  lr_fgemm_job j;
+  j.A = A; j.B = Bm; j.C = C;
+  j.bias = nullptr; j.addend = nullptr; j.mask = nullptr; j.colsum = nullptr; j.slabs = nullptr;
+  j.M = M; j.N = N; j.K = K; j.lda = lda; j.ldb = ldb; j.ldc = ldc;
+  j.ldadd = 0; j.add_period = 0; j.ldmask = 0; j.flags = 0; j.splits = 1;
+  j.alpha = 1.f; j.beta = 0.f;
+  return j;
+}
+
+#define LR_TRY_(expr)              \
+  do {                             \
+    const int lr_st_ = (expr);     \
+    if (lr_st_ != LR_OK) return lr_st_; \
+  } while (0)
+
+// per (sample, head): P = softmax(scale Q K^T), a = P V on the fp32 matrix cores (probs kept for the backward)
+int attention_f32_forward(const float* qkv, const int32_t* lens, float* probs, float* out, int B, int T, int nh, int dh,
+                          hipStream_t st) {
+  const int D = nh * dh, D3 = 3 * D;
+  const float scale = 1.f / sqrtf((float)dh);
+  LR_TRY_(lr_sgemm_batched(0, 1, T, T, dh, 1.f, qkv, D3, (int64_t)T * D3, dh, qkv + D, D3, (int64_t)T * D3, dh, 0.f, probs, T,
+                           (int64_t)nh * T * T, (int64_t)T * T, B, nh, st));
+  LR_TRY_(lr_attn_softmax_forward(probs, lens, scale, B, nh, T, st));
+  return lr_sgemm_batched(0, 0, T, dh, T, 1.f, probs, T, (int64_t)nh * T * T, (int64_t)T * T, qkv + 2 * D, D3, (int64_t)T * D3, dh,
+                          0.f, out, D, (int64_t)T * D, dh, B, nh, st);
+}
+int attention_f32_backward(const float* qkv, const float* probs, const float* dout, float* dP, float* dqkv, int B, int T,
+                           int nh, int dh, hipStream_t st) {
+  const int D = nh * dh, D3 = 3 * D;
+  const float scale = 1.f / sqrtf((float)dh);
+  const int64_t PS = (int64_t)nh * T * T, PI = (int64_t)T * T;
+  const float *q = qkv, *k = qkv + D, *v = qkv + 2 * D;
+  float *dq = dqkv, *dk = dqkv + D, *dv = dqkv + 2 * D;
+  // dP = dO V^T ; dV = P^T dO ; dS = softmax backward ; dQ = dS K ; dK = dS^T Q
+  LR_TRY_(lr_sgemm_batched(0, 1, T, T, dh, 1.f, dout, D, (int64_t)T * D, dh, v, D3, (int64_t)T * D3, dh, 0.f, dP, T, PS, PI, B, nh, st));
+  LR_TRY_(lr_sgemm_batched(1, 0, T, dh, T, 1.f, probs, T, PS, PI, dout, D, (int64_t)T * D, dh, 0.f, dv, D3, (int64_t)T * D3, dh, B, nh, st));
+  LR_TRY_(lr_attn_softmax_backward(probs, dP, scale, B, nh, T, st));
+  LR_TRY_(lr_sgemm_batched(0, 0, T, dh, T, 1.f, dP, T, PS, PI, k, D3, (int64_t)T * D3, dh, 0.f, dq, D3, (int64_t)T * D3, dh, B, nh, st));
+  return lr_sgemm_batched(1, 0, T, dh, T, 1.f, dP, T, PS, PI, q, D3, (int64_t)T * D3, dh, 0.f, dk, D3, (int64_t)T * D3, dh, B, nh, st);
+}
+
+int ln_forward(const float* s, const float* gamma, const float* beta, float* y, float* stats, int R, int D, float eps,
+               hipStream_t st) {
+  LR_LAUNCH(layernorm_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, st, s, (const float*)nullptr, gamma, beta, y, stats, R, D, eps);
+  return lr_launch_status();
+}
+int ln_backward(const float* s, const float* gamma, const float* stats, const float* dy, float* ds, float* partial, int R,
+                int D, hipStream_t st) {
+  LR_LAUNCH(layernorm_bwd_kernel, dim3(kLnBlocks), dim3(256), (size_t)4 * 2 * D * sizeof(float), st, s, (const float*)nullptr,
+            gamma, stats, dy, ds, partial, R, D);
   return lr_launch_status();
 }
 
-extern "C" int lr_relu_backward(const float* y, const float* dy, float* dx, int64_t n, lr_stream_t stream) {
-  LR_CHECK_ARG(y && dy && dx && n > 0);
-  LR_LAUNCH(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, y, dy, dx, n);
-  return lr_launch_status();
+}  // namespace
+
+extern "C" size_t lr_tfm_reserve_bytes(int mode, int B, int T, int I, int Dm, int nhead, int F, int nlayers) {
+  if (!tfm_dims_ok(mode, B, T, I, Dm, nhead, F, nlayers)) return 0;
+  return tfm_reserve(mode, B, T, Dm, nhead, F, nlayers).total * sizeof(float);
+}
+extern "C" size_t lr_tfm_workspace_bytes(int mode, int B, int T, int I, int Dm, int nhead, int F, int nlayers) {
+  if (!tfm_dims_ok(mode, B, T, I, Dm, nhead, F, nlayers)) return 0;
+  return tfm_ws(mode, B, T, I, Dm, nhead, F, nlayers).total * sizeof(float);
 }
 
-extern "C" int lr_add_rows(float* x, const float* pe, int B, int T, int D, lr_stream_t stream) {
-  LR_CHECK_ARG(x && pe && B > 0 && T > 0 && D > 0);
-  const int64_t n = (int64_t)B * T * D;
-  LR_LAUNCH(add_rows_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, pe, n, (int64_t)T * D);
+extern "C" int lr_tfm_forward(int mode, const void* x, const int32_t* key_lens, const float* const* weights, const float* pe,
+                              float* h_out, void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                              int B, int T, int I, int Dm, int nhead, int F, int nlayers, float eps, lr_stream_t stream_) {
+  LR_CHECK_ARG(tfm_dims_ok(mode, B, T, I, Dm, nhead, F, nlayers));
+  LR_CHECK_ARG(x && key_lens && weights && pe && h_out && reserve && workspace);
+  for (int i = 0; i < 2 + 12 * nlayers; ++i) LR_CHECK_ARG(weights[i]);
+  const TfmReserve r = tfm_reserve(mode, B, T, Dm, nhead, F, nlayers);
+  const TfmWs w = tfm_ws(mode, B, T, I, Dm, nhead, F, nlayers);
+  if (reserve_bytes < r.total * sizeof(float) || workspace_bytes < w.total * sizeof(float)) return LR_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream_;
+  const int prec = (mode & LR_TFM_X3) ? LR_FGEMM_X3 : LR_FGEMM_F32;
+  const int xbf = (mode & LR_TFM_X_BF16) ? 1 : 0;
+  const int R = B * T, dh = Dm / nhead;
+  float* base = (float*)reserve;
+  float* wsb = (float*)workspace;
+  // h0 = x W_p^T + b_p + pe[t]   (K = I may be long and the product has few tiles: split K)
+  float* h = base + r.h0;
+  {
+    lr_fgemm_job j = job(x, I, weights[0], I, h, Dm, R, Dm, I);
+    j.bias = weights[1];
+    j.addend = pe; j.ldadd = Dm; j.add_period = T;
+    j.splits = lr_fgemm_want_splits(R, Dm, I);
+    j.slabs = wsb + w.slabs;
+    LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NT, xbf, 0, &j, 1, st));
+  }
+  for (int l = 0; l < nlayers; ++l) {
+    const float* const* W = weights + 2 + 12 * l;
+    float* L = base + r.layer0 + (size_t)l * r.per_layer;
+    float* h2 = l == nlayers - 1 ? h_out : L + r.h2;
+    lr_fgemm_job j = job(h, Dm, W[0], Dm, L + r.qkv, 3 * Dm, R, 3 * Dm, Dm);
+    j.bias = W[1];
+    LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NT, 0, 0, &j, 1, st));
+    if (mode & LR_TFM_ATTN_FUSED)
+      LR_TRY_(lr_attn_fused_forward(L + r.qkv, key_lens, L + r.a, 1.f / sqrtf((float)dh), B, T, nhead, dh, st));
+    else
+      LR_TRY_(attention_f32_forward(L + r.qkv, key_lens, L + r.probs, L + r.a, B, T, nhead, dh, st));
+    j = job(L + r.a, Dm, W[2], Dm, L + r.s1, Dm, R, Dm, Dm);      // s1 = a W_o^T + b_o + h
+    j.bias = W[3];
+    j.addend = h; j.ldadd = Dm; j.add_period = R;
+    LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NT, 0, 0, &j, 1, st));
+    LR_TRY_(ln_forward(L + r.s1, W[8], W[9], L + r.h1, L + r.st1, R, Dm, eps, st));
+    j = job(L + r.h1, Dm, W[4], Dm, L + r.f1, F, R, F, Dm);        // f1 = relu(h1 W_1^T + b_1)
+    j.bias = W[5];
+    j.flags = LR_FGEMM_RELU;
+    LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NT, 0, 0, &j, 1, st));
+    j = job(L + r.f1, F, W[6], F, L + r.s2, Dm, R, Dm, F);         // s2 = f1 W_2^T + b_2 + h1
+    j.bias = W[7];
+    j.addend = L + r.h1; j.ldadd = Dm; j.add_period = R;
+    LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NT, 0, 0, &j, 1, st));
+    LR_TRY_(ln_forward(L + r.s2, W[10], W[11], h2, L + r.st2, R, Dm, eps, st));
+    h = h2;
+  }
+  return LR_OK;
+}
+
+extern "C" int lr_tfm_backward_data(int mode, const int32_t* key_lens, const float* const* weights, const float* dh_out,
+                                    void* dx, void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                                    int B, int T, int I, int Dm, int nhead, int F, int nlayers, lr_stream_t stream_) {
+  LR_CHECK_ARG(tfm_dims_ok(mode, B, T, I, Dm, nhead, F, nlayers));
+  LR_CHECK_ARG(key_lens && weights && dh_out && reserve && workspace);
+  const TfmReserve r = tfm_reserve(mode, B, T, Dm, nhead, F, nlayers);
+  const TfmWs w = tfm_ws(mode, B, T, I, Dm, nhead, F, nlayers);
+  if (reserve_bytes < r.total * sizeof(float) || workspace_bytes < w.total * sizeof(float)) return LR_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream_;
+  const int prec = (mode & LR_TFM_X3) ? LR_FGEMM_X3 : LR_FGEMM_F32;
+  const int R = B * T, dh = Dm / nhead;
+  float* base = (float*)reserve;
+  float* wsb = (float*)workspace;
+  const float* dh_cur = dh_out;
+  for (int l = nlayers - 1; l >= 0; --l) {
+    const float* const* W = weights + 2 + 12 * l;
+    float* L = base + r.layer0 + (size_t)l * r.per_layer;
+    float* G = wsb + w.layer0 + (size_t)l * w.per_layer;
+    // the gradient of layer l's input: layer 0's lands in dhA (backward_weights reads it there)
+    float* dh_prev = wsb + ((l & 1) ? w.dhB : w.dhA);
+    LR_TRY_(ln_backward(L + r.s2, W[10], L + r.st2, dh_cur, G + w.ds2, G + w.lnp2, R, Dm, st));
+    lr_fgemm_job j = job(G + w.ds2, Dm, W[6], F, G + w.df1, F, R, F, Dm);      // df1 = (ds2 W_2) where f1 > 0
+    j.mask = L + r.f1; j.ldmask = F;
+    LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NN, 0, 0, &j, 1, st));
+    j = job(G + w.df1, F, W[4], Dm, wsb + w.dh1, Dm, R, Dm, F);                // dh1 = df1 W_1 + ds2
+    j.addend = G + w.ds2; j.ldadd = Dm; j.add_period = R;
+    LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NN, 0, 0, &j, 1, st));
+    LR_TRY_(ln_backward(L + r.s1, W[8], L + r.st1, wsb + w.dh1, G + w.ds1, G + w.lnp1, R, Dm, st));
+    j = job(G + w.ds1, Dm, W[2], Dm, wsb + w.da, Dm, R, Dm, Dm);               // da = ds1 W_o
+    LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NN, 0, 0, &j, 1, st));
+    if (mode & LR_TFM_ATTN_FUSED)
+      LR_TRY_(lr_attn_fused_backward(L + r.qkv, key_lens, wsb + w.da, G + w.dqkv, 1.f / sqrtf((float)dh), B, T, nhead, dh, st));
+    else
+      LR_TRY_(attention_f32_backward(L + r.qkv, L + r.probs, wsb + w.da, wsb + w.dP, G + w.dqkv, B, T, nhead, dh, st));
+    j = job(G + w.dqkv, 3 * Dm, W[0], Dm, dh_prev, Dm, R, Dm, 3 * Dm);         // dh = dqkv W_qkv + ds1
+    j.addend = G + w.ds1; j.ldadd = Dm; j.add_period = R;
+    LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NN, 0, 0, &j, 1, st));
+    dh_cur = dh_prev;
+  }
+  if (dx) {   // dx = dh0 W_p
+    lr_fgemm_job j = job(dh_cur, Dm, weights[0], I, dx, I, R, I, Dm);
+    if (mode & LR_TFM_DX_BF16) j.flags = LR_FGEMM_C_BF16;
+    LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NN, 0, 0, &j, 1, st));
+  }
+  return LR_OK;
+}
+
+extern "C" int lr_tfm_backward_weights(int mode, const void* x, float* const* grads, int accumulate, void* reserve,
+                                       size_t reserve_bytes, void* workspace, size_t workspace_bytes, int B, int T, int I,
+                                       int Dm, int nhead, int F, int nlayers, lr_stream_t stream_) {
+  LR_CHECK_ARG(tfm_dims_ok(mode, B, T, I, Dm, nhead, F, nlayers));
+  LR_CHECK_ARG(x && grads && reserve && workspace);
+  for (int i = 0; i < 2 + 12 * nlayers; ++i) LR_CHECK_ARG(grads[i]);
+  const TfmReserve r = tfm_reserve(mode, B, T, Dm, nhead, F, nlayers);
+  const TfmWs w = tfm_ws(mode, B, T, I, Dm, nhead, F, nlayers);
+  if (reserve_bytes < r.total * sizeof(float) || workspace_bytes < w.total * sizeof(float)) return LR_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream_;
+  const int prec = (mode & LR_TFM_X3) ? LR_FGEMM_X3 : LR_FGEMM_F32;
+  const int xbf = (mode & LR_TFM_X_BF16) ? 1 : 0;
+  const int R = B * T;
+  float* base = (float*)reserve;
+  float* wsb = (float*)workspace;
+  const float beta = accumulate ? 1.f : 0.f;
+  // dW = dy^T x with db = column sums of dy, for every Linear of the stack: jobs of ONE launch (20 at a time)
+  lr_fgemm_job jobs[20];
+  int n = 0;
+  auto flush = [&](int b_bf16) -> int {
+    if (n == 0) return LR_OK;
+    const int st_ = lr_fgemm_launch(prec, LR_FGEMM_TN, 0, b_bf16, jobs, n, st);
+    n = 0;
+    return st_;
+  };
+  auto add = [&](const float* dy, int ldy, const void* xin, int ldx, float* dW, float* db, int M, int N) {
+    lr_fgemm_job j = job(dy, ldy, xin, ldx, dW, N, M, N, R);
+    j.colsum = db;
+    j.beta = beta;
+    jobs[n++] = j;
+  };
+  for (int l = 0; l < nlayers; ++l) {
+    float* const* Gd = grads + 2 + 12 * l;
+    float* L = base + r.layer0 + (size_t)l * r.per_layer;
+    float* G = wsb + w.layer0 + (size_t)l * w.per_layer;
+    const float* h_in = l == 0 ? base + r.h0 : base + r.layer0 + (size_t)(l - 1) * r.per_layer + r.h2;
+    if (n + 4 > 20) LR_TRY_(flush(0));
+    add(G + w.dqkv, 3 * Dm, h_in, Dm, Gd[0], Gd[1], 3 * Dm, Dm);
+    add(G + w.ds1, Dm, L + r.a, Dm, Gd[2], Gd[3], Dm, Dm);
+    add(G + w.df1, F, L + r.h1, Dm, Gd[4], Gd[5], F, Dm);
+    add(G + w.ds2, Dm, L + r.f1, F, Gd[6], Gd[7], Dm, F);
+  }
+  if (xbf) {
+    LR_TRY_(flush(0));
+    add(wsb + w.dhA, Dm, x, I, grads[0], grads[1], Dm, I);
+    LR_TRY_(flush(1));
+  } else {
+    if (n + 1 > 20) LR_TRY_(flush(0));
+    add(wsb + w.dhA, Dm, x, I, grads[0], grads[1], Dm, I);
+    LR_TRY_(flush(0));
+  }
+  LnJobs lj;
+  for (int l = 0; l < nlayers; ++l) {
+    float* const* Gd = grads + 2 + 12 * l;
+    float* G = wsb + w.layer0 + (size_t)l * w.per_layer;
+    lj.partial[2 * l] = G + w.lnp1; lj.dgamma[2 * l] = Gd[8]; lj.dbeta[2 * l] = Gd[9];
+    lj.partial[2 * l + 1] = G + w.lnp2; lj.dgamma[2 * l + 1] = Gd[10]; lj.dbeta[2 * l + 1] = Gd[11];
+  }
+  LR_LAUNCH(ln_param_reduce_kernel, dim3((2 * Dm + 63) / 64, 2 * nlayers), dim3(256), 0, st, lj, Dm, accumulate);
   return lr_launch_status();
 }

@@ -21,7 +21,7 @@ from .data import BOS, PAD
 _ALLOWED_RNN_TYPES = {'LSTM', 'GRU', 'RNN'}          # better_model.py:9
 _ALLOWED_FRAME_PROCESSING = {'flatten'}              # better_model.py:10
 _MODES = {'GRU': 0, 'LSTM': 1, 'RNN': 2}
-_PROJ_BF16X3, _INPUT_BF16_EXACT, _RECUR_BF16, _INPUT_STORED_BF16, _RECUR_SPLIT = 0x100, 0x200, 0x400, 0x800, 0x1000   # lr_rnn_mode flags
+_PROJ_BF16X3, _INPUT_BF16_EXACT, _INPUT_STORED_BF16, _RECUR_SPLIT = 0x100, 0x200, 0x800, 0x1000   # lr_rnn_mode flags
 _PROJ_BF16X1 = 0x2000
 _GATES = {'GRU': 3, 'LSTM': 4, 'RNN': 1}
 
@@ -77,18 +77,35 @@ def flush_deferred():
   del _deferred[:]   # the tensors the side stream was using may be released now
 
 
-# (rnn_type, H) pairs whose fall-back to the per-step kernels has been announced (one warning each)
+# (rnn_type, H, why) triples whose fall-back to the per-step kernels has been announced (one warning each)
 _fallback_noted = set()
+_WHY = {
+    1: "there is no one-launch kernel for this shape (GRU / LSTM with a hidden size that is a multiple of 4, up to the "
+       "largest cluster: lr_rnn_cluster.hip)",
+    2: "the one-launch recurrences were switched off for this process (lr_rnn_one_launch_enable(0): lipreading_amd.train "
+       "does that after repeated time-outs, see its own warning)",
+    3: "the test hook lr_rnn_debug_disable_cluster is set",
+    4: "this device has too few compute units for a launch's clusters, which must be resident together",
+}
 
 
-def _note_step_kernel_fallback(rnn_type, H):
-  if (rnn_type, H) in _fallback_noted:
+def _note_step_kernel_fallback(rnn_type, H, why):
+  """Says ONCE per (cell, size, reason) that a layer runs one launch per time step, and WHY (lr_rnn_one_launch_status):
+  an unsupported shape, the product's switch after time-outs, the test hook, or a small device — and, under
+  torch.distributed, on which rank."""
+  if (rnn_type, H, why) in _fallback_noted:
     return
-  _fallback_noted.add((rnn_type, H))
+  _fallback_noted.add((rnn_type, H, why))
   import warnings
-  warnings.warn("lipreading_amd: no one-launch recurrence for %s-%d (a member's slice of W_hh must fit one compute unit: "
-                "hidden sizes up to 1152, multiples of 4, on a device with enough compute units for a launch's clusters); "
-                "this layer runs one launch per time step (2-5x slower per pass)" % (rnn_type, H), stacklevel=3)
+  rank = ""
+  try:
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+      rank = " [rank %d of %d]" % (dist.get_rank(), dist.get_world_size())
+  except Exception:
+    pass
+  warnings.warn("lipreading_amd%s: %s-%d runs one launch per time step (2-5x slower per pass, same results): %s"
+                % (rank, rnn_type, H, _WHY.get(why, "status %d" % why)), stacklevel=3)
 
 
 class _RNNLayerFunction(torch.autograd.Function):
@@ -337,9 +354,7 @@ class VideoEncoder(nn.Module):
     #   'f32'    one launch per time step, exact fp32 MFMA — every shape
     #   'split'  ONE launch per layer pass, fp32-faithful (W_hh and the state as bf16 hi + lo planes, ~1e-6
     #            of the fp32 product): a cluster of ceil(H / 32) CUs per (direction, 8 samples) (lr_rnn_cluster.hip) —
-    #            H <= 1152 (16-unit members on larger clusters past 864 / 768); larger layers as 'f32' (announced once)
-    #   'bf16'   one launch per pass with single-plane bf16 recurrent operands (~1e-3): the build-defined
-    #            pixel regime's choice (frontend.PixelLipReader sets it); where unsupported as 'f32'
+    #            every H the clusters hold (16-unit members past 864 / 768); larger layers as 'f32' (announced once)
     #   'auto'   (default) same as 'split': reference-faithful numerics at the one-launch speed
     self.recurrence = 'auto'
     if self.enable_ctc:
@@ -395,17 +410,13 @@ class VideoEncoder(nn.Module):
           lmode |= _PROJ_BF16X1
         if layer == 0 and stored_bf16:
           lmode |= _INPUT_STORED_BF16
-      assert self.recurrence in ('auto', 'f32', 'split', 'bf16'), self.recurrence
-      if self.recurrence == 'bf16' and _C.lib().lr_rnn_persistent_supported(mode, B, max_len, x.shape[2], H, D):
-        lmode |= _RECUR_BF16
-      else:
-        # lr_rnn_pair_supported: 2 = clusters of ceil(H / 32) (or, past 864 / 768 units, ceil(H / 16)) CUs, H <= 1152;
-        # 1 = GRU-256 on CU pairs (a device too small for a cluster launch); 0 = step kernels
-        if self.recurrence in ('auto', 'split'):
-          if _C.lib().lr_rnn_pair_supported(mode, B, max_len, x.shape[2], H, D):
-            lmode |= _RECUR_SPLIT
-          elif mode != 2:
-            _note_step_kernel_fallback(self.rnn_type, H)
+      assert self.recurrence in ('auto', 'f32', 'split'), self.recurrence
+      if self.recurrence in ('auto', 'split') and mode != 2:
+        why = _C.lib().lr_rnn_one_launch_status(mode, B, max_len, x.shape[2], H, D)
+        if why == 0:
+          lmode |= _RECUR_SPLIT
+        else:
+          _note_step_kernel_fallback(self.rnn_type, H, why)
       y, h_n, c_n = _RNNLayerFunction.apply(x, lens, lmode, H, need_dx, need_final_state, *weights)
       if need_final_state:
         # (D,B,H) -> (B, D*H): forward direction first, as _cat_directions (better_model.py:98-112); h and c in one launch

@@ -241,7 +241,7 @@ class _ConvFrontendFunction(torch.autograd.Function):
           rc = L.lr_conv3d_wgrad_pooled(x_in.data_ptr(), pooled.data_ptr(), act.data_ptr(), dP_in.data_ptr(),
                                         grads[2 * li].data_ptr(), grads[2 * li + 1].data_ptr(), ws.data_ptr(), wbytes,
                                         accumulate, B, T, h, w, cin_p, cin, cout, kt, kh, kw, stride, pt, ph, pw, 0, stream)
-          if rc != -4:   # LR_ERR_UNSUPPORTED: a frame count whose tile table does not fit the kernel's LDS
+          if rc != _C.LR_ERR_UNSUPPORTED:   # (a frame count whose tile table does not fit the kernel's LDS)
             _C.check(rc, "lr_conv3d_wgrad_pooled")
             return None
         # ... else un-pool (the bias gradient — the sum of the routed gradients — falls out of that pass), then dW
@@ -348,12 +348,9 @@ class PixelLipReader(nn.Module):
     encoder.input_projection = 'bf16x3'
     encoder.input_is_bf16 = True
     # ... and run the recurrence of every layer that has the kernels as ONE launch per pass, fp32-FAITHFUL
-    # ('split': W_hh and the state as bf16 hi + lo planes on the cluster kernels, lr_rnn_cluster.hip).  Round 2 ran
-    # the single-plane 'bf16' kernels here (lr_rnn_persist.hip: 97 + 126 us per GRU-256 layer pass against 118 + 131);
-    # measured at the bench shape against the oracle (bench.py parity block, B = 32, T = 75, random initialisation):
-    # 'bf16' flips the greedy argmax of 9 of 2400 frames (all within 1.8e-4 of a tie; CTC loss 3.1e-5 off), 'split'
-    # flips none (loss identical to 7 digits) — north_star asks for identical strings, so 'split' is the default and
-    # costs ~2 % of the step.  `encoder.recurrence = 'bf16'` selects the faster, looser kernels; 'f32' the per-step ones.
+    # ('split': W_hh and the state as bf16 hi + lo planes on the cluster kernels, lr_rnn_cluster.hip).  Rounds 1-4 also
+    # carried a single-plane bf16 recurrence (2 % faster, 9 of 2400 greedy argmaxes flipped against the oracle at the
+    # bench shape); north_star asks for identical strings, nothing shipped ran it, and round 5 removed it.
     encoder.recurrence = 'split'
     if hasattr(encoder, "attention"):
       encoder.attention = 'bf16'     # transformer encoder: fused attention on the bf16 matrix cores

@@ -13,9 +13,10 @@ CTC").  The specification is this repo's:
 i.e. exactly torch.nn.TransformerEncoder, which is also the CPU oracle (there is NO reference
 parity for this stage).  Parameters live in real torch modules (same names, shapes and
 initialisation as nn.TransformerEncoder; state_dicts interchange) that are never called: the
-arithmetic is the HIP path — projections and the per-(sample, head) QK^T / PV products on the fp32
-matrix cores (lr_sgemm, lr_sgemm_batched reading Q/K/V in place out of the fused QKV projection),
-LayerNorm(+residual), key-masked softmax, ReLU and the positional add in lr_transformer.hip.
+arithmetic is the HIP path, and since round 5 the whole stack is THREE enqueues (lr_tfm_forward,
+lr_tfm_backward_data, lr_tfm_backward_weights: lr_transformer.hip): every projection a product that
+reads its operands as they lie in memory (lr_fgemm.hip) with bias / residual / positional table / ReLU
+in its epilogue, every weight gradient of the stack (bias gradients included) in one launch.
 It drops in wherever VideoEncoder does: forward(frames, frame_lens) -> (log_probs, hidden, None).
 """
 import math
@@ -25,91 +26,74 @@ import torch.nn as nn
 
 from . import _C
 from .data import BOS, PAD
-from .encoder import _ProjLogSoftmaxFunction
+from .encoder import _ProjLogSoftmaxFunction, _direct_grads, _notify, _ptr_array
 
 
-def _gemm(ta, tb, M, N, K, A, lda, Bm, ldb, C, ldc, bias=None, alpha=1.0, beta=0.0, x3=False):
-  """fp32 GEMM on the fp32 matrix cores (lr_sgemm) or, x3, on the bf16 matrix cores with hi/lo split
-  operands (lr_xgemm, ~1e-5 relative): the pixel regime's choice, as for the recurrent encoder."""
-  L = _C.lib()
-  if x3:
-    wsb = L.lr_xgemm_workspace_bytes(int(ta), int(tb), M, N, K)
-    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=C.device)
-    _C.check(L.lr_xgemm(int(ta), int(tb), M, N, K, alpha, A.data_ptr(), lda, Bm.data_ptr(), ldb, beta, C.data_ptr(),
-                        ldc, _C.ptr(bias), 0, 0, ws.data_ptr(), wsb, _C.stream_handle()), "lr_xgemm")
-    return
-  wsb = L.lr_sgemm_workspace_bytes(M, N, K)
-  ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=C.device)
-  _C.check(L.lr_sgemm(int(ta), int(tb), M, N, K, alpha, A.data_ptr(), lda, Bm.data_ptr(), ldb, beta, C.data_ptr(),
-                      ldc, _C.ptr(bias), 0, 0, ws.data_ptr() if wsb else None, wsb, _C.stream_handle()), "lr_sgemm")
+_X3, _X_BF16, _DX_BF16, _ATTN_FUSED = 1, 2, 4, 8   # LR_TFM_* (include/lipreading_hip.h)
 
 
-class _LinearFunction(torch.autograd.Function):
-  """y[R,N] = x[R,K] W[N,K]^T + b — torch.nn.Linear on the matrix cores."""
+class _StackFunction(torch.autograd.Function):
+  """input projection + positional table + every encoder layer: lr_tfm_forward / lr_tfm_backward_data /
+  lr_tfm_backward_weights (three enqueues; lr_transformer.hip composes them from lr_fgemm.hip products, the fused
+  attention and the LayerNorm kernels).  x (B, T, I) fp32 or — the conv frontend's features — bf16."""
 
   @staticmethod
-  def forward(ctx, x, weight, bias, x3=False):
-    shape = x.shape
-    x2 = x.reshape(-1, shape[-1]).contiguous()
-    R, K = x2.shape
-    N = weight.shape[0]
-    x3 = bool(x3) and R >= 256 and K >= 128   # the split path pays only for real contractions
-    y = torch.empty((R, N), dtype=torch.float32, device=x.device)
-    _gemm(0, 1, R, N, K, x2, K, weight, K, y, N, bias=bias, x3=x3)
-    ctx.save_for_backward(x2, weight)
-    ctx.shape = shape
-    ctx.x3 = x3
-    return y.reshape(shape[:-1] + (N,))
-
-  @staticmethod
-  def backward(ctx, dy):
-    x2, weight = ctx.saved_tensors
-    R, K = x2.shape
-    N = weight.shape[0]
-    dy2 = dy.reshape(R, N).contiguous()
-    dx = torch.empty_like(x2)
-    _gemm(0, 0, R, K, N, dy2, N, weight, K, dx, K, x3=ctx.x3)         # dx = dy W
-    dW = torch.empty_like(weight)
-    _gemm(1, 0, N, K, R, dy2, N, x2, K, dW, K, x3=ctx.x3)             # dW = dy^T x
-    ones = torch.ones((R, 1), dtype=torch.float32, device=dy.device)
-    db = torch.empty((N,), dtype=torch.float32, device=dy.device)
-    _gemm(1, 0, N, 1, R, dy2, N, ones, 1, db, 1)                      # db = dy^T 1
-    return dx.reshape(ctx.shape), dW, db, None
-
-
-class _LayerNormFunction(torch.autograd.Function):
-  """y = LayerNorm(x + residual) * gamma + beta."""
-
-  @staticmethod
-  def forward(ctx, x, residual, gamma, beta, eps):
+  def forward(ctx, x, lens, pe, cfg, *weights):
     L = _C.lib()
-    D = x.shape[-1]
-    x = x.contiguous()
-    residual = residual.contiguous()
-    R = x.numel() // D
-    y = torch.empty_like(x)
-    stats = torch.empty((R, 2), dtype=torch.float32, device=x.device)
-    _C.check(L.lr_layernorm_forward(x.data_ptr(), residual.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                    stats.data_ptr(), R, D, eps, _C.stream_handle()), "lr_layernorm_forward")
-    ctx.save_for_backward(x, residual, gamma, stats)
-    return y
+    mode, Dm, nhead, F, nlayers, eps = cfg
+    B, T, I = x.shape
+    dev = x.device
+    dims = (B, T, I, Dm, nhead, F, nlayers)
+    rbytes, wbytes = L.lr_tfm_reserve_bytes(mode, *dims), L.lr_tfm_workspace_bytes(mode, *dims)
+    if rbytes == 0:
+      raise ValueError("lr_tfm: unsupported shape (d_model %d, heads %d, feed-forward %d, T %d)" % (Dm, nhead, F, T))
+    reserve = torch.empty(rbytes, dtype=torch.uint8, device=dev)
+    ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)    # (the forward's split-K slabs; then the backward's buffers)
+    h = torch.empty((B, T, Dm), dtype=torch.float32, device=dev)
+    _C.check(L.lr_tfm_forward(mode, x.data_ptr(), lens.data_ptr(), _ptr_array(weights), pe.data_ptr(), h.data_ptr(),
+                              reserve.data_ptr(), rbytes, ws.data_ptr(), wbytes, *dims, float(eps), _C.stream_handle()),
+             "lr_tfm_forward")
+    ctx.save_for_backward(x, lens, reserve, ws, *weights)
+    ctx.cfg = cfg
+    return h
 
   @staticmethod
-  def backward(ctx, dy):
-    x, residual, gamma, stats = ctx.saved_tensors
+  def backward(ctx, dh):
+    from . import encoder as _enc
+    x, lens, reserve, ws = ctx.saved_tensors[:4]
+    weights = ctx.saved_tensors[4:]
     L = _C.lib()
-    D = x.shape[-1]
-    R = x.numel() // D
-    dy = dy.contiguous()
-    dx = torch.empty_like(x)
-    dg = torch.empty_like(gamma)
-    db = torch.empty_like(gamma)
-    wsb = L.lr_layernorm_workspace_bytes(D)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-    _C.check(L.lr_layernorm_backward(x.data_ptr(), residual.data_ptr(), gamma.data_ptr(), stats.data_ptr(),
-                                     dy.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), wsb,
-                                     0, R, D, _C.stream_handle()), "lr_layernorm_backward")
-    return dx, dx, dg, db, None
+    mode, Dm, nhead, F, nlayers, eps = ctx.cfg
+    B, T, I = x.shape
+    dims = (B, T, I, Dm, nhead, F, nlayers)
+    dh = dh.contiguous()
+    dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None   # (bf16 where x is: LR_TFM_DX_BF16)
+    _C.check(L.lr_tfm_backward_data(mode, lens.data_ptr(), _ptr_array(weights), dh.data_ptr(), _C.ptr(dx),
+                                    reserve.data_ptr(), reserve.numel(), ws.data_ptr(), ws.numel(), *dims,
+                                    _C.stream_handle()), "lr_tfm_backward_data")
+    direct = _direct_grads(weights)
+    grads = [w.grad for w in weights] if direct else [torch.empty_like(w) for w in weights]
+
+    def weight_half():
+      _C.check(L.lr_tfm_backward_weights(mode, x.data_ptr(), _ptr_array(grads), 1 if direct else 0, reserve.data_ptr(),
+                                         reserve.numel(), ws.data_ptr(), ws.numel(), *dims, _C.stream_handle()),
+               "lr_tfm_backward_weights")
+    if _enc.overlap_weight_grads and direct and dx is not None:
+      # the pixel regime: whatever produced x (the conv frontend) only waits for dx — every weight gradient of the
+      # stack goes to the encoder's side stream and runs beside the conv backward (joined by flush_deferred)
+      _enc.flush_deferred()
+      side = _enc._get_side_stream(x.device)
+      side.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(side):
+        weight_half()
+        _notify(weights)
+      _enc._deferred.append((x, dh, reserve, ws, grads, weights))
+      return (dx, None, None, None) + (None,) * len(weights)
+    weight_half()
+    if direct:
+      _notify(weights)
+      return (dx, None, None, None) + (None,) * len(weights)
+    return (dx, None, None, None) + tuple(grads)
 
 
 class _AttentionFunction(torch.autograd.Function):
@@ -187,40 +171,6 @@ class _AttentionFunction(torch.autograd.Function):
     return dqkv, None, None, None
 
 
-class _ReluFunction(torch.autograd.Function):
-  @staticmethod
-  def forward(ctx, x):
-    x = x.contiguous()
-    y = torch.empty_like(x)
-    _C.check(_C.lib().lr_relu_forward(x.data_ptr(), y.data_ptr(), x.numel(), _C.stream_handle()), "lr_relu_forward")
-    ctx.save_for_backward(y)
-    return y
-
-  @staticmethod
-  def backward(ctx, dy):
-    (y,) = ctx.saved_tensors
-    dy = dy.contiguous()
-    dx = torch.empty_like(dy)
-    _C.check(_C.lib().lr_relu_backward(y.data_ptr(), dy.data_ptr(), dx.data_ptr(), dy.numel(), _C.stream_handle()),
-             "lr_relu_backward")
-    return dx
-
-
-class _AddPositionalFunction(torch.autograd.Function):
-  """x[b,t,:] + pe[t,:]; the encoding is a constant, the gradient passes through."""
-
-  @staticmethod
-  def forward(ctx, x, pe):
-    B, T, D = x.shape
-    y = x.contiguous().clone()
-    _C.check(_C.lib().lr_add_rows(y.data_ptr(), pe.data_ptr(), B, T, D, _C.stream_handle()), "lr_add_rows")
-    return y
-
-  @staticmethod
-  def backward(ctx, dy):
-    return dy, None
-
-
 def sinusoidal_encoding(max_len, d_model):
   pos = torch.arange(max_len, dtype=torch.float32).unsqueeze(1)
   div = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float32) * (-math.log(10000.0) / d_model))
@@ -272,21 +222,23 @@ class TransformerVideoEncoder(nn.Module):
     if max_len is None:
       max_len = int(frame_lens.max())
     assert 1 <= max_len <= min(T, self.pe.shape[0])
-    x = frames[:, :max_len].to(torch.float32).contiguous()
+    # the pixel regime hands the conv frontend's bf16 features over as they are (LR_TFM_X_BF16)
+    stored_bf16 = frames.dtype == torch.bfloat16 and self.input_is_bf16
+    x = frames[:, :max_len]
+    x = x.contiguous() if stored_bf16 else x.to(torch.float32).contiguous()
     lens = frame_lens.to(device=x.device, dtype=torch.int32).contiguous()
-    x3 = self.input_projection == 'bf16x3'
-    h = _LinearFunction.apply(x, self.input_proj.weight, self.input_proj.bias, x3)
-    h = _AddPositionalFunction.apply(h, self.pe[:max_len].contiguous())
+    fused = self.attention == 'bf16' and bool(_C.lib().lr_attn_fused_supported(max_len, self.d_model // self.nhead))
+    mode = ((_X3 if self.input_projection == 'bf16x3' else 0) | ((_X_BF16 | _DX_BF16) if stored_bf16 else 0) |
+            (_ATTN_FUSED if fused else 0))
+    weights = [self.input_proj.weight, self.input_proj.bias]
     for layer in self.layers:
       at = layer.self_attn
-      qkv = _LinearFunction.apply(h, at.in_proj_weight, at.in_proj_bias, x3)
-      fused = self.attention == 'bf16' and bool(_C.lib().lr_attn_fused_supported(max_len, self.d_model // self.nhead))
-      a = _AttentionFunction.apply(qkv, lens, self.nhead, fused)
-      o = _LinearFunction.apply(a, at.out_proj.weight, at.out_proj.bias, x3)
-      h = _LayerNormFunction.apply(o, h, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
-      f = _ReluFunction.apply(_LinearFunction.apply(h, layer.linear1.weight, layer.linear1.bias, x3))
-      f = _LinearFunction.apply(f, layer.linear2.weight, layer.linear2.bias, x3)
-      h = _LayerNormFunction.apply(f, h, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
+      weights += [at.in_proj_weight, at.in_proj_bias, at.out_proj.weight, at.out_proj.bias, layer.linear1.weight,
+                  layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, layer.norm1.weight, layer.norm1.bias,
+                  layer.norm2.weight, layer.norm2.bias]
+    cfg = (mode, self.d_model, self.nhead, self.layers[0].linear1.out_features, len(self.layers),
+           float(self.layers[0].norm1.eps))
+    h = _StackFunction.apply(x, lens, self.pe, cfg, *weights)
     if self.enable_ctc:
       lp = _ProjLogSoftmaxFunction.apply(h, self.output_proj.weight, self.output_proj.bias, self.output_mask)
       return lp, h, None

@@ -195,7 +195,9 @@ def make_pair(rnn_type, H, layers, bi, dev, seed=123456):
 CFG = [("GRU", 256, 1, True, 32, 75), ("LSTM", 768, 1, True, 32, 75), ("GRU", 700, 1, True, 9, 40),
        ("LSTM", 700, 1, True, 32, 75), ("LSTM", 512, 1, True, 32, 75), ("GRU", 800, 2, True, 32, 75),
        ("LSTM", 64, 2, True, 20, 33), ("GRU", 48, 2, False, 17, 21), ("LSTM", 36, 1, False, 5, 12),
-       ("RNN", 256, 1, True, 32, 75), ("RNN", 52, 2, False, 11, 19)]
+       ("RNN", 256, 1, True, 32, 75), ("RNN", 52, 2, False, 11, 19),
+       # round 4's 16-unit-member clusters against the ORACLE (they were only compared with the step kernels)
+       ("LSTM", 800, 1, True, 32, 75), ("LSTM", 1024, 1, False, 32, 31), ("GRU", 1100, 1, False, 13, 12)]
 
 
 @pytest.mark.parametrize("rnn_type,H,layers,bi,B,T", CFG)
@@ -220,9 +222,9 @@ def test_encoder_forward_backward_matches_oracle(dev, rnn_type, H, layers, bi, B
     return l
 
   from lipreading_amd import _C
-  if rnn_type != "RNN" and H in (256, 512, 700, 768, 800):
+  if rnn_type != "RNN" and H in (256, 512, 700, 768, 800, 1024, 1100):
     # the default path IS the one-launch recurrence for these
-    assert _C.lib().lr_rnn_pair_supported({"GRU": 0, "LSTM": 1}[rnn_type], B, T, 204, H, 2 if bi else 1) in (1, 2)
+    assert _C.lib().lr_rnn_pair_supported({"GRU": 0, "LSTM": 1}[rnn_type], B, T, 204, H, 2 if bi else 1) == 2
   _C.lib().lr_rnn_pair_errors()
   out_r = ref(frames, lens)
   loss_of(out_r).backward()
@@ -313,84 +315,17 @@ def test_bf16x3_input_projection_tracks_the_fp32_path(dev, rnn_type):
     assert float((a - b).abs().max()) / scale < (1e-2 if i == 2 else 1e-4), i
 
 
-@pytest.mark.parametrize("B,T,lens", [(32, 40, None),
-                                      (20, 40, [5, 9, 9, 12, 17, 20, 23, 23, 30, 30, 30, 31, 33, 36, 36, 38, 40, 40, 40, 40]),
-                                      (5, 7, [7, 7, 4, 2, 1]), (2, 1, None)])
-def test_persistent_bf16_recurrence_tracks_the_step_kernels(dev, B, T, lens):
-  """Pixel-regime option (LR_RNN_RECUR_BF16): all T steps of a GRU-256 layer in one launch with W_hh
-  in bf16 registers/LDS.  Same interface buffers as the step kernels; results agree to bf16 level."""
-  from lipreading_amd.data import default_char2idx
-  from lipreading_amd.encoder import VideoEncoder
-  torch.manual_seed(21)
-  enc = VideoEncoder(96, 256, rnn_type='GRU', num_layers=2, bidirectional=True, enable_ctc=True,
-                     vocab_size=64, char2idx=default_char2idx()).to(dev)
-  g = torch.Generator().manual_seed(22)
-  x = torch.randn(B, T, 96, 1, generator=g)
-  lens = torch.tensor(lens) if lens is not None else torch.full((B,), T)
-  wgt = torch.randn(B, T, 65, generator=g).to(dev)
-  valid = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).float().unsqueeze(-1).to(dev)
-  res = {}
-  for mode in ("f32", "bf16"):
-    enc.recurrence = mode
-    enc.zero_grad()
-    lp, hid, fin = enc(x.to(dev), lens, max_len=T)
-    # the final state takes part in the loss: its gradient (dh_n) is injected at each sample's last step
-    ((lp * wgt * valid).sum() + hid.pow(2).sum() + 3.0 * fin.pow(2).sum()).backward()
-    res[mode] = [lp.detach().cpu() * valid.cpu(), hid.detach().cpu(), fin.detach().cpu()] + \
-                [p.grad.cpu().clone() for p in enc.parameters()]
-  enc.recurrence = "f32"
-  assert float((res["f32"][1] - res["bf16"][1]).abs().max()) > 0      # the other path really ran
-  for a, b in zip(res["f32"], res["bf16"]):
-    assert float((a - b).norm()) / max(1e-6, float(a.norm())) < 2e-2
-  # padded positions are exactly zero in both
-  assert float((res["bf16"][1] * (1 - valid.cpu())).abs().max()) == 0.0
-
-
-def test_bf16_recurrence_against_the_oracle_at_the_bench_shape(dev):
-  """VideoEncoder.recurrence = 'bf16' (the pixel regime's default) compared with the ORACLE — the
-  reference's fp32 nn.GRU path — not with this repo's step kernels: landmarks (B=32,T=75), BiGRU-256,
-  ragged lengths.  Stated tolerances: CTC 'mean' loss within 1e-4 absolute (north_star), log-probs
-  within 2e-3 absolute on valid frames (bf16 recurrent operands: 2^-9 relative per product term)."""
-  from lipreading_amd.ctc import ctc_loss_with_status
-  ref, enc = make_pair("GRU", 256, 1, True, dev)
-  enc.recurrence = 'bf16'
-  g = torch.Generator().manual_seed(5)
-  B, T = 32, 75
-  lens = torch.sort(torch.randint(40, T + 1, (B,), generator=g))[0]
-  lens[-8:] = T
-  frames = torch.randn(B, T, 68, 3, generator=g)
-  for b in range(B):
-    frames[b, int(lens[b]):] = 0
-  labels = torch.randint(4, 64, (B, 30), generator=g)
-  ll = torch.full((B,), 30)
-  with torch.no_grad():
-    lp_r, hid_r, _ = ref(frames, lens)
-    lp_h, hid_h, _ = enc(frames.to(dev), lens.to(dev), max_len=T)
-    loss_r = O.ctc_loss(lp_r, labels, lens, ll, 'mean')
-    loss_h, status, _ = ctc_loss_with_status(lp_h, labels.to(dev), lens.to(dev), ll.to(dev), 'mean')
-  assert int(status) == 0
-  from lipreading_amd import _C
-  assert _C.lib().lr_rnn_persistent_supported(0, B, T, 204, 256, 2) == 1     # the one-launch path really ran
-  valid = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(-1)
-  d_lp = float(((lp_h.cpu() - lp_r) * valid).abs().max())
-  d_loss = abs(float(loss_h) - float(loss_r))
-  print("bf16 recurrence vs oracle: loss %.7f vs %.7f (|d| %.3g), max |d log-prob| %.3g" % (float(loss_h), float(loss_r), d_loss, d_lp))
-  assert d_loss <= 1e-4 and d_lp <= 2e-3
-
-
 @pytest.mark.parametrize("B,T,bi,lens", [(32, 75, True, None),
                                          (40, 30, True, "ragged"),      # more pairs than one launch holds: chunked
                                          (70, 9, False, "ragged"),      # unidirectional: 64 samples per launch + 6
                                          (3, 1, True, None), (5, 2, True, [2, 1, 2, 1, 1])])
-@pytest.mark.parametrize("kernels", ["pair", "cluster"])
-def test_split_recurrence_is_fp32_faithful(dev, B, T, bi, lens, kernels):
+def test_split_recurrence_is_fp32_faithful(dev, B, T, bi, lens):
   """LR_RNN_RECUR_SPLIT (VideoEncoder's default where supported) on GRU, H = 256: the whole recurrence of a
-  layer pass in one launch, W_hh and the state as bf16 hi + lo planes — on the 8-member cluster kernels
-  (lr_rnn_cluster.hip, the default since round 3: 118 + 131 us per pass) and on the CU-pair kernels
-  (lr_rnn_pair.hip: 125 + 160 us; what a device too small for a cluster launch runs — selected here by switching
-  the cluster kernels off).  Against the exact-fp32 step kernels on the same weights (2 layers: the second layer's input is
-  the first's output), forward and backward, ragged lengths, final-state gradient injected: agreement to
-  ~1e-5 relative — two orders tighter than the single-plane bf16 kernel — and no pair ever timed out."""
+  layer pass in one launch, W_hh and the state as bf16 hi + lo planes on the 8-member cluster kernels
+  (lr_rnn_cluster.hip; rounds 2-4 also kept CU-pair kernels for devices too small for a cluster launch: removed in
+  round 5, nothing on an MI355X reached them).  Against the exact-fp32 step kernels on the same weights (2 layers: the
+  second layer's input is the first's output), forward and backward, ragged lengths, final-state gradient injected:
+  agreement to ~1e-5 relative, and no member ever timed out."""
   from lipreading_amd import _C
   from lipreading_amd.data import default_char2idx
   from lipreading_amd.encoder import VideoEncoder
@@ -408,20 +343,16 @@ def test_split_recurrence_is_fp32_faithful(dev, B, T, bi, lens, kernels):
     lens = torch.tensor(lens)
   wgt = torch.randn(B, T, 65, generator=g).to(dev)
   valid = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).float().unsqueeze(-1).to(dev)
-  _C.lib().lr_rnn_debug_disable_cluster(1 if kernels == "pair" else 0)
-  try:
-    assert _C.lib().lr_rnn_pair_supported(0, B, T, 96, 256, 2 if bi else 1) == (1 if kernels == "pair" else 2)
-    _C.lib().lr_rnn_pair_errors()
-    res = {}
-    for mode in ("f32", "split"):
-      enc.recurrence = mode
-      enc.zero_grad()
-      lp, hid, fin = enc(x.to(dev), lens, max_len=T)
-      ((lp * wgt * valid).sum() + hid.pow(2).sum() + 3.0 * fin.pow(2).sum()).backward()
-      res[mode] = [lp.detach().cpu() * valid.cpu(), hid.detach().cpu(), fin.detach().cpu()] + \
-                  [p.grad.cpu().clone() for p in enc.parameters()]
-  finally:
-    _C.lib().lr_rnn_debug_disable_cluster(0)
+  assert _C.lib().lr_rnn_pair_supported(0, B, T, 96, 256, 2 if bi else 1) == 2
+  _C.lib().lr_rnn_pair_errors()
+  res = {}
+  for mode in ("f32", "split"):
+    enc.recurrence = mode
+    enc.zero_grad()
+    lp, hid, fin = enc(x.to(dev), lens, max_len=T)
+    ((lp * wgt * valid).sum() + hid.pow(2).sum() + 3.0 * fin.pow(2).sum()).backward()
+    res[mode] = [lp.detach().cpu() * valid.cpu(), hid.detach().cpu(), fin.detach().cpu()] + \
+                [p.grad.cpu().clone() for p in enc.parameters()]
   enc.recurrence = "auto"
   assert _C.lib().lr_rnn_pair_errors() == 0
   if T > 1:
@@ -502,7 +433,7 @@ def test_one_launch_recurrence_covers_every_hidden_size_its_storage_holds(dev):
     assert L.lr_rnn_pair_supported(1, 32, 75, 204, H, 1) == 2 and L.lr_rnn_pair_supported(0, 32, 75, 204, max(H, 868), 1) == 2, H
   for mode, H in ((1, 1156), (1, 1400), (1, 1536), (0, 1156), (0, 2048), (1, 30)):
     assert L.lr_rnn_pair_supported(mode, 32, 75, 204, H, 1) == 0, (mode, H)
-  enc = E.VideoEncoder(16, 1400, rnn_type='LSTM', bidirectional=False, enable_ctc=True, vocab_size=64,
+  enc = E.VideoEncoder(16, 2048, rnn_type='LSTM', bidirectional=False, enable_ctc=True, vocab_size=64,
                        char2idx=default_char2idx()).to(dev)
   x = torch.randn(2, 3, 16, 1, device=dev)
   E._fallback_noted.clear()
@@ -510,8 +441,47 @@ def test_one_launch_recurrence_covers_every_hidden_size_its_storage_holds(dev):
     warnings.simplefilter("always")
     enc(x, torch.tensor([3, 3]), max_len=3)
     enc(x, torch.tensor([3, 3]), max_len=3)
-  notes = [str(m.message) for m in w if "one-launch recurrence" in str(m.message)]
-  assert len(notes) == 1 and "LSTM-1400" in notes[0], notes
+  notes = [str(m.message) for m in w if "one launch per time step" in str(m.message)]
+  assert len(notes) == 1 and "LSTM-2048" in notes[0] and "no one-launch kernel for this shape" in notes[0], notes
+
+
+def test_the_fallback_warning_says_why(dev):
+  """lr_rnn_one_launch_status: a layer that runs the step kernels says whether its SHAPE has no one-launch kernel (1),
+  the product switched them off after time-outs (2: lr_rnn_one_launch_enable(0), train.RecurrenceWatch), the test hook
+  is set (3) or the device is too small (4) — round 4 gave the shape explanation for all of them."""
+  import warnings
+  from lipreading_amd import _C, encoder as E
+  from lipreading_amd.data import default_char2idx
+  L = _C.lib()
+  assert L.lr_rnn_one_launch_status(1, 32, 75, 204, 768, 2) == 0
+  assert L.lr_rnn_one_launch_status(1, 32, 75, 204, 2048, 1) == 1 and L.lr_rnn_one_launch_status(1, 32, 75, 204, 30, 1) == 1
+  assert L.lr_rnn_one_launch_status(2, 32, 75, 204, 256, 2) == 1       # tanh RNN
+  enc = E.VideoEncoder(16, 64, rnn_type='GRU', bidirectional=True, enable_ctc=True, vocab_size=64,
+                       char2idx=default_char2idx()).to(dev)
+  x = torch.randn(2, 3, 16, 1, device=dev)
+
+  def notes_of():
+    E._fallback_noted.clear()
+    with warnings.catch_warnings(record=True) as w:
+      warnings.simplefilter("always")
+      enc(x, torch.tensor([3, 3]), max_len=3)
+    return [str(m.message) for m in w if "one launch per time step" in str(m.message)]
+  assert notes_of() == []
+  try:
+    L.lr_rnn_one_launch_enable(0)
+    assert L.lr_rnn_one_launch_status(0, 2, 3, 16, 64, 2) == 2 and L.lr_rnn_pair_supported(0, 2, 3, 16, 64, 2) == 0
+    n = notes_of()
+    assert len(n) == 1 and "switched off for this process" in n[0] and "no one-launch kernel" not in n[0], n
+  finally:
+    L.lr_rnn_one_launch_enable(1)
+  try:
+    L.lr_rnn_debug_disable_cluster(1)
+    assert L.lr_rnn_one_launch_status(0, 2, 3, 16, 64, 2) == 3
+    n = notes_of()
+    assert len(n) == 1 and "test hook" in n[0], n
+  finally:
+    L.lr_rnn_debug_disable_cluster(0)
+  assert L.lr_rnn_one_launch_status(0, 2, 3, 16, 64, 2) == 0 and notes_of() == []
 
 
 @pytest.mark.parametrize("rnn_type,H,B,T,bi,lens,layers", CLUSTER_CASES)
@@ -561,9 +531,9 @@ def test_cluster_recurrence_is_fp32_faithful(dev, rnn_type, H, B, T, bi, lens, l
   assert float((res["split"][1] * (1 - valid.cpu())).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("rnn_type,H,pair", [("GRU", 256, False), ("GRU", 256, True), ("LSTM", 512, False)])
-def test_a_recurrence_time_out_skips_the_step_and_is_reported(dev, rnn_type, H, pair, capsys):
-  """A member of a pair / cluster that never shows up (here: the test hook makes member 1 return at once) leaves
+@pytest.mark.parametrize("rnn_type,H", [("GRU", 256), ("LSTM", 512)])
+def test_a_recurrence_time_out_skips_the_step_and_is_reported(dev, rnn_type, H, capsys):
+  """A member of a cluster that never shows up (here: the test hook makes member 1 return at once) leaves
   its partners waiting; their waits are bounded, what they produce is garbage, and the reference's contract for a
   batch it cannot use is assert / None => skip (src/train/train_better_model.py:46-50).  Here the fault travels on
   the device: lr_ctc_reduce reports status != 0 with loss 0, lr_adam_step leaves the weights alone, train() counts
@@ -586,7 +556,6 @@ def test_a_recurrence_time_out_skips_the_step_and_is_reported(dev, rnn_type, H, 
   char_lens = torch.full((B,), 7)
   batch = [(frames, lens, chars, char_lens)]
   L.lr_rnn_pair_errors()
-  L.lr_rnn_debug_disable_cluster(1 if pair else 0)      # pair: the CU-pair kernels instead of the cluster kernels
   # a healthy step first
   before = opt.flat.data.clone()
   loss, status = T_.ctc_step(enc, opt, frames.to(dev), lens.to(dev), chars.to(dev), char_lens.to(dev), grad_norm=50)
