@@ -204,8 +204,8 @@ int lr_rnn_one_launch_status(int mode, int B, int T, int I, int H, int D);
  * lr_rnn_pair_errors   pending + total since the last call, and clears both; synchronises the device (once per
  *                      epoch in train(), tests, bench).
  * lr_step_begin        zeroes the flat gradient buffer grad[0..n) (16-byte aligned; what opt.zero_grad() does,
- *                      train_better_model.py:67) and rolls the fault words; also_zero (may be NULL): one more float
- *                      to clear (the accumulator lr_sumsq adds into); one launch.
+ *                      train_better_model.py:67) and rolls the fault words; also_zero (may be NULL): TWO more words
+ *                      to clear (lr_clip_adam_step's `sumsq`: the accumulator and its ticket); one launch.
  * lr_rnn_debug_drop_member   TEST HOOK: member `m` (>= 0) of every pair / cluster returns at once, so its partners
  *                      time out (a few tenths of a second) and raise the fault; -1 (default) = off.
  * lr_rnn_debug_disable_cluster   TEST HOOK: bit 0 makes lr_rnn_pair_supported answer 0 for the cluster shapes
@@ -233,6 +233,12 @@ int lr_debug_busy(int workgroups, int lds_bytes, int microseconds, lr_stream_t s
 int lr_rnn_pair_errors(void);
 int lr_fault_export(const int32_t* status, int32_t* out2, lr_stream_t stream);
 int lr_fault_import(const int32_t* in2, int32_t* status, lr_stream_t stream);
+/* The same two facts as FLOATS that the gradient all-reduce itself can sum (round 5: no second collective): out2 = {1 if
+ * status[0] != 0 else 0, 1 if a recurrence of this step timed out else 0}.  lipreading_amd.distributed writes them
+ * into the two spare words at the front of the flat gradient buffer; lr_adam_step / lr_clip_adam_step take the summed
+ * words as `dist_words` with the number of ranks: the batch is skipped if every rank skipped it (words[0] > world - 0.5),
+ * nobody updates if any rank timed out (words[1] > 0.5). */
+int lr_fault_export_f32(const int32_t* status, float* out2, lr_stream_t stream);
 void* lr_fault_words_ptr(void);
 int lr_step_begin(float* grad, int64_t n, float* also_zero, lr_stream_t stream);
 /* lr_step_begin and lr_ctc_prepare_i64 (below) in ONE launch: the two first launches of a training step
@@ -760,18 +766,23 @@ int lr_sumsq(const float* x, int64_t n, float* out, lr_stream_t stream);
  *               pending recurrence fault), so the caller can report them without a per-step host read;
  *   skip        [1] int32 DEVICE flag or NULL: non-zero = the reference skipped this batch
  *               (`continue`, train_better_model.py:49-50): nothing is updated, step_count stays;
- *   scratch     [4] floats of device scratch. */
+ *   scratch     [4] floats of device scratch;
+ *   dist_words  NULL, or (data parallel) the two summed words of lr_fault_export_f32 with `world` = the number of
+ *               ranks: they then decide skip / fault instead of `skip` (a local fault still counts), and skip[0]
+ *               is overwritten with the ranks' verdict (1 = every rank skipped the batch, else 0). */
 int lr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                  const float* sumsq, float max_norm, float grad_scale, float lr, float beta1,
-                 float beta2, float eps, int32_t* step_count, const int32_t* skip, float* scratch,
-                 lr_stream_t stream);
+                 float beta2, float eps, int32_t* step_count, int32_t* skip, float* scratch,
+                 const float* dist_words, float world, lr_stream_t stream);
 /* lr_sumsq + lr_adam_step with max_norm > 0 in TWO launches instead of three: the sum-of-squares kernel's last workgroup
- * (a ticket in scratch8[4], which it puts back to 0) derives the step's coefficients.  sumsq [1]: cleared by the caller
- * (lr_step_begin's also_zero), receives the sum of squares; scratch8: EIGHT floats of device scratch, zero before the
- * first call; everything else as lr_adam_step. */
+ * (a ticket in sumsq[1]) derives the step's coefficients.  sumsq [2]: {accumulator, ticket}, both zero before the first
+ * call and put back to zero by every call (lr_step_begin's also_zero clears them as well: a launch that was torn down
+ * half-way leaves nothing behind); scratch8: EIGHT floats of device scratch: [0..3] the step's coefficients, [5] the sum
+ * of squares of this step; everything else as lr_adam_step. */
 int lr_clip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* sumsq,
                       float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
-                      int32_t* step_count, const int32_t* skip, float* scratch8, lr_stream_t stream);
+                      int32_t* step_count, int32_t* skip, float* scratch8, const float* dist_words, float world,
+                      lr_stream_t stream);
 
 #ifdef __cplusplus
 }

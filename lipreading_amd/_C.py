@@ -58,6 +58,7 @@ SIGNATURES = {
     "lr_fault_words_ptr": (c_void_p, []),
     "lr_fault_export": (c_int, [P, P, P]),
     "lr_fault_import": (c_int, [P, P, P]),
+    "lr_fault_export_f32": (c_int, [P, P, P]),
     "lr_step_begin": (c_int, [P, c_int64, P, P]),
     "lr_step_begin_ctc": (c_int, [P, c_int64, P, P, c_int64, P, P, P, P, P, c_int, c_int, P]),
     "lr_rnn_debug_drop_member": (None, [c_int]),
@@ -126,9 +127,9 @@ SIGNATURES = {
     "lr_cat_directions": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "lr_sumsq": (c_int, [P, c_int64, P, P]),
     "lr_adam_step": (c_int, [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_float,
-                              c_float, P, P, P, P]),
+                              c_float, P, P, P, P, c_float, P]),
     "lr_clip_adam_step": (c_int, [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_float,
-                                   c_float, P, P, P, P]),
+                                   c_float, P, P, P, P, c_float, P]),
 }
 
 

@@ -37,6 +37,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short bf16_t;
 
 constexpr int FBM = 128, FBN = 128, FBK = 32;
@@ -46,6 +49,7 @@ constexpr int KS_LDF = 128;           // floats per k row of a K-strided fp32 ti
 // bytes of one operand's LDS image (the largest of its forms)
 constexpr int OP_BYTES_X3 = 2 * FBM * KC_LD * 2;     // hi + lo planes, K-contiguous form: 20480 (K-strided: 16384)
 constexpr int OP_BYTES_F32 = FBM * KC_LDF * 4;       // 16896 (K-strided: 16384)
+constexpr int C_LDS = FBN + 4;        // floats per row of the epilogue's staging tile
 
 enum { PREC_X3 = 0, PREC_F32 = 1 };
 
@@ -61,6 +65,7 @@ struct FJob {
   int M, N, K, lda, ldb, ldc, ldadd, add_period, ldmask;
   int flags, splits, k_chunk, tile0, ny, tiles;
   int vec_a, vec_b;      // 0: element loads; 1: 16-byte (fp32) / 8-byte (bf16) loads where a quad is whole; 2: whole quads only
+  int vec_c;             // the epilogue's row-contiguous accesses (C, slabs, bias, addend, mask) are whole aligned quads
   float alpha, beta;
 };
 constexpr int FMAXJOBS = 20;
@@ -120,66 +125,68 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
 //                quad lane & 7 — a wave's store of one pass is 512 contiguous bytes of its plane.
 template <int PREC, bool KS, bool BF>
 struct Tile {
-  // ---- global -> registers --------------------------------------------------------------------------------------
-  // `fast` (workgroup-uniform, the common case): whole aligned quads only — every load is UNCONDITIONAL and nothing is
-  // selected behind it: a quad outside the matrix is read from a CLAMPED address instead (rows / columns past the edge
-  // feed accumulators that are never stored; the K tail is zeroed on the way into LDS, store() below), so an operand's
-  // four loads are in flight together and stay in flight under the previous stage's MFMAs.  A predicate around each load
-  // — the guarded path, for leading dimensions or extents that are not multiples of four — makes hipcc close every
-  // branch with a wait for its load (measured: 5.6 us per 32-k stage, ten times the stage's MFMAs), and a select right
-  // behind an unconditional load puts the wait there as well.
-  static __device__ __forceinline__ float4 quad(const void* base, int64_t off) {
-    float4 v;
-    if (BF) {
-      const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(base) + off);
-      v.x = __builtin_bit_cast(float, u.x << 16);
-      v.y = __builtin_bit_cast(float, u.x & 0xffff0000u);
-      v.z = __builtin_bit_cast(float, u.y << 16);
-      v.w = __builtin_bit_cast(float, u.y & 0xffff0000u);
-    } else {
-      v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+  // ---- global -> registers, FAST form: buffer loads (see the kernel) ------------------------------------------------
+  static constexpr int ES = BF ? 2 : 4;     // bytes per element
+  // byte offset of each of the thread's four quads from (matrix base + the stage's scalar offset); bit 31: the quad's row
+  // (K contiguous) / columns (K strided) lie past the matrix edge — never in range, always zeros
+  static __device__ __forceinline__ void offsets(unsigned (&voff)[4], int ld, int row0, int rows, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (KS) {
+        const int lane = tid & 63, col = row0 + 32 * (tid >> 6) + 4 * (lane & 7), kr = 8 * i + (lane >> 3);
+        voff[i] = col < rows ? (unsigned)((kr * ld + col) * ES) : 0x80000000u;
+      } else {
+        const int e = tid + 256 * i, row = row0 + (e >> 3);
+        voff[i] = row < rows ? (unsigned)((row * ld + 4 * (e & 7)) * ES) : 0x80000000u;
+      }
     }
-    return v;
   }
-  // K: the operand's whole contraction extent (clamp limit); kend: where this workgroup's K range ends
+  static __device__ __forceinline__ unsigned stage_offset(int k0, int ld) { return (unsigned)(KS ? k0 * ld : k0) * ES; }
+  // krem = kend - k0: a quad whose k (relative to the stage) is at or past it is the K tail -> bit 31 -> zeros.  Only a K
+  // range's last stages have one (workgroup-uniform branch); every other stage's loads have no VALU instruction at all.
+  static __device__ __forceinline__ void loadf(float4 (&r)[4], __amdgpu_buffer_rsrc_t rsrc, const unsigned (&voff)[4],
+                                               unsigned soff, int krem, int tid) {
+    unsigned o[4] = {voff[0], voff[1], voff[2], voff[3]};
+    if (krem < FBK) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = KS ? 8 * i + ((tid & 63) >> 3) : 4 * ((tid + 256 * i) & 7);
+        if (k >= krem) o[i] = 0x80000000u;
+      }
+      if (krem <= 0) soff = 0;     // (a stage past the end of the K range: nothing but zeros, whatever its offset)
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (BF) {
+        const u32x2 u = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)o[i], (int)soff, 0));
+        r[i].x = __builtin_bit_cast(float, u[0] << 16);
+        r[i].y = __builtin_bit_cast(float, u[0] & 0xffff0000u);
+        r[i].z = __builtin_bit_cast(float, u[1] << 16);
+        r[i].w = __builtin_bit_cast(float, u[1] & 0xffff0000u);
+      } else {
+        // (the WHOLE vector is reinterpreted: taking the builtin's result apart element by element makes this hipcc
+        // narrow the load to one dword and use it for all four — seen in the ISA, not in any diagnostic)
+        const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o[i], (int)soff, 0));
+        r[i] = make_float4(f[0], f[1], f[2], f[3]);
+      }
+    }
+  }
+  // ---- global -> registers, guarded form: element (or whole-quad) loads under predicates ----------------------------
   static __device__ __forceinline__ void load(float4 (&r)[4], const void* base, int ld, int row0, int rows, int k0,
-                                              int kend, int K, int how, int tid) {
-    const bool fast = how == 2, vec = how != 0;
+                                              int kend, bool vec, int tid) {
     if (KS) {
       const int lane = tid & 63, col = row0 + 32 * (tid >> 6) + 4 * (lane & 7);
-      if (fast) {
-        const int cc = min(col, rows - 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = quad(base, (int64_t)min(k0 + 8 * i + (lane >> 3), K - 1) * ld + cc);
-        return;
-      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int k = k0 + 8 * i + (lane >> 3);
         r[i] = ld4<BF>(base, (int64_t)k * ld + col, k < kend ? rows - col : 0, vec);
       }
     } else {
-      if (fast) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int e = tid + 256 * i;
-          r[i] = quad(base, (int64_t)min(row0 + (e >> 3), rows - 1) * ld + min(k0 + 4 * (e & 7), K - 4));
-        }
-        return;
-      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int e = tid + 256 * i, row = row0 + (e >> 3), k = k0 + 4 * (e & 7);
         r[i] = ld4<BF>(base, (int64_t)row * ld + k, row < rows ? kend - k : 0, vec);
       }
-    }
-  }
-  // the K tail of a `fast` operand (only a K range's last stage has one: workgroup-uniform): quads at or past kend -> 0
-  static __device__ __forceinline__ void zero_tail(float4 (&r)[4], int k0, int kend, int tid) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = KS ? k0 + 8 * i + ((tid & 63) >> 3) : k0 + 4 * ((tid + 256 * i) & 7);
-      if (k >= kend) r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   // ---- registers -> LDS -----------------------------------------------------------------------------------------
@@ -242,17 +249,35 @@ struct Tile {
 };
 
 template <int PREC, bool TA, bool TB, bool ABF, bool BBF>
-__global__ __launch_bounds__(256, 2) void fgemm_kernel(const FArgs args) {
+__global__ __launch_bounds__(256, 1) void fgemm_kernel(const FArgs args) {
   constexpr int OPB = PREC == PREC_X3 ? OP_BYTES_X3 : OP_BYTES_F32;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * OPB];
-  unsigned char* As = smem;
-  unsigned char* Bs = smem + OPB;
+  // two stage buffers (A + B each); the epilogue stages 64 x 128 outputs at a time through the same memory
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * OPB];
+  static_assert(4 * OPB >= 64 * C_LDS * 4, "the epilogue's staging tile fits the stage buffers");
   typedef Tile<PREC, TA, ABF> TileA;      // A^T is stored [K][M]: K strided
   typedef Tile<PREC, !TB, BBF> TileB;     // B stored [K][N] unless TB ([N][K])
   int ji = 0;
   for (int q = 1; q < args.njobs; ++q)
     if ((int)blockIdx.x >= args.j[q].tile0) ji = q;      // workgroup-uniform
-  const FJob& g = args.j[ji];
+  // The job's fields as LOCAL scalars, read once.  Through a reference into the kernel arguments hipcc re-loads a field
+  // at every use behind a global store (1003 scalar loads + waits in the first cut, ~6 per output element of the
+  // epilogue).
+  struct Job {
+    const void *A, *B;
+    float* C;
+    const float *bias, *addend, *mask;
+    float *colsum, *slabs;
+    int M, N, K, lda, ldb, ldc, ldadd, add_period, ldmask, flags, k_chunk, tile0, ny, tiles, vec_a, vec_b, vec_c;
+    float alpha, beta;
+  } g;
+  {
+    const FJob& j = args.j[ji];
+    g.A = j.A; g.B = j.B; g.C = j.C; g.bias = j.bias; g.addend = j.addend; g.mask = j.mask; g.colsum = j.colsum;
+    g.slabs = j.slabs; g.M = j.M; g.N = j.N; g.K = j.K; g.lda = j.lda; g.ldb = j.ldb; g.ldc = j.ldc; g.ldadd = j.ldadd;
+    g.add_period = j.add_period; g.ldmask = j.ldmask; g.flags = j.flags; g.k_chunk = j.k_chunk; g.tile0 = j.tile0;
+    g.ny = j.ny; g.tiles = j.tiles; g.vec_a = j.vec_a; g.vec_b = j.vec_b; g.vec_c = j.vec_c; g.alpha = j.alpha;
+    g.beta = j.beta;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int t = (int)blockIdx.x - g.tile0;
@@ -270,33 +295,10 @@ __global__ __launch_bounds__(256, 2) void fgemm_kernel(const FArgs args) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // the K loop in two instantiations: FAST (both operands in whole aligned quads: the straight-line loop with no
-  // predicate around any load) and the guarded one; the choice is workgroup-uniform
-  auto k_loop = [&](auto fast_tag) {
-  constexpr bool FAST = decltype(fast_tag)::value;
-  const int how_a = FAST ? 2 : (g.vec_a == 2 ? 1 : g.vec_a), how_b = FAST ? 2 : (g.vec_b == 2 ? 1 : g.vec_b);
-  float4 ra[4], rb[4];
-  TileA::load(ra, g.A, g.lda, m0, g.M, kbeg, kend, g.K, how_a, tid);
-  TileB::load(rb, g.B, g.ldb, n0, g.N, kbeg, kend, g.K, how_b, tid);
-  for (int k0 = kbeg; k0 < kend; k0 += FBK) {
-    lr_lds_barrier();                       // every wave has read the previous stage
-    if (FAST && k0 + FBK > kend) {          // (workgroup-uniform) the K tail of operands loaded without predicates
-      TileA::zero_tail(ra, k0, kend, tid);
-      TileB::zero_tail(rb, k0, kend, tid);
-    }
-    TileA::store(ra, As, tid);
-    TileB::store(rb, Bs, tid);
-    if (do_colsum) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        cs.x += ra[i].x; cs.y += ra[i].y; cs.z += ra[i].z; cs.w += ra[i].w;
-      }
-    }
-    lr_lds_barrier();
-    if (k0 + FBK < kend) {                  // the next stage's loads fly under this stage's MFMAs
-      TileA::load(ra, g.A, g.lda, m0, g.M, k0 + FBK, kend, g.K, how_a, tid);
-      TileB::load(rb, g.B, g.ldb, n0, g.N, k0 + FBK, kend, g.K, how_b, tid);
-    }
+  // one stage's contraction out of the stage buffer at `buf`
+  auto contract = [&](const unsigned char* buf) __attribute__((always_inline)) {
+    const unsigned char* As = buf;
+    const unsigned char* Bs = buf + OPB;
     if (PREC == PREC_X3) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -341,10 +343,81 @@ __global__ __launch_bounds__(256, 2) void fgemm_kernel(const FArgs args) {
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
-  }
   };
-  if (g.vec_a == 2 && g.vec_b == 2) k_loop(std::true_type{});
-  else k_loop(std::false_type{});
+  auto add_colsum = [&](const float4 (&r)[4]) __attribute__((always_inline)) {
+    if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        cs.x += r[i].x; cs.y += r[i].y; cs.z += r[i].z; cs.w += r[i].w;
+      }
+    }
+  };
+
+  if (g.vec_a == 2 && g.vec_b == 2) {
+    // ---- FAST (workgroup-uniform: both operands in whole aligned quads) ------------------------------------------------
+    // These products leave one workgroup per compute unit at best (38 .. 152 tiles on 256 CUs): one wave per SIMD with
+    // nothing to switch to, so everything a stage does besides its 24 MFMAs has to ride UNDER them in the same wave.
+    //   * loads are buffer loads from a per-thread byte offset fixed at the start + the stage's SCALAR offset: no
+    //     address arithmetic in the loop; a quad outside the matrix (rows / columns past the edge, the K tail) has bit 31
+    //     set in its offset, is out of the resource's range and comes back as zeros — no predicate, no select;
+    //   * two register sets, loads issued two stages ahead (the wait in front of a stage's LDS write is a counted one);
+    //   * two stage buffers in LDS: while the MFMAs of stage s read buffer s & 1, the split (fp32 -> bf16 hi + lo) and the
+    //     LDS writes of stage s + 1 go to the other one in the same basic block; ONE barrier per stage.
+    // Measured on the way here (M 2400, N 768): one buffer + one register set 1.17 us per 32-k stage; two register
+    // sets 0.95; a launch's fixed cost 27 us -> 19 us when the job's fields moved out of the kernel arguments' memory,
+    // and the rest of it went with the unrolled per-register epilogue (see below).
+    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), (short)0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), (short)0, 0x7fffffff, 0x00020000);
+    unsigned offa[4], offb[4];
+    TileA::offsets(offa, g.lda, m0, g.M, tid);
+    TileB::offsets(offb, g.ldb, n0, g.N, tid);
+    float4 ra[2][4], rb[2][4];
+    auto load_stage = [&](int q, int k0) __attribute__((always_inline)) {
+      TileA::loadf(ra[q], ra_rsrc, offa, TileA::stage_offset(k0, g.lda), kend - k0, tid);
+      TileB::loadf(rb[q], rb_rsrc, offb, TileB::stage_offset(k0, g.ldb), kend - k0, tid);
+    };
+    load_stage(0, kbeg);
+    load_stage(1, kbeg + FBK);
+    TileA::store(ra[0], smem, tid);
+    TileB::store(rb[0], smem + OPB, tid);
+    add_colsum(ra[0]);
+    load_stage(0, kbeg + 2 * FBK);
+    lr_lds_barrier();
+    for (int kq = kbeg; kq < kend; kq += 2 * FBK) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {          // (fully unrolled: buffers and register sets are static)
+        // stage kq + q * FBK: contract buffer q; registers of the NEXT stage (set q ^ 1) -> buffer q ^ 1
+        contract(smem + q * 2 * OPB);
+        TileA::store(ra[q ^ 1], smem + (q ^ 1) * 2 * OPB, tid);
+        TileB::store(rb[q ^ 1], smem + (q ^ 1) * 2 * OPB + OPB, tid);
+        add_colsum(ra[q ^ 1]);
+        load_stage(q ^ 1, kq + (q + 3) * FBK);
+        lr_lds_barrier();
+      }
+    }
+  } else {
+    // ---- guarded: leading dimensions or extents that are not multiples of four — element loads under predicates, one
+    // stage buffer, one register set (hipcc closes every predicated load with a wait: a memory round trip each) ---------
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + OPB;
+    const int how_a = g.vec_a == 2 ? 1 : g.vec_a, how_b = g.vec_b == 2 ? 1 : g.vec_b;
+    float4 ra[4], rb[4];
+    TileA::load(ra, g.A, g.lda, m0, g.M, kbeg, kend, how_a != 0, tid);
+    TileB::load(rb, g.B, g.ldb, n0, g.N, kbeg, kend, how_b != 0, tid);
+    for (int k0 = kbeg; k0 < kend; k0 += FBK) {
+      lr_lds_barrier();                       // every wave has read the previous stage
+      TileA::store(ra, As, tid);
+      TileB::store(rb, Bs, tid);
+      add_colsum(ra);
+      lr_lds_barrier();
+      if (k0 + FBK < kend) {
+        TileA::load(ra, g.A, g.lda, m0, g.M, k0 + FBK, kend, how_a != 0, tid);
+        TileB::load(rb, g.B, g.ldb, n0, g.N, k0 + FBK, kend, how_b != 0, tid);
+      }
+      contract(smem);
+    }
+    lr_lds_barrier();
+  }
 
   // ---- column sums of A (the bias gradient of a weight-gradient product): thread (wave w, lane) holds columns
   // 32 w + 4 (lane & 7) .. + 3 of its k rows; fold the 8 row groups of a wave in a fixed order -------------------------
@@ -365,57 +438,90 @@ __global__ __launch_bounds__(256, 2) void fgemm_kernel(const FArgs args) {
     }
   }
 
-  // ---- epilogue: C/D layout of a 32 x 32 tile: column = lane & 31, row of register r = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-  // What the epilogue reads — addend, mask, C for beta — is fetched for eight registers at a time, from clamped rows
-  // and through 32-bit element offsets from the (uniform) base pointers, so that the loads are in flight together
-  // (one load, one wait, one store per element is a memory round trip for each of a thread's 64 outputs).
+  // ---- epilogue, staged through LDS 64 rows at a time.  The accumulators leave the registers with 64 LDS stores per
+  // wave half (C/D layout of a 32 x 32 tile: column = lane & 31, row of register r = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+  // and everything else is a LOOP over row-contiguous quads: 16-byte loads of bias / addend / mask / C and 16-byte
+  // stores, a few dozen instructions executed eight times.  The first cut applied the epilogue per accumulator register,
+  // fully unrolled: ~20 KB of straight-line code that every workgroup ran once — fetched cold, it was most of a
+  // launch's 19 us fixed cost at every K.
+  float* Cs = reinterpret_cast<float*>(smem);
   const int lr = lane & 31, lk = lane >> 5;
-  const bool wrap = g.addend && g.add_period < g.M;    // workgroup-uniform: a periodic table (else a residual: row itself)
-  const bool has_add = g.addend != nullptr, has_mask = g.mask != nullptr, has_beta = g.beta != 0.f;
+  const bool wrap = g.addend && g.add_period < g.M;    // a periodic table (else a residual: the row itself)
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + lr;
-      const bool cok = col < g.N;
-      const int ccol = cok ? col : 0;
-      const int rbase = m0 + wm * 64 + i * 32 + 4 * lk;
-      const float bv = (g.bias && !g.slabs && cok) ? g.bias[ccol] : 0.f;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float add[8], mk[8], old[8];
+          for (int r = 0; r < 16; ++r)
+            Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * C_LDS + wn * 64 + j * 32 + lr] = acc[i][j][r];
+    }
+    lr_lds_barrier();
+#pragma unroll 2
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + 256 * u, rl = idx >> 5, c4 = 4 * (idx & 31);
+      const int row = m0 + 64 * half + rl, col = n0 + c4;
+      if (row >= g.M || col >= g.N) continue;
+      const float4 a4 = *reinterpret_cast<const float4*>(Cs + rl * C_LDS + c4);
+      float v[4] = {a4.x, a4.y, a4.z, a4.w};
+      const int nv = min(4, g.N - col);                 // (4 when the row-contiguous accesses are whole quads: vec_c)
+      if (g.slabs) {
+        float* sp = g.slabs + ((int64_t)zs * g.M + row) * g.N + col;
+        if (g.vec_c) *reinterpret_cast<float4*>(sp) = a4;
+        else {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int r = 8 * h + q;
-          const int row = min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1);
-          add[q] = 0.f; mk[q] = 1.f; old[q] = 0.f;
-          if (g.slabs) continue;
-          if (has_add) add[q] = g.addend[(unsigned)((wrap ? row % g.add_period : row) * g.ldadd + ccol)];
-          if (has_mask) mk[q] = g.mask[(unsigned)(row * g.ldmask + ccol)];
-          if (has_beta) old[q] = g.C[(unsigned)(row * g.ldc + ccol)];
+          for (int e = 0; e < 4; ++e)
+            if (e < nv) sp[e] = v[e];
         }
+        continue;
+      }
+      float bv[4] = {0.f, 0.f, 0.f, 0.f}, add[4] = {0.f, 0.f, 0.f, 0.f}, mk[4] = {1.f, 1.f, 1.f, 1.f}, old[4] = {0.f, 0.f, 0.f, 0.f};
+      const int arow = wrap ? row % g.add_period : row;
+      if (g.vec_c) {
+        if (g.bias) { const float4 q = *reinterpret_cast<const float4*>(g.bias + col); bv[0] = q.x; bv[1] = q.y; bv[2] = q.z; bv[3] = q.w; }
+        if (g.addend) { const float4 q = *reinterpret_cast<const float4*>(g.addend + (int64_t)arow * g.ldadd + col); add[0] = q.x; add[1] = q.y; add[2] = q.z; add[3] = q.w; }
+        if (g.mask) { const float4 q = *reinterpret_cast<const float4*>(g.mask + (int64_t)row * g.ldmask + col); mk[0] = q.x; mk[1] = q.y; mk[2] = q.z; mk[3] = q.w; }
+        if (g.beta != 0.f) { const float4 q = *reinterpret_cast<const float4*>(g.C + (int64_t)row * g.ldc + col); old[0] = q.x; old[1] = q.y; old[2] = q.z; old[3] = q.w; }
+      } else {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int r = 8 * h + q;
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
-          const bool ok = cok && row < g.M;
-          if (g.slabs) {
-            if (ok) g.slabs[((int64_t)zs * g.M + row) * g.N + col] = acc[i][j][r];
-            continue;
-          }
-          float out = g.alpha * acc[i][j][r] + bv + add[q];
-          if (g.flags & LR_FGEMM_RELU) out = fmaxf(out, 0.f);
-          out = mk[q] > 0.f ? out : 0.f;
-          if (g.flags & LR_FGEMM_C_BF16) {
-            const __bf16 hb = (__bf16)out;
-            if (ok) reinterpret_cast<bf16_t*>(g.C)[(unsigned)(row * g.ldc + col)] = __builtin_bit_cast(bf16_t, hb);
-          } else if (ok) {
-            g.C[(unsigned)(row * g.ldc + col)] = out + g.beta * old[q];
-          }
+        for (int e = 0; e < 4; ++e) {
+          if (e >= nv) continue;
+          if (g.bias) bv[e] = g.bias[col + e];
+          if (g.addend) add[e] = g.addend[(int64_t)arow * g.ldadd + col + e];
+          if (g.mask) mk[e] = g.mask[(int64_t)row * g.ldmask + col + e];
+          if (g.beta != 0.f && !(g.flags & LR_FGEMM_C_BF16)) old[e] = g.C[(int64_t)row * g.ldc + col + e];
         }
-        __builtin_amdgcn_sched_barrier(0);   // eight outputs' operands at a time (a whole tile's at once spills)
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float out = g.alpha * v[e] + bv[e] + add[e];
+        if (g.flags & LR_FGEMM_RELU) out = fmaxf(out, 0.f);
+        out = mk[e] > 0.f ? out : 0.f;
+        v[e] = out + g.beta * old[e];
+      }
+      if (g.flags & LR_FGEMM_C_BF16) {
+        bf16_t* cp = reinterpret_cast<bf16_t*>(g.C) + (int64_t)row * g.ldc + col;
+        const bf16x2 p0 = __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2), p1 = __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2);
+        if (g.vec_c) *reinterpret_cast<uint2*>(cp) = make_uint2(__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1));
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < nv) { const __bf16 hb = (__bf16)v[e]; cp[e] = __builtin_bit_cast(bf16_t, hb); }
+        }
+      } else {
+        float* cp = g.C + (int64_t)row * g.ldc + col;
+        if (g.vec_c) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < nv) cp[e] = v[e];
+        }
       }
     }
+    lr_lds_barrier();
+  }
 }
 
 // split-K combine (fixed order over the slabs) + the epilogue
@@ -493,8 +599,14 @@ int lr_fgemm_launch(int prec, int form, int a_bf16, int b_bf16, const lr_fgemm_j
     g.vec_b = (s.ldb % 4 == 0) && aligned_to(s.B, 4 * eb);
     // whole quads only: the contiguous extent of the operand is a multiple of four as well (A: K, or M when stored
     // [K][M]; B: K when stored [N][K], else N)
-    if (g.vec_a && (form == LR_FGEMM_TN ? s.M : s.K) % 4 == 0) g.vec_a = 2;
-    if (g.vec_b && (form == LR_FGEMM_NT ? s.K : s.N) % 4 == 0) g.vec_b = 2;
+    // ... and the matrix stays below 2^31 bytes (the buffer loads' offsets)
+    const int64_t rows_a = form == LR_FGEMM_TN ? s.K : s.M, rows_b = form == LR_FGEMM_NT ? s.N : s.K;
+    if (g.vec_a && (form == LR_FGEMM_TN ? s.M : s.K) % 4 == 0 && rows_a * s.lda * (int64_t)ea < (1ll << 31)) g.vec_a = 2;
+    if (g.vec_b && (form == LR_FGEMM_NT ? s.K : s.N) % 4 == 0 && rows_b * s.ldb * (int64_t)eb < (1ll << 31)) g.vec_b = 2;
+    const size_t ec = (s.flags & LR_FGEMM_C_BF16) ? 2 : 4;
+    g.vec_c = s.N % 4 == 0 && s.ldc % 4 == 0 && aligned_to(s.C, 4 * ec) && (!s.bias || aligned_to(s.bias, 16)) &&
+              (!s.addend || (s.ldadd % 4 == 0 && aligned_to(s.addend, 16))) &&
+              (!s.mask || (s.ldmask % 4 == 0 && aligned_to(s.mask, 16))) && (splits <= 1 || aligned_to(s.slabs, 16));
   }
   lr_clear_error();
   const dim3 grid(tile0), block(256);

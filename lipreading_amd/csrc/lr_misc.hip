@@ -219,13 +219,23 @@ __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __re
 // whole optimiser step replayable from a hipGraph (host-computed corrections would be frozen).
 //   st[0] = active (0/1), st[1] = lr / (1 - beta1^t), st[2] = 1 / sqrt(1 - beta2^t),
 //   st[3] = gradient scale (grad_scale x clip coefficient)
-__device__ __forceinline__ void adam_prepare_body(int32_t* __restrict__ step_count, const int32_t* __restrict__ skip,
+__device__ __forceinline__ void adam_prepare_body(int32_t* __restrict__ step_count, int32_t* __restrict__ skip,
                                                   const int32_t* __restrict__ fault, bool has_sumsq, float sumsq_value,
                                                   float max_norm, float grad_scale, float lr, float beta1, float beta2,
-                                                  float* __restrict__ st) {
+                                                  float* __restrict__ st, const float* __restrict__ dist_words,
+                                                  float world) {
   // fault[0] != 0: a one-launch recurrence of THIS step gave up waiting for a partner workgroup (its outputs
-  // and gradients are garbage): the step is skipped like a batch the reference skips (train_better_model.py:49-50)
-  const bool active = !(skip && skip[0] != 0) && !(fault && fault[0] != 0);
+  // and gradients are garbage): the step is skipped like a batch the reference skips (train_better_model.py:49-50).
+  // dist_words (data parallel): {number of ranks whose batch was skipped, number of ranks whose recurrence timed out},
+  // summed over the ranks by the gradient all-reduce itself (lr_fault_export_f32): the batch counts as skipped only if
+  // EVERY rank skipped it, and nobody updates if ANY rank's gradient is garbage — it is in everybody's sum.
+  bool skipped = skip && skip[0] != 0, faulted = fault && fault[0] != 0;
+  if (dist_words) {
+    skipped = dist_words[0] > world - 0.5f;
+    faulted = faulted || dist_words[1] > 0.5f;
+    if (skip) skip[0] = skipped ? 1 : 0;     // the caller's status becomes the ranks' verdict (rounds 1-4: a MIN all-reduce)
+  }
+  const bool active = !skipped && !faulted;
   int t = step_count[0];
   if (active) step_count[0] = ++t;
   else step_count[1] += 1;      // steps skipped (a batch the reference `continue`s past, or a recurrence fault)
@@ -244,20 +254,25 @@ __device__ __forceinline__ void adam_prepare_body(int32_t* __restrict__ step_cou
   st[2] = 1.f / sqrtf(bc2);
   st[3] = scale;
 }
-__global__ void adam_prepare_kernel(int32_t* __restrict__ step_count, const int32_t* __restrict__ skip,
+__global__ void adam_prepare_kernel(int32_t* __restrict__ step_count, int32_t* __restrict__ skip,
                                     const int32_t* __restrict__ fault, const float* __restrict__ sumsq, float max_norm,
-                                    float grad_scale, float lr, float beta1, float beta2, float* __restrict__ st) {
+                                    float grad_scale, float lr, float beta1, float beta2, float* __restrict__ st,
+                                    const float* __restrict__ dist_words, float world) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   adam_prepare_body(step_count, skip, fault, sumsq != nullptr, sumsq ? sumsq[0] : 0.f, max_norm, grad_scale, lr, beta1, beta2,
-                    st);
+                    st, dist_words, world);
 }
 // sumsq_kernel AND adam_prepare_kernel in one launch (lr_clip_adam_step): every workgroup adds its partial sum of squares
-// to out[0] and takes a ticket (st[4], an unsigned that the last workgroup puts back to 0); the one that draws the last
-// ticket — every other partial sum is in out[0] by then — derives the step's coefficients.
+// to out[0] and takes a ticket (out[1], an unsigned); the one that draws the last ticket — every other partial sum is in
+// out[0] by then — derives the step's coefficients, leaves the sum in st[5] (FusedAdam.total_norm) and puts BOTH words
+// back to 0: the accumulator is clean for the next step whoever launches it (an eager optimiser step behind a replayed
+// graph used to pay an ATen fill for that), and lr_step_begin clears both words as well, so a launch that was torn down
+// half-way cannot leave a ticket behind that no later launch would ever complete.
 __global__ void sumsq_prepare_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out,
-                                     int32_t* __restrict__ step_count, const int32_t* __restrict__ skip,
+                                     int32_t* __restrict__ step_count, int32_t* __restrict__ skip,
                                      const int32_t* __restrict__ fault, float max_norm, float grad_scale, float lr,
-                                     float beta1, float beta2, float* __restrict__ st) {
+                                     float beta1, float beta2, float* __restrict__ st,
+                                     const float* __restrict__ dist_words, float world) {
   float acc = 0.f;
   const int64_t n4 = n >> 2;
   const float4* x4 = reinterpret_cast<const float4*>(x);
@@ -277,12 +292,13 @@ __global__ void sumsq_prepare_kernel(const float* __restrict__ x, int64_t n, flo
   for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += part[w];
   atomicAdd(out, s);
   __threadfence();
-  unsigned* ticket = reinterpret_cast<unsigned*>(st + 4);
+  unsigned* ticket = reinterpret_cast<unsigned*>(out + 1);
   if (atomicAdd(ticket, 1u) != gridDim.x - 1) return;
   *ticket = 0u;
   __threadfence();
-  const float total = atomicAdd(out, 0.f);   // (an atomic read: served where the other workgroups' adds were)
-  adam_prepare_body(step_count, skip, fault, true, total, max_norm, grad_scale, lr, beta1, beta2, st);
+  const float total = atomicExch(out, 0.f);   // (an atomic read, served where the other workgroups' adds were, and the reset)
+  st[5] = total;
+  adam_prepare_body(step_count, skip, fault, true, total, max_norm, grad_scale, lr, beta1, beta2, st, dist_words, world);
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -615,7 +631,7 @@ __global__ void step_begin_kernel(float4* __restrict__ g, int64_t n4, float* __r
     fault[1] += fault[0];
     fault[0] = 0;
   }
-  if (i0 == 0 && also_zero) also_zero[0] = 0.f;
+  if (i0 == 0 && also_zero) also_zero[0] = also_zero[1] = 0.f;   // (sum-of-squares accumulator, its ticket)
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int64_t i = i0; i < n4; i += (int64_t)gridDim.x * blockDim.x) g[i] = z;
   if (i0 < ntail) tail[i0] = 0.f;
@@ -646,7 +662,7 @@ __global__ void step_begin_ctc_kernel(float4* __restrict__ g, int64_t n4, float*
     fault[1] += fault[0];
     fault[0] = 0;
   }
-  if (i0 == 0 && also_zero) also_zero[0] = 0.f;
+  if (i0 == 0 && also_zero) also_zero[0] = also_zero[1] = 0.f;   // (sum-of-squares accumulator, its ticket)
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int64_t i = i0; i < n4; i += (int64_t)zero_blocks * blockDim.x) g[i] = z;
   if (i0 < ntail) tail[i0] = 0.f;
@@ -656,6 +672,14 @@ __global__ void fault_export_kernel(const int32_t* __restrict__ status, const in
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   out2[0] = status ? status[0] : 0;
   out2[1] = (fault && fault[0] != 0) ? -1 : 0;
+}
+// the same two facts as floats the gradient all-reduce can SUM: {1 if this rank's batch was skipped, 1 if its recurrence
+// timed out} (lipreading_amd.distributed writes them into the spare words at the front of the flat gradient buffer)
+__global__ void fault_export_f32_kernel(const int32_t* __restrict__ status, const int32_t* __restrict__ fault,
+                                        float* __restrict__ out2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  out2[0] = (status && status[0] != 0) ? 1.f : 0.f;
+  out2[1] = (fault && fault[0] != 0) ? 1.f : 0.f;
 }
 __global__ void fault_import_kernel(const int32_t* __restrict__ in2, int32_t* __restrict__ status,
                                     int32_t* __restrict__ fault) {
@@ -766,6 +790,11 @@ extern "C" int lr_fault_export(const int32_t* status, int32_t* out2, lr_stream_t
   LR_LAUNCH(fault_export_kernel, dim3(1), dim3(64), 0, stream, status, (const int32_t*)lr_fault_words(), out2);
   return lr_launch_status();
 }
+extern "C" int lr_fault_export_f32(const int32_t* status, float* out2, lr_stream_t stream) {
+  LR_CHECK_ARG(out2);
+  LR_LAUNCH(fault_export_f32_kernel, dim3(1), dim3(64), 0, stream, status, (const int32_t*)lr_fault_words(), out2);
+  return lr_launch_status();
+}
 extern "C" int lr_fault_import(const int32_t* in2, int32_t* status, lr_stream_t stream) {
   LR_CHECK_ARG(in2);
   LR_LAUNCH(fault_import_kernel, dim3(1), dim3(64), 0, stream, in2, status, lr_fault_words());
@@ -810,10 +839,11 @@ extern "C" int lr_sumsq(const float* x, int64_t n, float* out, lr_stream_t strea
 extern "C" int lr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                             int64_t n, const float* sumsq, float max_norm, float grad_scale,
                             float lr, float beta1, float beta2, float eps, int32_t* step_count,
-                            const int32_t* skip, float* scratch, lr_stream_t stream) {
+                            int32_t* skip, float* scratch, const float* dist_words, float world,
+                            lr_stream_t stream) {
   LR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_count && scratch && n >= 0);
   LR_LAUNCH(adam_prepare_kernel, dim3(1), dim3(64), 0, stream, step_count, skip, (const int32_t*)lr_fault_words(),
-            sumsq, max_norm, grad_scale, lr, beta1, beta2, scratch);
+            sumsq, max_norm, grad_scale, lr, beta1, beta2, scratch, dist_words, world);
   int st = lr_launch_status();
   if (st != LR_OK || n == 0) return st;
   LR_LAUNCH(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, param, grad, exp_avg,
@@ -823,13 +853,14 @@ extern "C" int lr_adam_step(float* param, const float* grad, float* exp_avg, flo
 
 extern "C" int lr_clip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                                  float* sumsq, float max_norm, float grad_scale, float lr, float beta1, float beta2,
-                                 float eps, int32_t* step_count, const int32_t* skip, float* scratch8, lr_stream_t stream) {
+                                 float eps, int32_t* step_count, int32_t* skip, float* scratch8,
+                                 const float* dist_words, float world, lr_stream_t stream) {
   LR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_count && scratch8 && sumsq && n > 0 && max_norm > 0.f);
   LR_CHECK_ARG((reinterpret_cast<uintptr_t>(grad) & 15) == 0);
   int g = grid_for((n + 3) / 4, 256);
   if (g > 256) g = 256;  // one atomic per workgroup
   LR_LAUNCH(sumsq_prepare_kernel, dim3(g), dim3(256), 0, stream, grad, n, sumsq, step_count, skip,
-            (const int32_t*)lr_fault_words(), max_norm, grad_scale, lr, beta1, beta2, scratch8);
+            (const int32_t*)lr_fault_words(), max_norm, grad_scale, lr, beta1, beta2, scratch8, dist_words, world);
   int st = lr_launch_status();
   if (st != LR_OK) return st;
   LR_LAUNCH(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, n,

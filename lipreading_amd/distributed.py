@@ -50,6 +50,21 @@ class GradSync(object):
       hi = flat.offsets[last + 1] if last + 1 < len(params) else flat.numel
       self.bounds.append((lo, hi))
     self._contiguous = all(self.bounds[i][1] == self.bounds[i + 1][0] for i in range(len(self.bounds) - 1))
+    # The bucket that holds the FIRST parameter also carries the two words in front of it (optim.FlatParameters.words:
+    # {ranks whose batch was skipped, ranks whose recurrence timed out}, written by lr_fault_export_f32 right before that
+    # bucket goes out).  It is the last bucket of a backward — the first layer's gradients come last —, so every
+    # recurrence of the step has been enqueued by then, and the sum over the ranks arrives with the gradients: no second
+    # collective, no import kernel (round 4: a MIN all-reduce of two ints behind the last bucket, 0.04 ms of a step).
+    self._words_bucket = None
+    if self.cuda and getattr(flat, "first", 0) >= 2:
+      for gi, (lo, hi) in enumerate(self.bounds):
+        if lo == flat.first:
+          self._words_bucket = gi
+          self.bounds[gi] = (0, hi)
+    self._status = None          # the step's status tensor, announced by set_status() before backward
+    self._words_done = False     # the words of this round have been exported (with or without a status)
+    self._words_have_status = False
+    self.dist_words = None       # after __call__: flat.words when they carry the round's skip / fault sums, else None
     self._owner = {}
     for gi, g in enumerate(groups):
       for pi in g:
@@ -171,11 +186,25 @@ class GradSync(object):
       self._direct_hook = None
     self._closed = True
 
-  def _launch(self, gi):
+  def set_status(self, status):
+    """Announce the step's status tensor (int32[1], device) BEFORE backward: the bucket that carries the words may go
+    out from a gradient-ready hook, before __call__ hands the status over.  (train.ctc_step / decoder_step do.)"""
+    self._status = status
+
+  def _export_words(self, status):
+    from . import _C
+    _C.check(_C.lib().lr_fault_export_f32(_C.ptr(status), self.flat.words.data_ptr(), _C.stream_handle()),
+             "lr_fault_export_f32")
+    self._words_done = True
+    self._words_have_status = status is not None
+
+  def _launch(self, gi, status=None):
     if self._launched[gi]:
       return
     self._launched[gi] = True
     lo, hi = self.bounds[gi]
+    if gi == self._words_bucket and not self._words_done:
+      self._export_words(status if status is not None else self._status)
     self._all_reduce(self.flat.grad[lo:hi])
 
   def _all_reduce(self, buf):
@@ -188,40 +217,54 @@ class GradSync(object):
 
   def __call__(self, status=None):
     """Finish the exchange; returns the gradient scale (1/world).  Called between backward and
-    the optimiser (train.ctc_step's grad_sync).  `status` (int32[1]) becomes the MIN over ranks:
-    the step is skipped only if every rank's batch was skipped; a rank whose own batch was
-    skipped contributed zero gradients."""
+    the optimiser (train.ctc_step's grad_sync).  On the GPU the step's skip / fault facts travel as two floats in
+    front of the gradients (see __init__): afterwards `self.dist_words` holds their sums for FusedAdam.step(dist_words=,
+    world=) — the step is skipped only if every rank's batch was skipped (a rank whose own batch was skipped
+    contributed zero gradients), nobody updates if any rank's recurrence timed out — and `status` keeps THIS rank's
+    value.  Where the words could not travel (CPU tensors; the status unknown when their bucket left) `status`
+    becomes the MIN over ranks as in rounds 1-4 and dist_words is None."""
+    st_in = status if status is not None else self._status
     if not any(self._launched) and self._contiguous and len(self.groups) > 1:
       # nothing has gone out yet (no-overlap mode — the step was a hipGraph replay, or ran under hold()): the
       # buckets tile one stretch of the flat buffer, so ONE all-reduce carries them all (a collective costs its
       # launch and latency whatever its size: five per step were +0.3 ms on the 2.7 ms pixel step)
       self._launched = [True] * len(self.groups)
+      if self._words_bucket is not None and not self._words_done:
+        self._export_words(st_in)
       self._all_reduce(self.flat.grad[self.bounds[0][0]:self.bounds[-1][1]])
     else:
       for gi in range(len(self.groups)):
-        self._launch(gi)   # anything backward did not reach
-    word = status
-    if self.cuda:
-      # On the GPU the exchanged word is {status, -(fault pending)}: a rank whose one-launch recurrence timed out
-      # (include/lipreading_hip.h, fault words) has put garbage into the gradient sum, so EVERY rank must skip the
-      # update (MIN of -1/0), while a batch is skipped as such only if every rank skipped it (MIN of status).
-      from . import _C
-      word = self._pair
-      _C.check(_C.lib().lr_fault_export(_C.ptr(status), word.data_ptr(), _C.stream_handle()), "lr_fault_export")
-    if word is not None:
-      if self.overlap:
-        self.side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.side):
-          dist.all_reduce(word, op=dist.ReduceOp.MIN, group=self.pg)
-      else:
-        self._works.append(dist.all_reduce(word, op=dist.ReduceOp.MIN, group=self.pg, async_op=True))
+        self._launch(gi, st_in)   # anything backward did not reach
+    # the words travelled with the gradients unless there are none (CPU / gloo) or the bucket that carries them left
+    # before anybody had announced the status (a caller that uses neither train.ctc_step nor set_status)
+    folded = self._words_bucket is not None and self._words_done and (self._words_have_status or status is None)
+    word = None
+    if not folded:
+      word = status
+      if self.cuda:
+        # the legacy exchange: {status, -(fault pending)} in ONE MIN all-reduce — a rank whose one-launch recurrence timed
+        # out (include/lipreading_hip.h, fault words) has put garbage into the gradient sum, so EVERY rank must skip the
+        # update (MIN of -1/0), while a batch is skipped as such only if every rank skipped it (MIN of status)
+        from . import _C
+        word = self._pair
+        _C.check(_C.lib().lr_fault_export(_C.ptr(status), word.data_ptr(), _C.stream_handle()), "lr_fault_export")
+      if word is not None:
+        if self.overlap:
+          self.side.wait_stream(torch.cuda.current_stream())
+          with torch.cuda.stream(self.side):
+            dist.all_reduce(word, op=dist.ReduceOp.MIN, group=self.pg)
+        else:
+          self._works.append(dist.all_reduce(word, op=dist.ReduceOp.MIN, group=self.pg, async_op=True))
     if self.overlap:
       torch.cuda.current_stream().wait_stream(self.side)
     for w in self._works:
       w.wait()
     self._works = []
-    if self.cuda:
+    if self.cuda and not folded:
+      from . import _C
       _C.check(_C.lib().lr_fault_import(word.data_ptr(), _C.ptr(status), _C.stream_handle()), "lr_fault_import")
+    self.dist_words = self.flat.words if folded else None
+    self._status, self._words_done, self._words_have_status = None, False, False
     self._reset_round()
     return 1.0 / self.world
 

@@ -22,7 +22,10 @@ class FlatParameters(object):
     assert self.params, "module has no parameters"
     dev = self.params[0].device   # storage only: works on any device (gloo tests run on CPU)
     self.offsets = []
-    off = 0
+    # the first _ALIGN floats of the buffers belong to no parameter: grad[0:2] are the two WORDS a data-parallel step
+    # sums with its gradients — {ranks whose batch was skipped, ranks whose recurrence timed out}
+    # (distributed.GradSync, lr_fault_export_f32) — so that the exchange needs no second collective
+    off = _ALIGN
     for p in self.params:
       assert p.dtype == torch.float32 and p.device == dev
       self.offsets.append(off)
@@ -30,6 +33,8 @@ class FlatParameters(object):
     self.numel = off
     self.data = torch.zeros(off, dtype=torch.float32, device=dev)
     self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+    self.words = self.grad[0:2]
+    self.first = _ALIGN     # where the parameters start
     for p, o in zip(self.params, self.offsets):
       n = p.numel()
       self.data[o:o + n].copy_(p.data.reshape(-1))
@@ -85,8 +90,8 @@ class FusedAdam(object):
     self.exp_avg = torch.zeros_like(flat.data)
     self.exp_avg_sq = torch.zeros_like(flat.data)
     self.step_count = torch.zeros(2, dtype=torch.int32, device=dev)   # [updates taken, steps skipped]
-    self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
-    self._scratch = torch.zeros(8, dtype=torch.float32, device=dev)   # [0..3] the step's coefficients, [4] a ticket
+    self._sumsq = torch.zeros(2, dtype=torch.float32, device=dev)     # {accumulator, ticket}: lr_clip_adam_step leaves both 0
+    self._scratch = torch.zeros(8, dtype=torch.float32, device=dev)   # [0..3] the step's coefficients, [5] the sum of squares
 
   def zero_grad(self):
     """opt.zero_grad() — and THE TOP OF A STEP for the device-side fault words: the same launch rolls a recurrence
@@ -95,18 +100,16 @@ class FusedAdam(object):
     forward -> zero_grad -> backward -> step would clear a time-out raised by its own forward pass before lr_adam_step
     reads it, and update the weights from garbage gradients.  Gradient accumulation over micro-batches: one
     zero_grad() in front of the first micro-batch's forward, none in between."""
-    # (the clip's accumulator is cleared by the same launch: one fill launch less per step)
+    # (the clip's accumulator and ticket are cleared by the same launch — they are clean already, lr_clip_adam_step puts
+    # them back to zero itself; this only mends a launch that was torn down half-way)
     self.flat.zero_grad(also_zero=self._sumsq)
-    self._sumsq_clean = True
 
   step_begin = zero_grad
 
   def zero_grad_and_prepare_ctc(self, chars, frame_lens, char_lens):
     """zero_grad() with the step's CTC label plumbing (ctc.prepare_ctc_inputs) in the same launch; returns
     (labels_p1, frame_lens32, label_lens32)."""
-    out = self.flat.zero_grad(also_zero=self._sumsq, ctc_inputs=(chars, frame_lens, char_lens))
-    self._sumsq_clean = True
-    return out
+    return self.flat.zero_grad(also_zero=self._sumsq, ctc_inputs=(chars, frame_lens, char_lens))
 
   def reset(self, lr=None):
     """What re-creating torch.optim.Adam each epoch does (train.py:280): moments and step
@@ -117,32 +120,33 @@ class FusedAdam(object):
     if lr is not None:
       self.lr = float(lr)
 
-  def step(self, grad_norm=None, grad_scale=1.0, skip=None):
+  def step(self, grad_norm=None, grad_scale=1.0, skip=None, dist_words=None, world=1):
     """grad_norm: max norm for clip_grad_norm_ (None = no clipping); grad_scale: multiplies the
     gradient first (1/world after an all-reduce sum); skip: int32[1] device flag — non-zero
     leaves parameters, moments and step count untouched (the reference's `continue`).  The
     kernel also reads the device-side fault word: a step whose one-launch recurrence timed out
-    (garbage gradients) updates nothing either."""
+    (garbage gradients) updates nothing either.  dist_words (data parallel, distributed.GradSync): the two summed words
+    at the front of the flat gradient buffer decide instead of `skip` — skipped only if all `world` ranks skipped,
+    no update if any rank timed out."""
     from .encoder import flush_deferred
     flush_deferred()   # weight-gradient work still on the side stream (encoder.overlap_weight_grads)
     L = _C.lib()
     f = self.flat
     st = _C.stream_handle()
+    o, n = f.first, f.numel - f.first          # (the words in front of the parameters are no gradient)
+    ptrs = [t.data_ptr() + 4 * o for t in (f.data, f.grad, self.exp_avg, self.exp_avg_sq)]
     if grad_norm is not None and float(grad_norm) > 0:
-      if not getattr(self, "_sumsq_clean", False):
-        self._sumsq.zero_()     # (a caller that cleared the gradients some other way than self.zero_grad())
-      self._sumsq_clean = False
       # sum of squares -> clip coefficient -> Adam in two launches (the first one's last workgroup derives the coefficients)
-      _C.check(L.lr_clip_adam_step(f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),
-                                   self.exp_avg_sq.data_ptr(), f.numel, self._sumsq.data_ptr(), float(grad_norm),
+      _C.check(L.lr_clip_adam_step(*ptrs, n, self._sumsq.data_ptr(), float(grad_norm),
                                    float(grad_scale), self.lr, self.betas[0], self.betas[1], self.eps,
-                                   self.step_count.data_ptr(), _C.ptr(skip), self._scratch.data_ptr(), st),
+                                   self.step_count.data_ptr(), _C.ptr(skip), self._scratch.data_ptr(),
+                                   _C.ptr(dist_words), float(world), st),
                "lr_clip_adam_step")
       return
-    _C.check(L.lr_adam_step(f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),
-                            self.exp_avg_sq.data_ptr(), f.numel, None, 0.0, float(grad_scale),
+    _C.check(L.lr_adam_step(*ptrs, n, None, 0.0, float(grad_scale),
                             self.lr, self.betas[0], self.betas[1], self.eps,
-                            self.step_count.data_ptr(), _C.ptr(skip), self._scratch.data_ptr(), st),
+                            self.step_count.data_ptr(), _C.ptr(skip), self._scratch.data_ptr(),
+                            _C.ptr(dist_words), float(world), st),
              "lr_adam_step")
 
   def skipped_steps(self):
@@ -152,4 +156,4 @@ class FusedAdam(object):
 
   def total_norm(self):
     """sqrt of the last sum of squares (valid after a step with grad_norm)."""
-    return self._sumsq.sqrt()
+    return self._scratch[5:6].sqrt()

@@ -303,6 +303,8 @@ def ctc_step(encoder, opt, frames, frame_lens, chars, char_lens, grad_norm=None,
       loss, status, _ = ctc_loss_prepared(log_probs, labels_p1, frame_lens32, label_lens32, 'mean')
     else:
       loss, status, _ = ctc_loss_with_status(log_probs, chars[:, 1:], frame_lens, char_lens - 1, 'mean')
+    if grad_sync is not None and hasattr(grad_sync, "set_status"):
+      grad_sync.set_status(status)   # (the bucket that carries the skip / fault words may leave during backward)
     loss.backward(_one(loss.device))
     if whole:
       opt.step(grad_norm=grad_norm, grad_scale=1.0, skip=status)
@@ -322,7 +324,8 @@ def ctc_step(encoder, opt, frames, frame_lens, chars, char_lens, grad_norm=None,
       loss, status = graphs.run(key, inputs, body, capturable=(ml == frames.shape[1]))
   if not whole:
     scale = grad_sync(status)
-    opt.step(grad_norm=grad_norm, grad_scale=scale, skip=status)
+    opt.step(grad_norm=grad_norm, grad_scale=scale, skip=status, dist_words=getattr(grad_sync, "dist_words", None),
+             world=getattr(grad_sync, "world", 1))
   return loss, status
 
 
@@ -364,6 +367,9 @@ def decoder_step(encoder, decoding_step, opts, frames, frame_lens, chars, char_l
     decoder_loss = decoder_nll(log_probs_d, labels, pad)
     # one traversal from BOTH roots (the reference's two backward calls, train_better_model.py:70,74, add up to this);
     # no `decoder_loss + ctc` tensor: that sum was an elementwise launch of its own
+    for sy in syncs:
+      if sy is not None and hasattr(sy, "set_status"):
+        sy.set_status(status)
     one = _one(decoder_loss.device)
     if use_ctc:
       torch.autograd.backward([decoder_loss, total], [one, one])
@@ -394,7 +400,8 @@ def decoder_step(encoder, decoding_step, opts, frames, frame_lens, chars, char_l
     # updates nothing (with several ranks: only if every rank skipped, GradSync's MIN over ranks)
     for o, sync in zip(opts, syncs):
       scale = sync(status) if sync is not None else 1.0
-      o.step(grad_norm=grad_norm, grad_scale=scale, skip=status)
+      o.step(grad_norm=grad_norm, grad_scale=scale, skip=status, dist_words=getattr(sync, "dist_words", None),
+             world=getattr(sync, "world", 1))
   return decoder_loss, ctc, status
 
 
@@ -573,15 +580,21 @@ def greedy_cer(encoder, data_loader, device, char2idx):
   encoder.eval()
   dist, total = 0, 0
   on_gpu = torch.device(device).type == "cuda"
+  flag2 = torch.zeros(2, dtype=torch.int32, device=device) if on_gpu else None
   with torch.no_grad():
     for frames, frame_lens, chars, char_lens in data_loader:
       max_len = int(frame_lens.max()) if not frame_lens.is_cuda else None
+      if on_gpu:
+        # per batch, as eval() does: only THIS batch's time-out counts.  (Round 4 read lr_rnn_pair_errors() here —
+        # pending + total, cleared by the read —, so one timed-out TRAINING step of the epoch made the first
+        # validation batch look faulted and took the epoch's count away from whoever reads it next.)
+        _roll_faults(device)
       log_probs, _, _ = encoder(frames.to(device), frame_lens.to(device), max_len=max_len)
       strings, _ = dec.decode(log_probs, frame_lens.to(device))
-      if on_gpu and _C.lib().lr_rnn_pair_errors() != 0:
-        # (decode() has just synchronised: reading the fault words costs nothing more.)  The one-launch recurrence
-        # timed out: these strings are garbage, and val_cer drives save_best_model and the annealing — decode this
-        # batch again on the per-step kernels instead of scoring it
+      # (decode() has just synchronised: reading the flag costs no wait of its own)
+      if on_gpu and not bool(_fault_keep(flag2)):
+        # The one-launch recurrence timed out: these strings are garbage, and val_cer drives save_best_model and the
+        # annealing — decode this batch again on the per-step kernels instead of scoring it
         inner = getattr(encoder, "encoder", encoder)   # (PixelLipReader wraps the VideoEncoder)
         if hasattr(inner, "recurrence"):
           saved, inner.recurrence = inner.recurrence, 'f32'

@@ -67,13 +67,19 @@ def test_overlapped_gradient_exchange_matches_plain_step(dev, pg, pixels):
       opt.zero_grad()
       lp, _, _ = model(x, lens, max_len=T)
       loss, status, _ = ctc_loss_with_status(lp, labels, lens, ll, 'mean')
+      if sync is not None:
+        sync.set_status(status)         # (the bucket that carries the skip / fault words leaves during backward)
       loss.backward()
       scale = 1.0
       if sync is not None:
         assert any(sync._launched)      # buckets went out from the hooks, during backward
         scale = sync(status)
         assert scale == 1.0 and not any(sync._launched)
-      opt.step(grad_norm=50, grad_scale=scale, skip=status)
+      # (what train.ctc_step does: the skip / fault words travelled with the gradients)
+      opt.step(grad_norm=50, grad_scale=scale, skip=status, dist_words=sync.dist_words if sync is not None else None,
+               world=sync.world if sync is not None else 1)
+      if sync is not None:
+        assert sync.dist_words is not None and sync.dist_words.data_ptr() == flat.grad.data_ptr()
     torch.cuda.synchronize()
     results.append(flat.data.detach().cpu().numpy().copy())
     if sync is not None:

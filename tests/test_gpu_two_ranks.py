@@ -112,10 +112,12 @@ def test_a_rank_whose_batch_is_skipped_contributes_nothing(dev, tmp_path):
   from tests import two_rank_worker as W
   ranks = run_ranks("landmarks_skip", tmp_path)
   np.testing.assert_array_equal(ranks[0]["data"], ranks[1]["data"])
-  assert list(ranks[0]["statuses"]) == [0, 0] and list(ranks[1]["statuses"]) == [0, 0]   # after the MIN over ranks
+  assert list(ranks[0]["statuses"]) == [0, 0] and list(ranks[1]["statuses"]) == [0, 0]   # the ranks' verdict (lr_clip_adam_step)
   assert float(ranks[1]["losses"][0]) == 0.0 and float(ranks[0]["losses"][0]) > 0
   assert int(ranks[0]["steps"]) == 2 and int(ranks[1]["steps"]) == 2
   data, grad, losses, _, init = twin("landmarks", dev, 2, 0, W.B_FULL // 2, grad_scale=0.5)
   np.testing.assert_allclose(ranks[0]["losses"], np.array(losses), rtol=1e-5, atol=1e-6)
-  assert np.abs(ranks[0]["grad"] - grad).max() <= 2e-5 * float(np.abs(grad).max())
+  # (the two words in front of the gradients travelled with them: one rank skipped its batch, nobody timed out)
+  assert float(ranks[0]["grad"][0]) == 1.0 and float(ranks[0]["grad"][1]) == 0.0 and float(grad[0]) == 0.0
+  assert np.abs(ranks[0]["grad"][64:] - grad[64:]).max() <= 2e-5 * float(np.abs(grad).max())
   updates_agree(ranks[0]["data"], data, init, 2e-3)
