@@ -553,6 +553,7 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
   else:
     # (the attention regime follows the reference's config file: --no-ctc = enable_ctc False, config/defaults.txt:12)
     enc = VideoEncoder(frame_dim, H, rnn_type=rnn_type, num_layers=layers, bidirectional=bi,
+                       rnn_dropout=(args.rnn_dropout if attn else 0),
                        enable_ctc=not (attn and args.no_ctc), vocab_size=VOCAB, char2idx=default_char2idx())
   model = PixelLipReader(enc, ConvFrontend3D()) if pixels else enc
   # experiment switch: 'f32' = step kernels instead of the one-launch cluster recurrence
@@ -576,7 +577,7 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
     import torch.nn.functional as F
     from lipreading_amd.attention_decoder import CharDecodingStep
     dec = CharDecodingStep(enc, char_dim=args.char_dim, vocab_size=VOCAB, char2idx=default_char2idx(),
-                           attention_type=args.attention).to(dev).train()
+                           rnn_dropout=args.rnn_dropout, attention_type=args.attention).to(dev).train()
     dec_flat = FlatParameters(dec)
     dec_opt = FusedAdam(dec_flat, lr=1e-4)
   use_graph = not args.no_graph
@@ -950,6 +951,10 @@ def main():
                   "(config/defaults.txt: 300; config/train/attn/attention_type: 256)")
   ap.add_argument("--attention", default="1_layer_nn", help="landmarks_attn: attention_type of CharDecodingStep")
   ap.add_argument("--no-ctc", action="store_true", help="landmarks_attn: enable_ctc False (config/defaults.txt)")
+  ap.add_argument("--rnn-dropout", type=float, default=0.0,
+                  help="landmarks_attn: rnn_dropout of the flag file (config/archive/experiments/ecd/*: 0.3).  With the one "
+                       "recurrent layer every shipped config has, nn.LSTM / nn.GRU apply no dropout (it acts BETWEEN "
+                       "layers): accepted so that a config can be quoted as shipped, and passed on to both modules")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-budget", type=float, default=12.0,
                   help="seconds of timed CPU-oracle steps per regime (never fewer than 10 steps)")

@@ -480,9 +480,16 @@ Res res_layout(const Sizes& z) {
   return r;
 }
 
+// A WIDE decoder's recurrent weight gradients (G * Hd >= 1536: the 1024-unit decoder of config/train/attn/attention_type,
+// the 1400 / 1536-unit ones of config/defaults.txt-style and ecd flag files, better_model.py:134-148) are split-bf16
+// products straight from dG and the states (lr_fgemm.hip, TN form, ~1e-5 relative — the encoder's rule for its own
+// wide layers, lr_rnn.hip wgrad_split) instead of the fp32-MFMA grouped GEMM: at LSTM-1536, B = 32 that GEMM was
+// 295 us of a 2.68 ms step at 40 % of the fp32 matrix peak.
+inline bool wide_wgrad(int G, int Hd) { return G * Hd >= 1536 && !lr_debug_wgrad_f32(); }
+
 struct Wsp {
   size_t wpT, dG, dcar, dgp, dy, dlogits, dpre, dctx, dlg, dsum, dEW, dsrc, dcterm, dPE, dph, dw2p, colsum, gemm,
-      total;
+      hprev, total;
   size_t dgp_slot, gemm_bytes;
   size_t xch, xch_bytes;
 };
@@ -539,6 +546,7 @@ Wsp ws_layout(const Sizes& z) {
     if (g2 > w.gemm_bytes) w.gemm_bytes = g2;
   }
   w.gemm = take((w.gemm_bytes + 3) / 4);
+  w.hprev = take(wide_wgrad(z.G, z.Hd) ? BL * z.Hd : 0);    // (see lr_decoder_backward: h_{t-1} of every (sample, step) row)
   w.total = o;
   return w;
 }
@@ -560,6 +568,18 @@ __global__ void dec_mask_rows_kernel(const float* __restrict__ x, const float* _
     const float4 m = reinterpret_cast<const float4*>(mask + base)[i];
     reinterpret_cast<float4*>(out + base)[i] = make_float4(a.x * m.x, a.y * m.y, a.z * m.z, a.w * m.w);
   }
+}
+// out[b][t][:] = t ? hs[b][t - 1][:] : h0[b][:] — the state every step of the loop STARTED from (4 floats per thread)
+__global__ void dec_hprev_kernel(const float* __restrict__ hs, const float* __restrict__ h0, float* __restrict__ out, int L,
+                                 int Hd) {
+  const int b = blockIdx.y;
+  const int q = Hd / 4;
+  const int64_t total4 = (int64_t)L * q;
+  const float4* hs4 = reinterpret_cast<const float4*>(hs + (int64_t)b * L * Hd);
+  const float4* h04 = reinterpret_cast<const float4*>(h0 + (int64_t)b * Hd);
+  float4* o4 = reinterpret_cast<float4*>(out + (int64_t)b * L * Hd);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x)
+    o4[i] = i < q ? h04[i] : hs4[i - q];
 }
 
 #define LR_TRY(expr)              \
@@ -954,8 +974,38 @@ extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_par
                         dc0 ? dc0 + k * state : nullptr, B, L, Hd, stream));
     }
     // W_hh (h_prev of step t is hs[b][t-1]; step 0 used h0) and, for an upper layer, W_ih (x = the (dropped-out)
-    // states of the layer below): ONE grouped launch + one combine (lr_gemm.hip)
-    {
+    // states of the layer below)
+    if (wide_wgrad(G, Hd)) {
+      // split-bf16 products of ONE launch: h_{t-1} of every (sample, step) row is gathered once (the initial state in the
+      // rows of step 0), so the W_hh product is a plain dG^T . h_prev over all B * L rows — no row shift, no separate
+      // product for the initial state
+      float* hprev = wb + w.hprev;
+      {
+        int gx_ = (int)(((int64_t)L * Hd / 4 + 255) / 256);
+        if (gx_ > 64) gx_ = 64;
+        LR_LAUNCH(dec_hprev_kernel, dim3(gx_, B), dim3(256), 0, stream, hs_k, h0_k, hprev, L, Hd);
+        LR_TRY(lr_launch_status());
+      }
+      lr_fgemm_job jobs[3];
+      int n = 0;
+      auto add = [&](int M, const float* A, const float* Bm, float* C) {
+        lr_fgemm_job& j = jobs[n++];
+        j.A = A; j.B = Bm; j.C = C;
+        j.bias = nullptr; j.addend = nullptr; j.mask = nullptr; j.colsum = nullptr; j.slabs = nullptr;
+        j.M = M; j.N = Hd; j.K = BL; j.lda = ldg; j.ldb = Hd; j.ldc = Hd;
+        j.ldadd = 0; j.add_period = 0; j.ldmask = 0; j.flags = 0; j.splits = 1;
+        j.alpha = 1.f; j.beta = beta;
+      };
+      if (G == 3) {
+        add(2 * Hd, dG, hprev, gw_hh);
+        add(Hd, dG + 3 * Hd, hprev, gw_hh + (size_t)2 * Hd * Hd);
+      } else {
+        add(GH, dG, hprev, gw_hh);
+      }
+      if (k > 0) add(GH, dG, drop ? rb + r.xm[k - 1] : rb + r.hsl[k - 1], gup->w_ih[k - 1]);
+      LR_TRY(lr_fgemm_launch(LR_FGEMM_X3, LR_FGEMM_TN, 0, 0, jobs, n, stream));
+    } else {
+      // ONE grouped fp32 launch + one combine (lr_gemm.hip), then the initial state's rows
       int Ms[3], Ns[3], Ks[3], ldas[3], ldbs[3], ldcs[3], shifts[3], periods[3], n = 0;
       const float* As[3];
       const float* Bs[3];
@@ -974,15 +1024,15 @@ extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_par
       if (k > 0) add(GH, dG, drop ? rb + r.xm[k - 1] : rb + r.hsl[k - 1], gup->w_ih[k - 1], 0, 0);
       LR_TRY(lr_sgemm_grouped_tn_impl(n, Ms, Ns, Ks, As, ldas, Bs, ldbs, Cs, ldcs, beta, shifts, periods, gws,
                                       w.gemm_bytes, stream));
-    }
-    if (G == 3) {
-      LR_TRY(lr_sgemm_impl(1, 0, 2 * Hd, Hd, B, 1.f, dG, L * ldg, h0_k, Hd, 1.f, gw_hh, Hd, nullptr, 0, 0, nullptr, 0,
-                           stream));
-      LR_TRY(lr_sgemm_impl(1, 0, Hd, Hd, B, 1.f, dG + 3 * Hd, L * ldg, h0_k, Hd, 1.f, gw_hh + (size_t)2 * Hd * Hd, Hd,
-                           nullptr, 0, 0, nullptr, 0, stream));
-    } else {
-      LR_TRY(lr_sgemm_impl(1, 0, GH, Hd, B, 1.f, dG, L * ldg, h0_k, Hd, 1.f, gw_hh, Hd, nullptr, 0, 0, nullptr, 0,
-                           stream));
+      if (G == 3) {
+        LR_TRY(lr_sgemm_impl(1, 0, 2 * Hd, Hd, B, 1.f, dG, L * ldg, h0_k, Hd, 1.f, gw_hh, Hd, nullptr, 0, 0, nullptr, 0,
+                             stream));
+        LR_TRY(lr_sgemm_impl(1, 0, Hd, Hd, B, 1.f, dG + 3 * Hd, L * ldg, h0_k, Hd, 1.f, gw_hh + (size_t)2 * Hd * Hd, Hd,
+                             nullptr, 0, 0, nullptr, 0, stream));
+      } else {
+        LR_TRY(lr_sgemm_impl(1, 0, GH, Hd, B, 1.f, dG, L * ldg, h0_k, Hd, 1.f, gw_hh, Hd, nullptr, 0, 0, nullptr, 0,
+                             stream));
+      }
     }
     LR_TRY(lr_rnn_bias_grads(dG, colsum, gb_ih, gb_hh, BL, Hd, G, accumulate, stream));
     if (k > 0) {

@@ -145,6 +145,64 @@ def test_sampled_inputs_and_bench_sizes_match_oracle(dev):
     assert np.abs(p.grad.cpu().numpy() - r).max() / max(1e-4, np.abs(r).max()) < 5e-4, k
 
 
+@pytest.mark.parametrize("Henc,attn,char_dim,B", [(512, "1_layer_nn", 256, 4), (512, "1_layer_nn", 256, 32),
+                                                 (768, "none", 256, 8)])
+def test_shipped_decoder_configs_match_oracle(dev, Henc, attn, char_dim, B):
+  """The decoders of the reference's SHIPPED flag files against the ORACLE (round 4 checked them inside bench.py only):
+  config/train/attn/attention_type:8-19 — BiLSTM-512 encoder, so an LSTM-1024 decoder (better_model.py:134), char_dim 256,
+  1_layer_nn attention, at the config's batch of 4 and at 32 — and the ecd family (config/archive/experiments/ecd/*:
+  BiLSTM-768 -> LSTM-1536, attention none).  Every step teacher forced (teacher_forcing_ratio 1.0 in those files): the
+  loop's RNN runs as ONE cluster launch where the size has one (1024: 16-unit members), else on the step kernels."""
+  from lipreading_amd import _C
+  from lipreading_amd.attention_decoder import CharDecodingStep
+  from lipreading_amd.data import default_char2idx
+
+  class Enc:   # only what CharDecodingStep reads from the encoder (better_model.py:134-136)
+    hidden_size, bidirectional, rnn_type, num_layers = Henc, True, 'LSTM', 1
+
+  Hd = 2 * Henc
+  torch.manual_seed(15)
+  ref = O.OracleCharDecodingStep(Hd, 'LSTM', 1, char_dim, 64, O.default_char2idx(), attention_type=attn)
+  dec = CharDecodingStep(Enc(), char_dim, 64, default_char2idx(), attention_type=attn)
+  dec.load_state_dict(ref.state_dict())
+  dec = dec.to(dev)
+  g = torch.Generator().manual_seed(16)
+  T, L = 75, 31
+  enc = torch.randn(B, T, Hd, generator=g) * 0.5
+  lens = torch.sort(torch.randint(40, T + 1, (B,), generator=g))[0]
+  h0, c0 = torch.randn(1, B, Hd, generator=g) * 0.5, torch.randn(1, B, Hd, generator=g) * 0.5
+  chars = torch.randint(4, 64, (B, L), generator=g)
+  if Hd == 1024:
+    assert _C.lib().lr_rnn_pair_supported(1, B, L, Hd, Hd, 1) == 2      # the one-launch path is what runs
+  _C.lib().lr_rnn_pair_errors()
+  encd = enc.to(dev).requires_grad_(True)
+  h0d, c0d = h0.to(dev).requires_grad_(True), c0.to(dev).requires_grad_(True)
+  lp, _, _ = dec.decode_sequence(chars.to(dev), (h0d, c0d), lens, encd, seed=11)
+  encr, h0r, c0r = enc.clone().requires_grad_(True), h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+  state, rows = (h0r, c0r), []
+  for i in range(L):
+    o, state = ref(chars[:, i], state, lens, encr)
+    rows.append(o)
+  want = torch.stack(rows, 1)
+  np.testing.assert_allclose(lp.detach().cpu().numpy(), want.detach().numpy(), rtol=2e-4, atol=5e-5)
+  wgt = torch.randn(B, L, 64, generator=g) / 100
+  (lp * wgt.to(dev)).sum().backward()
+  (want * wgt).sum().backward()
+  assert _C.lib().lr_rnn_pair_errors() == 0
+  pairs = [(h0d.grad, h0r.grad), (c0d.grad, c0r.grad)]
+  if attn != "none":
+    pairs.append((encd.grad, encr.grad))
+  for a, b in pairs:
+    assert float((a.cpu() - b).abs().max()) <= 5e-4 * float(b.abs().max())
+  gr = dict(ref.named_parameters())
+  for k, p in dec.named_parameters():
+    if gr[k].grad is None:      # (attention 'none' never touches concat_layer: better_model.py:226-227)
+      assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+      continue
+    r = gr[k].grad.numpy()
+    assert np.abs(p.grad.cpu().numpy() - r).max() / max(1e-4, np.abs(r).max()) < 5e-4, k
+
+
 @pytest.mark.parametrize("rnn_type,layers,attn", [("LSTM", 2, "general"), ("GRU", 3, "dot"), ("RNN", 2, "1_layer_nn")])
 def test_multilayer_decoder_with_sampled_inputs_matches_oracle(dev, rnn_type, layers, attn):
   """Decoder stacks deeper than one layer (better_model.py:136,147-148) under a MIXED teacher-forcing

@@ -466,7 +466,7 @@ def test_stride1_weight_gradient_against_torch(dev, layer, B, T, H):
 PIXEL_LOSS_TOL = 1e-4
 
 
-@pytest.mark.parametrize("B,lens", [(8, None), (8, [40, 52, 52, 60, 75, 75, 75, 75])])
+@pytest.mark.parametrize("B,lens", [(8, None), (8, [40, 52, 52, 60, 75, 75, 75, 75]), (32, None)])   # (32: the headline batch)
 def test_pixel_regime_defaults_match_the_oracle(dev, B, lens):
   """Same uint8 clips and the same weights through (a) PixelLipReader with its DEFAULTS (bf16 conv
   stack, bf16 features handed over as stored, split-bf16 input projection, one-launch fp32-faithful

@@ -17,8 +17,6 @@ PIXELS = {  # bench.py's conv names -> a substring of the kernel symbol
     "conv3_dgrad": "conv_patch16_kernel<3, 2, false", "conv1_wgrad": "conv1_wgrad_roles_kernel",
     "conv2_wgrad": "conv_wgrad_tr2_kernel<32", "conv3_wgrad": "conv_wgrad_tr2_kernel<64"}
 RECURRENT = {"rnn_fwd_step_kernel": "rnn_fwd_step_kernel", "rnn_bwd_step_kernel": "rnn_bwd_step_kernel",
-             "gru256_fwd_pair_kernel": "gru256_fwd_pair_kernel", "gru256_bwd_pair_kernel": "gru256_bwd_pair_kernel",
-             "gru256_fwd_persist_kernel": "gru256_fwd_persist_kernel", "gru256_bwd_persist_kernel": "gru256_bwd_persist_kernel",
              "sgemm_grouped_kernel": "sgemm_grouped_kernel", "xgemm_kernel": "xgemm_kernel"}
 # the cluster recurrence's instantiations (lr_rnn_cluster.hip): bench.py's name "rnnc_fwd_kernel<G,CC>"
 for _g, _cc in [(3, c) for c in range(1, 28)] + [(4, c) for c in range(1, 25)]:
@@ -43,6 +41,27 @@ def read(path):
         vals = line[i + len(counter) + 2:].split()
         rows.append((line[:i].strip(), counter, int(vals[0]), float(vals[1])))
   return rows
+
+
+def read_stats(path):
+  """<round>_<model>_kernel_stats.txt (tools/rocpd_summary.py): kernel name -> average duration in us"""
+  out = []
+  if not os.path.exists(path):
+    return out
+  for line in open(path):
+    if line.startswith("#") or line.startswith("kernel "):
+      continue
+    parts = line.rstrip().rsplit(None, 6)
+    if len(parts) == 7:
+      try:
+        out.append((parts[0].strip(), float(parts[3])))
+      except ValueError:
+        pass
+  return out
+
+
+SIMDS = 256 * 4            # compute units x SIMDs
+PEAK_CLOCK_MHZ = 2400.0    # cycles per microsecond at the peak engine clock (MI355X_MICROARCH.md)
 
 
 def lookup(rows, sub, counter=None):
@@ -71,6 +90,7 @@ def main(tag, d="profiles"):
     f = read(os.path.join(d, "%s_%s_pmc_FETCH_SIZE.txt" % (tag, model)))
     w = read(os.path.join(d, "%s_%s_pmc_WRITE_SIZE.txt" % (tag, model)))
     sq = read(os.path.join(d, "%s_%s_pmc_SQ_pass1.txt" % (tag, model)))
+    stats = read_stats(os.path.join(d, "%s_%s_kernel_stats.txt" % (tag, model)))
     if not f or not w:
       continue
     out["source_files"] += ["%s/%s_%s_pmc_%s.txt" % (d, tag, model, c) for c in ("FETCH_SIZE", "WRITE_SIZE")]
@@ -88,8 +108,18 @@ def main(tag, d="profiles"):
       busy, wave = lookup(sq, sub, "SQ_VALU_MFMA_BUSY_CYCLES"), lookup(sq, sub, "SQ_WAVE_CYCLES")
       wait = lookup(sq, sub, "SQ_WAIT_ANY")
       if busy and wave and wave[0] > 0:
-        # matrix-pipe busy fraction: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_WAVE_CYCLES) (one wave per SIMD kernels)
-        rec["mfma_busy"] = round(busy[0] / (4.0 * wave[0]), 4)
+        # Two normalisations.  mfma_busy: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x the kernel's average duration x the
+        # 2.4 GHz peak clock) — the fraction of the chip's matrix-pipe cycles the launch used, whatever its occupancy
+        # (a lower bound where the clock sagged under the profiler).  mfma_busy_per_wave_cycle: / (4 x SQ_WAVE_CYCLES),
+        # rounds 1-4's figure: the matrix pipe's share of the cycles a wave was RESIDENT, right only for kernels
+        # with one wave per SIMD (round 4 quoted 0.25-0.36 for layer 3's two-workgroups-per-CU kernels, which run at
+        # 0.50 of the flop peak: each of their waves' cycles was counted, the pipe they share only once).
+        subs = sub if isinstance(sub, tuple) else (sub,)
+        dur = next((us for name, us in stats if any(x in name for x in subs)), None)
+        rec["mfma_busy_per_wave_cycle"] = round(busy[0] / (4.0 * wave[0]), 4)
+        if dur:
+          rec["avg_us"] = dur
+          rec["mfma_busy"] = round(busy[0] / (SIMDS * dur * PEAK_CLOCK_MHZ), 4)
         if wait:
           rec["wait_any_frac"] = round(wait[0] / wave[0], 4)
       sec[key] = rec
