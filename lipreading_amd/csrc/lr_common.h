@@ -72,6 +72,58 @@ __device__ __forceinline__ float lr_wave_sum(float v) {
 // stage 2 (caller specific): out[col] = sum_rs partial[rs][col] in fixed order.
 constexpr int LR_COLSUM_SPLITS = 32;
 int lr_colsum_partial(const float* x, int ld, int rows, int ncol, float* partial, hipStream_t stream);
+// stage 1 as a device function (256 threads = 4 row lanes x 64 columns; bx = 64-column block, by = row slice): the
+// kernel of lr_colsum_partial, and the RIDER blocks of a grouped GEMM launch (LrRnnBiasJob below)
+__device__ __forceinline__ void lr_colsum_partial_body(const float* __restrict__ x, int ld, int rows, int ncol,
+                                                       float* __restrict__ partial, int bx, int by) {
+  __shared__ float lr_part_[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = bx * 64 + cl;
+  const int per = (rows + LR_COLSUM_SPLITS - 1) / LR_COLSUM_SPLITS;
+  const int r0 = by * per;
+  const int r1 = min(rows, r0 + per);
+  float s = 0.f;
+  if (col < ncol)
+    for (int r = r0 + rl; r < r1; r += 4) s += x[(int64_t)r * ld + col];
+  lr_part_[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && col < ncol)
+    partial[(int64_t)by * ncol + col] = lr_part_[0][cl] + lr_part_[1][cl] + lr_part_[2][cl] + lr_part_[3][cl];
+}
+// The bias gradients of a recurrent layer — column sums of dG [rows][D][4][H] scattered into db_ih / db_hh (GRU: the
+// input side's n gate is slot 2, the recurrent side's slot 3) — as a RIDER of the layer's grouped weight-gradient
+// launch: the partial sums are extra workgroups of the GEMM launch, the fixed-order finish extra workgroups of its
+// combine launch (round 5: two launches of a regime-R step instead of four).
+struct LrRnnBiasJob {
+  const float* dG;
+  float* partial;      // [LR_COLSUM_SPLITS][D * 4 * H]
+  float* db_ih[2];
+  float* db_hh[2];
+  int ld, rows, H, D, G, accumulate;
+};
+__device__ __forceinline__ void lr_rnn_bias_final_body(const LrRnnBiasJob& p, int col) {
+  const int ncol = p.D * 4 * p.H, H = p.H;
+  if (col >= ncol) return;
+  float s = 0.f;
+  for (int r = 0; r < LR_COLSUM_SPLITS; ++r) s += p.partial[(int64_t)r * ncol + col];
+  const int d = col / (4 * H), slot = (col / H) & 3, j = col % H;
+  float* ih = nullptr;
+  float* hh = nullptr;
+  if (p.G == 1) {
+    if (slot == 0) {
+      ih = p.db_ih[d] + j;
+      hh = p.db_hh[d] + j;
+    }
+  } else if (p.G == 4) {
+    ih = p.db_ih[d] + slot * H + j;
+    hh = p.db_hh[d] + slot * H + j;
+  } else {
+    if (slot < 3) ih = p.db_ih[d] + slot * H + j;
+    if (slot != 2) hh = p.db_hh[d] + (slot == 3 ? 2 : slot) * H + j;
+  }
+  if (ih) *ih = p.accumulate ? *ih + s : s;
+  if (hh) *hh = p.accumulate ? *hh + s : s;
+}
 
 // ---- optional instrumentation (bench.py roofline leg; lr_misc.hip) ------------------------------
 // While enabled, selected launches are issued through hipExtLaunchKernelGGL with a hipEvent pair
@@ -158,7 +210,7 @@ size_t lr_sgemm_grouped_workspace_bytes(int n, const int* M, const int* N, const
 int lr_sgemm_grouped_tn_impl(int n, const int* M, const int* N, const int* K, const float* const* A, const int* lda,
                              const float* const* B, const int* ldb, float* const* C, const int* ldc, float beta,
                              const int* row_shift, const int* period, void* workspace, size_t workspace_bytes,
-                             hipStream_t stream);
+                             hipStream_t stream, const LrRnnBiasJob* rider = nullptr);
 // lr_fgemm.hip: products straight from the tensors as they lie in memory (include/lipreading_hip.h lr_fgemm)
 int lr_fgemm_launch(int prec, int form, int a_bf16, int b_bf16, const lr_fgemm_job* jobs, int njobs, hipStream_t stream);
 int lr_fgemm_want_splits(int M, int N, int K);

@@ -244,10 +244,20 @@ struct GroupItem {
 struct GroupArgs {
   GroupItem it[kMaxGroup];
   int n;
+  // rider (lr_common.h LrRnnBiasJob): workgroups [rider_begin, ...) of the GEMM launch take the partial column sums of
+  // dG, row blockIdx.y == n of the combine launch finishes them; rider_begin < 0: none
+  int rider_begin, rider_nxb;
+  LrRnnBiasJob rider;
 };
 
 template <int BM, int BN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void sgemm_grouped_kernel(GroupArgs ga) {
+  if (ga.rider_begin >= 0 && (int)blockIdx.x >= ga.rider_begin) {   // workgroup-uniform
+    const int rb = blockIdx.x - ga.rider_begin;
+    lr_colsum_partial_body(ga.rider.dG, ga.rider.ld, ga.rider.rows, ga.rider.D * 4 * ga.rider.H, ga.rider.partial,
+                           rb % ga.rider_nxb, rb / ga.rider_nxb);
+    return;
+  }
   int i = 0;
 #pragma unroll
   for (int k = 1; k < kMaxGroup; ++k)
@@ -272,6 +282,12 @@ __global__ __launch_bounds__(256) void sgemm_grouped_kernel(GroupArgs ga) {
 
 // grid (ceil(max M*N / 256), items): C_i = sum over the item's slabs in fixed order (+ beta * C_i)
 __global__ void grouped_reduce_kernel(GroupArgs ga) {
+  if ((int)blockIdx.y == ga.n) {   // the rider's finish (only launched with one)
+    const int ncol = ga.rider.D * 4 * ga.rider.H;
+    for (int col = blockIdx.x * blockDim.x + threadIdx.x; col < ncol; col += gridDim.x * blockDim.x)
+      lr_rnn_bias_final_body(ga.rider, col);
+    return;
+  }
   const GroupItem& it = ga.it[blockIdx.y];
   if (!it.slabs) return;   // a problem that was not split wrote C itself
   const int64_t total = (int64_t)it.M * it.N;
@@ -435,7 +451,7 @@ size_t lr_sgemm_grouped_workspace_bytes(int n, const int* M, const int* N, const
 int lr_sgemm_grouped_tn_impl(int n, const int* M, const int* N, const int* K, const float* const* A, const int* lda,
                              const float* const* B, const int* ldb, float* const* C, const int* ldc, float beta,
                              const int* row_shift, const int* period, void* workspace, size_t workspace_bytes,
-                             hipStream_t stream) {
+                             hipStream_t stream, const LrRnnBiasJob* rider) {
   LR_CHECK_ARG(n > 0 && n <= kMaxGroup && M && N && K && A && lda && B && ldb && C && ldc && workspace);
   if (workspace_bytes < lr_sgemm_grouped_workspace_bytes(n, M, N, K)) return LR_ERR_WORKSPACE;
   int splits[kMaxGroup], chunk[kMaxGroup];
@@ -466,15 +482,29 @@ int lr_sgemm_grouped_tn_impl(int n, const int* M, const int* N, const int* K, co
     }
   }
   for (int i = n; i < kMaxGroup; ++i) ga.it[i] = ga.it[0];
+  ga.rider_begin = -1;
+  ga.rider_nxb = 1;
+  if (rider) {
+    LR_CHECK_ARG(rider->dG && rider->partial && rider->rows > 0 && rider->H > 0 && (rider->D == 1 || rider->D == 2));
+    ga.rider = *rider;
+    ga.rider_begin = blocks;
+    ga.rider_nxb = (rider->D * 4 * rider->H + 63) / 64;
+    blocks += ga.rider_nxb * LR_COLSUM_SPLITS;
+  } else {
+    ga.rider.dG = nullptr; ga.rider.partial = nullptr;
+    ga.rider.db_ih[0] = ga.rider.db_ih[1] = ga.rider.db_hh[0] = ga.rider.db_hh[1] = nullptr;
+    ga.rider.ld = ga.rider.rows = ga.rider.H = ga.rider.D = ga.rider.G = ga.rider.accumulate = 0;
+  }
   lr_clear_error();
   if (T == 128) hipLaunchKernelGGL((sgemm_grouped_kernel<128, 128, true, false>), dim3(blocks), dim3(256), 0, stream, ga);
   else hipLaunchKernelGGL((sgemm_grouped_kernel<64, 64, true, false>), dim3(blocks), dim3(256), 0, stream, ga);
   int st = lr_launch_status();
   if (st != LR_OK) return st;
-  if (biggest == 0) return LR_OK;   // nothing was split
+  if (biggest == 0 && !rider) return LR_OK;   // nothing was split
   int rb = (int)((biggest + 255) / 256);
   if (rb > 512) rb = 512;
-  LR_LAUNCH(grouped_reduce_kernel, dim3(rb, n), dim3(256), 0, stream, ga);
+  if (rb < 8) rb = 8;
+  LR_LAUNCH(grouped_reduce_kernel, dim3(rb, rider ? n + 1 : n), dim3(256), 0, stream, ga);
   return lr_launch_status();
 }
 

@@ -321,19 +321,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
 // 256 threads = 4 row lanes x 64 columns; blockIdx.y = row slice.
 __global__ void colsum_partial_kernel(const float* __restrict__ x, int ld, int rows, int ncol,
                                       float* __restrict__ partial) {
-  __shared__ float part[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cl;
-  const int per = (rows + LR_COLSUM_SPLITS - 1) / LR_COLSUM_SPLITS;
-  const int r0 = blockIdx.y * per;
-  const int r1 = min(rows, r0 + per);
-  float s = 0.f;
-  if (col < ncol)
-    for (int r = r0 + rl; r < r1; r += 4) s += x[(int64_t)r * ld + col];
-  part[rl][cl] = s;
-  __syncthreads();
-  if (rl == 0 && col < ncol)
-    partial[(int64_t)blockIdx.y * ncol + col] = part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl];
+  lr_colsum_partial_body(x, ld, rows, ncol, partial, blockIdx.x, blockIdx.y);
 }
 
 inline int grid_for(int64_t n, int block) {

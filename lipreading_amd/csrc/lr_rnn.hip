@@ -435,34 +435,8 @@ __global__ void final_state_kernel(const float* __restrict__ y, const float* __r
 
 // Bias gradients: fixed-order sum of the LR_COLSUM_SPLITS partial column sums of
 // dG [rows][D][4][H] (lr_colsum_partial), scattered into db_ih / db_hh.
-struct BiasPtrs {
-  float* db_ih[2];
-  float* db_hh[2];
-};
-__global__ void bias_grad_final_kernel(const float* __restrict__ partial, BiasPtrs p, int H, int D,
-                                       int G, int accumulate) {
-  const int ncol = D * 4 * H;
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= ncol) return;
-  float s = 0.f;
-  for (int r = 0; r < LR_COLSUM_SPLITS; ++r) s += partial[(int64_t)r * ncol + col];
-  const int d = col / (4 * H), slot = (col / H) & 3, j = col % H;
-  float* ih = nullptr;
-  float* hh = nullptr;
-  if (G == 1) {
-    if (slot == 0) {
-      ih = p.db_ih[d] + j;
-      hh = p.db_hh[d] + j;
-    }
-  } else if (G == 4) {
-    ih = p.db_ih[d] + slot * H + j;
-    hh = p.db_hh[d] + slot * H + j;
-  } else {
-    if (slot < 3) ih = p.db_ih[d] + slot * H + j;
-    if (slot != 2) hh = p.db_hh[d] + (slot == 3 ? 2 : slot) * H + j;
-  }
-  if (ih) *ih = accumulate ? *ih + s : s;
-  if (hh) *hh = accumulate ? *hh + s : s;
+__global__ void bias_grad_final_kernel(LrRnnBiasJob p) {
+  lr_rnn_bias_final_body(p, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // h [B][H] -> one packed state slot [batch tile][chunk][64][4] (rows past B / k past H stay zero)
@@ -901,6 +875,14 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
     st = lr_xproj_dwhh(dG, ldg, y, D * H, R, T, H, G, D, dw_hh, wbeta, xws, xws_bytes, stream);
     if (st != LR_OK) return st;
   }
+  LrRnnBiasJob bias_job;
+  bias_job.dG = dG; bias_job.partial = wbase + wl.colsum;
+  for (int d = 0; d < 2; ++d) {
+    bias_job.db_ih[d] = db_ih[d < D ? d : 0];
+    bias_job.db_hh[d] = db_hh[d < D ? d : 0];
+  }
+  bias_job.ld = ldg; bias_job.rows = R; bias_job.H = H; bias_job.D = D; bias_job.G = G; bias_job.accumulate = accumulate;
+  bool bias_done = false;
   if (!x3 && !wx) {
     // every weight gradient of the layer in ONE grouped launch + one combine (lr_gemm.hip): each of these
     // small-M*N, K = B*T products fills a sixth of the chip on its own.
@@ -928,9 +910,12 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
         add(GH, H, dGd, yd, D * H, dw_hh[d], shift, T);
       }
     }
+    // (the bias gradients ride along: their partial column sums are extra workgroups of this launch, the finish extra
+    // workgroups of its combine launch)
     st = lr_sgemm_grouped_tn_impl(n, Ms, Ns, Ks, As, ldas, Bs, ldbs, Cs, ldcs, wbeta, shifts, periods, gws,
-                                  wl.gemm_bytes, stream);
+                                  wl.gemm_bytes, stream, &bias_job);
     if (st != LR_OK) return st;
+    bias_done = true;
   }
   for (int d = 0; d < D && !x3; ++d) {
     const float* dGd = dG + (size_t)d * 4 * H;
@@ -940,16 +925,10 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
       if (st != LR_OK) return st;
     }
   }
-  BiasPtrs bp;
-  for (int d = 0; d < 2; ++d) {
-    bp.db_ih[d] = db_ih[d < D ? d : 0];
-    bp.db_hh[d] = db_hh[d < D ? d : 0];
-  }
-  float* partial = wbase + wl.colsum;
-  st = lr_colsum_partial(dG, ldg, R, ldg, partial, stream);
+  if (bias_done) return LR_OK;
+  st = lr_colsum_partial(dG, ldg, R, ldg, bias_job.partial, stream);
   if (st != LR_OK) return st;
-  LR_LAUNCH(bias_grad_final_kernel, dim3((ldg + 255) / 256), dim3(256), 0, stream,
-            (const float*)partial, bp, H, D, G, accumulate);
+  LR_LAUNCH(bias_grad_final_kernel, dim3((ldg + 255) / 256), dim3(256), 0, stream, bias_job);
   return lr_launch_status();
 }
 
@@ -1047,10 +1026,11 @@ int lr_rnn_bias_grads(const float* dG, float* partial, float* db_ih, float* db_h
   const int ldg = 4 * H;
   int st = lr_colsum_partial(dG, ldg, rows, ldg, partial, stream);
   if (st != LR_OK) return st;
-  BiasPtrs bp;
+  LrRnnBiasJob bp;
+  bp.dG = dG; bp.partial = partial;
   bp.db_ih[0] = bp.db_ih[1] = db_ih;
   bp.db_hh[0] = bp.db_hh[1] = db_hh;
-  LR_LAUNCH(bias_grad_final_kernel, dim3((ldg + 255) / 256), dim3(256), 0, stream, (const float*)partial, bp, H,
-            1, G, accumulate);
+  bp.ld = ldg; bp.rows = rows; bp.H = H; bp.D = 1; bp.G = G; bp.accumulate = accumulate;
+  LR_LAUNCH(bias_grad_final_kernel, dim3((ldg + 255) / 256), dim3(256), 0, stream, bp);
   return lr_launch_status();
 }
