@@ -209,7 +209,8 @@ int lr_rnn_one_launch_status(int mode, int B, int T, int I, int H, int D);
  * lr_rnn_debug_drop_member   TEST HOOK: member `m` (>= 0) of every pair / cluster returns at once, so its partners
  *                      time out (a few tenths of a second) and raise the fault; -1 (default) = off.
  * lr_rnn_debug_disable_cluster   TEST HOOK: bit 0 makes lr_rnn_pair_supported answer 0 for the cluster shapes
- *                      (and the decoder loop take its step kernels), bit 2 keeps the weight gradients of
+ *                      (and the decoder loop take its step kernels), bit 3 puts the first pixel-regime layer's dW_ih back on the
+ *                      packed lr_xgemm path (round 5's A/B against lr_fgemm), bit 2 keeps the weight gradients of
  *                      LR_RNN_RECUR_SPLIT layers on the fp32 grouped GEMM, so the paths can be compared on one
  *                      model.  Size queries depend on it: set it BEFORE the forward whose backward it should cover.
  * lr_fault_export / lr_fault_import   data parallel (lipreading_amd/distributed.py): out2 = {status[0] (0 when

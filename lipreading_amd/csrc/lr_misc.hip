@@ -752,6 +752,7 @@ extern "C" int lr_debug_busy(int workgroups, int lds_bytes, int microseconds, lr
   return lr_launch_status();
 }
 int lr_debug_wgrad_f32() { return (g_cluster_off >> 2) & 1; }
+int lr_debug_dwih_packed() { return (g_cluster_off >> 3) & 1; }
 // tuning knobs of the cluster recurrence's exchange (lr_rnn_debug_tune): [0] forward, [1] backward; bits 0-7 = 64-clock
 // sleeps before the first poll, bits 8-15 = sleeps between poll rounds
 namespace { int g_tune[2] = {1 << 8, 1 << 8}; }   // (swept on the MI355X: one sleep between rounds, no first-poll delay)

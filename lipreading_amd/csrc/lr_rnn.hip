@@ -856,8 +856,27 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
       if (st != LR_OK) return st;
     }
     if (!(parts & 2)) return LR_OK;
-    st = lr_xproj_dw(dG, ldg, 4 * H, x, R, I, GH, D, dw_ih, wbeta, x_exact(mode) ? 1 : 0, x_stored_bf16(mode) ? 1 : 0,
-                     xws, xws_bytes, stream, proj_x1(mode) ? 1 : 0);
+    if (x_stored_bf16(mode) && !proj_x1(mode) && !lr_debug_dwih_packed()) {
+      // dW_ih[d] = dG[:, d, :GH]^T . x straight from dG and the stored bf16 features (lr_fgemm.hip, TN form, B stored
+      // as bf16: ds_read_b64_tr_b16 delivers both operands' K-major fragments): no transposed pack of either operand.
+      // Round 5, same-visit A/B at the bench shape (M 1536, N 3456, K 2400; profiles/r05_variants_ab.txt): pixel step
+      // 2.517 / 2.477 ms (packed lr_xgemm path, first / last line of the visit) -> 2.397 / 2.393; the whole gradient
+      // BIT-identical (the same products accumulated in the same order).  lr_rnn_debug_disable_cluster bit 3 = the
+      // packed path, for that A/B.
+      lr_fgemm_job jobs[2];
+      for (int d = 0; d < D; ++d) {
+        lr_fgemm_job& j = jobs[d];
+        j.A = dG + (size_t)d * 4 * H; j.B = x; j.C = dw_ih[d];
+        j.bias = nullptr; j.addend = nullptr; j.mask = nullptr; j.colsum = nullptr; j.slabs = nullptr;
+        j.M = GH; j.N = I; j.K = R; j.lda = ldg; j.ldb = I; j.ldc = I;
+        j.ldadd = 0; j.add_period = 0; j.ldmask = 0; j.flags = 0; j.splits = 1;
+        j.alpha = 1.f; j.beta = wbeta;
+      }
+      st = lr_fgemm_launch(LR_FGEMM_X3, LR_FGEMM_TN, 0, 1, jobs, D, stream);
+    } else {
+      st = lr_xproj_dw(dG, ldg, 4 * H, x, R, I, GH, D, dw_ih, wbeta, x_exact(mode) ? 1 : 0, x_stored_bf16(mode) ? 1 : 0,
+                       xws, xws_bytes, stream, proj_x1(mode) ? 1 : 0);
+    }
     if (st != LR_OK) return st;
     // recurrent weight gradient on the same split-bf16 path (one contraction per direction)
     st = lr_xproj_dwhh(dG, ldg, y, D * H, R, T, H, G, D, dw_hh, wbeta, xws, xws_bytes, stream, proj_x1(mode) ? 1 : 0);

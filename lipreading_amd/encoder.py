@@ -58,6 +58,9 @@ def _notify(weights):
 overlap_weight_grads = False     # PixelLipReader switches it on; needs in-place (.grad) gradients
 _side_stream = None
 _deferred = []
+# (Measured and dropped, round 5: starting an upper layer's weight half BEHIND the lower layer's recurrence — which it
+# slows from 131 to 163 us at the bench shape — instead of beside it: 2.500 against 2.517 / 2.477 ms for the default in
+# the same visit, 2.393 against 2.397 on top of the lr_fgemm dW_ih: inside the noise.  profiles/r05_variants_ab.txt.)
 
 
 def _get_side_stream(device):
@@ -168,15 +171,18 @@ class _RNNLayerFunction(torch.autograd.Function):
               _ptr_array(grads[0::4]), _ptr_array(grads[1::4]), _ptr_array(grads[2::4]), _ptr_array(grads[3::4]),
               reserve.data_ptr(), reserve.numel(), ws.data_ptr(), wbytes, 1, B, T, I, H, D)
       _C.check(L.lr_rnn_layer_backward_parts(*args, 1, _C.stream_handle()), "lr_rnn_layer_backward_parts(data)")
-      flush_deferred()                      # at most one deferred half in flight
-      side = _get_side_stream(dev)
-      side.wait_stream(torch.cuda.current_stream())
-      with torch.cuda.stream(side):
+
+      def weight_half():
         _C.check(L.lr_rnn_layer_backward_parts(*args, 2, _C.stream_handle()), "lr_rnn_layer_backward_parts(weights)")
         # announced from the side stream: a gradient all-reduce (distributed.GradSync) then waits for
         # THIS stream, i.e. starts as soon as these gradients exist, not when the streams are joined
         _notify(weights)
-      _deferred.append((x, lens, y, dy, reserve, ws, grads, weights))
+      flush_deferred()                      # at most one deferred half in flight
+      _deferred.append((x, lens, y, dy, reserve, ws, grads, weights, args))
+      side = _get_side_stream(dev)
+      side.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(side):
+        weight_half()
       return (dx, None, None, None, None, None) + (None,) * len(weights)
     _C.check(L.lr_rnn_layer_backward(
         mode, x.data_ptr(), lens.data_ptr(), _ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(b_ih),

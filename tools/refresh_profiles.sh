@@ -15,7 +15,7 @@
 # PMC passes never share a run with trace domains other than the kernel trace rocprofv3 adds itself.
 set -u
 R=$PWD
-TAG=${1:-r04}
+TAG=${1:-r05}
 ONLY=${2:-all}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
@@ -31,11 +31,14 @@ kt() {   # name, bench args...
   python tools/rocpd_summary.py "$(find "$OUT/kt_$name" -name '*.db' | head -1)" 60 > "$OUT/${TAG}_${name}_kernel_stats.txt"
   rm -rf "$OUT/kt_$name"
 }
-tl() {   # name, anchor kernel, bench args...: one graph-replay step of the timed region as a timeline
-  local name=$1 anchor=$2; shift 2
+tl() {   # name, anchor kernel, step index, bench args...: one step of the TIMED region as a timeline.  The trace ends with
+         # bench.py's roofline leg (5 eager steps in the pixel regimes, 8 elsewhere); the 8 timed steps sit in front of it:
+         # index -9 (pixels) / -12 (landmarks) from the end.  (Rounds 2-4 took step 8 from the START: a step of the
+         # untimed eager-versus-replay probe, with staging copies the timed steps do not have.)
+  local name=$1 anchor=$2 which=$3; shift 3
   (cd /tmp && rocprofv3 --kernel-trace -d "$OUT/tl_$name" -o kt -- \
      python "$R/bench.py" "$@" --steps 8 --warmup 2 --repeats 1 --no-cpu-baseline > /dev/null 2>&1)
-  python tools/rocpd_timeline.py "$(find "$OUT/tl_$name" -name '*.db' | head -1)" "$anchor" 8 > "$OUT/${TAG}_${name}_step_timeline.txt"
+  python tools/rocpd_timeline.py "$(find "$OUT/tl_$name" -name '*.db' | head -1)" "$anchor" $which > "$OUT/${TAG}_${name}_step_timeline.txt"
   rm -rf "$OUT/tl_$name"
 }
 pmc() {   # name, counter list, filters..., -- bench args
@@ -54,7 +57,8 @@ python -c "from lipreading_amd import _build; print(_build._fingerprint())" > "$
 python bench.py 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_default.json"
 kt pixels --regime pixels
 for c in FETCH_SIZE WRITE_SIZE; do pmc px_$c $c pixels_pmc_$c -- --regime pixels; done
-tl pixels conv1_fwd --regime pixels
+tl pixels conv1_fwd -9 --regime pixels
+tl pixels_tfm conv1_fwd -9 --regime pixels_tfm
 kt pixels_tfm --regime pixels_tfm
 LIPREADING_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_forcedist.json"
 pmc sq1 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" pixels_pmc_SQ_pass1 conv_ conv1_ rnnc_ xgemm -- --regime pixels
@@ -69,8 +73,14 @@ if [ "$ONLY" != "pixels" ]; then
   kt lstm768 --regime landmarks --model lstm768
   kt lstm700 --regime landmarks --model lstm700
   kt landmarks_attn --regime landmarks_attn
-  tl gru256 step_begin --regime landmarks --model gru256
-  tl lstm768 step_begin --regime landmarks --model lstm768
+  # the reference's dominant flag-file family as shipped (config/archive/experiments/ecd/*: BiLSTM-768, char_dim 256,
+  # attention none, rnn_dropout 0.3) at 32 and at the files' own batch of 128
+  for b in 32 128; do
+    python bench.py --regime landmarks_attn --model lstm768 --attention none --char-dim 256 --rnn-dropout 0.3 --batch $b 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_ecd_lstm768_b$b.json"
+  done
+  kt ecd_lstm768_b32 --regime landmarks_attn --model lstm768 --attention none --char-dim 256 --batch 32
+  tl gru256 step_begin -12 --regime landmarks --model gru256
+  tl lstm768 step_begin -12 --regime landmarks --model lstm768
   for c in FETCH_SIZE WRITE_SIZE; do
     pmc gru_$c $c gru256_pmc_$c -- --regime landmarks --model gru256
     pmc lstm_$c $c lstm768_pmc_$c -- --regime landmarks --model lstm768
