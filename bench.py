@@ -572,6 +572,8 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
   enc = model.encoder if pixels else model
   flat = FlatParameters(model)
   opt = FusedAdam(flat, lr=1e-4)
+  if pixels and not DIST_ON and os.environ.get("LIPREADING_SUMSQ_EARLY", "1") != "0":
+    opt.sum_squares_early(enc)     # the encoder's share of the clip's sum of squares beside the conv backward
   dec = dec_opt = dec_sync = None
   if attn:
     import torch.nn.functional as F

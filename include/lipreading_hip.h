@@ -514,6 +514,9 @@ typedef struct {
   float* slabs;
   int32_t M, N, K, lda, ldb, ldc, ldadd, add_period, ldmask, flags, splits;
   float alpha, beta;
+  int32_t b_shift, b_period;   /* NN / TN, fp32 B: row k of B is read from row k + b_shift, as zeros where (k % b_period) +
+                                  b_shift leaves [0, b_period) — the previous / next time step of a [B*T][N] sequence tensor
+                                  (a recurrent layer's dW_hh = dG^T . h_prev straight from y); b_period 0: off */
 } lr_fgemm_job;
 int lr_fgemm(int prec, int form, int a_bf16, int b_bf16, const lr_fgemm_job* jobs, int njobs, lr_stream_t stream);
 int lr_fgemm_splits(int M, int N, int K);
@@ -779,11 +782,13 @@ int lr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
  * (a ticket in sumsq[1]) derives the step's coefficients.  sumsq [2]: {accumulator, ticket}, both zero before the first
  * call and put back to zero by every call (lr_step_begin's also_zero clears them as well: a launch that was torn down
  * half-way leaves nothing behind); scratch8: EIGHT floats of device scratch: [0..3] the step's coefficients, [5] the sum
- * of squares of this step; everything else as lr_adam_step. */
+ * of squares of this step; n_sumsq (<= n): the sum of squares is taken over grad[0 .. n_sumsq) only — the rest of the
+ * buffer's was added to sumsq[0] by lr_sumsq calls earlier in the step (FusedAdam.sum_squares_early: the encoder's share,
+ * beside the conv backward); n_sumsq = n: over everything; everything else as lr_adam_step. */
 int lr_clip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float* sumsq,
                       float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
                       int32_t* step_count, int32_t* skip, float* scratch8, const float* dist_words, float world,
-                      lr_stream_t stream);
+                      int64_t n_sumsq, lr_stream_t stream);
 
 #ifdef __cplusplus
 }

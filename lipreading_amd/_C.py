@@ -129,7 +129,7 @@ SIGNATURES = {
     "lr_adam_step": (c_int, [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_float,
                               c_float, P, P, P, P, c_float, P]),
     "lr_clip_adam_step": (c_int, [P, P, P, P, c_int64, P, c_float, c_float, c_float, c_float, c_float,
-                                   c_float, P, P, P, P, c_float, P]),
+                                   c_float, P, P, P, P, c_float, c_int64, P]),
 }
 
 
@@ -149,7 +149,8 @@ class FgemmJob(ctypes.Structure):
   """lr_fgemm_job (include/lipreading_hip.h)."""
   _fields_ = [(n, c_void_p) for n in ("A", "B", "C", "bias", "addend", "mask", "colsum", "slabs")] + \
              [(n, ctypes.c_int32) for n in ("M", "N", "K", "lda", "ldb", "ldc", "ldadd", "add_period", "ldmask", "flags",
-                                            "splits")] + [("alpha", c_float), ("beta", c_float)]
+                                            "splits")] + [("alpha", c_float), ("beta", c_float)] + \
+             [("b_shift", ctypes.c_int32), ("b_period", ctypes.c_int32)]
 
 
 DEC_MAX_LAYERS = 8   # LR_DEC_MAX_LAYERS

@@ -995,6 +995,7 @@ extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_par
         j.M = M; j.N = Hd; j.K = BL; j.lda = ldg; j.ldb = Hd; j.ldc = Hd;
         j.ldadd = 0; j.add_period = 0; j.ldmask = 0; j.flags = 0; j.splits = 1;
         j.alpha = 1.f; j.beta = beta;
+        j.b_shift = 0; j.b_period = 0;
       };
       if (G == 3) {
         add(2 * Hd, dG, hprev, gw_hh);

@@ -66,6 +66,8 @@ struct FJob {
   int flags, splits, k_chunk, tile0, ny, tiles;
   int vec_a, vec_b;      // 0: element loads; 1: 16-byte (fp32) / 8-byte (bf16) loads where a quad is whole; 2: whole quads only
   int vec_c;             // the epilogue's row-contiguous accesses (C, slabs, bias, addend, mask) are whole aligned quads
+  int b_shift, b_period; // B stored [K][N]: row k is read from row k + b_shift, as zeros where (k % b_period) + b_shift
+                         // leaves [0, b_period) (B already points b_shift rows off); b_period 0: off
   float alpha, beta;
 };
 constexpr int FMAXJOBS = 20;
@@ -144,9 +146,15 @@ struct Tile {
   static __device__ __forceinline__ unsigned stage_offset(int k0, int ld) { return (unsigned)(KS ? k0 * ld : k0) * ES; }
   // krem = kend - k0: a quad whose k (relative to the stage) is at or past it is the K tail -> bit 31 -> zeros.  Only a K
   // range's last stages have one (workgroup-uniform branch); every other stage's loads have no VALU instruction at all.
+  // kill: bit i = quad i is zeros whatever its address (a row whose shifted neighbour lies across a sequence end)
   static __device__ __forceinline__ void loadf(float4 (&r)[4], __amdgpu_buffer_rsrc_t rsrc, const unsigned (&voff)[4],
-                                               unsigned soff, int krem, int tid) {
+                                               unsigned soff, int krem, int tid, unsigned kill = 0u) {
     unsigned o[4] = {voff[0], voff[1], voff[2], voff[3]};
+    if (kill) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if ((kill >> i) & 1u) o[i] = 0x80000000u;
+    }
     if (krem < FBK) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -173,13 +181,18 @@ struct Tile {
   }
   // ---- global -> registers, guarded form: element (or whole-quad) loads under predicates ----------------------------
   static __device__ __forceinline__ void load(float4 (&r)[4], const void* base, int ld, int row0, int rows, int k0,
-                                              int kend, bool vec, int tid) {
+                                              int kend, bool vec, int tid, int shift = 0, int period = 0) {
     if (KS) {
       const int lane = tid & 63, col = row0 + 32 * (tid >> 6) + 4 * (lane & 7);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int k = k0 + 8 * i + (lane >> 3);
-        r[i] = ld4<BF>(base, (int64_t)k * ld + col, k < kend ? rows - col : 0, vec);
+        bool ok = k < kend;
+        if (period > 0) {
+          const int tt = k % period + shift;
+          ok = ok && tt >= 0 && tt < period;
+        }
+        r[i] = ld4<BF>(base, (int64_t)k * ld + col, ok ? rows - col : 0, vec);
       }
     } else {
 #pragma unroll
@@ -267,7 +280,8 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(const FArgs args) {
     float* C;
     const float *bias, *addend, *mask;
     float *colsum, *slabs;
-    int M, N, K, lda, ldb, ldc, ldadd, add_period, ldmask, flags, k_chunk, tile0, ny, tiles, vec_a, vec_b, vec_c;
+    int M, N, K, lda, ldb, ldc, ldadd, add_period, ldmask, flags, k_chunk, tile0, ny, tiles, vec_a, vec_b, vec_c, b_shift,
+        b_period;
     float alpha, beta;
   } g;
   {
@@ -276,6 +290,7 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(const FArgs args) {
     g.slabs = j.slabs; g.M = j.M; g.N = j.N; g.K = j.K; g.lda = j.lda; g.ldb = j.ldb; g.ldc = j.ldc; g.ldadd = j.ldadd;
     g.add_period = j.add_period; g.ldmask = j.ldmask; g.flags = j.flags; g.k_chunk = j.k_chunk; g.tile0 = j.tile0;
     g.ny = j.ny; g.tiles = j.tiles; g.vec_a = j.vec_a; g.vec_b = j.vec_b; g.vec_c = j.vec_c; g.alpha = j.alpha;
+    g.b_shift = j.b_shift; g.b_period = j.b_period;
     g.beta = j.beta;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -372,9 +387,27 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(const FArgs args) {
     TileA::offsets(offa, g.lda, m0, g.M, tid);
     TileB::offsets(offb, g.ldb, n0, g.N, tid);
     float4 ra[2][4], rb[2][4];
+    // (B read through a row shift: the phase of each of the thread's four rows within its period, advanced by a stage
+    // per load_stage call — the calls come in stage order —, no division in the loop)
+    int bt[4] = {0, 0, 0, 0};
+    if (!TB && g.b_period > 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bt[i] = (kbeg + 8 * i + (lane >> 3)) % g.b_period;
+    }
     auto load_stage = [&](int q, int k0) __attribute__((always_inline)) {
+      unsigned kill = 0u;
+      if (!TB && g.b_period > 0) {     // workgroup-uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int tt = bt[i] + g.b_shift;
+          if (tt < 0 || tt >= g.b_period) kill |= 1u << i;
+          bt[i] += FBK;
+          if (bt[i] >= g.b_period) bt[i] -= g.b_period;
+          if (bt[i] >= g.b_period) bt[i] %= g.b_period;
+        }
+      }
       TileA::loadf(ra[q], ra_rsrc, offa, TileA::stage_offset(k0, g.lda), kend - k0, tid);
-      TileB::loadf(rb[q], rb_rsrc, offb, TileB::stage_offset(k0, g.ldb), kend - k0, tid);
+      TileB::loadf(rb[q], rb_rsrc, offb, TileB::stage_offset(k0, g.ldb), kend - k0, tid, kill);
     };
     load_stage(0, kbeg);
     load_stage(1, kbeg + FBK);
@@ -403,7 +436,7 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(const FArgs args) {
     const int how_a = g.vec_a == 2 ? 1 : g.vec_a, how_b = g.vec_b == 2 ? 1 : g.vec_b;
     float4 ra[4], rb[4];
     TileA::load(ra, g.A, g.lda, m0, g.M, kbeg, kend, how_a != 0, tid);
-    TileB::load(rb, g.B, g.ldb, n0, g.N, kbeg, kend, how_b != 0, tid);
+    TileB::load(rb, g.B, g.ldb, n0, g.N, kbeg, kend, how_b != 0, tid, g.b_shift, TB ? 0 : g.b_period);
     for (int k0 = kbeg; k0 < kend; k0 += FBK) {
       lr_lds_barrier();                       // every wave has read the previous stage
       TileA::store(ra, As, tid);
@@ -412,7 +445,7 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(const FArgs args) {
       lr_lds_barrier();
       if (k0 + FBK < kend) {
         TileA::load(ra, g.A, g.lda, m0, g.M, k0 + FBK, kend, how_a != 0, tid);
-        TileB::load(rb, g.B, g.ldb, n0, g.N, k0 + FBK, kend, how_b != 0, tid);
+        TileB::load(rb, g.B, g.ldb, n0, g.N, k0 + FBK, kend, how_b != 0, tid, g.b_shift, TB ? 0 : g.b_period);
       }
       contract(smem);
     }
@@ -579,9 +612,13 @@ int lr_fgemm_launch(int prec, int form, int a_bf16, int b_bf16, const lr_fgemm_j
     LR_CHECK_ARG(!s.addend || (s.add_period > 0 && s.ldadd >= s.N));
     LR_CHECK_ARG(!s.mask || s.ldmask >= s.N);
     LR_CHECK_ARG(!s.colsum || (form == LR_FGEMM_TN && s.splits <= 1));
+    LR_CHECK_ARG(s.b_period >= 0 && (s.b_period == 0 || (form != LR_FGEMM_NT && !b_bf16)));
     LR_CHECK_ARG(s.splits <= 1 || s.slabs);
     LR_CHECK_ARG(!(s.flags & LR_FGEMM_C_BF16) || s.beta == 0.f);
-    g.A = s.A; g.B = s.B; g.C = (float*)s.C; g.bias = s.bias; g.addend = s.addend; g.mask = s.mask; g.colsum = s.colsum;
+    g.A = s.A; g.B = s.B; g.C = (float*)s.C;
+    g.b_shift = s.b_period > 0 ? s.b_shift : 0; g.b_period = s.b_period;
+    // (row k of B comes from row k + b_shift: the base moves, the rows whose neighbour does not exist are never read)
+    if (g.b_period > 0) g.B = reinterpret_cast<const float*>(s.B) + (int64_t)g.b_shift * s.ldb; g.bias = s.bias; g.addend = s.addend; g.mask = s.mask; g.colsum = s.colsum;
     g.M = s.M; g.N = s.N; g.K = s.K; g.lda = s.lda; g.ldb = s.ldb; g.ldc = s.ldc; g.ldadd = s.ldadd;
     g.add_period = s.add_period > 0 ? s.add_period : 1; g.ldmask = s.ldmask; g.flags = s.flags;
     g.alpha = s.alpha; g.beta = s.beta;

@@ -843,12 +843,13 @@ extern "C" int lr_adam_step(float* param, const float* grad, float* exp_avg, flo
 extern "C" int lr_clip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                                  float* sumsq, float max_norm, float grad_scale, float lr, float beta1, float beta2,
                                  float eps, int32_t* step_count, int32_t* skip, float* scratch8,
-                                 const float* dist_words, float world, lr_stream_t stream) {
+                                 const float* dist_words, float world, int64_t n_sumsq, lr_stream_t stream) {
   LR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_count && scratch8 && sumsq && n > 0 && max_norm > 0.f);
-  LR_CHECK_ARG((reinterpret_cast<uintptr_t>(grad) & 15) == 0);
-  int g = grid_for((n + 3) / 4, 256);
+  LR_CHECK_ARG((reinterpret_cast<uintptr_t>(grad) & 15) == 0 && n_sumsq >= 0 && n_sumsq <= n);
+  int g = grid_for((n_sumsq + 3) / 4, 256);
   if (g > 256) g = 256;  // one atomic per workgroup
-  LR_LAUNCH(sumsq_prepare_kernel, dim3(g), dim3(256), 0, stream, grad, n, sumsq, step_count, skip,
+  // (n_sumsq < n: the rest of the buffer's sum of squares is in sumsq[0] already — lr_sumsq calls of this step)
+  LR_LAUNCH(sumsq_prepare_kernel, dim3(g), dim3(256), 0, stream, grad, n_sumsq, sumsq, step_count, skip,
             (const int32_t*)lr_fault_words(), max_norm, grad_scale, lr, beta1, beta2, scratch8, dist_words, world);
   int st = lr_launch_status();
   if (st != LR_OK) return st;

@@ -674,7 +674,23 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
     int st = lr_launch_status();
     if (st != LR_OK) return st;
   }
-  if (proj_x3(mode)) {
+  if (proj_x3(mode) && !x_stored_bf16(mode) && !x_exact(mode) && !proj_x1(mode) && I <= 1024 && !lr_debug_dwih_packed()) {
+    // an UPPER layer of the pixel regime (fp32 input, short K): gates[:, d, :] = x . W_ih[d]^T + folded bias straight from
+    // x and the weights (lr_fgemm.hip, NT form, bias in the epilogue), the directions as two jobs of one launch — no
+    // pack launch (round 5, bench shape: 37 us of pack + contraction -> one launch)
+    lr_fgemm_job jobs[2];
+    for (int d = 0; d < D; ++d) {
+      lr_fgemm_job& j = jobs[d];
+      j.A = x; j.B = w_ih[d]; j.C = gates + (size_t)d * GH;
+      j.bias = bias + (size_t)d * GH; j.addend = nullptr; j.mask = nullptr; j.colsum = nullptr; j.slabs = nullptr;
+      j.M = B * T; j.N = GH; j.K = I; j.lda = I; j.ldb = I; j.ldc = D * GH;
+      j.ldadd = 0; j.add_period = 0; j.ldmask = 0; j.flags = 0; j.splits = 1;
+      j.alpha = 1.f; j.beta = 0.f;
+      j.b_shift = 0; j.b_period = 0;
+    }
+    int st = lr_fgemm_launch(LR_FGEMM_X3, LR_FGEMM_NT, 0, 0, jobs, D, stream);
+    if (st != LR_OK) return st;
+  } else if (proj_x3(mode)) {
     // gates[b,t,:,:] = x[b,t,:] @ [W_ih[0]; W_ih[1]]^T + folded bias: both directions in one product
     int st = lr_xproj_forward(x, B * T, I, w_ih, GH, D, bias, gates, x_exact(mode) ? 1 : 0, x_stored_bf16(mode) ? 1 : 0,
                               l.gemm_bytes ? (void*)(base + l.gemm) : nullptr, l.gemm_bytes, stream, proj_x1(mode) ? 1 : 0);
@@ -856,27 +872,52 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
       if (st != LR_OK) return st;
     }
     if (!(parts & 2)) return LR_OK;
-    if (x_stored_bf16(mode) && !proj_x1(mode) && !lr_debug_dwih_packed()) {
-      // dW_ih[d] = dG[:, d, :GH]^T . x straight from dG and the stored bf16 features (lr_fgemm.hip, TN form, B stored
-      // as bf16: ds_read_b64_tr_b16 delivers both operands' K-major fragments): no transposed pack of either operand.
-      // Round 5, same-visit A/B at the bench shape (M 1536, N 3456, K 2400; profiles/r05_variants_ab.txt): pixel step
-      // 2.517 / 2.477 ms (packed lr_xgemm path, first / last line of the visit) -> 2.397 / 2.393; the whole gradient
-      // BIT-identical (the same products accumulated in the same order).  lr_rnn_debug_disable_cluster bit 3 = the
-      // packed path, for that A/B.
-      lr_fgemm_job jobs[2];
-      for (int d = 0; d < D; ++d) {
-        lr_fgemm_job& j = jobs[d];
-        j.A = dG + (size_t)d * 4 * H; j.B = x; j.C = dw_ih[d];
-        j.bias = nullptr; j.addend = nullptr; j.mask = nullptr; j.colsum = nullptr; j.slabs = nullptr;
-        j.M = GH; j.N = I; j.K = R; j.lda = ldg; j.ldb = I; j.ldc = I;
+    if (!proj_x1(mode) && !lr_debug_dwih_packed()) {
+      // The layer's whole weight half straight from dG, x and y (lr_fgemm.hip, TN form: ds_read_b64_tr_b16 delivers both
+      // operands' K-major fragments, nothing is packed or transposed in memory):
+      //   dW_ih[d] = dG[:, d, :GH]^T . x                        (x fp32, or the stored bf16 features: their own hi plane)
+      //   dW_hh[d] = dGh^T . h_prev, h_prev[b,t] = y[b,t-1] (forward) / y[b,t+1] (reverse), zero across sequence ends: B
+      //              read through a row shift; the GRU's n-gate rows take slot 3 (d/d(W_hn h + b_hn)) instead of slot 2
+      //   db_ih / db_hh = the column sums of those products' A operands, emitted by their first column tiles
+      // ONE launch (two when x is stored as bf16: that operand form is its own instantiation) of 24-350 workgroups in
+      // place of 2 pack launches + 2 contractions + 2 split-K combines + 2 bias-gradient launches that each swept the
+      // chip.  Round 5, same-visit A/B at the bench shape (profiles/r05_variants_ab.txt): dW_ih of the first layer alone
+      // (M 1536, N 3456, K 2400) took the pixel step from 2.517 / 2.477 ms to 2.397 / 2.393, the whole gradient
+      // BIT-identical (same products, same order).  lr_rnn_debug_disable_cluster bit 3 = the packed path, for that A/B.
+      lr_fgemm_job jobs[8];
+      int n = 0;
+      auto add = [&](const float* A, const void* Bm, int ldb, float* C, float* bias_out, int M, int N, int shift, int period) {
+        lr_fgemm_job& j = jobs[n++];
+        j.A = A; j.B = Bm; j.C = C;
+        j.bias = nullptr; j.addend = nullptr; j.mask = nullptr; j.colsum = bias_out; j.slabs = nullptr;
+        j.M = M; j.N = N; j.K = R; j.lda = ldg; j.ldb = ldb; j.ldc = N;
         j.ldadd = 0; j.add_period = 0; j.ldmask = 0; j.flags = 0; j.splits = 1;
         j.alpha = 1.f; j.beta = wbeta;
+        j.b_shift = shift; j.b_period = period;
+      };
+      const bool xbf = x_stored_bf16(mode);
+      if (xbf) {
+        for (int d = 0; d < D; ++d) add(dG + (size_t)d * 4 * H, x, I, dw_ih[d], db_ih[d], GH, I, 0, 0);
+        st = lr_fgemm_launch(LR_FGEMM_X3, LR_FGEMM_TN, 0, 1, jobs, n, stream);
+        if (st != LR_OK) return st;
+        n = 0;
       }
-      st = lr_fgemm_launch(LR_FGEMM_X3, LR_FGEMM_TN, 0, 1, jobs, D, stream);
-    } else {
-      st = lr_xproj_dw(dG, ldg, 4 * H, x, R, I, GH, D, dw_ih, wbeta, x_exact(mode) ? 1 : 0, x_stored_bf16(mode) ? 1 : 0,
-                       xws, xws_bytes, stream, proj_x1(mode) ? 1 : 0);
+      for (int d = 0; d < D; ++d) {
+        const float* dGd = dG + (size_t)d * 4 * H;
+        const float* yd = y + (size_t)d * H;
+        const int shift = d == 0 ? -1 : 1;
+        if (!xbf) add(dGd, x, I, dw_ih[d], db_ih[d], GH, I, 0, 0);
+        if (G == 3) {
+          add(dGd, yd, D * H, dw_hh[d], db_hh[d], 2 * H, H, shift, T);
+          add(dGd + 3 * H, yd, D * H, dw_hh[d] + (size_t)2 * H * H, db_hh[d] + 2 * H, H, H, shift, T);
+        } else {
+          add(dGd, yd, D * H, dw_hh[d], db_hh[d], GH, H, shift, T);
+        }
+      }
+      return lr_fgemm_launch(LR_FGEMM_X3, LR_FGEMM_TN, 0, 0, jobs, n, stream);
     }
+    st = lr_xproj_dw(dG, ldg, 4 * H, x, R, I, GH, D, dw_ih, wbeta, x_exact(mode) ? 1 : 0, x_stored_bf16(mode) ? 1 : 0,
+                     xws, xws_bytes, stream, proj_x1(mode) ? 1 : 0);
     if (st != LR_OK) return st;
     // recurrent weight gradient on the same split-bf16 path (one contraction per direction)
     st = lr_xproj_dwhh(dG, ldg, y, D * H, R, T, H, G, D, dw_hh, wbeta, xws, xws_bytes, stream, proj_x1(mode) ? 1 : 0);

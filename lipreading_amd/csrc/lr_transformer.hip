@@ -271,6 +271,7 @@ lr_fgemm_job job(const void* A, int lda, const void* Bm, int ldb, void* C, int l
   j.M = M; j.N = N; j.K = K; j.lda = lda; j.ldb = ldb; j.ldc = ldc;
   j.ldadd = 0; j.add_period = 0; j.ldmask = 0; j.flags = 0; j.splits = 1;
   j.alpha = 1.f; j.beta = 0.f;
+  j.b_shift = 0; j.b_period = 0;
   return j;
 }
 

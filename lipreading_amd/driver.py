@@ -259,6 +259,10 @@ def run(**flags):
     return _cer(correct, count)
 
   opt = tuple(FusedAdam(fl, lr=f["learning_rate"]) for fl in flats)
+  if pixels and hasattr(encoder, "encoder"):
+    # (single process, one backward per step: the sequence encoder's share of the clip's sum of squares is taken beside
+    # the conv backward, optim.FusedAdam.sum_squares_early)
+    opt[0].sum_squares_early(encoder.encoder)
   # the step of every batch shape (B, Tmax, Lmax) is captured once as a hipGraph and replayed
   graphs = T.StepGraphs(enabled=bool(f["step_graphs"]))
 

@@ -53,6 +53,11 @@ def _notify(weights):
     hook(list(weights))
 
 
+# Callables invoked (on the stream that produced them) when the LAST gradients of the encoder have been enqueued: the
+# weight half of the layer that reads the model's input features (optim.FusedAdam.sum_squares_early registers here).
+encoder_grads_complete_hooks = []
+
+
 # Weight-gradient halves of layer backwards that were put on the side stream (see
 # _RNNLayerFunction.backward): the tensors they use, kept alive until flush_deferred() joins the streams.
 overlap_weight_grads = False     # PixelLipReader switches it on; needs in-place (.grad) gradients
@@ -183,6 +188,9 @@ class _RNNLayerFunction(torch.autograd.Function):
       side.wait_stream(torch.cuda.current_stream())
       with torch.cuda.stream(side):
         weight_half()
+        if mode & _INPUT_STORED_BF16:         # (the layer that reads the frontend's features: the encoder's last gradients)
+          for hook in encoder_grads_complete_hooks:
+            hook()
       return (dx, None, None, None, None, None) + (None,) * len(weights)
     _C.check(L.lr_rnn_layer_backward(
         mode, x.data_ptr(), lens.data_ptr(), _ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(b_ih),

@@ -103,12 +103,14 @@ class FusedAdam(object):
     # (the clip's accumulator and ticket are cleared by the same launch — they are clean already, lr_clip_adam_step puts
     # them back to zero itself; this only mends a launch that was torn down half-way)
     self.flat.zero_grad(also_zero=self._sumsq)
+    self._early_armed = hasattr(self, "_early_lo")
 
   step_begin = zero_grad
 
   def zero_grad_and_prepare_ctc(self, chars, frame_lens, char_lens):
     """zero_grad() with the step's CTC label plumbing (ctc.prepare_ctc_inputs) in the same launch; returns
     (labels_p1, frame_lens32, label_lens32)."""
+    self._early_armed = hasattr(self, "_early_lo")
     return self.flat.zero_grad(also_zero=self._sumsq, ctc_inputs=(chars, frame_lens, char_lens))
 
   def reset(self, lr=None):
@@ -119,6 +121,36 @@ class FusedAdam(object):
     self.step_count.zero_()
     if lr is not None:
       self.lr = float(lr)
+
+  def sum_squares_early(self, module):
+    """Pixel regime, single process, ONE backward per step: `module` (the encoder) owns the TAIL of the flat buffer, and its
+    gradients are complete long before the conv frontend's (its last weight half runs on the side stream beside the conv
+    backward): take their share of the clip's sum of squares there, so that the launch in front of Adam only sweeps the
+    frontend's 1.3 MB (round 5: 23 -> 6 us at the end of the step).  Not under data parallelism (the clip is taken on the
+    all-reduced gradient) and not with several backward passes per step (the early sum would see a partial gradient)."""
+    from . import encoder as _enc
+    ids = {id(p) for p in module.parameters()}
+    idx = [i for i, p in enumerate(self.flat.params) if id(p) in ids]
+    assert idx and idx == list(range(idx[0], len(self.flat.params))), "the module must own the tail of the flat buffer"
+    self._early_lo = self.flat.offsets[idx[0]]
+    self._early_done = False
+    self._early_armed = False        # between this optimiser's zero_grad() and its step(): the backward in between is ours
+    import weakref
+    ref = weakref.ref(self)
+
+    def hook():
+      me = ref()
+      if me is None:
+        if hook in _enc.encoder_grads_complete_hooks:
+          _enc.encoder_grads_complete_hooks.remove(hook)
+        return
+      if not me._early_armed or me._early_done:
+        return
+      n = me.flat.numel - me._early_lo
+      _C.check(_C.lib().lr_sumsq(me.flat.grad.data_ptr() + 4 * me._early_lo, n, me._sumsq.data_ptr(),
+                                 _C.stream_handle()), "lr_sumsq")
+      me._early_done = True
+    _enc.encoder_grads_complete_hooks.append(hook)
 
   def step(self, grad_norm=None, grad_scale=1.0, skip=None, dist_words=None, world=1):
     """grad_norm: max norm for clip_grad_norm_ (None = no clipping); grad_scale: multiplies the
@@ -135,14 +167,21 @@ class FusedAdam(object):
     st = _C.stream_handle()
     o, n = f.first, f.numel - f.first          # (the words in front of the parameters are no gradient)
     ptrs = [t.data_ptr() + 4 * o for t in (f.data, f.grad, self.exp_avg, self.exp_avg_sq)]
+    early = getattr(self, "_early_done", False)
+    self._early_done = False
+    self._early_armed = False
     if grad_norm is not None and float(grad_norm) > 0:
       # sum of squares -> clip coefficient -> Adam in two launches (the first one's last workgroup derives the coefficients)
+      assert not (early and dist_words is not None), "sum_squares_early is a single-process option"
+      n_sumsq = (self._early_lo - o) if early else n
       _C.check(L.lr_clip_adam_step(*ptrs, n, self._sumsq.data_ptr(), float(grad_norm),
                                    float(grad_scale), self.lr, self.betas[0], self.betas[1], self.eps,
                                    self.step_count.data_ptr(), _C.ptr(skip), self._scratch.data_ptr(),
-                                   _C.ptr(dist_words), float(world), st),
+                                   _C.ptr(dist_words), float(world), n_sumsq, st),
                "lr_clip_adam_step")
       return
+    if early:
+      self._sumsq.zero_()     # (no clip this step: the early sum is dropped)
     _C.check(L.lr_adam_step(*ptrs, n, None, 0.0, float(grad_scale),
                             self.lr, self.betas[0], self.betas[1], self.eps,
                             self.step_count.data_ptr(), _C.ptr(skip), self._scratch.data_ptr(),

@@ -87,6 +87,8 @@ class _StackFunction(torch.autograd.Function):
       with torch.cuda.stream(side):
         weight_half()
         _notify(weights)
+        for hook in _enc.encoder_grads_complete_hooks:   # (the head's gradients were written before this backward)
+          hook()
       _enc._deferred.append((x, dh, reserve, ws, grads, weights))
       return (dx, None, None, None) + (None,) * len(weights)
     weight_half()

@@ -23,7 +23,7 @@ def dev():
 
 
 def run_job(prec, form, A, Bm, M, N, K, bias=None, addend=None, add_period=0, mask=None, relu=False, c_bf16=False,
-            colsum=None, beta=0.0, alpha=1.0, C0=None, splits=1, a_bf16=False, b_bf16=False):
+            colsum=None, beta=0.0, alpha=1.0, C0=None, splits=1, a_bf16=False, b_bf16=False, b_shift=0, b_period=0):
   from lipreading_amd import _C
   dev = A.device
   C = C0.clone() if C0 is not None else torch.full((M, N), float("nan"), dtype=torch.bfloat16 if c_bf16 else torch.float32,
@@ -41,6 +41,7 @@ def run_job(prec, form, A, Bm, M, N, K, bias=None, addend=None, add_period=0, ma
   j.flags = (RELU if relu else 0) | (C_BF16 if c_bf16 else 0)
   j.splits = splits
   j.alpha, j.beta = alpha, beta
+  j.b_shift, j.b_period = b_shift, b_period
   _C.check(_C.lib().lr_fgemm(prec, form, int(a_bf16), int(b_bf16), ctypes.byref(j), 1, _C.stream_handle()), "lr_fgemm")
   torch.cuda.synchronize()
   return C
@@ -194,8 +195,32 @@ def test_several_products_share_a_launch(dev):
     j.M, j.N, j.K, j.lda, j.ldb, j.ldc = No, Ki, R, No, Ki, Ki
     j.ldadd = j.add_period = j.ldmask = j.flags = 0
     j.splits, j.alpha, j.beta = 1, 1.0, 0.0
+    j.b_shift = j.b_period = 0
   _C.check(_C.lib().lr_fgemm(X3, TN, 0, 0, jobs, len(shapes), _C.stream_handle()), "lr_fgemm")
   torch.cuda.synchronize()
   for (dy, x, C, cs), (w, ws) in zip(keep, want):
     assert float((C.double() - w).norm()) <= 3e-5 * float(w.norm())
     assert float((cs.double() - ws).norm()) <= 2e-6 * float(ws.norm())
+
+
+@pytest.mark.parametrize("prec", [X3, F32])
+@pytest.mark.parametrize("shift", [-1, 1])
+@pytest.mark.parametrize("Bn,T,H,G4", [(32, 75, 256, 512), (5, 7, 36, 72), (3, 1, 64, 128), (2, 40, 30, 90)])
+def test_recurrent_weight_gradient_reads_the_neighbouring_time_step(dev, prec, shift, Bn, T, H, G4):
+  """TN with b_shift / b_period: dW_hh = dG^T . h_prev straight from y [B*T][H] — h_prev[b,t] = y[b,t-1] (shift -1: the
+  forward direction) or y[b,t+1] (+1: the reverse one), zero across the ends of a sequence (lr_rnn.hip's weight half;
+  rounds 1-4 packed a shifted, transposed copy of y for it)."""
+  g = torch.Generator().manual_seed(Bn * 100 + T + H + shift)
+  R = Bn * T
+  y = torch.randn(Bn, T, H + 4, generator=g)          # (a direction's columns of a wider [B][T][D*H] tensor)
+  dG = torch.randn(R, G4, generator=g)
+  hp = torch.zeros(Bn, T, H)
+  if shift < 0:
+    hp[:, 1:] = y[:, :-1, :H]
+  else:
+    hp[:, :-1] = y[:, 1:, :H]
+  want = dG.double().t() @ hp.reshape(R, H).double()
+  yd = y.to(dev).reshape(R, H + 4)[:, :H]
+  got = run_job(prec, TN, dG.to(dev), yd, G4, H, R, b_shift=shift, b_period=T)
+  scale = max(float(want.norm()), 1e-6)
+  assert float((got.cpu().double() - want).norm()) <= (3e-5 if prec == X3 else 2e-6) * scale + (1e-30 if T > 1 else 0)

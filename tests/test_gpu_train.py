@@ -561,3 +561,53 @@ def test_decoder_nll_for_any_vocabulary_size(dev, V):
   assert abs(float(loss) - float(want)) < 1e-5 and float((lp.grad - lp_r.grad).abs().max()) < 1e-7
   s, n = T.decoder_nll_sum(lp.detach(), labels, 0)
   assert abs(float(s) - float(want) * float(n)) < 1e-4 and int(n) == int((labels[:, :L] != 0).sum())
+
+
+@pytest.mark.parametrize("encoder_kind,graph", [("rnn", False), ("rnn", True), ("transformer", False)])
+def test_early_sum_of_squares_gives_the_same_clipped_step(dev, encoder_kind, graph):
+  """FusedAdam.sum_squares_early (round 5): the sequence encoder's share of clip_grad_norm_'s sum of squares
+  (train_better_model.py:78) is taken on the side stream as soon as its last weight gradients exist — beside the conv
+  backward — and the launch in front of Adam only sweeps the frontend's gradients.  Same total norm (two partial sums in
+  another order: 1e-6 relative), same weights after clipped steps, eager and from a replayed hipGraph."""
+  from lipreading_amd import train as T_
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.frontend import ConvFrontend3D, PixelLipReader, feature_dim
+  from lipreading_amd.optim import FlatParameters, FusedAdam
+  from lipreading_amd.transformer import TransformerVideoEncoder
+  c2i = default_char2idx()
+  g = torch.Generator().manual_seed(8)
+  B, Tn = 4, 12
+  clips = torch.randint(0, 256, (B, Tn, 3, 32, 32), generator=g, dtype=torch.uint8).to(dev)
+  lens = torch.full((B,), Tn)
+  chars = torch.zeros(B, 6, dtype=torch.long)
+  chars[:, 0], chars[:, 1:5], chars[:, 5] = c2i['<BOS>'], torch.randint(4, 64, (B, 4), generator=g), c2i['<EOS>']
+  char_lens = torch.full((B,), 6)
+  out = {}
+  for early in (False, True):
+    torch.manual_seed(9)
+    if encoder_kind == "rnn":
+      enc = VideoEncoder(feature_dim(32, 32), 32, rnn_type='GRU', num_layers=2, bidirectional=True, enable_ctc=True,
+                         vocab_size=64, char2idx=c2i)
+    else:
+      enc = TransformerVideoEncoder(feature_dim(32, 32), d_model=64, nhead=4, num_layers=2, dim_feedforward=128,
+                                    enable_ctc=True, vocab_size=64, char2idx=c2i)
+    model = PixelLipReader(enc, ConvFrontend3D()).to(dev).train()
+    opt = FusedAdam(FlatParameters(model), lr=1e-3)
+    if early:
+      opt.sum_squares_early(enc)
+    graphs = T_.StepGraphs() if graph else None
+    norms = []
+    for _ in range(5 if graph else 3):
+      loss, status = T_.ctc_step(model, opt, clips, lens.to(dev), chars.to(dev), char_lens.to(dev), grad_norm=0.05,
+                                 max_len=Tn, graphs=graphs)
+      norms.append(float(opt.total_norm()))
+      assert int(status) == 0
+    if graph:
+      assert graphs.replays >= 1
+    out[early] = (opt.flat.data.detach().cpu().numpy().copy(), norms)
+  assert all(n > 0.05 for n in out[False][1])                       # the clip was active in every step
+  # the first step's norm is the same sum in another order; later steps start from weights that differ by that rounding
+  np.testing.assert_allclose(out[True][1][0], out[False][1][0], rtol=2e-6)
+  np.testing.assert_allclose(out[True][1], out[False][1], rtol=1e-3)
+  np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-3, atol=1e-5)
