@@ -492,10 +492,10 @@ int lr_attn_fused_backward(const float* qkv, const int32_t* key_lens, const floa
  *   products on the bf16 matrix cores (~1e-5 relative); LR_FGEMM_F32: exact fp32 matrix-core products.  a_bf16 (NT
  *   only) / b_bf16 (TN only): that operand is stored as bf16.  Epilogue per job: out = alpha * acc + bias[n] +
  *   addend[(m % add_period) * ldadd + n]; LR_FGEMM_RELU; mask (out = mask[m * ldmask + n] > 0 ? out : 0); + beta * C;
- *   LR_FGEMM_C_BF16: C is a bf16 matrix (beta must be 0).  colsum (TN only, splits <= 1): colsum[m] = beta *
- *   colsum[m] + sum_k A[k][m] — the bias gradient of a weight-gradient product.  splits > 1: K is cut into that many
- *   ranges whose partial sums go through `slabs` ([splits][M][N] floats) and one combine launch (lr_fgemm_splits
- *   suggests a count).  Up to 20 jobs of one form share a launch.  Only enqueues. */
+ *   LR_FGEMM_C_BF16: C is a bf16 matrix (beta must be 0).  colsum (TN only): colsum[m] = beta * colsum[m] + sum_k A[k][m] — the
+ *   bias gradient of a weight-gradient product.  splits > 1: K is cut into that many ranges whose partial sums (and
+ *   partial column sums) go through `slabs` (lr_fgemm_slab_floats(M, N, splits) floats) and one combine launch for all
+ *   the launch's split jobs (lr_fgemm_splits suggests a count).  Up to 20 jobs of one form share a launch.  Only enqueues. */
 #define LR_FGEMM_X3 0
 #define LR_FGEMM_F32 1
 #define LR_FGEMM_NT 0
@@ -520,6 +520,7 @@ typedef struct {
 } lr_fgemm_job;
 int lr_fgemm(int prec, int form, int a_bf16, int b_bf16, const lr_fgemm_job* jobs, int njobs, lr_stream_t stream);
 int lr_fgemm_splits(int M, int N, int K);
+long long lr_fgemm_slab_floats(int M, int N, int splits);
 
 /* The whole encoder stack of lipreading_amd/transformer.py as three enqueues (lr_transformer.hip):
  *   h0 = x W_p^T + b_p + pe[t];  per layer (post-LN, ReLU feed-forward, dropout 0 — torch.nn.TransformerEncoderLayer):

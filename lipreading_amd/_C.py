@@ -47,6 +47,7 @@ SIGNATURES = {
     "lr_attn_fused_backward": (c_int, [P, P, P, P, c_float, c_int, c_int, c_int, c_int, P]),
     "lr_fgemm": (c_int, [c_int, c_int, c_int, c_int, P, c_int, P]),
     "lr_fgemm_splits": (c_int, [c_int, c_int, c_int]),
+    "lr_fgemm_slab_floats": (ctypes.c_longlong, [c_int, c_int, c_int]),
     "lr_tfm_reserve_bytes": (c_size_t, [c_int] * 8),
     "lr_tfm_workspace_bytes": (c_size_t, [c_int] * 8),
     "lr_tfm_forward": (c_int, [c_int, P, P, P, P, P, P, c_size_t, P, c_size_t] + [c_int] * 7 + [c_float, P]),

@@ -215,7 +215,7 @@ int lr_sgemm_grouped_tn_impl(int n, const int* M, const int* N, const int* K, co
 // lr_fgemm.hip: products straight from the tensors as they lie in memory (include/lipreading_hip.h lr_fgemm)
 int lr_fgemm_launch(int prec, int form, int a_bf16, int b_bf16, const lr_fgemm_job* jobs, int njobs, hipStream_t stream);
 int lr_fgemm_want_splits(int M, int N, int K);
-size_t lr_fgemm_slab_floats(int M, int N, int splits);
+size_t lr_fgemm_slab_floats_impl(int M, int N, int splits);
 // lr_rnn_cluster.hip: the GRU / LSTM recurrence as one launch per layer pass, fp32-faithful (W_hh sliced over a
 // cluster of ceil(H / 32) CUs per (direction, 8 samples), bf16 hi + lo planes, self-tagged 4-byte exchange words);
 // G = 3 (GRU) or 4 (LSTM); h0 / c0 (may be NULL) = the state before the first step, [D][B][H]; dh0 / dc0 (may be

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(const FArgs args) {
     const float *bias, *addend, *mask;
     float *colsum, *slabs;
     int M, N, K, lda, ldb, ldc, ldadd, add_period, ldmask, flags, k_chunk, tile0, ny, tiles, vec_a, vec_b, vec_c, b_shift,
-        b_period;
+        b_period, splits;
     float alpha, beta;
   } g;
   {
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(const FArgs args) {
     g.slabs = j.slabs; g.M = j.M; g.N = j.N; g.K = j.K; g.lda = j.lda; g.ldb = j.ldb; g.ldc = j.ldc; g.ldadd = j.ldadd;
     g.add_period = j.add_period; g.ldmask = j.ldmask; g.flags = j.flags; g.k_chunk = j.k_chunk; g.tile0 = j.tile0;
     g.ny = j.ny; g.tiles = j.tiles; g.vec_a = j.vec_a; g.vec_b = j.vec_b; g.vec_c = j.vec_c; g.alpha = j.alpha;
-    g.b_shift = j.b_shift; g.b_period = j.b_period;
+    g.b_shift = j.b_shift; g.b_period = j.b_period; g.splits = j.splits;
     g.beta = j.beta;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -466,8 +466,11 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(const FArgs args) {
       const int c = m0 + 32 * wave + 4 * lane;
       const float v[4] = {cs.x, cs.y, cs.z, cs.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (c + e < g.M) g.colsum[c + e] = g.beta != 0.f ? g.beta * g.colsum[c + e] + v[e] : v[e];
+      for (int e = 0; e < 4; ++e) {
+        if (c + e >= g.M) continue;
+        if (g.slabs) g.slabs[(size_t)g.splits * g.M * g.N + (size_t)zs * g.M + c + e] = v[e];   // this K range's share
+        else g.colsum[c + e] = g.beta != 0.f ? g.beta * g.colsum[c + e] + v[e] : v[e];
+      }
     }
   }
 
@@ -557,10 +560,22 @@ __global__ __launch_bounds__(256, 1) void fgemm_kernel(const FArgs args) {
   }
 }
 
-// split-K combine (fixed order over the slabs) + the epilogue
-__global__ __launch_bounds__(256) void fgemm_reduce_kernel(const FJob g) {
+// split-K combine of every split job of a launch (grid (blocks, jobs); fixed order over the slabs) + the epilogue, and
+// the jobs' column sums (TN with colsum): the K ranges' shares in fixed order
+__global__ __launch_bounds__(256) void fgemm_reduce_kernel(const FArgs args) {
+  const FJob& g = args.j[blockIdx.y];
+  if (g.splits <= 1) return;
   const int64_t total = (int64_t)g.M * g.N;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g.colsum) {
+    const float* part = g.slabs + (size_t)g.splits * total;
+    for (int64_t i = i0; i < g.M; i += stride) {
+      float s = 0.f;
+      for (int z = 0; z < g.splits; ++z) s += part[(int64_t)z * g.M + i];
+      g.colsum[i] = g.beta != 0.f ? g.beta * g.colsum[i] + s : s;
+    }
+  }
+  for (int64_t i = i0; i < total; i += stride) {
     float s = 0.f;
     for (int z = 0; z < g.splits; ++z) s += g.slabs[(int64_t)z * total + i];
     const int row = (int)(i / g.N), col = (int)(i - (int64_t)row * g.N);
@@ -584,7 +599,8 @@ bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p
 }  // namespace
 
 // ---- host side (internal C++ interface, lr_common.h) ------------------------------------------------------------------
-size_t lr_fgemm_slab_floats(int M, int N, int splits) { return splits > 1 ? (size_t)splits * M * N : 0; }
+// [splits][M][N] partial products, then [splits][M] partial column sums (TN jobs with colsum)
+size_t lr_fgemm_slab_floats_impl(int M, int N, int splits) { return splits > 1 ? (size_t)splits * ((size_t)M * N + M) : 0; }
 
 // K split so that a product of few tiles and a long K (the K = 3456 input projection: 38 tiles) fills the chip;
 // >= 8 stages per split, never more splits than bring the launch to ~2 workgroups per CU
@@ -611,14 +627,15 @@ int lr_fgemm_launch(int prec, int form, int a_bf16, int b_bf16, const lr_fgemm_j
     LR_CHECK_ARG(s.A && s.B && s.C && s.M > 0 && s.N > 0 && s.K > 0 && s.lda > 0 && s.ldb > 0 && s.ldc >= s.N);
     LR_CHECK_ARG(!s.addend || (s.add_period > 0 && s.ldadd >= s.N));
     LR_CHECK_ARG(!s.mask || s.ldmask >= s.N);
-    LR_CHECK_ARG(!s.colsum || (form == LR_FGEMM_TN && s.splits <= 1));
+    LR_CHECK_ARG(!s.colsum || form == LR_FGEMM_TN);
     LR_CHECK_ARG(s.b_period >= 0 && (s.b_period == 0 || (form != LR_FGEMM_NT && !b_bf16)));
     LR_CHECK_ARG(s.splits <= 1 || s.slabs);
     LR_CHECK_ARG(!(s.flags & LR_FGEMM_C_BF16) || s.beta == 0.f);
     g.A = s.A; g.B = s.B; g.C = (float*)s.C;
     g.b_shift = s.b_period > 0 ? s.b_shift : 0; g.b_period = s.b_period;
     // (row k of B comes from row k + b_shift: the base moves, the rows whose neighbour does not exist are never read)
-    if (g.b_period > 0) g.B = reinterpret_cast<const float*>(s.B) + (int64_t)g.b_shift * s.ldb; g.bias = s.bias; g.addend = s.addend; g.mask = s.mask; g.colsum = s.colsum;
+    if (g.b_period > 0) g.B = reinterpret_cast<const float*>(s.B) + (int64_t)g.b_shift * s.ldb;
+    g.bias = s.bias; g.addend = s.addend; g.mask = s.mask; g.colsum = s.colsum;
     g.M = s.M; g.N = s.N; g.K = s.K; g.lda = s.lda; g.ldb = s.ldb; g.ldc = s.ldc; g.ldadd = s.ldadd;
     g.add_period = s.add_period > 0 ? s.add_period : 1; g.ldmask = s.ldmask; g.flags = s.flags;
     g.alpha = s.alpha; g.beta = s.beta;
@@ -660,19 +677,18 @@ int lr_fgemm_launch(int prec, int form, int a_bf16, int b_bf16, const lr_fgemm_j
 #undef LR_FG
   int st = lr_launch_status();
   if (st != LR_OK) return st;
+  int64_t biggest = 0;
   for (int q = 0; q < njobs; ++q) {
-    const FJob& g = a.j[q];
+    FJob& g = a.j[q];
     if (g.splits <= 1) continue;
-    FJob r = g;
-    r.bias = jobs[q].bias;
-    const int64_t total = (int64_t)g.M * g.N;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    LR_LAUNCH(fgemm_reduce_kernel, dim3(blocks), dim3(256), 0, stream, r);
-    st = lr_launch_status();
-    if (st != LR_OK) return st;
+    g.slabs = jobs[q].slabs;      // (the combine reads slabs, bias, colsum of the job as given)
+    if ((int64_t)g.M * g.N > biggest) biggest = (int64_t)g.M * g.N;
   }
-  return LR_OK;
+  if (biggest == 0) return LR_OK;
+  int blocks = (int)((biggest + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  LR_LAUNCH(fgemm_reduce_kernel, dim3(blocks, njobs), dim3(256), 0, stream, a);
+  return lr_launch_status();
 }
 
 extern "C" int lr_fgemm(int prec, int form, int a_bf16, int b_bf16, const lr_fgemm_job* jobs, int njobs,
@@ -680,3 +696,4 @@ extern "C" int lr_fgemm(int prec, int form, int a_bf16, int b_bf16, const lr_fge
   return lr_fgemm_launch(prec, form, a_bf16, b_bf16, jobs, njobs, (hipStream_t)stream);
 }
 extern "C" int lr_fgemm_splits(int M, int N, int K) { return lr_fgemm_want_splits(M, N, K); }
+extern "C" long long lr_fgemm_slab_floats(int M, int N, int splits) { return (long long)lr_fgemm_slab_floats_impl(M, N, splits); }

@@ -526,6 +526,27 @@ Layout reserve_layout(int G, int B, int T, int I, int H, int D, bool x3 = false)
   l.total = l.xch + (l.xch_bytes + 3) / 4;
   return l;
 }
+// A layer's weight half as split-K lr_fgemm jobs (what a regime-R layer on the one-launch recurrence runs, see
+// rnn_layer_backward_impl): K = B * T rows is long and the products are a few dozen tiles, so K is cut until the launch
+// is ~1.5 workgroups per compute unit.  Returns the K split; *slab_floats = what the jobs' partial sums take.
+int wgrad_fgemm_plan(int G, int R, int I, int H, int D, size_t* slab_floats) {
+  const int GH = G * H;
+  int Ms[3] = {GH, G == 3 ? 2 * H : GH, H}, Ns[3] = {I, H, H};
+  const int nj = G == 3 ? 3 : 2;
+  long tiles = 0;
+  for (int j = 0; j < nj; ++j) tiles += (long)((Ms[j] + 127) / 128) * ((Ns[j] + 127) / 128);
+  tiles *= D;
+  const long stages = (R + 31) / 32;
+  long sp = tiles > 0 ? 384 / tiles : 1;
+  if (sp > stages / 8) sp = stages / 8;
+  if (sp > 16) sp = 16;
+  if (sp < 1) sp = 1;
+  size_t f = 0;
+  for (int j = 0; j < nj; ++j) f += (lr_fgemm_slab_floats_impl(Ms[j], Ns[j], (int)sp) + 63) / 64 * 64;
+  *slab_floats = f * D;
+  return (int)sp;
+}
+
 struct WsLayout {
   size_t dG, dcar, wT, dgp, colsum, gemm, xch, total;  // float offsets
   size_t gemm_bytes, wp_per_dir, dgp_floats, xch_bytes;
@@ -567,6 +588,11 @@ WsLayout ws_layout(int G, int B, int T, int I, int H, int D) {
     }
     g2 = lr_sgemm_grouped_workspace_bytes(n, Ms, Ns, Ks);
     if (g2 > gb) gb = g2;
+  }
+  {
+    size_t sf = 0;
+    wgrad_fgemm_plan(G, B * T, I, H, D, &sf);
+    if (sf * sizeof(float) > gb) gb = sf * sizeof(float);
   }
   l.gemm_bytes = gb;
   l.xch = (l.gemm + (gb + 3) / 4 + 63) / 64 * 64;
@@ -943,7 +969,45 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
   }
   bias_job.ld = ldg; bias_job.rows = R; bias_job.H = H; bias_job.D = D; bias_job.G = G; bias_job.accumulate = accumulate;
   bool bias_done = false;
-  if (!x3 && !wx) {
+  if (!x3 && !wx && recur_split(mode) && !lr_debug_wgrad_f32()) {
+    // Regime R on the one-launch recurrence (round 5): the weight half as split-bf16 products straight from dG, x and y
+    // (lr_fgemm.hip, TN form, K cut into `sp` ranges; ~1e-5 relative, the recurrence that produced dG is itself a
+    // split-bf16 product) with the bias gradients as the products' column sums — one launch + one combine in place of
+    // the exact-fp32 grouped GEMM (64 us at BiGRU-256, B = 32: the fp32 matrix cores' rate), its combine and two
+    // bias-gradient launches.  recurrence = 'f32' (the per-step kernels) keeps every product exact fp32.
+    size_t sf = 0;
+    const int sp = wgrad_fgemm_plan(G, R, I, H, D, &sf);
+    if (wl.gemm_bytes < sf * sizeof(float)) return LR_ERR_WORKSPACE;
+    float* slab = (float*)gws;
+    lr_fgemm_job jobs[8];
+    int n = 0;
+    auto add = [&](const float* A, const float* Bm, int ldb, float* C, float* bias_out, int M, int N, int shift, int period) {
+      lr_fgemm_job& j = jobs[n++];
+      j.A = A; j.B = Bm; j.C = C;
+      j.bias = nullptr; j.addend = nullptr; j.mask = nullptr; j.colsum = bias_out;
+      j.slabs = sp > 1 ? slab : nullptr;
+      slab += (lr_fgemm_slab_floats_impl(M, N, sp) + 63) / 64 * 64;
+      j.M = M; j.N = N; j.K = R; j.lda = ldg; j.ldb = ldb; j.ldc = N;
+      j.ldadd = 0; j.add_period = 0; j.ldmask = 0; j.flags = 0; j.splits = sp;
+      j.alpha = 1.f; j.beta = wbeta;
+      j.b_shift = shift; j.b_period = period;
+    };
+    for (int d = 0; d < D; ++d) {
+      const float* dGd = dG + (size_t)d * 4 * H;
+      const float* yd = y + (size_t)d * H;
+      const int shift = d == 0 ? -1 : 1;
+      add(dGd, x, I, dw_ih[d], db_ih[d], GH, I, 0, 0);
+      if (G == 3) {
+        add(dGd, yd, D * H, dw_hh[d], db_hh[d], 2 * H, H, shift, T);
+        add(dGd + 3 * H, yd, D * H, dw_hh[d] + (size_t)2 * H * H, db_hh[d] + 2 * H, H, H, shift, T);
+      } else {
+        add(dGd, yd, D * H, dw_hh[d], db_hh[d], GH, H, shift, T);
+      }
+    }
+    st = lr_fgemm_launch(LR_FGEMM_X3, LR_FGEMM_TN, 0, 0, jobs, n, stream);
+    if (st != LR_OK) return st;
+    bias_done = true;
+  } else if (!x3 && !wx) {
     // every weight gradient of the layer in ONE grouped launch + one combine (lr_gemm.hip): each of these
     // small-M*N, K = B*T products fills a sixth of the chip on its own.
     //   dW_ih[d] (G*H x I) = dGx^T (slots 0..G-1 are contiguous rows) @ x

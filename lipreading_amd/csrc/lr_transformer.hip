@@ -251,7 +251,7 @@ TfmWs tfm_ws(int mode, int B, int T, int I, int Dm, int nh, int F, int nl) {
   w.dhB = o; o += al64(R * Dm);
   w.dP = o; o += (mode & LR_TFM_ATTN_FUSED) ? 0 : al64((size_t)B * nh * T * T);
   w.slabs = o;
-  w.slab_floats = al64(lr_fgemm_slab_floats((int)R, Dm, lr_fgemm_want_splits((int)R, Dm, I)));
+  w.slab_floats = al64(lr_fgemm_slab_floats_impl((int)R, Dm, lr_fgemm_want_splits((int)R, Dm, I)));
   o += w.slab_floats;
   w.total = o;
   return w;

@@ -28,7 +28,7 @@ def run_job(prec, form, A, Bm, M, N, K, bias=None, addend=None, add_period=0, ma
   dev = A.device
   C = C0.clone() if C0 is not None else torch.full((M, N), float("nan"), dtype=torch.bfloat16 if c_bf16 else torch.float32,
                                                    device=dev)
-  slabs = torch.empty(max(1, splits) * M * N, dtype=torch.float32, device=dev) if splits > 1 else None
+  slabs = torch.full((max(1, splits) * (M * N + M),), float("nan"), dtype=torch.float32, device=dev) if splits > 1 else None
   j = _C.FgemmJob()
   j.A, j.B, j.C = A.data_ptr(), Bm.data_ptr(), C.data_ptr()
   j.bias, j.addend, j.mask = _C.ptr(bias), _C.ptr(addend), _C.ptr(mask)
@@ -224,3 +224,54 @@ def test_recurrent_weight_gradient_reads_the_neighbouring_time_step(dev, prec, s
   got = run_job(prec, TN, dG.to(dev), yd, G4, H, R, b_shift=shift, b_period=T)
   scale = max(float(want.norm()), 1e-6)
   assert float((got.cpu().double() - want).norm()) <= (3e-5 if prec == X3 else 2e-6) * scale + (1e-30 if T > 1 else 0)
+
+
+@pytest.mark.parametrize("prec", [X3, F32])
+@pytest.mark.parametrize("splits", [2, 7])
+def test_split_weight_gradient_keeps_its_bias_gradient_and_row_shift(dev, prec, splits):
+  """a regime-R layer's weight half (lr_rnn.hip, round 5): K = B * T cut into ranges, the column sums of A reduced with
+  the slabs, the recurrent product's neighbouring-step read across the range boundaries"""
+  Bn, T, H, G4 = 32, 75, 64, 256
+  g = torch.Generator().manual_seed(77 + splits)
+  R = Bn * T
+  y = torch.randn(Bn, T, H, generator=g)
+  dG = torch.randn(R, G4, generator=g)
+  hp = torch.zeros(Bn, T, H)
+  hp[:, 1:] = y[:, :-1]
+  want, wsum = dG.double().t() @ hp.reshape(R, H).double(), dG.double().sum(0)
+  C0, c0 = torch.randn(G4, H, generator=g), torch.randn(G4, generator=g)
+  tol = 3e-5 if prec == X3 else 2e-6
+  for beta in (0.0, 1.0):
+    cs = c0.to(dev).clone()
+    got = run_job(prec, TN, dG.to(dev), y.to(dev).reshape(R, H), G4, H, R, colsum=cs, splits=splits, b_shift=-1, b_period=T,
+                  beta=beta, C0=C0.to(dev))
+    assert float((got.cpu().double() - (want + beta * C0.double())).norm()) <= tol * float(want.norm()), beta
+    assert float((cs.cpu().double() - (wsum + beta * c0.double())).norm()) <= 2e-6 * float(wsum.norm()), beta
+
+
+def test_split_and_unsplit_products_share_a_launch_and_one_combine(dev):
+  from lipreading_amd import _C
+  g = torch.Generator().manual_seed(41)
+  R = 1200
+  shapes = [(192, 64, 4), (64, 64, 1), (128, 72, 3), (40, 12, 4)]
+  jobs = (_C.FgemmJob * len(shapes))()
+  keep, want = [], []
+  for q, (No, Ki, sp) in enumerate(shapes):
+    dy, x = torch.randn(R, No, generator=g).to(dev), torch.randn(R, Ki, generator=g).to(dev)
+    C, cs = torch.empty(No, Ki, device=dev), torch.empty(No, device=dev)
+    slabs = torch.full((_C.lib().lr_fgemm_slab_floats(No, Ki, sp),), float("nan"), device=dev) if sp > 1 else None
+    keep.append((dy, x, C, cs, slabs))
+    want.append((dy.double().t() @ x.double(), dy.double().sum(0)))
+    j = jobs[q]
+    j.A, j.B, j.C, j.colsum = dy.data_ptr(), x.data_ptr(), C.data_ptr(), cs.data_ptr()
+    j.bias = j.addend = j.mask = None
+    j.slabs = _C.ptr(slabs)
+    j.M, j.N, j.K, j.lda, j.ldb, j.ldc = No, Ki, R, No, Ki, Ki
+    j.ldadd = j.add_period = j.ldmask = j.flags = 0
+    j.splits, j.alpha, j.beta = sp, 1.0, 0.0
+    j.b_shift = j.b_period = 0
+  _C.check(_C.lib().lr_fgemm(X3, TN, 0, 0, jobs, len(shapes), _C.stream_handle()), "lr_fgemm")
+  torch.cuda.synchronize()
+  for (dy, x, C, cs, _), (w, ws) in zip(keep, want):
+    assert float((C.double() - w).norm()) <= 3e-5 * float(w.norm())
+    assert float((cs.double() - ws).norm()) <= 2e-6 * float(ws.norm())

@@ -33,7 +33,8 @@ kt() {   # name, bench args...
 }
 tl() {   # name, anchor kernel, step index, bench args...: one step of the TIMED region as a timeline.  The trace ends with
          # bench.py's roofline leg (5 eager steps in the pixel regimes, 8 elsewhere); the 8 timed steps sit in front of it:
-         # index -9 (pixels) / -12 (landmarks) from the end.  (Rounds 2-4 took step 8 from the START: a step of the
+         # index -9 from the end in the pixel regimes.  The landmark regimes' trace ends with the
+         # recurrence = 'f32' option run instead, and their probe phase has no staging copies: index 8 from the start.  (Rounds 2-4 took step 8 from the START: a step of the
          # untimed eager-versus-replay probe, with staging copies the timed steps do not have.)
   local name=$1 anchor=$2 which=$3; shift 3
   (cd /tmp && rocprofv3 --kernel-trace -d "$OUT/tl_$name" -o kt -- \
@@ -79,8 +80,8 @@ if [ "$ONLY" != "pixels" ]; then
     python bench.py --regime landmarks_attn --model lstm768 --attention none --char-dim 256 --rnn-dropout 0.3 --batch $b 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_ecd_lstm768_b$b.json"
   done
   kt ecd_lstm768_b32 --regime landmarks_attn --model lstm768 --attention none --char-dim 256 --batch 32
-  tl gru256 step_begin -12 --regime landmarks --model gru256
-  tl lstm768 step_begin -12 --regime landmarks --model lstm768
+  tl gru256 step_begin 8 --regime landmarks --model gru256
+  tl lstm768 step_begin 8 --regime landmarks --model lstm768
   for c in FETCH_SIZE WRITE_SIZE; do
     pmc gru_$c $c gru256_pmc_$c -- --regime landmarks --model gru256
     pmc lstm_$c $c lstm768_pmc_$c -- --regime landmarks --model lstm768
