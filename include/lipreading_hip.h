@@ -268,7 +268,11 @@ int lr_rnn_layer_forward(int mode, const float* x, const int32_t* lens,
  *   dw_ih/dw_hh/db_ih/db_hh: HOST arrays of D device pointers; overwritten with the grads, or
  *   (accumulate != 0) added to — the reference step runs two backward passes over the same
  *   encoder graph and lets the gradients accumulate (train_better_model.py:69,74).
- *   workspace: lr_rnn_workspace_bytes. */
+ *   workspace: lr_rnn_workspace_bytes.
+ *   reserve: the forward's, at the SAME address (const for the caller's purposes: the gates are only read).  On the
+ *   one-launch recurrence the forward's prologue launch also left the backward's W_hh fragments and cleared exchange
+ *   words in it (round 5); the first backward over a forward's reserve uses them (and dirties the exchange words), a
+ *   second one over the same forward re-packs with a launch of its own — the library keeps track by the address. */
 int lr_rnn_layer_backward(int mode, const float* x, const int32_t* lens,
                           const float* const* w_ih_host, const float* const* w_hh_host,
                           const float* const* b_ih_host, const float* const* b_hh_host,
@@ -610,6 +614,15 @@ int lr_ctc_grad_scaled(const float* log_probs, int64_t stride_b, int64_t stride_
 int lr_ctc_reduce(const float* nll, const int32_t* frame_lens, const int32_t* label_lens,
                   int reduction, float* out_loss, int32_t* out_status, float* grad_weight, int B,
                   lr_stream_t stream);
+
+/* lr_ctc_nll followed by lr_ctc_reduce with the same arguments, as ONE launch when every label has at most 31
+ * characters (the one-wave recursion kernel: its last workgroup to finish runs the batch reduction — round 5; the
+ * train step's path, lipreading_amd/ctc.py), as the two launches otherwise.  Launches of this entry must not overlap
+ * in time within a process (one completion counter; launches on one stream never do). */
+int lr_ctc_nll_reduce(const float* log_probs, int64_t stride_b, int64_t stride_t, const int32_t* labels,
+                      int label_stride, const int32_t* frame_lens, const int32_t* label_lens, float* nll,
+                      void* workspace, size_t workspace_bytes, int reduction, float* out_loss, int32_t* out_status,
+                      float* grad_weight, int B, int T, int C, int max_label_len, lr_stream_t stream);
 
 /* The train loop's label plumbing in ONE launch (train_better_model.py:31-32 labels = chars[:, 1:], label_lens =
  * char_lens - 1; ctc_loss.py:42,80 int32 integers, labels moved up by one so that index 0 is the blank):

@@ -101,6 +101,8 @@ SIGNATURES = {
                              c_int, c_int, c_int, P]),
     "lr_ctc_grad_scaled": (c_int, [P, c_int64, c_int64, P, c_int, P, P, P, P, P, P, P, c_size_t, c_int,
                                     c_int, c_int, c_int, P]),
+    "lr_ctc_nll_reduce": (c_int, [P, c_int64, c_int64, P, c_int, P, P, P, P, c_size_t, c_int, P, P, P, c_int, c_int,
+                                  c_int, c_int, P]),
     "lr_ctc_reduce": (c_int, [P, P, P, c_int, P, P, P, c_int, P]),
     "lr_ctc_greedy_decode": (c_int, [P, c_int64, c_int64, P, P, P, P, P, c_int, c_int, c_int,
                                       c_int, P]),

@@ -229,12 +229,15 @@ size_t lr_rnn_cluster_xch_bytes(int B, int H, int D, int backward);
 int lr_rnn_cluster_forward(int G, float* gates, float* extra, float* y, const float* const* w_hh, const float* const* b_hh,
                            const float* h0, const float* c0, const int32_t* lens, void* wpack, void* xch, int B, int T,
                            int D, int H, hipStream_t stream, int prologue_done = 0);
+// wpack_b / xch_b (may be NULL): the BACKWARD pass's fragments (lr_rnn_cluster_pack_bytes(.., 1)) and exchange words
+// (lr_rnn_cluster_xch_bytes(.., 1)) prepared by the same launch -> lr_rnn_cluster_backward(.., pack_done = 1)
 int lr_rnn_cluster_prologue(int G, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
-                            float* bias_out, void* wpack, void* xch, int B, int D, int H, hipStream_t stream);
+                            float* bias_out, void* wpack, void* xch, int B, int D, int H, hipStream_t stream,
+                            void* wpack_b = nullptr, void* xch_b = nullptr);
 int lr_rnn_cluster_backward(int G, const float* gates, const float* extra, const float* y, const float* dy,
                             const float* dh_n, const float* dc_n, float* dG, float* dh0, float* dc0, const float* h0,
                             const float* c0, const float* const* w_hh, const int32_t* lens, void* wpack, void* xch, int B,
-                            int T, int D, int H, hipStream_t stream);
+                            int T, int D, int H, hipStream_t stream, int pack_done = 0);
 // lr_xgemm.hip: fp32 GEMM on the bf16 matrix cores by hi/lo operand splitting (same operand
 // conventions; a_exact / b_exact: the operand's elements are bf16 values already)
 int lr_xgemm_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,

@@ -186,16 +186,13 @@ __device__ __forceinline__ float lse3_fast(float a, float b, float c) {
 // the bench's label length): wave 0 runs alpha, wave 1 beta, a state per lane, and the previous
 // row's neighbours come from lane shuffles — no LDS exchange row and no barrier per time step
 // (the T-step chain is then ~T x (2 shuffles + one log-sum-exp) instead of T barriers).
-__global__ __launch_bounds__(128) void ctc_alpha_beta_wave_kernel(const float* __restrict__ lp, int64_t stride_b,
-                                                                  int64_t stride_t,
-                                                                  const int32_t* __restrict__ labels,
-                                                                  int label_stride,
-                                                                  const int32_t* __restrict__ frame_lens,
-                                                                  const int32_t* __restrict__ label_lens,
-                                                                  float* __restrict__ nll, CtcWs ws, int T, int C,
-                                                                  int max_label_len) {
+__device__ __forceinline__ void ctc_alpha_beta_wave_body(char* smem_raw, const float* __restrict__ lp, int64_t stride_b,
+                                                         int64_t stride_t, const int32_t* __restrict__ labels,
+                                                         int label_stride, const int32_t* __restrict__ frame_lens,
+                                                         const int32_t* __restrict__ label_lens,
+                                                         float* __restrict__ nll, CtcWs ws, int T, int C,
+                                                         int max_label_len) {
   constexpr int sst = 64;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   int* lab_s = reinterpret_cast<int*>(smem_raw);                  // [32]
   float* lat = reinterpret_cast<float*>(lab_s + 32);              // [T][C]
   const int b = blockIdx.x;
@@ -376,11 +373,13 @@ __global__ void ctc_grad_rows_kernel(const float* __restrict__ lp, int64_t strid
 // ---------------------------------------------------------------------------------------
 constexpr int kReduceMaxB = 2048;
 
-__global__ void ctc_reduce_kernel(const float* __restrict__ nll,
-                                  const int32_t* __restrict__ frame_lens,
-                                  const int32_t* __restrict__ label_lens, int reduction,
-                                  float* __restrict__ out_loss, int32_t* __restrict__ out_status,
-                                  float* __restrict__ grad_weight, int B, const int32_t* __restrict__ fault) {
+// (the body of the batch reduction; s_nll / s_fl / s_ll / s_w: B-entry LDS arrays of the caller.  nll is read with
+// agent-scope atomic loads: in the fused form below other workgroups of the same launch wrote it)
+__device__ __forceinline__ void ctc_reduce_body(const float* nll, const int32_t* __restrict__ frame_lens,
+                                                const int32_t* __restrict__ label_lens, int reduction,
+                                                float* __restrict__ out_loss, int32_t* __restrict__ out_status,
+                                                float* __restrict__ grad_weight, int B, const int32_t* __restrict__ fault,
+                                                float* s_nll, int* s_fl, int* s_ll, float* s_w) {
   // fault[0] != 0: a one-launch recurrence that produced these log-probs gave up waiting for a partner workgroup
   // (lr_common.h lr_fault_words): the numbers are garbage, so the batch is reported like one the reference
   // skips (loss 0, status 2, zero gradient) — train_better_model.py:49-50.
@@ -392,14 +391,10 @@ __global__ void ctc_reduce_kernel(const float* __restrict__ nll,
     for (int i = threadIdx.x; i < B; i += blockDim.x) grad_weight[i] = 0.f;
     return;
   }
-  __shared__ float s_nll[kReduceMaxB];
-  __shared__ int s_fl[kReduceMaxB];
-  __shared__ int s_ll[kReduceMaxB];
-  __shared__ float s_w[kReduceMaxB];
   // compact away the label_len > 256 samples (ctc_loss.py:46-56) while staging into LDS;
   // done serially by thread 0 after a parallel copy so the order is preserved.
   for (int i = threadIdx.x; i < B; i += blockDim.x) {
-    s_nll[i] = nll[i];
+    s_nll[i] = __hip_atomic_load(nll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_fl[i] = frame_lens[i];
     s_ll[i] = label_lens[i];
     s_w[i] = 0.f;
@@ -534,6 +529,66 @@ __global__ void ctc_reduce_kernel(const float* __restrict__ nll,
   for (int i = threadIdx.x; i < B; i += blockDim.x) grad_weight[i] = s_w[i] * inv;
 }
 
+__global__ void ctc_reduce_kernel(const float* __restrict__ nll,
+                                  const int32_t* __restrict__ frame_lens,
+                                  const int32_t* __restrict__ label_lens, int reduction,
+                                  float* __restrict__ out_loss, int32_t* __restrict__ out_status,
+                                  float* __restrict__ grad_weight, int B, const int32_t* __restrict__ fault) {
+  __shared__ float s_nll[kReduceMaxB];
+  __shared__ int s_fl[kReduceMaxB];
+  __shared__ int s_ll[kReduceMaxB];
+  __shared__ float s_w[kReduceMaxB];
+  ctc_reduce_body(nll, frame_lens, label_lens, reduction, out_loss, out_status, grad_weight, B, fault, s_nll, s_fl, s_ll, s_w);
+}
+
+// What the batch reduction writes, riding the alpha/beta launch (lr_ctc_nll_reduce): out_loss == NULL: no rider.
+struct CtcTail {
+  int reduction;
+  float* out_loss;
+  int32_t* out_status;
+  float* grad_weight;
+  const int32_t* fault;
+};
+// workgroups of the current alpha/beta launch that have stored their sample's nll; the last one resets it.  One word for
+// the process: launches of lr_ctc_nll_reduce must not overlap in time (launches on one stream never do; a caller with two
+// losses in flight on two streams uses lr_ctc_nll + lr_ctc_reduce).
+__device__ unsigned g_ctc_ticket = 0u;
+
+// One workgroup per sample as above; with a rider (round 5) the LAST workgroup to finish runs the reference's batch
+// reduction (ctc_loss.py:64-112) in the same launch: the 5 us ctc_reduce launch between the recursions and the gradient
+// rows leaves a training step's critical path.  Its B-entry arrays lie over the lattice image, which is dead by then.
+__global__ __launch_bounds__(128) void ctc_alpha_beta_wave_kernel(const float* __restrict__ lp, int64_t stride_b,
+                                                                  int64_t stride_t,
+                                                                  const int32_t* __restrict__ labels,
+                                                                  int label_stride,
+                                                                  const int32_t* __restrict__ frame_lens,
+                                                                  const int32_t* __restrict__ label_lens,
+                                                                  float* __restrict__ nll, CtcWs ws, int T, int C,
+                                                                  int max_label_len, CtcTail tail) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  ctc_alpha_beta_wave_body(smem_raw, lp, stride_b, stride_t, labels, label_stride, frame_lens, label_lens, nll, ws, T, C,
+                           max_label_len);
+  if (!tail.out_loss) return;
+  __shared__ int s_last;
+  __syncthreads();                      // (every exit of the body is workgroup-uniform; thread 0 stored nll[b])
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const bool last = atomicAdd(&g_ctc_ticket, 1u) == gridDim.x - 1;
+    if (last) atomicExch(&g_ctc_ticket, 0u);
+    s_last = last ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const int B = (int)gridDim.x;
+  float* s_nll = reinterpret_cast<float*>(smem_raw);
+  int* s_fl = reinterpret_cast<int*>(s_nll + B);
+  int* s_ll = s_fl + B;
+  float* s_w = reinterpret_cast<float*>(s_ll + B);
+  ctc_reduce_body(nll, frame_lens, label_lens, tail.reduction, tail.out_loss, tail.out_status, tail.grad_weight, B,
+                  tail.fault, s_nll, s_fl, s_ll, s_w);
+}
+
 // ---------------------------------------------------------------------------------------
 // greedy decode
 // ---------------------------------------------------------------------------------------
@@ -606,11 +661,14 @@ extern "C" size_t lr_ctc_workspace_bytes(int B, int T, int C, int max_label_len)
   return ctc_ws_floats(B, T, C, max_label_len) * sizeof(float);
 }
 
-extern "C" int lr_ctc_nll(const float* log_probs, int64_t stride_b, int64_t stride_t,
+namespace {
+// *fused (may be NULL): set to 1 when the launch took the rider `tail` along (the one-wave kernel), else 0
+int ctc_nll_impl(const float* log_probs, int64_t stride_b, int64_t stride_t,
                           const int32_t* labels, int label_stride, const int32_t* frame_lens,
                           const int32_t* label_lens, float* nll, void* workspace,
                           size_t workspace_bytes, int B, int T, int C, int max_label_len,
-                          lr_stream_t stream) {
+                          lr_stream_t stream, CtcTail tail, int* fused) {
+  if (fused) *fused = 0;
   LR_CHECK_ARG(log_probs && labels && frame_lens && label_lens && nll && workspace);
   LR_CHECK_ARG(B > 0 && T > 0 && C > 0 && max_label_len >= 0 && label_stride >= 0);
   if (max_label_len > kMaxLabelLen) max_label_len = kMaxLabelLen;
@@ -623,8 +681,15 @@ extern "C" int lr_ctc_nll(const float* log_probs, int64_t stride_b, int64_t stri
   const size_t lat = (size_t)T * C * sizeof(float);
   if (sst == 64 && max_label_len <= 31 && 32 * sizeof(int) + lat + 16 <= 60 * 1024) {
     // every state fits one wave: shuffle recursion, no per-step barrier
-    LR_LAUNCH_PROF(LR_PROF_CTC_ALPHA_BETA, ctc_alpha_beta_wave_kernel, dim3(B), dim3(128), 32 * sizeof(int) + lat + 16, stream, log_probs, stride_b,
-              stride_t, labels, label_stride, frame_lens, label_lens, nll, ws, T, C, max_label_len);
+    size_t lds = 32 * sizeof(int) + lat + 16;
+    if (tail.out_loss && (size_t)B * 16 <= 60 * 1024) {
+      if (lds < (size_t)B * 16) lds = (size_t)B * 16;
+      if (fused) *fused = 1;
+    } else {
+      tail.out_loss = nullptr;
+    }
+    LR_LAUNCH_PROF(LR_PROF_CTC_ALPHA_BETA, ctc_alpha_beta_wave_kernel, dim3(B), dim3(128), lds, stream, log_probs, stride_b,
+              stride_t, labels, label_stride, frame_lens, label_lens, nll, ws, T, C, max_label_len, tail);
   } else if (base + lat <= 60 * 1024) {
     LR_LAUNCH_PROF(LR_PROF_CTC_ALPHA_BETA, ctc_alpha_beta_kernel<true>, dim3(B), dim3(nthr), base + lat, stream, log_probs,
               stride_b, stride_t, labels, label_stride, frame_lens, label_lens, nll, ws, T, C, sst,
@@ -635,6 +700,39 @@ extern "C" int lr_ctc_nll(const float* log_probs, int64_t stride_b, int64_t stri
               max_label_len, concurrent);
   }
   return lr_launch_status();
+}
+}  // namespace
+
+extern "C" int lr_ctc_nll(const float* log_probs, int64_t stride_b, int64_t stride_t,
+                          const int32_t* labels, int label_stride, const int32_t* frame_lens,
+                          const int32_t* label_lens, float* nll, void* workspace,
+                          size_t workspace_bytes, int B, int T, int C, int max_label_len,
+                          lr_stream_t stream) {
+  CtcTail none = {0, nullptr, nullptr, nullptr, nullptr};
+  return ctc_nll_impl(log_probs, stride_b, stride_t, labels, label_stride, frame_lens, label_lens, nll, workspace,
+                      workspace_bytes, B, T, C, max_label_len, stream, none, nullptr);
+}
+
+extern "C" int lr_ctc_reduce(const float* nll, const int32_t* frame_lens,
+                             const int32_t* label_lens, int reduction, float* out_loss,
+                             int32_t* out_status, float* grad_weight, int B, lr_stream_t stream);
+
+// lr_ctc_nll then lr_ctc_reduce, as ONE launch where the one-wave recursion kernel applies (labels of <= 31 characters:
+// every shipped caption configuration), two otherwise
+extern "C" int lr_ctc_nll_reduce(const float* log_probs, int64_t stride_b, int64_t stride_t,
+                                 const int32_t* labels, int label_stride, const int32_t* frame_lens,
+                                 const int32_t* label_lens, float* nll, void* workspace, size_t workspace_bytes,
+                                 int reduction, float* out_loss, int32_t* out_status, float* grad_weight, int B, int T,
+                                 int C, int max_label_len, lr_stream_t stream) {
+  LR_CHECK_ARG(out_loss && out_status && grad_weight);
+  LR_CHECK_ARG(reduction == LR_CTC_SUM || reduction == LR_CTC_MEAN);
+  if (B > kReduceMaxB) return LR_ERR_UNSUPPORTED;
+  CtcTail tail = {reduction, out_loss, out_status, grad_weight, (const int32_t*)lr_fault_words()};
+  int fused = 0;
+  int st = ctc_nll_impl(log_probs, stride_b, stride_t, labels, label_stride, frame_lens, label_lens, nll, workspace,
+                        workspace_bytes, B, T, C, max_label_len, stream, tail, &fused);
+  if (st != LR_OK || fused) return st;
+  return lr_ctc_reduce(nll, frame_lens, label_lens, reduction, out_loss, out_status, grad_weight, B, stream);
 }
 
 extern "C" int lr_ctc_grad_scaled(const float* log_probs, int64_t stride_b, int64_t stride_t,

@@ -26,6 +26,8 @@
 //   4. Backward: the same chain in reverse with dG·W_hh as the per-step product (W_hh transposed
 //      once per call so its rows are again K-contiguous), then one GEMM each for dW_ih, dW_hh
 //      (with the "previous hidden state" row-shift view of y), dx, and a column-sum for the biases.
+#include <mutex>
+
 #include "lr_common.h"
 #include <hip/hip_ext.h>
 
@@ -502,8 +504,8 @@ __global__ __launch_bounds__(NW * 64) void rnn_dh0_kernel(const float* __restric
 }
 
 struct Layout {
-  size_t gates, extra, bias, wp, hp, gemm, xch, total;  // float offsets / total floats
-  size_t wp_per_dir, hp_floats, gemm_bytes, xch_bytes;
+  size_t gates, extra, bias, wp, hp, gemm, xch, wpb, xchb, total;  // float offsets / total floats
+  size_t wp_per_dir, hp_floats, gemm_bytes, xch_bytes, wpb_bytes, xchb_bytes;
 };
 Layout reserve_layout(int G, int B, int T, int I, int H, int D, bool x3 = false) {
   Layout l;
@@ -523,9 +525,41 @@ Layout reserve_layout(int G, int B, int T, int I, int H, int D, bool x3 = false)
   l.gemm_bytes = x3 ? lr_xproj_workspace_bytes(B * T, I, G * H, D, H) : lr_sgemm_workspace_bytes(B * T, G * H, I);
   l.xch = (l.gemm + (l.gemm_bytes + 3) / 4 + 63) / 64 * 64;   // exchange words of the cluster recurrence
   l.xch_bytes = lr_rnn_cluster_supported(G, B, H) ? lr_rnn_cluster_xch_bytes(B, H, D, 0) : 0;
-  l.total = l.xch + (l.xch_bytes + 3) / 4;
+  // the cluster recurrence's BACKWARD fragments of W_hh and first exchange words: prepared by the forward's prologue
+  // launch (round 5), kept with the gates for the backward
+  l.wpb = (l.xch + (l.xch_bytes + 3) / 4 + 63) / 64 * 64;
+  l.wpb_bytes = lr_rnn_cluster_supported(G, B, H) ? lr_rnn_cluster_pack_bytes(G, H, D, 1) : 0;
+  l.xchb = (l.wpb + (l.wpb_bytes + 3) / 4 + 63) / 64 * 64;
+  l.xchb_bytes = lr_rnn_cluster_supported(G, B, H) ? lr_rnn_cluster_xch_bytes(B, H, D, 1) : 0;
+  l.total = l.xchb + (l.xchb_bytes + 3) / 4;
   return l;
 }
+
+// Which reserves hold backward fragments that no backward has consumed yet (host side, keyed by the reserve's address):
+// set by a forward whose prologue packed them, taken by the first backward over that reserve, which then skips its own
+// pack launch.  A second backward over the same forward (retain_graph), or one whose forward ran with the one-launch
+// recurrence switched off, finds no entry and packs (and clears the exchange words) itself, as rounds 1-4 always did.
+// Under stream capture the decision is taken once, at capture: the graph replays forward-then-backward as captured.
+struct FreshPacks {
+  static constexpr int N = 64;
+  std::mutex mu;
+  const void* key[N] = {};
+  int next = 0;
+  void put(const void* p) {
+    std::lock_guard<std::mutex> g(mu);
+    for (int i = 0; i < N; ++i)
+      if (key[i] == p) return;
+    key[next] = p;
+    next = (next + 1) % N;
+  }
+  bool take(const void* p) {
+    std::lock_guard<std::mutex> g(mu);
+    for (int i = 0; i < N; ++i)
+      if (key[i] == p) { key[i] = nullptr; return true; }
+    return false;
+  }
+};
+FreshPacks g_fresh_packs;
 // A layer's weight half as split-K lr_fgemm jobs (what a regime-R layer on the one-launch recurrence runs, see
 // rnn_layer_backward_impl): K = B * T rows is long and the products are a few dozen tiles, so K is cut until the launch
 // is ~1.5 workgroups per compute unit.  Returns the K split; *slab_floats = what the jobs' partial sums take.
@@ -692,9 +726,12 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
   const bool cluster = recur_split(mode) && lr_rnn_cluster_supported(G, B, H);
   if (cluster) {
     if ((size_t)D * l.wp_per_dir * sizeof(float) < lr_rnn_cluster_pack_bytes(G, H, D, 0)) return LR_ERR_WORKSPACE;
-    int st = lr_rnn_cluster_prologue(G, w_hh, b_ih, b_hh, bias, base + l.wp, base + l.xch, B, D, H, stream);
+    int st = lr_rnn_cluster_prologue(G, w_hh, b_ih, b_hh, bias, base + l.wp, base + l.xch, B, D, H, stream, base + l.wpb,
+                                     base + l.xchb);
     if (st != LR_OK) return st;
+    g_fresh_packs.put(reserve);
   } else {
+    g_fresh_packs.take(reserve);
     LR_LAUNCH(fold_bias2_kernel, dim3((GH + 255) / 256, D), dim3(256), 0, stream, b_ih[0], b_hh[0], b_ih[D - 1],
               b_hh[D - 1], bias, G, H);
     int st = lr_launch_status();
@@ -720,6 +757,22 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
     // gates[b,t,:,:] = x[b,t,:] @ [W_ih[0]; W_ih[1]]^T + folded bias: both directions in one product
     int st = lr_xproj_forward(x, B * T, I, w_ih, GH, D, bias, gates, x_exact(mode) ? 1 : 0, x_stored_bf16(mode) ? 1 : 0,
                               l.gemm_bytes ? (void*)(base + l.gemm) : nullptr, l.gemm_bytes, stream, proj_x1(mode) ? 1 : 0);
+    if (st != LR_OK) return st;
+  } else if (I % 4 == 0 && D <= 2 && !lr_debug_dwih_packed()) {
+    // exact fp32 (regime R, recurrence 'f32'): gates[:, d, :] = x . W_ih[d]^T + folded bias as lr_fgemm jobs on the fp32
+    // matrix cores, the directions as two jobs of one launch (round 5: 128 x 128 tiles with double-buffered stages in
+    // place of lr_gemm's 64 x 64 ones: 35.5 -> see profiles/r05_variants_ab.txt at B*T = 2400, I = 204, G*H = 768)
+    lr_fgemm_job jobs[2];
+    for (int d = 0; d < D; ++d) {
+      lr_fgemm_job& j = jobs[d];
+      j.A = x; j.B = w_ih[d]; j.C = gates + (size_t)d * GH;
+      j.bias = bias + (size_t)d * GH; j.addend = nullptr; j.mask = nullptr; j.colsum = nullptr; j.slabs = nullptr;
+      j.M = B * T; j.N = GH; j.K = I; j.lda = I; j.ldb = I; j.ldc = D * GH;
+      j.ldadd = 0; j.add_period = 0; j.ldmask = 0; j.flags = 0; j.splits = 1;
+      j.alpha = 1.f; j.beta = 0.f;
+      j.b_shift = 0; j.b_period = 0;
+    }
+    int st = lr_fgemm_launch(LR_FGEMM_F32, LR_FGEMM_NT, 0, 0, jobs, D, stream);
     if (st != LR_OK) return st;
   } else if (D == 2 && (((w_ih[1] - w_ih[0]) & 3) == 0)) {
     // gates[b,t,d,:] = x[b,t,:] @ W_ih[d]^T + folded bias: both directions as one batched launch (x shared,
@@ -846,8 +899,11 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
     // dG is already in the workspace
   } else if (recur_split(mode) && lr_rnn_cluster_supported(G, B, H)) {
     if ((size_t)D * wl.wp_per_dir * sizeof(float) < lr_rnn_cluster_pack_bytes(G, H, D, 1)) return LR_ERR_WORKSPACE;
+    // fragments of W_hh and exchange words: in the reserve, left there by the forward's prologue unless an earlier
+    // backward used them up (g_fresh_packs)
+    float* rw = const_cast<float*>(rbase);
     st = lr_rnn_cluster_backward(G, gates, extra, y, dy, dh_n, dc_n, dG, nullptr, nullptr, nullptr, nullptr, w_hh, lens,
-                                 wT, wbase + wl.xch, B, T, D, H, stream);
+                                 rw + rl.wpb, rw + rl.xchb, B, T, D, H, stream, g_fresh_packs.take(reserve) ? 1 : 0);
     if (st != LR_OK) return st;
   } else {
     StepPtrs p;

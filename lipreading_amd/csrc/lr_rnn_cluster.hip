@@ -228,9 +228,44 @@ struct FoldPtrs {
   const float* b_hh[2];
   float* out;      // [D][G*H], or nullptr: nothing to fold
 };
+// backward: out[((((d*CC + c)*4 + wave)*NT + tile)*BFW + f)*64 + lane] = plane f & 1 of W_hh[gate * H + unit + e][j],
+// e = 0..7: entry 8 kg + e of k step f >> 1 of the member's own dG — U = 32: gate = the k step, unit = 32 c + 8 kg;
+// U = 16: gate = 2 (k step) + (kg >> 1), unit = 16 c + 8 (kg & 1) — and j = U (wave + 4 (tile / TPD)) + 16 (tile % TPD) + col
+// (the units of destination member wave + 4 (tile / TPD)); zero where gate >= G, unit + e >= H or j >= H.
+template <int G, int CC, int U>
+__device__ __forceinline__ void pack_bwd_body(const float* __restrict__ w0, const float* __restrict__ w1,
+                                              bf16x8* __restrict__ out, int D, int H, u32* __restrict__ xch, int nzero) {
+  using C = Cfg<G, CC, U>;
+  constexpr int NT = C::NT, BFW = C::BFW, TPD = C::TPD;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += gridDim.x * blockDim.x) xch[i] = 0u;
+  const int64_t total = (int64_t)D * CC * 4 * NT * BFW * 64;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63), f = (int)((i >> 6) % BFW), tile = (int)((i / (64 * BFW)) % NT);
+    const int wave = (int)((i / (64 * BFW * NT)) & 3), c = (int)((i / (64 * BFW * NT * 4)) % CC);
+    const int d = (int)(i / ((int64_t)64 * BFW * NT * 4 * CC));
+    const int col = lane & 15, kg = lane >> 4, kb = f >> 1, plane = f & 1;
+    const int j = U * (wave + 4 * (tile / TPD)) + 16 * (tile % TPD) + col;
+    const int gate = U == 32 ? kb : 2 * kb + (kg >> 1);
+    const int u0 = U == 32 ? U * c + 8 * kg : U * c + 8 * (kg & 1);
+    const float* src = (d ? w1 : w0) + ((int64_t)gate * H + u0) * H + j;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bf16_t hi, lo;
+      split_bf16(gate < G && j < H && u0 + e < H ? src[(int64_t)e * H] : 0.f, hi, lo);
+      v[e] = __builtin_bit_cast(__bf16, plane ? lo : hi);
+    }
+    out[i] = v;
+  }
+}
+
+// out_b != NULL (a training layer of lr_rnn.hip, round 5): the BACKWARD pass's fragments of the same W_hh and its first
+// launch's exchange words as well — the weights are the ones the backward differentiates through, and the backward loses
+// a ~5 us launch from its critical path
 template <int G, int CC, int U>
 __global__ void rnnc_pack_fwd_kernel(const float* __restrict__ w0, const float* __restrict__ w1, bf16x8* __restrict__ out,
-                                     int D, int H, u32* __restrict__ xch, int nzero, FoldPtrs fold) {
+                                     int D, int H, u32* __restrict__ xch, int nzero, FoldPtrs fold,
+                                     bf16x8* __restrict__ out_b, u32* __restrict__ xch_b, int nzero_b) {
   using C = Cfg<G, CC, U>;
   constexpr int CF = C::CF, NTILE = C::NTILE, UW = C::UW, GPT = C::GPT, KS = C::KS;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += gridDim.x * blockDim.x) xch[i] = 0u;
@@ -260,37 +295,13 @@ __global__ void rnnc_pack_fwd_kernel(const float* __restrict__ w0, const float* 
     }
     out[i] = v;
   }
+  if (out_b) pack_bwd_body<G, CC, U>(w0, w1, out_b, D, H, xch_b, nzero_b);
 }
 
-// backward: out[((((d*CC + c)*4 + wave)*NT + tile)*BFW + f)*64 + lane] = plane f & 1 of W_hh[gate * H + unit + e][j],
-// e = 0..7: entry 8 kg + e of k step f >> 1 of the member's own dG — U = 32: gate = the k step, unit = 32 c + 8 kg;
-// U = 16: gate = 2 (k step) + (kg >> 1), unit = 16 c + 8 (kg & 1) — and j = U (wave + 4 (tile / TPD)) + 16 (tile % TPD) + col
-// (the units of destination member wave + 4 (tile / TPD)); zero where gate >= G, unit + e >= H or j >= H.
 template <int G, int CC, int U>
 __global__ void rnnc_pack_bwd_kernel(const float* __restrict__ w0, const float* __restrict__ w1, bf16x8* __restrict__ out,
                                      int D, int H, u32* __restrict__ xch, int nzero) {
-  using C = Cfg<G, CC, U>;
-  constexpr int NT = C::NT, BFW = C::BFW, TPD = C::TPD;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nzero; i += gridDim.x * blockDim.x) xch[i] = 0u;
-  const int64_t total = (int64_t)D * CC * 4 * NT * BFW * 64;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int lane = (int)(i & 63), f = (int)((i >> 6) % BFW), tile = (int)((i / (64 * BFW)) % NT);
-    const int wave = (int)((i / (64 * BFW * NT)) & 3), c = (int)((i / (64 * BFW * NT * 4)) % CC);
-    const int d = (int)(i / ((int64_t)64 * BFW * NT * 4 * CC));
-    const int col = lane & 15, kg = lane >> 4, kb = f >> 1, plane = f & 1;
-    const int j = U * (wave + 4 * (tile / TPD)) + 16 * (tile % TPD) + col;
-    const int gate = U == 32 ? kb : 2 * kb + (kg >> 1);
-    const int u0 = U == 32 ? U * c + 8 * kg : U * c + 8 * (kg & 1);
-    const float* src = (d ? w1 : w0) + ((int64_t)gate * H + u0) * H + j;
-    bf16x8 v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      bf16_t hi, lo;
-      split_bf16(gate < G && j < H && u0 + e < H ? src[(int64_t)e * H] : 0.f, hi, lo);
-      v[e] = __builtin_bit_cast(__bf16, plane ? lo : hi);
-    }
-    out[i] = v;
-  }
+  pack_bwd_body<G, CC, U>(w0, w1, out, D, H, xch, nzero);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -948,7 +959,7 @@ inline int first_xch_words(int CC, int U, int maxcl, int B, int D, int backward)
 // NULL: nothing to fold)
 template <int G, int CC, int U>
 int fwd_prologue(const float* const* w_hh, const float* const* b_ih, const float* const* b_hh, float* bias_out, void* wpack,
-                 void* xch, int B, int D, int H, hipStream_t stream) {
+                 void* xch, int B, int D, int H, hipStream_t stream, void* wpack_b = nullptr, void* xch_b = nullptr) {
   FoldPtrs fold;
   for (int d = 0; d < 2; ++d) {
     fold.b_ih[d] = b_ih ? b_ih[d < D ? d : 0] : nullptr;
@@ -956,7 +967,8 @@ int fwd_prologue(const float* const* w_hh, const float* const* b_ih, const float
   }
   fold.out = b_ih ? bias_out : nullptr;
   LR_LAUNCH((rnnc_pack_fwd_kernel<G, CC, U>), dim3(1024), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D, H,
-            (u32*)xch, first_xch_words(CC, U, Cfg<G, CC, U>::MAXCL, B, D, 0), fold);
+            (u32*)xch, first_xch_words(CC, U, Cfg<G, CC, U>::MAXCL, B, D, 0), fold, (bf16x8*)wpack_b, (u32*)xch_b,
+            wpack_b ? first_xch_words(CC, U, Cfg<G, CC, U>::MAXCL, B, D, 1) : 0);
   return lr_launch_status();
 }
 
@@ -1005,7 +1017,7 @@ int fwd_launch(float* gates, float* extra, float* y, const float* const* w_hh, c
 template <int G, int CC, int U>
 int bwd_launch(const float* gates, const float* extra, const float* y, const float* dy, const float* dh_n, const float* dc_n,
                float* dG, float* dh0, float* dc0, const float* h0, const float* c0, const float* const* w_hh,
-               const int32_t* lens, void* wpack, void* xch, int B, int T, int D, int H, hipStream_t stream) {
+               const int32_t* lens, void* wpack, void* xch, int B, int T, int D, int H, hipStream_t stream, int pack_done) {
   using C = Cfg<G, CC, U>;
   static bool attr_set = false;
   lr_clear_error();
@@ -1015,10 +1027,13 @@ int bwd_launch(const float* gates, const float* extra, const float* y, const flo
       return LR_ERR_LAUNCH;
     attr_set = true;
   }
-  LR_LAUNCH((rnnc_pack_bwd_kernel<G, CC, U>), dim3(1024), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D, H,
-            (u32*)xch, first_xch_words(CC, U, C::MAXCL, B, D, 1));
-  int st = lr_launch_status();
-  if (st != LR_OK) return st;
+  int st = LR_OK;
+  if (!pack_done) {   // (else: the layer's forward prologue left the fragments and the cleared words in wpack / xch)
+    LR_LAUNCH((rnnc_pack_bwd_kernel<G, CC, U>), dim3(1024), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D,
+              H, (u32*)xch, first_xch_words(CC, U, C::MAXCL, B, D, 1));
+    st = lr_launch_status();
+    if (st != LR_OK) return st;
+  }
   int32_t* fault = lr_fault_words();
   const int drop = lr_debug_drop_member_value();
   const int tune = lr_debug_tune_value(1);
@@ -1148,12 +1163,14 @@ int lr_rnn_cluster_forward(int G, float* gates, float* extra, float* y, const fl
 }
 
 int lr_rnn_cluster_prologue(int G, const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
-                            float* bias_out, void* wpack, void* xch, int B, int D, int H, hipStream_t stream) {
+                            float* bias_out, void* wpack, void* xch, int B, int D, int H, hipStream_t stream,
+                            void* wpack_b, void* xch_b) {
   int cc, u;
   lr_clear_error();
   if (!resolve_shape(G, H, &cc, &u)) return LR_ERR_UNSUPPORTED;
 #define X(g, c, uu) \
-  if (G == g && cc == c && u == uu) return fwd_prologue<g, c, uu>(w_hh, b_ih, b_hh, bias_out, wpack, xch, B, D, H, stream);
+  if (G == g && cc == c && u == uu) \
+    return fwd_prologue<g, c, uu>(w_hh, b_ih, b_hh, bias_out, wpack, xch, B, D, H, stream, wpack_b, xch_b);
   LR_CLUSTER_SHAPES(X)
 #undef X
   return LR_ERR_UNSUPPORTED;
@@ -1162,13 +1179,13 @@ int lr_rnn_cluster_prologue(int G, const float* const* w_hh, const float* const*
 int lr_rnn_cluster_backward(int G, const float* gates, const float* extra, const float* y, const float* dy,
                             const float* dh_n, const float* dc_n, float* dG, float* dh0, float* dc0, const float* h0,
                             const float* c0, const float* const* w_hh, const int32_t* lens, void* wpack, void* xch, int B,
-                            int T, int D, int H, hipStream_t stream) {
+                            int T, int D, int H, hipStream_t stream, int pack_done) {
   int cc, u;
   if (!resolve_shape(G, H, &cc, &u)) return LR_ERR_UNSUPPORTED;
 #define X(g, c, uu)                                                                                                      \
   if (G == g && cc == c && u == uu)                                                                                      \
     return bwd_launch<g, c, uu>(gates, extra, y, dy, dh_n, dc_n, dG, dh0, dc0, h0, c0, w_hh, lens, wpack, xch, B, T, D, H, \
-                                stream);
+                                stream, pack_done);
   LR_CLUSTER_SHAPES(X)
 #undef X
   return LR_ERR_UNSUPPORTED;

