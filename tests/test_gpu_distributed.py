@@ -181,7 +181,10 @@ def test_second_backward_before_sync_is_loud_or_held(dev, pg):
       assert not any(sync._launched)
     assert sync(status) == 1.0
     torch.cuda.synchronize()
-    np.testing.assert_allclose(flat.grad.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=1e-7)
+    # (the weight gradients are split-bf16 products of dG — round 5, lr_rnn.hip — whose rounding is ~1e-5 of the
+    # PRODUCT's scale: two passes summed differ from one pass over the summed dG by that much of the largest elements)
+    w = want.cpu().numpy()
+    np.testing.assert_allclose(flat.grad.cpu().numpy(), w, rtol=2e-5, atol=3e-5 * float(np.abs(w).max()))
     # without hold(): loud
     flat.zero_grad()
     a, b, status = losses()
