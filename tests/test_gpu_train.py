@@ -609,7 +609,7 @@ def test_early_sum_of_squares_gives_the_same_clipped_step(dev, encoder_kind, gra
   assert all(n > 0.05 for n in out[False][1])                       # the clip was active in every step
   # the first step's norm is the same sum in another order; later steps start from weights that differ by that rounding
   np.testing.assert_allclose(out[True][1][0], out[False][1][0], rtol=2e-6)
-  np.testing.assert_allclose(out[True][1], out[False][1], rtol=1e-3)
+  np.testing.assert_allclose(out[True][1], out[False][1], rtol=5e-3)   # (five clipped Adam steps amplify that rounding)
   # (not even the same run twice gives the same bits: the sum of squares adds its workgroups' shares with float atomics)
   # Weights: Adam divides by sqrt(v), so an element whose gradient is ~1e-9 (a conv tap that only sees border pixels)
   # moves by ~lr per step in a direction the LAST BIT of the previous step decides; a fraction of a percent of the
