@@ -734,6 +734,10 @@ int lr_conv3d_wgrad(const void* X, const void* dZ, float* dW, float* dbias, void
  * and may be NULL; dbias = column sums of dP over the windows ReLU did not block.  Workspace as for lr_conv3d_wgrad. */
 int lr_conv3d_wgrad_pooled_supported(int Hin, int Win, int Cin_pad, int Cin_real, int Cout, int KT, int KH,
                                      int KW, int stride, int pt, int ph, int pw);
+/* The same answer for a given frame count B * T: 0 where lr_conv3d_wgrad_pooled would return LR_ERR_UNSUPPORTED for it
+ * (the stride-1 layers' kernel keeps a tile table in LDS that has to fit). */
+int lr_conv3d_wgrad_pooled_supported_frames(int frames, int Hin, int Win, int Cin_pad, int Cin_real, int Cout, int KT,
+                                            int KH, int KW, int stride, int pt, int ph, int pw);
 int lr_conv3d_wgrad_pooled(const void* X, const void* pooled, const void* code, const void* dP, float* dW,
                            float* dbias, void* workspace, size_t workspace_bytes, int accumulate, int B, int T,
                            int Hin, int Win, int Cin_pad, int Cin_real, int Cout, int KT, int KH, int KW,

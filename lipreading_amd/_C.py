@@ -119,6 +119,7 @@ SIGNATURES = {
     "lr_conv3d_wgrad_workspace_bytes": (c_size_t, [c_int] * 5),
     "lr_conv3d_wgrad": (c_int, [P, P, P, P, P, c_size_t] + [c_int] * 15 + [P]),
     "lr_conv3d_wgrad_pooled_supported": (c_int, [c_int] * 12),
+    "lr_conv3d_wgrad_pooled_supported_frames": (c_int, [c_int] * 13),
     "lr_conv3d_wgrad_pooled": (c_int, [P, P, P, P, P, P, P, c_size_t] + [c_int] * 16 + [P]),
     "lr_maxpool_hw2_bf16": (c_int, [P, P, c_int64, c_int, c_int, c_int, P]),
     "lr_unpool_workspace_bytes": (c_size_t, [c_int]),

@@ -1346,6 +1346,16 @@ extern "C" int lr_conv3d_wgrad_pooled_supported(int Hin, int Win, int Cin_pad, i
   return wgrad_tr2_layer(1, Hin, Win, Cin_pad, Cin_real, Cout, KT, KH, KW, stride, pt, ph, pw) && Hin % 2 == 0 ? 2 : 0;
 }
 
+// ... with the frame count: 0 where lr_conv3d_wgrad_pooled would answer LR_ERR_UNSUPPORTED for B * T = frames (the
+// transpose-read kernel's tile table has to fit its LDS), so that a caller can choose its path — and allocate the
+// un-pooled gradient of the other one — before it enqueues anything
+extern "C" int lr_conv3d_wgrad_pooled_supported_frames(int frames, int Hin, int Win, int Cin_pad, int Cin_real, int Cout,
+                                                      int KT, int KH, int KW, int stride, int pt, int ph, int pw) {
+  const int kind = lr_conv3d_wgrad_pooled_supported(Hin, Win, Cin_pad, Cin_real, Cout, KT, KH, KW, stride, pt, ph, pw);
+  if (kind == 2 && !wgrad_tr2_layer(frames, Hin, Win, Cin_pad, Cin_real, Cout, KT, KH, KW, stride, pt, ph, pw)) return 0;
+  return frames > 0 ? kind : 0;
+}
+
 extern "C" int lr_conv3d_wgrad_pooled(const void* X, const void* pooled, const void* code, const void* dP, float* dW,
                                       float* dbias, void* workspace, size_t workspace_bytes, int accumulate, int B,
                                       int T, int Hin, int Win, int Cin_pad, int Cin_real, int Cout, int KT, int KH,

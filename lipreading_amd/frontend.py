@@ -233,19 +233,24 @@ class _ConvFrontendFunction(torch.autograd.Function):
         _C.check(L.lr_conv3d_dgrad_pooled(dP_in.data_ptr(), act.data_ptr(), wd.data_ptr(), dP.data_ptr(), B, T, ho, wo,
                                           cout, cin, kt, kh, kw, pt, ph, pw, st), "lr_conv3d_dgrad_pooled")
 
+      # (decided — and the other path's full-resolution dZ allocated — HERE, on the stream this backward runs on: the
+      # weight half may be enqueued on the side stream, whose allocator pool a per-step dZ should not come from)
+      pooled_wgrad = bool(coded and _FUSE_UNPOOL_WGRAD and L.lr_conv3d_wgrad_pooled_supported_frames(
+          frames, h, w, cin_p, cin, cout, kt, kh, kw, stride, pt, ph, pw) == 2)
+      dZ_fallback = (torch.empty((frames, ho, wo, cout), dtype=bf, device=dev)
+                     if fused_dgrad and not pooled_wgrad else None)
+
       def weight_half(accumulate, stream):
         # dW and the bias gradient straight from the pooled gradient and the codes where the layer has the kernel
         # (no dZ at all then) ...
-        if coded and _FUSE_UNPOOL_WGRAD and L.lr_conv3d_wgrad_pooled_supported(h, w, cin_p, cin, cout, kt, kh, kw, stride,
-                                                                              pt, ph, pw) == 2:
-          rc = L.lr_conv3d_wgrad_pooled(x_in.data_ptr(), pooled.data_ptr(), act.data_ptr(), dP_in.data_ptr(),
-                                        grads[2 * li].data_ptr(), grads[2 * li + 1].data_ptr(), ws.data_ptr(), wbytes,
-                                        accumulate, B, T, h, w, cin_p, cin, cout, kt, kh, kw, stride, pt, ph, pw, 0, stream)
-          if rc != _C.LR_ERR_UNSUPPORTED:   # (a frame count whose tile table does not fit the kernel's LDS)
-            _C.check(rc, "lr_conv3d_wgrad_pooled")
-            return None
+        if pooled_wgrad:
+          _C.check(L.lr_conv3d_wgrad_pooled(x_in.data_ptr(), pooled.data_ptr(), act.data_ptr(), dP_in.data_ptr(),
+                                            grads[2 * li].data_ptr(), grads[2 * li + 1].data_ptr(), ws.data_ptr(),
+                                            wbytes, accumulate, B, T, h, w, cin_p, cin, cout, kt, kh, kw, stride, pt, ph,
+                                            pw, 0, stream), "lr_conv3d_wgrad_pooled")
+          return None
         # ... else un-pool (the bias gradient — the sum of the routed gradients — falls out of that pass), then dW
-        dZ = torch.empty((frames, ho, wo, cout), dtype=bf, device=dev)
+        dZ = dZ_fallback
         if coded:
           _C.check(L.lr_unpool_code_bf16(pooled.data_ptr(), act.data_ptr(), dP_in.data_ptr(), dZ.data_ptr(),
                                          grads[2 * li + 1].data_ptr(), accumulate, ws.data_ptr(), wbytes,
