@@ -603,18 +603,22 @@ def test_early_sum_of_squares_gives_the_same_clipped_step(dev, encoder_kind, gra
                                  max_len=Tn, graphs=graphs)
       norms.append(float(opt.total_norm()))
       assert int(status) == 0
+      if len(norms) == 1:
+        first = opt.flat.data.detach().cpu().numpy().copy()
     if graph:
       assert graphs.replays >= 1
-    out[early] = (opt.flat.data.detach().cpu().numpy().copy(), norms)
+    out[early] = (opt.flat.data.detach().cpu().numpy().copy(), norms, first)
   assert all(n > 0.05 for n in out[False][1])                       # the clip was active in every step
   # the first step's norm is the same sum in another order; later steps start from weights that differ by that rounding
   np.testing.assert_allclose(out[True][1][0], out[False][1][0], rtol=2e-6)
   np.testing.assert_allclose(out[True][1], out[False][1], rtol=5e-3)   # (five clipped Adam steps amplify that rounding)
   # (not even the same run twice gives the same bits: the sum of squares adds its workgroups' shares with float atomics)
-  # Weights: Adam divides by sqrt(v), so an element whose gradient is ~1e-9 (a conv tap that only sees border pixels)
-  # moves by ~lr per step in a direction the LAST BIT of the previous step decides; a fraction of a percent of the
-  # elements may differ by up to lr * steps, everything else agrees
+  # Weights after the FIRST clipped step: the same gradients scaled by coefficients that differ by that rounding
+  np.testing.assert_allclose(out[True][2], out[False][2], rtol=1e-4, atol=1e-6)
+  # ... and after the last one: Adam divides by sqrt(v), so an element whose gradient is ~1e-9 (a conv tap that only
+  # sees border pixels) moves by ~lr per step in a direction the LAST BIT of the previous step decides, and five steps
+  # amplify it; a few percent of the elements may differ, none by more than lr * steps
   steps, lr = len(out[False][1]), 1e-3
   a, b = out[True][0], out[False][0]
   off = ~np.isclose(a, b, rtol=1e-3, atol=1e-5)
-  assert off.mean() < 5e-3 and float(np.abs(a - b).max()) <= lr * steps
+  assert off.mean() < 5e-2 and float(np.abs(a - b).max()) <= lr * steps
