@@ -7,7 +7,7 @@ OUT=gpurun_out
 mkdir -p $OUT
 timeout 300 python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' > $OUT/${TAG}_smoke.log 2>&1
 echo "smoke exit $?"; tail -2 $OUT/${TAG}_smoke.log
-timeout 1500 python -m pytest tests -m gpu -x -q --durations=10 > $OUT/${TAG}_pytest_gpu.log 2>&1
+timeout 1800 python -m pytest tests -m gpu -q --durations=10 > $OUT/${TAG}_pytest_gpu.log 2>&1
 echo "pytest exit $?"; grep -E "passed|failed|FAILED|Error" $OUT/${TAG}_pytest_gpu.log | tail -5
 bash tools/refresh_profiles.sh $TAG > $OUT/${TAG}_refresh.log 2>&1
 echo "refresh exit $?"

@@ -3,7 +3,7 @@
 #   gpurun --timeout 600 -- 'bash tools/gpu_timeline.sh r04a conv1_fwd --regime pixels'
 # The step shown is one of the TIMED region's: with --steps 8 the trace ends with bench.py's roofline leg (5 eager steps
 # in the pixel regimes, 8 elsewhere), the timed steps sit right in front of it (TL_STEP: index from the end, default
-# -9 = inside the timed region of a pixel regime; landmarks: TL_STEP=-12).  (Rounds 2-4 showed step 8 from the start —
+# -9 = inside the timed region of a pixel regime; landmarks: TL_STEP=8, from the start — their trace ends with the recurrence = f32 option run).  (Rounds 2-4 showed step 8 from the start —
 # a step of the untimed eager-versus-replay probe, whose replays still copy the inputs into the graph's buffers: the
 # "staging copies" and the idle gap in front of them in those timelines are not part of the timed step.)
 set -u
