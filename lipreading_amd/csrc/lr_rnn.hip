@@ -1005,12 +1005,15 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
     st = lr_xproj_dwhh(dG, ldg, y, D * H, R, T, H, G, D, dw_hh, wbeta, xws, xws_bytes, stream, proj_x1(mode) ? 1 : 0);
     if (st != LR_OK) return st;
   }
-  if (wx && G != 3) {
+  // (round 5: the lr_fgemm weight half below serves the large layers too; test hook bit 3 keeps them on lr_xgemm's
+  // packed contractions, for the A/B)
+  const bool wx_packed = wx && lr_debug_dwih_packed();
+  if (wx_packed && G != 3) {
     // fp32-faithful on the bf16 matrix cores, like the recurrence that produced dG (lr_xgemm.hip); both products
     // read the same dG slots: ONE pack of dG
     st = lr_xproj_dw_both(dG, ldg, 4 * H, x, y, D * H, R, T, I, H, GH, D, dw_ih, dw_hh, wbeta, xws, xws_bytes, stream);
     if (st != LR_OK) return st;
-  } else if (wx) {
+  } else if (wx_packed) {
     // (GRU: the recurrent side reads slot 3 where the input side reads slot 2)
     st = lr_xproj_dw(dG, ldg, 4 * H, x, R, I, GH, D, dw_ih, wbeta, 0, 0, xws, xws_bytes, stream);
     if (st != LR_OK) return st;
@@ -1025,7 +1028,7 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
   }
   bias_job.ld = ldg; bias_job.rows = R; bias_job.H = H; bias_job.D = D; bias_job.G = G; bias_job.accumulate = accumulate;
   bool bias_done = false;
-  if (!x3 && !wx && recur_split(mode) && !lr_debug_wgrad_f32()) {
+  if (!x3 && !wx_packed && recur_split(mode) && !lr_debug_wgrad_f32()) {
     // Regime R on the one-launch recurrence (round 5): the weight half as split-bf16 products straight from dG, x and y
     // (lr_fgemm.hip, TN form, K cut into `sp` ranges; ~1e-5 relative, the recurrence that produced dG is itself a
     // split-bf16 product) with the bias gradients as the products' column sums — one launch + one combine in place of
@@ -1063,7 +1066,7 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
     st = lr_fgemm_launch(LR_FGEMM_X3, LR_FGEMM_TN, 0, 0, jobs, n, stream);
     if (st != LR_OK) return st;
     bias_done = true;
-  } else if (!x3 && !wx) {
+  } else if (!x3 && !wx_packed) {
     // every weight gradient of the layer in ONE grouped launch + one combine (lr_gemm.hip): each of these
     // small-M*N, K = B*T products fills a sixth of the chip on its own.
     //   dW_ih[d] (G*H x I) = dGx^T (slots 0..G-1 are contiguous rows) @ x
