@@ -659,13 +659,12 @@ size_t x3_ws_floats(int G, int B, int T, int I, int H, int D) {
   if (b2 > b) b = b2;
   return (b / sizeof(float) + 63) / 64 * 64;
 }
-// The weight gradients of a layer whose recurrence runs fp32-FAITHFUL on the bf16 matrix cores (LR_RNN_RECUR_SPLIT)
-// take the same route: dW_ih and dW_hh as split-bf16 products (bf16 hi + lo operand planes, three cross terms, fp32
-// accumulation: ~1e-5 of the fp32 product, lr_xgemm.hip) instead of the fp32-MFMA grouped GEMM — at LSTM-768 that
-// GEMM was 325 us of a 1.22 ms step at 56 % of the fp32 matrix peak.  Small layers stay on the grouped fp32 GEMM
-// (one launch + one combine beats two packs + two contractions + two combines).
+// Rounds 3-4: the weight gradients of a LARGE layer whose recurrence runs fp32-faithful on the bf16 matrix cores
+// (LR_RNN_RECUR_SPLIT, G * H >= 1536) as packed split-bf16 products (lr_xgemm.hip: one pack of dG, two contractions, a
+// combine) instead of the fp32-MFMA grouped GEMM (LSTM-768: 1.218 -> 1.155 ms per step then).  Round 5: EVERY such layer,
+// large or small, takes the one-launch lr_fgemm weight half (rnn_layer_backward_impl; BiLSTM-768 1.01 -> 0.87 ms); this
+// predicate now only sizes the workspace of the packed path, which test hook bit 3 still selects for the A/B.
 bool wgrad_split(int mode, int G, int H) {
-  // (measured, B = 32, T = 75: LSTM-768 1.218 -> 1.155 ms per step; GRU-256 0.479 -> 0.484: too small to pay)
   return recur_split(mode) && !proj_x3(mode) && G * H >= 1536 && !lr_debug_wgrad_f32();
 }
 
@@ -1029,7 +1028,8 @@ static int rnn_layer_backward_impl(int mode, const float* x, const int32_t* lens
   bias_job.ld = ldg; bias_job.rows = R; bias_job.H = H; bias_job.D = D; bias_job.G = G; bias_job.accumulate = accumulate;
   bool bias_done = false;
   if (!x3 && !wx_packed && recur_split(mode) && !lr_debug_wgrad_f32()) {
-    // Regime R on the one-launch recurrence (round 5): the weight half as split-bf16 products straight from dG, x and y
+    // A layer on the one-launch recurrence, exact-fp32 projection (regime R; round 5): the weight half as split-bf16
+    // products straight from dG, x and y
     // (lr_fgemm.hip, TN form, K cut into `sp` ranges; ~1e-5 relative, the recurrence that produced dG is itself a
     // split-bf16 product) with the bias gradients as the products' column sums — one launch + one combine in place of
     // the exact-fp32 grouped GEMM (64 us at BiGRU-256, B = 32: the fp32 matrix cores' rate), its combine and two
