@@ -263,8 +263,11 @@ def run(**flags):
     # (single process, one backward per step: the sequence encoder's share of the clip's sum of squares is taken beside
     # the conv backward, optim.FusedAdam.sum_squares_early)
     opt[0].sum_squares_early(encoder.encoder)
-  # the step of every batch shape (B, Tmax, Lmax) is captured once as a hipGraph and replayed
-  graphs = T.StepGraphs(enabled=bool(f["step_graphs"]))
+  # the step of every batch shape (B, Tmax, Lmax) is captured once as a hipGraph and replayed — in the landmark
+  # regimes, whose steps are launch-bound (0.4-2 ms of 14-100 short launches).  The pixel regimes' steps are GPU-bound
+  # (~45 launches, 2.3 ms) and replay no faster than eager launches (2.55 against 2.47 ms at the bench shape, bench.py's
+  # launch_probe; with six hardware queues the replay is 3.4 ms, lipreading_amd/__init__.py): eager there.
+  graphs = T.StepGraphs(enabled=bool(f["step_graphs"]) and not pixels)
 
   print("Initial evaluation...")
   val_cer = error_of(val_loader)
