@@ -180,3 +180,26 @@ def test_batch_loader_is_lazy_and_counts_batches():
   assert len(loader) == 3 and calls == []            # nothing is collated until iteration
   assert list(loader) == [4, 4, 2] and calls == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]
   assert list(loader) == [4, 4, 2] and len(calls) == 6      # each epoch collates afresh
+
+
+def test_six_hardware_queues_are_set_for_ranks_only():
+  """lipreading_amd/__init__.py: GPU_MAX_HW_QUEUES=6 in a process launched as one of several ranks (or as bench.py's
+  one-rank stand-in), HIP's default otherwise (a single process's hipGraph-replayed pixel step takes 3.4 ms with six
+  queues, 2.5 with four: profiles/r05_variants_ab.txt); a value the user set is never overwritten."""
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+  def queues(**env):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "GPU_MAX_HW_QUEUES", "LIPREADING_BENCH_FORCE_DIST")}
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", "import os, lipreading_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))"],
+                         capture_output=True, text=True, env=e, cwd=root, timeout=300)
+    assert out.returncode == 0, out.stderr[-1000:]
+    return out.stdout.strip().splitlines()[-1]
+  assert queues() == "None"
+  assert queues(WORLD_SIZE="1") == "None"
+  assert queues(WORLD_SIZE="8") == "6"
+  assert queues(LIPREADING_BENCH_FORCE_DIST="1") == "6"
+  assert queues(WORLD_SIZE="8", GPU_MAX_HW_QUEUES="4") == "4"
