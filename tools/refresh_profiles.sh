@@ -11,7 +11,9 @@
 #   <round>_{pixels,gru256,lstm768}_pmc_SQ_pass1.txt, <round>_pixels_pmc_SQ_pass2.txt   matrix-pipe / LDS counters of the
 #                                                                       conv, recurrence and GEMM kernels
 #   <round>_pixels_pmc_SQ_pass3.txt   the conv kernels' wave cycles by state (parked / issue-stalled / issuing per pipe)
-#   <round>_{pixels,gru256}_step_timeline.txt   every dispatch of one replayed step with start offset and queue
+#   <round>_{pixels,pixels_tfm,gru256,lstm768}_step_timeline.txt   every dispatch of one step of the TIMED region with start
+#                                                                       offset and queue
+#   <round>_bench_ecd_lstm768_b{32,128}.json, <round>_ecd_lstm768_b32_kernel_stats.txt   the reference's ecd flag-file family
 # PMC passes never share a run with trace domains other than the kernel trace rocprofv3 adds itself.
 set -u
 R=$PWD
