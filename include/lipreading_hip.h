@@ -11,7 +11,14 @@
  *   - every pointer is a DEVICE pointer unless the name ends in _host;
  *   - every function only ENQUEUES work on `stream` (a hipStream_t passed as void*); it never
  *     allocates, frees, synchronises or copies to the host, so a whole training step can be
- *     captured in one hipGraph;
+ *     captured in one hipGraph.  TWO exceptions, both outside any captured region:
+ *       (1) the per-device fault words (16 bytes: {recurrence timed out, 3 spare}) are
+ *           hipMalloc'ed + hipMemset the FIRST time any entry point needs them on a device;
+ *           call lr_fault_words_ptr() once per device before capturing (lipreading_amd.train's
+ *           StepGraphs does: its first steps of a shape run eagerly) — afterwards nothing
+ *           allocates again for the life of the process;
+ *       (2) the host-side readers lr_rnn_pair_errors / lr_profile_read
+ *           synchronise the device and copy a few words back: diagnostics, never on a step;
  *   - scratch comes from the caller: ask `*_workspace_bytes`, pass the buffer back in;
  *   - return value: LR_OK (0) or a negative lr_status; no C++ exception crosses the boundary;
  *   - all floating point is IEEE fp32 (subnormals kept), all indices int32 unless noted.

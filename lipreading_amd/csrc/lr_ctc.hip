@@ -549,9 +549,13 @@ struct CtcTail {
   float* grad_weight;
   const int32_t* fault;
 };
-// workgroups of the current alpha/beta launch that have stored their sample's nll; the last one resets it.  One word for
-// the process: launches of lr_ctc_nll_reduce must not overlap in time (launches on one stream never do; a caller with two
-// losses in flight on two streams uses lr_ctc_nll + lr_ctc_reduce).
+// workgroups of the current alpha/beta launch that have stored their sample's nll; the last one resets it.  The word
+// is the THIRD of the device's fault words (lr_common.h lr_fault_words: {pending, total, ctc ticket, spare}), which
+// lr_step_begin / lr_step_begin_ctc put back to 0 at the top of every step: a launch that was torn down half-way
+// cannot leave a count behind that no later launch would ever complete (round 5 kept it in a __device__ global that
+// nothing reset).  One word per device: launches of lr_ctc_nll_reduce must not overlap in time (launches on one
+// stream never do; a caller with two losses in flight on two streams uses lr_ctc_nll + lr_ctc_reduce).
+// g_ctc_ticket: only where the fault words could not be allocated.
 __device__ unsigned g_ctc_ticket = 0u;
 
 // One workgroup per sample as above; with a rider (round 5) the LAST workgroup to finish runs the reference's batch
@@ -573,8 +577,9 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_wave_kernel(const float* _
   __syncthreads();                      // (every exit of the body is workgroup-uniform; thread 0 stored nll[b])
   if (threadIdx.x == 0) {
     __threadfence();
-    const bool last = atomicAdd(&g_ctc_ticket, 1u) == gridDim.x - 1;
-    if (last) atomicExch(&g_ctc_ticket, 0u);
+    unsigned* ticket = tail.fault ? reinterpret_cast<unsigned*>(const_cast<int32_t*>(tail.fault) + 2) : &g_ctc_ticket;
+    const bool last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    if (last) atomicExch(ticket, 0u);
     s_last = last ? 1 : 0;
   }
   __syncthreads();

@@ -220,7 +220,7 @@ __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __re
 //   st[0] = active (0/1), st[1] = lr / (1 - beta1^t), st[2] = 1 / sqrt(1 - beta2^t),
 //   st[3] = gradient scale (grad_scale x clip coefficient)
 __device__ __forceinline__ void adam_prepare_body(int32_t* __restrict__ step_count, int32_t* __restrict__ skip,
-                                                  const int32_t* __restrict__ fault, bool has_sumsq, float sumsq_value,
+                                                  int32_t* __restrict__ fault, bool has_sumsq, float sumsq_value,
                                                   float max_norm, float grad_scale, float lr, float beta1, float beta2,
                                                   float* __restrict__ st, const float* __restrict__ dist_words,
                                                   float world) {
@@ -229,11 +229,19 @@ __device__ __forceinline__ void adam_prepare_body(int32_t* __restrict__ step_cou
   // dist_words (data parallel): {number of ranks whose batch was skipped, number of ranks whose recurrence timed out},
   // summed over the ranks by the gradient all-reduce itself (lr_fault_export_f32): the batch counts as skipped only if
   // EVERY rank skipped it, and nobody updates if ANY rank's gradient is garbage — it is in everybody's sum.
+  // With dist_words the verdict comes from the SUMMED words ALONE — every rank reads the same two numbers, so the ranks
+  // cannot disagree about whether this update happens (round 5 also OR-ed the local fault word read here, at Adam time:
+  // a recurrence that timed out after the words had left would then have skipped the update on ONE rank and let the
+  // weights drift apart).  lipreading_amd.distributed guarantees the words are exported behind the step's last
+  // recurrence — it falls back to the exchange after backward when their bucket was not the last to leave.  The
+  // verdict is written back into the local words, so that every rank's status / fault word (the per-epoch loss, the
+  // `keep` masks of eval) says the same as the ranks' sum.
   bool skipped = skip && skip[0] != 0, faulted = fault && fault[0] != 0;
   if (dist_words) {
     skipped = dist_words[0] > world - 0.5f;
-    faulted = faulted || dist_words[1] > 0.5f;
+    faulted = dist_words[1] > 0.5f;
     if (skip) skip[0] = skipped ? 1 : 0;     // the caller's status becomes the ranks' verdict (rounds 1-4: a MIN all-reduce)
+    if (fault && faulted) fault[0] |= 1;     // ... and so does the fault word of a rank whose own recurrence was fine
   }
   const bool active = !skipped && !faulted;
   int t = step_count[0];
@@ -255,7 +263,7 @@ __device__ __forceinline__ void adam_prepare_body(int32_t* __restrict__ step_cou
   st[3] = scale;
 }
 __global__ void adam_prepare_kernel(int32_t* __restrict__ step_count, int32_t* __restrict__ skip,
-                                    const int32_t* __restrict__ fault, const float* __restrict__ sumsq, float max_norm,
+                                    int32_t* __restrict__ fault, const float* __restrict__ sumsq, float max_norm,
                                     float grad_scale, float lr, float beta1, float beta2, float* __restrict__ st,
                                     const float* __restrict__ dist_words, float world) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -270,7 +278,7 @@ __global__ void adam_prepare_kernel(int32_t* __restrict__ step_count, int32_t* _
 // half-way cannot leave a ticket behind that no later launch would ever complete.
 __global__ void sumsq_prepare_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out,
                                      int32_t* __restrict__ step_count, int32_t* __restrict__ skip,
-                                     const int32_t* __restrict__ fault, float max_norm, float grad_scale, float lr,
+                                     int32_t* __restrict__ fault, float max_norm, float grad_scale, float lr,
                                      float beta1, float beta2, float* __restrict__ st,
                                      const float* __restrict__ dist_words, float world) {
   float acc = 0.f;
@@ -618,6 +626,7 @@ __global__ void step_begin_kernel(float4* __restrict__ g, int64_t n4, float* __r
   if (i0 == 0 && fault) {
     fault[1] += fault[0];
     fault[0] = 0;
+    fault[2] = 0;   // lr_ctc.hip's completion count of the alpha/beta launch (a torn-down launch must not poison the next step)
   }
   if (i0 == 0 && also_zero) also_zero[0] = also_zero[1] = 0.f;   // (sum-of-squares accumulator, its ticket)
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -649,6 +658,7 @@ __global__ void step_begin_ctc_kernel(float4* __restrict__ g, int64_t n4, float*
   if (i0 == 0 && fault) {
     fault[1] += fault[0];
     fault[0] = 0;
+    fault[2] = 0;   // lr_ctc.hip's completion count of the alpha/beta launch (a torn-down launch must not poison the next step)
   }
   if (i0 == 0 && also_zero) also_zero[0] = also_zero[1] = 0.f;   // (sum-of-squares accumulator, its ticket)
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -831,7 +841,7 @@ extern "C" int lr_adam_step(float* param, const float* grad, float* exp_avg, flo
                             int32_t* skip, float* scratch, const float* dist_words, float world,
                             lr_stream_t stream) {
   LR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_count && scratch && n >= 0);
-  LR_LAUNCH(adam_prepare_kernel, dim3(1), dim3(64), 0, stream, step_count, skip, (const int32_t*)lr_fault_words(),
+  LR_LAUNCH(adam_prepare_kernel, dim3(1), dim3(64), 0, stream, step_count, skip, lr_fault_words(),
             sumsq, max_norm, grad_scale, lr, beta1, beta2, scratch, dist_words, world);
   int st = lr_launch_status();
   if (st != LR_OK || n == 0) return st;
@@ -850,7 +860,7 @@ extern "C" int lr_clip_adam_step(float* param, const float* grad, float* exp_avg
   if (g > 256) g = 256;  // one atomic per workgroup
   // (n_sumsq < n: the rest of the buffer's sum of squares is in sumsq[0] already — lr_sumsq calls of this step)
   LR_LAUNCH(sumsq_prepare_kernel, dim3(g), dim3(256), 0, stream, grad, n_sumsq, sumsq, step_count, skip,
-            (const int32_t*)lr_fault_words(), max_norm, grad_scale, lr, beta1, beta2, scratch8, dist_words, world);
+            lr_fault_words(), max_norm, grad_scale, lr, beta1, beta2, scratch8, dist_words, world);
   int st = lr_launch_status();
   if (st != LR_OK) return st;
   LR_LAUNCH(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, n,

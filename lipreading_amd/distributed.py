@@ -61,6 +61,7 @@ class GradSync(object):
         if lo == flat.first:
           self._words_bucket = gi
           self.bounds[gi] = (0, hi)
+    self._order = []             # buckets in the order they went out this round
     self._status = None          # the step's status tensor, announced by set_status() before backward
     self._words_done = False     # the words of this round have been exported (with or without a status)
     self._words_have_status = False
@@ -154,6 +155,7 @@ class GradSync(object):
     n = len(self.flat.params)
     self._pending = [len(g) for g in self.groups]
     self._launched = [False] * len(self.groups)
+    self._order = []
     self._ready = [False] * n
     self._count = ([0] * n, [0] * n)
 
@@ -202,6 +204,7 @@ class GradSync(object):
     if self._launched[gi]:
       return
     self._launched[gi] = True
+    self._order.append(gi)
     lo, hi = self.bounds[gi]
     if gi == self._words_bucket and not self._words_done:
       self._export_words(status if status is not None else self._status)
@@ -220,10 +223,15 @@ class GradSync(object):
     the optimiser (train.ctc_step's grad_sync).  On the GPU the step's skip / fault facts travel as two floats in
     front of the gradients (see __init__): afterwards `self.dist_words` holds their sums for FusedAdam.step(dist_words=,
     world=) — the step is skipped only if every rank's batch was skipped (a rank whose own batch was skipped
-    contributed zero gradients), nobody updates if any rank's recurrence timed out — and `status` keeps THIS rank's
-    value.  Where the words could not travel (CPU tensors; the status unknown when their bucket left) `status`
+    contributed zero gradients), nobody updates if any rank's recurrence timed out.  `status` keeps THIS rank's value
+    until the optimiser step: lr_adam_step / lr_clip_adam_step then overwrite it (and OR the fault word) with the
+    ranks' verdict, so a caller that wants its own rank's code must read it before opt.step(); train.decoder_step's
+    second sync re-exports the verdict the encoder's optimiser step wrote, which is why the encoder steps first.
+    Where the words could not travel (CPU tensors; the status unknown when their bucket left) `status`
     becomes the MIN over ranks as in rounds 1-4 and dist_words is None."""
     st_in = status if status is not None else self._status
+    # did a bucket leave from a gradient-ready hook AFTER the one that carries the words?  (see `folded` below)
+    words_left_early = self._words_bucket in self._order and self._order[-1] != self._words_bucket
     if not any(self._launched) and self._contiguous and len(self.groups) > 1:
       # nothing has gone out yet (no-overlap mode — the step was a hipGraph replay, or ran under hold()): the
       # buckets tile one stretch of the flat buffer, so ONE all-reduce carries them all (a collective costs its
@@ -238,6 +246,12 @@ class GradSync(object):
     # the words travelled with the gradients unless there are none (CPU / gloo) or the bucket that carries them left
     # before anybody had announced the status (a caller that uses neither train.ctc_step nor set_status)
     folded = self._words_bucket is not None and self._words_done and (self._words_have_status or status is None)
+    # ... and unless another bucket left AFTER the words' bucket: the words are a snapshot taken when their bucket was
+    # exported, and a recurrence enqueued later (custom groups whose first-parameter bucket is not the last of backward)
+    # could still raise this rank's fault word — lr_clip_adam_step decides from the summed words alone, so such a
+    # time-out would go unseen.  The exchange after backward (below) reads the words as they are now.
+    if words_left_early:
+      folded = False
     word = None
     if not folded:
       word = status

@@ -55,6 +55,7 @@ def _notify(weights):
 
 # Callables invoked (on the stream that produced them) when the LAST gradients of the encoder have been enqueued: the
 # weight half of the layer that reads the model's input features (optim.FusedAdam.sum_squares_early registers here).
+# Argument: one parameter tensor of that layer, so that a hook can tell whose backward it is.
 encoder_grads_complete_hooks = []
 
 
@@ -190,7 +191,7 @@ class _RNNLayerFunction(torch.autograd.Function):
         weight_half()
         if mode & _INPUT_STORED_BF16:         # (the layer that reads the frontend's features: the encoder's last gradients)
           for hook in encoder_grads_complete_hooks:
-            hook()
+            hook(weights[0])   # (which encoder: a parameter of the layer that just finished)
       return (dx, None, None, None, None, None) + (None,) * len(weights)
     _C.check(L.lr_rnn_layer_backward(
         mode, x.data_ptr(), lens.data_ptr(), _ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(b_ih),

@@ -129,22 +129,35 @@ class FusedAdam(object):
     frontend's 1.3 MB (round 5: 23 -> 6 us at the end of the step).  Not under data parallelism (the clip is taken on the
     all-reduced gradient) and not with several backward passes per step (the early sum would see a partial gradient)."""
     from . import encoder as _enc
+    import torch.distributed as _dist
+    if _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1:
+      # the clip is taken on the ALL-REDUCED gradient; an early sum would see this rank's share only
+      raise RuntimeError("FusedAdam.sum_squares_early is a single-process option (torch.distributed world size > 1)")
     ids = {id(p) for p in module.parameters()}
     idx = [i for i, p in enumerate(self.flat.params) if id(p) in ids]
-    assert idx and idx == list(range(idx[0], len(self.flat.params))), "the module must own the tail of the flat buffer"
+    if not (idx and idx == list(range(idx[0], len(self.flat.params)))):
+      raise ValueError("sum_squares_early: the module must own the tail of the flat buffer")
+    if self.flat.offsets[idx[0]] <= self.flat.first:
+      # the module owns the WHOLE buffer: nothing would be left for the launch in front of Adam (a zero-sized grid)
+      raise ValueError("sum_squares_early: the module owns every parameter; there is no later share to overlap with")
     self._early_lo = self.flat.offsets[idx[0]]
+    early_ptrs = {p.data_ptr() for p in module.parameters()}
     self._early_done = False
     self._early_armed = False        # between this optimiser's zero_grad() and its step(): the backward in between is ours
     import weakref
     ref = weakref.ref(self)
 
-    def hook():
+    def hook(done=None):
+      # `done`: a parameter of the encoder whose gradients are complete (encoder.py passes it); another model's backward
+      # between this optimiser's zero_grad() and step() must not trigger the sum over THIS buffer
       me = ref()
       if me is None:
         if hook in _enc.encoder_grads_complete_hooks:
           _enc.encoder_grads_complete_hooks.remove(hook)
         return
       if not me._early_armed or me._early_done:
+        return
+      if done is not None and done.data_ptr() not in early_ptrs:
         return
       n = me.flat.numel - me._early_lo
       _C.check(_C.lib().lr_sumsq(me.flat.grad.data_ptr() + 4 * me._early_lo, n, me._sumsq.data_ptr(),

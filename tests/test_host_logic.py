@@ -1,4 +1,6 @@
 """CPU: host-side mirror of the reference interface (no GPU, no kernels)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -203,3 +205,63 @@ def test_six_hardware_queues_are_set_for_ranks_only():
   assert queues(WORLD_SIZE="8") == "6"
   assert queues(LIPREADING_BENCH_FORCE_DIST="1") == "6"
   assert queues(WORLD_SIZE="8", GPU_MAX_HW_QUEUES="4") == "4"
+
+
+REF_CONFIG = "/root/reference/config"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONFIG), reason="build container only: the reference tree is not on the GPU box")
+def test_every_reference_flag_file_parses_to_the_model_it_describes():
+  """Every non-empty flag file the reference ships for its trainers — config/defaults.txt, config/train/**,
+  config/archive/experiments/** — goes through driver.parse_flags unchanged (the reference reads them through
+  src/utils/cmd_line.py:91-141 into src/scripts/train.py:134-167's keyword arguments), and the model the flags imply
+  is the one this test reads out of the file with its own three-line tokenizer: encoder cell / width / directions,
+  CTC head or not, batch, attention, and the decoder width CharDecodingStep derives (better_model.py:134-148:
+  hidden = directions x encoder hidden).  config/gen_dataview/* drive the ETL, which is out of scope."""
+  from lipreading_amd import driver
+  files = []
+  for root, _, names in os.walk(REF_CONFIG):
+    if "gen_dataview" in root:
+      continue
+    files += [os.path.join(root, n) for n in names]
+  files = sorted(f for f in files if os.path.getsize(f) > 0)
+  assert len(files) >= 61                       # 52 archived experiments + defaults + 6 attention files + micro + nano
+  truthy = lambda v: v.lower() not in ("false", "0", "no")
+  shapes = {}
+  for path in files:
+    raw = {}
+    for tok in open(path).read().split():
+      if tok.startswith("--"):
+        name, eq, val = tok[2:].partition("=")
+        raw[name] = val if eq else "True"        # a bare flag is a boolean switch (cmd_line.py:110-118)
+    f = driver.parse_flags([path])
+    rel = os.path.relpath(path, REF_CONFIG)
+    archived_trainer = "hidden_layers" in raw or "batch" in raw      # archive/train_model.py's flag names
+    if "hidden_size" in raw:
+      assert f["hidden_size"] == int(raw["hidden_size"]), rel
+    if "rnn_type" in raw:
+      assert f["rnn_type"] == raw["rnn_type"].upper(), rel
+    layers = raw.get("num_layers", raw.get("hidden_layers"))
+    if layers is not None:
+      assert f["num_layers"] == int(layers), rel
+    batch = raw.get("batch_size", raw.get("batch"))
+    if batch is not None:
+      assert f["batch_size"] == int(batch), rel
+    if "attention_type" in raw:
+      assert f["attention_type"] == raw["attention_type"], rel
+    if "char_dim" in raw:
+      assert f["char_dim"] == int(raw["char_dim"]), rel
+    if archived_trainer:                         # CTC-only, bidirectional throughout (archive/train_model.py:186-205)
+      assert f["enable_ctc"] is True and f["ctc_only"] is True and f["bidirectional"] is True, rel
+    else:
+      for flag in ("enable_ctc", "bidirectional"):
+        if flag in raw:
+          assert f[flag] is truthy(raw[flag]), (rel, flag)
+    D = 2 if f["bidirectional"] else 1
+    shapes.setdefault((f["rnn_type"], f["hidden_size"], D, f["enable_ctc"], D * f["hidden_size"]), []).append(rel)
+  # the families the kernels are sized for (DESIGN section 4.1 / 9.3): the archived experiments are all BiLSTM-768 with an
+  # LSTM-1536 decoder, at batch 128
+  ecd = [k for k in shapes if k[:3] == ("LSTM", 768, 2)]
+  assert sum(len(shapes[k]) for k in ecd) == 52 and all(k[4] == 1536 for k in ecd)
+  assert ("LSTM", 700, 1, False, 700) in shapes and ("LSTM", 512, 2, True, 1024) in shapes
+  assert any(k[:2] == ("GRU", 800) for k in shapes)
