@@ -198,6 +198,11 @@ int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D);         
  * switched off by lr_rnn_one_launch_enable(0); 3 = switched off by the test hook lr_rnn_debug_disable_cluster; 4 = the
  * device has too few compute units for a launch's clusters.  (What a caller says when it falls back.) */
 int lr_rnn_one_launch_status(int mode, int B, int T, int I, int H, int D);
+/* Recurrence launches ONE pass (forward or backward) of the layer takes on this device: 1 where every (direction,
+ * 8 samples) cluster of the batch fits one launch — up to 8 * floor(32 / members) clusters, members = ceil(H / 32):
+ * BiGRU-256 up to B = 128, BiLSTM-512 up to B = 64 (BASELINE configs[3]'s whole batch on one GPU) —, more where the
+ * batch is cut into several launches, T where the layer runs one launch per time step. */
+int lr_rnn_pass_launches(int mode, int B, int T, int I, int H, int D);
 /* LR_RNN_RECUR_SPLIT's workgroups of a pair / cluster must be resident together (lr_rnn_pair_supported checks the
  * device's compute-unit count); their waits are bounded, and a member that gave up leaves garbage and raises the
  * device-side FAULT WORD.  The reference's contract for a batch it cannot use is assert / `None` => skip

@@ -55,6 +55,7 @@ SIGNATURES = {
     "lr_tfm_backward_weights": (c_int, [c_int, P, P, c_int, P, c_size_t, P, c_size_t] + [c_int] * 7 + [P]),
     "lr_rnn_pair_supported": (c_int, [c_int] * 6),
     "lr_rnn_one_launch_status": (c_int, [c_int] * 6),
+    "lr_rnn_pass_launches": (c_int, [c_int] * 6),
     "lr_rnn_pair_errors": (c_int, []),
     "lr_fault_words_ptr": (c_void_p, []),
     "lr_fault_export": (c_int, [P, P, P]),

@@ -221,7 +221,8 @@ size_t lr_fgemm_slab_floats_impl(int M, int N, int splits);
 // G = 3 (GRU) or 4 (LSTM); h0 / c0 (may be NULL) = the state before the first step, [D][B][H]; dh0 / dc0 (may be
 // NULL) receive the gradient into it
 int lr_rnn_cluster_supported(int G, int B, int H);
-int lr_rnn_cluster_cus(int G, int H);   // compute units one launch needs resident together; 0: no kernel for the shape
+int lr_rnn_cluster_cus(int G, int H);   // compute units the SMALLEST launch needs resident together; 0: no kernel for the shape
+int lr_rnn_cluster_launches(int G, int B, int H, int D);   // recurrence launches per layer pass on this device
 size_t lr_rnn_cluster_pack_bytes(int G, int H, int D, int backward);
 size_t lr_rnn_cluster_xch_bytes(int B, int H, int D, int backward);
 // prologue_done: lr_rnn_cluster_prologue already ran for this pass (W_hh packed into wpack, the first launch's

@@ -84,7 +84,13 @@ struct Cfg {
   static constexpr int CLD = HP + 8;               // bf16 per LDS row of the state
   static constexpr int XB = NS * U, TPB = XB / 4;
   static constexpr int NL = (CC * TPB + 255) / 256;   // 16-byte gather loads per thread and step
-  static constexpr int MAXCL = CC <= 32 ? 8 : (CC <= 64 ? 4 : 2);   // clusters per launch (block b -> cluster b % MAXCL)
+  // clusters per launch: block b -> cluster b % ncl, member b / ncl, with ncl a multiple of XS chosen per launch.  XS = 8
+  // for 32-unit members: the dispatcher places blocks k, k + 8, ... on ONE XCD (observed), and since 8 | ncl every
+  // member of cluster k sits on XCD k % 8.  Rounds 2-5 launched 8 clusters whatever CC was: GRU-256 (CC = 8) at B = 64
+  // became two serial launches on 64 CUs each.  An XCD has 32 CUs, so it holds floor(32 / CC) whole clusters: round 6
+  // launches up to MAXCL = 8 floor(32 / CC) of them (GRU-256: 32 clusters = B 128 in one launch, LSTM-512: 16 = B 64).
+  static constexpr int XS = CC <= 32 ? 8 : (CC <= 64 ? 4 : 2);
+  static constexpr int MAXCL = (U == 32 && CC <= 16) ? XS * (32 / CC) : XS;
   // forward: CF fragments per tile: f = 2 * local k step + plane
   static constexpr int CF = 2 * KS;
   static constexpr int CF_A = imin(CF, 60 / NTILE);             // f < CF_A in AGPRs (60 fragments per wave)
@@ -307,8 +313,8 @@ __global__ void rnnc_pack_bwd_kernel(const float* __restrict__ w0, const float* 
 // ---------------------------------------------------------------------------------------------------------------
 // forward recurrence
 // ---------------------------------------------------------------------------------------------------------------
-// grid: MAXCL * CC workgroups x 256 threads; block b -> cluster b % MAXCL (U = 32: MAXCL = 8, the cluster = one XCD;
-// U = 16: 4 or 2, a cluster spans XCDs k, k + MAXCL, ...), member b / MAXCL.
+// grid: ncl * CC workgroups x 256 threads; block b -> cluster b % ncl (U = 32: ncl = 8, 16, ... <= MAXCL, cluster k on XCD
+// k % 8; U = 16: 4 or 2, a cluster spans XCDs k, k + ncl, ...), member b / ncl.
 // cluster k -> (sample group g0 + k / D, direction k % D).  Gate phase: lane = sample * UW + unit of the wave: it
 // consumes its own wave's results (wave-local LDS exchange, no workgroup barrier); with 4-unit waves lanes 32-63 idle.
 // Exchange layout: [slot][cluster][member][wave][sample][unit of the wave] words — a wave publishes NS * UW consecutive
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
     float* __restrict__ gates, float* __restrict__ extra, float* __restrict__ y, const bf16x8* __restrict__ wpk,
     const float* __restrict__ bhh0, const float* __restrict__ bhh1, const float* __restrict__ h0,
     const float* __restrict__ c0, const int32_t* __restrict__ lens, u32* __restrict__ xch, int32_t* __restrict__ fault,
-    int drop, int tune, int g0, int nclusters, int B, int T, int D, int H) {
+    int drop, int tune, int g0, int nclusters, int ncl, int B, int T, int D, int H) {
   using C = Cfg<G, CC, U>;
   constexpr int CLD = C::CLD, CF = C::CF, CF_A = C::CF_A, CF_REG = C::CF_REG, CF_L = C::CF_L, NL = C::NL, HP = C::HP;
   constexpr int NTILE = C::NTILE, UW = C::UW, GPT = C::GPT, KS = C::KS, XB = C::XB, TPB = C::TPB;
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
   bf16x8* Wl = reinterpret_cast<bf16x8*>(smem + (size_t)2 * 16 * CLD * 2);                         // [4][NTILE][CF_L][64]
   float* S = reinterpret_cast<float*>(smem + (size_t)2 * 16 * CLD * 2 + (size_t)4 * NTILE * CF_L * 1024);   // [4][NTILE][16][16]
   __shared__ int s_local;
-  const int cluster = blockIdx.x % C::MAXCL, c = blockIdx.x / C::MAXCL;
+  const int cluster = blockIdx.x % ncl, c = blockIdx.x / ncl;
   const int ks_own = U == 32 ? c : c >> 1;   // the k step this member's units sit in
   if (cluster >= nclusters) return;     // whole clusters leave together
   if (c == drop) return;                // test hook (lr_rnn_debug_drop_member): the others must time out and report
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ dh_n, const float* __restrict__ dc_n, float* __restrict__ dG,
     float* __restrict__ dh0, float* __restrict__ dc0, const float* __restrict__ h0, const float* __restrict__ c0,
     const bf16x8* __restrict__ wpk, const int32_t* __restrict__ lens, u32* __restrict__ xch, int32_t* __restrict__ fault,
-    int drop, int tune, int g0, int nclusters, int B, int T, int D, int H) {
+    int drop, int tune, int g0, int nclusters, int ncl, int B, int T, int D, int H) {
   using C = Cfg<G, CC, U>;
   constexpr int KB = C::KB, NT = C::NT, NL = C::NL, BFW = C::BFW, BFW_A = C::BFW_A, BFW_REG = C::BFW_REG, BFW_L = C::BFW_L,
                 BKLD = C::BKLD;
@@ -647,7 +653,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
   bf16x8* Wl = reinterpret_cast<bf16x8*>(smem + (size_t)2 * 16 * BKLD * 2);                        // [4][NT][BFW_L][64]
   float* red = reinterpret_cast<float*>(smem + (size_t)2 * 16 * BKLD * 2 + (size_t)4 * NT * BFW_L * 1024);   // [NRED + 1][XB]: the sums of remote partials per (wave, block of the sweep), then this member's own
   __shared__ int s_local;
-  const int cluster = blockIdx.x % C::MAXCL, c = blockIdx.x / C::MAXCL;
+  const int cluster = blockIdx.x % ncl, c = blockIdx.x / ncl;
   if (cluster >= nclusters) return;
   if (c == drop) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -949,6 +955,22 @@ size_t xch_words(int CC, int U, int nclusters, int backward) {
   return (size_t)2 * nclusters * per + (size_t)nclusters * CC;
 }
 
+// clusters a launch is laid out for (its grid is ncl * CC workgroups): the smallest multiple of XS that holds `need`
+// clusters, at most MAXCL, and no more than the device has compute units for (all of them must be resident together)
+template <int G, int CC, int U>
+inline int launch_clusters(int need) {
+  using C = Cfg<G, CC, U>;
+  int m = (need + C::XS - 1) / C::XS * C::XS;
+  if (m > C::MAXCL) m = C::MAXCL;
+  const int cus = lr_device_cus();
+  while (m > C::XS && cus > 0 && m * CC > cus) m -= C::XS;
+  return m;
+}
+inline int max_clusters(int CC, int U) {   // Cfg::MAXCL without the template
+  const int xs = CC <= 32 ? 8 : (CC <= 64 ? 4 : 2);
+  return (U == 32 && CC <= 16) ? xs * (32 / CC) : xs;
+}
+
 // words of the first launch's exchange area
 inline int first_xch_words(int CC, int U, int maxcl, int B, int D, int backward) {
   const int groups = (B + NS - 1) / NS, gchunk = maxcl / D;
@@ -967,8 +989,9 @@ int fwd_prologue(const float* const* w_hh, const float* const* b_ih, const float
   }
   fold.out = b_ih ? bias_out : nullptr;
   LR_LAUNCH((rnnc_pack_fwd_kernel<G, CC, U>), dim3(1024), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D, H,
-            (u32*)xch, first_xch_words(CC, U, Cfg<G, CC, U>::MAXCL, B, D, 0), fold, (bf16x8*)wpack_b, (u32*)xch_b,
-            wpack_b ? first_xch_words(CC, U, Cfg<G, CC, U>::MAXCL, B, D, 1) : 0);
+            (u32*)xch, first_xch_words(CC, U, launch_clusters<G, CC, U>((B + NS - 1) / NS * D), B, D, 0), fold,
+            (bf16x8*)wpack_b, (u32*)xch_b,
+            wpack_b ? first_xch_words(CC, U, launch_clusters<G, CC, U>((B + NS - 1) / NS * D), B, D, 1) : 0);
   return lr_launch_status();
 }
 
@@ -993,21 +1016,21 @@ int fwd_launch(float* gates, float* extra, float* y, const float* const* w_hh, c
   int32_t* fault = lr_fault_words();
   const int drop = lr_debug_drop_member_value();
   const int tune = lr_debug_tune_value(0);
-  const int groups = (B + NS - 1) / NS, gchunk = C::MAXCL / D;   // sample groups per launch
+  const int groups = (B + NS - 1) / NS, ncl = launch_clusters<G, CC, U>(groups * D), gchunk = ncl / D;   // sample groups per launch
   for (int g0 = 0; g0 < groups; g0 += gchunk) {
     const int ng = groups - g0 < gchunk ? groups - g0 : gchunk, nclusters = ng * D;
     // (the first launch's words were cleared by the prologue)
     if (g0 > 0 && hipMemsetAsync(xch, 0, xch_words(CC, U, nclusters, 0) * sizeof(u32), stream) != hipSuccess) return LR_ERR_LAUNCH;
-    const dim3 grid(C::MAXCL * CC);
+    const dim3 grid(ncl * CC);
     hipEvent_t e0, e1;
     if (g0 == 0 && lr_prof_next(LR_PROF_RNN_FWD, &e0, &e1))
       hipExtLaunchKernelGGL((rnnc_fwd_kernel<G, CC, U>), grid, dim3(256), C::FWD_LDS, stream, e0, e1, 0, gates, extra, y,
                             (const bf16x8*)wpack, b_hh[0], b_hh[D - 1], h0, c0, lens, (u32*)xch, fault, drop, tune, g0,
-                            nclusters, B, T, D, H);
+                            nclusters, ncl, B, T, D, H);
     else
       hipLaunchKernelGGL((rnnc_fwd_kernel<G, CC, U>), grid, dim3(256), C::FWD_LDS, stream, gates, extra, y,
                          (const bf16x8*)wpack, b_hh[0], b_hh[D - 1], h0, c0, lens, (u32*)xch, fault, drop, tune, g0, nclusters,
-                         B, T, D, H);
+                         ncl, B, T, D, H);
     st = lr_launch_status();
     if (st != LR_OK) return st;
   }
@@ -1030,26 +1053,26 @@ int bwd_launch(const float* gates, const float* extra, const float* y, const flo
   int st = LR_OK;
   if (!pack_done) {   // (else: the layer's forward prologue left the fragments and the cleared words in wpack / xch)
     LR_LAUNCH((rnnc_pack_bwd_kernel<G, CC, U>), dim3(1024), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D,
-              H, (u32*)xch, first_xch_words(CC, U, C::MAXCL, B, D, 1));
+              H, (u32*)xch, first_xch_words(CC, U, launch_clusters<G, CC, U>((B + NS - 1) / NS * D), B, D, 1));
     st = lr_launch_status();
     if (st != LR_OK) return st;
   }
   int32_t* fault = lr_fault_words();
   const int drop = lr_debug_drop_member_value();
   const int tune = lr_debug_tune_value(1);
-  const int groups = (B + NS - 1) / NS, gchunk = C::MAXCL / D;
+  const int groups = (B + NS - 1) / NS, ncl = launch_clusters<G, CC, U>(groups * D), gchunk = ncl / D;
   for (int g0 = 0; g0 < groups; g0 += gchunk) {
     const int ng = groups - g0 < gchunk ? groups - g0 : gchunk, nclusters = ng * D;
     if (g0 > 0 && hipMemsetAsync(xch, 0, xch_words(CC, U, nclusters, 1) * sizeof(u32), stream) != hipSuccess) return LR_ERR_LAUNCH;
-    const dim3 grid(C::MAXCL * CC);
+    const dim3 grid(ncl * CC);
     hipEvent_t e0, e1;
     if (g0 == 0 && lr_prof_next(LR_PROF_RNN_BWD, &e0, &e1))
       hipExtLaunchKernelGGL((rnnc_bwd_kernel<G, CC, U>), grid, dim3(256), C::BWD_LDS, stream, e0, e1, 0, gates, extra, y, dy,
                             dh_n, dc_n, dG, dh0, dc0, h0, c0, (const bf16x8*)wpack, lens, (u32*)xch, fault, drop, tune, g0,
-                            nclusters, B, T, D, H);
+                            nclusters, ncl, B, T, D, H);
     else
       hipLaunchKernelGGL((rnnc_bwd_kernel<G, CC, U>), grid, dim3(256), C::BWD_LDS, stream, gates, extra, y, dy, dh_n, dc_n, dG,
-                         dh0, dc0, h0, c0, (const bf16x8*)wpack, lens, (u32*)xch, fault, drop, tune, g0, nclusters, B, T, D,
+                         dh0, dc0, h0, c0, (const bf16x8*)wpack, lens, (u32*)xch, fault, drop, tune, g0, nclusters, ncl, B, T, D,
                          H);
     st = lr_launch_status();
     if (st != LR_OK) return st;
@@ -1107,11 +1130,27 @@ bool resolve_shape(int G, int H, int* cc, int* u) {
 
 }  // namespace
 
-// all MAXCL * CC workgroups of a launch must be resident together, one per compute unit
+// all ncl * CC workgroups of a launch must be resident together, one per compute unit; the smallest launch (XS
+// clusters) is what a device must hold — larger batches get as many clusters per launch as it has room for
 int lr_rnn_cluster_cus(int G, int H) {
   int cc, u;
   if (H < 1 || (G != 3 && G != 4) || !resolve_shape(G, H, &cc, &u)) return 0;
   return (cc <= 32 ? 8 : (cc <= 64 ? 4 : 2)) * cc;
+}
+
+// recurrence launches one pass of a layer takes (both directions ride in one launch): ceil(sample groups / groups a
+// launch's clusters hold); 0: no kernel for the shape
+int lr_rnn_cluster_launches(int G, int B, int H, int D) {
+  int cc, u;
+  if (B < 1 || D < 1 || !resolve_shape(G, H, &cc, &u)) return 0;
+  int ncl = 0;
+#define X(g, c, uu) \
+  if (G == g && cc == c && u == uu) ncl = launch_clusters<g, c, uu>((B + NS - 1) / NS * D);
+  LR_CLUSTER_SHAPES(X)
+#undef X
+  if (ncl < D) return 0;
+  const int groups = (B + NS - 1) / NS, gchunk = ncl / D;
+  return (groups + gchunk - 1) / gchunk;
 }
 
 int lr_rnn_cluster_supported(int G, int B, int H) {
@@ -1134,13 +1173,13 @@ size_t lr_rnn_cluster_xch_bytes(int B, int H, int D, int backward) {
   int cc, u;
   // (the exchange area does not depend on the gate count: resolve as the LSTM, whose 32-unit range is the smaller)
   if (!resolve_shape(4, H, &cc, &u) && !resolve_shape(3, H, &cc, &u)) return 0;
-  const int maxcl = cc <= 32 ? 8 : (cc <= 64 ? 4 : 2);
+  const int maxcl = max_clusters(cc, u);
   int clusters = (B + NS - 1) / NS * D;
   if (clusters > maxcl) clusters = maxcl;
   size_t w = xch_words(cc, u, clusters, backward);
   int cc3, u3;
   if (resolve_shape(3, H, &cc3, &u3) && (cc3 != cc || u3 != u)) {   // a GRU of this size takes the other form: the larger
-    const int m3 = cc3 <= 32 ? 8 : (cc3 <= 64 ? 4 : 2);
+    const int m3 = max_clusters(cc3, u3);
     int cl3 = (B + NS - 1) / NS * D;
     if (cl3 > m3) cl3 = m3;
     const size_t w3 = xch_words(cc3, u3, cl3, backward);

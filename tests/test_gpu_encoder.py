@@ -315,14 +315,17 @@ def test_bf16x3_input_projection_tracks_the_fp32_path(dev, rnn_type):
     assert float((a - b).abs().max()) / scale < (1e-2 if i == 2 else 1e-4), i
 
 
-@pytest.mark.parametrize("B,T,bi,lens", [(32, 75, True, None),
-                                         (40, 30, True, "ragged"),      # more pairs than one launch holds: chunked
-                                         (70, 9, False, "ragged"),      # unidirectional: 64 samples per launch + 6
-                                         (3, 1, True, None), (5, 2, True, [2, 1, 2, 1, 1])])
-def test_split_recurrence_is_fp32_faithful(dev, B, T, bi, lens):
+@pytest.mark.parametrize("B,T,bi,lens,launches", [(32, 75, True, None, 1),
+                                                  (40, 30, True, "ragged", 1),     # 10 clusters: a 16-cluster launch (rounds 2-5: two launches of 8)
+                                                  (70, 9, False, "ragged", 1),     # unidirectional: 9 clusters
+                                                  (64, 75, True, None, 1),         # BASELINE configs[3]'s whole batch on one GPU: 16 clusters on 128 CUs
+                                                  (128, 20, True, "ragged", 1),    # 32 clusters x 8 members = every CU of the chip
+                                                  (136, 6, True, "ragged", 2),     # 34 clusters: a launch of 32 (16 groups) + the 17th group
+                                                  (3, 1, True, None, 1), (5, 2, True, [2, 1, 2, 1, 1], 1)])
+def test_split_recurrence_is_fp32_faithful(dev, B, T, bi, lens, launches):
   """LR_RNN_RECUR_SPLIT (VideoEncoder's default where supported) on GRU, H = 256: the whole recurrence of a
   layer pass in one launch, W_hh and the state as bf16 hi + lo planes on the 8-member cluster kernels
-  (lr_rnn_cluster.hip; rounds 2-4 also kept CU-pair kernels for devices too small for a cluster launch: removed in
+  (lr_rnn_cluster.hip; up to 32 clusters per launch, four to an XCD; rounds 2-4 also kept CU-pair kernels for devices too small for a cluster launch: removed in
   round 5, nothing on an MI355X reached them).  Against the exact-fp32 step kernels on the same weights (2 layers: the
   second layer's input is the first's output), forward and backward, ragged lengths, final-state gradient injected:
   agreement to ~1e-5 relative, and no member ever timed out."""
@@ -344,6 +347,8 @@ def test_split_recurrence_is_fp32_faithful(dev, B, T, bi, lens):
   wgt = torch.randn(B, T, 65, generator=g).to(dev)
   valid = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).float().unsqueeze(-1).to(dev)
   assert _C.lib().lr_rnn_pair_supported(0, B, T, 96, 256, 2 if bi else 1) == 2
+  # round 6: an XCD holds four 8-member clusters, a launch up to 32 of them — ONE launch per layer pass up to B = 128
+  assert _C.lib().lr_rnn_pass_launches(0, B, T, 96, 256, 2 if bi else 1) == launches
   _C.lib().lr_rnn_pair_errors()
   res = {}
   for mode in ("f32", "split"):
@@ -414,7 +419,16 @@ CLUSTER_CASES = [("LSTM", 768, 32, 75, True, None, 1), ("LSTM", 768, 37, 20, Tru
                  ("LSTM", 800, 32, 40, True, "ragged", 1), ("LSTM", 800, 11, 9, False, "ragged", 2),
                  ("GRU", 1024, 13, 12, False, "ragged", 1), ("GRU", 896, 32, 20, True, None, 1),
                  ("LSTM", 1152, 9, 6, False, "ragged", 1), ("LSTM", 788, 20, 7, True, "ragged", 1),
-                 ("GRU", 1100, 40, 5, False, "ragged", 1)]
+                 ("GRU", 1100, 40, 5, False, "ragged", 1),
+                 # round 6: more than 8 clusters per launch where an XCD holds several (8 floor(32 / members) of them):
+                 # BiLSTM-512 at configs[3]'s B = 64 (16 clusters), 10-member clusters three to an XCD (24), 4-member
+                 # ones at B = 130 (33 groups of a unidirectional layer: 64-cluster launches hold them all)
+                 ("LSTM", 512, 64, 12, True, "ragged", 1), ("LSTM", 320, 96, 6, True, "ragged", 1),
+                 ("GRU", 128, 130, 5, False, "ragged", 2), ("LSTM", 256, 128, 7, True, "ragged", 1)]
+# (rnn_type, H, B, bidirectional) -> recurrence launches per layer pass (lr_rnn_pass_launches)
+CLUSTER_LAUNCHES = {("LSTM", 512, 64, True): 1, ("LSTM", 320, 96, True): 1, ("GRU", 128, 130, False): 1,
+                    ("LSTM", 256, 128, True): 1, ("LSTM", 768, 37, True): 2, ("LSTM", 768, 70, False): 2,
+                    ("LSTM", 768, 32, True): 1, ("GRU", 704, 70, True): 3, ("GRU", 1100, 40, False): 3}
 
 
 def test_one_launch_recurrence_covers_every_hidden_size_its_storage_holds(dev):
@@ -509,6 +523,9 @@ def test_cluster_recurrence_is_fp32_faithful(dev, rnn_type, H, B, T, bi, lens, l
   wgt = torch.randn(B, T, 65, generator=g).to(dev)
   valid = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).float().unsqueeze(-1).to(dev)
   assert _C.lib().lr_rnn_pair_supported({"GRU": 0, "LSTM": 1}[rnn_type], B, T, 64, H, 2 if bi else 1) == 2
+  if (rnn_type, H, B, bi) in CLUSTER_LAUNCHES:
+    assert _C.lib().lr_rnn_pass_launches({"GRU": 0, "LSTM": 1}[rnn_type], B, T, 64, H, 2 if bi else 1) == \
+           CLUSTER_LAUNCHES[(rnn_type, H, B, bi)]
   _C.lib().lr_rnn_pair_errors()
   res = {}
   for mode in ("f32", "split"):
