@@ -964,8 +964,14 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
                           rnn_type, D * H, args.char_dim, args.attention))
     dec_kind = L.lr_rnn_pair_supported({"GRU": 0, "LSTM": 1, "RNN": 2}[rnn_type], B, LABEL_LEN + 1, args.char_dim + D * H, D * H, 1)
     dec_members = (D * H + 31) // 32 if D * H <= (864 if rnn_type == "GRU" else 768) else (D * H + 15) // 16 // 2 * 2 + ((D * H + 15) // 16 % 2) * 2
-    res["decoder_recurrence"] = ("one launch per loop pass (cluster of %d CUs per 8 samples)" % dec_members if dec_kind == 2
-                                 else "one launch per decoder step (no one-launch kernels for %s-%d)" % (rnn_type, D * H))
+    dec_launches = L.lr_rnn_pass_launches({"GRU": 0, "LSTM": 1, "RNN": 2}[rnn_type], B, LABEL_LEN + 1, args.char_dim + D * H, D * H, 1)
+    if dec_kind == 2 and D * H > 1152:
+      res["decoder_recurrence"] = ("%d launch(es) per loop pass: the 24 x 8 grid of 192 CUs (lr_rnn_grid.hip), 64 samples per launch"
+                                   % dec_launches)
+    else:
+      res["decoder_recurrence"] = ("%d launch(es) per loop pass (cluster of %d CUs per 8 samples)" % (dec_launches, dec_members)
+                                   if dec_kind == 2
+                                   else "one launch per decoder step (no one-launch kernels for %s-%d)" % (rnn_type, D * H))
   else:
     res["workload"] = ("regime R (reference-faithful): landmarks (B=%d,T=75,68,3) f32 -> %d-layer Bi%s-%d (%s) -> "
                        "Linear(%d,65) -> masked log-softmax -> CTC 'mean' (L=30+EOS) -> backward -> "

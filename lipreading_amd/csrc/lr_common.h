@@ -239,6 +239,21 @@ int lr_rnn_cluster_backward(int G, const float* gates, const float* extra, const
                             const float* dh_n, const float* dc_n, float* dG, float* dh0, float* dc0, const float* h0,
                             const float* c0, const float* const* w_hh, const int32_t* lens, void* wpack, void* xch, int B,
                             int T, int D, int H, hipStream_t stream, int pack_done = 0);
+// lr_rnn_grid.hip: the LSTM recurrence for 1152 < H <= 1536 (the 1400 / 1536-unit decoders behind BiLSTM-700 / 768) as one
+// launch per pass on a 24 x 8 grid of 192 compute units; reached through lr_rnn_cluster_* above, which delegate
+int lr_rnn_grid_shape(int G, int H);   // 1: this file's kernels cover the shape
+int lr_rnn_grid_cus();
+int lr_rnn_grid_launches(int B, int D);
+size_t lr_rnn_grid_pack_bytes(int D);
+size_t lr_rnn_grid_xch_bytes(int B, int backward);
+int lr_rnn_grid_prologue(const float* const* w_hh, const float* const* b_ih, const float* const* b_hh, float* bias_out,
+                         void* wpack, void* xch, int B, int D, int H, hipStream_t stream, void* wpack_b, void* xch_b);
+int lr_rnn_grid_forward(float* gates, float* extra, float* y, const float* const* w_hh, const float* h0, const float* c0,
+                        const int32_t* lens, void* wpack, void* xch, int B, int T, int D, int H, hipStream_t stream,
+                        int prologue_done);
+int lr_rnn_grid_backward(const float* gates, const float* extra, const float* dy, const float* dh_n, const float* dc_n,
+                         float* dG, float* dh0, float* dc0, const float* c0, const float* const* w_hh, const int32_t* lens,
+                         void* wpack, void* xch, int B, int T, int D, int H, hipStream_t stream, int pack_done);
 // lr_xgemm.hip: fp32 GEMM on the bf16 matrix cores by hi/lo operand splitting (same operand
 // conventions; a_exact / b_exact: the operand's elements are bf16 values already)
 int lr_xgemm_impl(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,

@@ -48,17 +48,12 @@
 // MEASURED: see DESIGN.md section 4 (round 2, 8-byte granules, LSTM-768 only: forward 4.6 us, backward 5.5 us per
 // step against 9.4 / 10.7 for the step kernels).
 #include "lr_common.h"
+#include "lr_rnn_xch.h"
 #include <hip/hip_ext.h>
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short bf16_t;
-typedef unsigned u32;
+using namespace lrx;
 
 constexpr int NS = 8;              // samples per cluster (rows 0-7 hi, 8-15 lo of the A operand)
 constexpr int SPIN_LIMIT = 1 << 18;
@@ -116,85 +111,6 @@ struct Cfg {
   static constexpr size_t FWD_PACK = (size_t)CC * 4 * NTILE * CF * 64 * sizeof(bf16x8);     // per direction
   static constexpr size_t BWD_PACK = (size_t)CC * 4 * NT * BFW * 64 * sizeof(bf16x8);
 };
-
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  __bf16 h = (__bf16)f;
-  return __builtin_bit_cast(bf16_t, h);
-}
-__device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
-__device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
-  hi = f2bf(x);
-  lo = f2bf(x - bf2f(hi));
-}
-// two values -> {hi0 | hi1 << 16}, {lo0 | lo1 << 16}
-__device__ __forceinline__ void split_bf16_pair(float a, float b, u32& hi, u32& lo) {
-  const bf16x2 h = __builtin_convertvector((f32x2){a, b}, bf16x2);
-  const float ha = (float)h[0], hb = (float)h[1];
-  const bf16x2 l = __builtin_convertvector((f32x2){a - ha, b - hb}, bf16x2);
-  hi = __builtin_bit_cast(u32, h);
-  lo = __builtin_bit_cast(u32, l);
-}
-
-// ---- gate non-linearities --------------------------------------------------------------------------------------
-// The cell runs ONCE per thread and step, on the critical path of the step chain, and its transcendental functions
-// were a sixth of a GRU-256 step: expf / tanhf of the device library cost ~10 / ~30+ instructions (range
-// reduction, fix-ups, an IEEE division).  Here: v_exp_f32 and v_rcp_f32 (1 ulp each) — sigmoid to ~3e-7 relative,
-// tanh to ~2e-7 ABSOLUTE (1 - 2 / (1 + e^2x): exact saturation at both ends, cancellation only where |tanh| is
-// small), an order of magnitude inside the 2^-18 of the hi + lo operand split these kernels already work with.
-__device__ __forceinline__ float fast_sigmoid(float x) {
-  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-}
-__device__ __forceinline__ float fast_tanh(float x) {
-  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
-}
-
-// ---- exchange words ------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 tag_of(int step) { return 1u + (u32)((step >> 1) % 3); }
-__device__ __forceinline__ u32 xword(float v, u32 tag) {
-  return ((__builtin_bit_cast(u32, v) + 2u) & ~3u) | tag;      // round to 22 mantissa bits, tag in the low two
-}
-__device__ __forceinline__ float xval(u32 w) { return __builtin_bit_cast(float, w & ~3u); }
-__device__ __forceinline__ void publish(u32* p, u32 w, bool local) {
-  // workgroup scope = the ISA's `sc0`: through the CU's write-through L1 into the XCD's L2, where it STAYS (an
-  // agent-scope `sc1` store writes through and drops the line: every reader then goes to the fabric).  Only other
-  // CUs of the same XCD are guaranteed to see it there — used when the cluster verified that it shares one XCD.
-  if (local) __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  else __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u32 peek(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// four words, L1-bypassing (`sc1`: served by the L2).  The compiler does not see the load: LR_VM_DRAIN + LR_TOUCH
-// before the first use.
-__device__ __forceinline__ u32x4 peek4(const u32* p) {
-  u32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-#define LR_VM_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define LR_TOUCH(x) asm volatile("" : "+v"(x))
-__device__ __forceinline__ int xcc_id() {
-  int x;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-  return x & 0xf;
-}
-
-#define LR_MFMA_A0(acc, a, w) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(w))
-#define LR_MFMA_A(acc, a, w) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w))
-#define LR_MFMA_V(acc, a, w) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(w))
-// The asm MFMAs are opaque to the compiler's hazard recogniser: let the last ones retire before any VALU instruction
-// reads an accumulator — and TIE every accumulator to a statement behind the wait (LR_ACC_READY), or the reads are free
-// to move in front of it: they are plain register arithmetic, which a volatile asm with a "memory" clobber does not
-// order.  (Round 4 found <3,2>'s ISA adding acc0 + acc1 of two registers BETWEEN the last two MFMAs: the 2-member
-// clusters were off by 1e-4 — the lo-plane product of the last k step — in half of the samples; every other
-// instantiation happened to be scheduled the other way round.)
-#define LR_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 3" ::: "memory")
-#define LR_ACC_READY(acc) asm volatile("" : "+v"(acc))
-// lanes 0-31: x + (x of lane + 32); lanes 32-63: y + (y of lane - 32).  (Inline asm: this ROCm's
-// __builtin_amdgcn_permlane32_swap folds its two results into one register.  s_nop: the wait states a lane-crossing
-// VALU read wants behind a VALU write of its operands, which the hazard recogniser cannot place around an asm.)
-__device__ __forceinline__ float fold32(float x, float y) {
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
-  return x + y;
-}
 
 // do all members of this cluster sit on one XCD?  Every member publishes its XCC id (agent scope) and reads all
 // CC; the verdict is the same on every member because it is computed from the same CC words.  Returns through
@@ -1134,6 +1050,7 @@ bool resolve_shape(int G, int H, int* cc, int* u) {
 // clusters) is what a device must hold — larger batches get as many clusters per launch as it has room for
 int lr_rnn_cluster_cus(int G, int H) {
   int cc, u;
+  if (lr_rnn_grid_shape(G, H)) return lr_rnn_grid_cus();   // 1152 < H <= 1536, LSTM: one grid of 192 (lr_rnn_grid.hip)
   if (H < 1 || (G != 3 && G != 4) || !resolve_shape(G, H, &cc, &u)) return 0;
   return (cc <= 32 ? 8 : (cc <= 64 ? 4 : 2)) * cc;
 }
@@ -1142,6 +1059,7 @@ int lr_rnn_cluster_cus(int G, int H) {
 // launch's clusters hold); 0: no kernel for the shape
 int lr_rnn_cluster_launches(int G, int B, int H, int D) {
   int cc, u;
+  if (B >= 1 && D >= 1 && lr_rnn_grid_shape(G, H)) return lr_rnn_grid_launches(B, D);
   if (B < 1 || D < 1 || !resolve_shape(G, H, &cc, &u)) return 0;
   int ncl = 0;
 #define X(g, c, uu) \
@@ -1161,6 +1079,7 @@ int lr_rnn_cluster_supported(int G, int B, int H) {
 
 size_t lr_rnn_cluster_pack_bytes(int G, int H, int D, int backward) {
   int cc, u;
+  if (lr_rnn_grid_shape(G, H)) return lr_rnn_grid_pack_bytes(D);
   if (!resolve_shape(G, H, &cc, &u)) return 0;
 #define X(g, c, uu) \
   if (G == g && cc == c && u == uu) return (size_t)D * (backward ? Cfg<g, c, uu>::BWD_PACK : Cfg<g, c, uu>::FWD_PACK);
@@ -1171,6 +1090,7 @@ size_t lr_rnn_cluster_pack_bytes(int G, int H, int D, int backward) {
 
 size_t lr_rnn_cluster_xch_bytes(int B, int H, int D, int backward) {
   int cc, u;
+  if (lr_rnn_grid_shape(4, H)) return lr_rnn_grid_xch_bytes(B, backward);   // (a GRU of this size has no one-launch kernel)
   // (the exchange area does not depend on the gate count: resolve as the LSTM, whose 32-unit range is the smaller)
   if (!resolve_shape(4, H, &cc, &u) && !resolve_shape(3, H, &cc, &u)) return 0;
   const int maxcl = max_clusters(cc, u);
@@ -1192,6 +1112,8 @@ int lr_rnn_cluster_forward(int G, float* gates, float* extra, float* y, const fl
                            const float* h0, const float* c0, const int32_t* lens, void* wpack, void* xch, int B, int T,
                            int D, int H, hipStream_t stream, int prologue_done) {
   int cc, u;
+  if (lr_rnn_grid_shape(G, H))
+    return lr_rnn_grid_forward(gates, extra, y, w_hh, h0, c0, lens, wpack, xch, B, T, D, H, stream, prologue_done);
   if (!resolve_shape(G, H, &cc, &u)) return LR_ERR_UNSUPPORTED;
 #define X(g, c, uu)                 \
   if (G == g && cc == c && u == uu) \
@@ -1206,6 +1128,7 @@ int lr_rnn_cluster_prologue(int G, const float* const* w_hh, const float* const*
                             void* wpack_b, void* xch_b) {
   int cc, u;
   lr_clear_error();
+  if (lr_rnn_grid_shape(G, H)) return lr_rnn_grid_prologue(w_hh, b_ih, b_hh, bias_out, wpack, xch, B, D, H, stream, wpack_b, xch_b);
   if (!resolve_shape(G, H, &cc, &u)) return LR_ERR_UNSUPPORTED;
 #define X(g, c, uu) \
   if (G == g && cc == c && u == uu) \
@@ -1220,6 +1143,8 @@ int lr_rnn_cluster_backward(int G, const float* gates, const float* extra, const
                             const float* c0, const float* const* w_hh, const int32_t* lens, void* wpack, void* xch, int B,
                             int T, int D, int H, hipStream_t stream, int pack_done) {
   int cc, u;
+  if (lr_rnn_grid_shape(G, H))
+    return lr_rnn_grid_backward(gates, extra, dy, dh_n, dc_n, dG, dh0, dc0, c0, w_hh, lens, wpack, xch, B, T, D, H, stream, pack_done);
   if (!resolve_shape(G, H, &cc, &u)) return LR_ERR_UNSUPPORTED;
 #define X(g, c, uu)                                                                                                      \
   if (G == g && cc == c && u == uu)                                                                                      \

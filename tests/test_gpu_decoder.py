@@ -146,13 +146,18 @@ def test_sampled_inputs_and_bench_sizes_match_oracle(dev):
 
 
 @pytest.mark.parametrize("Henc,attn,char_dim,B", [(512, "1_layer_nn", 256, 4), (512, "1_layer_nn", 256, 32),
-                                                 (768, "none", 256, 8)])
+                                                 (768, "none", 256, 8), (768, "none", 256, 32), (768, "1_layer_nn", 256, 32),
+                                                 (700, "1_layer_nn", 300, 32), (768, "none", 256, 72)])
 def test_shipped_decoder_configs_match_oracle(dev, Henc, attn, char_dim, B):
   """The decoders of the reference's SHIPPED flag files against the ORACLE (round 4 checked them inside bench.py only):
   config/train/attn/attention_type:8-19 — BiLSTM-512 encoder, so an LSTM-1024 decoder (better_model.py:134), char_dim 256,
   1_layer_nn attention, at the config's batch of 4 and at 32 — and the ecd family (config/archive/experiments/ecd/*:
   BiLSTM-768 -> LSTM-1536, attention none).  Every step teacher forced (teacher_forcing_ratio 1.0 in those files): the
-  loop's RNN runs as ONE cluster launch where the size has one (1024: 16-unit members), else on the step kernels."""
+  loop's RNN runs as ONE launch: 1024 on 16-unit cluster members, 1400 / 1536 (round 6) on the 192-CU grid recurrence
+  (lr_rnn_grid.hip; 72 samples: two launches) — and nothing announces a fallback to the step kernels."""
+  import warnings
+  from lipreading_amd import encoder as E
+  E._fallback_noted.clear()
   from lipreading_amd import _C
   from lipreading_amd.attention_decoder import CharDecodingStep
   from lipreading_amd.data import default_char2idx
@@ -172,12 +177,14 @@ def test_shipped_decoder_configs_match_oracle(dev, Henc, attn, char_dim, B):
   lens = torch.sort(torch.randint(40, T + 1, (B,), generator=g))[0]
   h0, c0 = torch.randn(1, B, Hd, generator=g) * 0.5, torch.randn(1, B, Hd, generator=g) * 0.5
   chars = torch.randint(4, 64, (B, L), generator=g)
-  if Hd == 1024:
-    assert _C.lib().lr_rnn_pair_supported(1, B, L, Hd, Hd, 1) == 2      # the one-launch path is what runs
+  assert _C.lib().lr_rnn_one_launch_status(1, B, L, Hd, Hd, 1) == 0      # the one-launch path is what runs
   _C.lib().lr_rnn_pair_errors()
   encd = enc.to(dev).requires_grad_(True)
   h0d, c0d = h0.to(dev).requires_grad_(True), c0.to(dev).requires_grad_(True)
-  lp, _, _ = dec.decode_sequence(chars.to(dev), (h0d, c0d), lens, encd, seed=11)
+  with warnings.catch_warnings(record=True) as caught:
+    warnings.simplefilter("always")
+    lp, _, _ = dec.decode_sequence(chars.to(dev), (h0d, c0d), lens, encd, seed=11)
+  assert not [w for w in caught if "one launch per time step" in str(w.message)], [str(w.message) for w in caught]
   encr, h0r, c0r = enc.clone().requires_grad_(True), h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
   state, rows = (h0r, c0r), []
   for i in range(L):
@@ -395,7 +402,14 @@ def test_fused_decoder_nll_equals_the_reference_formula(dev):
 
 @pytest.mark.parametrize("rnn_type,Hd,layers,attn,B,L", [("GRU", 512, 1, "1_layer_nn", 32, 31), ("LSTM", 512, 2, "general", 32, 31),
                                                          ("GRU", 256, 2, "none", 32, 31), ("LSTM", 704, 1, "dot", 32, 31),
-                                                         ("LSTM", 256, 1, "concat", 5, 3), ("GRU", 500, 1, "dot", 13, 1)])
+                                                         ("LSTM", 256, 1, "concat", 5, 3), ("GRU", 500, 1, "dot", 13, 1),
+                                                         # round 6: the 1400 / 1536-unit decoders behind BiLSTM-700 / 768 (config/defaults.txt
+                                                         # sizes made bidirectional; config/archive/experiments/e*: 52 of 56 sized files) on
+                                                         # the 192-CU grid recurrence (lr_rnn_grid.hip): one block of 32 samples, a partial
+                                                         # block, two blocks, two launches (70 samples), two layers, a single step
+                                                         ("LSTM", 1536, 1, "none", 32, 31), ("LSTM", 1400, 1, "1_layer_nn", 32, 31),
+                                                         ("LSTM", 1536, 1, "dot", 5, 3), ("LSTM", 1536, 1, "none", 40, 7),
+                                                         ("LSTM", 1400, 2, "none", 70, 4), ("LSTM", 1156, 1, "none", 13, 1)])
 def test_decoder_loop_on_the_cluster_recurrence_equals_the_step_kernels(dev, rnn_type, Hd, layers, attn, B, L):
   """With every step teacher forced (the shipped configs and eval) the decoder's RNN — unidirectional, started from
   the encoder's final state (better_model.py:134-148,181) — runs each layer's L steps as ONE launch of the cluster
@@ -415,6 +429,9 @@ def test_decoder_loop_on_the_cluster_recurrence_equals_the_step_kernels(dev, rnn
                          attn_hidden_size=(64 if attn == "concat" else -1)).to(dev)
   g = torch.Generator().manual_seed(22)
   T = 75 if B == 32 else 9     # (ragged sample groups, a single step: B % 8 != 0, L = 1)
+  import warnings
+  from lipreading_amd import encoder as E
+  E._fallback_noted.clear()
   enc = (torch.randn(B, T, Hd, generator=g) * 0.5).to(dev)
   lens = torch.sort(torch.randint(max(1, T // 2), T + 1, (B,), generator=g))[0]
   h0 = (torch.randn(layers, B, Hd, generator=g) * 0.5).to(dev)
@@ -424,6 +441,9 @@ def test_decoder_loop_on_the_cluster_recurrence_equals_the_step_kernels(dev, rnn
   wf = (torch.randn(layers, B, Hd, generator=g) / 50).to(dev)
   mode = {"GRU": 0, "LSTM": 1}[rnn_type]
   assert L_.lr_rnn_pair_supported(mode, B, L, Hd, Hd, 1) in (1, 2)   # (GRU-256: the encoder would take the pair kernels)
+  if Hd > 1152:
+    assert L_.lr_rnn_one_launch_status(mode, B, L, Hd, Hd, 1) == 0
+    assert L_.lr_rnn_pass_launches(mode, B, L, Hd, Hd, 1) == (B + 63) // 64     # 64 samples per launch of the grid
   L_.lr_rnn_pair_errors()
   out = {}
   try:
@@ -431,7 +451,11 @@ def test_decoder_loop_on_the_cluster_recurrence_equals_the_step_kernels(dev, rnn
       L_.lr_rnn_debug_disable_cluster(off)
       dec.zero_grad()
       e, h, c = enc.clone().requires_grad_(True), h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
-      lp, _, fin = dec.decode_sequence(chars, (h, c) if rnn_type == "LSTM" else h, lens, e, seed=5)
+      with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        lp, _, fin = dec.decode_sequence(chars, (h, c) if rnn_type == "LSTM" else h, lens, e, seed=5)
+      if name == "cluster":     # the one-launch path announces no fallback (rounds 1-5: "LSTM-1536 runs one launch per time step")
+        assert not [w for w in caught if "one launch per time step" in str(w.message)], [str(w.message) for w in caught]
       fins = fin if isinstance(fin, tuple) else (fin,)
       ((lp * wgt).sum() + sum((f * wf).sum() for f in fins)).backward()
       egrad = e.grad if e.grad is not None else torch.zeros_like(e)    # (attention 'none' never reads the encoder states)

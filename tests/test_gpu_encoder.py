@@ -424,11 +424,17 @@ CLUSTER_CASES = [("LSTM", 768, 32, 75, True, None, 1), ("LSTM", 768, 37, 20, Tru
                  # BiLSTM-512 at configs[3]'s B = 64 (16 clusters), 10-member clusters three to an XCD (24), 4-member
                  # ones at B = 130 (33 groups of a unidirectional layer: 64-cluster launches hold them all)
                  ("LSTM", 512, 64, 12, True, "ragged", 1), ("LSTM", 320, 96, 6, True, "ragged", 1),
-                 ("GRU", 128, 130, 5, False, "ragged", 2), ("LSTM", 256, 128, 7, True, "ragged", 1)]
+                 ("GRU", 128, 130, 5, False, "ragged", 2), ("LSTM", 256, 128, 7, True, "ragged", 1),
+                 # round 6: LSTM past 1152 units on the 24 x 8 grid of 192 CUs (lr_rnn_grid.hip): one and two blocks of 32
+                 # samples, both directions (a launch each), a hidden size that pads (1400 -> 1536), more than 64 samples
+                 ("LSTM", 1536, 32, 12, False, "ragged", 1), ("LSTM", 1400, 9, 5, True, "ragged", 1),
+                 ("LSTM", 1280, 70, 4, False, "ragged", 1), ("LSTM", 1156, 40, 6, False, None, 2)]
 # (rnn_type, H, B, bidirectional) -> recurrence launches per layer pass (lr_rnn_pass_launches)
 CLUSTER_LAUNCHES = {("LSTM", 512, 64, True): 1, ("LSTM", 320, 96, True): 1, ("GRU", 128, 130, False): 1,
                     ("LSTM", 256, 128, True): 1, ("LSTM", 768, 37, True): 2, ("LSTM", 768, 70, False): 2,
-                    ("LSTM", 768, 32, True): 1, ("GRU", 704, 70, True): 3, ("GRU", 1100, 40, False): 3}
+                    ("LSTM", 768, 32, True): 1, ("GRU", 704, 70, True): 3, ("GRU", 1100, 40, False): 3,
+                    ("LSTM", 1536, 32, False): 1, ("LSTM", 1400, 9, True): 2, ("LSTM", 1280, 70, False): 2,
+                    ("LSTM", 1156, 40, False): 1}
 
 
 def test_one_launch_recurrence_covers_every_hidden_size_its_storage_holds(dev):
@@ -445,7 +451,9 @@ def test_one_launch_recurrence_covers_every_hidden_size_its_storage_holds(dev):
     assert L.lr_rnn_pair_supported(0, 32, 75, 204, H, 2) == 2, H
   for H in (772, 800, 1024, 1100, 1152):
     assert L.lr_rnn_pair_supported(1, 32, 75, 204, H, 1) == 2 and L.lr_rnn_pair_supported(0, 32, 75, 204, max(H, 868), 1) == 2, H
-  for mode, H in ((1, 1156), (1, 1400), (1, 1536), (0, 1156), (0, 2048), (1, 30)):
+  for H in (1156, 1400, 1536):     # round 6: LSTM past 1152 units on the 24 x 8 grid of 192 CUs (lr_rnn_grid.hip)
+    assert L.lr_rnn_pair_supported(1, 32, 75, 204, H, 1) == 2 and L.lr_rnn_pair_supported(1, 128, 31, 204, H, 1) == 2, H
+  for mode, H in ((1, 1540), (0, 1156), (0, 1536), (0, 2048), (1, 2048), (1, 30)):
     assert L.lr_rnn_pair_supported(mode, 32, 75, 204, H, 1) == 0, (mode, H)
   enc = E.VideoEncoder(16, 2048, rnn_type='LSTM', bidirectional=False, enable_ctc=True, vocab_size=64,
                        char2idx=default_char2idx()).to(dev)
