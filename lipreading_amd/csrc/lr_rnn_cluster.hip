@@ -712,12 +712,14 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
           for (int e = 0; e < VPL; ++e) red[NRED * XB + VPL * lane + e] = v[e];
         } else {
           // one store per lane: the wave writes the destination's whole block.  Each WORD is valid on its own, so it
-          // does not matter whether the bytes land together.
+          // does not matter whether the bytes land together.  (s_nop behind the 16-byte stores: the wait state a VALU
+          // write to a store's data registers needs behind it, which hipcc cannot place behind an asm — lr_rnn_grid.hip
+          // store4 tells how that was found.)
           u32* p = xo + dstm * xdst;
           if constexpr (VPL == 4) {
             const u32x4 w = {xword(v[0], tg), xword(v[1], tg), xword(v[2], tg), xword(v[3], tg)};
-            if (local) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(w) : "memory");   // workgroup scope
-            else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");   // agent scope
+            if (local) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");   // workgroup scope
+            else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");   // agent scope
           } else {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             const u32x2 w = {xword(v[0], tg), xword(v[1], tg)};

@@ -40,9 +40,14 @@ constexpr int GLD = GR + 8;   // ... of the row group's dG (132 dwords)
 #define LRG_MFMA(acc, w, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b))
 
 __device__ __forceinline__ void store4(u32* p, u32x4 w, bool local) {
-  // workgroup scope (`sc0`) keeps the line in this XCD's L2 — only where the readers were verified to sit on it
-  if (local) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(w) : "memory");
-  else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+  // workgroup scope (`sc0`) keeps the line in this XCD's L2 — only where the readers were verified to sit on it.
+  // s_nop: a store of more than 8 bytes reads its data registers late; a VALU write to one of them in the next wait state
+  // changes what some lanes store.  hipcc's hazard recogniser places the wait state behind stores it can see, not behind
+  // an asm: the first cut of the backward kernel re-used the second data register in the very next instruction, and lanes
+  // 12-15 of every row of 16 published an UNTAGGED second word (found with tools/probes/grid_xch_dump.cpp: the row
+  // group waited for it until the time-out).
+  if (local) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
 }
 __device__ __forceinline__ u32x4 xword4(f32x4 v, u32 tg) {
   return (u32x4){xword(v[0], tg), xword(v[1], tg), xword(v[2], tg), xword(v[3], tg)};
@@ -54,8 +59,10 @@ __device__ __forceinline__ bool tags_ok(u32x4 v, u32 tg) {
 // N 16-byte loads at base + i * stride (words), the ones whose bit is set in `want`; polled until every word carries
 // `tg`.  Every load that is still missing a word is asked for again IN PARALLEL (lr_rnn_cluster.hip's scheme).  A thread
 // that has given up (`bad`) issues nothing.
+// `bad` collects WHICH wait gave up (the fault word is tested for != 0 everywhere; the bits are a diagnostic):
+//   1 handshake | 2 forward h gather | 4 forward partial sums | 8 backward partial dh | 16 backward dG gather
 template <int N>
-__device__ __forceinline__ void gather(u32x4 (&g)[N], const u32* base, int stride, unsigned want, u32 tg, int& bad, int tune) {
+__device__ __forceinline__ void gather(u32x4 (&g)[N], const u32* base, int stride, unsigned want, u32 tg, int& bad, int tune, int code) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     g[i] = (u32x4){0u, 0u, 0u, 0u};
@@ -71,7 +78,7 @@ __device__ __forceinline__ void gather(u32x4 (&g)[N], const u32* base, int strid
       if (((pend >> i) & 1u) && tags_ok(g[i], tg)) pend &= ~(1u << i);
     if (!pend) break;
     if (round > SPIN_LIMIT) {
-      bad = 1;
+      bad |= code;
       break;
     }
     for (int w = 0; w < ((tune >> 8) & 0xff); ++w) __builtin_amdgcn_s_sleep(1);
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void rnng_fwd_kernel(
     // ---- (1) the column group's h_{s-1}: 23 x 64 items of four units per block -> hS ---------------------------------
     if (s > 0) {
       u32x4 g[6 * NSB];
-      gather<6 * NSB>(g, hin + hoff, 1024, hwant, tag_of(s - 1), bad, tune);
+      gather<6 * NSB>(g, hin + hoff, 1024, hwant, tag_of(s - 1), bad, tune, 2);
 #pragma unroll
       for (int i = 0; i < 6 * NSB; ++i) {
         if (!((hwant >> i) & 1u)) continue;
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void rnng_fwd_kernel(
     // ---- (4) the seven partial sums addressed to this member, its own, the cell ----------------------------------------
     {
       u32x4 g[8 * NSB];
-      gather<8 * NSB>(g, pin + poff, 1024, pwant, tag_of(s), bad, tune);
+      gather<8 * NSB>(g, pin + poff, 1024, pwant, tag_of(s), bad, tune, 4);
       lr_lds_barrier();   // Pown complete; every wave is done with hS
       const int tnext = time_of(s + 1);
 #pragma unroll
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(256, 1) void rnng_fwd_kernel(
       if (s + 1 < T) fetch_gx(tnext);
     }
   }
-  if (bad && fault) atomicOr(fault, 1);
+  if (bad && fault) atomicOr(fault, bad);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(256, 1) void rnng_bwd_kernel(
     float prod[NSB];
     if (s > 0) {
       u32x4 g[6 * NSB];
-      gather<6 * NSB>(g, din + doff_in, 1024, dwant, tag_of(s - 1), bad, tune);
+      gather<6 * NSB>(g, din + doff_in, 1024, dwant, tag_of(s - 1), bad, tune, 8);
 #pragma unroll
       for (int sb = 0; sb < NSB; ++sb) {
         float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;   // this thread's sources of the block, in FIXED order
@@ -556,7 +563,7 @@ __global__ __launch_bounds__(256, 1) void rnng_bwd_kernel(
     // ---- (3) the row group's dG -> gS ---------------------------------------------------------------------------------
     {
       u32x4 g[8 * NSB];
-      gather<8 * NSB>(g, gin + goff, 1024, gwant, tg, bad, tune);
+      gather<8 * NSB>(g, gin + goff, 1024, gwant, tg, bad, tune, 16);
 #pragma unroll
       for (int i = 0; i < 8 * NSB; ++i) {
         if (!((gwant >> i) & 1u)) continue;
@@ -611,7 +618,7 @@ __global__ __launch_bounds__(256, 1) void rnng_bwd_kernel(
         }
     }
   }
-  if (bad && fault) atomicOr(fault, 1);
+  if (bad && fault) atomicOr(fault, bad);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
