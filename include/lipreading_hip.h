@@ -261,8 +261,9 @@ int lr_step_begin_ctc(float* grad, int64_t n, float* also_zero, const int64_t* c
                       int32_t* label_lens32, int B, int L, lr_stream_t stream);
 void lr_rnn_debug_drop_member(int member);
 void lr_rnn_debug_disable_cluster(int off);
-/* TUNING HOOK of the cluster recurrence's exchange polling: which = 0 forward / 1 backward kernels;
- * first_poll_delay = 64-clock sleeps between a member's publish and its first poll of the others (default 0),
+/* TUNING HOOK of the one-launch recurrences' exchange polling: which = 0 forward / 1 backward cluster kernels; 2 .. 5 the
+ * four gathers of the grid recurrence (LSTM past 1152 units): forward h, forward partial sums, backward partial dh,
+ * backward dG; first_poll_delay = 64-clock sleeps between a member's publish and its first poll of the others (default 0),
  * round_sleep = sleeps between two poll rounds (default 1). */
 void lr_rnn_debug_tune(int which, int first_poll_delay, int round_sleep);
 size_t lr_rnn_reserve_bytes(int mode, int B, int T, int I, int H, int D);

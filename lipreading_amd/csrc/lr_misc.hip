@@ -765,10 +765,13 @@ int lr_debug_wgrad_f32() { return (g_cluster_off >> 2) & 1; }
 int lr_debug_dwih_packed() { return (g_cluster_off >> 3) & 1; }
 // tuning knobs of the cluster recurrence's exchange (lr_rnn_debug_tune): [0] forward, [1] backward; bits 0-7 = 64-clock
 // sleeps before the first poll, bits 8-15 = sleeps between poll rounds
-namespace { int g_tune[2] = {1 << 8, 1 << 8}; }   // (swept on the MI355X: one sleep between rounds, no first-poll delay)
-int lr_debug_tune_value(int which) { return g_tune[which & 1]; }
+// which = 2 .. 5: the grid recurrence's four gathers (lr_rnn_grid.hip): forward h, forward partial sums, backward partial dh,
+// backward dG
+namespace { int g_tune[6] = {1 << 8, 1 << 8, 1 << 8, 1 << 8, 1 << 8, 1 << 8}; }   // (swept on the MI355X: one sleep between rounds, no first-poll delay)
+int lr_debug_tune_value(int which) { return g_tune[which >= 0 && which < 6 ? which : 0]; }
 extern "C" void lr_rnn_debug_tune(int which, int first_poll_delay, int round_sleep) {
-  g_tune[which & 1] = (first_poll_delay & 0xff) | ((round_sleep & 0xff) << 8);
+  if (which < 0 || which >= 6) return;
+  g_tune[which] = (first_poll_delay & 0xff) | ((round_sleep & 0xff) << 8);
 }
 
 extern "C" int lr_rnn_pair_errors(void) {

@@ -11,9 +11,9 @@
 // samples are the N dimension of the MFMAs (two 16-sample sub-blocks per block), the weights the A operand, so a
 // lane's four accumulator registers are the four gates of one (sample, unit) — one 16-byte exchange item.
 //
-// Per step, forward:  gather h[K_c] from the column group (XCD-local, 23 x 1 KB per block) -> 192 MFMAs per wave and
+// Per step, forward:  gather h[K_c] from the column group (23 x 1 KB per block, across XCDs) -> 192 MFMAs per wave and
 // block (all four cross terms of (W_hi + W_lo)(h_hi + h_lo), fp32 accumulate) -> publish the partial gate sums to the
-// seven row-group partners (4 KB each per block, across XCDs) -> gather the seven addressed to this member, add its
+// seven row-group partners (4 KB each per block, inside the XCD) -> gather the seven addressed to this member, add its
 // own, run the cell (nn.LSTM's arithmetic, better_model.py:47-49,74), publish h.  Backward mirrors it: partial dh
 // reduce-scatter inside the column group, cell backward, dG all-gather inside the row group, W^T dG.  The exchange uses
 // lr_rnn_xch.h's self-tagged words (fp32 rounded to 22 mantissa bits + a 2-bit step tag; two parity slots); waits are
@@ -63,6 +63,7 @@ __device__ __forceinline__ bool tags_ok(u32x4 v, u32 tg) {
 //   1 handshake | 2 forward h gather | 4 forward partial sums | 8 backward partial dh | 16 backward dG gather
 template <int N>
 __device__ __forceinline__ void gather(u32x4 (&g)[N], const u32* base, int stride, unsigned want, u32 tg, int& bad, int tune, int code) {
+  for (int w = 0; w < (tune & 0xff); ++w) __builtin_amdgcn_s_sleep(1);   // (tuning knob: sleeps before the first poll)
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     g[i] = (u32x4){0u, 0u, 0u, 0u};
@@ -88,19 +89,29 @@ __device__ __forceinline__ void gather(u32x4 (&g)[N], const u32* base, int strid
   }
 }
 
-// do the 24 members of this column group sit on one XCD?  (a speed matter: see lr_rnn_cluster.hip xcd_handshake)
-__device__ __forceinline__ void column_handshake(u32* xid, int m, int c, int tid, int* s_local, int& bad) {
+// -DLRG_TIMING (tools/build_variant.sh; never in the product build): thread 0 of every member stamps the shader clock at
+// the phase boundaries of every step; tools/probes/grid_timing.py reads them back through lr_rnn_grid_debug_times
+#ifdef LRG_TIMING
+__device__ long long g_lrg_times[2][NM][64][8];
+#define LRG_T(pass, k) do { if (threadIdx.x == 0 && s < 64) g_lrg_times[pass][blockIdx.x][s][k] = clock64(); } while (0)
+#else
+#define LRG_T(pass, k) do { } while (0)
+#endif
+
+// do the members first, first + stride, ... (count of them: this member's column group or row group) sit on one XCD?
+// (a speed matter: see lr_rnn_cluster.hip xcd_handshake)
+__device__ __forceinline__ void group_handshake(u32* xid, int m, int first, int stride, int count, int tid, int* s_local, int& bad) {
   if (tid == 0) {
     *s_local = 1;
     publish(xid + m, 0x100u | (u32)xcc_id(), false);
   }
   __syncthreads();
-  if (tid < R) {
-    u32 g = peek(xid + C * tid + c);
+  if (tid < count) {
+    u32 g = peek(xid + first + stride * tid);
     int n = 0;
     while (!(g & 0x100u) && n++ < SPIN_LIMIT) {
       __builtin_amdgcn_s_sleep(2);
-      g = peek(xid + C * tid + c);
+      g = peek(xid + first + stride * tid);
     }
     if (!(g & 0x100u)) bad = 1;
     if ((int)(g & 0xf) != xcc_id() || bad) *s_local = 0;
@@ -176,12 +187,18 @@ template <int NSB>
 __global__ __launch_bounds__(256, 1) void rnng_fwd_kernel(
     float* __restrict__ gates, float* __restrict__ extra, float* __restrict__ y, const bf16x8* __restrict__ wpk,
     const float* __restrict__ h0, const float* __restrict__ c0, const int32_t* __restrict__ lens, u32* __restrict__ xch,
-    int32_t* __restrict__ fault, int drop, int tune, int b0, int d, int B, int T, int D, int H) {
+    int32_t* __restrict__ fault, int drop, int tune, int tune2, int b0, int d, int B, int T, int D, int H) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* hS = reinterpret_cast<bf16_t*>(smem);                                            // [NSB][2][32][HLD]
   float* Pown = reinterpret_cast<float*>(smem + (size_t)NSB * 2 * SB * HLD * 2);          // [NSB][256][4]
   __shared__ int s_local;
-  const int m = blockIdx.x, c = m % C, r = m / C;
+  // Placement, forward: the ROW group on one XCD.  The dispatcher places blocks x, x + 8, ... on XCD x (observed): block
+  // 8 j + x is member (r = 3 x + j / 8, c = j % 8), so XCD x holds row groups 3 x .. 3 x + 2 whole.  What crosses XCDs is
+  // then the h all-gather (1 KB written, 23 KB read per member and block) and what stays inside one is the partial-sum
+  // exchange (28 KB written, 28 KB read).  The first cut had the column group on an XCD instead, as the backward does:
+  // every member then wrote its 28 KB through to the fabric in the same microsecond (5.4 MB chip-wide per step), and the
+  // partial-sum gather took 3.0 us of an 8.2 us step.
+  const int r = 3 * (blockIdx.x & 7) + (blockIdx.x >> 6), c = (blockIdx.x >> 3) & 7, m = r * C + c;
   if (m == drop) return;   // test hook (lr_rnn_debug_drop_member): the others must time out and report
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, kg = lane >> 4;
@@ -263,7 +280,7 @@ __global__ __launch_bounds__(256, 1) void rnng_fwd_kernel(
   for (int i = 0; i < 8 * NSB; ++i)
     if ((i & 7) != c) pwant |= 1u << i;
   int bad = 0;
-  column_handshake(XID, m, c, tid, &s_local, bad);   // (also: hS complete)
+  group_handshake(XID, m, r * C, 1, C, tid, &s_local, bad);   // the row group's 8 members (also: hS complete)
   const bool local = s_local != 0;
 
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the loads in front of the loop (lr_rnn_cluster.hip explains)
@@ -271,6 +288,7 @@ __global__ __launch_bounds__(256, 1) void rnng_fwd_kernel(
     const int t = time_of(s);
     int hoff = __builtin_amdgcn_readfirstlane(((s - 1) & 1) * hslot), poff = __builtin_amdgcn_readfirstlane((s & 1) * pslot);
     asm volatile("" : "+s"(hoff), "+s"(poff));
+    LRG_T(0, 0);
     // ---- (1) the column group's h_{s-1}: 23 x 64 items of four units per block -> hS ---------------------------------
     if (s > 0) {
       u32x4 g[6 * NSB];
@@ -287,20 +305,31 @@ __global__ __launch_bounds__(256, 1) void rnng_fwd_kernel(
         *reinterpret_cast<uint2*>(dst + SB * HLD) = make_uint2(lo0, lo1);
       }
     }
+    LRG_T(0, 1);
     lr_lds_barrier();   // hS complete (the own member's columns were written by the cell of step s - 1)
+    LRG_T(0, 2);
     // ---- (2) the product, block by block; (3) its partial sums go out as soon as a block is done -----------------------
 #pragma unroll
     for (int sb = 0; sb < NSB; ++sb) {
       f32x4 acc[4][2];
       const bf16_t* hb = hS + (sb * 2) * SB * HLD + col * HLD + kg * 8;
+      // the B operands of k step q + 1 are read while the 32 MFMAs of k step q issue (left to itself hipcc re-used one
+      // register set and put every k step's four ds_read_b128 in front of its MFMAs: their latency six times per block,
+      // a third of the product's time in the first cut)
+      bf16x8 bv[2][2], bn[2][2];   // [plane][sub-block]
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int sbb = 0; sbb < 2; ++sbb) bv[pl][sbb] = *reinterpret_cast<const bf16x8*>(hb + (pl * SB + 16 * sbb) * HLD);
 #pragma unroll
       for (int q = 0; q < FQ; ++q) {
-        bf16x8 bv[2][2];   // [plane][sub-block]
+        if (q + 1 < FQ) {
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
+          for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-          for (int sbb = 0; sbb < 2; ++sbb)
-            bv[pl][sbb] = *reinterpret_cast<const bf16x8*>(hb + (pl * SB + 16 * sbb) * HLD + 32 * q);
+            for (int sbb = 0; sbb < 2; ++sbb)
+              bn[pl][sbb] = *reinterpret_cast<const bf16x8*>(hb + (pl * SB + 16 * sbb) * HLD + 32 * (q + 1));
+        }
 #pragma unroll
         for (int wp = 0; wp < 2; ++wp)
 #pragma unroll
@@ -312,6 +341,12 @@ __global__ __launch_bounds__(256, 1) void rnng_fwd_kernel(
                 if (q == 0 && wp == 0 && hp == 0) LRG_MFMA0(acc[tt][sbb], Wf[tt][0][0], bv[0][sbb]);
                 else LRG_MFMA(acc[tt][sbb], Wf[tt][q][wp], bv[hp][sbb]);
               }
+        if (q + 1 < FQ) {
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int sbb = 0; sbb < 2; ++sbb) bv[pl][sbb] = bn[pl][sbb];
+        }
       }
       LR_MFMA_DRAIN();
 #pragma unroll
@@ -326,14 +361,17 @@ __global__ __launch_bounds__(256, 1) void rnng_fwd_kernel(
           int cd, item;
           fwd_acc_dest(4 * wave + tt, sbb, lane, cd, item);   // (cd is the same for the whole wave)
           if (cd == c) *reinterpret_cast<f32x4*>(Pown + (sb * 256 + item) * 4) = acc[tt][sbb];
-          else store4(pout + poff + (cd * NSB + sb) * (C * 1024) + item * 4, xword4(acc[tt][sbb], tg), false);
+          else store4(pout + poff + (cd * NSB + sb) * (C * 1024) + item * 4, xword4(acc[tt][sbb], tg), local);
         }
     }
+    LRG_T(0, 3);
     // ---- (4) the seven partial sums addressed to this member, its own, the cell ----------------------------------------
     {
       u32x4 g[8 * NSB];
-      gather<8 * NSB>(g, pin + poff, 1024, pwant, tag_of(s), bad, tune, 4);
+      gather<8 * NSB>(g, pin + poff, 1024, pwant, tag_of(s), bad, tune2, 4);
+      LRG_T(0, 4);
       lr_lds_barrier();   // Pown complete; every wave is done with hS
+      LRG_T(0, 5);
       const int tnext = time_of(s + 1);
 #pragma unroll
       for (int sb = 0; sb < NSB; ++sb) {
@@ -354,7 +392,13 @@ __global__ __launch_bounds__(256, 1) void rnng_fwd_kernel(
         float h = live ? og * fast_tanh(cn) : 0.f;
         creg[sb] = cn;
         const u32 w = xword(h, tag_of(s));
-        publish(hmine + (s & 1) * hslot + sb * (R * 256), w, local);   // first: the column group is waiting for it
+        {   // first: the column group (on the other XCDs) is waiting for it.  Four units of a sample sit in the four lanes
+            // of a quad: the quad's first lane collects them (DPP quad_perm) and writes ONE 16-byte item — a scalar
+            // write-through store is one fabric write each (MI355X_MICROARCH.md: a dword costs ~6x a dwordx4 per byte)
+          const u32x4 w4 = {w, (u32)__builtin_amdgcn_mov_dpp((int)w, 0x55, 0xf, 0xf, true), (u32)__builtin_amdgcn_mov_dpp((int)w, 0xaa, 0xf, 0xf, true),
+                            (u32)__builtin_amdgcn_mov_dpp((int)w, 0xff, 0xf, 0xf, true)};
+          if ((tid & 3) == 0) store4(hmine + (s & 1) * hslot + sb * (R * 256), w4, false);
+        }
         h = xval(w);                                                   // the state everyone uses, this member included
         bf16_t hi, lo;
         split_bf16(h, hi, lo);
@@ -374,6 +418,7 @@ __global__ __launch_bounds__(256, 1) void rnng_fwd_kernel(
         }
       }
       if (s + 1 < T) fetch_gx(tnext);
+      LRG_T(0, 6);
     }
   }
   if (bad && fault) atomicOr(fault, bad);
@@ -387,13 +432,16 @@ __global__ __launch_bounds__(256, 1) void rnng_bwd_kernel(
     const float* __restrict__ gates, const float* __restrict__ extra, const float* __restrict__ dy,
     const float* __restrict__ dh_n, const float* __restrict__ dc_n, float* __restrict__ dG, float* __restrict__ dh0,
     float* __restrict__ dc0, const float* __restrict__ c0, const bf16x8* __restrict__ wpk,
-    const int32_t* __restrict__ lens, u32* __restrict__ xch, int32_t* __restrict__ fault, int drop, int tune, int b0, int d,
-    int B, int T, int D, int H) {
+    const int32_t* __restrict__ lens, u32* __restrict__ xch, int32_t* __restrict__ fault, int drop, int tune, int tune2, int b0,
+    int d, int B, int T, int D, int H) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* gS = reinterpret_cast<bf16_t*>(smem);                                                   // [NSB][2][32][GLD]
   float* red = reinterpret_cast<float*>(smem + (size_t)NSB * 2 * SB * GLD * 2);                  // [NSB][4][256]
   float* ownD = red + NSB * 4 * 256;                                                             // [NSB][256]
   __shared__ int s_local;
+  // Placement, backward: the COLUMN group on one XCD (block b = member (r = b / 8, c = b % 8) on XCD b % 8): the partial dh
+  // reduce-scatter (23 KB written and read per member and block) stays inside it, the dG all-gather (4 KB written, 28 KB
+  // read) crosses — the light writer crosses in both passes.
   const int m = blockIdx.x, c = m % C, r = m / C;
   if (m == drop) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -471,7 +519,7 @@ __global__ __launch_bounds__(256, 1) void rnng_bwd_kernel(
   for (int i = 0; i < 8 * NSB; ++i)
     if ((i & 7) != c) gwant |= 1u << i;
   int bad = 0;
-  column_handshake(XID, m, c, tid, &s_local, bad);   // (also: gS / ownD cleared)
+  group_handshake(XID, m, c, C, R, tid, &s_local, bad);   // the column group's 24 members (also: gS / ownD cleared)
   const bool local = s_local != 0;
 
   const int nsteps = dh0 ? T + 1 : T;   // with dh0: one more reduce-scatter after the last step
@@ -481,6 +529,7 @@ __global__ __launch_bounds__(256, 1) void rnng_bwd_kernel(
     int doff_in = __builtin_amdgcn_readfirstlane(((s - 1) & 1) * dslot), goff = __builtin_amdgcn_readfirstlane((s & 1) * gslot),
         doff_out = __builtin_amdgcn_readfirstlane((s & 1) * dslot);
     asm volatile("" : "+s"(doff_in), "+s"(goff), "+s"(doff_out));
+    LRG_T(1, 0);
     // ---- (1) W_hh^T dG of the step before, for this member's units: 23 partial sums per block + its own ---------------
     float prod[NSB];
     if (s > 0) {
@@ -502,7 +551,9 @@ __global__ __launch_bounds__(256, 1) void rnng_bwd_kernel(
         *reinterpret_cast<float4*>(red + (sb * 4 + wave) * 256 + 4 * lane) = make_float4(p0, p1, p2, p3);
       }
     }
+    LRG_T(1, 1);
     lr_lds_barrier();   // `red`, ownD complete; every wave is done with gS
+    LRG_T(1, 2);
 #pragma unroll
     for (int sb = 0; sb < NSB; ++sb) {
       prod[sb] = 0.f;
@@ -560,10 +611,11 @@ __global__ __launch_bounds__(256, 1) void rnng_bwd_kernel(
       }
     }
     if (s + 1 < T) fetch(time_of(s + 1));
+    LRG_T(1, 3);
     // ---- (3) the row group's dG -> gS ---------------------------------------------------------------------------------
     {
       u32x4 g[8 * NSB];
-      gather<8 * NSB>(g, gin + goff, 1024, gwant, tg, bad, tune, 16);
+      gather<8 * NSB>(g, gin + goff, 1024, gwant, tg, bad, tune2, 16);
 #pragma unroll
       for (int i = 0; i < 8 * NSB; ++i) {
         if (!((gwant >> i) & 1u)) continue;
@@ -576,20 +628,28 @@ __global__ __launch_bounds__(256, 1) void rnng_bwd_kernel(
         *reinterpret_cast<uint2*>(dst + SB * GLD) = make_uint2(lo0, lo1);
       }
     }
+    LRG_T(1, 4);
     lr_lds_barrier();   // gS complete; `red` and ownD free again
+    LRG_T(1, 5);
     // ---- (4) partial dh of this column group's 192 units, published to their owners ------------------------------------
 #pragma unroll
     for (int sb = 0; sb < NSB; ++sb) {
       f32x4 acc[3][2];
       const bf16_t* gb = gS + (sb * 2) * SB * GLD + col * GLD + kg * 8;
+      bf16x8 bv[2][2], bn[2][2];   // (operands of k step q + 1 read under the MFMAs of k step q: see the forward kernel)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int sbb = 0; sbb < 2; ++sbb) bv[pl][sbb] = *reinterpret_cast<const bf16x8*>(gb + (pl * SB + 16 * sbb) * GLD);
 #pragma unroll
       for (int q = 0; q < BQ; ++q) {
-        bf16x8 bv[2][2];
+        if (q + 1 < BQ) {
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
+          for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-          for (int sbb = 0; sbb < 2; ++sbb)
-            bv[pl][sbb] = *reinterpret_cast<const bf16x8*>(gb + (pl * SB + 16 * sbb) * GLD + 32 * q);
+            for (int sbb = 0; sbb < 2; ++sbb)
+              bn[pl][sbb] = *reinterpret_cast<const bf16x8*>(gb + (pl * SB + 16 * sbb) * GLD + 32 * (q + 1));
+        }
 #pragma unroll
         for (int wp = 0; wp < 2; ++wp)
 #pragma unroll
@@ -601,6 +661,12 @@ __global__ __launch_bounds__(256, 1) void rnng_bwd_kernel(
                 if (q == 0 && wp == 0 && hp == 0) LRG_MFMA0(acc[jj][sbb], Wb[jj][0][0], bv[0][sbb]);
                 else LRG_MFMA(acc[jj][sbb], Wb[jj][q][wp], bv[hp][sbb]);
               }
+        if (q + 1 < BQ) {
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int sbb = 0; sbb < 2; ++sbb) bv[pl][sbb] = bn[pl][sbb];
+        }
       }
       LR_MFMA_DRAIN();
 #pragma unroll
@@ -617,6 +683,7 @@ __global__ __launch_bounds__(256, 1) void rnng_bwd_kernel(
           else store4(dout + doff_out + (rd * NSB + sb) * (R * 256) + item * 4, xword4(acc[jj][sbb], tg), local);
         }
     }
+    LRG_T(1, 6);
   }
   if (bad && fault) atomicOr(fault, bad);
 }
@@ -643,14 +710,14 @@ int fwd_launch1(float* gates, float* extra, float* y, const void* wpack, const f
     attr_set = true;
   }
   int32_t* fault = lr_fault_words();
-  const int drop = lr_debug_drop_member_value(), tune = lr_debug_tune_value(0);
+  const int drop = lr_debug_drop_member_value(), tune = lr_debug_tune_value(2), tune2 = lr_debug_tune_value(3);
   hipEvent_t e0, e1;
   if (prof && lr_prof_next(LR_PROF_RNN_FWD, &e0, &e1))
     hipExtLaunchKernelGGL((rnng_fwd_kernel<NSB>), dim3(NM), dim3(256), fwd_lds<NSB>(), stream, e0, e1, 0, gates, extra, y,
-                          (const bf16x8*)wpack, h0, c0, lens, (u32*)xch, fault, drop, tune, b0, d, B, T, D, H);
+                          (const bf16x8*)wpack, h0, c0, lens, (u32*)xch, fault, drop, tune, tune2, b0, d, B, T, D, H);
   else
     hipLaunchKernelGGL((rnng_fwd_kernel<NSB>), dim3(NM), dim3(256), fwd_lds<NSB>(), stream, gates, extra, y, (const bf16x8*)wpack,
-                       h0, c0, lens, (u32*)xch, fault, drop, tune, b0, d, B, T, D, H);
+                       h0, c0, lens, (u32*)xch, fault, drop, tune, tune2, b0, d, B, T, D, H);
   return lr_launch_status();
 }
 
@@ -665,18 +732,25 @@ int bwd_launch1(const float* gates, const float* extra, const float* dy, const f
     attr_set = true;
   }
   int32_t* fault = lr_fault_words();
-  const int drop = lr_debug_drop_member_value(), tune = lr_debug_tune_value(1);
+  const int drop = lr_debug_drop_member_value(), tune = lr_debug_tune_value(4), tune2 = lr_debug_tune_value(5);
   hipEvent_t e0, e1;
   if (prof && lr_prof_next(LR_PROF_RNN_BWD, &e0, &e1))
     hipExtLaunchKernelGGL((rnng_bwd_kernel<NSB>), dim3(NM), dim3(256), bwd_lds<NSB>(), stream, e0, e1, 0, gates, extra, dy, dh_n,
-                          dc_n, dG, dh0, dc0, c0, (const bf16x8*)wpack, lens, (u32*)xch, fault, drop, tune, b0, d, B, T, D, H);
+                          dc_n, dG, dh0, dc0, c0, (const bf16x8*)wpack, lens, (u32*)xch, fault, drop, tune, tune2, b0, d, B, T, D, H);
   else
     hipLaunchKernelGGL((rnng_bwd_kernel<NSB>), dim3(NM), dim3(256), bwd_lds<NSB>(), stream, gates, extra, dy, dh_n, dc_n, dG, dh0,
-                       dc0, c0, (const bf16x8*)wpack, lens, (u32*)xch, fault, drop, tune, b0, d, B, T, D, H);
+                       dc0, c0, (const bf16x8*)wpack, lens, (u32*)xch, fault, drop, tune, tune2, b0, d, B, T, D, H);
   return lr_launch_status();
 }
 
 }  // namespace
+
+#ifdef LRG_TIMING
+extern "C" int lr_rnn_grid_debug_times(long long* out_host) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_lrg_times), sizeof(long long) * 2 * NM * 64 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // shapes this file covers: LSTM (G = 4), 1152 < H <= 1536
 int lr_rnn_grid_shape(int G, int H) { return G == 4 && H > 1152 && H <= HP && H % 4 == 0 ? 1 : 0; }

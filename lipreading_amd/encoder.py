@@ -89,8 +89,8 @@ def flush_deferred():
 # (rnn_type, H, why) triples whose fall-back to the per-step kernels has been announced (one warning each)
 _fallback_noted = set()
 _WHY = {
-    1: "there is no one-launch kernel for this shape (GRU / LSTM with a hidden size that is a multiple of 4, up to the "
-       "largest cluster: lr_rnn_cluster.hip)",
+    1: "there is no one-launch kernel for this shape (GRU / LSTM with a hidden size that is a multiple of 4: up to 1152 "
+       "units on clusters, lr_rnn_cluster.hip; LSTM up to 1536 on the 192-CU grid, lr_rnn_grid.hip)",
     2: "the one-launch recurrences were switched off for this process (lr_rnn_one_launch_enable(0): lipreading_amd.train "
        "does that after repeated time-outs, see its own warning)",
     3: "the test hook lr_rnn_debug_disable_cluster is set",
@@ -369,7 +369,9 @@ class VideoEncoder(nn.Module):
     #   'f32'    one launch per time step, exact fp32 MFMA — every shape
     #   'split'  ONE launch per layer pass, fp32-faithful (W_hh and the state as bf16 hi + lo planes, ~1e-6
     #            of the fp32 product): a cluster of ceil(H / 32) CUs per (direction, 8 samples) (lr_rnn_cluster.hip) —
-    #            every H the clusters hold (16-unit members past 864 / 768); larger layers as 'f32' (announced once)
+    #            every H the clusters hold (16-unit members past 864 / 768); LSTM past 1152 up to 1536 units (the
+    #            decoders behind BiLSTM-700 / 768) on one 24 x 8 grid of 192 CUs (lr_rnn_grid.hip); larger layers as
+    #            'f32' (announced once)
     #   'auto'   (default) same as 'split': reference-faithful numerics at the one-launch speed
     self.recurrence = 'auto'
     if self.enable_ctc:
