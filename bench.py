@@ -984,6 +984,47 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
   return res
 
 
+def scaling_model(legs, dist_overhead_ms=0.06):
+  """MODELLED, NOT MEASURED (gpurun reaches one GPU; the driver's 8-GPU runs are the measurement): what the data-parallel
+  pixel step would cost on 2 / 4 / 8 GPUs of one node, from what CAN be measured on one — the per-rank step at the batch
+  sizes a weak (B = 32 per GPU) and a strong (configs[3]: 64 clips in total) run put on a rank, the conv backward window
+  the large bucket hides under, the one-rank price of the exchange path — and an alpha-beta model of RCCL's ring
+  all-reduce over xGMI whose two constants are ASSUMPTIONS, given as a slow and a fast case.
+
+  legs: {B: {"ms": step time, "conv_backward_us": sum of the stand-alone conv backward kernels}}."""
+  enc_bytes, conv_bytes = 27.7e6, 1.3e6            # distributed.GradSync.groups_for_pixel_model's two buckets
+  cases = {"slow": {"busbw_GBps": 120.0, "alpha_us": {2: 30.0, 4: 45.0, 8: 60.0}},     # one ring, one xGMI link at ~0.8 of 153 GB/s
+           "fast": {"busbw_GBps": 300.0, "alpha_us": {2: 20.0, 4: 30.0, 8: 40.0}}}     # several rings over the 7 links
+  def t_ar(n, nbytes, case):
+    return case["alpha_us"][n] * 1e-3 + 2.0 * (n - 1) / n * nbytes / (case["busbw_GBps"] * 1e9) * 1e3    # ms
+  def exposed(n, B, case):
+    window = legs[B]["conv_backward_us"] * 1e-3    # the [encoder] bucket leaves when the conv backward starts and hides under it
+    return max(0.0, t_ar(n, enc_bytes, case) - window) + t_ar(n, conv_bytes, case) + dist_overhead_ms
+  out = {"label": "MODELLED, NOT MEASURED", "regime": "pixels",
+         "measured_on_one_gpu": {str(b): {"ms_per_step": round(v["ms"], 4), "conv_backward_window_ms": round(v["conv_backward_us"] * 1e-3, 3)}
+                                 for b, v in sorted(legs.items())},
+         "assumptions": {
+             "all_reduce": "T(n, S) = alpha(n) + 2 (n - 1) / n * S / busbw; constants NOT measured here: " + json.dumps(cases),
+             "buckets": "[conv] 1.3 MB leaves at the end of backward (fully exposed); [encoder] 27.7 MB leaves when the conv "
+                        "backward starts and is exposed only where it outlasts that window (distributed.groups_for_pixel_model)",
+             "exchange_path_overhead_ms": dist_overhead_ms,
+             "exchange_path_overhead_source": "LIPREADING_BENCH_FORCE_DIST=1 against the plain step on one GPU "
+                                              "(profiles/r05_bench_forcedist.json: +0.04 .. +0.07 ms)",
+             "not_modelled": "RCCL's ring kernels sharing compute units and HBM with the conv backward they hide under; "
+                             "stragglers; host launch jitter across ranks; the 'mean' quirk of ctc_loss on ragged shards"},
+         "weak_efficiency_B32_per_gpu": {}, "strong_efficiency_global_batch_64": {}}
+  for n in (2, 4, 8):
+    w, st = {}, {}
+    for name, case in cases.items():
+      w[name] = round(legs[32]["ms"] / (legs[32]["ms"] + exposed(n, 32, case)), 3)
+      b = 64 // n
+      if b in legs and 64 in legs:
+        st[name] = round(legs[64]["ms"] / (n * (legs[b]["ms"] + exposed(n, b, case))), 3)
+    out["weak_efficiency_B32_per_gpu"][str(n)] = w
+    out["strong_efficiency_global_batch_64"][str(n)] = st or None
+  return out
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -1008,6 +1049,9 @@ def main():
                   help="landmarks_attn: rnn_dropout of the flag file (config/archive/experiments/ecd/*: 0.3).  With the one "
                        "recurrent layer every shipped config has, nn.LSTM / nn.GRU apply no dropout (it acts BETWEEN "
                        "layers): accepted so that a config can be quoted as shipped, and passed on to both modules")
+  ap.add_argument("--model-scaling", action="store_true",
+                  help="one GPU only: also time the pixel step at the per-rank batches of a strong-scaling run (8, 16, 64) and "
+                       "print a MODELLED (not measured) 2/4/8-GPU weak and strong efficiency under `scaling_model`")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-budget", type=float, default=12.0,
                   help="seconds of timed CPU-oracle steps per regime (never fewer than 10 steps)")
@@ -1089,6 +1133,20 @@ def main():
             name: {"note": notes[name], "value": o["value"], "unit": "frames/s", "ms_per_step": o["ms_per_step"],
                    "final_loss": round(o["loss"], 6), "final_loss_delta_vs_default": round(o["loss"] - base_loss, 7)}
             for name, o in options.items()}
+    if world == 1 and args.model_scaling and not DIST_ON:
+      import copy
+      legs = {}
+      conv_bwd = ("conv2_dgrad", "conv3_dgrad", "conv1_wgrad", "conv2_wgrad", "conv3_wgrad")
+      for b in (8, 16, 32, 64):
+        if b == args.batch and head["regime"] == "pixels":
+          r = head
+        else:
+          a2 = copy.copy(args)
+          a2.batch = b
+          r = run_regime(a2, "pixels", world, rank, dev)
+        by = (r.get("roofline") or {}).get("avg_launch_us_by_kernel") or {}
+        legs[b] = {"ms": r["ms_per_step"], "conv_backward_us": sum(by.get(k, 0.0) for k in conv_bwd)}
+      out["scaling_model"] = scaling_model(legs)
     if world == 1 and not args.no_cpu_baseline:
       # parity first (the metric's "+ CTC-loss parity"): HIP vs oracle on identical inputs and weights
       by_regime = {r["regime"]: r for r in results}

@@ -228,3 +228,68 @@ def test_one_rank_exchange_path_costs_what_it_measured(dev):
   print("one-rank exchange path: pixels %.4f -> %.4f ms, landmarks %.4f -> %.4f ms" % (px0, px1, lm0, lm1))
   assert px1 <= px0 + 0.09, (px0, px1)
   assert lm1 <= lm0 + 0.045, (lm0, lm1)
+
+
+@pytest.mark.parametrize("rnn_type,H,bi", [("GRU", 864, True), ("LSTM", 768, True), ("LSTM", 1536, False)])
+def test_gradient_all_reduce_on_the_side_stream_beside_the_cu_hungriest_recurrences(dev, pg, rnn_type, H, bi):
+  """The co-residency assumption of the data-parallel design, on the shapes that leave the fewest compute units free: a
+  one-launch recurrence needs ALL of its workgroups resident at once — 8 x 27 = 216 for BiGRU-864, 8 x 24 = 192 for
+  BiLSTM-768 (BASELINE configs[2]), 192 for the LSTM-1536 grid (the ecd family's decoder) — while GradSync's side stream
+  runs the step's large all-reduce: the [encoder] bucket of the pixel model, 27.7 MB (distributed.groups_for_pixel_model).
+  Here the REAL collective (torch.distributed 'nccl' = RCCL on a process group of this GPU; a world of one moves the
+  bytes without a ring) and, because a ring kernel of an 8-GPU node also holds compute units for the length of the
+  transfer, a foreign kernel of 48 workgroups x 350 us beside it (27.7 MB x 2 x 7/8 over ~150 GB/s of ring bandwidth).
+  Launched from the side stream right before every forward and every backward pass of the layer, five steps in a row.
+  Asserted: no member ever timed out, bit-identical results to the undisturbed run, and a bounded price — the passes may
+  start late (members wait for compute units the foreign kernel holds), never hang."""
+  from lipreading_amd import _C
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.encoder import VideoEncoder
+  L = _C.lib()
+  torch.manual_seed(61)
+  enc = VideoEncoder(64, H, rnn_type=rnn_type, bidirectional=bi, enable_ctc=True, vocab_size=64,
+                     char2idx=default_char2idx()).to(dev)
+  g = torch.Generator().manual_seed(62)
+  B, T = 32, 31
+  x = torch.randn(B, T, 64, 1, generator=g).to(dev)
+  lens = torch.full((B,), T)
+  wgt = torch.randn(B, T, 65, generator=g).to(dev)
+  assert L.lr_rnn_one_launch_status({"GRU": 0, "LSTM": 1}[rnn_type], B, T, 64, H, 2 if bi else 1) == 0
+  bucket = torch.randn(27_700_000 // 4, device=dev)      # the [encoder] bucket's size
+  side = torch.cuda.Stream()
+  L.lr_rnn_pair_errors()
+
+  def exchange():
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      dist.all_reduce(bucket)
+      _C.check(L.lr_debug_busy(48, 32 * 1024, 350, _C.stream_handle()), "lr_debug_busy")
+
+  def step(disturbed):
+    enc.zero_grad()
+    if disturbed:
+      exchange()
+    lp, hid, _ = enc(x, lens, max_len=T)
+    if disturbed:
+      exchange()
+    ((lp * wgt).sum() + hid.pow(2).sum()).backward()
+    return [lp.detach().clone(), hid.detach().clone()] + [p.grad.clone() for p in enc.parameters()]
+
+  def timed(disturbed, n=5):
+    step(disturbed)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+      out = step(disturbed)
+    e1.record()                       # (the main stream only: what the step's critical path sees)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n, out
+  t_plain, ref = timed(False)
+  t_dist, got = timed(True)
+  assert L.lr_rnn_pair_errors() == 0
+  for a, b in zip(ref, got):
+    assert torch.equal(a, b)
+  print("%s-%d beside a 27.7 MB all-reduce + 48 foreign workgroups: %.3f ms per step, %.3f undisturbed" % (rnn_type, H, t_dist, t_plain))
+  # the foreign kernel holds its CUs for 0.35 ms twice per step: a pass may have to wait that long, never longer
+  assert t_dist <= t_plain + 2 * 0.45, (t_plain, t_dist)
