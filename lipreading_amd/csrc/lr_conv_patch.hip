@@ -43,6 +43,20 @@ constexpr int P2_BDIST = 2;                        // taps between a B fragment'
 
 constexpr int kChipCUs = 256;                      // one workgroup of this kernel per CU
 
+// -DLRP_TIMING (tools/build_variant.sh; never in the product build): thread 0 of every workgroup adds up the shader
+// clock between the phase boundaries of its tile: [0] fill (until the barrier behind it), [1] taps, [2] epilogue, [3] whole
+// tile, [4] tiles; tools/probes/conv_patch_timing.py reads them back through lr_conv_patch_debug_times
+#ifdef LRP_TIMING
+__device__ long long g_lrp_times[4096][8];
+#define LRP_T0() long long lrp_t_ = clock64(), lrp_t0_ = lrp_t_
+#define LRP_T(k) do { const long long n_ = clock64(); if (threadIdx.x == 0) g_lrp_times[blockIdx.x & 4095][k] += n_ - lrp_t_; lrp_t_ = n_; } while (0)
+#define LRP_TEND() do { if (threadIdx.x == 0) { g_lrp_times[blockIdx.x & 4095][3] += clock64() - lrp_t0_; g_lrp_times[blockIdx.x & 4095][4] += 1; } } while (0)
+#else
+#define LRP_T0() do { } while (0)
+#define LRP_T(k) do { } while (0)
+#define LRP_TEND() do { } while (0)
+#endif
+
 // One tile.  SPLIT = false: the 4-frame tile described above, wave w = frame f0 + w with all 6 x NT accumulators.
 // SPLIT = true (the launch's LAST tiles, see conv_patch_kernel): a tile of FT = 1 (NT = 2) or 2 (NT = 1) frames
 // whose accumulator tiles are dealt to the four waves — three row tiles x one column tile each — so that it takes
@@ -101,8 +115,10 @@ __device__ __forceinline__ void conv_patch_tile(unsigned char* __restrict__ patc
       *reinterpret_cast<uint4*>(patch + (u >> 4) * P2_RS + (q < 2 ? q : P2_W + q) * 64 + (u & 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
     }
   }
+  LRP_T0();
   for (int cg = 0; cg < CG; ++cg) {
     if (cg > 0) __syncthreads();   // every wave is done with the previous channel group's patch
+    LRP_T(1);
     // ---- load the patch -------------------------------------------------------------------------
     // 224 threads cover two patch rows (28 positions x 4 sixteen-byte chunks each) per pass, 36
     // passes: slot and row of a pass are compile-time, so a unit costs a handful of VALU operations
@@ -183,6 +199,7 @@ __device__ __forceinline__ void conv_patch_tile(unsigned char* __restrict__ patc
       }
     }
     __syncthreads();
+    LRP_T(0);
     // ---- the taps out of LDS ---------------------------------------------------------------------
     // One wave per SIMD: nothing hides a latency unless the code does.  The loop body is one row of
     // five taps (dt, dh fixed; 25 taps per temporal offset, so no remainder and no branch), software
@@ -304,6 +321,7 @@ __device__ __forceinline__ void conv_patch_tile(unsigned char* __restrict__ patc
       }
     }
   }
+  LRP_T(1);
   // ---- epilogue: C/D layout col = lane&31, row i = (r&3) + 8*(r>>2) + 4*kg -> pixel (h, w) above ----
   // A lane holds ONE channel of 48 (pooled) or 96 pixels: written straight from the accumulators that is 96 two-
   // and one-byte stores per wave, 64 B contiguous at best — 9-10 k cycles of a whole tile's 86 k (s_memtime, round 3)
@@ -350,6 +368,8 @@ __device__ __forceinline__ void conv_patch_tile(unsigned char* __restrict__ patc
 #pragma unroll
       for (int i = 0; i < P2_STAGE / 2048; ++i)
         *reinterpret_cast<uint4*>(code + o + (i * 64 + lane) * 16) = *reinterpret_cast<const uint4*>(stage + (i * 64 + lane) * 16);
+      LRP_T(2);
+      LRP_TEND();
       return;
     }
     // full-resolution output: RPC rows of the tile per pass
@@ -378,6 +398,8 @@ __device__ __forceinline__ void conv_patch_tile(unsigned char* __restrict__ patc
         *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(Y + o) + (i * 64 + lane) * 16) =
             *reinterpret_cast<const uint4*>(stage + (i * 64 + lane) * 16);
     }
+    LRP_T(2);
+    LRP_TEND();
     return;
   }
   if (POOL) {
@@ -449,6 +471,18 @@ __global__ __launch_bounds__(256, 1) void conv_patch_kernel(const bf16_t* __rest
 }
 
 }  // namespace
+
+#ifdef LRP_TIMING
+extern "C" int lr_conv_patch_debug_times(long long* out_host, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_lrp_times), sizeof(long long) * 4096 * 8) != hipSuccess) return -1;
+  if (reset) {
+    static long long zeros[4096][8];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lrp_times), zeros, sizeof(zeros)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 // fwd: 32 -> 64 channels (code != nullptr: fused ReLU + 2x2 max-pool epilogue); else the data gradient, 64 -> 32
 // (unpool: X is the pooled gradient [F][Hin/2][12][64] and code the windows' codes, see conv_patch_tile).

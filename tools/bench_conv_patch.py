@@ -9,7 +9,7 @@ import torch
 from lipreading_amd import _C
 
 
-def main(reps):
+def main(reps, zeros=False):
   L = _C.lib()
   dev = torch.device("cuda:0")
   st = _C.stream_handle()
@@ -21,6 +21,8 @@ def main(reps):
   dz = dz * (torch.rand(B * T, h, w, cout, device=dev) < 0.25)   # max-pool backward: one in four is non-zero
   weight = torch.randn(cout, cin, kt, kh, kw, device=dev) * 0.02
   bias = torch.randn(cout, device=dev) * 0.1
+  if zeros:   # the same instruction stream on all-zero operands: what the chip's power budget takes from the dense kernels
+    x.zero_(); dz.zero_(); weight.zero_(); bias.zero_()
   wp = torch.empty((cout, kt * kh * kw, cin), dtype=bf, device=dev)
   wd = torch.empty((cin, kt * kh * kw, cout), dtype=bf, device=dev)
   _C.check(L.lr_conv3d_pack_weights(weight.data_ptr(), wp.data_ptr(), cout, cin, cin, kt, kh, kw, 2, st))
@@ -51,8 +53,10 @@ def main(reps):
         times.append(e0.elapsed_time(e1) * 1e3)
     times.sort()
     med = times[len(times) // 2]
-    print("%s: median %.1f us  min %.1f us  (%.0f TFLOP/s at the median)" % (name, med, times[0], flops / med / 1e6))
+    print("%s%s: median %.1f us  min %.1f us  (%.0f TFLOP/s at the median)" % (name, " [zero operands]" if zeros else "", med, times[0], flops / med / 1e6))
 
 
 if __name__ == "__main__":
   main(int(sys.argv[1]) if len(sys.argv) > 1 else 20)
+  if len(sys.argv) > 2 and sys.argv[2] == "zeros":
+    main(int(sys.argv[1]), zeros=True)
