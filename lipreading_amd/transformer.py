@@ -53,8 +53,11 @@ class _StackFunction(torch.autograd.Function):
     _C.check(L.lr_tfm_forward(mode, x.data_ptr(), lens.data_ptr(), _ptr_array(weights), pe.data_ptr(), h.data_ptr(),
                               reserve.data_ptr(), rbytes, ws.data_ptr(), wbytes, *dims, float(eps), _C.stream_handle()),
              "lr_tfm_forward")
-    ctx.save_for_backward(x, lens, reserve, ws, *weights)
-    ctx.cfg = cfg
+    if any(ctx.needs_input_grad):
+      ctx.save_for_backward(x, lens, reserve, ws, *weights)
+      ctx.cfg = cfg
+    # (inference — torch.no_grad(), eval loops: nothing is saved, so the reserve (every layer's activations) and the
+    # workspace go back to the caching allocator as soon as the head has read h)
     return h
 
   @staticmethod
@@ -88,7 +91,7 @@ class _StackFunction(torch.autograd.Function):
         weight_half()
         _notify(weights)
         for hook in _enc.encoder_grads_complete_hooks:   # (the head's gradients were written before this backward)
-          hook()
+          hook(weights[0])
       _enc._deferred.append((x, dh, reserve, ws, grads, weights))
       return (dx, None, None, None) + (None,) * len(weights)
     weight_half()
@@ -187,6 +190,12 @@ class TransformerVideoEncoder(nn.Module):
                vocab_size=-1, char2idx=None, max_len=512):
     super().__init__()
     assert d_model % nhead == 0 and d_model % 4 == 0 and (d_model // nhead) % 4 == 0
+    # what the one-call stack (lr_tfm_*, lr_transformer.hip) takes; said HERE rather than as "unsupported shape" at the
+    # first forward (the per-op path of rounds 1-4, which had no such limits, is gone)
+    if dim_feedforward % 4 != 0 or num_layers > 16 or d_model > 1920:
+      raise ValueError("TransformerVideoEncoder: the HIP stack needs d_model, the head dimension and dim_feedforward to be "
+                       "multiples of 4, at most 16 layers and d_model <= 1920 (got d_model %d, %d heads, feed-forward %d, "
+                       "%d layers)" % (d_model, nhead, dim_feedforward, num_layers))
     self.frame_dim, self.d_model, self.nhead, self.num_layers = frame_dim, d_model, nhead, num_layers
     self.enable_ctc = enable_ctc
     self.best_error = 1
