@@ -780,7 +780,13 @@ extern "C" int lr_rnn_layer_forward(int mode, const float* x, const int32_t* len
       j.alpha = 1.f; j.beta = 0.f;
       j.b_shift = 0; j.b_period = 0;
     }
-    int st = lr_fgemm_launch(LR_FGEMM_F32, LR_FGEMM_NT, 0, 0, jobs, D, stream);
+    // Round 6: the LARGE layers of the one-launch recurrence (G * H >= 1536: the reference's own sizes — LSTM-512 / 700 /
+    // 768, GRU-800 — whose weight gradients have been split-bf16 products since round 5) take the projection as three
+    // bf16 products too (~1e-5 relative; the recurrence it feeds contracts hi + lo planes itself): at M = 2400, N = 6144,
+    // K = 204 the exact-fp32 MFMA form runs at 65-73 TF/s (93 us at B = 32, 329 us at the ecd family's own B = 128).
+    // Small layers (BiGRU-256: 31 us) and recurrence = 'f32' stay exact.
+    const bool x3 = cluster && G * H >= 1536 && !lr_debug_wgrad_f32();
+    int st = lr_fgemm_launch(x3 ? LR_FGEMM_X3 : LR_FGEMM_F32, LR_FGEMM_NT, 0, 0, jobs, D, stream);
     if (st != LR_OK) return st;
   } else if (D == 2 && (((w_ih[1] - w_ih[0]) & 3) == 0)) {
     // gates[b,t,d,:] = x[b,t,:] @ W_ih[d]^T + folded bias: both directions as one batched launch (x shared,
