@@ -13,11 +13,17 @@
 #   <round>_pixels_pmc_SQ_pass3.txt   the conv kernels' wave cycles by state (parked / issue-stalled / issuing per pipe)
 #   <round>_{pixels,pixels_tfm,gru256,lstm768}_step_timeline.txt   every dispatch of one step of the TIMED region with start
 #                                                                       offset and queue
-#   <round>_bench_ecd_lstm768_b{32,128}.json, <round>_ecd_lstm768_b32_kernel_stats.txt   the reference's ecd flag-file family
+#   <round>_bench_ecd_lstm768_b{32,128}.json, <round>_ecd_lstm768_b{32,128}_kernel_stats.txt   the reference's ecd flag-file family
+#   round 6: <round>_bench_{pixels_b8,pixels_b64,gru256_b64,gru256_b128,lstm512_b64}.json + <round>_pixels_b{8,64}_step_timeline.txt
+#            (the per-rank shapes of BASELINE configs[3]), <round>_bench_scaling_model.json (bench.py --model-scaling),
+#            <round>_ecd_lstm768_pmc_{FETCH,WRITE}_SIZE.txt / _pmc_SQ_pass1.txt (the grid recurrence's traffic and matrix pipe),
+#            <round>_pixels_pmc_clock.txt (GRBM_GUI_ACTIVE: the effective shader clock of the conv kernels),
+#            <round>_grid_phase_timing.txt / <round>_conv_patch_phase_timing.txt (shader-clock stamps of the timing variants,
+#            when lipreading_amd/_lib/alt/{gridtime,patchtime}.so were built before the visit)
 # PMC passes never share a run with trace domains other than the kernel trace rocprofv3 adds itself.
 set -u
 R=$PWD
-TAG=${1:-r05}
+TAG=${1:-r06}
 ONLY=${2:-all}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
@@ -61,6 +67,13 @@ python bench.py 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_default.json"
 kt pixels --regime pixels
 for c in FETCH_SIZE WRITE_SIZE; do pmc px_$c $c pixels_pmc_$c -- --regime pixels; done
 tl pixels conv1_fwd -9 --regime pixels
+# the per-rank shapes of a data-parallel run of BASELINE configs[3] (64 clips): the whole batch on one GPU, and 8 per rank
+for b in 64 8; do
+  python bench.py --regime pixels --batch $b --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_pixels_b$b.json"
+  tl pixels_b$b conv1_fwd -9 --regime pixels --batch $b
+done
+python bench.py --regime pixels --model-scaling --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_scaling_model.json"
+pmc clk "GRBM_GUI_ACTIVE GRBM_COUNT" pixels_pmc_clock conv_ conv1_ rnnc_ xgemm -- --regime pixels
 tl pixels_tfm conv1_fwd -9 --regime pixels_tfm
 kt pixels_tfm --regime pixels_tfm
 LIPREADING_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_forcedist.json"
@@ -82,6 +95,22 @@ if [ "$ONLY" != "pixels" ]; then
     python bench.py --regime landmarks_attn --model lstm768 --attention none --char-dim 256 --rnn-dropout 0.3 --batch $b 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_ecd_lstm768_b$b.json"
   done
   kt ecd_lstm768_b32 --regime landmarks_attn --model lstm768 --attention none --char-dim 256 --batch 32
+  kt ecd_lstm768_b128 --regime landmarks_attn --model lstm768 --attention none --char-dim 256 --batch 128
+  for c in FETCH_SIZE WRITE_SIZE; do
+    pmc ecd_$c $c ecd_lstm768_pmc_$c rnng_ rnnc_ -- --regime landmarks_attn --model lstm768 --attention none --char-dim 256 --batch 32
+  done
+  pmc sq5 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" ecd_lstm768_pmc_SQ_pass1 rnng_ rnnc_ fgemm -- --regime landmarks_attn --model lstm768 --attention none --char-dim 256 --batch 32
+  for a in "gru256 64" "gru256 128" "lstm512 64"; do
+    set -- $a
+    python bench.py --regime landmarks --model $1 --batch $2 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_$1_b$2.json"
+  done
+  tl ecd_lstm768_b32 step_begin 8 --regime landmarks_attn --model lstm768 --attention none --char-dim 256 --batch 32
+  if [ -f lipreading_amd/_lib/alt/gridtime.so ]; then
+    (LIPREADING_HIP_LIB=$R/lipreading_amd/_lib/alt/gridtime.so python tools/probes/grid_timing.py 32 31; LIPREADING_HIP_LIB=$R/lipreading_amd/_lib/alt/gridtime.so python tools/probes/grid_timing.py 64 31) > "$OUT/${TAG}_grid_phase_timing.txt" 2>&1
+  fi
+  if [ -f lipreading_amd/_lib/alt/patchtime.so ]; then
+    LIPREADING_HIP_LIB=$R/lipreading_amd/_lib/alt/patchtime.so python tools/probes/conv_patch_timing.py > "$OUT/${TAG}_conv_patch_phase_timing.txt" 2>&1
+  fi
   tl gru256 step_begin 8 --regime landmarks --model gru256
   tl lstm768 step_begin 8 --regime landmarks --model lstm768
   for c in FETCH_SIZE WRITE_SIZE; do
