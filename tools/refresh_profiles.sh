@@ -104,7 +104,7 @@ if [ "$ONLY" != "pixels" ]; then
     set -- $a
     python bench.py --regime landmarks --model $1 --batch $2 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_$1_b$2.json"
   done
-  tl ecd_lstm768_b32 step_begin 8 --regime landmarks_attn --model lstm768 --attention none --char-dim 256 --batch 32
+  tl ecd_lstm768_b32 step_begin_ctc 8 --regime landmarks_attn --model lstm768 --attention none --char-dim 256 --batch 32
   if [ -f lipreading_amd/_lib/alt/gridtime.so ]; then
     (LIPREADING_HIP_LIB=$R/lipreading_amd/_lib/alt/gridtime.so python tools/probes/grid_timing.py 32 31; LIPREADING_HIP_LIB=$R/lipreading_amd/_lib/alt/gridtime.so python tools/probes/grid_timing.py 64 31) > "$OUT/${TAG}_grid_phase_timing.txt" 2>&1
   fi
