@@ -556,7 +556,7 @@ def test_cluster_recurrence_is_fp32_faithful(dev, rnn_type, H, B, T, bi, lens, l
   assert float((res["split"][1] * (1 - valid.cpu())).abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("rnn_type,H", [("GRU", 256), ("LSTM", 512)])
+@pytest.mark.parametrize("rnn_type,H", [("GRU", 256), ("LSTM", 512), ("LSTM", 1536)])   # (1536: the 192-CU grid, lr_rnn_grid.hip)
 def test_a_recurrence_time_out_skips_the_step_and_is_reported(dev, rnn_type, H, capsys):
   """A member of a cluster that never shows up (here: the test hook makes member 1 return at once) leaves
   its partners waiting; their waits are bounded, what they produce is garbage, and the reference's contract for a
