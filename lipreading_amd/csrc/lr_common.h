@@ -176,6 +176,7 @@ int lr_device_cus();                // compute units of the current device, 0 wi
 int lr_debug_drop_member_value();
 int lr_debug_cluster_disabled();    // test hook (lr_rnn_debug_disable_cluster, bit 0): lr_rnn_cluster_supported answers 0
 int lr_debug_tune_value(int which);  // lr_rnn_debug_tune: exchange polling knobs of the cluster recurrence (0 forward, 1 backward)
+int lr_debug_ns8();                 // (bit 4): the cluster recurrence keeps 8 samples per cluster at every batch (round 6's A/B)
 int lr_debug_dwih_packed();         // (bit 3): the stored-bf16 first layer's dW_ih on the packed lr_xgemm path (round 5's A/B) instead of lr_fgemm
 int lr_debug_wgrad_f32();           // (bit 2): LR_RNN_RECUR_SPLIT layers keep their weight gradients on the fp32 grouped GEMM   // test hook (lr_rnn_debug_drop_member): that member of every cluster / pair exits at once
 

@@ -763,6 +763,7 @@ extern "C" int lr_debug_busy(int workgroups, int lds_bytes, int microseconds, lr
 }
 int lr_debug_wgrad_f32() { return (g_cluster_off >> 2) & 1; }
 int lr_debug_dwih_packed() { return (g_cluster_off >> 3) & 1; }
+int lr_debug_ns8() { return (g_cluster_off >> 4) & 1; }
 // tuning knobs of the cluster recurrence's exchange (lr_rnn_debug_tune): [0] forward, [1] backward; bits 0-7 = 64-clock
 // sleeps before the first poll, bits 8-15 = sleeps between poll rounds
 // which = 2 .. 5: the grid recurrence's four gathers (lr_rnn_grid.hip): forward h, forward partial sums, backward partial dh,

@@ -55,7 +55,13 @@ namespace {
 
 using namespace lrx;
 
-constexpr int NS = 8;              // samples per cluster (rows 0-7 hi, 8-15 lo of the A operand)
+constexpr int NS = 8;              // samples per cluster (rows 0-7 hi, 8-15 lo of the A operand) — the default form
+// Round 6: SIXTEEN samples per cluster (template argument NSV = 16) for the shapes whose clusters fill an XCD (32-unit
+// members, CC >= 17: LSTM-576 .. 768, GRU-576 .. 864 — BiLSTM-700 / 768 of the reference's own flag files), used when the
+// batch needs more than one launch of 8-sample clusters: BiLSTM-768 at the ecd family's own B = 128 is 32 clusters of 24
+// CUs, 8 per launch = FOUR launches per pass with 64 CUs idle in each.  With 16 samples the state hi and lo planes are two
+// A operands (rows 0-15 each) instead of the two row halves of one: twice the MFMAs of a product that is a quarter of a
+// step, no hi / lo fold of the accumulator rows, twice the exchange words — and half the launches.
 constexpr int SPIN_LIMIT = 1 << 18;
 
 constexpr int imin(int a, int b) { return a < b ? a : b; }
@@ -69,9 +75,11 @@ constexpr int imax(int a, int b) { return a > b ? a : b; }
 //   KS    k steps of 32 state columns (CC | CC / 2: with 16-unit members a k step is a PAIR of members)
 //   XB    exchange words a member publishes per step (forward) / per destination and step (backward): NS x U
 //   TPB   16-byte gather items per XB block: a thread's item g = sweep * 256 + tid belongs to member g / TPB
-template <int G, int CC, int U>
+template <int G, int CC, int U, int NSV = 8>
 struct Cfg {
   static_assert(G == 3 || G == 4, "GRU or LSTM");
+  static_assert(NSV == 8 || (NSV == 16 && U == 32), "16 samples per cluster: 32-unit members only");
+  static constexpr int NS = NSV, NJ = NSV / 8;   // samples; (sample, unit) pairs a cell thread runs
   static_assert(U == 32 || (U == 16 && CC % 2 == 0), "16-unit members come in pairs (one k step of 32)");
   static constexpr int UW = U / 4, NTILE = U / 16, GPT = 16 / UW;
   static constexpr int HP = U * CC;                // padded hidden size
@@ -89,9 +97,10 @@ struct Cfg {
   // forward: CF fragments per tile: f = 2 * local k step + plane
   static constexpr int CF = 2 * KS;
   static constexpr int CF_A = imin(CF, 60 / NTILE);             // f < CF_A in AGPRs (60 fragments per wave)
-  static constexpr int CF_REG = imin(CF, CF_A + 28 / NTILE);    // f < CF_REG in registers; the rest in LDS
+  static constexpr int CF_REG = imin(CF, CF_A + (NSV == 16 ? 24 : 28) / NTILE);    // f < CF_REG in registers; the rest in LDS
+                                                                // (16 samples: 16 VGPRs less — the gather lands 12 loads, not 6)
   static constexpr int CF_L = CF - CF_REG;
-  static constexpr size_t FWD_LDS = (size_t)2 * 16 * CLD * 2 + (size_t)4 * NTILE * CF_L * 1024 + (size_t)4 * NTILE * 256 * 4;
+  static constexpr size_t FWD_LDS = (size_t)2 * 2 * NS * CLD * 2 + (size_t)4 * NTILE * CF_L * 1024 + (size_t)4 * NTILE * 256 * 4;
   // backward: K = the member's own dG in KB k steps of 32 (U = 32: one per gate — LSTM i, f, g, o; GRU dr, dz,
   // d(W_hn h); U = 16: two gates x 16 units per k step); the HP output units are column tiles of 16; wave w owns the
   // TPD tiles of every destination member w, w + 4, ... (a wave's 2 TPD accumulator values per lane and destination
@@ -100,14 +109,14 @@ struct Cfg {
   static constexpr int KB = U == 32 ? G : 2;
   static constexpr int TPD = U / 16, ND = (CC + 3) / 4;
   static constexpr int NT = ND * TPD;
-  static constexpr int VPL = 2 * TPD;              // values per lane and destination
+  static constexpr int VPL = (NSV / 4) * TPD;      // values per lane and destination (8 samples: two per tile behind the hi / lo fold; 16: four)
   static constexpr int BFW = 2 * KB;
   static constexpr int BFW_A = imin(BFW, 60 / NT);
   static constexpr int BFW_REG = imin(BFW, BFW_A + imax(1, 14 / NT));
   static constexpr int BFW_L = BFW - BFW_REG;
   static constexpr int BKLD = KB * 32 + 8;
   static constexpr int NRED = 256 / TPB;           // partial sums of the gather: one per (wave, block of the sweep)
-  static constexpr size_t BWD_LDS = (size_t)2 * 16 * BKLD * 2 + (size_t)4 * NT * BFW_L * 1024 + (size_t)(NRED + 1) * XB * 4;
+  static constexpr size_t BWD_LDS = (size_t)2 * 2 * NS * BKLD * 2 + (size_t)4 * NT * BFW_L * 1024 + (size_t)(NRED + 1) * XB * 4;
   static constexpr size_t FWD_PACK = (size_t)CC * 4 * NTILE * CF * 64 * sizeof(bf16x8);     // per direction
   static constexpr size_t BWD_PACK = (size_t)CC * 4 * NT * BFW * 64 * sizeof(bf16x8);
 };
@@ -235,19 +244,20 @@ __global__ void rnnc_pack_bwd_kernel(const float* __restrict__ w0, const float* 
 // consumes its own wave's results (wave-local LDS exchange, no workgroup barrier); with 4-unit waves lanes 32-63 idle.
 // Exchange layout: [slot][cluster][member][wave][sample][unit of the wave] words — a wave publishes NS * UW consecutive
 // words with one store instruction; a reading thread takes four consecutive units of one (member, wave, sample).
-template <int G, int CC, int U>
+template <int G, int CC, int U, int NSV>
 __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
     float* __restrict__ gates, float* __restrict__ extra, float* __restrict__ y, const bf16x8* __restrict__ wpk,
     const float* __restrict__ bhh0, const float* __restrict__ bhh1, const float* __restrict__ h0,
     const float* __restrict__ c0, const int32_t* __restrict__ lens, u32* __restrict__ xch, int32_t* __restrict__ fault,
     int drop, int tune, int g0, int nclusters, int ncl, int B, int T, int D, int H) {
-  using C = Cfg<G, CC, U>;
+  using C = Cfg<G, CC, U, NSV>;
+  constexpr int NS = C::NS, NJ = C::NJ, HSZ = 2 * C::NS * C::CLD;   // (this kernel's samples per cluster; bf16 per parity buffer of the state)
   constexpr int CLD = C::CLD, CF = C::CF, CF_A = C::CF_A, CF_REG = C::CF_REG, CF_L = C::CF_L, NL = C::NL, HP = C::HP;
   constexpr int NTILE = C::NTILE, UW = C::UW, GPT = C::GPT, KS = C::KS, XB = C::XB, TPB = C::TPB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* hS = reinterpret_cast<bf16_t*>(smem);                                                    // [2][16][CLD]
-  bf16x8* Wl = reinterpret_cast<bf16x8*>(smem + (size_t)2 * 16 * CLD * 2);                         // [4][NTILE][CF_L][64]
-  float* S = reinterpret_cast<float*>(smem + (size_t)2 * 16 * CLD * 2 + (size_t)4 * NTILE * CF_L * 1024);   // [4][NTILE][16][16]
+  bf16_t* hS = reinterpret_cast<bf16_t*>(smem);                                                    // [2][2 NS][CLD]: rows 0 .. NS-1 hi, NS .. 2 NS-1 lo
+  bf16x8* Wl = reinterpret_cast<bf16x8*>(smem + (size_t)2 * HSZ * 2);                              // [4][NTILE][CF_L][64]
+  float* S = reinterpret_cast<float*>(smem + (size_t)2 * HSZ * 2 + (size_t)4 * NTILE * CF_L * 1024);   // [4][NTILE][16][16]
   __shared__ int s_local;
   const int cluster = blockIdx.x % ncl, c = blockIdx.x / ncl;
   const int ks_own = U == 32 ? c : c >> 1;   // the k step this member's units sit in
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
     }
   }
   // ---- the state before step 0 (zero, or h0): hS[0], hi in rows 0-7, lo in rows 8-15, LOCAL k order ------------
-  for (int i = tid; i < 16 * CLD; i += 256) hS[16 * CLD + i] = 0;
+  for (int i = tid; i < HSZ; i += 256) hS[HSZ + i] = 0;
   for (int i = tid; i < NS * CLD; i += 256) {
     const int r = i / CLD, pos = i - r * CLD;
     float v = 0.f;
@@ -284,25 +294,32 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
     bf16_t hi, lo;
     split_bf16(v, hi, lo);
     hS[r * CLD + pos] = hi;
-    hS[(r + 8) * CLD + pos] = lo;
+    hS[(r + NS) * CLD + pos] = lo;
   }
 
   // ---- gate-phase role: one (sample, unit) per thread ----------------------------------------------------------
-  const bool active = lane < NS * UW;               // (4-unit waves: the upper half of the wave has no (sample, unit))
-  const int sl = (lane / UW) & 7, u8 = lane % UW;   // sample within the group, unit within the wave
+  // (16 samples per cluster: a lane runs NJ = 2 cells, samples sl0 and sl0 + 8 of its unit)
+  const bool active = lane < 8 * UW;                // (4-unit waves: the upper half of the wave has no (sample, unit))
+  const int sl0 = (lane / UW) & 7, u8 = lane % UW;  // sample within the group (+ 8 j), unit within the wave
   const int ul = UW * wave + u8;                    // member-local unit
   const int unit = U * c + ul;
   const int own_pos = ((U * c) & 31) + ul;          // its column in the own k step (local k step 0)
-  const int b = group * NS + sl;
-  const bool alive = active && b < B && unit < H;
-  const int len = alive ? lens[b] : 0;
-  const float bhn = (G == 3 && alive) ? (d ? bhh1 : bhh0)[2 * H + unit] : 0.f;
-  float sreg = 0.f;                                 // carried fp32 state of this (sample, unit): GRU h, LSTM c
-  if (alive) {
-    if (G == 3 && h0) sreg = h0[((int64_t)d * B + b) * H + unit];
-    if (G == 4 && c0) sreg = c0[((int64_t)d * B + b) * H + unit];
+  int b[NJ], len[NJ];
+  bool alive[NJ];
+  float sreg[NJ];                                   // carried fp32 state of this (sample, unit): GRU h, LSTM c
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    b[j] = group * NS + sl0 + 8 * j;
+    alive[j] = active && b[j] < B && unit < H;
+    len[j] = alive[j] ? lens[b[j]] : 0;
+    sreg[j] = 0.f;
+    if (alive[j]) {
+      if (G == 3 && h0) sreg[j] = h0[((int64_t)d * B + b[j]) * H + unit];
+      if (G == 4 && c0) sreg[j] = c0[((int64_t)d * B + b[j]) * H + unit];
+    }
   }
-  struct Gx { float v[G]; };
+  const float bhn = (G == 3 && active && unit < H) ? (d ? bhh1 : bhh0)[2 * H + unit] : 0.f;
+  struct Gx { float v[NJ][G]; };
   Gx gxA, gxB;   // pre-activations of even / odd steps, fetched TWO steps ahead
   auto time_of = [&](int s) {
     const int sc = s < T ? s : T - 1;
@@ -312,17 +329,22 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
   // the prefetch has counted waits only — <3,8> forward 111.0 -> 108.6 us, <4,24> 199.7 -> 202.1, backward 153.6 -> 153.9
   // / 277.1 -> 279.3: inside the pool's noise, and it costs a mask operand in the backward cell.)
   auto fetch_gx = [&](Gx& gx, int t) {
-    if (!alive) return;
-    const float* gp = gates + (((int64_t)b * T + t) * D + d) * (int64_t)(G * H) + unit;
 #pragma unroll
-    for (int g = 0; g < G; ++g) gx.v[g] = gp[(int64_t)g * H];
+    for (int j = 0; j < NJ; ++j) {
+      if (!alive[j]) continue;
+      const float* gp = gates + (((int64_t)b[j] * T + t) * D + d) * (int64_t)(G * H) + unit;
+#pragma unroll
+      for (int g = 0; g < G; ++g) gx.v[j][g] = gp[(int64_t)g * H];
+    }
   };
 #pragma unroll
-  for (int g = 0; g < G; ++g) gxA.v[g] = gxB.v[g] = 0.f;
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int g = 0; g < G; ++g) gxA.v[j][g] = gxB.v[j][g] = 0.f;
   fetch_gx(gxA, time_of(0));
   fetch_gx(gxB, time_of(1));
   const int xcluster = CC * XB, xslot = nclusters * xcluster;       // words (32-bit: scalar multiplies)
-  u32* xmine = xch + cluster * xcluster + c * XB + wave * (NS * UW) + lane;   // word (wave, sample, unit of the wave)
+  u32* xmine = xch + cluster * xcluster + c * XB + wave * (NS * UW) + lane;   // word (wave, sample, unit of the wave); + 64 j
   // what this thread gathers in sweep i: item g = 256 i + tid of the cluster's CC * TPB 16-byte items, i.e. member
   // g / TPB (32-unit members: 4 i + wave; 16-unit members: 8 i + 2 wave + (lane >> 5)), its words 4 w .. 4 w + 3 with
   // w = g % TPB: wave w / (2 NS) ... of the source, sample rsmp, member-local units rpos .. rpos + 3
@@ -343,22 +365,34 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
   auto step = [&](int s, Gx& gx) __attribute__((always_inline)) {
     const int t = time_of(s);
     const int tnext = time_of(s + 2);
-    bf16_t* hcur = hS + (s & 1) * 16 * CLD;
-    bf16_t* hnxt = hS + ((s + 1) & 1) * 16 * CLD;
-    float sum[G];
+    bf16_t* hcur = hS + (s & 1) * HSZ;
+    bf16_t* hnxt = hS + ((s + 1) & 1) * HSZ;
+    float sum[NJ][G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) sum[g] = 0.f;
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int g = 0; g < G; ++g) sum[j][g] = 0.f;
     if (s > 0 || has_h0) {
       f32x4 acc0[NTILE], acc1[NTILE];   // hi / lo weight plane: four accumulation chains per wave (eight — even / odd k
                                   // steps apart — measured 4 % slower: the chains are not what the product waits for)
       // ---- own member's k step (local q = 0): its operands are already in LDS (32-unit members; with 16-unit
       // members half of that k step is the partner's and arrives with the gather) ------------------------------------
+      // (16 samples: `col` is the SAMPLE, the hi plane in rows 0-15 and the lo plane in rows 16-31 of the state; every
+      // product below is issued for both, into the same accumulator)
+      constexpr int LO = 16 * CLD;
       if constexpr (U == 32) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(hcur + col * CLD + kg * 8);
         LR_MFMA_A0(acc0[0], a, Wa[0][0]);
         LR_MFMA_A0(acc0[1], a, Wa[1][0]);
         LR_MFMA_A0(acc1[0], a, Wa[0][1]);
         LR_MFMA_A0(acc1[1], a, Wa[1][1]);
+        if constexpr (NSV == 16) {
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(hcur + LO + col * CLD + kg * 8);
+          LR_MFMA_A(acc0[0], al, Wa[0][0]);
+          LR_MFMA_A(acc0[1], al, Wa[1][0]);
+          LR_MFMA_A(acc1[0], al, Wa[0][1]);
+          LR_MFMA_A(acc1[1], al, Wa[1][1]);
+        }
       }
       if (s > 0) {
         // ---- the other members' h_{s-1} (tag of step s-1, slot (s-1) & 1): asked for once the own k step is under
@@ -403,7 +437,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
                 split_bf16_pair(xval(v[0]), xval(v[1]), hi0, lo0);
                 split_bf16_pair(xval(v[2]), xval(v[3]), hi1, lo1);
                 *reinterpret_cast<uint2*>(hcur + rsmp * CLD + pos) = make_uint2(hi0, hi1);
-                *reinterpret_cast<uint2*>(hcur + (rsmp + 8) * CLD + pos) = make_uint2(lo0, lo1);
+                *reinterpret_cast<uint2*>(hcur + (rsmp + NS) * CLD + pos) = make_uint2(lo0, lo1);
                 pend &= ~(1u << i);
               }
             }
@@ -420,40 +454,90 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
         }
         lr_lds_barrier();
       }
-      constexpr int Q0 = U == 32 ? 1 : 0;    // first k step behind the gather
-      bf16x8 a_next = *reinterpret_cast<const bf16x8*>(hcur + col * CLD + 32 * Q0 + kg * 8);
-#pragma unroll
-      for (int q = Q0; q < KS; ++q) {
-        const bf16x8 a = a_next;
-        if (q + 1 < KS) a_next = *reinterpret_cast<const bf16x8*>(hcur + col * CLD + (q + 1) * 32 + kg * 8);
-        const int f0 = 2 * q, f1 = 2 * q + 1;
-        if (U == 16 && q == 0) {   // (16-unit members: nothing was accumulated in front of the gather)
-#pragma unroll
-          for (int t = 0; t < NTILE; ++t) {
-            LR_MFMA_A0(acc0[t], a, Wa[t][0]);
-            LR_MFMA_A0(acc1[t], a, Wa[t][1]);
+      if constexpr (NSV == 8) {
+        constexpr int Q0 = U == 32 ? 1 : 0;    // first k step behind the gather
+        bf16x8 a_next = *reinterpret_cast<const bf16x8*>(hcur + col * CLD + 32 * Q0 + kg * 8);
+  #pragma unroll
+        for (int q = Q0; q < KS; ++q) {
+          const bf16x8 a = a_next;
+          if (q + 1 < KS) a_next = *reinterpret_cast<const bf16x8*>(hcur + col * CLD + (q + 1) * 32 + kg * 8);
+          const int f0 = 2 * q, f1 = 2 * q + 1;
+          if (U == 16 && q == 0) {   // (16-unit members: nothing was accumulated in front of the gather)
+  #pragma unroll
+            for (int t = 0; t < NTILE; ++t) {
+              LR_MFMA_A0(acc0[t], a, Wa[t][0]);
+              LR_MFMA_A0(acc1[t], a, Wa[t][1]);
+            }
+          } else if (f1 < CF_A) {
+  #pragma unroll
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_A(acc0[t], a, Wa[t][f0]);
+  #pragma unroll
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_A(acc1[t], a, Wa[t][f1]);
+          } else if (f1 < CF_REG) {
+  #pragma unroll
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc0[t], a, Wv[t][f0 - CF_A]);
+  #pragma unroll
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc1[t], a, Wv[t][f1 - CF_A]);
+          } else {
+            bf16x8 w0[NTILE], w1[NTILE];
+  #pragma unroll
+            for (int t = 0; t < NTILE; ++t) {
+              w0[t] = Wl[((wave * NTILE + t) * CF_L + (f0 - CF_REG)) * 64 + lane];
+              w1[t] = Wl[((wave * NTILE + t) * CF_L + (f1 - CF_REG)) * 64 + lane];
+            }
+  #pragma unroll
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc0[t], a, w0[t]);
+  #pragma unroll
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc1[t], a, w1[t]);
           }
-        } else if (f1 < CF_A) {
+        }
+      } else {
+        // 16 samples: every fragment meets the hi rows and the lo rows of the state (four MFMAs on other accumulators
+        // between two on the same one)
+        bf16x8 ah_next = *reinterpret_cast<const bf16x8*>(hcur + col * CLD + 32 + kg * 8);
+        bf16x8 al_next = *reinterpret_cast<const bf16x8*>(hcur + LO + col * CLD + 32 + kg * 8);
 #pragma unroll
-          for (int t = 0; t < NTILE; ++t) LR_MFMA_A(acc0[t], a, Wa[t][f0]);
-#pragma unroll
-          for (int t = 0; t < NTILE; ++t) LR_MFMA_A(acc1[t], a, Wa[t][f1]);
-        } else if (f1 < CF_REG) {
-#pragma unroll
-          for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc0[t], a, Wv[t][f0 - CF_A]);
-#pragma unroll
-          for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc1[t], a, Wv[t][f1 - CF_A]);
-        } else {
-          bf16x8 w0[NTILE], w1[NTILE];
-#pragma unroll
-          for (int t = 0; t < NTILE; ++t) {
-            w0[t] = Wl[((wave * NTILE + t) * CF_L + (f0 - CF_REG)) * 64 + lane];
-            w1[t] = Wl[((wave * NTILE + t) * CF_L + (f1 - CF_REG)) * 64 + lane];
+        for (int q = 1; q < KS; ++q) {
+          const bf16x8 ah = ah_next, al = al_next;
+          if (q + 1 < KS) {
+            ah_next = *reinterpret_cast<const bf16x8*>(hcur + col * CLD + (q + 1) * 32 + kg * 8);
+            al_next = *reinterpret_cast<const bf16x8*>(hcur + LO + col * CLD + (q + 1) * 32 + kg * 8);
           }
+          const int f0 = 2 * q, f1 = 2 * q + 1;
+          if (f1 < CF_A) {
 #pragma unroll
-          for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc0[t], a, w0[t]);
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_A(acc0[t], ah, Wa[t][f0]);
 #pragma unroll
-          for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc1[t], a, w1[t]);
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_A(acc1[t], ah, Wa[t][f1]);
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_A(acc0[t], al, Wa[t][f0]);
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_A(acc1[t], al, Wa[t][f1]);
+          } else if (f1 < CF_REG) {
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc0[t], ah, Wv[t][f0 - CF_A]);
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc1[t], ah, Wv[t][f1 - CF_A]);
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc0[t], al, Wv[t][f0 - CF_A]);
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc1[t], al, Wv[t][f1 - CF_A]);
+          } else {
+            bf16x8 w0[NTILE], w1[NTILE];
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) {
+              w0[t] = Wl[((wave * NTILE + t) * CF_L + (f0 - CF_REG)) * 64 + lane];
+              w1[t] = Wl[((wave * NTILE + t) * CF_L + (f1 - CF_REG)) * 64 + lane];
+            }
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc0[t], ah, w0[t]);
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc1[t], ah, w1[t]);
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc0[t], al, w0[t]);
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) LR_MFMA_V(acc1[t], al, w1[t]);
+          }
         }
       }
       LR_MFMA_DRAIN();
@@ -462,7 +546,7 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
         LR_ACC_READY(acc0[t]);
         LR_ACC_READY(acc1[t]);
       }
-      // tile (wave, t): S[row 4 kg + r][col] ; rows 0-7 = state hi of samples 0-7, rows 8-15 = state lo
+      // tile (wave, t): S[row 4 kg + r][col] ; rows 0-7 = state hi of samples 0-7, rows 8-15 = state lo (16 samples: row = sample)
       float* Sw = S + wave * NTILE * 256;
 #pragma unroll
       for (int t2 = 0; t2 < NTILE; ++t2)
@@ -472,56 +556,76 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const float* Sg = Sw + (g / GPT) * 256 + (g % GPT) * UW + u8;
-        sum[g] = Sg[sl * 16] + Sg[(sl + 8) * 16];
+        if constexpr (NSV == 8) {
+          sum[0][g] = Sg[sl0 * 16] + Sg[(sl0 + 8) * 16];
+        } else {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) sum[j][g] = Sg[(sl0 + 8 * j) * 16];
+        }
       }
     }
     // ---- the cell (torch gate order: GRU r, z, n; LSTM i, f, g, o) ---------------------------------------------
-    const bool live = alive && t < len;
-    float h, ex;
-    float go[G];
-    if (G == 3) {
-      const float hn = sum[2] + bhn;
-      const float r = fast_sigmoid(gx.v[0] + sum[0]);
-      const float z = fast_sigmoid(gx.v[1] + sum[1]);
-      const float n = fast_tanh(gx.v[2] + r * hn);
-      h = live ? (1.f - z) * n + z * sreg : 0.f;
-      go[0] = r;
-      go[1] = z;
-      go[2] = n;
-      ex = live ? hn : 0.f;
-    } else {
-      const float ig = fast_sigmoid(gx.v[0] + sum[0]);
-      const float fg = fast_sigmoid(gx.v[1] + sum[1]);
-      const float gg = fast_tanh(gx.v[2] + sum[2]);
-      const float og = fast_sigmoid(gx.v[G - 1] + sum[G - 1]);
-      const float cn = live ? fg * sreg + ig * gg : 0.f;
-      h = live ? og * fast_tanh(cn) : 0.f;
-      go[0] = ig;
-      go[1] = fg;
-      go[2] = gg;
-      go[G - 1] = og;
-      ex = cn;
-      sreg = cn;
+    float hv[NJ], exv[NJ];
+    float go[NJ][G];
+    bool livev[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const bool live = alive[j] && t < len[j];
+      livev[j] = live;
+      float h, ex;
+      if (G == 3) {
+        const float hn = sum[j][2] + bhn;
+        const float r = fast_sigmoid(gx.v[j][0] + sum[j][0]);
+        const float z = fast_sigmoid(gx.v[j][1] + sum[j][1]);
+        const float n = fast_tanh(gx.v[j][2] + r * hn);
+        h = live ? (1.f - z) * n + z * sreg[j] : 0.f;
+        go[j][0] = r;
+        go[j][1] = z;
+        go[j][2] = n;
+        ex = live ? hn : 0.f;
+      } else {
+        const float ig = fast_sigmoid(gx.v[j][0] + sum[j][0]);
+        const float fg = fast_sigmoid(gx.v[j][1] + sum[j][1]);
+        const float gg = fast_tanh(gx.v[j][2] + sum[j][2]);
+        const float og = fast_sigmoid(gx.v[j][G - 1] + sum[j][G - 1]);
+        const float cn = live ? fg * sreg[j] + ig * gg : 0.f;
+        h = live ? og * fast_tanh(cn) : 0.f;
+        go[j][0] = ig;
+        go[j][1] = fg;
+        go[j][2] = gg;
+        go[j][G - 1] = og;
+        ex = cn;
+        sreg[j] = cn;
+      }
+      hv[j] = h;
+      exv[j] = ex;
     }
     fetch_gx(gx, tnext);
-    const u32 w = xword(h, tag_of(s));
-    if (active) publish(xmine + (s & 1) * xslot, w, local);      // first: the other members are waiting for it
-    h = xval(w);                                     // the state everyone uses, this member included
-    if (G == 3) sreg = h;
-    bf16_t hi, lo;
-    split_bf16(h, hi, lo);
-    if (active) {
-      hnxt[sl * CLD + own_pos] = hi;                 // local k position of the own member: q = 0
-      hnxt[(sl + 8) * CLD + own_pos] = lo;
-    }
-    if (alive) {
-      const int64_t bt = (int64_t)b * T + t;
-      y[bt * ((int64_t)D * H) + d * H + unit] = h;
-      extra[(bt * D + d) * H + unit] = ex;
-      if (live) {
-        float* gout = gates + (bt * D + d) * (int64_t)(G * H) + unit;
 #pragma unroll
-        for (int g = 0; g < G; ++g) gout[(int64_t)g * H] = go[g];
+    for (int j = 0; j < NJ; ++j) {
+      const u32 w = xword(hv[j], tag_of(s));
+      if (active) publish(xmine + (s & 1) * xslot + 64 * j, w, local);      // first: the other members are waiting for it
+      const float h = xval(w);                         // the state everyone uses, this member included
+      hv[j] = h;
+      if (G == 3) sreg[j] = h;
+      bf16_t hi, lo;
+      split_bf16(h, hi, lo);
+      if (active) {
+        hnxt[(sl0 + 8 * j) * CLD + own_pos] = hi;      // local k position of the own member: q = 0
+        hnxt[(sl0 + 8 * j + NS) * CLD + own_pos] = lo;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (alive[j]) {
+        const int64_t bt = (int64_t)b[j] * T + t;
+        y[bt * ((int64_t)D * H) + d * H + unit] = hv[j];
+        extra[(bt * D + d) * H + unit] = exv[j];
+        if (livev[j]) {
+          float* gout = gates + (bt * D + d) * (int64_t)(G * H) + unit;
+#pragma unroll
+          for (int g = 0; g < G; ++g) gout[(int64_t)g * H] = go[j][g];
+        }
       }
     }
     lr_lds_barrier();   // hnxt's own k step complete; hcur free for the next gather
@@ -553,21 +657,22 @@ __global__ __launch_bounds__(256, 1) void rnnc_fwd_kernel(
 // members ww, ww + 4, ... and adds them up (fixed order); the four waves' sums and the member's own partial meet in
 // LDS, where each thread picks up the five values of its own (sample, unit) and runs the cell backward
 // (rnn_bwd_step_kernel's arithmetic).
-template <int G, int CC, int U>
+template <int G, int CC, int U, int NSV>
 __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
     const float* __restrict__ gates, const float* __restrict__ extra, const float* __restrict__ y,
     const float* __restrict__ dy, const float* __restrict__ dh_n, const float* __restrict__ dc_n, float* __restrict__ dG,
     float* __restrict__ dh0, float* __restrict__ dc0, const float* __restrict__ h0, const float* __restrict__ c0,
     const bf16x8* __restrict__ wpk, const int32_t* __restrict__ lens, u32* __restrict__ xch, int32_t* __restrict__ fault,
     int drop, int tune, int g0, int nclusters, int ncl, int B, int T, int D, int H) {
-  using C = Cfg<G, CC, U>;
+  using C = Cfg<G, CC, U, NSV>;
+  constexpr int NS = C::NS, NJ = C::NJ, GSZ = 2 * C::NS * C::BKLD;   // (samples per cluster; cells per thread; bf16 per parity buffer of dG)
   constexpr int KB = C::KB, NT = C::NT, NL = C::NL, BFW = C::BFW, BFW_A = C::BFW_A, BFW_REG = C::BFW_REG, BFW_L = C::BFW_L,
                 BKLD = C::BKLD;
   constexpr int XB = C::XB, TPB = C::TPB, TPD = C::TPD, ND = C::ND, VPL = C::VPL, NRED = C::NRED;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* gS = reinterpret_cast<bf16_t*>(smem);                                                    // [2][16][BKLD]
-  bf16x8* Wl = reinterpret_cast<bf16x8*>(smem + (size_t)2 * 16 * BKLD * 2);                        // [4][NT][BFW_L][64]
-  float* red = reinterpret_cast<float*>(smem + (size_t)2 * 16 * BKLD * 2 + (size_t)4 * NT * BFW_L * 1024);   // [NRED + 1][XB]: the sums of remote partials per (wave, block of the sweep), then this member's own
+  bf16_t* gS = reinterpret_cast<bf16_t*>(smem);                                                    // [2][2 NS][BKLD]: rows 0 .. NS-1 hi, NS .. 2 NS-1 lo
+  bf16x8* Wl = reinterpret_cast<bf16x8*>(smem + (size_t)2 * GSZ * 2);                              // [4][NT][BFW_L][64]
+  float* red = reinterpret_cast<float*>(smem + (size_t)2 * GSZ * 2 + (size_t)4 * NT * BFW_L * 1024);   // [NRED + 1][XB]: the sums of remote partials per (wave, block of the sweep), then this member's own
   __shared__ int s_local;
   const int cluster = blockIdx.x % ncl, c = blockIdx.x / ncl;
   if (cluster >= nclusters) return;
@@ -589,43 +694,55 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
       else Wl[((wave * NT + tl) * BFW_L + (f - BFW_REG)) * 64 + lane] = w;
     }
   }
-  for (int i = tid; i < 2 * 16 * BKLD; i += 256) gS[i] = 0;
+  for (int i = tid; i < 2 * GSZ; i += 256) gS[i] = 0;
 
   // ---- one (sample, unit) per thread: sample = tid / U, unit = tid % U of this member (16-unit members: threads
   // 128-255 have none) ---------------------------------------------------------------------------------------------
-  const bool active = tid < NS * U;
-  const int sl = (tid / U) & 7, ul = tid % U;
+  // (16 samples per cluster: a thread runs NJ = 2 cells, samples sl0 and sl0 + 8 of its unit)
+  const bool active = tid < 8 * U;
+  const int sl0 = (tid / U) & 7, ul = tid % U;
   const int unit = U * c + ul;
-  const int b = group * NS + sl;
-  const bool alive = active && b < B && unit < H;
-  const int len = alive ? lens[b] : 0;
-  const float inj_h = (alive && dh_n) ? dh_n[((int64_t)d * B + b) * H + unit] : 0.f;
-  const float inj_c = (G == 4 && alive && dc_n) ? dc_n[((int64_t)d * B + b) * H + unit] : 0.f;
-  float car = 0.f;   // GRU: dh_{t'} * z_{t'}; LSTM: dc_{t'} * f_{t'} of the step processed before
-  struct In { float dy, g[G], ex, prev; };
+  int b[NJ], len[NJ];
+  bool alive[NJ];
+  float inj_h[NJ], inj_c[NJ], car[NJ];   // car: GRU dh_{t'} * z_{t'}; LSTM dc_{t'} * f_{t'} of the step processed before
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    b[j] = group * NS + sl0 + 8 * j;
+    alive[j] = active && b[j] < B && unit < H;
+    len[j] = alive[j] ? lens[b[j]] : 0;
+    inj_h[j] = (alive[j] && dh_n) ? dh_n[((int64_t)d * B + b[j]) * H + unit] : 0.f;
+    inj_c[j] = (G == 4 && alive[j] && dc_n) ? dc_n[((int64_t)d * B + b[j]) * H + unit] : 0.f;
+    car[j] = 0.f;
+  }
+  struct In1 { float dy, g[G], ex, prev; };
+  struct In { In1 v[NJ]; };
   In inA, inB;       // operands of even / odd steps, fetched TWO steps ahead
   auto time_of = [&](int s) {
     const int sc = s < T ? s : T - 1;
     return d == 0 ? T - 1 - sc : sc;
   };
-  auto fetch = [&](In& in, int t) {
-    in.dy = in.ex = in.prev = 0.f;
+  auto fetch = [&](In& inn, int t) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) in.g[g] = 0.f;
-    if (!alive) return;
-    const int tp = d == 0 ? t - 1 : t + 1;
-    const int64_t bt = (int64_t)b * T + t;
-    in.dy = dy[bt * DH + d * H + unit];
-    const float* gi = gates + (bt * D + d) * (int64_t)(G * H) + unit;
+    for (int j = 0; j < NJ; ++j) {
+      In1& in = inn.v[j];
+      in.dy = in.ex = in.prev = 0.f;
 #pragma unroll
-    for (int g = 0; g < G; ++g) in.g[g] = gi[(int64_t)g * H];
-    in.ex = extra[(bt * D + d) * H + unit];
-    if (tp >= 0 && tp < T) {
-      const int64_t btp = (int64_t)b * T + tp;
-      in.prev = G == 3 ? y[btp * DH + d * H + unit] : extra[(btp * D + d) * H + unit];
-    } else {
-      const float* src = G == 3 ? h0 : c0;     // the state before the first step (decoder loop), else zero
-      if (src) in.prev = src[((int64_t)d * B + b) * H + unit];
+      for (int g = 0; g < G; ++g) in.g[g] = 0.f;
+      if (!alive[j]) continue;
+      const int tp = d == 0 ? t - 1 : t + 1;
+      const int64_t bt = (int64_t)b[j] * T + t;
+      in.dy = dy[bt * DH + d * H + unit];
+      const float* gi = gates + (bt * D + d) * (int64_t)(G * H) + unit;
+#pragma unroll
+      for (int g = 0; g < G; ++g) in.g[g] = gi[(int64_t)g * H];
+      in.ex = extra[(bt * D + d) * H + unit];
+      if (tp >= 0 && tp < T) {
+        const int64_t btp = (int64_t)b[j] * T + tp;
+        in.prev = G == 3 ? y[btp * DH + d * H + unit] : extra[(btp * D + d) * H + unit];
+      } else {
+        const float* src = G == 3 ? h0 : c0;     // the state before the first step (decoder loop), else zero
+        if (src) in.prev = src[((int64_t)d * B + b[j]) * H + unit];
+      }
     }
   };
   fetch(inA, time_of(0));
@@ -636,7 +753,14 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
   const int gw = tid % TPB, gj0 = tid / TPB;
   const u32* xin = xch + cluster * xcluster + c * xdst + gj0 * XB + 4 * gw;    // + sweep * (256 / TPB) * XB
   // where this thread's (sample sl, unit ul) sits in a block: lane kg * 16 + col, word 2 * (tile of the destination) + row
-  const int rpos = ((((sl >> 1) & 1) * 2 + (sl >> 2)) * 16 + (ul & 15)) * VPL + (ul >> 4) * 2 + (sl & 1);
+  // (16 samples: the accumulator rows ARE the samples — lane (sl >> 2) * 16 + col, word 4 * tile + (sl & 3))
+  int rpos[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int sl = sl0 + 8 * j;
+    rpos[j] = NSV == 8 ? ((((sl >> 1) & 1) * 2 + (sl >> 2)) * 16 + (ul & 15)) * VPL + (ul >> 4) * 2 + (sl & 1)
+                       : ((sl >> 2) * 16 + (ul & 15)) * VPL + (ul >> 4) * 4 + (sl & 3);
+  }
   unsigned pend0 = 0;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
@@ -648,26 +772,45 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
   const bool local = s_local != 0;
 
   // W_hh^T dG of the step processed before step s, for this thread's (sample, unit): dG sits in gS[s & 1]
-  auto reduce = [&](int s) __attribute__((always_inline)) -> float {
-    const bf16_t* gcur = gS + (s & 1) * 16 * BKLD;    // rows 0-7 hi, 8-15 lo
+  auto reduce = [&](int s, float (&prod)[NJ]) __attribute__((always_inline)) {
+    const bf16_t* gcur = gS + (s & 1) * GSZ;    // rows 0-7 hi, 8-15 lo (16 samples: rows 0-15 hi, 16-31 lo)
     f32x4 acc[NT];
     bf16x8 a_next = *reinterpret_cast<const bf16x8*>(gcur + col * BKLD + kg * 8);
+    [[maybe_unused]] bf16x8 al_next = a_next;
+    if constexpr (NSV == 16) al_next = *reinterpret_cast<const bf16x8*>(gcur + (16 + col) * BKLD + kg * 8);
 #pragma unroll
     for (int ks = 0; ks < KB; ++ks) {
       const bf16x8 a = a_next;
-      if (ks + 1 < KB) a_next = *reinterpret_cast<const bf16x8*>(gcur + col * BKLD + (ks + 1) * 32 + kg * 8);
+      [[maybe_unused]] const bf16x8 al = al_next;
+      if (ks + 1 < KB) {
+        a_next = *reinterpret_cast<const bf16x8*>(gcur + col * BKLD + (ks + 1) * 32 + kg * 8);
+        if constexpr (NSV == 16) al_next = *reinterpret_cast<const bf16x8*>(gcur + (16 + col) * BKLD + (ks + 1) * 32 + kg * 8);
+      }
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) {
         const int f = 2 * ks + pl;
+        // (16 samples: every fragment meets the hi rows and then the lo rows of dG, NT MFMAs apart on an accumulator)
         if (f == 0) {
 #pragma unroll
           for (int tl = 0; tl < NT; ++tl) LR_MFMA_A0(acc[tl], a, Wa[tl][0]);
+          if constexpr (NSV == 16) {
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) LR_MFMA_A(acc[tl], al, Wa[tl][0]);
+          }
         } else if (f < BFW_A) {
 #pragma unroll
           for (int tl = 0; tl < NT; ++tl) LR_MFMA_A(acc[tl], a, Wa[tl][f]);
+          if constexpr (NSV == 16) {
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) LR_MFMA_A(acc[tl], al, Wa[tl][f]);
+          }
         } else if (f < BFW_REG) {
 #pragma unroll
           for (int tl = 0; tl < NT; ++tl) LR_MFMA_V(acc[tl], a, Wv[tl][f - BFW_A]);
+          if constexpr (NSV == 16) {
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) LR_MFMA_V(acc[tl], al, Wv[tl][f - BFW_A]);
+          }
         } else {   // LDS-resident fragments, up to six tiles at a time (all at once costs 4 NT registers)
 #pragma unroll
           for (int t0 = 0; t0 < NT; t0 += 6) {
@@ -678,6 +821,11 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
 #pragma unroll
             for (int i = 0; i < 6; ++i)
               if (t0 + i < NT) LR_MFMA_V(acc[t0 + i], a, wl[i]);
+            if constexpr (NSV == 16) {
+#pragma unroll
+              for (int i = 0; i < 6; ++i)
+                if (t0 + i < NT) LR_MFMA_V(acc[t0 + i], al, wl[i]);
+            }
           }
         }
       }
@@ -703,8 +851,13 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
         // lane + 32, lanes 32-63 a[2] + the a[2] of lane - 32 — in two VALU instructions per kept value (rounds 2-3: four
         // ds_bpermute + four adds + two selects per tile through the LDS pipe, half of them for values nobody keeps)
         const f32x4 a = acc[TPD * m + th];
-        v[2 * th] = fold32(a[0], a[2]);
-        v[2 * th + 1] = fold32(a[1], a[3]);
+        if constexpr (NSV == 8) {
+          v[2 * th] = fold32(a[0], a[2]);
+          v[2 * th + 1] = fold32(a[1], a[3]);
+        } else {   // 16 samples: rows 4 kg + r ARE samples 4 kg + r; nothing to fold
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[4 * th + r] = a[r];
+        }
       }
       if (dstm < CC) {
         if (dstm == c) {
@@ -716,10 +869,13 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
           // write to a store's data registers needs behind it, which hipcc cannot place behind an asm — lr_rnn_grid.hip
           // store4 tells how that was found.)
           u32* p = xo + dstm * xdst;
-          if constexpr (VPL == 4) {
-            const u32x4 w = {xword(v[0], tg), xword(v[1], tg), xword(v[2], tg), xword(v[3], tg)};
-            if (local) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");   // workgroup scope
-            else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");   // agent scope
+          if constexpr (VPL == 4 || VPL == 8) {
+#pragma unroll
+            for (int q4 = 0; q4 < VPL / 4; ++q4) {
+              const u32x4 w = {xword(v[4 * q4], tg), xword(v[4 * q4 + 1], tg), xword(v[4 * q4 + 2], tg), xword(v[4 * q4 + 3], tg)};
+              if (local) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" ::"v"(p + 4 * q4), "v"(w) : "memory");   // workgroup scope
+              else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p + 4 * q4), "v"(w) : "memory");   // agent scope
+            }
           } else {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             const u32x2 w = {xword(v[0], tg), xword(v[1], tg)};
@@ -776,83 +932,98 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
       *reinterpret_cast<float4*>(red + gj0 * XB + 4 * gw) = make_float4(p0, p1, p2, p3);
     }
     lr_lds_barrier();     // `red` complete
-    float prod = red[NRED * XB + rpos];
 #pragma unroll
-    for (int w = 0; w < NRED; ++w) prod += red[w * XB + rpos];
-    return prod;
+    for (int j = 0; j < NJ; ++j) {
+      prod[j] = red[NRED * XB + rpos[j]];
+#pragma unroll
+      for (int w = 0; w < NRED; ++w) prod[j] += red[w * XB + rpos[j]];
+    }
   };
 
-  auto step = [&](int s, In& in) __attribute__((always_inline)) {
+  auto step = [&](int s, In& inn) __attribute__((always_inline)) {
     const int t = time_of(s);
     const int tnext = time_of(s + 2);
-    bf16_t* gnxt = gS + ((s + 1) & 1) * 16 * BKLD;
-    const float prod = s > 0 ? reduce(s) : 0.f;
+    bf16_t* gnxt = gS + ((s + 1) & 1) * GSZ;
+    float prod[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) prod[j] = 0.f;
+    if (s > 0) reduce(s, prod);
     if (s == T) {   // past the last step (only with dh0): the gradient into the initial state (lr_rnn_dh0's arithmetic)
-      if (alive) {
-        dh0[((int64_t)d * B + b) * H + unit] = G == 3 ? prod + car : prod;
-        if (G == 4 && dc0) dc0[((int64_t)d * B + b) * H + unit] = car;
-      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (alive[j]) {
+          dh0[((int64_t)d * B + b[j]) * H + unit] = G == 3 ? prod[j] + car[j] : prod[j];
+          if (G == 4 && dc0) dc0[((int64_t)d * B + b[j]) * H + unit] = car[j];
+        }
       return;
     }
-    float dh = in.dy + prod;
-    const bool is_last = d == 0 ? (t == len - 1) : (t == 0);   // where the final state was read
-    if (is_last) dh += inj_h;
-    const bool live = alive && t < len;
-    float kv[G], dgv[4];
-    if (G == 3) {
-      // rnn_bwd_step_kernel<3>
-      dh += car;   // dh_{t+1} * z_{t+1}
-      const float r = in.g[0], z = in.g[1], n = in.g[2], hn = in.ex, hp = in.prev;
-      const float dn_pre = live ? dh * (1.f - z) * (1.f - n * n) : 0.f;
-      const float dr_pre = dn_pre * hn * r * (1.f - r);
-      const float dz_pre = live ? dh * (hp - n) * z * (1.f - z) : 0.f;
-      car = live ? dh * z : 0.f;
-      dgv[0] = dr_pre;
-      dgv[1] = dz_pre;
-      dgv[2] = dn_pre;
-      dgv[3] = dn_pre * r;
-      kv[0] = dr_pre;
-      kv[1] = dz_pre;
-      kv[2] = dn_pre * r;    // recurrent path of the n gate: d/d(W_hn h + b_hn)
-    } else {
-      // rnn_bwd_step_kernel<4>
-      const float ig = in.g[0], fg = in.g[1], gg = in.g[2], og = in.g[G - 1], ct = in.ex, cp = in.prev;
-      float dc = car;
-      if (is_last) dc += inj_c;
-      float di = 0.f, df = 0.f, dg_ = 0.f, do_ = 0.f;
-      car = 0.f;
-      if (live) {
-        const float tc = fast_tanh(ct);
-        dc += dh * og * (1.f - tc * tc);
-        di = dc * gg * ig * (1.f - ig);
-        df = dc * cp * fg * (1.f - fg);
-        dg_ = dc * ig * (1.f - gg * gg);
-        do_ = dh * tc * og * (1.f - og);
-        car = dc * fg;
-      }
-      dgv[0] = di;
-      dgv[1] = df;
-      dgv[2] = dg_;
-      dgv[3] = do_;
-      kv[0] = di;
-      kv[1] = df;
-      kv[2] = dg_;
-      kv[G - 1] = do_;
-    }
-    fetch(in, tnext);
-    if (active) {
+    float kv[NJ][G], dgv[NJ][4];
 #pragma unroll
-      for (int k = 0; k < G; ++k) {   // gate k's entry of this (sample, unit): k step (k U) / 32 of the member's dG
-        bf16_t hi, lo;
-        split_bf16(kv[k], hi, lo);
-        gnxt[sl * BKLD + k * U + ul] = hi;
-        gnxt[(sl + 8) * BKLD + k * U + ul] = lo;
+    for (int j = 0; j < NJ; ++j) {
+      const In1& in = inn.v[j];
+      float dh = in.dy + prod[j];
+      const bool is_last = d == 0 ? (t == len[j] - 1) : (t == 0);   // where the final state was read
+      if (is_last) dh += inj_h[j];
+      const bool live = alive[j] && t < len[j];
+      if (G == 3) {
+        // rnn_bwd_step_kernel<3>
+        dh += car[j];   // dh_{t+1} * z_{t+1}
+        const float r = in.g[0], z = in.g[1], n = in.g[2], hn = in.ex, hp = in.prev;
+        const float dn_pre = live ? dh * (1.f - z) * (1.f - n * n) : 0.f;
+        const float dr_pre = dn_pre * hn * r * (1.f - r);
+        const float dz_pre = live ? dh * (hp - n) * z * (1.f - z) : 0.f;
+        car[j] = live ? dh * z : 0.f;
+        dgv[j][0] = dr_pre;
+        dgv[j][1] = dz_pre;
+        dgv[j][2] = dn_pre;
+        dgv[j][3] = dn_pre * r;
+        kv[j][0] = dr_pre;
+        kv[j][1] = dz_pre;
+        kv[j][2] = dn_pre * r;    // recurrent path of the n gate: d/d(W_hn h + b_hn)
+      } else {
+        // rnn_bwd_step_kernel<4>
+        const float ig = in.g[0], fg = in.g[1], gg = in.g[2], og = in.g[G - 1], ct = in.ex, cp = in.prev;
+        float dc = car[j];
+        if (is_last) dc += inj_c[j];
+        float di = 0.f, df = 0.f, dg_ = 0.f, do_ = 0.f;
+        car[j] = 0.f;
+        if (live) {
+          const float tc = fast_tanh(ct);
+          dc += dh * og * (1.f - tc * tc);
+          di = dc * gg * ig * (1.f - ig);
+          df = dc * cp * fg * (1.f - fg);
+          dg_ = dc * ig * (1.f - gg * gg);
+          do_ = dh * tc * og * (1.f - og);
+          car[j] = dc * fg;
+        }
+        dgv[j][0] = di;
+        dgv[j][1] = df;
+        dgv[j][2] = dg_;
+        dgv[j][3] = do_;
+        kv[j][0] = di;
+        kv[j][1] = df;
+        kv[j][2] = dg_;
+        kv[j][G - 1] = do_;
       }
     }
-    if (alive) {
-      float* dgo = dG + (((int64_t)b * T + t) * D + d) * (int64_t)(4 * H) + unit;
+    fetch(inn, tnext);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) dgo[(int64_t)k * H] = dgv[k];
+    for (int j = 0; j < NJ; ++j) {
+      const int sl = sl0 + 8 * j;
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) {   // gate k's entry of this (sample, unit): k step (k U) / 32 of the member's dG
+          bf16_t hi, lo;
+          split_bf16(kv[j][k], hi, lo);
+          gnxt[sl * BKLD + k * U + ul] = hi;
+          gnxt[(sl + NS) * BKLD + k * U + ul] = lo;
+        }
+      }
+      if (alive[j]) {
+        float* dgo = dG + (((int64_t)b[j] * T + t) * D + d) * (int64_t)(4 * H) + unit;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dgo[(int64_t)k * H] = dgv[j][k];
+      }
     }
     lr_lds_barrier();   // gnxt complete; `red` free again
   };
@@ -867,8 +1038,8 @@ __global__ __launch_bounds__(256, 1) void rnnc_bwd_kernel(
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-size_t xch_words(int CC, int U, int nclusters, int backward) {
-  const size_t xb = (size_t)NS * U;
+size_t xch_words(int CC, int U, int ns, int nclusters, int backward) {
+  const size_t xb = (size_t)ns * U;
   const size_t per = backward ? (size_t)CC * CC * xb : (size_t)CC * xb;
   return (size_t)2 * nclusters * per + (size_t)nclusters * CC;
 }
@@ -888,11 +1059,18 @@ inline int max_clusters(int CC, int U) {   // Cfg::MAXCL without the template
   const int xs = CC <= 32 ? 8 : (CC <= 64 ? 4 : 2);
   return (U == 32 && CC <= 16) ? xs * (32 / CC) : xs;
 }
+// samples per cluster of a pass: 16 where the shape has the form (32-unit members, CC >= 17: one cluster per XCD) AND the
+// batch would take more than one launch of 8-sample clusters; 8 otherwise (and under the test hook, bit 4 of
+// lr_rnn_debug_disable_cluster, for the A/B)
+constexpr bool has_ns16(int CC, int U) { return U == 32 && CC >= 17 && CC <= 24; }   // (25 .. 27 GRU members: the state of 16 samples does not fit the LDS beside the fragments)
+inline int pick_ns(int CC, int U, int B, int D) {
+  return has_ns16(CC, U) && !lr_debug_ns8() && (B + 7) / 8 * D > max_clusters(CC, U) ? 16 : 8;
+}
 
 // words of the first launch's exchange area
-inline int first_xch_words(int CC, int U, int maxcl, int B, int D, int backward) {
-  const int groups = (B + NS - 1) / NS, gchunk = maxcl / D;
-  return (int)xch_words(CC, U, (groups < gchunk ? groups : gchunk) * D, backward);
+inline int first_xch_words(int CC, int U, int ns, int maxcl, int B, int D, int backward) {
+  const int groups = (B + ns - 1) / ns, gchunk = maxcl / D;
+  return (int)xch_words(CC, U, ns, (groups < gchunk ? groups : gchunk) * D, backward);
 }
 
 // the layer's prologue: W_hh -> fragments, exchange words of the first launch cleared, biases folded (b_ih may be
@@ -906,49 +1084,95 @@ int fwd_prologue(const float* const* w_hh, const float* const* b_ih, const float
     fold.b_hh[d] = b_hh ? b_hh[d < D ? d : 0] : nullptr;
   }
   fold.out = b_ih ? bias_out : nullptr;
+  const int ns = pick_ns(CC, U, B, D), ncl = launch_clusters<G, CC, U>((B + ns - 1) / ns * D);
   LR_LAUNCH((rnnc_pack_fwd_kernel<G, CC, U>), dim3(1024), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D, H,
-            (u32*)xch, first_xch_words(CC, U, launch_clusters<G, CC, U>((B + NS - 1) / NS * D), B, D, 0), fold,
-            (bf16x8*)wpack_b, (u32*)xch_b,
-            wpack_b ? first_xch_words(CC, U, launch_clusters<G, CC, U>((B + NS - 1) / NS * D), B, D, 1) : 0);
+            (u32*)xch, first_xch_words(CC, U, ns, ncl, B, D, 0), fold, (bf16x8*)wpack_b, (u32*)xch_b,
+            wpack_b ? first_xch_words(CC, U, ns, ncl, B, D, 1) : 0);
   return lr_launch_status();
+}
+
+template <int G, int CC, int U, int NSV>
+int fwd_launch_ns(float* gates, float* extra, float* y, const float* const* b_hh, const float* h0, const float* c0,
+                  const int32_t* lens, void* wpack, void* xch, int B, int T, int D, int H, hipStream_t stream) {
+  using C = Cfg<G, CC, U, NSV>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)rnnc_fwd_kernel<G, CC, U, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)C::FWD_LDS) != hipSuccess)
+      return LR_ERR_LAUNCH;
+    attr_set = true;
+  }
+  int st = LR_OK;
+  int32_t* fault = lr_fault_words();
+  const int drop = lr_debug_drop_member_value();
+  const int tune = lr_debug_tune_value(0);
+  const int groups = (B + NSV - 1) / NSV, ncl = launch_clusters<G, CC, U>(groups * D), gchunk = ncl / D;   // sample groups per launch
+  for (int g0 = 0; g0 < groups; g0 += gchunk) {
+    const int ng = groups - g0 < gchunk ? groups - g0 : gchunk, nclusters = ng * D;
+    // (the first launch's words were cleared by the prologue)
+    if (g0 > 0 && hipMemsetAsync(xch, 0, xch_words(CC, U, NSV, nclusters, 0) * sizeof(u32), stream) != hipSuccess) return LR_ERR_LAUNCH;
+    const dim3 grid(ncl * CC);
+    hipEvent_t e0, e1;
+    if (g0 == 0 && lr_prof_next(LR_PROF_RNN_FWD, &e0, &e1))
+      hipExtLaunchKernelGGL((rnnc_fwd_kernel<G, CC, U, NSV>), grid, dim3(256), C::FWD_LDS, stream, e0, e1, 0, gates, extra, y,
+                            (const bf16x8*)wpack, b_hh[0], b_hh[D - 1], h0, c0, lens, (u32*)xch, fault, drop, tune, g0,
+                            nclusters, ncl, B, T, D, H);
+    else
+      hipLaunchKernelGGL((rnnc_fwd_kernel<G, CC, U, NSV>), grid, dim3(256), C::FWD_LDS, stream, gates, extra, y,
+                         (const bf16x8*)wpack, b_hh[0], b_hh[D - 1], h0, c0, lens, (u32*)xch, fault, drop, tune, g0, nclusters,
+                         ncl, B, T, D, H);
+    st = lr_launch_status();
+    if (st != LR_OK) return st;
+  }
+  return LR_OK;
 }
 
 template <int G, int CC, int U>
 int fwd_launch(float* gates, float* extra, float* y, const float* const* w_hh, const float* const* b_hh, const float* h0,
                const float* c0, const int32_t* lens, void* wpack, void* xch, int B, int T, int D, int H,
                hipStream_t stream, int prologue_done) {
-  using C = Cfg<G, CC, U>;
-  static bool attr_set = false;
   lr_clear_error();
+  if (!prologue_done) {
+    const int st = fwd_prologue<G, CC, U>(w_hh, nullptr, nullptr, nullptr, wpack, xch, B, D, H, stream);
+    if (st != LR_OK) return st;
+  }
+  if constexpr (has_ns16(CC, U)) {
+    if (pick_ns(CC, U, B, D) == 16)
+      return fwd_launch_ns<G, CC, U, 16>(gates, extra, y, b_hh, h0, c0, lens, wpack, xch, B, T, D, H, stream);
+  }
+  return fwd_launch_ns<G, CC, U, 8>(gates, extra, y, b_hh, h0, c0, lens, wpack, xch, B, T, D, H, stream);
+}
+
+template <int G, int CC, int U, int NSV>
+int bwd_launch_ns(const float* gates, const float* extra, const float* y, const float* dy, const float* dh_n, const float* dc_n,
+                  float* dG, float* dh0, float* dc0, const float* h0, const float* c0, const int32_t* lens, void* wpack,
+                  void* xch, int B, int T, int D, int H, hipStream_t stream) {
+  using C = Cfg<G, CC, U, NSV>;
+  static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)rnnc_fwd_kernel<G, CC, U>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)C::FWD_LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)rnnc_bwd_kernel<G, CC, U, NSV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)C::BWD_LDS) != hipSuccess)
       return LR_ERR_LAUNCH;
     attr_set = true;
   }
   int st = LR_OK;
-  if (!prologue_done) {
-    st = fwd_prologue<G, CC, U>(w_hh, nullptr, nullptr, nullptr, wpack, xch, B, D, H, stream);
-    if (st != LR_OK) return st;
-  }
   int32_t* fault = lr_fault_words();
   const int drop = lr_debug_drop_member_value();
-  const int tune = lr_debug_tune_value(0);
-  const int groups = (B + NS - 1) / NS, ncl = launch_clusters<G, CC, U>(groups * D), gchunk = ncl / D;   // sample groups per launch
+  const int tune = lr_debug_tune_value(1);
+  const int groups = (B + NSV - 1) / NSV, ncl = launch_clusters<G, CC, U>(groups * D), gchunk = ncl / D;
   for (int g0 = 0; g0 < groups; g0 += gchunk) {
     const int ng = groups - g0 < gchunk ? groups - g0 : gchunk, nclusters = ng * D;
-    // (the first launch's words were cleared by the prologue)
-    if (g0 > 0 && hipMemsetAsync(xch, 0, xch_words(CC, U, nclusters, 0) * sizeof(u32), stream) != hipSuccess) return LR_ERR_LAUNCH;
+    if (g0 > 0 && hipMemsetAsync(xch, 0, xch_words(CC, U, NSV, nclusters, 1) * sizeof(u32), stream) != hipSuccess) return LR_ERR_LAUNCH;
     const dim3 grid(ncl * CC);
     hipEvent_t e0, e1;
-    if (g0 == 0 && lr_prof_next(LR_PROF_RNN_FWD, &e0, &e1))
-      hipExtLaunchKernelGGL((rnnc_fwd_kernel<G, CC, U>), grid, dim3(256), C::FWD_LDS, stream, e0, e1, 0, gates, extra, y,
-                            (const bf16x8*)wpack, b_hh[0], b_hh[D - 1], h0, c0, lens, (u32*)xch, fault, drop, tune, g0,
+    if (g0 == 0 && lr_prof_next(LR_PROF_RNN_BWD, &e0, &e1))
+      hipExtLaunchKernelGGL((rnnc_bwd_kernel<G, CC, U, NSV>), grid, dim3(256), C::BWD_LDS, stream, e0, e1, 0, gates, extra, y, dy,
+                            dh_n, dc_n, dG, dh0, dc0, h0, c0, (const bf16x8*)wpack, lens, (u32*)xch, fault, drop, tune, g0,
                             nclusters, ncl, B, T, D, H);
     else
-      hipLaunchKernelGGL((rnnc_fwd_kernel<G, CC, U>), grid, dim3(256), C::FWD_LDS, stream, gates, extra, y,
-                         (const bf16x8*)wpack, b_hh[0], b_hh[D - 1], h0, c0, lens, (u32*)xch, fault, drop, tune, g0, nclusters,
-                         ncl, B, T, D, H);
+      hipLaunchKernelGGL((rnnc_bwd_kernel<G, CC, U, NSV>), grid, dim3(256), C::BWD_LDS, stream, gates, extra, y, dy, dh_n, dc_n,
+                         dG, dh0, dc0, h0, c0, (const bf16x8*)wpack, lens, (u32*)xch, fault, drop, tune, g0, nclusters, ncl, B, T,
+                         D, H);
     st = lr_launch_status();
     if (st != LR_OK) return st;
   }
@@ -959,43 +1183,19 @@ template <int G, int CC, int U>
 int bwd_launch(const float* gates, const float* extra, const float* y, const float* dy, const float* dh_n, const float* dc_n,
                float* dG, float* dh0, float* dc0, const float* h0, const float* c0, const float* const* w_hh,
                const int32_t* lens, void* wpack, void* xch, int B, int T, int D, int H, hipStream_t stream, int pack_done) {
-  using C = Cfg<G, CC, U>;
-  static bool attr_set = false;
   lr_clear_error();
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)rnnc_bwd_kernel<G, CC, U>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)C::BWD_LDS) != hipSuccess)
-      return LR_ERR_LAUNCH;
-    attr_set = true;
-  }
-  int st = LR_OK;
+  const int ns = pick_ns(CC, U, B, D);
   if (!pack_done) {   // (else: the layer's forward prologue left the fragments and the cleared words in wpack / xch)
     LR_LAUNCH((rnnc_pack_bwd_kernel<G, CC, U>), dim3(1024), dim3(256), 0, stream, w_hh[0], w_hh[D - 1], (bf16x8*)wpack, D,
-              H, (u32*)xch, first_xch_words(CC, U, launch_clusters<G, CC, U>((B + NS - 1) / NS * D), B, D, 1));
-    st = lr_launch_status();
+              H, (u32*)xch, first_xch_words(CC, U, ns, launch_clusters<G, CC, U>((B + ns - 1) / ns * D), B, D, 1));
+    const int st = lr_launch_status();
     if (st != LR_OK) return st;
   }
-  int32_t* fault = lr_fault_words();
-  const int drop = lr_debug_drop_member_value();
-  const int tune = lr_debug_tune_value(1);
-  const int groups = (B + NS - 1) / NS, ncl = launch_clusters<G, CC, U>(groups * D), gchunk = ncl / D;
-  for (int g0 = 0; g0 < groups; g0 += gchunk) {
-    const int ng = groups - g0 < gchunk ? groups - g0 : gchunk, nclusters = ng * D;
-    if (g0 > 0 && hipMemsetAsync(xch, 0, xch_words(CC, U, nclusters, 1) * sizeof(u32), stream) != hipSuccess) return LR_ERR_LAUNCH;
-    const dim3 grid(ncl * CC);
-    hipEvent_t e0, e1;
-    if (g0 == 0 && lr_prof_next(LR_PROF_RNN_BWD, &e0, &e1))
-      hipExtLaunchKernelGGL((rnnc_bwd_kernel<G, CC, U>), grid, dim3(256), C::BWD_LDS, stream, e0, e1, 0, gates, extra, y, dy,
-                            dh_n, dc_n, dG, dh0, dc0, h0, c0, (const bf16x8*)wpack, lens, (u32*)xch, fault, drop, tune, g0,
-                            nclusters, ncl, B, T, D, H);
-    else
-      hipLaunchKernelGGL((rnnc_bwd_kernel<G, CC, U>), grid, dim3(256), C::BWD_LDS, stream, gates, extra, y, dy, dh_n, dc_n, dG,
-                         dh0, dc0, h0, c0, (const bf16x8*)wpack, lens, (u32*)xch, fault, drop, tune, g0, nclusters, ncl, B, T, D,
-                         H);
-    st = lr_launch_status();
-    if (st != LR_OK) return st;
+  if constexpr (has_ns16(CC, U)) {
+    if (ns == 16)
+      return bwd_launch_ns<G, CC, U, 16>(gates, extra, y, dy, dh_n, dc_n, dG, dh0, dc0, h0, c0, lens, wpack, xch, B, T, D, H, stream);
   }
-  return LR_OK;
+  return bwd_launch_ns<G, CC, U, 8>(gates, extra, y, dy, dh_n, dc_n, dG, dh0, dc0, h0, c0, lens, wpack, xch, B, T, D, H, stream);
 }
 
 // the instantiated (gates, members, units per member) triples — EVERY hidden size the kernels' storage holds:
@@ -1024,7 +1224,9 @@ int bwd_launch(const float* gates, const float* extra, const float* y, const flo
   LR_CLUSTER_CC_COMMON(X, 3) X(3, 25, 32) X(3, 26, 32) X(3, 27, 32) LR_CLUSTER_CC_COMMON(X, 4)                    \
   LR_CLUSTER_CC16_COMMON(X, 3) X(4, 50, 16) X(4, 52, 16) X(4, 54, 16) LR_CLUSTER_CC16_COMMON(X, 4)
 #define X(g, c, u)                                                                                               \
-  static_assert(Cfg<g, c, u>::FWD_LDS <= 160 * 1024 && Cfg<g, c, u>::BWD_LDS <= 160 * 1024, "a member's fragments fit one CU");
+  static_assert(Cfg<g, c, u>::FWD_LDS <= 160 * 1024 && Cfg<g, c, u>::BWD_LDS <= 160 * 1024, "a member's fragments fit one CU"); \
+  static_assert(!has_ns16(c, u) || (Cfg<g, c, 32, 16>::FWD_LDS <= 160 * 1024 && Cfg<g, c, 32, 16>::BWD_LDS <= 160 * 1024), \
+                "... with the state / dG of 16 samples too");
 LR_CLUSTER_SHAPES(X)
 #undef X
 
@@ -1064,12 +1266,13 @@ int lr_rnn_cluster_launches(int G, int B, int H, int D) {
   if (B >= 1 && D >= 1 && lr_rnn_grid_shape(G, H)) return lr_rnn_grid_launches(B, D);
   if (B < 1 || D < 1 || !resolve_shape(G, H, &cc, &u)) return 0;
   int ncl = 0;
+  const int ns = pick_ns(cc, u, B, D);
 #define X(g, c, uu) \
-  if (G == g && cc == c && u == uu) ncl = launch_clusters<g, c, uu>((B + NS - 1) / NS * D);
+  if (G == g && cc == c && u == uu) ncl = launch_clusters<g, c, uu>((B + ns - 1) / ns * D);
   LR_CLUSTER_SHAPES(X)
 #undef X
   if (ncl < D) return 0;
-  const int groups = (B + NS - 1) / NS, gchunk = ncl / D;
+  const int groups = (B + ns - 1) / ns, gchunk = ncl / D;
   return (groups + gchunk - 1) / gchunk;
 }
 
@@ -1095,16 +1298,23 @@ size_t lr_rnn_cluster_xch_bytes(int B, int H, int D, int backward) {
   if (lr_rnn_grid_shape(4, H)) return lr_rnn_grid_xch_bytes(B, backward);   // (a GRU of this size has no one-launch kernel)
   // (the exchange area does not depend on the gate count: resolve as the LSTM, whose 32-unit range is the smaller)
   if (!resolve_shape(4, H, &cc, &u) && !resolve_shape(3, H, &cc, &u)) return 0;
-  const int maxcl = max_clusters(cc, u);
-  int clusters = (B + NS - 1) / NS * D;
-  if (clusters > maxcl) clusters = maxcl;
-  size_t w = xch_words(cc, u, clusters, backward);
+  // (the largest of: 8-sample clusters, and 16-sample ones where the shape and the batch take them — the test hook may
+  // switch between the two after the buffers were sized)
+  auto words = [&](int c_, int u_) {
+    size_t best = 0;
+    for (int ns = 8; ns <= (has_ns16(c_, u_) && (B + 7) / 8 * D > max_clusters(c_, u_) ? 16 : 8); ns += 8) {
+      const int maxcl = max_clusters(c_, u_);
+      int clusters = (B + ns - 1) / ns * D;
+      if (clusters > maxcl) clusters = maxcl;
+      const size_t w_ = xch_words(c_, u_, ns, clusters, backward);
+      if (w_ > best) best = w_;
+    }
+    return best;
+  };
+  size_t w = words(cc, u);
   int cc3, u3;
   if (resolve_shape(3, H, &cc3, &u3) && (cc3 != cc || u3 != u)) {   // a GRU of this size takes the other form: the larger
-    const int m3 = max_clusters(cc3, u3);
-    int cl3 = (B + NS - 1) / NS * D;
-    if (cl3 > m3) cl3 = m3;
-    const size_t w3 = xch_words(cc3, u3, cl3, backward);
+    const size_t w3 = words(cc3, u3);
     if (w3 > w) w = w3;
   }
   return w * sizeof(u32);

@@ -428,11 +428,20 @@ CLUSTER_CASES = [("LSTM", 768, 32, 75, True, None, 1), ("LSTM", 768, 37, 20, Tru
                  # round 6: LSTM past 1152 units on the 24 x 8 grid of 192 CUs (lr_rnn_grid.hip): one and two blocks of 32
                  # samples, both directions (a launch each), a hidden size that pads (1400 -> 1536), more than 64 samples
                  ("LSTM", 1536, 32, 12, False, "ragged", 1), ("LSTM", 1400, 9, 5, True, "ragged", 1),
-                 ("LSTM", 1280, 70, 4, False, "ragged", 1), ("LSTM", 1156, 40, 6, False, None, 2)]
+                 ("LSTM", 1280, 70, 4, False, "ragged", 1), ("LSTM", 1156, 40, 6, False, None, 2),
+                 # round 6: SIXTEEN samples per cluster where a batch would take more than one launch of 8-sample clusters and
+                 # the cluster fills an XCD (17 .. 24 members): BiLSTM-768 at B = 64 and 128 (the ecd family's own batch), BiLSTM-700,
+                 # 18 GRU members, a partial last group, two layers — beside the (768, 37), (768, 70), (704, 70) cases above,
+                 # which now take the 16-sample form too
+                 ("LSTM", 768, 64, 12, True, "ragged", 1), ("LSTM", 768, 128, 5, True, "ragged", 1),
+                 ("LSTM", 700, 100, 6, True, "ragged", 1), ("GRU", 576, 45, 9, True, "ragged", 2),
+                 ("LSTM", 544, 72, 7, False, "ragged", 1)]
 # (rnn_type, H, B, bidirectional) -> recurrence launches per layer pass (lr_rnn_pass_launches)
 CLUSTER_LAUNCHES = {("LSTM", 512, 64, True): 1, ("LSTM", 320, 96, True): 1, ("GRU", 128, 130, False): 1,
-                    ("LSTM", 256, 128, True): 1, ("LSTM", 768, 37, True): 2, ("LSTM", 768, 70, False): 2,
-                    ("LSTM", 768, 32, True): 1, ("GRU", 704, 70, True): 3, ("GRU", 1100, 40, False): 3,
+                    ("LSTM", 256, 128, True): 1, ("LSTM", 768, 37, True): 1, ("LSTM", 768, 70, False): 1,
+                    ("LSTM", 768, 32, True): 1, ("GRU", 704, 70, True): 2, ("GRU", 1100, 40, False): 3,
+                    ("LSTM", 768, 64, True): 1, ("LSTM", 768, 128, True): 2, ("LSTM", 700, 100, True): 2,
+                    ("GRU", 576, 45, True): 1, ("LSTM", 544, 72, False): 1,
                     ("LSTM", 1536, 32, False): 1, ("LSTM", 1400, 9, True): 2, ("LSTM", 1280, 70, False): 2,
                     ("LSTM", 1156, 40, False): 1}
 
