@@ -200,8 +200,11 @@ int lr_rnn_pair_supported(int mode, int B, int T, int I, int H, int D);         
 int lr_rnn_one_launch_status(int mode, int B, int T, int I, int H, int D);
 /* Recurrence launches ONE pass (forward or backward) of the layer takes on this device: 1 where every (direction,
  * 8 samples) cluster of the batch fits one launch — up to 8 * floor(32 / members) clusters, members = ceil(H / 32):
- * BiGRU-256 up to B = 128, BiLSTM-512 up to B = 64 (BASELINE configs[3]'s whole batch on one GPU) —, more where the
- * batch is cut into several launches, T where the layer runs one launch per time step. */
+ * BiGRU-256 up to B = 128, BiLSTM-512 up to B = 64 (BASELINE configs[3]'s whole batch on one GPU); clusters of 17 .. 24
+ * members (one per XCD: BiLSTM-700 / 768) take SIXTEEN samples each once the batch needs more than eight of them:
+ * BiLSTM-768 one launch up to B = 64, two at the ecd files' B = 128 —, more where the batch is cut into several
+ * launches, T where the layer runs one launch per time step; LSTM past 1152 units: one launch per direction and 64
+ * samples. */
 int lr_rnn_pass_launches(int mode, int B, int T, int I, int H, int D);
 /* LR_RNN_RECUR_SPLIT's workgroups of a pair / cluster must be resident together (lr_rnn_pair_supported checks the
  * device's compute-unit count); their waits are bounded, and a member that gave up leaves garbage and raises the
@@ -260,7 +263,7 @@ int lr_step_begin_ctc(float* grad, int64_t n, float* also_zero, const int64_t* c
                       const int64_t* frame_lens, const int64_t* char_lens, int32_t* labels_p1, int32_t* frame_lens32,
                       int32_t* label_lens32, int B, int L, lr_stream_t stream);
 void lr_rnn_debug_drop_member(int member);
-void lr_rnn_debug_disable_cluster(int off);
+void lr_rnn_debug_disable_cluster(int off);   /* bit 0: no one-launch recurrence; 2: fp32 weight gradients + projection; 3: packed dW_ih; 4: always 8 samples per cluster */
 /* TUNING HOOK of the one-launch recurrences' exchange polling: which = 0 forward / 1 backward cluster kernels; 2 .. 5 the
  * four gathers of the grid recurrence (LSTM past 1152 units): forward h, forward partial sums, backward partial dh,
  * backward dG; first_poll_delay = 64-clock sleeps between a member's publish and its first poll of the others (default 0),

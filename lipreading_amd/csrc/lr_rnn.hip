@@ -689,7 +689,8 @@ extern "C" int lr_rnn_one_launch_status(int mode, int B, int T, int I, int H, in
 
 // recurrence launches ONE pass of the layer takes on this device: 1 where every (direction, 8 samples) cluster of the
 // batch fits one launch (round 6: up to 8 floor(32 / members) clusters per launch — GRU-256 up to B = 128, LSTM-512 up
-// to B = 64; 24-member LSTM-768 clusters: 8, i.e. B = 32 bidirectional), T where the layer runs the step kernels
+// to B = 64; 24-member LSTM-768 clusters: 8 of sixteen samples each, i.e. B = 64 bidirectional), T where the layer runs the
+// step kernels
 extern "C" int lr_rnn_pass_launches(int mode, int B, int T, int I, int H, int D) {
   if (!dims_ok(mode, B, T, I, H, D)) return 0;
   if (lr_rnn_one_launch_status(mode, B, T, I, H, D) != 0) return T;
