@@ -14,7 +14,7 @@
 #   <round>_{pixels,pixels_tfm,gru256,lstm768}_step_timeline.txt   every dispatch of one step of the TIMED region with start
 #                                                                       offset and queue
 #   <round>_bench_ecd_lstm768_b{32,128}.json, <round>_ecd_lstm768_b{32,128}_kernel_stats.txt   the reference's ecd flag-file family
-#   round 6: <round>_bench_{pixels_b8,pixels_b64,gru256_b64,gru256_b128,lstm512_b64}.json + <round>_pixels_b{8,64}_step_timeline.txt
+#   round 6: <round>_bench_{pixels_b8,pixels_b64,gru256_b64,gru256_b128,lstm512_b64,lstm768_b64,lstm768_b128}[_ns8].json + <round>_pixels_b{8,64}_step_timeline.txt
 #            (the per-rank shapes of BASELINE configs[3]), <round>_bench_scaling_model.json (bench.py --model-scaling),
 #            <round>_ecd_lstm768_pmc_{FETCH,WRITE}_SIZE.txt / _pmc_SQ_pass1.txt (the grid recurrence's traffic and matrix pipe),
 #            <round>_pixels_pmc_clock.txt (GRBM_GUI_ACTIVE: the effective shader clock of the conv kernels),
@@ -103,6 +103,11 @@ if [ "$ONLY" != "pixels" ]; then
   for a in "gru256 64" "gru256 128" "lstm512 64"; do
     set -- $a
     python bench.py --regime landmarks --model $1 --batch $2 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_$1_b$2.json"
+  done
+  # sixteen samples per cluster (BiLSTM-768 / 700 past B = 32) against the 8-sample form (test hook bit 4), same box
+  for b in 64 128; do
+    python bench.py --regime landmarks --model lstm768 --batch $b --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_lstm768_b$b.json"
+    LIPREADING_RNN_DEBUG=16 python bench.py --regime landmarks --model lstm768 --batch $b --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_lstm768_b${b}_ns8.json"
   done
   tl ecd_lstm768_b32 step_begin_ctc 8 --regime landmarks_attn --model lstm768 --attention none --char-dim 256 --batch 32
   if [ -f lipreading_amd/_lib/alt/gridtime.so ]; then
