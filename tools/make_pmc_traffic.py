@@ -23,8 +23,11 @@ for _g, _cc in [(3, c) for c in range(1, 28)] + [(4, c) for c in range(1, 25)]:
   for _w in ("fwd", "bwd"):
     # (the profiler leaves some of these names mangled: both spellings)
     # (32-unit members; third template argument = units per member)
-    RECURRENT["rnnc_%s_kernel<%d,%d>" % (_w, _g, _cc)] = ("rnnc_%s_kernel<%d, %d, 32>" % (_w, _g, _cc),
-                                                          "rnnc_%s_kernelILi%dELi%dELi32E" % (_w, _g, _cc))
+    # (round 6: a fourth template argument = samples per cluster; the B = 32 passes the lines profile are the 8-sample form)
+    RECURRENT["rnnc_%s_kernel<%d,%d>" % (_w, _g, _cc)] = ("rnnc_%s_kernel<%d, %d, 32, 8>" % (_w, _g, _cc),
+                                                          "rnnc_%s_kernelILi%dELi%dELi32ELi8E" % (_w, _g, _cc),
+                                                          "rnnc_%s_kernel<%d, %d, 32>" % (_w, _g, _cc),
+                                                          "rnnc_%s_kernelILi%dELi%dELi32EE" % (_w, _g, _cc))
 MODELS = ("gru256", "lstm768", "lstm700", "lstm512", "gru800")
 
 
