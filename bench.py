@@ -978,9 +978,10 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
                        "clip_grad_norm 50 -> Adam 1e-4"
                        % (B, layers, rnn_type, H,
                           {"f32": "recurrence: one fp32-MFMA launch per time step",
-                           "split": "recurrence: one launch per layer pass, W_hh and state as bf16 hi+lo planes held by a "
-                                    "cluster of %d CUs per (direction, 8 samples), fp32 accumulation — fp32-faithful"
-                                    % members}[rec], D * H))
+                           "split": "recurrence: %d launch(es) per layer pass, W_hh and state as bf16 hi+lo planes held by a "
+                                    "cluster of %d CUs per (direction, %d samples), fp32 accumulation — fp32-faithful"
+                                    % (L.lr_rnn_pass_launches({"GRU": 0, "LSTM": 1, "RNN": 2}[rnn_type], B, T_FRAMES, frame_dim, H, D),
+                                       members, 16 if (17 <= members <= 24 and (B + 7) // 8 * D > 8) else 8)}[rec], D * H))
   return res
 
 

@@ -197,7 +197,11 @@ CFG = [("GRU", 256, 1, True, 32, 75), ("LSTM", 768, 1, True, 32, 75), ("GRU", 70
        ("LSTM", 64, 2, True, 20, 33), ("GRU", 48, 2, False, 17, 21), ("LSTM", 36, 1, False, 5, 12),
        ("RNN", 256, 1, True, 32, 75), ("RNN", 52, 2, False, 11, 19),
        # round 4's 16-unit-member clusters against the ORACLE (they were only compared with the step kernels)
-       ("LSTM", 800, 1, True, 32, 75), ("LSTM", 1024, 1, False, 32, 31), ("GRU", 1100, 1, False, 13, 12)]
+       ("LSTM", 800, 1, True, 32, 75), ("LSTM", 1024, 1, False, 32, 31), ("GRU", 1100, 1, False, 13, 12),
+       # round 6 against the ORACLE too: sixteen samples per cluster (BiLSTM-768 / -700 past B = 32: the ecd family's own
+       # batch is 128), more than eight clusters per launch (BiLSTM-512 at configs[3]'s B = 64), the 192-CU grid (LSTM-1536)
+       ("LSTM", 768, 1, True, 64, 40), ("LSTM", 700, 1, True, 72, 21), ("LSTM", 512, 1, True, 64, 40),
+       ("LSTM", 1536, 1, False, 32, 31), ("LSTM", 1400, 1, False, 40, 12)]
 
 
 @pytest.mark.parametrize("rnn_type,H,layers,bi,B,T", CFG)
@@ -222,7 +226,7 @@ def test_encoder_forward_backward_matches_oracle(dev, rnn_type, H, layers, bi, B
     return l
 
   from lipreading_amd import _C
-  if rnn_type != "RNN" and H in (256, 512, 700, 768, 800, 1024, 1100):
+  if rnn_type != "RNN" and H in (256, 512, 700, 768, 800, 1024, 1100, 1400, 1536):
     # the default path IS the one-launch recurrence for these
     assert _C.lib().lr_rnn_pair_supported({"GRU": 0, "LSTM": 1}[rnn_type], B, T, 204, H, 2 if bi else 1) == 2
   _C.lib().lr_rnn_pair_errors()
