@@ -293,3 +293,42 @@ def test_gradient_all_reduce_on_the_side_stream_beside_the_cu_hungriest_recurren
   print("%s-%d beside a 27.7 MB all-reduce + 48 foreign workgroups: %.3f ms per step, %.3f undisturbed" % (rnn_type, H, t_dist, t_plain))
   # the foreign kernel holds its CUs for 0.35 ms twice per step: a pass may have to wait that long, never longer
   assert t_dist <= t_plain + 2 * 0.45, (t_plain, t_dist)
+
+
+def test_words_that_left_before_the_last_bucket_fall_back_to_the_exchange_after_backward(dev, pg):
+  """the skip / fault words ride in front of the first parameter's bucket and are a SNAPSHOT taken when
+  that bucket is exported; lr_clip_adam_step decides from their sum alone (so the ranks cannot disagree).  That is only
+  sound when no recurrence can be enqueued behind the snapshot, i.e. when the words' bucket is the LAST to leave — true
+  for the shipped groupings (the first layer's gradients come last).  With any other order GradSync must not hand the
+  summed words to the optimiser: it runs the exchange after backward instead (the MIN all-reduce of rounds 3-4, which
+  reads the fault word as it is then)."""
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.distributed import GradSync
+  from lipreading_amd.encoder import VideoEncoder
+  from lipreading_amd.optim import FlatParameters
+  torch.manual_seed(5)
+  enc = VideoEncoder(204, 16, rnn_type='GRU', num_layers=2, bidirectional=True, enable_ctc=True, vocab_size=64,
+                     char2idx=default_char2idx()).to(dev).train()
+  flat = FlatParameters(enc)
+  groups = GradSync.groups_for_encoder(enc, flat)          # [layer 0 (with parameter 0: carries the words), layer 1, head]
+  status = torch.zeros(1, dtype=torch.int32, device=dev)
+  sync = GradSync(flat, groups=groups, overlap=True)
+  try:
+    assert sync._words_bucket == 0
+    # the order of a real backward: head, layer 1, layer 0 — the words' bucket last: the summed words decide
+    flat.zero_grad()
+    sync.set_status(status)
+    for gi in (2, 1, 0):
+      sync._launch(gi)
+    assert sync(status) == 1.0 and sync.dist_words is not None
+    assert float(sync.dist_words[0]) == 0.0 and float(sync.dist_words[1]) == 0.0
+    # ... and an order in which a bucket leaves AFTER the words: no folded verdict, the legacy exchange ran
+    flat.zero_grad()
+    sync.set_status(status)
+    for gi in (2, 0, 1):
+      sync._launch(gi)
+    assert sync(status) == 1.0 and sync.dist_words is None
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+  finally:
+    sync.close()
