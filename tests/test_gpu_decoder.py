@@ -409,7 +409,10 @@ def test_fused_decoder_nll_equals_the_reference_formula(dev):
                                                          # block, two blocks, two launches (70 samples), two layers, a single step
                                                          ("LSTM", 1536, 1, "none", 32, 31), ("LSTM", 1400, 1, "1_layer_nn", 32, 31),
                                                          ("LSTM", 1536, 1, "dot", 5, 3), ("LSTM", 1536, 1, "none", 40, 7),
-                                                         ("LSTM", 1400, 2, "none", 70, 4), ("LSTM", 1156, 1, "none", 13, 1)])
+                                                         ("LSTM", 1400, 2, "none", 70, 4), ("LSTM", 1156, 1, "none", 13, 1),
+                                                         # sixteen samples per cluster with an initial state and its gradient (the
+                                                         # backward's extra step): 22 / 24-member decoders past 64 samples
+                                                         ("LSTM", 704, 1, "dot", 72, 5), ("GRU", 768, 1, "none", 100, 3)])
 def test_decoder_loop_on_the_cluster_recurrence_equals_the_step_kernels(dev, rnn_type, Hd, layers, attn, B, L):
   """With every step teacher forced (the shipped configs and eval) the decoder's RNN — unidirectional, started from
   the encoder's final state (better_model.py:134-148,181) — runs each layer's L steps as ONE launch of the cluster
