@@ -547,7 +547,8 @@ long long lr_fgemm_slab_floats(int M, int N, int splits);
  *   qkv = h W_qkv^T + b;  a = attention(qkv, key_lens);  h1 = LN1(a W_o^T + b_o + h);
  *   h2 = LN2(relu(h1 W_1^T + b_1) W_2^T + b_2 + h1).
  * mode: LR_TFM_X3 (projections as split-bf16 products, else exact fp32) | LR_TFM_X_BF16 (x is stored as bf16) |
- *   LR_TFM_DX_BF16 (dx is written as bf16) | LR_TFM_ATTN_FUSED (lr_attn_fused_*; else fp32 batched products + softmax).
+ *   LR_TFM_DX_BF16 (dx is written as bf16) | LR_TFM_ATTN_FUSED (lr_attn_fused_*; else fp32 batched products + softmax) |
+ *   LR_TFM_ROWBLOCK (below).
  * weights: 2 + 12 * nlayers device pointers in torch's registration order: input_proj.weight [Dm][I], .bias, then per
  *   layer in_proj_weight [3Dm][Dm], in_proj_bias, out_proj.weight [Dm][Dm], .bias, linear1.weight [F][Dm], .bias,
  *   linear2.weight [Dm][F], .bias, norm1.weight, .bias, norm2.weight, .bias.  pe: [>= T][Dm].
@@ -560,6 +561,10 @@ long long lr_fgemm_slab_floats(int M, int N, int splits);
 #define LR_TFM_X_BF16 2
 #define LR_TFM_DX_BF16 4
 #define LR_TFM_ATTN_FUSED 8
+#define LR_TFM_ROWBLOCK 16   /* out-projection .. LN2 (and their backward) as ONE launch per layer and direction over 32-row
+                                blocks (lr_tfm_rowblock.hip); needs LR_TFM_X3 and lr_tfm_rowblock_supported(): d_model 256,
+                                feed-forward width a multiple of 256, at most 8 layers and 8192 rows */
+int lr_tfm_rowblock_supported(int B, int T, int Dm, int F, int nlayers);
 size_t lr_tfm_reserve_bytes(int mode, int B, int T, int I, int Dm, int nhead, int F, int nlayers);
 size_t lr_tfm_workspace_bytes(int mode, int B, int T, int I, int Dm, int nhead, int F, int nlayers);
 int lr_tfm_forward(int mode, const void* x, const int32_t* key_lens, const float* const* weights, const float* pe,

@@ -50,6 +50,7 @@ SIGNATURES = {
     "lr_fgemm_slab_floats": (ctypes.c_longlong, [c_int, c_int, c_int]),
     "lr_tfm_reserve_bytes": (c_size_t, [c_int] * 8),
     "lr_tfm_workspace_bytes": (c_size_t, [c_int] * 8),
+    "lr_tfm_rowblock_supported": (c_int, [c_int] * 5),
     "lr_tfm_forward": (c_int, [c_int, P, P, P, P, P, P, c_size_t, P, c_size_t] + [c_int] * 7 + [c_float, P]),
     "lr_tfm_backward_data": (c_int, [c_int, P, P, P, P, P, c_size_t, P, c_size_t] + [c_int] * 7 + [P]),
     "lr_tfm_backward_weights": (c_int, [c_int, P, P, c_int, P, c_size_t, P, c_size_t] + [c_int] * 7 + [P]),

@@ -282,3 +282,14 @@ int lr_xproj_dw_both(const float* dG, int ldg, int dstride, const float* x, cons
 int lr_xproj_dwhh(const float* dG, int ldg, const float* y, int ldy, int R, int T, int H, int G, int D,
                   float* const* dw_hh, float beta, void* workspace, size_t workspace_bytes, hipStream_t stream,
                   int one_product = 0);
+
+// ---- lr_tfm_rowblock.hip: the row-wise half of an encoder layer as one launch per direction (LR_TFM_ROWBLOCK) ----
+int lr_tfm_rb_supported(int Dm, int F, int nlayers);
+size_t lr_tfm_rb_plane_elems(int F);   // bf16 elements of one layer's weight planes
+int lr_tfm_rb_pack(const float* const* weights, void* planes, int F, int nlayers, hipStream_t st);
+int lr_tfm_rb_forward(const void* planes, int l, const float* const* W, const float* a, const float* h, float* s1,
+                      float* st1, float* h1, float* f1, float* s2, float* st2, float* h2, int R, int F, float eps,
+                      hipStream_t st);
+int lr_tfm_rb_backward(const void* planes, int l, const float* const* W, const float* dh2, const float* s2,
+                       const float* st2, const float* f1, const float* s1, const float* st1, float* ds2, float* df1,
+                       float* ds1, float* da, float* lnp2, float* lnp1, int lnblocks, int R, int F, hipStream_t st);

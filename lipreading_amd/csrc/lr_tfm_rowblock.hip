@@ -1,0 +1,658 @@
+// lr_tfm_rowblock.hip — the ROW-WISE half of a transformer encoder layer as one launch per direction (round 6).
+//
+// BUILD-DEFINED like the rest of the stage (lr_transformer.hip has the specification).  Everything
+// of a post-LN encoder layer but the attention is row-wise: out-projection + residual + LayerNorm, feed-forward
+// (ReLU) + residual + LayerNorm.  lr_transformer.hip ran those as five launches per layer and direction — products of
+// 6-42 us at M = 2400 whose time is a launch's fixed latency, not its flops (VERDICT r5
+// item 6) — with every intermediate [R][256] / [R][1024] tensor written and read back between them.  Here a
+// workgroup owns 32 ROWS and walks the whole chain with the rows' activations in LDS:
+//
+//   forward :  a -> s1 = a Wo^T + bo + h -> h1 = LN1(s1) -> f1 = relu(h1 W1^T + b1) (256 hidden columns at a time)
+//              -> s2 = f1 W2^T + b2 + h1 -> h2 = LN2(s2)
+//   backward:  dh2 -> ds2 = LN2'(dh2) -> df1 = (ds2 W2) . [f1 > 0] (256 columns at a time) -> dh1 = df1 W1 + ds2
+//              -> ds1 = LN1'(dh1) -> da = ds1 Wo
+//
+// and writes what lr_tfm_backward_weights and the other direction read (s1, stats, h1, f1, s2, stats / ds2, df1,
+// ds1, da, LayerNorm partials) — the same tensors as before, so nothing else of the stack changes.
+//
+// Shape of the kernel.  512 threads = 8 waves; wave w owns output columns 32 w .. 32 w + 31 of every product, so a
+// product of the chain is 4 "groups" of 64 k: 12 v_mfma_f32_32x32x16_bf16 (hi hi + hi lo + lo hi, the stage's X3
+// arithmetic) on one 32 x 32 accumulator.  The activation operand comes out of LDS (bf16 hi / lo planes [32][264],
+// ds_read_b128, conflict-free at 528-byte rows); the WEIGHT operand never touches LDS: a lane's fragment — 8
+// consecutive k of one output column — is contiguous in a [N][K] weight matrix, so the lanes load it straight from
+// pre-split bf16 planes (lr_tfm_rowblock_pack: hi + lo of every weight and of its transpose, once per forward call)
+// with the k of a group permuted so that a lane's four fragments of a group are 64 contiguous bytes.  Nothing is
+// shared between waves, so the weight stream (2.36 MB per workgroup and layer, out of the L2: every workgroup reads
+// the same planes at about the same time) runs three groups ahead of the MFMAs through a ring of registers, across
+// barriers and epilogues.  One workgroup per CU, 75 of them at B x T = 2400: the bound is that stream,
+// ~64 B/clk per CU.
+#include "lr_common.h"
+#include "lr_rnn_xch.h"
+
+namespace {
+
+using lrx::bf16_t;
+using lrx::bf16x8;
+using lrx::u32;
+using lrx::u32x4;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int RB = 32;          // rows of a workgroup
+constexpr int DM = 256;         // model width = 8 waves x 32 columns
+constexpr int NW = 8;
+constexpr int PLD = DM + 8;     // bf16 elements per plane row (528 bytes: 16-byte slots of consecutive rows differ)
+constexpr int SLD = DM + 4;     // floats per stage row
+constexpr int PLANE = RB * PLD * 2;              // bytes of one bf16 plane
+constexpr int OFF_P0 = 0;                        // planes 0: the input rows, later hidden chunk 0 (hi, lo)
+constexpr int OFF_P1 = 2 * PLANE;                // planes 1: h1 / ds2 (the operand of the chunk products)
+constexpr int OFF_P2 = 4 * PLANE;                // planes 2: hidden chunk 1
+constexpr int OFF_ST = 6 * PLANE;                // fp32 stage [32][260]
+constexpr int OFF_PAR = OFF_ST + RB * SLD * 4;   // 134 656: the layer's bias / LayerNorm vectors (fp32), staged once
+// forward: bo, b2, g1, be1, g2, be2 (256 each), b1 (F); backward: g2, g1
+constexpr int PAR_BO = 0, PAR_B2 = 256, PAR_G1 = 512, PAR_BE1 = 768, PAR_G2 = 1024, PAR_BE2 = 1280, PAR_B1 = 1536;
+constexpr int lds_bytes(int F) { return OFF_PAR + (PAR_B1 + F) * 4; }
+
+struct PackJob {
+  const float* src;
+  bf16_t* hi;
+  bf16_t* lo;
+  int N, K, tile0, transpose;    // the operand M [N][K] = src [N][K], or (transpose) src^T with src [K][N]
+};
+constexpr int PACK_MAX = 48;
+struct PackJobs {
+  PackJob j[PACK_MAX];
+  int n;
+};
+
+// fp32 weight -> bf16 hi + lo planes in FRAGMENT ORDER.  A plane is a sequence of (32-column tile nt, 64-k group g)
+// blocks of 4 KB, tile-major; inside a block [k16 step s][lane l][8 values]: lane l's MFMA fragment of step s = column
+// nt 32 + l % 32, k = 64 g + 32 (l / 32) + 8 s + 0..7.  So one load instruction of the chain kernels (a wave, one step)
+// reads 1 KB of consecutive bytes: full cache lines.  (The first cut read row-major planes, 16 bytes per lane at a
+// 512-byte pitch — 32 lines touched for 1 KB — and ran at the L1's line rate: 30 GB/s per CU, 79 us per launch.)
+// One block per workgroup; the source tile goes through LDS so that both the straight and the transposed operand are
+// read along the source's rows.
+__global__ __launch_bounds__(256) void tfm_rb_pack_kernel(const PackJobs jobs) {
+  __shared__ float t[32][65];
+  int ji = 0;
+  for (int i = 1; i < jobs.n; ++i)
+    if ((int)blockIdx.x >= jobs.j[i].tile0) ji = i;
+  const float* src = jobs.j[ji].src;
+  const int N = jobs.j[ji].N, K = jobs.j[ji].K, tr = jobs.j[ji].transpose;
+  const int blk = blockIdx.x - jobs.j[ji].tile0, gk = K / 64;
+  const int n0 = (blk / gk) * 32, k0 = (blk % gk) * 64;
+  if (!tr) {
+    const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[r4 + 4 * i][c] = src[(int64_t)(n0 + r4 + 4 * i) * K + k0 + c];
+  } else {
+    const int r = threadIdx.x & 31, c8 = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[r][c8 + 8 * i] = src[(int64_t)(k0 + c8 + 8 * i) * N + n0 + r];
+  }
+  __syncthreads();
+  const int st = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const float* row = &t[l & 31][32 * (l >> 5) + 8 * st];
+  u32 h[4], lo4[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) lrx::split_bf16_pair(row[2 * e], row[2 * e + 1], h[e], lo4[e]);
+  const int64_t o = (int64_t)blk * 2048 + (st * 64 + l) * 8;
+  *reinterpret_cast<u32x4*>(jobs.j[ji].hi + o) = u32x4{h[0], h[1], h[2], h[3]};
+  *reinterpret_cast<u32x4*>(jobs.j[ji].lo + o) = u32x4{lo4[0], lo4[1], lo4[2], lo4[3]};
+}
+
+struct RbW {   // one weight of the chain as planes [N][K]
+  const bf16_t* hi;
+  const bf16_t* lo;
+};
+
+struct RbFwdArgs {
+  const float* a;     // [R][256] attention output
+  const float* h;     // [R][256] the layer's input (residual)
+  RbW wo, w1, w2;     // [256][256], [F][256], [256][F]
+  const float *bo, *b1, *b2, *g1, *be1, *g2, *be2;
+  float *s1, *st1, *h1, *f1, *s2, *st2, *h2;
+  int R, F;
+  float eps;
+};
+
+struct RbBwdArgs {
+  const float* dh2;   // [R][256] gradient of the layer's output
+  const float *s2, *st2, *g2, *f1, *s1, *st1, *g1;
+  RbW w2t, w1t, wot;  // W2^T [F][256], W1^T [256][F], Wo^T [256][256]
+  float *ds2, *df1, *ds1, *da;
+  float *lnp2, *lnp1;   // [kLnBlocks][2][256] partial sums of the LayerNorm parameter gradients
+  int R, F, lnblocks;
+};
+
+// ---- memory through buffer resources: a row past R (or a lane that has nothing to store) gets bit 31 set in its
+// offset, is out of the resource's range and reads zeros / is dropped — no branch anywhere in the kernels, which are
+// straight lines (the chunk loop is unrolled: NCH is a template argument), so that the compiler counts the weight
+// stream's loads exactly (`s_waitcnt vmcnt(n)`; with branches around guarded stores it fell back to vmcnt(0) in
+// front of every product and the stream ran one group at a time: 84 us per launch) ----
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, 0x7fffffff, 0x00020000);
+}
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ float ld_f32(rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ float4 ld_f32x4(rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ void st_f32(rsrc_t r, unsigned off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void st_f32x4(rsrc_t r, unsigned off, float4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)off, 0, 0);
+}
+
+// (barriers: lr_lds_barrier, which waits for LDS traffic only — __syncthreads would drain the stream's loads in flight)
+
+// ---- the weight stream of a wave ----------------------------------------------------------------------------------
+// group gi of the chain: phase gi >> 2 (one product of 256 k), quarter gi & 3 (64 k).  A lane holds column n = lane
+// % 32 of the wave's 32 and the k half kh = lane / 32: its fragments of the group's four k16 steps are the 64
+// contiguous bytes at k = k0 + 32 kh of row n of each plane.
+//   forward : phase 0 = Wo, then per chunk c: W1 rows 256 c + n, W2 columns 256 c + k
+//   backward: per chunk c: W2^T rows 256 c + n, W1^T columns 256 c + k; the last phase = Wo^T
+// The ring: THREE groups (96 registers) — the one being consumed and two in flight; a group's slot is refilled with
+// the group three ahead as soon as its MFMAs are issued.  Everything is unrolled, so a group's slot (GI % 3) is static.
+struct Ring {
+  u32x4 hi[3][4], lo[3][4];
+};
+// VMEM instructions stay where they are written (the scheduler otherwise sinks the stream's loads down to their use to
+// save registers, or lifts the MFMAs of the groups in between over them — either way the prefetch distance becomes
+// zero): VMEM and MFMA instructions do not cross; VALU, SALU and LDS reads may
+#define LR_RB_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x106)
+struct Stream {
+  rsrc_t first_hi, first_lo, a_hi, a_lo, b_hi, b_lo;   // planes of [256][256], [F][256], [256][F] operands
+  unsigned voff_a, voff_b;   // lane * 16 + the wave's tile row in a plane with 4 / with F / 64 groups per tile
+};
+// block (tile nt, group g) of a plane with GK groups per tile starts at (nt GK + g) 4096 bytes; step s at + 1024 s
+template <int NCH, bool BWD, int GI>
+__device__ __forceinline__ void ring_issue(Ring& ring, const Stream& sm) {
+  constexpr int P = GI >> 2, KQ = GI & 3, SLOT = GI % 3;
+  constexpr int PC = BWD ? P : P - 1;
+  constexpr bool SINGLE = BWD ? P >= 2 * NCH : P == 0;
+  if constexpr (GI < 4 * (1 + 2 * NCH)) {
+    if constexpr (SINGLE) {                  // tile = wave, 4 groups per tile
+      constexpr int so = KQ * 4096;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        ring.hi[SLOT][s] = __builtin_amdgcn_raw_buffer_load_b128(sm.first_hi, (int)sm.voff_a + s * 1024, so, 0);
+        ring.lo[SLOT][s] = __builtin_amdgcn_raw_buffer_load_b128(sm.first_lo, (int)sm.voff_a + s * 1024, so, 0);
+      }
+    } else if constexpr ((PC & 1) == 0) {    // [F][256]: tile = 8 chunk + wave, 4 groups per tile
+      constexpr int so = ((PC >> 1) * 8 * 4 + KQ) * 4096;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        ring.hi[SLOT][s] = __builtin_amdgcn_raw_buffer_load_b128(sm.a_hi, (int)sm.voff_a + s * 1024, so, 0);
+        ring.lo[SLOT][s] = __builtin_amdgcn_raw_buffer_load_b128(sm.a_lo, (int)sm.voff_a + s * 1024, so, 0);
+      }
+    } else {                                 // [256][F]: tile = wave, group = 4 chunk + quarter of F / 64
+      constexpr int so = ((PC >> 1) * 4 + KQ) * 4096;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        ring.hi[SLOT][s] = __builtin_amdgcn_raw_buffer_load_b128(sm.b_hi, (int)sm.voff_b + s * 1024, so, 0);
+        ring.lo[SLOT][s] = __builtin_amdgcn_raw_buffer_load_b128(sm.b_lo, (int)sm.voff_b + s * 1024, so, 0);
+      }
+    }
+  }
+}
+__device__ __forceinline__ Stream make_stream(const RbW& first, const RbW& a, const RbW& b, int F, int wave, int lane) {
+  Stream sm;
+  sm.first_hi = make_rsrc(first.hi); sm.first_lo = make_rsrc(first.lo);
+  sm.a_hi = make_rsrc(a.hi); sm.a_lo = make_rsrc(a.lo);
+  sm.b_hi = make_rsrc(b.hi); sm.b_lo = make_rsrc(b.lo);
+  sm.voff_a = (unsigned)(lane * 16 + wave * 4 * 4096);
+  sm.voff_b = (unsigned)(lane * 16 + wave * (F / 64) * 4096);
+  return sm;
+}
+
+// One product of the chain on a wave's accumulator: acc += A[32][256] (planes at `pa`, hi then lo) x the wave's 32
+// columns of the phase's weight; behind a group's MFMAs the loads of the group three ahead go into its ring slot.
+template <int NCH, bool BWD, int PHASE>
+__device__ __forceinline__ void product(f32x16& acc, Ring& ring, const Stream& sm, const unsigned char* lds, int pa,
+                                        int lane) {
+  const int m = lane & 31, kh = lane >> 5;
+  const int abase = pa + m * (PLD * 2) + kh * 64;
+#pragma unroll
+  for (int kq = 0; kq < 4; ++kq) {
+    const int slot = (PHASE * 4 + kq) % 3;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const u32x4 ah = *reinterpret_cast<const u32x4*>(lds + abase + kq * 128 + s * 16);
+      const u32x4 al = *reinterpret_cast<const u32x4*>(lds + abase + PLANE + kq * 128 + s * 16);
+      const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah), a_lo = __builtin_bit_cast(bf16x8, al);
+      const bf16x8 b_hi = __builtin_bit_cast(bf16x8, ring.hi[slot][s]), b_lo = __builtin_bit_cast(bf16x8, ring.lo[slot][s]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc, 0, 0, 0);
+    }
+    LR_RB_PIN_VMEM();
+    if (kq == 0) ring_issue<NCH, BWD, PHASE * 4 + 3>(ring, sm);
+    if (kq == 1) ring_issue<NCH, BWD, PHASE * 4 + 4>(ring, sm);
+    if (kq == 2) ring_issue<NCH, BWD, PHASE * 4 + 5>(ring, sm);
+    if (kq == 3) ring_issue<NCH, BWD, PHASE * 4 + 6>(ring, sm);
+    LR_RB_PIN_VMEM();
+  }
+}
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// a wave's accumulator tile -> bf16 hi / lo planes at `pp` (columns 32 wave + lane % 32)
+__device__ __forceinline__ void tile_to_planes(const f32x16& v, unsigned char* lds, int pp, int wave, int lane) {
+  const int col = wave * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    bf16_t h, l;
+    lrx::split_bf16(v[r], h, l);
+    const int o = pp + (acc_row(r, lane) * PLD + col) * 2;
+    *reinterpret_cast<bf16_t*>(lds + o) = h;
+    *reinterpret_cast<bf16_t*>(lds + o + PLANE) = l;
+  }
+}
+
+// byte offset of (row0 + row, col) in a [R][ld] fp32 tensor, out of range past R
+__device__ __forceinline__ unsigned roff(int row0, int row, int R, int ld, int col) {
+  return row0 + row < R ? (unsigned)((row0 + row) * ld + col) * 4u : OOB;
+}
+
+// rows [row0, row0 + 32) of x [R][256] fp32 -> planes at `pp` (zeros past R); 512 threads, 4 float4 each
+__device__ __forceinline__ void rows_to_planes(const float* __restrict__ x, int row0, int R, unsigned char* lds, int pp) {
+  const rsrc_t rx = make_rsrc(x);
+  float4 v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = threadIdx.x + 512 * i;
+    v[i] = ld_f32x4(rx, roff(row0, u >> 6, R, DM, (u & 63) * 4));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = threadIdx.x + 512 * i, r = u >> 6, c4 = (u & 63) * 4;
+    u32 h0, l0, h1, l1;
+    lrx::split_bf16_pair(v[i].x, v[i].y, h0, l0);
+    lrx::split_bf16_pair(v[i].z, v[i].w, h1, l1);
+    const int o = pp + (r * PLD + c4) * 2;
+    *reinterpret_cast<uint2*>(lds + o) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(lds + o + PLANE) = make_uint2(l0, l1);
+  }
+}
+
+// LayerNorm of the stage's rows (wave w: rows 4 w .. 4 w + 3; a lane: 4 consecutive columns): y = LN(stage) gamma +
+// beta -> `y` (global), stats; and, when `pp` >= 0, back into the stage and into the planes at pp
+__device__ __forceinline__ void ln_rows(unsigned char* lds, int par_gamma, int par_beta,
+                                        float* __restrict__ y, float* __restrict__ stats, int row0, int R, float eps,
+                                        int pp, int wave, int lane) {
+  float* stage = reinterpret_cast<float*>(lds + OFF_ST);
+  const float* par = reinterpret_cast<const float*>(lds + OFF_PAR);
+  const rsrc_t ry = make_rsrc(y), rs = make_rsrc(stats);
+  const float4 g = *reinterpret_cast<const float4*>(par + par_gamma + 4 * lane);
+  const float4 b = *reinterpret_cast<const float4*>(par + par_beta + 4 * lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 4 * wave + i;
+    const float4 v = *reinterpret_cast<const float4*>(stage + r * SLD + 4 * lane);
+    const float mean = lr_wave_sum((v.x + v.y) + (v.z + v.w)) * (1.f / DM);
+    const float4 d = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+    const float var = lr_wave_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.f / DM);
+    const float rstd = rsqrtf(var + eps);
+    const float4 o = make_float4(d.x * rstd * g.x + b.x, d.y * rstd * g.y + b.y, d.z * rstd * g.z + b.z, d.w * rstd * g.w + b.w);
+    st_f32x4(ry, roff(row0, r, R, DM, 4 * lane), o);
+    st_f32(rs, lane < 2 ? roff(row0, r, R, 2, lane) : OOB, lane == 0 ? mean : rstd);   // lanes 0, 1: (mean, rstd)
+    if (pp >= 0) {
+      *reinterpret_cast<float4*>(stage + r * SLD + 4 * lane) = o;
+      u32 h0, l0, h1, l1;
+      lrx::split_bf16_pair(o.x, o.y, h0, l0);
+      lrx::split_bf16_pair(o.z, o.w, h1, l1);
+      const int a = pp + (r * PLD + 4 * lane) * 2;
+      *reinterpret_cast<uint2*>(lds + a) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(lds + a + PLANE) = make_uint2(l0, l1);
+    }
+  }
+}
+
+template <int NCH, int C>
+__device__ __forceinline__ void fwd_chunks(const RbFwdArgs& p, Ring& ring, const Stream& sm, unsigned char* lds,
+                                           f32x16& acc2, rsrc_t rf1, int row0, int wave, int lane) {
+  if constexpr (C < NCH) {
+    constexpr int hp = (C & 1) ? OFF_P2 : OFF_P0;
+    const int col = wave * 32 + (lane & 31);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    product<NCH, false, 1 + 2 * C>(acc, ring, sm, lds, OFF_P1, lane);
+    {
+      const float bias = reinterpret_cast<const float*>(lds + OFF_PAR)[PAR_B1 + C * 256 + col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[r] = fmaxf(acc[r] + bias, 0.f);
+        st_f32(rf1, roff(row0, acc_row(r, lane), p.R, 256 * NCH, C * 256 + col), acc[r]);
+      }
+      tile_to_planes(acc, lds, hp, wave, lane);
+    }
+    lr_lds_barrier();
+    product<NCH, false, 2 + 2 * C>(acc2, ring, sm, lds, hp, lane);
+    fwd_chunks<NCH, C + 1>(p, ring, sm, lds, acc2, rf1, row0, wave, lane);
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(512, 1) void tfm_rb_fwd_kernel(const RbFwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* stage = reinterpret_cast<float*>(lds + OFF_ST);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row0 = blockIdx.x * RB, R = p.R;
+  const int col = wave * 32 + (lane & 31);
+  float* par = reinterpret_cast<float*>(lds + OFF_PAR);
+  // the layer's small vectors -> LDS, asked for IN FRONT of the weight stream: a load in the middle of the chain would
+  // have to wait for every older load, i.e. drain the stream
+  float pv[3 + NCH / 2 + 1];
+  {
+    const float* src[3] = {threadIdx.x < 256 ? p.bo : p.b2, threadIdx.x < 256 ? p.g1 : p.be1, threadIdx.x < 256 ? p.g2 : p.be2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pv[i] = src[i][threadIdx.x & 255];
+#pragma unroll
+    for (int i = 0; i < (256 * NCH + 511) / 512; ++i) {
+      const int c = threadIdx.x + 512 * i;
+      pv[3 + i] = c < 256 * NCH ? p.b1[c] : 0.f;
+    }
+  }
+  LR_RB_PIN_VMEM();
+  const Stream sm = make_stream(p.wo, p.w1, p.w2, 256 * NCH, wave, lane);
+  Ring ring;
+  ring_issue<NCH, false, 0>(ring, sm);
+  ring_issue<NCH, false, 1>(ring, sm);
+  ring_issue<NCH, false, 2>(ring, sm);
+  LR_RB_PIN_VMEM();
+#pragma unroll
+  for (int i = 0; i < 3; ++i) par[512 * i + threadIdx.x] = pv[i];
+#pragma unroll
+  for (int i = 0; i < (256 * NCH + 511) / 512; ++i)
+    if (threadIdx.x + 512 * i < 256 * NCH) par[PAR_B1 + threadIdx.x + 512 * i] = pv[3 + i];
+  rows_to_planes(p.a, row0, R, lds, OFF_P0);
+  lr_lds_barrier();
+
+  // s1 = a Wo^T + bo + h
+  f32x16 acc, pre;   // pre: what an epilogue reads from memory, asked for in front of the product
+  {
+    const rsrc_t rh = make_rsrc(p.h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[r] = 0.f;
+      pre[r] = ld_f32(rh, roff(row0, acc_row(r, lane), R, DM, col));
+    }
+  }
+  product<NCH, false, 0>(acc, ring, sm, lds, OFF_P0, lane);
+  {
+    const rsrc_t rs1 = make_rsrc(p.s1);
+    const float bias = par[PAR_BO + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, lane);
+      const float v = acc[r] + bias + pre[r];
+      st_f32(rs1, roff(row0, row, R, DM, col), v);
+      stage[row * SLD + col] = v;
+    }
+  }
+  lr_lds_barrier();
+  ln_rows(lds, PAR_G1, PAR_BE1, p.h1, p.st1, row0, R, p.eps, OFF_P1, wave, lane);
+  lr_lds_barrier();
+
+  f32x16 acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+  fwd_chunks<NCH, 0>(p, ring, sm, lds, acc2, make_rsrc(p.f1), row0, wave, lane);
+  {
+    const rsrc_t rs2 = make_rsrc(p.s2);
+    const float bias = par[PAR_B2 + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = acc_row(r, lane);
+      const float v = acc2[r] + bias + stage[row * SLD + col];   // + h1
+      st_f32(rs2, roff(row0, row, R, DM, col), v);
+      stage[row * SLD + col] = v;
+    }
+  }
+  lr_lds_barrier();
+  ln_rows(lds, PAR_G2, PAR_BE2, p.h2, p.st2, row0, R, p.eps, -1, wave, lane);
+}
+
+// LayerNorm backward of the stage's rows: stage holds dy; x rows (the LayerNorm's input) and stats from memory.
+// dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma -> `dx` (global), the stage and the planes at pp; the
+// rows' share of dgamma / dbeta is summed over the workgroup's rows into partial[0 / 1][256].
+__device__ __forceinline__ void ln_rows_bwd(unsigned char* lds, const float* __restrict__ x, const float* __restrict__ stats,
+                                            int par_gamma, float* __restrict__ dx,
+                                            float* __restrict__ partial, int row0, int R, int pp, int wave, int lane,
+                                            float* red) {
+  float* stage = reinterpret_cast<float*>(lds + OFF_ST);
+  const rsrc_t rx = make_rsrc(x), rst = make_rsrc(stats), rdx = make_rsrc(dx);
+  const float4 g = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(lds + OFF_PAR) + par_gamma + 4 * lane);
+  float4 sxh = make_float4(0.f, 0.f, 0.f, 0.f), sdy = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 xv[4];
+  float mean[4], rstd[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {   // (rows past R: x, mean and rstd read as zeros, dy is zero in the stage)
+    const int r = 4 * wave + i;
+    xv[i] = ld_f32x4(rx, roff(row0, r, R, DM, 4 * lane));
+    mean[i] = ld_f32(rst, roff(row0, r, R, 2, 0));
+    rstd[i] = ld_f32(rst, roff(row0, r, R, 2, 1));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 4 * wave + i;
+    const float4 dy = *reinterpret_cast<const float4*>(stage + r * SLD + 4 * lane);
+    const float mu = mean[i], rs = rstd[i];
+    const float4 xh = make_float4((xv[i].x - mu) * rs, (xv[i].y - mu) * rs, (xv[i].z - mu) * rs, (xv[i].w - mu) * rs);
+    const float4 gg = make_float4(dy.x * g.x, dy.y * g.y, dy.z * g.z, dy.w * g.w);
+    const float sg = lr_wave_sum((gg.x + gg.y) + (gg.z + gg.w)) * (1.f / DM);
+    const float sgx = lr_wave_sum((gg.x * xh.x + gg.y * xh.y) + (gg.z * xh.z + gg.w * xh.w)) * (1.f / DM);
+    sxh.x += dy.x * xh.x; sxh.y += dy.y * xh.y; sxh.z += dy.z * xh.z; sxh.w += dy.w * xh.w;
+    sdy.x += dy.x; sdy.y += dy.y; sdy.z += dy.z; sdy.w += dy.w;
+    const float4 o = make_float4(rs * (gg.x - sg - xh.x * sgx), rs * (gg.y - sg - xh.y * sgx),
+                                 rs * (gg.z - sg - xh.z * sgx), rs * (gg.w - sg - xh.w * sgx));
+    st_f32x4(rdx, roff(row0, r, R, DM, 4 * lane), o);
+    *reinterpret_cast<float4*>(stage + r * SLD + 4 * lane) = o;
+    u32 h0, l0, h1, l1;
+    lrx::split_bf16_pair(o.x, o.y, h0, l0);
+    lrx::split_bf16_pair(o.z, o.w, h1, l1);
+    const int a = pp + (r * PLD + 4 * lane) * 2;
+    *reinterpret_cast<uint2*>(lds + a) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(lds + a + PLANE) = make_uint2(l0, l1);
+  }
+  // the workgroup's partial sums: waves in fixed order through `red` [8][2][256]
+  *reinterpret_cast<float4*>(red + (wave * 2 + 0) * DM + 4 * lane) = sxh;
+  *reinterpret_cast<float4*>(red + (wave * 2 + 1) * DM + 4 * lane) = sdy;
+  lr_lds_barrier();
+  {
+    const int c = threadIdx.x;   // 512 threads = 2 x 256 columns
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w * 2 * DM + c];
+    partial[c] = s;
+  }
+}
+
+template <int NCH, int C>
+__device__ __forceinline__ void bwd_chunks(const RbBwdArgs& p, Ring& ring, const Stream& sm, unsigned char* lds,
+                                           f32x16& acc2, rsrc_t rf1, rsrc_t rdf1, int row0, int wave, int lane) {
+  if constexpr (C < NCH) {
+    constexpr int hp = (C & 1) ? OFF_P2 : OFF_P0;
+    const int col = wave * 32 + (lane & 31);
+    f32x16 acc, pre;   // pre: the chunk's f1 (the ReLU mask), asked for in front of the product
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[r] = 0.f;
+      pre[r] = ld_f32(rf1, roff(row0, acc_row(r, lane), p.R, 256 * NCH, C * 256 + col));
+    }
+    product<NCH, true, 2 * C>(acc, ring, sm, lds, OFF_P1, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[r] = pre[r] > 0.f ? acc[r] : 0.f;
+      st_f32(rdf1, roff(row0, acc_row(r, lane), p.R, 256 * NCH, C * 256 + col), acc[r]);
+    }
+    tile_to_planes(acc, lds, hp, wave, lane);
+    lr_lds_barrier();
+    product<NCH, true, 2 * C + 1>(acc2, ring, sm, lds, hp, lane);
+    bwd_chunks<NCH, C + 1>(p, ring, sm, lds, acc2, rf1, rdf1, row0, wave, lane);
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(512, 1) void tfm_rb_bwd_kernel(const RbBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* stage = reinterpret_cast<float*>(lds + OFF_ST);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row0 = blockIdx.x * RB, R = p.R;
+  const int col = wave * 32 + (lane & 31);
+  float* red = reinterpret_cast<float*>(lds + OFF_P2);   // [8][2][256] floats = 16 KB: inside planes 2 while they are idle
+  const float pv = (threadIdx.x < 256 ? p.g2 : p.g1)[threadIdx.x & 255];   // (in front of the stream, as in the forward)
+  LR_RB_PIN_VMEM();
+  const Stream sm = make_stream(p.wot, p.w2t, p.w1t, 256 * NCH, wave, lane);
+  Ring ring;
+  ring_issue<NCH, true, 0>(ring, sm);
+  ring_issue<NCH, true, 1>(ring, sm);
+  ring_issue<NCH, true, 2>(ring, sm);
+  LR_RB_PIN_VMEM();
+  // the partial rows nobody writes stay zero (the first workgroups clear the unused tail)
+  for (int b = gridDim.x + blockIdx.x; b < p.lnblocks; b += gridDim.x) {
+    p.lnp2[(int64_t)b * 2 * DM + threadIdx.x] = 0.f;
+    p.lnp1[(int64_t)b * 2 * DM + threadIdx.x] = 0.f;
+  }
+  reinterpret_cast<float*>(lds + OFF_PAR)[threadIdx.x] = pv;   // g2 at 0, g1 at 256
+  {   // dy rows -> stage
+    const rsrc_t rdy = make_rsrc(p.dh2);
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = threadIdx.x + 512 * i;
+      v[i] = ld_f32x4(rdy, roff(row0, u >> 6, R, DM, (u & 63) * 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = threadIdx.x + 512 * i;
+      *reinterpret_cast<float4*>(stage + (u >> 6) * SLD + (u & 63) * 4) = v[i];
+    }
+  }
+  lr_lds_barrier();
+  ln_rows_bwd(lds, p.s2, p.st2, 0, p.ds2, p.lnp2 + (int64_t)blockIdx.x * 2 * DM, row0, R, OFF_P1, wave, lane, red);
+  lr_lds_barrier();   // planes 1 = ds2 (and the stage, fp32); `red` is free again
+
+  f32x16 acc, acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+  bwd_chunks<NCH, 0>(p, ring, sm, lds, acc2, make_rsrc(p.f1), make_rsrc(p.df1), row0, wave, lane);
+  // dh1 = df1 W1 + ds2 -> stage
+#pragma unroll
+  for (int r = 0; r < 16; ++r) stage[acc_row(r, lane) * SLD + col] += acc2[r];
+  lr_lds_barrier();   // (every wave is past its last read of planes 2: `red` may be written)
+  ln_rows_bwd(lds, p.s1, p.st1, 256, p.ds1, p.lnp1 + (int64_t)blockIdx.x * 2 * DM, row0, R, OFF_P1, wave, lane, red);
+  lr_lds_barrier();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  product<NCH, true, 2 * NCH>(acc, ring, sm, lds, OFF_P1, lane);
+  {
+    const rsrc_t rda = make_rsrc(p.da);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st_f32(rda, roff(row0, acc_row(r, lane), R, DM, col), acc[r]);
+  }
+}
+
+bool g_attr_set[2][4] = {{false, false, false, false}, {false, false, false, false}};
+
+}  // namespace
+
+// ---- host side (declared in lr_common.h; lr_transformer.hip composes the stack) -------------------------------------
+int lr_tfm_rb_supported(int Dm, int F, int nlayers) {
+  return Dm == DM && (F == 256 || F == 512 || F == 1024 || F == 2048) && nlayers >= 1 && 6 * nlayers <= PACK_MAX;
+}
+// bf16 elements of one layer's planes: hi + lo of Wo, W1, W2 and of their transposes
+size_t lr_tfm_rb_plane_elems(int F) { return (size_t)4 * ((size_t)DM * DM + 2 * (size_t)DM * F); }
+
+// planes of layer l inside `planes`: [Wo | W1 | W2 | Wo^T | W1^T | W2^T] each as hi then lo
+static void rb_layer_planes(void* planes, int l, int F, RbW out[6]) {
+  bf16_t* b = (bf16_t*)planes + (size_t)l * lr_tfm_rb_plane_elems(F);
+  const size_t sz[6] = {(size_t)DM * DM, (size_t)DM * F, (size_t)DM * F, (size_t)DM * DM, (size_t)DM * F, (size_t)DM * F};
+  for (int i = 0; i < 6; ++i) {
+    out[i].hi = b;
+    out[i].lo = b + sz[i];
+    b += 2 * sz[i];
+  }
+}
+
+// weights: the stack's pointer table (2 + 12 per layer, torch's registration order)
+int lr_tfm_rb_pack(const float* const* weights, void* planes, int F, int nlayers, hipStream_t st) {
+  PackJobs jobs;
+  int n = 0, tiles = 0;
+  for (int l = 0; l < nlayers; ++l) {
+    const float* const* W = weights + 2 + 12 * l;
+    RbW pl[6];
+    rb_layer_planes(planes, l, F, pl);
+    const float* src[3] = {W[2], W[4], W[6]};
+    const int Ns[3] = {DM, F, DM}, Ks[3] = {DM, DM, F};
+    for (int t = 0; t < 2; ++t)
+      for (int i = 0; i < 3; ++i) {
+        PackJob& j = jobs.j[n++];
+        j.src = src[i];
+        j.hi = const_cast<bf16_t*>(pl[3 * t + i].hi);
+        j.lo = const_cast<bf16_t*>(pl[3 * t + i].lo);
+        j.N = t ? Ks[i] : Ns[i]; j.K = t ? Ns[i] : Ks[i]; j.tile0 = tiles; j.transpose = t;   // the OPERAND's shape
+        tiles += (j.N / 32) * (j.K / 64);
+      }
+  }
+  jobs.n = n;
+  LR_LAUNCH(tfm_rb_pack_kernel, dim3(tiles), dim3(256), 0, st, jobs);
+  return lr_launch_status();
+}
+
+static int rb_attr(const void* fn, int dir, int idx) {
+  if (g_attr_set[dir][idx]) return LR_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2048)) != hipSuccess) return LR_ERR_LAUNCH;
+  g_attr_set[dir][idx] = true;
+  return LR_OK;
+}
+// the kernels are instantiated for 1, 2, 4, 8 chunks of 256 hidden columns
+#define LR_RB_DISPATCH(KERNEL, DIR, ...)                                                                   \
+  do {                                                                                                     \
+    const int nch_ = F / 256, idx_ = nch_ == 1 ? 0 : nch_ == 2 ? 1 : nch_ == 4 ? 2 : 3;                    \
+    const void* fn_ = nch_ == 1 ? (const void*)KERNEL<1> : nch_ == 2 ? (const void*)KERNEL<2>              \
+                      : nch_ == 4 ? (const void*)KERNEL<4> : (const void*)KERNEL<8>;                       \
+    const int rc_ = rb_attr(fn_, DIR, idx_);                                                               \
+    if (rc_ != LR_OK) return rc_;                                                                          \
+    const dim3 grid_((R + RB - 1) / RB);                                                                   \
+    if (nch_ == 1) LR_LAUNCH(KERNEL<1>, grid_, dim3(512), lds_bytes(F), st, p);                               \
+    else if (nch_ == 2) LR_LAUNCH(KERNEL<2>, grid_, dim3(512), lds_bytes(F), st, p);                          \
+    else if (nch_ == 4) LR_LAUNCH(KERNEL<4>, grid_, dim3(512), lds_bytes(F), st, p);                          \
+    else LR_LAUNCH(KERNEL<8>, grid_, dim3(512), lds_bytes(F), st, p);                                         \
+  } while (0)
+
+// W: the layer's 12 weight pointers; the tensors are the layer's block of the reserve (lr_transformer.hip)
+int lr_tfm_rb_forward(const void* planes, int l, const float* const* W, const float* a, const float* h, float* s1,
+                      float* st1, float* h1, float* f1, float* s2, float* st2, float* h2, int R, int F, float eps,
+                      hipStream_t st) {
+  RbW pl[6];
+  rb_layer_planes(const_cast<void*>(planes), l, F, pl);
+  RbFwdArgs p;
+  p.a = a; p.h = h;
+  p.wo = pl[0]; p.w1 = pl[1]; p.w2 = pl[2];
+  p.bo = W[3]; p.b1 = W[5]; p.b2 = W[7]; p.g1 = W[8]; p.be1 = W[9]; p.g2 = W[10]; p.be2 = W[11];
+  p.s1 = s1; p.st1 = st1; p.h1 = h1; p.f1 = f1; p.s2 = s2; p.st2 = st2; p.h2 = h2;
+  p.R = R; p.F = F; p.eps = eps;
+  LR_RB_DISPATCH(tfm_rb_fwd_kernel, 0);
+  return lr_launch_status();
+}
+
+int lr_tfm_rb_backward(const void* planes, int l, const float* const* W, const float* dh2, const float* s2,
+                       const float* st2, const float* f1, const float* s1, const float* st1, float* ds2, float* df1,
+                       float* ds1, float* da, float* lnp2, float* lnp1, int lnblocks, int R, int F, hipStream_t st) {
+  RbW pl[6];
+  rb_layer_planes(const_cast<void*>(planes), l, F, pl);
+  RbBwdArgs p;
+  p.dh2 = dh2; p.s2 = s2; p.st2 = st2; p.g2 = W[10]; p.f1 = f1; p.s1 = s1; p.st1 = st1; p.g1 = W[8];
+  p.wot = pl[3]; p.w1t = pl[4]; p.w2t = pl[5];
+  p.ds2 = ds2; p.df1 = df1; p.ds1 = ds1; p.da = da; p.lnp2 = lnp2; p.lnp1 = lnp1;
+  p.R = R; p.F = F; p.lnblocks = lnblocks;
+  if ((R + RB - 1) / RB > lnblocks) return LR_ERR_UNSUPPORTED;
+  LR_RB_DISPATCH(tfm_rb_bwd_kernel, 1);
+  return lr_launch_status();
+}

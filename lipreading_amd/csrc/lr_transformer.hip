@@ -205,6 +205,7 @@ inline size_t al64(size_t n) { return (n + 63) / 64 * 64; }
 struct TfmReserve {
   size_t h0, layer0, per_layer, total;
   size_t qkv, a, s1, st1, h1, f1, s2, st2, h2, probs;   // inside a layer's block
+  size_t planes;                                        // LR_TFM_ROWBLOCK: the bf16 weight planes of every layer
 };
 TfmReserve tfm_reserve(int mode, int B, int T, int Dm, int nh, int F, int nl) {
   TfmReserve r;
@@ -223,7 +224,8 @@ TfmReserve tfm_reserve(int mode, int B, int T, int Dm, int nh, int F, int nl) {
   r.h2 = p; p += al64(R * Dm);
   r.probs = p; p += (mode & LR_TFM_ATTN_FUSED) ? 0 : al64((size_t)B * nh * T * T);
   r.per_layer = p;
-  r.total = r.layer0 + (size_t)nl * p;
+  r.planes = r.layer0 + (size_t)nl * p;
+  r.total = r.planes + ((mode & LR_TFM_ROWBLOCK) ? al64((size_t)nl * lr_tfm_rb_plane_elems(F) / 2) : 0);
   return r;
 }
 
@@ -260,8 +262,9 @@ TfmWs tfm_ws(int mode, int B, int T, int I, int Dm, int nh, int F, int nl) {
 bool tfm_dims_ok(int mode, int B, int T, int I, int Dm, int nh, int F, int nl) {
   return B > 0 && T > 0 && I > 0 && Dm > 0 && nh > 0 && F > 0 && nl > 0 && Dm % nh == 0 && Dm % 4 == 0 && F % 4 == 0 &&
          (Dm / nh) % 4 == 0 && 2 * nl <= LN_MAX_JOBS && (size_t)4 * 2 * Dm * sizeof(float) <= 60 * 1024 &&
-         (mode & ~(LR_TFM_X3 | LR_TFM_X_BF16 | LR_TFM_DX_BF16 | LR_TFM_ATTN_FUSED)) == 0 &&
-         (!(mode & LR_TFM_ATTN_FUSED) || lr_attn_fused_supported(T, Dm / nh));
+         (mode & ~(LR_TFM_X3 | LR_TFM_X_BF16 | LR_TFM_DX_BF16 | LR_TFM_ATTN_FUSED | LR_TFM_ROWBLOCK)) == 0 &&
+         (!(mode & LR_TFM_ATTN_FUSED) || lr_attn_fused_supported(T, Dm / nh)) &&
+         (!(mode & LR_TFM_ROWBLOCK) || ((mode & LR_TFM_X3) && lr_tfm_rb_supported(Dm, F, nl) && ((size_t)B * T + 31) / 32 <= (size_t)kLnBlocks));
 }
 
 lr_fgemm_job job(const void* A, int lda, const void* Bm, int ldb, void* C, int ldc, int M, int N, int K) {
@@ -355,6 +358,8 @@ extern "C" int lr_tfm_forward(int mode, const void* x, const int32_t* key_lens, 
     j.slabs = wsb + w.slabs;
     LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NT, xbf, 0, &j, 1, st));
   }
+  const bool rowblock = (mode & LR_TFM_ROWBLOCK) != 0;
+  if (rowblock) LR_TRY_(lr_tfm_rb_pack(weights, base + r.planes, F, nlayers, st));
   for (int l = 0; l < nlayers; ++l) {
     const float* const* W = weights + 2 + 12 * l;
     float* L = base + r.layer0 + (size_t)l * r.per_layer;
@@ -366,6 +371,12 @@ extern "C" int lr_tfm_forward(int mode, const void* x, const int32_t* key_lens, 
       LR_TRY_(lr_attn_fused_forward(L + r.qkv, key_lens, L + r.a, 1.f / sqrtf((float)dh), B, T, nhead, dh, st));
     else
       LR_TRY_(attention_f32_forward(L + r.qkv, key_lens, L + r.probs, L + r.a, B, T, nhead, dh, st));
+    if (rowblock) {   // out-projection .. LN2 in one launch (lr_tfm_rowblock.hip)
+      LR_TRY_(lr_tfm_rb_forward(base + r.planes, l, W, L + r.a, h, L + r.s1, L + r.st1, L + r.h1, L + r.f1, L + r.s2,
+                                L + r.st2, h2, R, F, eps, st));
+      h = h2;
+      continue;
+    }
     j = job(L + r.a, Dm, W[2], Dm, L + r.s1, Dm, R, Dm, Dm);      // s1 = a W_o^T + b_o + h
     j.bias = W[3];
     j.addend = h; j.ldadd = Dm; j.add_period = R;
@@ -405,16 +416,22 @@ extern "C" int lr_tfm_backward_data(int mode, const int32_t* key_lens, const flo
     float* G = wsb + w.layer0 + (size_t)l * w.per_layer;
     // the gradient of layer l's input: layer 0's lands in dhA (backward_weights reads it there)
     float* dh_prev = wsb + ((l & 1) ? w.dhB : w.dhA);
-    LR_TRY_(ln_backward(L + r.s2, W[10], L + r.st2, dh_cur, G + w.ds2, G + w.lnp2, R, Dm, st));
-    lr_fgemm_job j = job(G + w.ds2, Dm, W[6], F, G + w.df1, F, R, F, Dm);      // df1 = (ds2 W_2) where f1 > 0
-    j.mask = L + r.f1; j.ldmask = F;
-    LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NN, 0, 0, &j, 1, st));
-    j = job(G + w.df1, F, W[4], Dm, wsb + w.dh1, Dm, R, Dm, F);                // dh1 = df1 W_1 + ds2
-    j.addend = G + w.ds2; j.ldadd = Dm; j.add_period = R;
-    LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NN, 0, 0, &j, 1, st));
-    LR_TRY_(ln_backward(L + r.s1, W[8], L + r.st1, wsb + w.dh1, G + w.ds1, G + w.lnp1, R, Dm, st));
-    j = job(G + w.ds1, Dm, W[2], Dm, wsb + w.da, Dm, R, Dm, Dm);               // da = ds1 W_o
-    LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NN, 0, 0, &j, 1, st));
+    lr_fgemm_job j;
+    if (mode & LR_TFM_ROWBLOCK) {   // LN2' .. the out-projection's data gradient in one launch (lr_tfm_rowblock.hip)
+      LR_TRY_(lr_tfm_rb_backward(base + r.planes, l, W, dh_cur, L + r.s2, L + r.st2, L + r.f1, L + r.s1, L + r.st1,
+                                 G + w.ds2, G + w.df1, G + w.ds1, wsb + w.da, G + w.lnp2, G + w.lnp1, kLnBlocks, R, F, st));
+    } else {
+      LR_TRY_(ln_backward(L + r.s2, W[10], L + r.st2, dh_cur, G + w.ds2, G + w.lnp2, R, Dm, st));
+      j = job(G + w.ds2, Dm, W[6], F, G + w.df1, F, R, F, Dm);      // df1 = (ds2 W_2) where f1 > 0
+      j.mask = L + r.f1; j.ldmask = F;
+      LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NN, 0, 0, &j, 1, st));
+      j = job(G + w.df1, F, W[4], Dm, wsb + w.dh1, Dm, R, Dm, F);                // dh1 = df1 W_1 + ds2
+      j.addend = G + w.ds2; j.ldadd = Dm; j.add_period = R;
+      LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NN, 0, 0, &j, 1, st));
+      LR_TRY_(ln_backward(L + r.s1, W[8], L + r.st1, wsb + w.dh1, G + w.ds1, G + w.lnp1, R, Dm, st));
+      j = job(G + w.ds1, Dm, W[2], Dm, wsb + w.da, Dm, R, Dm, Dm);               // da = ds1 W_o
+      LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NN, 0, 0, &j, 1, st));
+    }
     if (mode & LR_TFM_ATTN_FUSED)
       LR_TRY_(lr_attn_fused_backward(L + r.qkv, key_lens, wsb + w.da, G + w.dqkv, 1.f / sqrtf((float)dh), B, T, nhead, dh, st));
     else
@@ -492,4 +509,8 @@ extern "C" int lr_tfm_backward_weights(int mode, const void* x, float* const* gr
   }
   LR_LAUNCH(ln_param_reduce_kernel, dim3((2 * Dm + 63) / 64, 2 * nlayers), dim3(256), 0, st, lj, Dm, accumulate);
   return lr_launch_status();
+}
+
+extern "C" int lr_tfm_rowblock_supported(int B, int T, int Dm, int F, int nlayers) {
+  return B > 0 && T > 0 && lr_tfm_rb_supported(Dm, F, nlayers) && ((size_t)B * T + 31) / 32 <= (size_t)kLnBlocks;
 }

@@ -29,7 +29,10 @@ from .data import BOS, PAD
 from .encoder import _ProjLogSoftmaxFunction, _direct_grads, _notify, _ptr_array
 
 
-_X3, _X_BF16, _DX_BF16, _ATTN_FUSED = 1, 2, 4, 8   # LR_TFM_* (include/lipreading_hip.h)
+_X3, _X_BF16, _DX_BF16, _ATTN_FUSED, _ROWBLOCK = 1, 2, 4, 8, 16   # LR_TFM_* (include/lipreading_hip.h)
+
+# test hook: False keeps the row-wise half of a layer as five launches per direction (lr_fgemm products + LayerNorm)
+rowblock_layers = True
 
 
 class _StackFunction(torch.autograd.Function):
@@ -241,6 +244,9 @@ class TransformerVideoEncoder(nn.Module):
     fused = self.attention == 'bf16' and bool(_C.lib().lr_attn_fused_supported(max_len, self.d_model // self.nhead))
     mode = ((_X3 if self.input_projection == 'bf16x3' else 0) | ((_X_BF16 | _DX_BF16) if stored_bf16 else 0) |
             (_ATTN_FUSED if fused else 0))
+    F = self.layers[0].linear1.out_features
+    if (mode & _X3) and rowblock_layers and _C.lib().lr_tfm_rowblock_supported(B, max_len, self.d_model, F, len(self.layers)):
+      mode |= _ROWBLOCK   # out-projection .. LN2 as one launch per layer and direction (lr_tfm_rowblock.hip)
     weights = [self.input_proj.weight, self.input_proj.bias]
     for layer in self.layers:
       at = layer.self_attn

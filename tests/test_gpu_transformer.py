@@ -156,3 +156,45 @@ def test_transformer_at_the_bench_shape(dev, attention):
   for k, p in enc.named_parameters():
     r = (want[k] if k in want else want["encoder." + k]).grad
     assert float((p.grad.cpu() - r).norm()) <= tol * max(1e-6, float(r.norm())), (attention, k)
+
+
+@pytest.mark.parametrize("B,T,ff,layers,lens", [(4, 20, 512, 2, [20, 13, 20, 5]),       # 80 rows: two full blocks and a half
+                                               (3, 11, 256, 1, [11, 11, 4]),           # 33 rows: one row past a block
+                                               (32, 75, 1024, 4, None)])               # the bench shape (75 blocks)
+def test_rowblock_layers_equal_the_five_launch_path(dev, B, T, ff, layers, lens):
+  """LR_TFM_ROWBLOCK (lr_tfm_rowblock.hip: out-projection .. LN2 and their backward as one launch per layer and
+  direction) against the same stack composed of lr_fgemm products + LayerNorm launches: the same X3 arithmetic in
+  another summation order.  Every output, the input gradient and every parameter gradient."""
+  import lipreading_amd.transformer as tfm
+  _, enc = make_pair(dev, frame_dim=96, d_model=256, nhead=4, layers=layers, ff=ff, seed=11, attention='bf16')
+  enc.input_projection = 'bf16x3'
+  assert _lib().lr_tfm_rowblock_supported(B, T, 256, ff, layers) == 1
+  g = torch.Generator().manual_seed(12)
+  x0 = torch.randn(B, T, 96, generator=g).to(dev)
+  lens_t = torch.full((B,), T) if lens is None else torch.tensor(lens)
+  wgt = torch.randn(B, T, 65, generator=g).to(dev)
+  valid = (torch.arange(T).unsqueeze(0) < lens_t.unsqueeze(1)).float().unsqueeze(-1).to(dev)
+  res = {}
+  for rb in (False, True):
+    tfm.rowblock_layers = rb
+    try:
+      enc.zero_grad()
+      x = x0.clone().requires_grad_(True)
+      lp, h, _ = enc(x, lens_t, max_len=T)
+      ((lp * wgt * valid).sum() + (h * valid).pow(2).sum()).backward()
+      res[rb] = [lp.detach().cpu(), h.detach().cpu(), x.grad.cpu()] + [p.grad.cpu().clone() for p in enc.parameters()]
+    finally:
+      tfm.rowblock_layers = True
+  names = ["log_probs", "hidden", "dx"] + [k for k, _ in enc.named_parameters()]
+  for k, a, b in zip(names, res[False], res[True]):
+    assert torch.isfinite(b).all(), k
+    # (norm-wise, as in the test above: a ReLU whose pre-activation sits within 1e-6 of zero may switch)
+    # gradients: 1e-3 up to two layers; 3e-3 through four (the same stack in exact fp32 differs from the CPU's
+    # summation order by 1.3e-3 there: test_transformer_at_the_bench_shape)
+    tol = 2e-4 if k in ("log_probs", "hidden") else (1e-3 if layers <= 2 else 3e-3)
+    assert float((a - b).norm()) / max(1e-6, float(a.norm())) < tol, (k, float((a - b).norm()), float(a.norm()))
+
+
+def _lib():
+  from lipreading_amd import _C
+  return _C.lib()
