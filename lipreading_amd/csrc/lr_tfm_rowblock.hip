@@ -124,6 +124,15 @@ struct RbBwdArgs {
   int R, F, lnblocks;
 };
 
+// -DLR_RB_TIMING (tools/build_variant.sh; never in the product build): lane 0 of every wave of workgroup 0 stamps the
+// clock at the phase boundaries; tools/probes/rb_timing.py reads them back through lr_tfm_rb_debug_times
+#ifdef LR_RB_TIMING
+__device__ long long g_rb_times[2][8][32];
+#define LR_RB_T(dir, k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_rb_times[dir][threadIdx.x >> 6][k] = wall_clock64(); } while (0)
+#else
+#define LR_RB_T(dir, k) do { } while (0)
+#endif
+
 // ---- memory through buffer resources: a row past R (or a lane that has nothing to store) gets bit 31 set in its
 // offset, is out of the resource's range and reads zeros / is dropped — no branch anywhere in the kernels, which are
 // straight lines (the chunk loop is unrolled: NCH is a template argument), so that the compiler counts the weight
@@ -168,12 +177,18 @@ struct Stream {
   rsrc_t first_hi, first_lo, a_hi, a_lo, b_hi, b_lo;   // planes of [256][256], [F][256], [256][F] operands
   unsigned voff_a, voff_b;   // lane * 16 + the wave's tile row in a plane with 4 / with F / 64 groups per tile
 };
+// (measured and dropped, round 6: every wave taking a group's four k16 steps in its own rotated order, so that the
+// eight waves and the launch's workgroups do not ask for the same 1 KB quarter of their 4 KB blocks at once — no
+// change in the products' time, eight more live registers: 34.7 -> 36.0 us.)
 // block (tile nt, group g) of a plane with GK groups per tile starts at (nt GK + g) 4096 bytes; step s at + 1024 s
 template <int NCH, bool BWD, int GI>
 __device__ __forceinline__ void ring_issue(Ring& ring, const Stream& sm) {
   constexpr int P = GI >> 2, KQ = GI & 3, SLOT = GI % 3;
   constexpr int PC = BWD ? P : P - 1;
   constexpr bool SINGLE = BWD ? P >= 2 * NCH : P == 0;
+#ifdef LR_RB_EXP_NOSTREAM   // timing experiment: the chain without its weight stream (results are garbage)
+  if constexpr (GI >= 3) return;
+#endif
   if constexpr (GI < 4 * (1 + 2 * NCH)) {
     if constexpr (SINGLE) {                  // tile = wave, 4 groups per tile
       constexpr int so = KQ * 4096;
@@ -214,20 +229,27 @@ __device__ __forceinline__ Stream make_stream(const RbW& first, const RbW& a, co
 template <int NCH, bool BWD, int PHASE>
 __device__ __forceinline__ void product(f32x16& acc, Ring& ring, const Stream& sm, const unsigned char* lds, int pa,
                                         int lane) {
-  const int m = lane & 31, kh = lane >> 5;
-  const int abase = pa + m * (PLD * 2) + kh * 64;
+  const int abase = pa + (lane & 31) * (PLD * 2) + (lane >> 5) * 64;
 #pragma unroll
   for (int kq = 0; kq < 4; ++kq) {
     const int slot = (PHASE * 4 + kq) % 3;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
+#ifdef LR_RB_EXP_NOLDS      // timing experiment: no LDS reads of the activation operand
+      const u32x4 ah = u32x4{(u32)lane, 1u, 2u, 3u}, al = u32x4{4u, 5u, (u32)lane, 7u};
+#else
       const u32x4 ah = *reinterpret_cast<const u32x4*>(lds + abase + kq * 128 + s * 16);
       const u32x4 al = *reinterpret_cast<const u32x4*>(lds + abase + PLANE + kq * 128 + s * 16);
+#endif
       const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah), a_lo = __builtin_bit_cast(bf16x8, al);
       const bf16x8 b_hi = __builtin_bit_cast(bf16x8, ring.hi[slot][s]), b_lo = __builtin_bit_cast(bf16x8, ring.lo[slot][s]);
+#ifdef LR_RB_EXP_X1         // timing experiment: one MFMA per step instead of three (the loads stay: lo joins by xor)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah ^ al), __builtin_bit_cast(bf16x8, ring.hi[slot][s] ^ ring.lo[slot][s]), acc, 0, 0, 0);
+#else
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc, 0, 0, 0);
+#endif
     }
     LR_RB_PIN_VMEM();
     if (kq == 0) ring_issue<NCH, BWD, PHASE * 4 + 3>(ring, sm);
@@ -279,6 +301,30 @@ __device__ __forceinline__ void rows_to_planes(const float* __restrict__ x, int 
   }
 }
 
+// four 64-lane sums at once, on DPP: two quad permutes, half-row mirror, row mirror (every lane of a 16-lane row then
+// holds the row's sum), the four rows through v_readlane.  (__shfl_xor is ds_bpermute: six dependent LDS-crossbar
+// round trips per sum — 1.9 us of a LayerNorm's 2.3, round 6 stamps.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void wave_sum4(float (&v)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = dpp_add<0xb1>(v[i]);    // quad_perm [1, 0, 3, 2]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = dpp_add<0x4e>(v[i]);    // quad_perm [2, 3, 0, 1]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = dpp_add<0x141>(v[i]);   // row_half_mirror
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = dpp_add<0x140>(v[i]);   // row_mirror
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int w = __builtin_bit_cast(int, v[i]);
+    v[i] = (__builtin_bit_cast(float, __builtin_amdgcn_readlane(w, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(w, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(w, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(w, 48)));
+  }
+}
+
 // LayerNorm of the stage's rows (wave w: rows 4 w .. 4 w + 3; a lane: 4 consecutive columns): y = LN(stage) gamma +
 // beta -> `y` (global), stats; and, when `pp` >= 0, back into the stage and into the planes at pp
 __device__ __forceinline__ void ln_rows(unsigned char* lds, int par_gamma, int par_beta,
@@ -289,17 +335,31 @@ __device__ __forceinline__ void ln_rows(unsigned char* lds, int par_gamma, int p
   const rsrc_t ry = make_rsrc(y), rs = make_rsrc(stats);
   const float4 g = *reinterpret_cast<const float4*>(par + par_gamma + 4 * lane);
   const float4 b = *reinterpret_cast<const float4*>(par + par_beta + 4 * lane);
+  // the wave's four rows side by side: four independent reduction chains (one row after the other is four times the
+  // shuffle latency: 2.3 us per LayerNorm, round 6 stamps)
+  float4 v[4];
+  float mean[4], var[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] = *reinterpret_cast<const float4*>(stage + (4 * wave + i) * SLD + 4 * lane);
+    mean[i] = (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  wave_sum4(mean);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    mean[i] *= 1.f / DM;
+    v[i] = make_float4(v[i].x - mean[i], v[i].y - mean[i], v[i].z - mean[i], v[i].w - mean[i]);
+    var[i] = (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  wave_sum4(var);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = 4 * wave + i;
-    const float4 v = *reinterpret_cast<const float4*>(stage + r * SLD + 4 * lane);
-    const float mean = lr_wave_sum((v.x + v.y) + (v.z + v.w)) * (1.f / DM);
-    const float4 d = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
-    const float var = lr_wave_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.f / DM);
-    const float rstd = rsqrtf(var + eps);
+    const float rstd = rsqrtf(var[i] * (1.f / DM) + eps);
+    const float4 d = v[i];
     const float4 o = make_float4(d.x * rstd * g.x + b.x, d.y * rstd * g.y + b.y, d.z * rstd * g.z + b.z, d.w * rstd * g.w + b.w);
     st_f32x4(ry, roff(row0, r, R, DM, 4 * lane), o);
-    st_f32(rs, lane < 2 ? roff(row0, r, R, 2, lane) : OOB, lane == 0 ? mean : rstd);   // lanes 0, 1: (mean, rstd)
+    st_f32(rs, lane < 2 ? roff(row0, r, R, 2, lane) : OOB, lane == 0 ? mean[i] : rstd);   // lanes 0, 1: (mean, rstd)
     if (pp >= 0) {
       *reinterpret_cast<float4*>(stage + r * SLD + 4 * lane) = o;
       u32 h0, l0, h1, l1;
@@ -322,6 +382,7 @@ __device__ __forceinline__ void fwd_chunks(const RbFwdArgs& p, Ring& ring, const
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     product<NCH, false, 1 + 2 * C>(acc, ring, sm, lds, OFF_P1, lane);
+    LR_RB_T(0, 8 + 4 * C);
     {
       const float bias = reinterpret_cast<const float*>(lds + OFF_PAR)[PAR_B1 + C * 256 + col];
 #pragma unroll
@@ -331,8 +392,11 @@ __device__ __forceinline__ void fwd_chunks(const RbFwdArgs& p, Ring& ring, const
       }
       tile_to_planes(acc, lds, hp, wave, lane);
     }
+    LR_RB_T(0, 9 + 4 * C);
     lr_lds_barrier();
+    LR_RB_T(0, 10 + 4 * C);
     product<NCH, false, 2 + 2 * C>(acc2, ring, sm, lds, hp, lane);
+    LR_RB_T(0, 11 + 4 * C);
     fwd_chunks<NCH, C + 1>(p, ring, sm, lds, acc2, rf1, row0, wave, lane);
   }
 }
@@ -345,6 +409,7 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_fwd_kernel(const RbFwdArgs p) {
   const int row0 = blockIdx.x * RB, R = p.R;
   const int col = wave * 32 + (lane & 31);
   float* par = reinterpret_cast<float*>(lds + OFF_PAR);
+  LR_RB_T(0, 0);
   // the layer's small vectors -> LDS, asked for IN FRONT of the weight stream: a load in the middle of the chain would
   // have to wait for every older load, i.e. drain the stream
   float pv[3 + NCH / 2 + 1];
@@ -371,7 +436,9 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_fwd_kernel(const RbFwdArgs p) {
   for (int i = 0; i < (256 * NCH + 511) / 512; ++i)
     if (threadIdx.x + 512 * i < 256 * NCH) par[PAR_B1 + threadIdx.x + 512 * i] = pv[3 + i];
   rows_to_planes(p.a, row0, R, lds, OFF_P0);
+  LR_RB_T(0, 1);
   lr_lds_barrier();
+  LR_RB_T(0, 2);
 
   // s1 = a Wo^T + bo + h
   f32x16 acc, pre;   // pre: what an epilogue reads from memory, asked for in front of the product
@@ -384,6 +451,7 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_fwd_kernel(const RbFwdArgs p) {
     }
   }
   product<NCH, false, 0>(acc, ring, sm, lds, OFF_P0, lane);
+  LR_RB_T(0, 3);
   {
     const rsrc_t rs1 = make_rsrc(p.s1);
     const float bias = par[PAR_BO + col];
@@ -395,9 +463,13 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_fwd_kernel(const RbFwdArgs p) {
       stage[row * SLD + col] = v;
     }
   }
+  LR_RB_T(0, 4);
   lr_lds_barrier();
+  LR_RB_T(0, 5);
   ln_rows(lds, PAR_G1, PAR_BE1, p.h1, p.st1, row0, R, p.eps, OFF_P1, wave, lane);
+  LR_RB_T(0, 6);
   lr_lds_barrier();
+  LR_RB_T(0, 7);
 
   f32x16 acc2;
 #pragma unroll
@@ -414,8 +486,11 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_fwd_kernel(const RbFwdArgs p) {
       stage[row * SLD + col] = v;
     }
   }
+  LR_RB_T(0, 24);
   lr_lds_barrier();
+  LR_RB_T(0, 25);
   ln_rows(lds, PAR_G2, PAR_BE2, p.h2, p.st2, row0, R, p.eps, -1, wave, lane);
+  LR_RB_T(0, 26);
 }
 
 // LayerNorm backward of the stage's rows: stage holds dy; x rows (the LayerNorm's input) and stats from memory.
@@ -438,19 +513,27 @@ __device__ __forceinline__ void ln_rows_bwd(unsigned char* lds, const float* __r
     mean[i] = ld_f32(rst, roff(row0, r, R, 2, 0));
     rstd[i] = ld_f32(rst, roff(row0, r, R, 2, 1));
   }
+  float4 dy[4], xh[4], gg[4];
+  float sg[4], sgx[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    dy[i] = *reinterpret_cast<const float4*>(stage + (4 * wave + i) * SLD + 4 * lane);
+    const float mu = mean[i], rs = rstd[i];
+    xh[i] = make_float4((xv[i].x - mu) * rs, (xv[i].y - mu) * rs, (xv[i].z - mu) * rs, (xv[i].w - mu) * rs);
+    gg[i] = make_float4(dy[i].x * g.x, dy[i].y * g.y, dy[i].z * g.z, dy[i].w * g.w);
+    sg[i] = (gg[i].x + gg[i].y) + (gg[i].z + gg[i].w);
+    sgx[i] = (gg[i].x * xh[i].x + gg[i].y * xh[i].y) + (gg[i].z * xh[i].z + gg[i].w * xh[i].w);
+    sxh.x += dy[i].x * xh[i].x; sxh.y += dy[i].y * xh[i].y; sxh.z += dy[i].z * xh[i].z; sxh.w += dy[i].w * xh[i].w;
+    sdy.x += dy[i].x; sdy.y += dy[i].y; sdy.z += dy[i].z; sdy.w += dy[i].w;
+  }
+  wave_sum4(sg);
+  wave_sum4(sgx);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = 4 * wave + i;
-    const float4 dy = *reinterpret_cast<const float4*>(stage + r * SLD + 4 * lane);
-    const float mu = mean[i], rs = rstd[i];
-    const float4 xh = make_float4((xv[i].x - mu) * rs, (xv[i].y - mu) * rs, (xv[i].z - mu) * rs, (xv[i].w - mu) * rs);
-    const float4 gg = make_float4(dy.x * g.x, dy.y * g.y, dy.z * g.z, dy.w * g.w);
-    const float sg = lr_wave_sum((gg.x + gg.y) + (gg.z + gg.w)) * (1.f / DM);
-    const float sgx = lr_wave_sum((gg.x * xh.x + gg.y * xh.y) + (gg.z * xh.z + gg.w * xh.w)) * (1.f / DM);
-    sxh.x += dy.x * xh.x; sxh.y += dy.y * xh.y; sxh.z += dy.z * xh.z; sxh.w += dy.w * xh.w;
-    sdy.x += dy.x; sdy.y += dy.y; sdy.z += dy.z; sdy.w += dy.w;
-    const float4 o = make_float4(rs * (gg.x - sg - xh.x * sgx), rs * (gg.y - sg - xh.y * sgx),
-                                 rs * (gg.z - sg - xh.z * sgx), rs * (gg.w - sg - xh.w * sgx));
+    const float rs = rstd[i], a0 = sg[i] * (1.f / DM), a1 = sgx[i] * (1.f / DM);
+    const float4 o = make_float4(rs * (gg[i].x - a0 - xh[i].x * a1), rs * (gg[i].y - a0 - xh[i].y * a1),
+                                 rs * (gg[i].z - a0 - xh[i].z * a1), rs * (gg[i].w - a0 - xh[i].w * a1));
     st_f32x4(rdx, roff(row0, r, R, DM, 4 * lane), o);
     *reinterpret_cast<float4*>(stage + r * SLD + 4 * lane) = o;
     u32 h0, l0, h1, l1;
@@ -612,6 +695,12 @@ static int rb_attr(const void* fn, int dir, int idx) {
   return LR_OK;
 }
 // the kernels are instantiated for 1, 2, 4, 8 chunks of 256 hidden columns
+#ifdef LR_RB_TIMING
+extern "C" int lr_tfm_rb_debug_times(long long* out_host) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_rb_times), sizeof(long long) * 2 * 8 * 32) == hipSuccess ? 0 : -1;
+}
+#endif
 #define LR_RB_DISPATCH(KERNEL, DIR, ...)                                                                   \
   do {                                                                                                     \
     const int nch_ = F / 256, idx_ = nch_ == 1 ? 0 : nch_ == 2 ? 1 : nch_ == 4 ? 2 : 3;                    \

@@ -163,36 +163,48 @@ def test_transformer_at_the_bench_shape(dev, attention):
                                                (32, 75, 1024, 4, None)])               # the bench shape (75 blocks)
 def test_rowblock_layers_equal_the_five_launch_path(dev, B, T, ff, layers, lens):
   """LR_TFM_ROWBLOCK (lr_tfm_rowblock.hip: out-projection .. LN2 and their backward as one launch per layer and
-  direction) against the same stack composed of lr_fgemm products + LayerNorm launches: the same X3 arithmetic in
-  another summation order.  Every output, the input gradient and every parameter gradient."""
+  direction) against the same stack composed of lr_fgemm products + LayerNorm launches — the same X3 arithmetic in
+  another summation order — and both against torch.nn.TransformerEncoder on the CPU.  Every output, the input
+  gradient and every parameter gradient."""
   import lipreading_amd.transformer as tfm
-  _, enc = make_pair(dev, frame_dim=96, d_model=256, nhead=4, layers=layers, ff=ff, seed=11, attention='bf16')
+  ref, enc = make_pair(dev, frame_dim=96, d_model=256, nhead=4, layers=layers, ff=ff, seed=11, attention='bf16')
   enc.input_projection = 'bf16x3'
   assert _lib().lr_tfm_rowblock_supported(B, T, 256, ff, layers) == 1
   g = torch.Generator().manual_seed(12)
-  x0 = torch.randn(B, T, 96, generator=g).to(dev)
+  x0 = torch.randn(B, T, 96, generator=g)
   lens_t = torch.full((B,), T) if lens is None else torch.tensor(lens)
-  wgt = torch.randn(B, T, 65, generator=g).to(dev)
-  valid = (torch.arange(T).unsqueeze(0) < lens_t.unsqueeze(1)).float().unsqueeze(-1).to(dev)
+  wgt = torch.randn(B, T, 65, generator=g)
+  valid = (torch.arange(T).unsqueeze(0) < lens_t.unsqueeze(1)).float().unsqueeze(-1)
+  xr = x0.clone().requires_grad_(True)
+  lp_r, h_r = ref(xr.unsqueeze(-1), lens_t)
+  ((lp_r * wgt * valid).sum() + (h_r * valid).pow(2).sum()).backward()
+  want = dict(ref.named_parameters())
+  names = ["log_probs", "hidden", "dx"] + [k for k, _ in enc.named_parameters()]
+  oracle = [lp_r.detach() * valid, h_r.detach() * valid, xr.grad] + \
+           [(want[k] if k in want else want["encoder." + k]).grad for k in names[3:]]
   res = {}
+  vd = valid.to(dev)
   for rb in (False, True):
     tfm.rowblock_layers = rb
     try:
       enc.zero_grad()
-      x = x0.clone().requires_grad_(True)
+      x = x0.to(dev).requires_grad_(True)
       lp, h, _ = enc(x, lens_t, max_len=T)
-      ((lp * wgt * valid).sum() + (h * valid).pow(2).sum()).backward()
-      res[rb] = [lp.detach().cpu(), h.detach().cpu(), x.grad.cpu()] + [p.grad.cpu().clone() for p in enc.parameters()]
+      ((lp * wgt.to(dev) * vd).sum() + (h * vd).pow(2).sum()).backward()
+      res[rb] = [(lp.detach() * vd).cpu(), (h.detach() * vd).cpu(), x.grad.cpu()] + [p.grad.cpu().clone() for p in enc.parameters()]
     finally:
       tfm.rowblock_layers = True
-  names = ["log_probs", "hidden", "dx"] + [k for k, _ in enc.named_parameters()]
-  for k, a, b in zip(names, res[False], res[True]):
+  for k, a, b, r in zip(names, res[False], res[True], oracle):
     assert torch.isfinite(b).all(), k
-    # (norm-wise, as in the test above: a ReLU whose pre-activation sits within 1e-6 of zero may switch)
-    # gradients: 1e-3 up to two layers; 3e-3 through four (the same stack in exact fp32 differs from the CPU's
-    # summation order by 1.3e-3 there: test_transformer_at_the_bench_shape)
-    tol = 2e-4 if k in ("log_probs", "hidden") else (1e-3 if layers <= 2 else 3e-3)
-    assert float((a - b).norm()) / max(1e-6, float(a.norm())) < tol, (k, float((a - b).norm()), float(a.norm()))
+    scale = max(1e-6, float(r.norm()))
+    err_five, err_rb, gap = float((a - r).norm()) / scale, float((b - r).norm()) / scale, float((a - b).norm()) / scale
+    # Norm-wise.  The outputs agree to the products' 1e-5; a gradient moves by a sample's worth wherever a ReLU whose
+    # pre-activation sits within that of zero switches (~40 of the 2.4 M hidden units of a layer at the bench shape:
+    # 4e-3 of a feed-forward gradient's norm), so the two paths are held to each other loosely and to the CPU's
+    # result equally well: the row-block path may not be further from it than the five-launch path is (+ the gap a
+    # handful of switches makes)
+    assert gap < (2e-4 if k in ("log_probs", "hidden") else 1e-2), (k, gap)
+    assert err_rb <= 1.5 * err_five + (1e-4 if k in ("log_probs", "hidden") else 5e-3), (k, err_rb, err_five)
 
 
 def _lib():
