@@ -288,8 +288,9 @@ int lr_tfm_rb_supported(int Dm, int F, int nlayers);
 size_t lr_tfm_rb_plane_elems(int F);   // bf16 elements of one layer's weight planes
 int lr_tfm_rb_pack(const float* const* weights, void* planes, int F, int nlayers, hipStream_t st);
 int lr_tfm_rb_forward(const void* planes, int l, const float* const* W, const float* a, const float* h, float* s1,
-                      float* st1, float* h1, float* f1, float* s2, float* st2, float* h2, int R, int F, float eps,
-                      hipStream_t st);
-int lr_tfm_rb_backward(const void* planes, int l, const float* const* W, const float* dh2, const float* s2,
-                       const float* st2, const float* f1, const float* s1, const float* st1, float* ds2, float* df1,
-                       float* ds1, float* da, float* lnp2, float* lnp1, int lnblocks, int R, int F, hipStream_t st);
+                      float* st1, float* h1, float* f1, float* s2, float* st2, float* h2, const float* const* Wnext,
+                      float* qkv_next, int R, int F, float eps, hipStream_t st);
+int lr_tfm_rb_backward(const void* planes, int l, const float* const* W, const float* dh2, const float* dqkv_up,
+                       const float* ds1_up, const float* s2, const float* st2, const float* f1, const float* s1,
+                       const float* st1, float* ds2, float* df1, float* ds1, float* da, float* lnp2, float* lnp1,
+                       int lnblocks, int R, int F, hipStream_t st);

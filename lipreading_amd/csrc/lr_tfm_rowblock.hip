@@ -50,7 +50,7 @@ constexpr int OFF_ST = 6 * PLANE;                // fp32 stage [32][260]
 constexpr int OFF_PAR = OFF_ST + RB * SLD * 4;   // 134 656: the layer's bias / LayerNorm vectors (fp32), staged once
 // forward: bo, b2, g1, be1, g2, be2 (256 each), b1 (F); backward: g2, g1
 constexpr int PAR_BO = 0, PAR_B2 = 256, PAR_G1 = 512, PAR_BE1 = 768, PAR_G2 = 1024, PAR_BE2 = 1280, PAR_B1 = 1536;
-constexpr int lds_bytes(int F) { return OFF_PAR + (PAR_B1 + F) * 4; }
+constexpr int lds_bytes(int F) { return OFF_PAR + (PAR_B1 + F + 768) * 4; }   // (+ bqkv behind b1)
 
 struct PackJob {
   const float* src;
@@ -58,7 +58,7 @@ struct PackJob {
   bf16_t* lo;
   int N, K, tile0, transpose;    // the operand M [N][K] = src [N][K], or (transpose) src^T with src [K][N]
 };
-constexpr int PACK_MAX = 48;
+constexpr int PACK_MAX = 64;
 struct PackJobs {
   PackJob j[PACK_MAX];
   int n;
@@ -111,6 +111,10 @@ struct RbFwdArgs {
   RbW wo, w1, w2;     // [256][256], [F][256], [256][F]
   const float *bo, *b1, *b2, *g1, *be1, *g2, *be2;
   float *s1, *st1, *h1, *f1, *s2, *st2, *h2;
+  // QKV: the NEXT layer's fused projection rides at the end of the chain: qkv = h2 Wqkv^T + bqkv
+  RbW wq;             // [768][256]
+  const float* bq;
+  float* qkv;         // [R][768]
   int R, F;
   float eps;
 };
@@ -121,6 +125,10 @@ struct RbBwdArgs {
   RbW w2t, w1t, wot;  // W2^T [F][256], W1^T [256][F], Wo^T [256][256]
   float *ds2, *df1, *ds1, *da;
   float *lnp2, *lnp1;   // [kLnBlocks][2][256] partial sums of the LayerNorm parameter gradients
+  // DQ: the chain starts one product earlier — dh2 = dqkv Wqkv + ds1 of the layer ABOVE (its input gradient)
+  const float* dqkv_up;   // [R][768]
+  const float* ds1_up;    // [R][256]
+  RbW wqt;                // Wqkv^T [256][768] of the layer above
   int R, F, lnblocks;
 };
 
@@ -174,59 +182,79 @@ struct Ring {
 // zero): VMEM and MFMA instructions do not cross; VALU, SALU and LDS reads may
 #define LR_RB_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x106)
 struct Stream {
-  rsrc_t first_hi, first_lo, a_hi, a_lo, b_hi, b_lo;   // planes of [256][256], [F][256], [256][F] operands
-  unsigned voff_a, voff_b;   // lane * 16 + the wave's tile row in a plane with 4 / with F / 64 groups per tile
+  rsrc_t first_hi, first_lo, a_hi, a_lo, b_hi, b_lo, c_hi, c_lo;   // planes of the chain's operands
+  unsigned voff_a, voff_b, voff_c;   // lane * 16 + the wave's tile row in a plane with 4 / F / 64 / (backward) 12 groups per tile
 };
 // (measured and dropped, round 6: every wave taking a group's four k16 steps in its own rotated order, so that the
 // eight waves and the launch's workgroups do not ask for the same 1 KB quarter of their 4 KB blocks at once — no
 // change in the products' time, eight more live registers: 34.7 -> 36.0 us.)
+
+// The chain as a sequence of phases (one product of 256 k each), NCH = hidden chunks, X = the extra projection:
+//   forward : [Wo] [W1 c0] [W2 c0] [W1 c1] ... [W2 c(NCH-1)]  X: [Wqkv' 0] [Wqkv' 1] [Wqkv' 2]   (the next layer's)
+//   backward: X: [Wqkv'^T k0] [k1] [k2]   [W2^T c0] [W1^T c0] ... [W1^T c(NCH-1)] [Wo^T]           (the layer above's)
+// kind of a phase: 0 `first` (256 x 256), 1 `a` ([F][256]: tile = 8 c + wave), 2 `b` ([256][F]: group = 4 c + quarter),
+// 3 `c` (forward [768][256]: tile = 8 j + wave; backward [256][768]: group = 4 j + quarter)
+template <int NCH, bool BWD, bool X>
+struct Chain {
+  static constexpr int NPH = 1 + 2 * NCH + (X ? 3 : 0);
+  static constexpr int kind(int p) {
+    if (BWD) {
+      if (X && p < 3) return 3;
+      const int q = p - (X ? 3 : 0);
+      return q >= 2 * NCH ? 0 : ((q & 1) == 0 ? 1 : 2);
+    }
+    if (p == 0) return 0;
+    if (p > 2 * NCH) return 3;
+    return ((p - 1) & 1) == 0 ? 1 : 2;
+  }
+  static constexpr int block(int p, int kq) {   // the group's block index, less the wave's share (in the lane offset)
+    if (BWD) {
+      if (X && p < 3) return 4 * p + kq;
+      const int q = p - (X ? 3 : 0);
+      return q >= 2 * NCH ? kq : ((q & 1) == 0 ? (q >> 1) * 32 + kq : (q >> 1) * 4 + kq);
+    }
+    if (p == 0) return kq;
+    if (p > 2 * NCH) return (p - 2 * NCH - 1) * 32 + kq;
+    return ((p - 1) & 1) == 0 ? ((p - 1) >> 1) * 32 + kq : ((p - 1) >> 1) * 4 + kq;
+  }
+};
 // block (tile nt, group g) of a plane with GK groups per tile starts at (nt GK + g) 4096 bytes; step s at + 1024 s
-template <int NCH, bool BWD, int GI>
+template <int NCH, bool BWD, bool X, int GI>
 __device__ __forceinline__ void ring_issue(Ring& ring, const Stream& sm) {
+  typedef Chain<NCH, BWD, X> C;
   constexpr int P = GI >> 2, KQ = GI & 3, SLOT = GI % 3;
-  constexpr int PC = BWD ? P : P - 1;
-  constexpr bool SINGLE = BWD ? P >= 2 * NCH : P == 0;
 #ifdef LR_RB_EXP_NOSTREAM   // timing experiment: the chain without its weight stream (results are garbage)
   if constexpr (GI >= 3) return;
 #endif
-  if constexpr (GI < 4 * (1 + 2 * NCH)) {
-    if constexpr (SINGLE) {                  // tile = wave, 4 groups per tile
-      constexpr int so = KQ * 4096;
+  if constexpr (P < C::NPH) {
+    constexpr int K = C::kind(P), so = C::block(P, KQ) * 4096;
+    const rsrc_t rh = K == 0 ? sm.first_hi : K == 1 ? sm.a_hi : K == 2 ? sm.b_hi : sm.c_hi;
+    const rsrc_t rl = K == 0 ? sm.first_lo : K == 1 ? sm.a_lo : K == 2 ? sm.b_lo : sm.c_lo;
+    const int vo = (int)(K == 2 ? sm.voff_b : K == 3 ? sm.voff_c : sm.voff_a);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        ring.hi[SLOT][s] = __builtin_amdgcn_raw_buffer_load_b128(sm.first_hi, (int)sm.voff_a + s * 1024, so, 0);
-        ring.lo[SLOT][s] = __builtin_amdgcn_raw_buffer_load_b128(sm.first_lo, (int)sm.voff_a + s * 1024, so, 0);
-      }
-    } else if constexpr ((PC & 1) == 0) {    // [F][256]: tile = 8 chunk + wave, 4 groups per tile
-      constexpr int so = ((PC >> 1) * 8 * 4 + KQ) * 4096;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        ring.hi[SLOT][s] = __builtin_amdgcn_raw_buffer_load_b128(sm.a_hi, (int)sm.voff_a + s * 1024, so, 0);
-        ring.lo[SLOT][s] = __builtin_amdgcn_raw_buffer_load_b128(sm.a_lo, (int)sm.voff_a + s * 1024, so, 0);
-      }
-    } else {                                 // [256][F]: tile = wave, group = 4 chunk + quarter of F / 64
-      constexpr int so = ((PC >> 1) * 4 + KQ) * 4096;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        ring.hi[SLOT][s] = __builtin_amdgcn_raw_buffer_load_b128(sm.b_hi, (int)sm.voff_b + s * 1024, so, 0);
-        ring.lo[SLOT][s] = __builtin_amdgcn_raw_buffer_load_b128(sm.b_lo, (int)sm.voff_b + s * 1024, so, 0);
-      }
+    for (int s = 0; s < 4; ++s) {
+      ring.hi[SLOT][s] = __builtin_amdgcn_raw_buffer_load_b128(rh, vo + s * 1024, so, 0);
+      ring.lo[SLOT][s] = __builtin_amdgcn_raw_buffer_load_b128(rl, vo + s * 1024, so, 0);
     }
   }
 }
-__device__ __forceinline__ Stream make_stream(const RbW& first, const RbW& a, const RbW& b, int F, int wave, int lane) {
+template <bool BWD>
+__device__ __forceinline__ Stream make_stream(const RbW& first, const RbW& a, const RbW& b, const RbW& c, int F, int wave,
+                                              int lane) {
   Stream sm;
   sm.first_hi = make_rsrc(first.hi); sm.first_lo = make_rsrc(first.lo);
   sm.a_hi = make_rsrc(a.hi); sm.a_lo = make_rsrc(a.lo);
   sm.b_hi = make_rsrc(b.hi); sm.b_lo = make_rsrc(b.lo);
+  sm.c_hi = make_rsrc(c.hi); sm.c_lo = make_rsrc(c.lo);
   sm.voff_a = (unsigned)(lane * 16 + wave * 4 * 4096);
   sm.voff_b = (unsigned)(lane * 16 + wave * (F / 64) * 4096);
+  sm.voff_c = BWD ? (unsigned)(lane * 16 + wave * 12 * 4096) : sm.voff_a;
   return sm;
 }
 
 // One product of the chain on a wave's accumulator: acc += A[32][256] (planes at `pa`, hi then lo) x the wave's 32
 // columns of the phase's weight; behind a group's MFMAs the loads of the group three ahead go into its ring slot.
-template <int NCH, bool BWD, int PHASE>
+template <int NCH, bool BWD, bool X, int PHASE>
 __device__ __forceinline__ void product(f32x16& acc, Ring& ring, const Stream& sm, const unsigned char* lds, int pa,
                                         int lane) {
   const int abase = pa + (lane & 31) * (PLD * 2) + (lane >> 5) * 64;
@@ -252,10 +280,10 @@ __device__ __forceinline__ void product(f32x16& acc, Ring& ring, const Stream& s
 #endif
     }
     LR_RB_PIN_VMEM();
-    if (kq == 0) ring_issue<NCH, BWD, PHASE * 4 + 3>(ring, sm);
-    if (kq == 1) ring_issue<NCH, BWD, PHASE * 4 + 4>(ring, sm);
-    if (kq == 2) ring_issue<NCH, BWD, PHASE * 4 + 5>(ring, sm);
-    if (kq == 3) ring_issue<NCH, BWD, PHASE * 4 + 6>(ring, sm);
+    if (kq == 0) ring_issue<NCH, BWD, X, PHASE * 4 + 3>(ring, sm);
+    if (kq == 1) ring_issue<NCH, BWD, X, PHASE * 4 + 4>(ring, sm);
+    if (kq == 2) ring_issue<NCH, BWD, X, PHASE * 4 + 5>(ring, sm);
+    if (kq == 3) ring_issue<NCH, BWD, X, PHASE * 4 + 6>(ring, sm);
     LR_RB_PIN_VMEM();
   }
 }
@@ -281,13 +309,14 @@ __device__ __forceinline__ unsigned roff(int row0, int row, int R, int ld, int c
 }
 
 // rows [row0, row0 + 32) of x [R][256] fp32 -> planes at `pp` (zeros past R); 512 threads, 4 float4 each
-__device__ __forceinline__ void rows_to_planes(const float* __restrict__ x, int row0, int R, unsigned char* lds, int pp) {
+__device__ __forceinline__ void rows_to_planes(const float* __restrict__ x, int row0, int R, int ld, int c0,
+                                               unsigned char* lds, int pp) {
   const rsrc_t rx = make_rsrc(x);
   float4 v[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int u = threadIdx.x + 512 * i;
-    v[i] = ld_f32x4(rx, roff(row0, u >> 6, R, DM, (u & 63) * 4));
+    v[i] = ld_f32x4(rx, roff(row0, u >> 6, R, ld, c0 + (u & 63) * 4));
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -372,7 +401,7 @@ __device__ __forceinline__ void ln_rows(unsigned char* lds, int par_gamma, int p
   }
 }
 
-template <int NCH, int C>
+template <int NCH, bool X, int C>
 __device__ __forceinline__ void fwd_chunks(const RbFwdArgs& p, Ring& ring, const Stream& sm, unsigned char* lds,
                                            f32x16& acc2, rsrc_t rf1, int row0, int wave, int lane) {
   if constexpr (C < NCH) {
@@ -381,7 +410,7 @@ __device__ __forceinline__ void fwd_chunks(const RbFwdArgs& p, Ring& ring, const
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    product<NCH, false, 1 + 2 * C>(acc, ring, sm, lds, OFF_P1, lane);
+    product<NCH, false, X, 1 + 2 * C>(acc, ring, sm, lds, OFF_P1, lane);
     LR_RB_T(0, 8 + 4 * C);
     {
       const float bias = reinterpret_cast<const float*>(lds + OFF_PAR)[PAR_B1 + C * 256 + col];
@@ -395,13 +424,30 @@ __device__ __forceinline__ void fwd_chunks(const RbFwdArgs& p, Ring& ring, const
     LR_RB_T(0, 9 + 4 * C);
     lr_lds_barrier();
     LR_RB_T(0, 10 + 4 * C);
-    product<NCH, false, 2 + 2 * C>(acc2, ring, sm, lds, hp, lane);
+    product<NCH, false, X, 2 + 2 * C>(acc2, ring, sm, lds, hp, lane);
     LR_RB_T(0, 11 + 4 * C);
-    fwd_chunks<NCH, C + 1>(p, ring, sm, lds, acc2, rf1, row0, wave, lane);
+    fwd_chunks<NCH, X, C + 1>(p, ring, sm, lds, acc2, rf1, row0, wave, lane);
   }
 }
 
-template <int NCH>
+// the extra projection of the forward chain: qkv[:, 256 j ..] = h2 Wqkv'[256 j ..]^T + bqkv'
+template <int NCH, int J>
+__device__ __forceinline__ void fwd_qkv(const RbFwdArgs& p, Ring& ring, const Stream& sm, unsigned char* lds, rsrc_t rq,
+                                        int row0, int wave, int lane) {
+  if constexpr (J < 3) {
+    const int col = wave * 32 + (lane & 31);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    product<NCH, false, true, 1 + 2 * NCH + J>(acc, ring, sm, lds, OFF_P1, lane);
+    const float bias = reinterpret_cast<const float*>(lds + OFF_PAR)[PAR_B1 + 256 * NCH + J * 256 + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st_f32(rq, roff(row0, acc_row(r, lane), p.R, 768, J * 256 + col), acc[r] + bias);
+    fwd_qkv<NCH, J + 1>(p, ring, sm, lds, rq, row0, wave, lane);
+  }
+}
+
+template <int NCH, bool X>
 __global__ __launch_bounds__(512, 1) void tfm_rb_fwd_kernel(const RbFwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* stage = reinterpret_cast<float*>(lds + OFF_ST);
@@ -412,7 +458,7 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_fwd_kernel(const RbFwdArgs p) {
   LR_RB_T(0, 0);
   // the layer's small vectors -> LDS, asked for IN FRONT of the weight stream: a load in the middle of the chain would
   // have to wait for every older load, i.e. drain the stream
-  float pv[3 + NCH / 2 + 1];
+  float pv[3 + NCH / 2 + 1], pq[2];
   {
     const float* src[3] = {threadIdx.x < 256 ? p.bo : p.b2, threadIdx.x < 256 ? p.g1 : p.be1, threadIdx.x < 256 ? p.g2 : p.be2};
 #pragma unroll
@@ -422,20 +468,28 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_fwd_kernel(const RbFwdArgs p) {
       const int c = threadIdx.x + 512 * i;
       pv[3 + i] = c < 256 * NCH ? p.b1[c] : 0.f;
     }
+    if constexpr (X) {
+      pq[0] = p.bq[threadIdx.x];
+      pq[1] = threadIdx.x < 256 ? p.bq[512 + threadIdx.x] : 0.f;
+    }
   }
   LR_RB_PIN_VMEM();
-  const Stream sm = make_stream(p.wo, p.w1, p.w2, 256 * NCH, wave, lane);
+  const Stream sm = make_stream<false>(p.wo, p.w1, p.w2, p.wq, 256 * NCH, wave, lane);
   Ring ring;
-  ring_issue<NCH, false, 0>(ring, sm);
-  ring_issue<NCH, false, 1>(ring, sm);
-  ring_issue<NCH, false, 2>(ring, sm);
+  ring_issue<NCH, false, X, 0>(ring, sm);
+  ring_issue<NCH, false, X, 1>(ring, sm);
+  ring_issue<NCH, false, X, 2>(ring, sm);
   LR_RB_PIN_VMEM();
+  if constexpr (X) {
+    par[PAR_B1 + 256 * NCH + threadIdx.x] = pq[0];
+    if (threadIdx.x < 256) par[PAR_B1 + 256 * NCH + 512 + threadIdx.x] = pq[1];
+  }
 #pragma unroll
   for (int i = 0; i < 3; ++i) par[512 * i + threadIdx.x] = pv[i];
 #pragma unroll
   for (int i = 0; i < (256 * NCH + 511) / 512; ++i)
     if (threadIdx.x + 512 * i < 256 * NCH) par[PAR_B1 + threadIdx.x + 512 * i] = pv[3 + i];
-  rows_to_planes(p.a, row0, R, lds, OFF_P0);
+  rows_to_planes(p.a, row0, R, DM, 0, lds, OFF_P0);
   LR_RB_T(0, 1);
   lr_lds_barrier();
   LR_RB_T(0, 2);
@@ -450,7 +504,7 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_fwd_kernel(const RbFwdArgs p) {
       pre[r] = ld_f32(rh, roff(row0, acc_row(r, lane), R, DM, col));
     }
   }
-  product<NCH, false, 0>(acc, ring, sm, lds, OFF_P0, lane);
+  product<NCH, false, X, 0>(acc, ring, sm, lds, OFF_P0, lane);
   LR_RB_T(0, 3);
   {
     const rsrc_t rs1 = make_rsrc(p.s1);
@@ -474,7 +528,7 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_fwd_kernel(const RbFwdArgs p) {
   f32x16 acc2;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-  fwd_chunks<NCH, 0>(p, ring, sm, lds, acc2, make_rsrc(p.f1), row0, wave, lane);
+  fwd_chunks<NCH, X, 0>(p, ring, sm, lds, acc2, make_rsrc(p.f1), row0, wave, lane);
   {
     const rsrc_t rs2 = make_rsrc(p.s2);
     const float bias = par[PAR_B2 + col];
@@ -489,8 +543,13 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_fwd_kernel(const RbFwdArgs p) {
   LR_RB_T(0, 24);
   lr_lds_barrier();
   LR_RB_T(0, 25);
-  ln_rows(lds, PAR_G2, PAR_BE2, p.h2, p.st2, row0, R, p.eps, -1, wave, lane);
+  ln_rows(lds, PAR_G2, PAR_BE2, p.h2, p.st2, row0, R, p.eps, X ? OFF_P1 : -1, wave, lane);
   LR_RB_T(0, 26);
+  if constexpr (X) {
+    lr_lds_barrier();
+    fwd_qkv<NCH, 0>(p, ring, sm, lds, make_rsrc(p.qkv), row0, wave, lane);
+    LR_RB_T(0, 27);
+  }
 }
 
 // LayerNorm backward of the stage's rows: stage holds dy; x rows (the LayerNorm's input) and stats from memory.
@@ -556,7 +615,7 @@ __device__ __forceinline__ void ln_rows_bwd(unsigned char* lds, const float* __r
   }
 }
 
-template <int NCH, int C>
+template <int NCH, bool X, int C>
 __device__ __forceinline__ void bwd_chunks(const RbBwdArgs& p, Ring& ring, const Stream& sm, unsigned char* lds,
                                            f32x16& acc2, rsrc_t rf1, rsrc_t rdf1, int row0, int wave, int lane) {
   if constexpr (C < NCH) {
@@ -568,7 +627,7 @@ __device__ __forceinline__ void bwd_chunks(const RbBwdArgs& p, Ring& ring, const
       acc[r] = 0.f;
       pre[r] = ld_f32(rf1, roff(row0, acc_row(r, lane), p.R, 256 * NCH, C * 256 + col));
     }
-    product<NCH, true, 2 * C>(acc, ring, sm, lds, OFF_P1, lane);
+    product<NCH, true, X, (X ? 3 : 0) + 2 * C>(acc, ring, sm, lds, OFF_P1, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       acc[r] = pre[r] > 0.f ? acc[r] : 0.f;
@@ -576,12 +635,12 @@ __device__ __forceinline__ void bwd_chunks(const RbBwdArgs& p, Ring& ring, const
     }
     tile_to_planes(acc, lds, hp, wave, lane);
     lr_lds_barrier();
-    product<NCH, true, 2 * C + 1>(acc2, ring, sm, lds, hp, lane);
-    bwd_chunks<NCH, C + 1>(p, ring, sm, lds, acc2, rf1, rdf1, row0, wave, lane);
+    product<NCH, true, X, (X ? 3 : 0) + 2 * C + 1>(acc2, ring, sm, lds, hp, lane);
+    bwd_chunks<NCH, X, C + 1>(p, ring, sm, lds, acc2, rf1, rdf1, row0, wave, lane);
   }
 }
 
-template <int NCH>
+template <int NCH, bool X>
 __global__ __launch_bounds__(512, 1) void tfm_rb_bwd_kernel(const RbBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* stage = reinterpret_cast<float*>(lds + OFF_ST);
@@ -591,11 +650,11 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_bwd_kernel(const RbBwdArgs p) {
   float* red = reinterpret_cast<float*>(lds + OFF_P2);   // [8][2][256] floats = 16 KB: inside planes 2 while they are idle
   const float pv = (threadIdx.x < 256 ? p.g2 : p.g1)[threadIdx.x & 255];   // (in front of the stream, as in the forward)
   LR_RB_PIN_VMEM();
-  const Stream sm = make_stream(p.wot, p.w2t, p.w1t, 256 * NCH, wave, lane);
+  const Stream sm = make_stream<true>(p.wot, p.w2t, p.w1t, p.wqt, 256 * NCH, wave, lane);
   Ring ring;
-  ring_issue<NCH, true, 0>(ring, sm);
-  ring_issue<NCH, true, 1>(ring, sm);
-  ring_issue<NCH, true, 2>(ring, sm);
+  ring_issue<NCH, true, X, 0>(ring, sm);
+  ring_issue<NCH, true, X, 1>(ring, sm);
+  ring_issue<NCH, true, X, 2>(ring, sm);
   LR_RB_PIN_VMEM();
   // the partial rows nobody writes stay zero (the first workgroups clear the unused tail)
   for (int b = gridDim.x + blockIdx.x; b < p.lnblocks; b += gridDim.x) {
@@ -603,7 +662,48 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_bwd_kernel(const RbBwdArgs p) {
     p.lnp1[(int64_t)b * 2 * DM + threadIdx.x] = 0.f;
   }
   reinterpret_cast<float*>(lds + OFF_PAR)[threadIdx.x] = pv;   // g2 at 0, g1 at 256
-  {   // dy rows -> stage
+  if constexpr (X) {
+    // dy = dqkv Wqkv + ds1 of the layer above: its 32 x 768 rows as three plane sets (all three are free here), three
+    // products on one accumulator
+    {
+      const rsrc_t rx = make_rsrc(p.dqkv_up);
+      float4 v[3][4];
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int u = threadIdx.x + 512 * i;
+          v[j][i] = ld_f32x4(rx, roff(row0, u >> 6, R, 768, 256 * j + (u & 63) * 4));
+        }
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int u = threadIdx.x + 512 * i, r = u >> 6, c4 = (u & 63) * 4;
+          u32 h0, l0, h1, l1;
+          lrx::split_bf16_pair(v[j][i].x, v[j][i].y, h0, l0);
+          lrx::split_bf16_pair(v[j][i].z, v[j][i].w, h1, l1);
+          const int o = (j == 0 ? OFF_P0 : j == 1 ? OFF_P2 : OFF_P1) + (r * PLD + c4) * 2;
+          *reinterpret_cast<uint2*>(lds + o) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(lds + o + PLANE) = make_uint2(l0, l1);
+        }
+    }
+    f32x16 dacc, dpre;
+    {
+      const rsrc_t ru = make_rsrc(p.ds1_up);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dacc[r] = 0.f;
+        dpre[r] = ld_f32(ru, roff(row0, acc_row(r, lane), R, DM, col));
+      }
+    }
+    lr_lds_barrier();
+    product<NCH, true, true, 0>(dacc, ring, sm, lds, OFF_P0, lane);
+    product<NCH, true, true, 1>(dacc, ring, sm, lds, OFF_P2, lane);
+    product<NCH, true, true, 2>(dacc, ring, sm, lds, OFF_P1, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stage[acc_row(r, lane) * SLD + col] = dacc[r] + dpre[r];
+  } else {   // dy rows -> stage
     const rsrc_t rdy = make_rsrc(p.dh2);
     float4 v[4];
 #pragma unroll
@@ -624,7 +724,7 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_bwd_kernel(const RbBwdArgs p) {
   f32x16 acc, acc2;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-  bwd_chunks<NCH, 0>(p, ring, sm, lds, acc2, make_rsrc(p.f1), make_rsrc(p.df1), row0, wave, lane);
+  bwd_chunks<NCH, X, 0>(p, ring, sm, lds, acc2, make_rsrc(p.f1), make_rsrc(p.df1), row0, wave, lane);
   // dh1 = df1 W1 + ds2 -> stage
 #pragma unroll
   for (int r = 0; r < 16; ++r) stage[acc_row(r, lane) * SLD + col] += acc2[r];
@@ -633,7 +733,7 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_bwd_kernel(const RbBwdArgs p) {
   lr_lds_barrier();
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  product<NCH, true, 2 * NCH>(acc, ring, sm, lds, OFF_P1, lane);
+  product<NCH, true, X, (X ? 3 : 0) + 2 * NCH>(acc, ring, sm, lds, OFF_P1, lane);
   {
     const rsrc_t rda = make_rsrc(p.da);
 #pragma unroll
@@ -641,25 +741,25 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_bwd_kernel(const RbBwdArgs p) {
   }
 }
 
-bool g_attr_set[2][4] = {{false, false, false, false}, {false, false, false, false}};
+bool g_attr_set[2][8] = {};
 
 }  // namespace
 
 // ---- host side (declared in lr_common.h; lr_transformer.hip composes the stack) -------------------------------------
 int lr_tfm_rb_supported(int Dm, int F, int nlayers) {
-  return Dm == DM && (F == 256 || F == 512 || F == 1024 || F == 2048) && nlayers >= 1 && 6 * nlayers <= PACK_MAX;
+  return Dm == DM && (F == 256 || F == 512 || F == 1024 || F == 2048) && nlayers >= 1 && 8 * nlayers <= PACK_MAX;
 }
-// bf16 elements of one layer's planes: hi + lo of Wo, W1, W2 and of their transposes
-size_t lr_tfm_rb_plane_elems(int F) { return (size_t)4 * ((size_t)DM * DM + 2 * (size_t)DM * F); }
+// bf16 elements of one layer's planes: hi + lo of Wo, W1, W2, Wqkv and of their transposes
+size_t lr_tfm_rb_plane_elems(int F) { return (size_t)4 * (4 * (size_t)DM * DM + 2 * (size_t)DM * F); }
 
-// planes of layer l inside `planes`: [Wo | W1 | W2 | Wo^T | W1^T | W2^T] each as hi then lo
-static void rb_layer_planes(void* planes, int l, int F, RbW out[6]) {
+// planes of layer l inside `planes`: [Wo | W1 | W2 | Wqkv | Wo^T | W1^T | W2^T | Wqkv^T] each as hi then lo
+static void rb_layer_planes(void* planes, int l, int F, RbW out[8]) {
   bf16_t* b = (bf16_t*)planes + (size_t)l * lr_tfm_rb_plane_elems(F);
-  const size_t sz[6] = {(size_t)DM * DM, (size_t)DM * F, (size_t)DM * F, (size_t)DM * DM, (size_t)DM * F, (size_t)DM * F};
-  for (int i = 0; i < 6; ++i) {
+  const size_t sz[4] = {(size_t)DM * DM, (size_t)DM * F, (size_t)DM * F, 3 * (size_t)DM * DM};
+  for (int i = 0; i < 8; ++i) {
     out[i].hi = b;
-    out[i].lo = b + sz[i];
-    b += 2 * sz[i];
+    out[i].lo = b + sz[i & 3];
+    b += 2 * sz[i & 3];
   }
 }
 
@@ -669,16 +769,16 @@ int lr_tfm_rb_pack(const float* const* weights, void* planes, int F, int nlayers
   int n = 0, tiles = 0;
   for (int l = 0; l < nlayers; ++l) {
     const float* const* W = weights + 2 + 12 * l;
-    RbW pl[6];
+    RbW pl[8];
     rb_layer_planes(planes, l, F, pl);
-    const float* src[3] = {W[2], W[4], W[6]};
-    const int Ns[3] = {DM, F, DM}, Ks[3] = {DM, DM, F};
+    const float* src[4] = {W[2], W[4], W[6], W[0]};
+    const int Ns[4] = {DM, F, DM, 3 * DM}, Ks[4] = {DM, DM, F, DM};
     for (int t = 0; t < 2; ++t)
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < 4; ++i) {
         PackJob& j = jobs.j[n++];
         j.src = src[i];
-        j.hi = const_cast<bf16_t*>(pl[3 * t + i].hi);
-        j.lo = const_cast<bf16_t*>(pl[3 * t + i].lo);
+        j.hi = const_cast<bf16_t*>(pl[4 * t + i].hi);
+        j.lo = const_cast<bf16_t*>(pl[4 * t + i].lo);
         j.N = t ? Ks[i] : Ns[i]; j.K = t ? Ns[i] : Ks[i]; j.tile0 = tiles; j.transpose = t;   // the OPERAND's shape
         tiles += (j.N / 32) * (j.K / 64);
       }
@@ -694,54 +794,70 @@ static int rb_attr(const void* fn, int dir, int idx) {
   g_attr_set[dir][idx] = true;
   return LR_OK;
 }
-// the kernels are instantiated for 1, 2, 4, 8 chunks of 256 hidden columns
 #ifdef LR_RB_TIMING
 extern "C" int lr_tfm_rb_debug_times(long long* out_host) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_rb_times), sizeof(long long) * 2 * 8 * 32) == hipSuccess ? 0 : -1;
 }
 #endif
-#define LR_RB_DISPATCH(KERNEL, DIR, ...)                                                                   \
+// the kernels are instantiated for 1, 2, 4, 8 chunks of 256 hidden columns, with and without the extra projection
+#define LR_RB_LAUNCH_(KERNEL, DIR, NCH_, X_, IDX_)                                                         \
   do {                                                                                                     \
-    const int nch_ = F / 256, idx_ = nch_ == 1 ? 0 : nch_ == 2 ? 1 : nch_ == 4 ? 2 : 3;                    \
-    const void* fn_ = nch_ == 1 ? (const void*)KERNEL<1> : nch_ == 2 ? (const void*)KERNEL<2>              \
-                      : nch_ == 4 ? (const void*)KERNEL<4> : (const void*)KERNEL<8>;                       \
-    const int rc_ = rb_attr(fn_, DIR, idx_);                                                               \
+    const int rc_ = rb_attr((const void*)KERNEL<NCH_, X_>, DIR, IDX_);                                     \
     if (rc_ != LR_OK) return rc_;                                                                          \
-    const dim3 grid_((R + RB - 1) / RB);                                                                   \
-    if (nch_ == 1) LR_LAUNCH(KERNEL<1>, grid_, dim3(512), lds_bytes(F), st, p);                               \
-    else if (nch_ == 2) LR_LAUNCH(KERNEL<2>, grid_, dim3(512), lds_bytes(F), st, p);                          \
-    else if (nch_ == 4) LR_LAUNCH(KERNEL<4>, grid_, dim3(512), lds_bytes(F), st, p);                          \
-    else LR_LAUNCH(KERNEL<8>, grid_, dim3(512), lds_bytes(F), st, p);                                         \
+    LR_LAUNCH((KERNEL<NCH_, X_>), dim3((R + RB - 1) / RB), dim3(512), lds_bytes(F), st, p);                \
+  } while (0)
+#define LR_RB_DISPATCH(KERNEL, DIR, XFLAG)                                                                 \
+  do {                                                                                                     \
+    const int nch_ = F / 256;                                                                              \
+    if (XFLAG) {                                                                                           \
+      if (nch_ == 1) LR_RB_LAUNCH_(KERNEL, DIR, 1, true, 4);                                               \
+      else if (nch_ == 2) LR_RB_LAUNCH_(KERNEL, DIR, 2, true, 5);                                          \
+      else if (nch_ == 4) LR_RB_LAUNCH_(KERNEL, DIR, 4, true, 6);                                          \
+      else LR_RB_LAUNCH_(KERNEL, DIR, 8, true, 7);                                                         \
+    } else {                                                                                               \
+      if (nch_ == 1) LR_RB_LAUNCH_(KERNEL, DIR, 1, false, 0);                                              \
+      else if (nch_ == 2) LR_RB_LAUNCH_(KERNEL, DIR, 2, false, 1);                                         \
+      else if (nch_ == 4) LR_RB_LAUNCH_(KERNEL, DIR, 4, false, 2);                                         \
+      else LR_RB_LAUNCH_(KERNEL, DIR, 8, false, 3);                                                        \
+    }                                                                                                      \
   } while (0)
 
-// W: the layer's 12 weight pointers; the tensors are the layer's block of the reserve (lr_transformer.hip)
+// W: the layer's 12 weight pointers; the tensors are the layer's block of the reserve (lr_transformer.hip).
+// Wnext / qkv_next (or NULL): the NEXT layer's weights and its qkv buffer — its fused projection rides along.
 int lr_tfm_rb_forward(const void* planes, int l, const float* const* W, const float* a, const float* h, float* s1,
-                      float* st1, float* h1, float* f1, float* s2, float* st2, float* h2, int R, int F, float eps,
-                      hipStream_t st) {
-  RbW pl[6];
+                      float* st1, float* h1, float* f1, float* s2, float* st2, float* h2, const float* const* Wnext,
+                      float* qkv_next, int R, int F, float eps, hipStream_t st) {
+  RbW pl[8], pn[8];
   rb_layer_planes(const_cast<void*>(planes), l, F, pl);
+  rb_layer_planes(const_cast<void*>(planes), l + 1, F, pn);   // (only addresses; used when Wnext)
   RbFwdArgs p;
   p.a = a; p.h = h;
   p.wo = pl[0]; p.w1 = pl[1]; p.w2 = pl[2];
   p.bo = W[3]; p.b1 = W[5]; p.b2 = W[7]; p.g1 = W[8]; p.be1 = W[9]; p.g2 = W[10]; p.be2 = W[11];
   p.s1 = s1; p.st1 = st1; p.h1 = h1; p.f1 = f1; p.s2 = s2; p.st2 = st2; p.h2 = h2;
+  p.wq = Wnext ? pn[3] : pl[3]; p.bq = Wnext ? Wnext[1] : W[1]; p.qkv = qkv_next;
   p.R = R; p.F = F; p.eps = eps;
-  LR_RB_DISPATCH(tfm_rb_fwd_kernel, 0);
+  LR_RB_DISPATCH(tfm_rb_fwd_kernel, 0, Wnext != nullptr);
   return lr_launch_status();
 }
 
-int lr_tfm_rb_backward(const void* planes, int l, const float* const* W, const float* dh2, const float* s2,
-                       const float* st2, const float* f1, const float* s1, const float* st1, float* ds2, float* df1,
-                       float* ds1, float* da, float* lnp2, float* lnp1, int lnblocks, int R, int F, hipStream_t st) {
-  RbW pl[6];
+// dqkv_up / ds1_up (or NULL): the gradients of the layer ABOVE — then dh2 is not read: the chain starts with
+// dh2 = dqkv_up Wqkv(l + 1) + ds1_up
+int lr_tfm_rb_backward(const void* planes, int l, const float* const* W, const float* dh2, const float* dqkv_up,
+                       const float* ds1_up, const float* s2, const float* st2, const float* f1, const float* s1,
+                       const float* st1, float* ds2, float* df1, float* ds1, float* da, float* lnp2, float* lnp1,
+                       int lnblocks, int R, int F, hipStream_t st) {
+  RbW pl[8], pn[8];
   rb_layer_planes(const_cast<void*>(planes), l, F, pl);
+  rb_layer_planes(const_cast<void*>(planes), l + 1, F, pn);
   RbBwdArgs p;
   p.dh2 = dh2; p.s2 = s2; p.st2 = st2; p.g2 = W[10]; p.f1 = f1; p.s1 = s1; p.st1 = st1; p.g1 = W[8];
-  p.wot = pl[3]; p.w1t = pl[4]; p.w2t = pl[5];
+  p.wot = pl[4]; p.w1t = pl[5]; p.w2t = pl[6];
   p.ds2 = ds2; p.df1 = df1; p.ds1 = ds1; p.da = da; p.lnp2 = lnp2; p.lnp1 = lnp1;
+  p.dqkv_up = dqkv_up; p.ds1_up = ds1_up; p.wqt = dqkv_up ? pn[7] : pl[7];
   p.R = R; p.F = F; p.lnblocks = lnblocks;
   if ((R + RB - 1) / RB > lnblocks) return LR_ERR_UNSUPPORTED;
-  LR_RB_DISPATCH(tfm_rb_bwd_kernel, 1);
+  LR_RB_DISPATCH(tfm_rb_bwd_kernel, 1, dqkv_up != nullptr);
   return lr_launch_status();
 }

@@ -366,14 +366,17 @@ extern "C" int lr_tfm_forward(int mode, const void* x, const int32_t* key_lens, 
     float* h2 = l == nlayers - 1 ? h_out : L + r.h2;
     lr_fgemm_job j = job(h, Dm, W[0], Dm, L + r.qkv, 3 * Dm, R, 3 * Dm, Dm);
     j.bias = W[1];
-    LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NT, 0, 0, &j, 1, st));
+    if (!(rowblock && l > 0))   // (row blocks: layer l - 1's launch wrote this layer's qkv on its way out)
+      LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NT, 0, 0, &j, 1, st));
     if (mode & LR_TFM_ATTN_FUSED)
       LR_TRY_(lr_attn_fused_forward(L + r.qkv, key_lens, L + r.a, 1.f / sqrtf((float)dh), B, T, nhead, dh, st));
     else
       LR_TRY_(attention_f32_forward(L + r.qkv, key_lens, L + r.probs, L + r.a, B, T, nhead, dh, st));
     if (rowblock) {   // out-projection .. LN2 in one launch (lr_tfm_rowblock.hip)
+      const bool more = l + 1 < nlayers;   // the next layer's qkv = h2 W_qkv'^T + b' rides at the end of the chain
       LR_TRY_(lr_tfm_rb_forward(base + r.planes, l, W, L + r.a, h, L + r.s1, L + r.st1, L + r.h1, L + r.f1, L + r.s2,
-                                L + r.st2, h2, R, F, eps, st));
+                                L + r.st2, h2, more ? W + 12 : nullptr, more ? L + r.per_layer + r.qkv : nullptr, R, F, eps,
+                                st));
       h = h2;
       continue;
     }
@@ -418,8 +421,12 @@ extern "C" int lr_tfm_backward_data(int mode, const int32_t* key_lens, const flo
     float* dh_prev = wsb + ((l & 1) ? w.dhB : w.dhA);
     lr_fgemm_job j;
     if (mode & LR_TFM_ROWBLOCK) {   // LN2' .. the out-projection's data gradient in one launch (lr_tfm_rowblock.hip)
-      LR_TRY_(lr_tfm_rb_backward(base + r.planes, l, W, dh_cur, L + r.s2, L + r.st2, L + r.f1, L + r.s1, L + r.st1,
-                                 G + w.ds2, G + w.df1, G + w.ds1, wsb + w.da, G + w.lnp2, G + w.lnp1, kLnBlocks, R, F, st));
+      // (below the top layer the chain starts with the input gradient of the layer above: dqkv' W_qkv' + ds1')
+      const bool up = l + 1 < nlayers;
+      LR_TRY_(lr_tfm_rb_backward(base + r.planes, l, W, dh_cur, up ? G + w.per_layer + w.dqkv : nullptr,
+                                 up ? G + w.per_layer + w.ds1 : nullptr, L + r.s2, L + r.st2, L + r.f1, L + r.s1,
+                                 L + r.st1, G + w.ds2, G + w.df1, G + w.ds1, wsb + w.da, G + w.lnp2, G + w.lnp1, kLnBlocks, R,
+                                 F, st));
     } else {
       LR_TRY_(ln_backward(L + r.s2, W[10], L + r.st2, dh_cur, G + w.ds2, G + w.lnp2, R, Dm, st));
       j = job(G + w.ds2, Dm, W[6], F, G + w.df1, F, R, F, Dm);      // df1 = (ds2 W_2) where f1 > 0
@@ -438,7 +445,8 @@ extern "C" int lr_tfm_backward_data(int mode, const int32_t* key_lens, const flo
       LR_TRY_(attention_f32_backward(L + r.qkv, L + r.probs, wsb + w.da, wsb + w.dP, G + w.dqkv, B, T, nhead, dh, st));
     j = job(G + w.dqkv, 3 * Dm, W[0], Dm, dh_prev, Dm, R, Dm, 3 * Dm);         // dh = dqkv W_qkv + ds1
     j.addend = G + w.ds1; j.ldadd = Dm; j.add_period = R;
-    LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NN, 0, 0, &j, 1, st));
+    if (!((mode & LR_TFM_ROWBLOCK) && l > 0))   // (row blocks: the layer below takes it in at the start of its chain)
+      LR_TRY_(lr_fgemm_launch(prec, LR_FGEMM_NN, 0, 0, &j, 1, st));
     dh_cur = dh_prev;
   }
   if (dx) {   // dx = dh0 W_p
