@@ -563,7 +563,7 @@ long long lr_fgemm_slab_floats(int M, int N, int splits);
 #define LR_TFM_ATTN_FUSED 8
 #define LR_TFM_ROWBLOCK 16   /* out-projection .. LN2 (and their backward) as ONE launch per layer and direction over 32-row
                                 blocks (lr_tfm_rowblock.hip); needs LR_TFM_X3 and lr_tfm_rowblock_supported(): d_model 256,
-                                feed-forward width a multiple of 256, at most 8 layers and 8192 rows */
+                                feed-forward width 256, 512, 1024 or 2048, at most 8 layers */
 int lr_tfm_rowblock_supported(int B, int T, int Dm, int F, int nlayers);
 size_t lr_tfm_reserve_bytes(int mode, int B, int T, int I, int Dm, int nhead, int F, int nlayers);
 size_t lr_tfm_workspace_bytes(int mode, int B, int T, int I, int Dm, int nhead, int F, int nlayers);

@@ -115,7 +115,7 @@ struct RbFwdArgs {
   RbW wq;             // [768][256]
   const float* bq;
   float* qkv;         // [R][768]
-  int R, F;
+  int R, F, blk0;     // (blk0: set by the launcher, always 0 here)
   float eps;
 };
 
@@ -129,7 +129,7 @@ struct RbBwdArgs {
   const float* dqkv_up;   // [R][768]
   const float* ds1_up;    // [R][256]
   RbW wqt;                // Wqkv^T [256][768] of the layer above
-  int R, F, lnblocks;
+  int R, F, lnblocks, blk0;   // blk0: the first row block of this launch
 };
 
 // -DLR_RB_TIMING (tools/build_variant.sh; never in the product build): lane 0 of every wave of workgroup 0 stamps the
@@ -557,8 +557,8 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_fwd_kernel(const RbFwdArgs p) {
 // rows' share of dgamma / dbeta is summed over the workgroup's rows into partial[0 / 1][256].
 __device__ __forceinline__ void ln_rows_bwd(unsigned char* lds, const float* __restrict__ x, const float* __restrict__ stats,
                                             int par_gamma, float* __restrict__ dx,
-                                            float* __restrict__ partial, int row0, int R, int pp, int wave, int lane,
-                                            float* red) {
+                                            float* __restrict__ partial, bool first, int row0, int R, int pp, int wave,
+                                            int lane, float* red) {
   float* stage = reinterpret_cast<float*>(lds + OFF_ST);
   const rsrc_t rx = make_rsrc(x), rst = make_rsrc(stats), rdx = make_rsrc(dx);
   const float4 g = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(lds + OFF_PAR) + par_gamma + 4 * lane);
@@ -611,7 +611,8 @@ __device__ __forceinline__ void ln_rows_bwd(unsigned char* lds, const float* __r
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) s += red[w * 2 * DM + c];
-    partial[c] = s;
+    // (a later launch over the next row blocks adds to the row; the first reads a zero from out of range)
+    partial[c] = ld_f32(make_rsrc(partial), first ? OOB : (unsigned)c * 4u) + s;
   }
 }
 
@@ -645,7 +646,8 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_bwd_kernel(const RbBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* stage = reinterpret_cast<float*>(lds + OFF_ST);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int row0 = blockIdx.x * RB, R = p.R;
+  const int R = p.R, row0 = (p.blk0 + blockIdx.x) * RB;
+  const bool first = p.blk0 == 0;
   const int col = wave * 32 + (lane & 31);
   float* red = reinterpret_cast<float*>(lds + OFF_P2);   // [8][2][256] floats = 16 KB: inside planes 2 while they are idle
   const float pv = (threadIdx.x < 256 ? p.g2 : p.g1)[threadIdx.x & 255];   // (in front of the stream, as in the forward)
@@ -656,8 +658,10 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_bwd_kernel(const RbBwdArgs p) {
   ring_issue<NCH, true, X, 1>(ring, sm);
   ring_issue<NCH, true, X, 2>(ring, sm);
   LR_RB_PIN_VMEM();
-  // the partial rows nobody writes stay zero (the first workgroups clear the unused tail)
-  for (int b = gridDim.x + blockIdx.x; b < p.lnblocks; b += gridDim.x) {
+  // the partial rows nobody writes stay zero (the first workgroups clear the unused tail).  More than `lnblocks` row
+  // blocks (8192 rows): the host launches the kernel again for the next lnblocks of them (blk0 > 0), and workgroup i
+  // ADDS to partial row i — launches are ordered, so the sum's order is fixed
+  for (int b = gridDim.x + blockIdx.x; b < (first ? p.lnblocks : 0); b += gridDim.x) {
     p.lnp2[(int64_t)b * 2 * DM + threadIdx.x] = 0.f;
     p.lnp1[(int64_t)b * 2 * DM + threadIdx.x] = 0.f;
   }
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_bwd_kernel(const RbBwdArgs p) {
     }
   }
   lr_lds_barrier();
-  ln_rows_bwd(lds, p.s2, p.st2, 0, p.ds2, p.lnp2 + (int64_t)blockIdx.x * 2 * DM, row0, R, OFF_P1, wave, lane, red);
+  ln_rows_bwd(lds, p.s2, p.st2, 0, p.ds2, p.lnp2 + (int64_t)blockIdx.x * 2 * DM, first, row0, R, OFF_P1, wave, lane, red);
   lr_lds_barrier();   // planes 1 = ds2 (and the stage, fp32); `red` is free again
 
   f32x16 acc, acc2;
@@ -729,7 +733,7 @@ __global__ __launch_bounds__(512, 1) void tfm_rb_bwd_kernel(const RbBwdArgs p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) stage[acc_row(r, lane) * SLD + col] += acc2[r];
   lr_lds_barrier();   // (every wave is past its last read of planes 2: `red` may be written)
-  ln_rows_bwd(lds, p.s1, p.st1, 256, p.ds1, p.lnp1 + (int64_t)blockIdx.x * 2 * DM, row0, R, OFF_P1, wave, lane, red);
+  ln_rows_bwd(lds, p.s1, p.st1, 256, p.ds1, p.lnp1 + (int64_t)blockIdx.x * 2 * DM, first, row0, R, OFF_P1, wave, lane, red);
   lr_lds_barrier();
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -805,11 +809,15 @@ extern "C" int lr_tfm_rb_debug_times(long long* out_host) {
   do {                                                                                                     \
     const int rc_ = rb_attr((const void*)KERNEL<NCH_, X_>, DIR, IDX_);                                     \
     if (rc_ != LR_OK) return rc_;                                                                          \
-    LR_LAUNCH((KERNEL<NCH_, X_>), dim3((R + RB - 1) / RB), dim3(512), lds_bytes(F), st, p);                \
+    const int nblk_ = (R + RB - 1) / RB;                                                                   \
+    for (int b0_ = 0; b0_ < nblk_; b0_ += cap_) {                                                          \
+      p.blk0 = b0_;                                                                                        \
+      LR_LAUNCH((KERNEL<NCH_, X_>), dim3(nblk_ - b0_ > cap_ ? cap_ : nblk_ - b0_), dim3(512), lds_bytes(F), st, p); \
+    }                                                                                                      \
   } while (0)
-#define LR_RB_DISPATCH(KERNEL, DIR, XFLAG)                                                                 \
+#define LR_RB_DISPATCH(KERNEL, DIR, XFLAG, CAP)                                                            \
   do {                                                                                                     \
-    const int nch_ = F / 256;                                                                              \
+    const int nch_ = F / 256, cap_ = (CAP);                                                                              \
     if (XFLAG) {                                                                                           \
       if (nch_ == 1) LR_RB_LAUNCH_(KERNEL, DIR, 1, true, 4);                                               \
       else if (nch_ == 2) LR_RB_LAUNCH_(KERNEL, DIR, 2, true, 5);                                          \
@@ -838,7 +846,7 @@ int lr_tfm_rb_forward(const void* planes, int l, const float* const* W, const fl
   p.s1 = s1; p.st1 = st1; p.h1 = h1; p.f1 = f1; p.s2 = s2; p.st2 = st2; p.h2 = h2;
   p.wq = Wnext ? pn[3] : pl[3]; p.bq = Wnext ? Wnext[1] : W[1]; p.qkv = qkv_next;
   p.R = R; p.F = F; p.eps = eps;
-  LR_RB_DISPATCH(tfm_rb_fwd_kernel, 0, Wnext != nullptr);
+  LR_RB_DISPATCH(tfm_rb_fwd_kernel, 0, Wnext != nullptr, 0x7fffffff);
   return lr_launch_status();
 }
 
@@ -857,7 +865,6 @@ int lr_tfm_rb_backward(const void* planes, int l, const float* const* W, const f
   p.ds2 = ds2; p.df1 = df1; p.ds1 = ds1; p.da = da; p.lnp2 = lnp2; p.lnp1 = lnp1;
   p.dqkv_up = dqkv_up; p.ds1_up = ds1_up; p.wqt = dqkv_up ? pn[7] : pl[7];
   p.R = R; p.F = F; p.lnblocks = lnblocks;
-  if ((R + RB - 1) / RB > lnblocks) return LR_ERR_UNSUPPORTED;
-  LR_RB_DISPATCH(tfm_rb_bwd_kernel, 1, dqkv_up != nullptr);
+  LR_RB_DISPATCH(tfm_rb_bwd_kernel, 1, dqkv_up != nullptr, lnblocks);   // (more row blocks than partial rows: more launches)
   return lr_launch_status();
 }

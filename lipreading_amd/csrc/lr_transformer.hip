@@ -264,7 +264,7 @@ bool tfm_dims_ok(int mode, int B, int T, int I, int Dm, int nh, int F, int nl) {
          (Dm / nh) % 4 == 0 && 2 * nl <= LN_MAX_JOBS && (size_t)4 * 2 * Dm * sizeof(float) <= 60 * 1024 &&
          (mode & ~(LR_TFM_X3 | LR_TFM_X_BF16 | LR_TFM_DX_BF16 | LR_TFM_ATTN_FUSED | LR_TFM_ROWBLOCK)) == 0 &&
          (!(mode & LR_TFM_ATTN_FUSED) || lr_attn_fused_supported(T, Dm / nh)) &&
-         (!(mode & LR_TFM_ROWBLOCK) || ((mode & LR_TFM_X3) && lr_tfm_rb_supported(Dm, F, nl) && ((size_t)B * T + 31) / 32 <= (size_t)kLnBlocks));
+         (!(mode & LR_TFM_ROWBLOCK) || ((mode & LR_TFM_X3) && lr_tfm_rb_supported(Dm, F, nl)));
 }
 
 lr_fgemm_job job(const void* A, int lda, const void* Bm, int ldb, void* C, int ldc, int M, int N, int K) {
@@ -520,5 +520,5 @@ extern "C" int lr_tfm_backward_weights(int mode, const void* x, float* const* gr
 }
 
 extern "C" int lr_tfm_rowblock_supported(int B, int T, int Dm, int F, int nlayers) {
-  return B > 0 && T > 0 && lr_tfm_rb_supported(Dm, F, nlayers) && ((size_t)B * T + 31) / 32 <= (size_t)kLnBlocks;
+  return B > 0 && T > 0 && lr_tfm_rb_supported(Dm, F, nlayers);
 }

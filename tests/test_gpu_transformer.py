@@ -160,7 +160,8 @@ def test_transformer_at_the_bench_shape(dev, attention):
 
 @pytest.mark.parametrize("B,T,ff,layers,lens", [(4, 20, 512, 2, [20, 13, 20, 5]),       # 80 rows: two full blocks and a half
                                                (3, 11, 256, 1, [11, 11, 4]),           # 33 rows: one row past a block
-                                               (32, 75, 1024, 4, None)])               # the bench shape (75 blocks)
+                                               (32, 75, 1024, 4, None),                # the bench shape (75 blocks)
+                                               (112, 75, 256, 1, None)])               # 263 blocks > 256 partial rows: two backward launches
 def test_rowblock_layers_equal_the_five_launch_path(dev, B, T, ff, layers, lens):
   """LR_TFM_ROWBLOCK (lr_tfm_rowblock.hip: out-projection .. LN2 and their backward as one launch per layer and
   direction) against the same stack composed of lr_fgemm products + LayerNorm launches — the same X3 arithmetic in
