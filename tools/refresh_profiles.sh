@@ -20,6 +20,9 @@
 #            <round>_pixels_pmc_clock.txt (GRBM_GUI_ACTIVE: the effective shader clock of the conv kernels),
 #            <round>_grid_phase_timing.txt / <round>_conv_patch_phase_timing.txt (shader-clock stamps of the timing variants,
 #            when lipreading_amd/_lib/alt/{gridtime,patchtime}.so were built before the visit)
+#            <round>_bench_pixels_tfm.json, <round>_pixels_tfm_pmc_{FETCH,WRITE}_SIZE.txt / _pmc_SQ_pass1.txt (the transformer stage's
+#            row-block, attention and product kernels), <round>_rowblock_phase_timing.txt (alt/rbtime.so: the forward
+#            row-block launch by phase)
 # PMC passes never share a run with trace domains other than the kernel trace rocprofv3 adds itself.
 set -u
 R=$PWD
@@ -76,6 +79,12 @@ python bench.py --regime pixels --model-scaling --no-cpu-baseline 2>/dev/null | 
 pmc clk "GRBM_GUI_ACTIVE GRBM_COUNT" pixels_pmc_clock conv_ conv1_ rnnc_ xgemm -- --regime pixels
 tl pixels_tfm conv1_fwd -9 --regime pixels_tfm
 kt pixels_tfm --regime pixels_tfm
+python bench.py --regime pixels_tfm --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_pixels_tfm.json"
+for c in FETCH_SIZE WRITE_SIZE; do pmc tfm_$c $c pixels_tfm_pmc_$c tfm_rb attn_fused fgemm -- --regime pixels_tfm; done
+pmc sq6 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" pixels_tfm_pmc_SQ_pass1 tfm_rb attn_fused fgemm -- --regime pixels_tfm
+if [ -f lipreading_amd/_lib/alt/rbtime.so ]; then
+  LIPREADING_HIP_LIB=$R/lipreading_amd/_lib/alt/rbtime.so python tools/probes/rb_timing.py > "$OUT/${TAG}_rowblock_phase_timing.txt" 2>&1
+fi
 LIPREADING_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_forcedist.json"
 pmc sq1 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" pixels_pmc_SQ_pass1 conv_ conv1_ rnnc_ xgemm -- --regime pixels
 pmc sq2 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA" pixels_pmc_SQ_pass2 conv_ conv1_ rnnc_ xgemm -- --regime pixels
