@@ -454,6 +454,20 @@ int lr_decoder_backward(int mode, int attn_type, const lr_decoder_params* params
                         float* dh0, float* dc0, const void* reserve, size_t reserve_bytes, void* workspace,
                         size_t workspace_bytes, int accumulate, int B, int L, int T, int Hd, int Cd, int V,
                         int A, lr_stream_t stream);
+/* ... in two halves (as lr_rnn_layer_backward_parts): parts 1 = the data half — d_enc, dh0, dc0: what the encoder's
+ * backward waits for —, 2 = every parameter gradient from what part 1 left in `workspace` (same arguments, any stream
+ * that waits for part 1; the workspace must live until it has run), 3 = both.  Separable for a single-layer loop
+ * without attention (lr_decoder_backward_splittable: config/defaults.txt and the ecd flag-file family); otherwise
+ * only parts = 3 is accepted. */
+int lr_decoder_backward_splittable(int attn_type, int num_layers);
+int lr_decoder_backward_parts(int mode, int attn_type, const lr_decoder_params* params_host,
+                              const lr_decoder_upper* upper_host, const lr_decoder_grads* grads_host,
+                              const lr_decoder_upper_grads* upper_grads_host, const float* enc, const int32_t* enc_lens,
+                              const float* h0, const float* c0, const int32_t* step_lens, const float* log_probs,
+                              const float* d_log_probs, const float* dh_n, const float* dc_n, float* d_enc,
+                              float* dh0, float* dc0, const void* reserve, size_t reserve_bytes, void* workspace,
+                              size_t workspace_bytes, int accumulate, int B, int L, int T, int Hd, int Cd, int V,
+                              int A, int parts, lr_stream_t stream);
 
 /* The decoder loss of the train loop (train_better_model.py:62,65): over the R = B*L (sample, step) rows,
  * -sum_r log_probs[r][label_r] for label_r != ignore_index (F.nll_loss(ignore_index=PAD, reduction='sum') summed

@@ -92,6 +92,9 @@ SIGNATURES = {
                            [c_int] * 7 + [P]),
     "lr_decoder_backward": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P,
                                      c_size_t, c_int] + [c_int] * 7 + [P]),
+    "lr_decoder_backward_parts": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P,
+                                           c_size_t, c_int] + [c_int] * 7 + [c_int, P]),
+    "lr_decoder_backward_splittable": (c_int, [c_int, c_int]),
     "lr_ctc_prepare_i64": (c_int, [P, c_int64, P, P, P, P, P, c_int, c_int, P]),
     "lr_nll_mean_forward": (c_int, [P, P, c_int64, c_int, c_int, P, c_int, c_int, P]),
     "lr_nll_forward3": (c_int, [P, P, c_int64, c_int, c_int, P, c_int, c_int, P]),

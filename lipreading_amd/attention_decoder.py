@@ -55,6 +55,17 @@ def _step_lens(B, L, dev):
   return t
 
 
+# test hook / switch: False keeps the loop's weight half on the stream of its data half
+overlap_weight_half = True
+_split_flag = False   # the last backward put its weight half on the side stream (train._step_all takes it)
+
+
+def take_split_flag():
+  global _split_flag
+  f, _split_flag = _split_flag, False
+  return f
+
+
 class _AttnDecoderFunction(torch.autograd.Function):
   """All L decoder steps: (tokens, teacher-forcing pattern, encoder states, initial state, params)
   -> (log_probs (B,L,V), sampled (B,L), h_n, c_n).  `params` = the 13 tensors of lr_decoder_params
@@ -138,15 +149,33 @@ class _AttnDecoderFunction(torch.autograd.Function):
     dc0 = torch.empty_like(h0) if has_c else None
     wbytes = L_.lr_decoder_workspace_bytes(mode, attn_type, NL, B, L, T, Hd, Cd, V, A)
     ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-    _C.check(L_.lr_decoder_backward(mode, attn_type, ctypes.byref(pstruct),
-                                    ctypes.byref(ustruct) if ustruct is not None else None, ctypes.byref(gstruct),
-                                    ctypes.byref(gustruct) if gustruct is not None else None,
-                                    enc.data_ptr(), enc_lens.data_ptr(), h0.data_ptr(), _C.ptr(c0),
-                                    step_lens.data_ptr(), lp.data_ptr(), d_lp.data_ptr(), _C.ptr(dh_n),
-                                    _C.ptr(dc_n), d_enc.data_ptr(), dh0.data_ptr(), _C.ptr(dc0),
-                                    reserve.data_ptr(), reserve.numel(), ws.data_ptr(), wbytes,
-                                    1 if direct else 0, B, L, T, Hd, Cd, V, A, _C.stream_handle()),
-             "lr_decoder_backward")
+    args = (mode, attn_type, ctypes.byref(pstruct), ctypes.byref(ustruct) if ustruct is not None else None,
+            ctypes.byref(gstruct), ctypes.byref(gustruct) if gustruct is not None else None,
+            enc.data_ptr(), enc_lens.data_ptr(), h0.data_ptr(), _C.ptr(c0), step_lens.data_ptr(), lp.data_ptr(),
+            d_lp.data_ptr(), _C.ptr(dh_n), _C.ptr(dc_n), d_enc.data_ptr(), dh0.data_ptr(), _C.ptr(dc0),
+            reserve.data_ptr(), reserve.numel(), ws.data_ptr(), wbytes, 1 if direct else 0, B, L, T, Hd, Cd, V, A)
+    if overlap_weight_half and direct and L_.lr_decoder_backward_splittable(attn_type, NL):
+      # The encoder's backward only waits for dh0 / dc0 (and d_enc): the data half stays on this stream, every parameter
+      # gradient of the loop goes to the encoder module's side stream and runs beside the head's and the encoder's
+      # backward — whose recurrence leaves a quarter of the chip idle — until the encoder layer's backward (or the
+      # optimiser) joins the streams (encoder.flush_deferred).  Round 6: the ecd family's step 1.81 -> see DESIGN 4.9.
+      from . import encoder as _enc
+      _C.check(L_.lr_decoder_backward_parts(*args, 1, _C.stream_handle()), "lr_decoder_backward_parts(data)")
+      _enc.flush_deferred()                  # at most one deferred half in flight
+      side = _enc._get_side_stream(dev)
+      side.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(side):
+        _C.check(L_.lr_decoder_backward_parts(*args, 2, _C.stream_handle()), "lr_decoder_backward_parts(weights)")
+        _notify(real)
+      _enc._deferred.append((enc, enc_lens, h0, c0, step_lens, lp, d_lp, dh_n, dc_n, reserve, ws, grads, ugrads, real,
+                             pstruct, ustruct, gstruct, gustruct, out_mask, drop_mask))
+      # whoever reads the gradients after loss.backward() — an optimiser, a test, .cpu() — finds them complete: the
+      # streams are joined when this backward pass ends at the latest
+      torch.autograd.Variable._execution_engine.queue_callback(_enc.flush_deferred)
+      global _split_flag
+      _split_flag = True
+      return (None, None, None, None, None, None, d_enc, None, dh0, dc0, None, None) + (None,) * (len(params) + len(upper))
+    _C.check(L_.lr_decoder_backward_parts(*args, 3, _C.stream_handle()), "lr_decoder_backward")
     if direct:
       _notify(real)
       pgrads = (None,) * (len(params) + len(upper))

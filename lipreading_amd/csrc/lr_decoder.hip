@@ -809,15 +809,24 @@ extern "C" int lr_decoder_forward(int mode, int attn_type, const lr_decoder_para
   return LR_OK;
 }
 
-extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_params* p, const lr_decoder_upper* up,
-                                   const lr_decoder_grads* g, const lr_decoder_upper_grads* gup,
-                                   const float* enc, const int32_t* enc_lens, const float* h0, const float* c0,
-                                   const int32_t* step_lens, const float* log_probs, const float* d_log_probs,
-                                   const float* dh_n, const float* dc_n, float* d_enc, float* dh0, float* dc0,
-                                   const void* reserve, size_t reserve_bytes,
-                                   void* workspace, size_t workspace_bytes, int accumulate, int B, int L, int T,
-                                   int Hd, int Cd, int V, int A, lr_stream_t stream_) {
+// parts: 1 = the data half (everything the encoder's backward waits for: d_enc, dh0, dc0; leaves dG, dlogits in the
+// workspace), 2 = the weight half (every parameter gradient, from what part 1 left), 3 = both.  The two halves are
+// separable for a single-layer loop without attention (lr_decoder_backward_splittable): the reference's defaults and its
+// ecd flag-file family.
+extern "C" int lr_decoder_backward_splittable(int attn_type, int num_layers) {
+  return attn_type == ATT_NONE && num_layers == 1;
+}
+extern "C" int lr_decoder_backward_parts(int mode, int attn_type, const lr_decoder_params* p, const lr_decoder_upper* up,
+                                         const lr_decoder_grads* g, const lr_decoder_upper_grads* gup,
+                                         const float* enc, const int32_t* enc_lens, const float* h0, const float* c0,
+                                         const int32_t* step_lens, const float* log_probs, const float* d_log_probs,
+                                         const float* dh_n, const float* dc_n, float* d_enc, float* dh0, float* dc0,
+                                         const void* reserve, size_t reserve_bytes,
+                                         void* workspace, size_t workspace_bytes, int accumulate, int B, int L, int T,
+                                         int Hd, int Cd, int V, int A, int parts, lr_stream_t stream_) {
   const int NL = layers_of(up);
+  LR_CHECK_ARG(parts == 3 || ((parts == 1 || parts == 2) && lr_decoder_backward_splittable(attn_type, NL)));
+  const bool do_data = (parts & 1) != 0, do_weights = (parts & 2) != 0;
   LR_CHECK_ARG(sizes_ok(mode, attn_type, B, L, T, Hd, Cd, V, A, NL));
   LR_CHECK_ARG(p && g && enc && enc_lens && h0 && step_lens && log_probs && d_log_probs && d_enc && dh0 &&
                reserve && workspace);
@@ -858,15 +867,17 @@ extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_par
   const float* drop = (up && NL > 1) ? up->drop_mask : nullptr;
 
   // ---- output head, all (sample, step) rows at once -------------------------------------------------
-  LR_LAUNCH(dec_out_bwd_rows_kernel, dim3((BL + 3) / 4), dim3(256), 0, stream, d_log_probs, log_probs, dlogits, BL, V);
-  LR_TRY(lr_launch_status());
-  // d(new_h) = dlogits @ W_o; without attention new_h is the RNN state itself
-  LR_TRY(lr_sgemm_impl(0, 0, BL, Hd, V, 1.f, dlogits, V, p->w_o, Hd, 0.f, attn ? dpre : dy, Hd, nullptr, 0, 0, gws,
-                       w.gemm_bytes, stream));
+  if (do_data) {
+    LR_LAUNCH(dec_out_bwd_rows_kernel, dim3((BL + 3) / 4), dim3(256), 0, stream, d_log_probs, log_probs, dlogits, BL, V);
+    LR_TRY(lr_launch_status());
+    // d(new_h) = dlogits @ W_o; without attention new_h is the RNN state itself
+    LR_TRY(lr_sgemm_impl(0, 0, BL, Hd, V, 1.f, dlogits, V, p->w_o, Hd, 0.f, attn ? dpre : dy, Hd, nullptr, 0, 0, gws,
+                         w.gemm_bytes, stream));
+  }
   if (!attn) {
     lr_clear_error();
-    if (hipMemsetAsync(d_enc, 0, (size_t)R * Hd * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
-  } else {
+    if (do_data && hipMemsetAsync(d_enc, 0, (size_t)R * Hd * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
+  } else {   // (parts == 3 here: not splittable)
     const int64_t n4 = (int64_t)BL * Hd / 4;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -954,7 +965,9 @@ extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_par
     const float* hs_k = rb + r.hsl[k];
     const float* h0_k = h0 + k * state;
     const float* c0_k = c0 ? c0 + k * state : nullptr;
-    if (w.xch_bytes) {
+    if (!do_data) {
+      // (the weight half of a split call: dG is in the workspace)
+    } else if (w.xch_bytes) {
       // the L reverse steps AND the gradient into the initial state as one launch (lr_rnn_cluster.hip)
       const float* whh1[1] = {w_hh_k};
       LR_TRY(lr_rnn_cluster_backward(G, rb + r.gates[k], rb + r.extra[k], hs_k, dy, dh_n ? dh_n + k * state : nullptr,
@@ -973,6 +986,7 @@ extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_par
       LR_TRY(lr_rnn_dh0(G, wb + w.dcar, wb + w.dgp + (size_t)((L - 1) & 1) * w.dgp_slot, wb + w.wpT, dh0 + k * state,
                         dc0 ? dc0 + k * state : nullptr, B, L, Hd, stream));
     }
+    if (!do_weights) continue;   // (splittable: a single layer — nothing below waits for this layer's dy)
     // W_hh (h_prev of step t is hs[b][t-1]; step 0 used h0) and, for an upper layer, W_ih (x = the (dropped-out)
     // states of the layer below)
     if (wide_wgrad(G, Hd)) {
@@ -1049,6 +1063,7 @@ extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_par
       }
     }
   }
+  if (!do_weights) return LR_OK;
   // (the loop ends on layer 0: dG now holds layer 0's gate gradients for the embedding path below)
   // embedding / W_ih through the table: dEW[v] = sum of the dG_x rows that used token v
   LR_LAUNCH(dec_scatter_dew_kernel, dim3(V, (GH + 255) / 256), dim3(256), 0, stream, (const float*)dG, ids,
@@ -1076,4 +1091,17 @@ extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_par
   LR_TRY(colsum_into(dlogits, V, BL, V, colsum, g->b_o, accumulate, stream));
   if (attn) LR_TRY(colsum_into(dpre, Hd, BL, Hd, colsum, g->b_c, accumulate, stream));
   return LR_OK;
+}
+
+extern "C" int lr_decoder_backward(int mode, int attn_type, const lr_decoder_params* p, const lr_decoder_upper* up,
+                                   const lr_decoder_grads* g, const lr_decoder_upper_grads* gup,
+                                   const float* enc, const int32_t* enc_lens, const float* h0, const float* c0,
+                                   const int32_t* step_lens, const float* log_probs, const float* d_log_probs,
+                                   const float* dh_n, const float* dc_n, float* d_enc, float* dh0, float* dc0,
+                                   const void* reserve, size_t reserve_bytes,
+                                   void* workspace, size_t workspace_bytes, int accumulate, int B, int L, int T,
+                                   int Hd, int Cd, int V, int A, lr_stream_t stream_) {
+  return lr_decoder_backward_parts(mode, attn_type, p, up, g, gup, enc, enc_lens, h0, c0, step_lens, log_probs, d_log_probs,
+                                   dh_n, dc_n, d_enc, dh0, dc0, reserve, reserve_bytes, workspace, workspace_bytes,
+                                   accumulate, B, L, T, Hd, Cd, V, A, 3, stream_);
 }

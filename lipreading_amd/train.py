@@ -329,6 +329,26 @@ def ctc_step(encoder, opt, frames, frame_lens, chars, char_lens, grad_norm=None,
   return loss, status
 
 
+def _step_all(opts, grad_norm, status):
+  """The per-module clip + Adam of train_better_model.py:77-80 for opts = (encoder's, decoder's).  When the decoder
+  loop's weight half ran on the side stream (attention_decoder.overlap_weight_half), its gradients were complete long
+  before the encoder's: the decoder's optimiser goes to that stream as well — sum of squares + Adam are HBM-bound and run
+  beside the encoder's weight-gradient products — and the streams are joined behind the encoder's optimiser."""
+  from . import attention_decoder as _dec
+  from . import encoder as _enc
+  side_ok = len(opts) == 2 and _dec.take_split_flag() and _enc._side_stream is not None
+  if not side_ok:
+    for o in opts:
+      o.step(grad_norm=grad_norm, grad_scale=1.0, skip=status)
+    return
+  main = torch.cuda.current_stream()
+  side = _enc._side_stream
+  with torch.cuda.stream(side):     # (the side stream already holds everything the decoder's gradients depend on)
+    opts[1].step(grad_norm=grad_norm, grad_scale=1.0, skip=status)
+  opts[0].step(grad_norm=grad_norm, grad_scale=1.0, skip=status)
+  main.wait_stream(side)
+
+
 def decoder_step(encoder, decoding_step, opts, frames, frame_lens, chars, char_lens, flags, seed, pad,
                  grad_norm=None, max_len=None, grad_sync=(None, None), graphs=None):
   """The reference's WHOLE step (train_better_model.py:46-80) for one batch, all on the device:
@@ -376,8 +396,7 @@ def decoder_step(encoder, decoding_step, opts, frames, frame_lens, chars, char_l
     else:
       decoder_loss.backward(one)
     if whole:
-      for o in opts:
-        o.step(grad_norm=grad_norm, grad_scale=1.0, skip=status)
+      _step_all(opts, grad_norm, status)
     out = (decoder_loss.detach(),)
     return out + ((ctc.detach(), status) if use_ctc else ())
 
