@@ -457,8 +457,7 @@ int lr_decoder_backward(int mode, int attn_type, const lr_decoder_params* params
 /* ... in two halves (as lr_rnn_layer_backward_parts): parts 1 = the data half — d_enc, dh0, dc0: what the encoder's
  * backward waits for —, 2 = every parameter gradient from what part 1 left in `workspace` (same arguments, any stream
  * that waits for part 1; the workspace must live until it has run), 3 = both.  Separable for a single-layer loop
- * without attention (lr_decoder_backward_splittable: config/defaults.txt and the ecd flag-file family); otherwise
- * only parts = 3 is accepted. */
+ * (lr_decoder_backward_splittable: every flag file the reference ships); otherwise only parts = 3 is accepted. */
 int lr_decoder_backward_splittable(int attn_type, int num_layers);
 int lr_decoder_backward_parts(int mode, int attn_type, const lr_decoder_params* params_host,
                               const lr_decoder_upper* upper_host, const lr_decoder_grads* grads_host,

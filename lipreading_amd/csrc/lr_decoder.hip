@@ -811,10 +811,10 @@ extern "C" int lr_decoder_forward(int mode, int attn_type, const lr_decoder_para
 
 // parts: 1 = the data half (everything the encoder's backward waits for: d_enc, dh0, dc0; leaves dG, dlogits in the
 // workspace), 2 = the weight half (every parameter gradient, from what part 1 left), 3 = both.  The two halves are
-// separable for a single-layer loop without attention (lr_decoder_backward_splittable): the reference's defaults and its
-// ecd flag-file family.
+// separable for a single-layer loop (lr_decoder_backward_splittable), any attention type: every shipped flag file.
 extern "C" int lr_decoder_backward_splittable(int attn_type, int num_layers) {
-  return attn_type == ATT_NONE && num_layers == 1;
+  (void)attn_type;
+  return num_layers == 1;   // (layers above the first overwrite the gate-gradient buffer their weight products read)
 }
 extern "C" int lr_decoder_backward_parts(int mode, int attn_type, const lr_decoder_params* p, const lr_decoder_upper* up,
                                          const lr_decoder_grads* g, const lr_decoder_upper_grads* gup,
@@ -877,7 +877,8 @@ extern "C" int lr_decoder_backward_parts(int mode, int attn_type, const lr_decod
   if (!attn) {
     lr_clear_error();
     if (do_data && hipMemsetAsync(d_enc, 0, (size_t)R * Hd * sizeof(float), stream) != hipSuccess) return LR_ERR_LAUNCH;
-  } else {   // (parts == 3 here: not splittable)
+  } else {   // (attention: every launch below belongs to ONE half — data D, weights W)
+    if (do_data) {   // D: through the concat layer and the attention weights into dctx, dlg, d_enc, dy
     const int64_t n4 = (int64_t)BL * Hd / 4;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
@@ -910,48 +911,62 @@ extern "C" int lr_decoder_backward_parts(int mode, int attn_type, const lr_decod
       LR_LAUNCH(dec_sum_steps_kernel, dim3(B), dim3(128), 0, stream, (const float*)dlg, wb + w.dcterm, L, T);
       LR_TRY(lr_launch_status());
     }
+    }   // (do_data)
     if (attn_type == ATT_GENERAL) {
       LR_CHECK_ARG(g->attn_w1 && g->attn_b1);
       // GE = enc @ W_g: dW_g = enc^T @ dGE, d_enc += dGE @ W_g^T; cE = enc . b_g: db_g = enc^T dcE, d_enc += dcE b_g^T
-      LR_TRY(lr_sgemm_impl(1, 0, Hd, Hd, R, 1.f, enc, Hd, wb + w.dsrc, Hd, beta, g->attn_w1, Hd, nullptr, 0, 0, gws,
-                           w.gemm_bytes, stream));
-      LR_TRY(lr_sgemm_impl(0, 1, R, Hd, Hd, 1.f, wb + w.dsrc, Hd, p->attn_w1, Hd, 1.f, d_enc, Hd, nullptr, 0, 0, gws,
-                           w.gemm_bytes, stream));
-      LR_TRY(lr_sgemm_impl(1, 0, Hd, 1, R, 1.f, enc, Hd, wb + w.dcterm, 1, beta, g->attn_b1, 1, nullptr, 0, 0, gws,
-                           w.gemm_bytes, stream));
-      LR_TRY(lr_sgemm_impl(0, 0, R, Hd, 1, 1.f, wb + w.dcterm, 1, p->attn_b1, Hd, 1.f, d_enc, Hd, nullptr, 0, 0,
-                           nullptr, 0, stream));
+      if (do_weights)
+        LR_TRY(lr_sgemm_impl(1, 0, Hd, Hd, R, 1.f, enc, Hd, wb + w.dsrc, Hd, beta, g->attn_w1, Hd, nullptr, 0, 0, gws,
+                             w.gemm_bytes, stream));
+      if (do_data)
+        LR_TRY(lr_sgemm_impl(0, 1, R, Hd, Hd, 1.f, wb + w.dsrc, Hd, p->attn_w1, Hd, 1.f, d_enc, Hd, nullptr, 0, 0, gws,
+                             w.gemm_bytes, stream));
+      if (do_weights)
+        LR_TRY(lr_sgemm_impl(1, 0, Hd, 1, R, 1.f, enc, Hd, wb + w.dcterm, 1, beta, g->attn_b1, 1, nullptr, 0, 0, gws,
+                             w.gemm_bytes, stream));
+      if (do_data)
+        LR_TRY(lr_sgemm_impl(0, 0, R, Hd, 1, 1.f, wb + w.dcterm, 1, p->attn_b1, Hd, 1.f, d_enc, Hd, nullptr, 0, 0,
+                             nullptr, 0, stream));
     } else if (attn_type == ATT_1LNN) {
       LR_CHECK_ARG(g->attn_w1 && g->attn_b1);
       // logit = w_e . enc[t] + w_h . h + b:  dw_e = enc^T dse, d_enc += dse w_e^T,
       // dh += dsum w_h, dw_h = hs^T dsum, db = sum dsum
-      LR_TRY(lr_sgemm_impl(1, 0, Hd, 1, R, 1.f, enc, Hd, wb + w.dcterm, 1, beta, g->attn_w1, 1, nullptr, 0, 0, gws,
-                           w.gemm_bytes, stream));
-      LR_TRY(lr_sgemm_impl(0, 1, R, Hd, 1, 1.f, wb + w.dcterm, 1, p->attn_w1, 1, 1.f, d_enc, Hd, nullptr, 0, 0,
-                           nullptr, 0, stream));
-      LR_TRY(lr_sgemm_impl(0, 0, BL, Hd, 1, 1.f, dsum, 1, p->attn_w1 + Hd, Hd, 1.f, dy, Hd, nullptr, 0, 0, nullptr, 0,
-                           stream));
-      LR_TRY(lr_sgemm_impl(1, 0, Hd, 1, BL, 1.f, hs, Hd, dsum, 1, beta, g->attn_w1 + Hd, 1, nullptr, 0, 0, gws,
-                           w.gemm_bytes, stream));
-      LR_TRY(colsum_into(dsum, 1, BL, 1, colsum, g->attn_b1, accumulate, stream));
+      if (do_weights)
+        LR_TRY(lr_sgemm_impl(1, 0, Hd, 1, R, 1.f, enc, Hd, wb + w.dcterm, 1, beta, g->attn_w1, 1, nullptr, 0, 0, gws,
+                             w.gemm_bytes, stream));
+      if (do_data) {
+        LR_TRY(lr_sgemm_impl(0, 1, R, Hd, 1, 1.f, wb + w.dcterm, 1, p->attn_w1, 1, 1.f, d_enc, Hd, nullptr, 0, 0,
+                             nullptr, 0, stream));
+        LR_TRY(lr_sgemm_impl(0, 0, BL, Hd, 1, 1.f, dsum, 1, p->attn_w1 + Hd, Hd, 1.f, dy, Hd, nullptr, 0, 0, nullptr, 0,
+                             stream));
+      }
+      if (do_weights) {
+        LR_TRY(lr_sgemm_impl(1, 0, Hd, 1, BL, 1.f, hs, Hd, dsum, 1, beta, g->attn_w1 + Hd, 1, nullptr, 0, 0, gws,
+                             w.gemm_bytes, stream));
+        LR_TRY(colsum_into(dsum, 1, BL, 1, colsum, g->attn_b1, accumulate, stream));
+      }
     } else if (attn_type == ATT_CONCAT) {
       LR_CHECK_ARG(g->attn_w1 && g->attn_b1 && g->attn_w2 && g->attn_b2);
-      LR_LAUNCH(dec_concat_bwd_kernel, dim3((A + 63) / 64, B), dim3(64), (size_t)L * T * sizeof(float), stream,
-                rb + r.aux1, rb + r.ph, p->attn_w2, (const float*)dlg, enc_lens, wb + w.dPE, wb + w.dph, wb + w.dw2p,
-                L, T, A);
-      LR_TRY(lr_launch_status());
-      // W1 = [W1e | W1h] (A x 2Hd): PE = enc W1e^T + b1, ph = hs W1h^T
-      LR_TRY(lr_sgemm_impl(0, 0, BL, Hd, A, 1.f, wb + w.dph, A, p->attn_w1 + Hd, 2 * Hd, 1.f, dy, Hd, nullptr, 0, 0,
-                           gws, w.gemm_bytes, stream));                                  // dh += dph W1h
-      LR_TRY(lr_sgemm_impl(1, 0, A, Hd, BL, 1.f, wb + w.dph, A, hs, Hd, beta, g->attn_w1 + Hd, 2 * Hd, nullptr, 0, 0,
-                           gws, w.gemm_bytes, stream));                                  // dW1h = dph^T hs
-      LR_TRY(lr_sgemm_impl(1, 0, A, Hd, R, 1.f, wb + w.dPE, A, enc, Hd, beta, g->attn_w1, 2 * Hd, nullptr, 0, 0, gws,
-                           w.gemm_bytes, stream));                                       // dW1e = dPE^T enc
-      LR_TRY(lr_sgemm_impl(0, 0, R, Hd, A, 1.f, wb + w.dPE, A, p->attn_w1, 2 * Hd, 1.f, d_enc, Hd, nullptr, 0, 0, gws,
-                           w.gemm_bytes, stream));                                       // d_enc += dPE W1e
-      LR_TRY(colsum_into(wb + w.dPE, A, R, A, colsum, g->attn_b1, accumulate, stream));
-      LR_TRY(colsum_into(wb + w.dw2p, A, B, A, colsum, g->attn_w2, accumulate, stream));
-      LR_TRY(colsum_into(dsum, 1, BL, 1, colsum, g->attn_b2, accumulate, stream));
+      if (do_data) {
+        LR_LAUNCH(dec_concat_bwd_kernel, dim3((A + 63) / 64, B), dim3(64), (size_t)L * T * sizeof(float), stream,
+                  rb + r.aux1, rb + r.ph, p->attn_w2, (const float*)dlg, enc_lens, wb + w.dPE, wb + w.dph, wb + w.dw2p,
+                  L, T, A);
+        LR_TRY(lr_launch_status());
+        // W1 = [W1e | W1h] (A x 2Hd): PE = enc W1e^T + b1, ph = hs W1h^T
+        LR_TRY(lr_sgemm_impl(0, 0, BL, Hd, A, 1.f, wb + w.dph, A, p->attn_w1 + Hd, 2 * Hd, 1.f, dy, Hd, nullptr, 0, 0,
+                             gws, w.gemm_bytes, stream));                                  // dh += dph W1h
+        LR_TRY(lr_sgemm_impl(0, 0, R, Hd, A, 1.f, wb + w.dPE, A, p->attn_w1, 2 * Hd, 1.f, d_enc, Hd, nullptr, 0, 0, gws,
+                             w.gemm_bytes, stream));                                       // d_enc += dPE W1e
+      }
+      if (do_weights) {
+        LR_TRY(lr_sgemm_impl(1, 0, A, Hd, BL, 1.f, wb + w.dph, A, hs, Hd, beta, g->attn_w1 + Hd, 2 * Hd, nullptr, 0, 0,
+                             gws, w.gemm_bytes, stream));                                  // dW1h = dph^T hs
+        LR_TRY(lr_sgemm_impl(1, 0, A, Hd, R, 1.f, wb + w.dPE, A, enc, Hd, beta, g->attn_w1, 2 * Hd, nullptr, 0, 0, gws,
+                             w.gemm_bytes, stream));                                       // dW1e = dPE^T enc
+        LR_TRY(colsum_into(wb + w.dPE, A, R, A, colsum, g->attn_b1, accumulate, stream));
+        LR_TRY(colsum_into(wb + w.dw2p, A, B, A, colsum, g->attn_w2, accumulate, stream));
+        LR_TRY(colsum_into(dsum, 1, BL, 1, colsum, g->attn_b2, accumulate, stream));
+      }
     }
   }
 

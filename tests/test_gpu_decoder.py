@@ -477,3 +477,50 @@ def test_decoder_loop_on_the_cluster_recurrence_equals_the_step_kernels(dev, rnn
     worst = max(worst, rel)
     assert rel < 5e-5, (i, rel, tuple(a.shape))
   print("decoder %s-%d x%d: cluster vs step kernels, worst relative norm difference %.3g" % (rnn_type, Hd, layers, worst))
+
+
+@pytest.mark.parametrize("rnn_type,Hd,B,attn", [("LSTM", 1536, 32, "none"), ("GRU", 512, 8, "none"), ("LSTM", 1024, 4, "1_layer_nn"),
+                                                ("GRU", 512, 8, "general"), ("LSTM", 512, 8, "concat"), ("GRU", 512, 8, "dot")])
+def test_loop_weight_half_on_the_side_stream_is_bit_identical(dev, rnn_type, Hd, B, attn):
+  """A single-layer loop (every flag file the reference ships) splits its backward
+  (lr_decoder_backward_parts): the data half on the caller's stream, every parameter gradient on the encoder module's side
+  stream, joined when the backward pass ends.  Same kernels, same arguments: the gradients are the unsplit call's, bit for
+  bit, and whoever reads them after backward() finds them complete."""
+  import lipreading_amd.attention_decoder as AD
+  from lipreading_amd.data import default_char2idx
+  from lipreading_amd.optim import FlatParameters
+
+  class Enc:
+    hidden_size, bidirectional, rnn_type, num_layers = Hd // 2, True, None, 1
+  Enc.rnn_type = rnn_type
+  torch.manual_seed(21)
+  dec = AD.CharDecodingStep(Enc(), 64, 64, default_char2idx(), attention_type=attn,
+                            attn_hidden_size=96 if attn == "concat" else -1).to(dev)
+  FlatParameters(dec)                      # dense .grad buffers: the loop accumulates into them directly
+  g = torch.Generator().manual_seed(22)
+  T, L = 40, 19
+  enc = (torch.randn(B, T, Hd, generator=g) * 0.5).to(dev)
+  lens = torch.full((B,), T)
+  h0 = (torch.randn(1, B, Hd, generator=g) * 0.5).to(dev)
+  c0 = (torch.randn(1, B, Hd, generator=g) * 0.5).to(dev)
+  chars = torch.randint(4, 64, (B, L), generator=g).to(dev)
+  wgt = (torch.randn(B, L, 64, generator=g) / 100).to(dev)
+  res = {}
+  for overlap in (False, True):
+    AD.overlap_weight_half = overlap
+    try:
+      AD.take_split_flag()
+      for p in dec.parameters():
+        p.grad.zero_()
+      h0d = h0.clone().requires_grad_(True)
+      encd = enc.clone().requires_grad_(True)
+      state = (h0d, c0.clone().requires_grad_(True)) if rnn_type == "LSTM" else h0d
+      lp, _, _ = dec.decode_sequence(chars, state, lens, encd, seed=5)
+      (lp * wgt).sum().backward()
+      assert AD.take_split_flag() == overlap          # the split path is what ran (and only then)
+      # (no synchronisation of our own: reading on the current stream must be enough)
+      res[overlap] = [h0d.grad.clone(), encd.grad.clone()] + [p.grad.clone() for p in dec.parameters()]
+    finally:
+      AD.overlap_weight_half = True
+  for a, b in zip(res[False], res[True]):
+    assert torch.equal(a, b)
