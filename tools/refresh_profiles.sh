@@ -103,6 +103,8 @@ if [ "$ONLY" != "pixels" ]; then
   for b in 32 128; do
     python bench.py --regime landmarks_attn --model lstm768 --attention none --char-dim 256 --rnn-dropout 0.3 --batch $b 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_ecd_lstm768_b$b.json"
   done
+  # config/train/attn/attention_type as shipped (BiLSTM-512 -> LSTM-1024, 1_layer_nn, char_dim 256) at B = 32
+  python bench.py --regime landmarks_attn --model lstm512 --char-dim 256 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_attn_lstm512_b32.json"
   kt ecd_lstm768_b32 --regime landmarks_attn --model lstm768 --attention none --char-dim 256 --batch 32
   kt ecd_lstm768_b128 --regime landmarks_attn --model lstm768 --attention none --char-dim 256 --batch 128
   for c in FETCH_SIZE WRITE_SIZE; do
