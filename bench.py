@@ -683,9 +683,11 @@ def run_regime(args, regime, world, rank, dev, recurrence=None):
 
   # GPU-bound steps (the pixel regimes: ~100 long kernels, two streams) gain nothing from a graph and may lose
   # a little (the captured side-stream branches overlap less well than eager launches do): time both forms on
-  # a few untimed steps and keep the faster one.  Launch-bound steps (landmarks) always replay.
+  # a few untimed steps and keep the faster one.  So do the decoder regimes since round 6: an EAGER step runs the
+  # loop's weight half and the decoder's optimiser on a side stream (attention_decoder.overlap_weight_half), a
+  # captured one keeps them on one queue.  Launch-bound steps (landmarks, encoder + CTC only) always replay.
   launch_choice = None
-  if use_graph and pixels and not DIST_ON:
+  if use_graph and (pixels or attn) and not DIST_ON:
     def probe(g):
       fence()
       t0 = time.perf_counter()

@@ -57,13 +57,16 @@ def _step_lens(B, L, dev):
 
 # test hook / switch: False keeps the loop's weight half on the stream of its data half
 overlap_weight_half = True
-_split_flag = False   # the last backward put its weight half on the side stream (train._step_all takes it)
+# The stream whose backward pass put the loop's weight half on the side stream, until train._step_all takes it (or the
+# next loop starts): the decoder's optimiser may follow the weight half there only in THAT pass, from THAT stream.
+_split_from = None
 
 
 def take_split_flag():
-  global _split_flag
-  f, _split_flag = _split_flag, False
-  return f
+  """True once, if the backward pass that just ended on the current stream split the loop's backward."""
+  global _split_from
+  s, _split_from = _split_from, None
+  return s is not None and s == torch.cuda.current_stream()
 
 
 class _AttnDecoderFunction(torch.autograd.Function):
@@ -75,6 +78,8 @@ class _AttnDecoderFunction(torch.autograd.Function):
   def forward(ctx, tokens, teacher_forced, seed, mode, attn_type, attn_hidden, enc, enc_lens, h0, c0,
               out_mask, drop_mask, *params):
     L_ = _C.lib()
+    global _split_from
+    _split_from = None     # (a flag nobody took — a loop stepped outside train._step_all — does not outlive its step)
     B, L = tokens.shape
     T, Hd = enc.shape[1], enc.shape[2]
     params, upper = params[:13], params[13:]
@@ -154,7 +159,12 @@ class _AttnDecoderFunction(torch.autograd.Function):
             enc.data_ptr(), enc_lens.data_ptr(), h0.data_ptr(), _C.ptr(c0), step_lens.data_ptr(), lp.data_ptr(),
             d_lp.data_ptr(), _C.ptr(dh_n), _C.ptr(dc_n), d_enc.data_ptr(), dh0.data_ptr(), _C.ptr(dc0),
             reserve.data_ptr(), reserve.numel(), ws.data_ptr(), wbytes, 1 if direct else 0, B, L, T, Hd, Cd, V, A)
-    if overlap_weight_half and direct and L_.lr_decoder_backward_splittable(attn_type, NL):
+    # (Not inside a hipGraph capture: with this fork in the captured decoder steps the -m gpu suite — some forty
+    # captured graphs in one process — died inside hipGraphLaunch of a LATER, unrelated graph, reproducibly and only in
+    # one order of the test files; both halves on one stream, or the fork in eager steps only, and it does not.  Not
+    # root-caused in round 6; a captured step therefore keeps the loop's backward on one queue.)
+    if (overlap_weight_half and direct and L_.lr_decoder_backward_splittable(attn_type, NL) and
+        not torch.cuda.is_current_stream_capturing()):
       # The encoder's backward only waits for dh0 / dc0 (and d_enc): the data half stays on this stream, every parameter
       # gradient of the loop goes to the encoder module's side stream and runs beside the head's and the encoder's
       # backward — whose recurrence leaves a quarter of the chip idle — until the encoder layer's backward (or the
@@ -172,8 +182,8 @@ class _AttnDecoderFunction(torch.autograd.Function):
       # whoever reads the gradients after loss.backward() — an optimiser, a test, .cpu() — finds them complete: the
       # streams are joined when this backward pass ends at the latest
       torch.autograd.Variable._execution_engine.queue_callback(_enc.flush_deferred)
-      global _split_flag
-      _split_flag = True
+      global _split_from
+      _split_from = torch.cuda.current_stream()
       return (None, None, None, None, None, None, d_enc, None, dh0, dc0, None, None) + (None,) * (len(params) + len(upper))
     _C.check(L_.lr_decoder_backward_parts(*args, 3, _C.stream_handle()), "lr_decoder_backward")
     if direct:

@@ -10,6 +10,8 @@ device and read once per epoch.  `decoding_step=None` runs the encoder+CTC path 
 path BASELINE.json's north_star names; with a `CharDecodingStep` the attention decoder loop
 (:56-65) runs as one fused enqueue per batch (lipreading_amd/attention_decoder.py).
 """
+import os
+
 import torch
 
 from . import _C
