@@ -390,14 +390,16 @@ class VideoEncoder(nn.Module):
     if self.enable_ctc:
       self.output_proj = nn.Linear(self.num_dirs * self.hidden_size, self.adj_vocab_size)
 
-  def forward(self, frames, frame_lens, max_len=None, need_final_state=True):
+  def forward(self, frames, frame_lens, max_len=None, need_final_state=True, head_stream=None):
     """frames (B, seq_len, num_lmks, lmk_dim) f32, frame_lens (B,) -> as better_model.py:53-96:
     (log_probs (B,Tmax,V+1), hidden (B,Tmax,D*H), final_state) if enable_ctc else
     (hidden, final_state); final_state is (h, c) for the LSTM, each (layers, B, D*H).
 
     `max_len` (optional, not in the reference) = max(frame_lens) when the caller already knows
     it on the host; it avoids the one device->host read that the reference also performs
-    (better_model.py:69)."""
+    (better_model.py:69).  `head_stream` (not in the reference): the CTC head runs on that stream (it waits for this
+    one); the caller joins before it reads log_probs on another stream (train.decoder_step: the head and the CTC loss
+    beside the decoder loop)."""
     _C.require_cuda(frames)
     if self.frame_processing == 'flatten':
       frames = frames.reshape(frames.shape[0], frames.shape[1], -1)
@@ -456,8 +458,14 @@ class VideoEncoder(nn.Module):
         final_state = (final_state, c_fin[0].unsqueeze(0) if len(c_fin) == 1 else torch.stack(c_fin, 0))
 
     if self.enable_ctc:
-      output_log_probs = _ProjLogSoftmaxFunction.apply(hidden_states, self.output_proj.weight,
-                                                       self.output_proj.bias, self.output_mask)
+      if head_stream is not None:
+        head_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(head_stream):
+          output_log_probs = _ProjLogSoftmaxFunction.apply(hidden_states, self.output_proj.weight,
+                                                           self.output_proj.bias, self.output_mask)
+      else:
+        output_log_probs = _ProjLogSoftmaxFunction.apply(hidden_states, self.output_proj.weight,
+                                                         self.output_proj.bias, self.output_mask)
       return output_log_probs, hidden_states, final_state
     return hidden_states, final_state
 

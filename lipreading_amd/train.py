@@ -10,9 +10,12 @@ device and read once per epoch.  `decoding_step=None` runs the encoder+CTC path 
 path BASELINE.json's north_star names; with a `CharDecodingStep` the attention decoder loop
 (:56-65) runs as one fused enqueue per batch (lipreading_amd/attention_decoder.py).
 """
+import contextlib
 import os
 
 import torch
+
+from .encoder import VideoEncoder as _VideoEncoder
 
 from . import _C
 from .ctc import ctc_loss_prepared, ctc_loss_with_status, prepare_ctc_inputs
@@ -331,6 +334,18 @@ def ctc_step(encoder, opt, frames, frame_lens, chars, char_lens, grad_norm=None,
   return loss, status
 
 
+# test hook / switch: False keeps the CTC branch of a decoder step on the step's own stream
+overlap_ctc_branch = True
+_ctc_side = None
+
+
+def _ctc_stream(device):
+  global _ctc_side
+  if _ctc_side is None or _ctc_side.device != device:
+    _ctc_side = torch.cuda.Stream(device=device)
+  return _ctc_side
+
+
 def _step_all(opts, grad_norm, status):
   """The per-module clip + Adam of train_better_model.py:77-80 for opts = (encoder's, decoder's).  When the decoder
   loop's weight half ran on the side stream (attention_decoder.overlap_weight_half), its gradients were complete long
@@ -375,12 +390,22 @@ def decoder_step(encoder, decoding_step, opts, frames, frame_lens, chars, char_l
       labels_p1, frame_lens32, label_lens32 = opts[0].zero_grad_and_prepare_ctc(chars, frame_lens_d, char_lens_d)
     for o in (opts[1:] if fused_prep else opts):
       o.zero_grad()
+    ctc_side = None
     if use_ctc:
-      log_probs, hidden, state = encoder(frames, frame_lens32 if fused_prep else frame_lens_d, max_len=max_len)
-      if fused_prep:
-        ctc, status, _ = ctc_loss_prepared(log_probs, labels_p1, frame_lens32, label_lens32, 'mean')
-      else:
-        ctc, status, _ = ctc_loss_with_status(log_probs, labels, frame_lens_d, char_lens_d - 1, 'mean')
+      # The CTC branch (head, loss — and, because autograd runs a node's backward on the stream of its forward, their
+      # backward) on a stream of its own beside the decoder loop: both only read the encoder's states.  Eager steps
+      # only, as the loop's split backward (attention_decoder.py).
+      if (whole and overlap_ctc_branch and not torch.cuda.is_current_stream_capturing() and
+          isinstance(encoder, _VideoEncoder)):
+        ctc_side = _ctc_stream(frames.device)
+      log_probs, hidden, state = (encoder(frames, frame_lens32 if fused_prep else frame_lens_d, max_len=max_len,
+                                          head_stream=ctc_side) if ctc_side is not None else
+                                  encoder(frames, frame_lens32 if fused_prep else frame_lens_d, max_len=max_len))
+      with (torch.cuda.stream(ctc_side) if ctc_side is not None else contextlib.nullcontext()):
+        if fused_prep:
+          ctc, status, _ = ctc_loss_prepared(log_probs, labels_p1, frame_lens32, label_lens32, 'mean')
+        else:
+          ctc, status, _ = ctc_loss_with_status(log_probs, labels, frame_lens_d, char_lens_d - 1, 'mean')
       total = ctc
     else:
       hidden, state = encoder(frames, frame_lens_d, max_len=max_len)
@@ -393,10 +418,16 @@ def decoder_step(encoder, decoding_step, opts, frames, frame_lens, chars, char_l
       if sy is not None and hasattr(sy, "set_status"):
         sy.set_status(status)
     one = _one(decoder_loss.device)
+    if ctc_side is not None:
+      torch.cuda.current_stream().wait_stream(ctc_side)     # the loss and the status exist
     if use_ctc:
       torch.autograd.backward([decoder_loss, total], [one, one])
     else:
       decoder_loss.backward(one)
+    if ctc_side is not None:
+      # (the head's parameter gradients are written in place by its backward, on that stream: no AccumulateGrad node
+      # that would make the engine join it)
+      torch.cuda.current_stream().wait_stream(ctc_side)
     if whole:
       _step_all(opts, grad_norm, status)
     out = (decoder_loss.detach(),)
