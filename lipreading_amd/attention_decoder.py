@@ -168,7 +168,7 @@ class _AttnDecoderFunction(torch.autograd.Function):
       # The encoder's backward only waits for dh0 / dc0 (and d_enc): the data half stays on this stream, every parameter
       # gradient of the loop goes to the encoder module's side stream and runs beside the head's and the encoder's
       # backward — whose recurrence leaves a quarter of the chip idle — until the encoder layer's backward (or the
-      # optimiser) joins the streams (encoder.flush_deferred).  Round 6: the ecd family's step 1.81 -> see DESIGN 4.9.
+      # optimiser) joins the streams (encoder.flush_deferred).  Round 6: the ecd family's step 1.81 -> 1.66 ms.
       from . import encoder as _enc
       _C.check(L_.lr_decoder_backward_parts(*args, 1, _C.stream_handle()), "lr_decoder_backward_parts(data)")
       _enc.flush_deferred()                  # at most one deferred half in flight

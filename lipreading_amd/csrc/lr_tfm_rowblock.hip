@@ -8,24 +8,27 @@
 // workgroup owns 32 ROWS and walks the whole chain with the rows' activations in LDS:
 //
 //   forward :  a -> s1 = a Wo^T + bo + h -> h1 = LN1(s1) -> f1 = relu(h1 W1^T + b1) (256 hidden columns at a time)
-//              -> s2 = f1 W2^T + b2 + h1 -> h2 = LN2(s2)
-//   backward:  dh2 -> ds2 = LN2'(dh2) -> df1 = (ds2 W2) . [f1 > 0] (256 columns at a time) -> dh1 = df1 W1 + ds2
-//              -> ds1 = LN1'(dh1) -> da = ds1 Wo
+//              -> s2 = f1 W2^T + b2 + h1 -> h2 = LN2(s2)   [-> the NEXT layer's qkv = h2 Wqkv'^T + bqkv']
+//   backward:  [dh2 = dqkv' Wqkv' + ds1' of the layer ABOVE ->] ds2 = LN2'(dh2) -> df1 = (ds2 W2) . [f1 > 0]
+//              (256 columns at a time) -> dh1 = df1 W1 + ds2 -> ds1 = LN1'(dh1) -> da = ds1 Wo
 //
 // and writes what lr_tfm_backward_weights and the other direction read (s1, stats, h1, f1, s2, stats / ds2, df1,
-// ds1, da, LayerNorm partials) — the same tensors as before, so nothing else of the stack changes.
+// ds1, da, LayerNorm partials) — the same tensors as before, so nothing else of the stack changes.  The bracketed
+// products are the neighbouring layer's QKV projection and its data gradient (template argument X): they are row-wise
+// too, and riding along saves their launches (18 / 35 us each for + 8 / + 14 us here).
 //
 // Shape of the kernel.  512 threads = 8 waves; wave w owns output columns 32 w .. 32 w + 31 of every product, so a
-// product of the chain is 4 "groups" of 64 k: 12 v_mfma_f32_32x32x16_bf16 (hi hi + hi lo + lo hi, the stage's X3
+// product of the chain is 4 "groups" of 64 k: 48 v_mfma_f32_32x32x16_bf16 (hi hi + hi lo + lo hi, the stage's X3
 // arithmetic) on one 32 x 32 accumulator.  The activation operand comes out of LDS (bf16 hi / lo planes [32][264],
 // ds_read_b128, conflict-free at 528-byte rows); the WEIGHT operand never touches LDS: a lane's fragment — 8
-// consecutive k of one output column — is contiguous in a [N][K] weight matrix, so the lanes load it straight from
-// pre-split bf16 planes (lr_tfm_rowblock_pack: hi + lo of every weight and of its transpose, once per forward call)
-// with the k of a group permuted so that a lane's four fragments of a group are 64 contiguous bytes.  Nothing is
-// shared between waves, so the weight stream (2.36 MB per workgroup and layer, out of the L2: every workgroup reads
-// the same planes at about the same time) runs three groups ahead of the MFMAs through a ring of registers, across
-// barriers and epilogues.  One workgroup per CU, 75 of them at B x T = 2400: the bound is that stream,
-// ~64 B/clk per CU.
+// consecutive k of one output column — is a contiguous run of a [N][K] weight matrix, so lr_tfm_rb_pack (hi + lo of
+// every weight and of its transpose, once per forward call) writes the planes in MFMA FRAGMENT ORDER — blocks of
+// (32-column tile, 64-k group), inside [k16 step][lane][8 values] — and one load instruction of a wave reads 1 KB of
+// consecutive bytes.  Nothing is shared between waves, so the weight stream (2.36 MB per workgroup and layer, out of
+// the L2: every workgroup reads the same planes at about the same time) runs three groups ahead of the MFMAs through
+// a ring of 96 registers, across barriers and epilogues.  One workgroup per CU, 75 of them at B x T = 2400.  Bound
+// (stamps and switches below): that stream at ~52 B/clk per CU with the matrix pipe, two waves per
+// SIMD, within a quarter of it.
 #include "lr_common.h"
 #include "lr_rnn_xch.h"
 

@@ -10,7 +10,9 @@
 // they lie in memory and carries bias / residual / positional table / ReLU / ReLU mask in its epilogue, every weight
 // gradient of every layer (with its bias gradient) in ONE launch, LayerNorm parameter gradients in one more.
 // Round 4 composed the same arithmetic per operation from Python: 375 launches per step at the bench shape, 58 of
-// them ATen adds; this is 29 forward + 30 backward launches.
+// them ATen adds; this is 29 forward + 30 backward launches.  Round 6 (mode bit LR_TFM_ROWBLOCK, lr_tfm_rowblock.hip):
+// out-projection .. LN2, and the neighbouring layer's QKV product, as ONE launch per layer and direction over 32-row
+// blocks — 11 forward + 14 backward launches for the four-layer stack.
 #include "lr_common.h"
 
 namespace {
