@@ -170,9 +170,9 @@ __device__ __forceinline__ void st_f32x4(rsrc_t r, unsigned off, float4 v) {
 // (barriers: lr_lds_barrier, which waits for LDS traffic only — __syncthreads would drain the stream's loads in flight)
 
 // ---- the weight stream of a wave ----------------------------------------------------------------------------------
-// group gi of the chain: phase gi >> 2 (one product of 256 k), quarter gi & 3 (64 k).  A lane holds column n = lane
-// % 32 of the wave's 32 and the k half kh = lane / 32: its fragments of the group's four k16 steps are the 64
-// contiguous bytes at k = k0 + 32 kh of row n of each plane.
+// group gi of the chain: phase gi >> 2 (one product of 256 k), quarter gi & 3 (64 k) = one 4 KB block of the hi plane
+// and one of the lo plane (tfm_rb_pack_kernel's fragment order).  A lane holds column n = lane % 32 of the wave's 32
+// and the k half kh = lane / 32; its fragment of k16 step s is the 16 bytes at block + 1024 s + 16 lane.
 //   forward : phase 0 = Wo, then per chunk c: W1 rows 256 c + n, W2 columns 256 c + k
 //   backward: per chunk c: W2^T rows 256 c + n, W1^T columns 256 c + k; the last phase = Wo^T
 // The ring: THREE groups (96 registers) — the one being consumed and two in flight; a group's slot is refilled with

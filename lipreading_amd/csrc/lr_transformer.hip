@@ -12,7 +12,8 @@
 // Round 4 composed the same arithmetic per operation from Python: 375 launches per step at the bench shape, 58 of
 // them ATen adds; this is 29 forward + 30 backward launches.  Round 6 (mode bit LR_TFM_ROWBLOCK, lr_tfm_rowblock.hip):
 // out-projection .. LN2, and the neighbouring layer's QKV product, as ONE launch per layer and direction over 32-row
-// blocks — 11 forward + 14 backward launches for the four-layer stack.
+// blocks — 12 forward + 10 backward launches for the four-layer stack (input projection + its K-split combine, the
+// weight pack, layer 0's QKV, four x (attention, row block); four x (row block, attention), layer 0's input gradient, dx).
 #include "lr_common.h"
 
 namespace {
