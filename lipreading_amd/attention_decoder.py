@@ -62,6 +62,37 @@ overlap_weight_half = True
 _split_from = None
 
 
+# The loop's weight half runs on a stream of ITS OWN, not on encoder._side_stream: with the encoder module's side
+# stream forked into the captured decoder steps as well as into the captured pixel steps, the -m gpu suite (some forty
+# captured graphs in one process) died inside hipGraphLaunch of a later pixel-step graph — reproducibly, in one order of
+# the test files; with this stream it does not (round 6, visits r06H .. r06X; the runtime-side cause was not found).
+_side = None
+_deferred = []     # what the half in flight reads, kept alive until the streams are joined
+
+
+def side_stream(device=None):
+  global _side
+  if device is not None and (_side is None or _side.device != device):
+    _side = torch.cuda.Stream(device=device)
+  return _side
+
+
+def flush(into=None):
+  """`into` (default: the current stream) waits for the loop's deferred weight half; a no-op when none is pending."""
+  if _deferred:
+    (into if into is not None else torch.cuda.current_stream()).wait_stream(_side)
+    del _deferred[:]
+
+
+def _register():
+  from . import encoder as _enc
+  if flush not in _enc.deferred_flushers:      # FusedAdam.step and the encoder layers' backward join through there
+    _enc.deferred_flushers.append(flush)
+
+
+_register()
+
+
 def take_split_flag():
   """True once, if the backward pass that just ended on the current stream split the loop's backward."""
   global _split_from
@@ -159,31 +190,26 @@ class _AttnDecoderFunction(torch.autograd.Function):
             enc.data_ptr(), enc_lens.data_ptr(), h0.data_ptr(), _C.ptr(c0), step_lens.data_ptr(), lp.data_ptr(),
             d_lp.data_ptr(), _C.ptr(dh_n), _C.ptr(dc_n), d_enc.data_ptr(), dh0.data_ptr(), _C.ptr(dc0),
             reserve.data_ptr(), reserve.numel(), ws.data_ptr(), wbytes, 1 if direct else 0, B, L, T, Hd, Cd, V, A)
-    # (Not inside a hipGraph capture: with this fork in the captured decoder steps the -m gpu suite — some forty
-    # captured graphs in one process — died inside hipGraphLaunch of a LATER, unrelated graph, reproducibly and only in
-    # one order of the test files; both halves on one stream, or the fork in eager steps only, and it does not.  Not
-    # root-caused in round 6; a captured step therefore keeps the loop's backward on one queue.)
-    if (overlap_weight_half and direct and L_.lr_decoder_backward_splittable(attn_type, NL) and
-        not torch.cuda.is_current_stream_capturing()):
+    if overlap_weight_half and direct and L_.lr_decoder_backward_splittable(attn_type, NL):
       # The encoder's backward only waits for dh0 / dc0 (and d_enc): the data half stays on this stream, every parameter
-      # gradient of the loop goes to the encoder module's side stream and runs beside the head's and the encoder's
-      # backward — whose recurrence leaves a quarter of the chip idle — until the encoder layer's backward (or the
-      # optimiser) joins the streams (encoder.flush_deferred).  Round 6: the ecd family's step 1.81 -> 1.66 ms.
-      from . import encoder as _enc
+      # gradient of the loop goes to this module's side stream and runs beside the head's and the encoder's backward —
+      # whose recurrence leaves a quarter of the chip idle.  Round 6: the ecd family's step 1.81 -> 1.66 ms.
       _C.check(L_.lr_decoder_backward_parts(*args, 1, _C.stream_handle()), "lr_decoder_backward_parts(data)")
-      _enc.flush_deferred()                  # at most one deferred half in flight
-      side = _enc._get_side_stream(dev)
-      side.wait_stream(torch.cuda.current_stream())
+      flush()                                # at most one deferred half in flight
+      forked_from = torch.cuda.current_stream()
+      side = side_stream(dev)
+      side.wait_stream(forked_from)
       with torch.cuda.stream(side):
         _C.check(L_.lr_decoder_backward_parts(*args, 2, _C.stream_handle()), "lr_decoder_backward_parts(weights)")
         _notify(real)
-      _enc._deferred.append((enc, enc_lens, h0, c0, step_lens, lp, d_lp, dh_n, dc_n, reserve, ws, grads, ugrads, real,
-                             pstruct, ustruct, gstruct, gustruct, out_mask, drop_mask))
+      _deferred.append((enc, enc_lens, h0, c0, step_lens, lp, d_lp, dh_n, dc_n, reserve, ws, grads, ugrads, real,
+                        pstruct, ustruct, gstruct, gustruct, out_mask, drop_mask))
       # whoever reads the gradients after loss.backward() — an optimiser, a test, .cpu() — finds them complete: the
-      # streams are joined when this backward pass ends at the latest
-      torch.autograd.Variable._execution_engine.queue_callback(_enc.flush_deferred)
+      # streams are joined when this backward pass ends at the latest.  (The callback may run on an engine thread whose
+      # current stream is not this one: it joins the stream the fork came from.)
+      torch.autograd.Variable._execution_engine.queue_callback(lambda: flush(forked_from))
       global _split_from
-      _split_from = torch.cuda.current_stream()
+      _split_from = forked_from
       return (None, None, None, None, None, None, d_enc, None, dh0, dc0, None, None) + (None,) * (len(params) + len(upper))
     _C.check(L_.lr_decoder_backward_parts(*args, 3, _C.stream_handle()), "lr_decoder_backward")
     if direct:

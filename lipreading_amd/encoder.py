@@ -76,10 +76,17 @@ def _get_side_stream(device):
   return _side_stream
 
 
+# other modules' deferred halves on streams of their own (attention_decoder: the loop's weight half): callables that make
+# the current stream wait for theirs
+deferred_flushers = []
+
+
 def flush_deferred():
   """Join the side stream: the current stream waits for every deferred weight-gradient half.  Called
   at the end of the next layer's backward, by the conv frontend's backward and by FusedAdam.step; a
   no-op when nothing is pending."""
+  for f in deferred_flushers:
+    f()
   if not _deferred:
     return
   torch.cuda.current_stream().wait_stream(_side_stream)

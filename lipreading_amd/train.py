@@ -353,13 +353,13 @@ def _step_all(opts, grad_norm, status):
   beside the encoder's weight-gradient products — and the streams are joined behind the encoder's optimiser."""
   from . import attention_decoder as _dec
   from . import encoder as _enc
-  side_ok = len(opts) == 2 and _dec.take_split_flag() and _enc._side_stream is not None
+  side_ok = len(opts) == 2 and _dec.take_split_flag() and _dec.side_stream() is not None
   if not side_ok:
     for o in opts:
       o.step(grad_norm=grad_norm, grad_scale=1.0, skip=status)
     return
   main = torch.cuda.current_stream()
-  side = _enc._side_stream
+  side = _dec.side_stream()
   with torch.cuda.stream(side):     # (the side stream already holds everything the decoder's gradients depend on)
     opts[1].step(grad_norm=grad_norm, grad_scale=1.0, skip=status)
   opts[0].step(grad_norm=grad_norm, grad_scale=1.0, skip=status)
@@ -393,10 +393,8 @@ def decoder_step(encoder, decoding_step, opts, frames, frame_lens, chars, char_l
     ctc_side = None
     if use_ctc:
       # The CTC branch (head, loss — and, because autograd runs a node's backward on the stream of its forward, their
-      # backward) on a stream of its own beside the decoder loop: both only read the encoder's states.  Eager steps
-      # only, as the loop's split backward (attention_decoder.py).
-      if (whole and overlap_ctc_branch and not torch.cuda.is_current_stream_capturing() and
-          isinstance(encoder, _VideoEncoder)):
+      # backward) on a stream of its own beside the decoder loop: both only read the encoder's states.
+      if whole and overlap_ctc_branch and isinstance(encoder, _VideoEncoder):
         ctc_side = _ctc_stream(frames.device)
       log_probs, hidden, state = (encoder(frames, frame_lens32 if fused_prep else frame_lens_d, max_len=max_len,
                                           head_stream=ctc_side) if ctc_side is not None else
