@@ -483,7 +483,7 @@ def test_decoder_loop_on_the_cluster_recurrence_equals_the_step_kernels(dev, rnn
                                                 ("GRU", 512, 8, "general"), ("LSTM", 512, 8, "concat"), ("GRU", 512, 8, "dot")])
 def test_loop_weight_half_on_the_side_stream_is_bit_identical(dev, rnn_type, Hd, B, attn):
   """A single-layer loop (every flag file the reference ships) splits its backward
-  (lr_decoder_backward_parts): the data half on the caller's stream, every parameter gradient on the encoder module's side
+  (lr_decoder_backward_parts): the data half on the caller's stream, every parameter gradient on the decoder module's own side
   stream, joined when the backward pass ends.  Same kernels, same arguments: the gradients are the unsplit call's, bit for
   bit, and whoever reads them after backward() finds them complete."""
   import lipreading_amd.attention_decoder as AD
